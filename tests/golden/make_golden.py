@@ -1,0 +1,441 @@
+"""Generate golden fixtures from the REAL reference (askerlee/segtran @ /root/reference).
+
+Runs ONLY in the build container (the reference does not exist on the GPU box).  It
+  1. imports the reference on CPU (tools/refimport.py, recipe of SURVEY.md 8(c)),
+  2. loads name-hashed synthetic weights (segtran_amd/synth.py) into the reference modules,
+  3. runs them on seeded inputs and stores inputs + expected outputs (+ selected gradients)
+     as small .npz files next to this script,
+  4. asserts, for every case, that oracle/segtran_oracle.py reproduces the reference
+     (this is what "pins" the oracle).
+
+Fixtures are DATA (inputs / expected outputs); no reference source is stored.
+Usage:  python tests/golden/make_golden.py [case ...]
+"""
+import os, sys, json, hashlib, copy
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+import refimport as R                                     # noqa: E402
+from segtran_amd.synth import (synth_state_dict, load_synth, sample, synth_fundus_mask,   # noqa: E402
+                               synth_brats, synth_image2d)
+from oracle import segtran_oracle as O                    # noqa: E402
+
+torch.set_num_threads(8)
+SAMPLE = 4096
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('  wrote %s (%.0f KB)' % (name, os.path.getsize(path) / 1024))
+
+
+def close(a, b, tol, what):
+    scale = max(b.abs().max().item(), 1e-30)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale + 1e-30, '%s: oracle vs reference err %.3e (scale %.3e)' % (what, err, scale)
+    return err / scale
+
+
+def mk_shared_config(ss, in_dim, dims, A, pos_dim=2):
+    cfg = ss.SegtranConfig()
+    cfg.num_translayers = len(dims) - 1
+    cfg.translayer_dims = list(dims)
+    cfg.translayer_compress_ratios = [1] * len(dims)
+    cfg.trans_in_dim = dims[0]
+    cfg.min_feat_dim = min(dims)
+    cfg.in_feat_dim, cfg.feat_dim = dims[0], dims[1]
+    cfg.num_attractors = A
+    cfg.pos_dim = pos_dim
+    cfg.hidden_dropout_prob = 0.0
+    cfg.attention_probs_dropout_prob = 0.0
+    return cfg
+
+
+def load_prefixed(mod, prefix):
+    shapes = {prefix + k: tuple(v.shape) for k, v in mod.state_dict().items()}
+    sd = synth_state_dict(shapes)
+    mod.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    R.quiet(lambda: [m.tie_qk('shared') for m in mod.modules() if hasattr(m, 'tie_qk') and hasattr(m, 'query')])
+    return sd
+
+
+def ref_param_grads(mod, prefix):
+    return {prefix + k: p.grad for k, p in mod.named_parameters()}
+
+
+def oracle_grads(sdg):
+    g = {}
+    for k, v in sdg.items():
+        if v.grad is None:
+            continue
+        if '.key.' in k:
+            continue
+        gg = v.grad
+        if '.query.' in k:
+            kk = k.replace('.query.', '.key.')
+            if kk in sdg and sdg[kk].grad is not None:
+                gg = gg + sdg[kk].grad
+        g[k] = gg
+    return g
+
+
+def req(sd):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in k else v.clone())
+            for k, v in sd.items()}
+
+
+# --------------------------------------------------------------------------------------
+def case_squeeze():
+    ss = R.ref_shared()
+    for tag, (C, Fd) in {'c64f64': (64, 64), 'c64f32': (64, 32)}.items():
+        cfg = mk_shared_config(ss, C, [C, Fd], 16)
+        mod = R.quiet(ss.SqueezedAttFeatTrans, cfg, 'L')
+        prefix = 'voxel_fusion.translayers.0.'
+        sd = load_prefixed(mod, prefix)
+        mod.eval()
+        g = torch.Generator().manual_seed(11)
+        X = torch.randn(2, 48, C, generator=g).requires_grad_(True)
+        G = torch.randn(2, 48, Fd, generator=g)
+        Y = mod(X); (Y * G).sum().backward()
+        sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
+        Yo = O.squeezed_att_feat_trans(sdg, prefix[:-1], Xo, 4); (Yo * G).sum().backward()
+        close(Yo, Y, 1e-5, 'squeeze Y'); close(Xo.grad, X.grad, 1e-4, 'squeeze dX')
+        rg, og = ref_param_grads(mod, prefix), oracle_grads(sdg)
+        arrs = dict(X=X, G=G, Y=Y, dX=X.grad)
+        gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+        for k, v in rg.items():
+            if v is None:
+                assert k not in og or og[k].abs().max() == 0, k
+                continue
+            assert (og[k] - v).abs().max().item() <= 2e-4 * gscale, k
+            arrs['grad:' + k] = v
+        save('squeeze_' + tag, **arrs)
+
+
+def case_fusion():
+    ss = R.ref_shared()
+    dims = [64, 64, 32]
+    cfg = mk_shared_config(ss, 64, dims, 16)
+    mod = R.quiet(ss.SegtranFusionEncoder, cfg, 'Fusion')
+    prefix = 'voxel_fusion.'
+    sd = load_prefixed(mod, prefix)
+    mod.eval()
+    g = torch.Generator().manual_seed(12)
+    H2, W2 = 6, 8
+    X = torch.randn(2, H2 * W2, 64, generator=g).requires_grad_(True)
+    G = torch.randn(2, H2 * W2, 32, generator=g)
+    vmask = (torch.rand(2, H2 * W2, 1, generator=g) > 0.25)
+    pos = (O.gen_all_indices((H2, W2)).view(-1, 2).float() * 8).unsqueeze(0).repeat(2, 1, 1)
+    Y = mod(X, pos, vmask, torch.Size((H2, W2))); (Y * G).sum().backward()
+    sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
+    Yo = O.fusion_encoder(sdg, 'voxel_fusion', Xo, pos, vmask, dims); (Yo * G).sum().backward()
+    close(Yo, Y, 1e-5, 'fusion Y'); close(Xo.grad, X.grad, 1e-4, 'fusion dX')
+    rg, og = ref_param_grads(mod, prefix), oracle_grads(sdg)
+    arrs = dict(X=X, G=G, vmask=vmask, pos=pos, Y=Y, dX=X.grad, dims=np.array(dims))
+    gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+    for k, v in rg.items():
+        if v is None:
+            continue
+        assert (og[k] - v).abs().max().item() <= 2e-4 * gscale, k
+        arrs['grad:' + k] = v
+    save('fusion_small', **arrs)
+
+
+def case_posbias():
+    ss = R.ref_shared()
+    g = torch.Generator().manual_seed(13)
+    m2 = R.quiet(ss.SlidingPosBiases2D, 2, 2, (8, 8))
+    m2.biases.data = torch.randn(5, 5, generator=g)
+    b2 = m2(torch.Size((5, 6)), 'cpu')
+    G2 = torch.randn(30, 30, generator=g); (b2 * G2).sum().backward()
+    t2 = m2.biases.detach().clone().requires_grad_(True)
+    o2 = O.sliding_pos_biases(t2, (5, 6)); (o2 * G2).sum().backward()
+    assert torch.equal(o2, b2) and torch.allclose(t2.grad, m2.biases.grad, atol=1e-6)
+    m3 = R.quiet(ss.SlidingPosBiases3D, 3, 1, (4, 4, 4))
+    m3.biases.data = torch.randn(3, 3, 3, generator=g)
+    b3 = m3(torch.Size((3, 4, 2)), 'cpu')
+    G3 = torch.randn(24, 24, generator=g); (b3 * G3).sum().backward()
+    t3 = m3.biases.detach().clone().requires_grad_(True)
+    o3 = O.sliding_pos_biases(t3, (3, 4, 2)); (o3 * G3).sum().backward()
+    assert torch.equal(o3, b3) and torch.allclose(t3.grad, m3.biases.grad, atol=1e-6)
+    save('posbias', table2=m2.biases, bias2=b2, G2=G2, dtable2=m2.biases.grad,
+         table3=m3.biases, bias3=b3, G3=G3, dtable3=m3.biases.grad)
+
+
+def case_effnet():
+    net = R.ref_efficientnet_b4()
+    prefix = 'backbone.'
+    shapes = {prefix + k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth_state_dict(shapes)
+    net.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    net.eval()
+    g = torch.Generator().manual_seed(14)
+    arrs = {}
+    for tag, shp in {'a': (1, 3, 64, 64), 'b': (1, 3, 96, 64)}.items():
+        x = torch.randn(*shp, generator=g)
+        with torch.no_grad():
+            ep = net.extract_endpoints(x)
+            fo = O.effnet_b4_endpoints(sd, 'backbone', x)
+        arrs['x_' + tag] = x
+        for i in range(5):
+            r = ep['reduction_%d' % (i + 1)]
+            close(fo[i], r, 2e-5, 'effnet ep%d' % i)
+            arrs['%s_shape%d' % (tag, i)] = np.array(r.shape)
+            arrs['%s_ep%d' % (tag, i)] = r if tag == 'a' and i > 0 else sample(r, 16384)
+    blocks, ep_idx = O.effnet_b4_blocks()
+    arrs['pads'] = np.array([b['pad'] for b in blocks]); arrs['endpoint_blk'] = np.array(ep_idx)
+    assert ep_idx == net.endpoint_blk_indices
+    save('effnet_b4', **arrs)
+
+
+def case_i3d():
+    net = R.ref_i3d()
+    prefix = 'backbone.'
+    shapes = {prefix + k: tuple(v.shape) for k, v in net.state_dict().items()}
+    sd = synth_state_dict(shapes)
+    net.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    net.eval()
+    g = torch.Generator().manual_seed(15)
+    x = synth_image2d(1, 16 * 112, 1501, 112).view(1, 3, 16, 112, 112)
+    with torch.no_grad():
+        fd = net.extract_features(x)
+        fo = O.i3d_features(sd, 'backbone', x)
+    names = ['MaxPool3d_2a_3x3', 'Conv3d_2c_3x3', 'Mixed_3c', 'Mixed_4f', 'Mixed_5c']
+    arrs = dict(x_sample=sample(x), x_seed=np.array(1501))
+    for i, n in enumerate(names):
+        close(fo[i], fd[n], 2e-5, 'i3d ' + n)
+        arrs['shape%d' % i] = np.array(fd[n].shape)
+        arrs['ep%d' % i] = sample(fd[n], 32768)
+    save('i3d', **arrs)
+
+
+GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.bias', 'out_gn3b.weight',
+                'in_fpn34_conv.weight', 'in_gn4b.bias',
+                'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight',
+                'voxel_fusion.vfeat_norm_layers.0.weight',
+                'voxel_fusion.translayers.0.attractors',
+                'voxel_fusion.translayers.0.in_ator_trans.query.weight',
+                'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_linear.weight',
+                'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_norm_layer.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.query.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.query.bias',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.first_linear.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.intermediate.shared_linear.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.intermediate.shared_linear.bias',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.group_linear.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.group_linear.bias',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.resout_norm_layer.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.feat_softaggr.feat2score.weight',
+                'backbone._conv_stem.weight', 'backbone._bn0.weight',
+                'backbone._blocks.0._depthwise_conv.weight', 'backbone._blocks.5._se_reduce.weight',
+                'backbone._blocks.9._expand_conv.weight', 'backbone._blocks.21._project_conv.weight',
+                'backbone._blocks.31._bn1.bias', 'backbone._conv_head.weight']
+
+
+def run_seg2d(tag, tl, compress, dims, A, B, S, train):
+    net = R.ref_segtran2d(num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0)
+    sd = load_synth(net)
+    if train:
+        net.train()
+        net.backbone._global_params = net.backbone._global_params._replace(drop_connect_rate=0.0)
+    else:
+        net.eval()
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(B, 3, S, S, generator=g)
+    mask = synth_fundus_mask(B, S, 1338)
+    nhot = O.fundus_map_mask(mask)
+    pw = O.bce_pos_weight([0., 1., 2.])
+    y = R.quiet(net, x)
+    loss, ce, dice, _ = O.seg_loss(y, nhot, pw)          # composition restated; pinned separately by case_loss
+    loss.backward()
+    sdg = req(sd)
+    yo = O.segtran2d_forward(sdg, x, dims, training=train)
+    lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
+    close(yo, y, 2e-5, tag + ' logits')
+    og = oracle_grads(sdg)
+    rg = dict(net.named_parameters())
+    gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
+    arrs = dict(x=x, mask=mask, logits=y, labels=(y > 0), loss=loss.detach(), margin=y.abs().min().detach(),
+                dims=np.array(dims), A=np.array(A), train=np.array(int(train)))
+    for k in GRAD_KEYS_2D:
+        if k not in rg:
+            continue
+        gr = rg[k].grad
+        assert (og[k] - gr).abs().max().item() <= 3e-4 * gscale, (k, (og[k] - gr).abs().max().item(), gscale)
+        arrs['grad:' + k] = sample(gr)
+    arrs['gscale'] = np.array(gscale)
+    unused = sorted(k for k, p in rg.items() if p.grad is None)
+    arrs['unused'] = np.array(unused)
+    zero = sorted(k for k, p in rg.items() if p.grad is not None and p.grad.abs().max() == 0)
+    arrs['zero_grad'] = np.array(zero)
+    save(tag, **arrs)
+
+
+def case_seg2d():
+    run_seg2d('seg2d_cfg2_eval', 3, (1, 1, 2, 2), [1792, 1792, 896, 448], 32, 2, 64, False)
+    run_seg2d('seg2d_cfg1_eval', 1, (1, 1), [1792, 1792], 32, 2, 64, False)
+    run_seg2d('seg2d_cfg2_train', 3, (1, 1, 2, 2), [1792, 1792, 896, 448], 32, 2, 64, True)
+
+
+GRAD_KEYS_3D = ['in_bridge_to3.weight', 'out_conv3d.weight', 'out_fpn_bridgeconv3d.weight', 'out_fpn12_conv3d.weight',
+                'out_gn2b.weight', 'in_fpn34_conv.weight', 'in_gn4b.weight',
+                'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight',
+                'voxel_fusion.translayers.0.attractors',
+                'voxel_fusion.translayers.0.ator_out_trans.query.weight',
+                'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.group_linear.weight',
+                'backbone.Conv3d_1a_7x7.conv3d.weight', 'backbone.Conv3d_1a_7x7.bn.weight',
+                'backbone.Conv3d_2c_3x3.conv3d.weight', 'backbone.Mixed_3b.b1b.conv3d.weight',
+                'backbone.Mixed_4d.b2b.conv3d.weight', 'backbone.Mixed_4f.b3b.bn.bias',
+                'backbone.Mixed_5c.b0.conv3d.weight']
+
+
+def case_seg3d():
+    for tag, train in (('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)):
+        A = 64
+        net = R.ref_segtran3d(num_attractors=A, dropout_prob=0)
+        sd = load_synth(net)
+        net.train() if train else net.eval()
+        x, lab = synth_brats(1, 112, 112, 16, 1337)
+        nhot = O.brats_map_label(lab)
+        pw = O.bce_pos_weight([0., 3., 1., 1.75])
+        y = R.quiet(net, x)
+        loss = O.seg_loss(y, nhot, pw)[0]; loss.backward()
+        sdg = req(sd)
+        yo = O.segtran3d_forward(sdg, x, [1024, 1024], training=train)
+        lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
+        close(yo, y, 3e-5, tag + ' logits')
+        og = oracle_grads(sdg); rg = dict(net.named_parameters())
+        gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
+        arrs = dict(x_sample=sample(x), logits=sample(y, 65536), labels=np.packbits((y > 0).numpy()),
+                    loss=loss.detach(), margin=y.abs().min().detach(), A=np.array(A), train=np.array(int(train)))
+        for k in GRAD_KEYS_3D:
+            gr = rg[k].grad
+            assert (og[k] - gr).abs().max().item() <= 3e-4 * gscale, (k, (og[k] - gr).abs().max().item(), gscale)
+            arrs['grad:' + k] = sample(gr)
+        arrs['gscale'] = np.array(gscale)
+        arrs['unused'] = np.array(sorted(k for k, p in rg.items() if p.grad is None))
+        save(tag, **arrs)
+
+
+def case_loss():
+    """train2d.py:1219-1242,1314-1318 composed from the reference's own dice_loss_indiv + torch BCE."""
+    dice_ref = R.ref_dice()
+    g = torch.Generator().manual_seed(17)
+    arrs = {}
+    for tag, shp, bw in (('2d', (2, 3, 24, 20), [0., 1., 2.]), ('3d', (2, 4, 10, 12, 6), [0., 3., 1., 1.75])):
+        logits = (torch.randn(*shp, generator=g) * 2).requires_grad_(True)
+        nc = shp[1]
+        mask = (torch.rand(*shp, generator=g) > 0.6).float()
+        pw = torch.tensor(bw); pw = pw * (nc - 1) / pw.sum()
+        perm = (0,) + tuple(range(2, len(shp))) + (1,)
+        ce = torch.nn.BCEWithLogitsLoss(pos_weight=pw)(logits.permute(*perm), mask.permute(*perm))
+        soft = torch.sigmoid(logits)
+        cw = torch.ones(nc); cw[0] = 0; cw /= cw.sum()
+        dice = 0
+        for c in range(1, nc):
+            dice = dice + dice_ref(soft[:, c], mask[:, c]) * cw[c]
+        loss = 0.5 * ce + 0.5 * dice
+        loss.backward()
+        lo = logits.detach().clone().requires_grad_(True)
+        l2, ce2, d2, _ = O.seg_loss(lo, mask, pw); l2.backward()
+        assert torch.allclose(l2, loss, atol=1e-6) and torch.allclose(lo.grad, logits.grad, atol=1e-7)
+        arrs.update({'logits' + tag: logits, 'mask' + tag: mask, 'pw' + tag: pw, 'loss' + tag: loss,
+                     'ce' + tag: ce, 'dice' + tag: dice, 'dlogits' + tag: logits.grad})
+    save('loss', **arrs)
+
+
+def case_bertadam():
+    BertAdam = R.ref_bertadam()
+    g = torch.Generator().manual_seed(18)
+    shapes = [(7, 5), (33,), (4, 3, 2), (6,)]
+    p0 = [torch.randn(*s, generator=g) for s in shapes]
+    grads = [[torch.randn(*s, generator=g) * sc for s in shapes] for sc in (1.0, 0.01, 5.0, 0.1)]
+    params = [torch.nn.Parameter(p.clone()) for p in p0]
+    wds = [1e-4, 1e-5, 0.0, 1e-4]
+    groups = [dict(params=[params[0], params[3]], weight_decay=1e-4, lr=2e-4),
+              dict(params=[params[1]], weight_decay=1e-5, lr=2e-4),
+              dict(params=[params[2]], weight_decay=0.0, lr=2e-4)]
+    opt = BertAdam(groups, warmup=0.25, t_total=8, weight_decay=1e-4)
+    po = [p.clone() for p in p0]; state = [dict() for _ in po]
+    arrs = {'p0_%d' % i: p for i, p in enumerate(p0)}
+    for step, gs in enumerate(grads):
+        gs = [x.clone() for x in gs]
+        for p, gr in zip(params, gs):
+            p.grad = gr.clone()
+        params[3].grad = None                                   # N3: a parameter that never gets a grad
+        torch.nn.utils.clip_grad_norm_([p for p in params], 0.1)
+        opt.step()
+        og = [x.clone() for x in gs]; og[3] = None
+        O.global_clip_([x for x in og if x is not None], 0.1)
+        O.bertadam_step(po, og, state, 2e-4, wds, 0.25, 8)
+        for i in range(4):
+            assert torch.allclose(po[i], params[i].data, atol=1e-7), (step, i)
+            arrs['g%d_%d' % (step, i)] = gs[i]
+            arrs['p%d_%d' % (step + 1, i)] = params[i].data.clone()
+    save('bertadam', **arrs)
+
+
+def case_fullsize():
+    """Hash-only full-size smoke (cfg-2 and cfg-4 shapes, bs 1, eval)."""
+    out = {}
+    net = R.ref_segtran2d(); sd = load_synth(net); net.eval()
+    g = torch.Generator().manual_seed(1337)
+    x = torch.randn(1, 3, 512, 512, generator=g)
+    with torch.no_grad():
+        y = R.quiet(net, x)
+        yo = O.segtran2d_forward(sd, x, [1792, 1792, 896, 448])
+    close(yo, y, 5e-5, 'full 2d')
+    out['cfg2'] = dict(mean=y.mean().item(), absmax=y.abs().max().item(), margin=y.abs().min().item(),
+                       sample=sample(y, 256).tolist(),
+                       sha256=hashlib.sha256(np.packbits((y > 0).numpy()).tobytes()).hexdigest())
+    del net
+    net = R.ref_segtran3d(); sd = load_synth(net); net.eval()
+    x, _ = synth_brats(1, 112, 112, 96, 1337)
+    with torch.no_grad():
+        y = R.quiet(net, x)
+        yo = O.segtran3d_forward(sd, x, [1024, 1024])
+    close(yo, y, 5e-5, 'full 3d')
+    out['cfg4'] = dict(mean=y.mean().item(), absmax=y.abs().max().item(), margin=y.abs().min().item(),
+                       sample=sample(y, 256).tolist(),
+                       sha256=hashlib.sha256(np.packbits((y > 0).numpy()).tobytes()).hexdigest())
+    json.dump(out, open(os.path.join(HERE, 'fullsize.json'), 'w'), indent=1)
+    print('  wrote fullsize.json')
+
+
+def case_keys():
+    """state_dict key -> shape lists (checkpoint wire format)."""
+    n2 = R.ref_segtran2d()
+    n3 = R.ref_segtran3d()
+    n3b = R.ref_segtran3d(num_translayers=2, compress=(1, 1, 1))
+    n1 = R.ref_segtran2d(num_translayers=1, compress=(1, 1))
+    json.dump({'cfg2': {k: list(v.shape) for k, v in n2.state_dict().items()},
+               'cfg1': {k: list(v.shape) for k, v in n1.state_dict().items()},
+               'cfg4': {k: list(v.shape) for k, v in n3.state_dict().items()},
+               'cfg5': {k: list(v.shape) for k, v in n3b.state_dict().items()},
+               'cfg2_params': [k for k, _ in n2.named_parameters()],
+               'cfg4_params': [k for k, _ in n3.named_parameters()]},
+              open(os.path.join(HERE, 'state_dict_keys.json'), 'w'))
+    print('  wrote state_dict_keys.json')
+
+
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, posbias=case_posbias, effnet=case_effnet, i3d=case_i3d,
+             seg2d=case_seg2d, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
+             fullsize=case_fullsize)
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or list(CASES)
+    for c in todo:
+        print('[golden] ' + c)
+        CASES[c]()
+    print('done')
