@@ -1,0 +1,110 @@
+/* segx.h -- C ABI of libsegx.so: the MI355X (gfx950) hot-path kernels of the Segtran `--net segtran`
+ * train step.  This is the drop-in boundary: every entry point replaces an ATen
+ * dispatch the reference performs (file:line cited per function, relative to /root/reference/code).
+ *
+ * Conventions
+ *  - plain device pointers + sizes; fp32 everywhere (the reference computes in fp32).
+ *  - the library never allocates / frees / retains device memory: caller passes outputs + workspace.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), is re-entrant across
+ *    streams and has no mutable global state.
+ *  - return 0 = ok, <0 = invalid argument (see segx_last_error), >0 = HIP error code.
+ */
+#ifndef SEGX_H
+#define SEGX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int segx_version(void);
+/* copies the calling thread's last error message; returns its length */
+int segx_last_error(char* buf, int buflen);
+
+/* ---------------------------------------------------------------------------------------------
+ * Batched strided fp32 GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, H1):
+ *      C[z][m][n] = epilogue( alpha * sum_k A[z][m][k] * B[z][n][k] + bias )
+ * z = z0*nb1 + z1 walks two batch dims with independent strides (0 = broadcast), so per-mode /
+ * per-sample views of [B,N,M*d] tensors need no transposed copies (the reference bounces
+ * [B,M*F,U] <-> [B,M,U,F], networks/segtran_shared.py:416-419,449).  One of (a_m,a_k) and one of
+ * (b_n,b_k) must be 1.  Replaces: nn.Linear query/key :559-560, first_linear :414,
+ * shared_linear :243, Conv1d group_linear :267, torch.matmul :566 and :447, every 1x1(x1) conv
+ * (segtran2d.py:245,287,304,427; segtran3d.py:300,348,367,490; efficientnet/model.py:96,113,280;
+ * aj_i3d.py:92 for 1x1x1 kernels) and all of their backward GEMMs.
+ * ------------------------------------------------------------------------------------------- */
+enum { SEGX_EPI_NONE = 0, SEGX_EPI_GELU = 1 /* aux = pre-activation, C = dropout(gelu(.)), :244-245 */ };
+enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bias[m] */ };
+typedef struct {
+    int32_t M, N, K, nb0, nb1;
+    int64_t a_b0, a_b1, a_m, a_k;
+    int64_t b_b0, b_b1, b_n, b_k;
+    int64_t c_b0, c_b1, c_m;          /* C[m][n]: n contiguous */
+    float alpha;
+    int32_t epilogue, bias_mode;
+    int64_t bias_b1;                  /* bias stride over z1 (grouped / per-mode biases) */
+    const float* bias;
+    float* aux;                       /* SEGX_EPI_GELU: same layout as C */
+    float* gmax;                      /* optional: *gmax = max(*gmax, max(0, C)) (score clip flag, :570-580) */
+    float dropout_p;                  /* SEGX_EPI_GELU only */
+    uint64_t seed, offset;            /* Philox stream for the dropout mask */
+    int32_t splitk;                   /* >1: K split over `splitk` slabs in `workspace`, then reduced */
+    float* workspace;                 /* splitk*nb0*nb1*M*N floats when splitk>1 */
+} segx_gemm_desc;
+int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row kernels of the Squeeze-and-Expansion transformer (tokens.hip).  All tensors fp32, row-major,
+ * row width a multiple of 4 (<= 4096).  Dropout masks come from a Philox4x32 counter stream
+ * (seed, offset) with offset % 4 == 0 and are regenerated in backward (never stored).
+ * ------------------------------------------------------------------------------------------- */
+/* softmax over the last axis of S[rows, L]; clamps S to +-clip first iff gmax && *gmax > clip
+ * (conditional clip N5, networks/segtran_shared.py:578-580), softmax :601, attention dropout :605.
+ * P = probabilities (kept for backward); Pdrop = dropout(P) when p > 0 (else unused / may be NULL). */
+int segx_softmax_fwd(const float* S, float* P, float* Pdrop, int64_t rows, int L, float clip, const float* gmax,
+                     float p, uint64_t seed, uint64_t offset, void* stream);
+int segx_softmax_bwd(const float* P, const float* dPdrop, const float* S /* for the clamp mask, may be NULL */, float* dS,
+                     int64_t rows, int L, float clip, const float* gmax, float p, uint64_t seed, uint64_t offset, void* stream);
+/* nn.LayerNorm(eps=1e-12) (:262,:361 affine; :889 non-affine: w=b=NULL).  mean/rstd [rows] saved for backward. */
+int segx_layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd,
+                       int64_t rows, int C, float eps, void* stream);
+int segx_layernorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX,
+                       int64_t rows, int C, void* stream);
+/* deterministic two-stage column reductions; ws needs segx_colreduce_ws_floats(rows, C, nout) floats */
+int64_t segx_colreduce_ws_floats(int64_t rows, int64_t C, int nout);
+int segx_colsum(const float* X, float* out, float* ws, int64_t rows, int64_t C, void* stream);            /* nout = 1 */
+int segx_ln_param_grad(const float* dY, const float* X, const float* mean, const float* rstd, float* dw, float* db,
+                       float* ws, int64_t rows, int C, void* stream);                                      /* nout = 2 */
+int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1024 floats */, float scale, void* stream);
+/* SegtranFusionEncoder.forward per-layer prologue (:916-946):
+ *   Y = mask * dropout( LN_noaffine( LN_affine(X; w1,b1) + pos_weight * pos[n, :C] ) ),  X [B,N,C], pos [N,pos_ld], mask [B*N]
+ * stats = 4*B*N floats.  Backward returns dX and dU (grad wrt LN_affine's output): dpos = pos_weight * sum_b dU,
+ * (dw1, db1) = segx_ln_param_grad(dU, X, stats[0], stats[1]). */
+int segx_prenorm_fwd(const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
+                     const float* mask, float* Y, float* stats, int64_t B, int N, int C, float eps,
+                     float p, uint64_t seed, uint64_t offset, void* stream);
+int segx_prenorm_bwd(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld,
+                     float pos_weight, const float* mask, const float* stats, float* dX, float* dU, int64_t B, int N, int C,
+                     float p, uint64_t seed, uint64_t offset, void* stream);
+/* LearnedSinuPosEmbedder.forward (:989-998) for the batch-invariant [N, pd] normalised coordinates:
+ *   out = LN_noaffine(interleave(sin(z_even), cos(z_odd))), z = posn Wp^T + bp.  stats = 2*N floats.
+ * Backward gives dZ [N,C]; dWp = dZ^T posn (segx_gemm_f32), dbp = segx_colsum(dZ). */
+int segx_posembed_fwd(const float* posn, const float* Wp, const float* bp, float* out, float* stats, int64_t N, int C, int pd,
+                      float eps, void* stream);
+int segx_posembed_bwd(const float* dOut, const float* posn, const float* Wp, const float* bp, const float* stats, float* dZ,
+                      int64_t N, int C, int pd, void* stream);
+/* Expansion tail: MMPrivateOutput dropout + LayerNorm (:273-274) and LearnedSoftAggregate (:318-325) fused.
+ *   Z [Mo, R, F] (mode-major) -> Y [R, F];  stats = 3*Mo*R floats (mean, rstd, mode probability).
+ * Backward: dZ + dscore [Mo*R]; parameter grads via segx_modes_aggr_param_grad (ws: nout = 3), dba = sum(dscore). */
+int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float* lnb, const float* wa, const float* ba, float* Y, float* stats,
+                        int Mo, int64_t R, int F, float eps, float p, uint64_t seed, uint64_t offset, void* stream);
+int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
+                        float* dZ, float* dscore, int Mo, int64_t R, int F, float p, uint64_t seed, uint64_t offset, void* stream);
+int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa,
+                               const float* stats, const float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws,
+                               int Mo, int64_t R, int F, float p, uint64_t seed, uint64_t offset, void* stream);
+/* backward of the GELU(+dropout) epilogue of segx_gemm_f32 (MMSharedMid :244-245): dT = dH * keep * gelu'(T) */
+int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,106 @@
+// common.h -- shared device/host helpers for libsegx (gfx950 / CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/segx.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace segx {
+
+// ---- error reporting -------------------------------------------------------------------------
+inline char* err_buf() { static thread_local char buf[512] = {0}; return buf; }
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(err_buf(), 512, fmt, ap); va_end(ap); return code;
+}
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+#define SEGX_REQUIRE(cond, ...) do { if (!(cond)) return segx::fail(-1, __VA_ARGS__); } while (0)
+
+// ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// Block-wide sum for blocks of NW waves; every thread gets the result.  `red` = NW floats of LDS.
+template <int NW> __device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+template <int NW> __device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+// ---- Philox4x32-7 counter RNG (dropout masks are regenerated, never stored) -------------------
+// One call yields 4 x 32 random bits for elements 4*ctr .. 4*ctr+3 of stream (seed, offset).
+struct u32x4 { unsigned x, y, z, w; };
+__device__ __forceinline__ u32x4 philox4(uint64_t seed, uint64_t ctr) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x5eed5eedu, c3 = 0u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+        const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u32x4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3; return o;
+}
+__device__ __forceinline__ float keep_of(unsigned u, float p, float inv_keep) {
+    return ((float)(u >> 8) * (1.0f / 16777216.0f) >= p) ? inv_keep : 0.0f;
+}
+// keep-scales (0 or 1/(1-p)) of the 4 consecutive elements idx0..idx0+3 (idx0 % 4 == 0)
+__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint64_t offset, uint64_t idx0, float p, float inv_keep) {
+    const u32x4 r = philox4(seed, (offset + idx0) >> 2);
+    return make_float4(keep_of(r.x, p, inv_keep), keep_of(r.y, p, inv_keep), keep_of(r.z, p, inv_keep), keep_of(r.w, p, inv_keep));
+}
+// scalar form for kernels whose lanes own scattered elements (MFMA epilogue, column reductions)
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
+    const u32x4 r = philox4(seed, (offset + idx) >> 2);
+    const unsigned sel = (unsigned)((offset + idx) & 3);
+    const unsigned u = sel == 0 ? r.x : sel == 1 ? r.y : sel == 2 ? r.z : r.w;
+    return keep_of(u, p, inv_keep);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+__host__ __device__ inline int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
+__host__ __device__ inline int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }
+
+}  // namespace segx

@@ -1,0 +1,635 @@
+// tokens.hip -- HBM-bound row kernels of the Squeeze-and-Expansion transformer (fwd + bwd).
+//
+// Token tensors are [rows, C] fp32 with C in {1792, 896, 448, 1024, ...}.  Every kernel here is
+// bandwidth-bound, so the design rule is "one HBM read per input element, one write per output
+// element": a 64-lane wave owns one row and keeps it in registers as NV4 float4 per lane
+// (lane l holds columns 4*(l + 64*i) .. +3, i.e. every wave load/store is a contiguous 1-KiB
+// segment), statistics are wave shuffles, and dropout masks are regenerated from a Philox
+// counter instead of being stored.  4 rows per 256-thread workgroup; grids are >> 256 CUs.
+// Parameter gradients (column sums over all rows) use a deterministic two-stage column reduction.
+#include "common.h"
+
+namespace segx {
+
+constexpr int ROWS_PER_BLOCK = 4;
+constexpr int RED_CHUNKS = 256;          // stage-1 row chunks of the column reductions
+
+template <int NV4> struct Row { float4 v[NV4]; };
+
+#define SEGX_FOR_ROW(i, c4, F) _Pragma("unroll") for (int i = 0, c4 = (threadIdx.x & 63); i < NV4; ++i, c4 += 64) if (c4 * 4 < (F))
+
+template <int NV4> __device__ __forceinline__ void row_load(Row<NV4>& r, const float* __restrict__ p, int F) {
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    SEGX_FOR_ROW(i, c4, F) r.v[i] = reinterpret_cast<const float4*>(p)[c4];
+}
+template <int NV4> __device__ __forceinline__ void row_store(const Row<NV4>& r, float* __restrict__ p, int F) {
+    SEGX_FOR_ROW(i, c4, F) reinterpret_cast<float4*>(p)[c4] = r.v[i];
+}
+template <int NV4> __device__ __forceinline__ float row_sum(const Row<NV4>& r) {     // padding lanes hold 0
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+    return wave_sum(s);
+}
+template <int NV4> __device__ __forceinline__ float row_dot(const Row<NV4>& a, const Row<NV4>& b) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) s += (a.v[i].x * b.v[i].x + a.v[i].y * b.v[i].y) + (a.v[i].z * b.v[i].z + a.v[i].w * b.v[i].w);
+    return wave_sum(s);
+}
+// two-pass mean / rstd (matches torch's row-wise moments to fp32 round-off; eps = 1e-12 gives no slack)
+template <int NV4> __device__ __forceinline__ void row_stats(const Row<NV4>& r, int F, float eps, float& mean, float& rstd) {
+    mean = row_sum(r) / (float)F;
+    float s = 0.f;
+    SEGX_FOR_ROW(i, c4, F) {
+        const float a = r.v[i].x - mean, b = r.v[i].y - mean, c = r.v[i].z - mean, d = r.v[i].w - mean;
+        s += (a * a + b * b) + (c * c + d * d);
+    }
+    rstd = rsqrtf(wave_sum(s) / (float)F + eps);
+}
+#define SEGX_F4_OP(dst, expr_x, expr_y, expr_z, expr_w) do { dst.x = (expr_x); dst.y = (expr_y); dst.z = (expr_z); dst.w = (expr_w); } while (0)
+
+// all dropout streams use offsets that are multiples of 4, so idx0 % 4 == 0 <=> (offset + idx0) % 4 == 0
+__device__ __forceinline__ float4 f4_keep(uint64_t seed, uint64_t off, uint64_t idx0, float p, float inv_keep) {
+    return dropout_scale4(seed, off, idx0, p, inv_keep);
+}
+
+static inline int nv4_for(int F) { const int n = (F + 255) / 256; return n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 4 : n <= 7 ? 7 : n <= 8 ? 8 : n <= 16 ? 16 : 0; }
+#define SEGX_DISPATCH_NV4(F, KERNEL_CALL)                                                    \
+    switch (segx::nv4_for(F)) {                                                              \
+        case 1: { constexpr int NV4 = 1; KERNEL_CALL; } break;                               \
+        case 2: { constexpr int NV4 = 2; KERNEL_CALL; } break;                               \
+        case 4: { constexpr int NV4 = 4; KERNEL_CALL; } break;                               \
+        case 7: { constexpr int NV4 = 7; KERNEL_CALL; } break;                               \
+        case 8: { constexpr int NV4 = 8; KERNEL_CALL; } break;                               \
+        case 16: { constexpr int NV4 = 16; KERNEL_CALL; } break;                             \
+        default: return segx::fail(-1, "row width %d unsupported (max 4096, multiple of 4)", (int)(F)); \
+    }
+static inline dim3 row_grid(int64_t rows) { return dim3((unsigned)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK)); }
+#define SEGX_ROW_ID() ((int64_t)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6))
+
+// =================================================================================================
+// Row softmax over the key axis (networks/segtran_shared.py:578-580 clip, :601 softmax, :605 dropout)
+// =================================================================================================
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd,
+                                                          int64_t rows, int L, float clip, const float* __restrict__ gmax,
+                                                          float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    const bool clamp = gmax && (*gmax > clip);                 // N5: clamp only when the GLOBAL max exceeds the clip
+    Row<NV4> r; row_load(r, S + row * L, L);
+    float m = -INFINITY;
+    SEGX_FOR_ROW(i, c4, L) {
+        if (clamp) SEGX_F4_OP(r.v[i], fminf(fmaxf(r.v[i].x, -clip), clip), fminf(fmaxf(r.v[i].y, -clip), clip),
+                              fminf(fmaxf(r.v[i].z, -clip), clip), fminf(fmaxf(r.v[i].w, -clip), clip));
+        m = fmaxf(m, fmaxf(fmaxf(r.v[i].x, r.v[i].y), fmaxf(r.v[i].z, r.v[i].w)));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+    SEGX_FOR_ROW(i, c4, L) {
+        SEGX_F4_OP(r.v[i], expf(r.v[i].x - m), expf(r.v[i].y - m), expf(r.v[i].z - m), expf(r.v[i].w - m));
+        s += (r.v[i].x + r.v[i].y) + (r.v[i].z + r.v[i].w);
+    }
+    s = wave_sum(s);
+    SEGX_FOR_ROW(i, c4, L) SEGX_F4_OP(r.v[i], r.v[i].x / s, r.v[i].y / s, r.v[i].z / s, r.v[i].w / s);
+    row_store(r, P + row * L, L);
+    if (Pd) {
+        const float ik = 1.0f / (1.0f - p);
+        SEGX_FOR_ROW(i, c4, L) {
+            const float4 k = f4_keep(seed, off, (uint64_t)row * L + c4 * 4, p, ik);
+            SEGX_F4_OP(r.v[i], r.v[i].x * k.x, r.v[i].y * k.y, r.v[i].z * k.z, r.v[i].w * k.w);
+        }
+        row_store(r, Pd + row * L, L);
+    }
+}
+
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dPd, const float* __restrict__ S,
+                                                          float* __restrict__ dS, int64_t rows, int L, float clip,
+                                                          const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    const bool clamp = gmax && S && (*gmax > clip);
+    Row<NV4> pr, g; row_load(pr, P + row * L, L); row_load(g, dPd + row * L, L);
+    if (p > 0.f) {
+        const float ik = 1.0f / (1.0f - p);
+        SEGX_FOR_ROW(i, c4, L) {
+            const float4 k = f4_keep(seed, off, (uint64_t)row * L + c4 * 4, p, ik);
+            SEGX_F4_OP(g.v[i], g.v[i].x * k.x, g.v[i].y * k.y, g.v[i].z * k.z, g.v[i].w * k.w);
+        }
+    }
+    const float dot = row_dot(pr, g);
+    SEGX_FOR_ROW(i, c4, L) SEGX_F4_OP(g.v[i], pr.v[i].x * (g.v[i].x - dot), pr.v[i].y * (g.v[i].y - dot),
+                                       pr.v[i].z * (g.v[i].z - dot), pr.v[i].w * (g.v[i].w - dot));
+    if (clamp) {                                               // torch.clamp passes gradient where -clip <= s <= clip
+        Row<NV4> s; row_load(s, S + row * L, L);
+        SEGX_FOR_ROW(i, c4, L) SEGX_F4_OP(g.v[i], fabsf(s.v[i].x) <= clip ? g.v[i].x : 0.f, fabsf(s.v[i].y) <= clip ? g.v[i].y : 0.f,
+                                           fabsf(s.v[i].z) <= clip ? g.v[i].z : 0.f, fabsf(s.v[i].w) <= clip ? g.v[i].w : 0.f);
+    }
+    row_store(g, dS + row * L, L);
+}
+
+// =================================================================================================
+// LayerNorm (eps 1e-12, N4): fwd, dX.  (:262,361 affine; :889 non-affine -> w == nullptr)
+// =================================================================================================
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float* __restrict__ Y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                            int64_t rows, int C, float eps) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    Row<NV4> r; row_load(r, X + row * C, C);
+    float mean, rstd; row_stats(r, C, eps, mean, rstd);
+    SEGX_FOR_ROW(i, c4, C) {
+        float4 ww = make_float4(1.f, 1.f, 1.f, 1.f), bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w) { ww = reinterpret_cast<const float4*>(w)[c4]; bb = reinterpret_cast<const float4*>(b)[c4]; }
+        SEGX_F4_OP(r.v[i], (r.v[i].x - mean) * rstd * ww.x + bb.x, (r.v[i].y - mean) * rstd * ww.y + bb.y,
+                   (r.v[i].z - mean) * rstd * ww.z + bb.z, (r.v[i].w - mean) * rstd * ww.w + bb.w);
+    }
+    row_store(r, Y + row * C, C);
+    if ((threadIdx.x & 63) == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * w
+template <int NV4>
+__device__ __forceinline__ void ln_bwd_row(Row<NV4>& g, const Row<NV4>& xhat, int C, float rstd) {
+    const float m1 = row_sum(g) / (float)C, m2 = row_dot(g, xhat) / (float)C;
+    SEGX_FOR_ROW(i, c4, C) SEGX_F4_OP(g.v[i], rstd * (g.v[i].x - m1 - xhat.v[i].x * m2), rstd * (g.v[i].y - m1 - xhat.v[i].y * m2),
+                                       rstd * (g.v[i].z - m1 - xhat.v[i].z * m2), rstd * (g.v[i].w - m1 - xhat.v[i].w * m2));
+}
+
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
+                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                            float* __restrict__ dX, int64_t rows, int C) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    Row<NV4> x, g; row_load(x, X + row * C, C); row_load(g, dY + row * C, C);
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    SEGX_FOR_ROW(i, c4, C) {
+        SEGX_F4_OP(x.v[i], (x.v[i].x - mean) * rstd, (x.v[i].y - mean) * rstd, (x.v[i].z - mean) * rstd, (x.v[i].w - mean) * rstd);
+        if (w) { const float4 ww = reinterpret_cast<const float4*>(w)[c4];
+                 SEGX_F4_OP(g.v[i], g.v[i].x * ww.x, g.v[i].y * ww.y, g.v[i].z * ww.z, g.v[i].w * ww.w); }
+    }
+    ln_bwd_row(g, x, C, rstd);
+    row_store(g, dX + row * C, C);
+}
+
+// =================================================================================================
+// Column reductions (parameter gradients).  Stage 1: thread = column, block = (256 columns, row chunk);
+// consecutive threads read consecutive columns (coalesced).  Stage 2 sums the chunk partials in order.
+// =================================================================================================
+// mode 0: out0 = sum_r X              (bias grads, pos-code batch sum)
+// mode 1: out0 = sum_r dY * xhat, out1 = sum_r dY      (LayerNorm weight / bias grads), xhat = (X - mean) * rstd
+__global__ __launch_bounds__(256) void colreduce_stage1(const float* __restrict__ A, const float* __restrict__ X, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ ws, int64_t rows, int64_t C,
+                                                        int mode, int nchunks) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int64_t per = (rows + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(rows, r0 + per);
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float a = A[r * C + c];
+        if (mode == 0) s0 += a;
+        else { s0 += a * ((X[r * C + c] - mean[r]) * rstd[r]); s1 += a; }
+    }
+    ws[(int64_t)chunk * C + c] = s0;
+    if (mode == 1) ws[((int64_t)nchunks + chunk) * C + c] = s1;
+}
+__global__ __launch_bounds__(256) void colreduce_stage2(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
+                                                        float* __restrict__ out2, int64_t C, int nchunks, int nout) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int o = 0; o < nout; ++o) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += ws[((int64_t)o * nchunks + k) * C + c];
+        (o == 0 ? out0 : o == 1 ? out1 : out2)[c] = s;
+    }
+}
+static inline int chunks_for(int64_t rows) { return (int)i64max(1, i64min(RED_CHUNKS, rows / 8)); }
+
+// full sum of a flat array (loss pieces, scalar bias grads): two-stage, deterministic
+__global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ ws) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s += x[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void sum_stage2(const float* __restrict__ ws, int nb, float* __restrict__ out, float scale) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += ws[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// =================================================================================================
+// Token pre-norm (SegtranFusionEncoder.forward :916-946, K12):
+//   y = mask * dropout( LN_noaffine( LN_affine(x) + pos_weight * pos[n, :C] ) )
+// stats[0..3][row] = mean1, rstd1, mean2, rstd2
+// =================================================================================================
+template <int NV4>
+__global__ __launch_bounds__(256) void prenorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                          const float* __restrict__ pos, int64_t pos_ld, float pos_w, const float* __restrict__ mask,
+                                                          float* __restrict__ Y, float* __restrict__ stats, int64_t rows, int N, int C, float eps,
+                                                          float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    const int n = (int)(row % N);
+    Row<NV4> r; row_load(r, X + row * C, C);
+    float m1, r1; row_stats(r, C, eps, m1, r1);
+    SEGX_FOR_ROW(i, c4, C) {
+        const float4 ww = reinterpret_cast<const float4*>(w1)[c4], bb = reinterpret_cast<const float4*>(b1)[c4];
+        const float4 pp = reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4];
+        SEGX_F4_OP(r.v[i], (r.v[i].x - m1) * r1 * ww.x + bb.x + pos_w * pp.x, (r.v[i].y - m1) * r1 * ww.y + bb.y + pos_w * pp.y,
+                   (r.v[i].z - m1) * r1 * ww.z + bb.z + pos_w * pp.z, (r.v[i].w - m1) * r1 * ww.w + bb.w + pos_w * pp.w);
+    }
+    float m2, r2; row_stats(r, C, eps, m2, r2);
+    const float mk = mask[row];
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    SEGX_FOR_ROW(i, c4, C) {
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) k = f4_keep(seed, off, (uint64_t)row * C + c4 * 4, p, ik);
+        SEGX_F4_OP(r.v[i], (r.v[i].x - m2) * r2 * k.x * mk, (r.v[i].y - m2) * r2 * k.y * mk,
+                   (r.v[i].z - m2) * r2 * k.z * mk, (r.v[i].w - m2) * r2 * k.w * mk);
+    }
+    row_store(r, Y + row * C, C);
+    if ((threadIdx.x & 63) == 0) { stats[row] = m1; stats[rows + row] = r1; stats[2 * rows + row] = m2; stats[3 * rows + row] = r2; }
+}
+
+// outputs dX and dU (= grad wrt the sum LN_affine(x) + pos_w*pos, i.e. wrt LN_affine's output)
+template <int NV4>
+__global__ __launch_bounds__(256) void prenorm_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ pos, int64_t pos_ld, float pos_w,
+                                                          const float* __restrict__ mask, const float* __restrict__ stats,
+                                                          float* __restrict__ dX, float* __restrict__ dU, int64_t rows, int N, int C,
+                                                          float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= rows) return;
+    const int n = (int)(row % N);
+    const float m1 = stats[row], r1 = stats[rows + row], m2 = stats[2 * rows + row], r2 = stats[3 * rows + row];
+    const float mk = mask[row];
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    Row<NV4> xh, u, g; row_load(xh, X + row * C, C); row_load(g, dY + row * C, C);
+    SEGX_FOR_ROW(i, c4, C) {
+        const float4 ww = reinterpret_cast<const float4*>(w1)[c4], bb = reinterpret_cast<const float4*>(b1)[c4];
+        const float4 pp = reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4];
+        SEGX_F4_OP(xh.v[i], (xh.v[i].x - m1) * r1, (xh.v[i].y - m1) * r1, (xh.v[i].z - m1) * r1, (xh.v[i].w - m1) * r1);
+        SEGX_F4_OP(u.v[i], ((xh.v[i].x * ww.x + bb.x + pos_w * pp.x) - m2) * r2, ((xh.v[i].y * ww.y + bb.y + pos_w * pp.y) - m2) * r2,
+                   ((xh.v[i].z * ww.z + bb.z + pos_w * pp.z) - m2) * r2, ((xh.v[i].w * ww.w + bb.w + pos_w * pp.w) - m2) * r2);
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) k = f4_keep(seed, off, (uint64_t)row * C + c4 * 4, p, ik);
+        SEGX_F4_OP(g.v[i], g.v[i].x * k.x * mk, g.v[i].y * k.y * mk, g.v[i].z * k.z * mk, g.v[i].w * k.w * mk);
+    }
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) if (!(((threadIdx.x & 63) + 64 * i) * 4 < C)) u.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ln_bwd_row(g, u, C, r2);                      // g := dU
+    row_store(g, dU + row * C, C);
+    SEGX_FOR_ROW(i, c4, C) { const float4 ww = reinterpret_cast<const float4*>(w1)[c4];
+                             SEGX_F4_OP(g.v[i], g.v[i].x * ww.x, g.v[i].y * ww.y, g.v[i].z * ww.z, g.v[i].w * ww.w); }
+    ln_bwd_row(g, xh, C, r1);
+    row_store(g, dX + row * C, C);
+}
+
+// =================================================================================================
+// Learned sinusoidal positional code (LearnedSinuPosEmbedder.forward :989-998, K13), batch-invariant:
+//   z = posn @ Wp^T + bp ; mix[c] = c even ? sin z : cos z ; out = LN_noaffine(mix)
+// =================================================================================================
+template <int NV4>
+__global__ __launch_bounds__(256) void posembed_fwd_kernel(const float* __restrict__ posn, const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                           float* __restrict__ out, float* __restrict__ stats, int64_t N, int C, int pd, float eps) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= N) return;
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < pd; ++d) pc[d] = posn[row * pd + d];
+    Row<NV4> r;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) r.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    SEGX_FOR_ROW(i, c4, C) {
+        float z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 * 4 + j;
+            float a = 0.f;
+            for (int d = 0; d < pd; ++d) a += pc[d] * Wp[(int64_t)c * pd + d];
+            z[j] = a + bp[c];
+        }
+        SEGX_F4_OP(r.v[i], sinf(z[0]), cosf(z[1]), sinf(z[2]), cosf(z[3]));      // c4*4 is even
+    }
+    float m, rs; row_stats(r, C, eps, m, rs);
+    SEGX_FOR_ROW(i, c4, C) SEGX_F4_OP(r.v[i], (r.v[i].x - m) * rs, (r.v[i].y - m) * rs, (r.v[i].z - m) * rs, (r.v[i].w - m) * rs);
+    row_store(r, out + row * C, C);
+    if ((threadIdx.x & 63) == 0) { stats[row] = m; stats[N + row] = rs; }
+}
+// dZ[n,c] = d(loss)/d z[n,c];  then dWp = dZ^T posn (GEMM), dbp = colsum(dZ)
+template <int NV4>
+__global__ __launch_bounds__(256) void posembed_bwd_kernel(const float* __restrict__ dOut, const float* __restrict__ posn, const float* __restrict__ Wp,
+                                                           const float* __restrict__ bp, const float* __restrict__ stats, float* __restrict__ dZ,
+                                                           int64_t N, int C, int pd) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= N) return;
+    float pc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int d = 0; d < pd; ++d) pc[d] = posn[row * pd + d];
+    const float m = stats[row], rs = stats[N + row];
+    Row<NV4> mh, dv, g; row_load(g, dOut + row * C, C);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) { mh.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); dv.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    SEGX_FOR_ROW(i, c4, C) {
+        float z[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c4 * 4 + j;
+            float a = 0.f;
+            for (int d = 0; d < pd; ++d) a += pc[d] * Wp[(int64_t)c * pd + d];
+            z[j] = a + bp[c];
+        }
+        const float s0 = sinf(z[0]), c0 = cosf(z[0]), s1 = sinf(z[1]), c1 = cosf(z[1]);
+        const float s2 = sinf(z[2]), c2 = cosf(z[2]), s3 = sinf(z[3]), c3 = cosf(z[3]);
+        SEGX_F4_OP(mh.v[i], (s0 - m) * rs, (c1 - m) * rs, (s2 - m) * rs, (c3 - m) * rs);
+        SEGX_F4_OP(dv.v[i], c0, -s1, c2, -s3);                                   // d mix / d z
+    }
+    ln_bwd_row(g, mh, C, rs);
+    SEGX_FOR_ROW(i, c4, C) SEGX_F4_OP(g.v[i], g.v[i].x * dv.v[i].x, g.v[i].y * dv.v[i].y, g.v[i].z * dv.v[i].z, g.v[i].w * dv.v[i].w);
+    row_store(g, dZ + row * C, C);
+}
+
+// =================================================================================================
+// Expansion tail (MMPrivateOutput dropout + LayerNorm :273-274, LearnedSoftAggregate :318-325; K10b+K11)
+//   Z [Mo, R, F] mode-major -> zn_m = LN(dropout(z_m)) ; s_m = zn_m . wa + ba ; pr = softmax_m(s) ; y = sum_m pr_m zn_m
+// stats: mean[Mo*R], rstd[Mo*R], prob[Mo*R]
+// =================================================================================================
+template <int NV4, int MO>
+__global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ lnw, const float* __restrict__ lnb,
+                                                             const float* __restrict__ wa, const float* __restrict__ ba, float* __restrict__ Y,
+                                                             float* __restrict__ stats, int64_t R, int F, float eps,
+                                                             float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= R) return;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    Row<NV4> z[MO];
+    float sc[MO];
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const int64_t mr = (int64_t)m * R + row;
+        row_load(z[m], Z + mr * F, F);
+        if (p > 0.f) SEGX_FOR_ROW(i, c4, F) {
+            const float4 k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
+            SEGX_F4_OP(z[m].v[i], z[m].v[i].x * k.x, z[m].v[i].y * k.y, z[m].v[i].z * k.z, z[m].v[i].w * k.w);
+        }
+        float mean, rstd; row_stats(z[m], F, eps, mean, rstd);
+        float s = 0.f;
+        SEGX_FOR_ROW(i, c4, F) {
+            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], bb = reinterpret_cast<const float4*>(lnb)[c4];
+            const float4 aa = reinterpret_cast<const float4*>(wa)[c4];
+            SEGX_F4_OP(z[m].v[i], (z[m].v[i].x - mean) * rstd * ww.x + bb.x, (z[m].v[i].y - mean) * rstd * ww.y + bb.y,
+                       (z[m].v[i].z - mean) * rstd * ww.z + bb.z, (z[m].v[i].w - mean) * rstd * ww.w + bb.w);
+            s += (z[m].v[i].x * aa.x + z[m].v[i].y * aa.y) + (z[m].v[i].z * aa.z + z[m].v[i].w * aa.w);
+        }
+        sc[m] = wave_sum(s) + ba[0];
+        if ((threadIdx.x & 63) == 0) { stats[mr] = mean; stats[(int64_t)MO * R + mr] = rstd; }
+    }
+    float mx = sc[0];
+#pragma unroll
+    for (int m = 1; m < MO; ++m) mx = fmaxf(mx, sc[m]);
+    float den = 0.f;
+#pragma unroll
+    for (int m = 0; m < MO; ++m) { sc[m] = expf(sc[m] - mx); den += sc[m]; }
+    Row<NV4> y;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) y.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const float pr = sc[m] / den;
+        if ((threadIdx.x & 63) == 0) stats[(int64_t)2 * MO * R + (int64_t)m * R + row] = pr;
+        SEGX_FOR_ROW(i, c4, F) SEGX_F4_OP(y.v[i], y.v[i].x + z[m].v[i].x * pr, y.v[i].y + z[m].v[i].y * pr,
+                                           y.v[i].z + z[m].v[i].z * pr, y.v[i].w + z[m].v[i].w * pr);
+    }
+    row_store(y, Y + row * F, F);
+}
+
+// dZ and the per-(mode,row) score gradients ds (needed again by the parameter-gradient pass)
+template <int NV4, int MO>
+__global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
+                                                             const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
+                                                             float* __restrict__ dZ, float* __restrict__ dscore, int64_t R, int F,
+                                                             float p, uint64_t seed, uint64_t off) {
+    const int64_t row = SEGX_ROW_ID();
+    if (row >= R) return;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    Row<NV4> g; row_load(g, dY + row * F, F);
+    float dp[MO], pr[MO];
+    // pass 1: dp_m = dY . zn_m
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const int64_t mr = (int64_t)m * R + row;
+        const float mean = stats[mr], rstd = stats[(int64_t)MO * R + mr];
+        pr[m] = stats[(int64_t)2 * MO * R + mr];
+        Row<NV4> z; row_load(z, Z + mr * F, F);
+        float s = 0.f;
+        SEGX_FOR_ROW(i, c4, F) {
+            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
+            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], bb = reinterpret_cast<const float4*>(lnb)[c4];
+            s += (((z.v[i].x * k.x - mean) * rstd * ww.x + bb.x) * g.v[i].x + ((z.v[i].y * k.y - mean) * rstd * ww.y + bb.y) * g.v[i].y) +
+                 (((z.v[i].z * k.z - mean) * rstd * ww.z + bb.z) * g.v[i].z + ((z.v[i].w * k.w - mean) * rstd * ww.w + bb.w) * g.v[i].w);
+        }
+        dp[m] = wave_sum(s);
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int m = 0; m < MO; ++m) dot += pr[m] * dp[m];
+    // pass 2: per mode, dzn = pr*dY + ds*wa -> LN backward -> dropout backward
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const int64_t mr = (int64_t)m * R + row;
+        const float mean = stats[mr], rstd = stats[(int64_t)MO * R + mr];
+        const float ds = pr[m] * (dp[m] - dot);
+        if ((threadIdx.x & 63) == 0) dscore[mr] = ds;
+        Row<NV4> zh, d; row_load(zh, Z + mr * F, F);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) d.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        Row<NV4> kk;
+        SEGX_FOR_ROW(i, c4, F) {
+            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
+            kk.v[i] = k;
+            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], aa = reinterpret_cast<const float4*>(wa)[c4];
+            SEGX_F4_OP(zh.v[i], (zh.v[i].x * k.x - mean) * rstd, (zh.v[i].y * k.y - mean) * rstd, (zh.v[i].z * k.z - mean) * rstd, (zh.v[i].w * k.w - mean) * rstd);
+            SEGX_F4_OP(d.v[i], (pr[m] * g.v[i].x + ds * aa.x) * ww.x, (pr[m] * g.v[i].y + ds * aa.y) * ww.y,
+                       (pr[m] * g.v[i].z + ds * aa.z) * ww.z, (pr[m] * g.v[i].w + ds * aa.w) * ww.w);
+        }
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) if (!(((threadIdx.x & 63) + 64 * i) * 4 < F)) zh.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ln_bwd_row(d, zh, F, rstd);
+        SEGX_FOR_ROW(i, c4, F) SEGX_F4_OP(d.v[i], d.v[i].x * kk.v[i].x, d.v[i].y * kk.v[i].y, d.v[i].z * kk.v[i].z, d.v[i].w * kk.v[i].w);
+        row_store(d, dZ + mr * F, F);
+    }
+}
+
+// parameter gradients of the expansion tail: thread = column f, block.y = row chunk.
+//   dlnw = sum dzn * zhat ; dlnb = sum dzn ; dwa = sum ds * zn       with dzn = pr*dY + ds*wa
+__global__ __launch_bounds__(256) void modes_aggr_pgrad_stage1(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
+                                                               const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
+                                                               const float* __restrict__ dscore, float* __restrict__ ws, int Mo, int64_t R, int F,
+                                                               int nchunks, float p, uint64_t seed, uint64_t off) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int64_t per = (R + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(R, r0 + per);
+    if (c >= F) return;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const float w = lnw[c], b = lnb[c], a = wa[c];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int m = 0; m < Mo; ++m)
+        for (int64_t r = r0; r < r1; ++r) {
+            const int64_t mr = (int64_t)m * R + r;
+            float z = Z[mr * F + c];
+            if (p > 0.f) z *= dropout_scale(seed, off, (uint64_t)mr * F + c, p, ik);
+            const float zh = (z - stats[mr]) * stats[(int64_t)Mo * R + mr];
+            const float ds = dscore[mr];
+            const float dzn = stats[(int64_t)2 * Mo * R + mr] * dY[r * F + c] + ds * a;
+            s0 += dzn * zh; s1 += dzn; s2 += ds * (zh * w + b);
+        }
+    ws[(int64_t)chunk * F + c] = s0;
+    ws[((int64_t)nchunks + chunk) * F + c] = s1;
+    ws[((int64_t)2 * nchunks + chunk) * F + c] = s2;
+}
+
+// =================================================================================================
+// GELU backward (+ dropout of MMSharedMid :244-245): dT = dH * keep * gelu'(T)
+// =================================================================================================
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dH, const float* __restrict__ T, float* __restrict__ dT, int64_t n4,
+                                                       float p, uint64_t seed, uint64_t off) {
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 g = reinterpret_cast<const float4*>(dH)[i], t = reinterpret_cast<const float4*>(T)[i];
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) k = f4_keep(seed, off, (uint64_t)i * 4, p, ik);
+        float4 o;
+        SEGX_F4_OP(o, g.x * k.x * gelu_erf_grad(t.x), g.y * k.y * gelu_erf_grad(t.y), g.z * k.z * gelu_erf_grad(t.z), g.w * k.w * gelu_erf_grad(t.w));
+        reinterpret_cast<float4*>(dT)[i] = o;
+    }
+}
+
+}  // namespace segx
+
+using namespace segx;
+#define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
+#define SEGX_ROWCHK(F) SEGX_REQUIRE((F) > 0 && (F) % 4 == 0, "row width %d must be a positive multiple of 4", (int)(F))
+
+extern "C" int segx_softmax_fwd(const float* S, float* P, float* Pdrop, int64_t rows, int L, float clip, const float* gmax,
+                                float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(S && P && rows > 0, "segx_softmax_fwd: bad args"); SEGX_ROWCHK(L);
+    SEGX_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || Pdrop), "segx_softmax_fwd: dropout needs Pdrop");
+    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset));
+    return check_launch("segx_softmax_fwd");
+}
+extern "C" int segx_softmax_bwd(const float* P, const float* dPdrop, const float* S, float* dS, int64_t rows, int L, float clip,
+                                const float* gmax, float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(P && dPdrop && dS && rows > 0, "segx_softmax_bwd: bad args"); SEGX_ROWCHK(L);
+    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset));
+    return check_launch("segx_softmax_bwd");
+}
+extern "C" int segx_layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd,
+                                  int64_t rows, int C, float eps, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Y && mean && rstd && rows > 0 && (!w == !b), "segx_layernorm_fwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((layernorm_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, X, w, b, Y, mean, rstd, rows, C, eps));
+    return check_launch("segx_layernorm_fwd");
+}
+extern "C" int segx_layernorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX,
+                                  int64_t rows, int C, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && rstd && dX && rows > 0, "segx_layernorm_bwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((layernorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w, mean, rstd, dX, rows, C));
+    return check_launch("segx_layernorm_bwd");
+}
+extern "C" int64_t segx_colreduce_ws_floats(int64_t rows, int64_t C, int nout) { return (int64_t)nout * chunks_for(rows) * C; }
+extern "C" int segx_colsum(const float* X, float* out, float* ws, int64_t rows, int64_t C, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && out && ws && rows > 0 && C > 0, "segx_colsum: bad args");
+    const int nch = chunks_for(rows);
+    hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, X, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, ws, rows, C, 0, nch);
+    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)ws, out, (float*)nullptr, (float*)nullptr, C, nch, 1);
+    return check_launch("segx_colsum");
+}
+extern "C" int segx_ln_param_grad(const float* dY, const float* X, const float* mean, const float* rstd, float* dw, float* db, float* ws,
+                                  int64_t rows, int C, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && rstd && dw && db && ws && rows > 0 && C > 0, "segx_ln_param_grad: bad args");
+    const int nch = chunks_for(rows);
+    hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, dY, X, mean, rstd, ws, rows, (int64_t)C, 1, nch);
+    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)ws, dw, db, (float*)nullptr, (int64_t)C, nch, 2);
+    return check_launch("segx_ln_param_grad");
+}
+extern "C" int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1024 floats */, float scale, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(x && out && ws && n > 0, "segx_sum: bad args");
+    const int nb = (int)i64min(1024, (n + 255) / 256);
+    hipLaunchKernelGGL(sum_stage1, dim3(nb), dim3(256), 0, stream, x, n, ws);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, out, scale);
+    return check_launch("segx_sum");
+}
+extern "C" int segx_prenorm_fwd(const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
+                                const float* mask, float* Y, float* stats, int64_t B, int N, int C, float eps,
+                                float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && w1 && b1 && pos && mask && Y && stats && B > 0 && N > 0, "segx_prenorm_fwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_REQUIRE(pos_ld >= C && pos_ld % 4 == 0, "segx_prenorm_fwd: pos_ld %lld", (long long)pos_ld);
+    const int64_t rows = B * N;
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, X, w1, b1, pos, pos_ld, pos_weight, mask, Y, stats, rows, N, C, eps, p, seed, offset));
+    return check_launch("segx_prenorm_fwd");
+}
+extern "C" int segx_prenorm_bwd(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
+                                const float* mask, const float* stats, float* dX, float* dU, int64_t B, int N, int C,
+                                float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && w1 && b1 && pos && mask && stats && dX && dU && B > 0 && N > 0, "segx_prenorm_bwd: bad args"); SEGX_ROWCHK(C);
+    const int64_t rows = B * N;
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dU, rows, N, C, p, seed, offset));
+    return check_launch("segx_prenorm_bwd");
+}
+extern "C" int segx_posembed_fwd(const float* posn, const float* Wp, const float* bp, float* out, float* stats, int64_t N, int C, int pd,
+                                 float eps, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(posn && Wp && bp && out && stats && N > 0 && pd >= 1 && pd <= 4, "segx_posembed_fwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((posembed_fwd_kernel<NV4>), row_grid(N), dim3(256), 0, stream, posn, Wp, bp, out, stats, N, C, pd, eps));
+    return check_launch("segx_posembed_fwd");
+}
+extern "C" int segx_posembed_bwd(const float* dOut, const float* posn, const float* Wp, const float* bp, const float* stats, float* dZ,
+                                 int64_t N, int C, int pd, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dOut && posn && Wp && bp && stats && dZ && N > 0 && pd >= 1 && pd <= 4, "segx_posembed_bwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((posembed_bwd_kernel<NV4>), row_grid(N), dim3(256), 0, stream, dOut, posn, Wp, bp, stats, dZ, N, C, pd));
+    return check_launch("segx_posembed_bwd");
+}
+#define SEGX_DISPATCH_MO(Mo, CALL4, CALL1) if ((Mo) == 4) { constexpr int MO = 4; CALL4; } else if ((Mo) == 1) { constexpr int MO = 1; CALL1; } \
+    else return segx::fail(-1, "num_modes %d unsupported (1 or 4)", (int)(Mo));
+extern "C" int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float* lnb, const float* wa, const float* ba, float* Y, float* stats,
+                                   int Mo, int64_t R, int F, float eps, float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(Z && lnw && lnb && wa && ba && Y && stats && R > 0, "segx_modes_aggr_fwd: bad args"); SEGX_ROWCHK(F);
+    SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_fwd: F=%d too wide for the register-resident 4-mode kernel", F);
+    SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
+        hipLaunchKernelGGL((modes_aggr_fwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset),
+        hipLaunchKernelGGL((modes_aggr_fwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset)));
+    return check_launch("segx_modes_aggr_fwd");
+}
+extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
+                                   float* dZ, float* dscore, int Mo, int64_t R, int F, float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && Z && lnw && lnb && wa && stats && dZ && dscore && R > 0, "segx_modes_aggr_bwd: bad args"); SEGX_ROWCHK(F);
+    SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_bwd: F=%d too wide for the register-resident 4-mode kernel", F);
+    SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset),
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset)));
+    return check_launch("segx_modes_aggr_bwd");
+}
+extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
+                                          const float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws, int Mo, int64_t R, int F,
+                                          float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && Z && lnw && lnb && wa && stats && dscore && dlnw && dlnb && dwa && ws && R > 0, "segx_modes_aggr_param_grad: bad args");
+    const int nch = chunks_for(R);
+    hipLaunchKernelGGL(modes_aggr_pgrad_stage1, dim3((F + 255) / 256, nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dscore, ws, Mo, R, F, nch, p, seed, offset);
+    hipLaunchKernelGGL(colreduce_stage2, dim3((F + 255) / 256), dim3(256), 0, stream, (const float*)ws, dlnw, dlnb, dwa, (int64_t)F, nch, 3);
+    return check_launch("segx_modes_aggr_param_grad");
+}
+extern "C" int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dH && T && dT && n > 0 && n % 4 == 0, "segx_gelu_bwd: n=%lld must be a positive multiple of 4", (long long)n);
+    const int nb = (int)i64min(4096, (n / 4 + 255) / 256);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset);
+    return check_launch("segx_gelu_bwd");
+}

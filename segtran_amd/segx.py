@@ -1,0 +1,181 @@
+"""ctypes binding of the C ABI in include/segx.h (libsegx.so, hand-written HIP for gfx950).
+
+`lib()` loads the in-tree HIP build `segtran_amd/lib/libsegx.so` and raises if it is missing: the
+product path has NO fallback (no oracle, no eager-PyTorch replacement).  The class itself is
+path-parameterised only so that tests can point it at the fiber-emulated build of the SAME sources
+(tests/hipemu) and exercise kernel index math on CPU tensors.
+"""
+import ctypes
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libsegx.so')
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int32
+c_l = ctypes.c_int64
+c_u = ctypes.c_uint64
+c_p = ctypes.c_void_p
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [('M', c_i), ('N', c_i), ('K', c_i), ('nb0', c_i), ('nb1', c_i),
+                ('a_b0', c_l), ('a_b1', c_l), ('a_m', c_l), ('a_k', c_l),
+                ('b_b0', c_l), ('b_b1', c_l), ('b_n', c_l), ('b_k', c_l),
+                ('c_b0', c_l), ('c_b1', c_l), ('c_m', c_l),
+                ('alpha', c_f), ('epilogue', c_i), ('bias_mode', c_i), ('bias_b1', c_l),
+                ('bias', c_p), ('aux', c_p), ('gmax', c_p),
+                ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
+                ('splitk', c_i), ('workspace', c_p)]
+
+
+EPI_NONE, EPI_GELU = 0, 1
+BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SegxLib:
+    def __init__(self, path=LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError('libsegx not built: %s is missing '
+                               '(run `python -c "import __graft_entry__ as g; g.build()"`)' % path)
+        self.path = path
+        self.c = ctypes.CDLL(path)
+        self.c.segx_last_error.argtypes = [ctypes.c_char_p, c_i]
+        self.c.segx_version.restype = c_i
+        self.emulated = 'emu' in os.path.basename(path)
+        kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
+        for name, sig in _SIGS.items():
+            fn = getattr(self.c, name)
+            fn.argtypes = [kinds[k] for k in sig]
+            fn.restype = c_l if name.endswith('_floats') else c_i
+
+    # ---- plumbing -----------------------------------------------------------------------------
+    def stream(self, t):
+        if t.is_cuda:
+            return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return ctypes.c_void_p(0)
+
+    def check(self, rc, what):
+        if rc != 0:
+            buf = ctypes.create_string_buffer(512)
+            self.c.segx_last_error(buf, 512)
+            raise RuntimeError('%s failed (rc=%d): %s' % (what, rc, buf.value.decode()))
+
+    def _chk_t(self, *ts):
+        dev = None
+        for t in ts:
+            if t is None:
+                continue
+            if not self.emulated and not t.is_cuda:
+                raise RuntimeError('libsegx (HIP) called with a CPU tensor')
+            dev = dev or t.device
+            assert t.device == dev, 'tensors on different devices'
+
+    # ---- GEMM -----------------------------------------------------------------------------------
+    def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
+             bias_mode=BIAS_NONE, bias_b1=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
+             offset=0, splitk=1, workspace=None):
+        """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
+        a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m)."""
+        self._chk_t(A, B, C, bias, aux, gmax, workspace)
+        d = GemmDesc()
+        d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
+        d.a_b0, d.a_b1, d.a_m, d.a_k = a_strides
+        d.b_b0, d.b_b1, d.b_n, d.b_k = b_strides
+        d.c_b0, d.c_b1, d.c_m = c_strides
+        d.alpha, d.epilogue, d.bias_mode, d.bias_b1 = alpha, epilogue, bias_mode, bias_b1
+        d.bias, d.aux, d.gmax = _ptr(bias), _ptr(aux), _ptr(gmax)
+        d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+        d.splitk, d.workspace = splitk, _ptr(workspace)
+        rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
+        self.check(rc, 'segx_gemm_f32')
+
+
+    # ---- token row kernels (tokens.hip) ---------------------------------------------------------
+    def _call(self, name, ref, *args):
+        """args: tensors (-> device pointers), None (-> NULL) or python scalars; stream appended."""
+        ts = [a for a in args if isinstance(a, torch.Tensor)]
+        self._chk_t(*ts)
+        for t in ts:
+            assert t.is_contiguous(), name + ': non-contiguous tensor'
+        conv = [(_ptr(a) if isinstance(a, torch.Tensor) or a is None else a) for a in args]
+        rc = getattr(self.c, name)(*conv, self.stream(ref))
+        self.check(rc, name)
+
+    def colreduce_ws(self, rows, C, nout):
+        return int(self.c.segx_colreduce_ws_floats(rows, C, nout))
+
+    def softmax_fwd(self, S, P, Pdrop, rows, L, clip, gmax, p, seed, offset):
+        self._call('segx_softmax_fwd', S, S, P, Pdrop, rows, L, clip, gmax, p, seed, offset)
+
+    def softmax_bwd(self, P, dPd, S, dS, rows, L, clip, gmax, p, seed, offset):
+        self._call('segx_softmax_bwd', P, P, dPd, S, dS, rows, L, clip, gmax, p, seed, offset)
+
+    def layernorm_fwd(self, X, w, b, Y, mean, rstd, rows, C, eps):
+        self._call('segx_layernorm_fwd', X, X, w, b, Y, mean, rstd, rows, C, eps)
+
+    def layernorm_bwd(self, dY, X, w, mean, rstd, dX, rows, C):
+        self._call('segx_layernorm_bwd', X, dY, X, w, mean, rstd, dX, rows, C)
+
+    def colsum(self, X, out, ws, rows, C):
+        self._call('segx_colsum', X, X, out, ws, rows, C)
+
+    def ln_param_grad(self, dY, X, mean, rstd, dw, db, ws, rows, C):
+        self._call('segx_ln_param_grad', X, dY, X, mean, rstd, dw, db, ws, rows, C)
+
+    def sum(self, x, n, out, ws, scale=1.0):
+        self._call('segx_sum', x, x, n, out, ws, scale)
+
+    def prenorm_fwd(self, X, w1, b1, pos, pos_ld, pw, mask, Y, stats, B, N, C, eps, p, seed, offset):
+        self._call('segx_prenorm_fwd', X, X, w1, b1, pos, pos_ld, pw, mask, Y, stats, B, N, C, eps, p, seed, offset)
+
+    def prenorm_bwd(self, dY, X, w1, b1, pos, pos_ld, pw, mask, stats, dX, dU, B, N, C, p, seed, offset):
+        self._call('segx_prenorm_bwd', X, dY, X, w1, b1, pos, pos_ld, pw, mask, stats, dX, dU, B, N, C, p, seed, offset)
+
+    def posembed_fwd(self, posn, Wp, bp, out, stats, N, C, pd, eps):
+        self._call('segx_posembed_fwd', out, posn, Wp, bp, out, stats, N, C, pd, eps)
+
+    def posembed_bwd(self, dOut, posn, Wp, bp, stats, dZ, N, C, pd):
+        self._call('segx_posembed_bwd', dOut, dOut, posn, Wp, bp, stats, dZ, N, C, pd)
+
+    def modes_aggr_fwd(self, Z, lnw, lnb, wa, ba, Y, stats, Mo, R, F, eps, p, seed, offset):
+        self._call('segx_modes_aggr_fwd', Z, Z, lnw, lnb, wa, ba, Y, stats, Mo, R, F, eps, p, seed, offset)
+
+    def modes_aggr_bwd(self, dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, F, p, seed, offset):
+        self._call('segx_modes_aggr_bwd', Z, dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, F, p, seed, offset)
+
+    def modes_aggr_param_grad(self, dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa, ws, Mo, R, F, p, seed, offset):
+        self._call('segx_modes_aggr_param_grad', Z, dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa, ws, Mo, R, F,
+                   p, seed, offset)
+
+    def gelu_bwd(self, dH, T, dT, n, p, seed, offset):
+        self._call('segx_gelu_bwd', T, dH, T, dT, n, p, seed, offset)
+
+
+# C signatures (include/segx.h): p pointer, i int32, l int64, f float, u uint64; trailing p = stream
+_SIGS = {
+    'segx_softmax_fwd': 'ppplifpfuup', 'segx_softmax_bwd': 'pppplifpfuup',
+    'segx_layernorm_fwd': 'pppppplifp', 'segx_layernorm_bwd': 'pppppplip',
+    'segx_colreduce_ws_floats': 'lli', 'segx_colsum': 'pppllp', 'segx_ln_param_grad': 'ppppppplip',
+    'segx_sum': 'plppfp',
+    'segx_prenorm_fwd': 'pppplfppplliiffuup'.replace('lliif', 'liif'),
+    'segx_prenorm_bwd': 'ppppplfpppplii' + 'fuup',
+    'segx_posembed_fwd': 'pppppliifp', 'segx_posembed_bwd': 'ppppppliip',
+    'segx_modes_aggr_fwd': 'pppppppiliffuup', 'segx_modes_aggr_bwd': 'ppppppppilifuup',
+    'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
+}
+
+_LIB = None
+
+
+def lib():
+    """The product library (HIP, in-tree).  Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        _LIB = SegxLib(LIB_PATH)
+    return _LIB

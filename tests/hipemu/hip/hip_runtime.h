@@ -1,0 +1,187 @@
+// tests/hipemu/hip/hip_runtime.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny single-threaded SIMT emulator so that the product's HIP sources (segtran_amd/csrc/*.hip)
+// can be compiled, UNMODIFIED, by the host clang++ and exercised on CPU tensors in the `-m "not gpu"`
+// test-suite (there is no GPU in the build container and only 90 GPU-minutes per round).
+// Every GPU thread is a ucontext fiber; __syncthreads(), wave shuffles and the f32 MFMA builtins are
+// rendezvous points between the fibers of a block / of a 64-lane wave.  Blocks run one after the other.
+// It models *semantics* (index maps, MFMA lane layouts, barriers, LDS sharing), not timing, caches or
+// memory ordering.  It is never linked into, nor loaded by, the product library.
+#pragma once
+#include <ucontext.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+#include <functional>
+#include <vector>
+#include <algorithm>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define __constant__ static
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+struct int2 { int x, y; };
+struct int4 { int x, y, z, w; };
+struct uint2 { unsigned x, y; };
+struct uint4 { unsigned x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+typedef void* hipEvent_t;
+#define hipSuccess 0
+static inline hipError_t hipGetLastError() { return 0; }
+static inline hipError_t hipPeekAtLastError() { return 0; }
+static inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+#define hipMemcpyDeviceToDevice 3
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
+
+namespace hipemu {
+struct U3 { unsigned x, y, z; };
+struct Fiber { ucontext_t ctx; char* stack; bool done; U3 tid; int lane, wave; };
+struct Wave { int nlanes, arrived; unsigned gen; float fa[64], fb[64]; uint64_t ub[64]; };
+struct State {
+    dim3 grid, block; U3 bid; Fiber* cur; ucontext_t sched;
+    int nthreads, bar_arrived; unsigned bar_gen;
+    std::vector<Fiber> fibers; std::vector<Wave> waves; std::function<void()>* body;
+};
+inline State S;
+constexpr size_t STACK = 256 * 1024;
+
+inline void yield() { Fiber* f = S.cur; swapcontext(&f->ctx, &S.sched); }
+inline void trampoline() { (*S.body)(); S.cur->done = true; swapcontext(&S.cur->ctx, &S.sched); }
+
+inline void block_sync() {
+    unsigned g = S.bar_gen;
+    if (++S.bar_arrived == S.nthreads) { S.bar_arrived = 0; S.bar_gen++; }
+    else while (S.bar_gen == g) yield();
+}
+inline Wave& wave() { return S.waves[S.cur->wave]; }
+inline void wave_sync() {
+    Wave& w = wave(); unsigned g = w.gen;
+    if (++w.arrived == w.nlanes) { w.arrived = 0; w.gen++; }
+    else while (w.gen == g) yield();
+}
+
+template <class F> void launch(dim3 grid, dim3 block, F&& fn) {
+    std::function<void()> body = fn;
+    S.grid = grid; S.block = block; S.body = &body;
+    S.nthreads = block.x * block.y * block.z;
+    if ((int)S.fibers.size() < S.nthreads) {
+        size_t old = S.fibers.size(); S.fibers.resize(S.nthreads);
+        for (size_t i = old; i < S.fibers.size(); ++i) S.fibers[i].stack = (char*)malloc(STACK);
+    }
+    int nw = (S.nthreads + 63) / 64; S.waves.assign(nw, Wave());
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        S.bid = U3{bx, by, bz}; S.bar_arrived = 0; S.bar_gen = 0;
+        for (int w = 0; w < nw; ++w) { S.waves[w].nlanes = std::min(64, S.nthreads - 64 * w); S.waves[w].arrived = 0; S.waves[w].gen = 0; }
+        for (int t = 0; t < S.nthreads; ++t) {
+            Fiber& f = S.fibers[t]; f.done = false;
+            f.tid = U3{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+            f.lane = t & 63; f.wave = t >> 6;
+            getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
+            makecontext(&f.ctx, (void (*)())trampoline, 0);
+        }
+        int left = S.nthreads, guard = 0;
+        while (left > 0) {
+            int progressed = 0;
+            for (int t = 0; t < S.nthreads; ++t) {
+                Fiber& f = S.fibers[t]; if (f.done) continue;
+                S.cur = &f; swapcontext(&S.sched, &f.ctx);
+                if (f.done) { --left; ++progressed; }
+            }
+            if (!progressed && ++guard > 100000000) { fprintf(stderr, "hipemu: deadlock (barrier divergence?)\n"); abort(); }
+        }
+    }
+}
+
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+typedef float f32x4_ __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x2_f32: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D reg r of lane l = D[i=(r&3)+8*(r>>2)+4*(l>>5)][j=l&31]; exact k-ordered fmaf chain.
+inline f32x16_ mfma_32x32x2f32(float a, float b, f32x16_ c, int, int, int) {
+    Wave& w = wave(); int l = S.cur->lane;
+    w.fa[l] = a; w.fb[l] = b; wave_sync();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) { int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        c[r] = fmaf(w.fa[i + 32], w.fb[j + 32], fmaf(w.fa[i], w.fb[j], c[r])); }
+    wave_sync(); return c;
+}
+// v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r = D[i=4*(l>>4)+r][j=l&15].
+inline f32x4_ mfma_16x16x4f32(float a, float b, f32x4_ c, int, int, int) {
+    Wave& w = wave(); int l = S.cur->lane;
+    w.fa[l] = a; w.fb[l] = b; wave_sync();
+    int j = l & 15;
+    for (int r = 0; r < 4; ++r) { int i = 4 * (l >> 4) + r; float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fmaf(w.fa[i + 16 * k], w.fb[j + 16 * k], acc);
+        c[r] = acc; }
+    wave_sync(); return c;
+}
+template <class T> inline T shfl_idx(T v, int src) {
+    static_assert(sizeof(T) <= 8, "shfl width");
+    Wave& w = wave(); int l = S.cur->lane; uint64_t u = 0; memcpy(&u, &v, sizeof(T));
+    w.ub[l] = u; wave_sync();
+    uint64_t r = w.ub[(src >= 0 && src < w.nlanes) ? src : l]; wave_sync();
+    T out; memcpy(&out, &r, sizeof(T)); return out;
+}
+}  // namespace hipemu
+
+#define threadIdx (hipemu::S.cur->tid)
+#define blockIdx (hipemu::S.bid)
+#define blockDim (hipemu::S.block)
+#define gridDim (hipemu::S.grid)
+#define warpSize 64
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
+    hipemu::launch(dim3(grid), dim3(block), [&]() { kern(__VA_ARGS__); })
+
+static inline void __syncthreads() { hipemu::block_sync(); }
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2f32
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_16x16x4f32
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+
+template <class T> static inline T __shfl(T v, int src, int width = 64) {
+    int l = hipemu::S.cur->lane; int base = l - (l % width); return hipemu::shfl_idx(v, base + (src % width)); }
+template <class T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int l = hipemu::S.cur->lane; return hipemu::shfl_idx(v, l ^ mask); }
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = hipemu::S.cur->lane; int s = l + (int)d; if ((s / width) != (l / width)) s = l; return hipemu::shfl_idx(v, s); }
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int l = hipemu::S.cur->lane; int s = l - (int)d; if (s < 0 || (s / width) != (l / width)) s = l; return hipemu::shfl_idx(v, s); }
+
+static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; *p = std::max(o, v); return o; }
+static inline unsigned atomicMax(unsigned* p, unsigned v) { unsigned o = *p; *p = std::max(o, v); return o; }
+static inline int atomicMin(int* p, int v) { int o = *p; *p = std::min(o, v); return o; }
+static inline unsigned atomicMin(unsigned* p, unsigned v) { unsigned o = *p; *p = std::min(o, v); return o; }
+static inline void __threadfence() {}
+
+#define __expf(x) expf(x)
+#define __logf(x) logf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __frcp_rn(float x) { return 1.0f / x; }
+static inline float __fdividef(float a, float b) { return a / b; }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * b) >> 32); }
+static inline float __ldg(const float* p) { return *p; }
+using std::min; using std::max;

@@ -1,0 +1,231 @@
+"""CPU: segtran_amd/csrc/tokens.hip on the fiber emulator vs plain PyTorch fp32 (autograd) references."""
+import pytest
+import torch
+import torch.nn.functional as F
+from emu import emu_lib
+
+EPS = 1e-12
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, tol=2e-5):
+    s = max(b.abs().max().item(), 1e-20)
+    err = (a - b).abs().max().item()
+    assert err <= tol * s, 'err %.3e scale %.3e' % (err, s)
+
+
+@pytest.mark.parametrize('rows,L', [(7, 64), (5, 260), (9, 1024), (2, 4096)])
+@pytest.mark.parametrize('clamped', [False, True])
+def test_softmax_fwd_bwd(rows, L, clamped):
+    Lb = emu_lib()
+    S = rnd(rows, L, seed=1, scale=3.0)
+    clip = 4.0
+    gmax = torch.tensor([S.max().item() if clamped else 1.0])
+    if clamped:
+        assert S.max() > clip and S.min() < -clip
+    P = torch.empty_like(S)
+    Lb.softmax_fwd(S, P, None, rows, L, clip, gmax, 0.0, 0, 0)
+    Sr = S.clone().requires_grad_(True)
+    Pr = (Sr.clamp(-clip, clip) if clamped else Sr).softmax(-1)
+    close(P, Pr.detach(), 1e-5)
+    G = rnd(rows, L, seed=2)
+    Pr.backward(G)
+    dS = torch.empty_like(S)
+    Lb.softmax_bwd(P, G, S, dS, rows, L, clip, gmax, 0.0, 0, 0)
+    close(dS, Sr.grad, 2e-5)
+
+
+def test_softmax_dropout_consistent_fwd_bwd():
+    Lb = emu_lib()
+    rows, L, p = 6, 256, 0.25
+    S = rnd(rows, L, seed=3)
+    P = torch.empty_like(S); Pd = torch.empty_like(S)
+    Lb.softmax_fwd(S, P, Pd, rows, L, 500.0, None, p, 77, 1024)
+    keep = Pd != 0
+    assert 0.15 < 1 - keep.float().mean().item() < 0.35
+    assert torch.allclose(Pd[keep], P[keep] / (1 - p), rtol=1e-6)
+    mask = keep.float() / (1 - p)
+    Sr = S.clone().requires_grad_(True)
+    G = rnd(rows, L, seed=4)
+    (Sr.softmax(-1) * mask).backward(G)
+    dS = torch.empty_like(S)
+    Lb.softmax_bwd(P, G, None, dS, rows, L, 500.0, None, p, 77, 1024)
+    close(dS, Sr.grad, 2e-5)
+
+
+@pytest.mark.parametrize('rows,C', [(10, 64), (5, 448), (3, 1792), (4, 1024)])
+@pytest.mark.parametrize('affine', [True, False])
+def test_layernorm_fwd_bwd_param_grads(rows, C, affine):
+    Lb = emu_lib()
+    X = rnd(rows, C, seed=5) * 2 + 0.5
+    w = (1 + 0.1 * rnd(C, seed=6)) if affine else None
+    b = (0.1 * rnd(C, seed=7)) if affine else None
+    Y = torch.empty_like(X); mean = torch.empty(rows); rstd = torch.empty(rows)
+    Lb.layernorm_fwd(X, w, b, Y, mean, rstd, rows, C, EPS)
+    Xr = X.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True) if affine else None
+    br = b.clone().requires_grad_(True) if affine else None
+    Yr = F.layer_norm(Xr, (C,), wr, br, EPS)
+    close(Y, Yr.detach(), 1e-5)
+    G = rnd(rows, C, seed=8)
+    Yr.backward(G)
+    dX = torch.empty_like(X)
+    Lb.layernorm_bwd(G, X, w, mean, rstd, dX, rows, C)
+    close(dX, Xr.grad, 3e-5)
+    if affine:
+        dw = torch.empty(C); db = torch.empty(C); ws = torch.empty(Lb.colreduce_ws(rows, C, 2))
+        Lb.ln_param_grad(G, X, mean, rstd, dw, db, ws, rows, C)
+        close(dw, wr.grad, 2e-5); close(db, br.grad, 2e-5)
+
+
+def test_colsum_and_sum():
+    Lb = emu_lib()
+    X = rnd(1000, 70, seed=9)
+    out = torch.empty(70); ws = torch.empty(Lb.colreduce_ws(1000, 70, 1))
+    Lb.colsum(X, out, ws, 1000, 70)
+    close(out, X.double().sum(0).float(), 1e-5)
+    o = torch.empty(1); ws = torch.empty(1024)
+    Lb.sum(X, X.numel(), o, ws, 0.5)
+    assert abs(o.item() - 0.5 * X.double().sum().item()) < 1e-2
+
+
+def _prenorm_ref(X, w1, b1, pos, pw, mask, C, keep=None):
+    u = F.layer_norm(X, (C,), w1, b1, EPS) + pw * pos[None, :, :C]
+    y = F.layer_norm(u, (C,), None, None, EPS)
+    if keep is not None:
+        y = y * keep
+    return y * mask[:, :, None]
+
+
+@pytest.mark.parametrize('B,N,C,Cpos', [(2, 12, 64, 64), (2, 9, 448, 896), (1, 5, 1792, 1792)])
+def test_prenorm_fwd_bwd(B, N, C, Cpos):
+    Lb = emu_lib()
+    X = rnd(B, N, C, seed=10) + 0.3
+    w1 = 1 + 0.1 * rnd(C, seed=11); b1 = 0.1 * rnd(C, seed=12)
+    pos = rnd(N, Cpos, seed=13); pw = 0.7
+    mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(14)) > 0.3).float()
+    Y = torch.empty_like(X); stats = torch.empty(4 * B * N)
+    Lb.prenorm_fwd(X, w1, b1, pos, Cpos, pw, mask, Y, stats, B, N, C, EPS, 0.0, 0, 0)
+    Xr, w1r, b1r, posr = (t.clone().requires_grad_(True) for t in (X, w1, b1, pos))
+    Yr = _prenorm_ref(Xr, w1r, b1r, posr, pw, mask, C)
+    close(Y, Yr.detach(), 1e-5)
+    G = rnd(B, N, C, seed=15)
+    Yr.backward(G)
+    dX = torch.empty_like(X); dU = torch.empty_like(X)
+    Lb.prenorm_bwd(G, X, w1, b1, pos, Cpos, pw, mask, stats, dX, dU, B, N, C, 0.0, 0, 0)
+    close(dX, Xr.grad, 5e-5)
+    # parameter grads from dU via the column reductions
+    dw = torch.empty(C); db = torch.empty(C); ws = torch.empty(Lb.colreduce_ws(B * N, C, 2))
+    Lb.ln_param_grad(dU, X, stats[:B * N], stats[B * N:2 * B * N], dw, db, ws, B * N, C)
+    close(dw, w1r.grad, 5e-5); close(db, b1r.grad, 5e-5)
+    dpos = torch.empty(N * C); ws = torch.empty(Lb.colreduce_ws(B, N * C, 1))
+    Lb.colsum(dU, dpos, ws, B, N * C)
+    close(pw * dpos.view(N, C), posr.grad[:, :C], 5e-5)
+
+
+def test_prenorm_dropout_mask_matches_between_fwd_and_bwd():
+    Lb = emu_lib()
+    B, N, C, p = 2, 6, 64, 0.2
+    X = rnd(B, N, C, seed=16); w1 = 1 + 0.1 * rnd(C, seed=17); b1 = 0.1 * rnd(C, seed=18)
+    pos = rnd(N, C, seed=19); mask = torch.ones(B, N)
+    Y = torch.empty_like(X); stats = torch.empty(4 * B * N)
+    Lb.prenorm_fwd(X, w1, b1, pos, C, 1.0, mask, Y, stats, B, N, C, EPS, p, 5, 64)
+    full = _prenorm_ref(X, w1, b1, pos, 1.0, mask, C)
+    keep = (Y != 0).float() / (1 - p)
+    close(Y, full * keep, 1e-5)
+    Xr = X.clone().requires_grad_(True)
+    G = rnd(B, N, C, seed=20)
+    _prenorm_ref(Xr, w1, b1, pos, 1.0, mask, C, keep).backward(G)
+    dX = torch.empty_like(X); dU = torch.empty_like(X)
+    Lb.prenorm_bwd(G, X, w1, b1, pos, C, 1.0, mask, stats, dX, dU, B, N, C, p, 5, 64)
+    close(dX, Xr.grad, 5e-5)
+
+
+@pytest.mark.parametrize('N,C,pd', [(20, 64, 2), (7, 1792, 2), (11, 1024, 3)])
+def test_posembed_fwd_bwd(N, C, pd):
+    Lb = emu_lib()
+    posn = torch.rand(N, pd, generator=torch.Generator().manual_seed(21))
+    Wp = rnd(C, pd, seed=22); bp = 0.1 * rnd(C, seed=23)
+    out = torch.empty(N, C); stats = torch.empty(2 * N)
+    Lb.posembed_fwd(posn, Wp, bp, out, stats, N, C, pd, EPS)
+    Wr = Wp.clone().requires_grad_(True); br = bp.clone().requires_grad_(True)
+    z = posn @ Wr.t() + br
+    mix = torch.stack((torch.sin(z[:, 0::2]), torch.cos(z[:, 1::2])), dim=2).view(N, C)
+    ref = F.layer_norm(mix, (C,), None, None, EPS)
+    close(out, ref.detach(), 1e-5)
+    G = rnd(N, C, seed=24)
+    ref.backward(G)
+    dZ = torch.empty(N, C)
+    Lb.posembed_bwd(G, posn, Wp, bp, stats, dZ, N, C, pd)
+    close(dZ.t() @ posn, Wr.grad, 5e-5)
+    close(dZ.sum(0), br.grad, 5e-5)
+
+
+def _aggr_ref(Z, lnw, lnb, wa, ba, keep=None):
+    zd = Z if keep is None else Z * keep
+    zn = F.layer_norm(zd, (Z.shape[-1],), lnw, lnb, EPS)
+    sc = zn @ wa + ba                                           # [Mo, R]
+    return (zn * sc.softmax(0)[..., None]).sum(0)
+
+
+@pytest.mark.parametrize('Mo,R,Fd', [(4, 9, 64), (4, 5, 448), (4, 3, 1792), (1, 6, 1024), (4, 4, 32)])
+@pytest.mark.parametrize('p', [0.0, 0.2])
+def test_modes_aggr_fwd_bwd_param_grads(Mo, R, Fd, p):
+    Lb = emu_lib()
+    Z = rnd(Mo, R, Fd, seed=25) * 1.5 + 0.2
+    lnw = 1 + 0.1 * rnd(Fd, seed=26); lnb = 0.1 * rnd(Fd, seed=27)
+    wa = 0.2 * rnd(Fd, seed=28); ba = torch.tensor([0.3])
+    Y = torch.empty(R, Fd); stats = torch.empty(3 * Mo * R)
+    seed, off = 9, 4096
+    Lb.modes_aggr_fwd(Z, lnw, lnb, wa, ba, Y, stats, Mo, R, Fd, EPS, p, seed, off)
+    keep = None
+    if p > 0:
+        # recover the mask through the GELU-bwd kernel, which shares the (seed, offset, flat index) stream
+        ones = torch.ones(Mo * R * Fd); big = torch.full((Mo * R * Fd,), 30.0); k = torch.empty(Mo * R * Fd)
+        Lb.gelu_bwd(ones, big, k, Mo * R * Fd, p, seed, off)          # gelu'(30) == 1
+        keep = k.view(Mo, R, Fd)
+        assert 0.1 < (keep == 0).float().mean().item() < 0.3
+    Zr, lnwr, lnbr, war, bar = (t.clone().requires_grad_(True) for t in (Z, lnw, lnb, wa, ba))
+    Yr = _aggr_ref(Zr, lnwr, lnbr, war, bar, keep)
+    close(Y, Yr.detach(), 2e-5)
+    G = rnd(R, Fd, seed=29)
+    Yr.backward(G)
+    dZ = torch.empty_like(Z); dscore = torch.empty(Mo * R)
+    Lb.modes_aggr_bwd(G, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
+    close(dZ, Zr.grad, 1e-4)
+    dlnw = torch.empty(Fd); dlnb = torch.empty(Fd); dwa = torch.empty(Fd)
+    ws = torch.empty(Lb.colreduce_ws(R, Fd, 3))
+    Lb.modes_aggr_param_grad(G, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa, ws, Mo, R, Fd, p, seed, off)
+    close(dlnw, lnwr.grad, 1e-4); close(dlnb, lnbr.grad, 1e-4)
+    if Mo > 1:
+        close(dwa, war.grad, 1e-4)
+    else:
+        assert dwa.abs().max() < 1e-6 and dscore.abs().max() < 1e-6      # single mode: softmax == 1, zero grads
+
+
+def test_gelu_bwd():
+    Lb = emu_lib()
+    T = rnd(50, 36, seed=30) * 2
+    G = rnd(50, 36, seed=31)
+    Tr = T.clone().requires_grad_(True)
+    F.gelu(Tr).backward(G)
+    dT = torch.empty_like(T)
+    Lb.gelu_bwd(G, T, dT, T.numel(), 0.0, 0, 0)
+    close(dT, Tr.grad, 1e-5)
+
+
+def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask():
+    """The GEMM epilogue (scattered MFMA lanes) and gelu_bwd (float4 lanes) must regenerate the same mask."""
+    from segtran_amd import segx
+    Lb = emu_lib()
+    R, Fd, p = 70, 36, 0.3
+    H = rnd(R, Fd, seed=32); W = rnd(Fd, Fd, seed=33) * 0.3
+    Y = torch.zeros(R, Fd); T = torch.zeros(R, Fd)
+    Lb.gemm(H, W, Y, R, Fd, Fd, (0, 0, Fd, 1), (0, 0, Fd, 1), (0, 0, Fd), epilogue=segx.EPI_GELU, aux=T, dropout_p=p, seed=3, offset=8)
+    k = torch.empty(R * Fd)
+    Lb.gelu_bwd(torch.ones(R * Fd), torch.full((R * Fd,), 30.0), k, R * Fd, p, 3, 8)
+    close(Y, F.gelu(T) * k.view(R, Fd), 1e-5)
