@@ -104,6 +104,31 @@ int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw
 /* backward of the GELU(+dropout) epilogue of segx_gemm_f32 (MMSharedMid :244-245): dT = dH * keep * gelu'(T) */
 int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-step glue (train.hip)
+ * ------------------------------------------------------------------------------------------- */
+/* loss = (1-dice_w) * BCEWithLogits(pos_weight)(logits, mask) + dice_w * sum_c class_w[c] * mean_b dice_loss_indiv
+ * (train2d.py:1233-1242,1314-1318; train3d.py:738-756; utils/losses.py:47-60).  logits/mask [B, C, S] fp32 at mask
+ * resolution.  out[0]=loss, out[1]=ce, out[2]=dice_total, out[3+c]=dice_c.  ws: segx_loss_ws_floats(B, C) floats,
+ * must be kept untouched between fwd and bwd.  bwd: dlogits = grad_out[0] * dloss/dlogits. */
+int64_t segx_loss_ws_floats(int B, int C);
+int segx_seg_loss_fwd(const float* logits, const float* mask, const float* pos_weight, const float* class_w, float* out,
+                      float* ws, int B, int C, int64_t S, float dice_w, void* stream);
+int segx_seg_loss_bwd(const float* logits, const float* mask, const float* pos_weight, const float* class_w, const float* ws,
+                      const float* grad_out, float* dlogits, int B, int C, int64_t S, float dice_w, void* stream);
+/* One optimizer step for ALL parameter tensors in three launches: nn.utils.clip_grad_norm_(all, max_global_norm)
+ * (train2d.py:1324-1325) followed by BertAdam.step (optimization.py:90-164: per-tensor clip max_tensor_norm, Adam
+ * moments without bias correction, decoupled weight decay, lr * sched).  Device tables (built once by the caller):
+ * params/grads/m/v = arrays of device pointers [ntensors]; sizes [ntensors]; tensors cut into `chunk`-element chunks:
+ * chunk_tensor/chunk_off [nchunks], chunk_first [ntensors+1] (chunks of a tensor are consecutive); active[t] = 0 for
+ * parameters that never receive a gradient (N3: skipped, no weight decay).  ws: nchunks + 2*ntensors + 2 floats;
+ * afterwards ws[nchunks + 2*ntensors] = global grad norm. */
+int segx_mt_bertadam_step(void* const* params, const void* const* grads, void* const* m, void* const* v, const int64_t* sizes,
+                          const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_first, const int* active,
+                          const float* lr, const float* wd, int ntensors, int nchunks, int chunk,
+                          float max_global_norm, float max_tensor_norm, float sched, float b1, float b2, float eps,
+                          float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

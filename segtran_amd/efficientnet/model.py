@@ -1,0 +1,159 @@
+"""EfficientNet-B* feature extractor with the reference's customisations (stem_stride, endpoints).
+
+Host-side mirror of /root/reference/code/efficientnet/{model,utils}.py for the segtran path: same module /
+parameter names (so lukemelas-format and reference checkpoints load), same static-'same'-padding quirk N6
+(padding derived from the NOMINAL image size, the stem bookkept as stride 2 even when stem_stride=1:
+model.py:169-178, utils.py:248-275), same endpoint rule (endpoints are the INPUTS of blocks
+`endpoint_blk_indices`, model.py:184,211-212,275-277).
+
+Kernel status: every 1x1 convolution (127 of the 160 convs of B4) runs on libsegx's MFMA GEMM.  The
+stem 3x3, the 32 depthwise k3/k5 convolutions, BatchNorm, swish and the squeeze-excite pooling are still
+ATen/MIOpen calls here -- HBM-bound kernels scheduled for the next round (DESIGN.md "coverage").
+"""
+import math
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .. import functional as SF
+
+BN_MOM, BN_EPS = 1 - 0.99, 1e-3
+
+# (num_repeat, kernel, stride, expand, in, out, se_ratio)  -- EfficientNet-B0 base table (utils.py:514-522)
+_BASE = [(1, 3, 1, 1, 32, 16, 0.25), (2, 3, 2, 6, 16, 24, 0.25), (2, 5, 2, 6, 24, 40, 0.25), (3, 3, 2, 6, 40, 80, 0.25),
+         (3, 5, 1, 6, 80, 112, 0.25), (4, 5, 2, 6, 112, 192, 0.25), (1, 3, 1, 6, 192, 320, 0.25)]
+# name -> (width, depth, nominal resolution, dropout)   (utils.py:476-488)
+_PARAMS = {'efficientnet-b0': (1.0, 1.0, 224, 0.2), 'efficientnet-b1': (1.0, 1.1, 240, 0.2),
+           'efficientnet-b2': (1.1, 1.2, 260, 0.3), 'efficientnet-b3': (1.2, 1.4, 300, 0.3),
+           'efficientnet-b4': (1.4, 1.8, 380, 0.4), 'efficientnet-b5': (1.6, 2.2, 456, 0.4),
+           'efficientnet-b6': (1.8, 2.6, 528, 0.5), 'efficientnet-b7': (2.0, 3.1, 600, 0.5)}
+
+
+def round_filters(filters, width, divisor=8):
+    filters *= width
+    new = max(divisor, int(filters + divisor / 2) // divisor * divisor)
+    if new < 0.9 * filters:
+        new += divisor
+    return int(new)
+
+
+def round_repeats(repeats, depth):
+    return int(math.ceil(depth * repeats))
+
+
+class Conv2dStaticSamePadding(nn.Conv2d):
+    """TF-'SAME' conv whose padding is fixed at construction from a given image size (N6)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, image_size=None, **kwargs):
+        super().__init__(in_channels, out_channels, kernel_size, stride, **kwargs)
+        ih = iw = image_size
+        kh, kw = self.weight.shape[-2:]
+        sh, sw = self.stride
+        oh, ow = math.ceil(ih / sh), math.ceil(iw / sw)
+        ph = max((oh - 1) * sh + (kh - 1) * self.dilation[0] + 1 - ih, 0)
+        pw = max((ow - 1) * sw + (kw - 1) * self.dilation[1] + 1 - iw, 0)
+        self.static_pad = (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+        self.pointwise = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and self.groups == 1)
+
+    def forward(self, x):
+        if self.pointwise:
+            return SF.conv1x1(x, self.weight, self.bias)                 # libsegx MFMA GEMM
+        if any(self.static_pad):
+            x = F.pad(x, self.static_pad)
+        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def drop_connect(x, p, training):
+    """utils.py:129-154 -- per-sample stochastic depth."""
+    if not training:
+        return x
+    keep = 1 - p
+    r = keep + torch.rand([x.shape[0], 1, 1, 1], dtype=x.dtype, device=x.device)
+    return x / keep * torch.floor(r)
+
+
+class MBConvBlock(nn.Module):
+    def __init__(self, k, s, e, cin, cout, se_ratio, image_size):
+        super().__init__()
+        self.stride, self.expand_ratio, self.input_filters, self.output_filters = s, e, cin, cout
+        oup = cin * e
+        if e != 1:
+            self._expand_conv = Conv2dStaticSamePadding(cin, oup, 1, image_size=image_size, bias=False)
+            self._bn0 = nn.BatchNorm2d(oup, momentum=BN_MOM, eps=BN_EPS)
+        self._depthwise_conv = Conv2dStaticSamePadding(oup, oup, k, stride=s, image_size=image_size, groups=oup, bias=False)
+        self._bn1 = nn.BatchNorm2d(oup, momentum=BN_MOM, eps=BN_EPS)
+        nsq = max(1, int(cin * se_ratio))
+        self._se_reduce = Conv2dStaticSamePadding(oup, nsq, 1, image_size=1)
+        self._se_expand = Conv2dStaticSamePadding(nsq, oup, 1, image_size=1)
+        self._project_conv = Conv2dStaticSamePadding(oup, cout, 1, image_size=math.ceil(image_size / s), bias=False)
+        self._bn2 = nn.BatchNorm2d(cout, momentum=BN_MOM, eps=BN_EPS)
+
+    def forward(self, inputs, drop_connect_rate=None):
+        x = inputs
+        if self.expand_ratio != 1:
+            x = swish(self._bn0(self._expand_conv(x)))
+        x = swish(self._bn1(self._depthwise_conv(x)))
+        sq = F.adaptive_avg_pool2d(x, 1)
+        sq = self._se_expand(swish(self._se_reduce(sq)))
+        x = torch.sigmoid(sq) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.input_filters == self.output_filters:
+            if drop_connect_rate:
+                x = drop_connect(x, drop_connect_rate, self.training)
+            x = x + inputs
+        return x
+
+
+class EfficientNet(nn.Module):
+    def __init__(self, model_name='efficientnet-b4', stem_stride=2, drop_connect_rate=0.2, num_classes=1000):
+        super().__init__()
+        width, depth, res, _ = _PARAMS[model_name]
+        self.drop_connect_rate = drop_connect_rate
+        self.stem_stride = stem_stride
+        c0 = round_filters(32, width)
+        self._conv_stem = Conv2dStaticSamePadding(3, c0, 3, stride=stem_stride, image_size=res, bias=False)
+        self._bn0 = nn.BatchNorm2d(c0, momentum=BN_MOM, eps=BN_EPS)
+        size = math.ceil(res / 2)                               # N6: bookkeeping assumes a stride-2 stem
+        self._blocks = nn.ModuleList([])
+        self.endpoint_seg_indices = [0, 1, 2, 4]
+        self.endpoint_blk_indices = []
+        for i, (r, k, s, e, cin, cout, se) in enumerate(_BASE):
+            cin, cout, r = round_filters(cin, width), round_filters(cout, width), round_repeats(r, depth)
+            self._blocks.append(MBConvBlock(k, s, e, cin, cout, se, size))
+            size = math.ceil(size / s)
+            for _ in range(r - 1):
+                self._blocks.append(MBConvBlock(k, 1, e, cout, cout, se, size))
+            if i in self.endpoint_seg_indices:
+                self.endpoint_blk_indices.append(len(self._blocks))
+        chead = round_filters(1280, width)
+        self._conv_head = Conv2dStaticSamePadding(cout, chead, 1, image_size=size, bias=False)
+        self._bn1 = nn.BatchNorm2d(chead, momentum=BN_MOM, eps=BN_EPS)
+        self._fc = nn.Linear(chead, num_classes)               # kept for checkpoint compatibility; never used (N3)
+
+    @classmethod
+    def from_name(cls, model_name, stem_stride=2, **kw):
+        return cls(model_name, stem_stride=stem_stride, **kw)
+
+    @classmethod
+    def from_pretrained(cls, model_name, stem_stride=2, **kw):
+        raise RuntimeError('pretrained EfficientNet weights need network access; load a checkpoint with '
+                           'load_state_dict() or use segtran_amd.synth.load_synth()')
+
+    def extract_endpoints(self, inputs):
+        endpoints = {}
+        x = swish(self._bn0(self._conv_stem(inputs)))
+        prev_x = x
+        nblk = len(self._blocks)
+        for idx, block in enumerate(self._blocks):
+            rate = self.drop_connect_rate * float(idx) / nblk if self.drop_connect_rate else None
+            x = block(x, drop_connect_rate=rate)
+            if idx in self.endpoint_blk_indices:
+                endpoints['reduction_%d' % (len(endpoints) + 1)] = prev_x
+            prev_x = x
+        x = swish(self._bn1(self._conv_head(x)))
+        endpoints['reduction_%d' % (len(endpoints) + 1)] = x
+        return endpoints

@@ -1,0 +1,420 @@
+"""Autograd surface over libsegx (include/segx.h): every op here runs hand-written HIP kernels forward AND
+backward -- there is no PyTorch-eager fallback.  Tensors are fp32 and live on the GPU (or on the CPU only
+when a test has installed the fiber-emulated build of the same kernels through `segx.use_library`).
+"""
+import math
+import torch
+from . import segx
+from .segx import EPI_NONE, EPI_GELU, BIAS_NONE, BIAS_N, BIAS_M
+
+LN_EPS = 1e-12      # every LayerNorm of the Squeeze-and-Expansion transformer (segtran_shared.py:262,361,889,985)
+
+
+# -------------------------------------------------------------------------------------------------
+# Dropout RNG: one Philox stream per process; ops reserve disjoint counter ranges (multiples of 4).
+# -------------------------------------------------------------------------------------------------
+class _Rng:
+    seed = 0x5E67AD
+    offset = 0
+
+    @classmethod
+    def manual_seed(cls, s):
+        cls.seed, cls.offset = int(s) & 0x7FFFFFFFFFFFFFFF, 0
+
+    @classmethod
+    def reserve(cls, n):
+        o = cls.offset
+        cls.offset += (int(n) + 3) // 4 * 4
+        return cls.seed, o
+
+
+manual_seed = _Rng.manual_seed
+
+
+def _empty(ref, *shape):
+    return torch.empty(*shape, dtype=torch.float32, device=ref.device)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# -------------------------------------------------------------------------------------------------
+# Generic batched strided GEMM with autograd
+# -------------------------------------------------------------------------------------------------
+class GemmSpec:
+    """C[z0,z1][m][n] = alpha * sum_k A(z,m,k) B(z,n,k) (+bias); strides in elements (see segx.h)."""
+    __slots__ = ('M', 'N', 'K', 'nb', 'a', 'b', 'c', 'out_shape', 'alpha', 'bias_mode', 'bias_b1')
+
+    def __init__(self, M, N, K, a, b, c, out_shape, nb=(1, 1), alpha=1.0, bias_mode=BIAS_NONE, bias_b1=0):
+        self.M, self.N, self.K, self.nb, self.a, self.b, self.c = M, N, K, nb, tuple(a), tuple(b), tuple(c)
+        self.out_shape, self.alpha, self.bias_mode, self.bias_b1 = tuple(out_shape), alpha, bias_mode, bias_b1
+
+
+def _splitk(M, N, K, nbatch):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
+    if tiles >= 256 or K < 2048:
+        return 1
+    return int(max(1, min(16, 512 // tiles, K // 512)))
+
+
+def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
+    sk = _splitk(M, N, K, nb[0] * nb[1]) if not kw.get('epilogue') and kw.get('gmax') is None else 1
+    ws = _empty(C, sk * nb[0] * nb[1] * M * N) if sk > 1 else None
+    L.gemm(A, B, C, M, N, K, a, b, c, nb=nb, alpha=alpha, splitk=sk, workspace=ws, **kw)
+
+
+def _grad_operand(L, dC, other, s, which, like):
+    """Gradient of operand `which` ('a' or 'b') of spec s.  `other` is the other operand."""
+    nb = s.nb
+    if which == 'a':
+        rows, cols, st, ost = s.M, s.K, s.a, s.b      # dA(m,k) = alpha sum_n dC(m,n) B(n,k)
+    else:
+        rows, cols, st, ost = s.N, s.K, s.b, s.a      # dB(n,k) = alpha sum_m dC(m,n) A(m,k)
+    inner = s.N if which == 'a' else s.M
+    bcast = [(st[i] == 0 and nb[i] > 1) for i in (0, 1)]
+    if any(bcast):
+        # operand shared across a batch dim: per-batch partial grads, then a deterministic column sum
+        assert st[2] == 1 or st[3] == 1
+        k_contig = st[3] == 1
+        tmp_rows, tmp_cols = (rows, cols) if k_contig else (cols, rows)
+        tmp = _empty(dC, nb[0] * nb[1], tmp_rows, tmp_cols)
+        tb = (nb[1] * tmp_rows * tmp_cols, tmp_rows * tmp_cols)
+        out_rs = tmp_cols
+        tgt, tgt_b, row_stride = tmp, tb, out_rs
+    else:
+        k_contig = st[3] == 1
+        tgt = torch.zeros_like(like) if not like.is_contiguous() else torch.empty_like(like)
+        tgt_b, row_stride = (st[0], st[1]), (st[2] if k_contig else st[3])
+    # dC viewed as an operand: rows m (stride c_m) and cols n (stride 1)
+    if which == 'a':
+        dc_as_rows = (s.c[0], s.c[1], s.c[2], 1)       # (m, inner=n)
+        oth = (ost[0], ost[1], ost[3], ost[2])         # B as (k, inner=n): row stride b_k, inner stride b_n
+    else:
+        dc_as_rows = (s.c[0], s.c[1], 1, s.c[2])       # (n, inner=m)
+        oth = (ost[0], ost[1], ost[3], ost[2])         # A as (k, inner=m): row stride a_k, inner stride a_m
+    if k_contig:    # out[rows][cols=k]
+        _run_gemm(L, dC, other, tgt, rows, cols, inner, dc_as_rows, oth, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+    else:           # out^T[k][rows]
+        _run_gemm(L, other, dC, tgt, cols, rows, inner, oth, dc_as_rows, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+    if any(bcast):
+        assert all(bcast[i] or nb[i] == 1 for i in (0, 1)), 'partial batch broadcast is not supported'
+        nbt = nb[0] * nb[1]
+        out = torch.empty_like(like)
+        assert like.is_contiguous() and like.numel() == tmp_rows * tmp_cols
+        ws = _empty(dC, L.colreduce_ws(nbt, tmp_rows * tmp_cols, 1))
+        L.colsum(tmp, out, ws, nbt, tmp_rows * tmp_cols)
+        return out
+    return tgt
+
+
+class _BGemm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, A, B, bias, spec, gmax, gelu, drop_p):
+        L = segx.lib()
+        s = spec
+        A, B = _c(A), _c(B)
+        C = _empty(A, *s.out_shape)
+        kw = dict(bias=bias, bias_mode=s.bias_mode if bias is not None else BIAS_NONE, bias_b1=s.bias_b1, gmax=gmax)
+        T = None
+        seed = off = 0
+        if gelu:
+            T = torch.empty_like(C)
+            if drop_p > 0:
+                seed, off = _Rng.reserve(C.numel())
+            kw.update(epilogue=EPI_GELU, aux=T, dropout_p=drop_p, seed=seed, offset=off)
+        _run_gemm(L, A, B, C, s.M, s.N, s.K, s.a, s.b, s.c, s.nb, s.alpha, **kw)
+        ctx.spec, ctx.gelu, ctx.drop = s, gelu, (drop_p, seed, off)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(A, B, T)
+        return C
+
+    @staticmethod
+    def backward(ctx, dC):
+        L = segx.lib()
+        A, B, T = ctx.saved_tensors
+        s = ctx.spec
+        dC = _c(dC)
+        if ctx.gelu:
+            p, seed, off = ctx.drop
+            dT = torch.empty_like(dC)
+            L.gelu_bwd(dC, T, dT, dC.numel(), p, seed, off)
+            dC = dT
+        dA = _grad_operand(L, dC, B, s, 'a', A) if ctx.needs_input_grad[0] else None
+        dB = _grad_operand(L, dC, A, s, 'b', B) if ctx.needs_input_grad[1] else None
+        dbias = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            dbias = _bias_grad(L, dC, s)
+        return dA, dB, dbias, None, None, None, None
+
+
+def _bias_grad(L, dC, s):
+    """Only the layouts the model uses: C contiguous [nb0, nb1, M, N] (or [M, N])."""
+    nb0, nb1 = s.nb
+    assert s.c[2] == s.N, 'bias grad needs contiguous C rows'
+    if s.bias_mode == BIAS_N:
+        if nb1 == 1 or s.bias_b1 == 0:
+            rows = dC.numel() // s.N
+            out = _empty(dC, s.N)
+            L.colsum(dC, out, _empty(dC, L.colreduce_ws(rows, s.N, 1)), rows, s.N)
+            return out
+        assert nb0 == 1 and s.bias_b1 == s.N, 'grouped bias grad layout'
+        out = _empty(dC, nb1 * s.N)                    # per-mode biases: C is [nb1, M, N]
+        for z in range(nb1):
+            L.colsum(dC[z] if dC.dim() == 3 else dC.view(nb1, s.M, s.N)[z], out[z * s.N:(z + 1) * s.N],
+                     _empty(dC, L.colreduce_ws(s.M, s.N, 1)), s.M, s.N)
+        return out
+    # BIAS_M (conv-style, one bias per output row m): row sums, batch-summed
+    assert s.bias_b1 == 0
+    nbt = nb0 * nb1
+    rs = _empty(dC, nbt * s.M)
+    ones = torch.ones(s.N, 1, dtype=torch.float32, device=dC.device)
+    # row sums as a skinny GEMM: [nbt*M, N] x [1, N]^T
+    L.gemm(dC, ones, rs, nbt * s.M, 1, s.N, (0, 0, s.N, 1), (0, 0, s.N, 1), (0, 0, 1))
+    if nbt == 1:
+        return rs
+    out = _empty(dC, s.M)
+    L.colsum(rs, out, _empty(dC, L.colreduce_ws(nbt, s.M, 1)), nbt, s.M)
+    return out
+
+
+def bgemm(A, B, spec, bias=None, gmax=None, gelu=False, drop_p=0.0):
+    return _BGemm.apply(A, B, bias, spec, gmax, gelu, float(drop_p))
+
+
+def linear(x, W, b=None, gelu=False, drop_p=0.0):
+    """y = x W^T + b over the last axis (nn.Linear).  x [..., K], W [N, K]."""
+    K = x.shape[-1]
+    N = W.shape[0]
+    R = x.numel() // K
+    spec = GemmSpec(R, N, K, (0, 0, K, 1), (0, 0, K, 1), (0, 0, N), tuple(x.shape[:-1]) + (N,), bias_mode=BIAS_N)
+    return bgemm(x, W, spec, bias=b, gelu=gelu, drop_p=drop_p)
+
+
+# -------------------------------------------------------------------------------------------------
+# Row kernels
+# -------------------------------------------------------------------------------------------------
+class _Softmax(torch.autograd.Function):
+    """softmax over the last axis, conditional clip (N5) and attention dropout."""
+
+    @staticmethod
+    def forward(ctx, S, clip, gmax, drop_p):
+        L = segx.lib()
+        S = _c(S)
+        Lk = S.shape[-1]
+        rows = S.numel() // Lk
+        P = torch.empty_like(S)
+        Pd = torch.empty_like(S) if drop_p > 0 else None
+        seed, off = _Rng.reserve(S.numel()) if drop_p > 0 else (0, 0)
+        L.softmax_fwd(S, P, Pd, rows, Lk, clip, gmax, drop_p, seed, off)
+        ctx.cfg = (rows, Lk, clip, drop_p, seed, off)
+        ctx.save_for_backward(P, S if gmax is not None else None, gmax)
+        return Pd if drop_p > 0 else P
+
+    @staticmethod
+    def backward(ctx, dP):
+        L = segx.lib()
+        P, S, gmax = ctx.saved_tensors
+        rows, Lk, clip, p, seed, off = ctx.cfg
+        dS = torch.empty_like(P)
+        L.softmax_bwd(P, _c(dP), S, dS, rows, Lk, clip, gmax, p, seed, off)
+        return dS, None, None, None
+
+
+def softmax(S, clip=500.0, gmax=None, drop_p=0.0):
+    return _Softmax.apply(S, float(clip), gmax, float(drop_p))
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, w, b, eps):
+        L = segx.lib()
+        X = _c(X)
+        C = X.shape[-1]
+        rows = X.numel() // C
+        Y = torch.empty_like(X)
+        mean, rstd = _empty(X, rows), _empty(X, rows)
+        L.layernorm_fwd(X, w, b, Y, mean, rstd, rows, C, eps)
+        ctx.save_for_backward(X, w, mean, rstd)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = segx.lib()
+        X, w, mean, rstd = ctx.saved_tensors
+        dY = _c(dY)
+        C = X.shape[-1]
+        rows = X.numel() // C
+        dX = torch.empty_like(X)
+        L.layernorm_bwd(dY, X, w, mean, rstd, dX, rows, C)
+        dw = db = None
+        if w is not None:
+            dw, db = _empty(X, C), _empty(X, C)
+            L.ln_param_grad(dY, X, mean, rstd, dw, db, _empty(X, L.colreduce_ws(rows, C, 2)), rows, C)
+        return dX, dw, db, None
+
+
+def layer_norm(X, w=None, b=None, eps=LN_EPS):
+    return _LayerNorm.apply(X, w, b, eps)
+
+
+class _PreNorm(torch.autograd.Function):
+    """mask * dropout(LN_noaffine(LN_affine(x) + pos_weight * pos[:, :C]))  (segtran_shared.py:916-946)."""
+
+    @staticmethod
+    def forward(ctx, X, w1, b1, pos, mask, pos_weight, drop_p):
+        L = segx.lib()
+        X, pos, mask = _c(X), _c(pos), _c(mask)
+        B, N, C = X.shape
+        Y = torch.empty_like(X)
+        stats = _empty(X, 4 * B * N)
+        seed, off = _Rng.reserve(X.numel()) if drop_p > 0 else (0, 0)
+        L.prenorm_fwd(X, w1, b1, pos, pos.shape[1], pos_weight, mask, Y, stats, B, N, C, LN_EPS, drop_p, seed, off)
+        ctx.cfg = (pos_weight, drop_p, seed, off)
+        ctx.save_for_backward(X, w1, b1, pos, mask, stats)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = segx.lib()
+        X, w1, b1, pos, mask, stats = ctx.saved_tensors
+        pw, p, seed, off = ctx.cfg
+        B, N, C = X.shape
+        dX, dU = torch.empty_like(X), torch.empty_like(X)
+        L.prenorm_bwd(_c(dY), X, w1, b1, pos, pos.shape[1], pw, mask, stats, dX, dU, B, N, C, p, seed, off)
+        rows = B * N
+        dw, db = _empty(X, C), _empty(X, C)
+        L.ln_param_grad(dU, X, stats[:rows], stats[rows:2 * rows], dw, db, _empty(X, L.colreduce_ws(rows, C, 2)), rows, C)
+        dpos = None
+        if ctx.needs_input_grad[3]:
+            dsum = _empty(X, N * C)
+            L.colsum(dU, dsum, _empty(X, L.colreduce_ws(B, N * C, 1)), B, N * C)
+            dpos = torch.zeros_like(pos)
+            dpos[:, :C] = dsum.view(N, C) * pw
+        return dX, dw, db, dpos, None, None, None
+
+
+def prenorm(X, w1, b1, pos, mask, pos_weight=1.0, drop_p=0.0):
+    return _PreNorm.apply(X, w1, b1, pos, mask, float(pos_weight), float(drop_p))
+
+
+class _PosEmbed(torch.autograd.Function):
+    """LearnedSinuPosEmbedder on batch-invariant normalised coordinates [N, pd] -> [N, C]."""
+
+    @staticmethod
+    def forward(ctx, posn, Wp, bp):
+        L = segx.lib()
+        posn, Wp = _c(posn), _c(Wp)
+        N, pd = posn.shape
+        C = Wp.shape[0]
+        out = _empty(posn, N, C)
+        stats = _empty(posn, 2 * N)
+        L.posembed_fwd(posn, Wp, bp, out, stats, N, C, pd, LN_EPS)
+        ctx.save_for_backward(posn, Wp, bp, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        L = segx.lib()
+        posn, Wp, bp, stats = ctx.saved_tensors
+        N, pd = posn.shape
+        C = Wp.shape[0]
+        dZ = _empty(posn, N, C)
+        L.posembed_bwd(_c(dOut), posn, Wp, bp, stats, dZ, N, C, pd)
+        dW = _empty(posn, C, pd)
+        # dWp[c][d] = sum_n dZ[n][c] posn[n][d]   (TN GEMM, inner = tokens)
+        _run_gemm(L, dZ, posn, dW, C, pd, N, (0, 0, 1, C), (0, 0, 1, pd), (0, 0, pd), (1, 1), 1.0)
+        db = _empty(posn, C)
+        L.colsum(dZ, db, _empty(posn, L.colreduce_ws(N, C, 1)), N, C)
+        return None, dW, db
+
+
+def pos_embed(posn, Wp, bp):
+    return _PosEmbed.apply(posn, Wp, bp)
+
+
+class _ModesAggr(torch.autograd.Function):
+    """Z [Mo, R, F] -> LN(dropout(Z)) -> learned soft aggregation over modes -> [R, F]."""
+
+    @staticmethod
+    def forward(ctx, Z, lnw, lnb, wa, ba, drop_p):
+        L = segx.lib()
+        Z = _c(Z)
+        Mo, R, Fd = Z.shape
+        Y = _empty(Z, R, Fd)
+        stats = _empty(Z, 3 * Mo * R)
+        seed, off = _Rng.reserve(Z.numel()) if drop_p > 0 else (0, 0)
+        wa_f = _c(wa.reshape(-1))
+        L.modes_aggr_fwd(Z, lnw, lnb, wa_f, ba, Y, stats, Mo, R, Fd, LN_EPS, drop_p, seed, off)
+        ctx.cfg = (drop_p, seed, off, tuple(wa.shape))
+        ctx.save_for_backward(Z, lnw, lnb, wa_f, stats)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = segx.lib()
+        Z, lnw, lnb, wa, stats = ctx.saved_tensors
+        p, seed, off, wa_shape = ctx.cfg
+        Mo, R, Fd = Z.shape
+        dY = _c(dY)
+        dZ = torch.empty_like(Z)
+        dscore = _empty(Z, Mo * R)
+        L.modes_aggr_bwd(dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
+        dlnw, dlnb, dwa = _empty(Z, Fd), _empty(Z, Fd), _empty(Z, Fd)
+        L.modes_aggr_param_grad(dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa,
+                                _empty(Z, L.colreduce_ws(R, Fd, 3)), Mo, R, Fd, p, seed, off)
+        dba = _empty(Z, 1)
+        L.sum(dscore, Mo * R, dba, _empty(Z, 1024))
+        return dZ, dlnw, dlnb, dwa.view(wa_shape), dba, None
+
+
+def modes_aggr(Z, lnw, lnb, wa, ba, drop_p=0.0):
+    return _ModesAggr.apply(Z, lnw, lnb, wa, ba, float(drop_p))
+
+
+# -------------------------------------------------------------------------------------------------
+# Pointwise (1x1 / 1x1x1) convolution on NC[D]HW tensors = one batched GEMM, no layout change:
+#   Y[b][co][s] = sum_ci W[co][ci] X[b][ci][s] + bias[co]      (s = flattened spatial index, contiguous)
+# -------------------------------------------------------------------------------------------------
+def conv1x1(x, weight, bias=None):
+    """x [B, Cin, *spatial]; weight [Cout, Cin, 1, 1(, 1)] (nn.Conv2d / nn.Conv3d layout)."""
+    B, Cin = x.shape[0], x.shape[1]
+    S = x.numel() // (B * Cin)
+    Cout = weight.shape[0]
+    spec = GemmSpec(Cout, S, Cin, (0, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S),
+                    (B, Cout) + tuple(x.shape[2:]), nb=(B, 1), bias_mode=BIAS_M)
+    return bgemm(weight.reshape(Cout, Cin), x, spec, bias=bias)
+
+
+# -------------------------------------------------------------------------------------------------
+# Segmentation loss (train2d.py:1233-1242,1314-1318 / train3d.py:738-756), fused fwd + bwd
+# -------------------------------------------------------------------------------------------------
+class _SegLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mask, pos_weight, class_w, dice_w):
+        L = segx.lib()
+        logits, mask = _c(logits), _c(mask)
+        B, C = logits.shape[:2]
+        S = logits.numel() // (B * C)
+        out = _empty(logits, 3 + C)
+        ws = _empty(logits, L.loss_ws(B, C))
+        L.seg_loss_fwd(logits, mask, pos_weight, class_w, out, ws, B, C, S, dice_w)
+        ctx.cfg = (B, C, S, dice_w)
+        ctx.save_for_backward(logits, mask, pos_weight, class_w, ws)
+        ctx.mark_non_differentiable(out)
+        return out[0], out
+
+    @staticmethod
+    def backward(ctx, g, _g2):
+        L = segx.lib()
+        logits, mask, pw, cw, ws = ctx.saved_tensors
+        B, C, S, dice_w = ctx.cfg
+        d = torch.empty_like(logits)
+        L.seg_loss_bwd(logits, mask, pw, cw, ws, _c(g.reshape(1)), d, B, C, S, dice_w)
+        return d, None, None, None, None
+
+
+def seg_loss(logits, mask_nhot, pos_weight, class_w, dice_w=0.5):
+    """Returns (loss, stats) with stats = [loss, ce, dice_total, dice_c0, ...] (device tensor, no host sync)."""
+    loss, stats = _SegLoss.apply(logits, mask_nhot.to(torch.float32), pos_weight, class_w, float(dice_w))
+    return loss, stats

@@ -1,0 +1,109 @@
+"""Inception-v1 I3D feature extractor -- host-side mirror of /root/reference/code/networks/aj_i3d/aj_i3d.py.
+
+Same module / parameter names (`Conv3d_1a_7x7.conv3d.weight`, `Mixed_4b.b1b.bn.running_mean`, ...), the
+dynamic TF-'same' zero padding of N7 (front = pad // 2; aj_i3d.py:8-30, 68-90) and `do_pool1=False`
+(`MaxPool3d_2a_3x3` = Identity, :206-210).
+
+Kernel status: the 38 1x1x1 convolutions run on libsegx's MFMA GEMM.  The 7x7x7 stem, the 19 3x3x3
+convolutions (implicit-GEMM MFMA kernels are the next round's K20 work), BatchNorm3d, ReLU and the max
+pools are still ATen/MIOpen calls.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import functional as SF
+
+
+def _same_pad(x, kernel, stride):
+    pads = []
+    for dim in (2, 1, 0):
+        s, k, size = stride[dim], kernel[dim], x.shape[2 + dim]
+        tot = max(k - s, 0) if size % s == 0 else max(k - (size % s), 0)
+        pads += [tot // 2, tot - tot // 2]
+    return F.pad(x, pads) if any(pads) else x
+
+
+class MaxPool3dSamePadding(nn.MaxPool3d):
+    def forward(self, x):
+        return super().forward(_same_pad(x, self.kernel_size, self.stride))     # zero fill: inputs are post-ReLU
+
+
+class Unit3D(nn.Module):
+    def __init__(self, in_channels, output_channels, kernel_shape=(1, 1, 1), stride=(1, 1, 1), activation_fn=F.relu,
+                 use_batch_norm=True, use_bias=False, name='unit_3d'):
+        super().__init__()
+        self._kernel_shape, self._stride = tuple(kernel_shape), tuple(stride)
+        self._activation_fn, self._use_batch_norm = activation_fn, use_batch_norm
+        self.name = name
+        self.conv3d = nn.Conv3d(in_channels, output_channels, self._kernel_shape, self._stride, padding=0, bias=use_bias)
+        if use_batch_norm:
+            self.bn = nn.BatchNorm3d(output_channels, eps=0.001, momentum=0.01)
+        self.pointwise = self._kernel_shape == (1, 1, 1) and self._stride == (1, 1, 1)
+
+    def forward(self, x):
+        if self.pointwise:
+            x = SF.conv1x1(x, self.conv3d.weight, self.conv3d.bias)            # libsegx MFMA GEMM
+        else:
+            x = F.conv3d(_same_pad(x, self._kernel_shape, self._stride), self.conv3d.weight, self.conv3d.bias, self._stride)
+        if self._use_batch_norm:
+            x = self.bn(x)
+        if self._activation_fn is not None:
+            x = self._activation_fn(x)
+        return x
+
+
+class InceptionModule(nn.Module):
+    def __init__(self, in_channels, out_channels, name):
+        super().__init__()
+        o = out_channels
+        self.b0 = Unit3D(in_channels, o[0], name=name + '/Branch_0/Conv3d_0a_1x1')
+        self.b1a = Unit3D(in_channels, o[1], name=name + '/Branch_1/Conv3d_0a_1x1')
+        self.b1b = Unit3D(o[1], o[2], (3, 3, 3), name=name + '/Branch_1/Conv3d_0b_3x3')
+        self.b2a = Unit3D(in_channels, o[3], name=name + '/Branch_2/Conv3d_0a_1x1')
+        self.b2b = Unit3D(o[3], o[4], (3, 3, 3), name=name + '/Branch_2/Conv3d_0b_3x3')
+        self.b3a = MaxPool3dSamePadding(kernel_size=(3, 3, 3), stride=(1, 1, 1), padding=0)
+        self.b3b = Unit3D(in_channels, o[5], name=name + '/Branch_3/Conv3d_0b_1x1')
+        self.name = name
+
+    def forward(self, x):
+        return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
+
+
+class InceptionI3d(nn.Module):
+    VALID_ENDPOINTS = ('Conv3d_1a_7x7', 'MaxPool3d_2a_3x3', 'Conv3d_2b_1x1', 'Conv3d_2c_3x3', 'MaxPool3d_3a_3x3',
+                       'Mixed_3b', 'Mixed_3c', 'MaxPool3d_4a_3x3', 'Mixed_4b', 'Mixed_4c', 'Mixed_4d', 'Mixed_4e',
+                       'Mixed_4f', 'MaxPool3d_5a_2x2', 'Mixed_5b', 'Mixed_5c', 'Logits', 'Predictions')
+
+    def __init__(self, num_classes=400, in_channels=3, do_pool1=True, name='inception_i3d'):
+        super().__init__()
+        ep = {}
+        ep['Conv3d_1a_7x7'] = Unit3D(in_channels, 64, (7, 7, 7), (2, 2, 2), name=name + 'Conv3d_1a_7x7')
+        ep['MaxPool3d_2a_3x3'] = MaxPool3dSamePadding((1, 3, 3), (1, 2, 2), padding=0) if do_pool1 else nn.Identity()
+        ep['Conv3d_2b_1x1'] = Unit3D(64, 64, name=name + 'Conv3d_2b_1x1')
+        ep['Conv3d_2c_3x3'] = Unit3D(64, 192, (3, 3, 3), name=name + 'Conv3d_2c_3x3')
+        ep['MaxPool3d_3a_3x3'] = MaxPool3dSamePadding((1, 3, 3), (1, 2, 2), padding=0)
+        ep['Mixed_3b'] = InceptionModule(192, [64, 96, 128, 16, 32, 32], name + 'Mixed_3b')
+        ep['Mixed_3c'] = InceptionModule(256, [128, 128, 192, 32, 96, 64], name + 'Mixed_3c')
+        ep['MaxPool3d_4a_3x3'] = MaxPool3dSamePadding((3, 3, 3), (2, 2, 2), padding=0)
+        ep['Mixed_4b'] = InceptionModule(480, [192, 96, 208, 16, 48, 64], name + 'Mixed_4b')
+        ep['Mixed_4c'] = InceptionModule(512, [160, 112, 224, 24, 64, 64], name + 'Mixed_4c')
+        ep['Mixed_4d'] = InceptionModule(512, [128, 128, 256, 24, 64, 64], name + 'Mixed_4d')
+        ep['Mixed_4e'] = InceptionModule(512, [112, 144, 288, 32, 64, 64], name + 'Mixed_4e')
+        ep['Mixed_4f'] = InceptionModule(528, [256, 160, 320, 32, 128, 128], name + 'Mixed_4f')
+        ep['MaxPool3d_5a_2x2'] = MaxPool3dSamePadding((2, 2, 2), (2, 2, 2), padding=0)
+        ep['Mixed_5b'] = InceptionModule(832, [256, 160, 320, 32, 128, 128], name + 'Mixed_5b')
+        ep['Mixed_5c'] = InceptionModule(832, [384, 192, 384, 48, 128, 128], name + 'Mixed_5c')
+        self.end_points = ep
+        for k, m in ep.items():
+            self.add_module(k, m)
+        # classification head: parameters kept for checkpoint compatibility (never used on the segtran path)
+        self.logits = Unit3D(1024, num_classes, activation_fn=None, use_batch_norm=False, use_bias=True, name='logits')
+
+    def extract_features(self, x):
+        feat = {}
+        for name in self.VALID_ENDPOINTS:
+            if name in self.end_points:
+                x = self._modules[name](x)
+                feat[name] = x
+        return feat

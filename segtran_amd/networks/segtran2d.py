@@ -1,0 +1,164 @@
+"""Segtran2d -- host-side mirror of /root/reference/code/networks/segtran2d.py (`--net segtran`, 2D).
+
+Same constructor (`Segtran2d(config)` with `CONFIG.update_config(args)`), same forward signature
+([B,3,H,W] -> [B,num_classes,H,W] logits), same attribute surface read by the trainer
+(`voxel_fusion.translayers[i]...`, `layers_attn_scores`, `orig_feat_shape`, `feature_maps`,
+`backbone._blocks`, `backbone.endpoint_blk_indices`, `num_vis_layers`) and the same state_dict keys.
+Built: eff-b* backbones, in_fpn '34' / out_fpn '1234' with scheme 'AN' and GroupNorm (the values the
+trainer forces / defaults to).  ResNet / EfficientNet-V2 backbones, BN FPNs, modalities and the global-bias
+ablation are outside the hot path and raise.
+
+Kernel status: fusion encoder and every 1x1 conv on libsegx; bilinear resampling, GroupNorm and the mask
+pooling are still ATen calls (HBM-bound K15-K18 kernels: next round).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from argparse import Namespace
+
+from .. import functional as SF
+from ..efficientnet.model import EfficientNet
+from .segtran_shared import (SegtranConfig, bb2feat_dims, SegtranFusionEncoder, CrossAttFeatTrans,  # noqa: F401
+                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices)
+
+
+class Segtran2dConfig(SegtranConfig):
+    def __init__(self):
+        super().__init__()
+        self.backbone_type = 'eff-b4'
+        self.use_pretrained = True
+        self.bb_feat_dims = bb2feat_dims[self.backbone_type]
+        self.num_translayers = 1
+        self.set_fpn_layers('default', Namespace(in_fpn_layers='34', out_fpn_layers='1234', in_fpn_scheme='AN',
+                                                 out_fpn_scheme='AN', translayer_compress_ratios=[1, 1]), do_print=False)
+        self.bb_feat_upsize = True
+        self.in_fpn_use_bn = False
+        self.out_fpn_use_bn = False
+        self.resnet_bn_to_gn = False
+        self.G = 8
+        self.pos_dim = 2
+        self.max_pos_size = (100, 100)
+        self.num_classes = 2
+        self.num_modalities = 0
+        self.use_global_bias = False
+        self.device = 'cuda'
+
+    def update_config(self, args):
+        self.try_assign(args, 'num_classes', 'backbone_type', 'use_pretrained', 'bb_feat_upsize', 'in_fpn_use_bn',
+                        'use_squeezed_transformer', 'num_attractors', 'num_translayers', 'num_modes',
+                        'trans_output_type', 'mid_type', 'pos_code_type', 'pos_code_weight', 'pos_bias_radius',
+                        'ablate_multihead', 'out_fpn_do_dropout', 'has_FFN_in_squeeze', 'attn_clip', 'qk_have_bias',
+                        'tie_qk_scheme', 'num_modalities', 'device', 'eval_robustness', 'use_global_bias',
+                        'use_attn_consist_loss', 'use_mince_transformer', 'mince_scales', 'mince_channel_props')
+        a = args if isinstance(args, dict) else args.__dict__
+        if 'dropout_prob' in a and a['dropout_prob'] >= 0:
+            self.hidden_dropout_prob = a['dropout_prob']
+            self.attention_probs_dropout_prob = a['dropout_prob']
+        self.bb_feat_dims = bb2feat_dims[self.backbone_type]
+        self.set_fpn_layers('args', args, do_print=False)
+
+
+CONFIG = Segtran2dConfig()
+
+
+class _Conv1x1(nn.Conv2d):
+    """nn.Conv2d(k=1) parameter container whose forward is libsegx's MFMA GEMM."""
+
+    def forward(self, x):
+        return SF.conv1x1(x, self.weight, self.bias)
+
+
+def _up(x, size):
+    return F.interpolate(x, size=tuple(size), mode='bilinear', align_corners=False)
+
+
+class Segtran2d(SegtranInitWeights):
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.device = config.device
+        self.trans_in_dim, self.trans_out_dim = config.trans_in_dim, config.trans_out_dim
+        self.num_translayers = config.num_translayers
+        self.bb_feat_upsize = config.bb_feat_upsize
+        self.G = config.G
+        if config.use_global_bias or config.num_modalities > 0 or config.in_fpn_use_bn or config.out_fpn_use_bn:
+            raise NotImplementedError('global-bias / multi-modality / BN-FPN variants are outside the hot path')
+        self.use_global_bias = False
+        self.voxel_fusion = SegtranFusionEncoder(config, 'Fusion')
+        self.backbone_type = config.backbone_type
+        if not self.backbone_type.startswith('eff-'):
+            raise NotImplementedError("backbone '%s': only EfficientNet-V1 (eff-b0..b7) is built" % self.backbone_type)
+        stem_stride = 1 if self.bb_feat_upsize else 2
+        self.backbone = EfficientNet.from_name(self.backbone_type.replace('eff', 'efficientnet'), stem_stride=stem_stride)
+        self.in_fpn_layers, self.in_fpn_scheme = config.in_fpn_layers, config.in_fpn_scheme
+        self.out_fpn_layers, self.out_fpn_scheme = config.out_fpn_layers, config.out_fpn_scheme
+        if self.in_fpn_layers != [3, 4] or self.out_fpn_layers != [1, 2, 3, 4] or self.in_fpn_scheme != 'AN' \
+                or self.out_fpn_scheme != 'AN' or config.out_fpn_do_dropout:
+            raise NotImplementedError("only --infpn 34 --outfpn 1234 with the 'AN' scheme (reference defaults) are built")
+        pool_stride = 2 ** int(np.min(self.in_fpn_layers)) * (1 if self.bb_feat_upsize else 2)
+        self.mask_pool = nn.AvgPool2d((pool_stride, pool_stride))
+        d = self.bb_feat_dims = config.bb_feat_dims
+        self.in_fpn23_conv = _Conv1x1(d[2], d[3], 1)            # unused with in_fpn '34' (N3), kept for the checkpoint
+        self.in_fpn34_conv = _Conv1x1(d[3], d[4], 1)
+        self.in_fpn_bridgeconv = _Conv1x1(d[4], self.trans_in_dim, 1) if d[4] != self.trans_in_dim else nn.Identity()
+        self.in_gn3b = nn.GroupNorm(self.G, d[3])
+        self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.num_classes = config.num_classes
+        self.num_modalities = 0
+        self.do_out_fpn = True
+        self.out_fpn12_conv = _Conv1x1(d[1], d[2], 1)
+        self.out_fpn23_conv = _Conv1x1(d[2], d[3], 1)
+        self.out_fpn34_conv = _Conv1x1(d[3], d[4], 1)            # unused (N3)
+        self.out_fpn_bridgeconv = _Conv1x1(d[3], self.trans_out_dim, 1) if d[3] != self.trans_out_dim else nn.Identity()
+        self.out_gn2b = nn.GroupNorm(self.G, d[2])
+        self.out_gn3b = nn.GroupNorm(self.G, d[3])
+        self.out_gn4b = nn.GroupNorm(self.G, d[4])               # unused (N3)
+        self.out_conv = _Conv1x1(self.trans_out_dim, self.num_classes, 1)
+        self.out_fpn_dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.apply(self.init_weights)
+        self.apply(self.tie_qk)
+        self.apply(self.add_identity_bias)
+        self.translayer_dims = config.translayer_dims
+        self.num_vis_layers = 1 + 2 * self.num_translayers
+        self.feature_maps, self.layers_attn_scores, self.orig_feat_shape = [], None, None
+        self.keep_feature_maps = False       # the reference always stores them (visualisation); opt-in here
+
+    def get_mask(self, batch):
+        with torch.no_grad():
+            return self.mask_pool(batch.abs()).sum(dim=1) > 0
+
+    def in_fpn_forward(self, feats, nonzero_mask, B):
+        f3, f4 = feats[3], feats[4]
+        cur = self.in_gn4b(self.in_fpn34_conv(f3) + _up(f4, f3.shape[2:]))
+        cur = self.in_fpn_bridgeconv(cur)
+        H2, W2 = cur.shape[2:]
+        vfeat = cur.permute(0, 2, 3, 1).reshape(B, H2 * W2, self.trans_in_dim)
+        return vfeat, nonzero_mask.reshape(B, -1), H2, W2
+
+    def out_fpn_forward(self, feats, vfeat_fused, B0):
+        cur = self.out_gn2b(self.out_fpn12_conv(feats[1]) + _up(feats[2], feats[1].shape[2:]))
+        cur = self.out_gn3b(self.out_fpn23_conv(cur) + _up(feats[3], cur.shape[2:]))
+        return self.out_fpn_bridgeconv(cur) + _up(vfeat_fused, cur.shape[2:])
+
+    def forward(self, batch):
+        self.feature_maps = []
+        B, C, H, W = batch.shape
+        if H % 8 or W % 8:
+            raise ValueError('Segtran2d needs H and W divisible by 8 (reference segtran2d.py:379), got %dx%d' % (H, W))
+        nonzero_mask = self.get_mask(batch)
+        ep = self.backbone.extract_endpoints(batch)
+        feats = tuple(ep['reduction_%d' % i] for i in range(1, 6))
+        vfeat, vmask, H2, W2 = self.in_fpn_forward(feats, nonzero_mask, B)
+        xy_shape = torch.Size((H2, W2))
+        scale = torch.tensor([[H // H2, W // W2]], device=batch.device, dtype=torch.float32)
+        voxels_pos = gen_all_indices(xy_shape, batch.device).view(-1, 2).float() * scale        # [N, 2], batch-invariant
+        fused = self.voxel_fusion(vfeat, voxels_pos, vmask, xy_shape)
+        self.layers_attn_scores = self.voxel_fusion.layers_attn_scores
+        self.orig_feat_shape = xy_shape
+        if self.keep_feature_maps:
+            self.feature_maps = [vfeat.transpose(1, 2).view(B, -1, H2, W2)] + \
+                [lv.view(B, H2, W2, -1).permute(0, 3, 1, 2) for lv in self.voxel_fusion.layers_vfeat]
+        fused = fused.view(B, H2, W2, self.trans_out_dim).permute(0, 3, 1, 2)
+        out = self.out_fpn_forward(feats, fused, B)
+        return _up(self.out_conv(out), (H, W))

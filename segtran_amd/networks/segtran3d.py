@@ -1,0 +1,177 @@
+"""Segtran3d -- host-side mirror of /root/reference/code/networks/segtran3d.py (`--net segtran`, 3D / BraTS).
+
+Same constructor / forward signature ([B,C,H,W,D] -> [B,num_classes,H,W,D]) / attribute surface /
+state_dict keys.  Built: I3D backbone, 'bridgeconv' 4->3 input bridge, in_fpn '34' / out_fpn '1234' ('AN',
+GroupNorm), D_pool_K depth pooling with 'interp' un-pooling -- i.e. the configuration train3d.py forces.
+The reference's hard-coded device='cuda' (segtran3d.py:464, N8) is replaced by the input's device.
+
+Kernel status: fusion encoder and every 1x1x1 conv (incl. the 832->1024 out-FPN bridge = 256 GFLOP/volume)
+on libsegx; trilinear resampling, GroupNorm and 3^3 / 7^3 convolutions are still ATen/MIOpen calls.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from argparse import Namespace
+
+from .. import functional as SF
+from .aj_i3d.aj_i3d import InceptionI3d
+from .segtran_shared import (SegtranConfig, bb2feat_dims, SegtranFusionEncoder, CrossAttFeatTrans,  # noqa: F401
+                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices)
+
+
+class Segtran3dConfig(SegtranConfig):
+    def __init__(self):
+        super().__init__()
+        self.backbone_type = 'i3d'
+        self.use_pretrained = True
+        self.bb_feat_dims = bb2feat_dims[self.backbone_type]
+        self.num_translayers = 1
+        self.set_fpn_layers('default', Namespace(in_fpn_layers='34', out_fpn_layers='1234', in_fpn_scheme='AN',
+                                                 out_fpn_scheme='AN', translayer_compress_ratios=[1, 1]), do_print=False)
+        self.bb_feat_upsize = True
+        self.in_fpn_use_bn = False
+        self.out_fpn_use_bn = False
+        self.resnet_bn_to_gn = False
+        self.G = 8
+        self.pos_dim = 3
+        self.max_pos_size = (20, 20, 20)
+        self.input_scale = (1., 1., 1.)
+        self.num_classes = 2
+        self.num_attractors = 1024
+        self.orig_in_channels = 1
+        self.inchan_to3_scheme = 'bridgeconv'
+        self.D_groupsize = 1
+        self.D_pool_K = 2
+        self.out_fpn_upsampleD_scheme = 'interp'
+        self.device = 'cuda'
+
+    def update_config(self, args):
+        self.try_assign(args, 'num_classes', 'backbone_type', 'use_pretrained', 'bb_feat_upsize', 'in_fpn_use_bn',
+                        'use_squeezed_transformer', 'num_attractors', 'num_translayers', 'num_modes',
+                        'trans_output_type', 'mid_type', 'pos_code_type', 'pos_code_weight', 'pos_bias_radius',
+                        'ablate_multihead', 'out_fpn_do_dropout', 'has_FFN_in_squeeze', 'attn_clip', 'qk_have_bias',
+                        'tie_qk_scheme', 'orig_in_channels', 'inchan_to3_scheme', 'D_groupsize', 'D_pool_K',
+                        'out_fpn_upsampleD_scheme', 'input_scale', 'device', 'eval_robustness', 'use_attn_consist_loss',
+                        'use_mince_transformer', 'mince_scales', 'mince_channel_props')
+        a = args if isinstance(args, dict) else args.__dict__
+        if 'dropout_prob' in a and a['dropout_prob'] >= 0:
+            self.hidden_dropout_prob = a['dropout_prob']
+            self.attention_probs_dropout_prob = a['dropout_prob']
+        self.bb_feat_dims = bb2feat_dims[self.backbone_type]
+        self.set_fpn_layers('args', args, do_print=False)
+
+
+CONFIG = Segtran3dConfig()
+
+
+class _Conv1x1x1(nn.Conv3d):
+    def forward(self, x):
+        return SF.conv1x1(x, self.weight, self.bias)
+
+
+def _up(x, size):
+    return F.interpolate(x, size=tuple(size), mode='trilinear', align_corners=False)
+
+
+class Segtran3d(SegtranInitWeights):
+    def __init__(self, config):
+        super().__init__(config)
+        self.config = config
+        self.device = config.device
+        self.orig_in_channels = config.orig_in_channels
+        self.trans_in_dim, self.trans_out_dim = config.trans_in_dim, config.trans_out_dim
+        self.num_translayers = config.num_translayers
+        self.bb_feat_upsize = config.bb_feat_upsize
+        self.G = config.G
+        self.voxel_fusion = SegtranFusionEncoder(config, 'Fusion')
+        self.backbone_type = config.backbone_type
+        if not self.backbone_type.startswith('i3d'):
+            raise NotImplementedError('Only support i3d as the 3D backbone')
+        self.backbone = InceptionI3d(do_pool1=not self.bb_feat_upsize)
+        self.inchan_to3_scheme, self.D_groupsize = config.inchan_to3_scheme, config.D_groupsize
+        self.eff_in_channels = self.orig_in_channels * self.D_groupsize
+        self.D_pool_K = config.D_pool_K
+        self.out_fpn_upsampleD_scheme = config.out_fpn_upsampleD_scheme
+        self.input_scale = config.input_scale
+        if self.D_groupsize != 1 or self.inchan_to3_scheme != 'bridgeconv' or self.out_fpn_upsampleD_scheme != 'interp' \
+                or config.in_fpn_use_bn or config.out_fpn_use_bn or config.out_fpn_do_dropout or not self.bb_feat_upsize:
+            raise NotImplementedError("only inchan_to3_scheme='bridgeconv', D_groupsize=1, 'interp' depth un-pooling "
+                                      "(what train3d.py:180-195 forces) are built")
+        self.in_bridge_to3 = _Conv1x1x1(self.eff_in_channels, 3, 1) if self.eff_in_channels != 3 else nn.Identity()
+        self.in_fpn_layers, self.in_fpn_scheme = config.in_fpn_layers, config.in_fpn_scheme
+        self.out_fpn_layers, self.out_fpn_scheme = config.out_fpn_layers, config.out_fpn_scheme
+        if self.in_fpn_layers != [3, 4] or self.out_fpn_layers != [1, 2, 3, 4] or self.in_fpn_scheme != 'AN' \
+                or self.out_fpn_scheme != 'AN':
+            raise NotImplementedError("only --infpn 34 --outfpn 1234 with the 'AN' scheme (reference defaults) are built")
+        self.mask_pool = nn.AvgPool3d((4, 8, 8))
+        d = self.bb_feat_dims = config.bb_feat_dims
+        self.in_fpn23_conv = _Conv1x1x1(d[2], d[3], 1)           # unused (N3)
+        self.in_fpn34_conv = _Conv1x1x1(d[3], d[4], 1)
+        self.in_fpn_bridgeconv = _Conv1x1x1(d[4], self.trans_in_dim, 1) if d[4] != self.trans_in_dim else nn.Identity()
+        self.in_gn3b = nn.GroupNorm(self.G, d[3])
+        self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.num_classes = config.num_classes
+        self.do_out_fpn = True
+        self.out_fpn_out_dim = self.out_feat_dim = self.trans_out_dim
+        self.out_fpn12_conv3d = _Conv1x1x1(d[1], d[2], 1)
+        self.out_fpn23_conv3d = _Conv1x1x1(d[2], d[3], 1)
+        self.out_fpn34_conv3d = _Conv1x1x1(d[3], d[4], 1)        # unused (N3)
+        self.out_fpn_bridgeconv3d = _Conv1x1x1(d[3], self.trans_out_dim, 1)
+        self.out_gn2b = nn.GroupNorm(self.G, d[2])
+        self.out_gn3b = nn.GroupNorm(self.G, d[3])
+        self.out_gn4b = nn.GroupNorm(self.G, d[4])               # unused (N3)
+        self.out_conv3d = _Conv1x1x1(self.out_feat_dim, self.num_classes, 1)
+        self.out_fpn_dropout = nn.Dropout(config.hidden_dropout_prob)
+        self.apply(self.init_weights)
+        self.apply(self.tie_qk)
+        self.apply(self.add_identity_bias)
+        self.translayer_dims = config.translayer_dims
+        self.num_vis_layers = 1 + 2 * self.num_translayers
+        self.layers_attn_scores, self.orig_feat_shape = None, None
+
+    def get_mask(self, batch):
+        with torch.no_grad():
+            return (self.mask_pool(batch.abs()).sum(dim=1) > 0).long()
+
+    def in_fpn_forward(self, feats, nonzero_mask):
+        f3, f4 = feats[3], feats[4]
+        cur = self.in_gn4b(self.in_fpn34_conv(f3) + _up(f4, f3.shape[2:]))
+        cur = self.in_fpn_bridgeconv(cur)
+        dp = [cur.shape[2] // self.D_pool_K, cur.shape[3], cur.shape[4]]
+        cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
+        m = (_up(nonzero_mask.float().unsqueeze(1), dp).squeeze(1) >= 0.5)
+        B, Fd, D2, H2, W2 = cur.shape
+        vfeat = cur.permute(0, 2, 3, 4, 1).reshape(B, -1, Fd)
+        return vfeat, m.reshape(B, -1), D2, H2, W2
+
+    def out_fpn_forward(self, feats, vfeat_fused):
+        cur = self.out_gn2b(self.out_fpn12_conv3d(feats[1]) + _up(feats[2], feats[1].shape[2:]))
+        cur = self.out_gn3b(self.out_fpn23_conv3d(cur) + _up(feats[3], cur.shape[2:]))
+        out = self.out_fpn_bridgeconv3d(cur) + _up(vfeat_fused, cur.shape[2:])
+        if self.D_pool_K > 1:
+            out = _up(out, [out.shape[2] * self.D_pool_K, out.shape[3], out.shape[4]])
+        return out
+
+    def forward(self, batch):
+        B, C, H, W, D = batch.shape
+        assert C == self.orig_in_channels
+        if H % 8 or W % 8 or D % 8:
+            raise ValueError('Segtran3d needs H, W, D divisible by 8 (reference segtran3d.py:450), got %s' % ((H, W, D),))
+        rgb = self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3)                    # [B,3,D,H,W]
+        nonzero_mask = self.get_mask(rgb)
+        fd = self.backbone.extract_features(rgb)
+        feats = (fd['MaxPool3d_2a_3x3'], fd['Conv3d_2c_3x3'], fd['Mixed_3c'], fd['Mixed_4f'], fd['Mixed_5c'])
+        vfeat, vmask, D2, H2, W2 = self.in_fpn_forward(feats, nonzero_mask)
+        xyz_shape = torch.Size((D2, H2, W2))
+        scale = torch.tensor([[(D // D2) / self.input_scale[2], (H // H2) / self.input_scale[0],
+                               (W // W2) / self.input_scale[1]]], device=batch.device, dtype=torch.float32)
+        voxels_pos = gen_all_indices(xyz_shape, batch.device).view(-1, 3).float() * scale
+        fused = self.voxel_fusion(vfeat, voxels_pos, vmask, xyz_shape)
+        self.layers_attn_scores = self.voxel_fusion.layers_attn_scores
+        self.orig_feat_shape = xyz_shape
+        fused = fused.view(B, D2, H2, W2, self.trans_out_dim).permute(0, 4, 1, 2, 3)
+        out = self.out_fpn_forward(feats, fused)                                  # [B, F, D, H, W]
+        # the class projection is pointwise, so it commutes exactly with the (H,W,D) permutation of :488-490;
+        # doing it first permutes 4 channels instead of 1024.
+        scores_small = self.out_conv3d(out).permute(0, 1, 3, 4, 2)
+        return _up(scores_small, (H, W, D))

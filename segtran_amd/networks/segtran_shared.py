@@ -1,0 +1,399 @@
+"""Squeeze-and-Expansion transformer on libsegx -- host-side mirror of the reference plugin surface.
+
+Mirrors, name for name, what callers of the reference touch in `code/networks/segtran_shared.py`
+(SegtranConfig :90-196, ExpandedFeatTrans :329-476, CrossAttFeatTrans :478-610, SqueezedAttFeatTrans
+:787-816, SegtranFusionEncoder :819-975, LearnedSinuPosEmbedder :979-998, SegtranPosEncoder :1177-1238,
+SegtranInitWeights :1241-1264) and keeps the same parameter names/shapes, so reference checkpoints load
+unchanged.  The arithmetic is NOT ATen: every forward/backward step is a hand-written HIP kernel of
+libsegx reached through segtran_amd.functional.
+
+Layout choices that differ from the reference on purpose (internal, invisible in state_dict / outputs):
+  * per-mode tensors are mode-major [M, B, U, F] and never bounced through [B, M*F, U] (:416-419, :449);
+  * the attractor query projection is computed once per step, not per sample (:812 expands to B);
+  * the positional code is computed once per forward as [N, C] (batch-invariant, :1231 + segtran2d.py:392)
+    and sliced per layer, instead of being regenerated as [B, N, C] for every layer;
+  * attention diagnostics (:569-587) stay on the device: no `.item()` host syncs in the hot loop.
+Quirks reproduced on purpose: N1 dropped residual, N2 tied q/k, N3 unused parameters, N4 eps=1e-12,
+N5 conditional clip.  Out of scope here: Mince transformer, 'bias' positional codes,
+ablation embedders.
+"""
+import copy
+import math
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import Parameter
+
+from .. import functional as SF
+from ..functional import GemmSpec
+
+bb2feat_dims = {'resnet34': [64, 64, 128, 256, 512], 'resnet50': [64, 256, 512, 1024, 2048],
+                'resnet101': [64, 256, 512, 1024, 2048], 'resibn101': [64, 256, 512, 1024, 2048],
+                'eff-b0': [16, 24, 40, 112, 1280], 'eff-b1': [16, 24, 40, 112, 1280],
+                'eff-b2': [16, 24, 48, 120, 1408], 'eff-b3': [24, 32, 48, 136, 1536],
+                'eff-b4': [24, 32, 56, 160, 1792], 'effv2m': [24, 48, 80, 176, 512],
+                'i3d': [64, 192, 480, 832, 1024]}
+
+
+def gen_all_indices(shape, device):
+    """Coordinates of every cell of a grid, [*shape, len(shape)] (reference :28-36)."""
+    grids = torch.meshgrid(*[torch.arange(s, device=device) for s in shape], indexing='ij')
+    return torch.stack(grids, dim=len(shape))
+
+
+class SegtranConfig:
+    """Application-independent settings; same field names and defaults as the reference (:90-196)."""
+
+    def __init__(self):
+        self.feat_dim = -1
+        self.in_feat_dim = -1
+        self.num_modes = 4
+        self.use_squeezed_transformer = True
+        self.num_attractors = 256
+        self.tie_qk_scheme = 'shared'
+        self.mid_type = 'shared'
+        self.trans_output_type = 'private'
+        self.act_fun = torch.nn.functional.gelu
+        self.has_FFN = True
+        self.has_FFN_in_squeeze = False
+        self.pos_code_type = 'lsinu'
+        self.pos_code_weight = 1.
+        self.pos_bias_radius = 7
+        self.qk_have_bias = True
+        self.v_has_bias = False
+        self.attn_clip = 500
+        self.base_initializer_range = 0.02
+        self.query_idbias_scale = 10
+        self.feattrans_lin1_idbias_scale = 10
+        self.pool_modes_feat = 'softmax'
+        self.use_mince_transformer = False
+        self.mince_scales = None
+        self.mince_channel_props = None
+        self.hidden_dropout_prob = 0.1
+        self.attention_probs_dropout_prob = 0.1
+        self.out_fpn_do_dropout = False
+        self.eval_robustness = False
+        self.ablate_multihead = False
+        self.use_attn_consist_loss = False
+
+    def try_assign(self, args, *keys):
+        ok = False
+        src = args if isinstance(args, dict) else args.__dict__
+        for key in keys:
+            if key in src:
+                self.__dict__[key] = src[key]
+                ok = True
+        return ok
+
+    def set_fpn_layers(self, config_name, fpn_settings, do_print=True):
+        self.in_fpn_layers = [int(c) for c in fpn_settings.in_fpn_layers]
+        self.out_fpn_layers = [int(c) for c in fpn_settings.out_fpn_layers]
+        if self.out_fpn_layers[-1] > self.in_fpn_layers[-1]:
+            raise ValueError("in_fpn_layers=%s is not compatible with out_fpn_layers=%s"
+                             % (self.in_fpn_layers, self.out_fpn_layers))
+        self.orig_in_feat_dim = self.bb_feat_dims[self.in_fpn_layers[-1]]
+        ratios = fpn_settings.translayer_compress_ratios
+        self.translayer_compress_ratios = ratios
+        assert len(ratios) == self.num_translayers + 1, \
+            "Length of {} != 1 + num_translayers {}".format(ratios, self.num_translayers)
+        abs_ratios = np.cumprod(ratios)                       # adjacent ratios -> absolute (:177-183)
+        self.translayer_dims = [int(self.orig_in_feat_dim / r) for r in abs_ratios]
+        self.trans_in_dim = self.translayer_dims[0]
+        self.min_feat_dim = np.min(self.translayer_dims)
+        self.trans_out_dim = self.translayer_dims[-1]
+        self.in_fpn_scheme = fpn_settings.in_fpn_scheme
+        self.out_fpn_scheme = fpn_settings.out_fpn_scheme
+        if do_print:
+            print("'%s' orig in-feat: %d, in-feat: %d, out-feat: %d, in-scheme: %s, out-scheme: %s, translayer_dims: %s"
+                  % (config_name, self.orig_in_feat_dim, self.trans_in_dim, self.trans_out_dim,
+                     self.in_fpn_scheme, self.out_fpn_scheme, self.translayer_dims))
+
+
+def _unsupported(config):
+    if config.use_mince_transformer or config.ablate_multihead or config.eval_robustness:
+        raise NotImplementedError('Mince / multi-head ablation / robustness variants are outside the '
+                                  'MI355X hot path (SURVEY.md 8(f))')
+    if config.mid_type != 'shared' or config.trans_output_type != 'private' or config.pool_modes_feat != 'softmax':
+        raise NotImplementedError("only mid_type='shared', trans_output_type='private', pool_modes_feat='softmax' "
+                                  "(the values train2d.py:245-249 forces) are built")
+
+
+# ---- parameter containers with the reference's names (forward passes live in the owners) -------------
+class MMSharedMid(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.num_modes, self.feat_dim = config.num_modes, config.feat_dim
+        self.shared_linear = nn.Linear(self.feat_dim, self.feat_dim)
+
+
+class MMPrivateOutput(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.num_modes, self.feat_dim = config.num_modes, config.feat_dim
+        fa = self.feat_dim * self.num_modes
+        self.group_linear = nn.Conv1d(fa, fa, 1, groups=self.num_modes)
+        self.resout_norm_layer = nn.LayerNorm(self.feat_dim, eps=1e-12, elementwise_affine=True)
+
+
+class LearnedSoftAggregate(nn.Module):
+    def __init__(self, num_feat, group_dim, keepdim=False):
+        super().__init__()
+        self.group_dim, self.keepdim = group_dim, keepdim
+        self.feat2score = nn.Linear(num_feat, 1)
+
+
+class ExpandedFeatTrans(nn.Module):
+    """Value projection + expansion FFN + mode aggregation (reference :329-476)."""
+
+    def __init__(self, config, name):
+        super().__init__()
+        _unsupported(config)
+        self.config, self.name = config, name
+        self.in_feat_dim, self.feat_dim, self.num_modes = config.in_feat_dim, config.feat_dim, config.num_modes
+        self.feat_dim_allmode = self.feat_dim * self.num_modes
+        self.has_FFN = config.has_FFN
+        self.hidden_dropout_prob = config.hidden_dropout_prob
+        self.first_linear = nn.Linear(self.in_feat_dim, self.feat_dim_allmode, bias=config.v_has_bias)
+        self.first_norm_layer = nn.LayerNorm(self.feat_dim, eps=1e-12, elementwise_affine=True)
+        self.base_initializer_range = config.base_initializer_range
+        self.feat_softaggr = LearnedSoftAggregate(self.feat_dim, group_dim=1, keepdim=False)
+        self.intermediate = MMSharedMid(config)
+        self.output = MMPrivateOutput(config)
+
+    def add_identity_bias(self):
+        if self.config.feattrans_lin1_idbias_scale > 0:
+            F_ = self.feat_dim
+            eye = torch.diag(torch.ones(F_)) * self.base_initializer_range * self.config.feattrans_lin1_idbias_scale
+            w = self.first_linear.weight.data
+            w[:F_, :F_] = w[:F_, :F_] * 0.5 + eye.to(w.device)
+
+    def forward(self, input_feat, attention_probs):
+        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] -> [B, U1, F]."""
+        B, U2, IF = input_feat.shape
+        M, Fd = self.num_modes, self.feat_dim
+        U1 = attention_probs.shape[2]
+        drop = self.hidden_dropout_prob if self.training else 0.0
+        v = SF.linear(input_feat, self.first_linear.weight, self.first_linear.bias)       # [B, U2, M*F]
+        # fused[m,b] = probs[m,b] @ v[b, :, m*F:(m+1)*F]   (no [B,M*F,U] transposes)
+        fused = SF.bgemm(attention_probs, v,
+                         GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
+                                  (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M)))
+        agg = self.feat_softaggr.feat2score
+        if not self.has_FFN:
+            # LearnedSoftAggregate over M modes, then first_norm_layer (:452-457).  Built for the squeeze path
+            # where M == 1: the aggregate is the identity, its parameters get exact-zero gradients (N3).
+            assert M == 1, 'no-FFN branch is only built for num_modes == 1 (in-squeeze)'
+            y = SF.modes_aggr(fused.view(1, B * U1, Fd), self.first_norm_layer.weight, self.first_norm_layer.bias,
+                              agg.weight, agg.bias, 0.0)
+            return y.view(B, U1, Fd)
+        mid, out = self.intermediate.shared_linear, self.output
+        h = SF.linear(fused, mid.weight, mid.bias, gelu=True, drop_p=drop)               # MMSharedMid :232-251
+        R = B * U1
+        z = SF.bgemm(h, out.group_linear.weight,                                          # MMPrivateOutput :267
+                     GemmSpec(R, Fd, Fd, (0, R * Fd, Fd, 1), (0, Fd * Fd, Fd, 1), (0, R * Fd, Fd), (M, R, Fd),
+                              nb=(1, M), bias_mode=SF.BIAS_N, bias_b1=Fd),
+                     bias=out.group_linear.bias)
+        # N1: the reference adds the shortcut (:269) but normalises the un-added tensor (:272) -> no residual.
+        y = SF.modes_aggr(z, out.resout_norm_layer.weight, out.resout_norm_layer.bias, agg.weight, agg.bias, drop)
+        return y.view(B, U1, Fd)
+
+
+class CrossAttFeatTrans(nn.Module):
+    """Multi-mode cross attention (reference :478-610)."""
+
+    def __init__(self, config, name):
+        super().__init__()
+        _unsupported(config)
+        self.config, self.name = config, name
+        self.num_modes, self.in_feat_dim, self.feat_dim = config.num_modes, config.in_feat_dim, config.feat_dim
+        self.attention_mode_dim = self.in_feat_dim // self.num_modes
+        self.att_size_allmode = self.num_modes * self.attention_mode_dim
+        self.query = nn.Linear(self.in_feat_dim, self.att_size_allmode, bias=config.qk_have_bias)
+        self.key = nn.Linear(self.in_feat_dim, self.att_size_allmode, bias=config.qk_have_bias)
+        self.base_initializer_range = config.base_initializer_range
+        self.out_trans = ExpandedFeatTrans(config, name)
+        self.attention_probs_dropout_prob = config.attention_probs_dropout_prob
+        self.keep_attn_scores = config.use_attn_consist_loss
+        self.tie_qk_scheme = config.tie_qk_scheme
+        self.attn_clip = float(config.attn_clip)
+        self.attention_scores = None
+        self.attn_max_dev = None          # device-side running max of the (positive) scores of the last call
+
+    def tie_qk(self, tie_qk_scheme=None):
+        if tie_qk_scheme is not None:
+            self.tie_qk_scheme = tie_qk_scheme
+        if self.tie_qk_scheme == 'shared':                    # N2: one Parameter object under two names
+            self.key.weight = self.query.weight
+            if self.key.bias is not None:
+                self.key.bias = self.query.bias
+        elif self.tie_qk_scheme == 'loose':
+            self.key.weight.data.copy_(self.query.weight)
+            if self.key.bias is not None:
+                self.key.bias.data.copy_(self.query.bias)
+
+    def add_identity_bias(self):
+        d = self.attention_mode_dim
+        eye = torch.diag(torch.ones(d)) * self.base_initializer_range * self.config.query_idbias_scale
+        eye = eye.repeat([1, self.in_feat_dim // d])
+        w = self.key.weight.data
+        w[:d] = w[:d] * 0.5 + eye.to(w.device)
+
+    def forward(self, in_query, in_key=None, pos_biases=None):
+        """in_query [B or 1, U1, C] (a leading 1 = shared by the whole batch, e.g. the attractors);
+        in_key [B, U2, C].  Returns [B, U1, F]."""
+        if pos_biases is not None:
+            raise NotImplementedError("'bias' positional codes need --nosqueeze (SURVEY.md 8(f) rank 3)")
+        if in_key is None:
+            in_key = in_query
+        B, U2, C = in_key.shape
+        U1, M, d = in_query.shape[1], self.num_modes, self.attention_mode_dim
+        shared_q = in_query.shape[0] == 1 and B > 1
+        q = SF.linear(in_query, self.query.weight, self.query.bias)                      # :559
+        k = SF.linear(in_key, self.key.weight, self.key.bias)                            # :560
+        gmax = torch.zeros(1, dtype=torch.float32, device=in_key.device)
+        # scores[m,b] = q[b,:,m*d:(m+1)*d] k[b,:,m*d:(m+1)*d]^T / sqrt(d), max tracked in the epilogue (:566-570)
+        scores = SF.bgemm(q, k, GemmSpec(U1, U2, d, (0 if shared_q else U1 * C, d, C, 1), (U2 * C, d, C, 1),
+                                         (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),
+                                         alpha=1.0 / math.sqrt(d)), gmax=gmax)
+        self.attn_max_dev = gmax
+        self.attention_scores = scores if self.keep_attn_scores else None
+        drop = self.attention_probs_dropout_prob if self.training else 0.0
+        probs = SF.softmax(scores, self.attn_clip, gmax, drop)                           # :578-605
+        return self.out_trans(in_key, probs)
+
+
+class SqueezedAttFeatTrans(nn.Module):
+    """Squeezed attention: N tokens -> A attractors -> N tokens (reference :787-816)."""
+
+    def __init__(self, config, name):
+        super().__init__()
+        self.config, self.name = config, name
+        self.in_feat_dim, self.num_attractors = config.in_feat_dim, config.num_attractors
+        config1 = copy.copy(config)                           # in-squeeze: no compression, one mode, no FFN
+        config1.feat_dim = config1.in_feat_dim
+        config1.num_modes = 1
+        config1.has_FFN = config.has_FFN_in_squeeze
+        if config1.has_FFN:
+            raise NotImplementedError('has_FFN_in_squeeze=True is not built (reference default False)')
+        self.in_ator_trans = CrossAttFeatTrans(config1, name + '-in-squeeze')
+        self.ator_out_trans = CrossAttFeatTrans(config, name + '-squeeze-out')
+        self.attractors = Parameter(torch.randn(1, self.num_attractors, self.in_feat_dim))
+        self.attention_scores = None
+
+    def forward(self, in_feat, pos_biases=None):
+        new_attractors = self.in_ator_trans(self.attractors, in_feat, pos_biases)        # query shared by the batch
+        out_feat = self.ator_out_trans(in_feat, new_attractors, pos_biases)
+        self.attention_scores = self.ator_out_trans.attention_scores
+        return out_feat
+
+
+class LearnedSinuPosEmbedder(nn.Module):
+    def __init__(self, pos_dim, pos_embed_dim, omega=1, affine=False):
+        super().__init__()
+        assert omega == 1 and not affine
+        self.pos_dim, self.pos_embed_dim = pos_dim, pos_embed_dim
+        self.pos_fc = nn.Linear(pos_dim, pos_embed_dim, bias=True)
+
+    def forward(self, pos_normed):
+        """pos_normed [N, pos_dim] (batch-invariant) -> [N, C]; [B, N, pos_dim] input is accepted when all
+        samples share the coordinates (what Segtran2d/3d produce) and yields [B, N, C] by expansion."""
+        if pos_normed.dim() == 3:
+            code = SF.pos_embed(pos_normed[0], self.pos_fc.weight, self.pos_fc.bias)
+            return code.unsqueeze(0).expand(pos_normed.shape[0], -1, -1)
+        return SF.pos_embed(pos_normed, self.pos_fc.weight, self.pos_fc.bias)
+
+
+class SegtranPosEncoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.feat_dim = config.trans_in_dim
+        self.pos_embed_dim = self.feat_dim
+        self.pos_code_type = config.pos_code_type
+        if self.pos_code_type != 'lsinu':
+            raise NotImplementedError("pos_code_type='%s': only 'lsinu' (default) is built" % self.pos_code_type)
+        self.pos_coder = LearnedSinuPosEmbedder(config.pos_dim, self.pos_embed_dim, omega=1, affine=False)
+        self.cached_pos_code = None
+        self.cached_feat_shape = None
+
+    def forward(self, orig_feat_shape, voxels_pos):
+        """voxels_pos [N, pos_dim] or [B, N, pos_dim] (identical rows per sample).  Eval mode caches (:1208-1226)."""
+        vp = voxels_pos[0] if voxels_pos.dim() == 3 else voxels_pos
+        if (not self.training) and self.cached_pos_code is not None and self.cached_feat_shape == tuple(vp.shape) \
+                and self.cached_pos_code.device == vp.device:
+            return self.cached_pos_code
+        code = self.pos_coder(vp / vp.max())                                              # :1231
+        if not self.training:
+            self.cached_pos_code, self.cached_feat_shape = code.detach(), tuple(vp.shape)
+        return code
+
+
+class SegtranFusionEncoder(nn.Module):
+    """Stack of squeezed-attention layers with per-layer pre-norm + positional code (reference :819-975)."""
+
+    def __init__(self, config, name):
+        super().__init__()
+        self.name = name
+        self.num_translayers = config.num_translayers
+        self.pos_code_type = config.pos_code_type
+        self.translayer_compress_ratios = config.translayer_compress_ratios
+        self.translayer_dims = config.translayer_dims
+        self.hidden_dropout_prob = config.hidden_dropout_prob
+        self.use_squeezed_transformer = config.use_squeezed_transformer
+        if not self.use_squeezed_transformer:
+            raise NotImplementedError('--nosqueeze (full N x N attention) is a "next" row (SURVEY.md 8(f) rank 3)')
+        if config.use_mince_transformer or self.pos_code_type == 'bias':
+            raise ValueError('Squeezed transformer cannot be used with Mince / positional biases (reference :836-844)')
+        self.pos_code_weight = config.pos_code_weight
+        self.pos_code_layer = SegtranPosEncoder(config)
+        layers = []
+        for i in range(self.num_translayers):
+            c2 = copy.copy(config)
+            c2.in_feat_dim, c2.feat_dim = self.translayer_dims[i], self.translayer_dims[i + 1]
+            layers.append(SqueezedAttFeatTrans(c2, '%s%d' % (name, i)))
+        self.translayers = nn.ModuleList(layers)
+        dims = self.translayer_dims[:-1]
+        self.comb_norm_layers = nn.ModuleList([nn.LayerNorm(d, eps=1e-12, elementwise_affine=False) for d in dims])
+        self.vfeat_norm_layers = nn.ModuleList([nn.LayerNorm(d, eps=1e-12, elementwise_affine=True) for d in dims])
+        self.use_attn_consist_loss = config.use_attn_consist_loss
+        if self.use_attn_consist_loss:
+            raise NotImplementedError('attention-consistency loss is outside the hot path')
+        self.layers_vfeat, self.layers_attn_scores, self.orig_feat_shape = [], None, None
+
+    def forward(self, vfeat, voxels_pos, vmask, orig_feat_shape):
+        """vfeat [B,N,C0]; voxels_pos [N,pd] or [B,N,pd]; vmask [B,N,1] or [B,N] (bool/float)."""
+        self.layers_vfeat = []
+        B, N, _ = vfeat.shape
+        mask = vmask.reshape(B, N).to(torch.float32)
+        pos_code = self.pos_code_layer(orig_feat_shape, voxels_pos)                       # [N, C0], once per forward
+        for i, translayer in enumerate(self.translayers):
+            nl = self.vfeat_norm_layers[i]
+            drop = self.hidden_dropout_prob if (self.training and i == 0) else 0.0       # :944-945
+            feat = SF.prenorm(vfeat, nl.weight, nl.bias, pos_code, mask, self.pos_code_weight, drop)
+            vfeat = translayer(feat)
+            self.layers_vfeat.append(vfeat)
+        self.layers_attn_scores = None
+        self.orig_feat_shape = orig_feat_shape
+        return vfeat
+
+
+class SegtranInitWeights(nn.Module):
+    """Initialisation mix-in (reference :1241-1264)."""
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        self.config = config
+
+    def init_weights(self, module):
+        if isinstance(module, (nn.Linear, nn.Embedding)):
+            if not (np.array(module.weight.shape) < self.config.min_feat_dim).all():
+                module.weight.data.normal_(mean=0.0, std=self.config.base_initializer_range)
+        if isinstance(module, nn.Linear) and module.bias is not None:
+            module.bias.data.zero_()
+
+    def tie_qk(self, module):
+        if isinstance(module, CrossAttFeatTrans) and module.tie_qk_scheme != 'none':
+            module.tie_qk()
+
+    def add_identity_bias(self, module):
+        if isinstance(module, (CrossAttFeatTrans, ExpandedFeatTrans)):
+            module.add_identity_bias()

@@ -1,0 +1,130 @@
+"""BertAdam on libsegx -- mirror of /root/reference/code/optimization.py (BertAdam :40-164, warmup_linear :25-31).
+
+Same constructor arguments and param-group format as the reference class, same update rule (per-tensor
+gradient clip `max_grad_norm`=0.05, Adam moments WITHOUT bias correction, decoupled weight decay,
+warmup-linear LR, parameters without a gradient skipped entirely -- N3).  MI355X-native differences:
+  * ONE multi-tensor step (3 kernel launches for all ~530 tensors) instead of ~10 ATen launches per tensor;
+  * the trainer's preceding `nn.utils.clip_grad_norm_(net.parameters(), grad_clip)` (train2d.py:1324-1325) is
+    folded into the same pass: pass `global_grad_clip=` to `step()` / the constructor;
+  * gradients live in ONE flat fp32 buffer (each `p.grad` is a view), which is also what the data-parallel
+    reducer all-reduces in buckets over RCCL/xGMI (segtran_amd/dist.py).
+"""
+import torch
+from torch.optim import Optimizer
+
+from . import segx
+
+CHUNK = 65536
+
+
+def warmup_linear(x, warmup=0.002):
+    if x < warmup:
+        return x / warmup
+    return max((x - 1.) / (warmup - 1.), 0)
+
+
+def warmup_constant(x, warmup=0.002):
+    return x / warmup if x < warmup else 1.0
+
+
+SCHEDULES = {'warmup_linear': warmup_linear, 'warmup_constant': warmup_constant}
+
+
+class BertAdam(Optimizer):
+    def __init__(self, params, lr, warmup=-1, t_total=-1, schedule='warmup_linear', b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.05, max_grad_norm=0.05, global_grad_clip=0.0):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        defaults = dict(lr=lr, schedule=schedule, warmup=warmup, t_total=t_total, b1=b1, b2=b2, e=e,
+                        weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        super().__init__(params, defaults)
+        self.global_grad_clip = global_grad_clip
+        self.step_count = 0
+        self._tabs = None
+        self._touched = set()
+        self._hooks = []
+        self._build_flat_grads()
+
+    # ---- flat gradient buffer ---------------------------------------------------------------------------
+    def _all_params(self):
+        seen, out = set(), []
+        for g in self.param_groups:
+            for p in g['params']:
+                if id(p) not in seen:
+                    seen.add(id(p)); out.append((p, g))
+        return out
+
+    def _build_flat_grads(self):
+        ps = self._all_params()
+        dev = ps[0][0].device
+        total = sum((p.numel() + 3) // 4 * 4 for p, _ in ps)             # 16-B aligned slices
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slices = []
+        off = 0
+        for p, _ in ps:
+            n = p.numel()
+            p.grad = self.flat_grad[off:off + n].view_as(p)
+            self.slices.append((off, n))
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, s=self: s._touched.add(id(q))))
+            off += (n + 3) // 4 * 4
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients are views of one flat buffer: zero it (one memset) instead of dropping the tensors."""
+        self.flat_grad.zero_()
+
+    def _build_tables(self):
+        ps = self._all_params()
+        dev = self.flat_grad.device
+        i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)      # noqa: E731
+        i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)      # noqa: E731
+        f32 = lambda xs: torch.tensor(xs, dtype=torch.float32, device=dev)    # noqa: E731
+        gp, mp, vp = self.flat_grad.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr()
+        chunk_tensor, chunk_off, chunk_first = [], [], [0]
+        for t, ((p, g), (off, n)) in enumerate(zip(ps, self.slices)):
+            assert p.is_contiguous() and p.dtype == torch.float32
+            assert p.grad is not None and p.grad.data_ptr() == gp + 4 * off, 'p.grad was re-bound; use optimizer.zero_grad()'
+            for c in range(0, n, CHUNK):
+                chunk_tensor.append(t); chunk_off.append(c)
+            chunk_first.append(len(chunk_tensor))
+        self._tabs = dict(
+            params=i64([p.data_ptr() for p, _ in ps]), grads=i64([gp + 4 * o for o, _ in self.slices]),
+            m=i64([mp + 4 * o for o, _ in self.slices]), v=i64([vp + 4 * o for o, _ in self.slices]),
+            sizes=i64([n for _, n in self.slices]), chunk_tensor=i32(chunk_tensor), chunk_off=i64(chunk_off),
+            chunk_first=i32(chunk_first), active=i32([1 if id(p) in self._touched else 0 for p, _ in ps]),
+            lr=f32([g['lr'] for _, g in ps]), wd=f32([g['weight_decay'] for _, g in ps]))
+        self._nt, self._nch = len(ps), len(chunk_tensor)
+        self._ws = torch.zeros(self._nch + 2 * self._nt + 2, dtype=torch.float32, device=dev)
+        self._active_names = None
+
+    def get_lr(self):
+        g = self.param_groups[0]
+        if self.step_count == 0:
+            return [0]
+        sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
+        return [gr['lr'] * sched for gr in self.param_groups]
+
+    def grad_norm(self):
+        """Global gradient norm of the last step (device tensor; reading it synchronises)."""
+        return self._ws[self._nch + 2 * self._nt]
+
+    @torch.no_grad()
+    def step(self, closure=None, global_grad_clip=None):
+        loss = closure() if closure is not None else None
+        if self._tabs is None:
+            self._build_tables()
+            for h in self._hooks:
+                h.remove()                          # the touched set is static after the first backward (N3)
+            self._hooks = []
+        g = self.param_groups[0]
+        sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
+        clip = self.global_grad_clip if global_grad_clip is None else global_grad_clip
+        segx.lib().mt_bertadam_step(self._tabs, self._nt, self._nch, CHUNK, float(clip), float(g['max_grad_norm']),
+                                    float(sched), g['b1'], g['b2'], g['e'], self._ws)
+        self.step_count += 1
+        return loss

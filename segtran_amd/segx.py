@@ -156,6 +156,24 @@ class SegxLib:
     def gelu_bwd(self, dH, T, dT, n, p, seed, offset):
         self._call('segx_gelu_bwd', T, dH, T, dT, n, p, seed, offset)
 
+    # ---- train-step glue (train.hip) --------------------------------------------------------------
+    def loss_ws(self, B, C):
+        return int(self.c.segx_loss_ws_floats(B, C))
+
+    def seg_loss_fwd(self, logits, mask, pw, cw, out, ws, B, C, S, dice_w):
+        self._call('segx_seg_loss_fwd', logits, logits, mask, pw, cw, out, ws, B, C, S, dice_w)
+
+    def seg_loss_bwd(self, logits, mask, pw, cw, ws, gout, dlogits, B, C, S, dice_w):
+        self._call('segx_seg_loss_bwd', logits, logits, mask, pw, cw, ws, gout, dlogits, B, C, S, dice_w)
+
+    def mt_bertadam_step(self, tabs, ntensors, nchunks, chunk, max_global, max_tensor, sched, b1, b2, eps, ws):
+        """tabs: dict of device tensors params/grads/m/v (int64 pointer tables), sizes, chunk_tensor, chunk_off,
+        chunk_first, active, lr, wd."""
+        t = tabs
+        self._call('segx_mt_bertadam_step', ws, t['params'], t['grads'], t['m'], t['v'], t['sizes'], t['chunk_tensor'],
+                   t['chunk_off'], t['chunk_first'], t['active'], t['lr'], t['wd'], ntensors, nchunks, chunk,
+                   max_global, max_tensor, sched, b1, b2, eps, ws)
+
 
 # C signatures (include/segx.h): p pointer, i int32, l int64, f float, u uint64; trailing p = stream
 _SIGS = {
@@ -168,6 +186,8 @@ _SIGS = {
     'segx_posembed_fwd': 'pppppliifp', 'segx_posembed_bwd': 'ppppppliip',
     'segx_modes_aggr_fwd': 'pppppppiliffuup', 'segx_modes_aggr_bwd': 'ppppppppilifuup',
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
+    'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
+    'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
 }
 
 _LIB = None
@@ -179,3 +199,10 @@ def lib():
     if _LIB is None:
         _LIB = SegxLib(LIB_PATH)
     return _LIB
+
+
+def use_library(libobj):
+    """TEST HOOK: install another build of the same C ABI (the fiber-emulated one from tests/hipemu) so the
+    autograd layer can be exercised on CPU tensors.  Never called by product code; pass None to reset."""
+    global _LIB
+    _LIB = libobj

@@ -1,0 +1,56 @@
+"""CPU: the C ABI contract -- header, ctypes signatures and exported symbols agree."""
+import os, re, subprocess
+import pytest
+from segtran_amd import segx
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, 'include', 'segx.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r'\b(?:int|int64_t)\s+(segx_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S):
+        name, params = m.group(1), [p.strip() for p in m.group(2).split(',')]
+        sig = ''
+        for prm in params:
+            if prm == 'void':
+                continue
+            if '*' in prm: sig += 'p'
+            elif prm.startswith('int64_t'): sig += 'l'
+            elif prm.startswith('uint64_t'): sig += 'u'
+            elif prm.startswith('float'): sig += 'f'
+            elif prm.startswith('int'): sig += 'i'
+            else: sig += '?'
+        out[name] = sig
+    return out
+
+
+def test_ctypes_signatures_match_header():
+    decl = _declared()
+    for name, sig in segx._SIGS.items():
+        assert name in decl, name + ' missing from include/segx.h'
+        assert decl[name] == sig, '%s: header %s vs binding %s' % (name, decl[name], sig)
+    extra = set(decl) - set(segx._SIGS) - {'segx_version', 'segx_last_error', 'segx_gemm_f32'}
+    assert not extra, 'declared but unbound: %s' % sorted(extra)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    """The in-tree HIP build must load and export the whole ABI (no compute call: there is no GPU here)."""
+    from segtran_amd.build import build
+    lib = build()
+    syms = subprocess.check_output(['nm', '-D', '--defined-only', lib]).decode()
+    exported = set(re.findall(r' T (segx_\w+)', syms))
+    assert set(_declared()) <= exported, sorted(set(_declared()) - exported)
+    L = segx.SegxLib(lib)
+    assert L.c.segx_version() >= 100 and not L.emulated
+
+
+def test_product_refuses_cpu_tensors_and_missing_library(tmp_path):
+    import torch
+    from segtran_amd.build import build
+    L = segx.SegxLib(build())
+    with pytest.raises(RuntimeError, match='CPU tensor'):
+        L.layernorm_fwd(torch.zeros(4, 8), None, None, torch.zeros(4, 8), torch.zeros(4), torch.zeros(4), 4, 8, 1e-12)
+    with pytest.raises(RuntimeError, match='not built'):
+        segx.SegxLib(str(tmp_path / 'nope.so'))
