@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""bench.py -- train-step throughput of the MI355X-native Segtran hot path (BASELINE.json metric).
+
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under torch.distributed.run
+(one rank per GPU over RCCL).  Workload at every N: BASELINE.json configs[1] -- REFUGE fundus 2D, eff-b4,
+--translayers 3 --layercompress 1,1,2,2, 512x512, batch 6 PER GPU (weak scaling), fp32, train mode with the
+reference's dropout 0.2, synthetic inputs / name-hashed synthetic weights (no network).  A step is the full
+train step: forward -> BCE+Dice -> backward -> gradient all-reduce -> global clip + BertAdam.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def cpu_baseline(cfg_name, threads):
+    """oracle/ (CPU restatement of the reference, kind='port') timed on the host cores: ONE full train step
+    (fwd + loss + bwd + global clip + BertAdam) at batch 1 of the same shapes/weights.  Bounded: ~10-30 s."""
+    from oracle import segtran_oracle as O
+    from segtran_amd import engine
+    from segtran_amd.synth import synth_state_dict
+    c = engine.CONFIGS[cfg_name]
+    torch.set_num_threads(threads)
+    net = engine.build_model(cfg_name, 'cpu', synth=False)          # only for the key/shape list (no kernels run)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    del net
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and 'running' not in k else v) for k, v in sd.items()}
+    x, raw = engine.synth_batch(cfg_name, 1, 'cpu')
+    mask = engine.map_mask(c['task'], raw)
+    pw, _ = engine.loss_weights(c['task'], 'cpu')
+    dims = [1792 if c['dim'] == 2 else 1024]
+    for r in c['compress'][1:]:
+        dims.append(dims[-1] // r)
+    t0 = time.time()
+    if c['dim'] == 2:
+        y = O.segtran2d_forward(sd, x, dims, training=True)
+    else:
+        y = O.segtran3d_forward(sd, x, dims, training=True)
+    loss = O.seg_loss(y, mask, pw)[0]
+    loss.backward()
+    keys = [k for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and '.key.' not in k]
+    grads = [sd[k].grad for k in keys]
+    with torch.no_grad():
+        O.global_clip_([g for g in grads if g is not None], 0.1)
+        O.bertadam_step([sd[k] for k in keys], grads, [dict() for _ in keys], 2e-4,
+                        [1e-5 if 'backbone' in k else 1e-4 for k in keys], 0.05, 10000)
+    dt = time.time() - t0
+    return {'value': round(1.0 / dt, 4), 'unit': 'images/s' if c['dim'] == 2 else 'volumes/s', 'cores': threads, 'kind': 'port',
+            'sample': '1 full train step (fwd+loss+bwd+clip+BertAdam) of oracle/segtran_oracle.py at batch 1, same %s '
+                      'shapes and weights, dropout-free, %.1f s' % (cfg_name, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='cfg2', help='BASELINE config (cfg2 = metric default; cfg4 = BraTS 3D)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    from segtran_amd import engine, segx, dist as sdist, functional as SF
+    rank, local, world = sdist.init_distributed()
+    assert world == max(1, args.gpus) or world == 1, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    c = engine.CONFIGS[args.config]
+    B = c['bs']
+
+    torch.manual_seed(1234)
+    SF.manual_seed(1234 + rank)
+    net = engine.build_model(args.config, dev)
+    net = sdist.convert_sync_batchnorm(net)
+    net.train()
+    opt = engine.init_optimizer(net, c['task'])
+    reducer = sdist.GradReducer(opt) if world > 1 else None
+    step = engine.TrainStep(net, opt, c['task'], reducer)
+    x, raw = engine.synth_batch(args.config, B, dev, seed=1337 + rank)          # disjoint samples per rank
+
+    L = segx.lib()
+    for _ in range(args.warmup):
+        step(x, raw)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    L.gemm_prof = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(x, raw)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, L.gemm_prof = L.gemm_prof, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    lossv = float(loss)
+    assert lossv == lossv, 'loss is NaN'
+
+    # roofline of the dominant kernel (segx::gemm_f32_kernel, all layout variants): algorithmic FLOPs / HIP-event time
+    flops = sum(p[2] for p in prof)
+    ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+    achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roof = {'bound': 'mfma', 'kernel': 'segx::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+            'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
+            'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}
+    unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
+    res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), args.config), 'value': round(world * B * args.steps / dt, 3),
+           'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': {'cfg2': 'REFUGE fundus 2D, segtran eff-b4, translayers 3, layercompress 1,1,2,2, 512x512, bs 6/GPU',
+                                   'cfg4': 'BraTS 3D, segtran i3d, translayers 1, attractors 1024, 112x112x96 x4 modalities, bs 4/GPU'}
+                                  .get(args.config, args.config),
+                      'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'dropout': 0.2,
+                      'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5)},
+           'roofline': roof}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            res['cpu_baseline'] = cpu_baseline(args.config, os.cpu_count() or 1)
+        except Exception as e:                                                    # the baseline must never kill the bench line
+            res['cpu_baseline'] = {'value': None, 'error': repr(e)[:200]}
+    print(json.dumps(res))
+
+
+if __name__ == '__main__':
+    main()

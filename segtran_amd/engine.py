@@ -1,0 +1,120 @@
+"""Train-step engine shared by train2d.py / train3d.py / bench.py / smoke(): model construction from the
+reference's flag set, synthetic batches, and ONE full train step
+(forward -> BCE+Dice -> backward -> [gradient all-reduce] -> global clip + BertAdam)."""
+from argparse import Namespace
+import torch
+import torch.nn.functional as F
+
+from . import functional as SF
+from .optimization import BertAdam
+from .synth import load_synth, synth_image2d, synth_fundus_mask, synth_brats
+from .dataloaders.datasets2d import fundus_map_mask, polyp_map_mask
+from .dataloaders.datasets3d import brats_map_label
+
+# the BASELINE.json configs (flags as in SURVEY.md 8(d)); 'bs' = per-GPU batch of the benchmark
+CONFIGS = {
+    'cfg1': dict(dim=2, task='fundus', num_classes=3, translayers=1, compress=[1, 1], attractors=256, bs=2, size=(256, 256)),
+    'cfg2': dict(dim=2, task='fundus', num_classes=3, translayers=3, compress=[1, 1, 2, 2], attractors=256, bs=6, size=(512, 512)),
+    'cfg3': dict(dim=2, task='polyp', num_classes=2, translayers=3, compress=[1, 1, 2, 2], attractors=256, bs=6, size=(352, 352)),
+    'cfg4': dict(dim=3, task='brats', num_classes=4, translayers=1, compress=[1, 1], attractors=1024, bs=4, size=(112, 112, 96)),
+    'cfg5': dict(dim=3, task='brats', num_classes=4, translayers=2, compress=[1, 1, 1], attractors=1024, bs=4, size=(128, 128, 128)),
+}
+BCE_WEIGHT = {'fundus': [0., 1., 2.], 'polyp': [0., 1.], 'brats': [0., 3., 1., 1.75]}   # train2d.py:293,344; train3d.py:223
+DEFAULTS = dict(lr=2e-4, decay=1e-4, grad_clip=0.1, dropout_prob=0.2, num_modes=4)        # train2d.py:266-385 (segtran)
+
+
+def model_args(c, device, dropout_prob=None, attractors=None):
+    a = dict(num_classes=c['num_classes'], num_attractors=attractors or c['attractors'], num_translayers=c['translayers'],
+             translayer_compress_ratios=list(c['compress']), use_pretrained=False, bb_feat_upsize=True, in_fpn_use_bn=False,
+             use_squeezed_transformer=True, num_modes=4, trans_output_type='private', mid_type='shared',
+             pos_code_type='lsinu', pos_code_weight=1.0, pos_bias_radius=7, ablate_multihead=False, out_fpn_do_dropout=False,
+             has_FFN_in_squeeze=False, attn_clip=500, qk_have_bias=True, tie_qk_scheme='shared', device=str(device),
+             eval_robustness=False, use_attn_consist_loss=False, use_mince_transformer=False, mince_scales=None,
+             mince_channel_props=None, dropout_prob=DEFAULTS['dropout_prob'] if dropout_prob is None else dropout_prob,
+             in_fpn_layers='34', out_fpn_layers='1234', in_fpn_scheme='AN', out_fpn_scheme='AN')
+    if c['dim'] == 2:
+        a.update(backbone_type='eff-b4', num_modalities=0, use_global_bias=False)
+    else:
+        a.update(backbone_type='i3d', orig_in_channels=4, inchan_to3_scheme='bridgeconv', D_groupsize=1, D_pool_K=2,
+                 out_fpn_upsampleD_scheme='interp', input_scale=(1, 1, 1))
+    return Namespace(**a)
+
+
+def build_model(cfg, device, dropout_prob=None, attractors=None, synth=True):
+    c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    args = model_args(c, device, dropout_prob, attractors)
+    if c['dim'] == 2:
+        from .networks.segtran2d import Segtran2d, CONFIG
+    else:
+        from .networks.segtran3d import Segtran3d as Segtran2d, CONFIG
+    CONFIG.update_config(args)
+    net = Segtran2d(CONFIG)
+    if synth:
+        load_synth(net)
+    return net.to(device)
+
+
+def init_optimizer(net, c_or_task, t_total=10000, warmup_steps=500, lr=None, decay=None, grad_clip=None):
+    """4 param groups as train2d.py:513-545: names containing 'backbone' get decay x 0.1."""
+    lr = DEFAULTS['lr'] if lr is None else lr
+    decay = DEFAULTS['decay'] if decay is None else decay
+    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    low = [p for n, p in named if 'backbone' in n]
+    normal = [p for n, p in named if 'backbone' not in n]
+    groups = [dict(params=normal, weight_decay=decay, lr=lr), dict(params=low, weight_decay=decay * 0.1, lr=lr)]
+    warmup_steps = min(warmup_steps, t_total // 2)
+    return BertAdam(groups, lr=lr, warmup=warmup_steps / t_total, t_total=t_total, weight_decay=decay,
+                    global_grad_clip=DEFAULTS['grad_clip'] if grad_clip is None else grad_clip)
+
+
+def loss_weights(task, device):
+    w = torch.tensor(BCE_WEIGHT[task], dtype=torch.float32)
+    nc = len(BCE_WEIGHT[task])
+    pos_weight = (w * (nc - 1) / w.sum()).to(device)                           # train2d.py:813-814
+    cw = torch.ones(nc); cw[0] = 0; cw = (cw / cw.sum()).to(device)           # train2d.py:1123-1127
+    return pos_weight, cw
+
+
+def synth_batch(cfg, B, device, seed=1337):
+    """(input, raw mask/label) in the encodings the reference's loaders deliver, resident on `device`."""
+    c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
+    if c['dim'] == 2:
+        S = c['size'][0]
+        x = synth_image2d(B, S, seed)
+        m = synth_fundus_mask(B, S, seed + 1)
+        if c['task'] == 'polyp':
+            m = m[:, :1].repeat(1, 3, 1, 1)
+        return x.to(device), m.to(device)
+    x, lab = synth_brats(B, *c['size'], seed=seed)
+    return x.to(device), lab.to(device)
+
+
+def map_mask(task, raw):
+    if task == 'fundus':
+        return fundus_map_mask(raw)
+    if task == 'polyp':
+        return polyp_map_mask(raw)
+    return brats_map_label(raw, False)
+
+
+class TrainStep:
+    """One data-parallel train step (train2d.py:1147-1337 / train3d.py:708-768 for --net segtran)."""
+
+    def __init__(self, net, optimizer, task, reducer=None):
+        self.net, self.opt, self.task, self.reducer = net, optimizer, task, reducer
+        dev = next(net.parameters()).device
+        self.pos_weight, self.class_w = loss_weights(task, dev)
+        self.stats = None
+
+    def __call__(self, x, raw_mask):
+        mask = map_mask(self.task, raw_mask)
+        out = self.net(x)
+        if out.shape[2:] != mask.shape[2:]:
+            out = F.interpolate(out, size=mask.shape[2:], mode='bilinear' if out.dim() == 4 else 'trilinear', align_corners=False)
+        loss, self.stats = SF.seg_loss(out, mask, self.pos_weight, self.class_w, 0.5)
+        self.opt.zero_grad()
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.allreduce_grads()
+        self.opt.step()
+        return loss

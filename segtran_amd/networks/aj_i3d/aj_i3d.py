@@ -95,10 +95,11 @@ class InceptionI3d(nn.Module):
         ep['Mixed_5b'] = InceptionModule(832, [256, 160, 320, 32, 128, 128], name + 'Mixed_5b')
         ep['Mixed_5c'] = InceptionModule(832, [384, 192, 384, 48, 128, 128], name + 'Mixed_5c')
         self.end_points = ep
+        # classification head: parameters kept for checkpoint compatibility (never used on the segtran path);
+        # registered before the endpoints, as in the reference (aj_i3d.py:279-286), so parameter order matches.
+        self.logits = Unit3D(1024, num_classes, activation_fn=None, use_batch_norm=False, use_bias=True, name='logits')
         for k, m in ep.items():
             self.add_module(k, m)
-        # classification head: parameters kept for checkpoint compatibility (never used on the segtran path)
-        self.logits = Unit3D(1024, num_classes, activation_fn=None, use_batch_norm=False, use_bias=True, name='logits')
 
     def extract_features(self, x):
         feat = {}

@@ -48,6 +48,7 @@ class SegxLib:
         self.c.segx_last_error.argtypes = [ctypes.c_char_p, c_i]
         self.c.segx_version.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
+        self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
@@ -92,7 +93,15 @@ class SegxLib:
         d.bias, d.aux, d.gmax = _ptr(bias), _ptr(aux), _ptr(gmax)
         d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
         d.splitk, d.workspace = splitk, _ptr(workspace)
-        rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
+        if self.gemm_prof is not None and C.is_cuda:
+            # HIP events on the launch stream (torch's current stream IS the stream handed to the kernel)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
+            e1.record()
+            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1]))
+        else:
+            rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
         self.check(rc, 'segx_gemm_f32')
 
 

@@ -1,6 +1,8 @@
 import os, sys
 import pytest
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -9,3 +11,32 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: full-size CPU checks')
+
+
+class _Backend:
+    def __init__(self, name):
+        import torch
+        self.name = name
+        if name == 'emu':
+            from emu import emu_lib
+            self.L, self.dev = emu_lib(), torch.device('cpu')
+        else:
+            from segtran_amd import segx
+            self.L, self.dev = segx.lib(), torch.device('cuda', 0)
+
+
+@pytest.fixture(params=['emu', pytest.param('hip', marks=pytest.mark.gpu)])
+def backend(request):
+    """Kernel-level tests run twice: on the fiber emulator (CPU, here) and on the real HIP build (-m gpu)."""
+    import torch
+    from segtran_amd import segx
+    b = _Backend(request.param)
+    if request.param == 'emu':
+        segx.use_library(b.L)
+    else:
+        segx.use_library(None)
+    prev = torch.get_default_device()
+    torch.set_default_device(b.dev)
+    yield b
+    torch.set_default_device(prev)
+    segx.use_library(None)

@@ -1,7 +1,6 @@
 """CPU: segtran_amd/csrc/gemm.hip executed lane-by-lane on the fiber emulator vs torch fp64."""
 import pytest
 import torch
-from emu import emu_lib
 from segtran_amd import segx
 
 
@@ -9,13 +8,13 @@ def _ref(A, B):
     return A.double() @ B.double().transpose(-1, -2)
 
 
-@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (64, 96, 40), (130, 70, 33), (200, 136, 64)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 32), (64, 96, 40), (130, 70, 33), (200, 136, 64), (1, 1, 1), (3, 5, 2)])
 @pytest.mark.parametrize('akc,bkc', [(True, True), (True, False), (False, True), (False, False)])
-def test_gemm_layouts(M, N, K, akc, bkc):
-    L = emu_lib()
-    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
-    A = torch.randn(M, K, generator=g)
-    B = torch.randn(N, K, generator=g)             # asymmetric random operands: catches transposes
+def test_gemm_layouts(backend, M, N, K, akc, bkc):
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(M * 7 + N * 3 + K)
+    A = torch.randn(M, K, generator=g, device='cpu').to(backend.dev)
+    B = torch.randn(N, K, generator=g, device='cpu').to(backend.dev)             # asymmetric random operands: catches transposes
     Am = A if akc else A.t().contiguous()          # storage [M,K] or [K,M]
     Bm = B if bkc else B.t().contiguous()
     a_str = (0, 0, K, 1) if akc else (0, 0, 1, M)
@@ -26,13 +25,13 @@ def test_gemm_layouts(M, N, K, akc, bkc):
     assert (C.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
-def test_gemm_batched_modes_bias_alpha_gmax():
+def test_gemm_batched_modes_bias_alpha_gmax(backend):
     """squeeze-out QK^T view: Q [B,N,4*d], K [B,A,4*d] -> S [4,B,N,A] (mode-major), scaled, max tracked."""
-    L = emu_lib()
-    g = torch.Generator().manual_seed(5)
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(5)
     Bn, N, A, Mo, d = 2, 70, 24, 4, 12
-    Q = torch.randn(Bn, N, Mo * d, generator=g)
-    Kt = torch.randn(Bn, A, Mo * d, generator=g)
+    Q = torch.randn(Bn, N, Mo * d, generator=g, device='cpu').to(backend.dev)
+    Kt = torch.randn(Bn, A, Mo * d, generator=g, device='cpu').to(backend.dev)
     S = torch.zeros(Mo, Bn, N, A)
     gmax = torch.zeros(1)
     L.gemm(Q, Kt, S, N, A, d, (N * Mo * d, d, Mo * d, 1), (A * Mo * d, d, Mo * d, 1), (N * A, Bn * N * A, A),
@@ -42,14 +41,14 @@ def test_gemm_batched_modes_bias_alpha_gmax():
     assert abs(gmax.item() - max(ref.max().item(), 0.0)) < 1e-4
 
 
-def test_gemm_gelu_epilogue_grouped_bias():
+def test_gemm_gelu_epilogue_grouped_bias(backend):
     """grouped (per-mode) linear with per-mode bias + GELU epilogue writing the pre-activation."""
-    L = emu_lib()
-    g = torch.Generator().manual_seed(6)
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(6)
     Mo, R, F = 4, 50, 36
-    H = torch.randn(Mo, R, F, generator=g)
-    W = torch.randn(Mo, F, F, generator=g) * 0.3
-    b = torch.randn(Mo, F, generator=g)
+    H = torch.randn(Mo, R, F, generator=g, device='cpu').to(backend.dev)
+    W = torch.randn(Mo, F, F, generator=g, device='cpu').to(backend.dev) * 0.3
+    b = torch.randn(Mo, F, generator=g, device='cpu').to(backend.dev)
     Y = torch.zeros(Mo, R, F); T = torch.zeros(Mo, R, F)
     L.gemm(H, W, Y, R, F, F, (0, R * F, F, 1), (0, F * F, F, 1), (0, R * F, F), nb=(1, Mo), bias=b,
            bias_mode=segx.BIAS_N, bias_b1=F, epilogue=segx.EPI_GELU, aux=T)
@@ -58,11 +57,11 @@ def test_gemm_gelu_epilogue_grouped_bias():
     assert (Y.double() - torch.nn.functional.gelu(Tref)).abs().max().item() < 1e-4
 
 
-def test_gemm_gelu_dropout_is_mask_times_scale():
-    L = emu_lib()
-    g = torch.Generator().manual_seed(7)
+def test_gemm_gelu_dropout_is_mask_times_scale(backend):
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(7)
     R, F = 64, 32
-    H = torch.randn(R, F, generator=g); W = torch.randn(F, F, generator=g) * 0.3
+    H = torch.randn(R, F, generator=g, device='cpu').to(backend.dev); W = torch.randn(F, F, generator=g, device='cpu').to(backend.dev) * 0.3
     Y = torch.zeros(R, F); T = torch.zeros(R, F); Y2 = torch.zeros(R, F)
     kw = dict(epilogue=segx.EPI_GELU, aux=T, dropout_p=0.25, seed=123, offset=9)
     L.gemm(H, W, Y, R, F, F, (0, 0, F, 1), (0, 0, F, 1), (0, 0, F), **kw)
@@ -75,12 +74,12 @@ def test_gemm_gelu_dropout_is_mask_times_scale():
     assert 0.17 < frac < 0.33
 
 
-def test_gemm_splitk_and_bias_m():
+def test_gemm_splitk_and_bias_m(backend):
     """weight-gradient shape: dW = dY^T X with K = rows (TN), split-K 3, + conv-style per-row bias."""
-    L = emu_lib()
-    g = torch.Generator().manual_seed(8)
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(8)
     R, Fo, Fi = 210, 40, 24
-    dY = torch.randn(R, Fo, generator=g); X = torch.randn(R, Fi, generator=g); bias = torch.randn(Fo, generator=g)
+    dY = torch.randn(R, Fo, generator=g, device='cpu').to(backend.dev); X = torch.randn(R, Fi, generator=g, device='cpu').to(backend.dev); bias = torch.randn(Fo, generator=g, device='cpu').to(backend.dev)
     dW = torch.zeros(Fo, Fi); ws = torch.zeros(3 * Fo * Fi)
     L.gemm(dY, X, dW, Fo, Fi, R, (0, 0, 1, Fo), (0, 0, 1, Fi), (0, 0, Fi), alpha=0.5, bias=bias,
            bias_mode=segx.BIAS_M, splitk=3, workspace=ws)
@@ -88,8 +87,34 @@ def test_gemm_splitk_and_bias_m():
     assert (dW.double() - ref).abs().max().item() < 1e-4
 
 
-def test_gemm_rejects_bad_strides():
-    L = emu_lib()
+def test_gemm_rejects_bad_strides(backend):
+    L = backend.L
     A = torch.zeros(8, 8); C = torch.zeros(8, 8)
     with pytest.raises(RuntimeError, match='unit stride'):
         L.gemm(A, A, C, 8, 8, 4, (0, 0, 8, 2), (0, 0, 8, 1), (0, 0, 8))
+
+
+@pytest.mark.parametrize('shape', [(2, 12, 5, 7), (1, 8, 3, 4, 5), (3, 20, 6, 6)])
+@pytest.mark.parametrize('bias', [True, False])
+def test_conv1x1_autograd_vs_torch(backend, shape, bias):
+    """Pointwise conv on NC[D]HW through the batched GEMM (weights broadcast over the batch, per-row bias)."""
+    from segtran_amd import functional as SF
+    import torch.nn.functional as F
+    g = torch.Generator(device='cpu').manual_seed(sum(shape))
+    Cin, Cout = shape[1], 10
+    x = torch.randn(*shape, generator=g, device='cpu').to(backend.dev).requires_grad_(True)
+    wshape = (Cout, Cin) + (1,) * (len(shape) - 2)
+    w = torch.randn(*wshape, generator=g, device='cpu').to(backend.dev).requires_grad_(True)
+    b = torch.randn(Cout, generator=g, device='cpu').to(backend.dev).requires_grad_(True) if bias else None
+    G = torch.randn(shape[0], Cout, *shape[2:], generator=g, device='cpu').to(backend.dev)
+    y = SF.conv1x1(x, w, b)
+    y.backward(G)
+    got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone() if bias else None)
+    x.grad = None; w.grad = None
+    if bias:
+        b.grad = None
+    yr = (F.conv2d if len(shape) == 4 else F.conv3d)(x, w, b)
+    yr.backward(G)
+    for a, r in zip(got, (yr.detach(), x.grad, w.grad, b.grad if bias else None)):
+        if r is not None:
+            assert (a - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item())

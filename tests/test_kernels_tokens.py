@@ -2,14 +2,13 @@
 import pytest
 import torch
 import torch.nn.functional as F
-from emu import emu_lib
 
 EPS = 1e-12
 
 
 def rnd(*shape, seed=0, scale=1.0):
-    g = torch.Generator().manual_seed(seed + sum(shape))
-    return torch.randn(*shape, generator=g) * scale
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, device='cpu') * scale).to(torch.get_default_device())
 
 
 def close(a, b, tol=2e-5):
@@ -20,8 +19,8 @@ def close(a, b, tol=2e-5):
 
 @pytest.mark.parametrize('rows,L', [(7, 64), (5, 260), (9, 1024), (2, 4096)])
 @pytest.mark.parametrize('clamped', [False, True])
-def test_softmax_fwd_bwd(rows, L, clamped):
-    Lb = emu_lib()
+def test_softmax_fwd_bwd(backend, rows, L, clamped):
+    Lb = backend.L
     S = rnd(rows, L, seed=1, scale=3.0)
     clip = 4.0
     gmax = torch.tensor([S.max().item() if clamped else 1.0])
@@ -39,8 +38,8 @@ def test_softmax_fwd_bwd(rows, L, clamped):
     close(dS, Sr.grad, 2e-5)
 
 
-def test_softmax_dropout_consistent_fwd_bwd():
-    Lb = emu_lib()
+def test_softmax_dropout_consistent_fwd_bwd(backend):
+    Lb = backend.L
     rows, L, p = 6, 256, 0.25
     S = rnd(rows, L, seed=3)
     P = torch.empty_like(S); Pd = torch.empty_like(S)
@@ -59,8 +58,8 @@ def test_softmax_dropout_consistent_fwd_bwd():
 
 @pytest.mark.parametrize('rows,C', [(10, 64), (5, 448), (3, 1792), (4, 1024)])
 @pytest.mark.parametrize('affine', [True, False])
-def test_layernorm_fwd_bwd_param_grads(rows, C, affine):
-    Lb = emu_lib()
+def test_layernorm_fwd_bwd_param_grads(backend, rows, C, affine):
+    Lb = backend.L
     X = rnd(rows, C, seed=5) * 2 + 0.5
     w = (1 + 0.1 * rnd(C, seed=6)) if affine else None
     b = (0.1 * rnd(C, seed=7)) if affine else None
@@ -82,8 +81,8 @@ def test_layernorm_fwd_bwd_param_grads(rows, C, affine):
         close(dw, wr.grad, 2e-5); close(db, br.grad, 2e-5)
 
 
-def test_colsum_and_sum():
-    Lb = emu_lib()
+def test_colsum_and_sum(backend):
+    Lb = backend.L
     X = rnd(1000, 70, seed=9)
     out = torch.empty(70); ws = torch.empty(Lb.colreduce_ws(1000, 70, 1))
     Lb.colsum(X, out, ws, 1000, 70)
@@ -102,12 +101,12 @@ def _prenorm_ref(X, w1, b1, pos, pw, mask, C, keep=None):
 
 
 @pytest.mark.parametrize('B,N,C,Cpos', [(2, 12, 64, 64), (2, 9, 448, 896), (1, 5, 1792, 1792)])
-def test_prenorm_fwd_bwd(B, N, C, Cpos):
-    Lb = emu_lib()
+def test_prenorm_fwd_bwd(backend, B, N, C, Cpos):
+    Lb = backend.L
     X = rnd(B, N, C, seed=10) + 0.3
     w1 = 1 + 0.1 * rnd(C, seed=11); b1 = 0.1 * rnd(C, seed=12)
     pos = rnd(N, Cpos, seed=13); pw = 0.7
-    mask = (torch.rand(B, N, generator=torch.Generator().manual_seed(14)) > 0.3).float()
+    mask = (torch.rand(B, N, generator=torch.Generator(device='cpu').manual_seed(14), device='cpu').to(backend.dev) > 0.3).float()
     Y = torch.empty_like(X); stats = torch.empty(4 * B * N)
     Lb.prenorm_fwd(X, w1, b1, pos, Cpos, pw, mask, Y, stats, B, N, C, EPS, 0.0, 0, 0)
     Xr, w1r, b1r, posr = (t.clone().requires_grad_(True) for t in (X, w1, b1, pos))
@@ -127,8 +126,8 @@ def test_prenorm_fwd_bwd(B, N, C, Cpos):
     close(pw * dpos.view(N, C), posr.grad[:, :C], 5e-5)
 
 
-def test_prenorm_dropout_mask_matches_between_fwd_and_bwd():
-    Lb = emu_lib()
+def test_prenorm_dropout_mask_matches_between_fwd_and_bwd(backend):
+    Lb = backend.L
     B, N, C, p = 2, 6, 64, 0.2
     X = rnd(B, N, C, seed=16); w1 = 1 + 0.1 * rnd(C, seed=17); b1 = 0.1 * rnd(C, seed=18)
     pos = rnd(N, C, seed=19); mask = torch.ones(B, N)
@@ -146,9 +145,9 @@ def test_prenorm_dropout_mask_matches_between_fwd_and_bwd():
 
 
 @pytest.mark.parametrize('N,C,pd', [(20, 64, 2), (7, 1792, 2), (11, 1024, 3)])
-def test_posembed_fwd_bwd(N, C, pd):
-    Lb = emu_lib()
-    posn = torch.rand(N, pd, generator=torch.Generator().manual_seed(21))
+def test_posembed_fwd_bwd(backend, N, C, pd):
+    Lb = backend.L
+    posn = torch.rand(N, pd, generator=torch.Generator(device='cpu').manual_seed(21), device='cpu').to(backend.dev)
     Wp = rnd(C, pd, seed=22); bp = 0.1 * rnd(C, seed=23)
     out = torch.empty(N, C); stats = torch.empty(2 * N)
     Lb.posembed_fwd(posn, Wp, bp, out, stats, N, C, pd, EPS)
@@ -174,8 +173,8 @@ def _aggr_ref(Z, lnw, lnb, wa, ba, keep=None):
 
 @pytest.mark.parametrize('Mo,R,Fd', [(4, 9, 64), (4, 5, 448), (4, 3, 1792), (1, 6, 1024), (4, 4, 32)])
 @pytest.mark.parametrize('p', [0.0, 0.2])
-def test_modes_aggr_fwd_bwd_param_grads(Mo, R, Fd, p):
-    Lb = emu_lib()
+def test_modes_aggr_fwd_bwd_param_grads(backend, Mo, R, Fd, p):
+    Lb = backend.L
     Z = rnd(Mo, R, Fd, seed=25) * 1.5 + 0.2
     lnw = 1 + 0.1 * rnd(Fd, seed=26); lnb = 0.1 * rnd(Fd, seed=27)
     wa = 0.2 * rnd(Fd, seed=28); ba = torch.tensor([0.3])
@@ -207,8 +206,8 @@ def test_modes_aggr_fwd_bwd_param_grads(Mo, R, Fd, p):
         assert dwa.abs().max() < 1e-6 and dscore.abs().max() < 1e-6      # single mode: softmax == 1, zero grads
 
 
-def test_gelu_bwd():
-    Lb = emu_lib()
+def test_gelu_bwd(backend):
+    Lb = backend.L
     T = rnd(50, 36, seed=30) * 2
     G = rnd(50, 36, seed=31)
     Tr = T.clone().requires_grad_(True)
@@ -218,10 +217,10 @@ def test_gelu_bwd():
     close(dT, Tr.grad, 1e-5)
 
 
-def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask():
+def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask(backend):
     """The GEMM epilogue (scattered MFMA lanes) and gelu_bwd (float4 lanes) must regenerate the same mask."""
     from segtran_amd import segx
-    Lb = emu_lib()
+    Lb = backend.L
     R, Fd, p = 70, 36, 0.3
     H = rnd(R, Fd, seed=32); W = rnd(Fd, Fd, seed=33) * 0.3
     Y = torch.zeros(R, Fd); T = torch.zeros(R, Fd)

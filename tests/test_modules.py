@@ -3,18 +3,14 @@ kernels, checked against the golden fixtures generated from the real reference."
 import pytest
 import torch
 
-from emu import emu_lib
 from segtran_amd import segx
 from segtran_amd.networks import segtran_shared as ss
 from segtran_amd.synth import synth_state_dict
 from util import golden, assert_close
 
 
-@pytest.fixture(autouse=True)
-def _emulated_kernels():
-    segx.use_library(emu_lib())
-    yield
-    segx.use_library(None)
+def golden_on(name, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in golden(name).items()}
 
 
 def mk_config(dims, A, pos_dim=2):
@@ -36,6 +32,7 @@ def load(mod, prefix):
     shapes = {prefix + k: tuple(v.shape) for k, v in mod.state_dict().items()}
     sd = synth_state_dict(shapes)
     mod.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    mod.to(torch.get_default_device())
     for m in mod.modules():
         if isinstance(m, ss.CrossAttFeatTrans):
             m.tie_qk('shared')
@@ -57,9 +54,9 @@ def check_grads(mod, prefix, g, tol=3e-4):
 
 
 @pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32)])
-def test_squeezed_att_feat_trans_vs_reference(tag, C, Fd):
-    g = golden('squeeze_' + tag)
-    mod = ss.SqueezedAttFeatTrans(mk_config([C, Fd], 16), 'L')
+def test_squeezed_att_feat_trans_vs_reference(backend, tag, C, Fd):
+    g = golden_on('squeeze_' + tag, backend.dev)
+    mod = ss.SqueezedAttFeatTrans(mk_config([C, Fd], 16), 'L').to('cpu')
     prefix = 'voxel_fusion.translayers.0.'
     load(mod, prefix)
     mod.eval()
@@ -79,8 +76,8 @@ def test_squeezed_att_feat_trans_vs_reference(tag, C, Fd):
     assert z is not None and z.abs().max() == 0
 
 
-def test_fusion_encoder_vs_reference():
-    g = golden('fusion_small')
+def test_fusion_encoder_vs_reference(backend):
+    g = golden_on('fusion_small', backend.dev)
     dims = [int(d) for d in g['dims']]
     mod = ss.SegtranFusionEncoder(mk_config(dims, 16), 'Fusion')
     prefix = 'voxel_fusion.'
@@ -94,14 +91,14 @@ def test_fusion_encoder_vs_reference():
     check_grads(mod, prefix, g)
 
 
-def test_training_dropout_runs_and_is_reproducible():
+def test_training_dropout_runs_and_is_reproducible(backend):
     from segtran_amd import functional as SF
     cfg = mk_config([64, 32], 16)
     cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.2
     mod = ss.SqueezedAttFeatTrans(cfg, 'L')
     load(mod, 'voxel_fusion.translayers.0.')
     mod.train()
-    X = torch.randn(2, 20, 64, generator=torch.Generator().manual_seed(3))
+    X = torch.randn(2, 20, 64, generator=torch.Generator(device='cpu').manual_seed(3), device='cpu').to(backend.dev)
     SF.manual_seed(11); y1 = mod(X)
     SF.manual_seed(11); y2 = mod(X)
     SF.manual_seed(12); y3 = mod(X)

@@ -1,22 +1,18 @@
 """CPU: fused loss + multi-tensor BertAdam kernels on the emulator vs the golden fixtures from the reference."""
 import pytest
 import torch
-from emu import emu_lib
 from segtran_amd import segx
 from util import golden, assert_close
 
 
-@pytest.fixture(autouse=True)
-def _emulated_kernels():
-    segx.use_library(emu_lib())
-    yield
-    segx.use_library(None)
+def golden_on(name, dev):
+    return {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in golden(name).items()}
 
 
 @pytest.mark.parametrize('tag', ['2d', '3d'])
-def test_seg_loss_vs_reference(tag):
+def test_seg_loss_vs_reference(backend, tag):
     from segtran_amd import functional as SF
-    g = golden('loss')
+    g = golden_on('loss', backend.dev)
     lo = g['logits' + tag].clone().requires_grad_(True)
     nc = lo.shape[1]
     cw = torch.ones(nc); cw[0] = 0; cw /= cw.sum()
@@ -27,9 +23,9 @@ def test_seg_loss_vs_reference(tag):
     assert_close(lo.grad, g['dlogits' + tag], 2e-5, 'dlogits')
 
 
-def test_bertadam_vs_reference():
+def test_bertadam_vs_reference(backend):
     from segtran_amd.optimization import BertAdam
-    g = golden('bertadam')
+    g = golden_on('bertadam', backend.dev)
     params = [torch.nn.Parameter(g['p0_%d' % i].clone()) for i in range(4)]
     groups = [dict(params=[params[0], params[3]], weight_decay=1e-4, lr=2e-4),
               dict(params=[params[1]], weight_decay=1e-5, lr=2e-4),
