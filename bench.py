@@ -59,14 +59,33 @@ def cpu_baseline(cfg_name, threads):
                       'shapes and weights, dropout-free, %.1f s' % (cfg_name, dt)}
 
 
+def run_cpu_baseline(cfg_name, limit_s=240):
+    """The CPU leg runs in a child process with a hard time limit so that it can never cost the bench line.
+    Threads: physical cores, capped at 64 (PyTorch CPU ops stop scaling -- and oversubscribe -- beyond that)."""
+    import subprocess
+    threads = max(1, min(64, (os.cpu_count() or 2) // 2))
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', cfg_name, '--threads', str(threads)],
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=limit_s,
+                             env=dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads)))
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:
+        return {'value': None, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample': 'failed: %s' % repr(e)[:160]}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--threads', type=int, default=8, help=argparse.SUPPRESS)
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2', help='BASELINE config (cfg2 = metric default; cfg4 = BraTS 3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.threads)))
+        return
 
     from segtran_amd import engine, segx, dist as sdist, functional as SF
     rank, local, world = sdist.init_distributed()
@@ -111,7 +130,7 @@ def main():
         dt = t.item()
     if rank != 0:
         return
-    lossv = float(loss)
+    lossv = float(loss.detach())
     assert lossv == lossv, 'loss is NaN'
 
     # roofline of the dominant kernel (segx::gemm_f32_kernel, all layout variants): algorithmic FLOPs / HIP-event time
@@ -132,12 +151,11 @@ def main():
                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'dropout': 0.2,
                       'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5)},
            'roofline': roof}
+    print('[bench] %s: %.1f ms/step, %.2f %s, GEMM %.1f TFLOP/s' % (args.config, res['ms_per_step'], res['value'], unit, achieved),
+          file=sys.stderr, flush=True)
     if world == 1 and not args.no_cpu_baseline:
-        try:
-            res['cpu_baseline'] = cpu_baseline(args.config, os.cpu_count() or 1)
-        except Exception as e:                                                    # the baseline must never kill the bench line
-            res['cpu_baseline'] = {'value': None, 'error': repr(e)[:200]}
-    print(json.dumps(res))
+        res['cpu_baseline'] = run_cpu_baseline(args.config)
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == '__main__':
