@@ -141,6 +141,13 @@ def main():
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
             'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
             'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}
+    if os.environ.get('SEGX_BENCH_VERBOSE'):
+        agg = {}
+        for e0, e1, fl, shp in prof:
+            a = agg.setdefault(shp, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+        print('[bench] GEMM shapes by time (M,N,K,batch,A_kcontig,B_kcontig,splitk): count ms TFLOP/s', file=sys.stderr)
+        for shp, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            print('[bench]   %-46s %4d %8.2f %7.1f' % (shp, n, t, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
     res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), args.config), 'value': round(world * B * args.steps / dt, 3),
            'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),

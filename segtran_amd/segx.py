@@ -99,7 +99,7 @@ class SegxLib:
             e0.record()
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
             e1.record()
-            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1]))
+            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, splitk)))
         else:
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
         self.check(rc, 'segx_gemm_f32')

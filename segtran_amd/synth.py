@@ -19,7 +19,7 @@ def _seed(name):
 def _randn(name, shape):
     g = torch.Generator(device='cpu')
     g.manual_seed(_seed(name))
-    return torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    return torch.randn(tuple(shape), generator=g, dtype=torch.float32, device='cpu')
 
 
 def _canonical(name):
@@ -33,7 +33,7 @@ def synth_tensor(name, shape):
     leaf = name.rsplit('.', 1)[-1]
     cname = _canonical(name)
     if leaf == 'num_batches_tracked':
-        return torch.zeros(shape, dtype=torch.long)
+        return torch.zeros(shape, dtype=torch.long, device='cpu')
     if leaf == 'running_mean':
         return 0.1 * _randn(cname, shape)
     if leaf == 'running_var':
@@ -54,13 +54,13 @@ def synth_tensor(name, shape):
                 if '.query.' in cname:
                     modes = 1 if '.in_ator_trans.' in cname else 4
                     d = shape[0] // modes
-                    eye = torch.eye(d).repeat(1, shape[1] // d) * 0.2
+                    eye = torch.eye(d, device='cpu').repeat(1, shape[1] // d) * 0.2
                     w[:d] = w[:d] * 0.5 + eye
                 else:
                     modes = 1 if '.in_ator_trans.' in cname else 4
                     f = shape[0] // modes
                     if shape[1] >= f:
-                        w[:f, :f] = w[:f, :f] * 0.5 + torch.eye(f) * 0.2
+                        w[:f, :f] = w[:f, :f] * 0.5 + torch.eye(f, device='cpu') * 0.2
             return w
         if 'pos_fc' in name:
             return _randn(cname, shape)                         # phases spread over several periods
@@ -96,18 +96,18 @@ def sample(t, n=4096):
 
 def synth_image2d(B, S, seed=1337, S2=None):
     g = torch.Generator(device='cpu'); g.manual_seed(seed)
-    return torch.randn(B, 3, S, S2 or S, generator=g)
+    return torch.randn(B, 3, S, S2 or S, generator=g, device='cpu')
 
 
 def synth_fundus_mask(B, S, seed=1338):
     """uint8 {0,255} [B,3,S,S] in the loaders' on-disk encoding: ch0 = optic-disc region (incl. cup),
     ch1 = cup (nested disc), ch2 = 0."""
     g = torch.Generator(device='cpu'); g.manual_seed(seed)
-    yy, xx = torch.meshgrid(torch.arange(S), torch.arange(S), indexing='ij')
-    m = torch.zeros(B, 3, S, S, dtype=torch.uint8)
+    yy, xx = torch.meshgrid(torch.arange(S, device='cpu'), torch.arange(S, device='cpu'), indexing='ij')
+    m = torch.zeros(B, 3, S, S, dtype=torch.uint8, device='cpu')
     for b in range(B):
-        c = (torch.rand(2, generator=g) * 0.3 + 0.35) * S
-        r = (torch.rand(1, generator=g) * 0.1 + 0.25) * S
+        c = (torch.rand(2, generator=g, device='cpu') * 0.3 + 0.35) * S
+        r = (torch.rand(1, generator=g, device='cpu') * 0.1 + 0.25) * S
         d2 = (yy - c[0]) ** 2 + (xx - c[1]) ** 2
         m[b, 0][d2 <= r * r] = 255
         m[b, 1][d2 <= (0.5 * r) ** 2] = 255
@@ -118,10 +118,10 @@ def synth_brats(B, H, W, D, seed=1337, margin=8):
     """BraTS-like volume [B,4,H,W,D] with an exact-zero margin on every face (z-scored background
     is exactly 0, so get_mask is non-trivial) + integer labels [B,H,W,D] in {0..3}."""
     g = torch.Generator(device='cpu'); g.manual_seed(seed)
-    x = torch.randn(B, 4, H, W, D, generator=g)
+    x = torch.randn(B, 4, H, W, D, generator=g, device='cpu')
     md = margin if D > 2 * margin else D // 4
     x[:, :, :margin] = 0; x[:, :, -margin:] = 0
     x[:, :, :, :margin] = 0; x[:, :, :, -margin:] = 0
     x[..., :md] = 0; x[..., -md:] = 0
-    lab = torch.randint(0, 4, (B, H, W, D), generator=g)
+    lab = torch.randint(0, 4, (B, H, W, D), generator=g, device='cpu')
     return x, lab
