@@ -74,6 +74,8 @@ int segx_colsum(const float* X, float* out, float* ws, int64_t rows, int64_t C, 
 int segx_ln_param_grad(const float* dY, const float* X, const float* mean, const float* rstd, float* dw, float* db,
                        float* ws, int64_t rows, int C, void* stream);                                      /* nout = 2 */
 int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1024 floats */, float scale, void* stream);
+/* out[r] = sum_s X[r][s]: conv-style (per output channel) bias gradients on NC[D]HW tensors */
+int segx_rowsum(const float* X, float* out, int64_t R, int64_t S, void* stream);
 /* SegtranFusionEncoder.forward per-layer prologue (:916-946):
  *   Y = mask * dropout( LN_noaffine( LN_affine(X; w1,b1) + pos_weight * pos[n, :C] ) ),  X [B,N,C], pos [N,pos_ld], mask [B*N]
  * stats = 4*B*N floats.  Backward returns dX and dU (grad wrt LN_affine's output): dpos = pos_weight * sum_b dU,

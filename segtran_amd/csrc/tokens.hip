@@ -211,6 +211,21 @@ __global__ __launch_bounds__(256) void colreduce_stage2(const float* __restrict_
 }
 static inline int chunks_for(int64_t rows) { return (int)i64max(1, i64min(RED_CHUNKS, rows / 8)); }
 
+// row sums of X [R, S] (conv-style bias gradients: one value per (sample, channel)): one workgroup per row
+__global__ __launch_bounds__(256) void rowsum_kernel(const float* __restrict__ X, float* __restrict__ out, int64_t S, int vec) {
+    __shared__ float red[4];
+    const float* x = X + (int64_t)blockIdx.x * S;
+    float s = 0.f;
+    if (vec) {
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        for (int64_t i = threadIdx.x; i < S / 4; i += 256) { const float4 v = x4[i]; s += (v.x + v.y) + (v.z + v.w); }
+    } else {
+        for (int64_t i = threadIdx.x; i < S; i += 256) s += x[i];
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
 // full sum of a flat array (loss pieces, scalar bias grads): two-stage, deterministic
 __global__ __launch_bounds__(256) void sum_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ ws) {
     __shared__ float red[4];
@@ -561,6 +576,12 @@ extern "C" int segx_ln_param_grad(const float* dY, const float* X, const float* 
     hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, dY, X, mean, rstd, ws, rows, (int64_t)C, 1, nch);
     hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)ws, dw, db, (float*)nullptr, (int64_t)C, nch, 2);
     return check_launch("segx_ln_param_grad");
+}
+extern "C" int segx_rowsum(const float* X, float* out, int64_t R, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && out && R > 0 && S > 0 && R < 2147483647LL, "segx_rowsum: bad args");
+    const int vec = (S % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    hipLaunchKernelGGL(rowsum_kernel, dim3((unsigned)R), dim3(256), 0, stream, X, out, S, vec);
+    return check_launch("segx_rowsum");
 }
 extern "C" int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1024 floats */, float scale, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(x && out && ws && n > 0, "segx_sum: bad args");

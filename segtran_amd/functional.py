@@ -51,11 +51,26 @@ class GemmSpec:
         self.out_shape, self.alpha, self.bias_mode, self.bias_b1 = tuple(out_shape), alpha, bias_mode, bias_b1
 
 
+_SLOTS = 256 * 2          # workgroups resident at once: 256 CUs x 2 (the GEMM kernel allocates ~180 VGPR+AGPR)
+
+
 def _splitk(M, N, K, nbatch):
+    """Split-K factor minimising modelled time = rounds-of-workgroups x k-tiles per workgroup + slab reduction.
+    Whole-GEMM quantisation matters: 784 workgroups on 768 slots take two rounds, not 1.02."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
-    if tiles >= 256 or K < 2048:
+    if tiles >= 4 * _SLOTS or K < 1024:
         return 1
-    return int(max(1, min(16, 512 // tiles, K // 512)))
+    ktile_us = 3.4                                   # one 128x128x32 step with two workgroups sharing a CU
+    best, best_t = 1, None
+    for sk in range(1, 33):
+        if sk > 1 and K // sk < 256:
+            break
+        kt = -(-(-(-K // sk)) // 32)                 # ceil(ceil(K/sk)/32)
+        rounds = -(-tiles * sk // _SLOTS)
+        t = rounds * kt * ktile_us + (0 if sk == 1 else sk * M * N * nbatch * 8 / 3.0e6)
+        if best_t is None or t < best_t * 0.97:
+            best, best_t = sk, t
+    return best
 
 
 def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
@@ -168,9 +183,7 @@ def _bias_grad(L, dC, s):
     assert s.bias_b1 == 0
     nbt = nb0 * nb1
     rs = _empty(dC, nbt * s.M)
-    ones = torch.ones(s.N, 1, dtype=torch.float32, device=dC.device)
-    # row sums as a skinny GEMM: [nbt*M, N] x [1, N]^T
-    L.gemm(dC, ones, rs, nbt * s.M, 1, s.N, (0, 0, s.N, 1), (0, 0, s.N, 1), (0, 0, 1))
+    L.rowsum(dC, rs, nbt * s.M, s.N)
     if nbt == 1:
         return rs
     out = _empty(dC, s.M)

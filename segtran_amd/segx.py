@@ -137,6 +137,9 @@ class SegxLib:
     def ln_param_grad(self, dY, X, mean, rstd, dw, db, ws, rows, C):
         self._call('segx_ln_param_grad', X, dY, X, mean, rstd, dw, db, ws, rows, C)
 
+    def rowsum(self, X, out, R, S):
+        self._call('segx_rowsum', X, X, out, R, S)
+
     def sum(self, x, n, out, ws, scale=1.0):
         self._call('segx_sum', x, x, n, out, ws, scale)
 
@@ -189,7 +192,7 @@ _SIGS = {
     'segx_softmax_fwd': 'ppplifpfuup', 'segx_softmax_bwd': 'pppplifpfuup',
     'segx_layernorm_fwd': 'pppppplifp', 'segx_layernorm_bwd': 'pppppplip',
     'segx_colreduce_ws_floats': 'lli', 'segx_colsum': 'pppllp', 'segx_ln_param_grad': 'ppppppplip',
-    'segx_sum': 'plppfp',
+    'segx_sum': 'plppfp', 'segx_rowsum': 'ppllp',
     'segx_prenorm_fwd': 'pppplfppplliiffuup'.replace('lliif', 'liif'),
     'segx_prenorm_bwd': 'ppppplfpppplii' + 'fuup',
     'segx_posembed_fwd': 'pppppliifp', 'segx_posembed_bwd': 'ppppppliip',
