@@ -131,6 +131,63 @@ int segx_mt_bertadam_step(void* const* params, const void* const* grads, void* c
                           float max_global_norm, float max_tensor_norm, float sched, float b1, float b2, float eps,
                           float* ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backbone kernels (backbone.hip): BatchNorm(+activation), depthwise convolution, squeeze-excite plane ops.
+ * Tensors are NC[D]HW fp32; S = product of the spatial dims; a (sample, channel) plane is contiguous.
+ * act: 0 none, 1 swish (efficientnet/utils.py:64-79), 2 ReLU (aj_i3d.py:95-96).
+ * ------------------------------------------------------------------------------------------- */
+/* training-mode batch statistics (biased var) per channel; also updates running stats (momentum, unbiased var) when
+ * run_mean/run_var are non-NULL.  nn.BatchNorm2d/3d at efficientnet/model.py:54,64,78,177,221 and aj_i3d.py:65. */
+int64_t segx_bn_ws_floats(int B, int C);
+int segx_bn_stats(const float* X, float* mean, float* var, float* run_mean, float* run_var, float* ws,
+                  int B, int C, int64_t S, float momentum, void* stream);
+/* y = act((x - mean) * rsqrt(var + eps) * w + b) with the given (batch or running) statistics */
+int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
+                    int B, int C, int64_t S, float eps, int act, void* stream);
+/* backward of the above: dX, dw[C], db[C]; training != 0 differentiates through the batch statistics */
+int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                    float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
+                    void* stream);
+/* the two halves of segx_bn_act_bwd, for synchronised BatchNorm: reduce gives the LOCAL sums dw = sum du*xhat,
+ * db = sum du; after an all-reduce of both, apply uses the GLOBAL sums and inv_n = 1 / (global element count) */
+int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                           float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, void* stream);
+int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                          const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
+                          float inv_n, void* stream);
+/* depthwise k x k convolution (k in {3,5}, stride in {1,2}) with explicit top/left zero padding (static 'same'
+ * padding N6, efficientnet/utils.py:248-275): Y[b,c,oy,ox] = sum w[c,ky,kx] X[b,c,oy*s+ky-pad_t, ox*s+kx-pad_l] */
+int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
+                      int pad_t, int pad_l, void* stream);
+int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, int C, int H, int Wd, int OH, int OW, int k,
+                           int stride, int pad_t, int pad_l, void* stream);
+/* per-sample partial weight gradients part[B][C][k*k]; sum over B with segx_colsum */
+int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B, int C, int H, int Wd, int OH, int OW, int k,
+                             int stride, int pad_t, int pad_l, void* stream);
+/* squeeze-excite plane ops (efficientnet/model.py:105-110) on [planes = B*C, S]:
+ * Y = X * gate[plane];  out[plane] = sum_s A*B;  dX = dY * gate[plane] + dpool[plane] */
+int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream);
+/* Y = X * gate[plane] + R: MBConv skip connection with the per-sample drop_connect scale (model.py:118-122) */
+int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream);
+int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream);
+int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feature-pyramid kernels (fpn.hip)
+ * ------------------------------------------------------------------------------------------- */
+/* nn.GroupNorm(G, C) on [B, C, S] (segtran2d.py:148-149,190-192; segtran3d.py:182-183,225-227).  mean/rstd: [B*G].
+ * ws: segx_gn_ws_floats(B, C, G) floats. */
+int64_t segx_gn_ws_floats(int B, int C, int G);
+int segx_groupnorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd, float* ws,
+                       int B, int C, int G, int64_t S, float eps, void* stream);
+int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX,
+                       float* dw, float* db, float* ws, int B, int C, int G, int64_t S, void* stream);
+/* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);
+ * out = interp(in) (+ base, the FPN lateral, when base != NULL).  bwd is the exact adjoint, computed as a gather. */
+int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
+                           void* stream);
+int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

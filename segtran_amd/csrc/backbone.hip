@@ -1,0 +1,349 @@
+// backbone.hip -- HBM-bound kernels of the backbone feature extractors (EfficientNet MBConv blocks K19,
+// I3D units K20): BatchNorm(+activation) forward/backward over NC[D]HW tensors, depthwise k3/k5 convolution
+// forward / backward-data / backward-weight, squeeze-excite pooling / gating.
+//
+// None of these has a contraction worth the matrix cores: they are priced against the HBM
+// roofline.  Layout rule: a (sample, channel) plane is contiguous (S = D*H*W floats), so a workgroup always
+// streams contiguous float4 runs of one plane and carries the per-channel constants in scalars.
+#include "common.h"
+
+namespace segx {
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+
+__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_fwd(float u, int act) {
+    return act == ACT_SWISH ? u * sigm(u) : act == ACT_RELU ? fmaxf(u, 0.f) : u;
+}
+// d act(u) / du   (swish: efficientnet/utils.py:64-79)
+__device__ __forceinline__ float act_grad(float u, int act) {
+    if (act == ACT_SWISH) { const float s = sigm(u); return s * (1.0f + u * (1.0f - s)); }
+    if (act == ACT_RELU) return u > 0.f ? 1.0f : 0.f;
+    return 1.0f;
+}
+
+// =================================================================================================
+// BatchNorm statistics: per channel over (B, S).  Shifted sums around a per-channel pivot (the channel's
+// first element) keep E[d^2] - E[d]^2 free of catastrophic cancellation.  Stage 1: grid (C, B, slabs).
+// =================================================================================================
+constexpr int BN_SLABS = 8;
+
+__global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ X, float* __restrict__ ws, int C, int64_t S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y, slab = blockIdx.z;
+    const float pivot = X[(int64_t)c * S];
+    const float* x = X + ((int64_t)b * C + c) * S;
+    const int64_t per = ((S + BN_SLABS - 1) / BN_SLABS + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
+    float a = 0.f, q = 0.f;
+    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
+        for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + s);
+            const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
+            a += (d0 + d1) + (d2 + d3); q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else {
+        for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
+    }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + b) * BN_SLABS + slab) * 2; o[0] = a; o[1] = q; }
+}
+// one thread per channel: mean, biased var (+ running-stat update with the unbiased var, momentum m)
+__global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__ X, const float* __restrict__ ws, float* __restrict__ mean,
+                                                       float* __restrict__ var, float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                       int B, int C, int64_t S, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, q = 0.f;
+    for (int i = 0; i < B * BN_SLABS; ++i) { a += ws[((int64_t)c * B * BN_SLABS + i) * 2]; q += ws[((int64_t)c * B * BN_SLABS + i) * 2 + 1]; }
+    const float n = (float)B * (float)S, md = a / n;
+    const float m = X[(int64_t)c * S] + md, v = fmaxf(q / n - md * md, 0.f);
+    mean[c] = m; var[c] = v;
+    if (run_mean) {
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (v * n / fmaxf(n - 1.0f, 1.0f));
+    }
+}
+
+// y = act((x - mean) * rstd * w + b): grid (chunks, B*C)
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ var,
+                                                         const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ Y,
+                                                         int C, int64_t S, float eps, int act) {
+    const int bc = blockIdx.y, c = bc % C;
+    const float sc = rsqrtf(var[c] + eps) * w[c], sh = b[c] - mean[c] * sc;
+    const float* x = X + (int64_t)bc * S; float* y = Y + (int64_t)bc * S;
+    if ((S & 3) == 0) {
+        for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + s);
+            float4 o;
+            o.x = act_fwd(v.x * sc + sh, act); o.y = act_fwd(v.y * sc + sh, act); o.z = act_fwd(v.z * sc + sh, act); o.w = act_fwd(v.w * sc + sh, act);
+            *reinterpret_cast<float4*>(y + s) = o;
+        }
+    } else {
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = act_fwd(x[s] * sc + sh, act);
+    }
+}
+// backward reductions per channel: sums[c] = (sum du, sum du * xhat), du = dy * act'(u).  grid (C, B, slabs)
+__global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                                         const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
+                                                         float* __restrict__ ws, int C, int64_t S, float eps, int act) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
+    const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
+    const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
+    const int64_t per = (S + BN_SLABS - 1) / BN_SLABS, s0 = slab * per, s1 = i64min(S, s0 + per);
+    float a = 0.f, q = 0.f;
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
+        const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+        a += du; q += du * xh;
+    }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + bb) * BN_SLABS + slab) * 2; o[0] = a; o[1] = q; }
+}
+__global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, q = 0.f;
+    for (int i = 0; i < B * BN_SLABS; ++i) { a += ws[((int64_t)c * B * BN_SLABS + i) * 2]; q += ws[((int64_t)c * B * BN_SLABS + i) * 2 + 1]; }
+    db[c] = a; dw[c] = q;
+}
+// dx = w * rstd * (du - [training] (db + xhat * dw) / n)
+__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                                        const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
+                                                        const float* __restrict__ dw, const float* __restrict__ db, float* __restrict__ dX,
+                                                        int C, int64_t S, float eps, int act, float inv_n /* 0 in eval mode */) {
+    const int bc = blockIdx.y, c = bc % C;
+    const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
+    const float k1 = db[c] * inv_n, k2 = dw[c] * inv_n, sc = wc * rstd;
+    const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+        const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+        d[s] = sc * (du - k1 - xh * k2);
+    }
+}
+
+// =================================================================================================
+// Depthwise convolution (efficientnet/model.py:100, groups == channels), static TF-'same' padding (N6):
+//   y[b,c,oy,ox] = sum_{ky,kx} w[c,ky,kx] * x[b,c,oy*S+ky-pt, ox*S+kx-pl]
+// A workgroup owns a 16x16 output tile of one (b,c) plane; the input halo tile goes through LDS.
+// =================================================================================================
+template <int K, int ST>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
+                                                         int C, int H, int W, int OH, int OW, int pt, int pl, int tiles_x) {
+    constexpr int TI = 15 * ST + K;                 // input tile edge for 16 outputs
+    __shared__ float tile[TI][TI + 1];
+    const int bc = blockIdx.y, c = bc % C;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const float* x = X + (int64_t)bc * H * W;
+    const int iy0 = ty0 * ST - pt, ix0 = tx0 * ST - pl;
+    for (int i = threadIdx.x; i < TI * TI; i += 256) {
+        const int r = i / TI, q = i - r * TI, iy = iy0 + r, ix = ix0 + q;
+        tile[r][q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(int64_t)iy * W + ix] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, oy = ty0 + ly, ox = tx0 + lx;
+    float acc = 0.f;
+    const float* w = Wt + (int64_t)c * K * K;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) acc += w[ky * K + kx] * tile[ly * ST + ky][lx * ST + kx];
+    if (oy < OH && ox < OW) Y[(int64_t)bc * OH * OW + (int64_t)oy * OW + ox] = acc;
+}
+// dx[iy,ix] = sum_{ky,kx} w[ky,kx] * dy[(iy+pt-ky)/S, (ix+pl-kx)/S]   (terms with a non-integer quotient vanish)
+template <int K, int ST>
+__global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __restrict__ dY, const float* __restrict__ Wt, float* __restrict__ dX,
+                                                              int C, int H, int W, int OH, int OW, int pt, int pl, int tiles_x) {
+    constexpr int TO = (15 + K - 1) / ST + 2;       // dy rows/cols that can touch a 16-wide dx tile
+    __shared__ float tile[TO][TO + 1];
+    const int bc = blockIdx.y, c = bc % C;
+    const int iy0 = (blockIdx.x / tiles_x) * 16, ix0 = (blockIdx.x % tiles_x) * 16;
+    const float* g = dY + (int64_t)bc * OH * OW;
+    // first dy row that can contribute: oy >= (iy0 + pt - (K-1)) / S  (ceil), clamp below by 0 handled by the guard
+    const int oy0 = (iy0 + pt - (K - 1) >= 0) ? (iy0 + pt - (K - 1) + ST - 1) / ST : -((-(iy0 + pt - (K - 1))) / ST);
+    const int ox0 = (ix0 + pl - (K - 1) >= 0) ? (ix0 + pl - (K - 1) + ST - 1) / ST : -((-(ix0 + pl - (K - 1))) / ST);
+    for (int i = threadIdx.x; i < TO * TO; i += 256) {
+        const int r = i / TO, q = i - r * TO, oy = oy0 + r, ox = ox0 + q;
+        tile[r][q] = (oy >= 0 && oy < OH && ox >= 0 && ox < OW) ? g[(int64_t)oy * OW + ox] : 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, iy = iy0 + ly, ix = ix0 + lx;
+    float acc = 0.f;
+    const float* w = Wt + (int64_t)c * K * K;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int ny = iy + pt - ky;
+        if (ny < 0 || (ny % ST) != 0) continue;
+        const int r = ny / ST - oy0;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int nx = ix + pl - kx;
+            if (nx < 0 || (nx % ST) != 0) continue;
+            const int q = nx / ST - ox0;
+            if (r >= 0 && r < TO && q >= 0 && q < TO) acc += w[ky * K + kx] * tile[r][q];
+        }
+    }
+    if (iy < H && ix < W) dX[(int64_t)bc * H * W + (int64_t)iy * W + ix] = acc;
+}
+// dw[c,ky,kx] partial over one sample: grid (C, B) -> part[b][c][K*K]; summed over b afterwards (colsum)
+template <int K, int ST>
+__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
+                                                                int C, int H, int W, int OH, int OW, int pt, int pl) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* x = X + ((int64_t)b * C + c) * H * W; const float* g = dY + ((int64_t)b * C + c) * OH * OW;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int o = threadIdx.x; o < OH * OW; o += 256) {
+        const int oy = o / OW, ox = o - oy * OW;
+        const float gv = g[o];
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * ST + ky - pt;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * ST + kx - pl;
+                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(int64_t)iy * W + ix] : 0.f;
+                acc[ky * K + kx] += gv * xv;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        const float s = block_sum<4>(acc[i], red);
+        if (threadIdx.x == 0) part[((int64_t)b * C + c) * K * K + i] = s;
+    }
+}
+
+// =================================================================================================
+// Squeeze-excite plane ops (efficientnet/model.py:105-110): y = x * gate[b,c] ; dgate[b,c] = sum_s dy * x ;
+// dx = dy * gate + dpool[b,c]   (dpool = gradient of the mean pooled value, already divided by S)
+// =================================================================================================
+__global__ __launch_bounds__(256) void plane_scale_kernel(const float* __restrict__ X, const float* __restrict__ gate, float* __restrict__ Y, int64_t S) {
+    const float gt = gate[blockIdx.y];
+    const float* x = X + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * gt;
+}
+// y = x * gate[plane] + r   (MBConv skip connection with per-sample drop_connect scale, model.py:118-122)
+__global__ __launch_bounds__(256) void plane_scale_add_kernel(const float* __restrict__ X, const float* __restrict__ gate, const float* __restrict__ R,
+                                                              float* __restrict__ Y, int64_t S) {
+    const float gt = gate[blockIdx.y];
+    const float* x = X + (int64_t)blockIdx.y * S; const float* r = R + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * gt + r[s];
+}
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ out, int64_t S) {
+    __shared__ float red[4];
+    const float* a = A + (int64_t)blockIdx.x * S; const float* b = Bm + (int64_t)blockIdx.x * S;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < S; i += 256) s += a[i] * b[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void plane_scale_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ gate, const float* __restrict__ dpool,
+                                                              float* __restrict__ dX, int64_t S) {
+    const float gt = gate[blockIdx.y], dp = dpool[blockIdx.y];
+    const float* g = dY + (int64_t)blockIdx.y * S; float* d = dX + (int64_t)blockIdx.y * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) d[s] = g[s] * gt + dp;
+}
+
+static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
+
+}  // namespace segx
+
+using namespace segx;
+#define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
+
+extern "C" int64_t segx_bn_ws_floats(int B, int C) { return (int64_t)B * C * BN_SLABS * 2; }
+extern "C" int segx_bn_stats(const float* X, float* mean, float* var, float* run_mean, float* run_var, float* ws,
+                             int B, int C, int64_t S, float momentum, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && ws && B > 0 && C > 0 && S > 0 && (!run_mean == !run_var), "segx_bn_stats: bad args");
+    SEGX_REQUIRE(B <= 65535, "segx_bn_stats: batch too large");
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, X, ws, C, S);
+    hipLaunchKernelGGL(bn_stats_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, var, run_mean, run_var, B, C, S, momentum);
+    return check_launch("segx_bn_stats");
+}
+extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
+                               int B, int C, int64_t S, float eps, int act, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 2, "segx_bn_act_fwd: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd: more than 65535 (sample, channel) planes");
+    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, C, S, eps, act);
+    return check_launch("segx_bn_act_fwd");
+}
+extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                                      float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_reduce: bad args");
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C);
+    return check_launch("segx_bn_act_bwd_reduce");
+}
+extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                                     const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
+                                     float inv_n, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_apply: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 4), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n);
+    return check_launch("segx_bn_act_bwd_apply");
+}
+extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                               float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
+                               void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C);
+    const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 4), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
+                       (const float*)db, dX, C, S, eps, act, inv_n);
+    return check_launch("segx_bn_act_bwd");
+}
+
+#define SEGX_DW_DISPATCH(KERNEL, ...)                                                                          \
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((KERNEL<3, 1>), grid, dim3(256), 0, stream, __VA_ARGS__);     \
+    else if (k == 3 && stride == 2) hipLaunchKernelGGL((KERNEL<3, 2>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((KERNEL<5, 1>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 2) hipLaunchKernelGGL((KERNEL<5, 2>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else return segx::fail(-1, "depthwise conv: kernel %d stride %d unsupported (k in {3,5}, stride in {1,2})", k, stride);
+
+extern "C" int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
+                                 int pad_t, int pad_l, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && W && Y && B > 0 && C > 0 && H > 0 && Wd > 0 && OH > 0 && OW > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_fwd: bad args");
+    const int tx = (OW + 15) / 16, ty = (OH + 15) / 16;
+    dim3 grid(tx * ty, B * C);
+    SEGX_DW_DISPATCH(dwconv_fwd_kernel, X, W, Y, C, H, Wd, OH, OW, pad_t, pad_l, tx);
+    return check_launch("segx_dwconv2d_fwd");
+}
+extern "C" int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
+                                      int pad_t, int pad_l, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && B > 0 && C > 0 && H > 0 && Wd > 0 && OH > 0 && OW > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_bwd_data: bad args");
+    const int tx = (Wd + 15) / 16, ty = (H + 15) / 16;
+    dim3 grid(tx * ty, B * C);
+    SEGX_DW_DISPATCH(dwconv_bwd_data_kernel, dY, W, dX, C, H, Wd, OH, OW, pad_t, pad_l, tx);
+    return check_launch("segx_dwconv2d_bwd_data");
+}
+extern "C" int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part /* [B][C][k*k] */, int B, int C, int H, int Wd, int OH, int OW,
+                                        int k, int stride, int pad_t, int pad_l, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && part && B > 0 && C > 0 && B <= 65535, "segx_dwconv2d_bwd_weight: bad args");
+    dim3 grid(C, B);
+    SEGX_DW_DISPATCH(dwconv_bwd_weight_kernel, dY, X, part, C, H, Wd, OH, OW, pad_t, pad_l);
+    return check_launch("segx_dwconv2d_bwd_weight");
+}
+extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && gate && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale: bad args");
+    hipLaunchKernelGGL(plane_scale_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, gate, Y, S);
+    return check_launch("segx_plane_scale");
+}
+extern "C" int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && gate && R && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_add: bad args");
+    hipLaunchKernelGGL(plane_scale_add_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, gate, R, Y, S);
+    return check_launch("segx_plane_scale_add");
+}
+extern "C" int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(A && Bm && out && planes > 0 && S > 0 && planes < 2147483647LL, "segx_plane_dot: bad args");
+    hipLaunchKernelGGL(plane_dot_kernel, dim3((unsigned)planes), dim3(256), 0, stream, A, Bm, out, S);
+    return check_launch("segx_plane_dot");
+}
+extern "C" int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && gate && dpool && dX && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_bwd: bad args");
+    hipLaunchKernelGGL(plane_scale_bwd_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, dY, gate, dpool, dX, S);
+    return check_launch("segx_plane_scale_bwd");
+}

@@ -1,0 +1,200 @@
+// fpn.hip -- HBM-bound kernels of the input / output feature pyramids (K16-K18): GroupNorm(8) forward/backward
+// and (bi/tri)linear resampling with align_corners=False, with the FPN's "lateral + upsampled" addition fused
+// into the resampling pass.  Tensors are NC[D]HW fp32; a (sample, channel) plane is contiguous.
+#include "common.h"
+
+namespace segx {
+
+constexpr int GN_SLABS = 16;
+
+// =================================================================================================
+// GroupNorm (segtran2d.py:148-149,190-192 nn.GroupNorm(G=8, C), eps 1e-5).  Channels of a group are adjacent, so a
+// (sample, group) is one contiguous run of (C/G)*S floats.
+// =================================================================================================
+__global__ __launch_bounds__(256) void gn_stats_stage1(const float* __restrict__ X, float* __restrict__ ws, int64_t L) {
+    __shared__ float red[4];
+    const int bg = blockIdx.x, slab = blockIdx.y;
+    const float* x = X + (int64_t)bg * L;
+    const float pivot = x[0];
+    const int64_t per = (L + GN_SLABS - 1) / GN_SLABS, s0 = slab * per, s1 = i64min(L, s0 + per);
+    float a = 0.f, q = 0.f;
+    for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) { ws[((int64_t)bg * GN_SLABS + slab) * 2] = a; ws[((int64_t)bg * GN_SLABS + slab) * 2 + 1] = q; }
+}
+__global__ __launch_bounds__(256) void gn_stats_stage2(const float* __restrict__ X, const float* __restrict__ ws, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int BG, int64_t L, float eps) {
+    const int bg = blockIdx.x * 256 + threadIdx.x;
+    if (bg >= BG) return;
+    float a = 0.f, q = 0.f;
+    for (int i = 0; i < GN_SLABS; ++i) { a += ws[((int64_t)bg * GN_SLABS + i) * 2]; q += ws[((int64_t)bg * GN_SLABS + i) * 2 + 1]; }
+    const float n = (float)L, md = a / n;
+    mean[bg] = X[(int64_t)bg * L] + md;
+    rstd[bg] = rsqrtf(fmaxf(q / n - md * md, 0.f) + eps);
+}
+// grid (chunks, B*C)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ Y,
+                                                       int C, int G, int64_t S) {
+    const int bc = blockIdx.y, c = bc % C, bg = (bc / C) * G + c / (C / G);
+    const float sc = rstd[bg] * w[c], sh = b[c] - mean[bg] * sc;
+    const float* x = X + (int64_t)bc * S; float* y = Y + (int64_t)bc * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * sc + sh;
+}
+// per plane (b,c): psum[bc] = (sum dy, sum dy * xhat)
+__global__ __launch_bounds__(256) void gn_bwd_plane_sums(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ psum, int C, int G, int64_t S) {
+    __shared__ float red[4];
+    const int bc = blockIdx.x, c = bc % C, bg = (bc / C) * G + c / (C / G);
+    const float m = mean[bg], r = rstd[bg];
+    const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S;
+    float a = 0.f, q = 0.f;
+    for (int64_t s = threadIdx.x; s < S; s += 256) { const float gv = g[s]; a += gv; q += gv * ((x[s] - m) * r); }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) { psum[2 * bc] = a; psum[2 * bc + 1] = q; }
+}
+// tiny: group sums gsum[bg] = (sum_c w_c * psum0, sum_c w_c * psum1) ; dw[c] = sum_b psum1 ; db[c] = sum_b psum0
+__global__ __launch_bounds__(256) void gn_bwd_finalize(const float* __restrict__ psum, const float* __restrict__ w, float* __restrict__ gsum,
+                                                       float* __restrict__ dw, float* __restrict__ db, int B, int C, int G) {
+    const int t = blockIdx.x * 256 + threadIdx.x, cpg = C / G;
+    if (t < B * G) {
+        const int b = t / G, g = t % G;
+        float a = 0.f, q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += w[c] * psum[2 * (b * C + c)]; q += w[c] * psum[2 * (b * C + c) + 1]; }
+        gsum[2 * t] = a; gsum[2 * t + 1] = q;
+    }
+    if (t < C) {
+        float a = 0.f, q = 0.f;
+        for (int b = 0; b < B; ++b) { a += psum[2 * (b * C + t)]; q += psum[2 * (b * C + t) + 1]; }
+        db[t] = a; dw[t] = q;
+    }
+}
+// dx = rstd * (dy*w - s1/n - xhat * s2/n)
+__global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, const float* __restrict__ w, const float* __restrict__ gsum,
+                                                    float* __restrict__ dX, int C, int G, int64_t S) {
+    const int bc = blockIdx.y, c = bc % C, bg = (bc / C) * G + c / (C / G);
+    const float m = mean[bg], r = rstd[bg], wc = w[c];
+    const float inv_n = 1.0f / ((float)(C / G) * (float)S), k1 = gsum[2 * bg] * inv_n, k2 = gsum[2 * bg + 1] * inv_n;
+    const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256)
+        d[s] = r * (g[s] * wc - k1 - (x[s] - m) * r * k2);
+}
+
+// =================================================================================================
+// Linear resampling, align_corners=False (F.interpolate 'bilinear'/'trilinear': segtran2d.py:249,291,305,435;
+// segtran3d.py:304,319,351,364,384,495).  Source coordinate of destination index d along one axis, exactly as ATen:
+//   src = max(scale * (d + 0.5) - 0.5, 0),  scale = n_in / n_out (float);  i0 = floor(src), i1 = min(i0+1, n_in-1), l = src - i0
+// 2-D tensors use d = D = 1.  Forward optionally adds a base tensor (the FPN lateral) in the same pass.
+// =================================================================================================
+struct Axis { int i0, i1; float l; };
+__device__ __forceinline__ Axis axis_src(int d, int n_in, float scale) {
+    float src = scale * ((float)d + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Axis a; a.i0 = (int)src; if (a.i0 > n_in - 1) a.i0 = n_in - 1;
+    a.i1 = a.i0 + (a.i0 < n_in - 1 ? 1 : 0); a.l = src - (float)a.i0;
+    return a;
+}
+struct InterpDims { int d, h, w, D, H, W; float sd, sh, sw; };
+
+__global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                         InterpDims q, int64_t planes) {
+    const int64_t osz = (int64_t)q.D * q.H * q.W, isz = (int64_t)q.d * q.h * q.w, total = planes * osz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / osz; int64_t r = idx - p * osz;
+        const int z = (int)(r / ((int64_t)q.H * q.W)); r -= (int64_t)z * q.H * q.W;
+        const int y = (int)(r / q.W), x = (int)(r - (int64_t)y * q.W);
+        const Axis az = axis_src(z, q.d, q.sd), ay = axis_src(y, q.h, q.sh), ax = axis_src(x, q.w, q.sw);
+        const float* s = in + p * isz;
+        auto at = [&](int zz, int yy, int xx) { return s[((int64_t)zz * q.h + yy) * q.w + xx]; };
+        const float c00 = at(az.i0, ay.i0, ax.i0) * (1.f - ax.l) + at(az.i0, ay.i0, ax.i1) * ax.l;
+        const float c01 = at(az.i0, ay.i1, ax.i0) * (1.f - ax.l) + at(az.i0, ay.i1, ax.i1) * ax.l;
+        const float c10 = at(az.i1, ay.i0, ax.i0) * (1.f - ax.l) + at(az.i1, ay.i0, ax.i1) * ax.l;
+        const float c11 = at(az.i1, ay.i1, ax.i0) * (1.f - ax.l) + at(az.i1, ay.i1, ax.i1) * ax.l;
+        float v = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
+        if (base) v += base[idx];
+        out[idx] = v;
+    }
+}
+// adjoint as a GATHER (deterministic, no atomics): an input cell collects from every output cell it was blended into
+__device__ __forceinline__ void cand_range(int i, int n_out, float scale, int& lo, int& hi) {
+    const float inv = 1.0f / scale;
+    lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1; hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
+    lo = lo < 0 ? 0 : lo; hi = hi > n_out - 1 ? n_out - 1 : hi;
+}
+__device__ __forceinline__ float axis_weight(int i, int d, int n_in, float scale) {
+    const Axis a = axis_src(d, n_in, scale);
+    return (a.i0 == i ? 1.f - a.l : 0.f) + (a.i1 == i ? a.l : 0.f);
+}
+__global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din, InterpDims q, int64_t planes) {
+    const int64_t osz = (int64_t)q.D * q.H * q.W, isz = (int64_t)q.d * q.h * q.w, total = planes * isz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t p = idx / isz; int64_t r = idx - p * isz;
+        const int iz = (int)(r / ((int64_t)q.h * q.w)); r -= (int64_t)iz * q.h * q.w;
+        const int iy = (int)(r / q.w), ix = (int)(r - (int64_t)iy * q.w);
+        int z0, z1, y0, y1, x0, x1;
+        cand_range(iz, q.D, q.sd, z0, z1); cand_range(iy, q.H, q.sh, y0, y1); cand_range(ix, q.W, q.sw, x0, x1);
+        const float* g = dout + p * osz;
+        float acc = 0.f;
+        for (int z = z0; z <= z1; ++z) {
+            const float wz = axis_weight(iz, z, q.d, q.sd);
+            if (wz == 0.f) continue;
+            for (int y = y0; y <= y1; ++y) {
+                const float wy = axis_weight(iy, y, q.h, q.sh) * wz;
+                if (wy == 0.f) continue;
+                float rowacc = 0.f;
+                for (int x = x0; x <= x1; ++x) rowacc += axis_weight(ix, x, q.w, q.sw) * g[((int64_t)z * q.H + y) * q.W + x];
+                acc += wy * rowacc;
+            }
+        }
+        din[idx] = acc;
+    }
+}
+
+static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
+
+}  // namespace segx
+
+using namespace segx;
+#define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
+
+extern "C" int64_t segx_gn_ws_floats(int B, int C, int G) { return (int64_t)B * G * GN_SLABS * 2 + (int64_t)2 * B * C + (int64_t)2 * B * G; }
+extern "C" int segx_groupnorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd, float* ws,
+                                  int B, int C, int G, int64_t S, float eps, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && w && b && Y && mean && rstd && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_groupnorm_fwd: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_groupnorm_fwd: more than 65535 planes");
+    const int64_t L = (int64_t)(C / G) * S;
+    hipLaunchKernelGGL(gn_stats_stage1, dim3(B * G, GN_SLABS), dim3(256), 0, stream, X, ws, L);
+    hipLaunchKernelGGL(gn_stats_stage2, dim3((B * G + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, rstd, B * G, L, eps);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, X, (const float*)mean, (const float*)rstd, w, b, Y, C, G, S);
+    return check_launch("segx_groupnorm_fwd");
+}
+extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX, float* dw,
+                                  float* db, float* ws, int B, int C, int G, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && w && mean && rstd && dX && dw && db && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_groupnorm_bwd: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_groupnorm_bwd: more than 65535 planes");
+    float* psum = ws + (int64_t)B * G * GN_SLABS * 2; float* gsum = psum + (int64_t)2 * B * C;
+    hipLaunchKernelGGL(gn_bwd_plane_sums, dim3(B * C), dim3(256), 0, stream, dY, X, mean, rstd, psum, C, G, S);
+    const int n = B * G > C ? B * G : C;
+    hipLaunchKernelGGL(gn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)psum, w, gsum, dw, db, B, C, G);
+    hipLaunchKernelGGL(gn_bwd_apply, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, rstd, w, (const float*)gsum, dX, C, G, S);
+    return check_launch("segx_groupnorm_bwd");
+}
+static InterpDims make_dims(int d, int h, int w, int D, int H, int W) {
+    InterpDims q; q.d = d; q.h = h; q.w = w; q.D = D; q.H = H; q.W = W;
+    q.sd = (float)d / (float)D; q.sh = (float)h / (float)H; q.sw = (float)w / (float)W;
+    return q;
+}
+extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
+                                      void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
+    const int64_t total = planes * D * H * W;
+    hipLaunchKernelGGL(interp_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), planes);
+    return check_launch("segx_interp_linear_fwd");
+}
+extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dout && din && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_bwd: bad args");
+    const int64_t total = planes * d * h * w;
+    hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, make_dims(d, h, w, D, H, W), planes);
+    return check_launch("segx_interp_linear_bwd");
+}

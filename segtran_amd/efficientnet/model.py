@@ -6,9 +6,10 @@ parameter names (so lukemelas-format and reference checkpoints load), same stati
 model.py:169-178, utils.py:248-275), same endpoint rule (endpoints are the INPUTS of blocks
 `endpoint_blk_indices`, model.py:184,211-212,275-277).
 
-Kernel status: every 1x1 convolution (127 of the 160 convs of B4) runs on libsegx's MFMA GEMM.  The
-stem 3x3, the 32 depthwise k3/k5 convolutions, BatchNorm, swish and the squeeze-excite pooling are still
-ATen/MIOpen calls here -- HBM-bound kernels scheduled for the next round (DESIGN.md "coverage").
+Kernel status: every 1x1 convolution (127 of the 160 convs of B4) runs on libsegx's MFMA GEMM; the 32 depthwise
+k3/k5 convolutions, BatchNorm+swish (fused), the squeeze-excite pooling/gating planes and the drop_connect+skip add
+run on libsegx's HBM-bound kernels (backbone.hip).  Still ATen/MIOpen: the dense 3x3 stem convolution and the
+[B, C]-sized excitation MLP of squeeze-excite (a handful of tiny matmuls).
 """
 import math
 import torch
@@ -58,7 +59,9 @@ class Conv2dStaticSamePadding(nn.Conv2d):
     def forward(self, x):
         if self.pointwise:
             return SF.conv1x1(x, self.weight, self.bias)                 # libsegx MFMA GEMM
-        if any(self.static_pad):
+        if self.groups == self.in_channels and self.groups == self.out_channels and self.bias is None:
+            return SF.dwconv2d(x, self.weight, self.stride[0], self.static_pad)   # libsegx depthwise stencil
+        if any(self.static_pad):                                           # dense k x k: only the 3x3 stem (ATen/MIOpen)
             x = F.pad(x, self.static_pad)
         return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
 
@@ -95,16 +98,16 @@ class MBConvBlock(nn.Module):
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         if self.expand_ratio != 1:
-            x = swish(self._bn0(self._expand_conv(x)))
-        x = swish(self._bn1(self._depthwise_conv(x)))
-        sq = F.adaptive_avg_pool2d(x, 1)
-        sq = self._se_expand(swish(self._se_reduce(sq)))
-        x = torch.sigmoid(sq) * x
-        x = self._bn2(self._project_conv(x))
+            x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
+        x = SF.bn_act(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH)
+        x = SF.squeeze_excite(x, self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
+        x = SF.bn_act(self._project_conv(x), self._bn2, SF.ACT_NONE)
         if self.stride == 1 and self.input_filters == self.output_filters:
-            if drop_connect_rate:
-                x = drop_connect(x, drop_connect_rate, self.training)
-            x = x + inputs
+            scale = None
+            if drop_connect_rate and self.training:                      # utils.py:129-154, per-sample stochastic depth
+                keep = 1 - drop_connect_rate
+                scale = torch.floor(keep + torch.rand([x.shape[0]], dtype=x.dtype, device=x.device)) / keep
+            x = SF.skip_add(x, inputs, scale)
         return x
 
 
@@ -145,7 +148,7 @@ class EfficientNet(nn.Module):
 
     def extract_endpoints(self, inputs):
         endpoints = {}
-        x = swish(self._bn0(self._conv_stem(inputs)))
+        x = SF.bn_act(self._conv_stem(inputs), self._bn0, SF.ACT_SWISH)
         prev_x = x
         nblk = len(self._blocks)
         for idx, block in enumerate(self._blocks):
@@ -154,6 +157,6 @@ class EfficientNet(nn.Module):
             if idx in self.endpoint_blk_indices:
                 endpoints['reduction_%d' % (len(endpoints) + 1)] = prev_x
             prev_x = x
-        x = swish(self._bn1(self._conv_head(x)))
+        x = SF.bn_act(self._conv_head(x), self._bn1, SF.ACT_SWISH)
         endpoints['reduction_%d' % (len(endpoints) + 1)] = x
         return endpoints

@@ -110,7 +110,7 @@ class TrainStep:
         mask = map_mask(self.task, raw_mask)
         out = self.net(x)
         if out.shape[2:] != mask.shape[2:]:
-            out = F.interpolate(out, size=mask.shape[2:], mode='bilinear' if out.dim() == 4 else 'trilinear', align_corners=False)
+            out = SF.interp_linear(out, mask.shape[2:])          # train2d.py:1219 / train3d.py:731
         loss, self.stats = SF.seg_loss(out, mask, self.pos_weight, self.class_w, 0.5)
         self.opt.zero_grad()
         loss.backward()

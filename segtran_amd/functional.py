@@ -431,3 +431,250 @@ def seg_loss(logits, mask_nhot, pos_weight, class_w, dice_w=0.5):
     """Returns (loss, stats) with stats = [loss, ce, dice_total, dice_c0, ...] (device tensor, no host sync)."""
     loss, stats = _SegLoss.apply(logits, mask_nhot.to(torch.float32), pos_weight, class_w, float(dice_w))
     return loss, stats
+
+
+# -------------------------------------------------------------------------------------------------
+# Backbone ops (backbone.hip): BatchNorm + activation, depthwise conv, squeeze-excite
+# -------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+_bn_stats_sync = None        # set by segtran_amd.dist for data-parallel runs: merges (mean, var, count) across ranks
+_bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair of the BN backward
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        S = x.numel() // (B * C)
+        if training:
+            mean, var = _empty(x, C), _empty(x, C)
+            if _bn_stats_sync is None:
+                L.bn_stats(x, mean, var, run_mean, run_var, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+                n = B * S
+            else:
+                L.bn_stats(x, mean, var, None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+                mean, var, n = _bn_stats_sync(mean, var, B * S)
+                with torch.no_grad():
+                    run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
+                    run_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+        else:
+            mean, var, n = run_mean, run_var, B * S
+        y = torch.empty_like(x)
+        L.bn_act_fwd(x, mean, var, w, b, y, B, C, S, eps, act)
+        ctx.cfg = (B, C, S, eps, act, training, n)
+        ctx.save_for_backward(x, mean, var, w, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        x, mean, var, w, b = ctx.saved_tensors
+        B, C, S, eps, act, training, n = ctx.cfg
+        dx = torch.empty_like(x)
+        dw, db = _empty(x, C), _empty(x, C)
+        dy = _c(dy)
+        if training and _bn_grad_sync is not None:
+            # synchronised BN: local sums -> ONE all-reduce of [2C] -> apply with the global sums / global count
+            L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act)
+            sdw, sdb = _bn_grad_sync(dw, db)
+            L.bn_act_bwd_apply(dy, x, mean, var, w, b, sdw, sdb, dx, B, C, S, eps, act, 1.0 / n)
+        else:
+            L.bn_act_bwd(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0)
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def bn_act(x, bn, act=ACT_NONE):
+    """nn.BatchNorm2d/3d module `bn` (parameter container) followed by an activation, fused."""
+    if bn.training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act)
+
+
+class _DWConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        L = segx.lib()
+        x, w = _c(x), _c(w)
+        B, C, H, W = x.shape
+        k = w.shape[-1]
+        pl, pr, pt, pb = pad
+        OH, OW = (H + pt + pb - k) // stride + 1, (W + pl + pr - k) // stride + 1
+        y = _empty(x, B, C, OH, OW)
+        L.dwconv2d_fwd(x, w, y, B, C, H, W, OH, OW, k, stride, pt, pl)
+        ctx.cfg = (B, C, H, W, OH, OW, k, stride, pt, pl)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        x, w = ctx.saved_tensors
+        B, C, H, W, OH, OW, k, stride, pt, pl = ctx.cfg
+        dy = _c(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            L.dwconv2d_bwd_data(dy, w, dx, B, C, H, W, OH, OW, k, stride, pt, pl)
+        if ctx.needs_input_grad[1]:
+            part = _empty(x, B, C * k * k)
+            L.dwconv2d_bwd_weight(dy, x, part, B, C, H, W, OH, OW, k, stride, pt, pl)
+            dw = _empty(x, C * k * k)
+            L.colsum(part, dw, _empty(x, L.colreduce_ws(B, C * k * k, 1)), B, C * k * k)
+            dw = dw.view_as(w)
+        return dx, dw, None, None
+
+
+def dwconv2d(x, w, stride, pad):
+    """Depthwise conv; w [C,1,k,k]; pad = (left, right, top, bottom) zero padding (F.pad order)."""
+    return _DWConv.apply(x, w, int(stride), tuple(int(p) for p in pad))
+
+
+class _SqueezeExcite(torch.autograd.Function):
+    """x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)   (efficientnet/model.py:105-110).  The plane-sized work
+    (pool, scale, their backward) is HIP; the [B, C]-sized excitation MLP is a handful of tiny matmuls."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        pooled = _empty(x, B * C)
+        L.rowsum(x, pooled, B * C, S)
+        p = pooled.view(B, C) / S
+        W1, W2 = w1.reshape(w1.shape[0], C), w2.reshape(C, w1.shape[0])
+        hpre = torch.addmm(b1, p, W1.t())
+        sg = torch.sigmoid(hpre)
+        h = hpre * sg
+        gate = torch.sigmoid(torch.addmm(b2, h, W2.t()))
+        y = torch.empty_like(x)
+        L.plane_scale(x, gate.contiguous(), y, B * C, S)
+        ctx.save_for_backward(x, p, hpre, gate, W1, W2)
+        ctx.shapes = (w1.shape, w2.shape, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        x, p, hpre, gate, W1, W2 = ctx.saved_tensors
+        w1s, w2s, S = ctx.shapes
+        B, C = p.shape
+        dy = _c(dy)
+        dgate = _empty(x, B * C)
+        L.plane_dot(dy, x, dgate, B * C, S)
+        dz2 = dgate.view(B, C) * gate * (1 - gate)
+        sg = torch.sigmoid(hpre)
+        h = hpre * sg
+        dW2, db2 = dz2.t() @ h, dz2.sum(0)
+        dhpre = (dz2 @ W2) * (sg * (1 + hpre * (1 - sg)))
+        dW1, db1 = dhpre.t() @ p, dhpre.sum(0)
+        dpool = ((dhpre @ W1) / S).contiguous()
+        dx = torch.empty_like(x)
+        L.plane_scale_bwd(dy, gate.contiguous(), dpool, dx, B * C, S)
+        return dx, dW1.view(w1s), db1, dW2.view(w2s), db2
+
+
+def squeeze_excite(x, w1, b1, w2, b2):
+    return _SqueezeExcite.apply(x, w1, b1, w2, b2)
+
+
+class _SkipAdd(torch.autograd.Function):
+    """y = x * scale[b] + r: the MBConv skip connection with the per-sample drop_connect scale, one pass."""
+
+    @staticmethod
+    def forward(ctx, x, scale_b, r):
+        L = segx.lib()
+        x, r = _c(x), _c(r)
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        gate = scale_b.reshape(B, 1).expand(B, C).contiguous()
+        y = torch.empty_like(x)
+        L.plane_scale_add(x, gate, r, y, B * C, S)
+        ctx.save_for_backward(gate)
+        ctx.dims = (B * C, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        (gate,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        L.plane_scale(dy, gate, dx, *ctx.dims)
+        return dx, None, dy
+
+
+def skip_add(x, r, scale_b=None):
+    if scale_b is None:
+        scale_b = torch.ones(x.shape[0], dtype=torch.float32, device=x.device)
+    return _SkipAdd.apply(x, scale_b, r)
+
+
+# -------------------------------------------------------------------------------------------------
+# Feature-pyramid ops (fpn.hip): GroupNorm, linear resampling (+ fused lateral add)
+# -------------------------------------------------------------------------------------------------
+class _GroupNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, G, eps):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        mean, rstd = _empty(x, B * G), _empty(x, B * G)
+        L.groupnorm_fwd(x, w, b, y, mean, rstd, _empty(x, L.gn_ws(B, C, G)), B, C, G, S, eps)
+        ctx.cfg = (B, C, G, S)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        x, w, mean, rstd = ctx.saved_tensors
+        B, C, G, S = ctx.cfg
+        dx = torch.empty_like(x)
+        dw, db = _empty(x, C), _empty(x, C)
+        L.groupnorm_bwd(_c(dy), x, w, mean, rstd, dx, dw, db, _empty(x, L.gn_ws(B, C, G)), B, C, G, S)
+        return dx, dw, db, None, None
+
+
+def group_norm(x, gn):
+    """nn.GroupNorm module `gn` as parameter container."""
+    return _GroupNorm.apply(x, gn.weight, gn.bias, int(gn.num_groups), float(gn.eps))
+
+
+def _dhw(shape):
+    sp = tuple(int(v) for v in shape)
+    return (1,) + sp if len(sp) == 2 else sp
+
+
+class _InterpAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, base, size):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[:2]
+        d, h, w = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        out = _empty(x, B, C, *size)
+        L.interp_fwd(x, _c(base) if base is not None else None, out, B * C, d, h, w, D, H, W)
+        ctx.cfg = (B * C, d, h, w, D, H, W, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        planes, d, h, w, D, H, W, xshape = ctx.cfg
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(dy, *xshape)
+            L.interp_bwd(dy, dx, planes, d, h, w, D, H, W)
+        return dx, (dy if ctx.needs_input_grad[1] else None), None
+
+
+def interp_linear(x, size, base=None):
+    """F.interpolate(x, size, mode='bilinear'/'trilinear', align_corners=False) (+ base): NC[D]HW in, NC[D']H'W' out."""
+    return _InterpAdd.apply(x, base, tuple(int(s) for s in size))

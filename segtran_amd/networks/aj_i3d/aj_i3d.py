@@ -5,8 +5,8 @@ dynamic TF-'same' zero padding of N7 (front = pad // 2; aj_i3d.py:8-30, 68-90) a
 (`MaxPool3d_2a_3x3` = Identity, :206-210).
 
 Kernel status: the 38 1x1x1 convolutions run on libsegx's MFMA GEMM.  The 7x7x7 stem, the 19 3x3x3
-convolutions (implicit-GEMM MFMA kernels are the next round's K20 work), BatchNorm3d, ReLU and the max
-pools are still ATen/MIOpen calls.
+convolutions (implicit-GEMM MFMA kernels are the next round's K20 work) and the max pools are still
+ATen/MIOpen calls; BatchNorm3d+ReLU is one fused libsegx kernel (backbone.hip).
 """
 import torch
 import torch.nn as nn
@@ -46,8 +46,8 @@ class Unit3D(nn.Module):
             x = SF.conv1x1(x, self.conv3d.weight, self.conv3d.bias)            # libsegx MFMA GEMM
         else:
             x = F.conv3d(_same_pad(x, self._kernel_shape, self._stride), self.conv3d.weight, self.conv3d.bias, self._stride)
-        if self._use_batch_norm:
-            x = self.bn(x)
+        if self._use_batch_norm:                                               # fused BatchNorm3d (+ReLU), libsegx
+            return SF.bn_act(x, self.bn, SF.ACT_RELU if self._activation_fn is F.relu else SF.ACT_NONE)
         if self._activation_fn is not None:
             x = self._activation_fn(x)
         return x

@@ -8,8 +8,8 @@ Built: eff-b* backbones, in_fpn '34' / out_fpn '1234' with scheme 'AN' and Group
 trainer forces / defaults to).  ResNet / EfficientNet-V2 backbones, BN FPNs, modalities and the global-bias
 ablation are outside the hot path and raise.
 
-Kernel status: fusion encoder and every 1x1 conv on libsegx; bilinear resampling, GroupNorm and the mask
-pooling are still ATen calls (HBM-bound K15-K18 kernels: next round).
+Kernel status: fusion encoder, every 1x1 conv (MFMA GEMM), GroupNorm and the bilinear resampling with the fused
+lateral addition run on libsegx; the foreground-mask pooling (K15, [B,H/8,W/8] booleans) is still an ATen call.
 """
 import numpy as np
 import torch
@@ -69,8 +69,9 @@ class _Conv1x1(nn.Conv2d):
         return SF.conv1x1(x, self.weight, self.bias)
 
 
-def _up(x, size):
-    return F.interpolate(x, size=tuple(size), mode='bilinear', align_corners=False)
+def _up(x, size, base=None):
+    """bilinear resize (align_corners=False) with the FPN lateral `base` added in the same libsegx pass."""
+    return SF.interp_linear(x, size, base)
 
 
 class Segtran2d(SegtranInitWeights):
@@ -130,16 +131,16 @@ class Segtran2d(SegtranInitWeights):
 
     def in_fpn_forward(self, feats, nonzero_mask, B):
         f3, f4 = feats[3], feats[4]
-        cur = self.in_gn4b(self.in_fpn34_conv(f3) + _up(f4, f3.shape[2:]))
+        cur = SF.group_norm(_up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3)), self.in_gn4b)     # 'AN': add, then normalise
         cur = self.in_fpn_bridgeconv(cur)
         H2, W2 = cur.shape[2:]
         vfeat = cur.permute(0, 2, 3, 1).reshape(B, H2 * W2, self.trans_in_dim)
         return vfeat, nonzero_mask.reshape(B, -1), H2, W2
 
     def out_fpn_forward(self, feats, vfeat_fused, B0):
-        cur = self.out_gn2b(self.out_fpn12_conv(feats[1]) + _up(feats[2], feats[1].shape[2:]))
-        cur = self.out_gn3b(self.out_fpn23_conv(cur) + _up(feats[3], cur.shape[2:]))
-        return self.out_fpn_bridgeconv(cur) + _up(vfeat_fused, cur.shape[2:])
+        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv(feats[1])), self.out_gn2b)
+        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv(cur)), self.out_gn3b)
+        return _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv(cur))
 
     def forward(self, batch):
         self.feature_maps = []

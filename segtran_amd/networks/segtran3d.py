@@ -6,7 +6,8 @@ GroupNorm), D_pool_K depth pooling with 'interp' un-pooling -- i.e. the configur
 The reference's hard-coded device='cuda' (segtran3d.py:464, N8) is replaced by the input's device.
 
 Kernel status: fusion encoder and every 1x1x1 conv (incl. the 832->1024 out-FPN bridge = 256 GFLOP/volume)
-on libsegx; trilinear resampling, GroupNorm and 3^3 / 7^3 convolutions are still ATen/MIOpen calls.
+on libsegx, as are GroupNorm, the trilinear resampling (with the fused lateral add) and BatchNorm3d+ReLU; the 3^3 / 7^3
+convolutions and the max pools are still ATen/MIOpen calls.
 """
 import torch
 import torch.nn as nn
@@ -69,8 +70,9 @@ class _Conv1x1x1(nn.Conv3d):
         return SF.conv1x1(x, self.weight, self.bias)
 
 
-def _up(x, size):
-    return F.interpolate(x, size=tuple(size), mode='trilinear', align_corners=False)
+def _up(x, size, base=None):
+    """trilinear resize (align_corners=False) with the FPN lateral `base` added in the same libsegx pass."""
+    return SF.interp_linear(x, size, base)
 
 
 class Segtran3d(SegtranInitWeights):
@@ -135,7 +137,7 @@ class Segtran3d(SegtranInitWeights):
 
     def in_fpn_forward(self, feats, nonzero_mask):
         f3, f4 = feats[3], feats[4]
-        cur = self.in_gn4b(self.in_fpn34_conv(f3) + _up(f4, f3.shape[2:]))
+        cur = SF.group_norm(_up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3)), self.in_gn4b)
         cur = self.in_fpn_bridgeconv(cur)
         dp = [cur.shape[2] // self.D_pool_K, cur.shape[3], cur.shape[4]]
         cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
@@ -145,9 +147,9 @@ class Segtran3d(SegtranInitWeights):
         return vfeat, m.reshape(B, -1), D2, H2, W2
 
     def out_fpn_forward(self, feats, vfeat_fused):
-        cur = self.out_gn2b(self.out_fpn12_conv3d(feats[1]) + _up(feats[2], feats[1].shape[2:]))
-        cur = self.out_gn3b(self.out_fpn23_conv3d(cur) + _up(feats[3], cur.shape[2:]))
-        out = self.out_fpn_bridgeconv3d(cur) + _up(vfeat_fused, cur.shape[2:])
+        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv3d(feats[1])), self.out_gn2b)
+        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv3d(cur)), self.out_gn3b)
+        out = _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv3d(cur))
         if self.D_pool_K > 1:
             out = _up(out, [out.shape[2] * self.D_pool_K, out.shape[3], out.shape[4]])
         return out

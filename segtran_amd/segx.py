@@ -178,6 +178,62 @@ class SegxLib:
     def seg_loss_bwd(self, logits, mask, pw, cw, ws, gout, dlogits, B, C, S, dice_w):
         self._call('segx_seg_loss_bwd', logits, logits, mask, pw, cw, ws, gout, dlogits, B, C, S, dice_w)
 
+    # ---- backbone kernels (backbone.hip) ------------------------------------------------------------
+    def bn_ws(self, B, C):
+        return int(self.c.segx_bn_ws_floats(B, C))
+
+    def bn_stats(self, X, mean, var, run_mean, run_var, ws, B, C, S, momentum):
+        self._call('segx_bn_stats', X, X, mean, var, run_mean, run_var, ws, B, C, S, momentum)
+
+    def bn_act_fwd(self, X, mean, var, w, b, Y, B, C, S, eps, act):
+        self._call('segx_bn_act_fwd', X, X, mean, var, w, b, Y, B, C, S, eps, act)
+
+    def bn_act_bwd(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training):
+        self._call('segx_bn_act_bwd', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training)
+
+    def dwconv2d_fwd(self, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl):
+        self._call('segx_dwconv2d_fwd', X, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl)
+
+    def dwconv2d_bwd_data(self, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl):
+        self._call('segx_dwconv2d_bwd_data', dY, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl)
+
+    def dwconv2d_bwd_weight(self, dY, X, part, B, C, H, Wd, OH, OW, k, stride, pt, pl):
+        self._call('segx_dwconv2d_bwd_weight', dY, dY, X, part, B, C, H, Wd, OH, OW, k, stride, pt, pl)
+
+    def plane_scale(self, X, gate, Y, planes, S):
+        self._call('segx_plane_scale', X, X, gate, Y, planes, S)
+
+    def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act):
+        self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act)
+
+    def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n):
+        self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n)
+
+    def plane_scale_add(self, X, gate, R, Y, planes, S):
+        self._call('segx_plane_scale_add', X, X, gate, R, Y, planes, S)
+
+    def plane_dot(self, A, B, out, planes, S):
+        self._call('segx_plane_dot', A, A, B, out, planes, S)
+
+    def plane_scale_bwd(self, dY, gate, dpool, dX, planes, S):
+        self._call('segx_plane_scale_bwd', dY, dY, gate, dpool, dX, planes, S)
+
+    # ---- feature-pyramid kernels (fpn.hip) ----------------------------------------------------------
+    def gn_ws(self, B, C, G):
+        return int(self.c.segx_gn_ws_floats(B, C, G))
+
+    def groupnorm_fwd(self, X, w, b, Y, mean, rstd, ws, B, C, G, S, eps):
+        self._call('segx_groupnorm_fwd', X, X, w, b, Y, mean, rstd, ws, B, C, G, S, eps)
+
+    def groupnorm_bwd(self, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S):
+        self._call('segx_groupnorm_bwd', X, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S)
+
+    def interp_fwd(self, inp, base, out, planes, d, h, w, D, H, W):
+        self._call('segx_interp_linear_fwd', inp, inp, base, out, planes, d, h, w, D, H, W)
+
+    def interp_bwd(self, dout, din, planes, d, h, w, D, H, W):
+        self._call('segx_interp_linear_bwd', dout, dout, din, planes, d, h, w, D, H, W)
+
     def mt_bertadam_step(self, tabs, ntensors, nchunks, chunk, max_global, max_tensor, sched, b1, b2, eps, ws):
         """tabs: dict of device tensors params/grads/m/v (int64 pointer tables), sizes, chunk_tensor, chunk_off,
         chunk_first, active, lr, wd."""
@@ -200,6 +256,13 @@ _SIGS = {
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
+    'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
+    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip',
+    'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
+    'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
+    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
+    'segx_plane_scale_bwd': 'ppppllp', 'segx_plane_scale_add': 'ppppllp',
+    'segx_bn_act_bwd_reduce': 'pppppppppiilfip', 'segx_bn_act_bwd_apply': 'pppppppppiilfifp',
 }
 
 _LIB = None

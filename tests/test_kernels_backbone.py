@@ -1,0 +1,119 @@
+"""backbone.hip kernels (BatchNorm+act, depthwise conv, squeeze-excite) vs plain PyTorch fp32 autograd.
+Runs on the fiber emulator here and on the HIP build under -m gpu."""
+import pytest
+import torch
+import torch.nn.functional as F
+from segtran_amd import functional as SF
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, device='cpu') * scale).to(torch.get_default_device())
+
+
+def close(a, b, tol=3e-5):
+    s = max(b.abs().max().item(), 1e-20)
+    err = (a - b).abs().max().item()
+    assert err <= tol * s, 'err %.3e scale %.3e' % (err, s)
+
+
+def _act(u, act):
+    return u * torch.sigmoid(u) if act == 1 else F.relu(u) if act == 2 else u
+
+
+@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 4, 3, 4, 5), (2, 7, 8, 8)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_act(backend, shape, act, training):
+    C = shape[1]
+    cls = torch.nn.BatchNorm2d if len(shape) == 4 else torch.nn.BatchNorm3d
+    bn, ref = cls(C, eps=1e-3, momentum=0.01), cls(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        for m in (bn, ref):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=1)); m.bias.copy_(0.2 * rnd(C, seed=2))
+            m.running_mean.copy_(0.1 * rnd(C, seed=3)); m.running_var.copy_(1 + 0.1 * rnd(C, seed=4).abs())
+    bn.train(training); ref.train(training)
+    x = (rnd(*shape, seed=5) * 1.7 + 0.4).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = SF.bn_act(x, bn, act)
+    yr = _act(ref(xr), act)
+    close(y, yr.detach())
+    G = rnd(*shape, seed=6)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+    close(bn.weight.grad, ref.weight.grad, 1e-4); close(bn.bias.grad, ref.bias.grad, 1e-4)
+    close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize('k,stride,pad,H,W', [(3, 1, (1, 1, 1, 1), 20, 18), (5, 1, (2, 2, 2, 2), 17, 33), (3, 2, (0, 1, 0, 1), 32, 32),
+                                              (5, 2, (2, 2, 2, 2), 16, 16), (5, 2, (1, 2, 1, 2), 24, 40), (3, 2, (0, 1, 0, 1), 7, 9)])
+def test_dwconv2d(backend, k, stride, pad, H, W):
+    B, C = 2, 5
+    x = rnd(B, C, H, W, seed=7).requires_grad_(True)
+    w = rnd(C, 1, k, k, seed=8).requires_grad_(True)
+    y = SF.dwconv2d(x, w, stride, pad)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, pad), wr, None, stride, 0, 1, C)
+    assert y.shape == yr.shape
+    close(y, yr.detach())
+    G = rnd(*y.shape, seed=9)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4); close(w.grad, wr.grad, 1e-4)
+
+
+def test_squeeze_excite(backend):
+    B, C, Cs, H, W = 3, 12, 4, 9, 7
+    x = rnd(B, C, H, W, seed=10).requires_grad_(True)
+    ps = [rnd(Cs, C, 1, 1, seed=11, scale=0.5), rnd(Cs, seed=12, scale=0.1), rnd(C, Cs, 1, 1, seed=13, scale=0.5), rnd(C, seed=14, scale=0.1)]
+    ps = [p.requires_grad_(True) for p in ps]
+    y = SF.squeeze_excite(x, *ps)
+    xr = x.detach().clone().requires_grad_(True)
+    pr = [p.detach().clone().requires_grad_(True) for p in ps]
+    sq = F.adaptive_avg_pool2d(xr, 1)
+    sq = F.conv2d(sq, pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
+    yr = torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * xr
+    close(y, yr.detach())
+    G = rnd(B, C, H, W, seed=15)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+    for a, r in zip(ps, pr):
+        close(a.grad, r.grad, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(2, 16, 6, 10), (3, 8, 3, 4, 5), (1, 24, 9, 9)])
+def test_group_norm(backend, shape):
+    C = shape[1]
+    gn, ref = torch.nn.GroupNorm(8, C), torch.nn.GroupNorm(8, C)
+    with torch.no_grad():
+        for m in (gn, ref):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=1)); m.bias.copy_(0.2 * rnd(C, seed=2))
+    x = (rnd(*shape, seed=3) * 1.3 + 0.7).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = SF.group_norm(x, gn); yr = ref(xr)
+    close(y, yr.detach())
+    G = rnd(*shape, seed=4)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4); close(gn.weight.grad, ref.weight.grad, 1e-4); close(gn.bias.grad, ref.bias.grad, 1e-4)
+
+
+@pytest.mark.parametrize('inshape,size', [((2, 3, 4, 5), (8, 10)), ((1, 2, 7, 7), (14, 14)), ((2, 2, 8, 6), (16, 24)), ((1, 3, 16, 16), (13, 9)),
+                                          ((1, 2, 3, 4, 5), (6, 8, 10)), ((2, 2, 6, 7, 7), (12, 14, 14)), ((1, 2, 4, 3, 3), (4, 12, 12)),
+                                          ((1, 2, 8, 5, 5), (4, 5, 5)), ((1, 1, 12, 14, 14), (48, 56, 56))])
+@pytest.mark.parametrize('with_base', [False, True])
+def test_interp_linear(backend, inshape, size, with_base):
+    mode = 'bilinear' if len(size) == 2 else 'trilinear'
+    x = rnd(*inshape, seed=5).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    base = rnd(*(inshape[:2] + tuple(size)), seed=6).requires_grad_(True) if with_base else None
+    br = base.detach().clone().requires_grad_(True) if with_base else None
+    y = SF.interp_linear(x, size, base)
+    yr = F.interpolate(xr, size=size, mode=mode, align_corners=False)
+    if with_base:
+        yr = yr + br
+    close(y, yr.detach(), 1e-5)
+    G = rnd(*y.shape, seed=7)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-5)
+    if with_base:
+        close(base.grad, br.grad, 1e-6)

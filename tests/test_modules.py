@@ -107,3 +107,53 @@ def test_training_dropout_runs_and_is_reproducible(backend):
     assert not torch.allclose(mod(X), y1)
     y1.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize('k,s,e,cin,cout,pad,train', [(3, 1, 6, 8, 8, (1, 1), True), (5, 2, 6, 8, 12, (1, 2), True),
+                                                      (3, 1, 1, 8, 8, (1, 1), False), (5, 1, 6, 8, 8, (2, 2), False)])
+def test_mbconv_block_vs_oracle(backend, k, s, e, cin, cout, pad, train):
+    """Product MBConvBlock (libsegx GEMM + depthwise + BN/swish + SE + skip kernels) vs the oracle's restatement."""
+    from oracle import segtran_oracle as O
+    from segtran_amd.efficientnet.model import MBConvBlock
+    blk = MBConvBlock(k, s, e, cin, cout, 0.25, 16)
+    blk._depthwise_conv.static_pad = (pad[0], pad[1], pad[0], pad[1])
+    prefix = 'backbone._blocks.3.'
+    sd = synth_state_dict({prefix + n: tuple(v.shape) for n, v in blk.state_dict().items()})
+    blk.load_state_dict({n[len(prefix):]: v for n, v in sd.items()})
+    blk.to(backend.dev)
+    blk.train(train)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(2, cin, 12, 10, generator=g, device='cpu')
+    xo = x.clone().requires_grad_(True)
+    sdo = {n: (v.clone().requires_grad_(True) if v.is_floating_point() and 'running' not in n else v.clone()) for n, v in sd.items()}
+    yo = O.mbconv(sdo, prefix[:-1], xo, dict(k=k, s=s, e=e, cin=cin, cout=cout, pad=pad), train)
+    xp = x.to(backend.dev).requires_grad_(True)
+    y = blk(xp)
+    assert_close(y, yo, 3e-5, 'mbconv y')
+    G = torch.randn(*yo.shape, generator=g, device='cpu')
+    yo.backward(G); y.backward(G.to(backend.dev))
+    assert_close(xp.grad, xo.grad, 3e-4, 'mbconv dx')
+    gs = max(v.grad.abs().max().item() for v in sdo.values() if v.is_floating_point() and v.grad is not None)
+    for n, p in blk.named_parameters():
+        assert_close(p.grad, sdo[prefix + n].grad, 3e-4, n, scale=gs)
+
+
+def test_i3d_unit_vs_oracle(backend):
+    from oracle import segtran_oracle as O
+    from segtran_amd.networks.aj_i3d.aj_i3d import Unit3D
+    for kshape, stride in (((1, 1, 1), (1, 1, 1)), ((3, 3, 3), (1, 1, 1))):
+        u = Unit3D(6, 10, kshape, stride)
+        prefix = 'backbone.Mixed_3b.b1b.'
+        sd = synth_state_dict({prefix + n: tuple(v.shape) for n, v in u.state_dict().items()})
+        u.load_state_dict({n[len(prefix):]: v for n, v in sd.items()})
+        u.to(backend.dev).train()
+        g = torch.Generator(device='cpu').manual_seed(6)
+        x = torch.randn(2, 6, 4, 6, 5, generator=g, device='cpu')
+        xo = x.clone().requires_grad_(True)
+        yo = O.unit3d(sd, prefix[:-1], xo, kshape, stride, training=True)
+        xp = x.to(backend.dev).requires_grad_(True)
+        y = u(xp)
+        assert_close(y, yo, 3e-5, 'unit3d y')
+        G = torch.randn(*yo.shape, generator=g, device='cpu')
+        yo.backward(G); y.backward(G.to(backend.dev))
+        assert_close(xp.grad, xo.grad, 3e-4, 'unit3d dx')
