@@ -100,7 +100,7 @@ def main():
     torch.manual_seed(1234)
     SF.manual_seed(1234 + rank)
     net = engine.build_model(args.config, dev)
-    net = sdist.convert_sync_batchnorm(net)
+    sdist.enable_sync_batchnorm()
     net.train()
     opt = engine.init_optimizer(net, c['task'])
     reducer = sdist.GradReducer(opt) if world > 1 else None

@@ -6,8 +6,8 @@ Reference behaviour being replaced: torch DDP + SyncBatchNorm (train2d.py:796-80
     large buckets (xGMI links are point-to-point, ~153 GB/s each: few big collectives beat many small ones) and
     averaged; parameters that never receive gradients (N3) are simply zeros in the buffer -- no
     `find_unused_parameters` graph walk is needed;
-  * BatchNorm statistics are synchronised with torch's SyncBatchNorm (plumbing; batching its per-layer
-    collectives is listed in DESIGN.md as open work).
+  * BatchNorm statistics are synchronised inside libsegx's fused BN(+activation) op: one small all-gather per BN
+    layer forward, one small all-reduce backward (`enable_sync_batchnorm`).
 """
 import os
 import torch
@@ -57,7 +57,40 @@ def reduce_scalars(t, group=None):
     return t
 
 
-def convert_sync_batchnorm(net):
-    if dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
-        return torch.nn.SyncBatchNorm.convert_sync_batchnorm(net)
-    return net
+def enable_sync_batchnorm(group=None):
+    """Synchronised BatchNorm for libsegx's fused BN(+act) op (replaces nn.SyncBatchNorm, train2d.py:1109).
+
+    forward : ONE all-gather of [2C+1] floats per BN layer (mean, biased var, count) merged with Chan's formula;
+    backward: ONE all-reduce of [2C] floats (sum du*xhat, sum du); the apply kernel then uses the global sums / count.
+    Parameter gradients stay LOCAL sums (the flat-gradient all-reduce averages them like every other gradient)."""
+    from . import functional as SF
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        SF._bn_stats_sync = SF._bn_grad_sync = None
+        return False
+    world = dist.get_world_size(group)
+
+    def stats_sync(mean, var, n_local):
+        C = mean.numel()
+        loc = torch.cat([mean, var, mean.new_full((1,), float(n_local))])
+        allv = loc.new_empty(world * (2 * C + 1))
+        dist.all_gather_into_tensor(allv, loc, group=group)
+        allv = allv.view(world, 2 * C + 1)
+        means, vars_, ns = allv[:, :C], allv[:, C:2 * C], allv[:, 2 * C:]
+        N = ns.sum()
+        gmean = (means * ns).sum(0) / N
+        gvar = ((vars_ + (means - gmean) ** 2) * ns).sum(0) / N
+        return gmean.contiguous(), gvar.contiguous(), int(round(float(N)))
+
+    def grad_sync(dw, db):
+        both = torch.cat([dw, db])
+        dist.all_reduce(both, op=dist.ReduceOp.SUM, group=group)
+        C = dw.numel()
+        return both[:C].contiguous(), both[C:].contiguous()
+
+    SF._bn_stats_sync, SF._bn_grad_sync = stats_sync, grad_sync
+    return True
+
+
+def disable_sync_batchnorm():
+    from . import functional as SF
+    SF._bn_stats_sync = SF._bn_grad_sync = None
