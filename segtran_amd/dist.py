@@ -79,7 +79,9 @@ def enable_sync_batchnorm(group=None):
         N = ns.sum()
         gmean = (means * ns).sum(0) / N
         gvar = ((vars_ + (means - gmean) ** 2) * ns).sum(0) / N
-        return gmean.contiguous(), gvar.contiguous(), int(round(float(N)))
+        # every rank holds the same per-GPU batch (bs // world, train2d.py:791): the global count is known on the
+        # host without reading N back (a .item() here would be 96 host syncs per step)
+        return gmean.contiguous(), gvar.contiguous(), int(n_local) * world
 
     def grad_sync(dw, db):
         both = torch.cat([dw, db])

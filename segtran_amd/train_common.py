@@ -1,0 +1,169 @@
+"""Shared trainer skeleton for the `--net segtran` path of the reference's train2d.py / train3d.py.
+
+Same flag names / dests / defaults for everything the segtran path reads (train2d.py:58-243, train3d.py:51-172),
+same defaults table (train2d.py:266-385: BertAdam, lr 2e-4, decay 1e-4, grad_clip 0.1, dropout 0.2, 4 modes), same
+launcher contract (`python -m torch.distributed.run --nproc_per_node=N -m segtran_amd.train2d ...`, `--local_rank`
+/ env://, `--bs` = GLOBAL batch, `args.batch_size //= world_size`, train2d.py:791), same checkpoint wire format
+(`{'iter_num', 'model', 'args'}` every `--saveiter`, rank 0; train2d.py:640-648).
+
+Out of scope here: the file loaders / imgaug pipelines.  Batches come from
+`segtran_amd.engine.synth_batch` (the BASELINE.md synthetic inputs) unless the caller passes its own iterator of
+(image, raw_mask) tensors to `run()`.  Flags that select reference features outside the hot path are accepted and
+rejected with a clear message instead of being silently ignored.
+"""
+import argparse
+import logging
+import os
+import time
+from datetime import datetime
+
+import torch
+
+from . import engine, dist as sdist, functional as SF
+
+UNSUPPORTED = {'polyformer_mode': None, 'adversarial_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
+               'use_mince_transformer': False, 'use_attn_consist_loss': False, 'has_FFN_in_squeeze': False,
+               'in_fpn_use_bn': False, 'out_fpn_do_dropout': False, 'tune_bn_only': False}
+
+
+def common_flags(p, dim):
+    p.add_argument('--task', dest='task_name', type=str, default='fundus' if dim == 2 else 'brats')
+    p.add_argument('--ds', dest='ds_names', type=str, default=None, help='(file datasets are out of scope: synthetic batches are used)')
+    p.add_argument('--split', dest='ds_split', type=str, default='all')
+    p.add_argument('--maxiter', type=int, default=10000)
+    p.add_argument('--saveiter', type=int, default=500)
+    p.add_argument('--cp', dest='checkpoint_path', type=str, default=None)
+    p.add_argument('--lrwarmup', dest='lr_warmup_steps', type=int, default=500)
+    p.add_argument('--bs', dest='batch_size', type=int, default=6 if dim == 2 else 4, help='Total batch_size on all GPUs')
+    p.add_argument('--opt', type=str, default=None)
+    p.add_argument('--lr', type=float, default=-1)
+    p.add_argument('--decay', type=float, default=-1)
+    p.add_argument('--gradclip', dest='grad_clip', type=float, default=-1)
+    p.add_argument('--attnclip', dest='attn_clip', type=int, default=500)
+    p.add_argument('--local_rank', default=0, type=int)
+    p.add_argument('--diceweight', dest='MAX_DICE_W', type=float, default=0.5)
+    p.add_argument('--seed', type=int, default=1337)
+    p.add_argument('--debug', dest='debug', action='store_true')
+    p.add_argument('--net', type=str, default='segtran')
+    p.add_argument('--nopretrain', dest='use_pretrained', action='store_false')
+    p.add_argument('--nosqueeze', dest='use_squeezed_transformer', action='store_false')
+    p.add_argument('--attractors', dest='num_attractors', default=256 if dim == 2 else 1024, type=int)
+    p.add_argument('--noqkbias', dest='qk_have_bias', action='store_false')
+    p.add_argument('--translayers', dest='num_translayers', default=1, type=int)
+    p.add_argument('--layercompress', dest='translayer_compress_ratios', type=str, default=None)
+    p.add_argument('--modes', type=int, dest='num_modes', default=-1)
+    p.add_argument('--multihead', dest='ablate_multihead', action='store_true')
+    p.add_argument('--dropout', type=float, dest='dropout_prob', default=-1)
+    p.add_argument('--pos', dest='pos_code_type', type=str, default='lsinu')
+    p.add_argument('--posw', dest='pos_code_weight', type=float, default=1.0)
+    p.add_argument('--posr', dest='pos_bias_radius', type=int, default=7)
+    p.add_argument('--squeezeuseffn', dest='has_FFN_in_squeeze', action='store_true')
+    p.add_argument('--attnconsist', dest='use_attn_consist_loss', action='store_true')
+    p.add_argument('--mince', dest='use_mince_transformer', action='store_true')
+    p.add_argument('--infpn', dest='in_fpn_layers', default='34')
+    p.add_argument('--outfpn', dest='out_fpn_layers', default='1234')
+    p.add_argument('--outdrop', dest='out_fpn_do_dropout', action='store_true')
+    p.add_argument('--inbn', dest='in_fpn_use_bn', action='store_true')
+    p.add_argument('--nofeatup', dest='bb_feat_upsize', action='store_false')
+    p.add_argument('--logiter', type=int, default=50, help='host-side logging period (each log line synchronises the device)')
+    return p
+
+
+def finalize_args(args, dim):
+    if args.net != 'segtran':
+        raise SystemExit("only --net segtran is built (the reference's other models are out of scope, SURVEY.md section 2)")
+    for k, v in UNSUPPORTED.items():
+        if getattr(args, k, v) != v:
+            raise SystemExit('--%s selects a reference feature outside the MI355X hot path (SURVEY.md 8(f))' % k)
+    if args.opt not in (None, 'adamw'):
+        raise SystemExit("segtran default optimiser is BertAdam ('adamw' in the reference's table); other --opt values are not built")
+    d = engine.DEFAULTS
+    args.lr = d['lr'] if args.lr < 0 else args.lr
+    args.decay = d['decay'] if args.decay < 0 else args.decay
+    args.grad_clip = d['grad_clip'] if args.grad_clip < 0 else args.grad_clip
+    args.dropout_prob = d['dropout_prob'] if args.dropout_prob < 0 else args.dropout_prob
+    args.num_modes = d['num_modes'] if args.num_modes < 0 else args.num_modes
+    if args.translayer_compress_ratios is not None:
+        args.translayer_compress_ratios = [int(c) for c in str(args.translayer_compress_ratios).split(',')]
+    else:
+        args.translayer_compress_ratios = [1] * (args.num_translayers + 1)
+    return args
+
+
+def make_cfg(args, dim, size, num_classes):
+    return dict(dim=dim, task=args.task_name, num_classes=num_classes, translayers=args.num_translayers,
+                compress=args.translayer_compress_ratios, attractors=args.num_attractors, bs=args.batch_size, size=tuple(size))
+
+
+def save_model(net, args, ckpt_dir, iter_num):
+    """train2d.py:640-648 wire format."""
+    os.makedirs(ckpt_dir, exist_ok=True)
+    path = os.path.join(ckpt_dir, 'iter_%d.pth' % iter_num)
+    a = {k: v for k, v in vars(args).items() if not isinstance(v, torch.Tensor)}
+    torch.save({'iter_num': iter_num, 'model': net.state_dict(), 'args': a}, path)
+    logging.info('save model to %s', path)
+    return path
+
+
+def load_model(net, args, path):
+    """Tolerant partial load as train2d.py:567-638 (drops attn_scaler keys, keeps matching shapes)."""
+    ck = torch.load(path, map_location='cpu')
+    sd = ck.get('model', ck)
+    own = net.state_dict()
+    keep = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape) and 'attn_scaler' not in k}
+    own.update(keep)
+    net.load_state_dict(own)
+    logging.info('loaded %d/%d tensors from %s', len(keep), len(own), path)
+    return int(ck.get('iter_num', 0)) if isinstance(ck, dict) else 0
+
+
+def run(args, cfg, batches=None):
+    """The hot loop (train2d.py:1134-1389 / train3d.py:699-811) for --net segtran."""
+    rank, local, world = sdist.init_distributed()
+    args.world_size, args.distributed = world, world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit('segtran_amd trainers need an MI355X: the product path has no CPU fallback')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    args.batch_size //= world                                             # --bs is the GLOBAL batch (train2d.py:791)
+    if args.batch_size < 1:
+        raise SystemExit('--bs %d is smaller than the world size %d' % (args.batch_size * world, world))
+    torch.manual_seed(args.seed); SF.manual_seed(args.seed + rank)
+    is_master = rank == 0
+    ts = datetime.now().strftime('%m%d%H%M')
+    ckpt_dir = os.path.join('..', 'model', '%s-%s-%s' % (args.net, args.task_name, ts))
+    logging.basicConfig(level=logging.INFO if is_master else logging.WARNING, format='[%(asctime)s] %(message)s', datefmt='%H:%M:%S')
+
+    net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=not args.checkpoint_path)
+    iter_num = load_model(net, args, args.checkpoint_path) if args.checkpoint_path else 0
+    if dim_of(cfg) == 2:
+        iter_num = 0                                                      # train2d.py:1078-1081 always restarts the count
+    sdist.enable_sync_batchnorm()
+    net.train()
+    opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
+                                decay=args.decay, grad_clip=args.grad_clip)
+    reducer = sdist.GradReducer(opt) if world > 1 else None
+    step = engine.TrainStep(net, opt, args.task_name, reducer)
+    if batches is None:
+        fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
+        batches = iter(lambda: fixed, None)
+    t0 = time.time()
+    for x, raw in batches:
+        iter_num += 1
+        step(x.to(dev, non_blocking=True), raw.to(dev, non_blocking=True))
+        if iter_num % args.logiter == 0 or iter_num == args.maxiter:
+            stats = sdist.reduce_scalars(step.stats.detach())            # ONE collective for all logged scalars (C3)
+            if is_master:
+                s = stats.tolist()
+                logging.info('%d loss: %.4f, ce: %.4f, dice: %.4f (%s), lr %.2e, %.1f it/s', iter_num, s[0], s[1], s[2],
+                             ', '.join('%.3f' % v for v in s[4:]), opt.get_lr()[0], args.logiter / max(time.time() - t0, 1e-9))
+            t0 = time.time()
+        if is_master and (iter_num % args.saveiter == 0 or iter_num == args.maxiter):
+            save_model(net, args, ckpt_dir, iter_num)
+        if iter_num >= args.maxiter:
+            break
+    return net
+
+
+def dim_of(cfg):
+    return cfg['dim']
