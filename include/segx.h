@@ -187,6 +187,25 @@ int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const fl
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);
 int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
+/* separable form: adjoint along ONE axis of a tensor viewed as [outer, n_out, inner] -> [outer, n_in, inner] */
+int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inception-I3D spatial convolutions as implicit GEMM on the fp32 MFMA engine + TF-'same' max-pool (conv3d.hip).
+ * NCDHW fp32.  geom (int32[16]) = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}, p* = FRONT zero
+ * pads of the dynamic 'same' padding (aj_i3d.py:68-90: front = pad // 2).  nn.Conv3d at aj_i3d.py:57-62,92.
+ * ------------------------------------------------------------------------------------------- */
+int segx_conv3d_fwd(const float* X, const float* W /* [Cout][Cin][KD][KH][KW] */, float* Y, int B, int Cout, const int* geom, void* stream);
+/* Wt[ci][co][t] = W[co][ci][KV-1-t]: backward-data of a stride-1 conv = segx_conv3d_fwd(dY, Wt) with pads K-1-p */
+int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream);
+/* per-sample weight gradients dWb[B][Cout][Cin*KV] (sum over B with segx_colsum); split-K over output positions:
+ * workspace = splitk*B*Cout*Cin*KV floats when splitk > 1 */
+int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
+                           float* workspace, void* stream);
+/* MaxPool3dSamePadding (aj_i3d.py:6-30): zero 'same' padding then max-pool.  geom (int32[15]) =
+ * {ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}; arg = arg-max index per output (-1 = a padded zero won) */
+int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t planes, const int* geom, void* stream);
+int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream);
 
 #ifdef __cplusplus
 }

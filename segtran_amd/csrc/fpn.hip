@@ -151,6 +151,21 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
     }
 }
 
+// one-axis adjoint on a tensor viewed as [outer, n, inner]: the separable form of interp_bwd_kernel (three cheap passes
+// instead of one pass with prod(2*scale+1) candidates per cell -- 10x faster for the x4 trilinear up-sampling of the 3-D FPN)
+__global__ __launch_bounds__(256) void interp_bwd_axis_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
+                                                              int n_out, int n_in, int64_t inner, float scale) {
+    const int64_t total = outer * n_in * inner;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t in_ = idx % inner; const int64_t r = idx / inner; const int i = (int)(r % n_in); const int64_t o = r / n_in;
+        int lo, hi; cand_range(i, n_out, scale, lo, hi);
+        const float* g = dout + (o * n_out) * inner + in_;
+        float acc = 0.f;
+        for (int d = lo; d <= hi; ++d) acc += axis_weight(i, d, n_in, scale) * g[(int64_t)d * inner];
+        din[idx] = acc;
+    }
+}
+
 static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -197,4 +212,11 @@ extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t pla
     const int64_t total = planes * d * h * w;
     hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, make_dims(d, h, w, D, H, W), planes);
     return check_launch("segx_interp_linear_bwd");
+}
+extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n_out > 0 && n_in > 0 && inner > 0, "segx_interp_linear_bwd_axis: bad args");
+    const int64_t total = outer * n_in * inner;
+    hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out, n_in,
+                       inner, (float)n_in / (float)n_out);
+    return check_launch("segx_interp_linear_bwd_axis");
 }

@@ -18,201 +18,20 @@
 //   row-contiguous operand -> float4 along rows, float4 LDS stores.
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
-#include "common.h"
+#include "gemm_core.h"
 
 namespace segx {
-
-constexpr int BM = 128, BN = 128, BKT = 32, LDT = 132;
-
-struct GemmArgs {
-    const float* A; const float* B; float* C;
-    const float* bias; float* aux; float* gmax;
-    int M, N, K, nb1;
-    int64_t a_b0, a_b1, a_m, a_k;
-    int64_t b_b0, b_b1, b_n, b_k;
-    int64_t c_b0, c_b1, c_m;
-    int64_t bias_b1;
-    float alpha; int epilogue, bias_mode;
-    int vecA, vecB;                 // float4 global loads legal (alignment + stride checks done on host)
-    int tiles_m, tiles_n;
-    float dropout_p; uint64_t seed, offset;
-    int k_chunk;                    // split-K: this launch covers k in [z_k*k_chunk, min(K, (z_k+1)*k_chunk))
-    int splitk; int64_t c_split;    // slab stride in the workspace
-};
-
-// Load this thread's 4 float4 pieces of a 128 x 32 operand tile into registers.
-//  KC = true : operand is k-contiguous;  piece f -> row f>>3, k-chunk f&7
-//  KC = false: operand is row-contiguous; piece f -> k-row f>>5, row-chunk f&31
-// VEC = true (16-B aligned base, all strides and extents multiples of 4): every float4 is either wholly inside
-// or wholly outside the operand, so the load is issued UNCONDITIONALLY from a clamped address and zeroed by a
-// select -- no branches, so the 8 loads of a k-tile stay in flight together (a guarded load costs an exec-mask
-// branch plus an s_waitcnt vmcnt(0) each).  VEC = false is the slow scalar path for odd shapes (K = 2, Cin = 6 ...).
-// The zeroing select is deferred to store_tile (through the returned validity mask): consuming a loaded value
-// right after the load would make the compiler wait for it BEFORE the MFMA block and lose the overlap.
-template <bool KC, bool VEC>
-__device__ __forceinline__ unsigned load_tile(float4 (&r)[4], const float* __restrict__ base, int64_t s_row, int64_t s_k,
-                                              int row0, int rows, int k0, int kend, int tid) {
-    unsigned okmask = 0xFu;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 256 * i;
-        const int row = KC ? row0 + (f >> 3) : row0 + ((f & 31) << 2);
-        const int k = KC ? k0 + ((f & 7) << 2) : k0 + (f >> 5);
-        float4 v;
-        if (VEC) {
-            const int rc = KC ? (row < rows ? row : rows - 1) : (row < rows ? row : rows - 4);
-            const int kc = KC ? (k < kend ? k : kend - 4) : (k < kend ? k : kend - 1);
-            const float* p = KC ? base + (int64_t)rc * s_row + kc : base + (int64_t)kc * s_k + rc;
-            v = *reinterpret_cast<const float4*>(p);
-            if (!((row < rows) && (k < kend))) okmask &= ~(1u << i);
-        } else {
-            v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (KC) {
-                if (row < rows && k < kend) {
-                    const float* p = base + (int64_t)row * s_row + (int64_t)k * s_k;
-                    v.x = p[0]; if (k + 1 < kend) v.y = p[s_k]; if (k + 2 < kend) v.z = p[2 * s_k]; if (k + 3 < kend) v.w = p[3 * s_k];
-                }
-            } else {
-                if (k < kend && row < rows) {
-                    const float* p = base + (int64_t)k * s_k + (int64_t)row * s_row;
-                    v.x = p[0]; if (row + 1 < rows) v.y = p[s_row]; if (row + 2 < rows) v.z = p[2 * s_row]; if (row + 3 < rows) v.w = p[3 * s_row];
-                }
-            }
-        }
-        r[i] = v;
-    }
-    return okmask;
-}
-
-template <bool KC>
-__device__ __forceinline__ void store_tile(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + 256 * i;
-        if (!((okmask >> i) & 1u)) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (KC) {
-            const int row = f >> 3, k = (f & 7) << 2;
-            T[k + 0][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
-        } else {
-            const int k = f >> 5, row = (f & 31) << 2;
-            *reinterpret_cast<float4*>(&T[k][row]) = r[i];
-        }
-    }
-}
-
-// Workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only): remap so
-// that each XCD owns a CONTIGUOUS run of tiles (bijective for any tile count), and walk N fastest inside the run, so
-// the workgroups sharing an XCD's private 4-MiB L2 also share their A row-panels / B column-panels.
-__device__ __forceinline__ int xcd_tile(int wg, int ntiles) {
-    const int q = ntiles >> 3, r = ntiles & 7, xcd = wg & 7, idx = wg >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 template <bool AKC, bool BKC, bool VEC, int EPI>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_tile(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-    const int zb = blockIdx.y;                       // batch index
-    const int zk = blockIdx.z;                       // split-K slab
-    const int z0 = zb / g.nb1, z1 = zb - z0 * g.nb1;
-    const float* A = g.A + z0 * g.a_b0 + z1 * g.a_b1;
-    const float* B = g.B + z0 * g.b_b0 + z1 * g.b_b1;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int kbeg = zk * g.k_chunk;
-    const int kend = (kbeg + g.k_chunk < g.K) ? kbeg + g.k_chunk : g.K;
-
+    const TileCoord t = tile_coord(g);
+    const DenseLoader<AKC, VEC> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
+    const DenseLoader<BKC, VEC> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (kbeg < kend) {                               // an empty split-K slab just writes zeros
-        float4 ra[4], rb[4];
-        unsigned oka = load_tile<AKC, VEC>(ra, A, g.a_m, g.a_k, m0, g.M, kbeg, kend, tid);
-        unsigned okb = load_tile<BKC, VEC>(rb, B, g.b_n, g.b_k, n0, g.N, kbeg, kend, tid);
-        store_tile<AKC>(ra, oka, As, tid);
-        store_tile<BKC>(rb, okb, Bs, tid);
-        __syncthreads();
-
-        const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kl = lane >> 5;
-        for (int k0 = kbeg; k0 < kend; k0 += BKT) {
-            const bool more = (k0 + BKT) < kend;
-            if (more) {                              // next k-tile: global loads in flight under the 64 MFMAs below
-                oka = load_tile<AKC, VEC>(ra, A, g.a_m, g.a_k, m0, g.M, k0 + BKT, kend, tid);
-                okb = load_tile<BKC, VEC>(rb, B, g.b_n, g.b_k, n0, g.N, k0 + BKT, kend, tid);
-            }
-            // operand fragments are fetched one k2-step ahead of the MFMAs that consume them
-            float a0 = As[kl][arow], a1 = As[kl][arow + 32], b0 = Bs[kl][brow], b1 = Bs[kl][brow + 32];
-#pragma unroll
-            for (int kk = 0; kk < BKT; kk += 2) {
-                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-                if (kk + 2 < BKT) {
-                    na0 = As[kk + 2 + kl][arow]; na1 = As[kk + 2 + kl][arow + 32];
-                    nb0 = Bs[kk + 2 + kl][brow]; nb1 = Bs[kk + 2 + kl][brow + 32];
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of this step's MFMAs
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
-            }
-            __syncthreads();
-            if (more) {
-                store_tile<AKC>(ra, oka, As, tid);
-                store_tile<BKC>(rb, okb, Bs, tid);
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue: MFMA C layout  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----------
-    const bool split = g.splitk > 1;
-    float* C = split ? g.C + (int64_t)zk * g.c_split + (int64_t)zb * g.M * g.N : g.C + z0 * g.c_b0 + z1 * g.c_b1;
-    const int64_t ldc = split ? g.N : g.c_m;
-    const float alpha = split ? 1.0f : g.alpha;
-    const float* bias = (g.bias && !split) ? g.bias + z1 * g.bias_b1 : nullptr;
-    const bool bias_n = bias && g.bias_mode == SEGX_BIAS_N, bias_m = bias && g.bias_mode == SEGX_BIAS_M;
-    float* AUX = (EPI == SEGX_EPI_GELU) ? g.aux + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;
-    const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
-    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
-    float vmax = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            const bool col_ok = full || col < g.N;
-            const float bn = (bias_n && col_ok) ? bias[col] : 0.f;
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const bool ok = full || (col_ok && row < g.M);
-                float v = acc[i][j][r] * alpha + bn;
-                if (bias_m) v += ok ? bias[row] : 0.f;
-                if (EPI == SEGX_EPI_GELU) {
-                    if (ok) AUX[(int64_t)row * ldc + col] = v;
-                    v = gelu_erf(v);
-                    if (g.dropout_p > 0.f)
-                        v *= dropout_scale(g.seed, g.offset, ((uint64_t)zb * g.M + row) * g.N + col, g.dropout_p, inv_keep);
-                }
-                if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
-            }
-        }
-    }
-    if (g.gmax && !split) {
-        vmax = wave_max(vmax);
-        if (lane == 0) atomicMax(reinterpret_cast<int*>(g.gmax), __float_as_int(vmax));   // vmax >= 0: int order == float order
-    }
+    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
+    gemm_epilogue<EPI>(acc, g, t);
 }
 
 // Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.

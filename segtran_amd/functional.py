@@ -670,11 +670,134 @@ class _InterpAdd(torch.autograd.Function):
         dy = _c(dy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _empty(dy, *xshape)
-            L.interp_bwd(dy, dx, planes, d, h, w, D, H, W)
+            # separable adjoint: innermost axis first (shrinks the tensor fastest), one cheap pass per resized axis
+            cur, dims = dy, [D, H, W]
+            for ax, n_in in ((2, w), (1, h), (0, d)):
+                if dims[ax] == n_in:
+                    continue
+                outer = planes
+                for a in range(ax):
+                    outer *= dims[a]
+                inner = 1
+                for a in range(ax + 1, 3):
+                    inner *= dims[a]
+                nxt = _empty(dy, outer * n_in * inner)
+                L.interp_bwd_axis(cur, nxt, outer, dims[ax], n_in, inner)
+                cur, dims[ax] = nxt, n_in
+            dx = cur.view(xshape) if cur is not dy else dy.clone().view(xshape)
         return dx, (dy if ctx.needs_input_grad[1] else None), None
 
 
 def interp_linear(x, size, base=None):
     """F.interpolate(x, size, mode='bilinear'/'trilinear', align_corners=False) (+ base): NC[D]HW in, NC[D']H'W' out."""
     return _InterpAdd.apply(x, base, tuple(int(s) for s in size))
+
+
+# -------------------------------------------------------------------------------------------------
+# I3D spatial convolutions (implicit GEMM on the MFMA engine) and TF-'same' max-pool (conv3d.hip)
+# -------------------------------------------------------------------------------------------------
+def _same_pads(size, k, s):
+    """aj_i3d.py:68-90 -- dynamic TF-'same' padding: (front, back) per axis."""
+    out = []
+    for n, kk, ss in zip(size, k, s):
+        tot = max(kk - ss, 0) if n % ss == 0 else max(kk - (n % ss), 0)
+        out.append((tot // 2, tot - tot // 2))
+    return out
+
+
+class _Conv3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, stride, pads):
+        L = segx.lib()
+        x, w = _c(x), _c(w)
+        B, Cin, ID, IH, IW = x.shape
+        Cout, _, KD, KH, KW = w.shape
+        (pd, pdb), (ph, phb), (pw, pwb) = pads
+        OD = (ID + pd + pdb - KD) // stride[0] + 1
+        OH = (IH + ph + phb - KH) // stride[1] + 1
+        OW = (IW + pw + pwb - KW) // stride[2] + 1
+        y = _empty(x, B, Cout, OD, OH, OW)
+        geom = (Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW) + tuple(stride) + (pd, ph, pw)
+        L.conv3d_fwd(x, w, y, B, Cout, geom)
+        ctx.geom, ctx.stride, ctx.pads = geom, tuple(stride), pads
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        x, w = ctx.saved_tensors
+        dy = _c(dy)
+        B, Cin, ID, IH, IW = x.shape
+        Cout, _, KD, KH, KW = w.shape
+        KV = KD * KH * KW
+        geom = ctx.geom
+        OD, OH, OW = geom[4:7]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if ctx.stride == (1, 1, 1):
+                wt = _empty(x, Cin, Cout, KD, KH, KW)
+                L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
+                (pd, _), (ph, _), (pw, _) = ctx.pads
+                g2 = (Cout, OD, OH, OW, ID, IH, IW, KD, KH, KW, 1, 1, 1, KD - 1 - pd, KH - 1 - ph, KW - 1 - pw)
+                dx = torch.empty_like(x)
+                L.conv3d_fwd(dy, wt, dx, B, Cin, g2)
+            else:
+                # strided transposed convolution: only the 7x7x7 stride-2 stem (3 input channels) needs it.
+                # Still an ATen/MIOpen call (listed in DESIGN.md section 1, row a15).
+                (pd, pdb), (ph, phb), (pw, pwb) = ctx.pads
+                xp_shape = (B, Cin, ID + pd + pdb, IH + ph + phb, IW + pw + pwb)
+                dxp = torch.nn.grad.conv3d_input(xp_shape, w, dy, stride=ctx.stride, padding=0)
+                dx = dxp[:, :, pd:pd + ID, ph:ph + IH, pw:pw + IW].contiguous()
+        if ctx.needs_input_grad[1]:
+            P, N = OD * OH * OW, Cin * KV
+            sk = _splitk(Cout, N, P, B)
+            ws = _empty(x, sk * B * Cout * N) if sk > 1 else None
+            dwb = _empty(x, B, Cout * N)
+            L.conv3d_bwd_weight(dy, x, dwb, B, Cout, geom, sk, ws)
+            if B > 1:
+                dw = _empty(x, Cout * N)
+                L.colsum(dwb, dw, _empty(x, L.colreduce_ws(B, Cout * N, 1)), B, Cout * N)
+            else:
+                dw = dwb
+            dw = dw.view_as(w)
+        return dx, dw, None, None
+
+
+def conv3d_same(x, w, stride=(1, 1, 1)):
+    """nn.Conv3d(bias=False) with the dynamic TF-'same' zero padding of Unit3D (aj_i3d.py:75-92)."""
+    stride = tuple(int(s) for s in stride)
+    return _Conv3d.apply(x, w, stride, _same_pads(x.shape[2:], w.shape[2:], stride))
+
+
+class _MaxPool3d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, kernel, stride, pads):
+        L = segx.lib()
+        x = _c(x)
+        B, C, ID, IH, IW = x.shape
+        (pd, pdb), (ph, phb), (pw, pwb) = pads
+        OD = (ID + pd + pdb - kernel[0]) // stride[0] + 1
+        OH = (IH + ph + phb - kernel[1]) // stride[1] + 1
+        OW = (IW + pw + pwb - kernel[2]) // stride[2] + 1
+        y = _empty(x, B, C, OD, OH, OW)
+        arg = torch.empty(B, C, OD, OH, OW, dtype=torch.int32, device=x.device)
+        geom = (ID, IH, IW, OD, OH, OW) + tuple(kernel) + tuple(stride) + (pd, ph, pw)
+        L.maxpool3d_fwd(x, y, arg, B * C, geom)
+        ctx.geom, ctx.xshape = geom, tuple(x.shape)
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        (arg,) = ctx.saved_tensors
+        dx = _empty(dy, *ctx.xshape)
+        L.maxpool3d_bwd(_c(dy), arg, dx, ctx.xshape[0] * ctx.xshape[1], ctx.geom)
+        return dx, None, None, None
+
+
+def maxpool3d_same(x, kernel, stride):
+    """MaxPool3dSamePadding (aj_i3d.py:6-30)."""
+    kernel, stride = tuple(int(k) for k in kernel), tuple(int(s) for s in stride)
+    return _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride))

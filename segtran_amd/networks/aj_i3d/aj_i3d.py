@@ -4,9 +4,10 @@ Same module / parameter names (`Conv3d_1a_7x7.conv3d.weight`, `Mixed_4b.b1b.bn.r
 dynamic TF-'same' zero padding of N7 (front = pad // 2; aj_i3d.py:8-30, 68-90) and `do_pool1=False`
 (`MaxPool3d_2a_3x3` = Identity, :206-210).
 
-Kernel status: the 38 1x1x1 convolutions run on libsegx's MFMA GEMM.  The 7x7x7 stem, the 19 3x3x3
-convolutions (implicit-GEMM MFMA kernels are the next round's K20 work) and the max pools are still
-ATen/MIOpen calls; BatchNorm3d+ReLU is one fused libsegx kernel (backbone.hip).
+Kernel status: everything runs on libsegx -- the 38 1x1x1 convolutions on the MFMA GEMM, the 7x7x7 stem and the 19
+3x3x3 convolutions as implicit GEMM on the same MFMA engine (conv3d.hip: forward, backward-data, backward-weight),
+BatchNorm3d+ReLU as one fused kernel (backbone.hip), the 'same' max-pools in conv3d.hip.  One exception: the
+backward-DATA of the stride-2 stem (a transposed convolution onto 3 channels) is still an ATen/MIOpen call.
 """
 import torch
 import torch.nn as nn
@@ -26,7 +27,7 @@ def _same_pad(x, kernel, stride):
 
 class MaxPool3dSamePadding(nn.MaxPool3d):
     def forward(self, x):
-        return super().forward(_same_pad(x, self.kernel_size, self.stride))     # zero fill: inputs are post-ReLU
+        return SF.maxpool3d_same(x, self.kernel_size, self.stride)             # libsegx: zero 'same' padding + max-pool
 
 
 class Unit3D(nn.Module):
@@ -45,7 +46,8 @@ class Unit3D(nn.Module):
         if self.pointwise:
             x = SF.conv1x1(x, self.conv3d.weight, self.conv3d.bias)            # libsegx MFMA GEMM
         else:
-            x = F.conv3d(_same_pad(x, self._kernel_shape, self._stride), self.conv3d.weight, self.conv3d.bias, self._stride)
+            assert self.conv3d.bias is None
+            x = SF.conv3d_same(x, self.conv3d.weight, self._stride)              # libsegx implicit-GEMM MFMA convolution
         if self._use_batch_norm:                                               # fused BatchNorm3d (+ReLU), libsegx
             return SF.bn_act(x, self.bn, SF.ACT_RELU if self._activation_fn is F.relu else SF.ACT_NONE)
         if self._activation_fn is not None:

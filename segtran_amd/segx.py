@@ -234,6 +234,37 @@ class SegxLib:
     def interp_bwd(self, dout, din, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_bwd', dout, dout, din, planes, d, h, w, D, H, W)
 
+    # ---- implicit-GEMM conv3d + max-pool (conv3d.hip) -----------------------------------------------
+    @staticmethod
+    def _geom(vals):
+        return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+    def conv3d_fwd(self, X, W, Y, B, Cout, geom):
+        self._chk_t(X, W, Y)
+        rc = self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), self.stream(Y))
+        self.check(rc, 'segx_conv3d_fwd')
+
+    def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
+        self._call('segx_conv3d_flip_weights', W, W, Wt, Cout, Cin, KV)
+
+    def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws):
+        self._chk_t(dY, X, dWb, ws)
+        rc = self.c.segx_conv3d_bwd_weight(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(dWb))
+        self.check(rc, 'segx_conv3d_bwd_weight')
+
+    def maxpool3d_fwd(self, X, Y, arg, planes, geom):
+        self._chk_t(X, Y, arg)
+        rc = self.c.segx_maxpool3d_fwd(_ptr(X), _ptr(Y), _ptr(arg), planes, self._geom(geom), self.stream(Y))
+        self.check(rc, 'segx_maxpool3d_fwd')
+
+    def maxpool3d_bwd(self, dY, arg, dX, planes, geom):
+        self._chk_t(dY, arg, dX)
+        rc = self.c.segx_maxpool3d_bwd(_ptr(dY), _ptr(arg), _ptr(dX), planes, self._geom(geom), self.stream(dX))
+        self.check(rc, 'segx_maxpool3d_bwd')
+
+    def interp_bwd_axis(self, dout, din, outer, n_out, n_in, inner):
+        self._call('segx_interp_linear_bwd_axis', dout, dout, din, outer, n_out, n_in, inner)
+
     def mt_bertadam_step(self, tabs, ntensors, nchunks, chunk, max_global, max_tensor, sched, b1, b2, eps, ws):
         """tabs: dict of device tensors params/grads/m/v (int64 pointer tables), sizes, chunk_tensor, chunk_off,
         chunk_first, active, lr, wd."""
@@ -257,7 +288,9 @@ _SIGS = {
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
-    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip',
+    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
+    'segx_conv3d_fwd': 'pppiipp', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
+    'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',

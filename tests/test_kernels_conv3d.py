@@ -1,0 +1,51 @@
+"""conv3d.hip: implicit-GEMM 3-D convolution (fwd / bwd-data / bwd-weight) and 'same' max-pool vs PyTorch."""
+import pytest
+import torch
+import torch.nn.functional as F
+from segtran_amd import functional as SF
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g, device='cpu') * scale).to(torch.get_default_device())
+
+
+def close(a, b, tol=5e-5):
+    s = max(b.abs().max().item(), 1e-20)
+    err = (a - b).abs().max().item()
+    assert err <= tol * s, 'err %.3e scale %.3e' % (err, s)
+
+
+def _ref_conv(x, w, stride):
+    pads = SF._same_pads(x.shape[2:], w.shape[2:], stride)
+    xp = F.pad(x, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    return F.conv3d(xp, w, None, stride)
+
+
+@pytest.mark.parametrize('B,Cin,Cout,size,k,stride', [(2, 8, 12, (4, 6, 5), (3, 3, 3), (1, 1, 1)), (1, 3, 8, (8, 10, 12), (7, 7, 7), (2, 2, 2)),
+                                                      (1, 16, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)), (2, 4, 6, (5, 7, 7), (1, 3, 3), (1, 1, 1))])
+def test_conv3d_same(backend, B, Cin, Cout, size, k, stride):
+    x = rnd(B, Cin, *size, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, *k, seed=2) * 0.2).requires_grad_(True)
+    y = SF.conv3d_same(x, w, stride)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = _ref_conv(xr, wr, stride)
+    assert y.shape == yr.shape
+    close(y, yr.detach())
+    G = rnd(*y.shape, seed=3)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4); close(w.grad, wr.grad, 1e-4)
+
+
+@pytest.mark.parametrize('size,k,stride', [((4, 9, 10), (1, 3, 3), (1, 2, 2)), ((6, 8, 8), (3, 3, 3), (2, 2, 2)), ((4, 7, 7), (2, 2, 2), (2, 2, 2)),
+                                           ((3, 5, 6), (3, 3, 3), (1, 1, 1))])
+def test_maxpool3d_same(backend, size, k, stride):
+    x = torch.relu(rnd(2, 3, *size, seed=4)).requires_grad_(True)          # post-ReLU inputs as in I3D (incl. exact zeros)
+    y = SF.maxpool3d_same(x, k, stride)
+    xr = x.detach().clone().requires_grad_(True)
+    pads = SF._same_pads(size, k, stride)
+    yr = F.max_pool3d(F.pad(xr, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1])), k, stride)
+    assert torch.equal(y, yr.detach())
+    G = rnd(*y.shape, seed=5)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-6)
