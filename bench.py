@@ -133,11 +133,13 @@ def main():
     lossv = float(loss.detach())
     assert lossv == lossv, 'loss is NaN'
 
-    # roofline of the dominant kernel (segx::gemm_f32_kernel, all layout variants): algorithmic FLOPs / HIP-event time
+    # roofline of the dominant kernel family (the fp32-MFMA tile engine of gemm_core.h: dense GEMM in all layouts and the
+    # implicit-GEMM convolutions): algorithmic FLOPs of every launch / its HIP-event time on the launch stream
     flops = sum(p[2] for p in prof)
     ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roof = {'bound': 'mfma', 'kernel': 'segx::gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+    roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
+            'achieved': round(achieved, 2),
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
             'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
             'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}

@@ -246,6 +246,72 @@ __global__ __launch_bounds__(256) void plane_scale_bwd_kernel(const float* __res
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) d[s] = g[s] * gt + dp;
 }
 
+// ---- squeeze-excite excitation MLP on the pooled [B, C] vector (efficientnet/model.py:106-110) -------------------
+//   p = pooled_sum / S ; hpre = W1 p + b1 ; h = swish(hpre) ; gate = sigmoid(W2 h + b2).  One workgroup per sample.
+constexpr int SE_MAX_C = 4096, SE_MAX_CS = 256;
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled_sum, float inv_S, const float* __restrict__ W1,
+                                                          const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                          float* __restrict__ p_out, float* __restrict__ hpre_out, float* __restrict__ gate, int C, int Cs) {
+    __shared__ float p[SE_MAX_C];
+    __shared__ float h[SE_MAX_CS];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += 256) { const float v = pooled_sum[(int64_t)b * C + c] * inv_S; p[c] = v; p_out[(int64_t)b * C + c] = v; }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += W1[(int64_t)j * C + c] * p[c];
+        s = wave_sum(s) + b1[j];
+        if (lane == 0) { hpre_out[(int64_t)b * Cs + j] = s; h[j] = s * sigm(s); }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float z = b2[c];
+        for (int j = 0; j < Cs; ++j) z += W2[(int64_t)c * Cs + j] * h[j];
+        gate[(int64_t)b * C + c] = sigm(z);
+    }
+}
+// per sample: dz2 = dgate * gate * (1 - gate) ; dhpre = (W2^T dz2) * swish'(hpre) ; dpool = (W1^T dhpre) / S
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hpre,
+                                                          const float* __restrict__ W1, const float* __restrict__ W2, float inv_S,
+                                                          float* __restrict__ dz2_out, float* __restrict__ dhpre_out, float* __restrict__ dpool, int C, int Cs) {
+    __shared__ float dz2[SE_MAX_C];
+    __shared__ float dh[SE_MAX_CS];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float g = gate[(int64_t)b * C + c], v = dgate[(int64_t)b * C + c] * g * (1.0f - g);
+        dz2[c] = v; dz2_out[(int64_t)b * C + c] = v;
+    }
+    __syncthreads();
+    for (int j = wave; j < Cs; j += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += dz2[c] * W2[(int64_t)c * Cs + j];
+        s = wave_sum(s);
+        if (lane == 0) { const float hp = hpre[(int64_t)b * Cs + j]; const float v = s * act_grad(hp, ACT_SWISH); dh[j] = v; dhpre_out[(int64_t)b * Cs + j] = v; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < Cs; ++j) s += dh[j] * W1[(int64_t)j * C + c];
+        dpool[(int64_t)b * C + c] = s * inv_S;
+    }
+}
+// weight gradients (sums over the batch): thread per (c, j)
+__global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ dhpre, const float* __restrict__ p,
+                                                            const float* __restrict__ hpre, float* __restrict__ dW1, float* __restrict__ db1,
+                                                            float* __restrict__ dW2, float* __restrict__ db2, int B, int C, int Cs) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)C * Cs) return;
+    const int c = (int)(idx / Cs), j = (int)(idx % Cs);
+    float a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float hp = hpre[(int64_t)b * Cs + j], dz = dz2[(int64_t)b * C + c], dh = dhpre[(int64_t)b * Cs + j];
+        a2 += dz * (hp * sigm(hp)); a1 += dh * p[(int64_t)b * C + c]; s2 += dz; s1 += dh;
+    }
+    dW2[(int64_t)c * Cs + j] = a2; dW1[(int64_t)j * C + c] = a1;
+    if (j == 0) db2[c] = s2;
+    if (c == 0) db1[j] = s1;
+}
+
 static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -346,4 +412,22 @@ extern "C" int segx_plane_scale_bwd(const float* dY, const float* gate, const fl
     SEGX_STREAM; SEGX_REQUIRE(dY && gate && dpool && dX && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_bwd: bad args");
     hipLaunchKernelGGL(plane_scale_bwd_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, dY, gate, dpool, dX, S);
     return check_launch("segx_plane_scale_bwd");
+}
+extern "C" int segx_se_gate_fwd(const float* pooled_sum, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2,
+                                float* p, float* hpre, float* gate, int B, int C, int Cs, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(pooled_sum && W1 && b1 && W2 && b2 && p && hpre && gate && B > 0 && C > 0 && Cs > 0, "segx_se_gate_fwd: bad args");
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS, "segx_se_gate_fwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), 0, stream, pooled_sum, inv_S, W1, b1, W2, b2, p, hpre, gate, C, Cs);
+    return check_launch("segx_se_gate_fwd");
+}
+extern "C" int segx_se_gate_bwd(const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1, const float* W2,
+                                float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws /* B*(C+Cs) */,
+                                int B, int C, int Cs, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dgate && gate && hpre && p && W1 && W2 && dpool && dW1 && db1 && dW2 && db2 && ws && B > 0 && C > 0 && Cs > 0, "segx_se_gate_bwd: bad args");
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS, "segx_se_gate_bwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    float* dz2 = ws; float* dhpre = ws + (int64_t)B * C;
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), 0, stream, dgate, gate, hpre, W1, W2, inv_S, dz2, dhpre, dpool, C, Cs);
+    hipLaunchKernelGGL(se_gate_wgrad_kernel, dim3((unsigned)(((int64_t)C * Cs + 255) / 256)), dim3(256), 0, stream, (const float*)dz2, (const float*)dhpre,
+                       p, hpre, dW1, db1, dW2, db2, B, C, Cs);
+    return check_launch("segx_se_gate_bwd");
 }

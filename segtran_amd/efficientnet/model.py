@@ -8,8 +8,9 @@ model.py:169-178, utils.py:248-275), same endpoint rule (endpoints are the INPUT
 
 Kernel status: every 1x1 convolution (127 of the 160 convs of B4) runs on libsegx's MFMA GEMM; the 32 depthwise
 k3/k5 convolutions, BatchNorm+swish (fused), the squeeze-excite pooling/gating planes and the drop_connect+skip add
-run on libsegx's HBM-bound kernels (backbone.hip).  Still ATen/MIOpen: the dense 3x3 stem convolution and the
-[B, C]-sized excitation MLP of squeeze-excite (a handful of tiny matmuls).
+run on libsegx's HBM-bound kernels (backbone.hip); the dense 3x3 stem is an implicit GEMM on the MFMA engine
+(conv3d.hip with depth 1); the squeeze-excite excitation MLP has its own one-workgroup-per-sample kernels.  No ATen
+arithmetic is left in this file (only the per-sample drop_connect random draw, a [B]-sized tensor).
 """
 import math
 import torch
@@ -61,9 +62,8 @@ class Conv2dStaticSamePadding(nn.Conv2d):
             return SF.conv1x1(x, self.weight, self.bias)                 # libsegx MFMA GEMM
         if self.groups == self.in_channels and self.groups == self.out_channels and self.bias is None:
             return SF.dwconv2d(x, self.weight, self.stride[0], self.static_pad)   # libsegx depthwise stencil
-        if any(self.static_pad):                                           # dense k x k: only the 3x3 stem (ATen/MIOpen)
-            x = F.pad(x, self.static_pad)
-        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+        assert self.groups == 1 and self.bias is None and self.dilation == (1, 1)
+        return SF.conv2d_dense(x, self.weight, self.stride[0], self.static_pad)   # the 3x3 stem: libsegx implicit GEMM
 
 
 def swish(x):

@@ -532,27 +532,25 @@ def dwconv2d(x, w, stride, pad):
 
 
 class _SqueezeExcite(torch.autograd.Function):
-    """x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)   (efficientnet/model.py:105-110).  The plane-sized work
-    (pool, scale, their backward) is HIP; the [B, C]-sized excitation MLP is a handful of tiny matmuls."""
+    """x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)   (efficientnet/model.py:105-110), all on libsegx: plane pooling /
+    scaling kernels plus one-workgroup-per-sample kernels for the [B, C]-sized excitation MLP and its gradients."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         L = segx.lib()
         x = _c(x)
         B, C = x.shape[:2]
+        Cs = w1.shape[0]
         S = x.numel() // (B * C)
         pooled = _empty(x, B * C)
         L.rowsum(x, pooled, B * C, S)
-        p = pooled.view(B, C) / S
-        W1, W2 = w1.reshape(w1.shape[0], C), w2.reshape(C, w1.shape[0])
-        hpre = torch.addmm(b1, p, W1.t())
-        sg = torch.sigmoid(hpre)
-        h = hpre * sg
-        gate = torch.sigmoid(torch.addmm(b2, h, W2.t()))
+        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
+        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
+        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
         y = torch.empty_like(x)
-        L.plane_scale(x, gate.contiguous(), y, B * C, S)
+        L.plane_scale(x, gate, y, B * C, S)
         ctx.save_for_backward(x, p, hpre, gate, W1, W2)
-        ctx.shapes = (w1.shape, w2.shape, S)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), S)
         return y
 
     @staticmethod
@@ -561,18 +559,15 @@ class _SqueezeExcite(torch.autograd.Function):
         x, p, hpre, gate, W1, W2 = ctx.saved_tensors
         w1s, w2s, S = ctx.shapes
         B, C = p.shape
+        Cs = hpre.shape[1]
         dy = _c(dy)
         dgate = _empty(x, B * C)
         L.plane_dot(dy, x, dgate, B * C, S)
-        dz2 = dgate.view(B, C) * gate * (1 - gate)
-        sg = torch.sigmoid(hpre)
-        h = hpre * sg
-        dW2, db2 = dz2.t() @ h, dz2.sum(0)
-        dhpre = (dz2 @ W2) * (sg * (1 + hpre * (1 - sg)))
-        dW1, db1 = dhpre.t() @ p, dhpre.sum(0)
-        dpool = ((dhpre @ W1) / S).contiguous()
+        dpool = _empty(x, B * C)
+        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
+        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, B * (C + Cs)), B, C, Cs)
         dx = torch.empty_like(x)
-        L.plane_scale_bwd(dy, gate.contiguous(), dpool, dx, B * C, S)
+        L.plane_scale_bwd(dy, gate, dpool, dx, B * C, S)
         return dx, dW1.view(w1s), db1, dW2.view(w2s), db2
 
 
@@ -801,3 +796,10 @@ def maxpool3d_same(x, kernel, stride):
     """MaxPool3dSamePadding (aj_i3d.py:6-30)."""
     kernel, stride = tuple(int(k) for k in kernel), tuple(int(s) for s in stride)
     return _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride))
+
+
+def conv2d_dense(x, w, stride, pad):
+    """Dense k x k 2-D convolution (only the EfficientNet stem) on the implicit-GEMM engine: a 3-D convolution with depth 1.
+    pad = (left, right, top, bottom) zero padding."""
+    s = int(stride)
+    return _Conv3d.apply(x.unsqueeze(2), w.unsqueeze(2), (1, s, s), ((0, 0), (int(pad[2]), int(pad[3])), (int(pad[0]), int(pad[1])))).squeeze(2)

@@ -212,6 +212,12 @@ class SegxLib:
     def plane_scale_add(self, X, gate, R, Y, planes, S):
         self._call('segx_plane_scale_add', X, X, gate, R, Y, planes, S)
 
+    def se_gate_fwd(self, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs):
+        self._call('segx_se_gate_fwd', gate, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
+
+    def se_gate_bwd(self, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs):
+        self._call('segx_se_gate_bwd', gate, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs)
+
     def plane_dot(self, A, B, out, planes, S):
         self._call('segx_plane_dot', A, A, B, out, planes, S)
 
@@ -239,9 +245,20 @@ class SegxLib:
     def _geom(vals):
         return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
 
+    def _timed(self, ref, flops, tag, fn):
+        if self.gemm_prof is not None and ref.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); rc = fn(); e1.record()
+            self.gemm_prof.append((e0, e1, flops, tag))
+            return rc
+        return fn()
+
     def conv3d_fwd(self, X, W, Y, B, Cout, geom):
         self._chk_t(X, W, Y)
-        rc = self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), self.stream(Y))
+        g = [int(v) for v in geom]
+        K, P = g[0] * g[7] * g[8] * g[9], g[4] * g[5] * g[6]
+        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B),
+                         lambda: self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), self.stream(Y)))
         self.check(rc, 'segx_conv3d_fwd')
 
     def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
@@ -249,7 +266,11 @@ class SegxLib:
 
     def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws):
         self._chk_t(dY, X, dWb, ws)
-        rc = self.c.segx_conv3d_bwd_weight(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(dWb))
+        g = [int(v) for v in geom]
+        N, P = g[0] * g[7] * g[8] * g[9], g[4] * g[5] * g[6]
+        rc = self._timed(dWb, 2.0 * B * Cout * P * N, ('conv3d_wgrad', Cout, N, P, B, splitk),
+                         lambda: self.c.segx_conv3d_bwd_weight(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws),
+                                                               self.stream(dWb)))
         self.check(rc, 'segx_conv3d_bwd_weight')
 
     def maxpool3d_fwd(self, X, Y, arg, planes, geom):
@@ -294,7 +315,7 @@ _SIGS = {
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
-    'segx_plane_scale_bwd': 'ppppllp', 'segx_plane_scale_add': 'ppppllp',
+    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfip', 'segx_bn_act_bwd_apply': 'pppppppppiilfifp',
 }
 

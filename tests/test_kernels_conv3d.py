@@ -49,3 +49,16 @@ def test_maxpool3d_same(backend, size, k, stride):
     G = rnd(*y.shape, seed=5)
     y.backward(G); yr.backward(G)
     close(x.grad, xr.grad, 1e-6)
+
+
+def test_stem_conv2d_on_implicit_gemm(backend):
+    """EfficientNet stem: dense 3x3, 3 -> 48 channels, stride 1, static pad (1,1,1,1); input needs no gradient."""
+    x = rnd(2, 3, 20, 24, seed=6)
+    w = (rnd(48, 3, 3, 3, seed=7) * 0.3).requires_grad_(True)
+    y = SF.conv2d_dense(x, w, 1, (1, 1, 1, 1))
+    wr = w.detach().clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(x, (1, 1, 1, 1)), wr)
+    close(y, yr.detach())
+    G = rnd(*y.shape, seed=8)
+    y.backward(G); yr.backward(G)
+    close(w.grad, wr.grad, 1e-4)
