@@ -135,12 +135,27 @@ def main():
 
     # roofline of the dominant kernel family (the fp32-MFMA tile engine of gemm_core.h: dense GEMM in all layouts and the
     # implicit-GEMM convolutions): algorithmic FLOPs of every launch / its HIP-event time on the launch stream
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'r01_e_pmc_gemm_traffic.json')
+    if args.config == 'cfg2' and os.path.exists(tfile):      # PMC passes cannot run inside the timed bench: read the committed result
+        traffic = round(json.load(open(tfile))['traffic_bytes_per_launch'])
+    alg_bytes = 0.0
+    for pr in prof:
+        shp = pr[3]
+        if isinstance(shp[0], str):                             # conv3d: (tag, M, N, K, B, ...): weights + activation + output
+            _, M_, N_, K_, B_ = shp[:5]
+            alg_bytes += 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] == 'conv3d_fwd' else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
+        else:
+            M_, N_, K_, nb_ = shp[:4]
+            alg_bytes += 4.0 * nb_ * (M_ * K_ + N_ * K_ + M_ * N_)
     flops = sum(p[2] for p in prof)
     ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
             'achieved': round(achieved, 2),
-            'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+            'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'traffic_note': 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01_e_pmc_gemm_traffic.json' if traffic else None,
+            'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
             'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
             'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}
     if os.environ.get('SEGX_BENCH_VERBOSE'):

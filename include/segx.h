@@ -208,6 +208,13 @@ int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int K
  * workspace = splitk*B*Cout*Cin*KV floats when splitk > 1 */
 int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
                            float* workspace, void* stream);
+/* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
+int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream);
+/* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
+int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream);
+/* in-step label -> n-hot maps (datasets2d.py:90-139,200-223; datasets3d.py:16-40): mode 0 fundus uint8 [B,Cin,S] -> [B,3,S];
+ * 1 polyp uint8 -> [B,2,S]; 2 brats int32 [B,S] -> [B,4,S] */
+int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, int mode, void* stream);
 /* MaxPool3dSamePadding (aj_i3d.py:6-30): zero 'same' padding then max-pool.  geom (int32[15]) =
  * {ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}; arg = arg-max index per output (-1 = a padded zero won) */
 int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t planes, const int* geom, void* stream);

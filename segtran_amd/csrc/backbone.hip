@@ -90,11 +90,21 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
     const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
-    const int64_t per = (S + BN_SLABS - 1) / BN_SLABS, s0 = slab * per, s1 = i64min(S, s0 + per);
+    const int64_t per = ((S + BN_SLABS - 1) / BN_SLABS + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
-    for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
-        const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
-        a += du; q += du * xh;
+    if ((S & 3) == 0) {
+        for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
+            const float h0 = (xv.x - m) * rstd, h1 = (xv.y - m) * rstd, h2 = (xv.z - m) * rstd, h3 = (xv.w - m) * rstd;
+            const float d0 = gv.x * act_grad(h0 * wc + bc_, act), d1 = gv.y * act_grad(h1 * wc + bc_, act);
+            const float d2 = gv.z * act_grad(h2 * wc + bc_, act), d3 = gv.w * act_grad(h3 * wc + bc_, act);
+            a += (d0 + d1) + (d2 + d3); q += (d0 * h0 + d1 * h1) + (d2 * h2 + d3 * h3);
+        }
+    } else {
+        for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
+            const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+            a += du; q += du * xh;
+        }
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
     if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + bb) * BN_SLABS + slab) * 2; o[0] = a; o[1] = q; }
@@ -115,9 +125,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     const float k1 = db[c] * inv_n, k2 = dw[c] * inv_n, sc = wc * rstd;
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
-    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
-        const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
-        d[s] = sc * (du - k1 - xh * k2);
+    if ((S & 3) == 0) {
+        for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
+            const float h0 = (xv.x - m) * rstd, h1 = (xv.y - m) * rstd, h2 = (xv.z - m) * rstd, h3 = (xv.w - m) * rstd;
+            float4 o;
+            o.x = sc * (gv.x * act_grad(h0 * wc + bc_, act) - k1 - h0 * k2); o.y = sc * (gv.y * act_grad(h1 * wc + bc_, act) - k1 - h1 * k2);
+            o.z = sc * (gv.z * act_grad(h2 * wc + bc_, act) - k1 - h2 * k2); o.w = sc * (gv.w * act_grad(h3 * wc + bc_, act) - k1 - h3 * k2);
+            *reinterpret_cast<float4*>(d + s) = o;
+        }
+    } else {
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+            const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+            d[s] = sc * (du - k1 - xh * k2);
+        }
     }
 }
 
@@ -347,7 +368,7 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
                                      float inv_n, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_apply: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 4), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n);
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n);
     return check_launch("segx_bn_act_bwd_apply");
 }
 extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -358,7 +379,7 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C);
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 4), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
                        (const float*)db, dX, C, S, eps, act, inv_n);
     return check_launch("segx_bn_act_bwd");
 }

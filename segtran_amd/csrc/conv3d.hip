@@ -16,94 +16,102 @@ struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
 };
 
-// ---- forward / backward-data: B(n = output position, k = (ci, tap)), positions contiguous ---------------------
-// thread map (row-contiguous operand): piece i -> k-row (tid>>5) + 8*i, positions n0 + 4*(tid&31) + j
+// exact floor(n / d) for 0 <= n < 2^31: multiply-high by ceil(2^32 / d) over-estimates by at most one -> one correction
+struct FastDiv { unsigned d, magic; };
+__host__ __device__ inline FastDiv make_fastdiv(int d) { FastDiv f; f.d = (unsigned)d; f.magic = d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); return f; }
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    if (f.d <= 1) return n;
+    const unsigned q = __umulhi((unsigned)n, f.magic);
+    return (int)(q - (q * f.d > (unsigned)n ? 1u : 0u));
+}
+
+// ---- forward / backward-data: B(n = output position, k = (ci, tap)) ------------------------------------------------
+// Thread map: ONE output position per thread (n0 + (tid & 127): the 64 lanes of a wave read 64 consecutive positions,
+// i.e. whole 128-B lines for every tap), 16 k-rows (tid>>7)*16 + i.  The (ci, tap) decode of a k-row is wave-uniform.
 struct ConvFwdLoaderB {
-    static constexpr bool kc = false;
-    const float* X; ConvGeom q; int K;
-    int bd[4], bh[4], bw[4]; unsigned nvalid;
-    __device__ __forceinline__ ConvFwdLoaderB(const float* X_, const ConvGeom& q_, int n0, int P, int K_) : X(X_), q(q_), K(K_) {
-        nvalid = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + ((threadIdx.x & 31) << 2) + j;
-            const int nn = n < P ? n : 0;
-            const int od = nn / (q.OH * q.OW), r = nn - od * q.OH * q.OW, oh = r / q.OW, ow = r - oh * q.OW;
-            bd[j] = od * q.sd - q.pd; bh[j] = oh * q.sh - q.ph; bw[j] = ow * q.sw - q.pw;
-            if (n < P) nvalid |= 1u << j;
-        }
+    const float* X; ConvGeom q; FastDiv dKV, dKHW, dKW;
+    int bd, bh, bw; bool nvalid;
+    __device__ __forceinline__ ConvFwdLoaderB(const float* X_, const ConvGeom& q_, int n0, int P) : X(X_), q(q_) {
+        dKV = make_fastdiv(q.KD * q.KH * q.KW); dKHW = make_fastdiv(q.KH * q.KW); dKW = make_fastdiv(q.KW);
+        const int n = n0 + (threadIdx.x & 127);
+        nvalid = n < P;
+        const int nn = nvalid ? n : 0;
+        const int od = nn / (q.OH * q.OW), r = nn - od * q.OH * q.OW, oh = r / q.OW, ow = r - oh * q.OW;
+        bd = od * q.sd - q.pd; bh = oh * q.sh - q.ph; bw = ow * q.sw - q.pw;
     }
     __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
         unsigned okmask = 0;
         const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
+        const int kbase = k0 + ((tid >> 7) << 4);                    // wave-uniform
+        float* v = reinterpret_cast<float*>(&r[0]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int k = k0 + (tid >> 5) + 8 * i;
+        for (int i = 0; i < 16; ++i) {
+            const int k = kbase + i;
             const bool kok = k < kend;
             const int kk = kok ? k : 0;
-            const int ci = kk / KV, t = kk - ci * KV, kd = t / KHW, t2 = t - kd * KHW, kh = t2 / q.KW, kw = t2 - kh * q.KW;
-            const int64_t cbase = (int64_t)ci * q.ID * q.IH * q.IW;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = bd[j] + kd, ih = bh[j] + kh, iw = bw[j] + kw;
-                const bool ok = kok && ((nvalid >> j) & 1u) && id >= 0 && id < q.ID && ih >= 0 && ih < q.IH && iw >= 0 && iw < q.IW;
-                const int64_t off = ok ? cbase + ((int64_t)id * q.IH + ih) * q.IW + iw : 0;
-                v[j] = X[off];
-                if (ok) okmask |= 1u << (4 * i + j);
-            }
-            r[i] = make_float4(v[0], v[1], v[2], v[3]);
+            const int ci = fdiv(kk, dKV), t = kk - ci * KV, kd = fdiv(t, dKHW), t2 = t - kd * KHW, kh = fdiv(t2, dKW), kw = t2 - kh * q.KW;
+            const int id = bd + kd, ih = bh + kh, iw = bw + kw;
+            const bool ok = kok && nvalid && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
+            const int64_t off = ok ? (((int64_t)ci * q.ID + id) * q.IH + ih) * q.IW + iw : 0;
+            v[i] = X[off];
+            if (ok) okmask |= 1u << i;
         }
         return okmask;
+    }
+    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const {
+        const int n = tid & 127, kr = (tid >> 7) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned mk = okmask >> (4 * i);
+            T[kr + 4 * i + 0][n] = (mk & 1u) ? r[i].x : 0.f; T[kr + 4 * i + 1][n] = (mk & 2u) ? r[i].y : 0.f;
+            T[kr + 4 * i + 2][n] = (mk & 4u) ? r[i].z : 0.f; T[kr + 4 * i + 3][n] = (mk & 8u) ? r[i].w : 0.f;
+        }
     }
 };
 
 // ---- backward-weight: B(n = (ci, tap), k = output position) ------------------------------------------------------
-// thread map (k-contiguous operand): piece i -> row n0 + (tid>>3) + 32*i, k-chunk 4*(tid&7) + j
+// Thread map: ONE output position per thread and k-tile (k0 + (tid & 31): 32 consecutive positions = one 128-B line per
+// row), 16 rows (tid>>5) + 8*i whose (channel offset, tap) are decoded once into two registers each.
 struct ConvWgradLoaderB {
-    static constexpr bool kc = true;
-    const float* X; ConvGeom q; int P;
-    int64_t cbase[4]; int kd[4], kh[4], kw[4]; unsigned rvalid;
-    __device__ __forceinline__ ConvWgradLoaderB(const float* X_, const ConvGeom& q_, int n0, int N, int P_) : X(X_), q(q_), P(P_) {
-        const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
-        rvalid = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + (threadIdx.x >> 3) + 32 * i;
+    const float* X; ConvGeom q; FastDiv dOHW, dOW;
+    const int* rowinfo;                                        // LDS: [128][2] = {channel offset (or -1: row outside N), kd | kh<<10 | kw<<20}
+    // fills the per-row table; the caller must __syncthreads() before the first load
+    __device__ __forceinline__ ConvWgradLoaderB(const float* X_, const ConvGeom& q_, int n0, int N, int* rowinfo_lds) : X(X_), q(q_), rowinfo(rowinfo_lds) {
+        dOHW = make_fastdiv(q.OH * q.OW); dOW = make_fastdiv(q.OW);
+        if (threadIdx.x < 128) {
+            const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
+            const int n = n0 + threadIdx.x;
             const int nn = n < N ? n : 0;
-            const int ci = nn / KV, t = nn - ci * KV;
-            kd[i] = t / KHW; const int t2 = t - kd[i] * KHW; kh[i] = t2 / q.KW; kw[i] = t2 - kh[i] * q.KW;
-            cbase[i] = (int64_t)ci * q.ID * q.IH * q.IW;
-            if (n < N) rvalid |= 1u << i;
+            const int ci = nn / KV, t = nn - ci * KV, kd = t / KHW, t2 = t - kd * KHW, kh = t2 / q.KW, kw = t2 - kh * q.KW;
+            rowinfo_lds[2 * threadIdx.x] = n < N ? ci * q.ID * q.IH * q.IW : -1;      // < 2^31: checked on the host
+            rowinfo_lds[2 * threadIdx.x + 1] = kd | (kh << 10) | (kw << 20);
         }
     }
     __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
         unsigned okmask = 0;
-        int od[4], oh[4], ow[4]; bool pok[4];
-        const int p0 = k0 + ((tid & 7) << 2);
-        {   // decode the first position once, then carry
-            const int pp = p0 < P ? p0 : 0;
-            int d = pp / (q.OH * q.OW), rr = pp - d * q.OH * q.OW, h = rr / q.OW, w = rr - h * q.OW;
+        const int p = k0 + (tid & 31);
+        const bool pok = p < kend;
+        const int pp = pok ? p : 0;
+        const int od = fdiv(pp, dOHW), rr = pp - od * q.OH * q.OW, oh = fdiv(rr, dOW), ow = rr - oh * q.OW;
+        const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
+        float* v = reinterpret_cast<float*>(&r[0]);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                od[j] = d; oh[j] = h; ow[j] = w; pok[j] = (p0 + j) < kend;
-                if (++w == q.OW) { w = 0; if (++h == q.OH) { h = 0; ++d; } }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int id = od[j] * q.sd - q.pd + kd[i], ih = oh[j] * q.sh - q.ph + kh[i], iw = ow[j] * q.sw - q.pw + kw[i];
-                const bool ok = pok[j] && ((rvalid >> i) & 1u) && id >= 0 && id < q.ID && ih >= 0 && ih < q.IH && iw >= 0 && iw < q.IW;
-                const int64_t off = ok ? cbase[i] + ((int64_t)id * q.IH + ih) * q.IW + iw : 0;
-                v[j] = X[off];
-                if (ok) okmask |= 1u << (4 * i + j);
-            }
-            r[i] = make_float4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 16; ++i) {
+            const int row = (tid >> 5) + 8 * i;
+            const int cb = rowinfo[2 * row], tp = rowinfo[2 * row + 1];
+            const int id = bd + (tp & 1023), ih = bh + ((tp >> 10) & 1023), iw = bw + (tp >> 20);
+            const bool ok = pok && cb >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
+            const int64_t off = ok ? (int64_t)cb + ((int64_t)id * q.IH + ih) * q.IW + iw : 0;
+            v[i] = X[off];
+            if (ok) okmask |= 1u << i;
         }
         return okmask;
+    }
+    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const {
+        const int k = tid & 31, r0 = tid >> 5;
+        const float* v = reinterpret_cast<const float*>(&r[0]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[k][r0 + 8 * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
     }
 };
 
@@ -113,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q)
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
     const TileCoord t = tile_coord(g);
     const DenseLoader<true, VEC> la{g.A, g.a_m, 1, t.m0, g.M};                       // weights [Cout][Cin*KV]
-    const ConvFwdLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, g.K);        // X[b]
+    const ConvFwdLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);             // X[b]
     f32x16 acc[2][2];
     gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
     gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
@@ -124,7 +132,9 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom 
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
     const TileCoord t = tile_coord(g);
     const DenseLoader<true, VEC> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};   // dY[b] [Cout][P]
-    const ConvWgradLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, g.K);           // X[b]
+    __shared__ int rowinfo[256];
+    const ConvWgradLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, rowinfo);       // X[b]
+    __syncthreads();
     f32x16 acc[2][2];
     gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
     gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
@@ -136,6 +146,73 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int t = (int)(i % KV); const int64_t r = i / KV; const int co = (int)(r % Cout), ci = (int)(r / Cout);
         Wt[i] = W[((int64_t)co * Cin + ci) * KV + (KV - 1 - t)];
+    }
+}
+
+// Backward-data for STRIDED convolutions (only the 7x7x7 stride-2 stem, 3 input channels): a direct gather on the
+// vector ALU -- dX[b][ci][i] = sum_{co} sum_{taps t with (i + p - t) % s == 0} W[co][ci][t] * dY[b][co][(i + p - t) / s].
+// M = Cin = 3 would leave 97 % of an MFMA tile empty, so this one stays off the matrix cores.
+__global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
+                                                                     int B, int Cout, ConvGeom q) {
+    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW, total = (int64_t)B * q.Cin * isz;
+    const int KV = q.KD * q.KH * q.KW;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx; const int iw = (int)(r % q.IW); r /= q.IW; const int ih = (int)(r % q.IH); r /= q.IH;
+        const int id = (int)(r % q.ID); r /= q.ID; const int ci = (int)(r % q.Cin); const int b = (int)(r / q.Cin);
+        float acc = 0.f;
+        for (int kd = (id + q.pd) % q.sd; kd < q.KD; kd += q.sd) {
+            const int od = (id + q.pd - kd) / q.sd; if (id + q.pd - kd < 0 || od >= q.OD) continue;
+            for (int kh = (ih + q.ph) % q.sh; kh < q.KH; kh += q.sh) {
+                const int oh = (ih + q.ph - kh) / q.sh; if (ih + q.ph - kh < 0 || oh >= q.OH) continue;
+                for (int kw = (iw + q.pw) % q.sw; kw < q.KW; kw += q.sw) {
+                    const int ow = (iw + q.pw - kw) / q.sw; if (iw + q.pw - kw < 0 || ow >= q.OW) continue;
+                    const float* g = dY + (int64_t)b * Cout * osz + ((int64_t)od * q.OH + oh) * q.OW + ow;
+                    const float* w = W + (int64_t)ci * KV + (kd * q.KH + kh) * q.KW + kw;
+                    for (int co = 0; co < Cout; ++co) acc += w[(int64_t)co * q.Cin * KV] * g[(int64_t)co * osz];
+                }
+            }
+        }
+        dX[idx] = acc;
+    }
+}
+
+// out[b][cell] = 1 if the average-pooled |x| summed over channels is > 0 (get_mask: segtran2d.py:229-233, segtran3d.py:266-270)
+__global__ __launch_bounds__(256) void nonzero_mask_kernel(const float* __restrict__ X, float* __restrict__ out, int B, int C, int D, int H, int W,
+                                                           int kd, int kh, int kw) {
+    const int OD = D / kd, OH = H / kh, OW = W / kw;
+    const int64_t total = (int64_t)B * OD * OH * OW;
+    const float inv = 1.0f / (float)(kd * kh * kw);
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx; const int ow = (int)(r % OW); r /= OW; const int oh = (int)(r % OH); r /= OH; const int od = (int)(r % OD); const int b = (int)(r / OD);
+        float tot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* x = X + (((int64_t)b * C + c) * D + od * kd) * H * W;
+            float s = 0.f;
+            for (int z = 0; z < kd; ++z) for (int y = 0; y < kh; ++y) for (int xx = 0; xx < kw; ++xx)
+                s += fabsf(x[((int64_t)z * H + oh * kh + y) * W + ow * kw + xx]);
+            tot += s * inv;
+        }
+        out[idx] = tot > 0.f ? 1.0f : 0.f;
+    }
+}
+
+// n-hot label maps of the train step (datasets2d.py:90-139,200-223; datasets3d.py:16-40), uint8 / int32 labels -> float planes
+//   mode 0 fundus (exclusive=False): in [B,Cin>=2,S] uint8 -> [B,3,S]: (ch0==0, ch0>=1, ch1>=1)
+//   mode 1 polyp: [B,Cin>=1,S] uint8 -> [B,2,S]: (ch0==0, ch0>0)
+//   mode 2 brats: [B,S] int32 -> [B,4,S]: (l==0, l==3, l in {1,2,3}, l in {1,3})
+__global__ __launch_bounds__(256) void label_nhot_kernel(const void* __restrict__ lab, float* __restrict__ out, int B, int Cin, int64_t S, int mode) {
+    const int64_t total = (int64_t)B * S;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t b = idx / S, s = idx - b * S;
+        if (mode == 2) {
+            const int l = reinterpret_cast<const int*>(lab)[idx];
+            float* o = out + b * 4 * S + s;
+            o[0] = l == 0; o[S] = l == 3; o[2 * S] = (l == 1 || l == 2 || l == 3); o[3 * S] = (l == 1 || l == 3);
+        } else {
+            const unsigned char* m = reinterpret_cast<const unsigned char*>(lab) + b * Cin * S + s;
+            if (mode == 0) { float* o = out + b * 3 * S + s; o[0] = m[0] == 0; o[S] = m[0] >= 1; o[2 * S] = m[S] >= 1; }
+            else { float* o = out + b * 2 * S + s; o[0] = m[0] == 0; o[S] = m[0] > 0; }
+        }
     }
 }
 
@@ -235,6 +312,7 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int N = q.Cin * q.KD * q.KH * q.KW;
     SEGX_REQUIRE(P > 0 && P < 2147483647LL && N > 0, "segx_conv3d_bwd_weight: bad geometry");
+    SEGX_REQUIRE((int64_t)q.Cin * q.ID * q.IH * q.IW < 2147483647LL && q.KD < 1024 && q.KH < 1024 && q.KW < 1024, "segx_conv3d_bwd_weight: sample too large");
     if (splitk < 1) splitk = 1;
     SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_bwd_weight: split-K needs a workspace");
     GemmArgs g; g.A = dY; g.B = X; g.C = dWb;
@@ -271,4 +349,23 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const int64_t total = planes * q.ID * q.IH * q.IW;
     hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
     return check_launch("segx_maxpool3d_bwd");
+}
+extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && geom && B > 0 && Cout > 0, "segx_conv3d_bwd_data_direct: bad args");
+    const ConvGeom q = make_geom(geom);
+    const int64_t total = (int64_t)B * q.Cin * q.ID * q.IH * q.IW;
+    hipLaunchKernelGGL(conv3d_bwd_data_direct_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, W, dX, B, Cout, q);
+    return check_launch("segx_conv3d_bwd_data_direct");
+}
+extern "C" int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && out && B > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "segx_nonzero_mask: bad args");
+    const int64_t total = (int64_t)B * (D / kd) * (H / kh) * (W / kw);
+    hipLaunchKernelGGL(nonzero_mask_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, X, out, B, C, D, H, W, kd, kh, kw);
+    return check_launch("segx_nonzero_mask");
+}
+extern "C" int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, int mode, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(labels && out && B > 0 && S > 0 && mode >= 0 && mode <= 2 && (mode == 2 || Cin >= (mode == 0 ? 2 : 1)), "segx_label_nhot: bad args");
+    const int64_t total = (int64_t)B * S;
+    hipLaunchKernelGGL(label_nhot_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, labels, out, B, Cin, S, mode);
+    return check_launch("segx_label_nhot");
 }

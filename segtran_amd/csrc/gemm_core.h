@@ -94,14 +94,16 @@ __device__ __forceinline__ int xcd_tile(int wg, int ntiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Operand loader concept:  unsigned load(float4 (&r)[4], int k0, int kend, int tid) const;  static constexpr bool kc;
+// Operand loader concept: `unsigned load(float4 (&r)[4], int k0, int kend, int tid) const` fetches this thread's 16 floats
+// of the 128 x 32 tile starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing
+// the invalid ones) into the k-major LDS tile T[k][row].
 template <bool KC, bool VEC>
 struct DenseLoader {
-    static constexpr bool kc = KC;
     const float* base; int64_t s_row, s_k; int row0, rows;
     __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
         return load_tile<KC, VEC>(r, base, s_row, s_k, row0, rows, k0, kend, tid);
     }
+    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const { store_tile<KC>(r, okmask, T, tid); }
 };
 
 struct TileCoord { int m0, n0, zb, zk, z0, z1, kbeg, kend; };
@@ -133,8 +135,8 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
     float4 ra[4], rb[4];
     unsigned oka = la.load(ra, kbeg, kend, tid);
     unsigned okb = lb.load(rb, kbeg, kend, tid);
-    store_tile<LA::kc>(ra, oka, As, tid);
-    store_tile<LB::kc>(rb, okb, Bs, tid);
+    la.store(ra, oka, As, tid);
+    lb.store(rb, okb, Bs, tid);
     __syncthreads();
     const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kl = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
@@ -161,8 +163,8 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
         }
         __syncthreads();
         if (more) {
-            store_tile<LA::kc>(ra, oka, As, tid);
-            store_tile<LB::kc>(rb, okb, Bs, tid);
+            la.store(ra, oka, As, tid);
+            lb.store(rb, okb, Bs, tid);
         }
         __syncthreads();
     }

@@ -90,6 +90,10 @@ def synth_batch(cfg, B, device, seed=1337):
 
 
 def map_mask(task, raw):
+    """In-step label -> n-hot map.  On the GPU this is libsegx's label kernel; the torch expressions in
+    segtran_amd/dataloaders (same semantics, used by CPU-side tooling) are the readable statement of it."""
+    if raw.is_cuda:
+        return SF.label_nhot(raw, task)
     if task == 'fundus':
         return fundus_map_mask(raw)
     if task == 'polyp':

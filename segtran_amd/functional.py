@@ -738,12 +738,9 @@ class _Conv3d(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 L.conv3d_fwd(dy, wt, dx, B, Cin, g2)
             else:
-                # strided transposed convolution: only the 7x7x7 stride-2 stem (3 input channels) needs it.
-                # Still an ATen/MIOpen call (listed in DESIGN.md section 1, row a15).
-                (pd, pdb), (ph, phb), (pw, pwb) = ctx.pads
-                xp_shape = (B, Cin, ID + pd + pdb, IH + ph + phb, IW + pw + pwb)
-                dxp = torch.nn.grad.conv3d_input(xp_shape, w, dy, stride=ctx.stride, padding=0)
-                dx = dxp[:, :, pd:pd + ID, ph:ph + IH, pw:pw + IW].contiguous()
+                # strided transposed convolution (only the 7x7x7 stride-2 stem, 3 input channels): direct gather kernel
+                dx = torch.empty_like(x)
+                L.conv3d_bwd_data_direct(dy, w, dx, B, Cout, geom)
         if ctx.needs_input_grad[1]:
             P, N = OD * OH * OW, Cin * KV
             sk = _splitk(Cout, N, P, B)
@@ -803,3 +800,35 @@ def conv2d_dense(x, w, stride, pad):
     pad = (left, right, top, bottom) zero padding."""
     s = int(stride)
     return _Conv3d.apply(x.unsqueeze(2), w.unsqueeze(2), (1, s, s), ((0, 0), (int(pad[2]), int(pad[3])), (int(pad[0]), int(pad[1])))).squeeze(2)
+
+
+# -------------------------------------------------------------------------------------------------
+# Foreground mask and label maps (no gradients)
+# -------------------------------------------------------------------------------------------------
+def nonzero_mask(x, pool):
+    """get_mask (segtran2d.py:229-233 / segtran3d.py:266-270): [B,C,*spatial] -> 0/1 float [B, *spatial // pool]."""
+    L = segx.lib()
+    x = _c(x.detach())
+    B, C = x.shape[:2]
+    D, H, W = _dhw(x.shape[2:])
+    kd, kh, kw = _dhw(pool)
+    out = _empty(x, B, D // kd, H // kh, W // kw)
+    L.nonzero_mask(x, out, B, C, D, H, W, kd, kh, kw)
+    return out if x.dim() == 5 else out[:, 0]
+
+
+def label_nhot(labels, mode):
+    """mode 'fundus' | 'polyp' (uint8 [B,Cin,*S]) | 'brats' (integer [B,*S]) -> float n-hot [B,C,*S]."""
+    L = segx.lib()
+    m = {'fundus': 0, 'polyp': 1, 'brats': 2}[mode]
+    if m == 2:
+        lab = _c(labels.to(torch.int32))
+        B, S = lab.shape[0], lab[0].numel()
+        out = torch.empty((B, 4) + tuple(lab.shape[1:]), dtype=torch.float32, device=lab.device)
+        L.label_nhot(lab, out, B, 1, S, 2)
+    else:
+        lab = _c(labels.to(torch.uint8))
+        B, Cin, S = lab.shape[0], lab.shape[1], lab[0, 0].numel()
+        out = torch.empty((B, 3 if m == 0 else 2) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
+        L.label_nhot(lab, out, B, Cin, S, m)
+    return out

@@ -9,7 +9,7 @@ trainer forces / defaults to).  ResNet / EfficientNet-V2 backbones, BN FPNs, mod
 ablation are outside the hot path and raise.
 
 Kernel status: fusion encoder, every 1x1 conv (MFMA GEMM), GroupNorm and the bilinear resampling with the fused
-lateral addition run on libsegx; the foreground-mask pooling (K15, [B,H/8,W/8] booleans) is still an ATen call.
+lateral addition and the foreground-mask pooling (K15) all run on libsegx.
 """
 import numpy as np
 import torch
@@ -126,8 +126,8 @@ class Segtran2d(SegtranInitWeights):
         self.keep_feature_maps = False       # the reference always stores them (visualisation); opt-in here
 
     def get_mask(self, batch):
-        with torch.no_grad():
-            return self.mask_pool(batch.abs()).sum(dim=1) > 0
+        ks = self.mask_pool.kernel_size
+        return SF.nonzero_mask(batch, ks if isinstance(ks, tuple) else (ks, ks))       # 0/1 floats [B, H/8, W/8]
 
     def in_fpn_forward(self, feats, nonzero_mask, B):
         f3, f4 = feats[3], feats[4]

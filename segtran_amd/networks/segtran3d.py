@@ -132,8 +132,7 @@ class Segtran3d(SegtranInitWeights):
         self.layers_attn_scores, self.orig_feat_shape = None, None
 
     def get_mask(self, batch):
-        with torch.no_grad():
-            return (self.mask_pool(batch.abs()).sum(dim=1) > 0).long()
+        return SF.nonzero_mask(batch, self.mask_pool.kernel_size)                       # 0/1 floats [B, D/4, H/8, W/8]
 
     def in_fpn_forward(self, feats, nonzero_mask):
         f3, f4 = feats[3], feats[4]
@@ -141,7 +140,7 @@ class Segtran3d(SegtranInitWeights):
         cur = self.in_fpn_bridgeconv(cur)
         dp = [cur.shape[2] // self.D_pool_K, cur.shape[3], cur.shape[4]]
         cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
-        m = (_up(nonzero_mask.float().unsqueeze(1), dp).squeeze(1) >= 0.5)
+        m = (_up(nonzero_mask.unsqueeze(1), dp).squeeze(1) >= 0.5)
         B, Fd, D2, H2, W2 = cur.shape
         vfeat = cur.permute(0, 2, 3, 4, 1).reshape(B, -1, Fd)
         return vfeat, m.reshape(B, -1), D2, H2, W2

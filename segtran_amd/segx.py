@@ -261,6 +261,17 @@ class SegxLib:
                          lambda: self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), self.stream(Y)))
         self.check(rc, 'segx_conv3d_fwd')
 
+    def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
+        self._chk_t(dY, W, dX)
+        rc = self.c.segx_conv3d_bwd_data_direct(_ptr(dY), _ptr(W), _ptr(dX), B, Cout, self._geom(geom), self.stream(dX))
+        self.check(rc, 'segx_conv3d_bwd_data_direct')
+
+    def nonzero_mask(self, X, out, B, C, D, H, W, kd, kh, kw):
+        self._call('segx_nonzero_mask', X, X, out, B, C, D, H, W, kd, kh, kw)
+
+    def label_nhot(self, labels, out, B, Cin, S, mode):
+        self._call('segx_label_nhot', out, labels, out, B, Cin, S, mode)
+
     def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
         self._call('segx_conv3d_flip_weights', W, W, Wt, Cout, Cin, KV)
 
@@ -311,6 +322,7 @@ _SIGS = {
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
     'segx_conv3d_fwd': 'pppiipp', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
+    'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',

@@ -62,3 +62,32 @@ def test_stem_conv2d_on_implicit_gemm(backend):
     G = rnd(*y.shape, seed=8)
     y.backward(G); yr.backward(G)
     close(w.grad, wr.grad, 1e-4)
+
+
+def test_strided_backward_data_direct(backend):
+    """The stem's transposed convolution (7x7x7, stride 2) through the direct gather kernel."""
+    x = rnd(1, 3, 8, 10, 12, seed=9).requires_grad_(True)
+    w = (rnd(6, 3, 7, 7, 7, seed=10) * 0.1).requires_grad_(True)
+    y = SF.conv3d_same(x, w, (2, 2, 2))
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = _ref_conv(xr, wr, (2, 2, 2))
+    G = rnd(*y.shape, seed=11)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+
+
+def test_nonzero_mask_and_label_maps(backend):
+    from oracle import segtran_oracle as O
+    x = rnd(2, 3, 16, 24, seed=12); x[:, :, :8, :8] = 0; x[1, :, 8:, 16:] = 0
+    m = SF.nonzero_mask(x, (8, 8))
+    ref = (F.avg_pool2d(x.abs(), 8).sum(dim=1) > 0).float()
+    assert torch.equal(m, ref)
+    v = rnd(1, 4, 8, 16, 16, seed=13); v[:, :, :4] = 0; v[:, :, :, :8, 8:] = 0
+    m3 = SF.nonzero_mask(v, (4, 8, 8))
+    assert torch.equal(m3, (F.avg_pool3d(v.abs(), (4, 8, 8)).sum(dim=1) > 0).float())
+    g = torch.Generator(device='cpu').manual_seed(14)
+    fm = (torch.randint(0, 2, (2, 3, 9, 7), generator=g, device='cpu') * 255).to(torch.uint8)
+    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'fundus').cpu(), O.fundus_map_mask(fm))
+    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'polyp').cpu(), O.polyp_map_mask(fm))
+    lab = torch.randint(0, 4, (2, 5, 6, 4), generator=g, device='cpu')
+    assert torch.equal(SF.label_nhot(lab.to(backend.dev), 'brats').cpu(), O.brats_map_label(lab))
