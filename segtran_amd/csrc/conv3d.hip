@@ -152,14 +152,18 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restri
 // Backward-data for STRIDED convolutions (only the 7x7x7 stride-2 stem, 3 input channels): a direct gather on the
 // vector ALU -- dX[b][ci][i] = sum_{co} sum_{taps t with (i + p - t) % s == 0} W[co][ci][t] * dY[b][co][(i + p - t) / s].
 // M = Cin = 3 would leave 97 % of an MFMA tile empty, so this one stays off the matrix cores.
+// One thread per input POSITION accumulating all CIN channels (each dY value is loaded once for the CIN outputs).
+template <int CIN>
 __global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
                                                                      int B, int Cout, ConvGeom q) {
-    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW, total = (int64_t)B * q.Cin * isz;
+    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW, total = (int64_t)B * isz;
     const int KV = q.KD * q.KH * q.KW;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         int64_t r = idx; const int iw = (int)(r % q.IW); r /= q.IW; const int ih = (int)(r % q.IH); r /= q.IH;
-        const int id = (int)(r % q.ID); r /= q.ID; const int ci = (int)(r % q.Cin); const int b = (int)(r / q.Cin);
-        float acc = 0.f;
+        const int id = (int)(r % q.ID); const int b = (int)(r / q.ID);
+        float acc[CIN];
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
         for (int kd = (id + q.pd) % q.sd; kd < q.KD; kd += q.sd) {
             const int od = (id + q.pd - kd) / q.sd; if (id + q.pd - kd < 0 || od >= q.OD) continue;
             for (int kh = (ih + q.ph) % q.sh; kh < q.KH; kh += q.sh) {
@@ -167,12 +171,17 @@ __global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float
                 for (int kw = (iw + q.pw) % q.sw; kw < q.KW; kw += q.sw) {
                     const int ow = (iw + q.pw - kw) / q.sw; if (iw + q.pw - kw < 0 || ow >= q.OW) continue;
                     const float* g = dY + (int64_t)b * Cout * osz + ((int64_t)od * q.OH + oh) * q.OW + ow;
-                    const float* w = W + (int64_t)ci * KV + (kd * q.KH + kh) * q.KW + kw;
-                    for (int co = 0; co < Cout; ++co) acc += w[(int64_t)co * q.Cin * KV] * g[(int64_t)co * osz];
+                    const float* w = W + (kd * q.KH + kh) * q.KW + kw;
+                    for (int co = 0; co < Cout; ++co) {
+                        const float gv = g[(int64_t)co * osz];
+#pragma unroll
+                        for (int c = 0; c < CIN; ++c) acc[c] += w[((int64_t)co * CIN + c) * KV] * gv;
+                    }
                 }
             }
         }
-        dX[idx] = acc;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dX[((int64_t)b * CIN + c) * isz + (idx - (int64_t)b * isz)] = acc[c];
     }
 }
 
@@ -353,8 +362,15 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
 extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && geom && B > 0 && Cout > 0, "segx_conv3d_bwd_data_direct: bad args");
     const ConvGeom q = make_geom(geom);
-    const int64_t total = (int64_t)B * q.Cin * q.ID * q.IH * q.IW;
-    hipLaunchKernelGGL(conv3d_bwd_data_direct_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, W, dX, B, Cout, q);
+    const int64_t total = (int64_t)B * q.ID * q.IH * q.IW;
+    dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+    switch (q.Cin) {
+        case 1: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<1>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
+        case 2: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<2>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
+        case 3: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<3>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
+        case 4: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<4>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
+        default: return segx::fail(-1, "segx_conv3d_bwd_data_direct: built for Cin <= 4 (the I3D stem), got %d", q.Cin);
+    }
     return check_launch("segx_conv3d_bwd_data_direct");
 }
 extern "C" int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream_) {

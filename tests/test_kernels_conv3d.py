@@ -87,7 +87,7 @@ def test_nonzero_mask_and_label_maps(backend):
     assert torch.equal(m3, (F.avg_pool3d(v.abs(), (4, 8, 8)).sum(dim=1) > 0).float())
     g = torch.Generator(device='cpu').manual_seed(14)
     fm = (torch.randint(0, 2, (2, 3, 9, 7), generator=g, device='cpu') * 255).to(torch.uint8)
-    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'fundus').cpu(), O.fundus_map_mask(fm))
-    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'polyp').cpu(), O.polyp_map_mask(fm))
+    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'fundus').cpu(), O.fundus_map_mask(fm).cpu())
+    assert torch.equal(SF.label_nhot(fm.to(backend.dev), 'polyp').cpu(), O.polyp_map_mask(fm).cpu())
     lab = torch.randint(0, 4, (2, 5, 6, 4), generator=g, device='cpu')
-    assert torch.equal(SF.label_nhot(lab.to(backend.dev), 'brats').cpu(), O.brats_map_label(lab))
+    assert torch.equal(SF.label_nhot(lab.to(backend.dev), 'brats').cpu(), O.brats_map_label(lab).cpu())
