@@ -27,7 +27,7 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
 
 // ---- forward / backward-data: B(n = output position, k = (ci, tap)) ------------------------------------------------
 // Thread map: ONE output position per thread (n0 + (tid & 127): the 64 lanes of a wave read 64 consecutive positions,
-// i.e. whole 128-B lines for every tap), 16 k-rows (tid>>7)*16 + i.  The (ci, tap) decode of a k-row is wave-uniform.
+// i.e. whole 128-B lines for every tap), BKT/2 k-rows (tid>>7)*(BKT/2) + i.  The (ci, tap) decode of a k-row is wave-uniform.
 struct ConvFwdLoaderB {
     const float* X; ConvGeom q; FastDiv dKV, dKHW, dKW;
     int bd, bh, bw; bool nvalid;
@@ -39,13 +39,13 @@ struct ConvFwdLoaderB {
         const int od = nn / (q.OH * q.OW), r = nn - od * q.OH * q.OW, oh = r / q.OW, ow = r - oh * q.OW;
         bd = od * q.sd - q.pd; bh = oh * q.sh - q.ph; bw = ow * q.sw - q.pw;
     }
-    __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
+    __device__ __forceinline__ unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const {
         unsigned okmask = 0;
         const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
-        const int kbase = k0 + ((tid >> 7) << 4);                    // wave-uniform
+        const int kbase = k0 + (tid >> 7) * (BKT / 2);               // wave-uniform
         float* v = reinterpret_cast<float*>(&r[0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < BKT / 2; ++i) {
             const int k = kbase + i;
             const bool kok = k < kend;
             const int kk = kok ? k : 0;
@@ -58,10 +58,10 @@ struct ConvFwdLoaderB {
         }
         return okmask;
     }
-    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const {
-        const int n = tid & 127, kr = (tid >> 7) << 4;
+    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const {
+        const int n = tid & 127, kr = (tid >> 7) * (BKT / 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const unsigned mk = okmask >> (4 * i);
             T[kr + 4 * i + 0][n] = (mk & 1u) ? r[i].x : 0.f; T[kr + 4 * i + 1][n] = (mk & 2u) ? r[i].y : 0.f;
             T[kr + 4 * i + 2][n] = (mk & 4u) ? r[i].z : 0.f; T[kr + 4 * i + 3][n] = (mk & 8u) ? r[i].w : 0.f;
@@ -70,8 +70,8 @@ struct ConvFwdLoaderB {
 };
 
 // ---- backward-weight: B(n = (ci, tap), k = output position) ------------------------------------------------------
-// Thread map: ONE output position per thread and k-tile (k0 + (tid & 31): 32 consecutive positions = one 128-B line per
-// row), 16 rows (tid>>5) + 8*i whose (channel offset, tap) are decoded once into two registers each.
+// Thread map: ONE output position per thread and k-tile (k0 + (tid & (BKT-1)): a wave reads BKT consecutive positions of
+// one row = whole 128-B lines), 128*BKT/256 rows (tid / BKT) + (256/BKT)*i whose (channel offset, tap) sit in an LDS table.
 struct ConvWgradLoaderB {
     const float* X; ConvGeom q; FastDiv dOHW, dOW;
     const int* rowinfo;                                        // LDS: [128][2] = {channel offset (or -1: row outside N), kd | kh<<10 | kw<<20}
@@ -87,17 +87,17 @@ struct ConvWgradLoaderB {
             rowinfo_lds[2 * threadIdx.x + 1] = kd | (kh << 10) | (kw << 20);
         }
     }
-    __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
+    __device__ __forceinline__ unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const {
         unsigned okmask = 0;
-        const int p = k0 + (tid & 31);
+        const int p = k0 + (tid & (BKT - 1));
         const bool pok = p < kend;
         const int pp = pok ? p : 0;
         const int od = fdiv(pp, dOHW), rr = pp - od * q.OH * q.OW, oh = fdiv(rr, dOW), ow = rr - oh * q.OW;
         const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
         float* v = reinterpret_cast<float*>(&r[0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = (tid >> 5) + 8 * i;
+        for (int i = 0; i < 4 * NP; ++i) {
+            const int row = tid / BKT + (256 / BKT) * i;
             const int cb = rowinfo[2 * row], tp = rowinfo[2 * row + 1];
             const int id = bd + (tp & 1023), ih = bh + ((tp >> 10) & 1023), iw = bw + (tp >> 20);
             const bool ok = pok && cb >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
@@ -107,11 +107,11 @@ struct ConvWgradLoaderB {
         }
         return okmask;
     }
-    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const {
-        const int k = tid & 31, r0 = tid >> 5;
+    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const {
+        const int k = tid & (BKT - 1), r0 = tid / BKT;
         const float* v = reinterpret_cast<const float*>(&r[0]);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) T[k][r0 + 8 * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
+        for (int i = 0; i < 4 * NP; ++i) T[k][r0 + (256 / BKT) * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
     }
 };
 

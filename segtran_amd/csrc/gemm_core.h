@@ -6,7 +6,9 @@
 
 namespace segx {
 
-constexpr int BM = 128, BN = 128, BKT = 32, LDT = 132;
+constexpr int BM = 128, BN = 128, BKT = 64, LDT = 132;
+constexpr int NP = BKT / 8;            // float4 pieces per thread per operand tile: 128 * BKT / 4 / 256
+constexpr int KCH = BKT / 4;           // float4 chunks along k of a k-contiguous operand row
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -24,8 +26,8 @@ struct GemmArgs {
     int splitk; int64_t c_split;    // slab stride in the workspace
 };
 
-// Load this thread's 4 float4 pieces of a 128 x 32 operand tile into registers.
-//  KC = true : operand is k-contiguous;  piece f -> row f>>3, k-chunk f&7
+// Load this thread's NP float4 pieces of a 128 x BKT operand tile into registers.
+//  KC = true : operand is k-contiguous;  piece f -> row f / KCH, k-chunk f % KCH
 //  KC = false: operand is row-contiguous; piece f -> k-row f>>5, row-chunk f&31
 // VEC = true (16-B aligned base, all strides and extents multiples of 4): every float4 is either wholly inside
 // or wholly outside the operand, so the load is issued UNCONDITIONALLY from a clamped address and zeroed by a
@@ -34,14 +36,14 @@ struct GemmArgs {
 // The zeroing select is deferred to store_tile (through the returned validity mask): consuming a loaded value
 // right after the load would make the compiler wait for it BEFORE the MFMA block and lose the overlap.
 template <bool KC, bool VEC>
-__device__ __forceinline__ unsigned load_tile(float4 (&r)[4], const float* __restrict__ base, int64_t s_row, int64_t s_k,
+__device__ __forceinline__ unsigned load_tile(float4 (&r)[NP], const float* __restrict__ base, int64_t s_row, int64_t s_k,
                                               int row0, int rows, int k0, int kend, int tid) {
-    unsigned okmask = 0xFFFFu;                      // bit 4*i+j: element j of piece i is inside the operand
+    unsigned okmask = 0xFFFFFFFFu;                  // bit 4*i+j: element j of piece i is inside the operand
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int f = tid + 256 * i;
-        const int row = KC ? row0 + (f >> 3) : row0 + ((f & 31) << 2);
-        const int k = KC ? k0 + ((f & 7) << 2) : k0 + (f >> 5);
+        const int row = KC ? row0 + f / KCH : row0 + ((f & 31) << 2);
+        const int k = KC ? k0 + ((f % KCH) << 2) : k0 + (f >> 5);
         float4 v;
         if (VEC) {
             const int rc = KC ? (row < rows ? row : rows - 1) : (row < rows ? row : rows - 4);
@@ -69,15 +71,15 @@ __device__ __forceinline__ unsigned load_tile(float4 (&r)[4], const float* __res
 }
 
 template <bool KC>
-__device__ __forceinline__ void store_tile(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) {
+__device__ __forceinline__ void store_tile(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NP; ++i) {
         const int f = tid + 256 * i;
         const unsigned mk = okmask >> (4 * i);
         r[i].x = (mk & 1u) ? r[i].x : 0.f; r[i].y = (mk & 2u) ? r[i].y : 0.f;
         r[i].z = (mk & 4u) ? r[i].z : 0.f; r[i].w = (mk & 8u) ? r[i].w : 0.f;
         if (KC) {
-            const int row = f >> 3, k = (f & 7) << 2;
+            const int row = f / KCH, k = (f % KCH) << 2;
             T[k + 0][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
         } else {
             const int k = f >> 5, row = (f & 31) << 2;
@@ -94,16 +96,16 @@ __device__ __forceinline__ int xcd_tile(int wg, int ntiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Operand loader concept: `unsigned load(float4 (&r)[4], int k0, int kend, int tid) const` fetches this thread's 16 floats
-// of the 128 x 32 tile starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing
+// Operand loader concept: `unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const` fetches this thread's 4*NP floats
+// of the 128 x BKT tile starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing
 // the invalid ones) into the k-major LDS tile T[k][row].
 template <bool KC, bool VEC>
 struct DenseLoader {
     const float* base; int64_t s_row, s_k; int row0, rows;
-    __device__ __forceinline__ unsigned load(float4 (&r)[4], int k0, int kend, int tid) const {
+    __device__ __forceinline__ unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const {
         return load_tile<KC, VEC>(r, base, s_row, s_k, row0, rows, k0, kend, tid);
     }
-    __device__ __forceinline__ void store(float4 (&r)[4], unsigned okmask, float (*T)[LDT], int tid) const { store_tile<KC>(r, okmask, T, tid); }
+    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const { store_tile<KC>(r, okmask, T, tid); }
 };
 
 struct TileCoord { int m0, n0, zb, zk, z0, z1, kbeg, kend; };
@@ -132,7 +134,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (kbeg >= kend) return;                        // an empty split-K slab just writes zeros
-    float4 ra[4], rb[4];
+    float4 ra[NP], rb[NP];
     unsigned oka = la.load(ra, kbeg, kend, tid);
     unsigned okb = lb.load(rb, kbeg, kend, tid);
     la.store(ra, oka, As, tid);
