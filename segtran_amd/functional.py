@@ -65,7 +65,7 @@ def _splitk(M, N, K, nbatch):
     for sk in range(1, 33):
         if sk > 1 and K // sk < 256:
             break
-        kt = 2 * -(-(-(-K // sk)) // 64)             # k-tiles of 64 (= two 32-deep units of ktile_us each)
+        kt = -(-(-(-K // sk)) // 32)                 # ceil(ceil(K/sk)/32)
         rounds = -(-tiles * sk // _SLOTS)
         t = rounds * kt * ktile_us + (0 if sk == 1 else sk * M * N * nbatch * 8 / 3.0e6)
         if best_t is None or t < best_t * 0.97:
