@@ -116,7 +116,7 @@ struct ConvWgradLoaderB {
 };
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q) {
+__global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q) {
     __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
     const TileCoord t = tile_coord(g);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q)
     gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
 }
 template <bool VEC>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom q) {
+__global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom q) {
     __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
     const TileCoord t = tile_coord(g);

@@ -23,7 +23,7 @@
 namespace segx {
 
 template <bool AKC, bool BKC, bool VEC, int EPI>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
     const TileCoord t = tile_coord(g);

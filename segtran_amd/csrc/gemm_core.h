@@ -137,55 +137,43 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
     // Register prefetch is TWO k-tiles deep (two register sets, the k-loop is unrolled by two so that the sets are
     // statically indexed): the loads of tile t+2 are issued before the MFMAs of tile t and consumed after the MFMAs of
     // tile t+1, which rides out HBM/L2 latency spikes when all workgroups of a round fetch in lock step.
-    float4 ra0[NP], rb0[NP], ra1[NP], rb1[NP];
-    unsigned oka0, okb0, oka1 = 0, okb1 = 0;
-    oka0 = la.load(ra0, kbeg, kend, tid);
-    okb0 = lb.load(rb0, kbeg, kend, tid);
-    if (kbeg + BKT < kend) { oka1 = la.load(ra1, kbeg + BKT, kend, tid); okb1 = lb.load(rb1, kbeg + BKT, kend, tid); }
-    la.store(ra0, oka0, As, tid);
-    lb.store(rb0, okb0, Bs, tid);
+    float4 ra[2][NP], rb[2][NP];
+    unsigned oka[2] = {0u, 0u}, okb[2] = {0u, 0u};
+    oka[0] = la.load(ra[0], kbeg, kend, tid);
+    okb[0] = lb.load(rb[0], kbeg, kend, tid);
+    if (kbeg + BKT < kend) { oka[1] = la.load(ra[1], kbeg + BKT, kend, tid); okb[1] = lb.load(rb[1], kbeg + BKT, kend, tid); }
+    la.store(ra[0], oka[0], As, tid);
+    lb.store(rb[0], okb[0], Bs, tid);
     __syncthreads();
     const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kl = lane >> 5;
-
-#define SEGX_KTILE_MFMAS()                                                                                   \
-    {                                                                                                        \
-        float a0 = As[kl][arow], a1 = As[kl][arow + 32], b0 = Bs[kl][brow], b1 = Bs[kl][brow + 32];          \
-        _Pragma("unroll") for (int kk = 0; kk < BKT; kk += 2) {                                              \
-            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;                                                \
-            if (kk + 2 < BKT) {                                                                              \
-                na0 = As[kk + 2 + kl][arow]; na1 = As[kk + 2 + kl][arow + 32];                               \
-                nb0 = Bs[kk + 2 + kl][brow]; nb1 = Bs[kk + 2 + kl][brow + 32];                               \
-            }                                                                                                \
-            __builtin_amdgcn_sched_barrier(0); /* keep the fragment prefetch ahead of this step's MFMAs */   \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);                    \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);                    \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);                    \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);                    \
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;                                                          \
-        }                                                                                                    \
-    }
-
     for (int k0 = kbeg; k0 < kend; k0 += 2 * BKT) {
-        // ---- even tile (in LDS from set 0); set 0 is free again: fetch tile k0 + 2*BKT into it
-        const bool more1 = (k0 + BKT) < kend, more2 = (k0 + 2 * BKT) < kend;
-        if (more2) { oka0 = la.load(ra0, k0 + 2 * BKT, kend, tid); okb0 = lb.load(rb0, k0 + 2 * BKT, kend, tid); }
-        SEGX_KTILE_MFMAS();
-        __syncthreads();
-        if (!more1) break;
-        la.store(ra1, oka1, As, tid);
-        lb.store(rb1, okb1, Bs, tid);
-        __syncthreads();
-        // ---- odd tile (from set 1); fetch tile k0 + 3*BKT into set 1
-        const bool more3 = (k0 + 3 * BKT) < kend;
-        if (more3) { oka1 = la.load(ra1, k0 + 3 * BKT, kend, tid); okb1 = lb.load(rb1, k0 + 3 * BKT, kend, tid); }
-        SEGX_KTILE_MFMAS();
-        __syncthreads();
-        if (!more2) break;
-        la.store(ra0, oka0, As, tid);
-        lb.store(rb0, okb0, Bs, tid);
-        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                // h is a compile-time constant after unrolling: static register sets
+            const int kt = k0 + h * BKT;             // the tile now in LDS (it came from set h, which is free again)
+            if (kt < kend) {
+                if (kt + 2 * BKT < kend) { oka[h] = la.load(ra[h], kt + 2 * BKT, kend, tid); okb[h] = lb.load(rb[h], kt + 2 * BKT, kend, tid); }
+                // operand fragments are fetched one k2-step ahead of the MFMAs that consume them
+                float a0 = As[kl][arow], a1 = As[kl][arow + 32], b0 = Bs[kl][brow], b1 = Bs[kl][brow + 32];
+#pragma unroll
+                for (int kk = 0; kk < BKT; kk += 2) {
+                    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                    if (kk + 2 < BKT) {
+                        na0 = As[kk + 2 + kl][arow]; na1 = As[kk + 2 + kl][arow + 32];
+                        nb0 = Bs[kk + 2 + kl][brow]; nb1 = Bs[kk + 2 + kl][brow + 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of this step's MFMAs
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+                    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+                }
+                __syncthreads();
+                if (kt + BKT < kend) { la.store(ra[h ^ 1], oka[h ^ 1], As, tid); lb.store(rb[h ^ 1], okb[h ^ 1], Bs, tid); }
+                __syncthreads();
+            }
+        }
     }
-#undef SEGX_KTILE_MFMAS
 }
 
 // MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
