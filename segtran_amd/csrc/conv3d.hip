@@ -117,26 +117,24 @@ struct ConvWgradLoaderB {
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q) {
-    __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileLds lds;
     const TileCoord t = tile_coord(g);
     const DenseLoader<true, VEC> la{g.A, g.a_m, 1, t.m0, g.M};                       // weights [Cout][Cin*KV]
     const ConvFwdLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);             // X[b]
     f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
+    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
 }
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom q) {
-    __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileLds lds;
     const TileCoord t = tile_coord(g);
     const DenseLoader<true, VEC> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};   // dY[b] [Cout][P]
     __shared__ int rowinfo[256];
     const ConvWgradLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, rowinfo);       // X[b]
     __syncthreads();
     f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
+    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
 }
 

@@ -24,13 +24,12 @@ namespace segx {
 
 template <bool AKC, bool BKC, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) float As[BKT][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[BKT][LDT];
+    __shared__ __attribute__((aligned(16))) TileLds lds;
     const TileCoord t = tile_coord(g);
     const DenseLoader<AKC, VEC> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
     const DenseLoader<BKC, VEC> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
     f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, As, Bs);
+    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<EPI>(acc, g, t);
 }
 

@@ -38,7 +38,7 @@ struct GemmArgs {
 template <bool KC, bool VEC>
 __device__ __forceinline__ unsigned load_tile(float4 (&r)[NP], const float* __restrict__ base, int64_t s_row, int64_t s_k,
                                               int row0, int rows, int k0, int kend, int tid) {
-    unsigned okmask = 0xFFFFFFFFu;                  // bit 4*i+j: element j of piece i is inside the operand
+    unsigned okmask = NP == 8 ? 0xFFFFFFFFu : ((1u << (4 * NP)) - 1u);   // bit 4*i+j: element j of piece i is inside the operand
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int f = tid + 256 * i;
@@ -72,12 +72,17 @@ __device__ __forceinline__ unsigned load_tile(float4 (&r)[NP], const float* __re
 
 template <bool KC>
 __device__ __forceinline__ void store_tile(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) {
+    if (okmask != (NP == 8 ? 0xFFFFFFFFu : ((1u << (4 * NP)) - 1u))) {     // only tiles on an operand edge pay for the selects
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const unsigned mk = okmask >> (4 * i);
+            r[i].x = (mk & 1u) ? r[i].x : 0.f; r[i].y = (mk & 2u) ? r[i].y : 0.f;
+            r[i].z = (mk & 4u) ? r[i].z : 0.f; r[i].w = (mk & 8u) ? r[i].w : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
         const int f = tid + 256 * i;
-        const unsigned mk = okmask >> (4 * i);
-        r[i].x = (mk & 1u) ? r[i].x : 0.f; r[i].y = (mk & 2u) ? r[i].y : 0.f;
-        r[i].z = (mk & 4u) ? r[i].z : 0.f; r[i].w = (mk & 8u) ? r[i].w : 0.f;
         if (KC) {
             const int row = f / KCH, k = (f % KCH) << 2;
             T[k + 0][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
@@ -122,9 +127,11 @@ __device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
 }
 
 // acc += A_tile . B_tile^T over k in [kbeg, kend): the k-tile pipeline shared by every MFMA kernel of the library
+// LDS: two buffers per operand (2 x 2 x BKT x LDT x 4 B = 67.6 KB per workgroup -> two workgroups per CU)
+struct TileLds { float A[2][BKT][LDT]; float B[2][BKT][LDT]; };
+
 template <class LA, class LB>
-__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la, const LB& lb, int kbeg, int kend,
-                                              float (*As)[LDT], float (*Bs)[LDT]) {
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la, const LB& lb, int kbeg, int kend, TileLds& S) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -134,25 +141,28 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (kbeg >= kend) return;                        // an empty split-K slab just writes zeros
-    // Register prefetch is TWO k-tiles deep (two register sets, the k-loop is unrolled by two so that the sets are
-    // statically indexed): the loads of tile t+2 are issued before the MFMAs of tile t and consumed after the MFMAs of
-    // tile t+1, which rides out HBM/L2 latency spikes when all workgroups of a round fetch in lock step.
+    // Pipeline (per k-tile t, h = t & 1 static after unrolling by two):
+    //   global loads of tile t+2 -> register set h        (two tiles ahead: rides out lock-step fetch latency)
+    //   LDS stores of tile t+1 (register set h^1) -> LDS buffer h^1   (issued BEFORE the MFMAs, so they drain under them)
+    //   64 MFMAs on LDS buffer h, operand fragments fetched one k2-step ahead
+    //   ONE barrier (buffer h may be overwritten / buffer h^1 is complete)
     float4 ra[2][NP], rb[2][NP];
     unsigned oka[2] = {0u, 0u}, okb[2] = {0u, 0u};
     oka[0] = la.load(ra[0], kbeg, kend, tid);
     okb[0] = lb.load(rb[0], kbeg, kend, tid);
     if (kbeg + BKT < kend) { oka[1] = la.load(ra[1], kbeg + BKT, kend, tid); okb[1] = lb.load(rb[1], kbeg + BKT, kend, tid); }
-    la.store(ra[0], oka[0], As, tid);
-    lb.store(rb[0], okb[0], Bs, tid);
+    la.store(ra[0], oka[0], S.A[0], tid);
+    lb.store(rb[0], okb[0], S.B[0], tid);
     __syncthreads();
     const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kl = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += 2 * BKT) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                // h is a compile-time constant after unrolling: static register sets
-            const int kt = k0 + h * BKT;             // the tile now in LDS (it came from set h, which is free again)
+        for (int h = 0; h < 2; ++h) {
+            const int kt = k0 + h * BKT;
             if (kt < kend) {
+                float (*As)[LDT] = S.A[h]; float (*Bs)[LDT] = S.B[h];
                 if (kt + 2 * BKT < kend) { oka[h] = la.load(ra[h], kt + 2 * BKT, kend, tid); okb[h] = lb.load(rb[h], kt + 2 * BKT, kend, tid); }
-                // operand fragments are fetched one k2-step ahead of the MFMAs that consume them
+                if (kt + BKT < kend) { la.store(ra[h ^ 1], oka[h ^ 1], S.A[h ^ 1], tid); lb.store(rb[h ^ 1], okb[h ^ 1], S.B[h ^ 1], tid); }
                 float a0 = As[kl][arow], a1 = As[kl][arow + 32], b0 = Bs[kl][brow], b1 = Bs[kl][brow + 32];
 #pragma unroll
                 for (int kk = 0; kk < BKT; kk += 2) {
@@ -168,8 +178,6 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
                     a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
                 }
-                __syncthreads();
-                if (kt + BKT < kend) { la.store(ra[h ^ 1], oka[h ^ 1], As, tid); lb.store(rb[h ^ 1], okb[h ^ 1], Bs, tid); }
                 __syncthreads();
             }
         }
