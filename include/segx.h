@@ -63,6 +63,14 @@ int segx_softmax_fwd(const float* S, float* P, float* Pdrop, int64_t rows, int L
                      float p, uint64_t seed, uint64_t offset, void* stream);
 int segx_softmax_bwd(const float* P, const float* dPdrop, const float* S /* for the clamp mask, may be NULL */, float* dS,
                      int64_t rows, int L, float clip, const float* gmax, float p, uint64_t seed, uint64_t offset, void* stream);
+/* Sliding positional biases (SlidingPosBiases2D/3D, :1002-1175) as a relative-offset lookup that is never materialised:
+ * out = clamp_if(*gmax > clip)(S) + weight * table[pos(j) - pos(i) + R] for the nmat score matrices S [nmat, N, N]
+ * (:578-580 then :590-592).  geom (int32[5]) = {D, H, W, R, nd}: token grid (D = 1 in 2-D), radius, 2 or 3 position dims.
+ * bwd: dtable [(2R+1)^nd]; dS = clamp-masked dOut (pass S = dS = NULL when the clamp was inactive: dS == dOut). */
+int segx_posbias_fwd(const float* S, float* out, const float* table, int64_t nmat, int N, const int* geom, float weight, float clip,
+                     const float* gmax, void* stream);
+int segx_posbias_bwd(const float* dOut, const float* S, float* dS, float* dtable, int64_t nmat, int N, const int* geom, float weight,
+                     float clip, void* stream);
 /* nn.LayerNorm(eps=1e-12) (:262,:361 affine; :889 non-affine: w=b=NULL).  mean/rstd [rows] saved for backward. */
 int segx_layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd,
                        int64_t rows, int C, float eps, void* stream);
@@ -78,6 +86,7 @@ int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1024 floats 
 int segx_rowsum(const float* X, float* out, int64_t R, int64_t S, void* stream);
 /* SegtranFusionEncoder.forward per-layer prologue (:916-946):
  *   Y = mask * dropout( LN_noaffine( LN_affine(X; w1,b1) + pos_weight * pos[n, :C] ) ),  X [B,N,C], pos [N,pos_ld], mask [B*N]
+ * pos == NULL ('bias' positional codes, :937-940): Y = mask * dropout(LN_affine(X)), no second norm.
  * stats = 4*B*N floats.  Backward returns dX and dU (grad wrt LN_affine's output): dpos = pos_weight * sum_b dU,
  * (dw1, db1) = segx_ln_param_grad(dU, X, stats[0], stats[1]). */
 int segx_prenorm_fwd(const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,

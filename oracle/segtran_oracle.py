@@ -116,16 +116,29 @@ def sliding_pos_biases(table, shape):
 
 
 def fusion_encoder(sd, p, vfeat, voxels_pos, vmask, translayer_dims, num_modes=4, attn_clip=500.,
-                   pos_code_weight=1.0, stats=None, layers_out=None):
-    """SegtranFusionEncoder.forward  (segtran_shared.py:907-975), squeezed + 'lsinu' path."""
+                   pos_code_weight=1.0, stats=None, layers_out=None, squeezed=True, pos_code_type='lsinu',
+                   feat_shape=None):
+    """SegtranFusionEncoder.forward  (segtran_shared.py:907-975).  squeezed=False is --nosqueeze (plain multi-mode
+    self-attention, :873-878); pos_code_type 'bias' (:937-940, needs feat_shape) adds sliding positional biases to
+    the attention scores instead of positional embeddings to the tokens."""
     pos_normed = voxels_pos / voxels_pos.max()                 # SegtranPosEncoder.forward :1231
     for i in range(len(translayer_dims) - 1):
         vn = _ln(vfeat, sd, '%s.vfeat_norm_layers.%d' % (p, i))                       # :916
-        pos = learned_sinu_pos_embed(sd, p + '.pos_code_layer.pos_coder', pos_normed)  # :927 (regenerated per layer)
-        comb = vn + pos_code_weight * pos[:, :, :translayer_dims[i]]                   # :930-932
-        fn = F.layer_norm(comb, (comb.shape[-1],), None, None, LN_EPS)                 # :934 (no affine)
+        biases = None
+        if pos_code_type == 'bias':
+            biases = sliding_pos_biases(sd[p + '.pos_code_layer.pos_coder.biases'], feat_shape)   # :927, :1235-1238
+            fn = vn                                                                    # :940
+        else:
+            pos = learned_sinu_pos_embed(sd, p + '.pos_code_layer.pos_coder', pos_normed)  # :927 (regenerated per layer)
+            comb = vn + pos_code_weight * pos[:, :, :translayer_dims[i]]               # :930-932
+            fn = F.layer_norm(comb, (comb.shape[-1],), None, None, LN_EPS)             # :934 (no affine)
         fm = fn * vmask                                                                # :946
-        vfeat = squeezed_att_feat_trans(sd, '%s.translayers.%d' % (p, i), fm, num_modes, attn_clip, stats)
+        lp = '%s.translayers.%d' % (p, i)
+        if squeezed:
+            vfeat = squeezed_att_feat_trans(sd, lp, fm, num_modes, attn_clip, stats)
+        else:                                                                          # :955 self-attention
+            vfeat = cross_att_feat_trans(sd, lp, fm, fm, num_modes, True, attn_clip, pos_biases=biases,
+                                         pos_code_weight=pos_code_weight if biases is not None else 1.0, stats=stats)
         if layers_out is not None:
             layers_out.append(vfeat)
     return vfeat
@@ -296,7 +309,8 @@ def _up(x, size):
     return F.interpolate(x, size=tuple(size), mode='bilinear' if x.dim() == 4 else 'trilinear', align_corners=False)
 
 
-def segtran2d_forward(sd, x, translayer_dims, num_modes=4, training=False, attn_clip=500., stats=None, aux=None):
+def segtran2d_forward(sd, x, translayer_dims, num_modes=4, training=False, attn_clip=500., stats=None, aux=None,
+                      fusion_kw=None):
     """Segtran2d.forward (segtran2d.py:314-438): eff-b4, in_fpn '34', out_fpn '1234', scheme 'AN'."""
     B, _, H, W = x.shape
     mask = F.avg_pool2d(x.abs(), 8).sum(dim=1) > 0                                   # get_mask :229-233
@@ -308,7 +322,8 @@ def segtran2d_forward(sd, x, translayer_dims, num_modes=4, training=False, attn_
     vmask = mask.reshape(B, -1, 1)
     pos = gen_all_indices((H2, W2)).view(-1, 2).float() * torch.tensor([[H // H2, W // W2]])   # :372-389
     voxels_pos = pos.unsqueeze(0).repeat(B, 1, 1)
-    y = fusion_encoder(sd, 'voxel_fusion', vfeat, voxels_pos, vmask, translayer_dims, num_modes, attn_clip, stats=stats)
+    y = fusion_encoder(sd, 'voxel_fusion', vfeat, voxels_pos, vmask, translayer_dims, num_modes, attn_clip, stats=stats,
+                       **(dict(fusion_kw, feat_shape=(H2, W2)) if fusion_kw else {}))
     if aux is not None:
         aux['vfeat'] = vfeat; aux['vmask'] = vmask; aux['fused'] = y
     y = y.view(B, H2, W2, -1).permute(0, 3, 1, 2)                                    # :421-423

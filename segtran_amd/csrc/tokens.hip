@@ -132,6 +132,59 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 }
 
 // =================================================================================================
+// Sliding positional biases (SlidingPosBiases2D/3D, networks/segtran_shared.py:1002-1175; K14): the [N, N] bias is a
+// relative-offset lookup  bias[i][j] = table[pos(j) - pos(i) + R]  (0 outside the radius) and is NEVER materialised
+// (the reference scatters it into a zero [H,W,H+2R,W+2R] tensor: 64 MB at N = 4096).
+//   out = clamp_if_global_max_exceeds_clip(S) + w * bias        (:578-580 then :590-592)
+// =================================================================================================
+struct PosGeom { int D, H, W, R, nd; };          // token grid (D = 1 for 2-D), radius, number of position dims (2 or 3)
+__device__ __forceinline__ int posbias_index(int i, int j, const PosGeom& q) {
+    const int HW = q.H * q.W, T = 2 * q.R + 1;
+    const int di = i / HW, ri = i - di * HW, hi = ri / q.W, wi = ri - hi * q.W;
+    const int dj = j / HW, rj = j - dj * HW, hj = rj / q.W, wj = rj - hj * q.W;
+    const int dd = dj - di, dh = hj - hi, dw = wj - wi;
+    if (dd < -q.R || dd > q.R || dh < -q.R || dh > q.R || dw < -q.R || dw > q.R) return -1;
+    return q.nd == 3 ? ((dd + q.R) * T + (dh + q.R)) * T + (dw + q.R) : (dh + q.R) * T + (dw + q.R);
+}
+__global__ __launch_bounds__(256) void posbias_fwd_kernel(const float* __restrict__ S, float* __restrict__ out, const float* __restrict__ table,
+                                                          int64_t rows, int N, PosGeom q, float w, float clip, const float* __restrict__ gmax) {
+    const bool clamp = gmax && (*gmax > clip);
+    const int64_t total = rows * N;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / N; const int j = (int)(idx - row * N), i = (int)(row % N);
+        float v = S[idx];
+        if (clamp) v = fminf(fmaxf(v, -clip), clip);
+        const int t = posbias_index(i, j, q);
+        out[idx] = t >= 0 ? v + w * table[t] : v;
+    }
+}
+// dS = dOut where the clamp passed the gradient (only launched when the clamp was active)
+__global__ __launch_bounds__(256) void posbias_bwd_clamp_kernel(const float* __restrict__ dOut, const float* __restrict__ S, float* __restrict__ dS,
+                                                                int64_t total, float clip) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256)
+        dS[idx] = fabsf(S[idx]) <= clip ? dOut[idx] : 0.f;
+}
+// dtable[t] = w * sum over all (score matrix z, query i) of dOut[z][i][i + offset(t)]: one workgroup per table entry
+__global__ __launch_bounds__(256) void posbias_bwd_table_kernel(const float* __restrict__ dOut, float* __restrict__ dtable, int64_t nmat, int N,
+                                                                PosGeom q, float w) {
+    __shared__ float red[4];
+    const int T = 2 * q.R + 1, t = blockIdx.x;
+    int dd = 0, dh, dw;
+    if (q.nd == 3) { dd = t / (T * T) - q.R; dh = (t / T) % T - q.R; dw = t % T - q.R; } else { dh = t / T - q.R; dw = t % T - q.R; }
+    const int HW = q.H * q.W;
+    float s = 0.f;
+    for (int64_t e = threadIdx.x; e < nmat * N; e += 256) {
+        const int64_t z = e / N; const int i = (int)(e - z * N);
+        const int di = i / HW, ri = i - di * HW, hi = ri / q.W, wi = ri - hi * q.W;
+        const int dj = di + dd, hj = hi + dh, wj = wi + dw;
+        if (dj < 0 || dj >= q.D || hj < 0 || hj >= q.H || wj < 0 || wj >= q.W) continue;
+        s += dOut[(z * N + i) * N + (dj * q.H + hj) * q.W + wj];
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) dtable[t] = w * s;
+}
+
+// =================================================================================================
 // LayerNorm (eps 1e-12, N4): fwd, dX.  (:262,361 affine; :889 non-affine -> w == nullptr)
 // =================================================================================================
 template <int NV4>
@@ -259,11 +312,12 @@ __global__ __launch_bounds__(256) void prenorm_fwd_kernel(const float* __restric
     float m1, r1; row_stats(r, C, eps, m1, r1);
     SEGX_FOR_ROW(i, c4, C) {
         const float4 ww = reinterpret_cast<const float4*>(w1)[c4], bb = reinterpret_cast<const float4*>(b1)[c4];
-        const float4 pp = reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4];
+        const float4 pp = pos ? reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         SEGX_F4_OP(r.v[i], (r.v[i].x - m1) * r1 * ww.x + bb.x + pos_w * pp.x, (r.v[i].y - m1) * r1 * ww.y + bb.y + pos_w * pp.y,
                    (r.v[i].z - m1) * r1 * ww.z + bb.z + pos_w * pp.z, (r.v[i].w - m1) * r1 * ww.w + bb.w + pos_w * pp.w);
     }
-    float m2, r2; row_stats(r, C, eps, m2, r2);
+    float m2 = 0.f, r2 = 1.f;                     // pos == NULL ('bias' codes, :937-940): no second norm
+    if (pos) row_stats(r, C, eps, m2, r2);
     const float mk = mask[row];
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     SEGX_FOR_ROW(i, c4, C) {
@@ -292,7 +346,7 @@ __global__ __launch_bounds__(256) void prenorm_bwd_kernel(const float* __restric
     Row<NV4> xh, u, g; row_load(xh, X + row * C, C); row_load(g, dY + row * C, C);
     SEGX_FOR_ROW(i, c4, C) {
         const float4 ww = reinterpret_cast<const float4*>(w1)[c4], bb = reinterpret_cast<const float4*>(b1)[c4];
-        const float4 pp = reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4];
+        const float4 pp = pos ? reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         SEGX_F4_OP(xh.v[i], (xh.v[i].x - m1) * r1, (xh.v[i].y - m1) * r1, (xh.v[i].z - m1) * r1, (xh.v[i].w - m1) * r1);
         SEGX_F4_OP(u.v[i], ((xh.v[i].x * ww.x + bb.x + pos_w * pp.x) - m2) * r2, ((xh.v[i].y * ww.y + bb.y + pos_w * pp.y) - m2) * r2,
                    ((xh.v[i].z * ww.z + bb.z + pos_w * pp.z) - m2) * r2, ((xh.v[i].w * ww.w + bb.w + pos_w * pp.w) - m2) * r2);
@@ -302,7 +356,7 @@ __global__ __launch_bounds__(256) void prenorm_bwd_kernel(const float* __restric
     }
 #pragma unroll
     for (int i = 0; i < NV4; ++i) if (!(((threadIdx.x & 63) + 64 * i) * 4 < C)) u.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    ln_bwd_row(g, u, C, r2);                      // g := dU
+    if (pos) ln_bwd_row(g, u, C, r2);             // g := dU
     row_store(g, dU + row * C, C);
     SEGX_FOR_ROW(i, c4, C) { const float4 ww = reinterpret_cast<const float4*>(w1)[c4];
                              SEGX_F4_OP(g.v[i], g.v[i].x * ww.x, g.v[i].y * ww.y, g.v[i].z * ww.z, g.v[i].w * ww.w); }
@@ -593,8 +647,8 @@ extern "C" int segx_sum(const float* x, int64_t n, float* out, float* ws /* >= 1
 extern "C" int segx_prenorm_fwd(const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
                                 const float* mask, float* Y, float* stats, int64_t B, int N, int C, float eps,
                                 float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && w1 && b1 && pos && mask && Y && stats && B > 0 && N > 0, "segx_prenorm_fwd: bad args"); SEGX_ROWCHK(C);
-    SEGX_REQUIRE(pos_ld >= C && pos_ld % 4 == 0, "segx_prenorm_fwd: pos_ld %lld", (long long)pos_ld);
+    SEGX_STREAM; SEGX_REQUIRE(X && w1 && b1 && mask && Y && stats && B > 0 && N > 0, "segx_prenorm_fwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_REQUIRE(!pos || (pos_ld >= C && pos_ld % 4 == 0), "segx_prenorm_fwd: pos_ld %lld", (long long)pos_ld);
     const int64_t rows = B * N;
     SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, X, w1, b1, pos, pos_ld, pos_weight, mask, Y, stats, rows, N, C, eps, p, seed, offset));
     return check_launch("segx_prenorm_fwd");
@@ -602,7 +656,7 @@ extern "C" int segx_prenorm_fwd(const float* X, const float* w1, const float* b1
 extern "C" int segx_prenorm_bwd(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
                                 const float* mask, const float* stats, float* dX, float* dU, int64_t B, int N, int C,
                                 float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && w1 && b1 && pos && mask && stats && dX && dU && B > 0 && N > 0, "segx_prenorm_bwd: bad args"); SEGX_ROWCHK(C);
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && w1 && b1 && mask && stats && dX && dU && B > 0 && N > 0, "segx_prenorm_bwd: bad args"); SEGX_ROWCHK(C);
     const int64_t rows = B * N;
     SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dU, rows, N, C, p, seed, offset));
     return check_launch("segx_prenorm_bwd");
@@ -653,4 +707,26 @@ extern "C" int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t
     const int nb = (int)i64min(4096, (n / 4 + 255) / 256);
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset);
     return check_launch("segx_gelu_bwd");
+}
+/* geom = {D, H, W, R, nd}: token grid (D = 1 in 2-D), radius, position dims */
+extern "C" int segx_posbias_fwd(const float* S, float* out, const float* table, int64_t nmat, int N, const int* geom, float weight, float clip,
+                                const float* gmax, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(S && out && table && geom && nmat > 0 && N > 0, "segx_posbias_fwd: bad args");
+    PosGeom q{geom[0], geom[1], geom[2], geom[3], geom[4]};
+    SEGX_REQUIRE(q.D * q.H * q.W == N && (q.nd == 2 || q.nd == 3) && q.R >= 0, "segx_posbias_fwd: geometry does not match N=%d", N);
+    const int64_t total = nmat * N * N;
+    hipLaunchKernelGGL(posbias_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, S, out, table, nmat * N, N, q, weight, clip, gmax);
+    return check_launch("segx_posbias_fwd");
+}
+/* dS (clamp-masked copy of dOut; pass S = NULL when the clamp is known inactive and reuse dOut) and dtable */
+extern "C" int segx_posbias_bwd(const float* dOut, const float* S, float* dS, float* dtable, int64_t nmat, int N, const int* geom, float weight,
+                                float clip, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dOut && dtable && geom && nmat > 0 && N > 0 && (!S == !dS), "segx_posbias_bwd: bad args");
+    PosGeom q{geom[0], geom[1], geom[2], geom[3], geom[4]};
+    SEGX_REQUIRE(q.D * q.H * q.W == N && (q.nd == 2 || q.nd == 3), "segx_posbias_bwd: geometry does not match N=%d", N);
+    const int T = 2 * q.R + 1, nt = q.nd == 3 ? T * T * T : T * T;
+    const int64_t total = nmat * N * N;
+    if (S) hipLaunchKernelGGL(posbias_bwd_clamp_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dOut, S, dS, total, clip);
+    hipLaunchKernelGGL(posbias_bwd_table_kernel, dim3(nt), dim3(256), 0, stream, dOut, dtable, nmat, N, q, weight);
+    return check_launch("segx_posbias_bwd");
 }

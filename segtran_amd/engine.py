@@ -23,7 +23,7 @@ BCE_WEIGHT = {'fundus': [0., 1., 2.], 'polyp': [0., 1.], 'brats': [0., 3., 1., 1
 DEFAULTS = dict(lr=2e-4, decay=1e-4, grad_clip=0.1, dropout_prob=0.2, num_modes=4)        # train2d.py:266-385 (segtran)
 
 
-def model_args(c, device, dropout_prob=None, attractors=None):
+def model_args(c, device, dropout_prob=None, attractors=None, **over):
     a = dict(num_classes=c['num_classes'], num_attractors=attractors or c['attractors'], num_translayers=c['translayers'],
              translayer_compress_ratios=list(c['compress']), use_pretrained=False, bb_feat_upsize=True, in_fpn_use_bn=False,
              use_squeezed_transformer=True, num_modes=4, trans_output_type='private', mid_type='shared',
@@ -37,12 +37,15 @@ def model_args(c, device, dropout_prob=None, attractors=None):
     else:
         a.update(backbone_type='i3d', orig_in_channels=4, inchan_to3_scheme='bridgeconv', D_groupsize=1, D_pool_K=2,
                  out_fpn_upsampleD_scheme='interp', input_scale=(1, 1, 1))
+    unknown = set(over) - set(a)
+    assert not unknown, 'unknown model option(s): %s' % sorted(unknown)
+    a.update(over)                      # e.g. use_squeezed_transformer=False, pos_code_type='bias' (--nosqueeze --pos bias)
     return Namespace(**a)
 
 
-def build_model(cfg, device, dropout_prob=None, attractors=None, synth=True):
+def build_model(cfg, device, dropout_prob=None, attractors=None, synth=True, **over):
     c = CONFIGS[cfg] if isinstance(cfg, str) else cfg
-    args = model_args(c, device, dropout_prob, attractors)
+    args = model_args(c, device, dropout_prob, attractors, **over)
     if c['dim'] == 2:
         from .networks.segtran2d import Segtran2d, CONFIG
     else:

@@ -238,6 +238,41 @@ def softmax(S, clip=500.0, gmax=None, drop_p=0.0):
     return _Softmax.apply(S, float(clip), gmax, float(drop_p))
 
 
+class _PosBias(torch.autograd.Function):
+    """scores [.., N, N] -> clamp_if(global max > clip)(scores) + weight * sliding positional bias (never materialised)."""
+
+    @staticmethod
+    def forward(ctx, S, table, grid_shape, weight, clip, gmax):
+        L = segx.lib()
+        S, table = _c(S), _c(table)
+        N = S.shape[-1]
+        nmat = S.numel() // (N * N)
+        nd = table.dim()
+        dims = ((1,) + tuple(grid_shape)) if nd == 2 else tuple(grid_shape)
+        geom = tuple(int(v) for v in dims) + ((table.shape[0] - 1) // 2, nd)
+        out = torch.empty_like(S)
+        L.posbias_fwd(S, out, table, nmat, N, geom, weight, clip, gmax)
+        ctx.cfg = (nmat, N, geom, weight, clip)
+        ctx.save_for_backward(S, table, gmax)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        L = segx.lib()
+        S, table, gmax = ctx.saved_tensors
+        nmat, N, geom, weight, clip = ctx.cfg
+        dOut = _c(dOut)
+        dtable = torch.empty_like(table)
+        clamped = gmax is not None and bool(gmax.item() > clip)          # rare branch; one scalar read in backward only
+        dS = torch.empty_like(dOut) if clamped else None
+        L.posbias_bwd(dOut, S if clamped else None, dS, dtable, nmat, N, geom, weight, clip)
+        return (dS if clamped else dOut), dtable, None, None, None, None
+
+
+def pos_bias_add(S, table, grid_shape, weight=1.0, clip=500.0, gmax=None):
+    return _PosBias.apply(S, table, tuple(grid_shape), float(weight), float(clip), gmax)
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, w, b, eps):
@@ -277,12 +312,13 @@ class _PreNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, w1, b1, pos, mask, pos_weight, drop_p):
         L = segx.lib()
-        X, pos, mask = _c(X), _c(pos), _c(mask)
+        X, mask = _c(X), _c(mask)
+        pos = _c(pos) if pos is not None else None            # None: 'bias' codes, single norm (:937-940)
         B, N, C = X.shape
         Y = torch.empty_like(X)
         stats = _empty(X, 4 * B * N)
         seed, off = _Rng.reserve(X.numel()) if drop_p > 0 else (0, 0)
-        L.prenorm_fwd(X, w1, b1, pos, pos.shape[1], pos_weight, mask, Y, stats, B, N, C, LN_EPS, drop_p, seed, off)
+        L.prenorm_fwd(X, w1, b1, pos, pos.shape[1] if pos is not None else 0, pos_weight, mask, Y, stats, B, N, C, LN_EPS, drop_p, seed, off)
         ctx.cfg = (pos_weight, drop_p, seed, off)
         ctx.save_for_backward(X, w1, b1, pos, mask, stats)
         return Y
@@ -294,12 +330,12 @@ class _PreNorm(torch.autograd.Function):
         pw, p, seed, off = ctx.cfg
         B, N, C = X.shape
         dX, dU = torch.empty_like(X), torch.empty_like(X)
-        L.prenorm_bwd(_c(dY), X, w1, b1, pos, pos.shape[1], pw, mask, stats, dX, dU, B, N, C, p, seed, off)
+        L.prenorm_bwd(_c(dY), X, w1, b1, pos, pos.shape[1] if pos is not None else 0, pw, mask, stats, dX, dU, B, N, C, p, seed, off)
         rows = B * N
         dw, db = _empty(X, C), _empty(X, C)
         L.ln_param_grad(dU, X, stats[:rows], stats[rows:2 * rows], dw, db, _empty(X, L.colreduce_ws(rows, C, 2)), rows, C)
         dpos = None
-        if ctx.needs_input_grad[3]:
+        if pos is not None and ctx.needs_input_grad[3]:
             dsum = _empty(X, N * C)
             L.colsum(dU, dsum, _empty(X, L.colreduce_ws(B, N * C, 1)), B, N * C)
             dpos = torch.zeros_like(pos)

@@ -216,6 +216,7 @@ class CrossAttFeatTrans(nn.Module):
         self.keep_attn_scores = config.use_attn_consist_loss
         self.tie_qk_scheme = config.tie_qk_scheme
         self.attn_clip = float(config.attn_clip)
+        self.pos_code_weight = config.pos_code_weight if config.pos_code_type == 'bias' else 1      # :493-497
         self.attention_scores = None
         self.attn_max_dev = None          # device-side running max of the (positive) scores of the last call
 
@@ -240,9 +241,8 @@ class CrossAttFeatTrans(nn.Module):
 
     def forward(self, in_query, in_key=None, pos_biases=None):
         """in_query [B or 1, U1, C] (a leading 1 = shared by the whole batch, e.g. the attractors);
-        in_key [B, U2, C].  Returns [B, U1, F]."""
-        if pos_biases is not None:
-            raise NotImplementedError("'bias' positional codes need --nosqueeze (SURVEY.md 8(f) rank 3)")
+        in_key [B, U2, C].  Returns [B, U1, F].  pos_biases: a `SlidingPosBiasCode` (table + token grid) --
+        the [U1, U2] bias matrix of the reference is never materialised."""
         if in_key is None:
             in_key = in_query
         B, U2, C = in_key.shape
@@ -256,9 +256,15 @@ class CrossAttFeatTrans(nn.Module):
                                          (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),
                                          alpha=1.0 / math.sqrt(d)), gmax=gmax)
         self.attn_max_dev = gmax
-        self.attention_scores = scores if self.keep_attn_scores else None
         drop = self.attention_probs_dropout_prob if self.training else 0.0
-        probs = SF.softmax(scores, self.attn_clip, gmax, drop)                           # :578-605
+        if pos_biases is not None:                                                       # :578-580 then :590-592
+            assert U1 == U2 == pos_biases.numel, 'positional biases need self-attention over the whole token grid'
+            scores = SF.pos_bias_add(scores, pos_biases.table, pos_biases.grid_shape, self.pos_code_weight,
+                                     self.attn_clip, gmax)
+            probs = SF.softmax(scores, self.attn_clip, None, drop)                       # clamp already applied
+        else:
+            probs = SF.softmax(scores, self.attn_clip, gmax, drop)                       # :578-605
+        self.attention_scores = scores if self.keep_attn_scores else None
         return self.out_trans(in_key, probs)
 
 
@@ -303,20 +309,69 @@ class LearnedSinuPosEmbedder(nn.Module):
         return SF.pos_embed(pos_normed, self.pos_fc.weight, self.pos_fc.bias)
 
 
+class SlidingPosBiasCode:
+    """What SlidingPosBiases*.forward hands to the attention layers here: the learnable offset table and the
+    token grid.  bias[i, j] = table[pos(j) - pos(i) + R] inside the radius, 0 outside (reference :1051-1072)."""
+    __slots__ = ('table', 'grid_shape', 'numel')
+
+    def __init__(self, table, grid_shape):
+        self.table, self.grid_shape = table, tuple(int(s) for s in grid_shape)
+        self.numel = int(np.prod(self.grid_shape))
+
+
+class _SlidingPosBiases(nn.Module):
+    """Sliding-window positional biases (reference :1002-1175).  One Parameter `biases` [(2R+1)]^pos_dim.  The
+    reference also registers index buffers all_h1s/... (72 MB at max_pos_size 100x100) used to scatter the table
+    into a padded [H,W,H+2R,W+2R] tensor; the kernel computes the offset instead, so those buffers do not exist
+    here and are ignored when a reference checkpoint is loaded."""
+    _INDEX_BUFFERS = ('all_h1s', 'all_w1s', 'all_d1s', 'all_h2s', 'all_w2s', 'all_d2s')
+
+    def __init__(self, pos_dim, pos_bias_radius=7, max_pos_size=None):
+        super().__init__()
+        assert pos_dim == self.POS_DIM
+        self.pos_dim, self.R, self.max_pos_size = pos_dim, pos_bias_radius, max_pos_size
+        self.biases = Parameter(torch.zeros([2 * pos_bias_radius + 1] * pos_dim))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        for b in self._INDEX_BUFFERS:
+            state_dict.pop(prefix + b, None)
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+    def forward(self, feat_shape, device=None):
+        spatial = tuple(feat_shape)[-self.pos_dim:]
+        if self.max_pos_size is not None:
+            assert all(s <= m for s, m in zip(spatial, self.max_pos_size)), 'feature map exceeds max_pos_size'
+        return SlidingPosBiasCode(self.biases, spatial)
+
+
+class SlidingPosBiases2D(_SlidingPosBiases):
+    POS_DIM = 2
+
+
+class SlidingPosBiases3D(_SlidingPosBiases):
+    POS_DIM = 3
+
+
 class SegtranPosEncoder(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.feat_dim = config.trans_in_dim
         self.pos_embed_dim = self.feat_dim
         self.pos_code_type = config.pos_code_type
-        if self.pos_code_type != 'lsinu':
-            raise NotImplementedError("pos_code_type='%s': only 'lsinu' (default) is built" % self.pos_code_type)
-        self.pos_coder = LearnedSinuPosEmbedder(config.pos_dim, self.pos_embed_dim, omega=1, affine=False)
+        if self.pos_code_type == 'lsinu':
+            self.pos_coder = LearnedSinuPosEmbedder(config.pos_dim, self.pos_embed_dim, omega=1, affine=False)
+        elif self.pos_code_type == 'bias':
+            cls = SlidingPosBiases2D if config.pos_dim == 2 else SlidingPosBiases3D
+            self.pos_coder = cls(config.pos_dim, config.pos_bias_radius, config.max_pos_size)
+        else:
+            raise NotImplementedError("pos_code_type='%s': 'lsinu' (default) and 'bias' are built" % self.pos_code_type)
         self.cached_pos_code = None
         self.cached_feat_shape = None
 
     def forward(self, orig_feat_shape, voxels_pos):
         """voxels_pos [N, pos_dim] or [B, N, pos_dim] (identical rows per sample).  Eval mode caches (:1208-1226)."""
+        if self.pos_code_type == 'bias':
+            return self.pos_coder(orig_feat_shape)               # nothing to cache: the code is (table, grid)
         vp = voxels_pos[0] if voxels_pos.dim() == 3 else voxels_pos
         if (not self.training) and self.cached_pos_code is not None and self.cached_feat_shape == tuple(vp.shape) \
                 and self.cached_pos_code.device == vp.device:
@@ -339,17 +394,19 @@ class SegtranFusionEncoder(nn.Module):
         self.translayer_dims = config.translayer_dims
         self.hidden_dropout_prob = config.hidden_dropout_prob
         self.use_squeezed_transformer = config.use_squeezed_transformer
-        if not self.use_squeezed_transformer:
-            raise NotImplementedError('--nosqueeze (full N x N attention) is a "next" row (SURVEY.md 8(f) rank 3)')
-        if config.use_mince_transformer or self.pos_code_type == 'bias':
-            raise ValueError('Squeezed transformer cannot be used with Mince / positional biases (reference :836-844)')
-        self.pos_code_weight = config.pos_code_weight
+        if config.use_mince_transformer:
+            raise NotImplementedError('Mince transformer is outside the built path')
+        if self.use_squeezed_transformer and self.pos_code_type == 'bias':
+            raise ValueError("Squeezed transformer cannot use positional biases; specify --nosqueeze (reference :836-844)")
+        self.pos_code_weight = config.pos_code_weight if self.pos_code_type != 'bias' else 0      # :847-850
         self.pos_code_layer = SegtranPosEncoder(config)
+        # --nosqueeze: plain multi-mode self-attention over all N tokens (:873-878)
+        TransformerClass = SqueezedAttFeatTrans if self.use_squeezed_transformer else CrossAttFeatTrans
         layers = []
         for i in range(self.num_translayers):
             c2 = copy.copy(config)
             c2.in_feat_dim, c2.feat_dim = self.translayer_dims[i], self.translayer_dims[i + 1]
-            layers.append(SqueezedAttFeatTrans(c2, '%s%d' % (name, i)))
+            layers.append(TransformerClass(c2, '%s%d' % (name, i)))
         self.translayers = nn.ModuleList(layers)
         dims = self.translayer_dims[:-1]
         self.comb_norm_layers = nn.ModuleList([nn.LayerNorm(d, eps=1e-12, elementwise_affine=False) for d in dims])
@@ -365,11 +422,16 @@ class SegtranFusionEncoder(nn.Module):
         B, N, _ = vfeat.shape
         mask = vmask.reshape(B, N).to(torch.float32)
         pos_code = self.pos_code_layer(orig_feat_shape, voxels_pos)                       # [N, C0], once per forward
+        biases = pos_code if self.pos_code_type == 'bias' else None
         for i, translayer in enumerate(self.translayers):
             nl = self.vfeat_norm_layers[i]
             drop = self.hidden_dropout_prob if (self.training and i == 0) else 0.0       # :944-945
-            feat = SF.prenorm(vfeat, nl.weight, nl.bias, pos_code, mask, self.pos_code_weight, drop)
-            vfeat = translayer(feat)
+            if biases is not None:          # codes go to the attention scores; tokens get LN_affine only (:937-940)
+                feat = SF.prenorm(vfeat, nl.weight, nl.bias, None, mask, 0.0, drop)
+                vfeat = translayer(feat, pos_biases=biases)
+            else:
+                feat = SF.prenorm(vfeat, nl.weight, nl.bias, pos_code, mask, self.pos_code_weight, drop)
+                vfeat = translayer(feat)
             self.layers_vfeat.append(vfeat)
         self.layers_attn_scores = None
         self.orig_feat_shape = orig_feat_shape

@@ -125,6 +125,16 @@ class SegxLib:
     def softmax_bwd(self, P, dPd, S, dS, rows, L, clip, gmax, p, seed, offset):
         self._call('segx_softmax_bwd', P, P, dPd, S, dS, rows, L, clip, gmax, p, seed, offset)
 
+    def posbias_fwd(self, S, out, table, nmat, N, geom, weight, clip, gmax):
+        self._chk_t(S, out, table, gmax)
+        rc = self.c.segx_posbias_fwd(_ptr(S), _ptr(out), _ptr(table), nmat, N, self._geom(geom), weight, clip, _ptr(gmax), self.stream(out))
+        self.check(rc, 'segx_posbias_fwd')
+
+    def posbias_bwd(self, dOut, S, dS, dtable, nmat, N, geom, weight, clip):
+        self._chk_t(dOut, S, dS, dtable)
+        rc = self.c.segx_posbias_bwd(_ptr(dOut), _ptr(S), _ptr(dS), _ptr(dtable), nmat, N, self._geom(geom), weight, clip, self.stream(dtable))
+        self.check(rc, 'segx_posbias_bwd')
+
     def layernorm_fwd(self, X, w, b, Y, mean, rstd, rows, C, eps):
         self._call('segx_layernorm_fwd', X, X, w, b, Y, mean, rstd, rows, C, eps)
 
@@ -308,6 +318,7 @@ class SegxLib:
 
 # C signatures (include/segx.h): p pointer, i int32, l int64, f float, u uint64; trailing p = stream
 _SIGS = {
+    'segx_posbias_fwd': 'ppplipffpp', 'segx_posbias_bwd': 'pppplipffp',
     'segx_softmax_fwd': 'ppplifpfuup', 'segx_softmax_bwd': 'pppplifpfuup',
     'segx_layernorm_fwd': 'pppppplifp', 'segx_layernorm_bwd': 'pppppplip',
     'segx_colreduce_ws_floats': 'lli', 'segx_colsum': 'pppllp', 'segx_ln_param_grad': 'ppppppplip',

@@ -152,6 +152,47 @@ def case_fusion():
     save('fusion_small', **arrs)
 
 
+def case_fusion_nosqueeze():
+    """--nosqueeze (plain multi-mode self-attention over all tokens), with 'lsinu' codes and with '--pos bias'
+    sliding positional biases (2-D and 3-D), small radius so that in-radius and out-of-radius pairs both occur."""
+    ss = R.ref_shared()
+    dims = [64, 64, 32]
+    for tag, (pos_type, shape) in {'lsinu': ('lsinu', (6, 8)), 'bias2d': ('bias', (6, 8)), 'bias3d': ('bias', (3, 4, 5))}.items():
+        pd = len(shape)
+        cfg = mk_shared_config(ss, 64, dims, 16, pos_dim=pd)
+        cfg.use_squeezed_transformer = False
+        cfg.pos_code_type, cfg.pos_bias_radius, cfg.pos_code_weight = pos_type, 2, 0.8
+        cfg.max_pos_size = (8,) * pd
+        mod = R.quiet(ss.SegtranFusionEncoder, cfg, 'Fusion')
+        prefix = 'voxel_fusion.'
+        shapes = {prefix + k: tuple(v.shape) for k, v in mod.state_dict().items() if '.all_' not in k}   # not the index buffers
+        sd = synth_state_dict(shapes)
+        mod.load_state_dict({k[len(prefix):]: v for k, v in sd.items()}, strict=False)
+        R.quiet(lambda: [m.tie_qk('shared') for m in mod.modules() if hasattr(m, 'tie_qk') and hasattr(m, 'query')])
+        mod.eval()
+        g = torch.Generator().manual_seed(21)
+        N = int(np.prod(shape))
+        X = torch.randn(2, N, 64, generator=g).requires_grad_(True)
+        G = torch.randn(2, N, 32, generator=g)
+        vmask = (torch.rand(2, N, 1, generator=g) > 0.25)
+        pos = (O.gen_all_indices(shape).view(-1, pd).float() * 8).unsqueeze(0).repeat(2, 1, 1)
+        Y = mod(X, pos, vmask, torch.Size(shape)); (Y * G).sum().backward()
+        sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
+        Yo = O.fusion_encoder(sdg, 'voxel_fusion', Xo, pos, vmask, dims, pos_code_weight=0.8, squeezed=False,
+                              pos_code_type=pos_type, feat_shape=shape)
+        (Yo * G).sum().backward()
+        close(Yo, Y, 1e-5, 'nosqueeze Y'); close(Xo.grad, X.grad, 1e-4, 'nosqueeze dX')
+        rg, og = ref_param_grads(mod, prefix), oracle_grads(sdg)
+        arrs = dict(X=X, G=G, vmask=vmask, pos=pos, Y=Y, dX=X.grad, dims=np.array(dims), shape=np.array(shape))
+        gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+        for k, v in rg.items():
+            if v is None:
+                continue
+            assert (og[k] - v).abs().max().item() <= 2e-4 * gscale, k
+            arrs['grad:' + k] = v
+        save('fusion_nosqueeze_' + tag, **arrs)
+
+
 def case_posbias():
     ss = R.ref_shared()
     g = torch.Generator().manual_seed(13)
@@ -224,6 +265,9 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'in_fpn34_conv.weight', 'in_gn4b.bias',
                 'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight',
                 'voxel_fusion.vfeat_norm_layers.0.weight',
+                'voxel_fusion.pos_code_layer.pos_coder.biases',
+                'voxel_fusion.translayers.0.query.weight', 'voxel_fusion.translayers.0.out_trans.first_linear.weight',
+                'voxel_fusion.translayers.0.out_trans.output.group_linear.weight',
                 'voxel_fusion.translayers.0.attractors',
                 'voxel_fusion.translayers.0.in_ator_trans.query.weight',
                 'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_linear.weight',
@@ -243,8 +287,8 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'backbone._blocks.31._bn1.bias', 'backbone._conv_head.weight']
 
 
-def run_seg2d(tag, tl, compress, dims, A, B, S, train):
-    net = R.ref_segtran2d(num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0)
+def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, **over):
+    net = R.ref_segtran2d(num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0, **over)
     sd = load_synth(net)
     if train:
         net.train()
@@ -260,7 +304,7 @@ def run_seg2d(tag, tl, compress, dims, A, B, S, train):
     loss, ce, dice, _ = O.seg_loss(y, nhot, pw)          # composition restated; pinned separately by case_loss
     loss.backward()
     sdg = req(sd)
-    yo = O.segtran2d_forward(sdg, x, dims, training=train)
+    yo = O.segtran2d_forward(sdg, x, dims, training=train, fusion_kw=fusion_kw)
     lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
     close(yo, y, 2e-5, tag + ' logits')
     og = oracle_grads(sdg)
@@ -286,6 +330,10 @@ def case_seg2d():
     run_seg2d('seg2d_cfg2_eval', 3, (1, 1, 2, 2), [1792, 1792, 896, 448], 32, 2, 64, False)
     run_seg2d('seg2d_cfg1_eval', 1, (1, 1), [1792, 1792], 32, 2, 64, False)
     run_seg2d('seg2d_cfg2_train', 3, (1, 1, 2, 2), [1792, 1792, 896, 448], 32, 2, 64, True)
+    # --nosqueeze --pos bias --posr 3 (8x8 tokens: pairs inside and outside the radius)
+    run_seg2d('seg2d_cfg1_nosq_bias_train', 1, (1, 1), [1792, 1792], 32, 2, 64, True,
+              fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0),
+              use_squeezed_transformer=False, pos_code_type='bias', pos_bias_radius=3)
 
 
 GRAD_KEYS_3D = ['in_bridge_to3.weight', 'out_conv3d.weight', 'out_fpn_bridgeconv3d.weight', 'out_fpn12_conv3d.weight',
@@ -429,7 +477,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, posbias=case_posbias, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 

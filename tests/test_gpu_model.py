@@ -53,6 +53,27 @@ def test_segtran2d_vs_reference(tag, cfg, train):
     _grads_vs_golden(net, g)
 
 
+def test_segtran2d_nosqueeze_pos_bias_vs_reference():
+    """--nosqueeze --pos bias --posr 3, train mode, logits + loss + gradients (incl. the bias table)."""
+    g = golden('seg2d_cfg1_nosq_bias_train')
+    c = dict(engine.CONFIGS['cfg1'], size=(64, 64))
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']), use_squeezed_transformer=False,
+                             pos_code_type='bias', pos_bias_radius=3)
+    net.backbone.drop_connect_rate = 0.0
+    net.train()
+    y = net(g['x'].to(DEV))
+    assert_close(y, g['logits'], 1e-4, 'logits')
+    assert (y.cpu() - g['logits']).abs().max().item() < 1e-3
+    safe = g['logits'].abs() > 1e-5
+    assert torch.equal((y.cpu() > 0)[safe], g['labels'][safe])
+    pw, cw = engine.loss_weights('fundus', DEV)
+    loss, _ = SF.seg_loss(y, engine.map_mask('fundus', g['mask'].to(DEV)), pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    loss.backward()
+    assert 'grad:voxel_fusion.pos_code_layer.pos_coder.biases' in g
+    _grads_vs_golden(net, g)
+
+
 @pytest.mark.parametrize('tag,train', [('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)])
 def test_segtran3d_vs_reference(tag, train):
     g = golden(tag)

@@ -228,3 +228,30 @@ def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask(backend):
     k = torch.empty(R * Fd)
     Lb.gelu_bwd(torch.ones(R * Fd), torch.full((R * Fd,), 30.0), k, R * Fd, p, 3, 8)
     close(Y, F.gelu(T) * k.view(R, Fd), 1e-5)
+
+
+@pytest.mark.parametrize('shape,R', [((5, 6), 2), ((3, 4, 2), 1), ((4, 4), 7)])
+@pytest.mark.parametrize('clamped', [False, True])
+def test_sliding_pos_bias_add(backend, shape, R, clamped):
+    """K14: scores + w * bias[N,N] computed on the fly from the (2R+1)^d table, vs the oracle's materialised lookup."""
+    from oracle import segtran_oracle as O
+    from segtran_amd import functional as SF
+    N = 1
+    for s_ in shape:
+        N *= s_
+    nd = len(shape)
+    table = rnd(*([2 * R + 1] * nd), seed=40)
+    S = rnd(3, 2, N, N, seed=41, scale=3.0)
+    clip, w = 4.0, 0.7
+    gmax = torch.tensor([S.max().item() if clamped else 1.0])
+    tr = table.detach().clone().cpu().requires_grad_(True)
+    Sr = S.detach().clone().cpu().requires_grad_(True)
+    with torch.device('cpu'):                                  # the oracle is CPU code; the hip backend sets a cuda default device
+        ref = (Sr.clamp(-clip, clip) if clamped else Sr) + w * O.sliding_pos_biases(tr, shape)
+    t2 = table.clone().requires_grad_(True); S2 = S.clone().requires_grad_(True)
+    out = SF.pos_bias_add(S2, t2, shape, w, clip, gmax)
+    close(out.cpu(), ref.detach(), 1e-6)
+    G = rnd(3, 2, N, N, seed=42)
+    out.backward(G); ref.backward(G.cpu())
+    close(S2.grad.cpu(), Sr.grad, 1e-6)
+    close(t2.grad.cpu(), tr.grad, 1e-5)

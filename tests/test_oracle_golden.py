@@ -62,6 +62,24 @@ def test_fusion_encoder():
     _grad_check(g, tied_grads(sdg))
 
 
+@pytest.mark.parametrize('tag', ['lsinu', 'bias2d', 'bias3d'])
+def test_fusion_encoder_nosqueeze(tag):
+    g = golden('fusion_nosqueeze_' + tag)
+    shapes = {k[5:]: tuple(v.shape) for k, v in g.items() if k.startswith('grad:')}
+    for k in list(shapes):
+        if '.query.' in k:
+            shapes[k.replace('.query.', '.key.')] = shapes[k]
+    sdg = req(synth_state_dict(shapes))
+    X = g['X'].clone().requires_grad_(True)
+    Y = O.fusion_encoder(sdg, 'voxel_fusion', X, g['pos'], g['vmask'], [int(d) for d in g['dims']], pos_code_weight=0.8,
+                         squeezed=False, pos_code_type='lsinu' if tag == 'lsinu' else 'bias',
+                         feat_shape=tuple(int(v) for v in g['shape']))
+    (Y * g['G']).sum().backward()
+    assert_close(Y, g['Y'], 1e-5, 'Y')
+    assert_close(X.grad, g['dX'], 1e-4, 'dX')
+    _grad_check(g, tied_grads(sdg))
+
+
 def test_sliding_pos_biases():
     g = golden('posbias')
     for d, shape in (('2', (5, 6)), ('3', (3, 4, 2))):
@@ -125,6 +143,24 @@ def test_segtran2d(tag, cfg):
     og = tied_grads(sdg)
     for k in g['unused']:                                     # N3: never receive a gradient
         assert str(k) not in og or og[str(k)].abs().max() == 0
+
+
+def test_segtran2d_nosqueeze_pos_bias():
+    """SURVEY 8 a11 whole model (--nosqueeze --pos bias --posr 3); the state-dict layout comes from the product model,
+    so this also pins its parameter names/shapes for that variant against the reference-generated fixture."""
+    from segtran_amd import engine
+    g = golden('seg2d_cfg1_nosq_bias_train')
+    net = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(64, 64)), 'cpu', dropout_prob=0.0, attractors=int(g['A']),
+                             synth=False, use_squeezed_transformer=False, pos_code_type='bias', pos_bias_radius=3)
+    sdg = req(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    y = O.segtran2d_forward(sdg, g['x'], [int(d) for d in g['dims']], training=True,
+                            fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0))
+    assert_close(y, g['logits'], 2e-5, 'logits')
+    assert torch.equal(y > 0, g['labels'])
+    loss = O.seg_loss(y, O.fundus_map_mask(g['mask']), O.bce_pos_weight([0., 1., 2.]))[0]
+    assert abs(loss.item() - float(g['loss'])) < 1e-5
+    loss.backward()
+    _grad_check(g, tied_grads(sdg))
 
 
 @pytest.mark.parametrize('tag', ['seg3d_cfg4_eval', 'seg3d_cfg4_train'])
