@@ -163,7 +163,8 @@ def main():
         for e0, e1, fl, shp in prof:
             a = agg.setdefault(shp, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
         print('[bench] GEMM shapes by time (M,N,K,batch,A_kcontig,B_kcontig,splitk): count ms TFLOP/s', file=sys.stderr)
-        for shp, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+        top = None if os.environ['SEGX_BENCH_VERBOSE'] == '2' else 40
+        for shp, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
             print('[bench]   %-46s %4d %8.2f %7.1f' % (shp, n, t, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
     res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), args.config), 'value': round(world * B * args.steps / dt, 3),

@@ -170,7 +170,9 @@ int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, in
                       int pad_t, int pad_l, void* stream);
 int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, int C, int H, int Wd, int OH, int OW, int k,
                            int stride, int pad_t, int pad_l, void* stream);
-/* per-sample partial weight gradients part[B][C][k*k]; sum over B with segx_colsum */
+/* partial weight gradients part[B * rows][C][k*k], rows = segx_dwconv2d_wgrad_rows(OH, OW) row strips per sample;
+ * dW = segx_colsum over the B*rows rows (deterministic two-stage sum, no atomics) */
+int64_t segx_dwconv2d_wgrad_rows(int OH, int OW);
 int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B, int C, int H, int Wd, int OH, int OW, int k,
                              int stride, int pad_t, int pad_l, void* stream);
 /* squeeze-excite plane ops (efficientnet/model.py:105-110) on [planes = B*C, S]:

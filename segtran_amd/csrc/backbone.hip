@@ -145,30 +145,263 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
 // =================================================================================================
 // Depthwise convolution (efficientnet/model.py:100, groups == channels), static TF-'same' padding (N6):
 //   y[b,c,oy,ox] = sum_{ky,kx} w[c,ky,kx] * x[b,c,oy*S+ky-pt, ox*S+kx-pl]
-// A workgroup owns a 16x16 output tile of one (b,c) plane; the input halo tile goes through LDS.
+// HBM-bound (one read of x, one write of y).  A thread owns ONE output column and DW_TY consecutive output rows and
+// slides down the input rows keeping nothing but the K values of the current row: a row of the plane is read as whole
+// 128-byte lines by neighbouring lanes (the x-halo comes out of L1), the y-halo costs (TY+K-1)/TY.  The earlier
+// 16x16-tile version fetched 3.6x the plane (r01-e PMC): 64-byte tile rows used half of every line they touched and
+// the neighbouring tile sat on another XCD's L2.
+//   workgroup = (256 >> txw_log2) row groups x (1 << txw_log2) columns;  FLIP = correlate with the 180-degree rotated
+//   filter (the stride-1 data gradient is exactly that, with pads K-1-pt / K-1-pl).
 // =================================================================================================
-template <int K, int ST>
-__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
-                                                         int C, int H, int W, int OH, int OW, int pt, int pl, int tiles_x) {
-    constexpr int TI = 15 * ST + K;                 // input tile edge for 16 outputs
-    __shared__ float tile[TI][TI + 1];
+constexpr int DW_TY = 8;
+struct DwTile { int ox, oy0; bool live; };
+__device__ __forceinline__ DwTile dw_tile(int tile, int tiles_x, int txw_log2, int OH, int OW) {
+    const int txw = 1 << txw_log2, rg = threadIdx.x >> txw_log2, nrg = 256 >> txw_log2;
+    const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+    DwTile t;
+    t.ox = txi * txw + (threadIdx.x & (txw - 1));
+    t.oy0 = (tyi * nrg + rg) * DW_TY;
+    t.live = t.ox < OW && t.oy0 < OH;
+    return t;
+}
+template <int K, int ST, bool FLIP>
+__global__ __launch_bounds__(256) void dwconv_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
+                                                          int C, int H, int W, int OH, int OW, int pt, int pl, int tiles_x, int txw_log2) {
     const int bc = blockIdx.y, c = bc % C;
-    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const DwTile t = dw_tile(blockIdx.x, tiles_x, txw_log2, OH, OW);
+    if (!t.live) return;
     const float* x = X + (int64_t)bc * H * W;
-    const int iy0 = ty0 * ST - pt, ix0 = tx0 * ST - pl;
-    for (int i = threadIdx.x; i < TI * TI; i += 256) {
-        const int r = i / TI, q = i - r * TI, iy = iy0 + r, ix = ix0 + q;
-        tile[r][q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(int64_t)iy * W + ix] : 0.f;
+    float w[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) w[i] = Wt[(int64_t)c * K * K + (FLIP ? K * K - 1 - i : i)];
+    float acc[DW_TY];
+#pragma unroll
+    for (int i = 0; i < DW_TY; ++i) acc[i] = 0.f;
+    const int ix0 = t.ox * ST - pl, iy0 = t.oy0 * ST - pt;
+    constexpr int NR = (DW_TY - 1) * ST + K;            // input rows under DW_TY output rows
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int iy = iy0 + r;
+        const bool rowok = iy >= 0 && iy < H;
+        const float* xr = x + (int64_t)min(max(iy, 0), H - 1) * W;
+        float v[K];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int ix = ix0 + kx;
+            const float q = xr[min(max(ix, 0), W - 1)];
+            v[kx] = (rowok && ix >= 0 && ix < W) ? q : 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if ((r - ky) < 0 || (r - ky) % ST != 0 || (r - ky) / ST >= DW_TY) continue;      // compile-time
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) acc[(r - ky) / ST] += w[ky * K + kx] * v[kx];
+            SEGX_PIN(acc[(r - ky) / ST]);             // keep the FMAs next to their loads (see dwconv_rows4_kernel)
+        }
     }
-    __syncthreads();
-    const int ly = threadIdx.x >> 4, lx = threadIdx.x & 15, oy = ty0 + ly, ox = tx0 + lx;
-    float acc = 0.f;
-    const float* w = Wt + (int64_t)c * K * K;
+    float* y = Y + (int64_t)bc * OH * OW + t.ox;
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky)
+    for (int i = 0; i < DW_TY; ++i) if (t.oy0 + i < OH) y[(int64_t)(t.oy0 + i) * OW] = acc[i];
+}
+// ---- float4 variant (W % 4 == 0, OW % 4 == 0, left pad PL known at compile time): a thread owns FOUR adjacent output columns.
+// Every input row is read as NV aligned float4 per thread (the one under the outputs plus its neighbours, which are L1
+// hits), so a wave issues 1 KB loads/stores like a streaming kernel.  Row groups are flattened over (plane, tile) so small
+// planes (32 x 32) still fill the workgroup.
+constexpr int DW4_TY = 8, DW4_AHEAD = 2;
+template <int K, int ST> struct Dw4 { static constexpr int NV = ST == 1 ? 3 : 4; };   // aligned float4 loaded per input row
+template <int NV>
+__device__ __forceinline__ void dw4_load_row(float (&e)[4 * NV], const float* __restrict__ xr, const int (&xo)[NV], const bool (&okv)[NV], bool rowok) {
 #pragma unroll
-        for (int kx = 0; kx < K; ++kx) acc += w[ky * K + kx] * tile[ly * ST + ky][lx * ST + kx];
-    if (oy < OH && ox < OW) Y[(int64_t)bc * OH * OW + (int64_t)oy * OW + ox] = acc;
+    for (int i = 0; i < NV; ++i) {
+        const float4 q = *reinterpret_cast<const float4*>(xr + xo[i]);
+        const bool ok = rowok && okv[i];
+        e[4 * i] = ok ? q.x : 0.f; e[4 * i + 1] = ok ? q.y : 0.f; e[4 * i + 2] = ok ? q.z : 0.f; e[4 * i + 3] = ok ? q.w : 0.f;
+    }
+}
+template <int K, int ST, int PL, bool FLIP>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_rows4_kernel(const float* __restrict__ X, const float* __restrict__ Wt, float* __restrict__ Y,
+                                                           int C, int H, int W, int OH, int OW, int pt, int tiles_x, int tiles_y, int tpr_log2,
+                                                           int64_t ngroups) {
+    constexpr int NV = Dw4<K, ST>::NV;
+    static_assert(PL <= 4 && 4 + 3 * ST + K - 1 - PL < 4 * NV, "window does not fit the loaded float4s");
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> tpr_log2;
+    if (gid >= ngroups) return;
+    const int gpp = tiles_x * tiles_y;
+    const int64_t plane = gid / gpp;
+    const int rem = (int)(gid - plane * gpp), tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int ox = ((txi << tpr_log2) + (threadIdx.x & ((1 << tpr_log2) - 1))) * 4, oy0 = tyi * DW4_TY;
+    if (ox >= OW) return;
+    const int c = (int)(plane % C);
+    const float* x = X + plane * H * W;
+    float w[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) w[i] = Wt[(int64_t)c * K * K + (FLIP ? K * K - 1 - i : i)];
+    float acc[DW4_TY][4];
+#pragma unroll
+    for (int i = 0; i < DW4_TY; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; acc[i][2] = 0.f; acc[i][3] = 0.f; }
+    int xo[NV]; bool okv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int col = ox * ST - 4 + 4 * i; okv[i] = col >= 0 && col < W; xo[i] = min(max(col, 0), W - 4); }
+    const int iy0 = oy0 * ST - pt;
+    constexpr int NR = (DW4_TY - 1) * ST + K;
+    // rows are loaded DW4_AHEAD ahead of their use into a statically rotated ring; the scheduling barriers keep the compiler
+    // from hoisting every load of the unrolled loop to the top (206-256 VGPRs, one wave per SIMD, when left alone)
+    float e[DW4_AHEAD + 1][4 * NV];
+#pragma unroll
+    for (int r = 0; r < DW4_AHEAD && r < NR; ++r)
+        dw4_load_row<NV>(e[r], x + (int64_t)min(max(iy0 + r, 0), H - 1) * W, xo, okv, iy0 + r >= 0 && iy0 + r < H);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (r + DW4_AHEAD < NR) {
+            const int iy = iy0 + r + DW4_AHEAD;
+            dw4_load_row<NV>(e[(r + DW4_AHEAD) % (DW4_AHEAD + 1)], x + (int64_t)min(max(iy, 0), H - 1) * W, xo, okv, iy >= 0 && iy < H);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if ((r - ky) < 0 || (r - ky) % ST != 0 || (r - ky) / ST >= DW4_TY) continue;     // compile-time
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+                    acc[(r - ky) / ST][j] += w[ky * K + kx] * e[r % (DW4_AHEAD + 1)][4 + j * ST + kx - PL];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) SEGX_PIN(acc[(r - ky) / ST][j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* y = Y + plane * OH * OW + ox;
+#pragma unroll
+    for (int i = 0; i < DW4_TY; ++i)
+        if (oy0 + i < OH) *reinterpret_cast<float4*>(y + (int64_t)(oy0 + i) * OW) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+}
+// weight gradient, float4 variant: ONE WAVE per (plane, strip); it walks every strips-th tile of the plane ((64 >> tpr_log2)
+// row groups x 4 rows x (4 << tpr_log2) columns), then reduces its K*K sums with wave shuffles -- no LDS, no barrier.
+constexpr int DWG_TY = 4;
+template <int K, int ST, int PL>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_wgrad4_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
+                                                            int C, int H, int W, int OH, int OW, int pt, int tiles_x, int ntiles, int tpr_log2,
+                                                            int strips, int64_t nwork) {
+    constexpr int NV = Dw4<K, ST>::NV;
+    static_assert(PL <= 4 && 4 + 3 * ST + K - 1 - PL < 4 * NV, "window does not fit the loaded float4s");
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (wid >= nwork) return;                                   // whole waves leave together
+    const int64_t plane = wid / strips;
+    const int strip = (int)(wid - plane * strips), b = (int)(plane / C), c = (int)(plane - (int64_t)b * C);
+    const int lane = threadIdx.x & 63, lr = lane & ((1 << tpr_log2) - 1), rg = lane >> tpr_log2, nrg = 64 >> tpr_log2;
+    const float* x = X + plane * H * W; const float* g = dY + plane * OH * OW;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int tile = strip; tile < ntiles; tile += strips) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int ox = ((txi << tpr_log2) + lr) * 4, oy0 = (tyi * nrg + rg) * DWG_TY;
+        if (ox >= OW || oy0 >= OH) continue;
+        float gv[DWG_TY][4];
+#pragma unroll
+        for (int i = 0; i < DWG_TY; ++i) {
+            const float4 q = *reinterpret_cast<const float4*>(g + (int64_t)min(oy0 + i, OH - 1) * OW + ox);
+            const bool ok = oy0 + i < OH;
+            gv[i][0] = ok ? q.x : 0.f; gv[i][1] = ok ? q.y : 0.f; gv[i][2] = ok ? q.z : 0.f; gv[i][3] = ok ? q.w : 0.f;
+        }
+        int xo[NV]; bool okv[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { const int col = ox * ST - 4 + 4 * i; okv[i] = col >= 0 && col < W; xo[i] = min(max(col, 0), W - 4); }
+        const int iy0 = oy0 * ST - pt;
+        constexpr int NR = (DWG_TY - 1) * ST + K;
+        float e[DW4_AHEAD + 1][4 * NV];
+#pragma unroll
+        for (int r = 0; r < DW4_AHEAD && r < NR; ++r)
+            dw4_load_row<NV>(e[r], x + (int64_t)min(max(iy0 + r, 0), H - 1) * W, xo, okv, iy0 + r >= 0 && iy0 + r < H);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            if (r + DW4_AHEAD < NR) {
+                const int iy = iy0 + r + DW4_AHEAD;
+                dw4_load_row<NV>(e[(r + DW4_AHEAD) % (DW4_AHEAD + 1)], x + (int64_t)min(max(iy, 0), H - 1) * W, xo, okv, iy >= 0 && iy < H);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                if ((r - ky) < 0 || (r - ky) % ST != 0 || (r - ky) / ST >= DWG_TY) continue;  // compile-time
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[ky * K + kx] += gv[(r - ky) / ST][j] * e[r % (DW4_AHEAD + 1)][4 + j * ST + kx - PL];
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) SEGX_PIN(acc[ky * K + kx]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* o = part + (((int64_t)b * strips + strip) * C + c) * (K * K);
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        const float sw = wave_sum(acc[i]);
+        if (lane == 0) o[i] = sw;
+    }
+}
+
+// Stride-2 data gradient, float4 variant (W % 8 == 0, OW % 4 == 0, pads known at compile time):
+//   dx[iy,ix] = sum over (ky,kx) with iy+PT-ky and ix+PL-kx even of  w[ky,kx] * dy[(iy+PT-ky)/2, (ix+PL-kx)/2]
+// A thread owns 8 adjacent dx columns x 4 dx rows (tile origin multiple of (4, 8), so every parity test is a compile-time
+// constant) and walks the <= 4 dy rows underneath, each read as three aligned float4.
+constexpr int DWB_TY = 4;
+constexpr int dw_floor_half(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
+template <int K, int PL, int PT>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_bwd4s2_kernel(const float* __restrict__ dY, const float* __restrict__ Wt,
+                                                                                   float* __restrict__ dX, int C, int H, int W, int OH, int OW,
+                                                                                   int tiles_x, int tiles_y, int tpr_log2, int64_t ngroups) {
+    constexpr int CY = dw_floor_half(PT - K + 1), NQ = (DWB_TY - 1 + PT) / 2 - CY + 1;       // dy rows under 4 dx rows
+    static_assert(4 + dw_floor_half(PL - K + 1) >= 0 && 4 + (7 + PL) / 2 < 12, "window does not fit the loaded float4s");
+    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> tpr_log2;
+    if (gid >= ngroups) return;
+    const int gpp = tiles_x * tiles_y;
+    const int64_t plane = gid / gpp;
+    const int rem = (int)(gid - plane * gpp), tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int ix0 = ((txi << tpr_log2) + (threadIdx.x & ((1 << tpr_log2) - 1))) * 8, iy0 = tyi * DWB_TY;
+    if (ix0 >= W) return;
+    const int c = (int)(plane % C);
+    const float* g = dY + plane * OH * OW;
+    float w[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) w[i] = Wt[(int64_t)c * K * K + i];
+    float acc[DWB_TY][8];
+#pragma unroll
+    for (int i = 0; i < DWB_TY; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
+    int xo[3]; bool okv[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int col = ix0 / 2 - 4 + 4 * i; okv[i] = col >= 0 && col < OW; xo[i] = min(max(col, 0), OW - 4); }
+    const int oyb = iy0 / 2 + CY;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const int oy = oyb + q;
+        float e[12];
+        dw4_load_row<3>(e, g + (int64_t)min(max(oy, 0), OH - 1) * OW, xo, okv, oy >= 0 && oy < OH);
+#pragma unroll
+        for (int i = 0; i < DWB_TY; ++i) {
+            const int ky = i + PT - 2 * (q + CY);                      // compile-time after unrolling
+            if (ky < 0 || ky >= K) continue;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    if ((j + PL - kx) % 2 != 0) continue;              // compile-time
+                    acc[i][j] += w[ky * K + kx] * e[4 + dw_floor_half(j + PL - kx)];
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) SEGX_PIN(acc[i][j]);
+        }
+    }
+    float* d = dX + plane * H * W + ix0;
+#pragma unroll
+    for (int i = 0; i < DWB_TY; ++i)
+        if (iy0 + i < H) {
+            *reinterpret_cast<float4*>(d + (int64_t)(iy0 + i) * W) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+            *reinterpret_cast<float4*>(d + (int64_t)(iy0 + i) * W + 4) = make_float4(acc[i][4], acc[i][5], acc[i][6], acc[i][7]);
+        }
 }
 // dx[iy,ix] = sum_{ky,kx} w[ky,kx] * dy[(iy+pt-ky)/S, (ix+pl-kx)/S]   (terms with a non-integer quotient vanish)
 template <int K, int ST>
@@ -205,35 +438,57 @@ __global__ __launch_bounds__(256) void dwconv_bwd_data_kernel(const float* __res
     }
     if (iy < H && ix < W) dX[(int64_t)bc * H * W + (int64_t)iy * W + ix] = acc;
 }
-// dw[c,ky,kx] partial over one sample: grid (C, B) -> part[b][c][K*K]; summed over b afterwards (colsum)
+// dw[c,ky,kx] = sum_{b,oy,ox} dy[b,c,oy,ox] x[b,c,oy*S+ky-pt, ox*S+kx-pl]: same row-sliding walk (K loads of x and one of dy per
+// output instead of K*K+1).  grid (strips, B*C): a workgroup walks every strips-th tile of its plane, then reduces its K*K
+// sums once (wave shuffles + one LDS pass).  part[(b*strips + strip)][c][K*K] is summed over its rows by segx_colsum:
+// deterministic, no float atomics.
 template <int K, int ST>
-__global__ __launch_bounds__(256) void dwconv_bwd_weight_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
-                                                                int C, int H, int W, int OH, int OW, int pt, int pl) {
-    __shared__ float red[4];
-    const int c = blockIdx.x, b = blockIdx.y;
-    const float* x = X + ((int64_t)b * C + c) * H * W; const float* g = dY + ((int64_t)b * C + c) * OH * OW;
+__global__ __launch_bounds__(256) void dwconv_wgrad_rows_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
+                                                                int C, int H, int W, int OH, int OW, int pt, int pl, int tiles_x, int ntiles,
+                                                                int txw_log2) {
+    __shared__ float red[4][K * K];
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C, strips = gridDim.x;
+    const float* x = X + (int64_t)bc * H * W; const float* g = dY + (int64_t)bc * OH * OW;
     float acc[K * K];
 #pragma unroll
     for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
-    for (int o = threadIdx.x; o < OH * OW; o += 256) {
-        const int oy = o / OW, ox = o - oy * OW;
-        const float gv = g[o];
+    for (int tile = blockIdx.x; tile < ntiles; tile += strips) {
+        const DwTile t = dw_tile(tile, tiles_x, txw_log2, OH, OW);
+        if (!t.live) continue;
+        float gv[DW_TY];
 #pragma unroll
-        for (int ky = 0; ky < K; ++ky) {
-            const int iy = oy * ST + ky - pt;
+        for (int i = 0; i < DW_TY; ++i) gv[i] = (t.oy0 + i < OH) ? g[(int64_t)(t.oy0 + i) * OW + t.ox] : 0.f;
+        const int ix0 = t.ox * ST - pl, iy0 = t.oy0 * ST - pt;
+        constexpr int NR = (DW_TY - 1) * ST + K;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int iy = iy0 + r;
+            const bool rowok = iy >= 0 && iy < H;
+            const float* xr = x + (int64_t)min(max(iy, 0), H - 1) * W;
+            float v[K];
 #pragma unroll
             for (int kx = 0; kx < K; ++kx) {
-                const int ix = ox * ST + kx - pl;
-                const float xv = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(int64_t)iy * W + ix] : 0.f;
-                acc[ky * K + kx] += gv * xv;
+                const int ix = ix0 + kx;
+                const float q = xr[min(max(ix, 0), W - 1)];
+                v[kx] = (rowok && ix >= 0 && ix < W) ? q : 0.f;
+            }
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                if ((r - ky) < 0 || (r - ky) % ST != 0 || (r - ky) / ST >= DW_TY) continue;  // compile-time
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) acc[ky * K + kx] += gv[(r - ky) / ST] * v[kx];
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < K * K; ++i) {
-        const float s = block_sum<4>(acc[i], red);
-        if (threadIdx.x == 0) part[((int64_t)b * C + c) * K * K + i] = s;
+        const float sw = wave_sum(acc[i]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = sw;
     }
+    __syncthreads();
+    if (threadIdx.x < K * K)
+        part[(((int64_t)b * strips + blockIdx.x) * C + c) * (K * K) + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // =================================================================================================
@@ -390,28 +645,125 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
     else if (k == 5 && stride == 1) hipLaunchKernelGGL((KERNEL<5, 1>), grid, dim3(256), 0, stream, __VA_ARGS__); \
     else if (k == 5 && stride == 2) hipLaunchKernelGGL((KERNEL<5, 2>), grid, dim3(256), 0, stream, __VA_ARGS__); \
     else return segx::fail(-1, "depthwise conv: kernel %d stride %d unsupported (k in {3,5}, stride in {1,2})", k, stride);
+#define SEGX_DW_ROWS_DISPATCH(FLIP, ...)                                                                                          \
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dwconv_rows_kernel<3, 1, FLIP>), grid, dim3(256), 0, stream, __VA_ARGS__);      \
+    else if (k == 3 && stride == 2) hipLaunchKernelGGL((dwconv_rows_kernel<3, 2, FLIP>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dwconv_rows_kernel<5, 1, FLIP>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else if (k == 5 && stride == 2) hipLaunchKernelGGL((dwconv_rows_kernel<5, 2, FLIP>), grid, dim3(256), 0, stream, __VA_ARGS__); \
+    else return segx::fail(-1, "depthwise conv: kernel %d stride %d unsupported (k in {3,5}, stride in {1,2})", k, stride);
+
+namespace {
+struct DwGrid { int txw_log2, tiles_x, tiles_y; };
+// scalar kernels: column tile = smallest power of two >= OW in [32, 256]; (256 / tile) groups of DW_TY rows per workgroup
+DwGrid dw_grid(int OH, int OW) {
+    int l = 5;
+    while (l < 8 && (1 << l) < OW) ++l;
+    const int rows = (256 >> l) * segx::DW_TY;
+    return {l, (OW + (1 << l) - 1) >> l, (OH + rows - 1) / rows};
+}
+// float4 kernels: threads per row = smallest power of two >= OW/4 in [8, 64]
+struct Dw4Grid { int tpr_log2, tiles_x; };
+Dw4Grid dw4_grid(int OW) {
+    int l = 3;
+    while (l < 6 && (4 << l) < OW) ++l;
+    return {l, (OW + (4 << l) - 1) / (4 << l)};
+}
+// strips per plane for the weight gradient: ~8K outputs per strip, at most 16 (depends on the output size only)
+int dw_wgrad_strips(int OH, int OW) {
+    const int64_t n = ((int64_t)OH * OW + 8191) / 8192;
+    return (int)(n < 1 ? 1 : n > 16 ? 16 : n);
+}
+bool dw4_ok(const void* a, const void* b, int W, int OW) {
+    return W % 4 == 0 && OW % 4 == 0 && W >= 4 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
+}
+// float4 forward-type launch for the (k, stride, pad_l) combinations the model uses; false = not instantiated
+template <bool FLIP>
+bool dw4_rows_launch(hipStream_t stream, const float* X, const float* W, float* Y, int planes, int C, int H, int Wd, int OH, int OW, int k,
+                     int stride, int pt, int pl) {
+    const Dw4Grid g = dw4_grid(OW);
+    const int tiles_y = (OH + segx::DW4_TY - 1) / segx::DW4_TY;
+    const int64_t ngroups = (int64_t)planes * g.tiles_x * tiles_y;
+    const int64_t nblocks = ((ngroups << g.tpr_log2) + 255) / 256;
+    if (nblocks > 2147483647LL) return false;
+#define SEGX_DW4(KK, SS, PP)                                                                                                        \
+    if (k == KK && stride == SS && pl == PP) {                                                                                       \
+        hipLaunchKernelGGL((segx::dwconv_rows4_kernel<KK, SS, PP, FLIP>), dim3((unsigned)nblocks), dim3(256), 0, stream, X, W, Y, C, \
+                           H, Wd, OH, OW, pt, g.tiles_x, tiles_y, g.tpr_log2, ngroups);                                              \
+        return true;                                                                                                                 \
+    }
+    SEGX_DW4(3, 1, 1) SEGX_DW4(5, 1, 2) SEGX_DW4(3, 2, 0) SEGX_DW4(3, 2, 1) SEGX_DW4(5, 2, 1) SEGX_DW4(5, 2, 2)
+#undef SEGX_DW4
+    return false;
+}
+bool dw4_wgrad_launch(hipStream_t stream, const float* dY, const float* X, float* part, int B, int C, int H, int Wd, int OH, int OW, int k,
+                      int stride, int pt, int pl, int strips) {
+    const Dw4Grid g = dw4_grid(OW);
+    const int rows = (64 >> g.tpr_log2) * segx::DWG_TY, ntiles = g.tiles_x * ((OH + rows - 1) / rows);
+    const int64_t nwork = (int64_t)B * C * strips;
+    const int64_t nblocks = (nwork + 3) / 4;
+#define SEGX_DW4(KK, SS, PP)                                                                                                        \
+    if (k == KK && stride == SS && pl == PP) {                                                                                       \
+        hipLaunchKernelGGL((segx::dwconv_wgrad4_kernel<KK, SS, PP>), dim3((unsigned)nblocks), dim3(256), 0, stream, dY, X, part, C,  \
+                           H, Wd, OH, OW, pt, g.tiles_x, ntiles, g.tpr_log2, strips, nwork);                                         \
+        return true;                                                                                                                 \
+    }
+    SEGX_DW4(3, 1, 1) SEGX_DW4(5, 1, 2) SEGX_DW4(3, 2, 0) SEGX_DW4(3, 2, 1) SEGX_DW4(5, 2, 1) SEGX_DW4(5, 2, 2)
+#undef SEGX_DW4
+    return false;
+}
+}  // namespace
 
 extern "C" int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
                                  int pad_t, int pad_l, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && W && Y && B > 0 && C > 0 && H > 0 && Wd > 0 && OH > 0 && OW > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_fwd: bad args");
-    const int tx = (OW + 15) / 16, ty = (OH + 15) / 16;
-    dim3 grid(tx * ty, B * C);
-    SEGX_DW_DISPATCH(dwconv_fwd_kernel, X, W, Y, C, H, Wd, OH, OW, pad_t, pad_l, tx);
+    if (dw4_ok(X, Y, Wd, OW) && dw4_rows_launch<false>(stream, X, W, Y, B * C, C, H, Wd, OH, OW, k, stride, pad_t, pad_l))
+        return check_launch("segx_dwconv2d_fwd");
+    const DwGrid g = dw_grid(OH, OW);
+    dim3 grid(g.tiles_x * g.tiles_y, B * C);
+    SEGX_DW_ROWS_DISPATCH(false, X, W, Y, C, H, Wd, OH, OW, pad_t, pad_l, g.tiles_x, g.txw_log2);
     return check_launch("segx_dwconv2d_fwd");
 }
 extern "C" int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
                                       int pad_t, int pad_l, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && B > 0 && C > 0 && H > 0 && Wd > 0 && OH > 0 && OW > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_bwd_data: bad args");
+    if (stride == 1) {      // correlation of dy with the rotated filter: "input" dy [OH,OW], "output" dx [H,W], pads K-1-p
+        if (dw4_ok(dY, dX, OW, Wd) && dw4_rows_launch<true>(stream, dY, W, dX, B * C, C, OH, OW, H, Wd, k, 1, k - 1 - pad_t, k - 1 - pad_l))
+            return check_launch("segx_dwconv2d_bwd_data");
+        const DwGrid g = dw_grid(H, Wd);
+        dim3 grid(g.tiles_x * g.tiles_y, B * C);
+        SEGX_DW_ROWS_DISPATCH(true, dY, W, dX, C, OH, OW, H, Wd, k - 1 - pad_t, k - 1 - pad_l, g.tiles_x, g.txw_log2);
+        return check_launch("segx_dwconv2d_bwd_data");
+    }
+    if (stride == 2 && Wd % 8 == 0 && OW % 4 == 0 && pad_t == pad_l && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0) {
+        int l = 3;
+        while (l < 6 && (8 << l) < Wd) ++l;                                  // threads per dx row: power of two >= W/8 in [8, 64]
+        const int tiles_x = (Wd + (8 << l) - 1) / (8 << l), tiles_y = (H + segx::DWB_TY - 1) / segx::DWB_TY;
+        const int64_t ngroups = (int64_t)B * C * tiles_x * tiles_y, nblocks = ((ngroups << l) + 255) / 256;
+#define SEGX_DWB(KK, PP)                                                                                                             \
+        if (k == KK && pad_l == PP && nblocks <= 2147483647LL) {                                                                      \
+            hipLaunchKernelGGL((segx::dwconv_bwd4s2_kernel<KK, PP, PP>), dim3((unsigned)nblocks), dim3(256), 0, stream, dY, W, dX, C, \
+                               H, Wd, OH, OW, tiles_x, tiles_y, l, ngroups);                                                          \
+            return check_launch("segx_dwconv2d_bwd_data");                                                                            \
+        }
+        SEGX_DWB(3, 0) SEGX_DWB(3, 1) SEGX_DWB(5, 1) SEGX_DWB(5, 2)
+#undef SEGX_DWB
+    }
     const int tx = (Wd + 15) / 16, ty = (H + 15) / 16;
     dim3 grid(tx * ty, B * C);
     SEGX_DW_DISPATCH(dwconv_bwd_data_kernel, dY, W, dX, C, H, Wd, OH, OW, pad_t, pad_l, tx);
     return check_launch("segx_dwconv2d_bwd_data");
 }
-extern "C" int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part /* [B][C][k*k] */, int B, int C, int H, int Wd, int OH, int OW,
+/* rows of `part` per sample (see segx_dwconv2d_bwd_weight) */
+extern "C" int64_t segx_dwconv2d_wgrad_rows(int OH, int OW) { return OH > 0 && OW > 0 ? dw_wgrad_strips(OH, OW) : 0; }
+extern "C" int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part /* [B*rows][C][k*k] */, int B, int C, int H, int Wd, int OH, int OW,
                                         int k, int stride, int pad_t, int pad_l, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && part && B > 0 && C > 0 && B <= 65535, "segx_dwconv2d_bwd_weight: bad args");
-    dim3 grid(C, B);
-    SEGX_DW_DISPATCH(dwconv_bwd_weight_kernel, dY, X, part, C, H, Wd, OH, OW, pad_t, pad_l);
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && part && B > 0 && C > 0 && OH > 0 && OW > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_bwd_weight: bad args");
+    const int strips = dw_wgrad_strips(OH, OW);
+    if (dw4_ok(dY, X, Wd, OW) && dw4_wgrad_launch(stream, dY, X, part, B, C, H, Wd, OH, OW, k, stride, pad_t, pad_l, strips))
+        return check_launch("segx_dwconv2d_bwd_weight");
+    const DwGrid g = dw_grid(OH, OW);
+    dim3 grid(strips, B * C);
+    SEGX_DW_DISPATCH(dwconv_wgrad_rows_kernel, dY, X, part, C, H, Wd, OH, OW, pad_t, pad_l, g.tiles_x, g.tiles_x * g.tiles_y, g.txw_log2);
     return check_launch("segx_dwconv2d_bwd_weight");
 }
 extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream_) {

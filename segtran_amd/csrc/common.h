@@ -23,6 +23,16 @@ inline int check_launch(const char* what) {
     if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
     return 0;
 }
+// register budget: keep at least n waves per SIMD resident (caps VGPRs at 512/n) -- stops the scheduler from hoisting every
+// load of a fully unrolled streaming loop into its own registers
+#ifndef SEGX_MIN_WAVES_PER_SIMD
+#define SEGX_MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+// code-motion fence on a VGPR value: the value must exist HERE (stops LLVM from sinking a whole accumulation chain below the
+// loads of later iterations, which turns a streaming loop into load-everything-then-compute)
+#ifndef SEGX_PIN
+#define SEGX_PIN(x) asm volatile("" : "+v"(x))
+#endif
 #define SEGX_REQUIRE(cond, ...) do { if (!(cond)) return segx::fail(-1, __VA_ARGS__); } while (0)
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------

@@ -554,10 +554,11 @@ class _DWConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.dwconv2d_bwd_data(dy, w, dx, B, C, H, W, OH, OW, k, stride, pt, pl)
         if ctx.needs_input_grad[1]:
-            part = _empty(x, B, C * k * k)
+            rows = B * L.dwconv2d_wgrad_rows(OH, OW)
+            part = _empty(x, rows, C * k * k)
             L.dwconv2d_bwd_weight(dy, x, part, B, C, H, W, OH, OW, k, stride, pt, pl)
             dw = _empty(x, C * k * k)
-            L.colsum(part, dw, _empty(x, L.colreduce_ws(B, C * k * k, 1)), B, C * k * k)
+            L.colsum(part, dw, _empty(x, L.colreduce_ws(rows, C * k * k, 1)), rows, C * k * k)
             dw = dw.view_as(w)
         return dx, dw, None, None
 

@@ -53,7 +53,7 @@ class SegxLib:
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
-            fn.restype = c_l if name.endswith('_floats') else c_i
+            fn.restype = c_l if name.endswith(('_floats', '_rows')) else c_i
 
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
@@ -207,6 +207,9 @@ class SegxLib:
     def dwconv2d_bwd_data(self, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl):
         self._call('segx_dwconv2d_bwd_data', dY, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl)
 
+    def dwconv2d_wgrad_rows(self, OH, OW):
+        return int(self.c.segx_dwconv2d_wgrad_rows(OH, OW))
+
     def dwconv2d_bwd_weight(self, dY, X, part, B, C, H, Wd, OH, OW, k, stride, pt, pl):
         self._call('segx_dwconv2d_bwd_weight', dY, dY, X, part, B, C, H, Wd, OH, OW, k, stride, pt, pl)
 
@@ -337,7 +340,7 @@ _SIGS = {
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
-    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
+    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfip', 'segx_bn_act_bwd_apply': 'pppppppppiilfifp',
 }

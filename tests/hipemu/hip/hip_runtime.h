@@ -24,6 +24,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define __launch_bounds__(...)
+#define SEGX_MIN_WAVES_PER_SIMD(n)      /* register-budget hint: meaningless on the host */
+#define SEGX_PIN(x) ((void)0)            /* code-motion fence on a register value: meaningless on the host */
 #define __constant__ static
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };

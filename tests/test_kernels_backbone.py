@@ -47,9 +47,17 @@ def test_bn_act(backend, shape, act, training):
 
 
 @pytest.mark.parametrize('k,stride,pad,H,W', [(3, 1, (1, 1, 1, 1), 20, 18), (5, 1, (2, 2, 2, 2), 17, 33), (3, 2, (0, 1, 0, 1), 32, 32),
-                                              (5, 2, (2, 2, 2, 2), 16, 16), (5, 2, (1, 2, 1, 2), 24, 40), (3, 2, (0, 1, 0, 1), 7, 9)])
+                                              (5, 2, (2, 2, 2, 2), 16, 16), (5, 2, (1, 2, 1, 2), 24, 40), (3, 2, (0, 1, 0, 1), 7, 9),
+                                              (3, 1, (0, 2, 2, 0), 12, 40),           # lopsided pads: flipped-filter data gradient
+                                              (3, 1, (1, 1, 1, 1), 37, 300),          # two column tiles (> 256 wide)
+                                              (5, 2, (1, 2, 1, 2), 150, 140),         # several row tiles -> several wgrad strips
+                                              (5, 1, (2, 2, 2, 2), 130, 64),
+                                              (3, 2, (1, 1, 1, 1), 16, 24),           # float4 path, left pad 1 at stride 2
+                                              (3, 1, (1, 1, 1, 1), 100, 128),         # float4 path, two wgrad strips
+                                              (5, 2, (2, 2, 2, 2), 96, 256),
+                                              (5, 2, (1, 2, 1, 2), 22, 40), (3, 2, (0, 1, 0, 1), 18, 600)])   # ragged rows / 2 column tiles
 def test_dwconv2d(backend, k, stride, pad, H, W):
-    B, C = 2, 5
+    B, C = (2, 5) if H * W < 4000 else (2, 2)
     x = rnd(B, C, H, W, seed=7).requires_grad_(True)
     w = rnd(C, 1, k, k, seed=8).requires_grad_(True)
     y = SF.dwconv2d(x, w, stride, pad)
