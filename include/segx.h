@@ -33,6 +33,7 @@ int segx_last_error(char* buf, int buflen);
  * ------------------------------------------------------------------------------------------- */
 enum { SEGX_EPI_NONE = 0, SEGX_EPI_GELU = 1 /* aux = pre-activation, C = dropout(gelu(.)), :244-245 */ };
 enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bias[m] */ };
+enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5 };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
     int64_t a_b0, a_b1, a_m, a_k;
@@ -48,8 +49,12 @@ typedef struct {
     uint64_t seed, offset;            /* Philox stream for the dropout mask */
     int32_t splitk;                   /* >1: K split over `splitk` slabs in `workspace`, then reduced */
     float* workspace;                 /* splitk*nb0*nb1*M*N floats when splitk>1 */
+    int32_t tile;                     /* workgroup tile: SEGX_TILE_AUTO or one of SEGX_TILE_* (a tuning knob; results are identical) */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
+/* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are
+ * ignored): callers that want split-K size the workspace from *splitk and pass both back through the desc. */
+int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels of the Squeeze-and-Expansion transformer (tokens.hip).  All tensors fp32, row-major,

@@ -115,27 +115,32 @@ struct ConvWgradLoaderB {
     }
 };
 
-template <bool VEC>
+// Cfg: 128 x 128, or 64 x 128 when Cout <= 64 (the I3D stem and the 64-channel branches: half of a 128-row A tile would be
+// clamped duplicates).  The B-side (im2col) loaders above are written for 128 columns.
+using CfgCout64 = TileCfg<2, 2, 1, 2>;
+template <bool VEC, class Cfg>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q) {
-    __shared__ __attribute__((aligned(16))) TileLds lds;
-    const TileCoord t = tile_coord(g);
-    const DenseLoader<true, VEC> la{g.A, g.a_m, 1, t.m0, g.M};                       // weights [Cout][Cin*KV]
+    static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
+    __shared__ __attribute__((aligned(16))) TileLdsT<Cfg> lds;
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader<true, VEC, Cfg::BM> la{g.A, g.a_m, 1, t.m0, g.M};             // weights [Cout][Cin*KV]
     const ConvFwdLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);             // X[b]
-    f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
-    gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
-template <bool VEC>
+template <bool VEC, class Cfg>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom q) {
-    __shared__ __attribute__((aligned(16))) TileLds lds;
-    const TileCoord t = tile_coord(g);
-    const DenseLoader<true, VEC> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};   // dY[b] [Cout][P]
+    static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
+    __shared__ __attribute__((aligned(16))) TileLdsT<Cfg> lds;
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader<true, VEC, Cfg::BM> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};   // dY[b] [Cout][P]
     __shared__ int rowinfo[256];
     const ConvWgradLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, rowinfo);       // X[b]
     __syncthreads();
-    f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
-    gemm_epilogue<SEGX_EPI_NONE>(acc, g, t);
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
 
 // Wt[ci][co][t] = W[co][ci][KV-1-t]: the transposed, spatially flipped filter bank of the backward-data convolution
@@ -301,9 +306,13 @@ extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, 
     GemmArgs g; g.A = W; g.B = X; g.C = Y;
     g.a_b0 = 0; g.a_m = K; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * P; g.c_m = P;
     fill_common(g, Cout, (int)P, K, B, 1, nullptr);
+    const bool vec = aligned16c(W) && K % 4 == 0, small = Cout % 128 >= 1 && Cout % 128 <= 64;
+    if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, 1);
-    if (aligned16c(W) && K % 4 == 0) hipLaunchKernelGGL((conv3d_fwd_kernel<true>), grid, dim3(256), 0, stream, g, q);
-    else hipLaunchKernelGGL((conv3d_fwd_kernel<false>), grid, dim3(256), 0, stream, g, q);
+    if (small && vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
+    else if (small) hipLaunchKernelGGL((conv3d_fwd_kernel<false, CfgCout64>), grid, dim3(256), 0, stream, g, q);
+    else if (vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, Cfg128>), grid, dim3(256), 0, stream, g, q);
+    else hipLaunchKernelGGL((conv3d_fwd_kernel<false, Cfg128>), grid, dim3(256), 0, stream, g, q);
     return check_launch("segx_conv3d_fwd");
 }
 extern "C" int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream_) {
@@ -325,9 +334,13 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
     GemmArgs g; g.A = dY; g.B = X; g.C = dWb;
     g.a_b0 = (int64_t)Cout * P; g.a_m = P; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * N; g.c_m = N;
     fill_common(g, Cout, N, (int)P, B, splitk, workspace);
+    const bool vec = aligned16c(dY) && P % 4 == 0, small = Cout % 128 >= 1 && Cout % 128 <= 64;
+    if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
-    if (aligned16c(dY) && P % 4 == 0) hipLaunchKernelGGL((conv3d_wgrad_kernel<true>), grid, dim3(256), 0, stream, g, q);
-    else hipLaunchKernelGGL((conv3d_wgrad_kernel<false>), grid, dim3(256), 0, stream, g, q);
+    if (small && vec) hipLaunchKernelGGL((conv3d_wgrad_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
+    else if (small) hipLaunchKernelGGL((conv3d_wgrad_kernel<false, CfgCout64>), grid, dim3(256), 0, stream, g, q);
+    else if (vec) hipLaunchKernelGGL((conv3d_wgrad_kernel<true, Cfg128>), grid, dim3(256), 0, stream, g, q);
+    else hipLaunchKernelGGL((conv3d_wgrad_kernel<false, Cfg128>), grid, dim3(256), 0, stream, g, q);
     int rc = check_launch("segx_conv3d_bwd_weight");
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;

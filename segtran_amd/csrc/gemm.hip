@@ -22,15 +22,15 @@
 
 namespace segx {
 
-template <bool AKC, bool BKC, bool VEC, int EPI>
+template <class Cfg, bool AKC, bool BKC, bool VEC, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) TileLds lds;
-    const TileCoord t = tile_coord(g);
-    const DenseLoader<AKC, VEC> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
-    const DenseLoader<BKC, VEC> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
-    f32x16 acc[2][2];
-    gemm_mainloop(acc, la, lb, t.kbeg, t.kend, lds);
-    gemm_epilogue<EPI>(acc, g, t);
+    __shared__ __attribute__((aligned(16))) TileLdsT<Cfg> lds;
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader<AKC, VEC, Cfg::BM> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
+    const DenseLoader<BKC, VEC, Cfg::BN> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<EPI, Cfg>(acc, g, t);
 }
 
 // Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.
@@ -55,7 +55,71 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Tile choice when the caller leaves it to the library.  Measured on MI355X (tools/gemm_bench.py tiles, r01-j):
+//  * an operand with <= 48 rows is streamed with the 32-row tile on that side (the 128-row tile spends 3/4 of its LDS
+//    traffic and MFMA issue slots on clamped duplicate rows: 192x32x65536 weight gradient 0.34 -> 0.14 ms);
+//  * problems that waste a quarter of their 128 x 128 edge tiles, cannot fill the 512 workgroup slots, or have a short
+//    k loop (tail-dominated) run on 64 x 64 tiles (4x the workgroups, 1/4 the padding);
+//  * M = 128 j + (1..64) rows (448-channel FPN bridges) take the 64 x 128 tile.
+static int auto_tile(int M, int N, int K, int64_t nwg128, bool vec) {
+    if (!vec) return SEGX_TILE_128x128;
+    if (N <= 48 && M > N) return SEGX_TILE_128x32;
+    if (M <= 48) return SEGX_TILE_32x128;
+    const double util = ((double)M * N) / ((double)ceil_div(M, 128) * 128 * (double)ceil_div(N, 128) * 128);
+    if (util <= 0.76 || nwg128 < 512 || (K <= 512 && nwg128 < 2048)) return SEGX_TILE_64x64;
+    if (M < 1024 && M % 128 >= 1 && M % 128 <= 64) return SEGX_TILE_64x128;
+    return SEGX_TILE_128x128;
+}
+struct TileInfo { int bm, bn, wg_per_cu; float ktile_us; };   // resident workgroups per CU (LDS bound), time of one k-tile step
+static TileInfo tile_info(int tile) {
+    switch (tile) {
+        case SEGX_TILE_64x64:  return {64, 64, 4, 1.1f};
+        case SEGX_TILE_128x32: return {128, 32, 3, 1.0f};
+        case SEGX_TILE_32x128: return {32, 128, 3, 1.0f};
+        case SEGX_TILE_64x128: return {64, 128, 3, 1.9f};
+        default:               return {128, 128, 2, 3.4f};
+    }
+}
+static bool gemm_vec_ok(const float* A, const float* B, const segx_gemm_desc* d) {
+    const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
+    // float4 loads need 16-B aligned bases, every non-unit stride and the contiguous extents multiples of 4
+    const bool vecA = aligned16(A) && (d->a_b0 % 4 == 0) && (d->a_b1 % 4 == 0) && ((akc ? d->a_m : d->a_k) % 4 == 0) &&
+                      ((akc ? d->K : d->M) % 4 == 0);
+    const bool vecB = aligned16(B) && (d->b_b0 % 4 == 0) && (d->b_b1 % 4 == 0) && ((bkc ? d->b_n : d->b_k) % 4 == 0) &&
+                      ((bkc ? d->K : d->N) % 4 == 0);
+    return vecA && vecB;
+}
+// Split-K factor minimising modelled time = rounds-of-workgroups x k-tiles per workgroup + slab reduction.  Whole-GEMM
+// quantisation matters: 784 workgroups on 768 slots take two rounds, not 1.02.
+static int auto_splitk(int M, int N, int K, int nbatch, int tile) {
+    const TileInfo ti = tile_info(tile);
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
+    if (tiles >= 4 * slots || K < 1024) return 1;
+    int best = 1; double best_t = -1.0;
+    for (int sk = 1; sk <= 128; ++sk) {
+        if (sk > 1 && K / sk < 256) break;
+        const int kt = ceil_div(ceil_div(K, sk), BKT);
+        const int64_t rounds = (tiles * sk + slots - 1) / slots;
+        const double t = (double)rounds * kt * ti.ktile_us + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
+        if (best_t < 0.0 || t < best_t * 0.97) { best = sk; best_t = t; }
+    }
+    return best;
+}
+
 }  // namespace segx
+
+extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk) {
+    using namespace segx;
+    SEGX_REQUIRE(A && B && d && tile && splitk && d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_plan: bad args");
+    const int nbatch = d->nb0 * d->nb1;
+    const bool plain = d->epilogue == SEGX_EPI_NONE, vec = gemm_vec_ok(A, B, d);
+    // the split factor is chosen for the tile the un-split problem would get, then the tile is re-chosen for the split grid
+    int t = (vec && plain) ? auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch, true) : SEGX_TILE_128x128;
+    const int sk = (plain && !d->gmax) ? auto_splitk(d->M, d->N, d->K, nbatch, t) : 1;
+    if (vec && plain) t = auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch * sk, true);
+    *tile = t; *splitk = sk;
+    return 0;
+}
 
 extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream_) {
     using namespace segx;
@@ -81,14 +145,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1;
     g.alpha = d->alpha; g.epilogue = d->epilogue; g.bias_mode = d->bias_mode;
     const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
-    // float4 loads need 16-B aligned bases, every non-unit stride and the contiguous extents multiples of 4
-    const bool vecA = aligned16(A) && (d->a_b0 % 4 == 0) && (d->a_b1 % 4 == 0) && ((akc ? d->a_m : d->a_k) % 4 == 0) &&
-                      ((akc ? d->K : d->M) % 4 == 0);
-    const bool vecB = aligned16(B) && (d->b_b0 % 4 == 0) && (d->b_b1 % 4 == 0) && ((bkc ? d->b_n : d->b_k) % 4 == 0) &&
-                      ((bkc ? d->K : d->N) % 4 == 0);
-    const bool vec = vecA && vecB;
-    g.vecA = vecA; g.vecB = vecB;
-    g.tiles_m = ceil_div(d->M, BM); g.tiles_n = ceil_div(d->N, BN);
+    const bool vec = gemm_vec_ok(A, B, d);
+    g.vecA = vec; g.vecB = vec;
     g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset;
     g.splitk = splitk;
     // k_chunk: multiple of the k-tile so slabs start on tile boundaries (and stay float4-aligned)
@@ -96,23 +154,42 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     const int nbatch = d->nb0 * d->nb1;
     g.c_split = (int64_t)nbatch * d->M * d->N;
     if (splitk > 1) g.C = d->workspace;
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_64x128, "segx_gemm_f32: bad tile %d", d->tile);
+    int tile = d->tile;
+    if (tile == SEGX_TILE_AUTO)
+        tile = auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch * splitk, vec && d->epilogue == SEGX_EPI_NONE);
+    if (!vec || d->epilogue != SEGX_EPI_NONE) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
 
-    dim3 grid(g.tiles_m * g.tiles_n, nbatch, splitk), block(256);
-#define SEGX_LAUNCH(AK, BK, V, E) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK, V, E>), grid, block, 0, stream, g)
-#define SEGX_LAUNCH_LAYOUT(V, E)                                   \
-    do {                                                           \
-        if (akc && bkc) SEGX_LAUNCH(true, true, V, E);             \
-        else if (akc && !bkc) SEGX_LAUNCH(true, false, V, E);      \
-        else if (!akc && bkc) SEGX_LAUNCH(false, true, V, E);      \
-        else SEGX_LAUNCH(false, false, V, E);                      \
+    dim3 block(256);
+#define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        hipLaunchKernelGGL((gemm_f32_kernel<CFG, AK, BK, V, E>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
+#define SEGX_LAUNCH_LAYOUT(CFG, V, E)                                   \
+    do {                                                                \
+        if (akc && bkc) SEGX_LAUNCH(CFG, true, true, V, E);             \
+        else if (akc && !bkc) SEGX_LAUNCH(CFG, true, false, V, E);      \
+        else if (!akc && bkc) SEGX_LAUNCH(CFG, false, true, V, E);      \
+        else SEGX_LAUNCH(CFG, false, false, V, E);                      \
+    } while (0)
+    using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
+    using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (d->epilogue == SEGX_EPI_GELU) {
         SEGX_REQUIRE(akc && bkc, "segx_gemm_f32: the GELU epilogue is built for k-contiguous operands (nn.Linear)");
-        if (vec) SEGX_LAUNCH(true, true, true, SEGX_EPI_GELU); else SEGX_LAUNCH(true, true, false, SEGX_EPI_GELU);
-    } else if (vec) {
-        SEGX_LAUNCH_LAYOUT(true, SEGX_EPI_NONE);
+        if (vec) SEGX_LAUNCH(Cfg128, true, true, true, SEGX_EPI_GELU); else SEGX_LAUNCH(Cfg128, true, true, false, SEGX_EPI_GELU);
+    } else if (!vec) {
+        SEGX_LAUNCH_LAYOUT(Cfg128, false, SEGX_EPI_NONE);
+    } else if (tile == SEGX_TILE_64x64) {
+        SEGX_LAUNCH_LAYOUT(Cfg64, true, SEGX_EPI_NONE);
+    } else if (tile == SEGX_TILE_128x32) {
+        SEGX_LAUNCH_LAYOUT(Cfg128x32, true, SEGX_EPI_NONE);
+    } else if (tile == SEGX_TILE_32x128) {
+        SEGX_LAUNCH_LAYOUT(Cfg32x128, true, SEGX_EPI_NONE);
+    } else if (tile == SEGX_TILE_64x128) {
+        SEGX_LAUNCH_LAYOUT(Cfg64x128, true, SEGX_EPI_NONE);
     } else {
-        SEGX_LAUNCH_LAYOUT(false, SEGX_EPI_NONE);
+        SEGX_LAUNCH_LAYOUT(Cfg128, true, SEGX_EPI_NONE);
     }
     int rc = check_launch("segx_gemm_f32");
     if (rc) return rc;

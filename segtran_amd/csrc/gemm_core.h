@@ -6,9 +6,24 @@
 
 namespace segx {
 
-constexpr int BM = 128, BN = 128, BKT = 32, LDT = 132;   // BKT = 64 measured 5-7 % slower (r01 microbench)
-constexpr int NP = BKT / 8;            // float4 pieces per thread per operand tile: 128 * BKT / 4 / 256
+constexpr int BKT = 32;                // k-tile (BKT = 64 measured 5-7 % slower, r01 microbench)
 constexpr int KCH = BKT / 4;           // float4 chunks along k of a k-contiguous operand row
+
+// Workgroup tile = 4 waves arranged WM x WN, each wave owning MI x NJ MFMA blocks of 32 x 32:
+//   TileCfg<2,2,2,2> 128 x 128  the compute-bound default (one LDS fragment read per MFMA)
+//   TileCfg<2,2,1,2>  64 x 128  Cout <= 64 convolutions / M <= 64 GEMMs (half the A-side waste of a 128-row tile)
+//   TileCfg<2,2,1,1>  64 x  64  mid-sized pointwise convolutions: more, smaller workgroups when 128 x 128 tiles leave CUs idle
+//   TileCfg<4,1,1,1> 128 x  32 / TileCfg<1,4,1,1> 32 x 128  skinny operands (channel counts 24..56): HBM-bound, stream them
+template <int WM_, int WN_, int MI_, int NJ_>
+struct TileCfg {
+    static_assert(WM_ * WN_ == 4, "four waves per workgroup");
+    static constexpr int WM = WM_, WN = WN_, MI = MI_, NJ = NJ_;
+    static constexpr int BM = WM * MI * 32, BN = WN * NJ * 32;
+    static constexpr int LDA = BM + 4, LDB = BN + 4;                            // LDS row strides (k-major tiles [k][row])
+    static constexpr int NPA = BM * BKT / 4 / 256, NPB = BN * BKT / 4 / 256;     // float4 pieces per thread per operand tile
+};
+using Cfg128 = TileCfg<2, 2, 2, 2>;
+constexpr int BM = Cfg128::BM, BN = Cfg128::BN, LDT = Cfg128::LDA, NP = Cfg128::NPA;   // the default tile (conv3d.hip loaders)
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -26,24 +41,25 @@ struct GemmArgs {
     int splitk; int64_t c_split;    // slab stride in the workspace
 };
 
-// Load this thread's NP float4 pieces of a 128 x BKT operand tile into registers.
+// Load this thread's ROWS*BKT/1024 float4 pieces of a ROWS x BKT operand tile into registers.
 //  KC = true : operand is k-contiguous;  piece f -> row f / KCH, k-chunk f % KCH
-//  KC = false: operand is row-contiguous; piece f -> k-row f>>5, row-chunk f&31
+//  KC = false: operand is row-contiguous; piece f -> k-row f / (ROWS/4), row-chunk f % (ROWS/4)
 // VEC = true (16-B aligned base, all strides and extents multiples of 4): every float4 is either wholly inside
 // or wholly outside the operand, so the load is issued UNCONDITIONALLY from a clamped address and zeroed by a
-// select -- no branches, so the 8 loads of a k-tile stay in flight together (a guarded load costs an exec-mask
+// select -- no branches, so the loads of a k-tile stay in flight together (a guarded load costs an exec-mask
 // branch plus an s_waitcnt vmcnt(0) each).  VEC = false is the slow scalar path for odd shapes (K = 2, Cin = 6 ...).
 // The zeroing select is deferred to store_tile (through the returned validity mask): consuming a loaded value
 // right after the load would make the compiler wait for it BEFORE the MFMA block and lose the overlap.
-template <bool KC, bool VEC>
-__device__ __forceinline__ unsigned load_tile(float4 (&r)[NP], const float* __restrict__ base, int64_t s_row, int64_t s_k,
+template <bool KC, bool VEC, int ROWS>
+__device__ __forceinline__ unsigned load_tile(float4 (&r)[ROWS * BKT / 1024], const float* __restrict__ base, int64_t s_row, int64_t s_k,
                                               int row0, int rows, int k0, int kend, int tid) {
-    unsigned okmask = NP == 8 ? 0xFFFFFFFFu : ((1u << (4 * NP)) - 1u);   // bit 4*i+j: element j of piece i is inside the operand
+    constexpr int NPT = ROWS * BKT / 1024, RC = ROWS / 4;
+    unsigned okmask = NPT == 8 ? 0xFFFFFFFFu : ((1u << (4 * NPT)) - 1u);   // bit 4*i+j: element j of piece i is inside the operand
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NPT; ++i) {
         const int f = tid + 256 * i;
-        const int row = KC ? row0 + f / KCH : row0 + ((f & 31) << 2);
-        const int k = KC ? k0 + ((f % KCH) << 2) : k0 + (f >> 5);
+        const int row = KC ? row0 + f / KCH : row0 + ((f % RC) << 2);
+        const int k = KC ? k0 + ((f % KCH) << 2) : k0 + f / RC;
         float4 v;
         if (VEC) {
             const int rc = KC ? (row < rows ? row : rows - 1) : (row < rows ? row : rows - 4);
@@ -70,24 +86,25 @@ __device__ __forceinline__ unsigned load_tile(float4 (&r)[NP], const float* __re
     return okmask;
 }
 
-template <bool KC>
-__device__ __forceinline__ void store_tile(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) {
-    if (okmask != (NP == 8 ? 0xFFFFFFFFu : ((1u << (4 * NP)) - 1u))) {     // only tiles on an operand edge pay for the selects
+template <bool KC, int ROWS>
+__device__ __forceinline__ void store_tile(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float (*T)[ROWS + 4], int tid) {
+    constexpr int NPT = ROWS * BKT / 1024, RC = ROWS / 4;
+    if (okmask != (NPT == 8 ? 0xFFFFFFFFu : ((1u << (4 * NPT)) - 1u))) {     // only tiles on an operand edge pay for the selects
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
+        for (int i = 0; i < NPT; ++i) {
             const unsigned mk = okmask >> (4 * i);
             r[i].x = (mk & 1u) ? r[i].x : 0.f; r[i].y = (mk & 2u) ? r[i].y : 0.f;
             r[i].z = (mk & 4u) ? r[i].z : 0.f; r[i].w = (mk & 8u) ? r[i].w : 0.f;
         }
     }
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NPT; ++i) {
         const int f = tid + 256 * i;
         if (KC) {
             const int row = f / KCH, k = (f % KCH) << 2;
             T[k + 0][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
         } else {
-            const int k = f >> 5, row = (f & 31) << 2;
+            const int k = f / RC, row = (f % RC) << 2;
             *reinterpret_cast<float4*>(&T[k][row]) = r[i];
         }
     }
@@ -101,52 +118,59 @@ __device__ __forceinline__ int xcd_tile(int wg, int ntiles) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// Operand loader concept: `unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const` fetches this thread's 4*NP floats
-// of the 128 x BKT tile starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing
-// the invalid ones) into the k-major LDS tile T[k][row].
-template <bool KC, bool VEC>
+// Operand loader concept (ROWS = the tile's BM for the A side, BN for the B side, NPT = ROWS*BKT/1024):
+// `unsigned load(float4 (&r)[NPT], int k0, int kend, int tid) const` fetches this thread's 4*NPT floats of the ROWS x BKT tile
+// starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing the invalid ones) into the
+// k-major LDS tile T[k][row] (row stride ROWS + 4).
+template <bool KC, bool VEC, int ROWS = 128>
 struct DenseLoader {
     const float* base; int64_t s_row, s_k; int row0, rows;
-    __device__ __forceinline__ unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const {
-        return load_tile<KC, VEC>(r, base, s_row, s_k, row0, rows, k0, kend, tid);
+    __device__ __forceinline__ unsigned load(float4 (&r)[ROWS * BKT / 1024], int k0, int kend, int tid) const {
+        return load_tile<KC, VEC, ROWS>(r, base, s_row, s_k, row0, rows, k0, kend, tid);
     }
-    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const { store_tile<KC>(r, okmask, T, tid); }
+    __device__ __forceinline__ void store(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float (*T)[ROWS + 4], int tid) const {
+        store_tile<KC, ROWS>(r, okmask, T, tid);
+    }
 };
 
 struct TileCoord { int m0, n0, zb, zk, z0, z1, kbeg, kend; };
+template <class Cfg = Cfg128>
 __device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
     TileCoord t;
     const int tile = xcd_tile(blockIdx.x, g.tiles_m * g.tiles_n);
     const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     t.zb = blockIdx.y; t.zk = blockIdx.z;
     t.z0 = t.zb / g.nb1; t.z1 = t.zb - t.z0 * g.nb1;
-    t.m0 = tm * BM; t.n0 = tn * BN;
+    t.m0 = tm * Cfg::BM; t.n0 = tn * Cfg::BN;
     t.kbeg = t.zk * g.k_chunk;
     t.kend = (t.kbeg + g.k_chunk < g.K) ? t.kbeg + g.k_chunk : g.K;
     return t;
 }
 
 // acc += A_tile . B_tile^T over k in [kbeg, kend): the k-tile pipeline shared by every MFMA kernel of the library
-// LDS: two buffers per operand (2 x 2 x BKT x LDT x 4 B = 67.6 KB per workgroup -> two workgroups per CU)
-struct TileLds { float A[2][BKT][LDT]; float B[2][BKT][LDT]; };
+// LDS: two buffers per operand (128 x 128: 2 x 2 x BKT x 132 x 4 B = 67.6 KB per workgroup -> two workgroups per CU)
+template <class Cfg>
+struct TileLdsT { float A[2][BKT][Cfg::LDA]; float B[2][BKT][Cfg::LDB]; };
+using TileLds = TileLdsT<Cfg128>;
 
-template <class LA, class LB>
-__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la, const LB& lb, int kbeg, int kend, TileLds& S) {
+template <class Cfg = Cfg128, class LA, class LB>
+__device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const LA& la, const LB& lb, int kbeg, int kend, TileLdsT<Cfg>& S) {
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     if (kbeg >= kend) return;                        // an empty split-K slab just writes zeros
     // Pipeline (per k-tile t, h = t & 1 static after unrolling by two):
     //   global loads of tile t+2 -> register set h        (two tiles ahead: rides out lock-step fetch latency)
     //   LDS stores of tile t+1 (register set h^1) -> LDS buffer h^1   (issued BEFORE the MFMAs, so they drain under them)
-    //   64 MFMAs on LDS buffer h, operand fragments fetched one k2-step ahead
+    //   MI*NJ*16 MFMAs on LDS buffer h, operand fragments fetched one k2-step ahead
     //   ONE barrier (buffer h may be overwritten / buffer h^1 is complete)
-    float4 ra[2][NP], rb[2][NP];
+    float4 ra[2][Cfg::NPA], rb[2][Cfg::NPB];
     unsigned oka[2] = {0u, 0u}, okb[2] = {0u, 0u};
     oka[0] = la.load(ra[0], kbeg, kend, tid);
     okb[0] = lb.load(rb[0], kbeg, kend, tid);
@@ -154,29 +178,36 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
     la.store(ra[0], oka[0], S.A[0], tid);
     lb.store(rb[0], okb[0], S.B[0], tid);
     __syncthreads();
-    const int arow = wm * 64 + (lane & 31), brow = wn * 64 + (lane & 31), kl = lane >> 5;
+    const int arow = wm * (32 * MI) + (lane & 31), brow = wn * (32 * NJ) + (lane & 31), kl = lane >> 5;
     for (int k0 = kbeg; k0 < kend; k0 += 2 * BKT) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int kt = k0 + h * BKT;
             if (kt < kend) {
-                float (*As)[LDT] = S.A[h]; float (*Bs)[LDT] = S.B[h];
+                float (*As)[Cfg::LDA] = S.A[h]; float (*Bs)[Cfg::LDB] = S.B[h];
                 if (kt + 2 * BKT < kend) { oka[h] = la.load(ra[h], kt + 2 * BKT, kend, tid); okb[h] = lb.load(rb[h], kt + 2 * BKT, kend, tid); }
                 if (kt + BKT < kend) { la.store(ra[h ^ 1], oka[h ^ 1], S.A[h ^ 1], tid); lb.store(rb[h ^ 1], okb[h ^ 1], S.B[h ^ 1], tid); }
-                float a0 = As[kl][arow], a1 = As[kl][arow + 32], b0 = Bs[kl][brow], b1 = Bs[kl][brow + 32];
+                float a[MI], b[NJ];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = As[kl][arow + 32 * i];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) b[j] = Bs[kl][brow + 32 * j];
 #pragma unroll
                 for (int kk = 0; kk < BKT; kk += 2) {
-                    float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-                    if (kk + 2 < BKT) {
-                        na0 = As[kk + 2 + kl][arow]; na1 = As[kk + 2 + kl][arow + 32];
-                        nb0 = Bs[kk + 2 + kl][brow]; nb1 = Bs[kk + 2 + kl][brow + 32];
-                    }
+                    float na[MI], nb[NJ];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) na[i] = (kk + 2 < BKT) ? As[kk + 2 + kl][arow + 32 * i] : 0.f;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) nb[j] = (kk + 2 < BKT) ? Bs[kk + 2 + kl][brow + 32 * j] : 0.f;
                     __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of this step's MFMAs
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-                    a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) a[i] = na[i];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) b[j] = nb[j];
                 }
                 __syncthreads();
             }
@@ -185,9 +216,10 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[2][2], const LA& la,
 }
 
 // MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const GemmArgs& g, const TileCoord& t) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+template <int EPI, class Cfg = Cfg128>
+__device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::NJ], const GemmArgs& g, const TileCoord& t) {
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int m0 = t.m0, n0 = t.n0, zb = t.zb, zk = t.zk, z0 = t.z0, z1 = t.z1;
     const bool split = g.splitk > 1;
     float* C = split ? g.C + (int64_t)zk * g.c_split + (int64_t)zb * g.M * g.N : g.C + z0 * g.c_b0 + z1 * g.c_b1;
@@ -197,16 +229,16 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[2][2], const G
     const bool bias_n = bias && g.bias_mode == SEGX_BIAS_N, bias_m = bias && g.bias_mode == SEGX_BIAS_M;
     float* AUX = (EPI == SEGX_EPI_GELU) ? g.aux + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;
     const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
-    const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+    const bool full = (m0 + Cfg::BM <= g.M) && (n0 + Cfg::BN <= g.N);
     float vmax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int j = 0; j < NJ; ++j) {
+            const int col = n0 + wn * (32 * NJ) + j * 32 + (lane & 31);
             const bool col_ok = full || col < g.N;
             const float bn = (bias_n && col_ok) ? bias[col] : 0.f;
-            const int rbase = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            const int rbase = m0 + wm * (32 * MI) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);

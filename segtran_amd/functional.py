@@ -74,9 +74,8 @@ def _splitk(M, N, K, nbatch):
 
 
 def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
-    sk = _splitk(M, N, K, nb[0] * nb[1]) if not kw.get('epilogue') and kw.get('gmax') is None else 1
-    ws = _empty(C, sk * nb[0] * nb[1] * M * N) if sk > 1 else None
-    L.gemm(A, B, C, M, N, K, a, b, c, nb=nb, alpha=alpha, splitk=sk, workspace=ws, **kw)
+    # splitk=0: the library plans tile shape + split-K (segx_gemm_plan); fused epilogues / gmax never split
+    L.gemm(A, B, C, M, N, K, a, b, c, nb=nb, alpha=alpha, splitk=0, **kw)
 
 
 def _grad_operand(L, dC, other, s, which, like):

@@ -27,10 +27,11 @@ class GemmDesc(ctypes.Structure):
                 ('alpha', c_f), ('epilogue', c_i), ('bias_mode', c_i), ('bias_b1', c_l),
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
-                ('splitk', c_i), ('workspace', c_p)]
+                ('splitk', c_i), ('workspace', c_p), ('tile', c_i)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
+TILE_AUTO, TILE_128x128, TILE_64x64, TILE_128x32, TILE_32x128, TILE_64x128 = range(6)
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 
@@ -48,6 +49,7 @@ class SegxLib:
         self.c.segx_last_error.argtypes = [ctypes.c_char_p, c_i]
         self.c.segx_version.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
+        self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
@@ -80,9 +82,10 @@ class SegxLib:
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
              bias_mode=BIAS_NONE, bias_b1=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
-             offset=0, splitk=1, workspace=None):
+             offset=0, splitk=1, workspace=None, tile=TILE_AUTO):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
-        a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m)."""
+        a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
+        splitk = 0: take tile and split factor from segx_gemm_plan and allocate the slab workspace here."""
         self._chk_t(A, B, C, bias, aux, gmax, workspace)
         d = GemmDesc()
         d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
@@ -92,18 +95,23 @@ class SegxLib:
         d.alpha, d.epilogue, d.bias_mode, d.bias_b1 = alpha, epilogue, bias_mode, bias_b1
         d.bias, d.aux, d.gmax = _ptr(bias), _ptr(aux), _ptr(gmax)
         d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+        if splitk == 0:
+            t, sk = c_i(0), c_i(0)
+            self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
+            tile, splitk = t.value, sk.value
+            workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if splitk > 1 else None
         d.splitk, d.workspace = splitk, _ptr(workspace)
+        d.tile = self.force_tile if self.force_tile is not None else tile
         if self.gemm_prof is not None and C.is_cuda:
             # HIP events on the launch stream (torch's current stream IS the stream handed to the kernel)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
             e1.record()
-            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, splitk)))
+            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, splitk, d.tile)))
         else:
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
         self.check(rc, 'segx_gemm_f32')
-
 
     # ---- token row kernels (tokens.hip) ---------------------------------------------------------
     def _call(self, name, ref, *args):

@@ -25,6 +25,29 @@ def test_gemm_layouts(backend, M, N, K, akc, bkc):
     assert (C.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x64, segx.TILE_128x32, segx.TILE_32x128, segx.TILE_64x128])
+@pytest.mark.parametrize('M,N,K,akc,bkc,sk', [(200, 136, 72, True, True, 1), (36, 260, 100, True, False, 1), (132, 24, 200, False, False, 3),
+                                              (68, 68, 64, False, True, 2)])
+def test_gemm_every_tile_shape_gives_the_same_result(backend, tile, M, N, K, akc, bkc, sk):
+    """The workgroup tile is a tuning knob: every TileCfg must produce the k-ordered fp32 result (bias + split-K included)."""
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(M + N + K)
+    nb = 2
+    A = torch.randn(nb, M, K, generator=g, device='cpu').to(backend.dev)
+    B = torch.randn(nb, N, K, generator=g, device='cpu').to(backend.dev)
+    bias = torch.randn(M, generator=g, device='cpu').to(backend.dev)
+    Am = A if akc else A.transpose(1, 2).contiguous()
+    Bm = B if bkc else B.transpose(1, 2).contiguous()
+    a_str = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+    b_str = (0, N * K, K, 1) if bkc else (0, N * K, 1, N)
+    C = torch.full((nb, M, N), float('nan'))
+    ws = torch.empty(sk * nb * M * N) if sk > 1 else None
+    L.gemm(Am, Bm, C, M, N, K, a_str, b_str, (0, M * N, N), nb=(1, nb), alpha=0.5, bias=bias, bias_mode=segx.BIAS_M,
+           splitk=sk, workspace=ws, tile=tile)
+    ref = 0.5 * _ref(A, B) + bias.double()[None, :, None]
+    assert (C.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_batched_modes_bias_alpha_gmax(backend):
     """squeeze-out QK^T view: Q [B,N,4*d], K [B,A,4*d] -> S [4,B,N,A] (mode-major), scaled, max tracked."""
     L = backend.L
