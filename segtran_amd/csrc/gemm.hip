@@ -55,29 +55,52 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// Tile choice when the caller leaves it to the library.  Measured on MI355X (tools/gemm_bench.py tiles, r01-j):
-//  * an operand with <= 48 rows is streamed with the 32-row tile on that side (the 128-row tile spends 3/4 of its LDS
-//    traffic and MFMA issue slots on clamped duplicate rows: 192x32x65536 weight gradient 0.34 -> 0.14 ms);
-//  * problems that waste a quarter of their 128 x 128 edge tiles, cannot fill the 512 workgroup slots, or have a short
-//    k loop (tail-dominated) run on 64 x 64 tiles (4x the workgroups, 1/4 the padding);
-//  * M = 128 j + (1..64) rows (448-channel FPN bridges) take the 64 x 128 tile.
-static int auto_tile(int M, int N, int K, int64_t nwg128, bool vec) {
-    if (!vec) return SEGX_TILE_128x128;
-    if (N <= 48 && M > N) return SEGX_TILE_128x32;
-    if (M <= 48) return SEGX_TILE_32x128;
-    const double util = ((double)M * N) / ((double)ceil_div(M, 128) * 128 * (double)ceil_div(N, 128) * 128);
-    if (util <= 0.76 || nwg128 < 512 || (K <= 512 && nwg128 < 2048)) return SEGX_TILE_64x64;
-    if (M < 1024 && M % 128 >= 1 && M % 128 <= 64) return SEGX_TILE_64x128;
-    return SEGX_TILE_128x128;
+// Tile / split-K planning.  Skinny operands are a rule (measured, tools/gemm_bench.py tiles, r01-j): an operand with <= 48 rows
+// is streamed with the 32-row tile on that side -- the 128-row tile spends 3/4 of its LDS traffic and MFMA issue slots on
+// clamped duplicate rows (192x32x65536 weight gradient: 0.34 -> 0.14 ms).  Everything else is priced with a small model:
+//   time = rounds of workgroups over the resident slots x (k-tiles x step time + prologue/epilogue) + split-K slab reduction
+// Whole-GEMM quantisation matters (784 workgroups on 768 slots take two rounds, not 1.02), and so do padded edge tiles, which
+// the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
+struct TileInfo { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };   // resident workgroups per CU (LDS bound)
+static const TileInfo kTiles[] = {{SEGX_TILE_128x128, 128, 128, 2, 4.8f, 4.0f},
+                                  {SEGX_TILE_64x128, 64, 128, 3, 3.5f, 2.5f},
+                                  {SEGX_TILE_64x64, 64, 64, 4, 2.4f, 1.5f},
+                                  {SEGX_TILE_128x32, 128, 32, 3, 2.4f, 1.5f},
+                                  {SEGX_TILE_32x128, 32, 128, 3, 2.4f, 1.5f}};
+static const TileInfo& tile_info(int tile) {
+    for (const TileInfo& t : kTiles) if (t.id == tile) return t;
+    return kTiles[0];
 }
-struct TileInfo { int bm, bn, wg_per_cu; float ktile_us; };   // resident workgroups per CU (LDS bound), time of one k-tile step
-static TileInfo tile_info(int tile) {
-    switch (tile) {
-        case SEGX_TILE_64x64:  return {64, 64, 4, 1.1f};
-        case SEGX_TILE_128x32: return {128, 32, 3, 1.0f};
-        case SEGX_TILE_32x128: return {32, 128, 3, 1.0f};
-        case SEGX_TILE_64x128: return {64, 128, 3, 1.9f};
-        default:               return {128, 128, 2, 3.4f};
+static double model_us(const TileInfo& ti, int M, int N, int K, int nbatch, int sk) {
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
+    const int kt = ceil_div(ceil_div(K, sk), BKT);
+    const int64_t rounds = (tiles * sk + slots - 1) / slots;
+    return (double)rounds * (kt * ti.ktile_us + ti.fixed_us) + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
+}
+static int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, double* t_out) {
+    int best = 1; double best_t = model_us(ti, M, N, K, nbatch, 1);
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch;
+    if (tiles < 4 * 256 * ti.wg_per_cu && K >= 1024)
+        for (int sk = 2; sk <= 128 && K / sk >= 256; ++sk) {
+            const double t = model_us(ti, M, N, K, nbatch, sk);
+            if (t < best_t * 0.97) { best = sk; best_t = t; }
+        }
+    *t_out = best_t;
+    return best;
+}
+// splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
+static void plan(int M, int N, int K, int nbatch, bool vec, bool may_split, int splitk_fixed, int* tile, int* splitk) {
+    const TileInfo* cand[3]; int nc = 0;
+    if (!vec) cand[nc++] = &kTiles[0];
+    else if (N <= 48 && M > N) cand[nc++] = &tile_info(SEGX_TILE_128x32);
+    else if (M <= 48) cand[nc++] = &tile_info(SEGX_TILE_32x128);
+    else { cand[nc++] = &kTiles[0]; cand[nc++] = &kTiles[1]; cand[nc++] = &kTiles[2]; }
+    double best_t = -1.0;
+    for (int i = 0; i < nc; ++i) {
+        double t; int sk;
+        if (splitk_fixed > 0 || !may_split) { sk = splitk_fixed > 0 ? splitk_fixed : 1; t = model_us(*cand[i], M, N, K, nbatch, sk); }
+        else sk = best_splitk(*cand[i], M, N, K, nbatch, &t);
+        if (best_t < 0.0 || t < best_t * 0.97) { best_t = t; *tile = cand[i]->id; *splitk = sk; }   // larger tiles win ties
     }
 }
 static bool gemm_vec_ok(const float* A, const float* B, const segx_gemm_desc* d) {
@@ -89,34 +112,14 @@ static bool gemm_vec_ok(const float* A, const float* B, const segx_gemm_desc* d)
                       ((bkc ? d->K : d->N) % 4 == 0);
     return vecA && vecB;
 }
-// Split-K factor minimising modelled time = rounds-of-workgroups x k-tiles per workgroup + slab reduction.  Whole-GEMM
-// quantisation matters: 784 workgroups on 768 slots take two rounds, not 1.02.
-static int auto_splitk(int M, int N, int K, int nbatch, int tile) {
-    const TileInfo ti = tile_info(tile);
-    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
-    if (tiles >= 4 * slots || K < 1024) return 1;
-    int best = 1; double best_t = -1.0;
-    for (int sk = 1; sk <= 128; ++sk) {
-        if (sk > 1 && K / sk < 256) break;
-        const int kt = ceil_div(ceil_div(K, sk), BKT);
-        const int64_t rounds = (tiles * sk + slots - 1) / slots;
-        const double t = (double)rounds * kt * ti.ktile_us + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
-        if (best_t < 0.0 || t < best_t * 0.97) { best = sk; best_t = t; }
-    }
-    return best;
-}
-
 }  // namespace segx
 
 extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk) {
     using namespace segx;
     SEGX_REQUIRE(A && B && d && tile && splitk && d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_plan: bad args");
-    const int nbatch = d->nb0 * d->nb1;
-    const bool plain = d->epilogue == SEGX_EPI_NONE, vec = gemm_vec_ok(A, B, d);
-    // the split factor is chosen for the tile the un-split problem would get, then the tile is re-chosen for the split grid
-    int t = (vec && plain) ? auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch, true) : SEGX_TILE_128x128;
-    const int sk = (plain && !d->gmax) ? auto_splitk(d->M, d->N, d->K, nbatch, t) : 1;
-    if (vec && plain) t = auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch * sk, true);
+    const bool plain = d->epilogue == SEGX_EPI_NONE;
+    int t = SEGX_TILE_128x128, sk = 1;
+    plan(d->M, d->N, d->K, d->nb0 * d->nb1, gemm_vec_ok(A, B, d) && plain, plain && !d->gmax, 0, &t, &sk);
     *tile = t; *splitk = sk;
     return 0;
 }
@@ -156,8 +159,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     if (splitk > 1) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_64x128, "segx_gemm_f32: bad tile %d", d->tile);
     int tile = d->tile;
-    if (tile == SEGX_TILE_AUTO)
-        tile = auto_tile(d->M, d->N, d->K, (int64_t)ceil_div(d->M, 128) * ceil_div(d->N, 128) * nbatch * splitk, vec && d->epilogue == SEGX_EPI_NONE);
+    if (tile == SEGX_TILE_AUTO) { int sk_unused = 1; plan(d->M, d->N, d->K, nbatch, vec && d->epilogue == SEGX_EPI_NONE, false, splitk, &tile, &sk_unused); }
     if (!vec || d->epilogue != SEGX_EPI_NONE) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
 
     dim3 block(256);
