@@ -217,7 +217,11 @@ int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, in
  * NCDHW fp32.  geom (int32[16]) = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}, p* = FRONT zero
  * pads of the dynamic 'same' padding (aj_i3d.py:68-90: front = pad // 2).  nn.Conv3d at aj_i3d.py:57-62,92.
  * ------------------------------------------------------------------------------------------- */
-int segx_conv3d_fwd(const float* X, const float* W /* [Cout][Cin][KD][KH][KW] */, float* Y, int B, int Cout, const int* geom, void* stream);
+/* splitk > 1: the contraction (Cin*KV) is split over slabs in `workspace` (splitk*B*Cout*P floats) and reduced deterministically;
+ * segx_conv3d_splitk returns the library's choice for the forward (wgrad = 0) or weight-gradient (wgrad = 1) GEMM */
+int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgrad);
+int segx_conv3d_fwd(const float* X, const float* W /* [Cout][Cin][KD][KH][KW] */, float* Y, int B, int Cout, const int* geom, int splitk,
+                    float* workspace, void* stream);
 /* Wt[ci][co][t] = W[co][ci][KV-1-t]: backward-data of a stride-1 conv = segx_conv3d_fwd(dY, Wt) with pads K-1-p */
 int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream);
 /* per-sample weight gradients dWb[B][Cout][Cin*KV] (sum over B with segx_colsum); split-K over output positions:

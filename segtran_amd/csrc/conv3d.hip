@@ -28,20 +28,39 @@ __device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
 // ---- forward / backward-data: B(n = output position, k = (ci, tap)) ------------------------------------------------
 // Thread map: ONE output position per thread (n0 + (tid & 127): the 64 lanes of a wave read 64 consecutive positions,
 // i.e. whole 128-B lines for every tap), BKT/2 k-rows (tid>>7)*(BKT/2) + i.  The (ci, tap) decode of a k-row is wave-uniform.
+// Per-thread state is ONE element offset of the window origin and the window's validity as bit masks (the whole window when
+// it has <= 32 taps, else one mask per axis), so a gathered element costs ~5 VALU ops (offset add, bit extract, select, mask
+// insert) instead of three coordinate adds + three range compares + the offset arithmetic.
 struct ConvFwdLoaderB {
     const float* X; ConvGeom q; FastDiv dKV, dKHW, dKW;
-    int bd, bh, bw; bool nvalid;
+    int pos_off;                    // ((bd * IH) + bh) * IW + bw of the window origin (may be negative: padding)
+    unsigned mk0, mk1, mk2;         // KV <= 32: mk0 bit t = tap t inside the input;  else per-axis masks (bits kd / kh / kw)
+    bool single;
     __device__ __forceinline__ ConvFwdLoaderB(const float* X_, const ConvGeom& q_, int n0, int P) : X(X_), q(q_) {
         dKV = make_fastdiv(q.KD * q.KH * q.KW); dKHW = make_fastdiv(q.KH * q.KW); dKW = make_fastdiv(q.KW);
         const int n = n0 + (threadIdx.x & 127);
-        nvalid = n < P;
+        const bool nvalid = n < P;
         const int nn = nvalid ? n : 0;
         const int od = nn / (q.OH * q.OW), r = nn - od * q.OH * q.OW, oh = r / q.OW, ow = r - oh * q.OW;
-        bd = od * q.sd - q.pd; bh = oh * q.sh - q.ph; bw = ow * q.sw - q.pw;
+        const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
+        pos_off = (bd * q.IH + bh) * q.IW + bw;
+        unsigned md = 0, mh = 0, mw = 0;
+        for (int i = 0; i < q.KD; ++i) md |= ((unsigned)(bd + i) < (unsigned)q.ID ? 1u : 0u) << i;
+        for (int i = 0; i < q.KH; ++i) mh |= ((unsigned)(bh + i) < (unsigned)q.IH ? 1u : 0u) << i;
+        for (int i = 0; i < q.KW; ++i) mw |= ((unsigned)(bw + i) < (unsigned)q.IW ? 1u : 0u) << i;
+        single = q.KD * q.KH * q.KW <= 32;
+        if (single) {
+            unsigned m = 0; int t = 0;
+            for (int a = 0; a < q.KD; ++a) for (int b2 = 0; b2 < q.KH; ++b2) for (int c = 0; c < q.KW; ++c, ++t)
+                m |= (((md >> a) & (mh >> b2) & (mw >> c)) & 1u) << t;
+            md = m;
+        }
+        if (!nvalid) md = 0;
+        mk0 = md; mk1 = mh; mk2 = mw;
     }
     __device__ __forceinline__ unsigned load(float4 (&r)[NP], int k0, int kend, int tid) const {
         unsigned okmask = 0;
-        const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
+        const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, plane = q.IH * q.IW;
         const int kbase = k0 + (tid >> 7) * (BKT / 2);               // wave-uniform
         float* v = reinterpret_cast<float*>(&r[0]);
 #pragma unroll
@@ -49,12 +68,13 @@ struct ConvFwdLoaderB {
             const int k = kbase + i;
             const bool kok = k < kend;
             const int kk = kok ? k : 0;
+            // wave-uniform decode of (ci, kd, kh, kw) and of the tap's element offset
             const int ci = fdiv(kk, dKV), t = kk - ci * KV, kd = fdiv(t, dKHW), t2 = t - kd * KHW, kh = fdiv(t2, dKW), kw = t2 - kh * q.KW;
-            const int id = bd + kd, ih = bh + kh, iw = bw + kw;
-            const bool ok = kok && nvalid && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
-            const int64_t off = ok ? (((int64_t)ci * q.ID + id) * q.IH + ih) * q.IW + iw : 0;
-            v[i] = X[off];
-            if (ok) okmask |= 1u << i;
+            const int tap_off = (ci * q.ID + kd) * plane + kh * q.IW + kw;
+            const unsigned bit = single ? (mk0 >> t) & 1u : ((mk0 >> kd) & (mk1 >> kh) & (mk2 >> kw)) & 1u;
+            const bool ok = kok && bit != 0u;
+            v[i] = X[ok ? (int64_t)pos_off + tap_off : 0];
+            okmask |= (ok ? 1u : 0u) << i;
         }
         return okmask;
     }
@@ -298,22 +318,49 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
 }
 
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads) */
-extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, void* stream_) {
+// split factor of the implicit GEMM (M = Cout, N, K, B samples) on the tile the convolution kernels use for this Cout
+static int conv_splitk(int M, int N, int K, int B) {
+    const bool small = M % 128 >= 1 && M % 128 <= 64;
+    double t;
+    return best_splitk(tile_info(small ? SEGX_TILE_64x128 : SEGX_TILE_128x128), M, N, K, B, &t);
+}
+/* the library's split-K factor for segx_conv3d_fwd (wgrad = 0) / segx_conv3d_bwd_weight (wgrad = 1); workspace = splitk * output floats */
+extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgrad) {
+    if (!geom || B <= 0 || Cout <= 0) return 1;
+    const ConvGeom q = make_geom(geom);
+    const int64_t P = (int64_t)q.OD * q.OH * q.OW, CK = (int64_t)q.Cin * q.KD * q.KH * q.KW;
+    if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
+    return wgrad ? conv_splitk(Cout, (int)CK, (int)P, B) : conv_splitk(Cout, (int)P, (int)CK, B);
+}
+/* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
+ * workspace (splitk*B*Cout*P floats), reduced deterministically -- for the low-resolution Inception stages whose position grid alone
+ * cannot fill the GPU (192 x 588 x 10368: 40 workgroups un-split) */
+extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                               void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && W && Y && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_fwd: bad args");
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int K = q.Cin * q.KD * q.KH * q.KW;
     SEGX_REQUIRE(P > 0 && P < 2147483647LL && K > 0, "segx_conv3d_fwd: bad geometry");
+    SEGX_REQUIRE((int64_t)q.Cin * q.ID * q.IH * q.IW < 2147483647LL && q.KD <= 32 && q.KH <= 32 && q.KW <= 32, "segx_conv3d_fwd: sample or window too large");
+    if (splitk < 1) splitk = 1;
+    SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_fwd: split-K needs a workspace");
     GemmArgs g; g.A = W; g.B = X; g.C = Y;
     g.a_b0 = 0; g.a_m = K; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * P; g.c_m = P;
-    fill_common(g, Cout, (int)P, K, B, 1, nullptr);
+    fill_common(g, Cout, (int)P, K, B, splitk, workspace);
     const bool vec = aligned16c(W) && K % 4 == 0, small = Cout % 128 >= 1 && Cout % 128 <= 64;
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
-    dim3 grid(g.tiles_m * g.tiles_n, B, 1);
+    dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
     if (small && vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
     else if (small) hipLaunchKernelGGL((conv3d_fwd_kernel<false, CfgCout64>), grid, dim3(256), 0, stream, g, q);
     else if (vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, Cfg128>), grid, dim3(256), 0, stream, g, q);
     else hipLaunchKernelGGL((conv3d_fwd_kernel<false, Cfg128>), grid, dim3(256), 0, stream, g, q);
-    return check_launch("segx_conv3d_fwd");
+    int rc = check_launch("segx_conv3d_fwd");
+    if (rc || splitk == 1) return rc;
+    const int64_t total = g.c_split;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, Y,
+                       (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
+                       (int64_t)0, total);
+    return check_launch("segx_conv3d_fwd/reduce");
 }
 extern "C" int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(W && Wt && Cout > 0 && Cin > 0 && KV > 0, "segx_conv3d_flip_weights: bad args");

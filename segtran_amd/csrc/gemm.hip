@@ -61,33 +61,6 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 //   time = rounds of workgroups over the resident slots x (k-tiles x step time + prologue/epilogue) + split-K slab reduction
 // Whole-GEMM quantisation matters (784 workgroups on 768 slots take two rounds, not 1.02), and so do padded edge tiles, which
 // the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
-struct TileInfo { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };   // resident workgroups per CU (LDS bound)
-static const TileInfo kTiles[] = {{SEGX_TILE_128x128, 128, 128, 2, 4.8f, 4.0f},
-                                  {SEGX_TILE_64x128, 64, 128, 3, 3.5f, 2.5f},
-                                  {SEGX_TILE_64x64, 64, 64, 4, 2.4f, 1.5f},
-                                  {SEGX_TILE_128x32, 128, 32, 3, 2.4f, 1.5f},
-                                  {SEGX_TILE_32x128, 32, 128, 3, 2.4f, 1.5f}};
-static const TileInfo& tile_info(int tile) {
-    for (const TileInfo& t : kTiles) if (t.id == tile) return t;
-    return kTiles[0];
-}
-static double model_us(const TileInfo& ti, int M, int N, int K, int nbatch, int sk) {
-    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
-    const int kt = ceil_div(ceil_div(K, sk), BKT);
-    const int64_t rounds = (tiles * sk + slots - 1) / slots;
-    return (double)rounds * (kt * ti.ktile_us + ti.fixed_us) + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
-}
-static int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, double* t_out) {
-    int best = 1; double best_t = model_us(ti, M, N, K, nbatch, 1);
-    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch;
-    if (tiles < 4 * 256 * ti.wg_per_cu && K >= 1024)
-        for (int sk = 2; sk <= 128 && K / sk >= 256; ++sk) {
-            const double t = model_us(ti, M, N, K, nbatch, sk);
-            if (t < best_t * 0.97) { best = sk; best_t = t; }
-        }
-    *t_out = best_t;
-    return best;
-}
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
 static void plan(int M, int N, int K, int nbatch, bool vec, bool may_split, int splitk_fixed, int* tile, int* splitk) {
     const TileInfo* cand[3]; int nc = 0;

@@ -261,6 +261,35 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     }
 }
 
+// ---- host-side cost model shared by the GEMM and convolution planners (see gemm.hip) ---------------------------------
+struct TileInfo { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };   // resident workgroups per CU (LDS bound)
+static const TileInfo kTiles[] = {{SEGX_TILE_128x128, 128, 128, 2, 4.8f, 4.0f},
+                                  {SEGX_TILE_64x128, 64, 128, 3, 3.5f, 2.5f},
+                                  {SEGX_TILE_64x64, 64, 64, 4, 2.4f, 1.5f},
+                                  {SEGX_TILE_128x32, 128, 32, 3, 2.4f, 1.5f},
+                                  {SEGX_TILE_32x128, 32, 128, 3, 2.4f, 1.5f}};
+inline const TileInfo& tile_info(int tile) {
+    for (const TileInfo& t : kTiles) if (t.id == tile) return t;
+    return kTiles[0];
+}
+inline double model_us(const TileInfo& ti, int M, int N, int K, int nbatch, int sk) {
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
+    const int kt = ceil_div(ceil_div(K, sk), BKT);
+    const int64_t rounds = (tiles * sk + slots - 1) / slots;
+    return (double)rounds * (kt * ti.ktile_us + ti.fixed_us) + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
+}
+inline int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, double* t_out) {
+    int best = 1; double best_t = model_us(ti, M, N, K, nbatch, 1);
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch;
+    if (tiles < 4 * 256 * ti.wg_per_cu && K >= 1024)
+        for (int sk = 2; sk <= 128 && K / sk >= 256; ++sk) {
+            const double t = model_us(ti, M, N, K, nbatch, sk);
+            if (t < best_t * 0.97) { best = sk; best_t = t; }
+        }
+    *t_out = best_t;
+    return best;
+}
+
 // Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,

@@ -51,28 +51,6 @@ class GemmSpec:
         self.out_shape, self.alpha, self.bias_mode, self.bias_b1 = tuple(out_shape), alpha, bias_mode, bias_b1
 
 
-_SLOTS = 256 * 2          # workgroups resident at once: 256 CUs x 2 (the GEMM kernel allocates ~180 VGPR+AGPR)
-
-
-def _splitk(M, N, K, nbatch):
-    """Split-K factor minimising modelled time = rounds-of-workgroups x k-tiles per workgroup + slab reduction.
-    Whole-GEMM quantisation matters: 784 workgroups on 768 slots take two rounds, not 1.02."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
-    if tiles >= 4 * _SLOTS or K < 1024:
-        return 1
-    ktile_us = 3.4                                   # one 128x128x32 step with two workgroups sharing a CU
-    best, best_t = 1, None
-    for sk in range(1, 33):
-        if sk > 1 and K // sk < 256:
-            break
-        kt = -(-(-(-K // sk)) // 32)                 # ceil(ceil(K/sk)/32)
-        rounds = -(-tiles * sk // _SLOTS)
-        t = rounds * kt * ktile_us + (0 if sk == 1 else sk * M * N * nbatch * 8 / 3.0e6)
-        if best_t is None or t < best_t * 0.97:
-            best, best_t = sk, t
-    return best
-
-
 def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
     # splitk=0: the library plans tile shape + split-K (segx_gemm_plan); fused epilogues / gmax never split
     L.gemm(A, B, C, M, N, K, a, b, c, nb=nb, alpha=alpha, splitk=0, **kw)
@@ -749,7 +727,8 @@ class _Conv3d(torch.autograd.Function):
         OW = (IW + pw + pwb - KW) // stride[2] + 1
         y = _empty(x, B, Cout, OD, OH, OW)
         geom = (Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW) + tuple(stride) + (pd, ph, pw)
-        L.conv3d_fwd(x, w, y, B, Cout, geom)
+        sk = L.conv3d_splitk(B, Cout, geom, False)
+        L.conv3d_fwd(x, w, y, B, Cout, geom, sk, _empty(x, sk * y.numel()) if sk > 1 else None)
         ctx.geom, ctx.stride, ctx.pads = geom, tuple(stride), pads
         ctx.save_for_backward(x, w)
         return y
@@ -772,14 +751,15 @@ class _Conv3d(torch.autograd.Function):
                 (pd, _), (ph, _), (pw, _) = ctx.pads
                 g2 = (Cout, OD, OH, OW, ID, IH, IW, KD, KH, KW, 1, 1, 1, KD - 1 - pd, KH - 1 - ph, KW - 1 - pw)
                 dx = torch.empty_like(x)
-                L.conv3d_fwd(dy, wt, dx, B, Cin, g2)
+                sk = L.conv3d_splitk(B, Cin, g2, False)
+                L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, _empty(x, sk * dx.numel()) if sk > 1 else None)
             else:
                 # strided transposed convolution (only the 7x7x7 stride-2 stem, 3 input channels): direct gather kernel
                 dx = torch.empty_like(x)
                 L.conv3d_bwd_data_direct(dy, w, dx, B, Cout, geom)
         if ctx.needs_input_grad[1]:
             P, N = OD * OH * OW, Cin * KV
-            sk = _splitk(Cout, N, P, B)
+            sk = L.conv3d_splitk(B, Cout, geom, True)
             ws = _empty(x, sk * B * Cout * N) if sk > 1 else None
             dwb = _empty(x, B, Cout * N)
             L.conv3d_bwd_weight(dy, x, dwb, B, Cout, geom, sk, ws)

@@ -55,7 +55,7 @@ class SegxLib:
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
-            fn.restype = c_l if name.endswith(('_floats', '_rows')) else c_i
+            fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk')) else c_i
 
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
@@ -274,12 +274,14 @@ class SegxLib:
             return rc
         return fn()
 
-    def conv3d_fwd(self, X, W, Y, B, Cout, geom):
-        self._chk_t(X, W, Y)
-        g = [int(v) for v in geom]
-        K, P = g[0] * g[7] * g[8] * g[9], g[4] * g[5] * g[6]
-        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B),
-                         lambda: self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), self.stream(Y)))
+    def conv3d_splitk(self, B, Cout, geom, wgrad):
+        return int(self.c.segx_conv3d_splitk(B, Cout, self._geom(geom), 1 if wgrad else 0))
+
+    def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None):
+        self._chk_t(X, W, Y, ws)
+        P = geom[4] * geom[5] * geom[6]; K = geom[0] * geom[7] * geom[8] * geom[9]
+        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk),
+                         lambda: self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))
         self.check(rc, 'segx_conv3d_fwd')
 
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
@@ -343,7 +345,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_conv3d_fwd': 'pppiipp', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
+    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',

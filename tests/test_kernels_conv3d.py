@@ -51,6 +51,23 @@ def test_maxpool3d_same(backend, size, k, stride):
     close(x.grad, xr.grad, 1e-6)
 
 
+@pytest.mark.parametrize('Cout,k', [(40, (3, 3, 3)), (130, (1, 3, 3)), (8, (7, 7, 7))])
+def test_conv3d_forward_split_k(backend, Cout, k):
+    """Forward with the contraction split over 3 slabs (the low-resolution Inception stages) == un-split result; both the
+    whole-window tap mask (<= 32 taps) and the per-axis masks (7x7x7) are exercised, Cout on both tile shapes."""
+    L = backend.L
+    B, Cin, size = 2, 6, (5, 6, 7)
+    x = rnd(B, Cin, *size, seed=21); w = rnd(Cout, Cin, *k, seed=22) * 0.2
+    pads = SF._same_pads(size, k, (1, 1, 1))
+    geom = (Cin,) + size + size + k + (1, 1, 1) + tuple(p[0] for p in pads)
+    y1 = torch.full((B, Cout) + size, float('nan')); y3 = torch.full((B, Cout) + size, float('nan'))
+    L.conv3d_fwd(x, w, y1, B, Cout, geom)
+    L.conv3d_fwd(x, w, y3, B, Cout, geom, 3, torch.empty(3 * y3.numel()))
+    close(y1, _ref_conv(x, w, (1, 1, 1)))
+    close(y3, y1, 1e-5)
+    assert L.conv3d_splitk(B, Cout, geom, False) >= 1 and L.conv3d_splitk(4, 192, (832, 3, 14, 14, 3, 14, 14, 3, 3, 3, 1, 1, 1, 1, 1, 1), False) > 1
+
+
 def test_stem_conv2d_on_implicit_gemm(backend):
     """EfficientNet stem: dense 3x3, 3 -> 48 channels, stride 1, static pad (1,1,1,1); input needs no gradient."""
     x = rnd(2, 3, 20, 24, seed=6)
