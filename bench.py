@@ -135,10 +135,13 @@ def main():
 
     # roofline of the dominant kernel family (the fp32-MFMA tile engine of gemm_core.h: dense GEMM in all layouts and the
     # implicit-GEMM convolutions): algorithmic FLOPs of every launch / its HIP-event time on the launch stream
-    traffic = None
-    tfile = os.path.join(ROOT, 'profiles', 'r01_e_pmc_gemm_traffic.json')
-    if args.config == 'cfg2' and os.path.exists(tfile):      # PMC passes cannot run inside the timed bench: read the committed result
-        traffic = round(json.load(open(tfile))['traffic_bytes_per_launch'])
+    traffic = tnote = None
+    tfile = os.path.join(ROOT, 'profiles', 'pmc_engine_traffic.json')
+    if os.path.exists(tfile):      # PMC passes cannot run inside the timed bench: read the committed result of the same workload
+        tj = json.load(open(tfile)).get(args.config)
+        if tj:
+            traffic = round(tj['traffic_bytes_per_launch'])
+            tnote = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/' + tj['file']
     alg_bytes = 0.0
     for pr in prof:
         shp = pr[3]
@@ -154,7 +157,7 @@ def main():
     roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
             'achieved': round(achieved, 2),
             'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-            'traffic_note': 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/r01_e_pmc_gemm_traffic.json' if traffic else None,
+            'traffic_note': tnote,
             'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
             'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
             'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}
