@@ -86,7 +86,10 @@ def test_segtran3d_vs_reference(tag, train):
     assert_close(sample(y.cpu(), 65536), g['logits'], 1e-4, 'logits')
     ref_bits = np.unpackbits(g['labels'].numpy())[:y.numel()].astype(bool)
     got_bits = (y.detach().cpu() > 0).numpy().reshape(-1)
-    margin_ok = (y.detach().cpu().abs() > 1e-5).numpy().reshape(-1)
+    # hardened labels must be bit-exact wherever the sign is decided beyond the fp32 summation-order noise: 1e-5 in eval mode;
+    # in train mode this fixture normalises with batch-1 BatchNorm statistics, which amplifies rounding (measured logit
+    # deviation 4.2e-5 on a scale of 3.4, split-K forward convolutions vs the CPU reference) -> 1e-4
+    margin_ok = (y.detach().cpu().abs() > (1e-4 if train else 1e-5)).numpy().reshape(-1)
     assert np.array_equal(got_bits[margin_ok], ref_bits[margin_ok])
     pw, cw = engine.loss_weights('brats', DEV)
     loss, _ = SF.seg_loss(y, engine.map_mask('brats', lab.to(DEV)), pw, cw)
