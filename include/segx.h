@@ -240,6 +240,25 @@ int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, i
 int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t planes, const int* geom, void* stream);
 int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sliding-window evaluation path (infer.hip)
+ * ------------------------------------------------------------------------------------------- */
+/* One window of test_single_batch (test_util2d.py:189-214) / test_single_case (test_util3d.py:151-166) after the network call:
+ *   acc[b][c][window] += sigmoid(F.interpolate(scores[b][c], size=window, align_corners=False));  cnt[b][window] += 1
+ * scores [B, C, d, h, w]; acc [B, C, CD, CH, CW]; cnt [B, CD, CH, CW];
+ * geom (int32[12]) = {d, h, w, D, H, W (window), CD, CH, CW (canvas), oz, oy, ox (window origin)}; 2-D: d = D = CD = 1, oz = 0 */
+int segx_window_accum(const float* scores, float* acc, float* cnt, int B, int C, const int* geom, void* stream);
+/* soft = acc / cnt (cnt NULL: soft = acc), then
+ *   mode 0: harden_segmap2d/3d (datasets2d.py:178-196, datasets3d.py:92-111): hard[c>=1] = soft[c] >= T, hard[0] = no other class on
+ *   mode 1: make_brats_pred_consistent(is_conservative=False) (datasets3d.py:43-63) first, C == 4 (test_util3d.py:169-174)
+ * acc/soft/hard [B, C, S] (hard as 0/1 floats), cnt [B, S]; soft may be NULL */
+int segx_harden_segmap(const float* acc, const float* cnt, float* soft, float* hard, int B, int C, int64_t S, int mode, float T,
+                       void* stream);
+/* calc_dice sums (test_util2d.py:233-240) per plane: part [chunks][planes][3] = {sum pred*gt, sum pred^2, sum gt^2},
+ * chunks*planes*3 = segx_dice_ws_floats(planes, S); reduce over chunks with segx_colsum */
+int64_t segx_dice_ws_floats(int64_t planes, int64_t S);
+int segx_dice_sums(const float* pred, const float* gt, float* part, int64_t planes, int64_t S, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -458,3 +458,118 @@ def bertadam_step(params, grads, state, lr, weight_decays, warmup, t_total, b1=0
         lr_s = lr * warmup_linear(st['step'] / t_total, warmup) if t_total != -1 else lr
         p.add_(-lr_s * upd)
         st['step'] += 1
+
+
+# ----------------------------------------------------------------------------------------
+# Evaluation path                     test_util2d.py, test_util3d.py
+# ----------------------------------------------------------------------------------------
+def harden_segmap_nd(mask_soft, batched, T=0.5):
+    """harden_segmap2d / harden_segmap3d (datasets2d.py:178-196, datasets3d.py:92-111)."""
+    hard = (mask_soft >= T).int()
+    if batched:
+        hard[:, 0] = (hard[:, 1:].sum(dim=1) == 0)
+    else:
+        hard[0] = (hard[1:].sum(dim=0) == 0)
+    return hard
+
+
+def make_brats_pred_consistent(preds_soft, is_conservative):
+    """datasets3d.py:43-63; preds_soft [4, ...] = (bg, ET, WT, TC)."""
+    out = preds_soft.clone()
+    if is_conservative:
+        out[1] = torch.min(preds_soft[1:], dim=0)[0]
+        out[3] = torch.min(preds_soft[2:], dim=0)[0]
+    else:
+        out[2] = torch.max(preds_soft[1:], dim=0)[0]
+        out[3] = torch.max(preds_soft[[1, 3]], dim=0)[0]
+    return out
+
+
+def brats_inv_map_label(orig_probs):
+    """datasets3d.py:65-90."""
+    inv = torch.zeros_like(orig_probs)
+    inv[0] = 1 - orig_probs[2]
+    inv[3] = orig_probs[1]
+    inv[1] = (orig_probs[3] - orig_probs[1]) * 1.5
+    inv[2] = (orig_probs[2] - orig_probs[3]) * 1.5
+    return inv
+
+
+def test_single_batch(net_fn, image_batch, orig_input_size, patch_size, stride, num_classes):
+    """test_util2d.py:153-227 for model_type 'segtran': zero-pad to the window size, slide, resize window -> patch, net,
+    resize scores -> window, sigmoid, average over the overlap count, harden."""
+    B, C, H, W = image_batch.shape
+    dx, dy = orig_input_size
+    h_pad, w_pad = max(dx - H, 0), max(dy - W, 0)
+    hl, wl = h_pad // 2, w_pad // 2
+    if h_pad or w_pad:
+        image_batch = F.pad(image_batch, (wl, w_pad - wl, hl, h_pad - hl))                  # :174-176
+    H2, W2 = image_batch.shape[2:]
+    sx = math.ceil((H2 - dx) / stride[0]) + 1                                               # :180-181
+    sy = math.ceil((W2 - dy) / stride[1]) + 1
+    soft = torch.zeros(B, num_classes, H2, W2); cnt = torch.zeros(B, H2, W2)
+    for x in range(sx):
+        xs = min(stride[0] * x, H2 - dx)
+        for y in range(sy):
+            ys = min(stride[1] * y, W2 - dy)
+            patch = F.interpolate(image_batch[:, :, xs:xs + dx, ys:ys + dy], size=patch_size, mode='bilinear', align_corners=False)
+            with torch.no_grad():
+                scores = net_fn(patch)
+            scores = F.interpolate(scores, size=orig_input_size, mode='bilinear', align_corners=False)   # :209-210
+            soft[:, :, xs:xs + dx, ys:ys + dy] += torch.sigmoid(scores)                     # :212-214
+            cnt[:, xs:xs + dx, ys:ys + dy] += 1
+    soft = soft / cnt.unsqueeze(1)                                                           # :216
+    hard = harden_segmap_nd(soft, True)
+    if h_pad or w_pad:
+        hard = hard[:, :, hl:hl + H, wl:wl + W]; soft = soft[:, :, hl:hl + H, wl:wl + W]
+    return hard, soft
+
+
+def test_single_case(net_fn, image, orig_patch_size, input_patch_size, batch_size, stride_xy, stride_z, num_classes=4):
+    """test_util3d.py:93-184, task 'brats', net_type 'segtran'."""
+    C, H, W, D = image.shape
+    dx, dy, dz = orig_patch_size
+    pads = [max(dx - H, 0), max(dy - W, 0), max(dz - D, 0)]
+    lp = [p // 2 for p in pads]
+    if any(pads):
+        # N9: the reference's F.pad tuple (0, 0, dl, dr, wl, wr, hl, hr) on a [C,H,W,D] tensor pads D by nothing, W by the D pads,
+        # H by the W pads and the CHANNEL dim by the H pads (:118-120) -- a volume smaller than the patch cannot run there.
+        raise NotImplementedError('reference pads the wrong dims for volumes smaller than the patch (N9); no oracle for that case')
+    _, H2, W2, D2 = image.shape
+    sx = math.ceil((H2 - dx) / stride_xy) + 1
+    sy = math.ceil((W2 - dy) / stride_xy) + 1
+    sz = math.ceil((D2 - dz) / stride_z) + 1
+    soft = torch.zeros((num_classes,) + tuple(image.shape[1:])); cnt = torch.zeros_like(image[0])
+    for x in range(sx):
+        xs = min(stride_xy * x, H2 - dx)
+        yzs, patches = [], []
+        for y in range(sy):
+            ys = min(stride_xy * y, W2 - dy)
+            for z in range(sz):
+                zs = min(stride_z * z, D2 - dz)
+                patches.append(image[:, xs:xs + dx, ys:ys + dy, zs:zs + dz]); yzs.append((ys, zs))
+                if len(patches) == batch_size or (y == sy - 1 and z == sz - 1):
+                    tb = F.interpolate(torch.stack(patches, 0), size=input_patch_size, mode='trilinear', align_corners=False)
+                    with torch.no_grad():
+                        sc = net_fn(tb)
+                    pr = torch.sigmoid(F.interpolate(sc, size=orig_patch_size, mode='trilinear', align_corners=False))
+                    for i, (ys_i, zs_i) in enumerate(yzs):
+                        soft[:, xs:xs + dx, ys_i:ys_i + dy, zs_i:zs_i + dz] += pr[i]
+                        cnt[xs:xs + dx, ys_i:ys_i + dy, zs_i:zs_i + dz] += 1
+                    patches, yzs = [], []
+    soft = soft / cnt.unsqueeze(0)
+    soft = make_brats_pred_consistent(soft, False)                                           # :168-170
+    hard = torch.zeros_like(soft)
+    hard[1:] = (soft[1:] >= 0.5)
+    hard[0] = (hard[1:].sum(dim=0) == 0)
+    if any(pads):
+        sl = (slice(None), slice(lp[0], lp[0] + H), slice(lp[1], lp[1] + W), slice(lp[2], lp[2] + D))
+        hard, soft = hard[sl].clone(), soft[sl].clone()
+    return hard, soft
+
+
+def calc_dice(predictions, gt_mask):
+    """test_util2d.py:233-240."""
+    gt = gt_mask.float(); pr = predictions.float()
+    inter = torch.sum(pr * gt, dim=(-1, -2)); y = torch.sum(gt * gt, dim=(-1, -2)); z = torch.sum(pr * pr, dim=(-1, -2))
+    return (2 * inter + 1e-5) / (z + y + 1e-5)

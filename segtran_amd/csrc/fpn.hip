@@ -1,7 +1,7 @@
 // fpn.hip -- HBM-bound kernels of the input / output feature pyramids (K16-K18): GroupNorm(8) forward/backward
 // and (bi/tri)linear resampling with align_corners=False, with the FPN's "lateral + upsampled" addition fused
 // into the resampling pass.  Tensors are NC[D]HW fp32; a (sample, channel) plane is contiguous.
-#include "common.h"
+#include "resample.h"
 
 namespace segx {
 
@@ -87,16 +87,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dY
 //   src = max(scale * (d + 0.5) - 0.5, 0),  scale = n_in / n_out (float);  i0 = floor(src), i1 = min(i0+1, n_in-1), l = src - i0
 // 2-D tensors use d = D = 1.  Forward optionally adds a base tensor (the FPN lateral) in the same pass.
 // =================================================================================================
-struct Axis { int i0, i1; float l; };
-__device__ __forceinline__ Axis axis_src(int d, int n_in, float scale) {
-    float src = scale * ((float)d + 0.5f) - 0.5f;
-    src = src < 0.f ? 0.f : src;
-    Axis a; a.i0 = (int)src; if (a.i0 > n_in - 1) a.i0 = n_in - 1;
-    a.i1 = a.i0 + (a.i0 < n_in - 1 ? 1 : 0); a.l = src - (float)a.i0;
-    return a;
-}
-struct InterpDims { int d, h, w, D, H, W; float sd, sh, sw; };
-
 __global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
                                                          InterpDims q, int64_t planes) {
     const int64_t osz = (int64_t)q.D * q.H * q.W, isz = (int64_t)q.d * q.h * q.w, total = planes * osz;
@@ -104,14 +94,7 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict
         const int64_t p = idx / osz; int64_t r = idx - p * osz;
         const int z = (int)(r / ((int64_t)q.H * q.W)); r -= (int64_t)z * q.H * q.W;
         const int y = (int)(r / q.W), x = (int)(r - (int64_t)y * q.W);
-        const Axis az = axis_src(z, q.d, q.sd), ay = axis_src(y, q.h, q.sh), ax = axis_src(x, q.w, q.sw);
-        const float* s = in + p * isz;
-        auto at = [&](int zz, int yy, int xx) { return s[((int64_t)zz * q.h + yy) * q.w + xx]; };
-        const float c00 = at(az.i0, ay.i0, ax.i0) * (1.f - ax.l) + at(az.i0, ay.i0, ax.i1) * ax.l;
-        const float c01 = at(az.i0, ay.i1, ax.i0) * (1.f - ax.l) + at(az.i0, ay.i1, ax.i1) * ax.l;
-        const float c10 = at(az.i1, ay.i0, ax.i0) * (1.f - ax.l) + at(az.i1, ay.i0, ax.i1) * ax.l;
-        const float c11 = at(az.i1, ay.i1, ax.i0) * (1.f - ax.l) + at(az.i1, ay.i1, ax.i1) * ax.l;
-        float v = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
+        float v = interp_at(in + p * isz, q, z, y, x);
         if (base) v += base[idx];
         out[idx] = v;
     }
@@ -194,11 +177,6 @@ extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* 
     hipLaunchKernelGGL(gn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)psum, w, gsum, dw, db, B, C, G);
     hipLaunchKernelGGL(gn_bwd_apply, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, rstd, w, (const float*)gsum, dX, C, G, S);
     return check_launch("segx_groupnorm_bwd");
-}
-static InterpDims make_dims(int d, int h, int w, int D, int H, int W) {
-    InterpDims q; q.d = d; q.h = h; q.w = w; q.D = D; q.H = H; q.W = W;
-    q.sd = (float)d / (float)D; q.sh = (float)h / (float)H; q.sw = (float)w / (float)W;
-    return q;
 }
 extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                                       void* stream_) {

@@ -22,8 +22,12 @@ def polyp_map_mask(mask, exclusive=True):
     return out
 
 
-def harden_segmap2d(probs, T=0.5):
-    """reference datasets2d.py:178-196: per-class threshold; background = none of the others."""
-    hard = (probs >= T).to(probs.dtype)
-    hard[:, 0] = (hard[:, 1:].sum(dim=1) == 0).to(probs.dtype)
-    return hard
+def harden_segmap2d(mask_soft, T=0.5):
+    """reference datasets2d.py:178-196: per-class threshold; background = none of the others.  (batch, channel, h, w) or
+    (channel, h, w) -> int32 0/1 maps (segx_harden_segmap)."""
+    from .. import functional as SF
+    batched = mask_soft.dim() == 4
+    x = mask_soft if batched else mask_soft.unsqueeze(0)
+    _, hard = SF.harden_segmap(x.float().contiguous(), None, mode=0, T=T, want_soft=False)
+    hard = hard.to(torch.int32)
+    return hard if batched else hard[0]

@@ -848,3 +848,43 @@ def label_nhot(labels, mode):
         out = torch.empty((B, 3 if m == 0 else 2) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
         L.label_nhot(lab, out, B, Cin, S, m)
     return out
+
+
+# -------------------------------------------------------------------------------------------------
+# Evaluation path (infer.hip): no autograd, everything under torch.no_grad()
+# -------------------------------------------------------------------------------------------------
+def window_accum(scores, acc, cnt, origin):
+    """acc[:, :, window] += sigmoid(resample(scores -> window)); cnt[:, window] += 1.  scores [B,C,*s], acc [B,C,*canvas], cnt [B,*canvas];
+    the window has the size given by `origin = (start..., size...)`: 2-D (y0, x0, H, W), 3-D (z0, y0, x0, D, H, W)."""
+    L = segx.lib()
+    scores = _c(scores.detach())
+    nd = scores.dim() - 2
+    B, C = scores.shape[:2]
+    s3 = (1,) * (3 - nd) + tuple(scores.shape[2:])
+    o3 = (0,) * (3 - nd) + tuple(origin[:nd]); w3 = (1,) * (3 - nd) + tuple(origin[nd:])
+    c3 = (1,) * (3 - nd) + tuple(acc.shape[2:])
+    assert acc.is_contiguous() and cnt.is_contiguous() and acc.shape[:2] == (B, C) and tuple(cnt.shape) == (B,) + tuple(acc.shape[2:])
+    L.window_accum(scores, acc, cnt, B, C, s3 + w3 + c3 + o3)
+
+
+def harden_segmap(acc, cnt=None, mode=0, T=0.5, want_soft=True):
+    """(soft, hard): soft = acc / cnt (or acc), hard = n-hot 0/1 floats with the background consistency rule; mode 1 = BraTS."""
+    L = segx.lib()
+    acc = _c(acc.detach())
+    B, C = acc.shape[:2]
+    S = acc.numel() // (B * C)
+    hard = torch.empty_like(acc)
+    soft = torch.empty_like(acc) if want_soft else None
+    L.harden_segmap(acc, _c(cnt) if cnt is not None else None, soft, hard, B, C, S, mode, T)
+    return soft, hard
+
+
+def dice_scores(pred, gt, smooth=1e-5):
+    """calc_dice (test_util2d.py:233-240) for every leading plane of pred/gt [..., *spatial] given as [P, S]-viewable tensors:
+    (2 sum(p g) + s) / (sum p^2 + sum g^2 + s).  Returns a [P] tensor."""
+    L = segx.lib()
+    pred, gt = _c(pred.detach().float()), _c(gt.detach().float())
+    P = pred.shape[0]
+    S = pred.numel() // P
+    sums = L.dice_sums(pred, gt, P, S)
+    return (2 * sums[:, 0] + smooth) / (sums[:, 1] + sums[:, 2] + smooth)

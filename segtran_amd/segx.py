@@ -274,6 +274,25 @@ class SegxLib:
             return rc
         return fn()
 
+    # ---- evaluation path (infer.hip) --------------------------------------------------------------
+    def window_accum(self, scores, acc, cnt, B, C, geom):
+        self._chk_t(scores, acc, cnt)
+        g = (c_i * 12)(*[int(v) for v in geom])
+        self.check(self.c.segx_window_accum(_ptr(scores), _ptr(acc), _ptr(cnt), B, C, g, self.stream(acc)), 'segx_window_accum')
+
+    def harden_segmap(self, acc, cnt, soft, hard, B, C, S, mode, T=0.5):
+        self._call('segx_harden_segmap', hard, acc, cnt, soft, hard, B, C, S, mode, T)
+
+    def dice_sums(self, pred, gt, planes, S):
+        n = int(self.c.segx_dice_ws_floats(planes, S))
+        part = torch.empty(n, dtype=torch.float32, device=pred.device)
+        self._call('segx_dice_sums', pred, pred, gt, part, planes, S)
+        chunks = n // (3 * planes)
+        out = torch.empty(planes * 3, dtype=torch.float32, device=pred.device)
+        ws = torch.empty(self.colreduce_ws(chunks, planes * 3, 1), dtype=torch.float32, device=pred.device)
+        self.colsum(part, out, ws, chunks, planes * 3)
+        return out.view(planes, 3)
+
     def conv3d_splitk(self, B, Cout, geom, wgrad):
         return int(self.c.segx_conv3d_splitk(B, Cout, self._geom(geom), 1 if wgrad else 0))
 
@@ -345,6 +364,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
+    'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

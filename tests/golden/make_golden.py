@@ -376,6 +376,69 @@ def case_seg3d():
         save(tag, **arrs)
 
 
+def _ref_functions(relpath, names, extra=None):
+    """exec only the named top-level functions of a reference file (its module imports cv2 / imgaug / medpy, which this image
+    lacks) in a namespace with torch on the CPU; the reference file itself is untouched."""
+    import ast, math
+    src = open(os.path.join('/root/reference/code', relpath)).read()
+    tree = ast.parse(src)
+    ns = dict(torch=R.cpu_torch(), np=np, F=torch.nn.functional, math=math)
+    ns.update(extra or {})
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            exec(compile(ast.Module([node], []), relpath, 'exec'), ns)
+    return ns
+
+
+def case_eval():
+    """sliding-window evaluation.  2-D: reference test_single_batch driving the reference Segtran2d (eval mode,
+    64x64 patches) over (a) an image larger than the window with overlapping strides, (b) an image smaller than the window (zero
+    padding) whose windows are resized 96 -> 64 for the network and back.  3-D: reference test_single_case on Segtran3d."""
+    d2 = _ref_functions('dataloaders/datasets2d.py', ['harden_segmap2d'])
+    t2 = _ref_functions('test_util2d.py', ['test_single_batch', 'calc_dice'], dict(harden_segmap2d=d2['harden_segmap2d']))
+    net = R.ref_segtran2d(num_attractors=32, num_translayers=1, compress=(1, 1), dropout_prob=0)
+    sd = load_synth(net); net.eval()
+    dims = [1792, 1792]
+    g = torch.Generator().manual_seed(31)
+    arrs = {}
+    for tag, (shape, orig, patch, stride) in {'a': ((2, 3, 80, 96), (64, 64), (64, 64), (32, 48)),
+                                              'b': ((1, 3, 80, 100), (96, 96), (64, 64), (96, 96))}.items():
+        x = torch.randn(*shape, generator=g)
+        hard, soft = R.quiet(t2['test_single_batch'], net, x, orig, patch, stride, 'fundus', 3, 'segtran')
+        oh, osf = O.test_single_batch(lambda p: O.segtran2d_forward(sd, p, dims), x, orig, patch, stride, 3)
+        close(osf, soft, 1e-5, 'eval2d soft ' + tag)
+        safe = (soft - 0.5).abs() > 1e-5
+        assert torch.equal(oh[:, 1:][safe[:, 1:]], hard[:, 1:][safe[:, 1:]])
+        arrs.update({'x_' + tag: x, 'soft_' + tag: soft, 'hard_' + tag: hard.to(torch.uint8),
+                     'cfg_' + tag: np.array(list(orig) + list(patch) + list(stride))})
+    gt = (torch.rand(2, 3, 80, 96, generator=g) > 0.5).float()
+    arrs['gt'] = gt.to(torch.uint8)
+    arrs['dice'] = torch.stack([t2['calc_dice'](arrs['hard_a'][:, c].float(), gt[:, c]) for c in range(3)], dim=1)
+    assert torch.allclose(arrs['dice'], torch.stack([O.calc_dice(arrs['hard_a'][:, c].float(), gt[:, c]) for c in range(3)], dim=1))
+    arrs['A'] = np.array(32)
+    save('eval2d', **arrs)
+
+    d3 = _ref_functions('dataloaders/datasets3d.py', ['make_brats_pred_consistent', 'brats_inv_map_label', 'harden_segmap3d'])
+    t3 = _ref_functions('test_util3d.py', ['test_single_case'], d3)
+    net3 = R.ref_segtran3d(num_attractors=32, dropout_prob=0)
+    sd3 = load_synth(net3); net3.eval()
+    vol = synth_brats(1, 112, 168, 16, 1441)[0][0]                   # [4, 112, 168, 16]: two overlapping windows along W
+    hard3, soft3 = R.quiet(t3['test_single_case'], net3, vol, (112, 112, 16), (112, 112, 16), 2, 56, 16, 'brats', 'segtran', 4)
+    oh3, os3 = O.test_single_case(lambda p: O.segtran3d_forward(sd3, p, [1024, 1024]), vol, (112, 112, 16), (112, 112, 16), 2, 56, 16)
+    close(os3, soft3, 1e-5, 'eval3d soft')
+    safe = (soft3 - 0.5).abs() > 1e-5
+    assert torch.equal(oh3[1:][safe[1:]], hard3[1:][safe[1:]])
+    p = torch.rand(4, 5, 6, 7, generator=g)
+    cons = {k: d3['make_brats_pred_consistent'](p, k) for k in (True, False)}
+    assert all(torch.equal(cons[k], O.make_brats_pred_consistent(p, k)) for k in cons)
+    pc = cons[False].clone(); pc[1] = torch.minimum(pc[1], pc[3]); pc[3] = torch.minimum(pc[3], pc[2])     # ET <= TC <= WT: no negative
+    inv = d3['brats_inv_map_label'](pc)
+    assert torch.equal(inv, O.brats_inv_map_label(pc))
+    save('eval3d', soft=sample(soft3, 65536), hard=torch.from_numpy(np.packbits(hard3.numpy().astype(bool))), seed=np.array(1441),
+         probs=p, cons_true=cons[True], cons_false=cons[False], inv_in=pc, inv=inv, harden3d=d3['harden_segmap3d'](p).to(torch.uint8),
+         A=np.array(32))
+
+
 def case_loss():
     """train2d.py:1219-1242,1314-1318 composed from the reference's own dice_loss_indiv + torch BCE."""
     dice_ref = R.ref_dice()
@@ -477,7 +540,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, eval=case_eval, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 

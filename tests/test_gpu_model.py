@@ -167,3 +167,41 @@ def test_gemm_fullsize_properties():
     ref = A @ W.t()
     assert_close(C1, ref, 2e-5, 'vs rocBLAS')
     assert_close(C12, C1 + C2, 2e-5, 'linearity')
+
+
+def test_eval_path_2d_vs_reference():
+    """product sliding-window inference (HIP net + infer.hip) vs the reference's test_single_batch fixture."""
+    from segtran_amd import test_util2d as T2
+    g = golden('eval2d')
+    net = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(64, 64)), DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.eval()
+    for tag in 'ab':
+        cfg = [int(v) for v in g['cfg_' + tag]]
+        hard, soft = T2.test_single_batch(net, g['x_' + tag].to(DEV), tuple(cfg[0:2]), tuple(cfg[2:4]), tuple(cfg[4:6]), 'fundus', 3)
+        assert hard.dtype == torch.int32 and hard.shape == g['hard_' + tag].shape
+        assert_close(soft.cpu(), g['soft_' + tag], 1e-5, 'soft ' + tag)
+        safe = (g['soft_' + tag] - 0.5).abs() > 1e-5
+        assert torch.equal(hard.cpu()[safe], g['hard_' + tag].int()[safe]), 'hardened label map differs'
+    m = T2.calc_batch_metric([g['hard_a'][i].float().to(DEV) for i in range(2)], [g['gt'][i].float().to(DEV) for i in range(2)], 3)
+    assert_close(torch.from_numpy(m).float(), g['dice'][:, 1:], 1e-6, 'dice')
+
+
+def test_eval_path_3d_vs_reference():
+    from segtran_amd import test_util3d as T3
+    from segtran_amd.dataloaders import datasets3d as D3
+    g = golden('eval3d')
+    net = engine.build_model(dict(engine.CONFIGS['cfg4'], size=(112, 112, 16)), DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.eval()
+    vol = synth_brats(1, 112, 168, 16, int(g['seed']))[0][0].to(DEV)
+    hard, soft = T3.test_single_case(net, vol, (112, 112, 16), (112, 112, 16), 2, 56, 16, 'brats')
+    assert_close(sample(soft.cpu(), 65536), g['soft'], 1e-5, 'soft')
+    ref_bits = np.unpackbits(g['hard'].numpy())[:hard.numel()].astype(bool).reshape(hard.shape)
+    safe = ((soft.cpu() - 0.5).abs() > 1e-5).numpy()
+    assert np.array_equal((hard.cpu().numpy() > 0)[safe], ref_bits[safe]), 'hardened label map differs'
+    metric, valid = T3.calculate_metric_percase(hard, hard, 4)
+    assert np.allclose(metric[valid[:, 0] > 0, 0][hard[1:].reshape(3, -1).sum(1).cpu().numpy() > 0], 1.0)
+    p = g['probs'].to(DEV)
+    for k in (True, False):
+        assert torch.equal(D3.make_brats_pred_consistent(p, k).cpu(), g['cons_true' if k else 'cons_false'])
+    assert torch.equal(D3.brats_inv_map_label(g['inv_in'].to(DEV)).cpu(), g['inv'])
+    assert torch.equal(D3.harden_segmap3d(p).cpu(), g['harden3d'].int())

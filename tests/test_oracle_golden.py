@@ -242,3 +242,33 @@ def test_fullsize_hash(cfg):
         # hash differs only if some |logit| is below fp32 re-association noise
         flips = int(((y.abs() < 1e-5)).sum())
         assert flips > 0, 'label map differs although no logit is near 0'
+
+
+def test_eval_path_2d():
+    """oracle sliding-window inference == reference test_single_batch (fixture from the real reference)."""
+    g = golden('eval2d')
+    net = engine_model_shapes('cfg1', int(g['A']))
+    sd = synth_state_dict(net)
+    for tag in 'ab':
+        cfg = [int(v) for v in g['cfg_' + tag]]
+        hard, soft = O.test_single_batch(lambda p: O.segtran2d_forward(sd, p, [1792, 1792]), g['x_' + tag], tuple(cfg[0:2]),
+                                         tuple(cfg[2:4]), tuple(cfg[4:6]), 3)
+        assert_close(soft, g['soft_' + tag], 1e-5, 'soft ' + tag)
+        safe = (g['soft_' + tag] - 0.5).abs() > 1e-5
+        assert torch.equal(hard[:, 1:][safe[:, 1:]], g['hard_' + tag].int()[:, 1:][safe[:, 1:]])
+    d = torch.stack([O.calc_dice(g['hard_a'][:, c].float(), g['gt'][:, c].float()) for c in range(3)], dim=1)
+    assert_close(d, g['dice'], 1e-6, 'dice')
+
+
+def test_eval_path_3d_pieces():
+    g = golden('eval3d')
+    for k in (True, False):
+        assert torch.equal(O.make_brats_pred_consistent(g['probs'], k), g['cons_true' if k else 'cons_false'])
+    assert torch.equal(O.brats_inv_map_label(g['inv_in']), g['inv'])
+    assert torch.equal(O.harden_segmap_nd(g['probs'], False), g['harden3d'].int())
+
+
+def engine_model_shapes(cfg, A):
+    from segtran_amd import engine
+    net = engine.build_model(dict(engine.CONFIGS[cfg], size=(64, 64)), 'cpu', dropout_prob=0.0, attractors=A, synth=False)
+    return {k: tuple(v.shape) for k, v in net.state_dict().items()}

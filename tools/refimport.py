@@ -58,6 +58,20 @@ def ref_segtran2d(num_classes=3, num_attractors=256, num_translayers=3, compress
     return quiet(build)
 
 
+def cpu_torch():
+    """`torch` stand-in for exec-ing reference functions that hard-code device='cuda' (test_util2d.py:184, test_util3d.py:130):
+    factory calls are redirected to the CPU, everything else is the real module."""
+    class _T:
+        def __getattr__(s, k): return getattr(torch, k)
+        def _cpu(s, fn, *a, **kw):
+            if kw.get('device') == 'cuda': kw['device'] = 'cpu'
+            return fn(*a, **kw)
+        def tensor(s, *a, **kw): return s._cpu(torch.tensor, *a, **kw)
+        def zeros(s, *a, **kw): return s._cpu(torch.zeros, *a, **kw)
+        def ones(s, *a, **kw): return s._cpu(torch.ones, *a, **kw)
+    return _T()
+
+
 def ref_segtran3d(num_classes=4, num_attractors=1024, num_translayers=1, compress=(1, 1), **over):
     _install_stubs()
     import networks.segtran3d as s3
