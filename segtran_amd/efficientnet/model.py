@@ -142,9 +142,14 @@ class EfficientNet(nn.Module):
         return cls(model_name, stem_stride=stem_stride, **kw)
 
     @classmethod
-    def from_pretrained(cls, model_name, stem_stride=2, **kw):
-        raise RuntimeError('pretrained EfficientNet weights need network access; load a checkpoint with '
-                           'load_state_dict() or use segtran_amd.synth.load_synth()')
+    def from_pretrained(cls, model_name, weights_path=None, advprop=False, ignore_missing_keys=False, stem_stride=2, **kw):
+        """reference efficientnet/model.py:357-398: build the model, then load the published lukemelas checkpoint.  There is no
+        network here, so the file must already be on disk: `weights_path`, or `<$SEGX_PRETRAINED_DIR>/<published file name>`
+        (efficientnet/utils.py:570-596: e.g. adv-efficientnet-b4-44fb3a87.pth for advprop b4)."""
+        model = cls.from_name(model_name, stem_stride=stem_stride, **kw)
+        load_pretrained_weights(model, model_name, weights_path=weights_path, load_fc=True, advprop=advprop,
+                                ignore_missing_keys=ignore_missing_keys)
+        return model
 
     def extract_endpoints(self, inputs):
         endpoints = {}
@@ -160,3 +165,39 @@ class EfficientNet(nn.Module):
         x = SF.bn_act(self._conv_head(x), self._bn1, SF.ACT_SWISH)
         endpoints['reduction_%d' % (len(endpoints) + 1)] = x
         return endpoints
+
+
+# published checkpoint file names (reference efficientnet/utils.py:570-596)
+PRETRAINED_FILES = {False: {'efficientnet-b0': 'efficientnet-b0-355c32eb.pth', 'efficientnet-b1': 'efficientnet-b1-f1951068.pth',
+                            'efficientnet-b2': 'efficientnet-b2-8bb594d6.pth', 'efficientnet-b3': 'efficientnet-b3-5fb5a3c3.pth',
+                            'efficientnet-b4': 'efficientnet-b4-6ed6700e.pth', 'efficientnet-b5': 'efficientnet-b5-b6417697.pth',
+                            'efficientnet-b6': 'efficientnet-b6-c76e70fd.pth', 'efficientnet-b7': 'efficientnet-b7-dcc49843.pth'},
+                    True: {'efficientnet-b0': 'adv-efficientnet-b0-b64d5a18.pth', 'efficientnet-b1': 'adv-efficientnet-b1-0f3ce85a.pth',
+                           'efficientnet-b2': 'adv-efficientnet-b2-6e9d97e5.pth', 'efficientnet-b3': 'adv-efficientnet-b3-cdd7c0f4.pth',
+                           'efficientnet-b4': 'adv-efficientnet-b4-44fb3a87.pth', 'efficientnet-b5': 'adv-efficientnet-b5-86493f6b.pth',
+                           'efficientnet-b6': 'adv-efficientnet-b6-ac80338e.pth', 'efficientnet-b7': 'adv-efficientnet-b7-4652b6dd.pth',
+                           'efficientnet-b8': 'adv-efficientnet-b8-22a8fe65.pth'}}
+
+
+def pretrained_path(model_name, advprop=False):
+    import os
+    d = os.environ.get('SEGX_PRETRAINED_DIR')
+    if not d:
+        raise RuntimeError('pretrained %s weights: no network access here -- download %s and pass weights_path=..., or put it '
+                           'under $SEGX_PRETRAINED_DIR (or build with use_pretrained=False)' % (model_name, PRETRAINED_FILES[advprop][model_name]))
+    path = os.path.join(d, PRETRAINED_FILES[advprop][model_name])
+    if not os.path.exists(path):
+        raise RuntimeError('pretrained weights not found: ' + path)
+    return path
+
+
+def load_pretrained_weights(model, model_name, weights_path=None, load_fc=True, advprop=False, ignore_missing_keys=False):
+    """reference efficientnet/utils.py:601-636 with a local file instead of model_zoo.load_url; same key checks."""
+    state_dict = torch.load(weights_path if isinstance(weights_path, str) else pretrained_path(model_name, advprop), map_location='cpu')
+    if not load_fc:
+        state_dict.pop('_fc.weight'); state_dict.pop('_fc.bias')
+    ret = model.load_state_dict(state_dict, strict=False)
+    if not ignore_missing_keys:
+        expect = set() if load_fc else {'_fc.weight', '_fc.bias'}
+        assert set(ret.missing_keys) == expect, 'Missing keys when loading pretrained weights: %s' % ret.missing_keys
+    assert not ret.unexpected_keys, 'Unexpected keys when loading pretrained weights: %s' % ret.unexpected_keys

@@ -91,7 +91,12 @@ class Segtran2d(SegtranInitWeights):
         if not self.backbone_type.startswith('eff-'):
             raise NotImplementedError("backbone '%s': only EfficientNet-V1 (eff-b0..b7) is built" % self.backbone_type)
         stem_stride = 1 if self.bb_feat_upsize else 2
-        self.backbone = EfficientNet.from_name(self.backbone_type.replace('eff', 'efficientnet'), stem_stride=stem_stride)
+        self.use_pretrained = config.use_pretrained
+        bb_name = self.backbone_type.replace('eff', 'efficientnet')
+        if self.use_pretrained:                                 # segtran2d.py:98-101 (advprop checkpoint, local file: no network)
+            self.backbone = EfficientNet.from_pretrained(bb_name, advprop=True, ignore_missing_keys=True, stem_stride=stem_stride)
+        else:
+            self.backbone = EfficientNet.from_name(bb_name, stem_stride=stem_stride)
         self.in_fpn_layers, self.in_fpn_scheme = config.in_fpn_layers, config.in_fpn_scheme
         self.out_fpn_layers, self.out_fpn_scheme = config.out_fpn_layers, config.out_fpn_scheme
         if self.in_fpn_layers != [3, 4] or self.out_fpn_layers != [1, 2, 3, 4] or self.in_fpn_scheme != 'AN' \

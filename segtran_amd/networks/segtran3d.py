@@ -90,6 +90,18 @@ class Segtran3d(SegtranInitWeights):
         if not self.backbone_type.startswith('i3d'):
             raise NotImplementedError('Only support i3d as the 3D backbone')
         self.backbone = InceptionI3d(do_pool1=not self.bb_feat_upsize)
+        self.use_pretrained = config.use_pretrained
+        if self.use_pretrained:                                 # segtran3d.py:99-104: aj_rgb_imagenet.pth beside aj_i3d.py
+            import os
+            from .aj_i3d import aj_i3d as _aj
+            cand = [os.path.join(os.path.dirname(_aj.__file__), 'aj_rgb_imagenet.pth')]
+            if os.environ.get('SEGX_PRETRAINED_DIR'):
+                cand.append(os.path.join(os.environ['SEGX_PRETRAINED_DIR'], 'aj_rgb_imagenet.pth'))
+            path = next((c for c in cand if os.path.exists(c)), None)
+            if path is None:
+                raise RuntimeError('pretrained I3D weights (aj_rgb_imagenet.pth) not found in %s -- the reference ships it as a '
+                                   'git-lfs blob; place it there or build with use_pretrained=False' % cand)
+            self.backbone.load_state_dict(torch.load(path, map_location=torch.device('cpu')))
         self.inchan_to3_scheme, self.D_groupsize = config.inchan_to3_scheme, config.D_groupsize
         self.eff_in_channels = self.orig_in_channels * self.D_groupsize
         self.D_pool_K = config.D_pool_K

@@ -34,3 +34,32 @@ def test_invalid_inputs_raise_like_the_reference_breakpoints():
     net = engine.build_model('cfg1', 'cpu', synth=False)
     with pytest.raises(ValueError, match='divisible by 8'):
         net(torch.zeros(1, 3, 60, 64))
+
+
+def test_pretrained_backbone_ingest_from_local_files(tmp_path, monkeypatch):
+    """`use_pretrained=True` loads the published EfficientNet (lukemelas advprop) / I3D (aj_rgb_imagenet.pth)
+    state_dicts from local files (no network); wrong files fail with the reference's key checks."""
+    import torch
+    from segtran_amd import engine
+    from segtran_amd.efficientnet.model import EfficientNet, PRETRAINED_FILES
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionI3d
+    from segtran_amd.synth import synth_state_dict
+    with pytest.raises(RuntimeError, match='no network'):
+        monkeypatch.delenv('SEGX_PRETRAINED_DIR', raising=False)
+        EfficientNet.from_pretrained('efficientnet-b4', advprop=True, stem_stride=1)
+    monkeypatch.setenv('SEGX_PRETRAINED_DIR', str(tmp_path))
+    eff = EfficientNet.from_name('efficientnet-b4', stem_stride=1)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in eff.state_dict().items()})
+    torch.save(sd, str(tmp_path / PRETRAINED_FILES[True]['efficientnet-b4']))
+    i3d = InceptionI3d(do_pool1=False)
+    sd3 = synth_state_dict({k: tuple(v.shape) for k, v in i3d.state_dict().items()})
+    torch.save(sd3, str(tmp_path / 'aj_rgb_imagenet.pth'))
+    net2 = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(64, 64)), 'cpu', synth=False, use_pretrained=True)
+    # `self.apply(self.init_weights)` (segtran2d.py, as in the reference) re-initialises every nn.Linear, i.e. the unused `_fc` head
+    assert all(torch.equal(v, sd[k]) for k, v in net2.backbone.state_dict().items() if not k.startswith('_fc.'))
+    net3 = engine.build_model(dict(engine.CONFIGS['cfg4'], size=(112, 112, 16)), 'cpu', synth=False, use_pretrained=True)
+    assert all(torch.equal(v, sd3[k]) for k, v in net3.backbone.state_dict().items() if 'logits' not in k)
+    bad = dict(sd); bad['_blocks.0.bogus'] = torch.zeros(1)
+    torch.save(bad, str(tmp_path / 'bad.pth'))
+    with pytest.raises(AssertionError, match='Unexpected keys'):
+        EfficientNet.from_pretrained('efficientnet-b4', weights_path=str(tmp_path / 'bad.pth'), stem_stride=1)
