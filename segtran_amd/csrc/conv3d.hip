@@ -78,13 +78,14 @@ struct ConvFwdLoaderB {
         }
         return okmask;
     }
-    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const {
+    static constexpr bool ROWK = true;              // LDS tile [position][k] (swizzled chunks): this thread's 16 k-values of one position are 4 float4 stores
+    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float* T, int tid) const {
         const int n = tid & 127, kr = (tid >> 7) * (BKT / 2);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const unsigned mk = okmask >> (4 * i);
-            T[kr + 4 * i + 0][n] = (mk & 1u) ? r[i].x : 0.f; T[kr + 4 * i + 1][n] = (mk & 2u) ? r[i].y : 0.f;
-            T[kr + 4 * i + 2][n] = (mk & 4u) ? r[i].z : 0.f; T[kr + 4 * i + 3][n] = (mk & 8u) ? r[i].w : 0.f;
+            *reinterpret_cast<float4*>(T + rowk_off(n, (kr >> 2) + i)) =
+                make_float4((mk & 1u) ? r[i].x : 0.f, (mk & 2u) ? r[i].y : 0.f, (mk & 4u) ? r[i].z : 0.f, (mk & 8u) ? r[i].w : 0.f);
         }
     }
 };
@@ -127,11 +128,12 @@ struct ConvWgradLoaderB {
         }
         return okmask;
     }
-    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float (*T)[LDT], int tid) const {
+    static constexpr bool ROWK = false;             // LDS tile [k][row]: one position (k) per thread, 16 rows
+    __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float* T, int tid) const {
         const int k = tid & (BKT - 1), r0 = tid / BKT;
         const float* v = reinterpret_cast<const float*>(&r[0]);
 #pragma unroll
-        for (int i = 0; i < 4 * NP; ++i) T[k][r0 + (256 / BKT) * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
+        for (int i = 0; i < 4 * NP; ++i) T[k * (BN + 4) + r0 + (256 / BKT) * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
     }
 };
 

@@ -19,11 +19,10 @@ struct TileCfg {
     static_assert(WM_ * WN_ == 4, "four waves per workgroup");
     static constexpr int WM = WM_, WN = WN_, MI = MI_, NJ = NJ_;
     static constexpr int BM = WM * MI * 32, BN = WN * NJ * 32;
-    static constexpr int LDA = BM + 4, LDB = BN + 4;                            // LDS row strides (k-major tiles [k][row])
     static constexpr int NPA = BM * BKT / 4 / 256, NPB = BN * BKT / 4 / 256;     // float4 pieces per thread per operand tile
 };
 using Cfg128 = TileCfg<2, 2, 2, 2>;
-constexpr int BM = Cfg128::BM, BN = Cfg128::BN, LDT = Cfg128::LDA, NP = Cfg128::NPA;   // the default tile (conv3d.hip loaders)
+constexpr int BM = Cfg128::BM, BN = Cfg128::BN, NP = Cfg128::NPA;   // the default tile (conv3d.hip loaders)
 
 struct GemmArgs {
     const float* A; const float* B; float* C;
@@ -86,8 +85,19 @@ __device__ __forceinline__ unsigned load_tile(float4 (&r)[ROWS * BKT / 1024], co
     return okmask;
 }
 
+// LDS tile layouts (per operand, chosen by its loader so that the global->LDS copy is always a float4 store):
+//   ROWK  (k-contiguous operands): T[row][k], 32 floats per row, UNPADDED; the eight 16-byte chunks of a row are stored at
+//         chunk ^ ((row >> 1) & 7).  An MFMA operand fragment for FOUR consecutive k2-steps is ONE ds_read_b128 per lane, and both
+//         that read (16 consecutive rows, one chunk index) and the store (2 rows x 8 chunks) touch 64 distinct banks.
+//   KROW  (row-contiguous operands): T[k][row], row stride ROWS + 4.  Fragments are four ds_read_b32.
+// Within a group of 8 consecutive k the lanes 0..31 hold k = 0..3 and the lanes 32..63 hold k = 4..7 of the fragment registers
+// (x, y, z, w); MFMA step j consumes register j of both operands, i.e. the k pairs (j, 4 + j).  Any pairing is exact as long
+// as A and B use the same one; it only fixes the (deterministic) order of the fp32 accumulation.
+template <int ROWS> struct TileFloats { static constexpr int value = BKT * (ROWS + 4); };      // >= ROWS * BKT (ROWK)
+__device__ __forceinline__ int rowk_off(int row, int chunk) { return row * BKT + ((chunk ^ ((row >> 1) & 7)) << 2); }
+
 template <bool KC, int ROWS>
-__device__ __forceinline__ void store_tile(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float (*T)[ROWS + 4], int tid) {
+__device__ __forceinline__ void store_tile(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float* __restrict__ T, int tid) {
     constexpr int NPT = ROWS * BKT / 1024, RC = ROWS / 4;
     if (okmask != (NPT == 8 ? 0xFFFFFFFFu : ((1u << (4 * NPT)) - 1u))) {     // only tiles on an operand edge pay for the selects
 #pragma unroll
@@ -100,14 +110,16 @@ __device__ __forceinline__ void store_tile(float4 (&r)[ROWS * BKT / 1024], unsig
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int f = tid + 256 * i;
-        if (KC) {
-            const int row = f / KCH, k = (f % KCH) << 2;
-            T[k + 0][row] = r[i].x; T[k + 1][row] = r[i].y; T[k + 2][row] = r[i].z; T[k + 3][row] = r[i].w;
-        } else {
-            const int k = f / RC, row = (f % RC) << 2;
-            *reinterpret_cast<float4*>(&T[k][row]) = r[i];
-        }
+        if (KC) *reinterpret_cast<float4*>(T + rowk_off(f / KCH, f % KCH)) = r[i];                     // ROWK: [row][k], swizzled chunks
+        else *reinterpret_cast<float4*>(T + (f / RC) * (ROWS + 4) + ((f % RC) << 2)) = r[i];          // KROW: [k][row]
     }
+}
+// this lane's fragment registers (4 consecutive k2-steps) of row `row` for the k-group g (8 consecutive k)
+template <bool ROWK, int ROWS>
+__device__ __forceinline__ float4 load_frag(const float* __restrict__ T, int row, int g, int khalf) {
+    if (ROWK) return *reinterpret_cast<const float4*>(T + rowk_off(row, g * 2 + khalf));
+    const float* p = T + (g * 8 + khalf * 4) * (ROWS + 4) + row;
+    return make_float4(p[0], p[ROWS + 4], p[2 * (ROWS + 4)], p[3 * (ROWS + 4)]);
 }
 
 // Workgroup -> tile map.  The dispatcher places workgroup b on XCD b % 8 (observed, used for speed only): remap so
@@ -121,14 +133,15 @@ __device__ __forceinline__ int xcd_tile(int wg, int ntiles) {
 // Operand loader concept (ROWS = the tile's BM for the A side, BN for the B side, NPT = ROWS*BKT/1024):
 // `unsigned load(float4 (&r)[NPT], int k0, int kend, int tid) const` fetches this thread's 4*NPT floats of the ROWS x BKT tile
 // starting at k0 and returns their validity mask; `store(r, mask, T, tid)` writes them (zeroing the invalid ones) into the
-// k-major LDS tile T[k][row] (row stride ROWS + 4).
+// LDS tile T (layout ROWK / KROW as the loader declares).
 template <bool KC, bool VEC, int ROWS = 128>
 struct DenseLoader {
+    static constexpr bool ROWK = KC;                 // LDS layout of this operand's tile (see store_tile)
     const float* base; int64_t s_row, s_k; int row0, rows;
     __device__ __forceinline__ unsigned load(float4 (&r)[ROWS * BKT / 1024], int k0, int kend, int tid) const {
         return load_tile<KC, VEC, ROWS>(r, base, s_row, s_k, row0, rows, k0, kend, tid);
     }
-    __device__ __forceinline__ void store(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float (*T)[ROWS + 4], int tid) const {
+    __device__ __forceinline__ void store(float4 (&r)[ROWS * BKT / 1024], unsigned okmask, float* T, int tid) const {
         store_tile<KC, ROWS>(r, okmask, T, tid);
     }
 };
@@ -150,12 +163,12 @@ __device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
 // acc += A_tile . B_tile^T over k in [kbeg, kend): the k-tile pipeline shared by every MFMA kernel of the library
 // LDS: two buffers per operand (128 x 128: 2 x 2 x BKT x 132 x 4 B = 67.6 KB per workgroup -> two workgroups per CU)
 template <class Cfg>
-struct TileLdsT { float A[2][BKT][Cfg::LDA]; float B[2][BKT][Cfg::LDB]; };
+struct TileLdsT { float A[2][TileFloats<Cfg::BM>::value]; float B[2][TileFloats<Cfg::BN>::value]; };
 using TileLds = TileLdsT<Cfg128>;
 
 template <class Cfg = Cfg128, class LA, class LB>
 __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const LA& la, const LB& lb, int kbeg, int kend, TileLdsT<Cfg>& S) {
-    constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ, NG = BKT / 8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
 #pragma unroll
@@ -168,7 +181,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
     // Pipeline (per k-tile t, h = t & 1 static after unrolling by two):
     //   global loads of tile t+2 -> register set h        (two tiles ahead: rides out lock-step fetch latency)
     //   LDS stores of tile t+1 (register set h^1) -> LDS buffer h^1   (issued BEFORE the MFMAs, so they drain under them)
-    //   MI*NJ*16 MFMAs on LDS buffer h, operand fragments fetched one k2-step ahead
+    //   MI*NJ*16 MFMAs on LDS buffer h; the fragments of k-group g+1 (four k2-steps) are fetched under the MFMAs of group g
     //   ONE barrier (buffer h may be overwritten / buffer h^1 is complete)
     float4 ra[2][Cfg::NPA], rb[2][Cfg::NPB];
     unsigned oka[2] = {0u, 0u}, okb[2] = {0u, 0u};
@@ -184,26 +197,38 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
         for (int h = 0; h < 2; ++h) {
             const int kt = k0 + h * BKT;
             if (kt < kend) {
-                float (*As)[Cfg::LDA] = S.A[h]; float (*Bs)[Cfg::LDB] = S.B[h];
+                const float* As = S.A[h]; const float* Bs = S.B[h];
                 if (kt + 2 * BKT < kend) { oka[h] = la.load(ra[h], kt + 2 * BKT, kend, tid); okb[h] = lb.load(rb[h], kt + 2 * BKT, kend, tid); }
                 if (kt + BKT < kend) { la.store(ra[h ^ 1], oka[h ^ 1], S.A[h ^ 1], tid); lb.store(rb[h ^ 1], okb[h ^ 1], S.B[h ^ 1], tid); }
-                float a[MI], b[NJ];
+                float4 a[MI], b[NJ];
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = As[kl][arow + 32 * i];
+                for (int i = 0; i < MI; ++i) a[i] = load_frag<LA::ROWK, Cfg::BM>(As, arow + 32 * i, 0, kl);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) b[j] = Bs[kl][brow + 32 * j];
+                for (int j = 0; j < NJ; ++j) b[j] = load_frag<LB::ROWK, Cfg::BN>(Bs, brow + 32 * j, 0, kl);
 #pragma unroll
-                for (int kk = 0; kk < BKT; kk += 2) {
-                    float na[MI], nb[NJ];
+                for (int g = 0; g < NG; ++g) {
+                    float4 na[MI], nb[NJ];
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) na[i] = (kk + 2 < BKT) ? As[kk + 2 + kl][arow + 32 * i] : 0.f;
+                    for (int i = 0; i < MI; ++i) na[i] = (g + 1 < NG) ? load_frag<LA::ROWK, Cfg::BM>(As, arow + 32 * i, g + 1, kl) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) nb[j] = (kk + 2 < BKT) ? Bs[kk + 2 + kl][brow + 32 * j] : 0.f;
-                    __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of this step's MFMAs
+                    for (int j = 0; j < NJ; ++j) nb[j] = (g + 1 < NG) ? load_frag<LB::ROWK, Cfg::BN>(Bs, brow + 32 * j, g + 1, kl) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the fragment prefetch ahead of this group's MFMAs
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
 #pragma unroll
                     for (int i = 0; i < MI; ++i) a[i] = na[i];
 #pragma unroll
@@ -263,8 +288,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
 
 // ---- host-side cost model shared by the GEMM and convolution planners (see gemm.hip) ---------------------------------
 struct TileInfo { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };   // resident workgroups per CU (LDS bound)
-static const TileInfo kTiles[] = {{SEGX_TILE_128x128, 128, 128, 2, 4.8f, 4.0f},
-                                  {SEGX_TILE_64x128, 64, 128, 3, 3.5f, 2.5f},
+static const TileInfo kTiles[] = {{SEGX_TILE_128x128, 128, 128, 2, 4.6f, 4.0f},
+                                  {SEGX_TILE_64x128, 64, 128, 3, 3.4f, 2.5f},
                                   {SEGX_TILE_64x64, 64, 64, 4, 2.4f, 1.5f},
                                   {SEGX_TILE_128x32, 128, 32, 3, 2.4f, 1.5f},
                                   {SEGX_TILE_32x128, 32, 128, 3, 2.4f, 1.5f}};
@@ -273,10 +298,15 @@ inline const TileInfo& tile_info(int tile) {
     return kTiles[0];
 }
 inline double model_us(const TileInfo& ti, int M, int N, int K, int nbatch, int sk) {
-    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch, slots = 256 * ti.wg_per_cu;
+    const int64_t tiles = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch * sk, slots = 256 * ti.wg_per_cu;
     const int kt = ceil_div(ceil_div(K, sk), BKT);
-    const int64_t rounds = (tiles * sk + slots - 1) / slots;
-    return (double)rounds * (kt * ti.ktile_us + ti.fixed_us) + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
+    // rounds of workgroups: a partial last round costs at least a third of a round (its workgroups still run start to end, but
+    // on emptier CUs); a grid below one round runs as long as its busiest CU, whose workgroups gain little from the free slots
+    const int64_t full = tiles / slots, rem = tiles % slots;
+    double rounds;
+    if (full == 0) rounds = 0.6 + 0.4 * (double)((rem + 255) / 256) / ti.wg_per_cu;   // a workgroup alone on its CU is only ~1.25x faster
+    else rounds = (double)full + (rem ? 0.35 + 0.65 * (double)rem / (double)slots : 0.0);
+    return rounds * (kt * ti.ktile_us + ti.fixed_us) + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
 }
 inline int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, double* t_out) {
     int best = 1; double best_t = model_us(ti, M, N, K, nbatch, 1);
