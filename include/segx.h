@@ -188,9 +188,10 @@ int segx_plane_scale_add(const float* X, const float* gate, const float* R, floa
 int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream);
 int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream);
 /* squeeze-excite excitation MLP on the pooled vector: p = pooled_sum * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2)
- * (W1 [Cs,C], W2 [C,Cs]: the 1x1 convs _se_reduce / _se_expand).  bwd: dpool (= dL/dpooled_sum), dW1, db1, dW2, db2; ws: B*(C+Cs) floats */
+ * (W1 [Cs,C], W2 [C,Cs]: the 1x1 convs _se_reduce / _se_expand).  bwd: dpool (= dL/dpooled_sum), dW1, db1, dW2, db2; ws: segx_se_ws_floats(B, C, Cs) floats */
 int segx_se_gate_fwd(const float* pooled_sum, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2,
                      float* p, float* hpre, float* gate, int B, int C, int Cs, void* stream);
+int64_t segx_se_ws_floats(int B, int C, int Cs);   /* workspace of segx_se_gate_bwd */
 int segx_se_gate_bwd(const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1, const float* W2,
                      float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws, int B, int C, int Cs, void* stream);
 

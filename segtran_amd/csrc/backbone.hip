@@ -26,14 +26,17 @@ __device__ __forceinline__ float act_grad(float u, int act) {
 // BatchNorm statistics: per channel over (B, S).  Shifted sums around a per-channel pivot (the channel's
 // first element) keep E[d^2] - E[d]^2 free of catastrophic cancellation.  Stage 1: grid (C, B, slabs).
 // =================================================================================================
-constexpr int BN_SLABS = 8;
+constexpr int BN_SLABS = 8;               // upper bound (workspace size); the launches use bn_slabs(S) <= BN_SLABS = gridDim.z
+// slabs per plane: ~8K floats each, so a 32 x 32 plane is ONE fully populated workgroup instead of eight with 32 live threads
+static inline int bn_slabs(int64_t S) { const int64_t n = S / 8192; return (int)(n < 1 ? 1 : n > BN_SLABS ? BN_SLABS : n); }
 
 __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ X, float* __restrict__ ws, int C, int64_t S) {
     __shared__ float red[4];
     const int c = blockIdx.x, b = blockIdx.y, slab = blockIdx.z;
     const float pivot = X[(int64_t)c * S];
     const float* x = X + ((int64_t)b * C + c) * S;
-    const int64_t per = ((S + BN_SLABS - 1) / BN_SLABS + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
+    const int nsl = gridDim.z;
+    const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
     if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
         for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
@@ -45,16 +48,16 @@ __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__
         for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + b) * BN_SLABS + slab) * 2; o[0] = a; o[1] = q; }
+    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + b) * nsl + slab) * 2; o[0] = a; o[1] = q; }
 }
 // one thread per channel: mean, biased var (+ running-stat update with the unbiased var, momentum m)
 __global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__ X, const float* __restrict__ ws, float* __restrict__ mean,
                                                        float* __restrict__ var, float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                       int B, int C, int64_t S, float momentum) {
+                                                       int B, int C, int64_t S, float momentum, int nsl) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float a = 0.f, q = 0.f;
-    for (int i = 0; i < B * BN_SLABS; ++i) { a += ws[((int64_t)c * B * BN_SLABS + i) * 2]; q += ws[((int64_t)c * B * BN_SLABS + i) * 2 + 1]; }
+    for (int i = 0; i < B * nsl; ++i) { a += ws[((int64_t)c * B * nsl + i) * 2]; q += ws[((int64_t)c * B * nsl + i) * 2 + 1]; }
     const float n = (float)B * (float)S, md = a / n;
     const float m = X[(int64_t)c * S] + md, v = fmaxf(q / n - md * md, 0.f);
     mean[c] = m; var[c] = v;
@@ -90,7 +93,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
     const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
-    const int64_t per = ((S + BN_SLABS - 1) / BN_SLABS + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
+    const int nsl = gridDim.z;
+    const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
     if ((S & 3) == 0) {
         for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
@@ -107,13 +111,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
         }
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + bb) * BN_SLABS + slab) * 2; o[0] = a; o[1] = q; }
+    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + bb) * nsl + slab) * 2; o[0] = a; o[1] = q; }
 }
-__global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int B, int C) {
+__global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db, int B, int C, int nsl) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float a = 0.f, q = 0.f;
-    for (int i = 0; i < B * BN_SLABS; ++i) { a += ws[((int64_t)c * B * BN_SLABS + i) * 2]; q += ws[((int64_t)c * B * BN_SLABS + i) * 2 + 1]; }
+    for (int i = 0; i < B * nsl; ++i) { a += ws[((int64_t)c * B * nsl + i) * 2]; q += ws[((int64_t)c * B * nsl + i) * 2 + 1]; }
     db[c] = a; dw[c] = q;
 }
 // dx = w * rstd * (du - [training] (db + xhat * dw) / n)
@@ -523,53 +527,68 @@ __global__ __launch_bounds__(256) void plane_scale_bwd_kernel(const float* __res
 }
 
 // ---- squeeze-excite excitation MLP on the pooled [B, C] vector (efficientnet/model.py:106-110) -------------------
-//   p = pooled_sum / S ; hpre = W1 p + b1 ; h = swish(hpre) ; gate = sigmoid(W2 h + b2).  One workgroup per sample.
-constexpr int SE_MAX_C = 4096, SE_MAX_CS = 256;
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pooled_sum, float inv_S, const float* __restrict__ W1,
-                                                          const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                          float* __restrict__ p_out, float* __restrict__ hpre_out, float* __restrict__ gate, int C, int Cs) {
-    __shared__ float p[SE_MAX_C];
-    __shared__ float h[SE_MAX_CS];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < C; c += 256) { const float v = pooled_sum[(int64_t)b * C + c] * inv_S; p[c] = v; p_out[(int64_t)b * C + c] = v; }
-    __syncthreads();
-    for (int j = wave; j < Cs; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += W1[(int64_t)j * C + c] * p[c];
-        s = wave_sum(s) + b1[j];
-        if (lane == 0) { hpre_out[(int64_t)b * Cs + j] = s; h[j] = s * sigm(s); }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float z = b2[c];
-        for (int j = 0; j < Cs; ++j) z += W2[(int64_t)c * Cs + j] * h[j];
-        gate[(int64_t)b * C + c] = sigm(z);
-    }
+//   p = pooled_sum / S ; hpre = W1 p + b1 ; h = swish(hpre) ; gate = sigmoid(W2 h + b2)
+// Every dot product is one WAVE reading a contiguous weight row (W1 [Cs][C], W2 [C][Cs]): B*Cs and B*C waves instead of the
+// earlier one-workgroup-per-sample kernel whose W2 walk was strided (84 us per layer at B = 6, latency bound).
+constexpr int SE_MAX_C = 4096, SE_MAX_CS = 256, SE_CCHUNK = 256;
+// hpre[b][j] = b1[j] + sum_c W1[j][c] * pooled_sum[b][c] / S ; also p[b][c] (kept for the weight gradients).  grid (ceil(Cs/4), B)
+__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled_sum, float inv_S, const float* __restrict__ W1,
+                                                        const float* __restrict__ b1, float* __restrict__ p_out, float* __restrict__ hpre_out,
+                                                        int C, int Cs) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0) for (int c = threadIdx.x; c < C; c += 256) p_out[(int64_t)b * C + c] = pooled_sum[(int64_t)b * C + c] * inv_S;
+    if (j >= Cs) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += W1[(int64_t)j * C + c] * (pooled_sum[(int64_t)b * C + c] * inv_S);
+    s = wave_sum(s);
+    if (lane == 0) hpre_out[(int64_t)b * Cs + j] = s + b1[j];
 }
-// per sample: dz2 = dgate * gate * (1 - gate) ; dhpre = (W2^T dz2) * swish'(hpre) ; dpool = (W1^T dhpre) / S
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate, const float* __restrict__ hpre,
-                                                          const float* __restrict__ W1, const float* __restrict__ W2, float inv_S,
-                                                          float* __restrict__ dz2_out, float* __restrict__ dhpre_out, float* __restrict__ dpool, int C, int Cs) {
-    __shared__ float dz2[SE_MAX_C];
+// gate[b][c] = sigmoid(b2[c] + sum_j W2[c][j] * swish(hpre[b][j])).  grid (ceil(C/4), B)
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int C, int Cs) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float s = 0.f;
+    for (int j = lane; j < Cs; j += 64) { const float hp = hpre[(int64_t)b * Cs + j]; s += W2[(int64_t)c * Cs + j] * (hp * sigm(hp)); }
+    s = wave_sum(s);
+    if (lane == 0) gate[(int64_t)b * C + c] = sigm(s + b2[c]);
+}
+// backward.  dz2 = dgate * gate * (1 - gate) ; part[b][chunk][j] = sum_{c in chunk} dz2[b][c] * W2[c][j]   (thread = j: coalesced W2 rows)
+// grid (ceil(C / SE_CCHUNK), B), Cs <= 256 threads active
+__global__ __launch_bounds__(256) void se_bwd_hidden_partial_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                                    const float* __restrict__ W2, float* __restrict__ dz2_out,
+                                                                    float* __restrict__ part, int C, int Cs) {
+    __shared__ float dz[SE_CCHUNK];
+    const int b = blockIdx.y, c0 = blockIdx.x * SE_CCHUNK, j = threadIdx.x;
+    const int c = c0 + threadIdx.x;
+    if (c < C) { const float g = gate[(int64_t)b * C + c], v = dgate[(int64_t)b * C + c] * g * (1.0f - g); dz[threadIdx.x] = v; dz2_out[(int64_t)b * C + c] = v; }
+    __syncthreads();
+    if (j >= Cs) return;
+    const int n = min(SE_CCHUNK, C - c0);
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += dz[i] * W2[(int64_t)(c0 + i) * Cs + j];
+    part[((int64_t)b * gridDim.x + blockIdx.x) * Cs + j] = s;
+}
+// dhpre[b][j] = swish'(hpre) * sum_chunks part ; then dpool[b][c] = sum_j dhpre[b][j] * W1[j][c] / S.  grid (ceil(C/256), B); every
+// workgroup recomputes the (tiny) dhpre vector of its sample into LDS, workgroup 0 also writes it out
+__global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restrict__ part, const float* __restrict__ hpre, const float* __restrict__ W1,
+                                                          float inv_S, float* __restrict__ dhpre_out, float* __restrict__ dpool, int C, int Cs,
+                                                          int nchunks) {
     __shared__ float dh[SE_MAX_CS];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        const float g = gate[(int64_t)b * C + c], v = dgate[(int64_t)b * C + c] * g * (1.0f - g);
-        dz2[c] = v; dz2_out[(int64_t)b * C + c] = v;
+    const int b = blockIdx.y;
+    for (int j = threadIdx.x; j < Cs; j += 256) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) s += part[((int64_t)b * nchunks + k) * Cs + j];
+        const float v = s * act_grad(hpre[(int64_t)b * Cs + j], ACT_SWISH);
+        dh[j] = v;
+        if (blockIdx.x == 0) dhpre_out[(int64_t)b * Cs + j] = v;
     }
     __syncthreads();
-    for (int j = wave; j < Cs; j += 4) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += dz2[c] * W2[(int64_t)c * Cs + j];
-        s = wave_sum(s);
-        if (lane == 0) { const float hp = hpre[(int64_t)b * Cs + j]; const float v = s * act_grad(hp, ACT_SWISH); dh[j] = v; dhpre_out[(int64_t)b * Cs + j] = v; }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
-        for (int j = 0; j < Cs; ++j) s += dh[j] * W1[(int64_t)j * C + c];
-        dpool[(int64_t)b * C + c] = s * inv_S;
-    }
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int j = 0; j < Cs; ++j) s += dh[j] * W1[(int64_t)j * C + c];
+    dpool[(int64_t)b * C + c] = s * inv_S;
 }
 // weight gradients (sums over the batch): thread per (c, j)
 __global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ dhpre, const float* __restrict__ p,
@@ -600,8 +619,8 @@ extern "C" int segx_bn_stats(const float* X, float* mean, float* var, float* run
                              int B, int C, int64_t S, float momentum, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && ws && B > 0 && C > 0 && S > 0 && (!run_mean == !run_var), "segx_bn_stats: bad args");
     SEGX_REQUIRE(B <= 65535, "segx_bn_stats: batch too large");
-    hipLaunchKernelGGL(bn_stats_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, X, ws, C, S);
-    hipLaunchKernelGGL(bn_stats_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, var, run_mean, run_var, B, C, S, momentum);
+    hipLaunchKernelGGL(bn_stats_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, ws, C, S);
+    hipLaunchKernelGGL(bn_stats_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, var, run_mean, run_var, B, C, S, momentum, bn_slabs(S));
     return check_launch("segx_bn_stats");
 }
 extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
@@ -614,8 +633,8 @@ extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* v
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_reduce: bad args");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
-    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     return check_launch("segx_bn_act_bwd_reduce");
 }
 extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -631,8 +650,8 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
                                void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, BN_SLABS), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
-    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
     hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
                        (const float*)db, dX, C, S, eps, act, inv_n);
@@ -789,17 +808,21 @@ extern "C" int segx_plane_scale_bwd(const float* dY, const float* gate, const fl
 extern "C" int segx_se_gate_fwd(const float* pooled_sum, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2,
                                 float* p, float* hpre, float* gate, int B, int C, int Cs, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(pooled_sum && W1 && b1 && W2 && b2 && p && hpre && gate && B > 0 && C > 0 && Cs > 0, "segx_se_gate_fwd: bad args");
-    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS, "segx_se_gate_fwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
-    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), 0, stream, pooled_sum, inv_S, W1, b1, W2, b2, p, hpre, gate, C, Cs);
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_gate_fwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    hipLaunchKernelGGL(se_hidden_kernel, dim3((Cs + 3) / 4, B), dim3(256), 0, stream, pooled_sum, inv_S, W1, b1, p, hpre, C, Cs);
+    hipLaunchKernelGGL(se_gate_kernel, dim3((C + 3) / 4, B), dim3(256), 0, stream, (const float*)hpre, W2, b2, gate, C, Cs);
     return check_launch("segx_se_gate_fwd");
 }
+extern "C" int64_t segx_se_ws_floats(int B, int C, int Cs) { return (int64_t)B * (C + Cs) + (int64_t)B * ((C + SE_CCHUNK - 1) / SE_CCHUNK) * Cs; }
 extern "C" int segx_se_gate_bwd(const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1, const float* W2,
-                                float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws /* B*(C+Cs) */,
+                                float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws /* segx_se_ws_floats */,
                                 int B, int C, int Cs, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dgate && gate && hpre && p && W1 && W2 && dpool && dW1 && db1 && dW2 && db2 && ws && B > 0 && C > 0 && Cs > 0, "segx_se_gate_bwd: bad args");
-    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS, "segx_se_gate_bwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
-    float* dz2 = ws; float* dhpre = ws + (int64_t)B * C;
-    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), 0, stream, dgate, gate, hpre, W1, W2, inv_S, dz2, dhpre, dpool, C, Cs);
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_gate_bwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    const int nchunks = (C + SE_CCHUNK - 1) / SE_CCHUNK;
+    float* dz2 = ws; float* dhpre = ws + (int64_t)B * C; float* part = dhpre + (int64_t)B * Cs;
+    hipLaunchKernelGGL(se_bwd_hidden_partial_kernel, dim3(nchunks, B), dim3(256), 0, stream, dgate, gate, W2, dz2, part, C, Cs);
+    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, (const float*)part, hpre, W1, inv_S, dhpre, dpool, C, Cs, nchunks);
     hipLaunchKernelGGL(se_gate_wgrad_kernel, dim3((unsigned)(((int64_t)C * Cs + 255) / 256)), dim3(256), 0, stream, (const float*)dz2, (const float*)dhpre,
                        p, hpre, dW1, db1, dW2, db2, B, C, Cs);
     return check_launch("segx_se_gate_bwd");

@@ -257,21 +257,35 @@ __global__ __launch_bounds__(256) void label_nhot_kernel(const void* __restrict_
 // =================================================================================================
 struct PoolGeom { int ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw; };
 
+// TKD/TKH/TKW > 0: compile-time window (fully unrolled scan); 0: runtime window.  One thread per output; 32-bit index math inside a
+// plane (the host checks plane sizes < 2^31), one 64-bit division per thread for the plane.
+template <int TKD, int TKH, int TKW>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg,
                                                             PoolGeom q, int64_t planes) {
-    const int64_t osz = (int64_t)q.OD * q.OH * q.OW, isz = (int64_t)q.ID * q.IH * q.IW, total = planes * osz;
+    const int KD = TKD ? TKD : q.KD, KH = TKH ? TKH : q.KH, KW = TKW ? TKW : q.KW;
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ohw = q.OH * q.OW;
+    const int64_t total = planes * osz;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / osz; int64_t r = idx - p * osz;
-        const int od = (int)(r / ((int64_t)q.OH * q.OW)); r -= (int64_t)od * q.OH * q.OW;
-        const int oh = (int)(r / q.OW), ow = (int)(r - (int64_t)oh * q.OW);
+        const int64_t p = idx / osz; const int r = (int)(idx - p * osz);
+        const int od = r / ohw, r2 = r - od * ohw, oh = r2 / q.OW, ow = r2 - oh * q.OW;
         const float* x = X + p * isz;
+        const int d0 = od * q.sd - q.pd, h0 = oh * q.sh - q.ph, w0 = ow * q.sw - q.pw;
         float best = -INFINITY; int bi = -1;
-        for (int kd = 0; kd < q.KD; ++kd) for (int kh = 0; kh < q.KH; ++kh) for (int kw = 0; kw < q.KW; ++kw) {
-            const int id = od * q.sd - q.pd + kd, ih = oh * q.sh - q.ph + kh, iw = ow * q.sw - q.pw + kw;
-            const bool in = id >= 0 && id < q.ID && ih >= 0 && ih < q.IH && iw >= 0 && iw < q.IW;
-            const int li = (id * q.IH + ih) * q.IW + iw;
-            const float v = in ? x[li] : 0.f;                      // zero padding
-            if (v > best || v != v) { best = v; bi = in ? li : -1; }
+#pragma unroll
+        for (int kd = 0; kd < KD; ++kd) {
+            const int id = d0 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
+#pragma unroll
+            for (int kh = 0; kh < KH; ++kh) {
+                const int ih = h0 + kh; const bool okh = okd && (unsigned)ih < (unsigned)q.IH;
+                const int rowbase = (id * q.IH + ih) * q.IW;
+#pragma unroll
+                for (int kw = 0; kw < KW; ++kw) {
+                    const int iw = w0 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
+                    const int li = rowbase + iw;
+                    const float v = in ? x[li] : 0.f;                      // zero padding
+                    if (v > best || v != v) { best = v; bi = in ? li : -1; }
+                }
+            }
         }
         Y[idx] = best; arg[idx] = bi;
     }
@@ -279,19 +293,20 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restr
 // gather form: an input cell sums the gradients of the windows whose arg-max it is
 __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
                                                             PoolGeom q, int64_t planes) {
-    const int64_t osz = (int64_t)q.OD * q.OH * q.OW, isz = (int64_t)q.ID * q.IH * q.IW, total = planes * isz;
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ihw = q.IH * q.IW;
+    const int64_t total = planes * isz;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int64_t p = idx / isz; const int li = (int)(idx - p * isz);
-        const int id = li / (q.IH * q.IW), r = li - id * q.IH * q.IW, ih = r / q.IW, iw = r - ih * q.IW;
+        const int id = li / ihw, r = li - id * ihw, ih = r / q.IW, iw = r - ih * q.IW;
         const float* g = dY + p * osz; const int* a = arg + p * osz;
         float acc = 0.f;
         // windows covering (id,ih,iw): od in [ceil((id+pd-KD+1)/sd), floor((id+pd)/sd)]
-        const int d1 = (id + q.pd) / q.sd, h1 = (ih + q.ph) / q.sh, w1 = (iw + q.pw) / q.sw;
+        const int d1 = min((id + q.pd) / q.sd, q.OD - 1), h1 = min((ih + q.ph) / q.sh, q.OH - 1), w1 = min((iw + q.pw) / q.sw, q.OW - 1);
         const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw + q.pw - q.KW + 1;
         const int d0 = dn > 0 ? (dn + q.sd - 1) / q.sd : 0, h0 = hn > 0 ? (hn + q.sh - 1) / q.sh : 0, w0 = wn > 0 ? (wn + q.sw - 1) / q.sw : 0;
-        for (int od = d0; od <= d1 && od < q.OD; ++od) for (int oh = h0; oh <= h1 && oh < q.OH; ++oh) for (int ow = w0; ow <= w1 && ow < q.OW; ++ow) {
-            const int64_t o = ((int64_t)od * q.OH + oh) * q.OW + ow;
-            if (a[o] == li) acc += g[o];
+        for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {
+            const int rowo = (od * q.OH + oh) * q.OW;
+            for (int ow = w0; ow <= w1; ++ow) if (a[rowo + ow] == li) acc += g[rowo + ow];
         }
         dX[idx] = acc;
     }
@@ -409,14 +424,20 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
     SEGX_STREAM; SEGX_REQUIRE(X && Y && arg && geom && planes > 0, "segx_maxpool3d_fwd: bad args");
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.OD * q.OH * q.OW;
-    hipLaunchKernelGGL(maxpool3d_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, X, Y, arg, q, planes);
+    SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_fwd: plane too large");
+    const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+    if (q.KD == 3 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<3, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
+    else if (q.KD == 1 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<1, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
+    else if (q.KD == 2 && q.KH == 2 && q.KW == 2) hipLaunchKernelGGL((maxpool3d_fwd_kernel<2, 2, 2>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
+    else hipLaunchKernelGGL((maxpool3d_fwd_kernel<0, 0, 0>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
     return check_launch("segx_maxpool3d_fwd");
 }
 extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && arg && dX && geom && planes > 0, "segx_maxpool3d_bwd: bad args");
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.ID * q.IH * q.IW;
-    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
+    SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
+    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
     return check_launch("segx_maxpool3d_bwd");
 }
 extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream_) {

@@ -5,7 +5,7 @@
 
 namespace segx {
 
-constexpr int GN_SLABS = 16;
+constexpr int GN_SLABS = 64;            // 32 (sample, group) pairs x 64 slabs = 2048 workgroups on the 616 MB 3-D FPN tensors
 
 // =================================================================================================
 // GroupNorm (segtran2d.py:148-149,190-192 nn.GroupNorm(G=8, C), eps 1e-5).  Channels of a group are adjacent, so a
@@ -16,9 +16,17 @@ __global__ __launch_bounds__(256) void gn_stats_stage1(const float* __restrict__
     const int bg = blockIdx.x, slab = blockIdx.y;
     const float* x = X + (int64_t)bg * L;
     const float pivot = x[0];
-    const int64_t per = (L + GN_SLABS - 1) / GN_SLABS, s0 = slab * per, s1 = i64min(L, s0 + per);
+    const int64_t per = ((L + GN_SLABS - 1) / GN_SLABS + 3) / 4 * 4, s0 = slab * per, s1 = i64min(L, s0 + per);
     float a = 0.f, q = 0.f;
-    for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
+    if ((L & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + s);
+            const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
+            a += (d0 + d1) + (d2 + d3); q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else {
+        for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
+    }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
     if (threadIdx.x == 0) { ws[((int64_t)bg * GN_SLABS + slab) * 2] = a; ws[((int64_t)bg * GN_SLABS + slab) * 2 + 1] = q; }
 }
@@ -99,6 +107,37 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict
         out[idx] = v;
     }
 }
+// float4 variant (W % 4 == 0, W <= 1024): a thread owns four adjacent outputs of one output row, so the (plane, z, y) decode and the
+// two row-axis sources are computed once per four outputs, the lateral is read and the result written as float4.  Same blend order
+// as interp_at (x, then y, then z), hence the same bits.
+__global__ __launch_bounds__(256) void interp_fwd_rows_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                              InterpDims q, int w4, int rpb, int64_t nrows) {
+    const int tr = threadIdx.x / w4, tx = threadIdx.x - tr * w4;
+    if (tr >= rpb) return;
+    const int64_t isz = (int64_t)q.d * q.h * q.w, DH = (int64_t)q.D * q.H;
+    Axis ax[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ax[j] = axis_src(tx * 4 + j, q.w, q.sw);
+    for (int64_t row = (int64_t)blockIdx.x * rpb + tr; row < nrows; row += (int64_t)gridDim.x * rpb) {
+        const int64_t p = row / DH; const int rem = (int)(row - p * DH);
+        const int z = rem / q.H, y = rem - z * q.H;
+        const Axis az = axis_src(z, q.d, q.sd), ay = axis_src(y, q.h, q.sh);
+        const float* s = in + p * isz;
+        const float* r00 = s + ((int64_t)az.i0 * q.h + ay.i0) * q.w; const float* r01 = s + ((int64_t)az.i0 * q.h + ay.i1) * q.w;
+        const float* r10 = s + ((int64_t)az.i1 * q.h + ay.i0) * q.w; const float* r11 = s + ((int64_t)az.i1 * q.h + ay.i1) * q.w;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float l = ax[j].l; const int i0 = ax[j].i0, i1 = ax[j].i1;
+            const float c00 = r00[i0] * (1.f - l) + r00[i1] * l, c01 = r01[i0] * (1.f - l) + r01[i1] * l;
+            const float c10 = r10[i0] * (1.f - l) + r10[i1] * l, c11 = r11[i0] * (1.f - l) + r11[i1] * l;
+            v[j] = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
+        }
+        const int64_t o = row * q.W + tx * 4;
+        if (base) { const float4 bv = *reinterpret_cast<const float4*>(base + o); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
 // adjoint as a GATHER (deterministic, no atomics): an input cell collects from every output cell it was blended into
 __device__ __forceinline__ void cand_range(int i, int n_out, float scale, int& lo, int& hi) {
     const float inv = 1.0f / scale;
@@ -149,6 +188,24 @@ __global__ __launch_bounds__(256) void interp_bwd_axis_kernel(const float* __res
     }
 }
 
+// float4 over the inner (contiguous) extent: the candidate range and the blend weights depend on the axis index only
+__global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
+                                                               int n_out, int n_in, int64_t inner4, float scale) {
+    const int64_t total = outer * n_in * inner4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t in_ = idx % inner4; const int64_t r = idx / inner4; const int i = (int)(r % n_in); const int64_t o = r / n_in;
+        int lo, hi; cand_range(i, n_out, scale, lo, hi);
+        const float4* g = reinterpret_cast<const float4*>(dout) + (o * n_out) * inner4 + in_;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int d = lo; d <= hi; ++d) {
+            const float w = axis_weight(i, d, n_in, scale);
+            const float4 v = g[(int64_t)d * inner4];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        reinterpret_cast<float4*>(din)[idx] = acc;
+    }
+}
+
 static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -182,7 +239,15 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
                                       void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
     const int64_t total = planes * D * H * W;
-    hipLaunchKernelGGL(interp_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), planes);
+    const bool al = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
+    if (W % 4 == 0 && W <= 1024 && al) {
+        const int w4 = W / 4, rpb = 256 / w4;
+        const int64_t nrows = planes * D * H;
+        hipLaunchKernelGGL(interp_fwd_rows_kernel, dim3((unsigned)i64min(1 << 20, (nrows + rpb - 1) / rpb)), dim3(256), 0, stream, in, base, out,
+                           make_dims(d, h, w, D, H, W), w4, rpb, nrows);
+    } else {
+        hipLaunchKernelGGL(interp_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), planes);
+    }
     return check_launch("segx_interp_linear_fwd");
 }
 extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
@@ -194,7 +259,11 @@ extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t pla
 extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n_out > 0 && n_in > 0 && inner > 0, "segx_interp_linear_bwd_axis: bad args");
     const int64_t total = outer * n_in * inner;
-    hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out, n_in,
-                       inner, (float)n_in / (float)n_out);
+    if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0)
+        hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,
+                           n_out, n_in, inner / 4, (float)n_in / (float)n_out);
+    else
+        hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out,
+                           n_in, inner, (float)n_in / (float)n_out);
     return check_launch("segx_interp_linear_bwd_axis");
 }

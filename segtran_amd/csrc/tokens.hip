@@ -244,10 +244,15 @@ __global__ __launch_bounds__(256) void colreduce_stage1(const float* __restrict_
     const int64_t per = (rows + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(rows, r0 + per);
     if (c >= C) return;
     float s0 = 0.f, s1 = 0.f;
-    for (int64_t r = r0; r < r1; ++r) {
-        const float a = A[r * C + c];
-        if (mode == 0) s0 += a;
-        else { s0 += a * ((X[r * C + c] - mean[r]) * rstd[r]); s1 += a; }
+    if (mode == 0) {
+#pragma unroll 8
+        for (int64_t r = r0; r < r1; ++r) s0 += A[r * C + c];          // unrolled: eight loads in flight instead of one
+    } else {
+#pragma unroll 4
+        for (int64_t r = r0; r < r1; ++r) {
+            const float a = A[r * C + c];
+            s0 += a * ((X[r * C + c] - mean[r]) * rstd[r]); s1 += a;
+        }
     }
     ws[(int64_t)chunk * C + c] = s0;
     if (mode == 1) ws[((int64_t)nchunks + chunk) * C + c] = s1;
@@ -258,6 +263,7 @@ __global__ __launch_bounds__(256) void colreduce_stage2(const float* __restrict_
     if (c >= C) return;
     for (int o = 0; o < nout; ++o) {
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nchunks; ++k) s += ws[((int64_t)o * nchunks + k) * C + c];
         (o == 0 ? out0 : o == 1 ? out1 : out2)[c] = s;
     }

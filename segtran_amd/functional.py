@@ -579,7 +579,7 @@ class _SqueezeExcite(torch.autograd.Function):
         L.plane_dot(dy, x, dgate, B * C, S)
         dpool = _empty(x, B * C)
         dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
-        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, B * (C + Cs)), B, C, Cs)
+        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
         dx = torch.empty_like(x)
         L.plane_scale_bwd(dy, gate, dpool, dx, B * C, S)
         return dx, dW1.view(w1s), db1, dW2.view(w2s), db2

@@ -236,6 +236,9 @@ class SegxLib:
     def se_gate_fwd(self, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs):
         self._call('segx_se_gate_fwd', gate, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
 
+    def se_ws(self, B, C, Cs):
+        return int(self.c.segx_se_ws_floats(B, C, Cs))
+
     def se_gate_bwd(self, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs):
         self._call('segx_se_gate_bwd', gate, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs)
 
@@ -364,7 +367,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

@@ -21,7 +21,7 @@ def _act(u, act):
     return u * torch.sigmoid(u) if act == 1 else F.relu(u) if act == 2 else u
 
 
-@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 4, 3, 4, 5), (2, 7, 8, 8)])
+@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 4, 3, 4, 5), (2, 7, 8, 8), (1, 2, 130, 130)])      # last: two reduction slabs per plane
 @pytest.mark.parametrize('act', [0, 1, 2])
 @pytest.mark.parametrize('training', [True, False])
 def test_bn_act(backend, shape, act, training):
@@ -70,8 +70,8 @@ def test_dwconv2d(backend, k, stride, pad, H, W):
     close(x.grad, xr.grad, 1e-4); close(w.grad, wr.grad, 1e-4)
 
 
-def test_squeeze_excite(backend):
-    B, C, Cs, H, W = 3, 12, 4, 9, 7
+@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 300, 70, 4, 5)])      # second: 2 channel chunks, Cs > one wave
+def test_squeeze_excite(backend, B, C, Cs, H, W):
     x = rnd(B, C, H, W, seed=10).requires_grad_(True)
     ps = [rnd(Cs, C, 1, 1, seed=11, scale=0.5), rnd(Cs, seed=12, scale=0.1), rnd(C, Cs, 1, 1, seed=13, scale=0.5), rnd(C, seed=14, scale=0.1)]
     ps = [p.requires_grad_(True) for p in ps]
