@@ -113,4 +113,14 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 __host__ __device__ inline int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
 __host__ __device__ inline int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }
 
+// exact floor(n / d) for 0 <= n < 2^31: multiply-high by ceil(2^32 / d) over-estimates by at most one -> one correction
+struct FastDiv { unsigned d, magic; };
+__host__ __device__ inline FastDiv make_fastdiv(int d) { FastDiv f; f.d = (unsigned)d; f.magic = d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); return f; }
+__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
+    if (f.d <= 1) return n;
+    const unsigned q = __umulhi((unsigned)n, f.magic);
+    return (int)(q - (q * f.d > (unsigned)n ? 1u : 0u));
+}
+
+
 }  // namespace segx

@@ -16,15 +16,6 @@ struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
 };
 
-// exact floor(n / d) for 0 <= n < 2^31: multiply-high by ceil(2^32 / d) over-estimates by at most one -> one correction
-struct FastDiv { unsigned d, magic; };
-__host__ __device__ inline FastDiv make_fastdiv(int d) { FastDiv f; f.d = (unsigned)d; f.magic = d <= 1 ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); return f; }
-__device__ __forceinline__ int fdiv(int n, const FastDiv& f) {
-    if (f.d <= 1) return n;
-    const unsigned q = __umulhi((unsigned)n, f.magic);
-    return (int)(q - (q * f.d > (unsigned)n ? 1u : 0u));
-}
-
 // ---- forward / backward-data: B(n = output position, k = (ci, tap)) ------------------------------------------------
 // Thread map: ONE output position per thread (n0 + (tid & 127): the 64 lanes of a wave read 64 consecutive positions,
 // i.e. whole 128-B lines for every tap), BKT/2 k-rows (tid>>7)*(BKT/2) + i.  The (ci, tap) decode of a k-row is wave-uniform.
@@ -178,36 +169,53 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restri
 // vector ALU -- dX[b][ci][i] = sum_{co} sum_{taps t with (i + p - t) % s == 0} W[co][ci][t] * dY[b][co][(i + p - t) / s].
 // M = Cin = 3 would leave 97 % of an MFMA tile empty, so this one stays off the matrix cores.
 // One thread per input POSITION accumulating all CIN channels (each dY value is loaded once for the CIN outputs).
+// Backward-data of a STRIDED convolution onto a few input channels (the 7x7x7 stride-2 I3D stem, 3 channels), by residue class:
+// a workgroup serves input positions whose (i + pad) has ONE residue (rd, rh, rw) modulo the strides, so the set of contributing
+// taps kd = rd + sd*m ... and every weight are UNIFORM across the workgroup (scalar loads), and neighbouring lanes read
+// neighbouring dY elements (coalesced).  The earlier position-major kernel re-read the filter bank per lane with two different
+// tap sets per wave: 11.9 ms and 22 GB fetched for a 58 MB result (r01-g PMC).
+// grid: (position blocks of the class, B * sd*sh*sw)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
                                                                      int B, int Cout, ConvGeom q) {
-    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW, total = (int64_t)B * isz;
+    const int nph = q.sd * q.sh * q.sw, b = blockIdx.y / nph, ph = blockIdx.y - b * nph;
+    const int rd = ph / (q.sh * q.sw), rh = (ph / q.sw) % q.sh, rw = ph % q.sw;
+    // positions of this class along an axis: i = r - pad + s*t for t in [t0, t1]
+    const int td0 = rd >= q.pd ? 0 : (q.pd - rd + q.sd - 1) / q.sd, td1 = (q.ID - 1 + q.pd - rd) >= 0 ? (q.ID - 1 + q.pd - rd) / q.sd : -1;
+    const int th0 = rh >= q.ph ? 0 : (q.ph - rh + q.sh - 1) / q.sh, th1 = (q.IH - 1 + q.ph - rh) >= 0 ? (q.IH - 1 + q.ph - rh) / q.sh : -1;
+    const int tw0 = rw >= q.pw ? 0 : (q.pw - rw + q.sw - 1) / q.sw, tw1 = (q.IW - 1 + q.pw - rw) >= 0 ? (q.IW - 1 + q.pw - rw) / q.sw : -1;
+    const int nD = td1 - td0 + 1, nH = th1 - th0 + 1, nW = tw1 - tw0 + 1;
+    if (nD <= 0 || nH <= 0 || nW <= 0) return;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nD * nH * nW) return;
+    const int td = td0 + l / (nH * nW), r2 = l % (nH * nW), th = th0 + r2 / nW, tw = tw0 + r2 % nW;
+    const int id = rd - q.pd + q.sd * td, ih = rh - q.ph + q.sh * th, iw = rw - q.pw + q.sw * tw;
+    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW;
     const int KV = q.KD * q.KH * q.KW;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        int64_t r = idx; const int iw = (int)(r % q.IW); r /= q.IW; const int ih = (int)(r % q.IH); r /= q.IH;
-        const int id = (int)(r % q.ID); const int b = (int)(r / q.ID);
-        float acc[CIN];
+    const float* gb = dY + (int64_t)b * Cout * osz;
+    float acc[CIN];
 #pragma unroll
-        for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
-        for (int kd = (id + q.pd) % q.sd; kd < q.KD; kd += q.sd) {
-            const int od = (id + q.pd - kd) / q.sd; if (id + q.pd - kd < 0 || od >= q.OD) continue;
-            for (int kh = (ih + q.ph) % q.sh; kh < q.KH; kh += q.sh) {
-                const int oh = (ih + q.ph - kh) / q.sh; if (ih + q.ph - kh < 0 || oh >= q.OH) continue;
-                for (int kw = (iw + q.pw) % q.sw; kw < q.KW; kw += q.sw) {
-                    const int ow = (iw + q.pw - kw) / q.sw; if (iw + q.pw - kw < 0 || ow >= q.OW) continue;
-                    const float* g = dY + (int64_t)b * Cout * osz + ((int64_t)od * q.OH + oh) * q.OW + ow;
-                    const float* w = W + (kd * q.KH + kh) * q.KW + kw;
-                    for (int co = 0; co < Cout; ++co) {
-                        const float gv = g[(int64_t)co * osz];
+    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+    for (int kd = rd, od = td; kd < q.KD; kd += q.sd, --od) {                 // od = (id + pd - kd) / sd = td - m
+        const bool okd = od >= 0 && od < q.OD;
+        for (int kh = rh, oh = th; kh < q.KH; kh += q.sh, --oh) {
+            const bool okh = okd && oh >= 0 && oh < q.OH;
+            for (int kw = rw, ow = tw; kw < q.KW; kw += q.sw, --ow) {
+                const bool ok = okh && ow >= 0 && ow < q.OW;
+                const int64_t goff = ok ? ((int64_t)od * q.OH + oh) * q.OW + ow : 0;
+                const float* w = W + (kd * q.KH + kh) * q.KW + kw;         // uniform
+#pragma unroll 4
+                for (int co = 0; co < Cout; ++co) {
+                    const float gv = ok ? gb[(int64_t)co * osz + goff] : 0.f;
 #pragma unroll
-                        for (int c = 0; c < CIN; ++c) acc[c] += w[((int64_t)co * CIN + c) * KV] * gv;
-                    }
+                    for (int c = 0; c < CIN; ++c) acc[c] += w[((int64_t)co * CIN + c) * KV] * gv;
                 }
             }
         }
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) dX[((int64_t)b * CIN + c) * isz + (idx - (int64_t)b * isz)] = acc[c];
     }
+    const int64_t pos = ((int64_t)id * q.IH + ih) * q.IW + iw;
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) dX[((int64_t)b * CIN + c) * isz + pos] = acc[c];
 }
 
 // out[b][cell] = 1 if the average-pooled |x| summed over channels is > 0 (get_mask: segtran2d.py:229-233, segtran3d.py:266-270)
@@ -443,8 +451,10 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
 extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && geom && B > 0 && Cout > 0, "segx_conv3d_bwd_data_direct: bad args");
     const ConvGeom q = make_geom(geom);
-    const int64_t total = (int64_t)B * q.ID * q.IH * q.IW;
-    dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+    SEGX_REQUIRE(q.sd >= 1 && q.sh >= 1 && q.sw >= 1 && (int64_t)B * q.sd * q.sh * q.sw <= 65535 && (int64_t)q.ID * q.IH * q.IW < 2147483647LL,
+                 "segx_conv3d_bwd_data_direct: bad strides / sample too large");
+    const int64_t per_class = (int64_t)ceil_div(q.ID, q.sd) * ceil_div(q.IH, q.sh) * ceil_div(q.IW, q.sw);      // upper bound of a class's positions
+    dim3 grid((unsigned)((per_class + 255) / 256), (unsigned)(B * q.sd * q.sh * q.sw));
     switch (q.Cin) {
         case 1: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<1>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
         case 2: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<2>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;

@@ -111,32 +111,29 @@ __global__ __launch_bounds__(256) void interp_fwd_kernel(const float* __restrict
 // two row-axis sources are computed once per four outputs, the lateral is read and the result written as float4.  Same blend order
 // as interp_at (x, then y, then z), hence the same bits.
 __global__ __launch_bounds__(256) void interp_fwd_rows_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
-                                                              InterpDims q, int w4, int rpb, int64_t nrows) {
-    const int tr = threadIdx.x / w4, tx = threadIdx.x - tr * w4;
-    if (tr >= rpb) return;
-    const int64_t isz = (int64_t)q.d * q.h * q.w, DH = (int64_t)q.D * q.H;
-    Axis ax[4];
+                                                              InterpDims q, int w4, int rpb, FastDiv divH, FastDiv divW4) {
+    // grid (row blocks of one plane, plane): no 64-bit division anywhere; one output row per thread group of w4 lanes
+    const int tr = fdiv(threadIdx.x, divW4), tx = threadIdx.x - tr * w4;
+    const int row = blockIdx.x * rpb + tr;                                   // (z, y) row of this plane
+    if (tr >= rpb || row >= q.D * q.H) return;
+    const int z = fdiv(row, divH), y = row - z * q.H;
+    const int64_t p = blockIdx.y;
+    const Axis az = axis_src(z, q.d, q.sd), ay = axis_src(y, q.h, q.sh);
+    const float* s = in + p * ((int64_t)q.d * q.h * q.w);
+    const float* r00 = s + (az.i0 * q.h + ay.i0) * q.w; const float* r01 = s + (az.i0 * q.h + ay.i1) * q.w;
+    const float* r10 = s + (az.i1 * q.h + ay.i0) * q.w; const float* r11 = s + (az.i1 * q.h + ay.i1) * q.w;
+    float v[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ax[j] = axis_src(tx * 4 + j, q.w, q.sw);
-    for (int64_t row = (int64_t)blockIdx.x * rpb + tr; row < nrows; row += (int64_t)gridDim.x * rpb) {
-        const int64_t p = row / DH; const int rem = (int)(row - p * DH);
-        const int z = rem / q.H, y = rem - z * q.H;
-        const Axis az = axis_src(z, q.d, q.sd), ay = axis_src(y, q.h, q.sh);
-        const float* s = in + p * isz;
-        const float* r00 = s + ((int64_t)az.i0 * q.h + ay.i0) * q.w; const float* r01 = s + ((int64_t)az.i0 * q.h + ay.i1) * q.w;
-        const float* r10 = s + ((int64_t)az.i1 * q.h + ay.i0) * q.w; const float* r11 = s + ((int64_t)az.i1 * q.h + ay.i1) * q.w;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float l = ax[j].l; const int i0 = ax[j].i0, i1 = ax[j].i1;
-            const float c00 = r00[i0] * (1.f - l) + r00[i1] * l, c01 = r01[i0] * (1.f - l) + r01[i1] * l;
-            const float c10 = r10[i0] * (1.f - l) + r10[i1] * l, c11 = r11[i0] * (1.f - l) + r11[i1] * l;
-            v[j] = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
-        }
-        const int64_t o = row * q.W + tx * 4;
-        if (base) { const float4 bv = *reinterpret_cast<const float4*>(base + o); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+    for (int j = 0; j < 4; ++j) {
+        const Axis ax = axis_src(tx * 4 + j, q.w, q.sw);
+        const float l = ax.l; const int i0 = ax.i0, i1 = ax.i1;
+        const float c00 = r00[i0] * (1.f - l) + r00[i1] * l, c01 = r01[i0] * (1.f - l) + r01[i1] * l;
+        const float c10 = r10[i0] * (1.f - l) + r10[i1] * l, c11 = r11[i0] * (1.f - l) + r11[i1] * l;
+        v[j] = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
     }
+    const int64_t o = (p * q.D * q.H + row) * q.W + tx * 4;
+    if (base) { const float4 bv = *reinterpret_cast<const float4*>(base + o); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+    *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 // adjoint as a GATHER (deterministic, no atomics): an input cell collects from every output cell it was blended into
 __device__ __forceinline__ void cand_range(int i, int n_out, float scale, int& lo, int& hi) {
@@ -240,11 +237,10 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
     const int64_t total = planes * D * H * W;
     const bool al = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
-    if (W % 4 == 0 && W <= 1024 && al) {
+    if (W % 4 == 0 && W <= 1024 && al && planes <= 65535 && (int64_t)d * h * w < 2147483647LL && (int64_t)D * H < 2147483647LL) {
         const int w4 = W / 4, rpb = 256 / w4;
-        const int64_t nrows = planes * D * H;
-        hipLaunchKernelGGL(interp_fwd_rows_kernel, dim3((unsigned)i64min(1 << 20, (nrows + rpb - 1) / rpb)), dim3(256), 0, stream, in, base, out,
-                           make_dims(d, h, w, D, H, W), w4, rpb, nrows);
+        hipLaunchKernelGGL(interp_fwd_rows_kernel, dim3((unsigned)((D * H + rpb - 1) / rpb), (unsigned)planes), dim3(256), 0, stream, in, base, out,
+                           make_dims(d, h, w, D, H, W), w4, rpb, make_fastdiv(H), make_fastdiv(w4));
     } else {
         hipLaunchKernelGGL(interp_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), planes);
     }

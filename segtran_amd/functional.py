@@ -679,9 +679,10 @@ class _InterpAdd(torch.autograd.Function):
         dy = _c(dy)
         dx = None
         if ctx.needs_input_grad[0]:
-            # separable adjoint: innermost axis first (shrinks the tensor fastest), one cheap pass per resized axis
+            # separable adjoint, one pass per resized axis, OUTERMOST axis first: the passes over the big tensors then have a long
+            # contiguous inner extent (float4 kernel); the scalar innermost-axis pass runs last, on the smallest tensor
             cur, dims = dy, [D, H, W]
-            for ax, n_in in ((2, w), (1, h), (0, d)):
+            for ax, n_in in ((0, d), (1, h), (2, w)):
                 if dims[ax] == n_in:
                     continue
                 outer = planes

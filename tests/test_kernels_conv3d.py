@@ -81,13 +81,16 @@ def test_stem_conv2d_on_implicit_gemm(backend):
     close(w.grad, wr.grad, 1e-4)
 
 
-def test_strided_backward_data_direct(backend):
-    """The stem's transposed convolution (7x7x7, stride 2) through the direct gather kernel."""
-    x = rnd(1, 3, 8, 10, 12, seed=9).requires_grad_(True)
-    w = (rnd(6, 3, 7, 7, 7, seed=10) * 0.1).requires_grad_(True)
-    y = SF.conv3d_same(x, w, (2, 2, 2))
+@pytest.mark.parametrize('size,k,stride,cin', [((8, 10, 12), (7, 7, 7), (2, 2, 2), 3), ((7, 9, 11), (3, 3, 3), (2, 2, 2), 2),
+                                                ((6, 9, 8), (3, 5, 3), (1, 2, 3), 4)])
+def test_strided_backward_data_direct(backend, size, k, stride, cin):
+    """The stem's transposed convolution (7x7x7, stride 2) through the residue-class gather kernel; odd sizes and mixed strides
+    exercise classes of different population."""
+    x = rnd(1, cin, *size, seed=9).requires_grad_(True)
+    w = (rnd(6, cin, *k, seed=10) * 0.1).requires_grad_(True)
+    y = SF.conv3d_same(x, w, stride)
     xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
-    yr = _ref_conv(xr, wr, (2, 2, 2))
+    yr = _ref_conv(xr, wr, stride)
     G = rnd(*y.shape, seed=11)
     y.backward(G); yr.backward(G)
     close(x.grad, xr.grad, 1e-4)
