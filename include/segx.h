@@ -207,8 +207,14 @@ int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const fl
                        float* dw, float* db, float* ws, int B, int C, int G, int64_t S, void* stream);
 /* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);
  * out = interp(in) (+ base, the FPN lateral, when base != NULL).  bwd is the exact adjoint, computed as a gather. */
+/* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows) */
+int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);
+/* forward along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chained x -> y -> z it is
+ * bit-identical to segx_interp_linear_fwd (same blends in the same order) and streams at HBM rate */
+int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
+                                void* stream);
 int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
 /* separable form: adjoint along ONE axis of a tensor viewed as [outer, n_out, inner] -> [outer, n_in, inner] */
 int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream);

@@ -203,6 +203,34 @@ __global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __re
     }
 }
 
+// Forward resampling along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chaining the axes
+// x -> y -> z performs exactly the operations of the fused formula in the same order (x blend, then y blend, then z blend), so the
+// result is bit-identical; each pass is a plain stream.  VEC: float4 over the contiguous inner extent.
+template <bool VEC>
+__global__ __launch_bounds__(256) void interp_fwd_axis_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                              int n_in, int n_out, int inner, FastDiv divInner, FastDiv divNout, float scale,
+                                                              int64_t outer) {
+    // grid (chunks of one outer slice's n_out * inner elements, outer slices)
+    const int64_t o = blockIdx.y;
+    const int per = n_out * inner;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+        const int i = fdiv(e, divInner), c = e - i * inner;
+        const Axis a = axis_src(i, n_in, scale);
+        const int64_t ob = o * per + e, i0 = (o * n_in + a.i0) * (int64_t)inner + c, i1 = (o * n_in + a.i1) * (int64_t)inner + c;
+        if (VEC) {
+            const float4 v0 = reinterpret_cast<const float4*>(in)[i0], v1 = reinterpret_cast<const float4*>(in)[i1];
+            float4 r = make_float4(v0.x * (1.f - a.l) + v1.x * a.l, v0.y * (1.f - a.l) + v1.y * a.l, v0.z * (1.f - a.l) + v1.z * a.l,
+                                   v0.w * (1.f - a.l) + v1.w * a.l);
+            if (base) { const float4 b = reinterpret_cast<const float4*>(base)[ob]; r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+            reinterpret_cast<float4*>(out)[ob] = r;
+        } else {
+            float r = in[i0] * (1.f - a.l) + in[i1] * a.l;
+            if (base) r += base[ob];
+            out[ob] = r;
+        }
+    }
+}
+
 static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -232,12 +260,14 @@ extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* 
     hipLaunchKernelGGL(gn_bwd_apply, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, rstd, w, (const float*)gsum, dX, C, G, S);
     return check_launch("segx_groupnorm_bwd");
 }
+static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
+extern "C" int segx_tune(int knob, int value) { if (knob == 1) { g_interp_variant = value; return 0; } return -1; }
 extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                                       void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
     const int64_t total = planes * D * H * W;
     const bool al = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
-    if (W % 4 == 0 && W <= 1024 && al && planes <= 65535 && (int64_t)d * h * w < 2147483647LL && (int64_t)D * H < 2147483647LL) {
+    if (g_interp_variant != 1 && W % 4 == 0 && W <= 1024 && al && planes <= 65535 && (int64_t)d * h * w < 2147483647LL && (int64_t)D * H < 2147483647LL) {
         const int w4 = W / 4, rpb = 256 / w4;
         hipLaunchKernelGGL(interp_fwd_rows_kernel, dim3((unsigned)((D * H + rpb - 1) / rpb), (unsigned)planes), dim3(256), 0, stream, in, base, out,
                            make_dims(d, h, w, D, H, W), w4, rpb, make_fastdiv(H), make_fastdiv(w4));
@@ -245,6 +275,29 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
         hipLaunchKernelGGL(interp_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), planes);
     }
     return check_launch("segx_interp_linear_fwd");
+}
+/* forward along one axis: in [outer, n_in, inner] -> out [outer, n_out, inner] (+ base, same shape as out) */
+extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
+                                           void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(in && out && outer > 0 && outer <= 2147483647LL && n_in > 0 && n_out > 0 && inner > 0 && (int64_t)n_out * inner < 2147483647LL,
+                              "segx_interp_linear_fwd_axis: bad args");
+    const bool vec = inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
+    const int in_ = (int)(vec ? inner / 4 : inner);
+    const int64_t per = (int64_t)n_out * in_;
+    // few slices: many chunks per slice; many slices: one or two chunks each (each thread then handles several elements)
+    const int64_t want = (per + 255) / 256, cap = outer >= 4096 ? 4 : outer >= 256 ? 64 : 4096;
+    const int64_t chunks = want < cap ? want : cap;
+    int64_t o0 = 0;
+    while (o0 < outer) {                               // gridDim.y <= 65535
+        const int64_t n = i64min(65535, outer - o0);
+        const float* bi = base ? base + o0 * n_out * inner : nullptr;
+        if (vec) hipLaunchKernelGGL((interp_fwd_axis_kernel<true>), dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, stream, in + o0 * n_in * inner, bi,
+                                    out + o0 * n_out * inner, n_in, n_out, in_, make_fastdiv(in_), make_fastdiv(n_out), (float)n_in / (float)n_out, n);
+        else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, stream, in + o0 * n_in * inner, bi,
+                                out + o0 * n_out * inner, n_in, n_out, in_, make_fastdiv(in_), make_fastdiv(n_out), (float)n_in / (float)n_out, n);
+        o0 += n;
+    }
+    return check_launch("segx_interp_linear_fwd_axis");
 }
 extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_bwd: bad args");

@@ -261,6 +261,9 @@ class SegxLib:
     def interp_fwd(self, inp, base, out, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_fwd', inp, inp, base, out, planes, d, h, w, D, H, W)
 
+    def interp_fwd_axis(self, inp, base, out, outer, n_in, n_out, inner):
+        self._call('segx_interp_linear_fwd_axis', inp, inp, base, out, outer, n_in, n_out, inner)
+
     def interp_bwd(self, dout, din, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_bwd', dout, dout, din, planes, d, h, w, D, H, W)
 
@@ -367,7 +370,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
