@@ -108,6 +108,8 @@ def main():
     x, raw = engine.synth_batch(args.config, B, dev, seed=1337 + rank)          # disjoint samples per rank
 
     L = segx.lib()
+    for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
+        k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
     for _ in range(args.warmup):
         step(x, raw)
     torch.cuda.synchronize()

@@ -321,6 +321,8 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
 }
 
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+int g_conv_small_policy = 0;          // segx_tune(2, v): 0 = 64-row tile when Cout % 128 in [1, 64]; 1 = only when Cout <= 64 (measured 1 % slower)
+static bool conv_small(int Cout) { return g_conv_small_policy == 1 ? Cout <= 64 : (Cout % 128 >= 1 && Cout % 128 <= 64); }
 
 }  // namespace segx
 
@@ -345,7 +347,7 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads) */
 // split factor of the implicit GEMM (M = Cout, N, K, B samples) on the tile the convolution kernels use for this Cout
 static int conv_splitk(int M, int N, int K, int B) {
-    const bool small = M % 128 >= 1 && M % 128 <= 64;
+    const bool small = conv_small(M);
     double t;
     return best_splitk(tile_info(small ? SEGX_TILE_64x128 : SEGX_TILE_128x128), M, N, K, B, &t);
 }
@@ -372,7 +374,7 @@ extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, 
     GemmArgs g; g.A = W; g.B = X; g.C = Y;
     g.a_b0 = 0; g.a_m = K; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * P; g.c_m = P;
     fill_common(g, Cout, (int)P, K, B, splitk, workspace);
-    const bool vec = aligned16c(W) && K % 4 == 0, small = Cout % 128 >= 1 && Cout % 128 <= 64;
+    const bool vec = aligned16c(W) && K % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
     if (small && vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
@@ -406,7 +408,7 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
     GemmArgs g; g.A = dY; g.B = X; g.C = dWb;
     g.a_b0 = (int64_t)Cout * P; g.a_m = P; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * N; g.c_m = N;
     fill_common(g, Cout, N, (int)P, B, splitk, workspace);
-    const bool vec = aligned16c(dY) && P % 4 == 0, small = Cout % 128 >= 1 && Cout % 128 <= 64;
+    const bool vec = aligned16c(dY) && P % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
     if (small && vec) hipLaunchKernelGGL((conv3d_wgrad_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);

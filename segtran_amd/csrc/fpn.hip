@@ -261,7 +261,12 @@ extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* 
     return check_launch("segx_groupnorm_bwd");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
-extern "C" int segx_tune(int knob, int value) { if (knob == 1) { g_interp_variant = value; return 0; } return -1; }
+namespace segx { extern int g_conv_small_policy; }
+extern "C" int segx_tune(int knob, int value) {
+    if (knob == 1) { g_interp_variant = value; return 0; }
+    if (knob == 2) { segx::g_conv_small_policy = value; return 0; }
+    return -1;
+}
 extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                                       void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
