@@ -155,6 +155,10 @@ int segx_mt_bertadam_step(void* const* params, const void* const* grads, void* c
 int64_t segx_bn_ws_floats(int B, int C);
 int segx_bn_stats(const float* X, float* mean, float* var, float* run_mean, float* run_var, float* ws,
                   int B, int C, int64_t S, float momentum, void* stream);
+/* synchronised BatchNorm (nn.SyncBatchNorm, train2d.py:1109): merge the all-gathered per-rank statistics all[world][2C] = (mean[C], biased
+ * var[C]) of equally sized shards (n_per_rank samples each) into the global mean / biased var and update the running statistics */
+int segx_bn_merge_stats(const float* all, float* mean, float* var, float* run_mean, float* run_var, int world, int C, int64_t n_per_rank,
+                        float momentum, void* stream);
 /* y = act((x - mean) * rsqrt(var + eps) * w + b) with the given (batch or running) statistics */
 int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
                     int B, int C, int64_t S, float eps, int act, void* stream);

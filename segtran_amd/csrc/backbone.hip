@@ -67,6 +67,27 @@ __global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__
     }
 }
 
+// Synchronised BatchNorm: merge the per-rank (mean, biased var) of `world` equally sized shards (Chan et al.) and update the running
+// statistics, one thread per channel.  all: [world][2C] = (mean[C], var[C]) per rank, n = samples per rank.
+__global__ __launch_bounds__(256) void bn_merge_stats_kernel(const float* __restrict__ all, float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int world, int C,
+                                                             float n, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float m = 0.f;
+    for (int r = 0; r < world; ++r) m += all[(int64_t)r * 2 * C + c];
+    m /= (float)world;
+    float v = 0.f;
+    for (int r = 0; r < world; ++r) { const float d = all[(int64_t)r * 2 * C + c] - m; v += all[(int64_t)r * 2 * C + C + c] + d * d; }
+    v /= (float)world;
+    mean[c] = m; var[c] = v;
+    if (run_mean) {
+        const float N = n * (float)world;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (v * N / fmaxf(N - 1.0f, 1.0f));
+    }
+}
+
 // y = act((x - mean) * rstd * w + b): grid (chunks, B*C)
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ var,
                                                          const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ Y,
@@ -622,6 +643,12 @@ extern "C" int segx_bn_stats(const float* X, float* mean, float* var, float* run
     hipLaunchKernelGGL(bn_stats_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, ws, C, S);
     hipLaunchKernelGGL(bn_stats_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, var, run_mean, run_var, B, C, S, momentum, bn_slabs(S));
     return check_launch("segx_bn_stats");
+}
+extern "C" int segx_bn_merge_stats(const float* all, float* mean, float* var, float* run_mean, float* run_var, int world, int C, int64_t n_per_rank,
+                                   float momentum, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(all && mean && var && world > 0 && C > 0 && n_per_rank > 0 && (!run_mean == !run_var), "segx_bn_merge_stats: bad args");
+    hipLaunchKernelGGL(bn_merge_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, all, mean, var, run_mean, run_var, world, C, (float)n_per_rank, momentum);
+    return check_launch("segx_bn_merge_stats");
 }
 extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
                                int B, int C, int64_t S, float eps, int act, void* stream_) {

@@ -462,16 +462,18 @@ class _BNAct(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         S = x.numel() // (B * C)
         if training:
-            mean, var = _empty(x, C), _empty(x, C)
             if _bn_stats_sync is None:
+                mean, var = _empty(x, C), _empty(x, C)
                 L.bn_stats(x, mean, var, run_mean, run_var, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
                 n = B * S
             else:
-                L.bn_stats(x, mean, var, None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
-                mean, var, n = _bn_stats_sync(mean, var, B * S)
-                with torch.no_grad():
-                    run_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                    run_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+                # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
+                loc = _empty(x, 2 * C)
+                L.bn_stats(x, loc[:C], loc[C:], None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+                allv, world = _bn_stats_sync(loc)
+                mean, var = _empty(x, C), _empty(x, C)
+                L.bn_merge_stats(allv, mean, var, run_mean, run_var, world, C, B * S, momentum)
+                n = B * S * world
         else:
             mean, var, n = run_mean, run_var, B * S
         y = torch.empty_like(x)
@@ -486,14 +488,17 @@ class _BNAct(torch.autograd.Function):
         x, mean, var, w, b = ctx.saved_tensors
         B, C, S, eps, act, training, n = ctx.cfg
         dx = torch.empty_like(x)
-        dw, db = _empty(x, C), _empty(x, C)
         dy = _c(dy)
         if training and _bn_grad_sync is not None:
-            # synchronised BN: local sums -> ONE all-reduce of [2C] -> apply with the global sums / global count
+            # synchronised BN: local sums written into one [2C] buffer -> ONE all-reduce -> apply with the global sums / global count.
+            # The parameter gradients stay the LOCAL sums (the flat-gradient all-reduce averages them like every other gradient).
+            both = _empty(x, 2 * C)
+            dw, db = both[:C], both[C:]
             L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act)
-            sdw, sdb = _bn_grad_sync(dw, db)
-            L.bn_act_bwd_apply(dy, x, mean, var, w, b, sdw, sdb, dx, B, C, S, eps, act, 1.0 / n)
+            glob = _bn_grad_sync(both)
+            L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n)
         else:
+            dw, db = _empty(x, C), _empty(x, C)
             L.bn_act_bwd(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0)
         return dx, dw, db, None, None, None, None, None, None
 

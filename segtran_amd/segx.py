@@ -224,6 +224,9 @@ class SegxLib:
     def plane_scale(self, X, gate, Y, planes, S):
         self._call('segx_plane_scale', X, X, gate, Y, planes, S)
 
+    def bn_merge_stats(self, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum):
+        self._call('segx_bn_merge_stats', allv, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum)
+
     def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act):
         self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act)
 
@@ -370,7 +373,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_tune': 'ii', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

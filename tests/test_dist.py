@@ -81,18 +81,23 @@ def _case_dp_step(rank, world, ret):
 
     g = torch.Generator().manual_seed(1)
     X = torch.randn(2, 12, 32, generator=g); T = torch.randn(2, 12, 32, generator=g)
-    # single-process reference over the full batch
+    # single-process reference over the full batch: THREE steps (step 1 arms the overlapped reducer, steps 2-3 run it)
     ref = make()
     oref = BertAdam([dict(params=list(ref.parameters()), weight_decay=1e-4, lr=1e-2)], lr=1e-2, warmup=0.1, t_total=10, global_grad_clip=0.1)
-    oref.zero_grad(); ((ref(X) - T) ** 2).mean().backward(); oref.step()
+    for _ in range(3):
+        oref.zero_grad(); ((ref(X) - T) ** 2).mean().backward(); oref.step()
     # data parallel: one sample per rank
     m = make()
     opt = BertAdam([dict(params=list(m.parameters()), weight_decay=1e-4, lr=1e-2)], lr=1e-2, warmup=0.1, t_total=10, global_grad_clip=0.1)
     red = sdist.GradReducer(opt, bucket_mb=0.01)              # tiny buckets: exercises the multi-bucket path
-    opt.zero_grad(); ((m(X[rank:rank + 1]) - T[rank:rank + 1]) ** 2).mean().backward()
-    red.allreduce_grads()
-    opt.step()
-    ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(m.parameters(), ref.parameters()))
+    in_bwd = []
+    for _ in range(3):
+        opt.zero_grad(); ((m(X[rank:rank + 1]) - T[rank:rank + 1]) ** 2).mean().backward()
+        red.allreduce_grads(); in_bwd.append(red._last_in_backward)
+        opt.step()
+    ok = all(torch.allclose(a, b, atol=2e-6) for a, b in zip(m.parameters(), ref.parameters()))
+    live = sum(1 for need in red._need if need > 0)
+    ok = ok and in_bwd[0] == 0 and in_bwd[1] == live and in_bwd[2] == live and 0 < live <= len(red.buckets)   # every live bucket left during backward
     s = sdist.reduce_scalars(torch.tensor([float(rank), 1.0]))
     ret[rank] = bool(ok and len(red.buckets) > 1 and torch.allclose(s, torch.tensor([0.5, 1.0])))
 
