@@ -210,10 +210,15 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void interp_fwd_axis_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
                                                               int n_in, int n_out, int inner, FastDiv divInner, FastDiv divNout, float scale,
                                                               int64_t outer) {
-    // grid (chunks of one outer slice's n_out * inner elements, outer slices)
-    const int64_t o = blockIdx.y;
+    // flat grid over outer * n_out * inner elements: the (slice, element) split of a workgroup's first element is uniform (scalar
+    // 64-bit division once), the per-thread remainder is a 32-bit multiply-high
     const int per = n_out * inner;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < per; e += gridDim.x * 256) {
+    const int64_t total = outer * per;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divNout);      // divNout = divider by `per`
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
         const int i = fdiv(e, divInner), c = e - i * inner;
         const Axis a = axis_src(i, n_in, scale);
         const int64_t ob = o * per + e, i0 = (o * n_in + a.i0) * (int64_t)inner + c, i1 = (o * n_in + a.i1) * (int64_t)inner + c;
@@ -289,19 +294,12 @@ extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, f
     const bool vec = inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
     const int in_ = (int)(vec ? inner / 4 : inner);
     const int64_t per = (int64_t)n_out * in_;
-    // few slices: many chunks per slice; many slices: one or two chunks each (each thread then handles several elements)
-    const int64_t want = (per + 255) / 256, cap = outer >= 4096 ? 4 : outer >= 256 ? 64 : 4096;
-    const int64_t chunks = want < cap ? want : cap;
-    int64_t o0 = 0;
-    while (o0 < outer) {                               // gridDim.y <= 65535
-        const int64_t n = i64min(65535, outer - o0);
-        const float* bi = base ? base + o0 * n_out * inner : nullptr;
-        if (vec) hipLaunchKernelGGL((interp_fwd_axis_kernel<true>), dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, stream, in + o0 * n_in * inner, bi,
-                                    out + o0 * n_out * inner, n_in, n_out, in_, make_fastdiv(in_), make_fastdiv(n_out), (float)n_in / (float)n_out, n);
-        else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), dim3((unsigned)chunks, (unsigned)n), dim3(256), 0, stream, in + o0 * n_in * inner, bi,
-                                out + o0 * n_out * inner, n_in, n_out, in_, make_fastdiv(in_), make_fastdiv(n_out), (float)n_in / (float)n_out, n);
-        o0 += n;
-    }
+    const int64_t total = outer * per;
+    const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+    if (vec) hipLaunchKernelGGL((interp_fwd_axis_kernel<true>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
+                                make_fastdiv((int)per), (float)n_in / (float)n_out, outer);
+    else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
+                            make_fastdiv((int)per), (float)n_in / (float)n_out, outer);
     return check_launch("segx_interp_linear_fwd_axis");
 }
 extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
