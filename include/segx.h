@@ -233,6 +233,13 @@ int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, in
 int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgrad);
 int segx_conv3d_fwd(const float* X, const float* W /* [Cout][Cin][KD][KH][KW] */, float* Y, int B, int Cout, const int* geom, int splitk,
                     float* workspace, void* stream);
+/* Packed contraction order for Cin % 8 == 0: k runs (channel block of 8, tap, channel in block), so eight consecutive k share one tap and
+ * the im2col loader decodes / masks once per eight gathers.  segx_conv3d_pack_weights writes Wp[o][c/8][t][c%8] from the layer's
+ * W [Cout][Cin][KV]: mode 0 forward filters (o = Cout, c = Cin), mode 1 backward-data filters (o = Cin, c = Cout, transposed + flipped,
+ * for segx_conv3d_fwd_packed(dY, Wp) with pads K-1-p); C = the contracted channel count. */
+int segx_conv3d_pack_weights(const float* W, float* Wp, int O, int C, int KV, int mode, void* stream);
+int segx_conv3d_fwd_packed(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                           void* stream);
 /* Wt[ci][co][t] = W[co][ci][KV-1-t]: backward-data of a stride-1 conv = segx_conv3d_fwd(dY, Wt) with pads K-1-p */
 int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream);
 /* per-sample weight gradients dWb[B][Cout][Cin*KV] (sum over B with segx_colsum); split-K over output positions:

@@ -22,6 +22,11 @@ struct ConvGeom {
 // Per-thread state is ONE element offset of the window origin and the window's validity as bit masks (the whole window when
 // it has <= 32 taps, else one mask per axis), so a gathered element costs ~5 VALU ops (offset add, bit extract, select, mask
 // insert) instead of three coordinate adds + three range compares + the offset arithmetic.
+// PACK8: the contraction index runs (channel block of 8, tap, channel in block) instead of (channel, tap) -- the weights are packed to
+// match (segx_conv3d_pack_weights).  Eight consecutive k then share ONE tap, so a thread's 16 gathers need two tap decodes, two mask
+// tests and a constant channel stride instead of sixteen of each (the decode-free loader experiment ran the big 3x3x3 convolutions
+// at 98 instead of 60 TFLOP/s), while the 27 taps of a channel block stay within 14 k-tiles of each other (L1/L2 reuse).
+template <bool PACK8>
 struct ConvFwdLoaderB {
     const float* X; ConvGeom q; FastDiv dKV, dKHW, dKW;
     int pos_off;                    // ((bd * IH) + bh) * IW + bw of the window origin (may be negative: padding)
@@ -54,6 +59,23 @@ struct ConvFwdLoaderB {
         const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, plane = q.IH * q.IW;
         const int kbase = k0 + (tid >> 7) * (BKT / 2);               // wave-uniform
         float* v = reinterpret_cast<float*>(&r[0]);
+        if (PACK8) {
+            const int chan = q.ID * plane;                           // channel stride
+#pragma unroll
+            for (int sub = 0; sub < BKT / 16; ++sub) {
+                const int kb = kbase + 8 * sub;                      // multiple of 8: one (channel block, tap) pair
+                const bool kok = kb < kend;
+                const int blk = (kok ? kb : 0) >> 3;
+                const int cb = fdiv(blk, dKV), t = blk - cb * KV, kd = fdiv(t, dKHW), t2 = t - kd * KHW, kh = fdiv(t2, dKW), kw = t2 - kh * q.KW;
+                const unsigned bit = single ? (mk0 >> t) & 1u : ((mk0 >> kd) & (mk1 >> kh) & (mk2 >> kw)) & 1u;
+                const bool ok = kok && bit != 0u;
+                const float* p = X + (int64_t)(cb * 8) * chan + (ok ? pos_off + (kd * q.IH + kh) * q.IW + kw : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[8 * sub + j] = p[(int64_t)j * chan];
+                okmask |= (ok ? 0xFFu : 0u) << (8 * sub);
+            }
+            return okmask;
+        }
 #pragma unroll
         for (int i = 0; i < BKT / 2; ++i) {
             const int k = kbase + i;
@@ -131,13 +153,13 @@ struct ConvWgradLoaderB {
 // Cfg: 128 x 128, or 64 x 128 when Cout <= 64 (the I3D stem and the 64-channel branches: half of a 128-row A tile would be
 // clamped duplicates).  The B-side (im2col) loaders above are written for 128 columns.
 using CfgCout64 = TileCfg<2, 2, 1, 2>;
-template <bool VEC, class Cfg>
+template <bool VEC, class Cfg, bool PACK8>
 __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(GemmArgs g, ConvGeom q) {
     static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
     __shared__ __attribute__((aligned(16))) TileLdsT<Cfg> lds;
     const TileCoord t = tile_coord<Cfg>(g);
     const DenseLoader<true, VEC, Cfg::BM> la{g.A, g.a_m, 1, t.m0, g.M};             // weights [Cout][Cin*KV]
-    const ConvFwdLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);             // X[b]
+    const ConvFwdLoaderB<PACK8> lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);      // X[b]
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
@@ -162,6 +184,17 @@ __global__ __launch_bounds__(256) void flip_weights_kernel(const float* __restri
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int t = (int)(i % KV); const int64_t r = i / KV; const int co = (int)(r % Cout), ci = (int)(r / Cout);
         Wt[i] = W[((int64_t)co * Cin + ci) * KV + (KV - 1 - t)];
+    }
+}
+
+// Weights in the PACK8 contraction order: Wp[o][cb][t][cj] (c = 8 cb + cj).  mode 0 (forward): o = co, c = ci, value W[co][ci][t];
+// mode 1 (backward-data): o = ci, c = co, value W[co][ci][KV-1-t] (transposed, spatially flipped).  C = channels contracted over.
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ W, float* __restrict__ Wp, int O, int C, int KV, int mode) {
+    const int64_t total = (int64_t)O * C * KV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cj = (int)(i & 7); int64_t r = i >> 3; const int t = (int)(r % KV); r /= KV; const int cb = (int)(r % (C / 8)), o = (int)(r / (C / 8));
+        const int c = cb * 8 + cj;
+        Wp[i] = mode == 0 ? W[((int64_t)o * C + c) * KV + t] : W[((int64_t)c * O + o) * KV + (KV - 1 - t)];
     }
 }
 
@@ -362,13 +395,14 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
  * workspace (splitk*B*Cout*P floats), reduced deterministically -- for the low-resolution Inception stages whose position grid alone
  * cannot fill the GPU (192 x 588 x 10368: 40 workgroups un-split) */
-extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
-                               void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && W && Y && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_fwd: bad args");
+static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace, bool packed,
+                           hipStream_t stream) {
+    SEGX_REQUIRE(X && W && Y && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_fwd: bad args");
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int K = q.Cin * q.KD * q.KH * q.KW;
     SEGX_REQUIRE(P > 0 && P < 2147483647LL && K > 0, "segx_conv3d_fwd: bad geometry");
     SEGX_REQUIRE((int64_t)q.Cin * q.ID * q.IH * q.IW < 2147483647LL && q.KD <= 32 && q.KH <= 32 && q.KW <= 32, "segx_conv3d_fwd: sample or window too large");
+    SEGX_REQUIRE(!packed || q.Cin % 8 == 0, "segx_conv3d_fwd_packed: Cin = %d is not a multiple of 8", q.Cin);
     if (splitk < 1) splitk = 1;
     SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_fwd: split-K needs a workspace");
     GemmArgs g; g.A = W; g.B = X; g.C = Y;
@@ -377,10 +411,13 @@ extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, 
     const bool vec = aligned16c(W) && K % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
-    if (small && vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
-    else if (small) hipLaunchKernelGGL((conv3d_fwd_kernel<false, CfgCout64>), grid, dim3(256), 0, stream, g, q);
-    else if (vec) hipLaunchKernelGGL((conv3d_fwd_kernel<true, Cfg128>), grid, dim3(256), 0, stream, g, q);
-    else hipLaunchKernelGGL((conv3d_fwd_kernel<false, Cfg128>), grid, dim3(256), 0, stream, g, q);
+#define SEGX_CONV_FWD(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
+                                   else hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
+    if (small && vec) SEGX_CONV_FWD(true, CfgCout64);
+    else if (small) SEGX_CONV_FWD(false, CfgCout64);
+    else if (vec) SEGX_CONV_FWD(true, Cfg128);
+    else SEGX_CONV_FWD(false, Cfg128);
+#undef SEGX_CONV_FWD
     int rc = check_launch("segx_conv3d_fwd");
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;
@@ -388,6 +425,23 @@ extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, 
                        (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
                        (int64_t)0, total);
     return check_launch("segx_conv3d_fwd/reduce");
+}
+extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                               void* stream_) {
+    return conv3d_fwd_impl(X, W, Y, B, Cout, geom, splitk, workspace, false, (hipStream_t)stream_);
+}
+/* the same convolution with the filter bank in the packed contraction order of segx_conv3d_pack_weights (Cin % 8 == 0) */
+extern "C" int segx_conv3d_fwd_packed(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                                      void* stream_) {
+    return conv3d_fwd_impl(X, Wp, Y, B, Cout, geom, splitk, workspace, true, (hipStream_t)stream_);
+}
+/* Wp[o][c/8][t][c%8]: mode 0 = forward filters (o = Cout index, c = Cin index, value W[o][c][t]); mode 1 = backward-data filters
+ * (o = Cin index, c = Cout index, value W[c][o][KV-1-t]); W is always the layer's [Cout][Cin][KV] tensor, C = contracted channels */
+extern "C" int segx_conv3d_pack_weights(const float* W, float* Wp, int O, int C, int KV, int mode, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(W && Wp && O > 0 && C > 0 && C % 8 == 0 && KV > 0 && (mode == 0 || mode == 1), "segx_conv3d_pack_weights: bad args");
+    const int64_t total = (int64_t)O * C * KV;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)i64min(4096, (total + 255) / 256)), dim3(256), 0, stream, W, Wp, O, C, KV, mode);
+    return check_launch("segx_conv3d_pack_weights");
 }
 extern "C" int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int KV, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(W && Wt && Cout > 0 && Cin > 0 && KV > 0, "segx_conv3d_flip_weights: bad args");

@@ -753,7 +753,13 @@ class _Conv3d(torch.autograd.Function):
         y = _empty(x, B, Cout, OD, OH, OW)
         geom = (Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW) + tuple(stride) + (pd, ph, pw)
         sk = L.conv3d_splitk(B, Cout, geom, False)
-        L.conv3d_fwd(x, w, y, B, Cout, geom, sk, _empty(x, sk * y.numel()) if sk > 1 else None)
+        ws = _empty(x, sk * y.numel()) if sk > 1 else None
+        if Cin % 8 == 0:                    # packed contraction order: one tap decode per eight gathers (see conv3d.hip)
+            wp = torch.empty_like(w)
+            L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
+            L.conv3d_fwd(x, wp, y, B, Cout, geom, sk, ws, packed=True)
+        else:
+            L.conv3d_fwd(x, w, y, B, Cout, geom, sk, ws)
         ctx.geom, ctx.stride, ctx.pads = geom, tuple(stride), pads
         ctx.save_for_backward(x, w)
         return y
@@ -772,12 +778,17 @@ class _Conv3d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.stride == (1, 1, 1):
                 wt = _empty(x, Cin, Cout, KD, KH, KW)
-                L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
                 (pd, _), (ph, _), (pw, _) = ctx.pads
                 g2 = (Cout, OD, OH, OW, ID, IH, IW, KD, KH, KW, 1, 1, 1, KD - 1 - pd, KH - 1 - ph, KW - 1 - pw)
                 dx = torch.empty_like(x)
                 sk = L.conv3d_splitk(B, Cin, g2, False)
-                L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, _empty(x, sk * dx.numel()) if sk > 1 else None)
+                ws = _empty(x, sk * dx.numel()) if sk > 1 else None
+                if Cout % 8 == 0:
+                    L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
+                    L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws, packed=True)
+                else:
+                    L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
+                    L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws)
             else:
                 # strided transposed convolution (only the 7x7x7 stride-2 stem, 3 input channels): direct gather kernel
                 dx = torch.empty_like(x)

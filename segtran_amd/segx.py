@@ -305,11 +305,12 @@ class SegxLib:
     def conv3d_splitk(self, B, Cout, geom, wgrad):
         return int(self.c.segx_conv3d_splitk(B, Cout, self._geom(geom), 1 if wgrad else 0))
 
-    def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None):
+    def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None, packed=False):
         self._chk_t(X, W, Y, ws)
         P = geom[4] * geom[5] * geom[6]; K = geom[0] * geom[7] * geom[8] * geom[9]
+        fn = self.c.segx_conv3d_fwd_packed if packed else self.c.segx_conv3d_fwd
         rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk),
-                         lambda: self.c.segx_conv3d_fwd(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))
+                         lambda: fn(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))
         self.check(rc, 'segx_conv3d_fwd')
 
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
@@ -322,6 +323,9 @@ class SegxLib:
 
     def label_nhot(self, labels, out, B, Cin, S, mode):
         self._call('segx_label_nhot', out, labels, out, B, Cin, S, mode)
+
+    def conv3d_pack_weights(self, W, Wp, O, C, KV, mode):
+        self._call('segx_conv3d_pack_weights', W, W, Wp, O, C, KV, mode)
 
     def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
         self._call('segx_conv3d_flip_weights', W, W, Wt, Cout, Cin, KV)
@@ -374,7 +378,7 @@ _SIGS = {
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
     'segx_tune': 'ii', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
-    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
+    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',

@@ -23,7 +23,9 @@ def _ref_conv(x, w, stride):
 
 
 @pytest.mark.parametrize('B,Cin,Cout,size,k,stride', [(2, 8, 12, (4, 6, 5), (3, 3, 3), (1, 1, 1)), (1, 3, 8, (8, 10, 12), (7, 7, 7), (2, 2, 2)),
-                                                      (1, 16, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)), (2, 4, 6, (5, 7, 7), (1, 3, 3), (1, 1, 1))])
+                                                      (1, 16, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)), (2, 4, 6, (5, 7, 7), (1, 3, 3), (1, 1, 1)),
+                                                      (2, 24, 16, (4, 5, 6), (3, 3, 3), (1, 1, 1)),     # packed K order forward AND backward-data
+                                                      (1, 8, 8, (6, 7, 8), (7, 7, 7), (1, 1, 1))])      # packed + per-axis masks (343 taps)
 def test_conv3d_same(backend, B, Cin, Cout, size, k, stride):
     x = rnd(B, Cin, *size, seed=1).requires_grad_(True)
     w = (rnd(Cout, Cin, *k, seed=2) * 0.2).requires_grad_(True)
