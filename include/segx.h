@@ -246,6 +246,11 @@ int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int Cin, int K
  * workspace = splitk*B*Cout*Cin*KV floats when splitk > 1 */
 int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
                            float* workspace, void* stream);
+/* packed-row variant (Cin % 8 == 0): gradient rows ordered [Cout][Cin/8][KV][8] (one tap lookup per eight gathers in the loader);
+ * segx_conv3d_unpack_wgrad(dWp, dW, Cout, Cin, KV) restores the layer's [Cout][Cin][KV] layout (after the sum over the batch) */
+int segx_conv3d_bwd_weight_packed(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
+                                  float* workspace, void* stream);
+int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int KV, void* stream);
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
 int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream);
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */

@@ -106,18 +106,30 @@ struct ConvFwdLoaderB {
 // ---- backward-weight: B(n = (ci, tap), k = output position) ------------------------------------------------------
 // Thread map: ONE output position per thread and k-tile (k0 + (tid & (BKT-1)): a wave reads BKT consecutive positions of
 // one row = whole 128-B lines), 128*BKT/256 rows (tid / BKT) + (256/BKT)*i whose (channel offset, tap) sit in an LDS table.
+// PACK8: the rows run (channel block of 8, tap, channel in block); a thread then owns TWO groups of eight consecutive rows that share a
+// tap (rows 8 g + j and 64 + 8 g + j, g = tid / BKT), so the tap lookup and the three range tests happen twice per k-tile instead
+// of sixteen times, the gathers of a group differ by the channel stride only, and the LDS copy is four float4 stores.  The result is
+// written in the packed row order (segx_conv3d_unpack_wgrad restores [Cout][Cin][KV]).
+template <bool PACK8>
 struct ConvWgradLoaderB {
     const float* X; ConvGeom q; FastDiv dOHW, dOW;
-    const int* rowinfo;                                        // LDS: [128][2] = {channel offset (or -1: row outside N), kd | kh<<10 | kw<<20}
-    // fills the per-row table; the caller must __syncthreads() before the first load
+    const int* rowinfo;                                        // LDS: per row (plain) or per 8-row group (packed): {channel offset (or -1), kd | kh<<10 | kw<<20}
+    // fills the table; the caller must __syncthreads() before the first load
     __device__ __forceinline__ ConvWgradLoaderB(const float* X_, const ConvGeom& q_, int n0, int N, int* rowinfo_lds) : X(X_), q(q_), rowinfo(rowinfo_lds) {
         dOHW = make_fastdiv(q.OH * q.OW); dOW = make_fastdiv(q.OW);
-        if (threadIdx.x < 128) {
-            const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW;
+        const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, chan = q.ID * q.IH * q.IW;
+        if (PACK8) {
+            if (threadIdx.x < 16) {
+                const int n = n0 + 8 * threadIdx.x;                                       // first row of the group; N % 8 == 0
+                const int blk = (n < N ? n : 0) >> 3, cb = blk / KV, t = blk - cb * KV, kd = t / KHW, t2 = t - kd * KHW, kh = t2 / q.KW, kw = t2 - kh * q.KW;
+                rowinfo_lds[2 * threadIdx.x] = n < N ? cb * 8 * chan : -1;
+                rowinfo_lds[2 * threadIdx.x + 1] = kd | (kh << 10) | (kw << 20);
+            }
+        } else if (threadIdx.x < 128) {
             const int n = n0 + threadIdx.x;
             const int nn = n < N ? n : 0;
             const int ci = nn / KV, t = nn - ci * KV, kd = t / KHW, t2 = t - kd * KHW, kh = t2 / q.KW, kw = t2 - kh * q.KW;
-            rowinfo_lds[2 * threadIdx.x] = n < N ? ci * q.ID * q.IH * q.IW : -1;      // < 2^31: checked on the host
+            rowinfo_lds[2 * threadIdx.x] = n < N ? ci * chan : -1;                        // < 2^31: checked on the host
             rowinfo_lds[2 * threadIdx.x + 1] = kd | (kh << 10) | (kw << 20);
         }
     }
@@ -129,6 +141,21 @@ struct ConvWgradLoaderB {
         const int od = fdiv(pp, dOHW), rr = pp - od * q.OH * q.OW, oh = fdiv(rr, dOW), ow = rr - oh * q.OW;
         const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
         float* v = reinterpret_cast<float*>(&r[0]);
+        if (PACK8) {
+            const int64_t chan = (int64_t)q.ID * q.IH * q.IW;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int grp = tid / BKT + 8 * h;
+                const int cb = rowinfo[2 * grp], tp = rowinfo[2 * grp + 1];
+                const int id = bd + (tp & 1023), ih = bh + ((tp >> 10) & 1023), iw = bw + (tp >> 20);
+                const bool ok = pok && cb >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
+                const float* src = X + (ok ? (int64_t)cb + ((int64_t)id * q.IH + ih) * q.IW + iw : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[8 * h + j] = src[j * chan];
+                okmask |= (ok ? 0xFFu : 0u) << (8 * h);
+            }
+            return okmask;
+        }
 #pragma unroll
         for (int i = 0; i < 4 * NP; ++i) {
             const int row = tid / BKT + (256 / BKT) * i;
@@ -144,6 +171,14 @@ struct ConvWgradLoaderB {
     static constexpr bool ROWK = false;             // LDS tile [k][row]: one position (k) per thread, 16 rows
     __device__ __forceinline__ void store(float4 (&r)[NP], unsigned okmask, float* T, int tid) const {
         const int k = tid & (BKT - 1), r0 = tid / BKT;
+        if (PACK8) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {                        // pieces 0,1 = rows 8 r0 .. +7; pieces 2,3 = rows 64 + 8 r0 .. +7
+                const bool ok = (okmask >> (4 * i)) & 1u;
+                *reinterpret_cast<float4*>(T + k * (BN + 4) + 64 * (i >> 1) + 8 * r0 + 4 * (i & 1)) = ok ? r[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            return;
+        }
         const float* v = reinterpret_cast<const float*>(&r[0]);
 #pragma unroll
         for (int i = 0; i < 4 * NP; ++i) T[k * (BN + 4) + r0 + (256 / BKT) * i] = ((okmask >> i) & 1u) ? v[i] : 0.f;
@@ -164,14 +199,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_fwd_kernel(GemmArgs g, ConvGeom
     gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
-template <bool VEC, class Cfg>
+template <bool VEC, class Cfg, bool PACK8>
 __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGeom q) {
     static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
     __shared__ __attribute__((aligned(16))) TileLdsT<Cfg> lds;
     const TileCoord t = tile_coord<Cfg>(g);
     const DenseLoader<true, VEC, Cfg::BM> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};   // dY[b] [Cout][P]
     __shared__ int rowinfo[256];
-    const ConvWgradLoaderB lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, rowinfo);       // X[b]
+    const ConvWgradLoaderB<PACK8> lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, rowinfo);   // X[b]
     __syncthreads();
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
@@ -195,6 +230,15 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         const int cj = (int)(i & 7); int64_t r = i >> 3; const int t = (int)(r % KV); r /= KV; const int cb = (int)(r % (C / 8)), o = (int)(r / (C / 8));
         const int c = cb * 8 + cj;
         Wp[i] = mode == 0 ? W[((int64_t)o * C + c) * KV + t] : W[((int64_t)c * O + o) * KV + (KV - 1 - t)];
+    }
+}
+
+// dW[co][ci][t] = dWp[co][ci/8][t][ci%8]: the packed-row weight gradient back in the layer's layout
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cout, int Cin, int KV) {
+    const int64_t total = (int64_t)Cout * Cin * KV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i % KV); int64_t r = i / KV; const int ci = (int)(r % Cin), co = (int)(r / Cin);
+        dW[i] = dWp[(((int64_t)co * (Cin / 8) + (ci >> 3)) * KV + t) * 8 + (ci & 7)];
     }
 }
 
@@ -450,13 +494,14 @@ extern "C" int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int
     return check_launch("segx_conv3d_flip_weights");
 }
 /* dWb[b][Cout][Cin*KV] per-sample weight gradients (sum over b with segx_colsum); workspace: splitk*B*Cout*Cin*KV floats when splitk > 1 */
-extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
-                                      float* workspace, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && dWb && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_bwd_weight: bad args");
+static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk, float* workspace,
+                             bool packed, hipStream_t stream) {
+    SEGX_REQUIRE(dY && X && dWb && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_bwd_weight: bad args");
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int N = q.Cin * q.KD * q.KH * q.KW;
     SEGX_REQUIRE(P > 0 && P < 2147483647LL && N > 0, "segx_conv3d_bwd_weight: bad geometry");
     SEGX_REQUIRE((int64_t)q.Cin * q.ID * q.IH * q.IW < 2147483647LL && q.KD < 1024 && q.KH < 1024 && q.KW < 1024, "segx_conv3d_bwd_weight: sample too large");
+    SEGX_REQUIRE(!packed || q.Cin % 8 == 0, "segx_conv3d_bwd_weight_packed: Cin = %d is not a multiple of 8", q.Cin);
     if (splitk < 1) splitk = 1;
     SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_bwd_weight: split-K needs a workspace");
     GemmArgs g; g.A = dY; g.B = X; g.C = dWb;
@@ -465,10 +510,13 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
     const bool vec = aligned16c(dY) && P % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
-    if (small && vec) hipLaunchKernelGGL((conv3d_wgrad_kernel<true, CfgCout64>), grid, dim3(256), 0, stream, g, q);
-    else if (small) hipLaunchKernelGGL((conv3d_wgrad_kernel<false, CfgCout64>), grid, dim3(256), 0, stream, g, q);
-    else if (vec) hipLaunchKernelGGL((conv3d_wgrad_kernel<true, Cfg128>), grid, dim3(256), 0, stream, g, q);
-    else hipLaunchKernelGGL((conv3d_wgrad_kernel<false, Cfg128>), grid, dim3(256), 0, stream, g, q);
+#define SEGX_CONV_WG(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
+                                  else hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
+    if (small && vec) SEGX_CONV_WG(true, CfgCout64);
+    else if (small) SEGX_CONV_WG(false, CfgCout64);
+    else if (vec) SEGX_CONV_WG(true, Cfg128);
+    else SEGX_CONV_WG(false, Cfg128);
+#undef SEGX_CONV_WG
     int rc = check_launch("segx_conv3d_bwd_weight");
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;
@@ -476,6 +524,21 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
                        (const float*)nullptr, Cout, N, 1, splitk, g.c_split, (int64_t)Cout * N, (int64_t)0, (int64_t)N, 1.0f, (int)SEGX_BIAS_NONE,
                        (int64_t)0, total);
     return check_launch("segx_conv3d_bwd_weight/reduce");
+}
+extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
+                                      float* workspace, void* stream_) {
+    return conv3d_wgrad_impl(dY, X, dWb, B, Cout, geom, splitk, workspace, false, (hipStream_t)stream_);
+}
+/* the same with the gradient rows in the packed order [Cout][Cin/8][KV][8] (Cin % 8 == 0); segx_conv3d_unpack_wgrad restores [Cout][Cin][KV] */
+extern "C" int segx_conv3d_bwd_weight_packed(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
+                                             float* workspace, void* stream_) {
+    return conv3d_wgrad_impl(dY, X, dWb, B, Cout, geom, splitk, workspace, true, (hipStream_t)stream_);
+}
+extern "C" int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int KV, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dWp && dW && Cout > 0 && Cin > 0 && Cin % 8 == 0 && KV > 0, "segx_conv3d_unpack_wgrad: bad args");
+    const int64_t total = (int64_t)Cout * Cin * KV;
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3((unsigned)i64min(4096, (total + 255) / 256)), dim3(256), 0, stream, dWp, dW, Cout, Cin, KV);
+    return check_launch("segx_conv3d_unpack_wgrad");
 }
 
 static PoolGeom make_pool(const int* g) {

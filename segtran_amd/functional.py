@@ -798,12 +798,16 @@ class _Conv3d(torch.autograd.Function):
             sk = L.conv3d_splitk(B, Cout, geom, True)
             ws = _empty(x, sk * B * Cout * N) if sk > 1 else None
             dwb = _empty(x, B, Cout * N)
-            L.conv3d_bwd_weight(dy, x, dwb, B, Cout, geom, sk, ws)
+            packed = Cin % 8 == 0               # packed row order: one tap lookup per eight gathers (see conv3d.hip)
+            L.conv3d_bwd_weight(dy, x, dwb, B, Cout, geom, sk, ws, packed=packed)
             if B > 1:
                 dw = _empty(x, Cout * N)
                 L.colsum(dwb, dw, _empty(x, L.colreduce_ws(B, Cout * N, 1)), B, Cout * N)
             else:
                 dw = dwb
+            if packed:
+                dwp, dw = dw, _empty(x, Cout * N)
+                L.conv3d_unpack_wgrad(dwp, dw, Cout, Cin, KV)
             dw = dw.view_as(w)
         return dx, dw, None, None
 

@@ -330,14 +330,17 @@ class SegxLib:
     def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
         self._call('segx_conv3d_flip_weights', W, W, Wt, Cout, Cin, KV)
 
-    def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws):
+    def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws, packed=False):
         self._chk_t(dY, X, dWb, ws)
         g = [int(v) for v in geom]
         N, P = g[0] * g[7] * g[8] * g[9], g[4] * g[5] * g[6]
+        fn = self.c.segx_conv3d_bwd_weight_packed if packed else self.c.segx_conv3d_bwd_weight
         rc = self._timed(dWb, 2.0 * B * Cout * P * N, ('conv3d_wgrad', Cout, N, P, B, splitk),
-                         lambda: self.c.segx_conv3d_bwd_weight(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws),
-                                                               self.stream(dWb)))
+                         lambda: fn(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(dWb)))
         self.check(rc, 'segx_conv3d_bwd_weight')
+
+    def conv3d_unpack_wgrad(self, dWp, dW, Cout, Cin, KV):
+        self._call('segx_conv3d_unpack_wgrad', dWp, dWp, dW, Cout, Cin, KV)
 
     def maxpool3d_fwd(self, X, Y, arg, planes, geom):
         self._chk_t(X, Y, arg)
@@ -378,7 +381,7 @@ _SIGS = {
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
     'segx_tune': 'ii', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
-    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp',
+    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
