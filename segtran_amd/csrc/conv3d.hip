@@ -397,6 +397,47 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
     }
 }
 
+// Stride-1 3x3x3 pools (the Inception branch pools, 10 of the 12 per step): a workgroup owns a 4 x 8 x 32 tile of input cells and stages
+// the arg-max indices and gradients of the 6 x 10 x 34 windows that can cover it in LDS once; each cell then probes its 27 windows
+// there (same od, oh, ow order as the generic gather).  The generic kernel issued those 27 probes against L1/L2: 1 TB/s (r01-j PMC).
+constexpr int MP_TD = 4, MP_TH = 8, MP_TW = 32;
+__global__ __launch_bounds__(256) void maxpool3d_bwd_s1k3_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
+                                                                 PoolGeom q, int tiles_h, int tiles_w) {
+    __shared__ int sa[MP_TD + 2][MP_TH + 2][MP_TW + 2];
+    __shared__ float sg[MP_TD + 2][MP_TH + 2][MP_TW + 2];
+    const int64_t p = blockIdx.y;
+    int t = blockIdx.x; const int tw = t % tiles_w; t /= tiles_w; const int th = t % tiles_h, td = t / tiles_h;
+    const int d0 = td * MP_TD, h0 = th * MP_TH, w0 = tw * MP_TW;
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW;
+    const float* g = dY + p * osz; const int* a = arg + p * osz;
+    const int od0 = d0 + q.pd - 2, oh0 = h0 + q.ph - 2, ow0 = w0 + q.pw - 2;           // first window that can cover the tile's first cell
+    constexpr int HN = (MP_TD + 2) * (MP_TH + 2) * (MP_TW + 2);
+    for (int i = threadIdx.x; i < HN; i += 256) {
+        const int hx = i % (MP_TW + 2), r = i / (MP_TW + 2), hy = r % (MP_TH + 2), hz = r / (MP_TH + 2);
+        const int od = od0 + hz, oh = oh0 + hy, ow = ow0 + hx;
+        const bool in = (unsigned)od < (unsigned)q.OD && (unsigned)oh < (unsigned)q.OH && (unsigned)ow < (unsigned)q.OW;
+        const int o = in ? (od * q.OH + oh) * q.OW + ow : 0;
+        sa[hz][hy][hx] = in ? a[o] : -2;
+        sg[hz][hy][hx] = in ? g[o] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MP_TD * MP_TH * MP_TW / 256; ++j) {
+        const int c = threadIdx.x + 256 * j, cx = c % MP_TW, cy = (c / MP_TW) % MP_TH, cz = c / (MP_TW * MP_TH);
+        const int id = d0 + cz, ih = h0 + cy, iw = w0 + cx;
+        if (id >= q.ID || ih >= q.IH || iw >= q.IW) continue;
+        const int li = (id * q.IH + ih) * q.IW + iw;
+        float acc = 0.f;
+#pragma unroll
+        for (int z = 0; z < 3; ++z)
+#pragma unroll
+            for (int y = 0; y < 3; ++y)
+#pragma unroll
+                for (int x = 0; x < 3; ++x) if (sa[cz + z][cy + y][cx + x] == li) acc += sg[cz + z][cy + y][cx + x];
+        dX[p * isz + li] = acc;
+    }
+}
+
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int g_conv_small_policy = 0;          // segx_tune(2, v): 0 = 64-row tile when Cout % 128 in [1, 64]; 1 = only when Cout <= 64 (measured 1 % slower)
 static bool conv_small(int Cout) { return g_conv_small_policy == 1 ? Cout <= 64 : (Cout % 128 >= 1 && Cout % 128 <= 64); }
@@ -564,6 +605,11 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.ID * q.IH * q.IW;
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
+    if (q.KD == 3 && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && planes <= 65535) {
+        const int td = ceil_div(q.ID, MP_TD), th = ceil_div(q.IH, MP_TH), tw = ceil_div(q.IW, MP_TW);
+        hipLaunchKernelGGL(maxpool3d_bwd_s1k3_kernel, dim3((unsigned)(td * th * tw), (unsigned)planes), dim3(256), 0, stream, dY, arg, dX, q, th, tw);
+        return check_launch("segx_maxpool3d_bwd");
+    }
     hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
     return check_launch("segx_maxpool3d_bwd");
 }
