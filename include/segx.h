@@ -252,7 +252,8 @@ int segx_conv3d_bwd_weight_packed(const float* dY, const float* X, float* dWb, i
                                   float* workspace, void* stream);
 int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int KV, void* stream);
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
-int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream);
+int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws /* Cout*Cin*KV floats of scratch */, int B, int Cout,
+                                const int* geom, void* stream);
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
 int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream);
 /* in-step label -> n-hot maps (datasets2d.py:90-139,200-223; datasets3d.py:16-40): mode 0 fundus uint8 [B,Cin,S] -> [B,3,S];

@@ -233,6 +233,72 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// Register-tiled variant: a thread owns FOUR consecutive positions of its class along W.  With at most 4 taps per axis (K <= 4 s) the
+// 4 positions x 4 w-taps read a window of 7 dY values per (kd, kh, co) instead of 16 -- the scalar kernel above is bound by exactly
+// those L1 loads (4096 per position).
+template <int CIN>
+__global__ __launch_bounds__(256) void conv3d_bwd_data_direct4_kernel(const float* __restrict__ dY, const float* __restrict__ Wt, float* __restrict__ dX,
+                                                                      int B, int Cout, ConvGeom q) {
+    const int nph = q.sd * q.sh * q.sw, b = blockIdx.y / nph, ph = blockIdx.y - b * nph;
+    const int rd = ph / (q.sh * q.sw), rh = (ph / q.sw) % q.sh, rw = ph % q.sw;
+    const int td0 = rd >= q.pd ? 0 : (q.pd - rd + q.sd - 1) / q.sd, td1 = (q.ID - 1 + q.pd - rd) >= 0 ? (q.ID - 1 + q.pd - rd) / q.sd : -1;
+    const int th0 = rh >= q.ph ? 0 : (q.ph - rh + q.sh - 1) / q.sh, th1 = (q.IH - 1 + q.ph - rh) >= 0 ? (q.IH - 1 + q.ph - rh) / q.sh : -1;
+    const int tw0 = rw >= q.pw ? 0 : (q.pw - rw + q.sw - 1) / q.sw, tw1 = (q.IW - 1 + q.pw - rw) >= 0 ? (q.IW - 1 + q.pw - rw) / q.sw : -1;
+    const int nD = td1 - td0 + 1, nH = th1 - th0 + 1, nW = tw1 - tw0 + 1;
+    if (nD <= 0 || nH <= 0 || nW <= 0) return;
+    const int nW4 = (nW + 3) >> 2;
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= nD * nH * nW4) return;
+    const int td = td0 + l / (nH * nW4), r2 = l % (nH * nW4), th = th0 + r2 / nW4, twb = tw0 + 4 * (r2 % nW4);
+    const int nkw = (q.KW - rw + q.sw - 1) / q.sw;                               // w-taps of this class: kw = rw + sw * m, m < nkw <= 4
+    const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW;
+    const float* gb = dY + (int64_t)b * Cout * osz;
+    float acc[4][CIN];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) acc[j][c] = 0.f;
+    // window columns ow = twb - 3 + i (i = 0..6): position j with w-tap m reads ow = twb + j - m = column i = j - m + 3
+    int colo[7]; bool colok[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { const int ow = twb - 3 + i; colok[i] = ow >= 0 && ow < q.OW; colo[i] = colok[i] ? ow : 0; }
+    for (int kd = rd, od = td; kd < q.KD; kd += q.sd, --od) {
+        if (od < 0 || od >= q.OD) continue;
+        for (int kh = rh, oh = th; kh < q.KH; kh += q.sh, --oh) {
+            if (oh < 0 || oh >= q.OH) continue;
+            const float* grow = gb + ((int64_t)od * q.OH + oh) * q.OW;
+            const float* wrow = Wt + (int64_t)((kd * q.KH + kh) * q.KW + rw) * Cout * CIN;      // tap (kd, kh, kw = rw); next w-tap: + sw * Cout * CIN
+            const int64_t wstep = (int64_t)q.sw * Cout * CIN;
+            for (int co = 0; co < Cout; ++co) {
+                const float* g = grow + (int64_t)co * osz;
+                float win[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { const float v = g[colo[i]]; win[i] = colok[i] ? v : 0.f; }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (m >= nkw) break;
+                    const float* w = wrow + m * wstep + co * CIN;                              // uniform
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) {
+                        const float wv = w[c];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j][c] += wv * win[j - m + 3];
+                    }
+                }
+            }
+        }
+    }
+    const int id = rd - q.pd + q.sd * td, ih = rh - q.ph + q.sh * th;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int iw = rw - q.pw + q.sw * (twb + j);
+        if (twb + j > tw1) continue;
+        const int64_t pos = ((int64_t)id * q.IH + ih) * q.IW + iw;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) dX[((int64_t)b * CIN + c) * isz + pos] = acc[j][c];
+    }
+}
+
 // dW[co][ci][t] = dWp[co][ci/8][t][ci%8]: the packed-row weight gradient back in the layer's layout
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cout, int Cin, int KV) {
     const int64_t total = (int64_t)Cout * Cin * KV;
@@ -252,8 +318,17 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 // neighbouring dY elements (coalesced).  The earlier position-major kernel re-read the filter bank per lane with two different
 // tap sets per wave: 11.9 ms and 22 GB fetched for a 58 MB result (r01-g PMC).
 // grid: (position blocks of the class, B * sd*sh*sw)
+// filters for the residue-class kernel: Wt[tap][co][ci] = W[co][ci][tap], so a workgroup's uniform (tap, co) walk reads consecutive
+// floats (wide scalar loads)
+__global__ __launch_bounds__(256) void tapmajor_weights_kernel(const float* __restrict__ W, float* __restrict__ Wt, int Cout, int Cin, int KV) {
+    const int64_t total = (int64_t)Cout * Cin * KV;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % Cin); const int64_t r = i / Cin; const int co = (int)(r % Cout), t = (int)(r / Cout);
+        Wt[i] = W[((int64_t)co * Cin + c) * KV + t];
+    }
+}
 template <int CIN>
-__global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ dX,
+__global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float* __restrict__ dY, const float* __restrict__ Wt, float* __restrict__ dX,
                                                                      int B, int Cout, ConvGeom q) {
     const int nph = q.sd * q.sh * q.sw, b = blockIdx.y / nph, ph = blockIdx.y - b * nph;
     const int rd = ph / (q.sh * q.sw), rh = (ph / q.sw) % q.sh, rw = ph % q.sw;
@@ -268,7 +343,6 @@ __global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float
     const int td = td0 + l / (nH * nW), r2 = l % (nH * nW), th = th0 + r2 / nW, tw = tw0 + r2 % nW;
     const int id = rd - q.pd + q.sd * td, ih = rh - q.ph + q.sh * th, iw = rw - q.pw + q.sw * tw;
     const int64_t isz = (int64_t)q.ID * q.IH * q.IW, osz = (int64_t)q.OD * q.OH * q.OW;
-    const int KV = q.KD * q.KH * q.KW;
     const float* gb = dY + (int64_t)b * Cout * osz;
     float acc[CIN];
 #pragma unroll
@@ -278,14 +352,14 @@ __global__ __launch_bounds__(256) void conv3d_bwd_data_direct_kernel(const float
         for (int kh = rh, oh = th; kh < q.KH; kh += q.sh, --oh) {
             const bool okh = okd && oh >= 0 && oh < q.OH;
             for (int kw = rw, ow = tw; kw < q.KW; kw += q.sw, --ow) {
-                const bool ok = okh && ow >= 0 && ow < q.OW;
-                const int64_t goff = ok ? ((int64_t)od * q.OH + oh) * q.OW + ow : 0;
-                const float* w = W + (kd * q.KH + kh) * q.KW + kw;         // uniform
+                if (!(okh && ow >= 0 && ow < q.OW)) continue;               // lanes outside dY sit this tap out (exec mask, no selects)
+                const float* g = gb + ((int64_t)od * q.OH + oh) * q.OW + ow;
+                const float* w = Wt + (int64_t)((kd * q.KH + kh) * q.KW + kw) * Cout * CIN;      // uniform, contiguous over (co, ci)
 #pragma unroll 4
                 for (int co = 0; co < Cout; ++co) {
-                    const float gv = ok ? gb[(int64_t)co * osz + goff] : 0.f;
+                    const float gv = g[(int64_t)co * osz];
 #pragma unroll
-                    for (int c = 0; c < CIN; ++c) acc[c] += w[((int64_t)co * CIN + c) * KV] * gv;
+                    for (int c = 0; c < CIN; ++c) acc[c] += w[co * CIN + c] * gv;
                 }
             }
         }
@@ -613,18 +687,35 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
     return check_launch("segx_maxpool3d_bwd");
 }
-extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, int B, int Cout, const int* geom, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && geom && B > 0 && Cout > 0, "segx_conv3d_bwd_data_direct: bad args");
+/* wt_ws: Cout*Cin*KV floats of scratch (the filters are re-laid out tap-major once per call) */
+extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws, int B, int Cout, const int* geom, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && W && dX && wt_ws && geom && B > 0 && Cout > 0, "segx_conv3d_bwd_data_direct: bad args");
     const ConvGeom q = make_geom(geom);
     SEGX_REQUIRE(q.sd >= 1 && q.sh >= 1 && q.sw >= 1 && (int64_t)B * q.sd * q.sh * q.sw <= 65535 && (int64_t)q.ID * q.IH * q.IW < 2147483647LL,
                  "segx_conv3d_bwd_data_direct: bad strides / sample too large");
+    const int KV = q.KD * q.KH * q.KW;
+    const int64_t wtot = (int64_t)Cout * q.Cin * KV;
+    hipLaunchKernelGGL(tapmajor_weights_kernel, dim3((unsigned)i64min(1024, (wtot + 255) / 256)), dim3(256), 0, stream, W, wt_ws, Cout, q.Cin, KV);
     const int64_t per_class = (int64_t)ceil_div(q.ID, q.sd) * ceil_div(q.IH, q.sh) * ceil_div(q.IW, q.sw);      // upper bound of a class's positions
     dim3 grid((unsigned)((per_class + 255) / 256), (unsigned)(B * q.sd * q.sh * q.sw));
+    const float* Wt = wt_ws;
+    if (q.KW <= 4 * q.sw) {                       // register-tiled: four positions per thread along W
+        const int64_t per4 = (int64_t)ceil_div(q.ID, q.sd) * ceil_div(q.IH, q.sh) * ceil_div(ceil_div(q.IW, q.sw), 4) + ceil_div(q.ID, q.sd) * ceil_div(q.IH, q.sh);
+        dim3 grid4((unsigned)((per4 + 255) / 256), (unsigned)(B * q.sd * q.sh * q.sw));
+        switch (q.Cin) {
+            case 1: hipLaunchKernelGGL((conv3d_bwd_data_direct4_kernel<1>), grid4, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+            case 2: hipLaunchKernelGGL((conv3d_bwd_data_direct4_kernel<2>), grid4, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+            case 3: hipLaunchKernelGGL((conv3d_bwd_data_direct4_kernel<3>), grid4, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+            case 4: hipLaunchKernelGGL((conv3d_bwd_data_direct4_kernel<4>), grid4, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+            default: return segx::fail(-1, "segx_conv3d_bwd_data_direct: built for Cin <= 4 (the I3D stem), got %d", q.Cin);
+        }
+        return check_launch("segx_conv3d_bwd_data_direct");
+    }
     switch (q.Cin) {
-        case 1: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<1>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
-        case 2: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<2>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
-        case 3: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<3>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
-        case 4: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<4>), grid, dim3(256), 0, stream, dY, W, dX, B, Cout, q); break;
+        case 1: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<1>), grid, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+        case 2: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<2>), grid, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+        case 3: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<3>), grid, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
+        case 4: hipLaunchKernelGGL((conv3d_bwd_data_direct_kernel<4>), grid, dim3(256), 0, stream, dY, Wt, dX, B, Cout, q); break;
         default: return segx::fail(-1, "segx_conv3d_bwd_data_direct: built for Cin <= 4 (the I3D stem), got %d", q.Cin);
     }
     return check_launch("segx_conv3d_bwd_data_direct");

@@ -314,8 +314,9 @@ class SegxLib:
         self.check(rc, 'segx_conv3d_fwd')
 
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
+        wt = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
         self._chk_t(dY, W, dX)
-        rc = self.c.segx_conv3d_bwd_data_direct(_ptr(dY), _ptr(W), _ptr(dX), B, Cout, self._geom(geom), self.stream(dX))
+        rc = self.c.segx_conv3d_bwd_data_direct(_ptr(dY), _ptr(W), _ptr(dX), _ptr(wt), B, Cout, self._geom(geom), self.stream(dX))
         self.check(rc, 'segx_conv3d_bwd_data_direct')
 
     def nonzero_mask(self, X, out, B, C, D, H, W, kd, kh, kw):
@@ -382,7 +383,7 @@ _SIGS = {
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
     'segx_tune': 'ii', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
-    'segx_conv3d_bwd_data_direct': 'pppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
+    'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',

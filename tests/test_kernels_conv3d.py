@@ -84,7 +84,7 @@ def test_stem_conv2d_on_implicit_gemm(backend):
 
 
 @pytest.mark.parametrize('size,k,stride,cin', [((8, 10, 12), (7, 7, 7), (2, 2, 2), 3), ((7, 9, 11), (3, 3, 3), (2, 2, 2), 2),
-                                                ((6, 9, 8), (3, 5, 3), (1, 2, 3), 4)])
+                                                ((6, 9, 8), (3, 5, 3), (1, 2, 3), 4), ((6, 8, 9), (3, 3, 5), (2, 2, 1), 2)])    # last: 5 w-taps -> scalar kernel
 def test_strided_backward_data_direct(backend, size, k, stride, cin):
     """The stem's transposed convolution (7x7x7, stride 2) through the residue-class gather kernel; odd sizes and mixed strides
     exercise classes of different population."""
