@@ -187,6 +187,54 @@ __global__ __launch_bounds__(256) void posbias_bwd_table_kernel(const float* __r
 // =================================================================================================
 // LayerNorm (eps 1e-12, N4): fwd, dX.  (:262,361 affine; :889 non-affine -> w == nullptr)
 // =================================================================================================
+// Softmax over rows of ANY width (token counts that are not a multiple of 4 -- an 88 x 88 image gives 11 x 11 = 121 tokens -- or exceed
+// the 4096 a register-resident row holds): one workgroup per row, three passes over the row (max, sum, write), which stay in L1/L2.
+// Same clamp rule and the same Philox stream indexing (element row * L + c) in forward and backward.
+__global__ __launch_bounds__(256) void softmax_fwd_generic_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd,
+                                                                  int64_t rows, int L, float clip, const float* __restrict__ gmax,
+                                                                  float p, uint64_t seed, uint64_t off) {
+    __shared__ float red[4];
+    const bool clamp = gmax && (*gmax > clip);
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float* s = S + row * L;
+        float m = -INFINITY;
+        for (int c = threadIdx.x; c < L; c += 256) { float v = s[c]; if (clamp) v = fminf(fmaxf(v, -clip), clip); m = fmaxf(m, v); }
+        m = block_max<4>(m, red);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < L; c += 256) { float v = s[c]; if (clamp) v = fminf(fmaxf(v, -clip), clip); sum += expf(v - m); }
+        sum = block_sum<4>(sum, red);
+        for (int c = threadIdx.x; c < L; c += 256) {
+            float v = s[c]; if (clamp) v = fminf(fmaxf(v, -clip), clip);
+            const float pr = expf(v - m) / sum;
+            P[row * L + c] = pr;
+            if (Pd) Pd[row * L + c] = pr * dropout_scale(seed, off, (uint64_t)row * L + c, p, ik);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_generic_kernel(const float* __restrict__ P, const float* __restrict__ dPd, const float* __restrict__ S,
+                                                                  float* __restrict__ dS, int64_t rows, int L, float clip,
+                                                                  const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off) {
+    __shared__ float red[4];
+    const bool clamp = gmax && S && (*gmax > clip);
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+        float dot = 0.f;
+        for (int c = threadIdx.x; c < L; c += 256) {
+            float g = dPd[row * L + c];
+            if (p > 0.f) g *= dropout_scale(seed, off, (uint64_t)row * L + c, p, ik);
+            dot += P[row * L + c] * g;
+        }
+        dot = block_sum<4>(dot, red);
+        for (int c = threadIdx.x; c < L; c += 256) {
+            float g = dPd[row * L + c];
+            if (p > 0.f) g *= dropout_scale(seed, off, (uint64_t)row * L + c, p, ik);
+            float d = P[row * L + c] * (g - dot);
+            if (clamp && !(fabsf(S[row * L + c]) <= clip)) d = 0.f;
+            dS[row * L + c] = d;
+        }
+    }
+}
 template <int NV4>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ w, const float* __restrict__ b,
                                                             float* __restrict__ Y, float* __restrict__ mean_o, float* __restrict__ rstd_o,
@@ -597,14 +645,22 @@ using namespace segx;
 
 extern "C" int segx_softmax_fwd(const float* S, float* P, float* Pdrop, int64_t rows, int L, float clip, const float* gmax,
                                 float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(S && P && rows > 0, "segx_softmax_fwd: bad args"); SEGX_ROWCHK(L);
+    SEGX_STREAM; SEGX_REQUIRE(S && P && rows > 0 && L > 0, "segx_softmax_fwd: bad args");
     SEGX_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || Pdrop), "segx_softmax_fwd: dropout needs Pdrop");
+    if (L % 4 != 0 || L > 4096) {
+        hipLaunchKernelGGL(softmax_fwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset);
+        return check_launch("segx_softmax_fwd");
+    }
     SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset));
     return check_launch("segx_softmax_fwd");
 }
 extern "C" int segx_softmax_bwd(const float* P, const float* dPdrop, const float* S, float* dS, int64_t rows, int L, float clip,
                                 const float* gmax, float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(P && dPdrop && dS && rows > 0, "segx_softmax_bwd: bad args"); SEGX_ROWCHK(L);
+    SEGX_STREAM; SEGX_REQUIRE(P && dPdrop && dS && rows > 0 && L > 0, "segx_softmax_bwd: bad args");
+    if (L % 4 != 0 || L > 4096) {
+        hipLaunchKernelGGL(softmax_bwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset);
+        return check_launch("segx_softmax_bwd");
+    }
     SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset));
     return check_launch("segx_softmax_bwd");
 }

@@ -287,8 +287,8 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'backbone._blocks.31._bn1.bias', 'backbone._conv_head.weight']
 
 
-def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, **over):
-    net = R.ref_segtran2d(num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0, **over)
+def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fundus', **over):
+    net = R.ref_segtran2d(num_classes=3 if task == 'fundus' else 2, num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0, **over)
     sd = load_synth(net)
     if train:
         net.train()
@@ -298,8 +298,15 @@ def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, **over):
     g = torch.Generator().manual_seed(16)
     x = torch.randn(B, 3, S, S, generator=g)
     mask = synth_fundus_mask(B, S, 1338)
-    nhot = O.fundus_map_mask(mask)
-    pw = O.bce_pos_weight([0., 1., 2.])
+    if task == 'polyp':                                   # single 0/255 channel tiled x3 (datasets2d.py:313-327), mapped by the REFERENCE function
+        mask = mask[:, :1].repeat(1, 3, 1, 1)
+        ref_map = _ref_functions('dataloaders/datasets2d.py', ['polyp_map_mask'])['polyp_map_mask']
+        nhot = O.polyp_map_mask(mask)
+        assert torch.equal(nhot, ref_map(mask.float()).float()) or torch.equal(nhot, ref_map(mask).float())
+        pw = O.bce_pos_weight([0., 1.])
+    else:
+        nhot = O.fundus_map_mask(mask)
+        pw = O.bce_pos_weight([0., 1., 2.])
     y = R.quiet(net, x)
     loss, ce, dice, _ = O.seg_loss(y, nhot, pw)          # composition restated; pinned separately by case_loss
     loss.backward()
@@ -311,7 +318,7 @@ def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, **over):
     rg = dict(net.named_parameters())
     gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
     arrs = dict(x=x, mask=mask, logits=y, labels=(y > 0), loss=loss.detach(), margin=y.abs().min().detach(),
-                dims=np.array(dims), A=np.array(A), train=np.array(int(train)))
+                dims=np.array(dims), A=np.array(A), train=np.array(int(train)), nhot=nhot.to(torch.uint8))
     for k in GRAD_KEYS_2D:
         if k not in rg:
             continue
@@ -348,10 +355,17 @@ GRAD_KEYS_3D = ['in_bridge_to3.weight', 'out_conv3d.weight', 'out_fpn_bridgeconv
                 'backbone.Mixed_5c.b0.conv3d.weight']
 
 
+def case_seg2d_polyp():
+    """cfg3 flags (polyp: 2 classes, 3 layers with compression) at 88 x 88 -> an 11 x 11 token grid (odd, not a power of two)"""
+    run_seg2d('seg2d_cfg3_polyp_train', 3, (1, 1, 2, 2), [1792, 1792, 896, 448], 32, 1, 88, True, task='polyp')
+
+
 def case_seg3d():
-    for tag, train in (('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)):
+    for tag, train, tl, comp in (('seg3d_cfg4_eval', False, 1, (1, 1)), ('seg3d_cfg4_train', True, 1, (1, 1)), ('seg3d_cfg5_eval', False, 2, (1, 1, 1))):
+        if len(sys.argv) > 2 and tag not in sys.argv[2:]:
+            continue
         A = 64
-        net = R.ref_segtran3d(num_attractors=A, dropout_prob=0)
+        net = R.ref_segtran3d(num_attractors=A, num_translayers=tl, compress=comp, dropout_prob=0)
         sd = load_synth(net)
         net.train() if train else net.eval()
         x, lab = synth_brats(1, 112, 112, 16, 1337)
@@ -360,13 +374,13 @@ def case_seg3d():
         y = R.quiet(net, x)
         loss = O.seg_loss(y, nhot, pw)[0]; loss.backward()
         sdg = req(sd)
-        yo = O.segtran3d_forward(sdg, x, [1024, 1024], training=train)
+        yo = O.segtran3d_forward(sdg, x, [1024] * (tl + 1), training=train)
         lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
         close(yo, y, 3e-5, tag + ' logits')
         og = oracle_grads(sdg); rg = dict(net.named_parameters())
         gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
         arrs = dict(x_sample=sample(x), logits=sample(y, 65536), labels=np.packbits((y > 0).numpy()),
-                    loss=loss.detach(), margin=y.abs().min().detach(), A=np.array(A), train=np.array(int(train)))
+                    loss=loss.detach(), margin=y.abs().min().detach(), A=np.array(A), train=np.array(int(train)), tl=np.array(tl))
         for k in GRAD_KEYS_3D:
             gr = rg[k].grad
             assert (og[k] - gr).abs().max().item() <= 3e-4 * gscale, (k, (og[k] - gr).abs().max().item(), gscale)
@@ -541,11 +555,11 @@ def case_keys():
 
 
 CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, eval=case_eval, effnet=case_effnet, i3d=case_i3d,
-             seg2d=case_seg2d, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
+             seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 
 if __name__ == '__main__':
-    todo = sys.argv[1:] or list(CASES)
+    todo = [a for a in sys.argv[1:] if a in CASES] or list(CASES)        # further arguments select sub-cases (see case_seg3d)
     for c in todo:
         print('[golden] ' + c)
         CASES[c]()

@@ -205,3 +205,42 @@ def test_eval_path_3d_vs_reference():
         assert torch.equal(D3.make_brats_pred_consistent(p, k).cpu(), g['cons_true' if k else 'cons_false'])
     assert torch.equal(D3.brats_inv_map_label(g['inv_in'].to(DEV)).cpu(), g['inv'])
     assert torch.equal(D3.harden_segmap3d(p).cpu(), g['harden3d'].int())
+
+
+def test_segtran2d_polyp_cfg3_vs_reference():
+    """cfg3 flags: polyp task (2 classes, label map through segx_label_nhot), 3 layers with compression, 88 x 88 -> 11 x 11 tokens."""
+    g = golden('seg2d_cfg3_polyp_train')
+    net = engine.build_model(dict(engine.CONFIGS['cfg3'], size=(88, 88)), DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.backbone.drop_connect_rate = 0.0
+    net.train()
+    y = net(g['x'].to(DEV))
+    assert_close(y, g['logits'], 1e-4, 'logits')
+    safe = g['logits'].abs() > 1e-4                       # batch-1 train-mode BatchNorm (see the 3-D train fixture)
+    assert torch.equal((y.cpu() > 0)[safe], g['labels'][safe]), 'hardened label map differs'
+    nhot = engine.map_mask('polyp', g['mask'].to(DEV))
+    assert torch.equal(nhot.cpu(), g['nhot'].float())
+    pw, cw = engine.loss_weights('polyp', DEV)
+    loss, _ = SF.seg_loss(y, nhot, pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 5e-5
+    loss.backward()
+    _grads_vs_golden(net, g, tol=2e-3)
+
+
+def test_segtran3d_cfg5_two_layers_vs_reference():
+    g = golden('seg3d_cfg5_eval')
+    c = dict(engine.CONFIGS['cfg5'], size=(112, 112, 16))
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.eval()
+    x, lab = synth_brats(1, 112, 112, 16, 1337)
+    assert torch.equal(sample(x), g['x_sample'])
+    y = net(x.to(DEV))
+    assert_close(sample(y.cpu(), 65536), g['logits'], 1e-4, 'logits')
+    ref_bits = np.unpackbits(g['labels'].numpy())[:y.numel()].astype(bool)
+    got = (y.detach().cpu() > 0).numpy().reshape(-1)
+    ok = (y.detach().cpu().abs() > 1e-5).numpy().reshape(-1)
+    assert np.array_equal(got[ok], ref_bits[ok])
+    pw, cw = engine.loss_weights('brats', DEV)
+    loss, _ = SF.seg_loss(y, engine.map_mask('brats', lab.to(DEV)), pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    loss.backward()
+    _grads_vs_golden(net, g)
