@@ -244,3 +244,43 @@ def test_segtran3d_cfg5_two_layers_vs_reference():
     assert abs(loss.item() - float(g['loss'])) < 2e-5
     loss.backward()
     _grads_vs_golden(net, g)
+
+
+@pytest.mark.parametrize('shape', [(1, 3, 72, 104), (2, 3, 40, 56), (1, 3, 576, 576)])       # last: 5184 tokens (> the 4096 a register row holds)
+def test_ragged_2d_sizes_vs_oracle(shape):
+    """Non-square inputs whose token grid (H/8 x W/8 = 9 x 13, 5 x 7) is odd in both directions: forward against the CPU oracle,
+    backward finite.  (The reference accepts any H, W divisible by 8.)"""
+    from oracle import segtran_oracle as O
+    from segtran_amd.synth import synth_state_dict
+    c = dict(engine.CONFIGS['cfg2'], size=shape[2:])
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=32)
+    net.eval()
+    x = torch.randn(*shape, generator=torch.Generator(device='cpu').manual_seed(5), device='cpu')
+    y = net(x.to(DEV))
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    with torch.no_grad(), torch.device('cpu'):
+        yo = O.segtran2d_forward(sd, x, [1792, 1792, 896, 448])
+    assert_close(y.cpu(), yo, 1e-4, 'logits')
+    safe = yo.abs() > 1e-5
+    assert torch.equal((y.cpu() > 0)[safe], (yo > 0)[safe])
+    y.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+def test_ragged_3d_size_vs_oracle():
+    """112 x 120 x 24 volume (token grid 14 x 15 x 3 -> 630 tokens, not a multiple of 4) against the CPU oracle."""
+    from oracle import segtran_oracle as O
+    from segtran_amd.synth import synth_state_dict
+    c = dict(engine.CONFIGS['cfg4'], size=(112, 120, 24))
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=32)
+    net.eval()
+    x, _ = synth_brats(1, 112, 120, 24, 77)
+    y = net(x.to(DEV))
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    with torch.no_grad(), torch.device('cpu'):
+        yo = O.segtran3d_forward(sd, x, [1024, 1024])
+    assert_close(y.cpu(), yo, 1e-4, 'logits')
+    safe = yo.abs() > 1e-5
+    assert torch.equal((y.cpu() > 0)[safe], (yo > 0)[safe])
+    y.sum().backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
