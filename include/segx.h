@@ -109,7 +109,8 @@ int segx_posembed_bwd(const float* dOut, const float* posn, const float* Wp, con
                       int64_t N, int C, int pd, void* stream);
 /* Expansion tail: MMPrivateOutput dropout + LayerNorm (:273-274) and LearnedSoftAggregate (:318-325) fused.
  *   Z [Mo, R, F] (mode-major) -> Y [R, F];  stats = 3*Mo*R floats (mean, rstd, mode probability).
- * Backward: dZ + dscore [Mo*R]; parameter grads via segx_modes_aggr_param_grad (ws: nout = 3), dba = sum(dscore). */
+ * Backward: dZ + dscore [Mo*R]; parameter grads via segx_modes_aggr_param_grad (ws: nout = 3), dba = sum(dscore).
+ * lnw == lnb == NULL: no LayerNorm -- the soft aggregate runs on the raw mode features (ExpandedFeatTrans without FFN, :452-457). */
 int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float* lnb, const float* wa, const float* ba, float* Y, float* stats,
                         int Mo, int64_t R, int F, float eps, float p, uint64_t seed, uint64_t offset, void* stream);
 int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
@@ -211,6 +212,11 @@ int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const fl
                        float* dw, float* db, float* ws, int B, int C, int G, int64_t S, void* stream);
 /* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);
  * out = interp(in) (+ base, the FPN lateral, when base != NULL).  bwd is the exact adjoint, computed as a gather. */
+/* PolyformerLayer glue (networks/polyformer.py:36-55): nn.AvgPool2d(2) on [planes, H, W] (+ adjoint) and the batched transpose
+ * [batch, R, C] -> [batch, C, R] between channel-major feature maps and token-major rows */
+int segx_avgpool2_fwd(const float* X, float* Y, int64_t planes, int H, int W, void* stream);
+int segx_avgpool2_bwd(const float* dY, float* dX, int64_t planes, int H, int W, void* stream);
+int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* stream);
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,

@@ -95,6 +95,22 @@ def squeezed_att_feat_trans(sd, p, in_feat, num_modes=4, attn_clip=500., stats=N
     return cross_att_feat_trans(sd, p + '.ator_out_trans', in_feat, att2, num_modes, True, attn_clip, stats=stats)
 
 
+def polyformer_layer(sd, p, in_feat, num_modes=4, attn_clip=500., do_layernorm=False):
+    """PolyformerLayer.forward (networks/polyformer.py:36-57): 2x average pool, squeeze-and-expansion attention pair WITHOUT FFN
+    (M modes aggregated on the raw features, then first_norm_layer), bilinear up-sampling, residual."""
+    B, C = in_feat.shape[:2]
+    half0 = F.avg_pool2d(in_feat, 2)                                          # :40
+    half = half0.transpose(1, -1)                                             # :41 (chan_axis = 1)
+    if do_layernorm:
+        half = F.layer_norm(half, (C,), None, None, LN_EPS)                   # :44-45
+    vfeat = half.reshape(B, -1, C)                                            # :46
+    att = sd[p + '.attractors'].expand(B, -1, -1)                             # :48
+    att2 = cross_att_feat_trans(sd, p + '.in_ator_trans', att, vfeat, num_modes, False, attn_clip)
+    vout = cross_att_feat_trans(sd, p + '.ator_out_trans', vfeat, att2, num_modes, False, attn_clip)
+    out_half = vout.transpose(1, -1).reshape(half0.shape)                     # :51-52 (sic: the same transpose/reshape pair as the reference)
+    return in_feat + F.interpolate(out_half, size=in_feat.shape[2:], mode='bilinear', align_corners=False)
+
+
 def learned_sinu_pos_embed(sd, p, pos_normed):
     """LearnedSinuPosEmbedder.forward  (segtran_shared.py:989-998), omega=1, no affine."""
     z = F.linear(pos_normed, sd[p + '.pos_fc.weight'], sd[p + '.pos_fc.bias'])

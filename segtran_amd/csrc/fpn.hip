@@ -236,6 +236,32 @@ __global__ __launch_bounds__(256) void interp_fwd_axis_kernel(const float* __res
     }
 }
 
+// nn.AvgPool2d(2) (PolyformerLayer.pool2x, polyformer.py:28,40): [planes, H, W] -> [planes, H/2, W/2] (floor), and its adjoint
+__global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t planes, int H, int W) {
+    const int OH = H / 2, OW = W / 2; const int64_t total = planes * OH * OW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int ox = (int)(i % OW); const int64_t r = i / OW; const int oy = (int)(r % OH); const int64_t p = r / OH;
+        const float* x = X + (p * H + 2 * oy) * W + 2 * ox;
+        Y[i] = ((x[0] + x[1]) + (x[W] + x[W + 1])) * 0.25f;
+    }
+}
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const float* __restrict__ dY, float* __restrict__ dX, int64_t planes, int H, int W) {
+    const int OH = H / 2, OW = W / 2; const int64_t total = planes * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x = (int)(i % W); const int64_t r = i / W; const int y = (int)(r % H); const int64_t p = r / H;
+        dX[i] = (y / 2 < OH && x / 2 < OW) ? 0.25f * dY[(p * OH + y / 2) * OW + x / 2] : 0.f;
+    }
+}
+// batched 2-D transpose [batch, R, C] -> [batch, C, R] through a 32 x 33 LDS tile (channel-major feature maps <-> token-major rows)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ X, float* __restrict__ Y, int R, int C) {
+    __shared__ float tile[32][33];
+    const int64_t b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8 threads
+    for (int j = ty; j < 32; j += 8) if (r0 + j < R && c0 + tx < C) tile[j][tx] = X[(b * R + r0 + j) * C + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) if (c0 + j < C && r0 + tx < R) Y[(b * C + c0 + j) * R + r0 + tx] = tile[tx][j];
+}
+
 static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -264,6 +290,26 @@ extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* 
     hipLaunchKernelGGL(gn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)psum, w, gsum, dw, db, B, C, G);
     hipLaunchKernelGGL(gn_bwd_apply, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, rstd, w, (const float*)gsum, dX, C, G, S);
     return check_launch("segx_groupnorm_bwd");
+}
+extern "C" int segx_avgpool2_fwd(const float* X, float* Y, int64_t planes, int H, int W, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Y && planes > 0 && H >= 2 && W >= 2, "segx_avgpool2_fwd: bad args");
+    const int64_t total = planes * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, X, Y, planes, H, W);
+    return check_launch("segx_avgpool2_fwd");
+}
+extern "C" int segx_avgpool2_bwd(const float* dY, float* dX, int64_t planes, int H, int W, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && dX && planes > 0 && H >= 2 && W >= 2, "segx_avgpool2_bwd: bad args");
+    const int64_t total = planes * H * W;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dY, dX, planes, H, W);
+    return check_launch("segx_avgpool2_bwd");
+}
+extern "C" int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Y && batch > 0 && R > 0 && C > 0 && (R + 31) / 32 <= 65535, "segx_transpose: bad args");
+    for (int64_t b0 = 0; b0 < batch; b0 += 65535) {                        // gridDim.z <= 65535
+        const int64_t n = i64min(65535, batch - b0);
+        hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32, (unsigned)n), dim3(256), 0, stream, X + b0 * R * C, Y + b0 * R * C, R, C);
+    }
+    return check_launch("segx_transpose");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
 namespace segx { extern int g_conv_small_policy; }

@@ -503,10 +503,12 @@ __global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __rest
             const float4 k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
             SEGX_F4_OP(z[m].v[i], z[m].v[i].x * k.x, z[m].v[i].y * k.y, z[m].v[i].z * k.z, z[m].v[i].w * k.w);
         }
-        float mean, rstd; row_stats(z[m], F, eps, mean, rstd);
+        float mean = 0.f, rstd = 1.f;                     // lnw == NULL: aggregate the raw mode features (no-FFN branch, :452-457)
+        if (lnw) row_stats(z[m], F, eps, mean, rstd);
         float s = 0.f;
         SEGX_FOR_ROW(i, c4, F) {
-            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], bb = reinterpret_cast<const float4*>(lnb)[c4];
+            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 bb = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 aa = reinterpret_cast<const float4*>(wa)[c4];
             SEGX_F4_OP(z[m].v[i], (z[m].v[i].x - mean) * rstd * ww.x + bb.x, (z[m].v[i].y - mean) * rstd * ww.y + bb.y,
                        (z[m].v[i].z - mean) * rstd * ww.z + bb.z, (z[m].v[i].w - mean) * rstd * ww.w + bb.w);
@@ -556,7 +558,8 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
         SEGX_FOR_ROW(i, c4, F) {
             float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
             if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
-            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], bb = reinterpret_cast<const float4*>(lnb)[c4];
+            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 bb = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
             s += (((z.v[i].x * k.x - mean) * rstd * ww.x + bb.x) * g.v[i].x + ((z.v[i].y * k.y - mean) * rstd * ww.y + bb.y) * g.v[i].y) +
                  (((z.v[i].z * k.z - mean) * rstd * ww.z + bb.z) * g.v[i].z + ((z.v[i].w * k.w - mean) * rstd * ww.w + bb.w) * g.v[i].w);
         }
@@ -580,14 +583,15 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
             float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
             if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
             kk.v[i] = k;
-            const float4 ww = reinterpret_cast<const float4*>(lnw)[c4], aa = reinterpret_cast<const float4*>(wa)[c4];
+            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 aa = reinterpret_cast<const float4*>(wa)[c4];
             SEGX_F4_OP(zh.v[i], (zh.v[i].x * k.x - mean) * rstd, (zh.v[i].y * k.y - mean) * rstd, (zh.v[i].z * k.z - mean) * rstd, (zh.v[i].w * k.w - mean) * rstd);
             SEGX_F4_OP(d.v[i], (pr[m] * g.v[i].x + ds * aa.x) * ww.x, (pr[m] * g.v[i].y + ds * aa.y) * ww.y,
                        (pr[m] * g.v[i].z + ds * aa.z) * ww.z, (pr[m] * g.v[i].w + ds * aa.w) * ww.w);
         }
 #pragma unroll
         for (int i = 0; i < NV4; ++i) if (!(((threadIdx.x & 63) + 64 * i) * 4 < F)) zh.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        ln_bwd_row(d, zh, F, rstd);
+        if (lnw) ln_bwd_row(d, zh, F, rstd);
         SEGX_FOR_ROW(i, c4, F) SEGX_F4_OP(d.v[i], d.v[i].x * kk.v[i].x, d.v[i].y * kk.v[i].y, d.v[i].z * kk.v[i].z, d.v[i].w * kk.v[i].w);
         row_store(d, dZ + mr * F, F);
     }
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(256) void modes_aggr_pgrad_stage1(const float* __re
     const int64_t per = (R + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(R, r0 + per);
     if (c >= F) return;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    const float w = lnw[c], b = lnb[c], a = wa[c];
+    const float w = lnw ? lnw[c] : 1.f, b = lnw ? lnb[c] : 0.f, a = wa[c];      // lnw == NULL: no LayerNorm (stats hold mean 0, rstd 1)
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int m = 0; m < Mo; ++m)
         for (int64_t r = r0; r < r1; ++r) {
@@ -739,7 +743,7 @@ extern "C" int segx_posembed_bwd(const float* dOut, const float* posn, const flo
     else return segx::fail(-1, "num_modes %d unsupported (1 or 4)", (int)(Mo));
 extern "C" int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float* lnb, const float* wa, const float* ba, float* Y, float* stats,
                                    int Mo, int64_t R, int F, float eps, float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(Z && lnw && lnb && wa && ba && Y && stats && R > 0, "segx_modes_aggr_fwd: bad args"); SEGX_ROWCHK(F);
+    SEGX_STREAM; SEGX_REQUIRE(Z && (!lnw == !lnb) && wa && ba && Y && stats && R > 0, "segx_modes_aggr_fwd: bad args"); SEGX_ROWCHK(F);
     SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_fwd: F=%d too wide for the register-resident 4-mode kernel", F);
     SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
         hipLaunchKernelGGL((modes_aggr_fwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset),
@@ -748,7 +752,7 @@ extern "C" int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float
 }
 extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
                                    float* dZ, float* dscore, int Mo, int64_t R, int F, float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && Z && lnw && lnb && wa && stats && dZ && dscore && R > 0, "segx_modes_aggr_bwd: bad args"); SEGX_ROWCHK(F);
+    SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dZ && dscore && R > 0, "segx_modes_aggr_bwd: bad args"); SEGX_ROWCHK(F);
     SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_bwd: F=%d too wide for the register-resident 4-mode kernel", F);
     SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
         hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset),
@@ -758,7 +762,7 @@ extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float*
 extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
                                           const float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws, int Mo, int64_t R, int F,
                                           float p, uint64_t seed, uint64_t offset, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && Z && lnw && lnb && wa && stats && dscore && dlnw && dlnb && dwa && ws && R > 0, "segx_modes_aggr_param_grad: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dscore && dlnw && dlnb && dwa && ws && R > 0, "segx_modes_aggr_param_grad: bad args");
     const int nch = chunks_for(R);
     hipLaunchKernelGGL(modes_aggr_pgrad_stage1, dim3((F + 255) / 256, nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dscore, ws, Mo, R, F, nch, p, seed, offset);
     hipLaunchKernelGGL(colreduce_stage2, dim3((F + 255) / 256), dim3(256), 0, stream, (const float*)ws, dlnw, dlnb, dwa, (int64_t)F, nch, 3);

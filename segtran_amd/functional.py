@@ -65,6 +65,26 @@ def _grad_operand(L, dC, other, s, which, like):
         rows, cols, st, ost = s.N, s.K, s.b, s.a      # dB(n,k) = alpha sum_m dC(m,n) A(m,k)
     inner = s.N if which == 'a' else s.M
     bcast = [(st[i] == 0 and nb[i] > 1) for i in (0, 1)]
+    partial = any(bcast) and not all(bcast[i] or nb[i] == 1 for i in (0, 1))
+    if partial:
+        # shared across ONE batch dim while the other one walks it (attractors shared by the batch, split into modes: Polyformer's
+        # in-squeeze): one slab in the operand's own layout per broadcast index, then a deterministic sum over the slabs
+        bd = 0 if bcast[0] else 1
+        assert like.is_contiguous() and (st[2] == 1 or st[3] == 1)
+        k_contig = st[3] == 1
+        n = like.numel()
+        tmp = torch.zeros(nb[bd], n, dtype=torch.float32, device=dC.device) if n != rows * cols * nb[1 - bd] else _empty(dC, nb[bd], n)
+        tgt_b = (n, st[1]) if bd == 0 else (st[0], n)
+        row_stride = st[2] if k_contig else st[3]
+        dc_as_rows = (s.c[0], s.c[1], s.c[2], 1) if which == 'a' else (s.c[0], s.c[1], 1, s.c[2])
+        oth = (ost[0], ost[1], ost[3], ost[2])
+        if k_contig:
+            _run_gemm(L, dC, other, tmp, rows, cols, inner, dc_as_rows, oth, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+        else:
+            _run_gemm(L, other, dC, tmp, cols, rows, inner, oth, dc_as_rows, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+        out = torch.empty_like(like)
+        L.colsum(tmp, out, _empty(dC, L.colreduce_ws(nb[bd], n, 1)), nb[bd], n)
+        return out
     if any(bcast):
         # operand shared across a batch dim: per-batch partial grads, then a deterministic column sum
         assert st[2] == 1 or st[3] == 1
@@ -386,16 +406,69 @@ class _ModesAggr(torch.autograd.Function):
         dZ = torch.empty_like(Z)
         dscore = _empty(Z, Mo * R)
         L.modes_aggr_bwd(dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
-        dlnw, dlnb, dwa = _empty(Z, Fd), _empty(Z, Fd), _empty(Z, Fd)
+        dlnw, dlnb, dwa = _empty(Z, Fd), _empty(Z, Fd), _empty(Z, Fd)             # lnw None (no LayerNorm): dlnw / dlnb are scratch
         L.modes_aggr_param_grad(dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa,
                                 _empty(Z, L.colreduce_ws(R, Fd, 3)), Mo, R, Fd, p, seed, off)
         dba = _empty(Z, 1)
         L.sum(dscore, Mo * R, dba, _empty(Z, 1024))
+        if lnw is None:
+            dlnw = dlnb = None
         return dZ, dlnw, dlnb, dwa.view(wa_shape), dba, None
 
 
 def modes_aggr(Z, lnw, lnb, wa, ba, drop_p=0.0):
+    """lnw = lnb = None: soft aggregation of the raw mode features (no LayerNorm)."""
     return _ModesAggr.apply(Z, lnw, lnb, wa, ba, float(drop_p))
+
+
+class _AvgPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = segx.lib()
+        x = _c(x)
+        B, C, H, W = x.shape
+        y = _empty(x, B, C, H // 2, W // 2)
+        L.avgpool2_fwd(x, y, B * C, H, W)
+        ctx.shape = (B, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        B, C, H, W = ctx.shape
+        dx = _empty(dy, B, C, H, W)
+        L.avgpool2_bwd(_c(dy), dx, B * C, H, W)
+        return dx
+
+
+def avg_pool2(x):
+    """nn.AvgPool2d(2) on [B, C, H, W]."""
+    return _AvgPool2.apply(x)
+
+
+class _Transpose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        L = segx.lib()
+        x = _c(x)
+        B, R, C = x.shape
+        y = _empty(x, B, C, R)
+        L.transpose(x, y, B, R, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        dy = _c(dy)
+        B, C, R = dy.shape
+        dx = _empty(dy, B, R, C)
+        L.transpose(dy, dx, B, C, R)
+        return dx
+
+
+def transpose12(x):
+    """[B, R, C] -> [B, C, R] as a contiguous tensor."""
+    return _Transpose.apply(x)
 
 
 # -------------------------------------------------------------------------------------------------

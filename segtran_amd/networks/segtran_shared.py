@@ -180,11 +180,15 @@ class ExpandedFeatTrans(nn.Module):
                                   (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M)))
         agg = self.feat_softaggr.feat2score
         if not self.has_FFN:
-            # LearnedSoftAggregate over M modes, then first_norm_layer (:452-457).  Built for the squeeze path
-            # where M == 1: the aggregate is the identity, its parameters get exact-zero gradients (N3).
-            assert M == 1, 'no-FFN branch is only built for num_modes == 1 (in-squeeze)'
-            y = SF.modes_aggr(fused.view(1, B * U1, Fd), self.first_norm_layer.weight, self.first_norm_layer.bias,
-                              agg.weight, agg.bias, 0.0)
+            # LearnedSoftAggregate over M modes, then first_norm_layer (:452-457).
+            if M == 1:
+                # squeeze path: the aggregate is the identity, its parameters get exact-zero gradients (N3); LN + aggregate fused
+                y = SF.modes_aggr(fused.view(1, B * U1, Fd), self.first_norm_layer.weight, self.first_norm_layer.bias,
+                                  agg.weight, agg.bias, 0.0)
+                return y.view(B, U1, Fd)
+            # Polyformer: aggregate the raw mode features (scores from the un-normalised features), then LayerNorm
+            y = SF.modes_aggr(fused.view(M, B * U1, Fd), None, None, agg.weight, agg.bias, 0.0)
+            y = SF.layer_norm(y, self.first_norm_layer.weight, self.first_norm_layer.bias)
             return y.view(B, U1, Fd)
         mid, out = self.intermediate.shared_linear, self.output
         h = SF.linear(fused, mid.weight, mid.bias, gelu=True, drop_p=drop)               # MMSharedMid :232-251

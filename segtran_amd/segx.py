@@ -283,6 +283,15 @@ class SegxLib:
             return rc
         return fn()
 
+    def avgpool2_fwd(self, X, Y, planes, H, W):
+        self._call('segx_avgpool2_fwd', X, X, Y, planes, H, W)
+
+    def avgpool2_bwd(self, dY, dX, planes, H, W):
+        self._call('segx_avgpool2_bwd', dY, dY, dX, planes, H, W)
+
+    def transpose(self, X, Y, batch, R, C):
+        self._call('segx_transpose', X, X, Y, batch, R, C)
+
     # ---- evaluation path (infer.hip) --------------------------------------------------------------
     def window_accum(self, scores, acc, cnt, B, C, geom):
         self._chk_t(scores, acc, cnt)
@@ -381,7 +390,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_tune': 'ii', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

@@ -193,6 +193,40 @@ def case_fusion_nosqueeze():
         save('fusion_nosqueeze_' + tag, **arrs)
 
 
+def case_polyformer():
+    """PolyformerLayer (no-FFN 4-mode attention pair on a 2x-pooled map + residual), square and non-square maps
+    (the reference maps the w-major token order back as (row, col): quirk N10)."""
+    R._install_stubs()
+    from networks.polyformer import Polyformer
+    for tag, (C, H, W) in {'sq': (64, 12, 12), 'rect': (32, 8, 12)}.items():
+        mod = R.quiet(Polyformer, C)
+        layer = mod.polyformer_layers[0]
+        layer.attractors.data = layer.attractors.data[:, :16]                 # 16 attractors keep the fixture small
+        prefix = 'polyformer.polyformer_layers.0.'
+        shapes = {prefix + k: tuple(v.shape) for k, v in layer.state_dict().items()}
+        sd = synth_state_dict(shapes)
+        layer.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+        mod.eval()                                                            # attention dropout (default 0.2) off
+        g = torch.Generator().manual_seed(41)
+        X = torch.randn(2, C, H, W, generator=g).abs().requires_grad_(True)   # post-ReLU like
+        G = torch.randn(2, C, H, W, generator=g)
+        Y = mod(X); (Y * G).sum().backward()
+        sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
+        Yo = O.polyformer_layer(sdg, prefix[:-1], Xo, 4); (Yo * G).sum().backward()
+        close(Yo, Y, 1e-5, 'polyformer Y'); close(Xo.grad, X.grad, 1e-4, 'polyformer dX')
+        rg = {prefix + k: p.grad for k, p in layer.named_parameters()}
+        og = {k: v.grad for k, v in sdg.items() if v.grad is not None}
+        arrs = dict(X=X, G=G, Y=Y, dX=X.grad)
+        gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+        for k, v in rg.items():
+            if v is None:
+                continue
+            assert (og[k] - v).abs().max().item() <= 2e-4 * gscale, k
+            arrs['grad:' + k] = v
+        arrs['unused'] = np.array(sorted(k for k, v in rg.items() if v is None))
+        save('polyformer_' + tag, **arrs)
+
+
 def case_posbias():
     ss = R.ref_shared()
     g = torch.Generator().manual_seed(13)
@@ -554,7 +588,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, eval=case_eval, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 

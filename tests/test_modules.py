@@ -190,3 +190,50 @@ def test_i3d_unit_vs_oracle(backend):
         G = torch.randn(*yo.shape, generator=g, device='cpu')
         yo.backward(G); y.backward(G.to(backend.dev))
         assert_close(xp.grad, xo.grad, 3e-4, 'unit3d dx')
+
+
+@pytest.mark.parametrize('tag', ['sq', 'rect'])
+def test_polyformer_layer_vs_reference(backend, tag):
+    """PolyformerLayer (no-FFN multi-mode attention pair on a pooled map + residual) incl. the reference's
+    w-major token order that is mapped back as (row, col) (N10)."""
+    from segtran_amd.networks.polyformer import Polyformer
+    g = golden_on('polyformer_' + tag, backend.dev)
+    B, C, H, W = g['X'].shape
+    mod = Polyformer(C)
+    layer = mod.polyformer_layers[0]
+    layer.attractors.data = layer.attractors.data[:, :16]
+    prefix = 'polyformer.polyformer_layers.0.'
+    shapes = {prefix + k: tuple(v.shape) for k, v in layer.state_dict().items()}
+    layer.load_state_dict({k[len(prefix):]: v for k, v in synth_state_dict(shapes).items()})
+    mod.to(torch.get_default_device()); mod.eval()
+    X = g['X'].clone().requires_grad_(True)
+    Y = mod(X)
+    assert_close(Y, g['Y'], 2e-5, 'Y')
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g['dX'], 1e-4, 'dX')
+    grads = {prefix + k: p.grad for k, p in layer.named_parameters()}
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('grad:'))
+    for k, v in g.items():
+        if k.startswith('grad:'):
+            assert grads[k[5:]] is not None, k
+            assert_close(grads[k[5:]], v, 3e-4, k[5:], scale=gscale)
+    for k in g['unused']:
+        assert grads[str(k)] is None, k
+
+
+def test_avgpool2_and_transpose(backend):
+    from segtran_amd import functional as SF
+    import torch.nn.functional as F
+    x = torch.randn(2, 3, 7, 10, generator=torch.Generator(device='cpu').manual_seed(8), device='cpu').to(backend.dev).requires_grad_(True)
+    y = SF.avg_pool2(x)
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    yr = F.avg_pool2d(xr, 2)
+    assert_close(y, yr.detach(), 1e-6, 'avgpool')
+    G = torch.randn(*yr.shape, generator=torch.Generator(device='cpu').manual_seed(9), device='cpu')
+    y.backward(G.to(backend.dev)); yr.backward(G)
+    assert_close(x.grad, xr.grad, 1e-6, 'avgpool bwd')
+    t = torch.randn(3, 37, 70, generator=torch.Generator(device='cpu').manual_seed(10), device='cpu').to(backend.dev).requires_grad_(True)
+    tt = SF.transpose12(t)
+    assert torch.equal(tt.cpu(), t.detach().cpu().transpose(1, 2))
+    tt.backward(tt.detach())
+    assert torch.equal(t.grad.cpu(), t.detach().cpu())
