@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
     if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
+#pragma unroll 4
         for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             const float4 v = *reinterpret_cast<const float4*>(x + s);
             const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
     if ((S & 3) == 0) {
+#pragma unroll 4
         for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
             const float h0 = (xv.x - m) * rstd, h1 = (xv.y - m) * rstd, h2 = (xv.z - m) * rstd, h3 = (xv.w - m) * rstd;
