@@ -20,7 +20,8 @@ def init_distributed(backend=None):
     if world <= 1:
         return 0, 0, 1
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
-    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+    # SEGX_DIST_BACKEND=gloo lets two ranks share ONE GPU (RCCL refuses duplicate devices): used by the single-GPU test of this path
+    backend = backend or os.environ.get('SEGX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
     if backend == 'nccl':
         torch.cuda.set_device(local)
     if not dist.is_initialized():
