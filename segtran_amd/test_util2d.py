@@ -86,3 +86,8 @@ def test_all_cases(net, batches, task_name, num_classes, orig_input_size, patch_
         m = calc_batch_metric(preds_soft, gt, num_classes)
         total += m.sum(axis=0); count += len(m)
     return total / max(count, 1), count
+
+
+# reference function names; not pytest tests
+test_single_batch.__test__ = False
+test_all_cases.__test__ = False

@@ -74,3 +74,7 @@ def calculate_metric_percase(allcls_pred, allcls_gt, num_classes):
         valid[c, 2] = valid[c, 3] = 0
         metric[c] = [dice, jc, 0, 0]
     return metric, valid
+
+
+# reference function names; not pytest tests
+test_single_case.__test__ = False
