@@ -223,11 +223,14 @@ int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64
                            void* stream);
 /* forward along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chained x -> y -> z it is
  * bit-identical to segx_interp_linear_fwd (same blends in the same order) and streams at HBM rate */
+/* src_scale: source step per destination index; <= 0 -> n_in / n_out (F.interpolate(size=...)); explicit s reproduces
+ * F.interpolate(scale_factor=1/s) on sizes s does not divide (Mince transformer, reference segtran_shared.py:47-66) */
 int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
-                                void* stream);
+                                float src_scale, void* stream);
 int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
 /* separable form: adjoint along ONE axis of a tensor viewed as [outer, n_out, inner] -> [outer, n_in, inner] */
-int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream);
+int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, float src_scale,
+                                void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Inception-I3D spatial convolutions as implicit GEMM on the fp32 MFMA engine + TF-'same' max-pool (conv3d.hip).

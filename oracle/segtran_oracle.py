@@ -86,6 +86,88 @@ def cross_att_feat_trans(sd, p, in_query, in_key, num_modes, has_ffn, attn_clip=
     return expanded_feat_trans(sd, p + '.out_trans', in_key, probs, M, has_ffn)   # :608
 
 
+def fracs_to_indices(feat_dim, props):
+    """segtran_shared.py:68-87 -- channel boundaries of the mince scales (the last scale takes the remainder)."""
+    fr = [float(v) for v in props]
+    tot = sum(fr)
+    idx = [0]
+    for f in fr[:-1]:
+        idx.append(idx[-1] + int(f / tot * feat_dim))
+    idx.append(feat_dim)
+    return idx
+
+
+def multi_resize_shape(shape, scales):
+    """segtran_shared.py:38-43."""
+    return [tuple(int(s / sc) for s in shape) for sc in scales]
+
+
+def resize_flat_features(x, geoshape, scale=None, orig_geoshape=None):
+    """segtran_shared.py:47-66: tokens [B,M,N,C] -> grid [B,M*C,*geoshape] -> F.interpolate (scale_factor OR size; a given
+    scale_factor is also the coordinate step, ATen's recompute_scale_factor=None rule) -> tokens [B,M,N',C]."""
+    B, M, N, C = x.shape
+    g = x.permute(0, 1, 3, 2).reshape(B, M * C, *geoshape)
+    mode = ('linear', 'bilinear', 'trilinear')[len(geoshape) - 1]
+    g = F.interpolate(g, size=orig_geoshape, scale_factor=scale, mode=mode, align_corners=False)
+    return g.reshape(B, M, C, -1).permute(0, 1, 3, 2)
+
+
+def cross_mince_att_feat_trans(sd, p, in_feat, geoshape, num_modes, mince_scales, mince_channel_props, attn_clip=500.,
+                               pos_biases=None, pos_code_weight=1.0, stats=None):
+    """CrossMinceAttFeatTrans.forward (segtran_shared.py:699-785) + the mince branch of ExpandedFeatTrans.forward (:421-443):
+    self-attention computed separately on S down-sampled copies of the token grid, each scale owning a slice of every mode's
+    Q/K channels (equal split, :633-634) and of the value channels (mince_channel_props, :353-354); fused values are resized
+    back and concatenated.  Query and key are NOT tied here (SegtranInitWeights.tie_qk only matches CrossAttFeatTrans, :1259)."""
+    M = num_modes
+    q = F.linear(in_feat, sd[p + '.query.weight'], sd.get(p + '.query.bias'))          # :707
+    k = F.linear(in_feat, sd[p + '.key.weight'], sd.get(p + '.key.bias'))              # :708
+    B, U, A = q.shape
+    d = A // M
+    q4 = q.view(B, U, M, d).permute(0, 2, 1, 3)
+    k4 = k.view(B, U, M, d).permute(0, 2, 1, 3)
+    qk_idx = fracs_to_indices(d, [1] * len(mince_scales))
+    probs = []
+    for s_, scale in enumerate(mince_scales):
+        L, R = qk_idx[s_], qk_idx[s_ + 1]
+        qs = resize_flat_features(q4[..., L:R], geoshape, 1. / scale)                  # :725-731
+        ks = resize_flat_features(k4[..., L:R], geoshape, 1. / scale)
+        sc = (qs @ ks.transpose(-1, -2)) / math.sqrt(d)                                # :735-736 (sqrt of the FULL mode dim)
+        smax = sc.max().item()
+        if stats is not None:
+            stats.append(smax)
+        if smax > attn_clip:                                                           # :747-749
+            sc = sc.clamp(-attn_clip, attn_clip)
+        if pos_biases is not None and pos_biases[s_] is not None:                      # :760-763
+            sc = sc + pos_code_weight * pos_biases[s_]
+        probs.append(sc.softmax(dim=-1))                                               # :769
+    po = p + '.out_trans'
+    W_v = sd[po + '.first_linear.weight']
+    Fd = W_v.shape[0] // M
+    v4 = (in_feat @ W_v.t()).view(B, U, M, Fd).permute(0, 2, 1, 3)                     # :414-419
+    v_idx = fracs_to_indices(Fd, mince_channel_props)
+    shapes = multi_resize_shape(geoshape, mince_scales)
+    parts = []
+    for s_, scale in enumerate(mince_scales):
+        L, R = v_idx[s_], v_idx[s_ + 1]
+        vs = resize_flat_features(v4[..., L:R], geoshape, 1. / scale)                  # :431
+        fs = probs[s_] @ vs                                                            # :436
+        parts.append(resize_flat_features(fs, shapes[s_], orig_geoshape=tuple(geoshape)))   # :439
+    fused = torch.cat(parts, dim=-1)                                                   # :443
+    return _expanded_tail(sd, po, fused, M)
+
+
+def _expanded_tail(sd, p, fused, M):
+    """ExpandedFeatTrans.forward after the value fusion, FFN branch (:459-476); see expanded_feat_trans."""
+    Fd = fused.shape[-1]
+    h = F.gelu(fused @ sd[p + '.intermediate.shared_linear.weight'].t() + sd[p + '.intermediate.shared_linear.bias'])
+    Wg = sd[p + '.output.group_linear.weight'].view(M, Fd, Fd)
+    bg = sd[p + '.output.group_linear.bias'].view(M, 1, Fd)
+    z = torch.einsum('bmuf,mgf->bmug', h, Wg) + bg
+    zn = _ln(z, sd, p + '.output.resout_norm_layer')                                   # N1: residual dropped
+    sc = zn @ sd[p + '.feat_softaggr.feat2score.weight'].t() + sd[p + '.feat_softaggr.feat2score.bias']
+    return (zn * sc.softmax(dim=1)).sum(dim=1)
+
+
 def squeezed_att_feat_trans(sd, p, in_feat, num_modes=4, attn_clip=500., stats=None):
     """SqueezedAttFeatTrans.forward  (segtran_shared.py:809-816)."""
     B = in_feat.shape[0]
@@ -133,7 +215,7 @@ def sliding_pos_biases(table, shape):
 
 def fusion_encoder(sd, p, vfeat, voxels_pos, vmask, translayer_dims, num_modes=4, attn_clip=500.,
                    pos_code_weight=1.0, stats=None, layers_out=None, squeezed=True, pos_code_type='lsinu',
-                   feat_shape=None):
+                   feat_shape=None, mince_scales=None, mince_channel_props=None):
     """SegtranFusionEncoder.forward  (segtran_shared.py:907-975).  squeezed=False is --nosqueeze (plain multi-mode
     self-attention, :873-878); pos_code_type 'bias' (:937-940, needs feat_shape) adds sliding positional biases to
     the attention scores instead of positional embeddings to the tokens."""
@@ -141,7 +223,12 @@ def fusion_encoder(sd, p, vfeat, voxels_pos, vmask, translayer_dims, num_modes=4
     for i in range(len(translayer_dims) - 1):
         vn = _ln(vfeat, sd, '%s.vfeat_norm_layers.%d' % (p, i))                       # :916
         biases = None
-        if pos_code_type == 'bias':
+        if pos_code_type == 'bias' and mince_scales:
+            # --mince: one bias table per scale, applied on that scale's resized grid (:859-861, :920-923)
+            biases = [sliding_pos_biases(sd['%s.pos_code_layers.%d.pos_coder.biases' % (p, s_)], shp)
+                      for s_, shp in enumerate(multi_resize_shape(feat_shape, mince_scales))]
+            fn = vn
+        elif pos_code_type == 'bias':
             biases = sliding_pos_biases(sd[p + '.pos_code_layer.pos_coder.biases'], feat_shape)   # :927, :1235-1238
             fn = vn                                                                    # :940
         else:
@@ -150,7 +237,10 @@ def fusion_encoder(sd, p, vfeat, voxels_pos, vmask, translayer_dims, num_modes=4
             fn = F.layer_norm(comb, (comb.shape[-1],), None, None, LN_EPS)             # :934 (no affine)
         fm = fn * vmask                                                                # :946
         lp = '%s.translayers.%d' % (p, i)
-        if squeezed:
+        if mince_scales:                                                               # :952-953
+            vfeat = cross_mince_att_feat_trans(sd, lp, fm, tuple(feat_shape), num_modes, mince_scales, mince_channel_props,
+                                               attn_clip, biases, pos_code_weight if biases is not None else 1.0, stats)
+        elif squeezed:
             vfeat = squeezed_att_feat_trans(sd, lp, fm, num_modes, attn_clip, stats)
         else:                                                                          # :955 self-attention
             vfeat = cross_att_feat_trans(sd, lp, fm, fm, num_modes, True, attn_clip, pos_biases=biases,

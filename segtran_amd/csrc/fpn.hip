@@ -334,7 +334,7 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
 }
 /* forward along one axis: in [outer, n_in, inner] -> out [outer, n_out, inner] (+ base, same shape as out) */
 extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
-                                           void* stream_) {
+                                           float src_scale, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && outer > 0 && outer <= 2147483647LL && n_in > 0 && n_out > 0 && inner > 0 && (int64_t)n_out * inner < 2147483647LL,
                               "segx_interp_linear_fwd_axis: bad args");
     const bool vec = inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
@@ -342,10 +342,11 @@ extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, f
     const int64_t per = (int64_t)n_out * in_;
     const int64_t total = outer * per;
     const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+    const float scale = src_scale > 0.f ? src_scale : (float)n_in / (float)n_out;      // explicit = F.interpolate(scale_factor=1/src_scale)
     if (vec) hipLaunchKernelGGL((interp_fwd_axis_kernel<true>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
-                                make_fastdiv((int)per), (float)n_in / (float)n_out, outer);
+                                make_fastdiv((int)per), scale, outer);
     else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
-                            make_fastdiv((int)per), (float)n_in / (float)n_out, outer);
+                            make_fastdiv((int)per), scale, outer);
     return check_launch("segx_interp_linear_fwd_axis");
 }
 extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
@@ -354,14 +355,16 @@ extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t pla
     hipLaunchKernelGGL(interp_bwd_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, make_dims(d, h, w, D, H, W), planes);
     return check_launch("segx_interp_linear_bwd");
 }
-extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, void* stream_) {
+extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, float src_scale,
+                                           void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n_out > 0 && n_in > 0 && inner > 0, "segx_interp_linear_bwd_axis: bad args");
     const int64_t total = outer * n_in * inner;
+    const float scale = src_scale > 0.f ? src_scale : (float)n_in / (float)n_out;
     if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0)
         hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,
-                           n_out, n_in, inner / 4, (float)n_in / (float)n_out);
+                           n_out, n_in, inner / 4, scale);
     else
         hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out,
-                           n_in, inner, (float)n_in / (float)n_out);
+                           n_in, inner, scale);
     return check_launch("segx_interp_linear_bwd_axis");
 }

@@ -96,9 +96,12 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(MtTables T, int chunk, fl
     __shared__ float red[4];
     const int ch = blockIdx.x, t = T.chunk_tensor[ch];
     const int64_t off = T.chunk_off[ch], n = i64min(chunk, T.sizes[t] - off);
-    const float* g = T.grads[t] + off;
+    const float* gbase = T.grads[t];                       // NULL: the parameter has no gradient (inactive, N3)
     float s = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) { const float x = g[i]; s += x * x; }
+    if (gbase) {
+        const float* g = gbase + off;
+        for (int64_t i = threadIdx.x; i < n; i += 256) { const float x = g[i]; s += x * x; }
+    }
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) chunk_ws[ch] = s;
 }

@@ -109,6 +109,8 @@ class TrainStep:
 
     def __init__(self, net, optimizer, task, reducer=None):
         self.net, self.opt, self.task, self.reducer = net, optimizer, task, reducer
+        if reducer is None and hasattr(optimizer, 'release_flat_grads') and optimizer.step_count == 0:
+            optimizer.release_flat_grads()          # single process: no flat bucket needed, no per-parameter accumulate kernels
         dev = next(net.parameters()).device
         self.pos_weight, self.class_w = loss_weights(task, dev)
         self.stats = None

@@ -800,6 +800,59 @@ def interp_linear(x, size, base=None):
     return _InterpAdd.apply(x, base, tuple(int(s) for s in size))
 
 
+class _InterpTokens(torch.autograd.Function):
+    """Linear resampling of a token grid kept channels-last, [B, prod(in_shape), C] -> [B, prod(out_shape), C]: one streaming pass
+    per resized axis (innermost first = ATen's blend order), the channels riding along as the contiguous inner extent."""
+
+    @staticmethod
+    def forward(ctx, x, in_shape, out_shape, src_scale):
+        L = segx.lib()
+        x = _c(x)
+        B, U, C = x.shape
+        assert U == math.prod(in_shape) and len(in_shape) == len(out_shape)
+        cur, dims = x, list(in_shape)
+        for ax in reversed(range(len(dims))):
+            if dims[ax] == out_shape[ax]:
+                continue
+            outer = B * math.prod(dims[:ax])
+            inner = C * math.prod(dims[ax + 1:])
+            nxt = _empty(x, outer * out_shape[ax] * inner)
+            L.interp_fwd_axis(cur, None, nxt, outer, dims[ax], out_shape[ax], inner, src_scale)
+            cur, dims[ax] = nxt, out_shape[ax]
+        ctx.cfg = (B, C, tuple(in_shape), tuple(out_shape), src_scale)
+        return cur.view(B, -1, C) if cur is not x else x.clone()
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        B, C, in_shape, out_shape, src_scale = ctx.cfg
+        cur, dims = _c(dy), list(out_shape)
+        for ax in range(len(dims)):                       # adjoint passes in the reverse order of the forward ones
+            if dims[ax] == in_shape[ax]:
+                continue
+            outer = B * math.prod(dims[:ax])
+            inner = C * math.prod(dims[ax + 1:])
+            nxt = _empty(dy, outer * in_shape[ax] * inner)
+            L.interp_bwd_axis(cur, nxt, outer, dims[ax], in_shape[ax], inner, src_scale)
+            cur, dims[ax] = nxt, in_shape[ax]
+        return cur.view(B, -1, C), None, None, None
+
+
+def interp_tokens(x, in_shape, out_shape=None, scale_factor=None):
+    """reference resize_flat_features (segtran_shared.py:47-66) on channels-last tokens [B, N, C].  Either `out_shape` (the
+    size= form: source step n_in/n_out) or `scale_factor` (output floor(n*sf), source step float(1/sf) -- ATen keeps the given
+    factor for the coordinates)."""
+    in_shape = tuple(int(v) for v in in_shape)
+    if scale_factor is not None:
+        out_shape = tuple(int(math.floor(v * scale_factor)) for v in in_shape)
+        src_scale = 1.0 / scale_factor          # rounded to fp32 at the C boundary, as ATen's static_cast<float>(1.0 / scale)
+    else:
+        out_shape, src_scale = tuple(int(v) for v in out_shape), 0.0
+    if out_shape == in_shape:
+        return x
+    return _InterpTokens.apply(x, in_shape, out_shape, src_scale)
+
+
 # -------------------------------------------------------------------------------------------------
 # I3D spatial convolutions (implicit GEMM on the MFMA engine) and TF-'same' max-pool (conv3d.hip)
 # -------------------------------------------------------------------------------------------------

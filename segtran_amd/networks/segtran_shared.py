@@ -109,10 +109,28 @@ class SegtranConfig:
                      self.in_fpn_scheme, self.out_fpn_scheme, self.translayer_dims))
 
 
+def multi_resize_shape(shape, scales):
+    """reference :38-43."""
+    return [tuple(int(v / scale) for v in shape) for scale in scales]
+
+
+def fracs_to_indices(feat_dim, mince_channel_props):
+    """reference :68-87: channel boundaries of the mince scales; the last scale takes the remainder."""
+    fracs = np.array(mince_channel_props, dtype=float)
+    fracs /= fracs.sum()
+    n = len(fracs)
+    indices, nums = [0] * (n + 1), [0] * n
+    for i in range(n - 1):
+        nums[i] = int(fracs[i] * feat_dim)
+        indices[i + 1] = nums[i] + indices[i]
+    indices[-1] = feat_dim
+    nums[-1] = indices[-1] - indices[-2]
+    return indices, nums
+
+
 def _unsupported(config):
-    if config.use_mince_transformer or config.ablate_multihead or config.eval_robustness:
-        raise NotImplementedError('Mince / multi-head ablation / robustness variants are outside the '
-                                  'MI355X hot path (SURVEY.md 8(f))')
+    if config.ablate_multihead or config.eval_robustness:
+        raise NotImplementedError('multi-head ablation / robustness variants are outside the MI355X hot path (SURVEY.md 8(f))')
     if config.mid_type != 'shared' or config.trans_output_type != 'private' or config.pool_modes_feat != 'softmax':
         raise NotImplementedError("only mid_type='shared', trans_output_type='private', pool_modes_feat='softmax' "
                                   "(the values train2d.py:245-249 forces) are built")
@@ -159,6 +177,12 @@ class ExpandedFeatTrans(nn.Module):
         self.feat_softaggr = LearnedSoftAggregate(self.feat_dim, group_dim=1, keepdim=False)
         self.intermediate = MMSharedMid(config)
         self.output = MMPrivateOutput(config)
+        if not config.use_mince_transformer or config.mince_scales is None:                # :344-354
+            self.num_scales, self.mince_scales = 0, None
+        else:
+            self.mince_scales, self.num_scales = config.mince_scales, len(config.mince_scales)
+            self.mince_channel_props = config.mince_channel_props
+            self.mince_channel_indices, _ = fracs_to_indices(self.feat_dim, self.mince_channel_props)
 
     def add_identity_bias(self):
         if self.config.feattrans_lin1_idbias_scale > 0:
@@ -167,17 +191,40 @@ class ExpandedFeatTrans(nn.Module):
             w = self.first_linear.weight.data
             w[:F_, :F_] = w[:F_, :F_] * 0.5 + eye.to(w.device)
 
-    def forward(self, input_feat, attention_probs):
-        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] -> [B, U1, F]."""
+    def _fuse_mince(self, v, probs, geoshape):
+        """Mince branch (:421-443): every scale fuses ITS slice of each mode's value channels on ITS down-sampled token grid with
+        ITS attention, the result is resized back to the full grid and the slices are concatenated.  v [B, U, M*F] -> [M, B, U, F]."""
+        B, U, _ = v.shape
+        M, Fd = self.num_modes, self.feat_dim
+        v4 = v.view(B, U, M, Fd)
+        shapes = multi_resize_shape(geoshape, self.mince_scales)
+        parts = []
+        for s_, scale in enumerate(self.mince_scales):
+            Lc, Rc = self.mince_channel_indices[s_], self.mince_channel_indices[s_ + 1]
+            fs = Rc - Lc
+            vs = SF.interp_tokens(v4[..., Lc:Rc].reshape(B, U, M * fs), geoshape, scale_factor=1. / scale)      # :431
+            Us = vs.shape[1]
+            fused = SF.bgemm(probs[s_], vs,                                                                    # :436
+                             GemmSpec(Us, fs, Us, (Us * Us, B * Us * Us, Us, 1), (Us * M * fs, fs, 1, M * fs),
+                                      (Us * M * fs, fs, M * fs), (B, Us, M * fs), nb=(B, M)))
+            parts.append(SF.interp_tokens(fused, shapes[s_], out_shape=geoshape).view(B, U, M, fs))            # :439
+        return torch.cat(parts, dim=-1).permute(2, 0, 1, 3).contiguous()                                       # :443
+
+    def forward(self, input_feat, attention_probs, in_geoshape=None):
+        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] (mince: a list, one per scale) -> [B, U1, F]."""
         B, U2, IF = input_feat.shape
         M, Fd = self.num_modes, self.feat_dim
-        U1 = attention_probs.shape[2]
         drop = self.hidden_dropout_prob if self.training else 0.0
         v = SF.linear(input_feat, self.first_linear.weight, self.first_linear.bias)       # [B, U2, M*F]
-        # fused[m,b] = probs[m,b] @ v[b, :, m*F:(m+1)*F]   (no [B,M*F,U] transposes)
-        fused = SF.bgemm(attention_probs, v,
-                         GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
-                                  (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M)))
+        if self.num_scales > 0:
+            U1 = U2
+            fused = self._fuse_mince(v, attention_probs, tuple(int(g) for g in in_geoshape))
+        else:
+            U1 = attention_probs.shape[2]
+            # fused[m,b] = probs[m,b] @ v[b, :, m*F:(m+1)*F]   (no [B,M*F,U] transposes)
+            fused = SF.bgemm(attention_probs, v,
+                             GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
+                                      (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M)))
         agg = self.feat_softaggr.feat2score
         if not self.has_FFN:
             # LearnedSoftAggregate over M modes, then first_norm_layer (:452-457).
@@ -272,6 +319,72 @@ class CrossAttFeatTrans(nn.Module):
         return self.out_trans(in_key, probs)
 
 
+class CrossMinceAttFeatTrans(nn.Module):
+    """Multi-scale ("mince") self-attention (reference :612-785): the token grid is down-sampled by every mince scale, each scale
+    attends with an equal slice of every mode's Q/K channels and owns a slice of the value channels (ExpandedFeatTrans).
+    As in the reference this is NOT a CrossAttFeatTrans, so SegtranInitWeights neither ties query/key nor adds the identity
+    bias to it (:1259-1263)."""
+
+    def __init__(self, config, name):
+        super().__init__()
+        _unsupported(config)
+        self.config, self.name = config, name
+        self.num_modes, self.in_feat_dim, self.feat_dim = config.num_modes, config.in_feat_dim, config.feat_dim
+        self.attention_mode_dim = self.in_feat_dim // self.num_modes
+        self.att_size_allmode = self.num_modes * self.attention_mode_dim
+        self.query = nn.Linear(self.in_feat_dim, self.att_size_allmode, bias=config.qk_have_bias)
+        self.key = nn.Linear(self.in_feat_dim, self.att_size_allmode, bias=config.qk_have_bias)
+        assert config.use_mince_transformer and config.mince_scales
+        self.mince_scales, self.num_scales = config.mince_scales, len(config.mince_scales)
+        self.mince_qk_channel_indices, _ = fracs_to_indices(self.attention_mode_dim, [1] * self.num_scales)     # :633-634
+        self.base_initializer_range = config.base_initializer_range
+        self.pos_code_weight = config.pos_code_weight if config.pos_code_type == 'bias' else 1
+        self.out_trans = ExpandedFeatTrans(config, name)
+        self.attention_probs_dropout_prob = config.attention_probs_dropout_prob
+        self.keep_attn_scores = config.use_attn_consist_loss
+        self.tie_qk_scheme = config.tie_qk_scheme
+        self.attn_clip = float(config.attn_clip)
+        self.attention_scores = None
+        self.attn_max_dev = None
+
+    tie_qk = CrossAttFeatTrans.tie_qk
+    add_identity_bias = CrossAttFeatTrans.add_identity_bias
+
+    def forward(self, in_query, query_geoshape, in_key=None, key_geoshape=None, pos_biases=None):
+        """in_query [B, U, C] over the grid `query_geoshape`; pos_biases: None or one SlidingPosBiasCode / None per scale."""
+        if in_key is not None and in_key is not in_query:
+            raise NotImplementedError('the mince transformer is built for self-attention (its only use, reference :953)')
+        geoshape = tuple(int(g) for g in query_geoshape)
+        B, U, C = in_query.shape
+        M, d = self.num_modes, self.attention_mode_dim
+        q = SF.linear(in_query, self.query.weight, self.query.bias)                      # :707
+        k = SF.linear(in_query, self.key.weight, self.key.bias)                          # :708
+        q4, k4 = q.view(B, U, M, d), k.view(B, U, M, d)
+        drop = self.attention_probs_dropout_prob if self.training else 0.0
+        probs, maxes = [], []
+        for s_, scale in enumerate(self.mince_scales):
+            Lc, Rc = self.mince_qk_channel_indices[s_], self.mince_qk_channel_indices[s_ + 1]
+            ds = Rc - Lc
+            qs = SF.interp_tokens(q4[..., Lc:Rc].reshape(B, U, M * ds), geoshape, scale_factor=1. / scale)      # :725-731
+            ks = SF.interp_tokens(k4[..., Lc:Rc].reshape(B, U, M * ds), geoshape, scale_factor=1. / scale)
+            Us = qs.shape[1]
+            gmax = torch.zeros(1, dtype=torch.float32, device=in_query.device)
+            scores = SF.bgemm(qs, ks, GemmSpec(Us, Us, ds, (Us * M * ds, ds, M * ds, 1), (Us * M * ds, ds, M * ds, 1),
+                                               (Us * Us, B * Us * Us, Us), (M, B, Us, Us), nb=(B, M),
+                                               alpha=1.0 / math.sqrt(d)), gmax=gmax)                             # :735-736
+            maxes.append(gmax)
+            pb = pos_biases[s_] if pos_biases is not None else None
+            if pb is not None:                                                                                  # :747-749 then :760-763
+                assert pb.numel == Us
+                scores = SF.pos_bias_add(scores, pb.table, pb.grid_shape, self.pos_code_weight, self.attn_clip, gmax)
+                probs.append(SF.softmax(scores, self.attn_clip, None, drop))
+            else:
+                probs.append(SF.softmax(scores, self.attn_clip, gmax, drop))
+        self.attn_max_dev = maxes
+        self.attention_scores = None
+        return self.out_trans(in_query, probs, geoshape)
+
+
 class SqueezedAttFeatTrans(nn.Module):
     """Squeezed attention: N tokens -> A attractors -> N tokens (reference :787-816)."""
 
@@ -285,6 +398,8 @@ class SqueezedAttFeatTrans(nn.Module):
         config1.has_FFN = config.has_FFN_in_squeeze
         if config1.has_FFN:
             raise NotImplementedError('has_FFN_in_squeeze=True is not built (reference default False)')
+        if config.use_mince_transformer:
+            raise ValueError('Squeezed transformer cannot be used with Mince transformer; specify --nosqueeze (reference :836-839)')
         self.in_ator_trans = CrossAttFeatTrans(config1, name + '-in-squeeze')
         self.ator_out_trans = CrossAttFeatTrans(config, name + '-squeeze-out')
         self.attractors = Parameter(torch.randn(1, self.num_attractors, self.in_feat_dim))
@@ -398,14 +513,24 @@ class SegtranFusionEncoder(nn.Module):
         self.translayer_dims = config.translayer_dims
         self.hidden_dropout_prob = config.hidden_dropout_prob
         self.use_squeezed_transformer = config.use_squeezed_transformer
-        if config.use_mince_transformer:
-            raise NotImplementedError('Mince transformer is outside the built path')
+        self.use_mince_transformer = config.use_mince_transformer
+        if self.use_squeezed_transformer and self.use_mince_transformer:
+            raise ValueError('Squeezed transformer cannot be used with Mince transformer; specify --nosqueeze (reference :836-839)')
         if self.use_squeezed_transformer and self.pos_code_type == 'bias':
             raise ValueError("Squeezed transformer cannot use positional biases; specify --nosqueeze (reference :836-844)")
         self.pos_code_weight = config.pos_code_weight if self.pos_code_type != 'bias' else 0      # :847-850
-        self.pos_code_layer = SegtranPosEncoder(config)
-        # --nosqueeze: plain multi-mode self-attention over all N tokens (:873-878)
-        TransformerClass = SqueezedAttFeatTrans if self.use_squeezed_transformer else CrossAttFeatTrans
+        if self.use_mince_transformer:                                                            # :852-861
+            self.num_scales, self.mince_scales = len(config.mince_scales), config.mince_scales
+            if self.pos_code_type == 'bias':
+                self.pos_code_layers = nn.ModuleList([SegtranPosEncoder(config) for _ in range(self.num_scales)])
+            else:
+                self.pos_code_layer = SegtranPosEncoder(config)
+        else:
+            self.num_scales = 0
+            self.pos_code_layer = SegtranPosEncoder(config)
+        # --nosqueeze: plain multi-mode self-attention over all N tokens (:873-878); --mince: its multi-scale variant
+        TransformerClass = SqueezedAttFeatTrans if self.use_squeezed_transformer else \
+            (CrossMinceAttFeatTrans if self.use_mince_transformer else CrossAttFeatTrans)
         layers = []
         for i in range(self.num_translayers):
             c2 = copy.copy(config)
@@ -425,16 +550,26 @@ class SegtranFusionEncoder(nn.Module):
         self.layers_vfeat = []
         B, N, _ = vfeat.shape
         mask = vmask.reshape(B, N).to(torch.float32)
-        pos_code = self.pos_code_layer(orig_feat_shape, voxels_pos)                       # [N, C0], once per forward
-        biases = pos_code if self.pos_code_type == 'bias' else None
+        geoshape = tuple(int(g) for g in orig_feat_shape)
+        if self.num_scales > 0 and self.pos_code_type == 'bias':                          # one bias table per scale (:920-923)
+            pos_code = None
+            biases = [self.pos_code_layers[s_](shp, voxels_pos)
+                      for s_, shp in enumerate(multi_resize_shape(geoshape, self.mince_scales))]
+        else:
+            pos_code = self.pos_code_layer(orig_feat_shape, voxels_pos)                   # [N, C0], once per forward
+            biases = pos_code if self.pos_code_type == 'bias' else None
         for i, translayer in enumerate(self.translayers):
             nl = self.vfeat_norm_layers[i]
             drop = self.hidden_dropout_prob if (self.training and i == 0) else 0.0       # :944-945
             if biases is not None:          # codes go to the attention scores; tokens get LN_affine only (:937-940)
                 feat = SF.prenorm(vfeat, nl.weight, nl.bias, None, mask, 0.0, drop)
-                vfeat = translayer(feat, pos_biases=biases)
             else:
                 feat = SF.prenorm(vfeat, nl.weight, nl.bias, pos_code, mask, self.pos_code_weight, drop)
+            if self.num_scales > 0:                                                       # :952-953
+                vfeat = translayer(feat, geoshape, pos_biases=biases)
+            elif biases is not None:
+                vfeat = translayer(feat, pos_biases=biases)
+            else:
                 vfeat = translayer(feat)
             self.layers_vfeat.append(vfeat)
         self.layers_attn_scores = None

@@ -6,8 +6,12 @@ warmup-linear LR, parameters without a gradient skipped entirely -- N3).  MI355X
   * ONE multi-tensor step (3 kernel launches for all ~530 tensors) instead of ~10 ATen launches per tensor;
   * the trainer's preceding `nn.utils.clip_grad_norm_(net.parameters(), grad_clip)` (train2d.py:1324-1325) is
     folded into the same pass: pass `global_grad_clip=` to `step()` / the constructor;
-  * gradients live in ONE flat fp32 buffer (each `p.grad` is a view), which is also what the data-parallel
-    reducer all-reduces in buckets over RCCL/xGMI (segtran_amd/dist.py).
+  * data parallel: gradients live in ONE flat fp32 buffer (each `p.grad` is a view), which is what the reducer
+    all-reduces in buckets over RCCL/xGMI (segtran_amd/dist.py);
+  * single process (`release_flat_grads()`): autograd keeps ownership of every gradient tensor (`p.grad = None`
+    before backward, so AccumulateGrad adopts the incoming tensor instead of issuing one `grad += g` kernel per
+    parameter -- 549 launches / 3.3 ms per cfg2 step) and the multi-tensor step reads them through a pointer
+    table refreshed each step.
 """
 import torch
 from torch.optim import Optimizer
@@ -47,6 +51,8 @@ class BertAdam(Optimizer):
         self._tabs = None
         self._touched = set()
         self._hooks = []
+        self._private = False
+        self._ring, self._ring_pos = None, 0
         self._build_flat_grads()
 
     # ---- flat gradient buffer ---------------------------------------------------------------------------
@@ -74,21 +80,62 @@ class BertAdam(Optimizer):
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, s=self: s._touched.add(id(q))))
             off += (n + 3) // 4 * 4
 
+    def release_flat_grads(self):
+        """Single-process mode (no reducer): drop the flat views, autograd owns the gradient tensors from now on."""
+        assert self._tabs is None or self._private, 'release_flat_grads() must precede the first step'
+        self._private = True
+        self.flat_grad = None
+        for p, _ in self._all_params():
+            p.grad = None
+
     def zero_grad(self, set_to_none=False):
-        """Gradients are views of one flat buffer: zero it (one memset) instead of dropping the tensors."""
-        self.flat_grad.zero_()
+        """Flat mode: gradients are views of one buffer, zero it (one memset) instead of dropping the tensors.
+        Private mode: drop the tensors, so that the next backward adopts the fresh ones without an accumulate kernel."""
+        if self._private:
+            for p, _ in self._all_params():
+                p.grad = None
+        else:
+            self.flat_grad.zero_()
+
+    def _refresh_grad_table(self):
+        """Private mode: this step's gradient addresses -> the device pointer table (async copy from a ring of pinned buffers)."""
+        ps = self._ps
+        ptrs = [0] * len(ps)
+        for i, p in enumerate(ps):
+            if self._active[i]:
+                if p.grad is None:
+                    raise RuntimeError('parameter #%d received a gradient in the first step but none now: the set of trained '
+                                       'parameters must stay fixed (N3)' % i)
+                g = p.grad
+                assert g.is_contiguous() and g.dtype == torch.float32
+                ptrs[i] = g.data_ptr()
+        tab = self._tabs['grads']
+        if tab.device.type != 'cuda':
+            tab.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            return
+        if self._ring is None:
+            self._ring = [(torch.empty(len(ps), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+        buf, ev = self._ring[self._ring_pos]
+        self._ring_pos = (self._ring_pos + 1) % len(self._ring)
+        ev.synchronize()                                  # the copy issued 4 steps ago from this slot (no-op in practice)
+        buf.copy_(torch.tensor(ptrs, dtype=torch.int64))
+        tab.copy_(buf, non_blocking=True)
+        ev.record()
 
     def _build_tables(self):
         ps = self._all_params()
-        dev = self.flat_grad.device
+        dev = self.flat_m.device
         i64 = lambda xs: torch.tensor(xs, dtype=torch.int64, device=dev)      # noqa: E731
         i32 = lambda xs: torch.tensor(xs, dtype=torch.int32, device=dev)      # noqa: E731
         f32 = lambda xs: torch.tensor(xs, dtype=torch.float32, device=dev)    # noqa: E731
-        gp, mp, vp = self.flat_grad.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr()
+        mp, vp = self.flat_m.data_ptr(), self.flat_v.data_ptr()
+        gp = 0 if self._private else self.flat_grad.data_ptr()
+        self._ps = [p for p, _ in ps]
+        self._active = [id(p) in self._touched for p, _ in ps]
         chunk_tensor, chunk_off, chunk_first = [], [], [0]
         for t, ((p, g), (off, n)) in enumerate(zip(ps, self.slices)):
             assert p.is_contiguous() and p.dtype == torch.float32
-            assert p.grad is not None and p.grad.data_ptr() == gp + 4 * off, 'p.grad was re-bound; use optimizer.zero_grad()'
+            assert self._private or (p.grad is not None and p.grad.data_ptr() == gp + 4 * off), 'p.grad was re-bound; use optimizer.zero_grad()'
             for c in range(0, n, CHUNK):
                 chunk_tensor.append(t); chunk_off.append(c)
             chunk_first.append(len(chunk_tensor))
@@ -121,6 +168,8 @@ class BertAdam(Optimizer):
             for h in self._hooks:
                 h.remove()                          # the touched set is static after the first backward (N3)
             self._hooks = []
+        if self._private:
+            self._refresh_grad_table()
         g = self.param_groups[0]
         sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
         clip = self.global_grad_clip if global_grad_clip is None else global_grad_clip

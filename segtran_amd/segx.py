@@ -264,8 +264,8 @@ class SegxLib:
     def interp_fwd(self, inp, base, out, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_fwd', inp, inp, base, out, planes, d, h, w, D, H, W)
 
-    def interp_fwd_axis(self, inp, base, out, outer, n_in, n_out, inner):
-        self._call('segx_interp_linear_fwd_axis', inp, inp, base, out, outer, n_in, n_out, inner)
+    def interp_fwd_axis(self, inp, base, out, outer, n_in, n_out, inner, src_scale=0.0):
+        self._call('segx_interp_linear_fwd_axis', inp, inp, base, out, outer, n_in, n_out, inner, float(src_scale))
 
     def interp_bwd(self, dout, din, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_bwd', dout, dout, din, planes, d, h, w, D, H, W)
@@ -362,8 +362,8 @@ class SegxLib:
         rc = self.c.segx_maxpool3d_bwd(_ptr(dY), _ptr(arg), _ptr(dX), planes, self._geom(geom), self.stream(dX))
         self.check(rc, 'segx_maxpool3d_bwd')
 
-    def interp_bwd_axis(self, dout, din, outer, n_out, n_in, inner):
-        self._call('segx_interp_linear_bwd_axis', dout, dout, din, outer, n_out, n_in, inner)
+    def interp_bwd_axis(self, dout, din, outer, n_out, n_in, inner, src_scale=0.0):
+        self._call('segx_interp_linear_bwd_axis', dout, dout, din, outer, n_out, n_in, inner, float(src_scale))
 
     def mt_bertadam_step(self, tabs, ntensors, nchunks, chunk, max_global, max_tensor, sched, b1, b2, eps, ws):
         """tabs: dict of device tensors params/grads/m/v (int64 pointer tables), sizes, chunk_tensor, chunk_off,
@@ -389,8 +389,8 @@ _SIGS = {
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
-    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilp',
-    'segx_tune': 'ii', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
+    'segx_tune': 'ii', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

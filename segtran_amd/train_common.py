@@ -22,7 +22,7 @@ import torch
 from . import engine, dist as sdist, functional as SF
 
 UNSUPPORTED = {'polyformer_mode': None, 'adversarial_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
-               'use_mince_transformer': False, 'use_attn_consist_loss': False, 'has_FFN_in_squeeze': False,
+               'use_attn_consist_loss': False, 'has_FFN_in_squeeze': False,
                'in_fpn_use_bn': False, 'out_fpn_do_dropout': False, 'tune_bn_only': False}
 
 
@@ -60,6 +60,8 @@ def common_flags(p, dim):
     p.add_argument('--squeezeuseffn', dest='has_FFN_in_squeeze', action='store_true')
     p.add_argument('--attnconsist', dest='use_attn_consist_loss', action='store_true')
     p.add_argument('--mince', dest='use_mince_transformer', action='store_true')
+    p.add_argument('--mincescales', dest='mince_scales', type=str, default=None, help='comma list of the mince scales, e.g. 4,2,1')
+    p.add_argument('--minceprops', dest='mince_channel_props', type=str, default=None, help='comma list of value-channel proportions')
     p.add_argument('--infpn', dest='in_fpn_layers', default='34')
     p.add_argument('--outfpn', dest='out_fpn_layers', default='1234')
     p.add_argument('--outdrop', dest='out_fpn_do_dropout', action='store_true')
@@ -87,7 +89,23 @@ def finalize_args(args, dim):
         args.translayer_compress_ratios = [int(c) for c in str(args.translayer_compress_ratios).split(',')]
     else:
         args.translayer_compress_ratios = [1] * (args.num_translayers + 1)
+    if args.mince_scales is not None:                                      # train2d.py:254-257
+        args.mince_scales = [int(v) for v in str(args.mince_scales).split(',')]
+    if args.mince_channel_props is not None:
+        args.mince_channel_props = [float(v) for v in str(args.mince_channel_props).split(',')]
+    if args.use_mince_transformer and not (args.mince_scales and args.mince_channel_props
+                                           and len(args.mince_scales) == len(args.mince_channel_props)):
+        raise SystemExit('--mince needs --mincescales and --minceprops of equal length')
     return args
+
+
+ARCH_FLAGS = ('use_squeezed_transformer', 'qk_have_bias', 'num_modes', 'pos_code_type', 'pos_code_weight', 'pos_bias_radius', 'attn_clip',
+              'use_mince_transformer', 'mince_scales', 'mince_channel_props', 'in_fpn_layers', 'out_fpn_layers', 'bb_feat_upsize')
+
+
+def arch_overrides(args):
+    """The architecture flags of the command line that Segtran2d/3d's config reads (train2d.py:256-303 -> CONFIG.update_config)."""
+    return {k: getattr(args, k) for k in ARCH_FLAGS if hasattr(args, k)}
 
 
 def make_cfg(args, dim, size, num_classes):
@@ -134,7 +152,8 @@ def run(args, cfg, batches=None):
     ckpt_dir = os.path.join('..', 'model', '%s-%s-%s' % (args.net, args.task_name, ts))
     logging.basicConfig(level=logging.INFO if is_master else logging.WARNING, format='[%(asctime)s] %(message)s', datefmt='%H:%M:%S')
 
-    net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=not args.checkpoint_path)
+    net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=not args.checkpoint_path,
+                             **arch_overrides(args))
     iter_num = load_model(net, args, args.checkpoint_path) if args.checkpoint_path else 0
     if dim_of(cfg) == 2:
         iter_num = 0                                                      # train2d.py:1078-1081 always restarts the count

@@ -193,6 +193,52 @@ def case_fusion_nosqueeze():
         save('fusion_nosqueeze_' + tag, **arrs)
 
 
+def case_fusion_mince():
+    """--mince (multi-scale self-attention, CrossMinceAttFeatTrans): 2-D with per-scale sliding biases, 2-D with 'lsinu' codes on
+    a grid the scales do not divide (scale_factor coordinate rule), 3-D with biases.  Query/key stay untied, as in the reference
+    (SegtranInitWeights.tie_qk does not match CrossMinceAttFeatTrans)."""
+    ss = R.ref_shared()
+    dims = [64, 64, 32]
+    cases = {'bias2d': ('bias', (8, 12), [4, 2, 1], [1, 1, 2]), 'lsinu2d': ('lsinu', (7, 10), [3, 2, 1], [1, 1, 1]),
+             'bias3d': ('bias', (4, 6, 5), [2, 1], [1, 3])}
+    for tag, (pos_type, shape, scales, props) in cases.items():
+        pd = len(shape)
+        cfg = mk_shared_config(ss, 64, dims, 16, pos_dim=pd)
+        cfg.use_squeezed_transformer, cfg.use_mince_transformer = False, True
+        cfg.mince_scales, cfg.mince_channel_props = scales, props
+        cfg.pos_code_type, cfg.pos_bias_radius, cfg.pos_code_weight = pos_type, 2, 0.8
+        cfg.max_pos_size = (12,) * pd
+        mod = R.quiet(ss.SegtranFusionEncoder, cfg, 'Fusion')
+        prefix = 'voxel_fusion.'
+        shapes = {prefix + k: tuple(v.shape) for k, v in mod.state_dict().items() if '.all_' not in k}
+        sd = synth_state_dict(shapes)
+        mod.load_state_dict({k[len(prefix):]: v for k, v in sd.items()}, strict=False)
+        mod.eval()
+        g = torch.Generator().manual_seed(23)
+        N = int(np.prod(shape))
+        X = torch.randn(2, N, 64, generator=g).requires_grad_(True)
+        G = torch.randn(2, N, 32, generator=g)
+        vmask = (torch.rand(2, N, 1, generator=g) > 0.2)
+        pos = (O.gen_all_indices(shape).view(-1, pd).float() * 8).unsqueeze(0).repeat(2, 1, 1)
+        Y = mod(X, pos, vmask, torch.Size(shape)); (Y * G).sum().backward()
+        sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
+        Yo = O.fusion_encoder(sdg, 'voxel_fusion', Xo, pos, vmask, dims, pos_code_weight=0.8, squeezed=False, pos_code_type=pos_type,
+                              feat_shape=shape, mince_scales=scales, mince_channel_props=props)
+        (Yo * G).sum().backward()
+        close(Yo, Y, 1e-5, 'mince Y'); close(Xo.grad, X.grad, 1e-4, 'mince dX')
+        rg = ref_param_grads(mod, prefix)
+        og = {k: v.grad for k, v in sdg.items() if v.grad is not None}               # untied: every key has its own gradient
+        arrs = dict(X=X, G=G, vmask=vmask, pos=pos, Y=Y, dX=X.grad, dims=np.array(dims), shape=np.array(shape),
+                    scales=np.array(scales), props=np.array(props, dtype=np.float64))
+        gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+        for k, v in rg.items():
+            if v is None:
+                continue
+            assert (og[k] - v).abs().max().item() <= 2e-4 * gscale, k
+            arrs['grad:' + k] = v
+        save('fusion_mince_' + tag, **arrs)
+
+
 def case_polyformer():
     """PolyformerLayer (no-FFN 4-mode attention pair on a 2x-pooled map + residual), square and non-square maps
     (the reference maps the w-major token order back as (row, col): quirk N10)."""
@@ -300,6 +346,8 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight',
                 'voxel_fusion.vfeat_norm_layers.0.weight',
                 'voxel_fusion.pos_code_layer.pos_coder.biases',
+                'voxel_fusion.pos_code_layers.0.pos_coder.biases', 'voxel_fusion.pos_code_layers.2.pos_coder.biases',
+                'voxel_fusion.translayers.0.key.weight',
                 'voxel_fusion.translayers.0.query.weight', 'voxel_fusion.translayers.0.out_trans.first_linear.weight',
                 'voxel_fusion.translayers.0.out_trans.output.group_linear.weight',
                 'voxel_fusion.translayers.0.attractors',
@@ -321,7 +369,7 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'backbone._blocks.31._bn1.bias', 'backbone._conv_head.weight']
 
 
-def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fundus', **over):
+def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fundus', tied=True, **over):
     net = R.ref_segtran2d(num_classes=3 if task == 'fundus' else 2, num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0, **over)
     sd = load_synth(net)
     if train:
@@ -348,7 +396,7 @@ def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fun
     yo = O.segtran2d_forward(sdg, x, dims, training=train, fusion_kw=fusion_kw)
     lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
     close(yo, y, 2e-5, tag + ' logits')
-    og = oracle_grads(sdg)
+    og = oracle_grads(sdg) if tied else {k: v.grad for k, v in sdg.items() if v.grad is not None}
     rg = dict(net.named_parameters())
     gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
     arrs = dict(x=x, mask=mask, logits=y, labels=(y > 0), loss=loss.detach(), margin=y.abs().min().detach(),
@@ -387,6 +435,15 @@ GRAD_KEYS_3D = ['in_bridge_to3.weight', 'out_conv3d.weight', 'out_fpn_bridgeconv
                 'backbone.Conv3d_2c_3x3.conv3d.weight', 'backbone.Mixed_3b.b1b.conv3d.weight',
                 'backbone.Mixed_4d.b2b.conv3d.weight', 'backbone.Mixed_4f.b3b.bn.bias',
                 'backbone.Mixed_5c.b0.conv3d.weight']
+
+
+def case_seg2d_mince():
+    """--nosqueeze --mince --mincescales 4,2,1 --minceprops 1,1,2 --pos bias --posr 2 (untied query/key) on a 96 x 96 input ->
+    12 x 12 tokens -> 3 x 3 / 6 x 6 / 12 x 12 grids"""
+    run_seg2d('seg2d_cfg1_mince_train', 1, (1, 1), [1792, 1792], 32, 2, 96, True, tied=False,
+              fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0, mince_scales=[4, 2, 1], mince_channel_props=[1, 1, 2]),
+              use_squeezed_transformer=False, use_mince_transformer=True, mince_scales=[4, 2, 1], mince_channel_props=[1, 1, 2],
+              pos_code_type='bias', pos_bias_radius=2)
 
 
 def case_seg2d_polyp():
@@ -588,8 +645,8 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
-             seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
+             seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 
 if __name__ == '__main__':

@@ -74,6 +74,29 @@ def test_segtran2d_nosqueeze_pos_bias_vs_reference():
     _grads_vs_golden(net, g)
 
 
+def test_segtran2d_mince_vs_reference():
+    """--nosqueeze --mince --mincescales 4,2,1 --minceprops 1,1,2 --pos bias --posr 2, train mode: 12 x 12 tokens attended on
+    3 x 3 / 6 x 6 / 12 x 12 grids, untied query/key, one bias table per scale; logits + loss + gradients."""
+    g = golden('seg2d_cfg1_mince_train')
+    c = dict(engine.CONFIGS['cfg1'], size=(96, 96))
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']), use_squeezed_transformer=False,
+                             use_mince_transformer=True, mince_scales=[4, 2, 1], mince_channel_props=[1, 1, 2],
+                             pos_code_type='bias', pos_bias_radius=2)
+    net.backbone.drop_connect_rate = 0.0
+    net.train()
+    y = net(g['x'].to(DEV))
+    assert_close(y, g['logits'], 1e-4, 'logits')
+    assert (y.cpu() - g['logits']).abs().max().item() < 1e-3
+    safe = g['logits'].abs() > 1e-5
+    assert torch.equal((y.cpu() > 0)[safe], g['labels'][safe])
+    pw, cw = engine.loss_weights('fundus', DEV)
+    loss, _ = SF.seg_loss(y, engine.map_mask('fundus', g['mask'].to(DEV)), pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    loss.backward()
+    assert 'grad:voxel_fusion.pos_code_layers.2.pos_coder.biases' in g and 'grad:voxel_fusion.translayers.0.key.weight' in g
+    _grads_vs_golden(net, g)
+
+
 @pytest.mark.parametrize('tag,train', [('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)])
 def test_segtran3d_vs_reference(tag, train):
     g = golden(tag)

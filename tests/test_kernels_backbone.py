@@ -125,3 +125,24 @@ def test_interp_linear(backend, inshape, size, with_base):
     close(x.grad, xr.grad, 1e-5)
     if with_base:
         close(base.grad, br.grad, 1e-6)
+
+
+@pytest.mark.parametrize('shape,C,kw', [((7, 10), 6, dict(scale_factor=1. / 3)), ((7, 10), 8, dict(scale_factor=0.5)), ((8, 12), 5, dict(scale_factor=0.25)),
+                                        ((5, 6, 7), 4, dict(scale_factor=0.5)), ((2, 3), 8, dict(out_shape=(7, 10))), ((2, 3, 3), 3, dict(out_shape=(5, 6, 7))),
+                                        ((4, 4), 4, dict(scale_factor=1.0))])
+def test_interp_tokens_channels_last(backend, shape, C, kw):
+    """resize_flat_features on channels-last tokens: the scale_factor form keeps the GIVEN factor for the source coordinates
+    (7 -> 2 at factor 1/3 steps by 3.0, not 3.5), the size form uses n_in/n_out; both == F.interpolate on the NC[D]HW view."""
+    B, N = 2, int(torch.tensor(shape).prod())
+    x = rnd(B, N, C, seed=31).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    y = SF.interp_tokens(x, shape, **kw)
+    mode = 'bilinear' if len(shape) == 2 else 'trilinear'
+    g = xr.permute(0, 2, 1).reshape(B, C, *shape)
+    yr = F.interpolate(g, size=kw.get('out_shape'), scale_factor=kw.get('scale_factor'), mode=mode, align_corners=False)
+    yr = yr.reshape(B, C, -1).permute(0, 2, 1)
+    assert y.shape == yr.shape
+    close(y, yr.detach(), 1e-6)
+    G = rnd(*y.shape, seed=32)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-5)

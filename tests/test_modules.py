@@ -113,6 +113,38 @@ def test_fusion_encoder_nosqueeze_vs_reference(backend, tag):
     check_grads(mod, prefix, g)
 
 
+@pytest.mark.parametrize('tag', ['bias2d', 'lsinu2d', 'bias3d'])
+def test_fusion_encoder_mince_vs_reference(backend, tag):
+    """--mince: multi-scale self-attention (CrossMinceAttFeatTrans) with per-scale sliding biases (2-D / 3-D) and with lsinu
+    codes on a 7x10 grid that the scales 3 and 2 do not divide (scale_factor coordinate rule of F.interpolate)."""
+    g = golden_on('fusion_mince_' + tag, backend.dev)
+    dims = [int(d) for d in g['dims']]
+    shape = tuple(int(v) for v in g['shape'])
+    cfg = mk_config(dims, 16, pos_dim=len(shape))
+    cfg.use_squeezed_transformer, cfg.use_mince_transformer = False, True
+    cfg.mince_scales, cfg.mince_channel_props = [int(v) for v in g['scales']], [float(v) for v in g['props']]
+    cfg.pos_code_type = 'lsinu' if tag.startswith('lsinu') else 'bias'
+    cfg.pos_bias_radius, cfg.pos_code_weight, cfg.max_pos_size = 2, 0.8, (12,) * len(shape)
+    mod = ss.SegtranFusionEncoder(cfg, 'Fusion')
+    prefix = 'voxel_fusion.'
+    load(mod, prefix)                                         # query/key stay untied: not CrossAttFeatTrans instances
+    assert all(m.key.weight is not m.query.weight for m in mod.modules() if isinstance(m, ss.CrossMinceAttFeatTrans))
+    mod.eval()
+    X = g['X'].clone().requires_grad_(True)
+    Y = mod(X, g['pos'], g['vmask'], torch.Size(shape))
+    assert_close(Y, g['Y'], 2e-5, 'Y')
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g['dX'], 1e-4, 'dX')
+    check_grads(mod, prefix, g)
+
+
+def test_mince_rejected_with_squeeze(backend):
+    cfg = mk_config([64, 32], 16)
+    cfg.use_mince_transformer, cfg.mince_scales, cfg.mince_channel_props = True, [2, 1], [1, 1]
+    with pytest.raises(ValueError):
+        ss.SegtranFusionEncoder(cfg, 'Fusion')
+
+
 def test_pos_bias_rejected_with_squeeze_and_reference_buffers_ignored(backend):
     cfg = mk_config([64, 32], 16)
     cfg.pos_code_type = 'bias'

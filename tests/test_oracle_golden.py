@@ -80,6 +80,22 @@ def test_fusion_encoder_nosqueeze(tag):
     _grad_check(g, tied_grads(sdg))
 
 
+@pytest.mark.parametrize('tag', ['bias2d', 'lsinu2d', 'bias3d'])
+def test_fusion_encoder_mince(tag):
+    g = golden('fusion_mince_' + tag)
+    shapes = {k[5:]: tuple(v.shape) for k, v in g.items() if k.startswith('grad:')}      # untied: key has its own gradient
+    sdg = req(synth_state_dict(shapes))
+    X = g['X'].clone().requires_grad_(True)
+    Y = O.fusion_encoder(sdg, 'voxel_fusion', X, g['pos'], g['vmask'], [int(d) for d in g['dims']], pos_code_weight=0.8,
+                         squeezed=False, pos_code_type='lsinu' if tag.startswith('lsinu') else 'bias',
+                         feat_shape=tuple(int(v) for v in g['shape']), mince_scales=[int(v) for v in g['scales']],
+                         mince_channel_props=[float(v) for v in g['props']])
+    (Y * g['G']).sum().backward()
+    assert_close(Y, g['Y'], 1e-5, 'Y')
+    assert_close(X.grad, g['dX'], 1e-4, 'dX')
+    _grad_check(g, {k: v.grad for k, v in sdg.items() if v.grad is not None})
+
+
 def test_sliding_pos_biases():
     g = golden('posbias')
     for d, shape in (('2', (5, 6)), ('3', (3, 4, 2))):
@@ -161,6 +177,26 @@ def test_segtran2d_nosqueeze_pos_bias():
     assert abs(loss.item() - float(g['loss'])) < 1e-5
     loss.backward()
     _grad_check(g, tied_grads(sdg))
+
+
+def test_segtran2d_mince():
+    """Whole model with --nosqueeze --mince --pos bias; parameter names/shapes of the product model for that variant (per-scale
+    pos_code_layers, separate key) against the reference-generated fixture."""
+    from segtran_amd import engine
+    g = golden('seg2d_cfg1_mince_train')
+    net = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(96, 96)), 'cpu', dropout_prob=0.0, attractors=int(g['A']),
+                             synth=False, use_squeezed_transformer=False, use_mince_transformer=True, mince_scales=[4, 2, 1],
+                             mince_channel_props=[1, 1, 2], pos_code_type='bias', pos_bias_radius=2)
+    sdg = req(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    y = O.segtran2d_forward(sdg, g['x'], [int(d) for d in g['dims']], training=True,
+                            fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0, mince_scales=[4, 2, 1],
+                                           mince_channel_props=[1, 1, 2]))
+    assert_close(y, g['logits'], 2e-5, 'logits')
+    assert torch.equal(y > 0, g['labels'])
+    loss = O.seg_loss(y, O.fundus_map_mask(g['mask']), O.bce_pos_weight([0., 1., 2.]))[0]
+    assert abs(loss.item() - float(g['loss'])) < 1e-5
+    loss.backward()
+    _grad_check(g, {k: v.grad for k, v in sdg.items() if v.grad is not None})
 
 
 @pytest.mark.parametrize('tag', ['seg3d_cfg4_eval', 'seg3d_cfg4_train'])

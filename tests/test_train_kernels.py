@@ -23,7 +23,10 @@ def test_seg_loss_vs_reference(backend, tag):
     assert_close(lo.grad, g['dlogits' + tag], 2e-5, 'dlogits')
 
 
-def test_bertadam_vs_reference(backend):
+@pytest.mark.parametrize('private', [False, True])
+def test_bertadam_vs_reference(backend, private):
+    """private=False: gradients are views of the flat buffer (data-parallel mode); private=True: autograd owns the gradient
+    tensors and the kernel follows a per-step pointer table (single-process mode) -- same numbers either way."""
     from segtran_amd.optimization import BertAdam
     g = golden_on('bertadam', backend.dev)
     params = [torch.nn.Parameter(g['p0_%d' % i].clone()) for i in range(4)]
@@ -31,12 +34,17 @@ def test_bertadam_vs_reference(backend):
               dict(params=[params[1]], weight_decay=1e-5, lr=2e-4),
               dict(params=[params[2]], weight_decay=0.0, lr=2e-4)]
     opt = BertAdam(groups, lr=2e-4, warmup=0.25, t_total=8, weight_decay=1e-4, global_grad_clip=0.1)
+    if private:
+        opt.release_flat_grads()
+        assert all(p.grad is None for p in params)
     order = [0, 3, 1, 2]                                    # optimizer-internal order = group order
     for step in range(4):
         opt.zero_grad()
         # parameters 0..2 receive gradients through autograd; parameter 3 never does (N3)
         loss = sum((params[i] * g['g%d_%d' % (step, i)]).sum() for i in range(3))
         loss.backward()
+        if private:
+            assert params[3].grad is None and all(params[i].grad.data_ptr() != 0 for i in range(3))
         opt.step()
         for i in range(4):
             assert torch.allclose(params[i].data, g['p%d_%d' % (step + 1, i)], atol=2e-7), (step, i)

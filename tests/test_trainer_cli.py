@@ -17,10 +17,29 @@ def test_reference_flag_names_and_segtran_defaults():
     assert (b.num_attractors, b.translayer_compress_ratios, b.batch_size) == (1024, [1, 1], 4)
 
 
-@pytest.mark.parametrize('flag', ['--mince', '--multihead', '--attnconsist', '--squeezeuseffn', '--inbn', '--outdrop'])
+@pytest.mark.parametrize('flag', ['--multihead', '--attnconsist', '--squeezeuseffn', '--inbn', '--outdrop'])
 def test_out_of_scope_features_are_rejected_loudly(flag):
     with pytest.raises(SystemExit):
         _parse([flag], 2)
+
+
+def test_architecture_flags_reach_the_model_builder():
+    """--nosqueeze --pos bias --posr 3 and --mince --mincescales/--minceprops are parsed as train2d.py:254-257 and handed to
+    engine.build_model; the model they build carries the reference's parameter names for that variant."""
+    a = _parse(['--nosqueeze', '--mince', '--mincescales', '4,2,1', '--minceprops', '1,1,2', '--pos', 'bias', '--posr', '3', '--attnclip', '100'], 2)
+    o = tc.arch_overrides(a)
+    assert (o['use_squeezed_transformer'], o['use_mince_transformer'], o['mince_scales'], o['mince_channel_props']) == (False, True, [4, 2, 1], [1., 1., 2.])
+    assert (o['pos_code_type'], o['pos_bias_radius'], o['attn_clip'], o['num_modes']) == ('bias', 3, 100, 4)
+    from segtran_amd import engine
+    cfg = tc.make_cfg(a, 2, (64, 64), 3)
+    net = engine.build_model(cfg, 'cpu', dropout_prob=a.dropout_prob, attractors=a.num_attractors, synth=False, **o)
+    keys = set(net.state_dict())
+    assert {'voxel_fusion.pos_code_layers.2.pos_coder.biases', 'voxel_fusion.translayers.0.key.weight',
+            'voxel_fusion.translayers.0.out_trans.first_linear.weight'} <= keys
+    assert net.voxel_fusion.pos_code_layers[0].pos_coder.biases.shape == (7, 7)
+    assert not any('attractors' in k for k in keys)
+    with pytest.raises(SystemExit):
+        _parse(['--mince'], 2)                           # scales / proportions are mandatory with --mince
 
 
 def test_other_networks_are_rejected():
