@@ -217,6 +217,10 @@ int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const fl
 int segx_avgpool2_fwd(const float* X, float* Y, int64_t planes, int H, int W, void* stream);
 int segx_avgpool2_bwd(const float* dY, float* dX, int64_t planes, int H, int W, void* stream);
 int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* stream);
+/* nn.Dropout as its own pass (out-FPN output under --outdrop, segtran2d.py:308-310 / segtran3d.py:392-394):
+ * y[i] = x[i] * keep(seed, offset + i) / (1 - p); the backward pass is the same call on dy.  offset % 4 == 0, 16-B aligned. */
+int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,

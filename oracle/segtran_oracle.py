@@ -168,12 +168,12 @@ def _expanded_tail(sd, p, fused, M):
     return (zn * sc.softmax(dim=1)).sum(dim=1)
 
 
-def squeezed_att_feat_trans(sd, p, in_feat, num_modes=4, attn_clip=500., stats=None):
+def squeezed_att_feat_trans(sd, p, in_feat, num_modes=4, attn_clip=500., stats=None, ffn_in_squeeze=False):
     """SqueezedAttFeatTrans.forward  (segtran_shared.py:809-816)."""
     B = in_feat.shape[0]
     att = sd[p + '.attractors'].expand(B, -1, -1)              # :812
-    # in-squeeze: num_modes=1, feat_dim=in_feat_dim, no FFN  (:796-799)
-    att2 = cross_att_feat_trans(sd, p + '.in_ator_trans', att, in_feat, 1, False, attn_clip, stats=stats)
+    # in-squeeze: num_modes=1, feat_dim=in_feat_dim, no FFN unless --squeezeuseffn (:796-799)
+    att2 = cross_att_feat_trans(sd, p + '.in_ator_trans', att, in_feat, 1, ffn_in_squeeze, attn_clip, stats=stats)
     return cross_att_feat_trans(sd, p + '.ator_out_trans', in_feat, att2, num_modes, True, attn_clip, stats=stats)
 
 
@@ -416,13 +416,18 @@ def _up(x, size):
 
 
 def segtran2d_forward(sd, x, translayer_dims, num_modes=4, training=False, attn_clip=500., stats=None, aux=None,
-                      fusion_kw=None):
-    """Segtran2d.forward (segtran2d.py:314-438): eff-b4, in_fpn '34', out_fpn '1234', scheme 'AN'."""
+                      fusion_kw=None, in_fpn_use_bn=False):
+    """Segtran2d.forward (segtran2d.py:314-438): eff-b4, in_fpn '34', out_fpn '1234', scheme 'AN'.
+    in_fpn_use_bn (--inbn, :143-146, :252): a default nn.BatchNorm2d (eps 1e-5, momentum 0.1) instead of the GroupNorm."""
     B, _, H, W = x.shape
     mask = F.avg_pool2d(x.abs(), 8).sum(dim=1) > 0                                   # get_mask :229-233
     f = effnet_b4_endpoints(sd, 'backbone', x, training)                             # :344-348
     cur = _conv1x1(f[3], sd, 'in_fpn34_conv') + _up(f[4], f[3].shape[2:])            # in_fpn_forward :245-252
-    cur = _gn(cur, sd, 'in_gn4b')
+    if in_fpn_use_bn:
+        cur = F.batch_norm(cur, sd['in_bn4b.running_mean'].clone(), sd['in_bn4b.running_var'].clone(), sd['in_bn4b.weight'],
+                           sd['in_bn4b.bias'], training, 0.1, 1e-5)
+    else:
+        cur = _gn(cur, sd, 'in_gn4b')
     H2, W2 = cur.shape[2:]
     vfeat = cur.permute(0, 2, 3, 1).reshape(B, H2 * W2, -1)                          # :264-266
     vmask = mask.reshape(B, -1, 1)

@@ -311,6 +311,27 @@ extern "C" int segx_transpose(const float* X, float* Y, int64_t batch, int R, in
     }
     return check_launch("segx_transpose");
 }
+// Standalone inverted dropout (nn.Dropout on the out-FPN output, --outdrop, segtran2d.py:308-310): y = x * keep(seed, offset + i) / (1 - p).
+// The mask is regenerated from the Philox stream, so the backward pass is the same kernel applied to dy.
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float inv_keep,
+                                                      uint64_t seed, uint64_t offset) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        const float4 k = dropout_scale4(seed, offset, (uint64_t)i * 4, p, inv_keep);
+        reinterpret_cast<float4*>(y)[i] = make_float4(v.x * k.x, v.y * k.y, v.z * k.z, v.w * k.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        y[i] = x[i] * dropout_scale(seed, offset, (uint64_t)i, p, inv_keep);
+    }
+}
+extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f && (offset & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
+                              "segx_dropout: bad args");
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)i64min(1 << 20, (n / 4 + 256) / 256)), dim3(256), 0, stream, x, y, n, p, 1.0f / (1.0f - p), seed, offset);
+    return check_launch("segx_dropout");
+}
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
 namespace segx { extern int g_conv_small_policy; }
 extern "C" int segx_tune(int knob, int value) {

@@ -421,6 +421,34 @@ def modes_aggr(Z, lnw, lnb, wa, ba, drop_p=0.0):
     return _ModesAggr.apply(Z, lnw, lnb, wa, ba, float(drop_p))
 
 
+class _Dropout(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p):
+        L = segx.lib()
+        x = _c(x)
+        seed, off = _Rng.reserve(x.numel())
+        y = torch.empty_like(x)
+        L.dropout(x, y, x.numel(), p, seed, off)
+        ctx.cfg = (p, seed, off)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        p, seed, off = ctx.cfg
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        L.dropout(dy, dx, dy.numel(), p, seed, off)
+        return dx, None
+
+
+def dropout(x, p, training=True):
+    """nn.Dropout(p) as its own pass (only the out-FPN output under --outdrop uses it; every other dropout is fused)."""
+    if not training or p <= 0:
+        return x
+    return _Dropout.apply(x, float(p))
+
+
 class _AvgPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

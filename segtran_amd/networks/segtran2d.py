@@ -83,8 +83,8 @@ class Segtran2d(SegtranInitWeights):
         self.num_translayers = config.num_translayers
         self.bb_feat_upsize = config.bb_feat_upsize
         self.G = config.G
-        if config.use_global_bias or config.num_modalities > 0 or config.in_fpn_use_bn or config.out_fpn_use_bn:
-            raise NotImplementedError('global-bias / multi-modality / BN-FPN variants are outside the hot path')
+        if config.use_global_bias or config.num_modalities > 0 or config.out_fpn_use_bn:
+            raise NotImplementedError('global-bias / multi-modality / BN-out-FPN variants are outside the hot path')
         self.use_global_bias = False
         self.voxel_fusion = SegtranFusionEncoder(config, 'Fusion')
         self.backbone_type = config.backbone_type
@@ -100,7 +100,7 @@ class Segtran2d(SegtranInitWeights):
         self.in_fpn_layers, self.in_fpn_scheme = config.in_fpn_layers, config.in_fpn_scheme
         self.out_fpn_layers, self.out_fpn_scheme = config.out_fpn_layers, config.out_fpn_scheme
         if self.in_fpn_layers != [3, 4] or self.out_fpn_layers != [1, 2, 3, 4] or self.in_fpn_scheme != 'AN' \
-                or self.out_fpn_scheme != 'AN' or config.out_fpn_do_dropout:
+                or self.out_fpn_scheme != 'AN':
             raise NotImplementedError("only --infpn 34 --outfpn 1234 with the 'AN' scheme (reference defaults) are built")
         pool_stride = 2 ** int(np.min(self.in_fpn_layers)) * (1 if self.bb_feat_upsize else 2)
         self.mask_pool = nn.AvgPool2d((pool_stride, pool_stride))
@@ -108,8 +108,14 @@ class Segtran2d(SegtranInitWeights):
         self.in_fpn23_conv = _Conv1x1(d[2], d[3], 1)            # unused with in_fpn '34' (N3), kept for the checkpoint
         self.in_fpn34_conv = _Conv1x1(d[3], d[4], 1)
         self.in_fpn_bridgeconv = _Conv1x1(d[4], self.trans_in_dim, 1) if d[4] != self.trans_in_dim else nn.Identity()
-        self.in_gn3b = nn.GroupNorm(self.G, d[3])
-        self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.in_fpn_use_bn = config.in_fpn_use_bn
+        if self.in_fpn_use_bn:                                  # --inbn (segtran2d.py:143-146): default BatchNorm2d (eps 1e-5, momentum 0.1)
+            self.in_bn3b = nn.BatchNorm2d(d[3])
+            self.in_bn4b = nn.BatchNorm2d(d[4])
+        else:
+            self.in_gn3b = nn.GroupNorm(self.G, d[3])
+            self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.out_fpn_do_dropout = config.out_fpn_do_dropout     # --outdrop (:308-310)
         self.num_classes = config.num_classes
         self.num_modalities = 0
         self.do_out_fpn = True
@@ -136,7 +142,8 @@ class Segtran2d(SegtranInitWeights):
 
     def in_fpn_forward(self, feats, nonzero_mask, B):
         f3, f4 = feats[3], feats[4]
-        cur = SF.group_norm(_up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3)), self.in_gn4b)     # 'AN': add, then normalise
+        cur = _up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3))                                   # 'AN': add, then normalise
+        cur = SF.bn_act(cur, self.in_bn4b) if self.in_fpn_use_bn else SF.group_norm(cur, self.in_gn4b)
         cur = self.in_fpn_bridgeconv(cur)
         H2, W2 = cur.shape[2:]
         vfeat = cur.permute(0, 2, 3, 1).reshape(B, H2 * W2, self.trans_in_dim)
@@ -145,7 +152,10 @@ class Segtran2d(SegtranInitWeights):
     def out_fpn_forward(self, feats, vfeat_fused, B0):
         cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv(feats[1])), self.out_gn2b)
         cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv(cur)), self.out_gn3b)
-        return _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv(cur))
+        out = _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv(cur))
+        if self.out_fpn_do_dropout:
+            out = SF.dropout(out, self.out_fpn_dropout.p, self.training)
+        return out
 
     def forward(self, batch):
         self.feature_maps = []

@@ -108,7 +108,7 @@ class Segtran3d(SegtranInitWeights):
         self.out_fpn_upsampleD_scheme = config.out_fpn_upsampleD_scheme
         self.input_scale = config.input_scale
         if self.D_groupsize != 1 or self.inchan_to3_scheme != 'bridgeconv' or self.out_fpn_upsampleD_scheme != 'interp' \
-                or config.in_fpn_use_bn or config.out_fpn_use_bn or config.out_fpn_do_dropout or not self.bb_feat_upsize:
+                or config.out_fpn_use_bn or not self.bb_feat_upsize:
             raise NotImplementedError("only inchan_to3_scheme='bridgeconv', D_groupsize=1, 'interp' depth un-pooling "
                                       "(what train3d.py:180-195 forces) are built")
         self.in_bridge_to3 = _Conv1x1x1(self.eff_in_channels, 3, 1) if self.eff_in_channels != 3 else nn.Identity()
@@ -122,8 +122,14 @@ class Segtran3d(SegtranInitWeights):
         self.in_fpn23_conv = _Conv1x1x1(d[2], d[3], 1)           # unused (N3)
         self.in_fpn34_conv = _Conv1x1x1(d[3], d[4], 1)
         self.in_fpn_bridgeconv = _Conv1x1x1(d[4], self.trans_in_dim, 1) if d[4] != self.trans_in_dim else nn.Identity()
-        self.in_gn3b = nn.GroupNorm(self.G, d[3])
-        self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.in_fpn_use_bn = config.in_fpn_use_bn
+        if self.in_fpn_use_bn:                                   # --inbn (segtran3d.py:177-180)
+            self.in_bn3b = nn.BatchNorm3d(d[3])
+            self.in_bn4b = nn.BatchNorm3d(d[4])
+        else:
+            self.in_gn3b = nn.GroupNorm(self.G, d[3])
+            self.in_gn4b = nn.GroupNorm(self.G, d[4])
+        self.out_fpn_do_dropout = config.out_fpn_do_dropout      # --outdrop (:392-394)
         self.num_classes = config.num_classes
         self.do_out_fpn = True
         self.out_fpn_out_dim = self.out_feat_dim = self.trans_out_dim
@@ -148,7 +154,8 @@ class Segtran3d(SegtranInitWeights):
 
     def in_fpn_forward(self, feats, nonzero_mask):
         f3, f4 = feats[3], feats[4]
-        cur = SF.group_norm(_up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3)), self.in_gn4b)
+        cur = _up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3))
+        cur = SF.bn_act(cur, self.in_bn4b) if self.in_fpn_use_bn else SF.group_norm(cur, self.in_gn4b)
         cur = self.in_fpn_bridgeconv(cur)
         dp = [cur.shape[2] // self.D_pool_K, cur.shape[3], cur.shape[4]]
         cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
@@ -163,6 +170,8 @@ class Segtran3d(SegtranInitWeights):
         out = _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv3d(cur))
         if self.D_pool_K > 1:
             out = _up(out, [out.shape[2] * self.D_pool_K, out.shape[3], out.shape[4]])
+        if self.out_fpn_do_dropout:
+            out = SF.dropout(out, self.out_fpn_dropout.p, self.training)
         return out
 
     def forward(self, batch):

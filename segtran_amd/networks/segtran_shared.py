@@ -396,8 +396,6 @@ class SqueezedAttFeatTrans(nn.Module):
         config1.feat_dim = config1.in_feat_dim
         config1.num_modes = 1
         config1.has_FFN = config.has_FFN_in_squeeze
-        if config1.has_FFN:
-            raise NotImplementedError('has_FFN_in_squeeze=True is not built (reference default False)')
         if config.use_mince_transformer:
             raise ValueError('Squeezed transformer cannot be used with Mince transformer; specify --nosqueeze (reference :836-839)')
         self.in_ator_trans = CrossAttFeatTrans(config1, name + '-in-squeeze')

@@ -111,14 +111,14 @@ class BertAdam(Optimizer):
                 ptrs[i] = g.data_ptr()
         tab = self._tabs['grads']
         if tab.device.type != 'cuda':
-            tab.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            tab.copy_(torch.tensor(ptrs, dtype=torch.int64, device='cpu'))
             return
         if self._ring is None:
-            self._ring = [(torch.empty(len(ps), dtype=torch.int64).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+            self._ring = [(torch.empty(len(ps), dtype=torch.int64, device='cpu').pin_memory(), torch.cuda.Event()) for _ in range(4)]
         buf, ev = self._ring[self._ring_pos]
         self._ring_pos = (self._ring_pos + 1) % len(self._ring)
         ev.synchronize()                                  # the copy issued 4 steps ago from this slot (no-op in practice)
-        buf.copy_(torch.tensor(ptrs, dtype=torch.int64))
+        buf.copy_(torch.tensor(ptrs, dtype=torch.int64, device='cpu'))
         tab.copy_(buf, non_blocking=True)
         ev.record()
 

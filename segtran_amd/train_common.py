@@ -22,8 +22,8 @@ import torch
 from . import engine, dist as sdist, functional as SF
 
 UNSUPPORTED = {'polyformer_mode': None, 'adversarial_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
-               'use_attn_consist_loss': False, 'has_FFN_in_squeeze': False,
-               'in_fpn_use_bn': False, 'out_fpn_do_dropout': False, 'tune_bn_only': False}
+               'use_attn_consist_loss': False,
+               'tune_bn_only': False}
 
 
 def common_flags(p, dim):
@@ -99,7 +99,7 @@ def finalize_args(args, dim):
     return args
 
 
-ARCH_FLAGS = ('use_squeezed_transformer', 'qk_have_bias', 'num_modes', 'pos_code_type', 'pos_code_weight', 'pos_bias_radius', 'attn_clip',
+ARCH_FLAGS = ('use_squeezed_transformer', 'has_FFN_in_squeeze', 'in_fpn_use_bn', 'out_fpn_do_dropout', 'qk_have_bias', 'num_modes', 'pos_code_type', 'pos_code_weight', 'pos_bias_radius', 'attn_clip',
               'use_mince_transformer', 'mince_scales', 'mince_channel_props', 'in_fpn_layers', 'out_fpn_layers', 'bb_feat_upsize')
 
 

@@ -98,8 +98,9 @@ def req(sd):
 # --------------------------------------------------------------------------------------
 def case_squeeze():
     ss = R.ref_shared()
-    for tag, (C, Fd) in {'c64f64': (64, 64), 'c64f32': (64, 32)}.items():
+    for tag, (C, Fd) in {'c64f64': (64, 64), 'c64f32': (64, 32), 'ffn': (64, 32)}.items():
         cfg = mk_shared_config(ss, C, [C, Fd], 16)
+        cfg.has_FFN_in_squeeze = tag == 'ffn'              # --squeezeuseffn: the in-squeeze layer keeps its (1-mode) FFN
         mod = R.quiet(ss.SqueezedAttFeatTrans, cfg, 'L')
         prefix = 'voxel_fusion.translayers.0.'
         sd = load_prefixed(mod, prefix)
@@ -109,7 +110,7 @@ def case_squeeze():
         G = torch.randn(2, 48, Fd, generator=g)
         Y = mod(X); (Y * G).sum().backward()
         sdg = req(sd); Xo = X.detach().clone().requires_grad_(True)
-        Yo = O.squeezed_att_feat_trans(sdg, prefix[:-1], Xo, 4); (Yo * G).sum().backward()
+        Yo = O.squeezed_att_feat_trans(sdg, prefix[:-1], Xo, 4, ffn_in_squeeze=tag == 'ffn'); (Yo * G).sum().backward()
         close(Yo, Y, 1e-5, 'squeeze Y'); close(Xo.grad, X.grad, 1e-4, 'squeeze dX')
         rg, og = ref_param_grads(mod, prefix), oracle_grads(sdg)
         arrs = dict(X=X, G=G, Y=Y, dX=X.grad)
@@ -341,7 +342,7 @@ def case_i3d():
     save('i3d', **arrs)
 
 
-GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.bias', 'out_gn3b.weight',
+GRAD_KEYS_2D = ['in_bn4b.weight', 'in_bn4b.bias', 'out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.bias', 'out_gn3b.weight',
                 'in_fpn34_conv.weight', 'in_gn4b.bias',
                 'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight',
                 'voxel_fusion.vfeat_norm_layers.0.weight',
@@ -369,7 +370,7 @@ GRAD_KEYS_2D = ['out_conv.weight', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.
                 'backbone._blocks.31._bn1.bias', 'backbone._conv_head.weight']
 
 
-def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fundus', tied=True, **over):
+def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fundus', tied=True, oracle_kw=None, **over):
     net = R.ref_segtran2d(num_classes=3 if task == 'fundus' else 2, num_attractors=A, num_translayers=tl, compress=compress, dropout_prob=0, **over)
     sd = load_synth(net)
     if train:
@@ -393,7 +394,7 @@ def run_seg2d(tag, tl, compress, dims, A, B, S, train, fusion_kw=None, task='fun
     loss, ce, dice, _ = O.seg_loss(y, nhot, pw)          # composition restated; pinned separately by case_loss
     loss.backward()
     sdg = req(sd)
-    yo = O.segtran2d_forward(sdg, x, dims, training=train, fusion_kw=fusion_kw)
+    yo = O.segtran2d_forward(sdg, x, dims, training=train, fusion_kw=fusion_kw, **(oracle_kw or {}))
     lo = O.seg_loss(yo, nhot, pw)[0]; lo.backward()
     close(yo, y, 2e-5, tag + ' logits')
     og = oracle_grads(sdg) if tied else {k: v.grad for k, v in sdg.items() if v.grad is not None}
@@ -444,6 +445,11 @@ def case_seg2d_mince():
               fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0, mince_scales=[4, 2, 1], mince_channel_props=[1, 1, 2]),
               use_squeezed_transformer=False, use_mince_transformer=True, mince_scales=[4, 2, 1], mince_channel_props=[1, 1, 2],
               pos_code_type='bias', pos_bias_radius=2)
+
+
+def case_seg2d_inbn():
+    """--inbn: BatchNorm2d (batch statistics, train mode) instead of GroupNorm in the in-FPN"""
+    run_seg2d('seg2d_cfg1_inbn_train', 1, (1, 1), [1792, 1792], 32, 2, 64, True, oracle_kw=dict(in_fpn_use_bn=True), in_fpn_use_bn=True)
 
 
 def case_seg2d_polyp():
@@ -646,7 +652,7 @@ def case_keys():
 
 
 CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
-             seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
+             seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullsize=case_fullsize)
 
 if __name__ == '__main__':

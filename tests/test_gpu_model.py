@@ -74,6 +74,41 @@ def test_segtran2d_nosqueeze_pos_bias_vs_reference():
     _grads_vs_golden(net, g)
 
 
+def test_segtran2d_inbn_and_outdrop_vs_reference():
+    """--inbn (BatchNorm2d in the in-FPN, train-mode batch statistics) against the reference fixture; --outdrop: identity in
+    eval mode, and in train mode a fresh mask per call that zeroes ~p of the out-FPN features."""
+    g = golden('seg2d_cfg1_inbn_train')
+    c = dict(engine.CONFIGS['cfg1'], size=(64, 64))
+    net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']), in_fpn_use_bn=True)
+    net.backbone.drop_connect_rate = 0.0
+    net.train()
+    y = net(g['x'].to(DEV))
+    assert_close(y, g['logits'], 1e-4, 'logits')
+    safe = g['logits'].abs() > 1e-5
+    assert torch.equal((y.cpu() > 0)[safe], g['labels'][safe])
+    pw, cw = engine.loss_weights('fundus', DEV)
+    loss, _ = SF.seg_loss(y, engine.map_mask('fundus', g['mask'].to(DEV)), pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 2e-5
+    loss.backward()
+    assert 'grad:in_bn4b.weight' in g
+    _grads_vs_golden(net, g)
+    assert int(net.in_bn4b.num_batches_tracked) == 1 and int(net.in_bn3b.num_batches_tracked) == 0
+
+    plain = engine.build_model(c, DEV, dropout_prob=0.3, attractors=32)
+    drop = engine.build_model(c, DEV, dropout_prob=0.3, attractors=32, out_fpn_do_dropout=True)
+    drop.load_state_dict(plain.state_dict())
+    plain.eval(); drop.eval()
+    x = g['x'].to(DEV)
+    assert torch.equal(plain(x), drop(x))                      # nn.Dropout is the identity in eval mode
+    feats = {}
+    drop.out_conv.register_forward_hook(lambda m, i, o: feats.__setitem__('f', i[0].detach()))
+    drop.train()
+    SF.manual_seed(5); y1 = drop(x); f1 = feats['f']
+    y2 = drop(x); f2 = feats['f']
+    z1, z2 = (f1 == 0).float().mean().item(), (f2 == 0).float().mean().item()
+    assert abs(z1 - 0.3) < 0.02 and abs(z2 - 0.3) < 0.02 and not torch.equal(f1 == 0, f2 == 0)
+
+
 def test_segtran2d_mince_vs_reference():
     """--nosqueeze --mince --mincescales 4,2,1 --minceprops 1,1,2 --pos bias --posr 2, train mode: 12 x 12 tokens attended on
     3 x 3 / 6 x 6 / 12 x 12 grids, untied query/key, one bias table per scale; logits + loss + gradients."""

@@ -146,3 +146,22 @@ def test_interp_tokens_channels_last(backend, shape, C, kw):
     G = rnd(*y.shape, seed=32)
     y.backward(G); yr.backward(G)
     close(x.grad, xr.grad, 1e-5)
+
+
+@pytest.mark.parametrize('n', [4096 * 3, 1003])
+def test_standalone_dropout(backend, n):
+    """segx_dropout (--outdrop): keep fraction ~ 1-p, survivors scaled by 1/(1-p), backward re-uses the forward mask, the
+    Philox stream advances between calls, and eval / p = 0 is the identity."""
+    x = (rnd(n, seed=41).abs() + 0.5).requires_grad_(True)
+    SF.manual_seed(9)
+    y = SF.dropout(x, 0.25)
+    keep = y != 0
+    assert abs(keep.float().mean().item() - 0.75) < (0.02 if n > 4096 else 0.06)
+    close(y[keep], (x.detach() / 0.75)[keep], 1e-6)
+    G = rnd(n, seed=42)
+    y.backward(G)
+    assert torch.equal(x.grad != 0, keep & (G != 0))
+    close(x.grad[keep], (G / 0.75)[keep], 1e-6)
+    y2 = SF.dropout(x.detach(), 0.25)
+    assert not torch.equal(y2 != 0, keep)
+    assert SF.dropout(x, 0.25, training=False) is x and SF.dropout(x, 0.0) is x

@@ -53,10 +53,12 @@ def check_grads(mod, prefix, g, tol=3e-4):
     return grads
 
 
-@pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32)])
+@pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32), ('ffn', 64, 32)])
 def test_squeezed_att_feat_trans_vs_reference(backend, tag, C, Fd):
     g = golden_on('squeeze_' + tag, backend.dev)
-    mod = ss.SqueezedAttFeatTrans(mk_config([C, Fd], 16), 'L').to('cpu')
+    cfg = mk_config([C, Fd], 16)
+    cfg.has_FFN_in_squeeze = tag == 'ffn'                      # --squeezeuseffn: the in-squeeze layer keeps its one-mode FFN
+    mod = ss.SqueezedAttFeatTrans(cfg, 'L').to('cpu')
     prefix = 'voxel_fusion.translayers.0.'
     load(mod, prefix)
     mod.eval()
@@ -66,10 +68,11 @@ def test_squeezed_att_feat_trans_vs_reference(backend, tag, C, Fd):
     (Y * g['G']).sum().backward()
     assert_close(X.grad, g['dX'], 1e-4, 'dX')
     grads = check_grads(mod, prefix, g)
-    # N3: in-squeeze FFN / output parameters and squeeze-out first_norm_layer never receive gradients
+    # N3: in-squeeze FFN / output parameters (unless --squeezeuseffn) and the first_norm_layer of every layer WITH an FFN
+    # never receive gradients
     for k, v in grads.items():
-        if ('in_ator_trans.out_trans.intermediate' in k or 'in_ator_trans.out_trans.output' in k
-                or 'ator_out_trans.out_trans.first_norm_layer' in k):
+        if ((tag != 'ffn' and ('in_ator_trans.out_trans.intermediate' in k or 'in_ator_trans.out_trans.output' in k))
+                or 'ator_out_trans.out_trans.first_norm_layer' in k or (tag == 'ffn' and 'in_ator_trans.out_trans.first_norm_layer' in k)):
             assert v is None, k
     # in-squeeze soft-aggregate: exact-zero gradients (softmax over a single mode)
     z = grads[prefix + 'in_ator_trans.out_trans.feat_softaggr.feat2score.weight']

@@ -28,7 +28,7 @@ def _grad_check(g, og, tol=3e-4):
     assert n > 0
 
 
-@pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32)])
+@pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32), ('ffn', 64, 32)])
 def test_squeeze_module(tag, C, Fd):
     g = golden('squeeze_' + tag)
     prefix = 'voxel_fusion.translayers.0'
@@ -40,7 +40,7 @@ def test_squeeze_module(tag, C, Fd):
                    prefix + '.in_ator_trans.out_trans.feat_softaggr.feat2score.bias': (1,)})
     sdg = req(synth_state_dict(shapes))
     X = g['X'].clone().requires_grad_(True)
-    Y = O.squeezed_att_feat_trans(sdg, prefix, X, 4)
+    Y = O.squeezed_att_feat_trans(sdg, prefix, X, 4, ffn_in_squeeze=tag == 'ffn')
     (Y * g['G']).sum().backward()
     assert_close(Y, g['Y'], 1e-5, 'Y')
     assert_close(X.grad, g['dX'], 1e-4, 'dX')
@@ -173,6 +173,23 @@ def test_segtran2d_nosqueeze_pos_bias():
                             fusion_kw=dict(squeezed=False, pos_code_type='bias', pos_code_weight=1.0))
     assert_close(y, g['logits'], 2e-5, 'logits')
     assert torch.equal(y > 0, g['labels'])
+    loss = O.seg_loss(y, O.fundus_map_mask(g['mask']), O.bce_pos_weight([0., 1., 2.]))[0]
+    assert abs(loss.item() - float(g['loss'])) < 1e-5
+    loss.backward()
+    _grad_check(g, tied_grads(sdg))
+
+
+def test_segtran2d_inbn():
+    """--inbn whole model (BatchNorm2d in the in-FPN, batch statistics); parameter/buffer names from the product model."""
+    from segtran_amd import engine
+    g = golden('seg2d_cfg1_inbn_train')
+    net = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(64, 64)), 'cpu', dropout_prob=0.0, attractors=int(g['A']),
+                             synth=False, in_fpn_use_bn=True)
+    keys = set(net.state_dict())
+    assert {'in_bn4b.weight', 'in_bn4b.running_var', 'in_bn3b.num_batches_tracked'} <= keys and 'in_gn4b.weight' not in keys
+    sdg = req(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    y = O.segtran2d_forward(sdg, g['x'], [int(d) for d in g['dims']], training=True, in_fpn_use_bn=True)
+    assert_close(y, g['logits'], 2e-5, 'logits')
     loss = O.seg_loss(y, O.fundus_map_mask(g['mask']), O.bce_pos_weight([0., 1., 2.]))[0]
     assert abs(loss.item() - float(g['loss'])) < 1e-5
     loss.backward()

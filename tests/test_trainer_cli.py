@@ -17,7 +17,7 @@ def test_reference_flag_names_and_segtran_defaults():
     assert (b.num_attractors, b.translayer_compress_ratios, b.batch_size) == (1024, [1, 1], 4)
 
 
-@pytest.mark.parametrize('flag', ['--multihead', '--attnconsist', '--squeezeuseffn', '--inbn', '--outdrop'])
+@pytest.mark.parametrize('flag', ['--multihead', '--attnconsist'])
 def test_out_of_scope_features_are_rejected_loudly(flag):
     with pytest.raises(SystemExit):
         _parse([flag], 2)
