@@ -513,6 +513,28 @@ def conv1x1(x, weight, bias=None):
     return bgemm(weight.reshape(Cout, Cin), x, spec, bias=bias)
 
 
+def conv1x1_tokens(tokens, grid_shape, weight):
+    """Pointwise convolution of a channels-last token tensor [B, N, C] straight into the NC[D]HW map [B, Cout, *grid_shape]
+    (y[b, o, n] = sum_c W[o, c] tokens[b, n, c]) -- the [B, N, C] -> [B, C, N] transposition never happens."""
+    B, N, C = tokens.shape
+    Cout = weight.shape[0]
+    spec = GemmSpec(Cout, N, C, (0, 0, C, 1), (N * C, 0, C, 1), (Cout * N, 0, N), (B, Cout) + tuple(int(g) for g in grid_shape), nb=(B, 1))
+    return bgemm(weight.reshape(Cout, C), tokens, spec)
+
+
+def compose_conv1x1(w_out, b_out, w_in, b_in):
+    """Weights of conv1x1(conv1x1(x, w_in, b_in), w_out, b_out) as ONE pointwise convolution: W = w_out @ w_in,
+    b = w_out @ b_in + b_out (both through the differentiable GEMM op, so each factor still receives its exact gradient)."""
+    nc, Fd = w_out.shape[0], w_out.shape[1]
+    Cin = w_in.shape[1]
+    wo = w_out.reshape(nc, Fd)
+    W = bgemm(wo, w_in.reshape(Fd, Cin), GemmSpec(nc, Cin, Fd, (0, 0, Fd, 1), (0, 0, 1, Cin), (0, 0, Cin), (nc, Cin)))
+    b = b_out
+    if b_in is not None:
+        b = linear(b_in.view(1, Fd), wo, b_out).view(nc)
+    return W.view((nc, Cin) + tuple(w_out.shape[2:])), b
+
+
 # -------------------------------------------------------------------------------------------------
 # Segmentation loss (train2d.py:1233-1242,1314-1318 / train3d.py:738-756), fused fwd + bwd
 # -------------------------------------------------------------------------------------------------

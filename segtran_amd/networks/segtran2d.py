@@ -116,6 +116,9 @@ class Segtran2d(SegtranInitWeights):
             self.in_gn3b = nn.GroupNorm(self.G, d[3])
             self.in_gn4b = nn.GroupNorm(self.G, d[4])
         self.out_fpn_do_dropout = config.out_fpn_do_dropout     # --outdrop (:308-310)
+        # out_fpn_bridgeconv -> (+ up-sampled transformer output) -> out_conv is a chain of LINEAR maps: by default the class
+        # projection is composed into the bridge weights and applied before the up-sampling (see out_head_forward)
+        self.fuse_output_tail = True
         self.num_classes = config.num_classes
         self.num_modalities = 0
         self.do_out_fpn = True
@@ -157,6 +160,22 @@ class Segtran2d(SegtranInitWeights):
             out = SF.dropout(out, self.out_fpn_dropout.p, self.training)
         return out
 
+    def out_head_forward(self, feats, fused_tokens, grid_shape, size):
+        """out_conv(out_fpn_bridgeconv(cur) + up(vfeat_fused)) re-associated as  (W_out W_bridge) cur + up(W_out vfeat_fused):
+        pointwise convolutions compose, and a pointwise convolution commutes with bilinear resampling (the blend weights sum
+        to 1, so the bias commutes too).  Same function and same gradients for every parameter (chain rule through the composed
+        weight), fp32 rounding aside; the trans_out_dim-channel map at the out-FPN resolution is never formed (reference op
+        order, :304-306 then :427-436: `fuse_output_tail = False`)."""
+        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv(feats[1])), self.out_gn2b)
+        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv(cur)), self.out_gn3b)
+        wo, bo = self.out_conv.weight, self.out_conv.bias
+        if isinstance(self.out_fpn_bridgeconv, nn.Identity):
+            lateral = SF.conv1x1(cur, wo, bo)
+        else:
+            lateral = SF.conv1x1(cur, *SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv.weight, self.out_fpn_bridgeconv.bias))
+        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), cur.shape[2:], base=lateral)
+        return _up(scores, size)
+
     def forward(self, batch):
         self.feature_maps = []
         B, C, H, W = batch.shape
@@ -175,6 +194,8 @@ class Segtran2d(SegtranInitWeights):
         if self.keep_feature_maps:
             self.feature_maps = [vfeat.transpose(1, 2).view(B, -1, H2, W2)] + \
                 [lv.view(B, H2, W2, -1).permute(0, 3, 1, 2) for lv in self.voxel_fusion.layers_vfeat]
+        if self.fuse_output_tail and not self.out_fpn_do_dropout:
+            return self.out_head_forward(feats, fused, (H2, W2), (H, W))
         fused = fused.view(B, H2, W2, self.trans_out_dim).permute(0, 3, 1, 2)
         out = self.out_fpn_forward(feats, fused, B)
         return _up(self.out_conv(out), (H, W))

@@ -130,6 +130,7 @@ class Segtran3d(SegtranInitWeights):
             self.in_gn3b = nn.GroupNorm(self.G, d[3])
             self.in_gn4b = nn.GroupNorm(self.G, d[4])
         self.out_fpn_do_dropout = config.out_fpn_do_dropout      # --outdrop (:392-394)
+        self.fuse_output_tail = True                             # see out_head_forward
         self.num_classes = config.num_classes
         self.do_out_fpn = True
         self.out_fpn_out_dim = self.out_feat_dim = self.trans_out_dim
@@ -174,6 +175,25 @@ class Segtran3d(SegtranInitWeights):
             out = SF.dropout(out, self.out_fpn_dropout.p, self.training)
         return out
 
+    def out_head_forward(self, feats, fused_tokens, grid_shape, size):
+        """out_conv3d(upD(out_fpn_bridgeconv3d(cur) + up(vfeat_fused))) re-associated as
+        upD((W_out W_bridge) cur + up(W_out vfeat_fused)): pointwise convolutions compose and commute with trilinear resampling
+        (blend weights sum to 1).  Same function, same parameter gradients (chain rule through the composed weight), fp32
+        rounding aside -- and the 1024-channel maps at the out-FPN resolution (2 x 2.5 GB at cfg4), the 832 -> 1024 bridge GEMMs
+        over 150528 voxels (fwd / bwd-data / bwd-weight) and their resampling passes never exist.  Reference op order
+        (:364-367, :381-386, :490): `fuse_output_tail = False`."""
+        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv3d(feats[1])), self.out_gn2b)
+        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv3d(cur)), self.out_gn3b)
+        wo, bo = self.out_conv3d.weight, self.out_conv3d.bias
+        if isinstance(self.out_fpn_bridgeconv3d, nn.Identity):
+            lateral = SF.conv1x1(cur, wo, bo)
+        else:
+            lateral = SF.conv1x1(cur, *SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv3d.weight, self.out_fpn_bridgeconv3d.bias))
+        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), cur.shape[2:], base=lateral)
+        if self.D_pool_K > 1:
+            scores = _up(scores, [scores.shape[2] * self.D_pool_K, scores.shape[3], scores.shape[4]])
+        return _up(scores.permute(0, 1, 3, 4, 2), size)
+
     def forward(self, batch):
         B, C, H, W, D = batch.shape
         assert C == self.orig_in_channels
@@ -191,6 +211,8 @@ class Segtran3d(SegtranInitWeights):
         fused = self.voxel_fusion(vfeat, voxels_pos, vmask, xyz_shape)
         self.layers_attn_scores = self.voxel_fusion.layers_attn_scores
         self.orig_feat_shape = xyz_shape
+        if self.fuse_output_tail and not self.out_fpn_do_dropout:
+            return self.out_head_forward(feats, fused, (D2, H2, W2), (H, W, D))
         fused = fused.view(B, D2, H2, W2, self.trans_out_dim).permute(0, 4, 1, 2, 3)
         out = self.out_fpn_forward(feats, fused)                                  # [B, F, D, H, W]
         # the class projection is pointwise, so it commutes exactly with the (H,W,D) permutation of :488-490;

@@ -32,12 +32,14 @@ def _grads_vs_golden(net, g, tol=1e-3, tol_backbone=None):
         assert named[str(k)].grad is None, k
 
 
+@pytest.mark.parametrize('fused_tail', [True, False], ids=['composed-head', 'reference-op-order'])
 @pytest.mark.parametrize('tag,cfg,train', [('seg2d_cfg2_eval', 'cfg2', False), ('seg2d_cfg1_eval', 'cfg1', False),
                                            ('seg2d_cfg2_train', 'cfg2', True)])
-def test_segtran2d_vs_reference(tag, cfg, train):
+def test_segtran2d_vs_reference(tag, cfg, train, fused_tail):
     g = golden(tag)
     c = dict(engine.CONFIGS[cfg], size=(64, 64))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.fuse_output_tail = fused_tail                      # default True: class projection composed into the bridge weights
     net.backbone.drop_connect_rate = 0.0                   # fixture: drop_connect off, dropout 0 (H3)
     net.train() if train else net.eval()
     x = g['x'].to(DEV)
@@ -97,6 +99,7 @@ def test_segtran2d_inbn_and_outdrop_vs_reference():
     plain = engine.build_model(c, DEV, dropout_prob=0.3, attractors=32)
     drop = engine.build_model(c, DEV, dropout_prob=0.3, attractors=32, out_fpn_do_dropout=True)
     drop.load_state_dict(plain.state_dict())
+    plain.fuse_output_tail = False                             # same op order as the --outdrop model (which never composes the head)
     plain.eval(); drop.eval()
     x = g['x'].to(DEV)
     assert torch.equal(plain(x), drop(x))                      # nn.Dropout is the identity in eval mode
@@ -132,11 +135,13 @@ def test_segtran2d_mince_vs_reference():
     _grads_vs_golden(net, g)
 
 
+@pytest.mark.parametrize('fused_tail', [True, False], ids=['composed-head', 'reference-op-order'])
 @pytest.mark.parametrize('tag,train', [('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)])
-def test_segtran3d_vs_reference(tag, train):
+def test_segtran3d_vs_reference(tag, train, fused_tail):
     g = golden(tag)
     c = dict(engine.CONFIGS['cfg4'], size=(112, 112, 16))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
+    net.fuse_output_tail = fused_tail
     net.train() if train else net.eval()
     x, lab = synth_brats(1, 112, 112, 16, 1337)
     assert torch.equal(sample(x), g['x_sample'])

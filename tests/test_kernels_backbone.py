@@ -165,3 +165,30 @@ def test_standalone_dropout(backend, n):
     y2 = SF.dropout(x.detach(), 0.25)
     assert not torch.equal(y2 != 0, keep)
     assert SF.dropout(x, 0.25, training=False) is x and SF.dropout(x, 0.0) is x
+
+
+@pytest.mark.parametrize('grid', [(6, 5), (3, 4, 5)])
+def test_composed_output_head_equals_reference_op_order(backend, grid):
+    """out_conv(bridge(cur) + up(y)) == conv(cur; W_out W_bridge, W_out b_bridge + b_out) + up(conv_tokens(y; W_out)): values and
+    the gradients of every factor (W_out, b_out, W_bridge, b_bridge, cur, y), against the reference op order in plain PyTorch."""
+    nd = len(grid)
+    B, d3, Fd, nc = 2, 12, 20, 3
+    big = tuple(2 * g for g in grid)
+    N = int(torch.tensor(grid).prod())
+    ones = (1,) * nd
+    cur = rnd(B, d3, *big, seed=51).requires_grad_(True)
+    tok = rnd(B, N, Fd, seed=52).requires_grad_(True)
+    Wb = (rnd(Fd, d3, *ones, seed=53) * 0.3).requires_grad_(True); bb = rnd(Fd, seed=54).requires_grad_(True)
+    Wo = (rnd(nc, Fd, *ones, seed=55) * 0.3).requires_grad_(True); bo = rnd(nc, seed=56).requires_grad_(True)
+    lateral = SF.conv1x1(cur, *SF.compose_conv1x1(Wo, bo, Wb, bb))
+    y = SF.interp_linear(SF.conv1x1_tokens(tok, grid, Wo), big, lateral)
+    ref_in = [t.detach().clone().requires_grad_(True) for t in (cur, tok, Wb, bb, Wo, bo)]
+    c_, t_, Wb_, bb_, Wo_, bo_ = ref_in
+    conv = F.conv2d if nd == 2 else F.conv3d
+    ymap = t_.view(B, *grid, Fd).permute(0, nd + 1, *range(1, nd + 1))
+    yr = conv(conv(c_, Wb_, bb_) + F.interpolate(ymap, size=big, mode='bilinear' if nd == 2 else 'trilinear', align_corners=False), Wo_, bo_)
+    close(y, yr.detach(), 1e-5)
+    G = rnd(*y.shape, seed=57)
+    y.backward(G); yr.backward(G)
+    for a, b in zip((cur, tok, Wb, bb, Wo, bo), ref_in):
+        close(a.grad, b.grad, 1e-4)
