@@ -210,13 +210,25 @@ class ExpandedFeatTrans(nn.Module):
             parts.append(SF.interp_tokens(fused, shapes[s_], out_shape=geoshape).view(B, U, M, fs))            # :439
         return torch.cat(parts, dim=-1).permute(2, 0, 1, 3).contiguous()                                       # :443
 
-    def forward(self, input_feat, attention_probs, in_geoshape=None):
-        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] (mince: a list, one per scale) -> [B, U1, F]."""
+    def forward(self, input_feat, attention_probs, in_geoshape=None, value_last=False):
+        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] (mince: a list, one per scale) -> [B, U1, F].
+        value_last (one mode, bias-free value projection): fuse first, project after -- (P X) Wv^T instead of P (X Wv^T); the
+        projection then runs over the U1 fused rows instead of the U2 input tokens (see CrossAttFeatTrans.forward)."""
         B, U2, IF = input_feat.shape
         M, Fd = self.num_modes, self.feat_dim
         drop = self.hidden_dropout_prob if self.training else 0.0
-        v = SF.linear(input_feat, self.first_linear.weight, self.first_linear.bias)       # [B, U2, M*F]
-        if self.num_scales > 0:
+        if value_last:
+            assert M == 1 and self.first_linear.bias is None and self.num_scales == 0
+            U1 = attention_probs.shape[2]
+            px = SF.bgemm(attention_probs, input_feat,
+                          GemmSpec(U1, IF, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * IF, 0, 1, IF), (U1 * IF, 0, IF), (B, U1, IF), nb=(B, 1)))
+            fused = SF.linear(px, self.first_linear.weight).view(1, B, U1, Fd)
+            v = None
+        else:
+            v = SF.linear(input_feat, self.first_linear.weight, self.first_linear.bias)   # [B, U2, M*F]
+        if value_last:
+            pass
+        elif self.num_scales > 0:
             U1 = U2
             fused = self._fuse_mince(v, attention_probs, tuple(int(g) for g in in_geoshape))
         else:
@@ -251,6 +263,7 @@ class ExpandedFeatTrans(nn.Module):
 
 class CrossAttFeatTrans(nn.Module):
     """Multi-mode cross attention (reference :478-610)."""
+    reassociate_projections = True        # False: the reference's op order everywhere (key/value projections over all tokens)
 
     def __init__(self, config, name):
         super().__init__()
@@ -300,14 +313,33 @@ class CrossAttFeatTrans(nn.Module):
         U1, M, d = in_query.shape[1], self.num_modes, self.attention_mode_dim
         shared_q = in_query.shape[0] == 1 and B > 1
         q = SF.linear(in_query, self.query.weight, self.query.bias)                      # :559
-        k = SF.linear(in_key, self.key.weight, self.key.bias)                            # :560
         gmax = torch.zeros(1, dtype=torch.float32, device=in_key.device)
+        drop = self.attention_probs_dropout_prob if self.training else 0.0
+        if (self.reassociate_projections and M == 1 and in_query.shape[0] == 1 and 2 * U1 <= U2 and pos_biases is None
+                and self.out_trans.first_linear.bias is None and self.out_trans.num_scales == 0):
+            # In-squeeze layer: few shared queries (the attractors) attend to many tokens with ONE mode.  The key and value
+            # projections are linear maps of the U2 tokens that are immediately contracted with U1-row operands, so they are
+            # re-associated onto the U1 side:   q (X Wk^T + bk)^T = (q Wk) X^T + (q.bk) 1^T   and   P (X Wv^T) = (P X) Wv^T.
+            # Same function, same parameter gradients (autograd through the same GEMM op), fp32 rounding aside; the two
+            # [B*U2, C] x [C, C] projection GEMMs (158 GFLOP each at cfg2, plus 2x that in backward) become U1-row GEMMs.
+            alpha = 1.0 / math.sqrt(d)
+            wk, bk = self.key.weight, self.key.bias
+            qk = SF.bgemm(q, wk, GemmSpec(U1, C, d, (0, 0, d, 1), (0, 0, 1, C), (0, 0, C), (U1, C), alpha=alpha))
+            rb = None
+            if bk is not None:
+                rb = SF.bgemm(q, bk.view(1, d), GemmSpec(U1, 1, d, (0, 0, d, 1), (0, 0, d, 1), (0, 0, 1), (U1,), alpha=alpha))
+            scores = SF.bgemm(qk, in_key, GemmSpec(U1, U2, C, (0, 0, C, 1), (U2 * C, 0, C, 1), (U1 * U2, B * U1 * U2, U2),
+                                                   (1, B, U1, U2), nb=(B, 1), bias_mode=SF.BIAS_M), bias=rb, gmax=gmax)
+            self.attn_max_dev = gmax
+            probs = SF.softmax(scores, self.attn_clip, gmax, drop)
+            self.attention_scores = scores if self.keep_attn_scores else None
+            return self.out_trans(in_key, probs, value_last=True)
+        k = SF.linear(in_key, self.key.weight, self.key.bias)                            # :560
         # scores[m,b] = q[b,:,m*d:(m+1)*d] k[b,:,m*d:(m+1)*d]^T / sqrt(d), max tracked in the epilogue (:566-570)
         scores = SF.bgemm(q, k, GemmSpec(U1, U2, d, (0 if shared_q else U1 * C, d, C, 1), (U2 * C, d, C, 1),
                                          (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),
                                          alpha=1.0 / math.sqrt(d)), gmax=gmax)
         self.attn_max_dev = gmax
-        drop = self.attention_probs_dropout_prob if self.training else 0.0
         if pos_biases is not None:                                                       # :578-580 then :590-592
             assert U1 == U2 == pos_biases.numel, 'positional biases need self-attention over the whole token grid'
             scores = SF.pos_bias_add(scores, pos_biases.table, pos_biases.grid_shape, self.pos_code_weight,

@@ -32,10 +32,12 @@ def _grads_vs_golden(net, g, tol=1e-3, tol_backbone=None):
         assert named[str(k)].grad is None, k
 
 
-@pytest.mark.parametrize('fused_tail', [True, False], ids=['composed-head', 'reference-op-order'])
+@pytest.mark.parametrize('fused_tail', [True, False], ids=['reassociated', 'reference-op-order'])
 @pytest.mark.parametrize('tag,cfg,train', [('seg2d_cfg2_eval', 'cfg2', False), ('seg2d_cfg1_eval', 'cfg1', False),
                                            ('seg2d_cfg2_train', 'cfg2', True)])
-def test_segtran2d_vs_reference(tag, cfg, train, fused_tail):
+def test_segtran2d_vs_reference(tag, cfg, train, fused_tail, monkeypatch):
+    from segtran_amd.networks import segtran_shared as ss
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', fused_tail)      # both re-associations on, or neither
     g = golden(tag)
     c = dict(engine.CONFIGS[cfg], size=(64, 64))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
@@ -135,9 +137,11 @@ def test_segtran2d_mince_vs_reference():
     _grads_vs_golden(net, g)
 
 
-@pytest.mark.parametrize('fused_tail', [True, False], ids=['composed-head', 'reference-op-order'])
+@pytest.mark.parametrize('fused_tail', [True, False], ids=['reassociated', 'reference-op-order'])
 @pytest.mark.parametrize('tag,train', [('seg3d_cfg4_eval', False), ('seg3d_cfg4_train', True)])
-def test_segtran3d_vs_reference(tag, train, fused_tail):
+def test_segtran3d_vs_reference(tag, train, fused_tail, monkeypatch):
+    from segtran_amd.networks import segtran_shared as ss
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', fused_tail)
     g = golden(tag)
     c = dict(engine.CONFIGS['cfg4'], size=(112, 112, 16))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))

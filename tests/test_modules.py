@@ -53,8 +53,15 @@ def check_grads(mod, prefix, g, tol=3e-4):
     return grads
 
 
+@pytest.mark.parametrize('reassoc', [True, False], ids=['projections-after-contraction', 'reference-op-order'])
 @pytest.mark.parametrize('tag,C,Fd', [('c64f64', 64, 64), ('c64f32', 64, 32), ('ffn', 64, 32)])
-def test_squeezed_att_feat_trans_vs_reference(backend, tag, C, Fd):
+def test_squeezed_att_feat_trans_vs_reference(backend, monkeypatch, tag, C, Fd, reassoc):
+    """reassoc=True (default): the in-squeeze key/value projections are applied after the contraction with the attractor-side
+    operands ((q Wk) X^T, (P X) Wv^T); False: projections over all tokens first, as the reference orders them."""
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassoc)
+    calls = []
+    orig = ss.ExpandedFeatTrans.forward
+    monkeypatch.setattr(ss.ExpandedFeatTrans, 'forward', lambda self, *a, **kw: (calls.append(kw.get('value_last', False)), orig(self, *a, **kw))[1])
     g = golden_on('squeeze_' + tag, backend.dev)
     cfg = mk_config([C, Fd], 16)
     cfg.has_FFN_in_squeeze = tag == 'ffn'                      # --squeezeuseffn: the in-squeeze layer keeps its one-mode FFN
@@ -64,6 +71,7 @@ def test_squeezed_att_feat_trans_vs_reference(backend, tag, C, Fd):
     mod.eval()
     X = g['X'].clone().requires_grad_(True)
     Y = mod(X)
+    assert calls == [reassoc, False]                           # in-squeeze (one mode, 16 queries, 48 tokens), then squeeze-out
     assert_close(Y, g['Y'], 2e-5, 'Y')
     (Y * g['G']).sum().backward()
     assert_close(X.grad, g['dX'], 1e-4, 'dX')
