@@ -151,8 +151,9 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
     using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (d->epilogue == SEGX_EPI_GELU) {
-        SEGX_REQUIRE(akc && bkc, "segx_gemm_f32: the GELU epilogue is built for k-contiguous operands (nn.Linear)");
-        if (vec) SEGX_LAUNCH(Cfg128, true, true, true, SEGX_EPI_GELU); else SEGX_LAUNCH(Cfg128, true, true, false, SEGX_EPI_GELU);
+        SEGX_REQUIRE(akc, "segx_gemm_f32: the GELU epilogue is built for a k-contiguous A operand (nn.Linear, attention fusion)");
+        if (bkc) { if (vec) SEGX_LAUNCH(Cfg128, true, true, true, SEGX_EPI_GELU); else SEGX_LAUNCH(Cfg128, true, true, false, SEGX_EPI_GELU); }
+        else { if (vec) SEGX_LAUNCH(Cfg128, true, false, true, SEGX_EPI_GELU); else SEGX_LAUNCH(Cfg128, true, false, false, SEGX_EPI_GELU); }
     } else if (!vec) {
         SEGX_LAUNCH_LAYOUT(Cfg128, false, SEGX_EPI_NONE);
     } else if (tile == SEGX_TILE_64x64) {

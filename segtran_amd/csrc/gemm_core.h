@@ -274,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
                     if (ok) AUX[(int64_t)row * ldc + col] = v;
                     v = gelu_erf(v);
                     if (g.dropout_p > 0.f)
-                        v *= dropout_scale(g.seed, g.offset, ((uint64_t)zb * g.M + row) * g.N + col, g.dropout_p, inv_keep);
+                        v *= dropout_scale(g.seed, g.offset, (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1) + (uint64_t)row * ldc + col, g.dropout_p, inv_keep);   // element offset in C: what segx_gelu_bwd regenerates
                 }
                 if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
             }

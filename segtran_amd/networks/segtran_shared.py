@@ -233,10 +233,20 @@ class ExpandedFeatTrans(nn.Module):
             fused = self._fuse_mince(v, attention_probs, tuple(int(g) for g in in_geoshape))
         else:
             U1 = attention_probs.shape[2]
+            fuse_spec = GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
+                                 (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M))
+            if self.has_FFN and U2 < U1 and CrossAttFeatTrans.reassociate_projections:
+                # Squeeze-out layer: U1 tokens gather from U2 << U1 attractors, then MMSharedMid (:232-251) applies one [F, F]
+                # linear map to every fused row:  (P v) Wmid^T + b  ==  P (v Wmid^T) + b.  The map is applied to the U2 value
+                # rows instead (M*B*U2 rows instead of M*B*U1: 39 vs 632 GFLOP at cfg2), and the fusion GEMM carries the bias +
+                # GELU + dropout epilogue.  The fused values themselves are needed by nothing else (N1: the residual is dropped).
+                mid, out = self.intermediate.shared_linear, self.output
+                u = SF.linear(v.view(B, U2, M, Fd), mid.weight)                           # [B, U2, M, F], bias added after fusion
+                fuse_spec.bias_mode = SF.BIAS_N
+                h = SF.bgemm(attention_probs, u, fuse_spec, bias=mid.bias, gelu=True, drop_p=drop)
+                return self._ffn_tail(h, B, U1, drop)
             # fused[m,b] = probs[m,b] @ v[b, :, m*F:(m+1)*F]   (no [B,M*F,U] transposes)
-            fused = SF.bgemm(attention_probs, v,
-                             GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
-                                      (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M)))
+            fused = SF.bgemm(attention_probs, v, fuse_spec)
         agg = self.feat_softaggr.feat2score
         if not self.has_FFN:
             # LearnedSoftAggregate over M modes, then first_norm_layer (:452-457).
@@ -249,8 +259,14 @@ class ExpandedFeatTrans(nn.Module):
             y = SF.modes_aggr(fused.view(M, B * U1, Fd), None, None, agg.weight, agg.bias, 0.0)
             y = SF.layer_norm(y, self.first_norm_layer.weight, self.first_norm_layer.bias)
             return y.view(B, U1, Fd)
-        mid, out = self.intermediate.shared_linear, self.output
+        mid = self.intermediate.shared_linear
         h = SF.linear(fused, mid.weight, mid.bias, gelu=True, drop_p=drop)               # MMSharedMid :232-251
+        return self._ffn_tail(h, B, U1, drop)
+
+    def _ffn_tail(self, h, B, U1, drop):
+        """MMPrivateOutput (per-mode linear, dropout, LayerNorm) + LearnedSoftAggregate on h [M, B, U1, F]."""
+        M, Fd = self.num_modes, self.feat_dim
+        out, agg = self.output, self.feat_softaggr.feat2score
         R = B * U1
         z = SF.bgemm(h, out.group_linear.weight,                                          # MMPrivateOutput :267
                      GemmSpec(R, Fd, Fd, (0, R * Fd, Fd, 1), (0, Fd * Fd, Fd, 1), (0, R * Fd, Fd), (M, R, Fd),

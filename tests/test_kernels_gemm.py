@@ -141,3 +141,32 @@ def test_conv1x1_autograd_vs_torch(backend, shape, bias):
     for a, r in zip(got, (yr.detach(), x.grad, w.grad, b.grad if bias else None)):
         if r is not None:
             assert (a - r).abs().max().item() < 1e-4 * max(1.0, r.abs().max().item())
+
+
+@pytest.mark.parametrize('p', [0.0, 0.3])
+def test_fusion_gemm_with_gelu_dropout_epilogue_mode_major(backend, p):
+    """The squeeze-out fusion h[m,b] = dropout(gelu(P[m,b] @ u[b,:,m,:] + bias)): A k-contiguous, B row-contiguous, batch (B, M)
+    written mode-major.  The dropout mask is keyed by the element's offset in C, so the backward pass (which regenerates it over
+    the contiguous tensor) sees the forward's mask: values and both operand gradients against PyTorch with the inferred mask."""
+    from segtran_amd import functional as SF
+    import torch.nn.functional as F
+    B, M, U1, U2, Fd = 2, 3, 40, 12, 36
+    g = torch.Generator(device='cpu').manual_seed(77)
+    mk = lambda *sh: torch.randn(*sh, generator=g, device='cpu').to(backend.dev)      # noqa: E731
+    P = mk(M, B, U1, U2).requires_grad_(True); u = mk(B, U2, M, Fd).requires_grad_(True); bias = mk(Fd).requires_grad_(True)
+    spec = SF.GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd), (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd),
+                       nb=(B, M), bias_mode=SF.BIAS_N)
+    SF.manual_seed(3)
+    h = SF.bgemm(P, u, spec, bias=bias, gelu=True, drop_p=p)
+    Pr, ur, br = (t.detach().clone().requires_grad_(True) for t in (P, u, bias))
+    pre = torch.einsum('mbik,bkmf->mbif', Pr, ur) + br
+    act = F.gelu(pre)
+    keep = (h.detach() != 0) | (act.detach() == 0)
+    if p > 0:
+        assert abs(keep.float().mean().item() - (1 - p)) < 0.05
+    href = act * keep / (1 - p)
+    assert (h.detach() - href.detach()).abs().max().item() <= 2e-5 * href.detach().abs().max().item()
+    G = mk(M, B, U1, Fd)
+    h.backward(G); href.backward(G)
+    for a, b in ((P, Pr), (u, ur), (bias, br)):
+        assert (a.grad - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
