@@ -82,6 +82,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2', help='BASELINE config (cfg2 = metric default; cfg4 = BraTS 3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--reference-op-order', action='store_true',
+                    help="time the reference's operation order (no linear-chain re-association, DESIGN.md section 5b) as the main number")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.threads)))
@@ -99,7 +101,16 @@ def main():
 
     torch.manual_seed(1234)
     SF.manual_seed(1234 + rank)
+    from segtran_amd.networks import segtran_shared as ss
+
+    def set_op_order(net_, reassociated):
+        # exact re-associations of consecutive linear maps (same function, same parameter gradients): attention projections applied
+        # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
+        ss.CrossAttFeatTrans.reassociate_projections = reassociated
+        net_.fuse_output_tail = reassociated
+
     net = engine.build_model(args.config, dev)
+    set_op_order(net, not args.reference_op_order)
     sdist.enable_sync_batchnorm()
     net.train()
     opt = engine.init_optimizer(net, c['task'])
@@ -130,6 +141,19 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
+    other = None
+    if world == 1:              # the same step in the OTHER operation order, outside the timed region (reported beside the main number)
+        set_op_order(net, args.reference_op_order)
+        for _ in range(2):
+            step(x, raw)
+        torch.cuda.synchronize()
+        k = max(2, args.steps // 2)
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step(x, raw)
+        torch.cuda.synchronize()
+        other = (time.perf_counter() - t1) / k
+        set_op_order(net, not args.reference_op_order)
     if rank != 0:
         return
     lossv = float(loss.detach())
@@ -179,7 +203,11 @@ def main():
                                    'cfg4': 'BraTS 3D, segtran i3d, translayers 1, attractors 1024, 112x112x96 x4 modalities, bs 4/GPU'}
                                   .get(args.config, args.config),
                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'dropout': 0.2,
-                      'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5)},
+                      'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5),
+                      'op_order': ("reference" if args.reference_op_order else "re-associated") + ' (DESIGN.md 5b: exact re-association of '
+                                  'consecutive linear maps; every layer, parameter and gradient is computed)',
+                      ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
+                          None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)}},
            'roofline': roof}
     print('[bench] %s: %.1f ms/step, %.2f %s, GEMM %.1f TFLOP/s' % (args.config, res['ms_per_step'], res['value'], unit, achieved),
           file=sys.stderr, flush=True)

@@ -50,6 +50,7 @@ typedef struct {
     int32_t splitk;                   /* >1: K split over `splitk` slabs in `workspace`, then reduced */
     float* workspace;                 /* splitk*nb0*nb1*M*N floats when splitk>1 */
     int32_t tile;                     /* workgroup tile: SEGX_TILE_AUTO or one of SEGX_TILE_* (a tuning knob; results are identical) */
+    int64_t bias_b0;                  /* bias stride over z0 (a bias vector per (z0, z1): the key-side term of re-associated scores) */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,
                                                             int64_t c_b0, int64_t c_b1, int64_t c_m, float alpha,
-                                                            int bias_mode, int64_t bias_b1, int64_t total) {
+                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(idx % N);
         const int64_t t = idx / N;
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int k = 0; k < splitk; ++k) s += ws[(int64_t)k * c_split + idx];
         s *= alpha;
         const int z0 = zb / nb1, z1 = zb - z0 * nb1;
-        if (bias_mode == SEGX_BIAS_N) s += bias[z1 * bias_b1 + col];
-        else if (bias_mode == SEGX_BIAS_M) s += bias[z1 * bias_b1 + row];
+        if (bias_mode == SEGX_BIAS_N) s += bias[z0 * bias_b0 + z1 * bias_b1 + col];
+        else if (bias_mode == SEGX_BIAS_M) s += bias[z0 * bias_b0 + z1 * bias_b1 + row];
         C[z0 * c_b0 + z1 * c_b1 + (int64_t)row * c_m + col] = s;
     }
 }
@@ -118,7 +118,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1;
     g.a_b0 = d->a_b0; g.a_b1 = d->a_b1; g.a_m = d->a_m; g.a_k = d->a_k;
     g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;
-    g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1;
+    g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1; g.bias_b0 = d->bias_b0;
     g.alpha = d->alpha; g.epilogue = d->epilogue; g.bias_mode = d->bias_mode;
     const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
     const bool vec = gemm_vec_ok(A, B, d);
@@ -173,7 +173,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         const int64_t total = g.c_split;
         const int blocks = (int)i64min(2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                           d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, total);
+                           d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, d->bias_b0, total);
         rc = check_launch("segx_gemm_f32/splitk_reduce");
     }
     return rc;

@@ -31,7 +31,7 @@ struct GemmArgs {
     int64_t a_b0, a_b1, a_m, a_k;
     int64_t b_b0, b_b1, b_n, b_k;
     int64_t c_b0, c_b1, c_m;
-    int64_t bias_b1;
+    int64_t bias_b1, bias_b0;
     float alpha; int epilogue, bias_mode;
     int vecA, vecB;                 // float4 global loads legal (alignment + stride checks done on host)
     int tiles_m, tiles_n;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     float* C = split ? g.C + (int64_t)zk * g.c_split + (int64_t)zb * g.M * g.N : g.C + z0 * g.c_b0 + z1 * g.c_b1;
     const int64_t ldc = split ? g.N : g.c_m;
     const float alpha = split ? 1.0f : g.alpha;
-    const float* bias = (g.bias && !split) ? g.bias + z1 * g.bias_b1 : nullptr;
+    const float* bias = (g.bias && !split) ? g.bias + z0 * g.bias_b0 + z1 * g.bias_b1 : nullptr;
     const bool bias_n = bias && g.bias_mode == SEGX_BIAS_N, bias_m = bias && g.bias_mode == SEGX_BIAS_M;
     float* AUX = (EPI == SEGX_EPI_GELU) ? g.aux + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;
     const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
@@ -324,6 +324,6 @@ inline int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, doub
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,
                                                             int64_t c_b0, int64_t c_b1, int64_t c_m, float alpha,
-                                                            int bias_mode, int64_t bias_b1, int64_t total);
+                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total);
 
 }  // namespace segx

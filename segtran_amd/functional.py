@@ -44,11 +44,11 @@ def _c(t):
 # -------------------------------------------------------------------------------------------------
 class GemmSpec:
     """C[z0,z1][m][n] = alpha * sum_k A(z,m,k) B(z,n,k) (+bias); strides in elements (see segx.h)."""
-    __slots__ = ('M', 'N', 'K', 'nb', 'a', 'b', 'c', 'out_shape', 'alpha', 'bias_mode', 'bias_b1')
+    __slots__ = ('M', 'N', 'K', 'nb', 'a', 'b', 'c', 'out_shape', 'alpha', 'bias_mode', 'bias_b1', 'bias_b0')
 
-    def __init__(self, M, N, K, a, b, c, out_shape, nb=(1, 1), alpha=1.0, bias_mode=BIAS_NONE, bias_b1=0):
+    def __init__(self, M, N, K, a, b, c, out_shape, nb=(1, 1), alpha=1.0, bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0):
         self.M, self.N, self.K, self.nb, self.a, self.b, self.c = M, N, K, nb, tuple(a), tuple(b), tuple(c)
-        self.out_shape, self.alpha, self.bias_mode, self.bias_b1 = tuple(out_shape), alpha, bias_mode, bias_b1
+        self.out_shape, self.alpha, self.bias_mode, self.bias_b1, self.bias_b0 = tuple(out_shape), alpha, bias_mode, bias_b1, bias_b0
 
 
 def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
@@ -127,7 +127,7 @@ class _BGemm(torch.autograd.Function):
         s = spec
         A, B = _c(A), _c(B)
         C = _empty(A, *s.out_shape)
-        kw = dict(bias=bias, bias_mode=s.bias_mode if bias is not None else BIAS_NONE, bias_b1=s.bias_b1, gmax=gmax)
+        kw = dict(bias=bias, bias_mode=s.bias_mode if bias is not None else BIAS_NONE, bias_b1=s.bias_b1, bias_b0=s.bias_b0, gmax=gmax)
         T = None
         seed = off = 0
         if gelu:
@@ -164,6 +164,13 @@ def _bias_grad(L, dC, s):
     """Only the layouts the model uses: C contiguous [nb0, nb1, M, N] (or [M, N])."""
     nb0, nb1 = s.nb
     assert s.c[2] == s.N, 'bias grad needs contiguous C rows'
+    if s.bias_mode == BIAS_N and s.bias_b0 != 0:
+        # one bias vector per (z0, z1), stored [nb0, nb1, N]: column sums of every C slab as ONE GEMM with a row of ones
+        assert s.bias_b0 == nb1 * s.N and s.bias_b1 == s.N
+        ones = torch.ones(s.M, dtype=torch.float32, device=dC.device)
+        out = _empty(dC, nb0, nb1, s.N)
+        _run_gemm(L, ones, dC, out, 1, s.N, s.M, (0, 0, s.M, 1), (s.c[0], s.c[1], 1, s.c[2]), (nb1 * s.N, s.N, s.N), s.nb, 1.0)
+        return out
     if s.bias_mode == BIAS_N:
         if nb1 == 1 or s.bias_b1 == 0:
             rows = dC.numel() // s.N

@@ -328,7 +328,6 @@ class CrossAttFeatTrans(nn.Module):
         B, U2, C = in_key.shape
         U1, M, d = in_query.shape[1], self.num_modes, self.attention_mode_dim
         shared_q = in_query.shape[0] == 1 and B > 1
-        q = SF.linear(in_query, self.query.weight, self.query.bias)                      # :559
         gmax = torch.zeros(1, dtype=torch.float32, device=in_key.device)
         drop = self.attention_probs_dropout_prob if self.training else 0.0
         if (self.reassociate_projections and M == 1 and in_query.shape[0] == 1 and 2 * U1 <= U2 and pos_biases is None
@@ -339,6 +338,7 @@ class CrossAttFeatTrans(nn.Module):
             # Same function, same parameter gradients (autograd through the same GEMM op), fp32 rounding aside; the two
             # [B*U2, C] x [C, C] projection GEMMs (158 GFLOP each at cfg2, plus 2x that in backward) become U1-row GEMMs.
             alpha = 1.0 / math.sqrt(d)
+            q = SF.linear(in_query, self.query.weight, self.query.bias)                  # :559 (U1 attractor rows)
             wk, bk = self.key.weight, self.key.bias
             qk = SF.bgemm(q, wk, GemmSpec(U1, C, d, (0, 0, d, 1), (0, 0, 1, C), (0, 0, C), (U1, C), alpha=alpha))
             rb = None
@@ -351,6 +351,29 @@ class CrossAttFeatTrans(nn.Module):
             self.attention_scores = scores if self.keep_attn_scores else None
             return self.out_trans(in_key, probs, value_last=True)
         k = SF.linear(in_key, self.key.weight, self.key.bias)                            # :560
+        if (self.reassociate_projections and pos_biases is None and not shared_q and in_query.shape[0] == B
+                and U2 * (C + U1 * (M - 1)) < U1 * C):
+            # Squeeze-out layer: MANY tokens (queries) attend to few attractors.  The query projection is a linear map of the U1
+            # tokens that is immediately contracted with the U2 keys, so it is folded into the key side:
+            #   (X Wq_m^T + 1 bq_m^T) k_m^T = X (Wq_m^T k_m^T) + 1 (k_m bq_m)^T
+            # G[b,m] = Wq_m^T k[b,m]^T is a [C, U2] operand per (sample, mode), the bias term a [U2] row vector per (sample, mode);
+            # cost 2 C^2 U2 + 2 U1 U2 C M instead of 2 U1 C^2 + 2 U1 U2 C per sample (the test above; cfg2: 100 vs 180 GFLOP).
+            alpha = 1.0 / math.sqrt(d)
+            wq, bq = self.query.weight, self.query.bias
+            G = SF.bgemm(wq, k, GemmSpec(C, U2, d, (0, d * C, 1, C), (U2 * M * d, d, M * d, 1), (M * C * U2, C * U2, U2),
+                                         (B, M, C, U2), nb=(B, M), alpha=alpha))
+            beta = None
+            if bq is not None:
+                beta = SF.bgemm(bq, k, GemmSpec(1, U2, d, (0, d, d, 1), (U2 * M * d, d, M * d, 1), (M * U2, U2, U2),
+                                                (B, M, U2), nb=(B, M), alpha=alpha))
+            scores = SF.bgemm(in_query, G, GemmSpec(U1, U2, C, (U1 * C, 0, C, 1), (M * C * U2, C * U2, 1, U2),
+                                                    (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),
+                                                    bias_mode=SF.BIAS_N, bias_b0=M * U2, bias_b1=U2), bias=beta, gmax=gmax)
+            self.attn_max_dev = gmax
+            probs = SF.softmax(scores, self.attn_clip, gmax, drop)
+            self.attention_scores = scores if self.keep_attn_scores else None
+            return self.out_trans(in_key, probs)
+        q = SF.linear(in_query, self.query.weight, self.query.bias)                      # :559
         # scores[m,b] = q[b,:,m*d:(m+1)*d] k[b,:,m*d:(m+1)*d]^T / sqrt(d), max tracked in the epilogue (:566-570)
         scores = SF.bgemm(q, k, GemmSpec(U1, U2, d, (0 if shared_q else U1 * C, d, C, 1), (U2 * C, d, C, 1),
                                          (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),

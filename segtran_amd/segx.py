@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
                 ('alpha', c_f), ('epilogue', c_i), ('bias_mode', c_i), ('bias_b1', c_l),
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
-                ('splitk', c_i), ('workspace', c_p), ('tile', c_i)]
+                ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
@@ -81,7 +81,7 @@ class SegxLib:
 
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
-             bias_mode=BIAS_NONE, bias_b1=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
+             bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
              offset=0, splitk=1, workspace=None, tile=TILE_AUTO):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
         a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
@@ -92,7 +92,7 @@ class SegxLib:
         d.a_b0, d.a_b1, d.a_m, d.a_k = a_strides
         d.b_b0, d.b_b1, d.b_n, d.b_k = b_strides
         d.c_b0, d.c_b1, d.c_m = c_strides
-        d.alpha, d.epilogue, d.bias_mode, d.bias_b1 = alpha, epilogue, bias_mode, bias_b1
+        d.alpha, d.epilogue, d.bias_mode, d.bias_b1, d.bias_b0 = alpha, epilogue, bias_mode, bias_b1, bias_b0
         d.bias, d.aux, d.gmax = _ptr(bias), _ptr(aux), _ptr(gmax)
         d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
         if splitk == 0:

@@ -87,6 +87,38 @@ def test_squeezed_att_feat_trans_vs_reference(backend, monkeypatch, tag, C, Fd, 
     assert z is not None and z.abs().max() == 0
 
 
+def test_squeeze_out_query_reassociation_equals_reference_op_order(backend, monkeypatch):
+    """Squeeze-out layer with many tokens and few attractors (40 tokens, 8 attractors, C = 128, 4 modes: the cost test selects the
+    key-side fold  X (Wq_m^T k_m^T) + 1 (k_m bq_m)^T ): output and every gradient equal the reference op order (which the
+    fixtures pin) to fp32 rounding."""
+    cfg = mk_config([128, 64], 8)
+    res = []
+    for reassoc in (True, False):
+        monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassoc)
+        taken = []
+        orig = ss.SF.bgemm
+        monkeypatch.setattr(ss.SF, 'bgemm', lambda A, B, spec, **kw: (taken.append(spec.bias_b0), orig(A, B, spec, **kw))[1])
+        mod = ss.SqueezedAttFeatTrans(cfg, 'L')
+        load(mod, 'voxel_fusion.translayers.0.')
+        mod.eval()
+        X = torch.randn(2, 40, 128, generator=torch.Generator(device='cpu').manual_seed(5), device='cpu').to(backend.dev).requires_grad_(True)
+        G = torch.randn(2, 40, 64, generator=torch.Generator(device='cpu').manual_seed(6), device='cpu').to(backend.dev)
+        Y = mod(X)
+        (Y * G).sum().backward()
+        monkeypatch.setattr(ss.SF, 'bgemm', orig)
+        assert any(b != 0 for b in taken) == reassoc            # the per-(sample, mode) key-side bias only exists in the folded form
+        res.append((Y.detach(), X.grad, {k: p.grad for k, p in mod.named_parameters()}))
+    (Y1, dX1, g1), (Y0, dX0, g0) = res
+    assert_close(Y1, Y0, 2e-5, 'Y')
+    assert_close(dX1, dX0, 1e-4, 'dX')
+    gscale = max(v.abs().max().item() for v in g0.values() if v is not None)
+    for k, v in g0.items():
+        if v is None:
+            assert g1[k] is None, k
+        else:
+            assert_close(g1[k], v, 3e-4, k, scale=gscale)
+
+
 def test_fusion_encoder_vs_reference(backend):
     g = golden_on('fusion_small', backend.dev)
     dims = [int(d) for d in g['dims']]
