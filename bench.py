@@ -82,6 +82,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='cfg2', help='BASELINE config (cfg2 = metric default; cfg4 = BraTS 3D)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-order', action='store_true', help='skip the comparison run in the other operation order (profiling runs)')
     ap.add_argument('--reference-op-order', action='store_true',
                     help="time the reference's operation order (no linear-chain re-association, DESIGN.md section 5b) as the main number")
     args = ap.parse_args()
@@ -142,7 +143,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     other = None
-    if world == 1:              # the same step in the OTHER operation order, outside the timed region (reported beside the main number)
+    if world == 1 and not args.single_order:   # the same step in the OTHER operation order, outside the timed region (reported beside the main number)
         set_op_order(net, args.reference_op_order)
         for _ in range(2):
             step(x, raw)
