@@ -235,7 +235,7 @@ class ExpandedFeatTrans(nn.Module):
             U1 = attention_probs.shape[2]
             fuse_spec = GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
                                  (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M))
-            if self.has_FFN and U2 < U1 and CrossAttFeatTrans.reassociate_projections:
+            if self.has_FFN and U2 < U1 and CrossAttFeatTrans.reassociate_projections and B * U1 >= CrossAttFeatTrans.reassociate_min_rows:
                 # Squeeze-out layer: U1 tokens gather from U2 << U1 attractors, then MMSharedMid (:232-251) applies one [F, F]
                 # linear map to every fused row:  (P v) Wmid^T + b  ==  P (v Wmid^T) + b.  The map is applied to the U2 value
                 # rows instead (M*B*U2 rows instead of M*B*U1: 39 vs 632 GFLOP at cfg2), and the fusion GEMM carries the bias +
@@ -280,6 +280,7 @@ class ExpandedFeatTrans(nn.Module):
 class CrossAttFeatTrans(nn.Module):
     """Multi-mode cross attention (reference :478-610)."""
     reassociate_projections = True        # False: the reference's op order everywhere (key/value projections over all tokens)
+    reassociate_min_rows = 4096           # below this many token rows (batch x tokens) the step is launch-bound: keep the op order
 
     def __init__(self, config, name):
         super().__init__()
@@ -330,7 +331,7 @@ class CrossAttFeatTrans(nn.Module):
         shared_q = in_query.shape[0] == 1 and B > 1
         gmax = torch.zeros(1, dtype=torch.float32, device=in_key.device)
         drop = self.attention_probs_dropout_prob if self.training else 0.0
-        if (self.reassociate_projections and M == 1 and in_query.shape[0] == 1 and 2 * U1 <= U2 and pos_biases is None
+        if (self.reassociate_projections and B * U2 >= self.reassociate_min_rows and M == 1 and in_query.shape[0] == 1 and 2 * U1 <= U2 and pos_biases is None
                 and self.out_trans.first_linear.bias is None and self.out_trans.num_scales == 0):
             # In-squeeze layer: few shared queries (the attractors) attend to many tokens with ONE mode.  The key and value
             # projections are linear maps of the U2 tokens that are immediately contracted with U1-row operands, so they are
@@ -351,7 +352,7 @@ class CrossAttFeatTrans(nn.Module):
             self.attention_scores = scores if self.keep_attn_scores else None
             return self.out_trans(in_key, probs, value_last=True)
         k = SF.linear(in_key, self.key.weight, self.key.bias)                            # :560
-        if (self.reassociate_projections and pos_biases is None and not shared_q and in_query.shape[0] == B
+        if (self.reassociate_projections and B * U1 >= self.reassociate_min_rows and pos_biases is None and not shared_q and in_query.shape[0] == B
                 and U2 * (C + U1 * (M - 1)) < U1 * C):
             # Squeeze-out layer: MANY tokens (queries) attend to few attractors.  The query projection is a linear map of the U1
             # tokens that is immediately contracted with the U2 keys, so it is folded into the key side:

@@ -38,6 +38,7 @@ def _grads_vs_golden(net, g, tol=1e-3, tol_backbone=None):
 def test_segtran2d_vs_reference(tag, cfg, train, fused_tail, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', fused_tail)      # both re-associations on, or neither
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)                  # the fixtures are small; the product's size threshold is 4096 rows
     g = golden(tag)
     c = dict(engine.CONFIGS[cfg], size=(64, 64))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
@@ -142,6 +143,7 @@ def test_segtran2d_mince_vs_reference():
 def test_segtran3d_vs_reference(tag, train, fused_tail, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', fused_tail)
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)
     g = golden(tag)
     c = dict(engine.CONFIGS['cfg4'], size=(112, 112, 16))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))

@@ -59,6 +59,7 @@ def test_squeezed_att_feat_trans_vs_reference(backend, monkeypatch, tag, C, Fd, 
     """reassoc=True (default): the in-squeeze key/value projections are applied after the contraction with the attractor-side
     operands ((q Wk) X^T, (P X) Wv^T); False: projections over all tokens first, as the reference orders them."""
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassoc)
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)      # fixtures are tiny; the product only re-associates at >= 4096 rows
     calls = []
     orig = ss.ExpandedFeatTrans.forward
     monkeypatch.setattr(ss.ExpandedFeatTrans, 'forward', lambda self, *a, **kw: (calls.append(kw.get('value_last', False)), orig(self, *a, **kw))[1])
@@ -95,6 +96,7 @@ def test_squeeze_out_query_reassociation_equals_reference_op_order(backend, monk
     res = []
     for reassoc in (True, False):
         monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassoc)
+        monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)
         taken = []
         orig = ss.SF.bgemm
         monkeypatch.setattr(ss.SF, 'bgemm', lambda A, B, spec, **kw: (taken.append(spec.bias_b0), orig(A, B, spec, **kw))[1])
