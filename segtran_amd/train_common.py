@@ -22,8 +22,7 @@ import torch
 from . import engine, dist as sdist, functional as SF
 
 UNSUPPORTED = {'polyformer_mode': None, 'adversarial_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
-               'use_attn_consist_loss': False,
-               'tune_bn_only': False}
+               'use_attn_consist_loss': False}
 
 
 def common_flags(p, dim):
@@ -67,6 +66,7 @@ def common_flags(p, dim):
     p.add_argument('--outdrop', dest='out_fpn_do_dropout', action='store_true')
     p.add_argument('--inbn', dest='in_fpn_use_bn', action='store_true')
     p.add_argument('--nofeatup', dest='bb_feat_upsize', action='store_false')
+    p.add_argument('--tunebn', dest='tune_bn_only', action='store_true', help='only refresh the BatchNorm statistics of the first backbone stages')
     p.add_argument('--logiter', type=int, default=50, help='host-side logging period (each log line synchronises the device)')
     return p
 
@@ -93,6 +93,10 @@ def finalize_args(args, dim):
         args.mince_scales = [int(v) for v in str(args.mince_scales).split(',')]
     if args.mince_channel_props is not None:
         args.mince_channel_props = [float(v) for v in str(args.mince_channel_props).split(',')]
+    if getattr(args, 'tune_bn_only', False):                               # train2d.py:747-751
+        if args.checkpoint_path is None:
+            raise SystemExit('Tuning BN requires to specify a checkpoint to load')
+        args.lr_warmup_steps = 0
     if args.use_mince_transformer and not (args.mince_scales and args.mince_channel_props
                                            and len(args.mince_scales) == len(args.mince_channel_props)):
         raise SystemExit('--mince needs --mincescales and --minceprops of equal length')
@@ -158,6 +162,11 @@ def run(args, cfg, batches=None):
     if dim_of(cfg) == 2:
         iter_num = 0                                                      # train2d.py:1078-1081 always restarts the count
     sdist.enable_sync_batchnorm()
+    if getattr(args, 'tune_bn_only', False):
+        if batches is None:
+            fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
+            batches = iter(lambda: fixed, None)
+        return tune_bn(net, args, batches, dev, ckpt_dir, is_master)
     net.train()
     opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
                                 decay=args.decay, grad_clip=args.grad_clip)
@@ -178,6 +187,36 @@ def run(args, cfg, batches=None):
                              ', '.join('%.3f' % v for v in s[4:]), opt.get_lr()[0], args.logiter / max(time.time() - t0, 1e-9))
             t0 = time.time()
         if is_master and (iter_num % args.saveiter == 0 or iter_num == args.maxiter):
+            save_model(net, args, ckpt_dir, iter_num)
+        if iter_num >= args.maxiter:
+            break
+    return net
+
+
+def set_tune_bn_mode(net):
+    """train2d.py:1089-1098: everything in eval mode except the EfficientNet blocks before endpoint 3, whose BatchNorm layers
+    keep updating their running statistics.  Returns the number of blocks left in training mode."""
+    net.eval()
+    if not hasattr(net.backbone, '_blocks'):
+        raise SystemExit("Backbone '%s' not supported by --tunebn." % getattr(net, 'backbone_type', '?'))
+    stop = net.backbone.endpoint_blk_indices[3]
+    for idx, block in enumerate(net.backbone._blocks):
+        if idx == stop:
+            break
+        block.train()
+    return stop
+
+
+def tune_bn(net, args, batches, dev, ckpt_dir, is_master):
+    """--tunebn loop (train2d.py:1195-1204): gradient-free forward passes that refresh the BatchNorm running statistics of the
+    first backbone stages; a checkpoint every 50 iterations."""
+    logging.info('Tuning stops at block %d', set_tune_bn_mode(net))
+    iter_num = 0
+    for x, _ in batches:
+        iter_num += 1
+        with torch.no_grad():
+            net(x.to(dev, non_blocking=True))
+        if is_master and (iter_num % 50 == 0 or iter_num == args.maxiter):
             save_model(net, args, ckpt_dir, iter_num)
         if iter_num >= args.maxiter:
             break

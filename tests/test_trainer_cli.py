@@ -42,6 +42,21 @@ def test_architecture_flags_reach_the_model_builder():
         _parse(['--mince'], 2)                           # scales / proportions are mandatory with --mince
 
 
+def test_tune_bn_mode_marks_only_the_first_backbone_stages_trainable():
+    """--tunebn (train2d.py:747-751, 1089-1098): needs a checkpoint; net.eval() except the MBConv blocks before endpoint 3."""
+    with pytest.raises(SystemExit):
+        _parse(['--tunebn'], 2)
+    a = _parse(['--tunebn', '--cp', 'x.pth'], 2)
+    assert a.tune_bn_only and a.lr_warmup_steps == 0
+    from segtran_amd import engine
+    net = engine.build_model(dict(engine.CONFIGS['cfg1'], size=(64, 64)), 'cpu', synth=False)
+    stop = tc.set_tune_bn_mode(net)
+    assert stop == net.backbone.endpoint_blk_indices[3] == 22
+    modes = [b.training for b in net.backbone._blocks]
+    assert all(modes[:stop]) and not any(modes[stop:])
+    assert not net.voxel_fusion.training and not net.backbone._bn0.training
+
+
 def test_other_networks_are_rejected():
     with pytest.raises(SystemExit):
         _parse(['--net', 'unet'], 2)
