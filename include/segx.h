@@ -147,6 +147,12 @@ int segx_mt_bertadam_step(void* const* params, const void* const* grads, void* c
                           float max_global_norm, float max_tensor_norm, float sched, float b1, float b2, float eps,
                           float* ws, void* stream);
 
+/* Multi-tensor gather (data parallel): copies chunks [chunk_begin, chunk_begin + nchunks) of the tensors src[t] (this step's
+ * gradient tensors, owned by autograd) into the flat slices dst[t] (their all-reduce bucket) in ONE launch -- replaces the
+ * per-parameter `grad += g` kernels of a view-based bucket.  Tables as in segx_mt_bertadam_step; src[t] == NULL leaves the slice. */
+int segx_mt_gather(const void* const* src, void* const* dst, const int64_t* sizes, const int* chunk_tensor, const int64_t* chunk_off,
+                   int chunk_begin, int nchunks, int chunk, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backbone kernels (backbone.hip): BatchNorm(+activation), depthwise convolution, squeeze-excite plane ops.
  * Tensors are NC[D]HW fp32; S = product of the spatial dims; a (sample, channel) plane is contiguous.

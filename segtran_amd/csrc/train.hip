@@ -178,6 +178,34 @@ extern "C" int segx_seg_loss_bwd(const float* logits, const float* mask, const f
     return check_launch("segx_seg_loss_bwd");
 }
 
+// Multi-tensor gather: chunks [chunk_begin, chunk_begin + gridDim.x) of the tensors listed in src -> the flat slices listed in dst
+// (data parallel: this step's gradient tensors into their all-reduce bucket, one launch per bucket).  src[t] == NULL: the slice is
+// left untouched (parameters without a gradient stay zero in the bucket).
+__global__ __launch_bounds__(256) void mt_gather_kernel(const float* const* __restrict__ src, float* const* __restrict__ dst,
+                                                        const int64_t* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                        const int64_t* __restrict__ chunk_off, int chunk_begin, int chunk) {
+    const int ch = chunk_begin + blockIdx.x, t = chunk_tensor[ch];
+    const int64_t off = chunk_off[ch], n = i64min(chunk, sizes[t] - off);
+    const float* s = src[t];
+    if (!s) return;
+    s += off; float* d = dst[t] + off;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(d)[i] = reinterpret_cast<const float4*>(s)[i];
+        for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) d[i] = s[i];
+    } else {
+        for (int64_t i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+    }
+}
+extern "C" int segx_mt_gather(const void* const* src, void* const* dst, const int64_t* sizes, const int* chunk_tensor, const int64_t* chunk_off,
+                              int chunk_begin, int nchunks, int chunk, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SEGX_REQUIRE(src && dst && sizes && chunk_tensor && chunk_off && chunk_begin >= 0 && nchunks > 0 && chunk > 0, "segx_mt_gather: bad args");
+    hipLaunchKernelGGL(mt_gather_kernel, dim3(nchunks), dim3(256), 0, stream, (const float* const*)src, (float* const*)dst, sizes, chunk_tensor,
+                       chunk_off, chunk_begin, chunk);
+    return check_launch("segx_mt_gather");
+}
+
 extern "C" int segx_mt_bertadam_step(void* const* params, const void* const* grads, void* const* m, void* const* v, const int64_t* sizes,
                                      const int* chunk_tensor, const int64_t* chunk_off, const int* chunk_first, const int* active,
                                      const float* lr, const float* wd, int ntensors, int nchunks, int chunk,

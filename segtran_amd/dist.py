@@ -2,10 +2,11 @@
 
 Reference behaviour being replaced: torch DDP + SyncBatchNorm (train2d.py:796-801, 1108-1113).  Here:
   * identical initial weights on every rank (same seed / synthetic weights), disjoint samples per rank;
-  * gradients already live in ONE flat fp32 buffer (optimization.BertAdam.flat_grad); it is all-reduced in a few
-    large buckets (xGMI links are point-to-point, ~153 GB/s each: few big collectives beat many small ones) and
-    averaged; parameters that never receive gradients (N3) are simply zeros in the buffer -- no
-    `find_unused_parameters` graph walk is needed;
+  * gradients travel through ONE flat fp32 buffer (optimization.BertAdam.flat_grad) cut into a few large buckets of whole
+    parameters (xGMI links are point-to-point, ~153 GB/s each: few big collectives beat many small ones); autograd owns the
+    gradient tensors, a bucket is filled by ONE multi-tensor gather launch when its last gradient is ready, all-reduced
+    (averaged) while backward continues, and the optimizer reads the buffer; parameters that never receive gradients (N3)
+    are simply zeros in the buffer -- no `find_unused_parameters` graph walk is needed;
   * BatchNorm statistics are synchronised inside libsegx's fused BN(+activation) op: one small all-gather per BN
     layer forward, one small all-reduce backward (`enable_sync_batchnorm`).
 """
@@ -38,47 +39,95 @@ class GradReducer:
     buckets travel over xGMI while the backbone is still differentiating.  `allreduce_grads()` then only launches what is left and
     waits.  Buckets that hold no live parameter are never sent (they are zeros on every rank)."""
 
-    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True):
-        self.opt, self.flat, self.group, self.overlap = optimizer, optimizer.flat_grad, group, overlap
+    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True):
+        """gather=True: gradients stay autograd's own tensors and are copied into their bucket by one multi-tensor launch per
+        bucket (no per-parameter `grad += g` kernels); gather=False: every p.grad is a view of the flat buffer."""
+        self.opt, self.flat, self.group, self.overlap, self.gather = optimizer, optimizer.flat_grad, group, overlap, gather
+        if gather:
+            optimizer.use_gathered_grads()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        n = self.flat.numel()
         step = max(1, int(bucket_mb * 1024 * 1024 // 4))
-        self.buckets = [(o, min(n, o + step)) for o in range(0, n, step)]
+        # buckets of WHOLE parameters (flat range a:b, parameter range i0:i1), closed once they reach bucket_mb
+        self.buckets, a, i0 = [], 0, 0
+        slices = optimizer.slices
+        for i, (off, n) in enumerate(slices):
+            end = off + (n + 3) // 4 * 4
+            if end - a >= step or i == len(slices) - 1:
+                self.buckets.append((a, end, i0, i + 1))
+                a, i0 = end, i + 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'        # RCCL averages in the collective; gloo has no AVG
         self._armed, self._hooks = False, []
         self._pending, self._need, self._works, self._launched = [], [], [], []
+        self._src, self._slot = None, 0
         self.launched_in_backward = 0                                                  # of the last step (tests / logging)
 
+    # ---- gather: this step's gradient addresses -> device table -> one multi-tensor copy per bucket -----------------------
+    def _src_slot(self):
+        dev = self.flat.device
+        if self._src is None:
+            nt = len(self.opt.slices)
+            mk = lambda: torch.zeros(nt, dtype=torch.int64, device='cpu')          # noqa: E731
+            self._src = [dict(dev=torch.zeros(nt, dtype=torch.int64, device=dev), host=mk().pin_memory() if dev.type == 'cuda' else mk(),
+                              ev=torch.cuda.Event() if dev.type == 'cuda' else None, fresh=True) for _ in range(4)]
+        slot = self._src[self._slot]
+        if slot['fresh']:
+            if slot['ev'] is not None:
+                slot['ev'].synchronize()            # the copies issued from this slot four steps ago (a no-op in practice)
+            slot['fresh'] = False
+        return slot
+
+    def _gather(self, k):
+        from . import segx
+        opt = self.opt
+        opt._ensure_tables()
+        a, b, i0, i1 = self.buckets[k]
+        slot = self._src_slot()
+        ptrs = []
+        for p in opt._ps[i0:i1]:
+            g = p.grad
+            if g is not None and not (g.is_contiguous() and g.dtype == torch.float32):
+                raise RuntimeError('gradient of a non-contiguous / non-fp32 layout cannot be gathered')
+            ptrs.append(0 if g is None else g.data_ptr())
+        slot['host'][i0:i1] = torch.tensor(ptrs, dtype=torch.int64, device='cpu')
+        slot['dev'][i0:i1].copy_(slot['host'][i0:i1], non_blocking=True)
+        if slot['ev'] is not None:
+            slot['ev'].record()
+        c0, c1 = opt._chunk_first_host[i0], opt._chunk_first_host[i1]
+        if c1 > c0:
+            from .optimization import CHUNK
+            segx.lib().mt_gather(slot['dev'], opt._tabs, c0, c1 - c0, CHUNK)
+
     def _launch(self, k):
-        a, b = self.buckets[k]
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        self._works.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
+        a, b = self.buckets[k][:2]
+        if self.gather:
+            self._gather(k)
+        if self.world > 1:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self._works.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
         self._launched[k] = True
 
     def _arm(self):
         """after the first backward: count the live parameters of each bucket and hook them"""
         ps, touched = self.opt._all_params(), self.opt._touched
         self._need = [0] * len(self.buckets)
-        for (p, _), (off, n) in zip(ps, self.opt.slices):
-            if id(p) not in touched or n == 0:
-                continue
-            ks = [k for k, (a, b) in enumerate(self.buckets) if a < off + n and off < b]
-            for k in ks:
+        for k, (a, b, i0, i1) in enumerate(self.buckets):
+            for (p, _), (off, n) in zip(ps[i0:i1], self.opt.slices[i0:i1]):
+                if id(p) not in touched or n == 0:
+                    continue
                 self._need[k] += 1
-            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, ks=ks: self._on_grad(ks)))
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, k=k: self._on_grad(k)))
         self._pending = list(self._need)
         self._launched = [False] * len(self.buckets)
         self._armed = True
 
-    def _on_grad(self, ks):
-        for k in ks:
-            self._pending[k] -= 1
-            if self._pending[k] == 0 and not self._launched[k]:
-                self._launch(k)
-                self.launched_in_backward += 1
+    def _on_grad(self, k):
+        self._pending[k] -= 1
+        if self._pending[k] == 0 and not self._launched[k]:
+            self._launch(k)
+            self.launched_in_backward += 1
 
     def allreduce_grads(self):
-        if self.world <= 1:
+        if self.world <= 1 and not self.gather:
             return
         if not self._armed:
             self._launched = [False] * len(self.buckets)
@@ -90,9 +139,12 @@ class GradReducer:
                 self._launch(k)
         for w in self._works:
             w.wait()
-        if not self._avg:
+        if not self._avg and self.world > 1:
             self.flat.mul_(1.0 / self.world)
         self._works = []
+        if self._src is not None:
+            self._slot = (self._slot + 1) % len(self._src)
+            self._src[self._slot]['fresh'] = True
         if not self._armed and self.overlap:
             self._arm()
         else:

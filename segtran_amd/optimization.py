@@ -11,7 +11,10 @@ warmup-linear LR, parameters without a gradient skipped entirely -- N3).  MI355X
   * single process (`release_flat_grads()`): autograd keeps ownership of every gradient tensor (`p.grad = None`
     before backward, so AccumulateGrad adopts the incoming tensor instead of issuing one `grad += g` kernel per
     parameter -- 549 launches / 3.3 ms per cfg2 step) and the multi-tensor step reads them through a pointer
-    table refreshed each step.
+    table refreshed each step;
+  * data parallel, gathered (`use_gathered_grads()`, what `dist.GradReducer` selects): autograd owns the gradient
+    tensors as above and the reducer copies each bucket's gradients into the flat buffer with ONE multi-tensor
+    launch right before that bucket's all-reduce; the step then reads the (averaged) flat buffer.
 """
 import torch
 from torch.optim import Optimizer
@@ -52,6 +55,7 @@ class BertAdam(Optimizer):
         self._touched = set()
         self._hooks = []
         self._private = False
+        self._gathered = False
         self._ring, self._ring_pos = None, 0
         self._build_flat_grads()
 
@@ -80,6 +84,21 @@ class BertAdam(Optimizer):
             self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, s=self: s._touched.add(id(q))))
             off += (n + 3) // 4 * 4
 
+    def use_gathered_grads(self):
+        """Data-parallel mode of `dist.GradReducer(gather=True)`: p.grad are autograd's own tensors, the flat buffer is filled by
+        the reducer's per-bucket gather and read by the step."""
+        assert self._tabs is None and not self._private, 'use_gathered_grads() must precede the first step'
+        self._gathered = True
+        for p, _ in self._all_params():
+            p.grad = None
+
+    def _ensure_tables(self):
+        if self._tabs is None:
+            self._build_tables()
+            for h in self._hooks:
+                h.remove()                          # the touched set is static after the first backward (N3)
+            self._hooks = []
+
     def release_flat_grads(self):
         """Single-process mode (no reducer): drop the flat views, autograd owns the gradient tensors from now on."""
         assert self._tabs is None or self._private, 'release_flat_grads() must precede the first step'
@@ -91,7 +110,7 @@ class BertAdam(Optimizer):
     def zero_grad(self, set_to_none=False):
         """Flat mode: gradients are views of one buffer, zero it (one memset) instead of dropping the tensors.
         Private mode: drop the tensors, so that the next backward adopts the fresh ones without an accumulate kernel."""
-        if self._private:
+        if self._private or self._gathered:
             for p, _ in self._all_params():
                 p.grad = None
         else:
@@ -135,7 +154,7 @@ class BertAdam(Optimizer):
         chunk_tensor, chunk_off, chunk_first = [], [], [0]
         for t, ((p, g), (off, n)) in enumerate(zip(ps, self.slices)):
             assert p.is_contiguous() and p.dtype == torch.float32
-            assert self._private or (p.grad is not None and p.grad.data_ptr() == gp + 4 * off), 'p.grad was re-bound; use optimizer.zero_grad()'
+            assert self._private or self._gathered or (p.grad is not None and p.grad.data_ptr() == gp + 4 * off), 'p.grad was re-bound; use optimizer.zero_grad()'
             for c in range(0, n, CHUNK):
                 chunk_tensor.append(t); chunk_off.append(c)
             chunk_first.append(len(chunk_tensor))
@@ -146,6 +165,7 @@ class BertAdam(Optimizer):
             chunk_first=i32(chunk_first), active=i32([1 if id(p) in self._touched else 0 for p, _ in ps]),
             lr=f32([g['lr'] for _, g in ps]), wd=f32([g['weight_decay'] for _, g in ps]))
         self._nt, self._nch = len(ps), len(chunk_tensor)
+        self._chunk_first_host = chunk_first
         self._ws = torch.zeros(self._nch + 2 * self._nt + 2, dtype=torch.float32, device=dev)
         self._active_names = None
 
@@ -163,11 +183,7 @@ class BertAdam(Optimizer):
     @torch.no_grad()
     def step(self, closure=None, global_grad_clip=None):
         loss = closure() if closure is not None else None
-        if self._tabs is None:
-            self._build_tables()
-            for h in self._hooks:
-                h.remove()                          # the touched set is static after the first backward (N3)
-            self._hooks = []
+        self._ensure_tables()
         if self._private:
             self._refresh_grad_table()
         g = self.param_groups[0]

@@ -377,6 +377,12 @@ class SegxLib:
                    max_global, max_tensor, sched, b1, b2, eps, ws)
 
 
+    def mt_gather(self, src_tab, tabs, chunk_begin, nchunks, chunk):
+        """src_tab: device int64 table of this step's gradient addresses (0 = none); tabs['grads'] = the flat slices."""
+        self._call('segx_mt_gather', src_tab, src_tab, tabs['grads'], tabs['sizes'], tabs['chunk_tensor'], tabs['chunk_off'],
+                   chunk_begin, nchunks, chunk)
+
+
 # C signatures (include/segx.h): p pointer, i int32, l int64, f float, u uint64; trailing p = stream
 _SIGS = {
     'segx_posbias_fwd': 'ppplipffpp', 'segx_posbias_bwd': 'pppplipffp',
@@ -390,7 +396,7 @@ _SIGS = {
     'segx_modes_aggr_fwd': 'pppppppiliffuup', 'segx_modes_aggr_bwd': 'ppppppppilifuup',
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
-    'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp',
+    'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_tune': 'ii', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',

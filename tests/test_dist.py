@@ -61,8 +61,13 @@ def _case_sync_bn(rank, world, ret):
     sdist.disable_sync_batchnorm()
 
 
-def _case_dp_step(rank, world, ret):
-    """2 ranks x 1 sample == 1 process x 2 samples: same averaged gradients, same parameters after BertAdam."""
+def _case_dp_step_views(rank, world, ret):
+    _case_dp_step(rank, world, ret, gather=False)
+
+
+def _case_dp_step(rank, world, ret, gather=True):
+    """2 ranks x 1 sample == 1 process x 2 samples: same averaged gradients, same parameters after BertAdam.  gather=True: autograd
+    owns the gradient tensors, one multi-tensor gather per bucket fills the flat buffer; gather=False: p.grad are views of it."""
     from segtran_amd import functional as SF, dist as sdist
     from segtran_amd.networks import segtran_shared as ss
     from segtran_amd.optimization import BertAdam
@@ -89,7 +94,8 @@ def _case_dp_step(rank, world, ret):
     # data parallel: one sample per rank
     m = make()
     opt = BertAdam([dict(params=list(m.parameters()), weight_decay=1e-4, lr=1e-2)], lr=1e-2, warmup=0.1, t_total=10, global_grad_clip=0.1)
-    red = sdist.GradReducer(opt, bucket_mb=0.01)              # tiny buckets: exercises the multi-bucket path
+    red = sdist.GradReducer(opt, bucket_mb=0.01, gather=gather)              # tiny buckets: exercises the multi-bucket path
+    assert all((p.grad is None) == gather for p in m.parameters())
     in_bwd = []
     for _ in range(3):
         opt.zero_grad(); ((m(X[rank:rank + 1]) - T[rank:rank + 1]) ** 2).mean().backward()
@@ -108,3 +114,7 @@ def test_sync_batchnorm_matches_full_batch():
 
 def test_data_parallel_step_matches_single_process():
     assert _run('_case_dp_step') == {0: True, 1: True}
+
+
+def test_data_parallel_step_with_view_gradients():
+    assert _run('_case_dp_step_views') == {0: True, 1: True}

@@ -49,3 +49,35 @@ def test_bertadam_vs_reference(backend, private):
         for i in range(4):
             assert torch.allclose(params[i].data, g['p%d_%d' % (step + 1, i)], atol=2e-7), (step, i)
     assert torch.equal(params[3].data, g['p0_3'])           # untouched: no update, no weight decay
+
+
+def test_mt_gather_copies_gradients_into_their_flat_slices(backend):
+    """segx_mt_gather: a chunk range of (possibly mis-aligned, possibly absent) source tensors -> the optimizer's flat slices."""
+    from segtran_amd.optimization import BertAdam, CHUNK
+    dev = backend.dev
+    sizes = [70000, 5, 131072 + 3, 9]                       # spans several chunks / tails that are not multiples of 4
+    params = [torch.nn.Parameter(torch.zeros(n, device=dev)) for n in sizes]
+    opt = BertAdam([dict(params=params, weight_decay=0.0, lr=1e-3)], lr=1e-3, warmup=-1, t_total=-1)
+    opt.use_gathered_grads()
+    sum((p * 1.0).sum() for p in params[:3]).backward()      # parameter 3 never receives a gradient
+    opt._ensure_tables()
+    g = torch.Generator(device='cpu').manual_seed(4)
+    big = torch.randn(70000 + 1, generator=g, device='cpu').to(dev)
+    srcs = [big[1:], torch.randn(5, generator=g, device='cpu').to(dev), torch.randn(sizes[2], generator=g, device='cpu').to(dev), None]
+    assert srcs[0].data_ptr() % 16 != 0                     # a 4-byte-aligned view: the scalar copy path
+    tab = torch.tensor([0 if t is None else t.data_ptr() for t in srcs], dtype=torch.int64, device='cpu').to(dev)
+    opt.flat_grad.fill_(-7.0)
+    L = segx.lib()
+    cf = opt._chunk_first_host
+    L.mt_gather(tab, opt._tabs, cf[0], cf[2] - cf[0], CHUNK)            # tensors 0 and 1 only
+    for i, (off, n) in enumerate(opt.slices):
+        got = opt.flat_grad[off:off + n]
+        if i < 2:
+            assert torch.equal(got, srcs[i])
+        else:
+            assert (got == -7.0).all()
+    L.mt_gather(tab, opt._tabs, cf[2], cf[4] - cf[2], CHUNK)            # tensor 2, and tensor 3 (no source: untouched)
+    off, n = opt.slices[2]
+    assert torch.equal(opt.flat_grad[off:off + n], srcs[2])
+    off, n = opt.slices[3]
+    assert (opt.flat_grad[off:off + n] == -7.0).all()
