@@ -85,19 +85,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     a[i][p] = *reinterpret_cast<const bf16x8*>(lds + (0 * 3 + p) * (BM * 64) + lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
                     b[i][p] = *reinterpret_cast<const bf16x8*>(lds + (1 * 3 + p) * (BM * 64) + lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
                 }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);     // hi . lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);     // lo . hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);     // mid . mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);     // hi . mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);     // mid . hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);     // hi . hi
-                    acc[i][j] = c;
-                }
+            // term-major order: consecutive MFMAs update DIFFERENT accumulators (no back-to-back dependent issue); small terms first
+#define TERM(PA_, PB_)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_], b[j][PB_], acc[i][j], 0, 0, 0);
+            TERM(0, 2) TERM(2, 0) TERM(1, 1) TERM(0, 1) TERM(1, 0) TERM(0, 0)
         }
     }
 #pragma unroll
@@ -111,6 +103,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
 }
 
+
+// ---- variant 2: BK = 16, double-buffered LDS (2 x 24 KB), ONE barrier per k-tile -----------------------------------------------
+// iteration kt: fragments from stage kt & 1 -> 24 MFMAs -> registers (tile kt + 1) into stage (kt + 1) & 1 -> barrier -> global loads of tile kt + 2
+constexpr int BK2 = 16;
+__device__ inline int lds_off16(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 1)) << 4); }   // 32-B rows, 2 chunks
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void gemm_bf16x6_db_kernel(const unsigned short* __restrict__ PA,
+                                                            const unsigned short* __restrict__ PB, float* __restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * 3 * BM * 32];     // [stage][operand][plane][row][32 B] = 48 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = N / BN;
+    const int m0 = (blockIdx.x / tiles_n) * BM, n0 = (blockIdx.x % tiles_n) * BN;
+    const int64_t planeA = (int64_t)M * K, planeB = (int64_t)N * K;
+    uint4 a0, a1, a2, b0, b1, b2;
+    const int row = tid >> 1, chk = tid & 1, so = lds_off16(row, chk);
+    const unsigned short* ga = PA + (int64_t)(m0 + row) * K + chk * 8;
+    const unsigned short* gb = PB + (int64_t)(n0 + row) * K + chk * 8;
+#define GLOAD2(k0)                                                                                                    \
+    a0 = *reinterpret_cast<const uint4*>(ga + (k0)); a1 = *reinterpret_cast<const uint4*>(ga + planeA + (k0));        \
+    a2 = *reinterpret_cast<const uint4*>(ga + 2 * planeA + (k0)); b0 = *reinterpret_cast<const uint4*>(gb + (k0));    \
+    b1 = *reinterpret_cast<const uint4*>(gb + planeB + (k0)); b2 = *reinterpret_cast<const uint4*>(gb + 2 * planeB + (k0));
+#define STAGE(st, op, p) (lds + (((st) * 2 + (op)) * 3 + (p)) * (BM * 32))
+#define LSTORE2(st)                                                                                                   \
+    *reinterpret_cast<uint4*>(STAGE(st, 0, 0) + so) = a0; *reinterpret_cast<uint4*>(STAGE(st, 0, 1) + so) = a1;       \
+    *reinterpret_cast<uint4*>(STAGE(st, 0, 2) + so) = a2; *reinterpret_cast<uint4*>(STAGE(st, 1, 0) + so) = b0;       \
+    *reinterpret_cast<uint4*>(STAGE(st, 1, 1) + so) = b1; *reinterpret_cast<uint4*>(STAGE(st, 1, 2) + so) = b2;
+    f32x16 acc[2][2] = {{{0}, {0}}, {{0}, {0}}};
+    const int KT = K / BK2;
+    GLOAD2(0)
+    LSTORE2(0)
+    __syncthreads();
+    { const int k1 = (KT > 1 ? 1 : 0) * BK2; GLOAD2(k1) }
+    const int half = lane >> 5;
+    const int fa0 = lds_off16(wm * 64 + (lane & 31), half), fa1 = lds_off16(wm * 64 + 32 + (lane & 31), half);
+    const int fb0 = lds_off16(wn * 64 + (lane & 31), half), fb1 = lds_off16(wn * 64 + 32 + (lane & 31), half);
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        bf16x8 a[2][3], b[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[0][p] = *reinterpret_cast<const bf16x8*>(STAGE(cur, 0, p) + fa0); a[1][p] = *reinterpret_cast<const bf16x8*>(STAGE(cur, 0, p) + fa1);
+            b[0][p] = *reinterpret_cast<const bf16x8*>(STAGE(cur, 1, p) + fb0); b[1][p] = *reinterpret_cast<const bf16x8*>(STAGE(cur, 1, p) + fb1);
+        }
+#define TERM2(PA_, PB_)                                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                       \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_], b[j][PB_], acc[i][j], 0, 0, 0);
+        TERM2(0, 2) TERM2(2, 0) TERM2(1, 1) TERM2(0, 1) TERM2(1, 0) TERM2(0, 0)
+        if (cur) { LSTORE2(0) } else { LSTORE2(1) }              // tile kt + 1 (on the last iteration: a harmless re-store)
+        __syncthreads();
+        const int kn = (kt + 2 < KT ? kt + 2 : KT - 1) * BK2;
+        GLOAD2(kn)
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int r = m0 + wm * 64 + i * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), c = n0 + wn * 64 + j * 32 + (lane & 31);
+                C[(int64_t)r * N + c] = acc[i][j][reg];
+            }
+}
+
+static int g_variant = 1;
 static void run_case(int M, int N, int K) {
     if (M % BM || N % BN || K % BK) { printf("[bf16x6] %d x %d x %d skipped: the prototype has no edge handling (multiples of %d x %d x %d only)\n", M, N, K, BM, BN, BK); return; }
     std::vector<float> A((size_t)M * K), B((size_t)N * K);
@@ -129,7 +185,8 @@ static void run_case(int M, int N, int K) {
         hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, dA, pA, (int64_t)M, K);
         hipLaunchKernelGGL(split3_kernel, dim3(4096), dim3(256), 0, 0, dB, pB, (int64_t)N, K);
         CHECK(hipEventRecord(e1));
-        hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, 0, pA, pB, dC, M, N, K);
+        if (g_variant == 1) hipLaunchKernelGGL(gemm_bf16x6_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, 0, pA, pB, dC, M, N, K);
+        else hipLaunchKernelGGL(gemm_bf16x6_db_kernel, dim3((M / BM) * (N / BN)), dim3(256), 0, 0, pA, pB, dC, M, N, K);
         CHECK(hipEventRecord(e2)); CHECK(hipEventSynchronize(e2));
         float a, b; CHECK(hipEventElapsedTime(&a, e0, e1)); CHECK(hipEventElapsedTime(&b, e1, e2));
         if (r) { ms_split += a; ms_gemm += b; }
@@ -144,18 +201,17 @@ static void run_case(int M, int N, int K) {
         err = fmax(err, fabs(C[(size_t)i * N + j] - ref)); scale = fmax(scale, fabs(ref));
     }
     const double fl = 2.0 * M * N * K;
-    printf("[bf16x6] %6d x %5d x %5d: max err / max |C| = %.3e | tile kernel %.3f ms = %.1f TFLOP/s fp32-equivalent | split %.3f ms | together %.1f TFLOP/s\n",
-           M, N, K, err / scale, ms_gemm, fl / (ms_gemm * 1e-3) / 1e12, ms_split, fl / ((ms_gemm + ms_split) * 1e-3) / 1e12);
+    printf("[bf16x6 v%d] %6d x %5d x %5d: max err / max |C| = %.3e | tile kernel %.3f ms = %.1f TFLOP/s fp32-equivalent | split %.3f ms | together %.1f TFLOP/s\n",
+           g_variant, M, N, K, err / scale, ms_gemm, fl / (ms_gemm * 1e-3) / 1e12, ms_split, fl / ((ms_gemm + ms_split) * 1e-3) / 1e12);
     CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dC)); CHECK(hipFree(pA)); CHECK(hipFree(pB));
 }
 
 int main() {
-    run_case(4096, 4096, 4096);
-    run_case(24576, 1792, 1792);       // cfg2: attention projections / per-mode group_linear slab
-    run_case(98304, 1792, 1792);       // cfg2: all four modes at once
-    run_case(24576, 896, 896);         // cfg2: layer 3
-    run_case(1792, 1792, 24576);       // cfg2: weight-gradient shape (long K, few tiles: no split-K here)
-    run_case(9472, 1024, 1024);        // cfg4: transformer projections (9408 rows rounded up to the tile)
-    run_case(8192, 1792, 256);         // short K: prologue / epilogue dominated
+    for (g_variant = 1; g_variant <= 2; ++g_variant) {      // 1: single LDS buffer, BK 32, two barriers; 2: double buffer, BK 16, one barrier
+        run_case(4096, 4096, 4096);
+        run_case(24576, 1792, 1792);       // cfg2: attention projections / per-mode group_linear slab
+        run_case(24576, 896, 896);         // cfg2: layer 3
+        run_case(8192, 1792, 256);         // short K: prologue / epilogue dominated
+    }
     return 0;
 }
