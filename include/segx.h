@@ -57,6 +57,13 @@ int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc
  * ignored): callers that want split-K size the workspace from *splitk and pass both back through the desc. */
 int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
 
+/* EXPERIMENTAL (not on the default path): segx_gemm_f32 semantics (same descriptor; splitk must be <= 1) evaluated on the bf16 matrix core
+ * with fp32-equivalent accuracy -- both operands are split once into three bf16 planes (hi + mid + lo == x exactly) in `ws`
+ * (segx_gemm_bf16x6_ws_bytes(desc) bytes, 16-byte aligned), the tile kernel issues six v_mfma_f32_32x32x16_bf16 per block and 16 k.
+ * See gemm_bf16x6.hip and DESIGN.md section 7. */
+int64_t segx_gemm_bf16x6_ws_bytes(const segx_gemm_desc* d);
+int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* ws, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Row kernels of the Squeeze-and-Expansion transformer (tokens.hip).  All tensors fp32, row-major,
  * row width a multiple of 4 (<= 4096).  Dropout masks come from a Philox4x32 counter stream

@@ -1,0 +1,203 @@
+// gemm_bf16x6.hip -- EXPERIMENTAL, not on the default path (segx.SegxLib.use_bf16x6 = False): the batched strided GEMM of gemm.hip
+// evaluated on the bf16 matrix core with fp32-equivalent accuracy.
+//
+// Both fp32 operands are split ONCE per call into three bf16 planes, x = hi + mid + lo exactly (8 + 8 + 8 significant bits), stored
+// k-contiguous [plane][batch][row][Kp] with rows padded to the 128-row tile and K to the 32-k tile (zeros), so the tile kernel needs
+// no edge handling and no layout variants: every operand layout of gemm.hip (k-contiguous or row-contiguous, any batch strides,
+// batch-broadcast operands) is resolved by the split pass.  The tile kernel issues six v_mfma_f32_32x32x16_bf16 per 32 x 32 block
+// and 16 k -- hi.lo, lo.hi, mid.mid, hi.mid, mid.hi, hi.hi (small terms first); the three dropped terms (mid.lo, lo.mid, lo.lo) are
+// below the rounding of the fp32 accumulation.  Measured on the box with the standalone prototype of the same structure
+// (tools/gemm_bf16x6_proto.hip, profiles/r01_l_bf16x6_proto.txt): 24576 x 1792 x 1792 at 146 TFLOP/s fp32-equivalent against
+// 115-124 for the fp32-MFMA engine, max error / max |C| 1.2e-6 against fp64 (the fp32 MFMA itself: 1.0e-6).
+//
+// Structure (the prototype's v1): 128 x 128 x 32 tile, 4 waves x (2 x 2) blocks, ONE 48-KB LDS buffer with register prefetch of the
+// next k-tile (152 VGPRs -> three workgroups per CU; a double-buffered 16-k variant was 27 % slower), [row][32 k] bf16 rows of 64 B
+// whose 16-B chunk index is XOR-swizzled by (row >> 1) & 3 (conflict-free ds_read_b128), XCD-contiguous tile map and the epilogue of
+// gemm_core.h (alpha, bias per column / row / (z0, z1), GELU + dropout, running max).  No split-K yet.
+#include "gemm_core.h"
+
+namespace segx {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+union FloatBits { float f; unsigned u; };
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) { FloatBits x; x.f = f; x.u += 0x7FFFu + ((x.u >> 16) & 1u); return (unsigned short)(x.u >> 16); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { FloatBits x; x.u = (unsigned)h << 16; return x.f; }
+
+// ---- split pass ------------------------------------------------------------------------------------------------------------
+// X(z0, z1, row, k) = X[z0*s_b0 + z1*s_b1 + row*s_row + k*s_k]  ->  P[plane][z][row][k8..k8+7], z = z0*nz1 + z1 over the operand's OWN
+// batch extents (a broadcast batch dimension has extent 1 here), rows < RP, k < Kp; outside (rows, K): zeros.
+// ROWFAST: consecutive threads take consecutive rows (row-contiguous operands) instead of consecutive k-chunks.
+struct SplitArgs {
+    const float* X; unsigned short* P;
+    int rows, K, RP, Kp, nz1; int64_t nz;
+    int64_t s_b0, s_b1, s_row, s_k, plane;
+};
+template <bool ROWFAST>
+__global__ __launch_bounds__(256) void split3_kernel(SplitArgs a) {
+    const int kc = a.Kp >> 3;
+    const int64_t per_z = (int64_t)a.RP * kc, total = a.nz * per_z;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t z = t / per_z; const int64_t e = t - z * per_z;
+        const int row = ROWFAST ? (int)(e % a.RP) : (int)(e / kc), c = ROWFAST ? (int)(e / a.RP) : (int)(e % kc);
+        const int z0 = (int)(z / a.nz1), z1 = (int)(z - (int64_t)z0 * a.nz1);
+        const float* src = a.X + z0 * a.s_b0 + z1 * a.s_b1 + (int64_t)row * a.s_row + (int64_t)(c * 8) * a.s_k;
+        union { unsigned short s[8]; uint4 q; } h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = row < a.rows && c * 8 + j < a.K;
+            const float x = ok ? src[j * a.s_k] : 0.f;
+            h.s[j] = f32_to_bf16_rne(x); const float r1 = x - bf16_to_f32(h.s[j]);
+            m.s[j] = f32_to_bf16_rne(r1); const float r2 = r1 - bf16_to_f32(m.s[j]);
+            l.s[j] = f32_to_bf16_rne(r2);
+        }
+        const int64_t o = (z * a.RP + row) * (int64_t)a.Kp + c * 8;
+        *reinterpret_cast<uint4*>(a.P + o) = h.q;
+        *reinterpret_cast<uint4*>(a.P + a.plane + o) = m.q;
+        *reinterpret_cast<uint4*>(a.P + 2 * a.plane + o) = l.q;
+    }
+}
+
+// ---- tile kernel -------------------------------------------------------------------------------------------------------------
+struct PlaneGeom { const unsigned short* PA; const unsigned short* PB; int Kp; int64_t planeA, planeB, pa_b0, pa_b1, pb_b0, pb_b1, zstrideA, zstrideB; };
+__device__ __forceinline__ int bf_lds_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 3)) << 4); }   // bytes in one plane tile
+
+template <int EPI>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void gemm_bf16x6_kernel(GemmArgs g, PlaneGeom pg) {
+    constexpr int TILE_BYTES = 128 * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];                      // [operand][plane][row][64 B] = 48 KB
+    const TileCoord t = tile_coord<Cfg128>(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int K = pg.Kp;
+    const unsigned short* PA = pg.PA + (t.z0 * pg.pa_b0 + t.z1 * pg.pa_b1) + (int64_t)t.m0 * K;
+    const unsigned short* PB = pg.PB + (t.z0 * pg.pb_b0 + t.z1 * pg.pb_b1) + (int64_t)t.n0 * K;
+    // global -> register staging of the next k-tile: 3 planes x 2 uint4 per operand per thread, as twelve NAMED registers (arrays of
+    // uint4 ended up in scratch in the prototype)
+    uint4 a00, a01, a10, a11, a20, a21, b00, b01, b10, b11, b20, b21;
+    const int row0 = tid >> 2, row1 = (tid + 256) >> 2, chk = tid & 3;
+    const int so0 = bf_lds_off(row0, chk), so1 = bf_lds_off(row1, chk);
+#define SEGX_BF_GL1(p, row, RA, RB, k0)                                                                    \
+    RA = *reinterpret_cast<const uint4*>(PA + (p) * pg.planeA + (int64_t)(row) * K + (k0) + chk * 8);       \
+    RB = *reinterpret_cast<const uint4*>(PB + (p) * pg.planeB + (int64_t)(row) * K + (k0) + chk * 8);
+#define SEGX_BF_GLOAD(k0)                                                                                              \
+    SEGX_BF_GL1(0, row0, a00, b00, k0) SEGX_BF_GL1(0, row1, a01, b01, k0) SEGX_BF_GL1(1, row0, a10, b10, k0)             \
+    SEGX_BF_GL1(1, row1, a11, b11, k0) SEGX_BF_GL1(2, row0, a20, b20, k0) SEGX_BF_GL1(2, row1, a21, b21, k0)
+#define SEGX_BF_LS1(p, so, RA, RB)                                                          \
+    *reinterpret_cast<uint4*>(lds + (0 * 3 + (p)) * TILE_BYTES + (so)) = RA;                 \
+    *reinterpret_cast<uint4*>(lds + (1 * 3 + (p)) * TILE_BYTES + (so)) = RB;
+#define SEGX_BF_LSTORE()                                                                                    \
+    SEGX_BF_LS1(0, so0, a00, b00) SEGX_BF_LS1(0, so1, a01, b01) SEGX_BF_LS1(1, so0, a10, b10)                \
+    SEGX_BF_LS1(1, so1, a11, b11) SEGX_BF_LS1(2, so0, a20, b20) SEGX_BF_LS1(2, so1, a21, b21)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int KT = K / 32;
+    SEGX_BF_GLOAD(0)
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+        SEGX_BF_LSTORE()
+        __syncthreads();
+        const int kn = (kt + 1 < KT ? kt + 1 : kt) * 32;             // branch-free: the last iteration re-reads its own tile
+        SEGX_BF_GLOAD(kn)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + (lane >> 5);                  // lane -> (row lane & 31, the 8 k of half lane >> 5 of this 16-k step)
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(lds + (0 * 3 + p) * TILE_BYTES + bf_lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
+                    b[i][p] = *reinterpret_cast<const bf16x8*>(lds + (1 * 3 + p) * TILE_BYTES + bf_lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);     // hi . lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);     // lo . hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);     // mid . mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);     // hi . mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);     // mid . hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);     // hi . hi
+                    acc[i][j] = c;
+                }
+        }
+    }
+#undef SEGX_BF_GL1
+#undef SEGX_BF_GLOAD
+#undef SEGX_BF_LS1
+#undef SEGX_BF_LSTORE
+    gemm_epilogue<EPI, Cfg128>(acc, g, t);
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+struct Bf16x6Plan { int RPA, RPB, Kp; int64_t nzA, nzB, planeA, planeB; int nzA1, nzB1; };
+static Bf16x6Plan bf16x6_plan(const segx_gemm_desc* d) {
+    Bf16x6Plan p;
+    p.RPA = round_up(d->M, 128); p.RPB = round_up(d->N, 128); p.Kp = round_up(d->K, 32);
+    const int a0 = d->a_b0 != 0 ? d->nb0 : 1, a1 = d->a_b1 != 0 ? d->nb1 : 1, b0 = d->b_b0 != 0 ? d->nb0 : 1, b1 = d->b_b1 != 0 ? d->nb1 : 1;
+    p.nzA = (int64_t)a0 * a1; p.nzB = (int64_t)b0 * b1; p.nzA1 = a1; p.nzB1 = b1;
+    p.planeA = p.nzA * p.RPA * p.Kp; p.planeB = p.nzB * p.RPB * p.Kp;
+    return p;
+}
+
+}  // namespace segx
+
+using namespace segx;
+
+/* bytes of the bf16 plane workspace segx_gemm_f32_bf16x6 needs for this problem */
+extern "C" int64_t segx_gemm_bf16x6_ws_bytes(const segx_gemm_desc* d) {
+    if (!d || d->M <= 0 || d->N <= 0 || d->K <= 0 || d->nb0 <= 0 || d->nb1 <= 0) return 0;
+    const Bf16x6Plan p = bf16x6_plan(d);
+    return 2 * 3 * (p.planeA + p.planeB) + 256;
+}
+
+extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* ws, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SEGX_REQUIRE(A && B && C && d && ws, "segx_gemm_f32_bf16x6: null argument");
+    SEGX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_f32_bf16x6: bad sizes");
+    SEGX_REQUIRE(d->epilogue == SEGX_EPI_NONE || d->epilogue == SEGX_EPI_GELU, "segx_gemm_f32_bf16x6: bad epilogue %d", d->epilogue);
+    SEGX_REQUIRE(d->epilogue != SEGX_EPI_GELU || d->aux, "segx_gemm_f32_bf16x6: GELU epilogue needs aux");
+    SEGX_REQUIRE(d->splitk <= 1, "segx_gemm_f32_bf16x6: split-K is not built on this path");
+    SEGX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "segx_gemm_f32_bf16x6: workspace must be 16-byte aligned");
+    const Bf16x6Plan p = bf16x6_plan(d);
+    unsigned short* PA = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* PB = PA + 3 * p.planeA;
+    SplitArgs sa{A, PA, d->M, d->K, p.RPA, p.Kp, p.nzA1, p.nzA, d->a_b0, d->a_b1, d->a_m, d->a_k, p.planeA};
+    SplitArgs sb{B, PB, d->N, d->K, p.RPB, p.Kp, p.nzB1, p.nzB, d->b_b0, d->b_b1, d->b_n, d->b_k, p.planeB};
+    const int64_t ta = p.nzA * p.RPA * (p.Kp / 8), tb = p.nzB * p.RPB * (p.Kp / 8);
+    const dim3 ga((unsigned)i64min(1 << 16, (ta + 255) / 256)), gb((unsigned)i64min(1 << 16, (tb + 255) / 256));
+    if (d->a_m == 1 && d->a_k != 1) hipLaunchKernelGGL((split3_kernel<true>), ga, dim3(256), 0, stream, sa);
+    else hipLaunchKernelGGL((split3_kernel<false>), ga, dim3(256), 0, stream, sa);
+    if (d->b_n == 1 && d->b_k != 1) hipLaunchKernelGGL((split3_kernel<true>), gb, dim3(256), 0, stream, sb);
+    else hipLaunchKernelGGL((split3_kernel<false>), gb, dim3(256), 0, stream, sb);
+    int rc = check_launch("segx_gemm_f32_bf16x6/split");
+    if (rc) return rc;
+
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = d->bias_mode ? d->bias : nullptr; g.aux = d->epilogue == SEGX_EPI_GELU ? d->aux : nullptr; g.gmax = d->gmax;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1;
+    g.a_b0 = d->a_b0; g.a_b1 = d->a_b1; g.a_m = d->a_m; g.a_k = d->a_k;
+    g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;
+    g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1; g.bias_b0 = d->bias_b0;
+    g.alpha = d->alpha; g.epilogue = d->epilogue; g.bias_mode = d->bias ? d->bias_mode : SEGX_BIAS_NONE;
+    g.vecA = g.vecB = 1; g.tiles_m = p.RPA / 128; g.tiles_n = p.RPB / 128;
+    g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset;
+    g.k_chunk = d->K; g.splitk = 1; g.c_split = 0;
+    PlaneGeom pg;
+    pg.PA = PA; pg.PB = PB; pg.Kp = p.Kp; pg.planeA = p.planeA; pg.planeB = p.planeB;
+    const int64_t zA = (int64_t)p.RPA * p.Kp, zB = (int64_t)p.RPB * p.Kp;
+    pg.pa_b1 = d->a_b1 != 0 ? zA : 0; pg.pa_b0 = d->a_b0 != 0 ? (int64_t)p.nzA1 * zA : 0;
+    pg.pb_b1 = d->b_b1 != 0 ? zB : 0; pg.pb_b0 = d->b_b0 != 0 ? (int64_t)p.nzB1 * zB : 0;
+    pg.zstrideA = zA; pg.zstrideB = zB;
+    const dim3 grid(g.tiles_m * g.tiles_n, d->nb0 * d->nb1, 1);
+    if (d->epilogue == SEGX_EPI_GELU) hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_GELU>), grid, dim3(256), 0, stream, g, pg);
+    else hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_NONE>), grid, dim3(256), 0, stream, g, pg);
+    return check_launch("segx_gemm_f32_bf16x6");
+}

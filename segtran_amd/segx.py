@@ -50,12 +50,16 @@ class SegxLib:
         self.c.segx_version.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
+        self.use_bf16x6 = False          # EXPERIMENTAL: large GEMMs on the bf16 matrix core, fp32-equivalent split
+        self.bf16x6_min_dim = 256        # only problems with min(M, N) and K at least this large
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
             fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk')) else c_i
+        if hasattr(self.c, 'segx_gemm_bf16x6_ws_bytes'):
+            self.c.segx_gemm_bf16x6_ws_bytes.restype = c_l
 
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
@@ -100,6 +104,12 @@ class SegxLib:
             self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
             tile, splitk = t.value, sk.value
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if splitk > 1 else None
+        if self.use_bf16x6 and splitk <= 1 and min(M, N) >= self.bf16x6_min_dim and K >= self.bf16x6_min_dim:
+            # EXPERIMENTAL: fp32-equivalent evaluation on the bf16 matrix core (gemm_bf16x6.hip); off by default
+            d.splitk, d.workspace, d.tile = 1, None, TILE_AUTO
+            ws = torch.empty(int(self.c.segx_gemm_bf16x6_ws_bytes(ctypes.byref(d))), dtype=torch.uint8, device=C.device)
+            self.check(self.c.segx_gemm_f32_bf16x6(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), _ptr(ws), self.stream(C)), 'segx_gemm_f32_bf16x6')
+            return
         d.splitk, d.workspace = splitk, _ptr(workspace)
         d.tile = self.force_tile if self.force_tile is not None else tile
         if self.gemm_prof is not None and C.is_cuda:

@@ -56,7 +56,7 @@ static inline hipError_t hipDeviceSynchronize() { return 0; }
 namespace hipemu {
 struct U3 { unsigned x, y, z; };
 struct Fiber { ucontext_t ctx; char* stack; bool done; U3 tid; int lane, wave; };
-struct Wave { int nlanes, arrived; unsigned gen; float fa[64], fb[64]; uint64_t ub[64]; };
+struct Wave { int nlanes, arrived; unsigned gen; float fa[64], fb[64]; uint64_t ub[64]; unsigned short sa[64][8], sb[64][8]; };
 struct State {
     dim3 grid, block; U3 bid; Fiber* cur; ucontext_t sched;
     int nthreads, bar_arrived; unsigned bar_gen;
@@ -124,6 +124,21 @@ inline f32x16_ mfma_32x32x2f32(float a, float b, f32x16_ c, int, int, int) {
         c[r] = fmaf(w.fa[i + 32], w.fb[j + 32], fmaf(w.fa[i], w.fb[j], c[r])); }
     wave_sync(); return c;
 }
+// v_mfma_f32_32x32x16_bf16 (gfx950): lane l holds A[i=l&31][k=8*(l>>5)+e], B[j=l&31][k=8*(l>>5)+e], e = 0..7 (8 bf16 per lane; layout
+// confirmed on the device by tools/mfma_bf16_probe.hip); D as the 32x32x2 form.  Products are exact in fp32; k-ordered fp32 accumulation.
+typedef short bf16x8_ __attribute__((ext_vector_type(8)));
+inline float bf16_bits_to_float(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+inline f32x16_ mfma_32x32x16bf16(bf16x8_ a, bf16x8_ b, f32x16_ c, int, int, int) {
+    Wave& w = wave(); int l = S.cur->lane;
+    for (int e = 0; e < 8; ++e) { w.sa[l][e] = (unsigned short)a[e]; w.sb[l][e] = (unsigned short)b[e]; }
+    wave_sync();
+    int j = l & 31;
+    for (int r = 0; r < 16; ++r) { int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); float acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc = fmaf(bf16_bits_to_float(w.sa[i + 32 * (k >> 3)][k & 7]), bf16_bits_to_float(w.sb[j + 32 * (k >> 3)][k & 7]), acc);
+        c[r] = acc; }
+    wave_sync(); return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r = D[i=4*(l>>4)+r][j=l&15].
 inline f32x4_ mfma_16x16x4f32(float a, float b, f32x4_ c, int, int, int) {
     Wave& w = wave(); int l = S.cur->lane;
@@ -154,6 +169,7 @@ template <class T> inline T shfl_idx(T v, int src) {
 static inline void __syncthreads() { hipemu::block_sync(); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_32x32x16bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 

@@ -170,3 +170,49 @@ def test_fusion_gemm_with_gelu_dropout_epilogue_mode_major(backend, p):
     h.backward(G); href.backward(G)
     for a, b in ((P, Pr), (u, ur), (bias, br)):
         assert (a.grad - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
+
+
+@pytest.mark.parametrize('case', ['nt', 'nn_batched_bias', 'tn', 'gelu', 'gmax_bcast'])
+def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
+    """EXPERIMENTAL path (off by default): the same descriptor evaluated by six bf16 MFMAs per block on operands
+    split into three bf16 planes.  Emulator only: the structure was timed on the box as a standalone prototype
+    (profiles/r01_l_bf16x6_proto.txt) but this entry point has not had its parity session on the device yet."""
+    if backend.name != 'emu':
+        pytest.skip('device parity session of the experimental path is scheduled for the next round')
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(91)
+    mk = lambda *sh: torch.randn(*sh, generator=g, device='cpu')      # noqa: E731
+    L.use_bf16x6, L.bf16x6_min_dim = True, 1
+    try:
+        if case == 'nt':                                   # C = A B^T, edges in every dimension (M, N not multiples of 128, K not of 32)
+            A, B = mk(150, 70), mk(133, 70)
+            C = torch.full((150, 133), float('nan'))
+            L.gemm(A, B, C, 150, 133, 70, (0, 0, 70, 1), (0, 0, 70, 1), (0, 0, 133), alpha=0.5)
+            ref = 0.5 * A.double() @ B.double().t()
+        elif case == 'nn_batched_bias':                    # row-contiguous B, batch (2, 3), per-(z1) column bias
+            A, B, bias = mk(2, 3, 40, 48), mk(2, 3, 48, 36), mk(3, 36)
+            C = torch.full((2, 3, 40, 36), float('nan'))
+            L.gemm(A, B, C, 40, 36, 48, (3 * 40 * 48, 40 * 48, 48, 1), (3 * 48 * 36, 48 * 36, 1, 36), (3 * 40 * 36, 40 * 36, 36), nb=(2, 3),
+                   bias=bias, bias_mode=segx.BIAS_N, bias_b1=36)
+            ref = A.double() @ B.double() + bias.double()[None, :, None, :]
+        elif case == 'tn':                                 # both operands row-contiguous (weight-gradient layout)
+            A, B = mk(64, 50), mk(64, 45)                  # A^T B : [50, 45], K = 64
+            C = torch.full((50, 45), float('nan'))
+            L.gemm(A, B, C, 50, 45, 64, (0, 0, 1, 50), (0, 0, 1, 45), (0, 0, 45))
+            ref = A.double().t() @ B.double()
+        elif case == 'gelu':                               # fused bias + GELU (+ pre-activation), no dropout
+            A, B, bias = mk(37, 64), mk(41, 64), mk(41)
+            C, T = torch.full((37, 41), float('nan')), torch.full((37, 41), float('nan'))
+            L.gemm(A, B, C, 37, 41, 64, (0, 0, 64, 1), (0, 0, 64, 1), (0, 0, 41), bias=bias, bias_mode=segx.BIAS_N, epilogue=segx.EPI_GELU, aux=T)
+            pre = A.double() @ B.double().t() + bias.double()
+            assert (T.double() - pre).abs().max().item() <= 2e-6 * pre.abs().max().item()
+            ref = torch.nn.functional.gelu(pre)
+        else:                                              # A shared by the batch (stride 0), running max
+            A, B, gmax = mk(33, 40), mk(4, 29, 40), torch.zeros(1)
+            C = torch.full((4, 33, 29), float('nan'))
+            L.gemm(A, B, C, 33, 29, 40, (0, 0, 40, 1), (29 * 40, 0, 40, 1), (33 * 29, 0, 29), nb=(4, 1), gmax=gmax)
+            ref = torch.einsum('mk,bnk->bmn', A.double(), B.double())
+            assert abs(gmax.item() - max(0.0, ref.max().item())) <= 1e-5 * ref.abs().max().item()
+        assert (C.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), case
+    finally:
+        L.use_bf16x6, L.bf16x6_min_dim = False, 256
