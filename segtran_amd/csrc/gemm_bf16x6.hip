@@ -13,7 +13,8 @@
 // Structure (the prototype's v1): 128 x 128 x 32 tile, 4 waves x (2 x 2) blocks, ONE 48-KB LDS buffer with register prefetch of the
 // next k-tile (152 VGPRs -> three workgroups per CU; a double-buffered 16-k variant was 27 % slower), [row][32 k] bf16 rows of 64 B
 // whose 16-B chunk index is XOR-swizzled by (row >> 1) & 3 (conflict-free ds_read_b128), XCD-contiguous tile map and the epilogue of
-// gemm_core.h (alpha, bias per column / row / (z0, z1), GELU + dropout, running max).  No split-K yet.
+// gemm_core.h (alpha, bias per column / row / (z0, z1), GELU + dropout, running max); split-K over 32-k tile boundaries with the slab
+// layout and the deterministic reduction of gemm.hip (splitk_reduce_kernel).
 #include "gemm_core.h"
 
 namespace segx {
@@ -95,9 +96,11 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void gemm_bf16x6_ke
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int KT = K / 32;
-    SEGX_BF_GLOAD(0)
-    for (int kt = 0; kt < KT; ++kt) {
+    // split-K: this workgroup covers the 32-k tiles [kt0, KT) of its slab (k_chunk is a multiple of 32; the padded planes make the last
+    // partial tile of the operand a full one)
+    const int kt0 = t.kbeg / 32, KT = (t.kend + 31) / 32;
+    SEGX_BF_GLOAD(kt0 * 32)
+    for (int kt = kt0; kt < KT; ++kt) {
         __syncthreads();
         SEGX_BF_LSTORE()
         __syncthreads();
@@ -164,7 +167,8 @@ extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, co
     SEGX_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_f32_bf16x6: bad sizes");
     SEGX_REQUIRE(d->epilogue == SEGX_EPI_NONE || d->epilogue == SEGX_EPI_GELU, "segx_gemm_f32_bf16x6: bad epilogue %d", d->epilogue);
     SEGX_REQUIRE(d->epilogue != SEGX_EPI_GELU || d->aux, "segx_gemm_f32_bf16x6: GELU epilogue needs aux");
-    SEGX_REQUIRE(d->splitk <= 1, "segx_gemm_f32_bf16x6: split-K is not built on this path");
+    const int splitk = d->splitk > 1 ? d->splitk : 1;
+    SEGX_REQUIRE(splitk == 1 || (d->workspace && d->epilogue == SEGX_EPI_NONE && !d->gmax), "segx_gemm_f32_bf16x6: split-K needs workspace and a plain epilogue");
     SEGX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "segx_gemm_f32_bf16x6: workspace must be 16-byte aligned");
     const Bf16x6Plan p = bf16x6_plan(d);
     unsigned short* PA = reinterpret_cast<unsigned short*>(ws);
@@ -189,15 +193,23 @@ extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, co
     g.alpha = d->alpha; g.epilogue = d->epilogue; g.bias_mode = d->bias ? d->bias_mode : SEGX_BIAS_NONE;
     g.vecA = g.vecB = 1; g.tiles_m = p.RPA / 128; g.tiles_n = p.RPB / 128;
     g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset;
-    g.k_chunk = d->K; g.splitk = 1; g.c_split = 0;
+    g.splitk = splitk;
+    g.k_chunk = splitk == 1 ? d->K : ceil_div(ceil_div(d->K, splitk), 32) * 32;
+    g.c_split = (int64_t)d->nb0 * d->nb1 * d->M * d->N;
+    if (splitk > 1) g.C = d->workspace;
     PlaneGeom pg;
     pg.PA = PA; pg.PB = PB; pg.Kp = p.Kp; pg.planeA = p.planeA; pg.planeB = p.planeB;
     const int64_t zA = (int64_t)p.RPA * p.Kp, zB = (int64_t)p.RPB * p.Kp;
     pg.pa_b1 = d->a_b1 != 0 ? zA : 0; pg.pa_b0 = d->a_b0 != 0 ? (int64_t)p.nzA1 * zA : 0;
     pg.pb_b1 = d->b_b1 != 0 ? zB : 0; pg.pb_b0 = d->b_b0 != 0 ? (int64_t)p.nzB1 * zB : 0;
     pg.zstrideA = zA; pg.zstrideB = zB;
-    const dim3 grid(g.tiles_m * g.tiles_n, d->nb0 * d->nb1, 1);
+    const dim3 grid(g.tiles_m * g.tiles_n, d->nb0 * d->nb1, splitk);
     if (d->epilogue == SEGX_EPI_GELU) hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_GELU>), grid, dim3(256), 0, stream, g, pg);
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_NONE>), grid, dim3(256), 0, stream, g, pg);
-    return check_launch("segx_gemm_f32_bf16x6");
+    rc = check_launch("segx_gemm_f32_bf16x6");
+    if (rc || splitk == 1) return rc;
+    const int64_t total = g.c_split;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C,
+                       g.bias, d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, g.bias_mode, d->bias_b1, d->bias_b0, total);
+    return check_launch("segx_gemm_f32_bf16x6/splitk_reduce");
 }

@@ -104,9 +104,10 @@ class SegxLib:
             self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
             tile, splitk = t.value, sk.value
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if splitk > 1 else None
-        if self.use_bf16x6 and splitk <= 1 and min(M, N) >= self.bf16x6_min_dim and K >= self.bf16x6_min_dim:
-            # EXPERIMENTAL: fp32-equivalent evaluation on the bf16 matrix core (gemm_bf16x6.hip); off by default
-            d.splitk, d.workspace, d.tile = 1, None, TILE_AUTO
+        if self.use_bf16x6 and min(M, N) >= self.bf16x6_min_dim and K >= self.bf16x6_min_dim:
+            # EXPERIMENTAL: fp32-equivalent evaluation on the bf16 matrix core (gemm_bf16x6.hip); off by default.  The split-K factor of the
+            # fp32 planner is kept (same 128 x 128 tile grid)
+            d.splitk, d.workspace, d.tile = max(1, splitk), _ptr(workspace), TILE_AUTO
             ws = torch.empty(int(self.c.segx_gemm_bf16x6_ws_bytes(ctypes.byref(d))), dtype=torch.uint8, device=C.device)
             self.check(self.c.segx_gemm_f32_bf16x6(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), _ptr(ws), self.stream(C)), 'segx_gemm_f32_bf16x6')
             return

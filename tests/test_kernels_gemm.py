@@ -172,7 +172,7 @@ def test_fusion_gemm_with_gelu_dropout_epilogue_mode_major(backend, p):
         assert (a.grad - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
 
 
-@pytest.mark.parametrize('case', ['nt', 'nn_batched_bias', 'tn', 'gelu', 'gmax_bcast'])
+@pytest.mark.parametrize('case', ['nt', 'nn_batched_bias', 'tn', 'tn_splitk', 'gelu', 'gmax_bcast'])
 def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
     """EXPERIMENTAL path (off by default): the same descriptor evaluated by six bf16 MFMAs per block on operands
     split into three bf16 planes.  Emulator only: the structure was timed on the box as a standalone prototype
@@ -200,6 +200,12 @@ def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
             C = torch.full((50, 45), float('nan'))
             L.gemm(A, B, C, 50, 45, 64, (0, 0, 1, 50), (0, 0, 1, 45), (0, 0, 45))
             ref = A.double().t() @ B.double()
+        elif case == 'tn_splitk':                          # long K split over 3 slabs (+ row bias applied by the reduction), batch 2
+            A, B, bias = mk(2, 200, 40), mk(2, 200, 37), mk(40)
+            C = torch.full((2, 40, 37), float('nan'))
+            L.gemm(A, B, C, 40, 37, 200, (200 * 40, 0, 1, 40), (200 * 37, 0, 1, 37), (40 * 37, 0, 37), nb=(2, 1), alpha=0.25, bias=bias,
+                   bias_mode=segx.BIAS_M, splitk=3, workspace=torch.empty(3 * 2 * 40 * 37))
+            ref = 0.25 * A.double().transpose(1, 2) @ B.double() + bias.double()[None, :, None]
         elif case == 'gelu':                               # fused bias + GELU (+ pre-activation), no dropout
             A, B, bias = mk(37, 64), mk(41, 64), mk(41)
             C, T = torch.full((37, 41), float('nan')), torch.full((37, 41), float('nan'))

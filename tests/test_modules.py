@@ -121,6 +121,30 @@ def test_squeeze_out_query_reassociation_equals_reference_op_order(backend, monk
             assert_close(g1[k], v, 3e-4, k, scale=gscale)
 
 
+def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
+    """Every GEMM of a squeeze-and-expansion layer (forward and backward, all layouts, split-K, fused epilogues) routed through the
+    EXPERIMENTAL bf16x6 path reproduces the reference fixture at the tolerances of the fp32-MFMA path.  Emulator only (see
+    test_kernels_gemm.py::test_experimental_bf16x6_gemm_matches_fp32)."""
+    if backend.name != 'emu':
+        pytest.skip('device parity session of the experimental path is scheduled for the next round')
+    L = backend.L
+    L.use_bf16x6, L.bf16x6_min_dim = True, 1
+    try:
+        g = golden_on('squeeze_c64f32', backend.dev)
+        mod = ss.SqueezedAttFeatTrans(mk_config([64, 32], 16), 'L').to('cpu')
+        prefix = 'voxel_fusion.translayers.0.'
+        load(mod, prefix)
+        mod.eval()
+        X = g['X'].clone().requires_grad_(True)
+        Y = mod(X)
+        assert_close(Y, g['Y'], 2e-5, 'Y')
+        (Y * g['G']).sum().backward()
+        assert_close(X.grad, g['dX'], 1e-4, 'dX')
+        check_grads(mod, prefix, g)
+    finally:
+        L.use_bf16x6, L.bf16x6_min_dim = False, 256
+
+
 def test_fusion_encoder_vs_reference(backend):
     g = golden_on('fusion_small', backend.dev)
     dims = [int(d) for d in g['dims']]
