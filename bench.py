@@ -120,6 +120,8 @@ def main():
     x, raw = engine.synth_batch(args.config, B, dev, seed=1337 + rank)          # disjoint samples per rank
 
     L = segx.lib()
+    if os.environ.get('SEGX_BF16X6'):        # EXPERIMENTAL: large GEMMs on the bf16 matrix core; value = minimum dimension
+        L.use_bf16x6, L.bf16x6_min_dim = True, max(1, int(os.environ['SEGX_BF16X6']))
     for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
         k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
     for _ in range(args.warmup):
@@ -205,6 +207,7 @@ def main():
                                   .get(args.config, args.config),
                       'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'dropout': 0.2,
                       'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5),
+                      'gemm_path': 'EXPERIMENTAL bf16x6 split for dims >= %d' % L.bf16x6_min_dim if L.use_bf16x6 else 'fp32 MFMA',
                       'op_order': ("reference" if args.reference_op_order else "re-associated") + ' (DESIGN.md 5b: exact re-association of '
                                   'consecutive linear maps; every layer, parameter and gradient is computed)',
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):

@@ -109,7 +109,15 @@ class SegxLib:
             # fp32 planner is kept (same 128 x 128 tile grid)
             d.splitk, d.workspace, d.tile = max(1, splitk), _ptr(workspace), TILE_AUTO
             ws = torch.empty(int(self.c.segx_gemm_bf16x6_ws_bytes(ctypes.byref(d))), dtype=torch.uint8, device=C.device)
-            self.check(self.c.segx_gemm_f32_bf16x6(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), _ptr(ws), self.stream(C)), 'segx_gemm_f32_bf16x6')
+            prof = self.gemm_prof is not None and C.is_cuda
+            if prof:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = self.c.segx_gemm_f32_bf16x6(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), _ptr(ws), self.stream(C))
+            if prof:
+                e1.record()                     # tile id 9 = bf16x6 (the operand split passes are inside the bracket)
+                self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, d.splitk, 9)))
+            self.check(rc, 'segx_gemm_f32_bf16x6')
             return
         d.splitk, d.workspace = splitk, _ptr(workspace)
         d.tile = self.force_tile if self.force_tile is not None else tile
