@@ -120,8 +120,7 @@ def main():
     x, raw = engine.synth_batch(args.config, B, dev, seed=1337 + rank)          # disjoint samples per rank
 
     L = segx.lib()
-    if os.environ.get('SEGX_BF16X6'):        # EXPERIMENTAL: large GEMMs on the bf16 matrix core; value = minimum dimension
-        L.use_bf16x6, L.bf16x6_min_dim = True, max(1, int(os.environ['SEGX_BF16X6']))
+    # SEGX_BF16X6=<min dim> (read by segx.lib()): EXPERIMENTAL, large GEMMs on the bf16 matrix core
     for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
         k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
     for _ in range(args.warmup):

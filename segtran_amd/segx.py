@@ -437,6 +437,8 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = SegxLib(LIB_PATH)
+        if os.environ.get('SEGX_BF16X6'):      # EXPERIMENTAL switch for a whole-process parity / timing session; value = min dim
+            _LIB.use_bf16x6, _LIB.bf16x6_min_dim = True, max(1, int(os.environ['SEGX_BF16X6']))
     return _LIB
 
 
