@@ -121,6 +121,26 @@ def test_squeeze_out_query_reassociation_equals_reference_op_order(backend, monk
             assert_close(g1[k], v, 3e-4, k, scale=gscale)
 
 
+def test_reassociation_is_gated_by_the_row_threshold(backend, monkeypatch):
+    """Below `reassociate_min_rows` token rows (launch-bound configurations such as cfg1) the layer keeps the reference op order."""
+    if backend.name != 'emu':
+        pytest.skip('host-side dispatch logic: covered once, on the emulator')
+    calls = []
+    orig = ss.ExpandedFeatTrans.forward
+    monkeypatch.setattr(ss.ExpandedFeatTrans, 'forward', lambda self, *a, **kw: (calls.append(kw.get('value_last', False)), orig(self, *a, **kw))[1])
+    mod = ss.SqueezedAttFeatTrans(mk_config([64, 32], 16), 'L')
+    load(mod, 'voxel_fusion.translayers.0.')
+    mod.eval()
+    X = torch.randn(2, 48, 64, generator=torch.Generator(device='cpu').manual_seed(2), device='cpu')
+    assert ss.CrossAttFeatTrans.reassociate_projections and ss.CrossAttFeatTrans.reassociate_min_rows == 4096
+    y_ref_order = mod(X)                                     # 96 token rows < 4096: reference order
+    assert calls == [False, False]
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)
+    y_reassoc = mod(X)
+    assert calls[2:] == [True, False]
+    assert_close(y_reassoc, y_ref_order, 2e-5, 'both orders')
+
+
 def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
     """Every GEMM of a squeeze-and-expansion layer (forward and backward, all layouts, split-K, fused epilogues) routed through the
     EXPERIMENTAL bf16x6 path reproduces the reference fixture at the tolerances of the fp32-MFMA path.  Emulator only (see
