@@ -235,7 +235,8 @@ int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* 
  * y[i] = x[i] * keep(seed, offset + i) / (1 - p); the backward pass is the same call on dy.  offset % 4 == 0, 16-B aligned. */
 int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
-/* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows) */
+/* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
+ * knob 3 = tile of the EXPERIMENTAL bf16x6 GEMM (1 = 128 x 128 x 32, 2 = 128 x 256 x 16) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);

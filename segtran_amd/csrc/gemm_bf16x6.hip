@@ -139,11 +139,103 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void gemm_bf16x6_ke
     gemm_epilogue<EPI, Cfg128>(acc, g, t);
 }
 
+// ---- wide variant (variant 2): 128 x 256 x 16 tile, a wave owns 2 x 4 blocks -------------------------------------------------------------
+// Motivation: the 128 x 128 kernel is LDS-port bound (a 2 x 2-block wave re-uses each fragment twice).  Here a wave
+// owns 64 x 128: 18 fragment reads per 48 MFMAs instead of 24; 16-k tiles keep the staging at 9 uint4 per thread; LDS is double-buffered
+// (2 x 36 KB) with ONE barrier per k-tile.  Not yet timed on the device.
+using CfgWide = TileCfg<2, 2, 2, 4>;
+__device__ __forceinline__ int bf_lds_off16(int row, int chunk) { return row * 32 + ((chunk ^ ((row >> 2) & 1)) << 4); }   // 32-B rows, 2 chunks
+
+template <int EPI>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void gemm_bf16x6_wide_kernel(GemmArgs g, PlaneGeom pg) {
+    constexpr int A_BYTES = 128 * 32, B_BYTES = 256 * 32, STAGE = 3 * (A_BYTES + B_BYTES);                   // 36 KB per stage
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    const TileCoord t = tile_coord<CfgWide>(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int K = pg.Kp;
+    const int row = tid >> 1, chk = tid & 1, so = bf_lds_off16(row, chk), so2 = bf_lds_off16(row + 128, chk);
+    const unsigned short* ga = pg.PA + (t.z0 * pg.pa_b0 + t.z1 * pg.pa_b1) + (int64_t)(t.m0 + row) * K + chk * 8;
+    const unsigned short* gb = pg.PB + (t.z0 * pg.pb_b0 + t.z1 * pg.pb_b1) + (int64_t)(t.n0 + row) * K + chk * 8;
+    const int64_t gb2 = (int64_t)128 * K;
+    uint4 a0, a1, a2, b00, b01, b10, b11, b20, b21;
+#define SEGX_BFW_GLOAD(k0)                                                                                                          \
+    a0 = *reinterpret_cast<const uint4*>(ga + (k0)); a1 = *reinterpret_cast<const uint4*>(ga + pg.planeA + (k0));                   \
+    a2 = *reinterpret_cast<const uint4*>(ga + 2 * pg.planeA + (k0));                                                                \
+    b00 = *reinterpret_cast<const uint4*>(gb + (k0)); b01 = *reinterpret_cast<const uint4*>(gb + gb2 + (k0));                       \
+    b10 = *reinterpret_cast<const uint4*>(gb + pg.planeB + (k0)); b11 = *reinterpret_cast<const uint4*>(gb + pg.planeB + gb2 + (k0)); \
+    b20 = *reinterpret_cast<const uint4*>(gb + 2 * pg.planeB + (k0)); b21 = *reinterpret_cast<const uint4*>(gb + 2 * pg.planeB + gb2 + (k0));
+#define SEGX_BFW_A(st, p) (lds + (st) * STAGE + (p) * A_BYTES)
+#define SEGX_BFW_B(st, p) (lds + (st) * STAGE + 3 * A_BYTES + (p) * B_BYTES)
+#define SEGX_BFW_LSTORE(st)                                                                                                         \
+    *reinterpret_cast<uint4*>(SEGX_BFW_A(st, 0) + so) = a0; *reinterpret_cast<uint4*>(SEGX_BFW_A(st, 1) + so) = a1;                 \
+    *reinterpret_cast<uint4*>(SEGX_BFW_A(st, 2) + so) = a2;                                                                         \
+    *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 0) + so) = b00; *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 0) + so2) = b01;              \
+    *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 1) + so) = b10; *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 1) + so2) = b11;              \
+    *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 2) + so) = b20; *reinterpret_cast<uint4*>(SEGX_BFW_B(st, 2) + so2) = b21;
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int kt0 = t.kbeg / 16, KT = (t.kend + 15) / 16;            // 16-k tiles of this slab (k_chunk is a multiple of 32)
+    SEGX_BFW_GLOAD(kt0 * 16)
+    SEGX_BFW_LSTORE(0)
+    __syncthreads();
+    { const int k1 = (kt0 + 1 < KT ? kt0 + 1 : kt0) * 16; SEGX_BFW_GLOAD(k1) }
+    const int half = lane >> 5;
+    const int fa0 = bf_lds_off16(wm * 64 + (lane & 31), half), fa1 = bf_lds_off16(wm * 64 + 32 + (lane & 31), half);
+    for (int kt = kt0; kt < KT; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        bf16x8 a[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            a[0][p] = *reinterpret_cast<const bf16x8*>(SEGX_BFW_A(cur, p) + fa0);
+            a[1][p] = *reinterpret_cast<const bf16x8*>(SEGX_BFW_A(cur, p) + fa1);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                             // two column blocks at a time: 6 B fragments live
+            bf16x8 b[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    b[q][p] = *reinterpret_cast<const bf16x8*>(SEGX_BFW_B(cur, p) + bf_lds_off16(wn * 128 + (2 * jj + q) * 32 + (lane & 31), half));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    f32x16 c = acc[i][2 * jj + q];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[q][2], c, 0, 0, 0);     // hi . lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[q][0], c, 0, 0, 0);     // lo . hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[q][1], c, 0, 0, 0);     // mid . mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[q][1], c, 0, 0, 0);     // hi . mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[q][0], c, 0, 0, 0);     // mid . hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[q][0], c, 0, 0, 0);     // hi . hi
+                    acc[i][2 * jj + q] = c;
+                }
+        }
+        if (cur) { SEGX_BFW_LSTORE(0) } else { SEGX_BFW_LSTORE(1) }     // tile kt + 1 into the other stage (last iteration: a harmless re-store)
+        __syncthreads();
+        const int kn = (kt + 2 < KT ? kt + 2 : KT - 1) * 16;
+        SEGX_BFW_GLOAD(kn)
+    }
+#undef SEGX_BFW_GLOAD
+#undef SEGX_BFW_A
+#undef SEGX_BFW_B
+#undef SEGX_BFW_LSTORE
+    gemm_epilogue<EPI, CfgWide>(acc, g, t);
+}
+
+static int g_bf16x6_variant = 1;      // segx_tune(3, v): 1 = 128 x 128 x 32 (timed on the device), 2 = 128 x 256 x 16 wide waves (not yet timed)
+int bf16x6_set_variant(int v) { if (v != 1 && v != 2) return -1; g_bf16x6_variant = v; return 0; }
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct Bf16x6Plan { int RPA, RPB, Kp; int64_t nzA, nzB, planeA, planeB; int nzA1, nzB1; };
 static Bf16x6Plan bf16x6_plan(const segx_gemm_desc* d) {
     Bf16x6Plan p;
-    p.RPA = round_up(d->M, 128); p.RPB = round_up(d->N, 128); p.Kp = round_up(d->K, 32);
+    p.RPA = round_up(d->M, 128); p.RPB = round_up(d->N, 256); p.Kp = round_up(d->K, 32);      // N padded for the widest tile (128 x 256)
     const int a0 = d->a_b0 != 0 ? d->nb0 : 1, a1 = d->a_b1 != 0 ? d->nb1 : 1, b0 = d->b_b0 != 0 ? d->nb0 : 1, b1 = d->b_b1 != 0 ? d->nb1 : 1;
     p.nzA = (int64_t)a0 * a1; p.nzB = (int64_t)b0 * b1; p.nzA1 = a1; p.nzB1 = b1;
     p.planeA = p.nzA * p.RPA * p.Kp; p.planeB = p.nzB * p.RPB * p.Kp;
@@ -191,7 +283,8 @@ extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, co
     g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;
     g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1; g.bias_b0 = d->bias_b0;
     g.alpha = d->alpha; g.epilogue = d->epilogue; g.bias_mode = d->bias ? d->bias_mode : SEGX_BIAS_NONE;
-    g.vecA = g.vecB = 1; g.tiles_m = p.RPA / 128; g.tiles_n = p.RPB / 128;
+    const bool wide = g_bf16x6_variant == 2;
+    g.vecA = g.vecB = 1; g.tiles_m = p.RPA / 128; g.tiles_n = wide ? p.RPB / 256 : ceil_div(d->N, 128);
     g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset;
     g.splitk = splitk;
     g.k_chunk = splitk == 1 ? d->K : ceil_div(ceil_div(d->K, splitk), 32) * 32;
@@ -204,7 +297,10 @@ extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, co
     pg.pb_b1 = d->b_b1 != 0 ? zB : 0; pg.pb_b0 = d->b_b0 != 0 ? (int64_t)p.nzB1 * zB : 0;
     pg.zstrideA = zA; pg.zstrideB = zB;
     const dim3 grid(g.tiles_m * g.tiles_n, d->nb0 * d->nb1, splitk);
-    if (d->epilogue == SEGX_EPI_GELU) hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_GELU>), grid, dim3(256), 0, stream, g, pg);
+    if (wide) {
+        if (d->epilogue == SEGX_EPI_GELU) hipLaunchKernelGGL((gemm_bf16x6_wide_kernel<SEGX_EPI_GELU>), grid, dim3(256), 0, stream, g, pg);
+        else hipLaunchKernelGGL((gemm_bf16x6_wide_kernel<SEGX_EPI_NONE>), grid, dim3(256), 0, stream, g, pg);
+    } else if (d->epilogue == SEGX_EPI_GELU) hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_GELU>), grid, dim3(256), 0, stream, g, pg);
     else hipLaunchKernelGGL((gemm_bf16x6_kernel<SEGX_EPI_NONE>), grid, dim3(256), 0, stream, g, pg);
     rc = check_launch("segx_gemm_f32_bf16x6");
     if (rc || splitk == 1) return rc;

@@ -172,8 +172,9 @@ def test_fusion_gemm_with_gelu_dropout_epilogue_mode_major(backend, p):
         assert (a.grad - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
 
 
+@pytest.mark.parametrize('variant', [1, 2], ids=['tile128x128x32', 'tile128x256x16'])
 @pytest.mark.parametrize('case', ['nt', 'nn_batched_bias', 'tn', 'tn_splitk', 'gelu', 'gmax_bcast'])
-def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
+def test_experimental_bf16x6_gemm_matches_fp32(backend, case, variant):
     """EXPERIMENTAL path (off by default): the same descriptor evaluated by six bf16 MFMAs per block on operands
     split into three bf16 planes.  Emulator only: the structure was timed on the box as a standalone prototype
     (profiles/r01_l_bf16x6_proto.txt) but this entry point has not had its parity session on the device yet."""
@@ -183,11 +184,12 @@ def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
     g = torch.Generator(device='cpu').manual_seed(91)
     mk = lambda *sh: torch.randn(*sh, generator=g, device='cpu')      # noqa: E731
     L.use_bf16x6, L.bf16x6_min_dim = True, 1
+    assert L.c.segx_tune(3, variant) == 0
     try:
         if case == 'nt':                                   # C = A B^T, edges in every dimension (M, N not multiples of 128, K not of 32)
-            A, B = mk(150, 70), mk(133, 70)
-            C = torch.full((150, 133), float('nan'))
-            L.gemm(A, B, C, 150, 133, 70, (0, 0, 70, 1), (0, 0, 70, 1), (0, 0, 133), alpha=0.5)
+            A, B = mk(150, 70), mk(300, 70)
+            C = torch.full((150, 300), float('nan'))
+            L.gemm(A, B, C, 150, 300, 70, (0, 0, 70, 1), (0, 0, 70, 1), (0, 0, 300), alpha=0.5)
             ref = 0.5 * A.double() @ B.double().t()
         elif case == 'nn_batched_bias':                    # row-contiguous B, batch (2, 3), per-(z1) column bias
             A, B, bias = mk(2, 3, 40, 48), mk(2, 3, 48, 36), mk(3, 36)
@@ -222,3 +224,4 @@ def test_experimental_bf16x6_gemm_matches_fp32(backend, case):
         assert (C.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), case
     finally:
         L.use_bf16x6, L.bf16x6_min_dim = False, 256
+        L.c.segx_tune(3, 1)
