@@ -63,6 +63,10 @@ int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int*
  * See gemm_bf16x6.hip and DESIGN.md section 7. */
 int64_t segx_gemm_bf16x6_ws_bytes(const segx_gemm_desc* d);
 int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* ws, void* stream);
+/* EXPERIMENTAL: segx_conv3d_fwd_packed (packed filters, same geom array; no split-K) on the bf16x6 tile; the activations are split into
+ * bf16 planes stored channels-last-8 in `ws` (segx_conv3d_bf16x6_ws_bytes bytes, 16-byte aligned).  Cin % 8 == 0. */
+int64_t segx_conv3d_bf16x6_ws_bytes(int B, int Cout, const int* geom);
+int segx_conv3d_fwd_bf16x6(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels of the Squeeze-and-Expansion transformer (tokens.hip).  All tensors fp32, row-major,

@@ -231,6 +231,125 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void gemm_bf16x6_wi
 static int g_bf16x6_variant = 1;      // segx_tune(3, v): 1 = 128 x 128 x 32 (timed on the device), 2 = 128 x 256 x 16 wide waves (not yet timed)
 int bf16x6_set_variant(int v) { if (v != 1 && v != 2) return -1; g_bf16x6_variant = v; return 0; }
 
+// ---- implicit-GEMM 3-D convolution forward on the same tile (packed contraction order of conv3d.hip) -----------------------------------
+// Y[b][co][p] = sum_k Wp[co][k] * im2col(X[b])[k][p],  k = (channel block of 8, tap, channel in block).  Eight consecutive k are the
+// eight channels of one block at ONE tap, so with the activations split into bf16 planes stored channels-last-8,
+// P[plane][b][cb][s][8], the B fragment of a lane (position, 8 k) is ONE 16-byte vector at (cb, window origin + tap offset): the
+// im2col gather costs one address and one validity test per 8 k.  Weights: the packed fp32 filters split like any k-contiguous A.
+struct ConvG { int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw; };
+
+__global__ __launch_bounds__(256) void split3_cl8_kernel(const float* __restrict__ X, unsigned short* __restrict__ P, int64_t nblk, int S, int64_t plane) {
+    const int64_t total = nblk * S;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t blk = t / S; const int sidx = (int)(t - blk * S);
+        const float* src = X + blk * 8 * S + sidx;
+        union { unsigned short s[8]; uint4 q; } h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = src[(int64_t)j * S];
+            h.s[j] = f32_to_bf16_rne(x); const float r1 = x - bf16_to_f32(h.s[j]);
+            m.s[j] = f32_to_bf16_rne(r1); const float r2 = r1 - bf16_to_f32(m.s[j]);
+            l.s[j] = f32_to_bf16_rne(r2);
+        }
+        *reinterpret_cast<uint4*>(P + t * 8) = h.q;
+        *reinterpret_cast<uint4*>(P + plane + t * 8) = m.q;
+        *reinterpret_cast<uint4*>(P + 2 * plane + t * 8) = l.q;
+    }
+}
+
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void conv3d_fwd_bf16x6_kernel(GemmArgs g, PlaneGeom pg, ConvG q) {
+    constexpr int TILE_BYTES = 128 * 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * TILE_BYTES];
+    const TileCoord t = tile_coord<Cfg128>(g);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int K = pg.Kp, KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, CB = q.Cin >> 3, nchunks = CB * KV;
+    const int S_in = q.ID * q.IH * q.IW, OHW = q.OH * q.OW;
+    const unsigned short* PA = pg.PA + (int64_t)t.m0 * K;
+    const unsigned short* PB = pg.PB + (int64_t)t.z0 * CB * S_in * 8;                // this sample's activation planes
+    uint4 a00, a01, a10, a11, a20, a21, b00, b01, b10, b11, b20, b21;
+    const int row0 = tid >> 2, row1 = (tid + 256) >> 2, chk = tid & 3;
+    const int so0 = bf_lds_off(row0, chk), so1 = bf_lds_off(row1, chk);
+    // window origins of this thread's two output positions
+    const int n0_ = t.n0 + row0, n1_ = t.n0 + row1;
+    const bool ok0 = n0_ < g.N, ok1 = n1_ < g.N;
+    const int p0 = ok0 ? n0_ : 0, p1 = ok1 ? n1_ : 0;
+    const int d0 = (p0 / OHW) * q.sd - q.pd, h0 = ((p0 / q.OW) % q.OH) * q.sh - q.ph, w0 = (p0 % q.OW) * q.sw - q.pw;
+    const int d1 = (p1 / OHW) * q.sd - q.pd, h1 = ((p1 / q.OW) % q.OH) * q.sh - q.ph, w1 = (p1 % q.OW) * q.sw - q.pw;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#define SEGX_CV_A1(p, row, RA, k0) RA = *reinterpret_cast<const uint4*>(PA + (p) * pg.planeA + (int64_t)(row) * K + (k0) + chk * 8);
+#define SEGX_CV_B1(RB0, RB1, RB2, dd, hh, ww, okr)                                                                                          \
+    {                                                                                                                                      \
+        const int id = (dd) + kd, ih = (hh) + kh, iw = (ww) + kw;                                                                          \
+        const bool v = (okr) && qv && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;      \
+        const int64_t off = v ? ((int64_t)cb * S_in + ((int64_t)id * q.IH + ih) * q.IW + iw) * 8 : 0;                                      \
+        const uint4 x0 = *reinterpret_cast<const uint4*>(PB + off), x1 = *reinterpret_cast<const uint4*>(PB + pg.planeB + off),            \
+                    x2 = *reinterpret_cast<const uint4*>(PB + 2 * pg.planeB + off);                                                        \
+        RB0 = v ? x0 : zero4; RB1 = v ? x1 : zero4; RB2 = v ? x2 : zero4;                                                                  \
+    }
+#define SEGX_CV_GLOAD(k0)                                                                                                                   \
+    {                                                                                                                                      \
+        SEGX_CV_A1(0, row0, a00, k0) SEGX_CV_A1(0, row1, a01, k0) SEGX_CV_A1(1, row0, a10, k0) SEGX_CV_A1(1, row1, a11, k0)                 \
+        SEGX_CV_A1(2, row0, a20, k0) SEGX_CV_A1(2, row1, a21, k0)                                                                          \
+        const int qi = ((k0) >> 3) + chk; const bool qv = qi < nchunks;                                                                    \
+        const int qc = qv ? qi : 0, cb = qc / KV, tap = qc - cb * KV, kd = tap / KHW, tr = tap - kd * KHW, kh = tr / q.KW, kw = tr - kh * q.KW; \
+        SEGX_CV_B1(b00, b10, b20, d0, h0, w0, ok0)                                                                                         \
+        SEGX_CV_B1(b01, b11, b21, d1, h1, w1, ok1)                                                                                         \
+    }
+#define SEGX_CV_LS1(p, so, RA, RB)                                                          \
+    *reinterpret_cast<uint4*>(lds + (0 * 3 + (p)) * TILE_BYTES + (so)) = RA;                 \
+    *reinterpret_cast<uint4*>(lds + (1 * 3 + (p)) * TILE_BYTES + (so)) = RB;
+#define SEGX_CV_LSTORE()                                                                                    \
+    SEGX_CV_LS1(0, so0, a00, b00) SEGX_CV_LS1(0, so1, a01, b01) SEGX_CV_LS1(1, so0, a10, b10)                \
+    SEGX_CV_LS1(1, so1, a11, b11) SEGX_CV_LS1(2, so0, a20, b20) SEGX_CV_LS1(2, so1, a21, b21)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int KT = K / 32;
+    SEGX_CV_GLOAD(0)
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+        SEGX_CV_LSTORE()
+        __syncthreads();
+        const int kn = (kt + 1 < KT ? kt + 1 : kt) * 32;
+        SEGX_CV_GLOAD(kn)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int chunk = 2 * s + (lane >> 5);
+            bf16x8 a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const bf16x8*>(lds + (0 * 3 + p) * TILE_BYTES + bf_lds_off(wm * 64 + i * 32 + (lane & 31), chunk));
+                    b[i][p] = *reinterpret_cast<const bf16x8*>(lds + (1 * 3 + p) * TILE_BYTES + bf_lds_off(wn * 64 + i * 32 + (lane & 31), chunk));
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+    }
+#undef SEGX_CV_A1
+#undef SEGX_CV_B1
+#undef SEGX_CV_GLOAD
+#undef SEGX_CV_LS1
+#undef SEGX_CV_LSTORE
+    gemm_epilogue<SEGX_EPI_NONE, Cfg128>(acc, g, t);
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 struct Bf16x6Plan { int RPA, RPB, Kp; int64_t nzA, nzB, planeA, planeB; int nzA1, nzB1; };
 static Bf16x6Plan bf16x6_plan(const segx_gemm_desc* d) {
@@ -308,4 +427,44 @@ extern "C" int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, co
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C,
                        g.bias, d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, g.bias_mode, d->bias_b1, d->bias_b0, total);
     return check_launch("segx_gemm_f32_bf16x6/splitk_reduce");
+}
+
+/* EXPERIMENTAL: segx_conv3d_fwd_packed semantics (packed filters Wp, stride/pad geometry as segx_conv3d_fwd) on the bf16x6 tile.
+ * ws: segx_conv3d_bf16x6_ws_bytes(B, Cout, geom) bytes, 16-byte aligned. */
+extern "C" int64_t segx_conv3d_bf16x6_ws_bytes(int B, int Cout, const int* geom) {
+    if (!geom || B <= 0 || Cout <= 0) return 0;
+    const int64_t K = (int64_t)geom[0] * geom[7] * geom[8] * geom[9], S_in = (int64_t)geom[1] * geom[2] * geom[3];
+    return 2 * 3 * ((int64_t)round_up(Cout, 128) * round_up((int)K, 32) + (int64_t)B * geom[0] * S_in) + 256;
+}
+extern "C" int segx_conv3d_fwd_bf16x6(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, void* ws, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SEGX_REQUIRE(X && Wp && Y && geom && ws && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_fwd_bf16x6: bad args");
+    ConvG q{geom[0], geom[1], geom[2], geom[3], geom[4], geom[5], geom[6], geom[7], geom[8], geom[9], geom[10], geom[11], geom[12], geom[13], geom[14], geom[15]};
+    SEGX_REQUIRE(q.Cin > 0 && q.Cin % 8 == 0, "segx_conv3d_fwd_bf16x6: Cin = %d is not a multiple of 8", q.Cin);
+    const int64_t P = (int64_t)q.OD * q.OH * q.OW, S_in = (int64_t)q.ID * q.IH * q.IW; const int K = q.Cin * q.KD * q.KH * q.KW;
+    SEGX_REQUIRE(P > 0 && P < 2147483647LL && K > 0 && (int64_t)q.Cin * S_in < 2147483647LL, "segx_conv3d_fwd_bf16x6: bad geometry");
+    SEGX_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "segx_conv3d_fwd_bf16x6: workspace must be 16-byte aligned");
+    const int RPA = round_up(Cout, 128), Kp = round_up(K, 32);
+    const int64_t planeA = (int64_t)RPA * Kp, planeB = (int64_t)B * q.Cin * S_in;
+    unsigned short* PA = reinterpret_cast<unsigned short*>(ws);
+    unsigned short* PB = PA + 3 * planeA;
+    SplitArgs sa{Wp, PA, Cout, K, RPA, Kp, 1, 1, 0, 0, K, 1, planeA};
+    const int64_t ta = (int64_t)RPA * (Kp / 8), tb = (int64_t)B * (q.Cin / 8) * S_in;
+    hipLaunchKernelGGL((split3_kernel<false>), dim3((unsigned)i64min(1 << 16, (ta + 255) / 256)), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL(split3_cl8_kernel, dim3((unsigned)i64min(1 << 16, (tb + 255) / 256)), dim3(256), 0, stream, X, PB, (int64_t)B * (q.Cin / 8), (int)S_in, planeB);
+    int rc = check_launch("segx_conv3d_fwd_bf16x6/split");
+    if (rc) return rc;
+    GemmArgs g;
+    g.A = Wp; g.B = X; g.C = Y; g.bias = nullptr; g.aux = nullptr; g.gmax = nullptr;
+    g.M = Cout; g.N = (int)P; g.K = K; g.nb1 = 1;
+    g.a_b0 = g.a_b1 = 0; g.a_m = K; g.a_k = 1; g.b_b0 = g.b_b1 = g.b_n = g.b_k = 0;
+    g.c_b0 = (int64_t)Cout * P; g.c_b1 = 0; g.c_m = P; g.bias_b1 = g.bias_b0 = 0;
+    g.alpha = 1.0f; g.epilogue = SEGX_EPI_NONE; g.bias_mode = SEGX_BIAS_NONE; g.vecA = g.vecB = 1;
+    g.tiles_m = RPA / 128; g.tiles_n = ceil_div(P, 128);
+    g.dropout_p = 0.f; g.seed = g.offset = 0; g.k_chunk = K; g.splitk = 1; g.c_split = 0;
+    PlaneGeom pg;
+    pg.PA = PA; pg.PB = PB; pg.Kp = Kp; pg.planeA = planeA; pg.planeB = planeB;
+    pg.pa_b0 = pg.pa_b1 = pg.pb_b0 = pg.pb_b1 = 0; pg.zstrideA = pg.zstrideB = 0;
+    hipLaunchKernelGGL(conv3d_fwd_bf16x6_kernel, dim3(g.tiles_m * g.tiles_n, B, 1), dim3(256), 0, stream, g, pg, q);
+    return check_launch("segx_conv3d_fwd_bf16x6");
 }

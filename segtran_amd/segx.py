@@ -52,6 +52,7 @@ class SegxLib:
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
         self.use_bf16x6 = False          # EXPERIMENTAL: large GEMMs on the bf16 matrix core, fp32-equivalent split
         self.bf16x6_min_dim = 256        # only problems with min(M, N) and K at least this large
+        self.bf16x6_calls = 0            # launches that took the experimental path (sessions / tests read it)
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
@@ -60,6 +61,7 @@ class SegxLib:
             fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk')) else c_i
         if hasattr(self.c, 'segx_gemm_bf16x6_ws_bytes'):
             self.c.segx_gemm_bf16x6_ws_bytes.restype = c_l
+            self.c.segx_conv3d_bf16x6_ws_bytes.restype = c_l
 
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
@@ -108,6 +110,7 @@ class SegxLib:
             # EXPERIMENTAL: fp32-equivalent evaluation on the bf16 matrix core (gemm_bf16x6.hip); off by default.  The split-K factor of the
             # fp32 planner is kept (same 128 x 128 tile grid)
             d.splitk, d.workspace, d.tile = max(1, splitk), _ptr(workspace), TILE_AUTO
+            self.bf16x6_calls += 1
             ws = torch.empty(int(self.c.segx_gemm_bf16x6_ws_bytes(ctypes.byref(d))), dtype=torch.uint8, device=C.device)
             prof = self.gemm_prof is not None and C.is_cuda
             if prof:
@@ -336,6 +339,15 @@ class SegxLib:
     def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None, packed=False):
         self._chk_t(X, W, Y, ws)
         P = geom[4] * geom[5] * geom[6]; K = geom[0] * geom[7] * geom[8] * geom[9]
+        if packed and self.use_bf16x6 and splitk <= 1 and min(Cout, P) >= self.bf16x6_min_dim:
+            # EXPERIMENTAL (off by default): the implicit GEMM on the bf16 matrix core, activations split into channels-last-8 bf16 planes
+            self.bf16x6_calls += 1
+            g_ = self._geom(geom)
+            wsb = torch.empty(int(self.c.segx_conv3d_bf16x6_ws_bytes(B, Cout, g_)), dtype=torch.uint8, device=Y.device)
+            rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd_bf16x6', Cout, P, K, B, 1),
+                             lambda: self.c.segx_conv3d_fwd_bf16x6(_ptr(X), _ptr(W), _ptr(Y), B, Cout, g_, _ptr(wsb), self.stream(Y)))
+            self.check(rc, 'segx_conv3d_fwd_bf16x6')
+            return
         fn = self.c.segx_conv3d_fwd_packed if packed else self.c.segx_conv3d_fwd
         rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk),
                          lambda: fn(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))

@@ -183,7 +183,7 @@ def test_experimental_bf16x6_gemm_matches_fp32(backend, case, variant):
     L = backend.L
     g = torch.Generator(device='cpu').manual_seed(91)
     mk = lambda *sh: torch.randn(*sh, generator=g, device='cpu')      # noqa: E731
-    L.use_bf16x6, L.bf16x6_min_dim = True, 1
+    L.use_bf16x6, L.bf16x6_min_dim, L.bf16x6_calls = True, 1, 0
     assert L.c.segx_tune(3, variant) == 0
     try:
         if case == 'nt':                                   # C = A B^T, edges in every dimension (M, N not multiples of 128, K not of 32)
@@ -222,6 +222,7 @@ def test_experimental_bf16x6_gemm_matches_fp32(backend, case, variant):
             ref = torch.einsum('mk,bnk->bmn', A.double(), B.double())
             assert abs(gmax.item() - max(0.0, ref.max().item())) <= 1e-5 * ref.abs().max().item()
         assert (C.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), case
+        assert L.bf16x6_calls > 0                          # the experimental path really ran
     finally:
         L.use_bf16x6, L.bf16x6_min_dim = False, 256
         L.c.segx_tune(3, 1)

@@ -148,7 +148,7 @@ def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
     if backend.name != 'emu':
         pytest.skip('device parity session of the experimental path is scheduled for the next round')
     L = backend.L
-    L.use_bf16x6, L.bf16x6_min_dim = True, 1
+    L.use_bf16x6, L.bf16x6_min_dim, L.bf16x6_calls = True, 1, 0
     try:
         g = golden_on('squeeze_c64f32', backend.dev)
         mod = ss.SqueezedAttFeatTrans(mk_config([64, 32], 16), 'L').to('cpu')
@@ -161,6 +161,7 @@ def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
         (Y * g['G']).sum().backward()
         assert_close(X.grad, g['dX'], 1e-4, 'dX')
         check_grads(mod, prefix, g)
+        assert L.bf16x6_calls > 0                          # the experimental path really ran
     finally:
         L.use_bf16x6, L.bf16x6_min_dim = False, 256
 
