@@ -250,6 +250,10 @@ int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64
  * F.interpolate(scale_factor=1/s) on sizes s does not divide (Mince transformer, reference segtran_shared.py:47-66) */
 int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
                                 float src_scale, void* stream);
+/* RandomResizedCrop of the 3-D trainer (dataloaders/datasets3d.py:611-665, train3d.py:713-715): resample X [planes, d, h, w] to (D, H, W)
+ * (trilinear, align_corners=False), zero-pad, crop (od, oh, ow) voxels -- as one gather pass that only computes the cropped window.
+ * geom (int32[12]) = {d, h, w, D, H, W, od, oh, ow, oz, oy, ox}; (oz, oy, ox) = crop start minus front pad, in the resampled grid */
+int segx_resized_crop3d(const float* X, float* Y, int64_t planes, const int* geom, void* stream);
 int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
 /* separable form: adjoint along ONE axis of a tensor viewed as [outer, n_out, inner] -> [outer, n_in, inner] */
 int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, float src_scale,
@@ -289,7 +293,7 @@ int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, floa
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
 int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream);
 /* in-step label -> n-hot maps (datasets2d.py:90-139,200-223; datasets3d.py:16-40): mode 0 fundus uint8 [B,Cin,S] -> [B,3,S];
- * 1 polyp uint8 -> [B,2,S]; 2 brats int32 [B,S] -> [B,4,S] */
+ * 1 polyp uint8 -> [B,2,S]; 2 brats int32 [B,S] -> [B,4,S]; 3 fundus with exclusive=True (--exclusive: disc = ch0 without the cup) */
 int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, int mode, void* stream);
 /* MaxPool3dSamePadding (aj_i3d.py:6-30): zero 'same' padding then max-pool.  geom (int32[15]) =
  * {ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}; arg = arg-max index per output (-1 = a padded zero won) */

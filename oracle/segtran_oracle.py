@@ -478,11 +478,11 @@ def segtran3d_forward(sd, x, translayer_dims, num_modes=4, training=False, attn_
 # ----------------------------------------------------------------------------------------
 # Train-step glue                                          train2d.py, train3d.py, utils/losses.py
 # ----------------------------------------------------------------------------------------
-def fundus_map_mask(mask):
-    """dataloaders/datasets2d.py:90-139 (4-D branch, exclusive=False): uint8 {0,255} -> n-hot [bg,disc,cup]."""
+def fundus_map_mask(mask, exclusive=False):
+    """dataloaders/datasets2d.py:90-139 (4-D branch): uint8 {0,255} -> n-hot [bg,disc,cup]; exclusive (:110-111): disc without cup."""
     out = torch.zeros(mask.shape[0], 3, *mask.shape[2:])
     out[:, 0] = (mask[:, 0] == 0)
-    out[:, 1] = (mask[:, 0] >= 1)
+    out[:, 1] = (mask[:, 0] >= 1) if not exclusive else ((mask[:, 0] >= 1) & (mask[:, 1] == 0))
     out[:, 2] = (mask[:, 1] >= 1)
     return out
 
@@ -503,6 +503,31 @@ def brats_map_label(label):
     out[2, (label == 3) | (label == 1) | (label == 2)] = 1
     out[3, (label == 3) | (label == 1)] = 1
     return out.permute(1, 0, *range(2, out.dim()))
+
+
+def random_resized_crop(volume, mask, out_size, crop_percents, isotropic=True):
+    """dataloaders/datasets3d.py:611-665 (train3d.py:713-715, --randscale): random rescale (one draw when isotropic) of volume and n-hot
+    mask by trilinear interpolation, zero padding up to out_size, random crop of out_size.  RNG: torch's global CPU generator, draws in
+    the reference's order.  The mask stays continuous (:661-662)."""
+    H, W, D = volume.shape[-3:]
+    lo, hi = 1 + crop_percents[0], 1 + crop_percents[1]
+    sH = torch.rand(1) * (hi - lo) + lo
+    if isotropic:
+        sW = sD = sH
+    else:
+        sW = torch.rand(1) * (hi - lo) + lo
+        sD = torch.rand(1) * (hi - lo) + lo
+    H2, W2, D2 = int(H * sH), int(W * sW), int(D * sD)
+    v2 = F.interpolate(volume, size=(H2, W2, D2), mode='trilinear', align_corners=False)
+    m2 = F.interpolate(mask, size=(H2, W2, D2), mode='trilinear', align_corners=False)
+    Ho, Wo, Do = out_size
+    if H2 < Ho or W2 < Wo or D2 < Do:
+        ph, pw, pd = max(Ho - H2, 0), max(Wo - W2, 0), max(Do - D2, 0)
+        pads = (pd // 2, pd - pd // 2, pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+        v2, m2 = F.pad(v2, pads, 'constant', 0), F.pad(m2, pads, 'constant', 0)
+    H2, W2, D2 = v2.shape[2:]
+    h0 = int(torch.randint(H2 - Ho + 1, (1,))); w0 = int(torch.randint(W2 - Wo + 1, (1,))); d0 = int(torch.randint(D2 - Do + 1, (1,)))
+    return v2[:, :, h0:h0 + Ho, w0:w0 + Wo, d0:d0 + Do].clone(), m2[:, :, h0:h0 + Ho, w0:w0 + Wo, d0:d0 + Do].clone()
 
 
 def bce_pos_weight(bce_weight):

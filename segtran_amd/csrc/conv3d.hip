@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void nonzero_mask_kernel(const float* __restri
 // n-hot label maps of the train step (datasets2d.py:90-139,200-223; datasets3d.py:16-40), uint8 / int32 labels -> float planes
 //   mode 0 fundus (exclusive=False): in [B,Cin>=2,S] uint8 -> [B,3,S]: (ch0==0, ch0>=1, ch1>=1)
 //   mode 1 polyp: [B,Cin>=1,S] uint8 -> [B,2,S]: (ch0==0, ch0>0)
+//   mode 3 fundus, exclusive=True (datasets2d.py:110-111): (ch0==0, ch0>=1 && ch1==0, ch1>=1)
 //   mode 2 brats: [B,S] int32 -> [B,4,S]: (l==0, l==3, l in {1,2,3}, l in {1,3})
 __global__ __launch_bounds__(256) void label_nhot_kernel(const void* __restrict__ lab, float* __restrict__ out, int B, int Cin, int64_t S, int mode) {
     const int64_t total = (int64_t)B * S;
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void label_nhot_kernel(const void* __restrict_
             o[0] = l == 0; o[S] = l == 3; o[2 * S] = (l == 1 || l == 2 || l == 3); o[3 * S] = (l == 1 || l == 3);
         } else {
             const unsigned char* m = reinterpret_cast<const unsigned char*>(lab) + b * Cin * S + s;
-            if (mode == 0) { float* o = out + b * 3 * S + s; o[0] = m[0] == 0; o[S] = m[0] >= 1; o[2 * S] = m[S] >= 1; }
+            if (mode == 0 || mode == 3) { float* o = out + b * 3 * S + s; o[0] = m[0] == 0; o[S] = (m[0] >= 1) && (mode == 0 || m[S] == 0); o[2 * S] = m[S] >= 1; }
             else { float* o = out + b * 2 * S + s; o[0] = m[0] == 0; o[S] = m[0] > 0; }
         }
     }
@@ -727,7 +728,7 @@ extern "C" int segx_nonzero_mask(const float* X, float* out, int B, int C, int D
     return check_launch("segx_nonzero_mask");
 }
 extern "C" int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, int mode, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(labels && out && B > 0 && S > 0 && mode >= 0 && mode <= 2 && (mode == 2 || Cin >= (mode == 0 ? 2 : 1)), "segx_label_nhot: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(labels && out && B > 0 && S > 0 && mode >= 0 && mode <= 3 && (mode == 2 || Cin >= (mode == 1 ? 1 : 2)), "segx_label_nhot: bad args");
     const int64_t total = (int64_t)B * S;
     hipLaunchKernelGGL(label_nhot_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, labels, out, B, Cin, S, mode);
     return check_launch("segx_label_nhot");

@@ -340,6 +340,22 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 3) return segx::bf16x6_set_variant(value);      // EXPERIMENTAL bf16x6 GEMM: 1 = 128 x 128 x 32 tile, 2 = 128 x 256 x 16 wide waves
     return -1;
 }
+// RandomResizedCrop (datasets3d.py:611-665) as ONE gather pass: the volume is (virtually) resampled to (D, H, W) with the trilinear
+// align_corners=False rule, zero-padded, and a window of (od, oh, ow) voxels is cut out at offset (oz, oy, ox) measured in the resampled,
+// UNPADDED grid (i.e. crop start - front pad; negative / beyond-the-end coordinates fall into the padding and read 0).  Only the voxels
+// of the window are ever computed; the resampled volume and its padded copy (the reference materialises both) never exist.
+__global__ __launch_bounds__(256) void resized_crop3d_kernel(const float* __restrict__ X, float* __restrict__ Y, InterpDims q, int od, int oh, int ow,
+                                                             int oz, int oy, int ox, int64_t planes) {
+    const int64_t osz = (int64_t)od * oh * ow, isz = (int64_t)q.d * q.h * q.w, total = planes * osz;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pl = idx / osz; const int64_t r = idx - pl * osz;
+        const int x = (int)(r % ow) + ox, y = (int)((r / ow) % oh) + oy, z = (int)(r / ((int64_t)ow * oh)) + oz;
+        float v = 0.f;
+        if ((unsigned)z < (unsigned)q.D && (unsigned)y < (unsigned)q.H && (unsigned)x < (unsigned)q.W) v = interp_at(X + pl * isz, q, z, y, x);
+        Y[idx] = v;
+    }
+}
+
 extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                                       void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
@@ -370,6 +386,18 @@ extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, f
     else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
                             make_fastdiv((int)per), scale, outer);
     return check_launch("segx_interp_linear_fwd_axis");
+}
+/* RandomResizedCrop (reference dataloaders/datasets3d.py:611-665): resample [planes, d, h, w] to (D, H, W) (trilinear, align_corners=False), zero-pad,
+ * crop (od, oh, ow) at offset (oz, oy, ox) of the resampled grid (crop start minus front pad), in one pass. geom (int32[12]) =
+ * {d, h, w, D, H, W, od, oh, ow, oz, oy, ox} */
+extern "C" int segx_resized_crop3d(const float* X, float* Y, int64_t planes, const int* geom, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Y && geom && planes > 0, "segx_resized_crop3d: bad args");
+    for (int i = 0; i < 9; ++i) SEGX_REQUIRE(geom[i] > 0, "segx_resized_crop3d: geom[%d] = %d", i, geom[i]);
+    SEGX_REQUIRE((int64_t)geom[0] * geom[1] * geom[2] < 2147483647LL, "segx_resized_crop3d: plane too large");
+    const int64_t total = planes * geom[6] * geom[7] * geom[8];
+    hipLaunchKernelGGL(resized_crop3d_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, X, Y,
+                       make_dims(geom[0], geom[1], geom[2], geom[3], geom[4], geom[5]), geom[6], geom[7], geom[8], geom[9], geom[10], geom[11], planes);
+    return check_launch("segx_resized_crop3d");
 }
 extern "C" int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_bwd: bad args");

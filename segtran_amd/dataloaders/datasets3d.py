@@ -1,6 +1,33 @@
-"""On-device label map of the 3D train step (mirror of reference code/dataloaders/datasets3d.py:16-40).
+"""On-device label map and augmentation of the 3D train step (mirror of reference code/dataloaders/datasets3d.py:16-40, 611-665).
 The reference hard-codes device='cuda' (N8); here the label's own device is used."""
 import torch
+
+
+def RandomResizedCrop(volume, mask, out_size, crop_percents, isotropic=True):
+    """reference datasets3d.py:611-665 (train3d.py:713-715, --randscale): random isotropic rescale of the batch by a factor in
+    [1 + crop_percents[0], 1 + crop_percents[1]] (trilinear, the n-hot mask is resampled too and STAYS continuous, :661-662),
+    zero padding back up to `out_size` where the rescaled volume is smaller, then a random crop of `out_size`.
+    volume [B, C, H, W, D], mask [B, K, H, W, D] (float n-hot) -> ([B, C, *out_size], [B, K, *out_size]).
+
+    Random numbers: the SAME draws in the same order from torch's CPU generator as the reference (`torch.rand(1)` per scale,
+    three `torch.randint`), so a seeded run crops where the reference crops.  Arithmetic: one libsegx gather pass per tensor
+    (segx_resized_crop3d) that computes only the cropped window; the reference's resampled and padded intermediates never exist."""
+    from .. import functional as SF
+    H, W, D = (int(v) for v in volume.shape[-3:])
+    min_scale, max_scale = 1 + crop_percents[0], 1 + crop_percents[1]
+    scale_H = torch.rand(1) * (max_scale - min_scale) + min_scale
+    if isotropic:
+        scale_W = scale_D = scale_H
+    else:
+        scale_W = torch.rand(1) * (max_scale - min_scale) + min_scale
+        scale_D = torch.rand(1) * (max_scale - min_scale) + min_scale
+    H2, W2, D2 = int(H * scale_H), int(W * scale_W), int(D * scale_D)          # float32 tensor arithmetic, truncated: as the reference
+    Ho, Wo, Do = (int(v) for v in out_size)
+    pads = [max(o - n, 0) // 2 for o, n in ((Ho, H2), (Wo, W2), (Do, D2))]      # front pads (:637-645)
+    Hp, Wp, Dp = max(H2, Ho), max(W2, Wo), max(D2, Do)                          # padded extents
+    starts = [int(torch.randint(Hp - Ho + 1, (1,))), int(torch.randint(Wp - Wo + 1, (1,))), int(torch.randint(Dp - Do + 1, (1,)))]
+    offs = [s - p for s, p in zip(starts, pads)]
+    return (SF.resized_crop3d(volume, (H2, W2, D2), (Ho, Wo, Do), offs), SF.resized_crop3d(mask, (H2, W2, D2), (Ho, Wo, Do), offs))
 
 
 def brats_map_label(mask, binarize=False):

@@ -92,13 +92,14 @@ def synth_batch(cfg, B, device, seed=1337):
     return x.to(device), lab.to(device)
 
 
-def map_mask(task, raw):
+def map_mask(task, raw, exclusive=False):
     """In-step label -> n-hot map.  On the GPU this is libsegx's label kernel; the torch expressions in
-    segtran_amd/dataloaders (same semantics, used by CPU-side tooling) are the readable statement of it."""
+    segtran_amd/dataloaders (same semantics, used by CPU-side tooling) are the readable statement of it.
+    exclusive: train2d.py --exclusive (fundus only, datasets2d.py:110-111)."""
     if raw.is_cuda:
-        return SF.label_nhot(raw, task)
+        return SF.label_nhot(raw, task, exclusive)
     if task == 'fundus':
-        return fundus_map_mask(raw)
+        return fundus_map_mask(raw, exclusive)
     if task == 'polyp':
         return polyp_map_mask(raw)
     return brats_map_label(raw, False)
@@ -107,8 +108,12 @@ def map_mask(task, raw):
 class TrainStep:
     """One data-parallel train step (train2d.py:1147-1337 / train3d.py:708-768 for --net segtran)."""
 
-    def __init__(self, net, optimizer, task, reducer=None):
+    def __init__(self, net, optimizer, task, reducer=None, dice_w=0.5, exclusive=False, augment=None):
+        """dice_w: args.MAX_DICE_W (train2d.py:1223 / train3d.py:735, --diceweight); exclusive: --exclusive fundus masks;
+        augment: optional callable (x, nhot_mask) -> (x, nhot_mask) applied on the device before the forward pass
+        (train3d.py:713-715 RandomResizedCrop under --randscale)."""
         self.net, self.opt, self.task, self.reducer = net, optimizer, task, reducer
+        self.dice_w, self.exclusive, self.augment = float(dice_w), bool(exclusive), augment
         if reducer is None and hasattr(optimizer, 'release_flat_grads') and optimizer.step_count == 0:
             optimizer.release_flat_grads()          # single process: no flat bucket needed, no per-parameter accumulate kernels
         dev = next(net.parameters()).device
@@ -116,11 +121,13 @@ class TrainStep:
         self.stats = None
 
     def __call__(self, x, raw_mask):
-        mask = map_mask(self.task, raw_mask)
+        mask = map_mask(self.task, raw_mask, self.exclusive)
+        if self.augment is not None:
+            x, mask = self.augment(x, mask)
         out = self.net(x)
         if out.shape[2:] != mask.shape[2:]:
             out = SF.interp_linear(out, mask.shape[2:])          # train2d.py:1219 / train3d.py:731
-        loss, self.stats = SF.seg_loss(out, mask, self.pos_weight, self.class_w, 0.5)
+        loss, self.stats = SF.seg_loss(out, mask, self.pos_weight, self.class_w, self.dice_w)
         self.opt.zero_grad()
         loss.backward()
         if self.reducer is not None:

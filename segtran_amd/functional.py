@@ -1056,10 +1056,13 @@ def nonzero_mask(x, pool):
     return out if x.dim() == 5 else out[:, 0]
 
 
-def label_nhot(labels, mode):
-    """mode 'fundus' | 'polyp' (uint8 [B,Cin,*S]) | 'brats' (integer [B,*S]) -> float n-hot [B,C,*S]."""
+def label_nhot(labels, mode, exclusive=False):
+    """mode 'fundus' | 'polyp' (uint8 [B,Cin,*S]) | 'brats' (integer [B,*S]) -> float n-hot [B,C,*S].
+    exclusive (fundus only, train2d.py --exclusive): the disc channel excludes the cup (datasets2d.py:110-111)."""
     L = segx.lib()
     m = {'fundus': 0, 'polyp': 1, 'brats': 2}[mode]
+    if m == 0 and exclusive:
+        m = 3
     if m == 2:
         lab = _c(labels.to(torch.int32))
         B, S = lab.shape[0], lab[0].numel()
@@ -1068,9 +1071,20 @@ def label_nhot(labels, mode):
     else:
         lab = _c(labels.to(torch.uint8))
         B, Cin, S = lab.shape[0], lab.shape[1], lab[0, 0].numel()
-        out = torch.empty((B, 3 if m == 0 else 2) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
+        out = torch.empty((B, 2 if m == 1 else 3) + tuple(lab.shape[2:]), dtype=torch.float32, device=lab.device)
         L.label_nhot(lab, out, B, Cin, S, m)
     return out
+
+
+def resized_crop3d(x, resized, out_size, offset):
+    """[B, C, d, h, w] --(trilinear resample to `resized`, zero pad, crop `out_size` at `offset` = crop start - front pad)--> [B, C, *out_size].
+    Data augmentation (no gradient): the fused form of F.interpolate + F.pad + slicing in reference datasets3d.py:611-665."""
+    L = segx.lib()
+    x = _c(x.detach().float())
+    B, C = x.shape[:2]
+    y = _empty(x, B, C, *out_size)
+    L.resized_crop3d(x, y, B * C, tuple(x.shape[2:]) + tuple(resized) + tuple(out_size) + tuple(offset))
+    return y
 
 
 # -------------------------------------------------------------------------------------------------

@@ -164,10 +164,70 @@ class BertAdam(Optimizer):
             sizes=i64([n for _, n in self.slices]), chunk_tensor=i32(chunk_tensor), chunk_off=i64(chunk_off),
             chunk_first=i32(chunk_first), active=i32([1 if id(p) in self._touched else 0 for p, _ in ps]),
             lr=f32([g['lr'] for _, g in ps]), wd=f32([g['weight_decay'] for _, g in ps]))
+        self._lrwd_host = self._lrwd_key()
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:          # one schedule / one set of Adam constants per step launch
+            for k in ('schedule', 'warmup', 't_total', 'b1', 'b2', 'e', 'max_grad_norm'):
+                if g[k] != g0[k]:
+                    raise ValueError("BertAdam (libsegx multi-tensor step): param groups must share '%s' (%r vs %r); only lr and "
+                                     "weight_decay may differ between groups" % (k, g[k], g0[k]))
         self._nt, self._nch = len(ps), len(chunk_tensor)
         self._chunk_first_host = chunk_first
         self._ws = torch.zeros(self._nch + 2 * self._nt + 2, dtype=torch.float32, device=dev)
         self._active_names = None
+
+    def _lrwd_key(self):
+        return tuple((float(g['lr']), float(g['weight_decay'])) for g in self.param_groups)
+
+    def _sync_lr_wd(self):
+        """param_groups[i]['lr' | 'weight_decay'] edited after the first step (LR schedulers, manual decay): refresh the per-tensor device
+        tables the kernel reads, so that get_lr() and the update cannot diverge."""
+        key = self._lrwd_key()
+        if key != self._lrwd_host:
+            ps = self._all_params()
+            dev = self.flat_m.device
+            self._tabs['lr'].copy_(torch.tensor([g['lr'] for _, g in ps], dtype=torch.float32, device='cpu').to(dev))
+            self._tabs['wd'].copy_(torch.tensor([g['weight_decay'] for _, g in ps], dtype=torch.float32, device='cpu').to(dev))
+            self._lrwd_host = key
+
+    # ---- checkpointing: the reference's per-parameter layout (state[p] = {'step', 'next_m', 'next_v'}, optimization.py:108-114) ------
+    def state_dict(self):
+        """Same wire format as the reference BertAdam (torch.optim state_dict with 'step' / 'next_m' / 'next_v' per parameter), built from
+        the flat moment buffers; parameters that never received a gradient carry no state, as in the reference (N3)."""
+        ps = self._all_params()
+        active = self._active if self._tabs is not None else [True] * len(ps)
+        self.state.clear()
+        if self.step_count > 0:
+            for (p, _), (off, n), a in zip(ps, self.slices, active):
+                if a:
+                    self.state[p] = dict(step=self.step_count, next_m=self.flat_m[off:off + n].view_as(p).clone(),
+                                         next_v=self.flat_v[off:off + n].view_as(p).clone())
+        sd = super().state_dict()
+        self.state.clear()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        """Accepts what state_dict() writes and what the reference's BertAdam writes ('optim_state' of a reference checkpoint,
+        train2d.py:629-635): moments go into the flat buffers, the step count (= position on the warm-up / decay schedule) is restored."""
+        super().load_state_dict(state_dict)
+        ps = self._all_params()
+        steps = []
+        with torch.no_grad():
+            for (p, _), (off, n) in zip(ps, self.slices):
+                st = self.state.get(p)
+                if not st:
+                    continue
+                self.flat_m[off:off + n].copy_(st['next_m'].reshape(-1))
+                self.flat_v[off:off + n].copy_(st['next_v'].reshape(-1))
+                steps.append(int(st['step']))
+        self.state.clear()
+        if steps:
+            if min(steps) != max(steps):
+                raise ValueError('BertAdam.load_state_dict: parameters carry different step counts (%d..%d); the multi-tensor step keeps one '
+                                 'schedule position' % (min(steps), max(steps)))
+            self.step_count = steps[0]
+        if self._tabs is not None:
+            self._lrwd_host = None                         # param_groups were replaced: refresh the device tables at the next step
 
     def get_lr(self):
         g = self.param_groups[0]
@@ -186,6 +246,7 @@ class BertAdam(Optimizer):
         self._ensure_tables()
         if self._private:
             self._refresh_grad_table()
+        self._sync_lr_wd()
         g = self.param_groups[0]
         sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
         clip = self.global_grad_clip if global_grad_clip is None else global_grad_clip

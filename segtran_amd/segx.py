@@ -289,6 +289,10 @@ class SegxLib:
     def interp_fwd_axis(self, inp, base, out, outer, n_in, n_out, inner, src_scale=0.0):
         self._call('segx_interp_linear_fwd_axis', inp, inp, base, out, outer, n_in, n_out, inner, float(src_scale))
 
+    def resized_crop3d(self, X, Y, planes, geom):
+        self._chk_t(X, Y)
+        self.check(self.c.segx_resized_crop3d(_ptr(X), _ptr(Y), planes, self._geom(geom), self.stream(Y)), 'segx_resized_crop3d')
+
     def interp_bwd(self, dout, din, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_bwd', dout, dout, din, planes, d, h, w, D, H, W)
 
@@ -430,7 +434,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
-    'segx_tune': 'ii', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_resized_crop3d': 'pplpp', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

@@ -14,6 +14,8 @@ def main(argv=None):
     p.add_argument('--patch', dest='patch_size', type=str, default=None)
     p.add_argument('--exclusive', dest='use_exclusive_masks', action='store_true')
     args = tc.finalize_args(p.parse_args(argv), 2)
+    if args.use_exclusive_masks and args.task_name != 'fundus':
+        raise SystemExit('--exclusive only changes the fundus label map (datasets2d.py:110-111)')
     if args.task_name not in NUM_CLASSES:
         raise SystemExit("--task %s: only 'fundus' and 'polyp' are wired (BASELINE configs)" % args.task_name)
     if args.backbone_type != 'eff-b4' and not args.backbone_type.startswith('eff-b'):

@@ -68,6 +68,9 @@ def common_flags(p, dim):
     p.add_argument('--nofeatup', dest='bb_feat_upsize', action='store_false')
     p.add_argument('--tunebn', dest='tune_bn_only', action='store_true', help='only refresh the BatchNorm statistics of the first backbone stages')
     p.add_argument('--logiter', type=int, default=50, help='host-side logging period (each log line synchronises the device)')
+    p.add_argument('--synthweights', dest='synth_weights', action='store_true',
+                   help='(not a reference flag) start from the name-hashed synthetic weights of segtran_amd/synth.py -- what bench.py and the '
+                        'parity fixtures use -- instead of the pretrained backbone (default) or the random initialisation (--nopretrain)')
     return p
 
 
@@ -127,16 +130,71 @@ def save_model(net, args, ckpt_dir, iter_num):
     return path
 
 
-def load_model(net, args, path):
-    """Tolerant partial load as train2d.py:567-638 (drops attn_scaler keys, keeps matching shapes)."""
+# checkpoint arguments that may differ from the command line (train2d.py:584-600 / train3d.py:372-387, merged)
+IGNORED_CP_ARGS = {'maxiter', 'checkpoint_path', 'model_input_size', 't_total', 'num_workers', 'lr_warmup_ratio', 'lr_warmup_steps', 'local_rank',
+                   'distributed', 'world_size', 'saveiter', 'dice_warmup_steps', 'opt', 'lr', 'decay', 'initializer_range',
+                   'base_initializer_range', 'grad_clip', 'localization_prob', 'tune_bn_only', 'MAX_DICE_W', 'deterministic', 'lr_schedule',
+                   'out_fpn_do_dropout', 'randscale', 'do_affine', 'focus_class', 'bce_weight', 'translayer_compress_ratios', 'seed', 'debug',
+                   'ds_name', 'batch_size', 'dropout_prob', 'patch_size', 'orig_input_size', 'output_upscale', 'use_pretrained', 'checkpoint_dir',
+                   'iters', 'out_origsize', 'out_softscores', 'verbose_output', 'gpu', 'test_interp', 'do_remove_frag', 'reload_mask', 'ds_split',
+                   'ds_names', 'train_ds_names', 'job_name', 'mean', 'std', 'mask_thres', 'sample_num', 'perturb_pew_range', 'pos_embed_every_layer',
+                   'pos_in_attn_only', 'attention_mode_dim', 'ablate_pos_embed_type', 'use_attn_consist_loss', 'ATTNCONSIST_W',
+                   'logiter', 'synth_weights'}            # the last two are flags of this mirror only
+WARN_CP_ARGS = {'num_recurrences'}
+
+
+def check_checkpoint_args(args, cp_args):
+    """train2d.py:602-609 / train3d.py:389-392: every architecture-relevant argument stored in the checkpoint must equal the command line's;
+    the reference prints the first inconsistent pair and exits -- here ALL of them are listed.  Keys the command line does not define
+    (a reference checkpoint carries its whole argparse namespace) are skipped: the reference would die on them with a KeyError."""
+    if cp_args is None:
+        return
+    have, bad = vars(args), []
+    for k, v in cp_args.items():
+        if k in IGNORED_CP_ARGS or k not in have:
+            continue
+        cur = have[k]
+        same = (list(cur) == list(v)) if isinstance(cur, (list, tuple)) and isinstance(v, (list, tuple)) else (cur == v)
+        if not same:
+            if k in WARN_CP_ARGS:
+                logging.warning('args[%s]=%s, checkpoint args[%s]=%s, inconsistent!', k, cur, k, v)
+            else:
+                bad.append('args[%s]=%s, checkpoint args[%s]=%s, inconsistent!' % (k, cur, k, v))
+    if bad:
+        raise SystemExit('\n'.join(bad))
+
+
+def load_model(net, args, path, optimizer=None, load_optim_state=False):
+    """train2d.py:567-638 / train3d.py:353-420: `{'iter_num', 'model', 'args'[, 'optim_state']}` or a bare state_dict; the checkpoint's
+    architecture arguments must agree with the command line (check_checkpoint_args); 'attn_scaler' entries are dropped (:611-623); the
+    checkpoint may miss keys but may not carry unknown ones or other shapes (`net.load_state_dict` raises, as in the reference).
+    Returns the checkpoint's iteration count."""
     ck = torch.load(path, map_location='cpu')
-    sd = ck.get('model', ck)
+    if isinstance(ck, dict) and 'model' in ck:
+        sd, cp_args, cp_iter, optim_state = ck['model'], ck.get('args'), int(ck.get('iter_num', 0)), ck.get('optim_state')
+    else:
+        sd, cp_args, cp_iter, optim_state = ck, None, 0, None
+    if isinstance(cp_args, argparse.Namespace):
+        cp_args = vars(cp_args)
+    if getattr(args, 'net', 'segtran') == 'segtran':
+        check_checkpoint_args(args, cp_args)
     own = net.state_dict()
-    keep = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape) and 'attn_scaler' not in k}
+    dropped = [k for k in sd if 'attn_scaler' in k]
+    keep = {k: v for k, v in sd.items() if 'attn_scaler' not in k and '.pos_coder.all_' not in k}   # all_*: the reference's index buffers (not built here)
+    unknown = sorted(k for k in keep if k not in own)
+    wrong = sorted('%s: checkpoint %s vs model %s' % (k, tuple(v.shape), tuple(own[k].shape)) for k, v in keep.items()
+                   if k in own and tuple(v.shape) != tuple(own[k].shape))
+    if unknown or wrong:
+        raise RuntimeError('checkpoint %s does not fit the model built from the command line:\n  unexpected keys: %s\n  shape mismatches: %s'
+                           % (path, unknown[:8], wrong[:8]))
     own.update(keep)
     net.load_state_dict(own)
-    logging.info('loaded %d/%d tensors from %s', len(keep), len(own), path)
-    return int(ck.get('iter_num', 0)) if isinstance(ck, dict) else 0
+    if load_optim_state and optimizer is not None and optim_state is not None and not dropped:      # :629-635
+        optimizer.load_state_dict(optim_state)
+        args.lr_warmup_steps = 0
+        logging.info('LR Warm up reset to 0 iters.')
+    logging.info("Model loaded from '%s' (%d/%d tensors)", path, len(keep), len(own))
+    return cp_iter
 
 
 def run(args, cfg, batches=None):
@@ -156,11 +214,25 @@ def run(args, cfg, batches=None):
     ckpt_dir = os.path.join('..', 'model', '%s-%s-%s' % (args.net, args.task_name, ts))
     logging.basicConfig(level=logging.INFO if is_master else logging.WARNING, format='[%(asctime)s] %(message)s', datefmt='%H:%M:%S')
 
-    net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=not args.checkpoint_path,
-                             **arch_overrides(args))
+    # Initial weights.  Reference: the pretrained backbone (default) or, with --nopretrain, the model's own random initialisation
+    # (SegtranInitWeights); a --cp checkpoint then overwrites everything.  The published backbone files cannot be fetched here (no
+    # network): without them the default fails loudly instead of training something else.  --synthweights (this mirror only) selects
+    # the name-hashed synthetic weights that bench.py and the parity fixtures use.
+    synth = bool(getattr(args, 'synth_weights', False)) and not args.checkpoint_path
+    pretrained = bool(args.use_pretrained) and not synth and not args.checkpoint_path
+    try:
+        net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=synth,
+                                 use_pretrained=pretrained, **arch_overrides(args))
+    except RuntimeError as e:
+        if 'pretrained' not in str(e):
+            raise
+        raise SystemExit('%s\n(use --nopretrain for a random initialisation, --synthweights for the synthetic benchmark weights, or --cp)' % e)
+    if synth:
+        logging.warning('--synthweights: training starts from SYNTHETIC name-hashed weights (segtran_amd/synth.py), not from a pretrained backbone')
     iter_num = load_model(net, args, args.checkpoint_path) if args.checkpoint_path else 0
     if dim_of(cfg) == 2:
-        iter_num = 0                                                      # train2d.py:1078-1081 always restarts the count
+        iter_num = 0                                                      # train2d.py:1074-1081 (`continue_iter = False`): 2-D always restarts the count
+    # 3-D resumes from the checkpoint's iteration (train3d.py:658-661): the LR schedule position (BertAdam's step count) follows it
     sdist.enable_sync_batchnorm()
     if getattr(args, 'tune_bn_only', False):
         if batches is None:
@@ -170,8 +242,16 @@ def run(args, cfg, batches=None):
     net.train()
     opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
                                 decay=args.decay, grad_clip=args.grad_clip)
+    if iter_num > 0:
+        opt.step_count = iter_num                 # the reference's schedule reads `iter_num / t_total` from the optimizer state it reloads
     reducer = sdist.GradReducer(opt) if world > 1 else None
-    step = engine.TrainStep(net, opt, args.task_name, reducer)
+    augment = None
+    if dim_of(cfg) == 3 and getattr(args, 'randscale', 0):              # train3d.py:524-527, 713-715
+        from .dataloaders.datasets3d import RandomResizedCrop
+        crop_percents, out_size = (-args.randscale, args.randscale), tuple(cfg['size'])
+        augment = lambda x, m: RandomResizedCrop(x, m, out_size, crop_percents)     # noqa: E731
+    step = engine.TrainStep(net, opt, args.task_name, reducer, dice_w=args.MAX_DICE_W,
+                            exclusive=getattr(args, 'use_exclusive_masks', False), augment=augment)
     if batches is None:
         fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
         batches = iter(lambda: fixed, None)

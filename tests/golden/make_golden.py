@@ -484,6 +484,23 @@ def case_seg3d():
             arrs['grad:' + k] = sample(gr)
         arrs['gscale'] = np.array(gscale)
         arrs['unused'] = np.array(sorted(k for k, p in rg.items() if p.grad is None))
+        # fp64 referee: the same reference modules in double precision.  Batch-1 train-mode BatchNorm over 49
+        # samples per channel amplifies fp32 summation-order noise; the referee says how far the fp32 CPU reference itself is from the
+        # exact result, which bounds what can be asked of any other fp32 implementation.
+        net64 = R.ref_segtran3d(num_attractors=A, num_translayers=tl, compress=comp, dropout_prob=0)
+        net64.load_state_dict(sd); net64 = net64.double(); _force_double_inputs(net64)
+        net64.train() if train else net64.eval()
+        y64 = R.quiet(net64, x.double())
+        l64 = O.seg_loss(y64, nhot.double(), pw.double())[0]; l64.backward()
+        rg64 = dict(net64.named_parameters())
+        arrs['logits64'] = sample(y64, 65536); arrs['loss64'] = l64.detach()
+        arrs['ref32_vs_64_logit_err'] = (y.double() - y64).abs().max().detach()
+        worst = 0.0
+        for k in GRAD_KEYS_3D:
+            arrs['grad64:' + k] = sample(rg64[k].grad)
+            worst = max(worst, (rg64[k].grad - rg[k].grad.double()).abs().max().item() / gscale)
+        arrs['ref32_vs_64_grad_err'] = np.array(worst)
+        print('    %s: fp32 reference vs fp64 referee: logits %.2e, gradients %.2e of gscale' % (tag, arrs['ref32_vs_64_logit_err'].item(), worst))
         save(tag, **arrs)
 
 
@@ -635,6 +652,204 @@ def case_fullsize():
     print('  wrote fullsize.json')
 
 
+FULL_GRAD_KEYS_2D = ['out_conv.weight', 'out_conv.bias', 'out_fpn_bridgeconv.weight', 'out_fpn12_conv.weight', 'out_fpn23_conv.weight', 'out_gn2b.weight',
+                     'out_gn3b.bias', 'in_fpn34_conv.weight', 'in_gn4b.weight',
+                     'voxel_fusion.pos_code_layer.pos_coder.pos_fc.weight', 'voxel_fusion.vfeat_norm_layers.0.weight', 'voxel_fusion.vfeat_norm_layers.2.bias',
+                     'voxel_fusion.translayers.0.attractors', 'voxel_fusion.translayers.0.in_ator_trans.query.weight',
+                     'voxel_fusion.translayers.0.in_ator_trans.query.bias',
+                     'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_linear.weight',
+                     'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_norm_layer.weight',
+                     'voxel_fusion.translayers.0.ator_out_trans.query.weight', 'voxel_fusion.translayers.0.ator_out_trans.query.bias',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.first_linear.weight',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.intermediate.shared_linear.weight',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.intermediate.shared_linear.bias',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.group_linear.weight',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.output.resout_norm_layer.weight',
+                     'voxel_fusion.translayers.0.ator_out_trans.out_trans.feat_softaggr.feat2score.weight',
+                     'voxel_fusion.translayers.1.attractors', 'voxel_fusion.translayers.1.ator_out_trans.query.weight',
+                     'voxel_fusion.translayers.1.ator_out_trans.out_trans.output.group_linear.weight',
+                     'voxel_fusion.translayers.2.in_ator_trans.query.weight',
+                     'voxel_fusion.translayers.2.ator_out_trans.out_trans.first_linear.weight',
+                     'voxel_fusion.translayers.2.ator_out_trans.out_trans.output.group_linear.weight',
+                     'backbone._conv_stem.weight', 'backbone._bn0.weight', 'backbone._blocks.0._depthwise_conv.weight',
+                     'backbone._blocks.2._expand_conv.weight', 'backbone._blocks.6._se_reduce.weight', 'backbone._blocks.10._bn1.bias',
+                     'backbone._blocks.22._project_conv.weight', 'backbone._blocks.31._depthwise_conv.weight', 'backbone._conv_head.weight']
+FULL_GRAD_KEYS_3D = GRAD_KEYS_3D + ['out_conv3d.bias', 'out_fpn23_conv3d.weight', 'out_gn3b.weight',
+                                    'voxel_fusion.vfeat_norm_layers.0.weight', 'voxel_fusion.translayers.0.in_ator_trans.query.weight',
+                                    'voxel_fusion.translayers.0.in_ator_trans.out_trans.first_linear.weight',
+                                    'voxel_fusion.translayers.0.ator_out_trans.out_trans.first_linear.weight',
+                                    'voxel_fusion.translayers.0.ator_out_trans.out_trans.intermediate.shared_linear.weight',
+                                    'voxel_fusion.translayers.0.ator_out_trans.out_trans.feat_softaggr.feat2score.weight',
+                                    'voxel_fusion.translayers.1.attractors',
+                                    'voxel_fusion.translayers.1.ator_out_trans.out_trans.output.group_linear.weight',
+                                    'backbone.Mixed_3c.b2b.conv3d.weight', 'backbone.Mixed_4b.b1a.conv3d.weight', 'backbone.Mixed_5b.b2b.bn.weight']
+NEAR0 = 1e-3          # reference logits with |y| < NEAR0 are stored (index + fp32 value + fp64 value): any label margin <= NEAR0 can be applied later
+
+
+def _force_double_inputs(net):
+    """fp64 referee runs: the reference creates a few fp32 tensors on the fly (`.float()` coordinates, scale factors); cast every
+    fp32 tensor argument of every sub-module to fp64 on entry (forward pre-hooks; the reference code itself is untouched)."""
+    def hook(mod, args):
+        return tuple(a.double() if isinstance(a, torch.Tensor) and a.dtype == torch.float32 else a for a in args)
+    for m in net.modules():
+        m.register_forward_pre_hook(hook)
+
+
+def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
+    """One BASELINE shape at batch 1: (a) eval forward -> packed label bits of EVERY logit + the near-zero logits, (b) one
+    dropout-free train-mode step (batch statistics in every BatchNorm, drop_connect off) -> loss + sampled parameter gradients,
+    both from the real reference in fp32, plus the same two runs of the same reference modules in fp64 as referee."""
+    import time
+    t0 = time.time()
+    net = build(); sd = load_synth(net)
+    fwd_o = O.segtran2d_forward if dim == 2 else O.segtran3d_forward
+    net.eval()
+    with torch.no_grad():
+        y = R.quiet(net, x)
+        yo = fwd_o(sd, x, dims)
+    close(yo, y, 5e-5, tag + ' eval logits (oracle)')
+    arrs = dict(shape=np.array(y.shape), absmax=y.abs().max(), logits=sample(y, 65536), labels=np.packbits((y > 0).numpy().reshape(-1)))
+    flat = y.reshape(-1)
+    near = torch.nonzero(flat.abs() < NEAR0).reshape(-1)
+    arrs['near_idx'] = near.to(torch.int32); arrs['near_val'] = flat[near]
+    print('    %s eval fwd done %.0fs, %d logits with |y| < %g, min |y| %.2e' % (tag, time.time() - t0, near.numel(), NEAR0, flat.abs().min().item()))
+    # train step
+    net.train()
+    if dim == 2:
+        net.backbone._global_params = net.backbone._global_params._replace(drop_connect_rate=0.0)
+    yt = R.quiet(net, x)
+    loss = O.seg_loss(yt, nhot, pw)[0]; loss.backward()
+    rg = dict(net.named_parameters())
+    gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
+    arrs.update(train_logits=sample(yt, 65536), loss=loss.detach(), gscale=np.array(gscale))
+    keys = [k for k in grad_keys if k in rg and rg[k].grad is not None]
+    for k in keys:
+        arrs['grad:' + k] = sample(rg[k].grad)
+    arrs['unused'] = np.array(sorted(k for k, p in rg.items() if p.grad is None))
+    print('    %s train step done %.0fs (loss %.5f, gscale %.3e, %d gradients stored)' % (tag, time.time() - t0, loss.item(), gscale, len(keys)))
+    save(tag, **arrs)                 # the fp32 part is complete: keep it even if the (slow) referee below is interrupted
+    if referee64:
+        # the SAME reference modules in double precision: tells which side is off when fp32 results disagree
+        net64 = build(); net64.load_state_dict(sd); net64 = net64.double()
+        _force_double_inputs(net64)
+        if dim == 2:
+            net64.backbone._global_params = net64.backbone._global_params._replace(drop_connect_rate=0.0)
+        net64.eval()
+        with torch.no_grad():
+            y64 = R.quiet(net64, x.double())
+        f64 = y64.reshape(-1)
+        arrs['near_val64'] = f64[near]
+        arrs['logits64'] = sample(y64, 65536)
+        arrs['ref32_vs_64_logit_err'] = (y.double() - y64).abs().max()
+        arrs['ref32_label_flips_vs_64'] = np.array(int(((y > 0) != (y64 > 0)).sum()))
+        net64.train()
+        yt64 = R.quiet(net64, x.double())
+        l64 = O.seg_loss(yt64, nhot.double(), pw.double())[0]; l64.backward()
+        rg64 = dict(net64.named_parameters())
+        arrs['loss64'] = l64.detach(); arrs['train_logits64'] = sample(yt64, 65536)
+        worst = 0.0
+        for k in keys:
+            arrs['grad64:' + k] = sample(rg64[k].grad)
+            worst = max(worst, (rg64[k].grad - rg[k].grad.double()).abs().max().item() / gscale)
+        arrs['ref32_vs_64_grad_err'] = np.array(worst)
+        print('    %s fp64 referee done %.0fs: fp32 reference vs fp64: logits %.2e, %d label flips, gradients %.2e of gscale'
+              % (tag, time.time() - t0, arrs['ref32_vs_64_logit_err'].item(), int(arrs['ref32_label_flips_vs_64']), worst))
+    save(tag, **arrs)
+
+
+def case_fullshape():
+    """BASELINE.json shapes at batch 1: label bits of the whole map, full-size gradients, fp64 referee.
+    Sub-cases: full_cfg2 full_cfg3 full_cfg4 full_cfg5 (python make_golden.py fullshape full_cfg4 ...)."""
+    want = [a for a in sys.argv[2:] if a.startswith('full_')] or ['full_cfg2', 'full_cfg3', 'full_cfg4', 'full_cfg5']
+    for tag in want:
+        if tag in ('full_cfg2', 'full_cfg3'):
+            S, task = (512, 'fundus') if tag == 'full_cfg2' else (352, 'polyp')
+            x = synth_image2d(1, S, 1337)
+            mask = synth_fundus_mask(1, S, 1338)
+            if task == 'polyp':
+                mask = mask[:, :1].repeat(1, 3, 1, 1)
+                nhot, pw = O.polyp_map_mask(mask), O.bce_pos_weight([0., 1.])
+            else:
+                nhot, pw = O.fundus_map_mask(mask), O.bce_pos_weight([0., 1., 2.])
+            nc = 3 if task == 'fundus' else 2
+            _full_one(tag, 2, lambda: R.ref_segtran2d(num_classes=nc, dropout_prob=0), x, nhot.float(), pw, [1792, 1792, 896, 448], FULL_GRAD_KEYS_2D)
+        else:
+            size, tl = ((112, 112, 96), 1) if tag == 'full_cfg4' else ((128, 128, 128), 2)
+            x, lab = synth_brats(1, *size, 1337)
+            nhot, pw = O.brats_map_label(lab), O.bce_pos_weight([0., 3., 1., 1.75])
+            _full_one(tag, 3, lambda: R.ref_segtran3d(num_translayers=tl, compress=(1,) * (tl + 1), dropout_prob=0), x, nhot.float(), pw,
+                      [1024] * (tl + 1), FULL_GRAD_KEYS_3D)
+
+
+def case_augment():
+    """In-step label maps (all three tasks, fundus with and without --exclusive) and the 3-D RandomResizedCrop (--randscale), produced by
+    the REFERENCE's own functions (datasets2d.py:90-139, 200-223; datasets3d.py:16-40, 611-665); the oracle restatements are asserted equal."""
+    f2 = _ref_functions('dataloaders/datasets2d.py', ['fundus_map_mask', 'polyp_map_mask'])
+    f3 = _ref_functions('dataloaders/datasets3d.py', ['brats_map_label', 'RandomResizedCrop'])
+    g = torch.Generator().manual_seed(31)
+    fm = synth_fundus_mask(2, 40, 77)
+    fm[:, 1] = torch.where(torch.rand(2, 40, 40, generator=g) < 0.1, torch.tensor(255, dtype=torch.uint8), fm[:, 1])   # cup pixels outside the disc too
+    lab = torch.randint(0, 4, (2, 6, 7, 5), generator=g)
+    arrs = dict(fundus_in=fm, brats_in=lab.to(torch.int8))
+    for ex in (False, True):
+        ref = f2['fundus_map_mask'](fm, ex).float()
+        assert torch.equal(O.fundus_map_mask(fm, ex), ref)
+        arrs['fundus_excl%d' % ex] = ref.to(torch.uint8)
+    ref = f2['polyp_map_mask'](fm[:, :1].repeat(1, 3, 1, 1)).float()
+    assert torch.equal(O.polyp_map_mask(fm[:, :1].repeat(1, 3, 1, 1)), ref)
+    arrs['polyp'] = ref.to(torch.uint8)
+    ref = f3['brats_map_label'](lab, False).float()
+    assert torch.equal(O.brats_map_label(lab), ref)
+    arrs['brats'] = ref.to(torch.uint8)
+    # RandomResizedCrop: seeds chosen below cover scale < 1 (pad) and scale > 1 (crop); the RNG is torch's global CPU generator
+    vol = torch.randn(1, 2, 14, 16, 10, generator=g)
+    mask = f3['brats_map_label'](torch.randint(0, 4, (1, 14, 16, 10), generator=g), False).float()
+    arrs.update(rrc_vol=vol, rrc_mask=mask.to(torch.uint8))
+    seen = set()
+    for i, seed in enumerate((3, 4, 11)):
+        for iso in (True, False):
+            torch.manual_seed(seed)
+            v3, m3 = f3['RandomResizedCrop'](vol, mask, (14, 16, 10), (-0.3, 0.3), iso)
+            torch.manual_seed(seed)
+            vo, mo = O.random_resized_crop(vol, mask, (14, 16, 10), (-0.3, 0.3), iso)
+            assert torch.equal(vo, v3) and torch.equal(mo, m3), 'oracle RandomResizedCrop differs from the reference'
+            torch.manual_seed(seed)
+            sc = float(torch.rand(1) * 0.6 + 0.7)
+            seen.add(sc > 1)
+            arrs['rrc_v_%d_%d' % (seed, iso)] = v3; arrs['rrc_m_%d_%d' % (seed, iso)] = m3
+    assert seen == {True, False}, 'seeds must cover both the padding and the cropping branch'
+    arrs['rrc_seeds'] = np.array([3, 4, 11])
+    save('augment', **arrs)
+
+
+def _tensor_digest(t):
+    f = t.detach().double().reshape(-1)
+    return np.concatenate([[f.sum().item(), (f * f).sum().item()], sample(t, 8).double().numpy()[:8], np.zeros(max(0, 8 - min(8, f.numel())))])[:10]
+
+
+def case_init():
+    """SegtranInitWeights.init_weights / tie_qk / add_identity_bias (segtran_shared.py:392-402, 522-546, 1241-1264) as the
+    model constructors apply them (segtran2d.py:210-213, segtran3d.py:246-249).  The random part is made comparable by re-running the
+    three passes on an already built model under a fixed seed: `Module.apply` visits the modules in registration order, which the
+    state_dict-order test pins, so the product's mirror must draw the same normal_() streams.  Stored: a digest (sum, sum of squares,
+    8 strided samples) of EVERY state_dict entry after the passes."""
+    out = {}
+    for tag, build in (('cfg2', lambda: R.ref_segtran2d(num_attractors=64)),
+                       ('cfg4', lambda: R.ref_segtran3d(num_attractors=64)),
+                       ('cfg1_nosq', lambda: R.ref_segtran2d(num_attractors=64, num_translayers=1, compress=(1, 1), use_squeezed_transformer=False))):
+        net = build(); load_synth(net)
+        torch.manual_seed(4242)
+        R.quiet(lambda: (net.apply(net.init_weights), net.apply(net.tie_qk), net.apply(net.add_identity_bias)))
+        sd = net.state_dict()
+        keys = [k for k in sd if '.pos_coder.all_' not in k and sd[k].is_floating_point()]
+        out[tag + '_keys'] = np.array(keys)
+        out[tag + '_digest'] = np.stack([_tensor_digest(sd[k]) for k in keys])
+        tl = net.voxel_fusion.translayers[0]
+        att = tl.ator_out_trans if hasattr(tl, 'ator_out_trans') else tl
+        assert att.key.weight is att.query.weight                                   # N2 after tie_qk
+    save('init', **out)
+
+
 def case_keys():
     """state_dict key -> shape lists (checkpoint wire format)."""
     n2 = R.ref_segtran2d()
@@ -653,7 +868,7 @@ def case_keys():
 
 CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
-             fullsize=case_fullsize)
+             fullsize=case_fullsize, fullshape=case_fullshape, augment=case_augment, init=case_init)
 
 if __name__ == '__main__':
     todo = [a for a in sys.argv[1:] if a in CASES] or list(CASES)        # further arguments select sub-cases (see case_seg3d)

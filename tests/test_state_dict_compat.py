@@ -63,3 +63,32 @@ def test_pretrained_backbone_ingest_from_local_files(tmp_path, monkeypatch):
     torch.save(bad, str(tmp_path / 'bad.pth'))
     with pytest.raises(AssertionError, match='Unexpected keys'):
         EfficientNet.from_pretrained('efficientnet-b4', weights_path=str(tmp_path / 'bad.pth'), stem_stride=1)
+
+
+@pytest.mark.parametrize('tag,cfg,over', [('cfg2', 'cfg2', {}), ('cfg4', 'cfg4', {}),
+                                          ('cfg1_nosq', 'cfg1', dict(use_squeezed_transformer=False))])
+def test_init_weights_tie_qk_identity_bias_match_reference(tag, cfg, over):
+    """the three initialisation passes of the model constructors (reference segtran_shared.py:392-402, 522-546,
+    1241-1264; segtran2d.py:210-213) against a digest of EVERY state_dict entry of the real reference after the same passes
+    (tests/golden/make_golden.py case_init): same normal_() streams in the same module order, query/key tied, identity bias on the
+    first mode of the tied key weight and of first_linear."""
+    import numpy as np
+    from util import golden
+    from segtran_amd.synth import load_synth, sample
+    g = golden('init')
+    net = engine.build_model(cfg, 'cpu', synth=False, attractors=64, **over)
+    load_synth(net)
+    torch.manual_seed(4242)
+    net.apply(net.init_weights); net.apply(net.tie_qk); net.apply(net.add_identity_bias)
+    sd = net.state_dict()
+    keys = [str(k) for k in g[tag + '_keys']]
+    assert keys == [k for k in sd if sd[k].is_floating_point()]
+    dig = g[tag + '_digest'].numpy() if hasattr(g[tag + '_digest'], 'numpy') else g[tag + '_digest']
+    for k, d in zip(keys, dig):
+        f = sd[k].detach().double().reshape(-1)
+        got = np.array([f.sum().item(), (f * f).sum().item()] + sample(sd[k], 8).double().tolist()[:8])
+        n = min(10, 2 + min(8, f.numel()))
+        assert np.allclose(got[:n], d[:n], rtol=1e-12, atol=1e-12), (k, got[:4], d[:4])
+    tl = net.voxel_fusion.translayers[0]
+    att = tl.ator_out_trans if hasattr(tl, 'ator_out_trans') else tl
+    assert att.key.weight is att.query.weight

@@ -81,3 +81,62 @@ def test_mt_gather_copies_gradients_into_their_flat_slices(backend):
     assert torch.equal(opt.flat_grad[off:off + n], srcs[2])
     off, n = opt.slices[3]
     assert (opt.flat_grad[off:off + n] == -7.0).all()
+
+
+def test_bertadam_state_dict_round_trip_continues_the_reference_trajectory(backend):
+    """moments and the schedule position live in flat buffers -- state_dict()/load_state_dict() must carry them, in the
+    reference's per-parameter layout (state[p] = {'step', 'next_m', 'next_v'}, optimization.py:108-114).  Two steps, checkpoint,
+    a NEW optimizer on cloned parameters, two more steps: still the golden trajectory of four uninterrupted reference steps."""
+    from segtran_amd.optimization import BertAdam
+    g = golden_on('bertadam', backend.dev)
+
+    def make(ps):
+        groups = [dict(params=[ps[0], ps[3]], weight_decay=1e-4, lr=2e-4), dict(params=[ps[1]], weight_decay=1e-5, lr=2e-4),
+                  dict(params=[ps[2]], weight_decay=0.0, lr=2e-4)]
+        return BertAdam(groups, lr=2e-4, warmup=0.25, t_total=8, weight_decay=1e-4, global_grad_clip=0.1)
+
+    def run(opt, ps, steps):
+        for step in steps:
+            opt.zero_grad()
+            sum((ps[i] * g['g%d_%d' % (step, i)]).sum() for i in range(3)).backward()
+            opt.step()
+
+    ps = [torch.nn.Parameter(g['p0_%d' % i].clone()) for i in range(4)]
+    opt = make(ps)
+    opt.release_flat_grads()
+    run(opt, ps, (0, 1))
+    sd = opt.state_dict()
+    st = sd['state']
+    assert sorted(st) == [0, 2, 3], 'the gradient-less parameter (index 1 = params[3]) carries no state (N3)'
+    assert set(st[0]) == {'step', 'next_m', 'next_v'} and st[0]['step'] == 2 and st[0]['next_m'].shape == ps[0].shape
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = make(ps2)
+    opt2.release_flat_grads()
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 2 and opt2.get_lr() == opt.get_lr()
+    run(opt2, ps2, (2, 3))
+    for i in range(4):
+        assert torch.allclose(ps2[i].data, g['p4_%d' % i], atol=2e-7), i
+
+
+def test_bertadam_follows_param_group_edits_and_rejects_mixed_schedules(backend):
+    from segtran_amd.optimization import BertAdam
+    dev = backend.dev
+    w = torch.nn.Parameter(torch.ones(8, device=dev))
+    opt = BertAdam([dict(params=[w], weight_decay=0.0, lr=1e-2)], lr=1e-2, warmup=-1, t_total=-1, max_grad_norm=-1)
+    opt.release_flat_grads()
+
+    def one():
+        opt.zero_grad(); (w * 1.0).sum().backward(); before = w.detach().clone(); opt.step(); return (before - w.detach()).abs().max().item()
+    d1 = one()
+    opt.param_groups[0]['lr'] = 1e-3                        # an LR scheduler / manual decay edits the group AFTER the tables were built
+    d2 = one()
+    # constant gradient 1, no bias correction: m/sqrt(v) = 0.1/sqrt(0.001) at step 1 and 0.19/sqrt(0.001999) at step 2; the step scales with lr
+    want = 0.1 * (0.19 / 0.001999 ** 0.5) / (0.1 / 0.001 ** 0.5)
+    assert d1 > 0 and abs(d2 / d1 - want) < 1e-3, (d1, d2, want)
+    a, b = torch.nn.Parameter(torch.ones(4, device=dev)), torch.nn.Parameter(torch.ones(4, device=dev))
+    bad = BertAdam([dict(params=[a], lr=1e-3), dict(params=[b], lr=1e-3, b1=0.5)], lr=1e-3, warmup=-1, t_total=-1)
+    bad.release_flat_grads()
+    bad.zero_grad(); (a.sum() + b.sum()).backward()
+    with pytest.raises(ValueError, match="share 'b1'"):
+        bad.step()
