@@ -33,6 +33,10 @@ int segx_last_error(char* buf, int buflen);
  * ------------------------------------------------------------------------------------------- */
 enum { SEGX_EPI_NONE = 0, SEGX_EPI_GELU = 1 /* aux = pre-activation, C = dropout(gelu(.)), :244-245 */ };
 enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bias[m] */ };
+/* tile engines (segx_tune knob 4): SEGX_ENGINE_F32 = v_mfma_f32_32x32x2_f32 on fp32 operands (bit-for-bit a k-ordered fmaf chain);
+ * SEGX_ENGINE_BF16X6 = fp32 operands split in registers into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per block (fp32-equivalent:
+ * error vs fp64 1.2e-6 against 1.0e-6), used for float4-legal operands with more than 48 rows on both sides; everything else stays on F32 */
+enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5 };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
@@ -240,7 +244,8 @@ int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* 
 int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
- * knob 3 = tile of the EXPERIMENTAL bf16x6 GEMM (1 = 128 x 128 x 32, 2 = 128 x 256 x 16) */
+ * knob 3 = tile of the EXPERIMENTAL pre-split bf16x6 GEMM (1 = 128 x 128 x 32, 2 = 128 x 256 x 16); knob 4 = tile engine of segx_gemm_f32 and the
+ * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4 */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);

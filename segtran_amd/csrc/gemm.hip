@@ -18,7 +18,7 @@
 //   row-contiguous operand -> float4 along rows, float4 LDS stores.
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
-#include "gemm_core.h"
+#include "gemm_x6.h"
 
 namespace segx {
 
@@ -30,6 +30,19 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const DenseLoader<BKC, VEC, Cfg::BN> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<EPI, Cfg>(acc, g, t);
+}
+
+// The same GEMM on the bf16x6 engine (gemm_x6.h): fp32 operands split into three bf16 planes on their way into LDS, six bf16 MFMAs per
+// block and 16 k.  WPE = resident waves per SIMD the register allocation must allow (LDS: 48 / 36 / 24 KB per workgroup).
+template <class Cfg, bool AKC, bool BKC, int EPI, int WPE>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void gemm_x6_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES];
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader6<AKC, Cfg::BM> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
+    const DenseLoader6<BKC, Cfg::BN> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<EPI, Cfg>(acc, g, t);
 }
 
@@ -62,6 +75,20 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Whole-GEMM quantisation matters (784 workgroups on 768 slots take two rounds, not 1.02), and so do padded edge tiles, which
 // the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
+int g_engine = SEGX_ENGINE_F32;            // segx_tune(4, v): which tile engine the eligible GEMMs / convolutions run on
+// bf16x6 engine: float4-legal operands, neither side skinny (those GEMMs are HBM-bound and stream through the 32-row fp32 tiles)
+static bool x6_eligible(int M, int N, bool vec) { return g_engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
+static void plan6(int M, int N, int K, int nbatch, bool gelu, bool may_split, int splitk_fixed, int* tile, int* splitk) {
+    double best_t = -1.0;
+    for (const TileInfo6& c6 : kTiles6) {
+        if (gelu && c6.id != SEGX_TILE_128x128) continue;                  // the fused GELU epilogue is built for the default tile
+        const TileInfo c{c6.id, c6.bm, c6.bn, c6.wg_per_cu, c6.ktile_us, c6.fixed_us};
+        double t; int sk;
+        if (splitk_fixed > 0 || !may_split) { sk = splitk_fixed > 0 ? splitk_fixed : 1; t = model_us(c, M, N, K, nbatch, sk); }
+        else sk = best_splitk(c, M, N, K, nbatch, &t);
+        if (best_t < 0.0 || t < best_t * 0.97) { best_t = t; *tile = c.id; *splitk = sk; }
+    }
+}
 static void plan(int M, int N, int K, int nbatch, bool vec, bool may_split, int splitk_fixed, int* tile, int* splitk) {
     const TileInfo* cand[3]; int nc = 0;
     if (!vec) cand[nc++] = &kTiles[0];
@@ -92,7 +119,9 @@ extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_de
     SEGX_REQUIRE(A && B && d && tile && splitk && d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_plan: bad args");
     const bool plain = d->epilogue == SEGX_EPI_NONE;
     int t = SEGX_TILE_128x128, sk = 1;
-    plan(d->M, d->N, d->K, d->nb0 * d->nb1, gemm_vec_ok(A, B, d) && plain, plain && !d->gmax, 0, &t, &sk);
+    const bool vec = gemm_vec_ok(A, B, d);
+    if (x6_eligible(d->M, d->N, vec) && (plain || d->a_k == 1)) plan6(d->M, d->N, d->K, d->nb0 * d->nb1, !plain, plain && !d->gmax, 0, &t, &sk);
+    else plan(d->M, d->N, d->K, d->nb0 * d->nb1, vec && plain, plain && !d->gmax, 0, &t, &sk);
     *tile = t; *splitk = sk;
     return 0;
 }
@@ -132,10 +161,39 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     if (splitk > 1) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_64x128, "segx_gemm_f32: bad tile %d", d->tile);
     int tile = d->tile;
-    if (tile == SEGX_TILE_AUTO) { int sk_unused = 1; plan(d->M, d->N, d->K, nbatch, vec && d->epilogue == SEGX_EPI_NONE, false, splitk, &tile, &sk_unused); }
-    if (!vec || d->epilogue != SEGX_EPI_NONE) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
+    const bool gelu = d->epilogue == SEGX_EPI_GELU;
+    bool x6 = x6_eligible(d->M, d->N, vec) && (!gelu || akc) &&
+              (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64);
+    if (tile == SEGX_TILE_AUTO) {
+        int sk_unused = 1;
+        if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, &tile, &sk_unused);
+        else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
+    }
+    if (!vec || gelu) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
 
     dim3 block(256);
+    using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
+    using Cfg64x128 = TileCfg<2, 2, 1, 2>;
+    if (x6) {
+#define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        hipLaunchKernelGGL((gemm_x6_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+    } while (0)
+#define SEGX_LAUNCH6_LAYOUT(CFG, W)                                          \
+    do {                                                                     \
+        if (akc && bkc) SEGX_LAUNCH6(CFG, true, true, SEGX_EPI_NONE, W);      \
+        else if (akc && !bkc) SEGX_LAUNCH6(CFG, true, false, SEGX_EPI_NONE, W); \
+        else if (!akc && bkc) SEGX_LAUNCH6(CFG, false, true, SEGX_EPI_NONE, W); \
+        else SEGX_LAUNCH6(CFG, false, false, SEGX_EPI_NONE, W);               \
+    } while (0)
+        if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
+        else if (tile == SEGX_TILE_64x64) SEGX_LAUNCH6_LAYOUT(Cfg64, 5);
+        else if (tile == SEGX_TILE_64x128) SEGX_LAUNCH6_LAYOUT(Cfg64x128, 4);
+        else SEGX_LAUNCH6_LAYOUT(Cfg128, 3);
+#undef SEGX_LAUNCH6
+#undef SEGX_LAUNCH6_LAYOUT
+    } else
 #define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
@@ -148,8 +206,6 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else if (!akc && bkc) SEGX_LAUNCH(CFG, false, true, V, E);      \
         else SEGX_LAUNCH(CFG, false, false, V, E);                      \
     } while (0)
-    using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
-    using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (d->epilogue == SEGX_EPI_GELU) {
         SEGX_REQUIRE(akc, "segx_gemm_f32: the GELU epilogue is built for a k-contiguous A operand (nn.Linear, attention fusion)");
         if (bkc) { if (vec) SEGX_LAUNCH(Cfg128, true, true, true, SEGX_EPI_GELU); else SEGX_LAUNCH(Cfg128, true, true, false, SEGX_EPI_GELU); }

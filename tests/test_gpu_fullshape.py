@@ -1,0 +1,102 @@
+"""GPU (-m gpu): parity at the BASELINE.json SHAPES (batch 1) against fixtures produced by the real reference on the CPU
+(tests/golden/make_golden.py case_fullshape): cfg2 512 x 512, cfg3 352 x 352, cfg4 112 x 112 x 96, cfg5 128^3 (two layers, 1024 attractors).
+
+  * eval forward: every hardened label of the WHOLE map is compared (the fixture stores the packed bits of all logits); a mismatch is
+    tolerated only where the reference's own |logit| < 1e-5 -- those positions (index + value) are stored in the fixture, 1..65 of
+    0.25..8.4 million -- and the logits within 1e-3 absolute (north_star) / 2e-4 of the tensor scale.
+  * one dropout-free TRAIN step (batch statistics in every BatchNorm): loss and ~30..40 sampled parameter gradients, in BOTH operation
+    orders, at the product's DEFAULT re-association gate (>= 4096 token rows) -- the configuration bench.py times.
+Referee: the fixtures also hold the same reference modules run in fp64.  A gradient passes when the product is within 1e-3 of the global
+gradient scale of the fp32 reference, OR no further from the fp64 result than 3x the fp32 CPU reference itself is (the 3-D models
+normalise with batch-1 statistics over as few as 588 samples per channel, where the fp32 reference is 4e-3..1e-2 off the exact result)."""
+import numpy as np
+import pytest
+import torch
+
+from segtran_amd import engine, functional as SF
+from segtran_amd.synth import sample, synth_brats, synth_image2d, synth_fundus_mask
+from util import golden
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device('cuda', 0)
+LABEL_MARGIN = 1e-5
+
+
+def _inputs(cfg):
+    c = engine.CONFIGS[cfg]
+    if c['dim'] == 2:
+        S = c['size'][0]
+        x = synth_image2d(1, S, 1337)
+        m = synth_fundus_mask(1, S, 1338)
+        if c['task'] == 'polyp':
+            m = m[:, :1].repeat(1, 3, 1, 1)
+        return x, m
+    return synth_brats(1, *c['size'], 1337)
+
+
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
+def test_fullshape_eval_every_label(cfg):
+    g = golden('full_' + cfg)
+    net = engine.build_model(cfg, DEV, dropout_prob=0.0)
+    net.eval()
+    x, _ = _inputs(cfg)
+    with torch.no_grad():
+        y = net(x.to(DEV)).cpu()
+    assert list(y.shape) == g['shape'].tolist()
+    absmax = float(g['absmax'])
+    err = (sample(y, 65536)[::4] - g['logits']).abs().max().item()
+    assert err < 1e-3 and err <= 2e-4 * absmax, 'logits differ from the reference by %.3e' % err
+    ref_bits = np.unpackbits(g['labels'].numpy())[:y.numel()].astype(bool)
+    got_bits = (y > 0).numpy().reshape(-1)
+    bad = np.nonzero(ref_bits != got_bits)[0]
+    uncertain = set(g['near_idx'].numpy()[np.abs(g['near_val'].numpy()) < LABEL_MARGIN].tolist())
+    outside = [int(i) for i in bad if int(i) not in uncertain]
+    assert not outside, '%d hardened labels differ where the reference |logit| >= %g (first: %s)' % (len(outside), LABEL_MARGIN, outside[:5])
+    # the near-zero logits themselves agree with the reference to fp32 rounding (they are where a label flip would happen)
+    near = g['near_idx'].long()
+    assert (y.reshape(-1)[near] - g['near_val']).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('reassociated', [True, False], ids=['reassociated', 'reference-op-order'])
+@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
+def test_fullshape_train_step_gradients(cfg, reassociated, monkeypatch):
+    from segtran_amd.networks import segtran_shared as ss
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)      # the size gate keeps its default (4096 rows)
+    g = golden('full_' + cfg)
+    c = engine.CONFIGS[cfg]
+    net = engine.build_model(cfg, DEV, dropout_prob=0.0)
+    net.fuse_output_tail = reassociated
+    if c['dim'] == 2:
+        net.backbone.drop_connect_rate = 0.0
+    net.train()
+    x, raw = _inputs(cfg)
+    y = net(x.to(DEV))
+    lerr = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits']).abs().max().item()
+    lerr64 = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits64']).abs().max().item()
+    ref64 = (g['train_logits'] - g['train_logits64']).abs().max().item()
+    assert lerr < 1e-3 and (lerr <= 2e-4 * float(g['absmax']) or lerr64 <= 3 * ref64), (lerr, lerr64, ref64)
+    pw, cw = engine.loss_weights(c['task'], DEV)
+    loss, _ = SF.seg_loss(y, engine.map_mask(c['task'], raw.to(DEV)), pw, cw)
+    assert abs(loss.item() - float(g['loss'])) < 5e-5, (loss.item(), float(g['loss']))
+    loss.backward()
+    named = dict(net.named_parameters())
+    gscale = float(g['gscale'])
+    n, worst = 0, (0.0, '')
+    for k, v in g.items():
+        if not k.startswith('grad:'):
+            continue
+        name = k[5:]
+        got = named[name].grad
+        assert got is not None, name
+        got = sample(got.cpu()) if got.numel() != v.numel() else got.cpu().reshape(-1)
+        e32 = (got - v.reshape(-1)).abs().max().item() / gscale
+        v64 = g['grad64:' + name].reshape(-1)
+        e64 = (got - v64).abs().max().item() / gscale
+        r64 = (v.reshape(-1) - v64).abs().max().item() / gscale
+        assert e32 <= 1e-3 or e64 <= 3 * r64, '%s: |hip - ref32| = %.2e, |hip - fp64| = %.2e, |ref32 - fp64| = %.2e (of the gradient scale)' % (name, e32, e64, r64)
+        worst = max(worst, (e32, name))
+        n += 1
+    assert n >= 25
+    for k in g['unused']:                                  # N3
+        assert named[str(k)].grad is None, k
+    print('%s %s: worst |hip - ref32| / gscale = %.2e (%s)' % (cfg, 'reassoc' if reassociated else 'ref-order', worst[0], worst[1]))

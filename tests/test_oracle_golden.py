@@ -279,22 +279,21 @@ def test_label_maps_known_answers():
 
 @pytest.mark.slow
 @pytest.mark.parametrize('cfg', ['cfg2', 'cfg4'])
-def test_fullsize_hash(cfg):
-    ref = golden_json('fullsize')[cfg]
+def test_fullshape_oracle_every_label(cfg):
+    """The oracle at the BASELINE shapes (batch 1) against the reference's full label map (tests/golden/full_cfg*.npz): a hardened
+    label may differ only where the reference's own |logit| < 1e-5 (those positions are stored in the fixture)."""
+    g = golden('full_' + cfg)
     sd = synth_state_dict({k: tuple(v) for k, v in KEYS[cfg].items()})
     with torch.no_grad():
         if cfg == 'cfg2':
             y = O.segtran2d_forward(sd, synth_image2d(1, 512, 1337), [1792, 1792, 896, 448])
         else:
             y = O.segtran3d_forward(sd, synth_brats(1, 112, 112, 96, 1337)[0], [1024, 1024])
-    got = sample(y, 256)
-    want = torch.tensor(ref['sample'])
-    assert (got - want).abs().max().item() <= 5e-5 * ref['absmax']
-    flips = 0
-    if hashlib.sha256(np.packbits((y > 0).numpy()).tobytes()).hexdigest() != ref['sha256']:
-        # hash differs only if some |logit| is below fp32 re-association noise
-        flips = int(((y.abs() < 1e-5)).sum())
-        assert flips > 0, 'label map differs although no logit is near 0'
+    assert (sample(y, 65536)[::4] - g['logits']).abs().max().item() <= 5e-5 * float(g['absmax'])
+    ref_bits = np.unpackbits(g['labels'].numpy())[:y.numel()].astype(bool)
+    bad = np.nonzero(ref_bits != (y > 0).numpy().reshape(-1))[0]
+    uncertain = set(g['near_idx'].numpy()[np.abs(g['near_val'].numpy()) < 1e-5].tolist())
+    assert all(int(i) in uncertain for i in bad), 'oracle label map differs where the reference |logit| >= 1e-5'
 
 
 def test_eval_path_2d():
