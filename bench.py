@@ -1,16 +1,24 @@
 #!/usr/bin/env python
 """bench.py -- train-step throughput of the MI355X-native Segtran hot path (BASELINE.json metric).
 
-`python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under torch.distributed.run
-(one rank per GPU over RCCL).  Workload at every N: BASELINE.json configs[1] -- REFUGE fundus 2D, eff-b4,
---translayers 3 --layercompress 1,1,2,2, 512x512, batch 6 PER GPU (weak scaling), fp32, train mode with the
-reference's dropout 0.2, synthetic inputs / name-hashed synthetic weights (no network).  A step is the full
-train step: forward -> BCE+Dice -> backward -> gradient all-reduce -> global clip + BertAdam.  Inputs are
-resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+`python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under torch.distributed.run (one rank per GPU over
+RCCL).  A step is the full train step: forward -> BCE+Dice -> backward -> gradient all-reduce -> global clip + BertAdam, fp32 results,
+train mode with the reference's dropout 0.2, synthetic inputs / name-hashed synthetic weights (no network), inputs resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line:
+
+  * the MAIN measurement (`metric`, `value`, ...): BASELINE.json configs[1] -- REFUGE fundus 2D, eff-b4, --translayers 3 --layercompress
+    1,1,2,2, 512 x 512, batch 6 PER GPU (weak scaling) -- W warm-up steps, then EXACTLY K steps inside one barrier + synchronize bracket;
+    `value` = images of all ranks / that time (max over ranks); per-step HIP-event times give `ms_per_step_median` beside it;
+  * `"brats"`: the 3-D half of the metric measured the same way in the same process (own `roofline`): cfg4 (BraTS 112 x 112 x 96, bs 4, one
+    layer, BASELINE configs[3]) at N = 1, and cfg5 (128^3, 4 volumes per GPU, two layers, BASELINE configs[4]: the configuration the
+    >= 6x scaling target is stated on) at every N;
+  * `roofline`: the dominant kernel family = the tile engine (dense + implicit-GEMM kernels); `cpu_baseline`: the oracle on the host cores.
+`--config cfgN` makes another BASELINE configuration the main measurement; `--engine f32` times the fp32-MFMA engine instead of bf16x6.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -20,6 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: bf16 MFMA dense (32x32x16); the bf16x6 engine issues 6 of them per fp32-equivalent block product
+WORKLOADS = {'cfg1': 'REFUGE fundus 2D, segtran eff-b4, translayers 1, 256x256, bs 2/GPU',
+             'cfg2': 'REFUGE fundus 2D, segtran eff-b4, translayers 3, layercompress 1,1,2,2, 512x512, bs 6/GPU',
+             'cfg3': 'Polyp 2D, segtran eff-b4, translayers 3, layercompress 1,1,2,2, 352x352, bs 6/GPU',
+             'cfg4': 'BraTS 3D, segtran i3d, translayers 1, attractors 1024, 112x112x96 x4 modalities, bs 4/GPU',
+             'cfg5': 'BraTS 3D, segtran i3d, translayers 2, attractors 1024, 128x128x128 x4 modalities, bs 4/GPU'}
 
 
 def cpu_baseline(cfg_name, threads):
@@ -73,100 +87,13 @@ def run_cpu_baseline(cfg_name, limit_s=240):
         return {'value': None, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample': 'failed: %s' % repr(e)[:160]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
-    ap.add_argument('--threads', type=int, default=8, help=argparse.SUPPRESS)
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', default='cfg2', help='BASELINE config (cfg2 = metric default; cfg4 = BraTS 3D)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--single-order', action='store_true', help='skip the comparison run in the other operation order (profiling runs)')
-    ap.add_argument('--reference-op-order', action='store_true',
-                    help="time the reference's operation order (no linear-chain re-association, DESIGN.md section 5b) as the main number")
-    args = ap.parse_args()
-    if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.threads)))
-        return
-
-    from segtran_amd import engine, segx, dist as sdist, functional as SF
-    rank, local, world = sdist.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-    c = engine.CONFIGS[args.config]
-    B = c['bs']
-
-    torch.manual_seed(1234)
-    SF.manual_seed(1234 + rank)
-    from segtran_amd.networks import segtran_shared as ss
-
-    def set_op_order(net_, reassociated):
-        # exact re-associations of consecutive linear maps (same function, same parameter gradients): attention projections applied
-        # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
-        ss.CrossAttFeatTrans.reassociate_projections = reassociated
-        net_.fuse_output_tail = reassociated
-
-    net = engine.build_model(args.config, dev)
-    set_op_order(net, not args.reference_op_order)
-    sdist.enable_sync_batchnorm()
-    net.train()
-    opt = engine.init_optimizer(net, c['task'])
-    reducer = sdist.GradReducer(opt) if world > 1 else None
-    step = engine.TrainStep(net, opt, c['task'], reducer)
-    x, raw = engine.synth_batch(args.config, B, dev, seed=1337 + rank)          # disjoint samples per rank
-
-    L = segx.lib()
-    # SEGX_BF16X6=<min dim> (read by segx.lib()): EXPERIMENTAL, large GEMMs on the bf16 matrix core
-    for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
-        k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
-    for _ in range(args.warmup):
-        step(x, raw)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    L.gemm_prof = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(x, raw)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    prof, L.gemm_prof = L.gemm_prof, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = t.item()
-    other = None
-    if world == 1 and not args.single_order:   # the same step in the OTHER operation order, outside the timed region (reported beside the main number)
-        set_op_order(net, args.reference_op_order)
-        for _ in range(2):
-            step(x, raw)
-        torch.cuda.synchronize()
-        k = max(2, args.steps // 2)
-        t1 = time.perf_counter()
-        for _ in range(k):
-            step(x, raw)
-        torch.cuda.synchronize()
-        other = (time.perf_counter() - t1) / k
-        set_op_order(net, not args.reference_op_order)
-    if rank != 0:
-        return
-    lossv = float(loss.detach())
-    assert lossv == lossv, 'loss is NaN'
-
-    # roofline of the dominant kernel family (the fp32-MFMA tile engine of gemm_core.h: dense GEMM in all layouts and the
-    # implicit-GEMM convolutions): algorithmic FLOPs of every launch / its HIP-event time on the launch stream
+def engine_roofline(prof, steps, cfg_name, engine_name):
+    """Roofline of the dominant kernel family: every launch of the tile engine inside the timed region is bracketed by HIP events on the
+    launch stream (segx.SegxLib.gemm / _timed); achieved = algorithmic FLOPs of those launches / their summed durations."""
     traffic = tnote = None
     tfile = os.path.join(ROOT, 'profiles', 'pmc_engine_traffic.json')
     if os.path.exists(tfile):      # PMC passes cannot run inside the timed bench: read the committed result of the same workload
-        tj = json.load(open(tfile)).get(args.config)
+        tj = json.load(open(tfile)).get(cfg_name if engine_name == 'x6' else cfg_name + '_f32')
         if tj:
             traffic = round(tj['traffic_bytes_per_launch'])
             tnote = 'bytes per launch, rocprofv3 --pmc FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, profiles/' + tj['file']
@@ -179,41 +106,176 @@ def main():
         else:
             M_, N_, K_, nb_ = shp[:4]
             alg_bytes += 4.0 * nb_ * (M_ * K_ + N_ * K_ + M_ * N_)
+    sel = {'x6': [p for p in prof if p[4]], 'f32': [p for p in prof if not p[4]]}
+    stat = {}
+    for k, ps in sel.items():
+        fl, ms = sum(p[2] for p in ps), sum(p[0].elapsed_time(p[1]) for p in ps)
+        stat[k] = dict(launches_per_step=len(ps) // max(1, steps), ms_per_step=round(ms / max(1, steps), 2),
+                       tflop_per_step=round(fl / max(1, steps) / 1e12, 3), tflops=round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else 0.0)
     flops = sum(p[2] for p in prof)
     ms = sum(p[0].elapsed_time(p[1]) for p in prof)
     achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
-            'achieved': round(achieved, 2),
-            'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
-            'traffic_note': tnote,
-            'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
-            'launches_per_step': len(prof) // max(1, args.steps), 'gemm_ms_per_step': round(ms / max(1, args.steps), 2),
-            'gemm_tflop_per_step': round(flops / max(1, args.steps) / 1e12, 3)}
-    if os.environ.get('SEGX_BENCH_VERBOSE'):
+    if engine_name == 'x6':
+        dom = stat['x6']
+        peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+        roof = {'bound': 'mfma',
+                'kernel': 'segx bf16x6 tile engine: gemm_x6_kernel + conv3d_{fwd,wgrad}_x6_kernel (fp32 operands split in registers into 3 bf16 '
+                          'planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block: fp32-equivalent results)',
+                'achieved': dom['tflops'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / peak, 4),
+                'peak_note': 'fp32-equivalent TFLOP/s: bf16 dense MFMA peak 2500 / 6 instructions per block product; executed bf16 MFMA rate = '
+                             '6 x achieved = %.0f TFLOP/s of 2500' % (6 * dom['tflops']),
+                'frac_of_f32_mfma_peak': round(dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 4)}
+    else:
+        dom = stat['f32']
+        roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
+                'achieved': dom['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 4)}
+    roof.update({'traffic': traffic, 'traffic_note': tnote, 'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
+                 'launches_per_step': dom['launches_per_step'], 'gemm_ms_per_step': dom['ms_per_step'], 'gemm_tflop_per_step': dom['tflop_per_step'],
+                 'all_engine_launches': {'launches_per_step': len(prof) // max(1, steps), 'ms_per_step': round(ms / max(1, steps), 2),
+                                         'tflop_per_step': round(flops / max(1, steps) / 1e12, 3), 'tflops': round(achieved, 2)},
+                 'f32_engine_remainder' if engine_name == 'x6' else 'x6_engine_part': stat['f32' if engine_name == 'x6' else 'x6']})
+    return roof, achieved
+
+
+def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
+    """W warm-up steps, EXACTLY `steps` timed steps inside a barrier + synchronize bracket (max over ranks), engine launches profiled."""
+    from segtran_amd import engine, segx, dist as sdist, functional as SF
+    from segtran_amd.networks import segtran_shared as ss
+    c = engine.CONFIGS[cfg_name]
+    B = c['bs']
+    torch.manual_seed(1234)
+    SF.manual_seed(1234 + rank)
+
+    def set_op_order(net_, reassociated):
+        # exact re-associations of consecutive linear maps (same function, same parameter gradients): attention projections applied
+        # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
+        ss.CrossAttFeatTrans.reassociate_projections = reassociated
+        net_.fuse_output_tail = reassociated
+
+    net = engine.build_model(cfg_name, dev)
+    set_op_order(net, not args.reference_op_order)
+    sdist.enable_sync_batchnorm()
+    net.train()
+    opt = engine.init_optimizer(net, c['task'])
+    reducer = sdist.GradReducer(opt) if world > 1 else None
+    step = engine.TrainStep(net, opt, c['task'], reducer)
+    x, raw = engine.synth_batch(cfg_name, B, dev, seed=1337 + rank)          # disjoint samples per rank
+    L = segx.lib()
+    for _ in range(warmup):
+        step(x, raw)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    L.gemm_prof = []
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(steps):
+        loss = step(x, raw)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, L.gemm_prof = L.gemm_prof, None
+    per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    other = None
+    if world == 1 and other_order and not args.single_order:   # the same step in the OTHER operation order, outside the timed region
+        set_op_order(net, args.reference_op_order)
+        for _ in range(2):
+            step(x, raw)
+        torch.cuda.synchronize()
+        k = max(2, min(10, steps // 4))
+        t1 = time.perf_counter()
+        for _ in range(k):
+            step(x, raw)
+        torch.cuda.synchronize()
+        other = (time.perf_counter() - t1) / k
+        set_op_order(net, not args.reference_op_order)
+    lossv = float(loss.detach())
+    assert lossv == lossv, 'loss is NaN'
+    del step, opt, net, reducer
+    torch.cuda.empty_cache()
+    unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
+    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine) if rank == 0 else (None, 0.0)
+    if rank == 0 and os.environ.get('SEGX_BENCH_VERBOSE'):
         agg = {}
-        for e0, e1, fl, shp in prof:
-            a = agg.setdefault(shp, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
-        print('[bench] GEMM shapes by time (M,N,K,batch,A_kcontig,B_kcontig,splitk): count ms TFLOP/s', file=sys.stderr)
+        for e0, e1, fl, shp, x6 in prof:
+            a = agg.setdefault(shp + (('x6',) if x6 else ('f32',)), [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += fl
+        print('[bench] %s engine launches by time (M,N,K,batch,A_kcontig,B_kcontig,splitk,tile,engine): count ms TFLOP/s' % cfg_name, file=sys.stderr)
         top = None if os.environ['SEGX_BENCH_VERBOSE'] == '2' else 40
         for shp, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
-            print('[bench]   %-46s %4d %8.2f %7.1f' % (shp, n, t, fl / (t * 1e-3) / 1e12), file=sys.stderr)
-    unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
-    res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), args.config), 'value': round(world * B * args.steps / dt, 3),
-           'unit': unit, 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 2),
-           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': {'cfg2': 'REFUGE fundus 2D, segtran eff-b4, translayers 3, layercompress 1,1,2,2, 512x512, bs 6/GPU',
-                                   'cfg4': 'BraTS 3D, segtran i3d, translayers 1, attractors 1024, 112x112x96 x4 modalities, bs 4/GPU'}
-                                  .get(args.config, args.config),
-                      'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world, 'dropout': 0.2,
-                      'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5),
-                      'gemm_path': 'EXPERIMENTAL bf16x6 split for dims >= %d' % L.bf16x6_min_dim if L.use_bf16x6 else 'fp32 MFMA',
-                      'op_order': ("reference" if args.reference_op_order else "re-associated") + ' (DESIGN.md 5b: exact re-association of '
+            print('[bench]   %-58s %4d %8.2f %7.1f' % (shp, n, t, fl / (t * 1e-3) / 1e12), file=sys.stderr)
+    med = statistics.median(per_step)
+    res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), cfg_name), 'value': round(world * B * steps / dt, 3), 'unit': unit,
+           'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 2),
+           'ms_per_step_median': round(med, 2), 'value_at_median': round(world * B / (med * 1e-3), 3),
+           'ms_per_step_min_max': [round(min(per_step), 2), round(max(per_step), 2)],
+           'config': {'workload': WORKLOADS.get(cfg_name, cfg_name), 'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world,
+                      'dropout': 0.2, 'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5),
+                      'gemm_path': 'bf16x6 tile engine (fp32-equivalent; float4-legal operands with > 48 rows per side), fp32 MFMA for the rest'
+                                   if args.engine == 'x6' else 'fp32 MFMA tile engine',
+                      'op_order': ('reference' if args.reference_op_order else 're-associated') + ' (DESIGN.md 5b: exact re-association of '
                                   'consecutive linear maps; every layer, parameter and gradient is computed)',
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
                           None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)}},
            'roofline': roof}
-    print('[bench] %s: %.1f ms/step, %.2f %s, GEMM %.1f TFLOP/s' % (args.config, res['ms_per_step'], res['value'], unit, achieved),
-          file=sys.stderr, flush=True)
+    if rank == 0:
+        print('[bench] %s: %.1f ms/step (median %.1f), %.2f %s, engine %.1f TFLOP/s' % (cfg_name, res['ms_per_step'], med, res['value'], unit, achieved),
+              file=sys.stderr, flush=True)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--threads', type=int, default=8, help=argparse.SUPPRESS)
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', default='cfg2', help='BASELINE config of the MAIN measurement (cfg2 = metric default)')
+    ap.add_argument('--engine', default=os.environ.get('SEGX_ENGINE', 'x6'), choices=['x6', 'f32'],
+                    help="tile engine: 'x6' = bf16x6 (default), 'f32' = v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument('--no-brats', action='store_true', help='skip the secondary BraTS block(s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--single-order', action='store_true', help='skip the comparison run in the other operation order (profiling runs)')
+    ap.add_argument('--reference-op-order', action='store_true',
+                    help="time the reference's operation order (no linear-chain re-association, DESIGN.md section 5b) as the main number")
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.threads)))
+        return
+
+    from segtran_amd import segx, dist as sdist
+    rank, local, world = sdist.init_distributed()
+    assert world == max(1, args.gpus) or world == 1, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    L = segx.lib()
+    L.set_engine(args.engine)
+    for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
+        k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
+
+    res = measure(args.config, args, args.steps, args.warmup, rank, world, dev)
+    res = dict(res, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic')
+    if not args.no_brats and args.config == 'cfg2':
+        k2, w2 = max(10, args.steps // 2), max(3, args.warmup // 2)
+        brats = {}
+        for cfg in (['cfg4'] if world == 1 else []) + ['cfg5']:
+            r = measure(cfg, args, k2, w2, rank, world, dev, other_order=False)
+            brats[cfg] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median',
+                                             'value_at_median', 'config', 'roofline')}
+        res['brats'] = brats
+    if rank != 0:
+        return
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = run_cpu_baseline(args.config)
     print(json.dumps(res), flush=True)

@@ -61,16 +61,6 @@ int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc
  * ignored): callers that want split-K size the workspace from *splitk and pass both back through the desc. */
 int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
 
-/* EXPERIMENTAL (not on the default path): segx_gemm_f32 semantics (same descriptor; splitk must be <= 1) evaluated on the bf16 matrix core
- * with fp32-equivalent accuracy -- both operands are split once into three bf16 planes (hi + mid + lo == x exactly) in `ws`
- * (segx_gemm_bf16x6_ws_bytes(desc) bytes, 16-byte aligned), the tile kernel issues six v_mfma_f32_32x32x16_bf16 per block and 16 k.
- * See gemm_bf16x6.hip and DESIGN.md section 7. */
-int64_t segx_gemm_bf16x6_ws_bytes(const segx_gemm_desc* d);
-int segx_gemm_f32_bf16x6(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* ws, void* stream);
-/* EXPERIMENTAL: segx_conv3d_fwd_packed (packed filters, same geom array; no split-K) on the bf16x6 tile; the activations are split into
- * bf16 planes stored channels-last-8 in `ws` (segx_conv3d_bf16x6_ws_bytes bytes, 16-byte aligned).  Cin % 8 == 0. */
-int64_t segx_conv3d_bf16x6_ws_bytes(int B, int Cout, const int* geom);
-int segx_conv3d_fwd_bf16x6(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row kernels of the Squeeze-and-Expansion transformer (tokens.hip).  All tensors fp32, row-major,
@@ -244,8 +234,9 @@ int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* 
 int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
- * knob 3 = tile of the EXPERIMENTAL pre-split bf16x6 GEMM (1 = 128 x 128 x 32, 2 = 128 x 256 x 16); knob 4 = tile engine of segx_gemm_f32 and the
- * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4 */
+ * knob 4 = tile engine of segx_gemm_f32 and the
+ * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4;
+ * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);

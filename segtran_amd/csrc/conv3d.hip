@@ -8,9 +8,12 @@
 // The im2col matrix is never materialised: the B-operand loader gathers straight from the NCDHW activation with
 // zero padding (dynamic 'same' padding N7: front = pad // 2) — unconditional loads from clamped addresses plus a
 // validity mask applied at LDS-store time, exactly like the dense loader.  The A operand (weights, or dY) is dense.
-#include "gemm_core.h"
+#include "gemm_x6.h"
 
 namespace segx {
+
+extern int g_engine;
+extern int g_x6_launches;
 
 struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
@@ -185,6 +188,91 @@ struct ConvWgradLoaderB {
     }
 };
 
+// ---- the same B operands for the bf16x6 engine (gemm_x6.h) -------------------------------------------------------------------------------
+// forward / backward-data: the PACK8 gather already hands a thread two groups of EIGHT consecutive k of ONE position -- exactly one 16-byte
+// bf16 chunk per plane each: the global side is ConvFwdLoaderB<true>::load unchanged, the LDS side is two split-and-store calls.
+struct ConvFwdLoaderB6 {
+    static constexpr int NREG = 4 * NP;
+    ConvFwdLoaderB<true> inner;
+    __device__ __forceinline__ ConvFwdLoaderB6(const float* X_, const ConvGeom& q_, int n0, int P) : inner(X_, q_, n0, P) {}
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int tid) const {
+        float4 t4[NP];
+        const unsigned ok = inner.load(t4, k0, kend, tid);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { r[4 * i] = t4[i].x; r[4 * i + 1] = t4[i].y; r[4 * i + 2] = t4[i].z; r[4 * i + 3] = t4[i].w; }
+        return ok;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned okmask, unsigned char* __restrict__ P, int tid) const {
+        const int n = tid & 127, c0 = (tid >> 7) * 2;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ((okmask >> (8 * sub + j)) & 1u) ? r[8 * sub + j] : 0.f;
+            x6_store8<X6Plane<128>::bytes>(P, x6_off(n, c0 + sub), v);
+        }
+    }
+};
+
+// backward-weight: B(n = packed row (channel block, tap, channel in block), k = output position).  The fp32 loader gives a thread ONE position
+// and 16 rows; the bf16 fragments need eight consecutive k (positions) of one row, so here a thread owns the position octet k0 + 8 (tid & 3) ..
+// + 7 and the TWO rows (tid >> 2) and 64 + (tid >> 2): the eight positions are decoded once (incrementally: ow, carry into oh, od) and serve
+// both rows; 16 lanes x 4 octets of a wave read 16 channels x 32 consecutive positions (128-byte runs wherever the octets stay in one image row).
+struct ConvWgradLoaderB6 {
+    static constexpr int NREG = 16;
+    const float* X; ConvGeom q; FastDiv dOHW, dOW;
+    const int* rowinfo;                                        // LDS, per 8-row group: {channel-block offset (or -1), kd | kh<<10 | kw<<20}
+    __device__ __forceinline__ ConvWgradLoaderB6(const float* X_, const ConvGeom& q_, int n0, int N, int* rowinfo_lds) : X(X_), q(q_), rowinfo(rowinfo_lds) {
+        dOHW = make_fastdiv(q.OH * q.OW); dOW = make_fastdiv(q.OW);
+        const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, chan = q.ID * q.IH * q.IW;
+        if (threadIdx.x < 16) {
+            const int n = n0 + 8 * threadIdx.x;                                       // first row of the group; N % 8 == 0
+            const int blk = (n < N ? n : 0) >> 3, cb = blk / KV, t = blk - cb * KV, kd = t / KHW, t2 = t - kd * KHW, kh = t2 / q.KW, kw = t2 - kh * q.KW;
+            rowinfo_lds[2 * threadIdx.x] = n < N ? cb * 8 * chan : -1;
+            rowinfo_lds[2 * threadIdx.x + 1] = kd | (kh << 10) | (kw << 20);
+        }
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int tid) const {
+        const int p0 = k0 + 8 * (tid & 3), row = tid >> 2;
+        const int chan = q.ID * q.IH * q.IW, OHW = q.OH * q.OW;
+        const int pp = p0 < kend ? p0 : 0;
+        int od = fdiv(pp, dOHW), rr = pp - od * OHW, oh = fdiv(rr, dOW), ow = rr - oh * q.OW;
+        int cb[2], kd[2], kh[2], kw[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int grp = (row >> 3) + 8 * h, tp = rowinfo[2 * grp + 1];
+            const int c = rowinfo[2 * grp];
+            cb[h] = c < 0 ? -1 : c + (row & 7) * chan;
+            kd[h] = tp & 1023; kh[h] = (tp >> 10) & 1023; kw[h] = tp >> 20;
+        }
+        unsigned okmask = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool pok = p0 + j < kend;
+            const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int id = bd + kd[h], ih = bh + kh[h], iw = bw + kw[h];
+                const bool ok = pok && cb[h] >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH && (unsigned)iw < (unsigned)q.IW;
+                r[8 * h + j] = X[ok ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw : 0];
+                okmask |= (ok ? 1u : 0u) << (8 * h + j);
+            }
+            if (++ow == q.OW) { ow = 0; if (++oh == q.OH) { oh = 0; ++od; } }
+        }
+        return okmask;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned okmask, unsigned char* __restrict__ P, int tid) const {
+        const int c = tid & 3, row = tid >> 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ((okmask >> (8 * h + j)) & 1u) ? r[8 * h + j] : 0.f;
+            x6_store8<X6Plane<128>::bytes>(P, x6_off(row + 64 * h, c), v);
+        }
+    }
+};
+
 // Cfg: 128 x 128, or 64 x 128 when Cout <= 64 (the I3D stem and the 64-channel branches: half of a 128-row A tile would be
 // clamped duplicates).  The B-side (im2col) loaders above are written for 128 columns.
 using CfgCout64 = TileCfg<2, 2, 1, 2>;
@@ -210,6 +298,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGe
     __syncthreads();
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
+}
+
+// the packed convolutions on the bf16x6 engine (float4-legal weights / dY: the host checks)
+template <class Cfg, int WPE>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_fwd_x6_kernel(GemmArgs g, ConvGeom q) {
+    static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES];
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader6<true, Cfg::BM> la{g.A, g.a_m, 1, t.m0, g.M};                  // packed weights [Cout][Cin*KV]
+    const ConvFwdLoaderB6 lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);            // X[b]
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
+}
+template <class Cfg, int WPE>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_wgrad_x6_kernel(GemmArgs g, ConvGeom q) {
+    static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES + 128];
+    const TileCoord t = tile_coord<Cfg>(g);
+    const DenseLoader6<true, Cfg::BM> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};       // dY[b] [Cout][P]
+    const ConvWgradLoaderB6 lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, reinterpret_cast<int*>(lds + X6Lds<Cfg>::BYTES));   // X[b]
+    __syncthreads();
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
 
@@ -573,7 +686,11 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
 #define SEGX_CONV_FWD(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
                                    else hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
-    if (small && vec) SEGX_CONV_FWD(true, CfgCout64);
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6) {          // bf16x6 engine (gemm_x6.h): same tiles, same grid, same split-K slabs
+        ++g_x6_launches;
+        if (small) hipLaunchKernelGGL((conv3d_fwd_x6_kernel<CfgCout64, 4>), grid, dim3(256), 0, stream, g, q);
+        else hipLaunchKernelGGL((conv3d_fwd_x6_kernel<Cfg128, 3>), grid, dim3(256), 0, stream, g, q);
+    } else if (small && vec) SEGX_CONV_FWD(true, CfgCout64);
     else if (small) SEGX_CONV_FWD(false, CfgCout64);
     else if (vec) SEGX_CONV_FWD(true, Cfg128);
     else SEGX_CONV_FWD(false, Cfg128);
@@ -628,7 +745,11 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
 #define SEGX_CONV_WG(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
                                   else hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
-    if (small && vec) SEGX_CONV_WG(true, CfgCout64);
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6) {
+        ++g_x6_launches;
+        if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4>), grid, dim3(256), 0, stream, g, q);
+        else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3>), grid, dim3(256), 0, stream, g, q);
+    } else if (small && vec) SEGX_CONV_WG(true, CfgCout64);
     else if (small) SEGX_CONV_WG(false, CfgCout64);
     else if (vec) SEGX_CONV_WG(true, Cfg128);
     else SEGX_CONV_WG(false, Cfg128);

@@ -333,12 +333,12 @@ extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64
     return check_launch("segx_dropout");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
-namespace segx { extern int g_conv_small_policy; extern int g_engine; int bf16x6_set_variant(int v); }
+namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; }
 extern "C" int segx_tune(int knob, int value) {
     if (knob == 1) { g_interp_variant = value; return 0; }
     if (knob == 2) { segx::g_conv_small_policy = value; return 0; }
     if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; const int prev = segx::g_engine; segx::g_engine = value; return prev; }
-    if (knob == 3) return segx::bf16x6_set_variant(value);      // EXPERIMENTAL bf16x6 GEMM: 1 = 128 x 128 x 32 tile, 2 = 128 x 256 x 16 wide waves
+    if (knob == 5) { const int n = segx::g_x6_launches; segx::g_x6_launches = 0; return n; }
     return -1;
 }
 // RandomResizedCrop (datasets3d.py:611-665) as ONE gather pass: the volume is (virtually) resampled to (D, H, W) with the trilinear

@@ -76,6 +76,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
 int g_engine = SEGX_ENGINE_F32;            // segx_tune(4, v): which tile engine the eligible GEMMs / convolutions run on
+int g_x6_launches = 0;                     // segx_tune(5, 0): launches that ran on the bf16x6 engine since the last query (tests / sessions)
 // bf16x6 engine: float4-legal operands, neither side skinny (those GEMMs are HBM-bound and stream through the 32-row fp32 tiles)
 static bool x6_eligible(int M, int N, bool vec) { return g_engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
 static void plan6(int M, int N, int K, int nbatch, bool gelu, bool may_split, int splitk_fixed, int* tile, int* splitk) {
@@ -175,6 +176,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
     using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (x6) {
+        ++g_x6_launches;
 #define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \

@@ -39,10 +39,12 @@ class GradReducer:
     buckets travel over xGMI while the backbone is still differentiating.  `allreduce_grads()` then only launches what is left and
     waits.  Buckets that hold no live parameter are never sent (they are zeros on every rank)."""
 
-    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True):
+    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True, force_collectives=False):
         """gather=True: gradients stay autograd's own tensors and are copied into their bucket by one multi-tensor launch per
-        bucket (no per-parameter `grad += g` kernels); gather=False: every p.grad is a view of the flat buffer."""
+        bucket (no per-parameter `grad += g` kernels); gather=False: every p.grad is a view of the flat buffer.
+        force_collectives: issue the all-reduces even in a one-rank group (the single-GPU RCCL test: AVG over one rank is the identity)."""
         self.opt, self.flat, self.group, self.overlap, self.gather = optimizer, optimizer.flat_grad, group, overlap, gather
+        self.force = bool(force_collectives) and dist.is_initialized()
         if gather:
             optimizer.use_gathered_grads()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -101,7 +103,7 @@ class GradReducer:
         a, b = self.buckets[k][:2]
         if self.gather:
             self._gather(k)
-        if self.world > 1:
+        if self.world > 1 or self.force:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._works.append(dist.all_reduce(self.flat[a:b], op=op, group=self.group, async_op=True))
         self._launched[k] = True
@@ -162,14 +164,27 @@ def reduce_scalars(t, group=None):
     return t
 
 
-def enable_sync_batchnorm(group=None):
+def check_equal_batch(n, group=None):
+    """Every rank must hold the same per-GPU batch (train2d.py:791 `bs // world_size`): the gradient AVG all-reduce, the synchronised
+    BatchNorm merge and its backward all weight the ranks equally.  One tiny all-gather, called by TrainStep only when the local batch
+    size changes (first step, a ragged last batch of a user-supplied iterator) -- raises instead of silently mis-weighting."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return
+    sizes = [None] * dist.get_world_size(group)
+    dist.all_gather_object(sizes, int(n), group=group)
+    if len(set(sizes)) != 1:
+        raise RuntimeError('data-parallel step with unequal per-rank batch sizes %s: gradients and synchronised BatchNorm statistics would be '
+                           'mis-weighted (drop or pad the ragged batch, as DistributedSampler does)' % sizes)
+
+
+def enable_sync_batchnorm(group=None, force=False):
     """Synchronised BatchNorm for libsegx's fused BN(+act) op (replaces nn.SyncBatchNorm, train2d.py:1109).
 
     forward : ONE all-gather of [2C] floats per BN layer (mean, biased var), merged with Chan's formula by one kernel;
     backward: ONE all-reduce of [2C] floats (sum du*xhat, sum du); the apply kernel then uses the global sums / count.
     Parameter gradients stay LOCAL sums (the flat-gradient all-reduce averages them like every other gradient)."""
     from . import functional as SF
-    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) <= 1 and not force):      # force: the one-rank RCCL test
         SF._bn_stats_sync = SF._bn_grad_sync = None
         return False
     world = dist.get_world_size(group)

@@ -119,8 +119,13 @@ class TrainStep:
         dev = next(net.parameters()).device
         self.pos_weight, self.class_w = loss_weights(task, dev)
         self.stats = None
+        self._bs = None
 
     def __call__(self, x, raw_mask):
+        if self.reducer is not None and x.shape[0] != self._bs:
+            from .dist import check_equal_batch
+            check_equal_batch(x.shape[0], self.reducer.group)
+            self._bs = x.shape[0]
         mask = map_mask(self.task, raw_mask, self.exclusive)
         if self.augment is not None:
             x, mask = self.augment(x, mask)

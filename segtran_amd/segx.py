@@ -50,18 +50,28 @@ class SegxLib:
         self.c.segx_version.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
-        self.use_bf16x6 = False          # EXPERIMENTAL: large GEMMs on the bf16 matrix core, fp32-equivalent split
-        self.bf16x6_min_dim = 256        # only problems with min(M, N) and K at least this large
-        self.bf16x6_calls = 0            # launches that took the experimental path (sessions / tests read it)
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
             fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk')) else c_i
-        if hasattr(self.c, 'segx_gemm_bf16x6_ws_bytes'):
-            self.c.segx_gemm_bf16x6_ws_bytes.restype = c_l
-            self.c.segx_conv3d_bf16x6_ws_bytes.restype = c_l
+
+    # ---- tile engine -------------------------------------------------------------------------
+    ENGINES = {'f32': 0, 'x6': 1}
+
+    def set_engine(self, name):
+        """'f32': every GEMM / implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (a k-ordered fp32 fmaf chain); 'x6': eligible ones
+        (float4-legal operands, > 48 rows on both sides) on the bf16 matrix core with the 3-way operand split (fp32-equivalent).
+        Returns the previous engine name."""
+        prev = self.c.segx_tune(4, self.ENGINES[name])
+        if prev < 0:
+            raise RuntimeError('segx_tune(4): engine %r rejected' % name)
+        return 'x6' if prev == 1 else 'f32'
+
+    def x6_launches(self):
+        """launches that ran on the bf16x6 engine since the last call"""
+        return int(self.c.segx_tune(5, 0))
 
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
@@ -106,31 +116,18 @@ class SegxLib:
             self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
             tile, splitk = t.value, sk.value
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if splitk > 1 else None
-        if self.use_bf16x6 and min(M, N) >= self.bf16x6_min_dim and K >= self.bf16x6_min_dim:
-            # EXPERIMENTAL: fp32-equivalent evaluation on the bf16 matrix core (gemm_bf16x6.hip); off by default.  The split-K factor of the
-            # fp32 planner is kept (same 128 x 128 tile grid)
-            d.splitk, d.workspace, d.tile = max(1, splitk), _ptr(workspace), TILE_AUTO
-            self.bf16x6_calls += 1
-            ws = torch.empty(int(self.c.segx_gemm_bf16x6_ws_bytes(ctypes.byref(d))), dtype=torch.uint8, device=C.device)
-            prof = self.gemm_prof is not None and C.is_cuda
-            if prof:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            rc = self.c.segx_gemm_f32_bf16x6(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), _ptr(ws), self.stream(C))
-            if prof:
-                e1.record()                     # tile id 9 = bf16x6 (the operand split passes are inside the bracket)
-                self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, d.splitk, 9)))
-            self.check(rc, 'segx_gemm_f32_bf16x6')
-            return
         d.splitk, d.workspace = splitk, _ptr(workspace)
         d.tile = self.force_tile if self.force_tile is not None else tile
         if self.gemm_prof is not None and C.is_cuda:
-            # HIP events on the launch stream (torch's current stream IS the stream handed to the kernel)
+            # HIP events on the launch stream (torch's current stream IS the stream handed to the kernel); the last field records which
+            # tile engine the library chose for this launch (knob 5 counts bf16x6 launches)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.x6_launches()
             e0.record()
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
             e1.record()
-            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, splitk, d.tile)))
+            self.gemm_prof.append((e0, e1, 2.0 * M * N * K * nb[0] * nb[1], (M, N, K, nb[0] * nb[1], a_strides[3] == 1, b_strides[3] == 1, splitk, d.tile),
+                                   self.x6_launches() > 0))
         else:
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
         self.check(rc, 'segx_gemm_f32')
@@ -304,8 +301,9 @@ class SegxLib:
     def _timed(self, ref, flops, tag, fn):
         if self.gemm_prof is not None and ref.is_cuda:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.x6_launches()
             e0.record(); rc = fn(); e1.record()
-            self.gemm_prof.append((e0, e1, flops, tag))
+            self.gemm_prof.append((e0, e1, flops, tag, self.x6_launches() > 0))
             return rc
         return fn()
 
@@ -343,15 +341,6 @@ class SegxLib:
     def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None, packed=False):
         self._chk_t(X, W, Y, ws)
         P = geom[4] * geom[5] * geom[6]; K = geom[0] * geom[7] * geom[8] * geom[9]
-        if packed and self.use_bf16x6 and splitk <= 1 and min(Cout, P) >= self.bf16x6_min_dim:
-            # EXPERIMENTAL (off by default): the implicit GEMM on the bf16 matrix core, activations split into channels-last-8 bf16 planes
-            self.bf16x6_calls += 1
-            g_ = self._geom(geom)
-            wsb = torch.empty(int(self.c.segx_conv3d_bf16x6_ws_bytes(B, Cout, g_)), dtype=torch.uint8, device=Y.device)
-            rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd_bf16x6', Cout, P, K, B, 1),
-                             lambda: self.c.segx_conv3d_fwd_bf16x6(_ptr(X), _ptr(W), _ptr(Y), B, Cout, g_, _ptr(wsb), self.stream(Y)))
-            self.check(rc, 'segx_conv3d_fwd_bf16x6')
-            return
         fn = self.c.segx_conv3d_fwd_packed if packed else self.c.segx_conv3d_fwd
         rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk),
                          lambda: fn(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))
@@ -446,6 +435,7 @@ _SIGS = {
 }
 
 _LIB = None
+DEFAULT_ENGINE = 'x6'
 
 
 def lib():
@@ -453,8 +443,9 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = SegxLib(LIB_PATH)
-        if os.environ.get('SEGX_BF16X6'):      # EXPERIMENTAL switch for a whole-process parity / timing session; value = min dim
-            _LIB.use_bf16x6, _LIB.bf16x6_min_dim = True, max(1, int(os.environ['SEGX_BF16X6']))
+        # tile engine of the process: 'x6' (default: bf16x6, fp32-equivalent) or 'f32' (v_mfma_f32_32x32x2_f32 everywhere); the whole -m gpu
+        # parity suite runs on both (tests/test_gpu_model.py, tests/test_gpu_fullshape.py)
+        _LIB.set_engine(os.environ.get('SEGX_ENGINE', DEFAULT_ENGINE))
     return _LIB
 
 

@@ -5,7 +5,8 @@
     tolerated only where the reference's own |logit| < 1e-5 -- those positions (index + value) are stored in the fixture, 1..65 of
     0.25..8.4 million -- and the logits within 1e-3 absolute (north_star) / 2e-4 of the tensor scale.
   * one dropout-free TRAIN step (batch statistics in every BatchNorm): loss and ~30..40 sampled parameter gradients, in BOTH operation
-    orders, at the product's DEFAULT re-association gate (>= 4096 token rows) -- the configuration bench.py times.
+    orders, at the product's DEFAULT re-association gate (>= 4096 token rows) -- the configuration bench.py times;
+  * both on the bf16x6 tile engine (the product default) and on the fp32-MFMA engine.
 Referee: the fixtures also hold the same reference modules run in fp64.  A gradient passes when the product is within 1e-3 of the global
 gradient scale of the fp32 reference, OR no further from the fp64 result than 3x the fp32 CPU reference itself is (the 3-D models
 normalise with batch-1 statistics over as few as 588 samples per channel, where the fp32 reference is 4e-3..1e-2 off the exact result)."""
@@ -34,8 +35,21 @@ def _inputs(cfg):
     return synth_brats(1, *c['size'], 1337)
 
 
+@pytest.fixture
+def engine_sel(request):
+    from segtran_amd import segx
+    L = segx.lib()
+    prev = L.set_engine(request.param)
+    L.x6_launches()
+    yield request.param
+    if request.param == 'x6':
+        assert L.x6_launches() > 50, 'the bf16x6 engine did not run'
+    L.set_engine(prev)
+
+
+@pytest.mark.parametrize('engine_sel', ['x6', 'f32'], indirect=True)
 @pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
-def test_fullshape_eval_every_label(cfg):
+def test_fullshape_eval_every_label(cfg, engine_sel):
     g = golden('full_' + cfg)
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)
     net.eval()
@@ -57,9 +71,10 @@ def test_fullshape_eval_every_label(cfg):
     assert (y.reshape(-1)[near] - g['near_val']).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('reassociated', [True, False], ids=['reassociated', 'reference-op-order'])
+@pytest.mark.parametrize('engine_sel,reassociated', [('x6', True), ('x6', False), ('f32', True)], indirect=['engine_sel'],
+                         ids=['x6-reassociated', 'x6-reference-op-order', 'f32-reassociated'])
 @pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
-def test_fullshape_train_step_gradients(cfg, reassociated, monkeypatch):
+def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)      # the size gate keeps its default (4096 rows)
     g = golden('full_' + cfg)

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 
 
+@pytest.fixture(params=['x6', 'f32'], autouse=True)
+def tile_engine(request):
+    """Every whole-model parity test runs on BOTH tile engines: bf16x6 (the product default) and the fp32 MFMA (segx_tune knob 4)."""
+    from segtran_amd import segx
+    L = segx.lib()
+    prev = L.set_engine(request.param)
+    yield request.param
+    L.set_engine(prev)
+
+
 def _grads_vs_golden(net, g, tol=1e-3, referee=False):
     named = dict(net.named_parameters())
     gscale = float(g['gscale'])

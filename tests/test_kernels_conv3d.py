@@ -116,15 +116,16 @@ def test_nonzero_mask_and_label_maps(backend):
 
 
 @pytest.mark.parametrize('B,Cin,Cout,size,k,stride', [(2, 8, 12, (4, 6, 5), (3, 3, 3), (1, 1, 1)), (1, 24, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)),
-                                                      (2, 16, 16, (5, 7, 7), (1, 3, 3), (1, 1, 1)), (1, 8, 8, (6, 8, 8), (3, 3, 3), (2, 2, 2))])
-def test_experimental_bf16x6_conv3d_matches_fp32(backend, B, Cin, Cout, size, k, stride):
-    """EXPERIMENTAL path (off by default): forward and backward-data convolutions through the implicit GEMM on the bf16 matrix core
-    (activations split into channels-last-8 bf16 planes); emulator only, see test_kernels_gemm.py."""
-    if backend.name != 'emu':
-        pytest.skip('device parity session of the experimental path is scheduled for the next round')
+                                                      (2, 16, 16, (5, 7, 7), (1, 3, 3), (1, 1, 1)), (1, 8, 8, (6, 8, 8), (3, 3, 3), (2, 2, 2)),
+                                                      (1, 8, 72, (4, 6, 10), (3, 3, 3), (1, 1, 1))])
+def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride):
+    """Forward, backward-data and backward-weight convolutions (packed contraction order) through the implicit GEMM on the bf16x6 engine:
+    same loaders on the global side, operands split into bf16 planes on their way into LDS.  Position counts that are not multiples of
+    8 / 32 and rows that wrap inside a thread's position octet (OW = 5, 7, 9, 10) exercise the incremental decode of the weight-gradient loader."""
     L = backend.L
-    L.use_bf16x6, L.bf16x6_min_dim, L.bf16x6_calls = True, 1, 0
+    prev = L.set_engine('x6')
     try:
+        L.x6_launches()
         dgrad = stride == (1, 1, 1)                      # the product differentiates strided convolutions w.r.t. x only for the 3-channel stem
         x = rnd(B, Cin, *size, seed=61).requires_grad_(dgrad)
         w = (rnd(Cout, Cin, *k, seed=62) * 0.2).requires_grad_(True)
@@ -137,6 +138,6 @@ def test_experimental_bf16x6_conv3d_matches_fp32(backend, B, Cin, Cout, size, k,
         if dgrad:
             close(x.grad, xr.grad, 1e-4)
         close(w.grad, wr.grad, 1e-4)
-        assert L.bf16x6_calls > 0                          # the experimental path really ran
+        assert L.x6_launches() >= 1                      # the engine really ran (forward; the backward passes where their operands are float4-legal)
     finally:
-        L.use_bf16x6, L.bf16x6_min_dim = False, 256
+        L.set_engine(prev)

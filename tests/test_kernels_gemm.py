@@ -172,57 +172,91 @@ def test_fusion_gemm_with_gelu_dropout_epilogue_mode_major(backend, p):
         assert (a.grad - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item()
 
 
-@pytest.mark.parametrize('variant', [1, 2], ids=['tile128x128x32', 'tile128x256x16'])
-@pytest.mark.parametrize('case', ['nt', 'nn_batched_bias', 'tn', 'tn_splitk', 'gelu', 'gmax_bcast'])
-def test_experimental_bf16x6_gemm_matches_fp32(backend, case, variant):
-    """EXPERIMENTAL path (off by default): the same descriptor evaluated by six bf16 MFMAs per block on operands
-    split into three bf16 planes.  Emulator only: the structure was timed on the box as a standalone prototype
-    (profiles/r01_l_bf16x6_proto.txt) but this entry point has not had its parity session on the device yet."""
-    if backend.name != 'emu':
-        pytest.skip('device parity session of the experimental path is scheduled for the next round')
+# ---- bf16x6 tile engine (gemm_x6.h): same entry point, same descriptor, fp32-equivalent results -----------------------------------------
+def _x6_case(L, dev, M, N, K, akc, bkc, nb=1, sk=1, tile=segx.TILE_AUTO, seed=0, **kw):
+    g = torch.Generator(device='cpu').manual_seed(seed + M * 7 + N * 3 + K)
+    A = torch.randn(nb, M, K, generator=g, device='cpu').to(dev)
+    B = (torch.randn(nb, N, K, generator=g, device='cpu') * 0.3).to(dev)
+    Am = A if akc else A.transpose(1, 2).contiguous()
+    Bm = B if bkc else B.transpose(1, 2).contiguous()
+    a_str = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+    b_str = (0, N * K, K, 1) if bkc else (0, N * K, 1, N)
+    C = torch.full((nb, M, N), float('nan'), device=dev)
+    ws = torch.empty(sk * nb * M * N, device=dev) if sk > 1 else None
+    L.gemm(Am, Bm, C, M, N, K, a_str, b_str, (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile, **kw)
+    return A, B, C
+
+
+@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x128, segx.TILE_64x64])
+@pytest.mark.parametrize('M,N,K,akc,bkc,sk', [(200, 136, 72, True, True, 1), (132, 260, 100, True, False, 1), (132, 84, 200, False, False, 3),
+                                              (68, 68, 64, False, True, 2), (256, 128, 32, False, False, 1), (52, 64, 8, True, False, 1)])
+def test_x6_engine_matches_fp64_every_tile_and_layout(backend, tile, M, N, K, akc, bkc, sk):
+    """bf16x6 engine: all four operand layouts, ragged edges in M, N and K, batches, alpha, per-row bias, split-K -- error against fp64
+    at fp32-rounding level (3e-6 of the result scale; the fp32 MFMA engine itself measures 1e-6 on these sizes)."""
     L = backend.L
-    g = torch.Generator(device='cpu').manual_seed(91)
-    mk = lambda *sh: torch.randn(*sh, generator=g, device='cpu')      # noqa: E731
-    L.use_bf16x6, L.bf16x6_min_dim, L.bf16x6_calls = True, 1, 0
-    assert L.c.segx_tune(3, variant) == 0
+    prev = L.set_engine('x6')
     try:
-        if case == 'nt':                                   # C = A B^T, edges in every dimension (M, N not multiples of 128, K not of 32)
-            A, B = mk(150, 70), mk(300, 70)
-            C = torch.full((150, 300), float('nan'))
-            L.gemm(A, B, C, 150, 300, 70, (0, 0, 70, 1), (0, 0, 70, 1), (0, 0, 300), alpha=0.5)
-            ref = 0.5 * A.double() @ B.double().t()
-        elif case == 'nn_batched_bias':                    # row-contiguous B, batch (2, 3), per-(z1) column bias
-            A, B, bias = mk(2, 3, 40, 48), mk(2, 3, 48, 36), mk(3, 36)
-            C = torch.full((2, 3, 40, 36), float('nan'))
-            L.gemm(A, B, C, 40, 36, 48, (3 * 40 * 48, 40 * 48, 48, 1), (3 * 48 * 36, 48 * 36, 1, 36), (3 * 40 * 36, 40 * 36, 36), nb=(2, 3),
-                   bias=bias, bias_mode=segx.BIAS_N, bias_b1=36)
-            ref = A.double() @ B.double() + bias.double()[None, :, None, :]
-        elif case == 'tn':                                 # both operands row-contiguous (weight-gradient layout)
-            A, B = mk(64, 50), mk(64, 45)                  # A^T B : [50, 45], K = 64
-            C = torch.full((50, 45), float('nan'))
-            L.gemm(A, B, C, 50, 45, 64, (0, 0, 1, 50), (0, 0, 1, 45), (0, 0, 45))
-            ref = A.double().t() @ B.double()
-        elif case == 'tn_splitk':                          # long K split over 3 slabs (+ row bias applied by the reduction), batch 2
-            A, B, bias = mk(2, 200, 40), mk(2, 200, 37), mk(40)
-            C = torch.full((2, 40, 37), float('nan'))
-            L.gemm(A, B, C, 40, 37, 200, (200 * 40, 0, 1, 40), (200 * 37, 0, 1, 37), (40 * 37, 0, 37), nb=(2, 1), alpha=0.25, bias=bias,
-                   bias_mode=segx.BIAS_M, splitk=3, workspace=torch.empty(3 * 2 * 40 * 37))
-            ref = 0.25 * A.double().transpose(1, 2) @ B.double() + bias.double()[None, :, None]
-        elif case == 'gelu':                               # fused bias + GELU (+ pre-activation), no dropout
-            A, B, bias = mk(37, 64), mk(41, 64), mk(41)
-            C, T = torch.full((37, 41), float('nan')), torch.full((37, 41), float('nan'))
-            L.gemm(A, B, C, 37, 41, 64, (0, 0, 64, 1), (0, 0, 64, 1), (0, 0, 41), bias=bias, bias_mode=segx.BIAS_N, epilogue=segx.EPI_GELU, aux=T)
-            pre = A.double() @ B.double().t() + bias.double()
-            assert (T.double() - pre).abs().max().item() <= 2e-6 * pre.abs().max().item()
-            ref = torch.nn.functional.gelu(pre)
-        else:                                              # A shared by the batch (stride 0), running max
-            A, B, gmax = mk(33, 40), mk(4, 29, 40), torch.zeros(1)
-            C = torch.full((4, 33, 29), float('nan'))
-            L.gemm(A, B, C, 33, 29, 40, (0, 0, 40, 1), (29 * 40, 0, 40, 1), (33 * 29, 0, 29), nb=(4, 1), gmax=gmax)
-            ref = torch.einsum('mk,bnk->bmn', A.double(), B.double())
-            assert abs(gmax.item() - max(0.0, ref.max().item())) <= 1e-5 * ref.abs().max().item()
-        assert (C.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), case
-        assert L.bf16x6_calls > 0                          # the experimental path really ran
+        L.x6_launches()
+        bias = torch.randn(M, generator=torch.Generator(device='cpu').manual_seed(1), device='cpu').to(backend.dev)
+        A, B, C = _x6_case(L, backend.dev, M, N, K, akc, bkc, nb=2, sk=sk, tile=tile, alpha=0.5, bias=bias, bias_mode=segx.BIAS_M)
+        assert L.x6_launches() == 1, 'the GEMM did not run on the bf16x6 engine'
     finally:
-        L.use_bf16x6, L.bf16x6_min_dim = False, 256
-        L.c.segx_tune(3, 1)
+        L.set_engine(prev)
+    ref = 0.5 * _ref(A, B) + bias.double()[None, :, None]
+    err = (C.double() - ref).abs().max().item()
+    assert err < 3e-6 * max(1.0, ref.abs().max().item()), err
+
+
+def test_x6_engine_planner_gmax_gelu_and_fallbacks(backend):
+    L = backend.L
+    dev = backend.dev
+    prev = L.set_engine('x6')
+    try:
+        L.x6_launches()
+        # (a) library-planned tile + split-K (splitk=0 path of the binding) on a weight-gradient shape
+        A, B, C = _x6_case(L, dev, 96, 80, 2048, False, False, nb=1, sk=0)
+        assert L.x6_launches() == 1
+        assert (C.double() - _ref(A, B)).abs().max().item() < 3e-6 * _ref(A, B).abs().max().item()
+        # (b) running max of the scores (N5 clip flag) in the epilogue
+        gmax = torch.zeros(1, device=dev)
+        A, B, C = _x6_case(L, dev, 72, 64, 48, True, True, gmax=gmax, alpha=0.25)
+        ref = 0.25 * _ref(A, B)
+        assert abs(gmax.item() - max(ref.max().item(), 0.0)) < 1e-5 and (C.double() - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+        # (c) fused bias + GELU + dropout epilogue (pre-activation in aux), per-mode bias
+        Mo, R, F = 2, 100, 64
+        g = torch.Generator(device='cpu').manual_seed(6)
+        H = torch.randn(Mo, R, F, generator=g, device='cpu').to(dev); W = (torch.randn(Mo, F, F, generator=g, device='cpu') * 0.3).to(dev)
+        b = torch.randn(Mo, F, generator=g, device='cpu').to(dev)
+        Y = torch.zeros(Mo, R, F, device=dev); T = torch.zeros(Mo, R, F, device=dev)
+        L.gemm(H, W, Y, R, F, F, (0, R * F, F, 1), (0, F * F, F, 1), (0, R * F, F), nb=(1, Mo), bias=b, bias_mode=segx.BIAS_N, bias_b1=F,
+               epilogue=segx.EPI_GELU, aux=T)
+        Tref = torch.einsum('mrf,mgf->mrg', H.double(), W.double()) + b[:, None, :].double()
+        assert (T.double() - Tref).abs().max().item() < 1e-5 and (Y.double() - torch.nn.functional.gelu(Tref)).abs().max().item() < 1e-5
+        assert L.x6_launches() == 2
+        # (d) skinny / odd operands stay on the fp32 engine
+        _x6_case(L, dev, 24, 256, 64, True, True)              # 24 rows: streamed through the 32-row fp32 tile
+        _x6_case(L, dev, 130, 70, 33, True, True)              # K = 33: not float4-legal
+        assert L.x6_launches() == 0
+    finally:
+        L.set_engine(prev)
+
+
+def test_x6_engine_k1792_accuracy_vs_fp32_engine(backend):
+    """The dominant contraction length of the model (K = 1792): both engines against fp64 -- the bf16x6 engine must be as accurate as the
+    fp32 MFMA (the parity bar of the whole step rests on this)."""
+    L = backend.L
+    M, N, K = 64, 64, 1792
+    prev = L.set_engine('f32')
+    try:
+        A, B, C32 = _x6_case(L, backend.dev, M, N, K, True, True, seed=3)
+        L.set_engine('x6')
+        _, _, C6 = _x6_case(L, backend.dev, M, N, K, True, True, seed=3)
+    finally:
+        L.set_engine(prev)
+    ref = _ref(A, B)
+    e32 = (C32.double() - ref).abs().max().item() / ref.abs().max().item()
+    e6 = (C6.double() - ref).abs().max().item() / ref.abs().max().item()
+    # device: measured 1.2e-6 vs 1.0e-6 (profiles/r01_l_bf16x6_proto.txt).  The emulator models the bf16 MFMA pessimistically -- as a
+    # sequential fp32 fmaf chain over all 16 products, six MFMAs per 16 k = 6x the rounding steps of the fp32 engine -- hence its looser bound
+    tol = 3e-6 if backend.name == 'hip' else 1.2e-5
+    assert e6 < tol and (backend.name != 'hip' or e6 < 3 * e32 + 1e-7), (e6, e32)

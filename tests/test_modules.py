@@ -141,17 +141,16 @@ def test_reassociation_is_gated_by_the_row_threshold(backend, monkeypatch):
     assert_close(y_reassoc, y_ref_order, 2e-5, 'both orders')
 
 
-def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
-    """Every GEMM of a squeeze-and-expansion layer (forward and backward, all layouts, split-K, fused epilogues) routed through the
-    EXPERIMENTAL bf16x6 path reproduces the reference fixture at the tolerances of the fp32-MFMA path.  Emulator only (see
-    test_kernels_gemm.py::test_experimental_bf16x6_gemm_matches_fp32)."""
-    if backend.name != 'emu':
-        pytest.skip('device parity session of the experimental path is scheduled for the next round')
+@pytest.mark.parametrize('tag,dims', [('squeeze_c64f64', [64, 64]), ('squeeze_c64f32', [64, 32])])
+def test_squeeze_layer_on_the_bf16x6_engine(backend, tag, dims):
+    """The squeeze-and-expansion layer with every eligible GEMM (forward and backward, all layouts, split-K, fused epilogues) on the
+    bf16x6 tile engine reproduces the reference fixture at the tolerances of the fp32-MFMA engine."""
     L = backend.L
-    L.use_bf16x6, L.bf16x6_min_dim, L.bf16x6_calls = True, 1, 0
+    prev = L.set_engine('x6')
     try:
-        g = golden_on('squeeze_c64f32', backend.dev)
-        mod = ss.SqueezedAttFeatTrans(mk_config([64, 32], 16), 'L').to('cpu')
+        L.x6_launches()
+        g = golden_on(tag, backend.dev)
+        mod = ss.SqueezedAttFeatTrans(mk_config(dims, 16), 'L').to('cpu')
         prefix = 'voxel_fusion.translayers.0.'
         load(mod, prefix)
         mod.eval()
@@ -161,9 +160,9 @@ def test_squeeze_layer_on_the_experimental_bf16x6_gemm(backend):
         (Y * g['G']).sum().backward()
         assert_close(X.grad, g['dX'], 1e-4, 'dX')
         check_grads(mod, prefix, g)
-        assert L.bf16x6_calls > 0                          # the experimental path really ran
+        assert L.x6_launches() >= 6                          # the engine really ran (projections + FFN, forward and backward)
     finally:
-        L.use_bf16x6, L.bf16x6_min_dim = False, 256
+        L.set_engine(prev)
 
 
 def test_fusion_encoder_vs_reference(backend):
