@@ -37,7 +37,8 @@ enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bia
  * SEGX_ENGINE_BF16X6 = fp32 operands split in registers into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per block (fp32-equivalent:
  * error vs fp64 1.2e-6 against 1.0e-6), used for float4-legal operands with more than 48 rows on both sides; everything else stays on F32 */
 enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
-enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5 };
+enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
+       SEGX_TILE_256x128 = 6 /* bf16x6 engine only */ };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
     int64_t a_b0, a_b1, a_m, a_k;
@@ -236,7 +237,8 @@ int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, ui
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
  * knob 4 = tile engine of segx_gemm_f32 and the
  * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4;
- * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
+ * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
+ * NOT the GEMM); knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);

@@ -35,14 +35,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
 
 // The same GEMM on the bf16x6 engine (gemm_x6.h): fp32 operands split into three bf16 planes on their way into LDS, six bf16 MFMAs per
 // block and 16 k.  WPE = resident waves per SIMD the register allocation must allow (LDS: 48 / 36 / 24 KB per workgroup).
-template <class Cfg, bool AKC, bool BKC, int EPI, int WPE>
+template <class Cfg, bool AKC, bool BKC, int EPI, int WPE, int VAR = 0>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void gemm_x6_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES];
     const TileCoord t = tile_coord<Cfg>(g);
     const DenseLoader6<AKC, Cfg::BM> la{g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M};
     const DenseLoader6<BKC, Cfg::BN> lb{g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N};
     f32x16 acc[Cfg::MI][Cfg::NJ];
-    gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_mainloop_x6<Cfg, DenseLoader6<AKC, Cfg::BM>, DenseLoader6<BKC, Cfg::BN>, VAR>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<EPI, Cfg>(acc, g, t);
 }
 
@@ -76,6 +76,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
 int g_engine = SEGX_ENGINE_F32;            // segx_tune(4, v): which tile engine the eligible GEMMs / convolutions run on
+int g_x6_variant = 0;                      // segx_tune(6, v): bench-only variants of the 128 x 128 k-contiguous kernel (gemm_x6.h)
 int g_x6_launches = 0;                     // segx_tune(5, 0): launches that ran on the bf16x6 engine since the last query (tests / sessions)
 // bf16x6 engine: float4-legal operands, neither side skinny (those GEMMs are HBM-bound and stream through the 32-row fp32 tiles)
 static bool x6_eligible(int M, int N, bool vec) { return g_engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
@@ -160,17 +161,17 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     const int nbatch = d->nb0 * d->nb1;
     g.c_split = (int64_t)nbatch * d->M * d->N;
     if (splitk > 1) g.C = d->workspace;
-    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_64x128, "segx_gemm_f32: bad tile %d", d->tile);
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_256x128 && (d->tile != SEGX_TILE_256x128 || g_engine == SEGX_ENGINE_BF16X6), "segx_gemm_f32: bad tile %d", d->tile);
     int tile = d->tile;
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
     bool x6 = x6_eligible(d->M, d->N, vec) && (!gelu || akc) &&
-              (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64);
+              (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64 || tile == SEGX_TILE_256x128);
     if (tile == SEGX_TILE_AUTO) {
         int sk_unused = 1;
         if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, &tile, &sk_unused);
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
-    if (!vec || gelu) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
+    if (!vec || gelu || (tile == SEGX_TILE_256x128 && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
 
     dim3 block(256);
     using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
@@ -189,11 +190,23 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else if (!akc && bkc) SEGX_LAUNCH6(CFG, false, true, SEGX_EPI_NONE, W); \
         else SEGX_LAUNCH6(CFG, false, false, SEGX_EPI_NONE, W);               \
     } while (0)
+        using Cfg256x128 = TileCfg<2, 2, 4, 2>;
+#define SEGX_LAUNCH6V(V)                                                                                   \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
+        hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, 3, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+    } while (0)
         if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
+        else if (g_x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
+            switch (g_x6_variant) { case 1: SEGX_LAUNCH6V(1); break; case 2: SEGX_LAUNCH6V(2); break; case 3: SEGX_LAUNCH6V(3); break;
+                                    case 4: SEGX_LAUNCH6V(4); break; default: SEGX_LAUNCH6V(5); break; }
+        }
+        else if (tile == SEGX_TILE_256x128) SEGX_LAUNCH6_LAYOUT(Cfg256x128, 2);
         else if (tile == SEGX_TILE_64x64) SEGX_LAUNCH6_LAYOUT(Cfg64, 5);
         else if (tile == SEGX_TILE_64x128) SEGX_LAUNCH6_LAYOUT(Cfg64x128, 4);
         else SEGX_LAUNCH6_LAYOUT(Cfg128, 3);
 #undef SEGX_LAUNCH6
+#undef SEGX_LAUNCH6V
 #undef SEGX_LAUNCH6_LAYOUT
     } else
 #define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \

@@ -105,7 +105,7 @@ struct DenseLoader6<true, ROWS> {
 // A wave's load covers ROWS consecutive floats of one k-row (whole 128-byte lines).
 template <int ROWS>
 struct DenseLoader6<false, ROWS> {
-    static_assert(ROWS == 128 || ROWS == 64, "row-contiguous x6 loader: 64 or 128 rows");
+    static_assert(ROWS == 256 || ROWS == 128 || ROWS == 64, "row-contiguous x6 loader: 64, 128 or 256 rows");
     static constexpr int KQ = ROWS / 16, NREG = 2 * KQ, RP = ROWS / 2;
     const float* base; int64_t s_row, s_k; int row0, rows;
     __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int tid) const {
@@ -132,7 +132,14 @@ struct DenseLoader6<false, ROWS> {
         const int row = 2 * (tid % RP), kg = tid / RP;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            if (KQ == 8) {
+            if (KQ == 16) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float v[8] = {r[16 * h + e], r[16 * h + 2 + e], r[16 * h + 4 + e], r[16 * h + 6 + e], r[16 * h + 8 + e], r[16 * h + 10 + e],
+                                        r[16 * h + 12 + e], r[16 * h + 14 + e]};
+                    x6_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, 2 * kg + h), v);
+                }
+            } else if (KQ == 8) {
                 const float v[8] = {r[e], r[2 + e], r[4 + e], r[6 + e], r[8 + e], r[10 + e], r[12 + e], r[14 + e]};
                 x6_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, kg), v);
             } else {
@@ -146,7 +153,10 @@ template <class Cfg> struct X6Lds { static constexpr int A_BYTES = 3 * X6Plane<C
 
 // acc += A_tile . B_tile^T over k in [kbeg, kend).  One LDS stage (48 KB at 128 x 128: three workgroups per CU cover each other's barriers --
 // measured in round 1: occupancy beats double buffering at this tile size), the next k-tile's global loads in flight under the MFMAs.
-template <class Cfg, class LA, class LB>
+// VAR (bench / bisect only, segx_tune knob 6; results are only defined for 0 and 1): 1 = raised wave priority during the MFMA phase;
+// ablations that leave parts of the k-tile loop out to price them: 2 = no split arithmetic, 3 = no LDS stores, 4 = no global loads after the
+// first tile, 5 = MFMAs and fragment reads only (no loads, stores or barriers).
+template <class Cfg, class LA, class LB, int VAR = 0>
 __device__ __forceinline__ void gemm_mainloop_x6(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const LA& la, const LB& lb, int kbeg, int kend,
                                                  unsigned char* __restrict__ lds) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ, PA = X6Plane<Cfg::BM>::bytes, PB = X6Plane<Cfg::BN>::bytes;
@@ -165,45 +175,76 @@ __device__ __forceinline__ void gemm_mainloop_x6(f32x16 (&acc)[Cfg::MI][Cfg::NJ]
     unsigned oka = la.load6(ra, kbeg, kend, tid), okb = lb.load6(rb, kbeg, kend, tid);
     const int arow = wm * (32 * MI) + (lane & 31), brow = wn * (32 * NJ) + (lane & 31), kh = lane >> 5;
     for (int kt = kbeg; kt < kend; kt += BKT) {
-        __syncthreads();                                  // every wave has read the previous tile's fragments
-        la.store6(ra, oka, LA_, tid);
-        lb.store6(rb, okb, LB_, tid);
-        __syncthreads();
-        if (kt + BKT < kend) { oka = la.load6(ra, kt + BKT, kend, tid); okb = lb.load6(rb, kt + BKT, kend, tid); }
+        if (VAR != 5) __syncthreads();                    // every wave has read the previous tile's fragments
+        if (VAR == 2) {                                   // ablation: the stores without the split arithmetic
+            unsigned* wa = reinterpret_cast<unsigned*>(LA_) + tid * 4; unsigned* wb = reinterpret_cast<unsigned*>(LB_) + tid * 4;
+#pragma unroll
+            for (int e = 0; e + 3 < LA::NREG; e += 4) *reinterpret_cast<float4*>(wa + 1024 * (e / 4)) = make_float4(ra[e], ra[e + 1], ra[e + 2], ra[e + 3]);
+#pragma unroll
+            for (int e = 0; e + 3 < LB::NREG; e += 4) *reinterpret_cast<float4*>(wb + 1024 * (e / 4)) = make_float4(rb[e], rb[e + 1], rb[e + 2], rb[e + 3]);
+        } else if (VAR != 3 && VAR != 5) {
+            la.store6(ra, oka, LA_, tid);
+            lb.store6(rb, okb, LB_, tid);
+        } else if (VAR == 3) {                            // keep the loaded values alive without storing them
+#pragma unroll
+            for (int e = 0; e < LA::NREG; ++e) asm volatile("" :: "v"(ra[e]));
+#pragma unroll
+            for (int e = 0; e < LB::NREG; ++e) asm volatile("" :: "v"(rb[e]));
+        }
+        if (VAR != 5) __syncthreads();
+        if (VAR < 4 && kt + BKT < kend) { oka = la.load6(ra, kt + BKT, kend, tid); okb = lb.load6(rb, kt + BKT, kend, tid); }
+        if (VAR == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int chunk = 2 * s + kh;                 // lane -> (row lane & 31, the 8 k of half lane >> 5 of this 16-k step)
-            bf16x8 a[MI][3];
+#define SEGX_X6_MFMA6(C, A_, B_)                                                                               \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[2], C, 0, 0, 0);     /* hi . lo   */                \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[2], B_[0], C, 0, 0, 0);     /* lo . hi   */                \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[1], C, 0, 0, 0);     /* mid . mid */                \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[1], C, 0, 0, 0);     /* hi . mid  */                \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[1], B_[0], C, 0, 0, 0);     /* mid . hi  */                \
+    C = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[0], C, 0, 0, 0);     /* hi . hi   */
+            if (MI > NJ) {                                // tall wave tile: the NJ x 3 B fragments stay, the A fragments stream one row block at a time
+                bf16x8 b[NJ][3];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(LA_ + p * PA + x6_off(arow + 32 * i, chunk));
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {                // one column block at a time: 3 B fragments live beside the MI x 3 A fragments
-                bf16x8 b[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(LB_ + p * PB + x6_off(brow + 32 * j, chunk));
+                    for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(LB_ + p * PB + x6_off(brow + 32 * j, chunk));
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);     // hi . lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);     // lo . hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);     // mid . mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);     // hi . mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);     // mid . hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);     // hi . hi
-                    acc[i][j] = c;
+                    bf16x8 a[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(LA_ + p * PA + x6_off(arow + 32 * i, chunk));
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { f32x16 c = acc[i][j]; SEGX_X6_MFMA6(c, a, b[j]) acc[i][j] = c; }
+                }
+            } else {                                      // the MI x 3 A fragments stay, one column block of B at a time
+                bf16x8 a[MI][3];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(LA_ + p * PA + x6_off(arow + 32 * i, chunk));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(LB_ + p * PB + x6_off(brow + 32 * j, chunk));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) { f32x16 c = acc[i][j]; SEGX_X6_MFMA6(c, a[i], b) acc[i][j] = c; }
                 }
             }
+#undef SEGX_X6_MFMA6
         }
+        if (VAR == 1) __builtin_amdgcn_s_setprio(0);
     }
 }
 
 // host-side cost model of this engine (same form as kTiles / model_us of gemm_core.h; constants from the r02 device sweeps)
 struct TileInfo6 { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };
-static const TileInfo6 kTiles6[] = {{SEGX_TILE_128x128, 128, 128, 3, 3.0f, 4.0f},
-                                    {SEGX_TILE_64x128, 64, 128, 4, 2.2f, 2.5f},
-                                    {SEGX_TILE_64x64, 64, 64, 6, 1.7f, 1.5f}};
+// r02_a sweep (24576 x 1792 x 1792 x 4: 3.54 / 4.03 / 4.54 ms on 14 / 21 / 28 rounds of 56 k-tiles): 4.5 / 3.4 / 2.9 us per k-tile and round
+static const TileInfo6 kTiles6[] = {{SEGX_TILE_128x128, 128, 128, 3, 4.5f, 4.0f},
+                                    {SEGX_TILE_64x128, 64, 128, 4, 3.4f, 2.5f},
+                                    {SEGX_TILE_64x64, 64, 64, 6, 2.9f, 1.5f}};
 inline double model_us6(const TileInfo6& ti, int M, int N, int K, int nbatch, int sk) {
     const TileInfo t{ti.id, ti.bm, ti.bn, ti.wg_per_cu, ti.ktile_us, ti.fixed_us};
     return model_us(t, M, N, K, nbatch, sk);

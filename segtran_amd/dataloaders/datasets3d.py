@@ -15,17 +15,18 @@ def RandomResizedCrop(volume, mask, out_size, crop_percents, isotropic=True):
     from .. import functional as SF
     H, W, D = (int(v) for v in volume.shape[-3:])
     min_scale, max_scale = 1 + crop_percents[0], 1 + crop_percents[1]
-    scale_H = torch.rand(1) * (max_scale - min_scale) + min_scale
+    # device='cpu': the reference draws from torch's CPU generator (default device); never from the GPU one, whatever the default device is
+    scale_H = torch.rand(1, device='cpu') * (max_scale - min_scale) + min_scale
     if isotropic:
         scale_W = scale_D = scale_H
     else:
-        scale_W = torch.rand(1) * (max_scale - min_scale) + min_scale
-        scale_D = torch.rand(1) * (max_scale - min_scale) + min_scale
+        scale_W = torch.rand(1, device='cpu') * (max_scale - min_scale) + min_scale
+        scale_D = torch.rand(1, device='cpu') * (max_scale - min_scale) + min_scale
     H2, W2, D2 = int(H * scale_H), int(W * scale_W), int(D * scale_D)          # float32 tensor arithmetic, truncated: as the reference
     Ho, Wo, Do = (int(v) for v in out_size)
     pads = [max(o - n, 0) // 2 for o, n in ((Ho, H2), (Wo, W2), (Do, D2))]      # front pads (:637-645)
     Hp, Wp, Dp = max(H2, Ho), max(W2, Wo), max(D2, Do)                          # padded extents
-    starts = [int(torch.randint(Hp - Ho + 1, (1,))), int(torch.randint(Wp - Wo + 1, (1,))), int(torch.randint(Dp - Do + 1, (1,)))]
+    starts = [int(torch.randint(n, (1,), device='cpu')) for n in (Hp - Ho + 1, Wp - Wo + 1, Dp - Do + 1)]
     offs = [s - p for s, p in zip(starts, pads)]
     return (SF.resized_crop3d(volume, (H2, W2, D2), (Ho, Wo, Do), offs), SF.resized_crop3d(mask, (H2, W2, D2), (Ho, Wo, Do), offs))
 

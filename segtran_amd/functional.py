@@ -633,10 +633,31 @@ class _BNAct(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+_bn_ticks = None          # a list while a model forward defers the `num_batches_tracked += 1` of its BatchNorm layers (defer_bn_ticks)
+
+
+def defer_bn_ticks():
+    """Segtran2d/3d.forward: collect the num_batches_tracked counters of the BatchNorm layers that run in training mode ..."""
+    global _bn_ticks
+    if _bn_ticks is None:
+        _bn_ticks = []
+
+
+def flush_bn_ticks():
+    """... and bump them with ONE multi-tensor launch at the end of the pass (96 layers in EfficientNet-B4: 96 scalar kernels otherwise)."""
+    global _bn_ticks
+    ticks, _bn_ticks = _bn_ticks, None
+    if ticks:
+        torch._foreach_add_(ticks, 1)
+
+
 def bn_act(x, bn, act=ACT_NONE):
     """nn.BatchNorm2d/3d module `bn` (parameter container) followed by an activation, fused."""
     if bn.training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _bn_ticks is not None:
+            _bn_ticks.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act)
 
 

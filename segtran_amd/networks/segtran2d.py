@@ -177,6 +177,13 @@ class Segtran2d(SegtranInitWeights):
         return _up(scores, size)
 
     def forward(self, batch):
+        SF.defer_bn_ticks()
+        try:
+            return self._forward(batch)
+        finally:
+            SF.flush_bn_ticks()               # one multi-tensor `num_batches_tracked += 1` for all BatchNorm layers of this pass
+
+    def _forward(self, batch):
         self.feature_maps = []
         B, C, H, W = batch.shape
         if H % 8 or W % 8:

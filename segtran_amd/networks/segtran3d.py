@@ -195,6 +195,13 @@ class Segtran3d(SegtranInitWeights):
         return _up(scores.permute(0, 1, 3, 4, 2), size)
 
     def forward(self, batch):
+        SF.defer_bn_ticks()
+        try:
+            return self._forward(batch)
+        finally:
+            SF.flush_bn_ticks()               # one multi-tensor `num_batches_tracked += 1` for all BatchNorm layers of this pass
+
+    def _forward(self, batch):
         B, C, H, W, D = batch.shape
         assert C == self.orig_in_channels
         if H % 8 or W % 8 or D % 8:

@@ -187,7 +187,7 @@ def _x6_case(L, dev, M, N, K, akc, bkc, nb=1, sk=1, tile=segx.TILE_AUTO, seed=0,
     return A, B, C
 
 
-@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x128, segx.TILE_64x64])
+@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x128, segx.TILE_64x64, segx.TILE_256x128])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk', [(200, 136, 72, True, True, 1), (132, 260, 100, True, False, 1), (132, 84, 200, False, False, 3),
                                               (68, 68, 64, False, True, 2), (256, 128, 32, False, False, 1), (52, 64, 8, True, False, 1)])
 def test_x6_engine_matches_fp64_every_tile_and_layout(backend, tile, M, N, K, akc, bkc, sk):

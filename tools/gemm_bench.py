@@ -9,7 +9,7 @@ L = segx.lib()
 dev = torch.device('cuda', 0)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 g = torch.Generator(device='cpu').manual_seed(0)
-NAMES = {0: 'auto', 1: '128x128', 2: '64x64', 3: '128x32', 4: '32x128', 5: '64x128'}
+NAMES = {0: 'auto', 1: '128x128', 2: '64x64', 3: '128x32', 4: '32x128', 5: '64x128', 6: '256x128'}
 
 
 def run(name, M, N, K, akc, bkc, splitk=1, nb=1, engine='x6', tile=0):
@@ -50,6 +50,18 @@ MAIN = [('group_linear fwd NT x4', 24576, 1792, 1792, True, True, 1, 4), ('group
         ('pw fwd 56->336', 336, 16384, 56, True, False, 1, 6), ('pw fwd 448->1792 head', 1792, 1024, 448, True, False, 1, 6),
         ('3d outfpn 832->4 comp', 832, 37632, 480, True, False, 1, 4), ('3d fpn 192->480', 480, 150528, 192, True, False, 1, 4)]
 
+if len(sys.argv) > 2 and sys.argv[2] == 'variants':
+    # what the parts of the 128 x 128 k-tile loop cost (segx_tune knob 6; variants >= 2 do NOT compute the GEMM), and the 256 x 128 tile
+    VN = {0: 'product', 1: 'setprio', 2: 'no split math', 3: 'no LDS stores', 4: 'no global loads', 5: 'MFMA + frag reads only'}
+    for sh in (MAIN[0], MAIN[8], MAIN[9], MAIN[6]):
+        for v in range(6):
+            L.c.segx_tune(6, v)
+            run('%s [%s]' % (sh[0][:14], VN[v]), *sh[1:7], nb=sh[7], engine='x6', tile=1)
+        L.c.segx_tune(6, 0)
+    for sh in MAIN[:10] + [('expand 112->672', 672, 4096, 112, True, False, 1, 6)]:
+        for tile in (1, 6, 5, 2):
+            run(sh[0], *sh[1:7], nb=sh[7], engine='x6', tile=tile)
+    sys.exit(0)
 if len(sys.argv) > 2 and sys.argv[2] == 'tiles':
     for sh in MAIN:
         run(sh[0], *sh[1:7], nb=sh[7], engine='f32', tile=0)
