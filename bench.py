@@ -151,6 +151,8 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
         ss.CrossAttFeatTrans.reassociate_projections = reassociated
         net_.fuse_output_tail = reassociated
+        if hasattr(net_, 'fuse_input_bridge'):
+            net_.fuse_input_bridge = reassociated          # 3-D: in_bridge_to3 composed into the stem filters
 
     net = engine.build_model(cfg_name, dev)
     set_op_order(net, not args.reference_op_order)

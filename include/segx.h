@@ -237,6 +237,7 @@ int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, ui
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
  * knob 4 = tile engine of segx_gemm_f32 and the
  * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4;
+ * knob 7 = 1: the weight gradient of every packed 3-D convolution on the bf16x6 engine (default: only where OW % 8 == 0 and the W stride is 1);
  * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
  * NOT the GEMM); knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
@@ -288,6 +289,14 @@ int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
 int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws /* Cout*Cin*KV floats of scratch */, int B, int Cout,
                                 const int* geom, void* stream);
+/* Input bridge composed into the I3D stem (segtran3d.py:420-423 feeding aj_i3d.py Conv3d_1a_7x7; exact re-association of two linear maps):
+ * Wc [O][Cc][T] = stem filters Ws [O][C3][T] contracted with the bridge Wb [C3][Cb]; channel Cb of Wc carries the bridge bias bb [C3] (NULL:
+ * none) for a constant-one input channel, channels above it are zero.  bwd: dWs, dWb, dbb from dWc by the chain rule. */
+int segx_stem_compose_fwd(const float* Ws, const float* Wb, const float* bb, float* Wc, int O, int C3, int Cb, int Cc, int T, void* stream);
+int segx_stem_compose_bwd(const float* dWc, const float* Ws, const float* Wb, const float* bb, float* dWs, float* dWb, float* dbb,
+                          int O, int C3, int Cb, int Cc, int T, void* stream);
+/* x [B][Cb][H][W][D] -> y [B][Cc][D][H][W]: depth moved in front (segtran3d.py:422), channel Cb = 1, channels above it = 0 */
+int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc, int H, int W, int D, void* stream);
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
 int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream);
 /* in-step label -> n-hot maps (datasets2d.py:90-139,200-223; datasets3d.py:16-40): mode 0 fundus uint8 [B,Cin,S] -> [B,3,S];

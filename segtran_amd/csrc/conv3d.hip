@@ -14,6 +14,7 @@ namespace segx {
 
 extern int g_engine;
 extern int g_x6_launches;
+int g_conv_x6_wgrad_all = 0;          // segx_tune(7, 1): weight gradients of EVERY packed convolution on the bf16x6 engine (tests of the general gather path)
 
 struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
@@ -218,12 +219,13 @@ struct ConvFwdLoaderB6 {
 // and 16 rows; the bf16 fragments need eight consecutive k (positions) of one row, so here a thread owns the position octet k0 + 8 (tid & 3) ..
 // + 7 and the TWO rows (tid >> 2) and 64 + (tid >> 2): the eight positions are decoded once (incrementally: ow, carry into oh, od) and serve
 // both rows; 16 lanes x 4 octets of a wave read 16 channels x 32 consecutive positions (128-byte runs wherever the octets stay in one image row).
+template <bool FASTW>
 struct ConvWgradLoaderB6 {
     static constexpr int NREG = 16;
-    const float* X; ConvGeom q; FastDiv dOHW, dOW;
+    const float* X; ConvGeom q; FastDiv dOHW, dOW, dSW;
     const int* rowinfo;                                        // LDS, per 8-row group: {channel-block offset (or -1), kd | kh<<10 | kw<<20}
     __device__ __forceinline__ ConvWgradLoaderB6(const float* X_, const ConvGeom& q_, int n0, int N, int* rowinfo_lds) : X(X_), q(q_), rowinfo(rowinfo_lds) {
-        dOHW = make_fastdiv(q.OH * q.OW); dOW = make_fastdiv(q.OW);
+        dOHW = make_fastdiv(q.OH * q.OW); dOW = make_fastdiv(q.OW); dSW = make_fastdiv(q.sw);
         const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, chan = q.ID * q.IH * q.IW;
         if (threadIdx.x < 16) {
             const int n = n0 + 8 * threadIdx.x;                                       // first row of the group; N % 8 == 0
@@ -246,6 +248,27 @@ struct ConvWgradLoaderB6 {
             kd[h] = tp & 1023; kh[h] = (tp >> 10) & 1023; kw[h] = tp >> 20;
         }
         unsigned okmask = 0;
+        if (FASTW) {
+            // OW % 8 == 0, unit stride along W, octets aligned to 8: the eight positions are eight consecutive ow of ONE output row, so the eight
+            // gathers of a row are eight consecutive floats of one input row -- one address, one (id, ih) test and an interval of valid j per row
+            const int npos = kend - p0;                                // < 8 only in the last k-tile (P % 8 != 0 cannot happen: OW % 8 == 0)
+            const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow * q.sw - q.pw;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int id = bd + kd[h], ih = bh + kh[h], iw0 = bw + kw[h];                 // position j reads iw0 + j * sw
+                const bool rok = npos > 0 && cb[h] >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH;
+                int lo = iw0 < 0 ? fdiv(-iw0 + q.sw - 1, dSW) : 0;
+                int hi = iw0 >= q.IW ? 0 : fdiv(q.IW - 1 - iw0, dSW) + 1;                    // first j with iw0 + j * sw >= IW
+                hi = hi > 8 ? 8 : hi; hi = hi > npos ? npos : hi;
+                if (!rok || hi < lo) { lo = 0; hi = 0; }
+                const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                const float* src = X + (m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[8 * h + j] = src[(((m >> j) & 1u) ? j : (m ? lo : 0)) * q.sw];
+                okmask |= m << (8 * h);
+            }
+            return okmask;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool pok = p0 + j < kend;
@@ -313,13 +336,13 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_fwd_x
     gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
-template <class Cfg, int WPE>
+template <class Cfg, int WPE, bool FASTW>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_wgrad_x6_kernel(GemmArgs g, ConvGeom q) {
     static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
     __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES + 128];
     const TileCoord t = tile_coord<Cfg>(g);
     const DenseLoader6<true, Cfg::BM> la{g.A + (int64_t)t.zb * g.a_b0, g.a_m, 1, t.m0, g.M};       // dY[b] [Cout][P]
-    const ConvWgradLoaderB6 lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, reinterpret_cast<int*>(lds + X6Lds<Cfg>::BYTES));   // X[b]
+    const ConvWgradLoaderB6<FASTW> lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N, reinterpret_cast<int*>(lds + X6Lds<Cfg>::BYTES));   // X[b]
     __syncthreads();
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
@@ -499,6 +522,66 @@ __global__ __launch_bounds__(256) void nonzero_mask_kernel(const float* __restri
             tot += s * inv;
         }
         out[idx] = tot > 0.f ? 1.0f : 0.f;
+    }
+}
+
+// ---- input bridge composed into the I3D stem (segtran3d.py:420-423 `in_bridge_to3` = Conv3d(4 -> 3, 1x1x1, bias) feeding Conv3d_1a_7x7) ------------
+// Two consecutive LINEAR maps: stem(pad0(Wb x + b)) = conv(pad0([x, 1, 0...]), Wc) with Wc[o][d][t] = sum_c Ws[o][c][t] Wb[c][d] for d < Cb,
+// Wc[o][Cb][t] = sum_c Ws[o][c][t] b[c] (the bias rides on a constant-one channel, which the zero 'same' padding switches off outside the
+// volume exactly as it switches off the padded bridge output), remaining channels zero (Cc = 8: the packed / bf16x6 contraction order).
+// With the composition the stride-2 7x7x7 transposed convolution onto 3 channels (5.4 ms of cfg4's step) is never needed: the input carries
+// no gradient, and dWs / dWb / db follow from dWc by the chain rule (stem_compose_bwd).
+__global__ __launch_bounds__(256) void stem_compose_fwd_kernel(const float* __restrict__ Ws, const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                               float* __restrict__ Wc, int O, int C3, int Cb, int Cc, int T) {
+    const int64_t total = (int64_t)O * Cc * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i % T); const int64_t r = i / T; const int d = (int)(r % Cc), o = (int)(r / Cc);
+        float v = 0.f;
+        if (d <= Cb) for (int c = 0; c < C3; ++c) v += Ws[((int64_t)o * C3 + c) * T + t] * (d < Cb ? Wb[c * Cb + d] : (bb ? bb[c] : 0.f));
+        Wc[i] = v;
+    }
+}
+// dWs[o][c][t] = sum_{d < Cb} dWc[o][d][t] Wb[c][d] + dWc[o][Cb][t] b[c]
+__global__ __launch_bounds__(256) void stem_compose_bwd_ws_kernel(const float* __restrict__ dWc, const float* __restrict__ Wb, const float* __restrict__ bb,
+                                                                  float* __restrict__ dWs, int O, int C3, int Cb, int Cc, int T) {
+    const int64_t total = (int64_t)O * C3 * T;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int t = (int)(i % T); const int64_t r = i / T; const int c = (int)(r % C3), o = (int)(r / C3);
+        const float* g = dWc + (int64_t)o * Cc * T + t;
+        float v = bb ? g[(int64_t)Cb * T] * bb[c] : 0.f;
+        for (int d = 0; d < Cb; ++d) v += g[(int64_t)d * T] * Wb[c * Cb + d];
+        dWs[i] = v;
+    }
+}
+// one workgroup per (c, d <= Cb): dWb[c][d] (d < Cb) / db[c] (d == Cb) = sum_{o, t} Ws[o][c][t] dWc[o][d][t], fixed summation order
+__global__ __launch_bounds__(256) void stem_compose_bwd_wb_kernel(const float* __restrict__ dWc, const float* __restrict__ Ws, float* __restrict__ dWb,
+                                                                  float* __restrict__ dbb, int O, int C3, int Cb, int Cc, int T) {
+    __shared__ float red[4];
+    const int c = blockIdx.x / (Cb + 1), d = blockIdx.x % (Cb + 1);
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < (int64_t)O * T; i += 256) {
+        const int o = (int)(i / T), t = (int)(i % T);
+        acc += Ws[((int64_t)o * C3 + c) * T + t] * dWc[((int64_t)o * Cc + d) * T + t];
+    }
+    const float tot = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) { if (d < Cb) dWb[c * Cb + d] = tot; else if (dbb) dbb[c] = tot; }
+}
+// x [B][Cb][H][W][D] -> x8 [B][Cc][D][H][W]: the volume with depth moved in front (the reference permutes after the bridge, :422), a constant-one
+// channel at index Cb and zero channels up to Cc.  Reads run along D (the input's contiguous axis), writes along W: tiles through LDS.
+__global__ __launch_bounds__(256) void bridge_input_kernel(const float* __restrict__ X, float* __restrict__ Y, int Cb, int Cc, int H, int W, int D) {
+    __shared__ float tile[32][33];
+    const int bc = blockIdx.z, b = bc / Cc, c = bc % Cc, h = blockIdx.y;
+    const int nwt = (W + 31) / 32, w0 = (blockIdx.x % nwt) * 32, d0 = (blockIdx.x / nwt) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (c < Cb) {
+        const float* x = X + (((int64_t)b * Cb + c) * H + h) * (int64_t)W * D;
+        for (int r = ty; r < 32; r += 8) { const int w = w0 + r, d = d0 + tx; tile[r][tx] = (w < W && d < D) ? x[(int64_t)w * D + d] : 0.f; }
+    }
+    __syncthreads();
+    float* y = Y + ((int64_t)b * Cc + c) * D * (int64_t)H * W;
+    for (int r = ty; r < 32; r += 8) {
+        const int d = d0 + r, w = w0 + tx;
+        if (d < D && w < W) y[((int64_t)d * H + h) * W + w] = c < Cb ? tile[tx][r] : (c == Cb ? 1.0f : 0.f);
     }
 }
 
@@ -745,10 +828,17 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
 #define SEGX_CONV_WG(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
                                   else hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6) {
+    // bf16x6 engine: where the eight positions of a thread are eight floats of one input row (OW % 8 == 0: the 56 x 56 stages,
+    // 2/3 of the weight-gradient FLOPs of I3D); elsewhere its per-position gather decode costs more VALU time than the six-fold
+    // faster matrix instruction saves (measured r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays
+    const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && (fastw || g_conv_x6_wgrad_all)) {
         ++g_x6_launches;
-        if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4>), grid, dim3(256), 0, stream, g, q);
-        else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3>), grid, dim3(256), 0, stream, g, q);
+        if (fastw) {
+            if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
+            else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, true>), grid, dim3(256), 0, stream, g, q);
+        } else if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, false>), grid, dim3(256), 0, stream, g, q);
+        else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, false>), grid, dim3(256), 0, stream, g, q);
     } else if (small && vec) SEGX_CONV_WG(true, CfgCout64);
     else if (small) SEGX_CONV_WG(false, CfgCout64);
     else if (vec) SEGX_CONV_WG(true, Cfg128);
@@ -841,6 +931,27 @@ extern "C" int segx_conv3d_bwd_data_direct(const float* dY, const float* W, floa
         default: return segx::fail(-1, "segx_conv3d_bwd_data_direct: built for Cin <= 4 (the I3D stem), got %d", q.Cin);
     }
     return check_launch("segx_conv3d_bwd_data_direct");
+}
+/* in_bridge_to3 composed into the I3D stem (see stem_compose_fwd_kernel): Wc [O][Cc][T] from Ws [O][C3][T], Wb [C3][Cb], bb [C3] (or NULL) */
+extern "C" int segx_stem_compose_fwd(const float* Ws, const float* Wb, const float* bb, float* Wc, int O, int C3, int Cb, int Cc, int T, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(Ws && Wb && Wc && O > 0 && C3 > 0 && Cb > 0 && Cc > Cb && T > 0, "segx_stem_compose_fwd: bad args");
+    const int64_t total = (int64_t)O * Cc * T;
+    hipLaunchKernelGGL(stem_compose_fwd_kernel, dim3((unsigned)i64min(4096, (total + 255) / 256)), dim3(256), 0, stream, Ws, Wb, bb, Wc, O, C3, Cb, Cc, T);
+    return check_launch("segx_stem_compose_fwd");
+}
+extern "C" int segx_stem_compose_bwd(const float* dWc, const float* Ws, const float* Wb, const float* bb, float* dWs, float* dWb, float* dbb,
+                                     int O, int C3, int Cb, int Cc, int T, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dWc && Ws && Wb && dWs && dWb && O > 0 && C3 > 0 && Cb > 0 && Cc > Cb && T > 0 && (!bb == !dbb), "segx_stem_compose_bwd: bad args");
+    const int64_t total = (int64_t)O * C3 * T;
+    hipLaunchKernelGGL(stem_compose_bwd_ws_kernel, dim3((unsigned)i64min(4096, (total + 255) / 256)), dim3(256), 0, stream, dWc, Wb, bb, dWs, O, C3, Cb, Cc, T);
+    hipLaunchKernelGGL(stem_compose_bwd_wb_kernel, dim3((unsigned)(C3 * (Cb + 1))), dim3(256), 0, stream, dWc, Ws, dWb, dbb, O, C3, Cb, Cc, T);
+    return check_launch("segx_stem_compose_bwd");
+}
+/* x [B][Cb][H][W][D] -> y [B][Cc][D][H][W]: depth first, a constant-one channel at index Cb, zero channels above it */
+extern "C" int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc, int H, int W, int D, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Y && B > 0 && Cb > 0 && Cc > Cb && H > 0 && W > 0 && D > 0 && (int64_t)B * Cc <= 65535 && H <= 65535, "segx_bridge_input: bad args");
+    hipLaunchKernelGGL(bridge_input_kernel, dim3((unsigned)(((W + 31) / 32) * ((D + 31) / 32)), (unsigned)H, (unsigned)(B * Cc)), dim3(256), 0, stream, X, Y, Cb, Cc, H, W, D);
+    return check_launch("segx_bridge_input");
 }
 extern "C" int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && out && B > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "segx_nonzero_mask: bad args");

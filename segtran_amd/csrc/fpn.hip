@@ -333,12 +333,13 @@ extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64
     return check_launch("segx_dropout");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
-namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; }
+namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; extern int g_conv_x6_wgrad_all; }
 extern "C" int segx_tune(int knob, int value) {
     if (knob == 1) { g_interp_variant = value; return 0; }
     if (knob == 2) { segx::g_conv_small_policy = value; return 0; }
     if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; const int prev = segx::g_engine; segx::g_engine = value; return prev; }
-    if (knob == 6) { if (value < 0 || value > 5) return -1; segx::g_x6_variant = value; return 0; }
+    if (knob == 7) { segx::g_conv_x6_wgrad_all = value ? 1 : 0; return 0; }
+    if (knob == 6) { if (value < 0 || value > 7) return -1; segx::g_x6_variant = value; return 0; }
     if (knob == 5) { const int n = segx::g_x6_launches; segx::g_x6_launches = 0; return n; }
     return -1;
 }

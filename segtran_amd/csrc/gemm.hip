@@ -191,15 +191,16 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else SEGX_LAUNCH6(CFG, false, false, SEGX_EPI_NONE, W);               \
     } while (0)
         using Cfg256x128 = TileCfg<2, 2, 4, 2>;
-#define SEGX_LAUNCH6V(V)                                                                                   \
+#define SEGX_LAUNCH6V(V, W)                                                                                \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
-        hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, 3, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+        hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
         if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
         else if (g_x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
-            switch (g_x6_variant) { case 1: SEGX_LAUNCH6V(1); break; case 2: SEGX_LAUNCH6V(2); break; case 3: SEGX_LAUNCH6V(3); break;
-                                    case 4: SEGX_LAUNCH6V(4); break; default: SEGX_LAUNCH6V(5); break; }
+            switch (g_x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 2: SEGX_LAUNCH6V(2, 3); break; case 3: SEGX_LAUNCH6V(3, 3); break;
+                                    case 4: SEGX_LAUNCH6V(4, 3); break; case 5: SEGX_LAUNCH6V(5, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;
+                                    default: SEGX_LAUNCH6V(0, 2); break; }      // 7: the product schedule at two waves per SIMD (what the split-early schedule is compared with)
         }
         else if (tile == SEGX_TILE_256x128) SEGX_LAUNCH6_LAYOUT(Cfg256x128, 2);
         else if (tile == SEGX_TILE_64x64) SEGX_LAUNCH6_LAYOUT(Cfg64, 5);

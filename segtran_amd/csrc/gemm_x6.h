@@ -67,6 +67,26 @@ __device__ __forceinline__ void x6_store4(unsigned char* __restrict__ P, int off
     *reinterpret_cast<uint2*>(P + 2 * PLANE_BYTES + off) = l;
 }
 
+// packed form (split now, store later): 2 fp32 registers -> 3 dwords of bf16 pairs; a group of 8 k -> uint4 per plane, of 4 k -> uint2 per plane
+struct Packed8 { uint4 h, m, l; };
+struct Packed4 { uint2 h, m, l; };
+__device__ __forceinline__ Packed8 x6_split8(const float (&v)[8]) {
+    const Split2 a = split3_pair(v[0], v[1]), b = split3_pair(v[2], v[3]), c = split3_pair(v[4], v[5]), d = split3_pair(v[6], v[7]);
+    Packed8 o; o.h = make_uint4(a.h, b.h, c.h, d.h); o.m = make_uint4(a.m, b.m, c.m, d.m); o.l = make_uint4(a.l, b.l, c.l, d.l);
+    return o;
+}
+__device__ __forceinline__ Packed4 x6_split4(float v0, float v1, float v2, float v3) {
+    const Split2 a = split3_pair(v0, v1), b = split3_pair(v2, v3);
+    Packed4 o; o.h.x = a.h; o.h.y = b.h; o.m.x = a.m; o.m.y = b.m; o.l.x = a.l; o.l.y = b.l;
+    return o;
+}
+template <int PLANE_BYTES> __device__ __forceinline__ void x6_put8(unsigned char* __restrict__ P, int off, const Packed8& v) {
+    *reinterpret_cast<uint4*>(P + off) = v.h; *reinterpret_cast<uint4*>(P + PLANE_BYTES + off) = v.m; *reinterpret_cast<uint4*>(P + 2 * PLANE_BYTES + off) = v.l;
+}
+template <int PLANE_BYTES> __device__ __forceinline__ void x6_put4(unsigned char* __restrict__ P, int off, const Packed4& v) {
+    *reinterpret_cast<uint2*>(P + off) = v.h; *reinterpret_cast<uint2*>(P + PLANE_BYTES + off) = v.m; *reinterpret_cast<uint2*>(P + 2 * PLANE_BYTES + off) = v.l;
+}
+
 // ---- dense operand loaders (float4-legal operands only: the host sends everything else to the fp32 engine) ---------------------------
 // Loader concept of this engine: NREG fp32 registers per thread and k-tile;
 //   unsigned load6(float (&r)[NREG], int k0, int kend, int tid) const   global -> registers (unconditional clamped loads) + validity mask
@@ -96,6 +116,24 @@ struct DenseLoader6<true, ROWS> {
         for (int i = 0; i < NPT; ++i) {
             const int f = tid + 256 * i, row = f >> 3, kc = f & 7;
             x6_store4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+        }
+    }
+    // split-early form (the split runs under the MFMAs of the previous k-tile, the packed registers are stored after the barrier)
+    struct Packed { Packed4 g[NPT]; };
+    __device__ __forceinline__ void split6(float (&r)[NREG], unsigned okmask, Packed& pk) const {
+        const unsigned full = NPT == 8 ? 0xFFFFFFFFu : ((1u << (4 * NPT)) - 1u);
+        if (okmask != full) {
+#pragma unroll
+            for (int e = 0; e < NREG; ++e) r[e] = ((okmask >> e) & 1u) ? r[e] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) pk.g[i] = x6_split4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    }
+    __device__ __forceinline__ void storep6(const Packed& pk, unsigned char* __restrict__ P, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, kc = f & 7;
+            x6_put4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), pk.g[i]);
         }
     }
 };
@@ -147,13 +185,49 @@ struct DenseLoader6<false, ROWS> {
             }
         }
     }
+    struct Packed { Packed8 g8[KQ >= 8 ? KQ / 4 : 1]; Packed4 g4[2]; };       // KQ 16: 2 rows x 2 octets; 8: 2 rows x 1 octet; 4: 2 rows x 1 quad
+    __device__ __forceinline__ void split6(float (&r)[NREG], unsigned okmask, Packed& pk) const {
+        const unsigned full = (1u << NREG) - 1u;
+        if (okmask != full) {
+#pragma unroll
+            for (int e = 0; e < NREG; ++e) r[e] = ((okmask >> e) & 1u) ? r[e] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (KQ >= 8) {
+#pragma unroll
+                for (int h = 0; h < KQ / 8; ++h) {
+                    const float v[8] = {r[16 * h + e], r[16 * h + 2 + e], r[16 * h + 4 + e], r[16 * h + 6 + e], r[16 * h + 8 + e], r[16 * h + 10 + e],
+                                        r[16 * h + 12 + e], r[16 * h + 14 + e]};
+                    pk.g8[e * (KQ / 8) + h] = x6_split8(v);
+                }
+            } else {
+                pk.g4[e] = x6_split4(r[e], r[2 + e], r[4 + e], r[6 + e]);
+            }
+        }
+    }
+    __device__ __forceinline__ void storep6(const Packed& pk, unsigned char* __restrict__ P, int tid) const {
+        const int row = 2 * (tid % RP), kg = tid / RP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            if (KQ >= 8) {
+#pragma unroll
+                for (int h = 0; h < KQ / 8; ++h) x6_put8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, (KQ / 8) * kg + h), pk.g8[e * (KQ / 8) + h]);
+            } else {
+                x6_put4<X6Plane<ROWS>::bytes>(P, x6_off(row + e, kg >> 1) + ((kg & 1) << 3), pk.g4[e]);
+            }
+        }
+    }
 };
 
 template <class Cfg> struct X6Lds { static constexpr int A_BYTES = 3 * X6Plane<Cfg::BM>::bytes, B_BYTES = 3 * X6Plane<Cfg::BN>::bytes, BYTES = A_BYTES + B_BYTES; };
 
 // acc += A_tile . B_tile^T over k in [kbeg, kend).  One LDS stage (48 KB at 128 x 128: three workgroups per CU cover each other's barriers --
 // measured in round 1: occupancy beats double buffering at this tile size), the next k-tile's global loads in flight under the MFMAs.
-// VAR (bench / bisect only, segx_tune knob 6; results are only defined for 0 and 1): 1 = raised wave priority during the MFMA phase;
+// VAR 6 = split-early schedule (a product candidate: same results as 0): the next tile's registers are split into packed bf16 between the two
+// 16-k MFMA groups of the current tile, so that the conversion arithmetic issues under matrix instructions of the SAME wave; after the
+// barrier only the packed stores remain.
+// VAR (bench / bisect only, segx_tune knob 6; results are only defined for 0, 1 and 6): 1 = raised wave priority during the MFMA phase;
 // ablations that leave parts of the k-tile loop out to price them: 2 = no split arithmetic, 3 = no LDS stores, 4 = no global loads after the
 // first tile, 5 = MFMAs and fragment reads only (no loads, stores or barriers).
 template <class Cfg, class LA, class LB, int VAR = 0>
@@ -174,6 +248,54 @@ __device__ __forceinline__ void gemm_mainloop_x6(f32x16 (&acc)[Cfg::MI][Cfg::NJ]
     float ra[LA::NREG], rb[LB::NREG];
     unsigned oka = la.load6(ra, kbeg, kend, tid), okb = lb.load6(rb, kbeg, kend, tid);
     const int arow = wm * (32 * MI) + (lane & 31), brow = wn * (32 * NJ) + (lane & 31), kh = lane >> 5;
+    if constexpr (VAR == 6) {
+        typename LA::Packed pa; typename LB::Packed pb;
+        la.split6(ra, oka, pa); lb.split6(rb, okb, pb);
+        for (int kt = kbeg; kt < kend; kt += BKT) {
+            __syncthreads();
+            la.storep6(pa, LA_, tid); lb.storep6(pb, LB_, tid);
+            __syncthreads();
+            const bool more = kt + BKT < kend;
+            if (more) { oka = la.load6(ra, kt + BKT, kend, tid); okb = lb.load6(rb, kt + BKT, kend, tid); }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int chunk = 2 * s + kh;
+                bf16x8 a[MI][3];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) a[i][p] = *reinterpret_cast<const bf16x8*>(LA_ + p * PA + x6_off(arow + 32 * i, chunk));
+                // the next tile's conversion arithmetic, UNCONDITIONALLY (after the last tile it converts stale registers, nothing is stored):
+                // in one basic block with the second 16-k MFMA group, and dealt out between its matrix instructions by the scheduling hints below
+                if (s == 1) { la.split6(ra, oka, pa); lb.split6(rb, okb, pb); }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bf16x8 b[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(LB_ + p * PB + x6_off(brow + 32 * j, chunk));
+#pragma unroll
+                    for (int i = 0; i < MI; ++i) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+                }
+                if (s == 1) {
+#pragma unroll
+                    for (int q = 0; q < MI * NJ * 6; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);       // five VALU (4.5 per element pair x 24 pairs / 24 MFMAs)
+                    }
+                }
+            }
+        }
+        return;
+    }
     for (int kt = kbeg; kt < kend; kt += BKT) {
         if (VAR != 5) __syncthreads();                    // every wave has read the previous tile's fragments
         if (VAR == 2) {                                   // ablation: the stores without the split arithmetic

@@ -1022,6 +1022,47 @@ def conv3d_same(x, w, stride=(1, 1, 1)):
     return _Conv3d.apply(x, w, stride, _same_pads(x.shape[2:], w.shape[2:], stride))
 
 
+class _StemCompose(torch.autograd.Function):
+    """Wc [O, Cc, *k] = stem filters [O, C3, *k] composed with the input bridge (weight [C3, Cb, 1, 1, 1], bias [C3]); see segx_stem_compose_fwd."""
+
+    @staticmethod
+    def forward(ctx, ws, wb, bb, Cc):
+        L = segx.lib()
+        ws, wb = _c(ws), _c(wb)
+        O, C3 = ws.shape[:2]
+        T = ws[0, 0].numel()
+        Cb = wb.shape[1]
+        wc = _empty(ws, O, Cc, *ws.shape[2:])
+        L.stem_compose_fwd(ws, wb, bb, wc, O, C3, Cb, Cc, T)
+        ctx.dims = (O, C3, Cb, Cc, T)
+        ctx.save_for_backward(ws, wb, bb)
+        return wc
+
+    @staticmethod
+    def backward(ctx, dwc):
+        L = segx.lib()
+        ws, wb, bb = ctx.saved_tensors
+        O, C3, Cb, Cc, T = ctx.dims
+        dws, dwb = torch.empty_like(ws), torch.empty_like(wb)
+        dbb = torch.empty_like(bb) if bb is not None else None
+        L.stem_compose_bwd(_c(dwc), ws, wb, bb, dws, dwb, dbb, O, C3, Cb, Cc, T)
+        return dws, dwb, dbb, None
+
+
+def stem_compose(stem_weight, bridge_weight, bridge_bias, Cc=8):
+    return _StemCompose.apply(stem_weight, bridge_weight, bridge_bias, int(Cc))
+
+
+def bridge_input(x, Cc=8):
+    """[B, Cb, H, W, D] -> [B, Cc, D, H, W] with a constant-one channel at index Cb and zeros above it (no gradient: network input)."""
+    L = segx.lib()
+    x = _c(x.detach())
+    B, Cb, H, W, D = x.shape
+    y = _empty(x, B, Cc, D, H, W)
+    L.bridge_input(x, y, B, Cb, Cc, H, W, D)
+    return y
+
+
 class _MaxPool3d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, kernel, stride, pads):

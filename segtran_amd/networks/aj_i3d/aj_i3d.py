@@ -6,23 +6,15 @@ dynamic TF-'same' zero padding of N7 (front = pad // 2; aj_i3d.py:8-30, 68-90) a
 
 Kernel status: everything runs on libsegx -- the 38 1x1x1 convolutions on the MFMA GEMM, the 7x7x7 stem and the 19
 3x3x3 convolutions as implicit GEMM on the same MFMA engine (conv3d.hip: forward, backward-data, backward-weight),
-BatchNorm3d+ReLU as one fused kernel (backbone.hip), the 'same' max-pools in conv3d.hip.  One exception: the
-backward-DATA of the stride-2 stem (a transposed convolution onto 3 channels) is still an ATen/MIOpen call.
+BatchNorm3d+ReLU as one fused kernel (backbone.hip), the 'same' max-pools in conv3d.hip; the backward-data of the stride-2 stem
+(a transposed convolution onto 3 channels) is the residue-class gather kernel of conv3d.hip -- and is not needed at all when Segtran3d
+composes its input bridge into the stem filters (the default).  No ATen / MIOpen / rocBLAS arithmetic anywhere.
 """
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import functional as SF
-
-
-def _same_pad(x, kernel, stride):
-    pads = []
-    for dim in (2, 1, 0):
-        s, k, size = stride[dim], kernel[dim], x.shape[2 + dim]
-        tot = max(k - s, 0) if size % s == 0 else max(k - (size % s), 0)
-        pads += [tot // 2, tot - tot // 2]
-    return F.pad(x, pads) if any(pads) else x
 
 
 class MaxPool3dSamePadding(nn.MaxPool3d):
@@ -42,8 +34,11 @@ class Unit3D(nn.Module):
             self.bn = nn.BatchNorm3d(output_channels, eps=0.001, momentum=0.01)
         self.pointwise = self._kernel_shape == (1, 1, 1) and self._stride == (1, 1, 1)
 
-    def forward(self, x):
-        if self.pointwise:
+    def forward(self, x, conv_out=None):
+        """conv_out: the convolution's output computed by the caller (Segtran3d composes its input bridge into the stem's filters)."""
+        if conv_out is not None:
+            x = conv_out
+        elif self.pointwise:
             x = SF.conv1x1(x, self.conv3d.weight, self.conv3d.bias)            # libsegx MFMA GEMM
         else:
             assert self.conv3d.bias is None
@@ -103,10 +98,14 @@ class InceptionI3d(nn.Module):
         for k, m in ep.items():
             self.add_module(k, m)
 
-    def extract_features(self, x):
+    def extract_features(self, x, stem_conv_out=None):
+        """stem_conv_out: output of the (bias-free) stem convolution computed by the caller; `x` is then not read."""
         feat = {}
         for name in self.VALID_ENDPOINTS:
             if name in self.end_points:
-                x = self._modules[name](x)
+                if name == 'Conv3d_1a_7x7' and stem_conv_out is not None:
+                    x = self._modules[name](None, conv_out=stem_conv_out)
+                else:
+                    x = self._modules[name](x)
                 feat[name] = x
         return feat

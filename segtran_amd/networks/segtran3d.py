@@ -131,6 +131,7 @@ class Segtran3d(SegtranInitWeights):
             self.in_gn4b = nn.GroupNorm(self.G, d[4])
         self.out_fpn_do_dropout = config.out_fpn_do_dropout      # --outdrop (:392-394)
         self.fuse_output_tail = True                             # see out_head_forward
+        self.fuse_input_bridge = True                            # see _forward: in_bridge_to3 composed into the stem filters
         self.num_classes = config.num_classes
         self.do_out_fpn = True
         self.out_fpn_out_dim = self.out_feat_dim = self.trans_out_dim
@@ -206,9 +207,21 @@ class Segtran3d(SegtranInitWeights):
         assert C == self.orig_in_channels
         if H % 8 or W % 8 or D % 8:
             raise ValueError('Segtran3d needs H, W, D divisible by 8 (reference segtran3d.py:450), got %s' % ((H, W, D),))
-        rgb = self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3)                    # [B,3,D,H,W]
-        nonzero_mask = self.get_mask(rgb)
-        fd = self.backbone.extract_features(rgb)
+        stem = self.backbone.Conv3d_1a_7x7
+        if self.fuse_input_bridge and not isinstance(self.in_bridge_to3, nn.Identity) and stem.conv3d.bias is None and self.eff_in_channels < 8:
+            # in_bridge_to3 (a pointwise linear map with bias, :420) feeds the 7x7x7 stem directly: the two are composed into ONE 8-channel
+            # convolution ([x, 1, 0, 0, 0] -> 64; the bias rides on the constant-one channel, which the zero padding switches off outside the
+            # volume exactly like the padded bridge output).  Same function and, through SF.stem_compose's chain rule, the same gradient for
+            # every parameter; what disappears is the stride-2 transposed convolution onto the 3-channel image (5.4 ms of the cfg4 step) and
+            # the bridge's own backward GEMMs.  The foreground mask still needs the bridged image itself (:425) -- forward only.
+            with torch.no_grad():
+                nonzero_mask = self.get_mask(self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3))
+            wc = SF.stem_compose(stem.conv3d.weight, self.in_bridge_to3.weight, self.in_bridge_to3.bias, 8)
+            fd = self.backbone.extract_features(None, stem_conv_out=SF.conv3d_same(SF.bridge_input(batch, 8), wc, stem._stride))
+        else:
+            rgb = self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3)                # [B,3,D,H,W]  (reference op order: fuse_input_bridge = False)
+            nonzero_mask = self.get_mask(rgb)
+            fd = self.backbone.extract_features(rgb)
         feats = (fd['MaxPool3d_2a_3x3'], fd['Conv3d_2c_3x3'], fd['Mixed_3c'], fd['Mixed_4f'], fd['Mixed_5c'])
         vfeat, vmask, D2, H2, W2 = self.in_fpn_forward(feats, nonzero_mask)
         xyz_shape = torch.Size((D2, H2, W2))

@@ -352,6 +352,15 @@ class SegxLib:
         rc = self.c.segx_conv3d_bwd_data_direct(_ptr(dY), _ptr(W), _ptr(dX), _ptr(wt), B, Cout, self._geom(geom), self.stream(dX))
         self.check(rc, 'segx_conv3d_bwd_data_direct')
 
+    def stem_compose_fwd(self, Ws, Wb, bb, Wc, O, C3, Cb, Cc, T):
+        self._call('segx_stem_compose_fwd', Wc, Ws, Wb, bb, Wc, O, C3, Cb, Cc, T)
+
+    def stem_compose_bwd(self, dWc, Ws, Wb, bb, dWs, dWb, dbb, O, C3, Cb, Cc, T):
+        self._call('segx_stem_compose_bwd', dWc, dWc, Ws, Wb, bb, dWs, dWb, dbb, O, C3, Cb, Cc, T)
+
+    def bridge_input(self, X, Y, B, Cb, Cc, H, W, D):
+        self._call('segx_bridge_input', X, X, Y, B, Cb, Cc, H, W, D)
+
     def nonzero_mask(self, X, out, B, C, D, H, W, kd, kh, kw):
         self._call('segx_nonzero_mask', X, X, out, B, C, D, H, W, kd, kh, kw)
 
@@ -423,7 +432,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
-    'segx_tune': 'ii', 'segx_resized_crop3d': 'pplpp', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',

@@ -172,6 +172,7 @@ static inline void __syncthreads() { hipemu::block_sync(); }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_32x32x16bf16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 
 template <class T> static inline T __shfl(T v, int src, int width = 64) {
     int l = hipemu::S.cur->lane; int base = l - (l % width); return hipemu::shfl_idx(v, base + (src % width)); }

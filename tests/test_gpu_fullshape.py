@@ -81,6 +81,8 @@ def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypat
     c = engine.CONFIGS[cfg]
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)
     net.fuse_output_tail = reassociated
+    if c['dim'] == 3:
+        net.fuse_input_bridge = reassociated
     if c['dim'] == 2:
         net.backbone.drop_connect_rate = 0.0
     net.train()

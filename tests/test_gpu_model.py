@@ -160,7 +160,7 @@ def test_segtran3d_vs_reference(tag, train, fused_tail, monkeypatch):
     g = golden(tag)
     c = dict(engine.CONFIGS['cfg4'], size=(112, 112, 16))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
-    net.fuse_output_tail = fused_tail
+    net.fuse_output_tail = net.fuse_input_bridge = fused_tail      # reference op order: neither the output head nor the input bridge is composed
     net.train() if train else net.eval()
     x, lab = synth_brats(1, 112, 112, 16, 1337)
     assert torch.equal(sample(x), g['x_sample'])

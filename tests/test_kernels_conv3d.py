@@ -117,13 +117,17 @@ def test_nonzero_mask_and_label_maps(backend):
 
 @pytest.mark.parametrize('B,Cin,Cout,size,k,stride', [(2, 8, 12, (4, 6, 5), (3, 3, 3), (1, 1, 1)), (1, 24, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)),
                                                       (2, 16, 16, (5, 7, 7), (1, 3, 3), (1, 1, 1)), (1, 8, 8, (6, 8, 8), (3, 3, 3), (2, 2, 2)),
-                                                      (1, 8, 72, (4, 6, 10), (3, 3, 3), (1, 1, 1))])
-def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride):
+                                                      (1, 8, 72, (4, 6, 10), (3, 3, 3), (1, 1, 1)), (2, 16, 24, (3, 5, 8), (3, 3, 3), (1, 1, 1)),
+                                                      (1, 8, 16, (2, 3, 16), (1, 3, 3), (1, 1, 1))])
+@pytest.mark.parametrize('wgrad_all', [0, 1], ids=['wgrad-x6-fast-rows', 'wgrad-x6-everywhere'])
+def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride, wgrad_all):
     """Forward, backward-data and backward-weight convolutions (packed contraction order) through the implicit GEMM on the bf16x6 engine:
     same loaders on the global side, operands split into bf16 planes on their way into LDS.  Position counts that are not multiples of
-    8 / 32 and rows that wrap inside a thread's position octet (OW = 5, 7, 9, 10) exercise the incremental decode of the weight-gradient loader."""
+    8 / 32 and rows that wrap inside a thread's position octet (OW = 5, 7, 9, 10) exercise the incremental decode of the weight-gradient loader;
+    OW = 8 / 16 its row-of-eight fast path (the one the product uses)."""
     L = backend.L
     prev = L.set_engine('x6')
+    L.c.segx_tune(7, wgrad_all)          # 1: also the general (per-position decode) weight-gradient gather; 0: only rows of 8 consecutive floats (OW % 8 == 0)
     try:
         L.x6_launches()
         dgrad = stride == (1, 1, 1)                      # the product differentiates strided convolutions w.r.t. x only for the 3-channel stem
@@ -140,4 +144,28 @@ def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride):
         close(w.grad, wr.grad, 1e-4)
         assert L.x6_launches() >= 1                      # the engine really ran (forward; the backward passes where their operands are float4-legal)
     finally:
+        L.c.segx_tune(7, 0)
         L.set_engine(prev)
+
+
+def test_input_bridge_composed_into_the_stem(backend):
+    """in_bridge_to3 (Conv3d 4 -> 3, 1x1x1, bias) followed by the stride-2 'same' stem convolution == ONE convolution of [x, 1, 0, 0, 0] with the
+    composed 8-channel filters (segx_stem_compose_fwd / segx_bridge_input): forward, and the gradients of the stem filters, the bridge weight and
+    the bridge bias through the composition's chain rule -- against the two-step computation in PyTorch (border voxels included: the bias must
+    NOT leak into the zero padding)."""
+    B, Cb, H, W, D, O, k = 2, 4, 8, 16, 6, 16, (3, 5, 5)
+    x = rnd(B, Cb, H, W, D, seed=71)
+    ws = (rnd(O, 3, *k, seed=72) * 0.2).requires_grad_(True)
+    wb = (rnd(3, Cb, 1, 1, 1, seed=73) * 0.5).requires_grad_(True)
+    bb = (rnd(3, seed=74) * 0.5).requires_grad_(True)
+    x8 = SF.bridge_input(x, 8)
+    assert x8.shape == (B, 8, D, H, W)
+    assert torch.equal(x8[:, :Cb], x.permute(0, 1, 4, 2, 3)) and bool((x8[:, Cb] == 1).all()) and bool((x8[:, Cb + 1:] == 0).all())
+    y = SF.conv3d_same(x8, SF.stem_compose(ws, wb, bb, 8), (2, 2, 2))
+    wsr, wbr, bbr = (t.detach().clone().requires_grad_(True) for t in (ws, wb, bb))
+    rgb = F.conv3d(x, wbr, bbr).permute(0, 1, 4, 2, 3)
+    yr = _ref_conv(rgb, wsr, (2, 2, 2))
+    close(y, yr.detach(), 2e-5)
+    G = rnd(*y.shape, seed=75)
+    y.backward(G); yr.backward(G)
+    close(ws.grad, wsr.grad, 1e-4); close(wb.grad, wbr.grad, 1e-4); close(bb.grad, bbr.grad, 1e-4)

@@ -260,3 +260,21 @@ def test_x6_engine_k1792_accuracy_vs_fp32_engine(backend):
     # sequential fp32 fmaf chain over all 16 products, six MFMAs per 16 k = 6x the rounding steps of the fp32 engine -- hence its looser bound
     tol = 3e-6 if backend.name == 'hip' else 1.2e-5
     assert e6 < tol and (backend.name != 'hip' or e6 < 3 * e32 + 1e-7), (e6, e32)
+
+
+def test_x6_split_early_schedule_gives_the_same_result(backend):
+    """segx_tune knob 6, value 6: the split-early schedule of the 128 x 128 k-contiguous kernel (conversion arithmetic of the next tile dealt
+    out between the matrix instructions of the current one) is a scheduling variant -- bit-identical results to the product schedule."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    try:
+        out = []
+        for v in (0, 6, 7):
+            assert L.c.segx_tune(6, v) == 0
+            A, B, C = _x6_case(L, backend.dev, 200, 136, 104, True, True, nb=2, tile=segx.TILE_128x128, seed=11)
+            out.append(C.clone())
+        assert torch.equal(out[0], out[1]) and torch.equal(out[0], out[2])
+        assert (out[0].double() - _ref(A, B)).abs().max().item() < 3e-6 * _ref(A, B).abs().max().item()
+    finally:
+        L.c.segx_tune(6, 0)
+        L.set_engine(prev)
