@@ -56,6 +56,9 @@ typedef struct {
     float* workspace;                 /* splitk*nb0*nb1*M*N floats when splitk>1 */
     int32_t tile;                     /* workgroup tile: SEGX_TILE_AUTO or one of SEGX_TILE_* (a tuning knob; results are identical) */
     int64_t bias_b0;                  /* bias stride over z0 (a bias vector per (z0, z1): the key-side term of re-associated scores) */
+    int32_t batch_reduce;             /* 1: C [M][N] = alpha * sum over ALL nb0*nb1 batch members (and split-K slabs) of A_z B_z^T (+ bias): the gradient of an
+                                       * operand shared by the batch (conv weights) in ONE deterministic reduction; needs workspace =
+                                       * max(1, splitk)*nb0*nb1*M*N floats, EPI_NONE, no gmax; c_b0 / c_b1 are ignored */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are

@@ -727,7 +727,7 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
     g.bias = nullptr; g.aux = nullptr; g.gmax = nullptr; g.nb1 = 1; g.bias_b1 = 0; g.bias_b0 = 0; g.alpha = 1.0f; g.epilogue = SEGX_EPI_NONE; g.bias_mode = SEGX_BIAS_NONE;
     g.a_b1 = g.b_b1 = g.c_b1 = 0; g.b_n = g.b_k = 0; g.a_k = 1; g.vecA = g.vecB = 0;
     g.M = M; g.N = N; g.K = K; g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
-    g.dropout_p = 0.f; g.seed = g.offset = 0; g.splitk = splitk;
+    g.dropout_p = 0.f; g.seed = g.offset = 0; g.splitk = splitk; g.slab = 0;
     g.k_chunk = splitk == 1 ? K : ceil_div(ceil_div(K, splitk), BKT) * BKT;
     g.c_split = (int64_t)nbatch * M * N;
     if (splitk > 1) g.C = workspace;
@@ -735,9 +735,16 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
 
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads) */
 // split factor of the implicit GEMM (M = Cout, N, K, B samples) on the tile the convolution kernels use for this Cout
-static int conv_splitk(int M, int N, int K, int B) {
+// x6: the launch will run on the bf16x6 engine (3 / 4 resident workgroups per CU and its own k-tile times: a split factor chosen for the
+// fp32 engine's 512 slots left 1008 workgroups on 768 slots -- 1.3 rounds, 64.8 TFLOP/s on the 192 x 1728 x 150528 weight gradient, r02_c)
+static int conv_splitk(int M, int N, int K, int B, bool x6) {
     const bool small = conv_small(M);
     double t;
+    if (x6) {
+        const TileInfo6& c6 = small ? kTiles6[1] : kTiles6[0];
+        const TileInfo c{c6.id, c6.bm, c6.bn, c6.wg_per_cu, c6.ktile_us, c6.fixed_us};
+        return best_splitk(c, M, N, K, B, &t);
+    }
     return best_splitk(tile_info(small ? SEGX_TILE_64x128 : SEGX_TILE_128x128), M, N, K, B, &t);
 }
 /* the library's split-K factor for segx_conv3d_fwd (wgrad = 0) / segx_conv3d_bwd_weight (wgrad = 1); workspace = splitk * output floats */
@@ -746,7 +753,10 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW, CK = (int64_t)q.Cin * q.KD * q.KH * q.KW;
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
-    return wgrad ? conv_splitk(Cout, (int)CK, (int)P, B) : conv_splitk(Cout, (int)P, (int)CK, B);
+    // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
+    const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (q.OW % 8 == 0 || g_conv_x6_wgrad_all));
+    return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
  * workspace (splitk*B*Cout*P floats), reduced deterministically -- for the low-resolution Inception stages whose position grid alone

@@ -142,6 +142,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     SEGX_REQUIRE(d->dropout_p >= 0.f && d->dropout_p < 1.f, "segx_gemm_f32: dropout_p out of range");
     const int splitk = d->splitk > 1 ? d->splitk : 1;
     SEGX_REQUIRE(splitk == 1 || (d->workspace && d->epilogue == SEGX_EPI_NONE && !d->gmax), "segx_gemm_f32: split-K needs workspace and a plain epilogue");
+    const bool breduce = d->batch_reduce != 0;
+    SEGX_REQUIRE(!breduce || (d->workspace && d->epilogue == SEGX_EPI_NONE && !d->gmax), "segx_gemm_f32: batch_reduce needs workspace and a plain epilogue");
 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = d->bias_mode ? d->bias : nullptr; g.aux = d->epilogue == SEGX_EPI_GELU ? d->aux : nullptr;
@@ -160,7 +162,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.k_chunk = splitk == 1 ? d->K : ceil_div(ceil_div(d->K, splitk), BKT) * BKT;
     const int nbatch = d->nb0 * d->nb1;
     g.c_split = (int64_t)nbatch * d->M * d->N;
-    if (splitk > 1) g.C = d->workspace;
+    g.slab = breduce ? 1 : 0;
+    if (splitk > 1 || breduce) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_256x128 && (d->tile != SEGX_TILE_256x128 || g_engine == SEGX_ENGINE_BF16X6), "segx_gemm_f32: bad tile %d", d->tile);
     int tile = d->tile;
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
@@ -241,6 +244,14 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     }
     int rc = check_launch("segx_gemm_f32");
     if (rc) return rc;
+    if (breduce) {
+        // the workspace holds splitk * nbatch slabs of M x N (slab (zk, zb) at (zk * nbatch + zb) * M * N): one deterministic sum over all of them
+        const int64_t total = (int64_t)d->M * d->N;
+        SEGX_REQUIRE((int64_t)splitk * nbatch < 2147483647LL, "segx_gemm_f32: too many slabs");
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                           d->M, d->N, 1, splitk * nbatch, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total);
+        return check_launch("segx_gemm_f32/batch_reduce");
+    }
     if (splitk > 1) {
         const int64_t total = g.c_split;
         const int blocks = (int)i64min(2048, (total + 255) / 256);

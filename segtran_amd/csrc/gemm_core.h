@@ -38,6 +38,7 @@ struct GemmArgs {
     float dropout_p; uint64_t seed, offset;
     int k_chunk;                    // split-K: this launch covers k in [z_k*k_chunk, min(K, (z_k+1)*k_chunk))
     int splitk; int64_t c_split;    // slab stride in the workspace
+    int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
 };
 
 // Load this thread's ROWS*BKT/1024 float4 pieces of a ROWS x BKT operand tile into registers.
@@ -246,7 +247,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / Cfg::WN, wn = wave % Cfg::WN;
     const int m0 = t.m0, n0 = t.n0, zb = t.zb, zk = t.zk, z0 = t.z0, z1 = t.z1;
-    const bool split = g.splitk > 1;
+    const bool split = g.splitk > 1 || g.slab;
     float* C = split ? g.C + (int64_t)zk * g.c_split + (int64_t)zb * g.M * g.N : g.C + z0 * g.c_b0 + z1 * g.c_b1;
     const int64_t ldc = split ? g.N : g.c_m;
     const float alpha = split ? 1.0f : g.alpha;

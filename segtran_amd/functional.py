@@ -85,6 +85,18 @@ def _grad_operand(L, dC, other, s, which, like):
         out = torch.empty_like(like)
         L.colsum(tmp, out, _empty(dC, L.colreduce_ws(nb[bd], n, 1)), nb[bd], n)
         return out
+    if any(bcast) and like.is_contiguous() and like.numel() == rows * cols and (st[2] == 1 or st[3] == 1):
+        # operand shared by the WHOLE batch (convolution / projection weights): the per-member products are slabs of one deterministic
+        # reduction inside the GEMM call (batch_reduce) -- no [batch, rows, cols] temporary, no separate column-sum launches
+        k_contig = st[3] == 1
+        out = torch.empty_like(like)
+        dc_as_rows = (s.c[0], s.c[1], s.c[2], 1) if which == 'a' else (s.c[0], s.c[1], 1, s.c[2])
+        oth = (ost[0], ost[1], ost[3], ost[2])
+        if k_contig:
+            _run_gemm(L, dC, other, out, rows, cols, inner, dc_as_rows, oth, (0, 0, cols), nb, s.alpha, batch_reduce=True)
+        else:
+            _run_gemm(L, other, dC, out, cols, rows, inner, oth, dc_as_rows, (0, 0, rows), nb, s.alpha, batch_reduce=True)
+        return out
     if any(bcast):
         # operand shared across a batch dim: per-batch partial grads, then a deterministic column sum
         assert st[2] == 1 or st[3] == 1

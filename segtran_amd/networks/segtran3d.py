@@ -5,9 +5,10 @@ state_dict keys.  Built: I3D backbone, 'bridgeconv' 4->3 input bridge, in_fpn '3
 GroupNorm), D_pool_K depth pooling with 'interp' un-pooling -- i.e. the configuration train3d.py forces.
 The reference's hard-coded device='cuda' (segtran3d.py:464, N8) is replaced by the input's device.
 
-Kernel status: fusion encoder and every 1x1x1 conv (incl. the 832->1024 out-FPN bridge = 256 GFLOP/volume)
-on libsegx, as are GroupNorm, the trilinear resampling (with the fused lateral add) and BatchNorm3d+ReLU; the 3^3 / 7^3
-convolutions and the max pools are still ATen/MIOpen calls.
+Kernel status: everything runs on libsegx -- fusion encoder, every 1x1x1 convolution, the 3^3 / 7^3 convolutions (implicit GEMM, forward /
+backward-data / backward-weight), 'same' max pools, GroupNorm, the trilinear resampling (with the fused lateral add), BatchNorm3d+ReLU.
+Two exact re-associations of consecutive linear maps are on by default (switches `fuse_output_tail`, `fuse_input_bridge`; both orders are
+parity-tested): the class projection composed into the out-FPN bridge, and the 4 -> 3 input bridge composed into the stem filters.
 """
 import torch
 import torch.nn as nn

@@ -14,8 +14,9 @@ Layout choices that differ from the reference on purpose (internal, invisible in
     and sliced per layer, instead of being regenerated as [B, N, C] for every layer;
   * attention diagnostics (:569-587) stay on the device: no `.item()` host syncs in the hot loop.
 Quirks reproduced on purpose: N1 dropped residual, N2 tied q/k, N3 unused parameters, N4 eps=1e-12,
-N5 conditional clip.  Out of scope here: Mince transformer, 'bias' positional codes,
-ablation embedders.
+N5 conditional clip, N11 untied q/k under --mince.  Built besides the squeezed default: the non-squeezed encoder with sliding positional
+biases (`--nosqueeze --pos bias`) and the Mince multi-scale transformer (`--mince`).  Not built (no BASELINE config uses them; they raise):
+multi-head ablation, 'rand' / 'sinu' positional embedders, attention-consistency loss.
 """
 import copy
 import math

@@ -5,7 +5,7 @@ import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
-ENGINE = ('gemm_f32_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel')
+ENGINE = ('gemm_f32_kernel', 'gemm_x6_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel', 'conv3d_fwd_x6_kernel', 'conv3d_wgrad_x6_kernel')
 
 
 def engine_traffic(cfg):
@@ -32,15 +32,42 @@ def engine_traffic(cfg):
             'traffic_bytes_per_launch': (2.0 * fk + wk) * 1024.0 / max(1, n)}
 
 
+def mfma_busy(cfg):
+    """Matrix-pipe utilisation per engine kernel from the SQ counter pass: SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs of the chip,
+    GRBM_GUI_ACTIVE over the 8 XCDs (calibration: SQ_BUSY_CYCLES, summed over 32 shader engines, is 4.0x GRBM_GUI_ACTIVE in every row), so
+    busy fraction = MFMA_BUSY / (1024 x GUI_ACTIVE / 8).  Kernels are serialised under counter collection; clocks differ from the timed run."""
+    f = os.path.join(src, 'pmc_%s_SQ_VALU_MFMA_BUSY_CYCLES_by_kernel.json' % cfg)
+    if not os.path.exists(f):
+        return None
+    out, tot_m, tot_g = {}, 0.0, 0.0
+    for k, v in json.load(open(f)).items():
+        if not any(e in k for e in ENGINE) or 'GRBM_GUI_ACTIVE' not in v:
+            continue
+        m, g = v['SQ_VALU_MFMA_BUSY_CYCLES']['total'], v['GRBM_GUI_ACTIVE']['total']
+        wc = max(v['SQ_WAVE_CYCLES']['total'], 1.0)
+        out[k] = {'launches': v['GRBM_GUI_ACTIVE']['launches'], 'mfma_busy_frac': round(m / (128.0 * g), 4),
+                  'sq_busy_over_gui': round(v['SQ_BUSY_CYCLES']['total'] / g, 3),
+                  'wave_cycles_waiting_any': round(v['SQ_WAIT_ANY']['total'] / wc, 3), 'wave_cycles_issue_stalled': round(v['SQ_WAIT_INST_ANY']['total'] / wc, 3),
+                  'wave_cycles_issuing': round(v['SQ_ACTIVE_INST_ANY']['total'] / wc, 3)}
+        if 'x6' in k:
+            tot_m += m; tot_g += g
+    return {'source': 'rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU '
+                      'GRBM_GUI_ACTIVE of `bench.py --config %s --steps 1 --warmup 1`, %s' % (cfg, tag),
+            'bf16x6_engine_mfma_busy_frac': round(tot_m / (128.0 * tot_g), 4) if tot_g else None, 'per_kernel': out}
+
+
 traffic = {}
 for name in sorted(os.listdir(src)):
-    if name.endswith(('.json', '.csv', '.txt', '.log')) and not name.startswith(('prof_', 'pmc_cfg2_FETCH_SIZE.log', 'pmc_cfg2_WRITE_SIZE.log', 'pmc_cfg4')) or name.endswith('_by_kernel.json'):
+    if name.endswith(('.json', '.csv', '.txt', '.log')) and not name.startswith(('prof_', 'pmc_')) and not name.endswith('.log') or name.endswith('_by_kernel.json'):
         shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
 for cfg in ('cfg2', 'cfg4'):
     t = engine_traffic(cfg)
     if t:
         json.dump(t, open(os.path.join(dst, '%s_pmc_engine_traffic_%s.json' % (tag, cfg)), 'w'), indent=1)
         traffic[cfg] = {'traffic_bytes_per_launch': t['traffic_bytes_per_launch'], 'file': '%s_pmc_engine_traffic_%s.json' % (tag, cfg)}
+    b = mfma_busy(cfg)
+    if b:
+        json.dump(b, open(os.path.join(dst, '%s_mfma_busy_%s.json' % (tag, cfg)), 'w'), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(dst, 'pmc_engine_traffic.json'), 'w'), indent=1)      # what bench.py reads
 print(sorted(n for n in os.listdir(dst) if n.startswith(tag)))
