@@ -163,13 +163,16 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     step = engine.TrainStep(net, opt, c['task'], reducer)
     x, raw = engine.synth_batch(cfg_name, B, dev, seed=1337 + rank)          # disjoint samples per rank
     L = segx.lib()
+    graphed = bool(args.graph) and world == 1
+    if graphed:                         # the whole step as ONE hipGraph launch (engine.GraphedTrainStep); per-launch engine events are not available
+        step = engine.GraphedTrainStep(step, x, raw, warmup=min(3, max(1, warmup)))
     for _ in range(warmup):
         step(x, raw)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    L.gemm_prof = []
+    L.gemm_prof = None if graphed else []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     ev[0].record()
@@ -181,14 +184,16 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof, L.gemm_prof = L.gemm_prof, None
+    prof, L.gemm_prof = (L.gemm_prof or []), None
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     other = None
-    if world == 1 and other_order and not args.single_order:   # the same step in the OTHER operation order, outside the timed region
+    if graphed:
+        step.close()
+    if world == 1 and other_order and not args.single_order and not graphed:   # the same step in the OTHER operation order, outside the timed region
         set_op_order(net, args.reference_op_order)
         for _ in range(2):
             step(x, raw)
@@ -205,7 +210,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     del step, opt, net, reducer
     torch.cuda.empty_cache()
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
-    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine) if rank == 0 else (None, 0.0)
+    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine) if (rank == 0 and prof) else (None, 0.0)
     if rank == 0 and os.environ.get('SEGX_BENCH_VERBOSE'):
         agg = {}
         for e0, e1, fl, shp, x6 in prof:
@@ -220,7 +225,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
            'ms_per_step_median': round(med, 2), 'value_at_median': round(world * B / (med * 1e-3), 3),
            'ms_per_step_min_max': [round(min(per_step), 2), round(max(per_step), 2)],
            'config': {'workload': WORKLOADS.get(cfg_name, cfg_name), 'global_batch': world * B, 'per_gpu_batch': B, 'parallelism': 'dp%d' % world,
-                      'dropout': 0.2, 'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam', 'final_loss': round(lossv, 5),
+                      'dropout': 0.2, 'step': 'fwd+BCE/Dice+bwd+allreduce+clip+BertAdam' + (' (one hipGraph launch per step)' if graphed else ''), 'final_loss': round(lossv, 5),
                       'gemm_path': 'bf16x6 tile engine (fp32-equivalent; float4-legal operands with > 48 rows per side), fp32 MFMA for the rest'
                                    if args.engine == 'x6' else 'fp32 MFMA tile engine',
                       'op_order': ('reference' if args.reference_op_order else 're-associated') + ' (DESIGN.md 5b: exact re-association of '
@@ -244,6 +249,7 @@ def main():
     ap.add_argument('--config', default='cfg2', help='BASELINE config of the MAIN measurement (cfg2 = metric default)')
     ap.add_argument('--engine', default=os.environ.get('SEGX_ENGINE', 'x6'), choices=['x6', 'f32'],
                     help="tile engine: 'x6' = bf16x6 (default), 'f32' = v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (single GPU; no per-launch roofline)')
     ap.add_argument('--no-brats', action='store_true', help='skip the secondary BraTS block(s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--single-order', action='store_true', help='skip the comparison run in the other operation order (profiling runs)')

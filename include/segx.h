@@ -179,17 +179,25 @@ int segx_bn_merge_stats(const float* all, float* mean, float* var, float* run_me
 /* y = act((x - mean) * rsqrt(var + eps) * w + b) with the given (batch or running) statistics */
 int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
                     int B, int C, int64_t S, float eps, int act, void* stream);
-/* backward of the above: dX, dw[C], db[C]; training != 0 differentiates through the batch statistics */
+/* the same pass that also leaves pooled[b][c] = sum over the plane of Y -- the squeeze-excite pooling that follows BatchNorm + swish in an
+ * MBConv block (efficientnet/model.py:104-106) without another pass over Y; ws: B*C*64 floats */
+int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
+                         int B, int C, int64_t S, float eps, int act, void* stream);
+/* backward of the above: dX, dw[C], db[C]; training != 0 differentiates through the batch statistics.
+ * gate / dpool (both or neither; [B*C]): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c], efficientnet/model.py:110) and dY is the
+ * gradient w.r.t. Z: the kernels then use dY * gate[b][c] + dpool[b][c] * inv_S in place of dY (dpool = gradient w.r.t. the pooled sums' mean),
+ * which replaces a pass that would write that tensor (same for the reduce / apply halves below) */
 int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                     float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                    void* stream);
+                    const float* gate, const float* dpool, float inv_S, void* stream);
 /* the two halves of segx_bn_act_bwd, for synchronised BatchNorm: reduce gives the LOCAL sums dw = sum du*xhat,
  * db = sum du; after an all-reduce of both, apply uses the GLOBAL sums and inv_n = 1 / (global element count) */
 int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
-                           float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, void* stream);
+                           float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
+                           const float* gate, const float* dpool, float inv_S, void* stream);
 int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                           const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
-                          float inv_n, void* stream);
+                          float inv_n, const float* gate, const float* dpool, float inv_S, void* stream);
 /* depthwise k x k convolution (k in {3,5}, stride in {1,2}) with explicit top/left zero padding (static 'same'
  * padding N6, efficientnet/utils.py:248-275): Y[b,c,oy,ox] = sum w[c,ky,kx] X[b,c,oy*s+ky-pad_t, ox*s+kx-pad_l] */
 int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,
@@ -236,6 +244,11 @@ int segx_transpose(const float* X, float* Y, int64_t batch, int R, int C, void* 
 /* nn.Dropout as its own pass (out-FPN output under --outdrop, segtran2d.py:308-310 / segtran3d.py:392-394):
  * y[i] = x[i] * keep(seed, offset + i) / (1 - p); the backward pass is the same call on dy.  offset % 4 == 0, 16-B aligned. */
 int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
+/* Device-side base of every dropout stream (library state, NULL = none): every kernel that takes (seed, offset) adds *base to offset.  It exists for
+ * hipGraph capture of the train step -- a replayed graph re-issues the captured offsets; a captured segx_rng_advance(base, span) at the end of the step
+ * moves the base by the number of stream positions the step reserved, so each replay draws fresh masks (forward and backward of ONE replay still agree). */
+int segx_set_rng_base(const uint64_t* base);
+int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
 
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
  * knob 4 = tile engine of segx_gemm_f32 and the

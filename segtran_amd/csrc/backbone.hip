@@ -89,31 +89,52 @@ __global__ __launch_bounds__(256) void bn_merge_stats_kernel(const float* __rest
     }
 }
 
-// y = act((x - mean) * rstd * w + b): grid (chunks, B*C)
+// y = act((x - mean) * rstd * w + b): grid (chunks, B*C).  POOL: also psum[plane][chunk] = sum of this chunk's outputs -- the squeeze-excite
+// pooling of the NEXT op (efficientnet/model.py:106) without another pass over y (fixed summation order: deterministic).
+template <bool POOL>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ var,
                                                          const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ Y,
-                                                         int C, int64_t S, float eps, int act) {
+                                                         float* __restrict__ psum, int C, int64_t S, float eps, int act) {
+    __shared__ float red[4];
     const int bc = blockIdx.y, c = bc % C;
     const float sc = rsqrtf(var[c] + eps) * w[c], sh = b[c] - mean[c] * sc;
     const float* x = X + (int64_t)bc * S; float* y = Y + (int64_t)bc * S;
+    float acc = 0.f;
     if ((S & 3) == 0) {
         for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
             const float4 v = *reinterpret_cast<const float4*>(x + s);
             float4 o;
             o.x = act_fwd(v.x * sc + sh, act); o.y = act_fwd(v.y * sc + sh, act); o.z = act_fwd(v.z * sc + sh, act); o.w = act_fwd(v.w * sc + sh, act);
             *reinterpret_cast<float4*>(y + s) = o;
+            if (POOL) acc += (o.x + o.y) + (o.z + o.w);
         }
     } else {
-        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = act_fwd(x[s] * sc + sh, act);
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) { const float o = act_fwd(x[s] * sc + sh, act); y[s] = o; if (POOL) acc += o; }
     }
+    if (POOL) {
+        acc = block_sum<4>(acc, red);
+        if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
+    }
+}
+// pooled[plane] = sum over the chunks of a plane (<= 64), in chunk order
+__global__ __launch_bounds__(256) void plane_chunk_sum_kernel(const float* __restrict__ psum, float* __restrict__ pooled, int planes, int nch) {
+    const int pl = blockIdx.x * 256 + threadIdx.x;
+    if (pl >= planes) return;
+    float a = 0.f;
+    for (int i = 0; i < nch; ++i) a += psum[(int64_t)pl * nch + i];
+    pooled[pl] = a;
 }
 // backward reductions per channel: sums[c] = (sum du, sum du * xhat), du = dy * act'(u).  grid (C, B, slabs)
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                          const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
-                                                         float* __restrict__ ws, int C, int64_t S, float eps, int act) {
+                                                         float* __restrict__ ws, int C, int64_t S, float eps, int act,
+                                                         const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S) {
     __shared__ float red[4];
     const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
+    // squeeze-excite behind this BatchNorm (bn_act_se): the incoming gradient is dz (w.r.t. y * gate); dy = dz * gate[plane] + dpool[plane] / S is
+    // formed on the fly instead of being written by a pass of its own (plane_scale_bwd)
+    const float gt = gate ? gate[(int64_t)bb * C + c] : 1.0f, dp = gate ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
     const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
     const int nsl = gridDim.z;
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
@@ -123,13 +144,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
         for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
             const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
             const float h0 = (xv.x - m) * rstd, h1 = (xv.y - m) * rstd, h2 = (xv.z - m) * rstd, h3 = (xv.w - m) * rstd;
-            const float d0 = gv.x * act_grad(h0 * wc + bc_, act), d1 = gv.y * act_grad(h1 * wc + bc_, act);
-            const float d2 = gv.z * act_grad(h2 * wc + bc_, act), d3 = gv.w * act_grad(h3 * wc + bc_, act);
+            const float d0 = (gv.x * gt + dp) * act_grad(h0 * wc + bc_, act), d1 = (gv.y * gt + dp) * act_grad(h1 * wc + bc_, act);
+            const float d2 = (gv.z * gt + dp) * act_grad(h2 * wc + bc_, act), d3 = (gv.w * gt + dp) * act_grad(h3 * wc + bc_, act);
             a += (d0 + d1) + (d2 + d3); q += (d0 * h0 + d1 * h1) + (d2 * h2 + d3 * h3);
         }
     } else {
         for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) {
-            const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+            const float xh = (x[s] - m) * rstd, du = (g[s] * gt + dp) * act_grad(xh * wc + bc_, act);
             a += du; q += du * xh;
         }
     }
@@ -147,9 +168,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float* __restrict
 __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                         const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
                                                         const float* __restrict__ dw, const float* __restrict__ db, float* __restrict__ dX,
-                                                        int C, int64_t S, float eps, int act, float inv_n /* 0 in eval mode */) {
+                                                        int C, int64_t S, float eps, int act, float inv_n /* 0 in eval mode */,
+                                                        const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S) {
     const int bc = blockIdx.y, c = bc % C;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
+    const float gt = gate ? gate[bc] : 1.0f, dp = gate ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
     const float k1 = db[c] * inv_n, k2 = dw[c] * inv_n, sc = wc * rstd;
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
     if ((S & 3) == 0) {
@@ -157,13 +180,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
             const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
             const float h0 = (xv.x - m) * rstd, h1 = (xv.y - m) * rstd, h2 = (xv.z - m) * rstd, h3 = (xv.w - m) * rstd;
             float4 o;
-            o.x = sc * (gv.x * act_grad(h0 * wc + bc_, act) - k1 - h0 * k2); o.y = sc * (gv.y * act_grad(h1 * wc + bc_, act) - k1 - h1 * k2);
-            o.z = sc * (gv.z * act_grad(h2 * wc + bc_, act) - k1 - h2 * k2); o.w = sc * (gv.w * act_grad(h3 * wc + bc_, act) - k1 - h3 * k2);
+            o.x = sc * ((gv.x * gt + dp) * act_grad(h0 * wc + bc_, act) - k1 - h0 * k2); o.y = sc * ((gv.y * gt + dp) * act_grad(h1 * wc + bc_, act) - k1 - h1 * k2);
+            o.z = sc * ((gv.z * gt + dp) * act_grad(h2 * wc + bc_, act) - k1 - h2 * k2); o.w = sc * ((gv.w * gt + dp) * act_grad(h3 * wc + bc_, act) - k1 - h3 * k2);
             *reinterpret_cast<float4*>(d + s) = o;
         }
     } else {
         for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
-            const float xh = (x[s] - m) * rstd, du = g[s] * act_grad(xh * wc + bc_, act);
+            const float xh = (x[s] - m) * rstd, du = (g[s] * gt + dp) * act_grad(xh * wc + bc_, act);
             d[s] = sc * (du - k1 - xh * k2);
         }
     }
@@ -656,34 +679,46 @@ extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* v
                                int B, int C, int64_t S, float eps, int act, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 2, "segx_bn_act_fwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, C, S, eps, act);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, (float*)nullptr, C, S, eps, act);
     return check_launch("segx_bn_act_fwd");
 }
+/* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
+extern "C" int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
+                                    int B, int C, int64_t S, float eps, int act, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && pooled && ws && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 2, "segx_bn_act_fwd_pool: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd_pool: more than 65535 (sample, channel) planes");
+    const int nch = plane_chunks(S, 8);
+    hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3(nch, B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, ws, C, S, eps, act);
+    hipLaunchKernelGGL(plane_chunk_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, pooled, B * C, nch);
+    return check_launch("segx_bn_act_fwd_pool");
+}
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
-                                      float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_reduce: bad args");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+                                      float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
+                                      const float* gate, const float* dpool, float inv_S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd_reduce: bad args");
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     return check_launch("segx_bn_act_bwd_reduce");
 }
 extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                      const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
-                                     float inv_n, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd_apply: bad args");
+                                     float inv_n, const float* gate, const float* dpool, float inv_S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd_apply: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n);
+    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n,
+                       gate, dpool, inv_S);
     return check_launch("segx_bn_act_bwd_apply");
 }
 extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                               void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0, "segx_bn_act_bwd: bad args");
+                               const float* gate, const float* dpool, float inv_S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
     hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
-                       (const float*)db, dX, C, S, eps, act, inv_n);
+                       (const float*)db, dX, C, S, eps, act, inv_n, gate, dpool, inv_S);
     return check_launch("segx_bn_act_bwd");
 }
 

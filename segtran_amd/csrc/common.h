@@ -109,6 +109,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     return cdf + x * pdf;
 }
 
+// host-side: device pointer every dropout launch hands to its kernel (segx_set_rng_base); one instance for the whole library
+inline const uint64_t*& rng_base() { static const uint64_t* p = nullptr; return p; }
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 __host__ __device__ inline int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
 __host__ __device__ inline int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }

@@ -727,7 +727,7 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
     g.bias = nullptr; g.aux = nullptr; g.gmax = nullptr; g.nb1 = 1; g.bias_b1 = 0; g.bias_b0 = 0; g.alpha = 1.0f; g.epilogue = SEGX_EPI_NONE; g.bias_mode = SEGX_BIAS_NONE;
     g.a_b1 = g.b_b1 = g.c_b1 = 0; g.b_n = g.b_k = 0; g.a_k = 1; g.vecA = g.vecB = 0;
     g.M = M; g.N = N; g.K = K; g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
-    g.dropout_p = 0.f; g.seed = g.offset = 0; g.splitk = splitk; g.slab = 0;
+    g.dropout_p = 0.f; g.seed = g.offset = 0; g.rbase = nullptr; g.splitk = splitk; g.slab = 0;
     g.k_chunk = splitk == 1 ? K : ceil_div(ceil_div(K, splitk), BKT) * BKT;
     g.c_split = (int64_t)nbatch * M * N;
     if (splitk > 1) g.C = workspace;
@@ -755,7 +755,7 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (q.OW % 8 == 0 || g_conv_x6_wgrad_all));
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || Cout <= 64)) || g_conv_x6_wgrad_all));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -841,7 +841,9 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // bf16x6 engine: where the eight positions of a thread are eight floats of one input row (OW % 8 == 0: the 56 x 56 stages,
     // 2/3 of the weight-gradient FLOPs of I3D); elsewhere its per-position gather decode costs more VALU time than the six-fold
     // faster matrix instruction saves (measured r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays
-    const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;
+    // small (64-row A tile): the B-side gather of a 128-column tile then feeds half the matrix work -- VALU-bound (r02_d: 65 TFLOP/s at Cout 192 against
+    // 94 on the fp32 engine); only the single-row-tile case (Cout <= 64: the stem) still gains
+    const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0 && (!small || Cout <= 64);
     if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && (fastw || g_conv_x6_wgrad_all)) {
         ++g_x6_launches;
         if (fastw) {

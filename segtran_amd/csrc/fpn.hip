@@ -314,7 +314,8 @@ extern "C" int segx_transpose(const float* X, float* Y, int64_t batch, int R, in
 // Standalone inverted dropout (nn.Dropout on the out-FPN output, --outdrop, segtran2d.py:308-310): y = x * keep(seed, offset + i) / (1 - p).
 // The mask is regenerated from the Philox stream, so the backward pass is the same kernel applied to dy.
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n, float p, float inv_keep,
-                                                      uint64_t seed, uint64_t offset) {
+                                                      uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase) {
+    offset += rbase ? *rbase : 0;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4*>(x)[i];
@@ -329,11 +330,21 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
 extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f && (offset & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0,
                               "segx_dropout: bad args");
-    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)i64min(1 << 20, (n / 4 + 256) / 256)), dim3(256), 0, stream, x, y, n, p, 1.0f / (1.0f - p), seed, offset);
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)i64min(1 << 20, (n / 4 + 256) / 256)), dim3(256), 0, stream, x, y, n, p, 1.0f / (1.0f - p), seed, offset, segx::rng_base());
     return check_launch("segx_dropout");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
 namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; extern int g_conv_x6_wgrad_all; }
+__global__ void rng_advance_kernel(uint64_t* base, uint64_t span) { if (threadIdx.x == 0 && blockIdx.x == 0) *base += span; }
+/* Device-side base of every dropout Philox stream: each kernel adds *base to the `offset` it was launched with.  A train step captured into a
+ * hipGraph replays the SAME offsets; advancing *base by the step's span (segx_rng_advance, itself a captured launch) gives every replay fresh
+ * masks, and forward / backward of one replay still regenerate identical ones.  NULL (default): offsets are used as passed. */
+extern "C" int segx_set_rng_base(const uint64_t* base) { segx::rng_base() = base; return 0; }
+extern "C" int segx_rng_advance(uint64_t* base, uint64_t span, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(base && span % 4 == 0, "segx_rng_advance: bad args");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, stream, base, span);
+    return check_launch("segx_rng_advance");
+}
 extern "C" int segx_tune(int knob, int value) {
     if (knob == 1) { g_interp_variant = value; return 0; }
     if (knob == 2) { segx::g_conv_small_policy = value; return 0; }

@@ -65,6 +65,30 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         C[z0 * c_b0 + z1 * c_b1 + (int64_t)row * c_m + col] = s;
     }
 }
+// The same reduction for MANY slabs over a SMALL output (batch_reduce of the skinny weight gradients: 6 x 63 slabs of 24 x 144 floats): the slab
+// loop is dealt out over PARTS threads per output element (slab s -> part s % PARTS, each part in slab order) and the PARTS partial sums are
+// added in part order through LDS -- a fixed summation tree, so still deterministic; 256 / PARTS outputs per workgroup.
+template <int PARTS>
+__global__ __launch_bounds__(256) void slab_sum_parts_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
+                                                             int M, int N, int nslabs, int64_t total, int64_t c_m, float alpha, int bias_mode) {
+    __shared__ float part[256];
+    constexpr int EPB = 256 / PARTS;
+    const int e = threadIdx.x % EPB, pt = threadIdx.x / EPB;
+    const int64_t idx = (int64_t)blockIdx.x * EPB + e;
+    float s = 0.f;
+    if (idx < total) for (int k = pt; k < nslabs; k += PARTS) s += ws[(int64_t)k * total + idx];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (pt == 0 && idx < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) t += part[q * EPB + e];
+        t *= alpha;
+        const int col = (int)(idx % N), row = (int)(idx / N);
+        if (bias_mode == SEGX_BIAS_N) t += bias[col]; else if (bias_mode == SEGX_BIAS_M) t += bias[row];
+        C[(int64_t)row * c_m + col] = t;
+    }
+}
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -156,7 +180,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
     const bool vec = gemm_vec_ok(A, B, d);
     g.vecA = vec; g.vecB = vec;
-    g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset;
+    g.dropout_p = d->dropout_p; g.seed = d->seed; g.offset = d->offset; g.rbase = rng_base();
     g.splitk = splitk;
     // k_chunk: multiple of the k-tile so slabs start on tile boundaries (and stay float4-aligned)
     g.k_chunk = splitk == 1 ? d->K : ceil_div(ceil_div(d->K, splitk), BKT) * BKT;
@@ -248,8 +272,16 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         // the workspace holds splitk * nbatch slabs of M x N (slab (zk, zb) at (zk * nbatch + zb) * M * N): one deterministic sum over all of them
         const int64_t total = (int64_t)d->M * d->N;
         SEGX_REQUIRE((int64_t)splitk * nbatch < 2147483647LL, "segx_gemm_f32: too many slabs");
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                           d->M, d->N, 1, splitk * nbatch, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total);
+        const int nslabs = splitk * nbatch;
+        if (total * 16 <= 512 * 1024 && nslabs >= 16)          // few outputs, many slabs: 16 threads per output
+            hipLaunchKernelGGL((slab_sum_parts_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                               d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
+        else if (total * 4 <= 1024 * 1024 && nslabs >= 4)
+            hipLaunchKernelGGL((slab_sum_parts_kernel<4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                               d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                               d->M, d->N, 1, nslabs, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total);
         return check_launch("segx_gemm_f32/batch_reduce");
     }
     if (splitk > 1) {

@@ -35,7 +35,7 @@ struct GemmArgs {
     float alpha; int epilogue, bias_mode;
     int vecA, vecB;                 // float4 global loads legal (alignment + stride checks done on host)
     int tiles_m, tiles_n;
-    float dropout_p; uint64_t seed, offset;
+    float dropout_p; uint64_t seed, offset; const uint64_t* rbase;     // rbase: device-side base added to offset (segx_set_rng_base)
     int k_chunk;                    // split-K: this launch covers k in [z_k*k_chunk, min(K, (z_k+1)*k_chunk))
     int splitk; int64_t c_split;    // slab stride in the workspace
     int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
@@ -255,6 +255,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     const bool bias_n = bias && g.bias_mode == SEGX_BIAS_N, bias_m = bias && g.bias_mode == SEGX_BIAS_M;
     float* AUX = (EPI == SEGX_EPI_GELU) ? g.aux + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;
     const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
+    const uint64_t roff = g.offset + ((EPI == SEGX_EPI_GELU && g.dropout_p > 0.f && g.rbase) ? *g.rbase : 0);
     const bool full = (m0 + Cfg::BM <= g.M) && (n0 + Cfg::BN <= g.N);
     float vmax = 0.f;
 #pragma unroll
@@ -275,7 +276,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
                     if (ok) AUX[(int64_t)row * ldc + col] = v;
                     v = gelu_erf(v);
                     if (g.dropout_p > 0.f)
-                        v *= dropout_scale(g.seed, g.offset, (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1) + (uint64_t)row * ldc + col, g.dropout_p, inv_keep);   // element offset in C: what segx_gelu_bwd regenerates
+                        v *= dropout_scale(g.seed, roff, (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1) + (uint64_t)row * ldc + col, g.dropout_p, inv_keep);   // element offset in C: what segx_gelu_bwd regenerates
                 }
                 if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
             }

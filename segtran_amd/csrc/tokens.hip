@@ -75,7 +75,8 @@ static inline dim3 row_grid(int64_t rows) { return dim3((unsigned)((rows + ROWS_
 template <int NV4>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd,
                                                           int64_t rows, int L, float clip, const float* __restrict__ gmax,
-                                                          float p, uint64_t seed, uint64_t off) {
+                                                          float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= rows) return;
     const bool clamp = gmax && (*gmax > clip);                 // N5: clamp only when the GLOBAL max exceeds the clip
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restric
 template <int NV4>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, const float* __restrict__ dPd, const float* __restrict__ S,
                                                           float* __restrict__ dS, int64_t rows, int L, float clip,
-                                                          const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off) {
+                                                          const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= rows) return;
     const bool clamp = gmax && S && (*gmax > clip);
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(256) void posbias_bwd_table_kernel(const float* __r
 // Same clamp rule and the same Philox stream indexing (element row * L + c) in forward and backward.
 __global__ __launch_bounds__(256) void softmax_fwd_generic_kernel(const float* __restrict__ S, float* __restrict__ P, float* __restrict__ Pd,
                                                                   int64_t rows, int L, float clip, const float* __restrict__ gmax,
-                                                                  float p, uint64_t seed, uint64_t off) {
+                                                                  float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     __shared__ float red[4];
     const bool clamp = gmax && (*gmax > clip);
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(256) void softmax_fwd_generic_kernel(const float* _
 }
 __global__ __launch_bounds__(256) void softmax_bwd_generic_kernel(const float* __restrict__ P, const float* __restrict__ dPd, const float* __restrict__ S,
                                                                   float* __restrict__ dS, int64_t rows, int L, float clip,
-                                                                  const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off) {
+                                                                  const float* __restrict__ gmax, float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     __shared__ float red[4];
     const bool clamp = gmax && S && (*gmax > clip);
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -358,7 +362,8 @@ template <int NV4>
 __global__ __launch_bounds__(256) void prenorm_fwd_kernel(const float* __restrict__ X, const float* __restrict__ w1, const float* __restrict__ b1,
                                                           const float* __restrict__ pos, int64_t pos_ld, float pos_w, const float* __restrict__ mask,
                                                           float* __restrict__ Y, float* __restrict__ stats, int64_t rows, int N, int C, float eps,
-                                                          float p, uint64_t seed, uint64_t off) {
+                                                          float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= rows) return;
     const int n = (int)(row % N);
@@ -390,7 +395,8 @@ __global__ __launch_bounds__(256) void prenorm_bwd_kernel(const float* __restric
                                                           const float* __restrict__ b1, const float* __restrict__ pos, int64_t pos_ld, float pos_w,
                                                           const float* __restrict__ mask, const float* __restrict__ stats,
                                                           float* __restrict__ dX, float* __restrict__ dU, int64_t rows, int N, int C,
-                                                          float p, uint64_t seed, uint64_t off) {
+                                                          float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= rows) return;
     const int n = (int)(row % N);
@@ -489,7 +495,8 @@ template <int NV4, int MO>
 __global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                              const float* __restrict__ wa, const float* __restrict__ ba, float* __restrict__ Y,
                                                              float* __restrict__ stats, int64_t R, int F, float eps,
-                                                             float p, uint64_t seed, uint64_t off) {
+                                                             float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= R) return;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -541,7 +548,8 @@ template <int NV4, int MO>
 __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
                                                              float* __restrict__ dZ, float* __restrict__ dscore, int64_t R, int F,
-                                                             float p, uint64_t seed, uint64_t off) {
+                                                             float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int64_t row = SEGX_ROW_ID();
     if (row >= R) return;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -602,7 +610,8 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void modes_aggr_pgrad_stage1(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
                                                                const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
                                                                const float* __restrict__ dscore, float* __restrict__ ws, int Mo, int64_t R, int F,
-                                                               int nchunks, float p, uint64_t seed, uint64_t off) {
+                                                               int nchunks, float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int chunk = blockIdx.y;
     const int64_t per = (R + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(R, r0 + per);
@@ -629,7 +638,8 @@ __global__ __launch_bounds__(256) void modes_aggr_pgrad_stage1(const float* __re
 // GELU backward (+ dropout of MMSharedMid :244-245): dT = dH * keep * gelu'(T)
 // =================================================================================================
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dH, const float* __restrict__ T, float* __restrict__ dT, int64_t n4,
-                                                       float p, uint64_t seed, uint64_t off) {
+                                                       float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         const float4 g = reinterpret_cast<const float4*>(dH)[i], t = reinterpret_cast<const float4*>(T)[i];
@@ -652,20 +662,20 @@ extern "C" int segx_softmax_fwd(const float* S, float* P, float* Pdrop, int64_t 
     SEGX_STREAM; SEGX_REQUIRE(S && P && rows > 0 && L > 0, "segx_softmax_fwd: bad args");
     SEGX_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || Pdrop), "segx_softmax_fwd: dropout needs Pdrop");
     if (L % 4 != 0 || L > 4096) {
-        hipLaunchKernelGGL(softmax_fwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset);
+        hipLaunchKernelGGL(softmax_fwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset, rng_base());
         return check_launch("segx_softmax_fwd");
     }
-    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset));
+    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, S, P, p > 0.f ? Pdrop : nullptr, rows, L, clip, gmax, p, seed, offset, rng_base()));
     return check_launch("segx_softmax_fwd");
 }
 extern "C" int segx_softmax_bwd(const float* P, const float* dPdrop, const float* S, float* dS, int64_t rows, int L, float clip,
                                 const float* gmax, float p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(P && dPdrop && dS && rows > 0 && L > 0, "segx_softmax_bwd: bad args");
     if (L % 4 != 0 || L > 4096) {
-        hipLaunchKernelGGL(softmax_bwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset);
+        hipLaunchKernelGGL(softmax_bwd_generic_kernel, dim3((unsigned)i64min(rows, 65536)), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset, rng_base());
         return check_launch("segx_softmax_bwd");
     }
-    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset));
+    SEGX_DISPATCH_NV4(L, hipLaunchKernelGGL((softmax_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, P, dPdrop, S, dS, rows, L, clip, gmax, p, seed, offset, rng_base()));
     return check_launch("segx_softmax_bwd");
 }
 extern "C" int segx_layernorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd,
@@ -716,7 +726,7 @@ extern "C" int segx_prenorm_fwd(const float* X, const float* w1, const float* b1
     SEGX_STREAM; SEGX_REQUIRE(X && w1 && b1 && mask && Y && stats && B > 0 && N > 0, "segx_prenorm_fwd: bad args"); SEGX_ROWCHK(C);
     SEGX_REQUIRE(!pos || (pos_ld >= C && pos_ld % 4 == 0), "segx_prenorm_fwd: pos_ld %lld", (long long)pos_ld);
     const int64_t rows = B * N;
-    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, X, w1, b1, pos, pos_ld, pos_weight, mask, Y, stats, rows, N, C, eps, p, seed, offset));
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_fwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, X, w1, b1, pos, pos_ld, pos_weight, mask, Y, stats, rows, N, C, eps, p, seed, offset, rng_base()));
     return check_launch("segx_prenorm_fwd");
 }
 extern "C" int segx_prenorm_bwd(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
@@ -724,7 +734,7 @@ extern "C" int segx_prenorm_bwd(const float* dY, const float* X, const float* w1
                                 float p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && w1 && b1 && mask && stats && dX && dU && B > 0 && N > 0, "segx_prenorm_bwd: bad args"); SEGX_ROWCHK(C);
     const int64_t rows = B * N;
-    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dU, rows, N, C, p, seed, offset));
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dU, rows, N, C, p, seed, offset, rng_base()));
     return check_launch("segx_prenorm_bwd");
 }
 extern "C" int segx_posembed_fwd(const float* posn, const float* Wp, const float* bp, float* out, float* stats, int64_t N, int C, int pd,
@@ -746,8 +756,8 @@ extern "C" int segx_modes_aggr_fwd(const float* Z, const float* lnw, const float
     SEGX_STREAM; SEGX_REQUIRE(Z && (!lnw == !lnb) && wa && ba && Y && stats && R > 0, "segx_modes_aggr_fwd: bad args"); SEGX_ROWCHK(F);
     SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_fwd: F=%d too wide for the register-resident 4-mode kernel", F);
     SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
-        hipLaunchKernelGGL((modes_aggr_fwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset),
-        hipLaunchKernelGGL((modes_aggr_fwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset)));
+        hipLaunchKernelGGL((modes_aggr_fwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset, rng_base()),
+        hipLaunchKernelGGL((modes_aggr_fwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, Z, lnw, lnb, wa, ba, Y, stats, R, F, eps, p, seed, offset, rng_base())));
     return check_launch("segx_modes_aggr_fwd");
 }
 extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
@@ -755,8 +765,8 @@ extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float*
     SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dZ && dscore && R > 0, "segx_modes_aggr_bwd: bad args"); SEGX_ROWCHK(F);
     SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_bwd: F=%d too wide for the register-resident 4-mode kernel", F);
     SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
-        hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset),
-        hipLaunchKernelGGL((modes_aggr_bwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset)));
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base()),
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base())));
     return check_launch("segx_modes_aggr_bwd");
 }
 extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
@@ -764,14 +774,14 @@ extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const
                                           float p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dscore && dlnw && dlnb && dwa && ws && R > 0, "segx_modes_aggr_param_grad: bad args");
     const int nch = chunks_for(R);
-    hipLaunchKernelGGL(modes_aggr_pgrad_stage1, dim3((F + 255) / 256, nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dscore, ws, Mo, R, F, nch, p, seed, offset);
+    hipLaunchKernelGGL(modes_aggr_pgrad_stage1, dim3((F + 255) / 256, nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dscore, ws, Mo, R, F, nch, p, seed, offset, rng_base());
     hipLaunchKernelGGL(colreduce_stage2, dim3((F + 255) / 256), dim3(256), 0, stream, (const float*)ws, dlnw, dlnb, dwa, (int64_t)F, nch, 3);
     return check_launch("segx_modes_aggr_param_grad");
 }
 extern "C" int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dH && T && dT && n > 0 && n % 4 == 0, "segx_gelu_bwd: n=%lld must be a positive multiple of 4", (long long)n);
     const int nb = (int)i64min(4096, (n / 4 + 255) / 256);
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset);
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset, rng_base());
     return check_launch("segx_gelu_bwd");
 }
 /* geom = {D, H, W, R, nd}: token grid (D = 1 in 2-D), radius, position dims */

@@ -99,8 +99,8 @@ class MBConvBlock(nn.Module):
         x = inputs
         if self.expand_ratio != 1:
             x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
-        x = SF.bn_act(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH)
-        x = SF.squeeze_excite(x, self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
+        x = SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH,
+                         self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
         x = SF.bn_act(self._project_conv(x), self._bn2, SF.ACT_NONE)
         if self.stride == 1 and self.input_filters == self.output_filters:
             scale = None

@@ -139,3 +139,56 @@ class TrainStep:
             self.reducer.allreduce_grads()
         self.opt.step()
         return loss
+
+
+class GraphedTrainStep:
+    """One train step captured into a hipGraph and replayed (single process): ~2300 launches (cfg2) / ~1500 (cfg1) become one graph launch,
+    which removes the host from the step -- what the small per-GPU batches need (cfg1 at batch 2 is launch-bound when run eagerly).
+
+    What makes the captured step replayable: (a) dropout -- every kernel adds a device-side base to its Philox offset (segx_set_rng_base) and
+    the graph ends with segx_rng_advance(base, span of the step), so each replay draws fresh masks while forward and backward of one replay
+    still regenerate the same ones; (b) the LR schedule -- folded into the optimizer's device lr table, refreshed by one small async copy
+    before each replay (BertAdam.prepare_replay); (c) gradients / activations live at fixed addresses in the graph's private memory pool, so
+    the optimizer's gradient pointer table is constant; (d) inputs are copied into static buffers.  Nothing in the step reads a device value
+    on the host (no `.item()`), so capture needs no special casing in the model."""
+
+    def __init__(self, step, x, raw, warmup=3):
+        from . import segx
+        assert step.reducer is None, 'GraphedTrainStep is the single-process step (collectives are not captured)'
+        self.step, self.L = step, segx.lib()
+        assert self.L.gemm_prof is None, 'per-launch event profiling cannot run inside a captured step'
+        self.x, self.raw = x.clone(), raw.clone()
+        self.rng_base = torch.zeros(1, dtype=torch.int64, device=x.device)
+        self.L.set_rng_base(self.rng_base)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                       # eager warm-up: optimizer tables, the set of trained parameters (N3), allocator pools
+            for _ in range(warmup):
+                step(self.x, self.raw)
+        torch.cuda.current_stream().wait_stream(side)
+        step.opt.enter_graph_mode()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        off0 = SF._Rng.offset
+        with torch.cuda.graph(self.graph):
+            self.loss = step(self.x, self.raw)
+            self.span = SF._Rng.offset - off0
+            self.L.rng_advance(self.rng_base, self.span)
+        self.replays = 0
+
+    def __call__(self, x, raw):
+        if x is not self.x:
+            self.x.copy_(x, non_blocking=True)
+        if raw is not self.raw:
+            self.raw.copy_(raw, non_blocking=True)
+        self.step.opt.prepare_replay()
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+    @property
+    def stats(self):
+        return self.step.stats
+
+    def close(self):
+        self.L.set_rng_base(None)

@@ -596,6 +596,41 @@ _bn_stats_sync = None        # set by segtran_amd.dist for data-parallel runs: m
 _bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair of the BN backward
 
 
+def _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S):
+    """(mean, var, n) the BatchNorm normalises with: batch statistics (merged over the ranks when synchronised) or the running ones."""
+    if not training:
+        return run_mean, run_var, B * S
+    if _bn_stats_sync is None:
+        mean, var = _empty(x, C), _empty(x, C)
+        L.bn_stats(x, mean, var, run_mean, run_var, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+        return mean, var, B * S
+    # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
+    loc = _empty(x, 2 * C)
+    L.bn_stats(x, loc[:C], loc[C:], None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+    allv, world = _bn_stats_sync(loc)
+    mean, var = _empty(x, C), _empty(x, C)
+    L.bn_merge_stats(allv, mean, var, run_mean, run_var, world, C, B * S, momentum)
+    return mean, var, B * S * world
+
+
+def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_S=0.0):
+    """dx, dw, db of BatchNorm + activation; gate / dpool: a squeeze-excite gate sits behind it (see segx_bn_act_bwd)."""
+    B, C, S, eps, act, training, n = cfg
+    dx = torch.empty_like(x)
+    if training and _bn_grad_sync is not None:
+        # synchronised BN: local sums written into one [2C] buffer -> ONE all-reduce -> apply with the global sums / global count.
+        # The parameter gradients stay the LOCAL sums (the flat-gradient all-reduce averages them like every other gradient).
+        both = _empty(x, 2 * C)
+        dw, db = both[:C], both[C:]
+        L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, gate, dpool, inv_S)
+        glob = _bn_grad_sync(both)
+        L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n, gate, dpool, inv_S)
+    else:
+        dw, db = _empty(x, C), _empty(x, C)
+        L.bn_act_bwd(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S)
+    return dx, dw, db
+
+
 class _BNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act):
@@ -603,21 +638,7 @@ class _BNAct(torch.autograd.Function):
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         S = x.numel() // (B * C)
-        if training:
-            if _bn_stats_sync is None:
-                mean, var = _empty(x, C), _empty(x, C)
-                L.bn_stats(x, mean, var, run_mean, run_var, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
-                n = B * S
-            else:
-                # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
-                loc = _empty(x, 2 * C)
-                L.bn_stats(x, loc[:C], loc[C:], None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
-                allv, world = _bn_stats_sync(loc)
-                mean, var = _empty(x, C), _empty(x, C)
-                L.bn_merge_stats(allv, mean, var, run_mean, run_var, world, C, B * S, momentum)
-                n = B * S * world
-        else:
-            mean, var, n = run_mean, run_var, B * S
+        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
         y = torch.empty_like(x)
         L.bn_act_fwd(x, mean, var, w, b, y, B, C, S, eps, act)
         ctx.cfg = (B, C, S, eps, act, training, n)
@@ -628,20 +649,7 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         L = segx.lib()
         x, mean, var, w, b = ctx.saved_tensors
-        B, C, S, eps, act, training, n = ctx.cfg
-        dx = torch.empty_like(x)
-        dy = _c(dy)
-        if training and _bn_grad_sync is not None:
-            # synchronised BN: local sums written into one [2C] buffer -> ONE all-reduce -> apply with the global sums / global count.
-            # The parameter gradients stay the LOCAL sums (the flat-gradient all-reduce averages them like every other gradient).
-            both = _empty(x, 2 * C)
-            dw, db = both[:C], both[C:]
-            L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act)
-            glob = _bn_grad_sync(both)
-            L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n)
-        else:
-            dw, db = _empty(x, C), _empty(x, C)
-            L.bn_act_bwd(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0)
+        dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg)
         return dx, dw, db, None, None, None, None, None, None
 
 
@@ -755,6 +763,58 @@ class _SqueezeExcite(torch.autograd.Function):
 
 def squeeze_excite(x, w1, b1, w2, b2):
     return _SqueezeExcite.apply(x, w1, b1, w2, b2)
+
+
+class _BNActSE(torch.autograd.Function):
+    """squeeze_excite(bn_act(x)) as ONE op (MBConvBlock.forward, efficientnet/model.py:101-110): the squeeze-excite pooling comes out of the
+    BatchNorm + swish pass (no separate plane-sum pass over y), and in backward the gate's product rule -- dy = dz * gate + dpool / S -- is
+    applied on the fly by the BatchNorm backward kernels instead of being written out by a pass of its own."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act, w1, b1, w2, b2):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        S = x.numel() // (B * C)
+        Cs = w1.shape[0]
+        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
+        y = torch.empty_like(x)
+        pooled = _empty(x, B * C)
+        L.bn_act_fwd_pool(x, mean, var, w, b, y, pooled, _empty(x, B * C * 64), B, C, S, eps, act)
+        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
+        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
+        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
+        z = torch.empty_like(x)
+        L.plane_scale(y, gate, z, B * C, S)
+        ctx.cfg = (B, C, S, eps, act, training, n)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), Cs)
+        ctx.save_for_backward(x, mean, var, w, b, y, p, hpre, gate, W1, W2)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        L = segx.lib()
+        x, mean, var, w, b, y, p, hpre, gate, W1, W2 = ctx.saved_tensors
+        B, C, S = ctx.cfg[:3]
+        w1s, w2s, Cs = ctx.shapes
+        dz = _c(dz)
+        dgate = _empty(x, B * C)
+        L.plane_dot(dz, y, dgate, B * C, S)
+        dpool = _empty(x, B * C)
+        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
+        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
+        dx, dw, db = _bn_act_backward(L, dz, x, mean, var, w, b, ctx.cfg, gate.reshape(-1), dpool, 1.0)
+        return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
+
+
+def bn_act_se(x, bn, act, w1, b1, w2, b2):
+    """squeeze_excite(bn_act(x, bn, act), w1, b1, w2, b2), fused (see _BNActSE)."""
+    if bn.training and bn.num_batches_tracked is not None:
+        if _bn_ticks is not None:
+            _bn_ticks.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _BNActSE.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
 
 
 class _SkipAdd(torch.autograd.Function):

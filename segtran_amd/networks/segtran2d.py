@@ -20,7 +20,7 @@ from argparse import Namespace
 from .. import functional as SF
 from ..efficientnet.model import EfficientNet
 from .segtran_shared import (SegtranConfig, bb2feat_dims, SegtranFusionEncoder, CrossAttFeatTrans,  # noqa: F401
-                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices)
+                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices, gen_scaled_positions)
 
 
 class Segtran2dConfig(SegtranConfig):
@@ -193,8 +193,7 @@ class Segtran2d(SegtranInitWeights):
         feats = tuple(ep['reduction_%d' % i] for i in range(1, 6))
         vfeat, vmask, H2, W2 = self.in_fpn_forward(feats, nonzero_mask, B)
         xy_shape = torch.Size((H2, W2))
-        scale = torch.tensor([[H // H2, W // W2]], device=batch.device, dtype=torch.float32)
-        voxels_pos = gen_all_indices(xy_shape, batch.device).view(-1, 2).float() * scale        # [N, 2], batch-invariant
+        voxels_pos = gen_scaled_positions(xy_shape, (H // H2, W // W2), batch.device)            # [N, 2], batch-invariant
         fused = self.voxel_fusion(vfeat, voxels_pos, vmask, xy_shape)
         self.layers_attn_scores = self.voxel_fusion.layers_attn_scores
         self.orig_feat_shape = xy_shape

@@ -18,7 +18,7 @@ from argparse import Namespace
 from .. import functional as SF
 from .aj_i3d.aj_i3d import InceptionI3d
 from .segtran_shared import (SegtranConfig, bb2feat_dims, SegtranFusionEncoder, CrossAttFeatTrans,  # noqa: F401
-                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices)
+                             ExpandedFeatTrans, SegtranInitWeights, gen_all_indices, gen_scaled_positions)
 
 
 class Segtran3dConfig(SegtranConfig):
@@ -226,9 +226,8 @@ class Segtran3d(SegtranInitWeights):
         feats = (fd['MaxPool3d_2a_3x3'], fd['Conv3d_2c_3x3'], fd['Mixed_3c'], fd['Mixed_4f'], fd['Mixed_5c'])
         vfeat, vmask, D2, H2, W2 = self.in_fpn_forward(feats, nonzero_mask)
         xyz_shape = torch.Size((D2, H2, W2))
-        scale = torch.tensor([[(D // D2) / self.input_scale[2], (H // H2) / self.input_scale[0],
-                               (W // W2) / self.input_scale[1]]], device=batch.device, dtype=torch.float32)
-        voxels_pos = gen_all_indices(xyz_shape, batch.device).view(-1, 3).float() * scale
+        voxels_pos = gen_scaled_positions(xyz_shape, ((D // D2) / self.input_scale[2], (H // H2) / self.input_scale[0],
+                                                     (W // W2) / self.input_scale[1]), batch.device)
         fused = self.voxel_fusion(vfeat, voxels_pos, vmask, xyz_shape)
         self.layers_attn_scores = self.voxel_fusion.layers_attn_scores
         self.orig_feat_shape = xyz_shape

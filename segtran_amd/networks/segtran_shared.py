@@ -42,6 +42,13 @@ def gen_all_indices(shape, device):
     return torch.stack(grids, dim=len(shape))
 
 
+def gen_scaled_positions(shape, scales, device):
+    """gen_all_indices(shape).view(-1, nd).float() * scales (segtran2d.py:375-389, segtran3d.py:443-468), built from device-side aranges and
+    python scalars only: no host-to-device tensor upload, so the forward pass can be captured into a hipGraph.  Same fp32 products."""
+    axes = [torch.arange(int(n), device=device, dtype=torch.float32) * float(sc) for n, sc in zip(shape, scales)]
+    return torch.stack(torch.meshgrid(*axes, indexing='ij'), dim=len(axes)).view(-1, len(axes))
+
+
 class SegtranConfig:
     """Application-independent settings; same field names and defaults as the reference (:90-196)."""
 

@@ -132,6 +132,12 @@ class BertAdam(Optimizer):
         if tab.device.type != 'cuda':
             tab.copy_(torch.tensor(ptrs, dtype=torch.int64, device='cpu'))
             return
+        if torch.cuda.is_current_stream_capturing():
+            # hipGraph capture (engine.GraphedTrainStep): the gradient tensors of a captured step live at fixed addresses of the graph's private
+            # pool, so the table written here is the table of every replay; no event bookkeeping (events cannot be waited on while capturing)
+            self._graph_ptrs.copy_(torch.tensor(ptrs, dtype=torch.int64, device='cpu'))        # pinned buffer allocated by enter_graph_mode()
+            tab.copy_(self._graph_ptrs, non_blocking=True)
+            return
         if self._ring is None:
             self._ring = [(torch.empty(len(ps), dtype=torch.int64, device='cpu').pin_memory(), torch.cuda.Event()) for _ in range(4)]
         buf, ev = self._ring[self._ring_pos]
@@ -240,14 +246,46 @@ class BertAdam(Optimizer):
         """Global gradient norm of the last step (device tensor; reading it synchronises)."""
         return self._ws[self._nch + 2 * self._nt]
 
+    # ---- hipGraph mode: the schedule factor cannot be a kernel argument of a replayed launch -> it is folded into the lr table ----------
+    def enter_graph_mode(self):
+        """After this call step() launches with schedule factor 1 and reads lr[t] * schedule(step) from the device table that
+        prepare_replay() refreshes (one 2-KB async copy on the step's stream) before every replay of the captured step."""
+        self._ensure_tables()
+        self._graph_mode = True
+        ps = self._all_params()
+        self._lr_host = torch.tensor([g['lr'] for _, g in ps], dtype=torch.float32, device='cpu')
+        self._lr_pinned = [torch.empty_like(self._lr_host).pin_memory() for _ in range(4)] if self.flat_m.is_cuda else None
+        self._lr_slot = 0
+        self._graph_ptrs = torch.empty(len(ps), dtype=torch.int64, device='cpu')
+        if self.flat_m.is_cuda:
+            self._graph_ptrs = self._graph_ptrs.pin_memory()
+        self.prepare_replay(advance=False)
+
+    def prepare_replay(self, advance=True):
+        g = self.param_groups[0]
+        sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
+        if self._lr_pinned is None:
+            self._tabs['lr'].copy_(self._lr_host * sched)
+        else:
+            buf = self._lr_pinned[self._lr_slot]; self._lr_slot = (self._lr_slot + 1) % len(self._lr_pinned)
+            torch.mul(self._lr_host, sched, out=buf)
+            self._tabs['lr'].copy_(buf, non_blocking=True)
+        if advance:
+            self.step_count += 1
+
     @torch.no_grad()
     def step(self, closure=None, global_grad_clip=None):
         loss = closure() if closure is not None else None
         self._ensure_tables()
         if self._private:
             self._refresh_grad_table()
-        self._sync_lr_wd()
         g = self.param_groups[0]
+        if getattr(self, '_graph_mode', False):
+            clip = self.global_grad_clip if global_grad_clip is None else global_grad_clip
+            segx.lib().mt_bertadam_step(self._tabs, self._nt, self._nch, CHUNK, float(clip), float(g['max_grad_norm']),
+                                        1.0, g['b1'], g['b2'], g['e'], self._ws)
+            return loss                                   # step_count advances in prepare_replay()
+        self._sync_lr_wd()
         sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
         clip = self.global_grad_clip if global_grad_clip is None else global_grad_clip
         segx.lib().mt_bertadam_step(self._tabs, self._nt, self._nch, CHUNK, float(clip), float(g['max_grad_norm']),

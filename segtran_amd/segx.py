@@ -69,6 +69,13 @@ class SegxLib:
             raise RuntimeError('segx_tune(4): engine %r rejected' % name)
         return 'x6' if prev == 1 else 'f32'
 
+    def set_rng_base(self, t):
+        """t: int64 [1] device tensor (kept alive by the caller) holding the device-side base of every dropout stream, or None."""
+        self.check(self.c.segx_set_rng_base(_ptr(t)), 'segx_set_rng_base')
+
+    def rng_advance(self, t, span):
+        self.check(self.c.segx_rng_advance(_ptr(t), int(span), self.stream(t)), 'segx_rng_advance')
+
     def x6_launches(self):
         """launches that ran on the bf16x6 engine since the last call"""
         return int(self.c.segx_tune(5, 0))
@@ -227,8 +234,11 @@ class SegxLib:
     def bn_act_fwd(self, X, mean, var, w, b, Y, B, C, S, eps, act):
         self._call('segx_bn_act_fwd', X, X, mean, var, w, b, Y, B, C, S, eps, act)
 
-    def bn_act_bwd(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training):
-        self._call('segx_bn_act_bwd', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training)
+    def bn_act_bwd(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0):
+        self._call('segx_bn_act_bwd', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate, dpool, float(inv_S))
+
+    def bn_act_fwd_pool(self, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act):
+        self._call('segx_bn_act_fwd_pool', X, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act)
 
     def dwconv2d_fwd(self, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl):
         self._call('segx_dwconv2d_fwd', X, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl)
@@ -248,11 +258,11 @@ class SegxLib:
     def bn_merge_stats(self, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum):
         self._call('segx_bn_merge_stats', allv, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum)
 
-    def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act):
-        self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act)
+    def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate=None, dpool=None, inv_S=0.0):
+        self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate, dpool, float(inv_S))
 
-    def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n):
-        self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n)
+    def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0):
+        self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S))
 
     def plane_scale_add(self, X, gate, R, Y, planes, S):
         self._call('segx_plane_scale_add', X, X, gate, R, Y, planes, S)
@@ -434,15 +444,15 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
-    'segx_tune': 'ii', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
-    'segx_bn_act_bwd': 'ppppppppppiilfiip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
+    'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp',
-    'segx_bn_act_bwd_reduce': 'pppppppppiilfip', 'segx_bn_act_bwd_apply': 'pppppppppiilfifp',
+    'segx_bn_act_bwd_reduce': 'pppppppppiilfippfp', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppfp',
 }
 
 _LIB = None

@@ -352,3 +352,46 @@ def test_ragged_3d_size_vs_oracle():
     assert torch.equal((y.cpu() > 0)[safe], (yo > 0)[safe])
     y.sum().backward()
     assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)
+
+
+def test_graphed_train_step_matches_eager_and_draws_fresh_dropout_masks(tile_engine):
+    """engine.GraphedTrainStep: the whole train step captured into one hipGraph.  Dropout-free it must reproduce the eager loss trajectory
+    (same kernels, same order; the LR schedule comes from the refreshed device table); with dropout every replay must use a NEW part of the
+    Philox stream (device-side base advanced by the captured segx_rng_advance) -- and the eager path must be unaffected afterwards."""
+    from segtran_amd import segx
+    if tile_engine != 'x6':
+        pytest.skip('one engine is enough for the capture mechanics')
+    c = dict(engine.CONFIGS['cfg1'], size=(64, 64))
+
+    def make(drop):
+        torch.manual_seed(7); SF.manual_seed(7)
+        net = engine.build_model(c, DEV, dropout_prob=drop, attractors=32)
+        net.backbone.drop_connect_rate = 0.0 if drop == 0 else net.backbone.drop_connect_rate
+        net.train()
+        return engine.TrainStep(net, engine.init_optimizer(net, 'fundus', t_total=50, warmup_steps=4), 'fundus')
+    x, raw = engine.synth_batch(c, 2, DEV)
+    eager = make(0.0)
+    ref = [float(eager(x, raw).detach()) for _ in range(8)]
+    g = engine.GraphedTrainStep(make(0.0), x, raw, warmup=3)
+    try:
+        got = [float(g(x, raw).detach()) for _ in range(5)]
+        assert max(abs(a - b) for a, b in zip(got, ref[3:])) < 2e-5, (got, ref[3:])
+        assert g.step.opt.step_count == 8 and abs(g.step.opt.get_lr()[0] - eager.opt.get_lr()[0]) < 1e-12
+    finally:
+        g.close()
+    gd = engine.GraphedTrainStep(make(0.2), x, raw, warmup=2)
+    try:
+        assert gd.span > 0 and gd.span % 4 == 0
+        for _ in range(3):
+            gd(x, raw)
+        torch.cuda.synchronize()
+        assert int(gd.rng_base.item()) == 3 * gd.span
+    finally:
+        gd.close()
+    # the device-side base is an additive shift of the stream: dropout at (offset 0, base b) == dropout at (offset b, no base)
+    L = segx.lib()
+    v = torch.ones(4096, device=DEV); y0 = torch.empty_like(v); y1 = torch.empty_like(v)
+    base = torch.full((1,), 1024, dtype=torch.int64, device=DEV)
+    L.set_rng_base(base); L.dropout(v, y0, 4096, 0.3, 99, 0); L.set_rng_base(None)
+    L.dropout(v, y1, 4096, 0.3, 99, 1024)
+    assert torch.equal(y0, y1) and 0.2 < (y0 == 0).float().mean().item() < 0.4

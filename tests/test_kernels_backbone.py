@@ -89,6 +89,37 @@ def test_squeeze_excite(backend, B, C, Cs, H, W):
         close(a.grad, r.grad, 1e-4)
 
 
+@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 70, 9, 4, 5), (1, 3, 2, 130, 130)])      # last: several chunks per plane
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
+    """The one-op form an MBConv block uses (BatchNorm + swish with the squeeze-excite pooling in the same pass, the gate's product rule applied
+    inside the BatchNorm backward kernels) vs BatchNorm -> swish -> squeeze-excite in plain PyTorch autograd."""
+    bn, ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        for m in (bn, ref):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=1)); m.bias.copy_(0.2 * rnd(C, seed=2))
+            m.running_mean.copy_(0.1 * rnd(C, seed=3)); m.running_var.copy_(1 + 0.1 * rnd(C, seed=4).abs())
+    bn.train(training); ref.train(training)
+    x = (rnd(B, C, H, W, seed=20) * 1.3 + 0.2).requires_grad_(True)
+    ps = [rnd(Cs, C, 1, 1, seed=21, scale=0.5), rnd(Cs, seed=22, scale=0.1), rnd(C, Cs, 1, 1, seed=23, scale=0.5), rnd(C, seed=24, scale=0.1)]
+    ps = [p.requires_grad_(True) for p in ps]
+    z = SF.bn_act_se(x, bn, SF.ACT_SWISH, *ps)
+    xr = x.detach().clone().requires_grad_(True)
+    pr = [p.detach().clone().requires_grad_(True) for p in ps]
+    yr = _act(ref(xr), 1)
+    sq = F.conv2d(F.adaptive_avg_pool2d(yr, 1), pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
+    zr = torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * yr
+    close(z, zr.detach())
+    G = rnd(B, C, H, W, seed=25)
+    z.backward(G); zr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+    close(bn.weight.grad, ref.weight.grad, 1e-4); close(bn.bias.grad, ref.bias.grad, 1e-4)
+    for a, r in zip(ps, pr):
+        close(a.grad, r.grad, 1e-4)
+    close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 6, 10), (3, 8, 3, 4, 5), (1, 24, 9, 9)])
 def test_group_norm(backend, shape):
     C = shape[1]

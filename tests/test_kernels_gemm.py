@@ -110,6 +110,24 @@ def test_gemm_splitk_and_bias_m(backend):
     assert (dW.double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize('nb,sk,M,N', [((2, 1), 1, 40, 24), ((3, 2), 1, 40, 24), ((5, 4), 1, 33, 17), ((2, 2), 3, 70, 50), ((2, 1), 1, 600, 520)])
+def test_gemm_batch_reduce_sums_over_the_batch(backend, nb, sk, M, N):
+    """batch_reduce: ONE [M, N] result = alpha * sum over the batch of A_z B_z^T (+ bias once) -- the shape of a weight gradient whose operand
+    is broadcast over the batch.  The cases walk the three slab-reduction kernels (16 / 4 threads per output, one thread per output)."""
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(9)
+    K = 26
+    A = torch.randn(nb[0], nb[1], M, K, generator=g, device='cpu').to(backend.dev)
+    B = torch.randn(nb[0], nb[1], N, K, generator=g, device='cpu').to(backend.dev)
+    bias = torch.randn(N, generator=g, device='cpu').to(backend.dev)
+    C = torch.zeros(M, N)
+    ws = torch.zeros(sk * nb[0] * nb[1] * M * N)
+    L.gemm(A, B, C, M, N, K, (nb[1] * M * K, M * K, K, 1), (nb[1] * N * K, N * K, K, 1), (0, 0, N), nb=nb, alpha=0.5, bias=bias, bias_mode=segx.BIAS_N,
+           splitk=sk, workspace=ws, batch_reduce=True)
+    ref = 0.5 * torch.einsum('xymk,xynk->mn', A.double(), B.double()) + bias.double()[None]
+    assert (C.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item() / 10)
+
+
 def test_gemm_rejects_bad_strides(backend):
     L = backend.L
     A = torch.zeros(8, 8); C = torch.zeros(8, 8)
