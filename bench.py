@@ -205,6 +205,23 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         torch.cuda.synchronize()
         other = (time.perf_counter() - t1) / k
         set_op_order(net, not args.reference_op_order)
+    replay = None
+    if world == 1 and other_order and not args.single_order and not graphed:   # and as ONE captured hipGraph per step (also outside the timed region)
+        try:
+            g = engine.GraphedTrainStep(step, x, raw, warmup=2)
+            for _ in range(3):
+                g(x, raw)
+            torch.cuda.synchronize()
+            k = max(5, min(20, steps // 2))
+            t1 = time.perf_counter()
+            for _ in range(k):
+                gl = g(x, raw)
+            torch.cuda.synchronize()
+            t = (time.perf_counter() - t1) / k
+            replay = {'value': round(B / t, 3), 'ms_per_step': round(t * 1e3, 2), 'steps': k, 'final_loss': round(float(gl), 5)}
+            g.close()
+        except Exception as e:                                                 # the eager line above is the measurement; say why this one is missing
+            replay = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
     lossv = float(loss.detach())
     assert lossv == lossv, 'loss is NaN'
     del step, opt, net, reducer
@@ -231,7 +248,8 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
                       'op_order': ('reference' if args.reference_op_order else 're-associated') + ' (DESIGN.md 5b: exact re-association of '
                                   'consecutive linear maps; every layer, parameter and gradient is computed)',
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
-                          None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)}},
+                          None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)},
+                      'hipgraph_replay': replay},
            'roofline': roof}
     if rank == 0:
         print('[bench] %s: %.1f ms/step (median %.1f), %.2f %s, engine %.1f TFLOP/s' % (cfg_name, res['ms_per_step'], med, res['value'], unit, achieved),

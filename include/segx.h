@@ -213,6 +213,9 @@ int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B
  * Y = X * gate[plane];  out[plane] = sum_s A*B;  dX = dY * gate[plane] + dpool[plane] */
 int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream);
 /* Y = X * gate[plane] + R: MBConv skip connection with the per-sample drop_connect scale (model.py:118-122) */
+/* Y[p][s] = X[p][s] + bias[p % C]: the bias of a dense k x k convolution run on the implicit-GEMM engine (nn.Conv2d(..., 3, padding=1) of the
+ * U-Net host, unet2d/unet_parts.py:16-20); in place allowed */
+int segx_plane_bias_add(const float* X, const float* bias, float* Y, int64_t planes, int C, int64_t S, void* stream);
 int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream);
 int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream);
 int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream);
@@ -261,8 +264,9 @@ int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64
                            void* stream);
 /* forward along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chained x -> y -> z it is
  * bit-identical to segx_interp_linear_fwd (same blends in the same order) and streams at HBM rate */
-/* src_scale: source step per destination index; <= 0 -> n_in / n_out (F.interpolate(size=...)); explicit s reproduces
- * F.interpolate(scale_factor=1/s) on sizes s does not divide (Mince transformer, reference segtran_shared.py:47-66) */
+/* src_scale: source step per destination index; 0 -> n_in / n_out (F.interpolate(size=...)); explicit s > 0 reproduces
+ * F.interpolate(scale_factor=1/s) on sizes s does not divide (Mince transformer, reference segtran_shared.py:47-66); s < 0 selects
+ * align_corners=True with |s| = (n_in - 1) / (n_out - 1) (nn.Upsample(..., align_corners=True) of the U-Net host, unet2d/unet_parts.py:48) */
 int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
                                 float src_scale, void* stream);
 /* RandomResizedCrop of the 3-D trainer (dataloaders/datasets3d.py:611-665, train3d.py:713-715): resample X [planes, d, h, w] to (D, H, W)

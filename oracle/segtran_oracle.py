@@ -193,6 +193,38 @@ def polyformer_layer(sd, p, in_feat, num_modes=4, attn_clip=500., do_layernorm=F
     return in_feat + F.interpolate(out_half, size=in_feat.shape[2:], mode='bilinear', align_corners=False)
 
 
+def unet_forward(sd, x, training=False, use_polyformer=True, num_modes=4, running=None):
+    """UNet.forward (networks/unet2d/unet_model.py:36-55) on the parts of unet_parts.py: DoubleConv = (Conv2d 3x3 pad 1 + bias -> BatchNorm2d ->
+    ReLU) x 2 (:9-26), Down = MaxPool2d(2) + DoubleConv (:29-41), Up = bilinear x2 with align_corners=True, zero-pad to the skip, cat [skip, up],
+    DoubleConv with in // 2 middle channels (:44-70), OutConv 1x1 (:73-78); the Polyformer layer sits before the class projection.
+    running (dict, optional): receives the updated running statistics of the BatchNorm layers (training mode)."""
+    def dconv(p, t):
+        for i in (0, 3):
+            t = F.conv2d(t, sd['%s.%d.weight' % (p, i)], sd['%s.%d.bias' % (p, i)], padding=1)
+            q = '%s.%d' % (p, i + 1)
+            rm, rv = sd[q + '.running_mean'].clone(), sd[q + '.running_var'].clone()
+            t = F.relu(F.batch_norm(t, rm, rv, sd[q + '.weight'], sd[q + '.bias'], training, 0.1, 1e-5))
+            if running is not None:
+                running[q + '.running_mean'], running[q + '.running_var'] = rm, rv
+        return t
+
+    def up(p, deep, skip):
+        u = F.interpolate(deep, scale_factor=2, mode='bilinear', align_corners=True)
+        dy, dx = skip.shape[2] - u.shape[2], skip.shape[3] - u.shape[3]
+        u = F.pad(u, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        return dconv(p + '.conv.double_conv', torch.cat([skip, u], dim=1))
+
+    x1 = dconv('inc.double_conv', x)
+    x2 = dconv('down1.maxpool_conv.1.double_conv', F.max_pool2d(x1, 2))
+    x3 = dconv('down2.maxpool_conv.1.double_conv', F.max_pool2d(x2, 2))
+    x4 = dconv('down3.maxpool_conv.1.double_conv', F.max_pool2d(x3, 2))
+    x5 = dconv('down4.maxpool_conv.1.double_conv', F.max_pool2d(x4, 2))
+    y = up('up4', up('up3', up('up2', up('up1', x5, x4), x3), x2), x1)
+    if use_polyformer:
+        y = polyformer_layer(sd, 'polyformer.polyformer_layers.0', y, num_modes)
+    return F.conv2d(y, sd['outc.conv.weight'], sd['outc.conv.bias'])
+
+
 def learned_sinu_pos_embed(sd, p, pos_normed):
     """LearnedSinuPosEmbedder.forward  (segtran_shared.py:989-998), omega=1, no affine."""
     z = F.linear(pos_normed, sd[p + '.pos_fc.weight'], sd[p + '.pos_fc.bias'])

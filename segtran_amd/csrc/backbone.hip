@@ -550,6 +550,12 @@ __global__ __launch_bounds__(256) void plane_scale_kernel(const float* __restric
     const float* x = X + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * gt;
 }
+// y = x + bias[plane % C]   (bias of a dense convolution whose GEMM runs without one)
+__global__ __launch_bounds__(256) void plane_bias_add_kernel(const float* __restrict__ X, const float* __restrict__ bias, float* __restrict__ Y, int C, int64_t S) {
+    const float bv = bias[blockIdx.y % C];
+    const float* x = X + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
+    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] + bv;
+}
 // y = x * gate[plane] + r   (MBConv skip connection with per-sample drop_connect scale, model.py:118-122)
 __global__ __launch_bounds__(256) void plane_scale_add_kernel(const float* __restrict__ X, const float* __restrict__ gate, const float* __restrict__ R,
                                                               float* __restrict__ Y, int64_t S) {
@@ -853,6 +859,11 @@ extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int
     SEGX_STREAM; SEGX_REQUIRE(X && gate && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale: bad args");
     hipLaunchKernelGGL(plane_scale_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, gate, Y, S);
     return check_launch("segx_plane_scale");
+}
+extern "C" int segx_plane_bias_add(const float* X, const float* bias, float* Y, int64_t planes, int C, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && bias && Y && planes > 0 && C > 0 && S > 0 && planes <= 65535, "segx_plane_bias_add: bad args");
+    hipLaunchKernelGGL(plane_bias_add_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, bias, Y, C, S);
+    return check_launch("segx_plane_bias_add");
 }
 extern "C" int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && gate && R && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_add: bad args");

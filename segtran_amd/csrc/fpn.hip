@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256) void interp_fwd_rows_kernel(const float* __res
 }
 // adjoint as a GATHER (deterministic, no atomics): an input cell collects from every output cell it was blended into
 __device__ __forceinline__ void cand_range(int i, int n_out, float scale, int& lo, int& hi) {
+    if (scale < 0.f) {                                   // align_corners: src = |scale| * d lies in (i - 1, i + 1)
+        const float inv = -1.0f / scale;
+        lo = (int)floorf(((float)i - 1.f) * inv) - 1; hi = (int)ceilf(((float)i + 1.f) * inv) + 1;
+        lo = lo < 0 ? 0 : lo; hi = hi > n_out - 1 ? n_out - 1 : hi;
+        return;
+    }
     const float inv = 1.0f / scale;
     lo = (int)floorf(((float)i - 0.5f) * inv - 0.5f) - 1; hi = (int)ceilf(((float)i + 1.5f) * inv - 0.5f) + 1;
     lo = lo < 0 ? 0 : lo; hi = hi > n_out - 1 ? n_out - 1 : hi;
@@ -394,7 +400,7 @@ extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, f
     const int64_t per = (int64_t)n_out * in_;
     const int64_t total = outer * per;
     const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
-    const float scale = src_scale > 0.f ? src_scale : (float)n_in / (float)n_out;      // explicit = F.interpolate(scale_factor=1/src_scale)
+    const float scale = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;     // > 0: F.interpolate(scale_factor=1/src_scale); < 0: align_corners=True, |.| = (n_in-1)/(n_out-1)
     if (vec) hipLaunchKernelGGL((interp_fwd_axis_kernel<true>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
                                 make_fastdiv((int)per), scale, outer);
     else hipLaunchKernelGGL((interp_fwd_axis_kernel<false>), grid, dim3(256), 0, stream, in, base, out, n_in, n_out, in_, make_fastdiv(in_),
@@ -423,7 +429,7 @@ extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_
                                            void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n_out > 0 && n_in > 0 && inner > 0, "segx_interp_linear_bwd_axis: bad args");
     const int64_t total = outer * n_in * inner;
-    const float scale = src_scale > 0.f ? src_scale : (float)n_in / (float)n_out;
+    const float scale = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;
     if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0)
         hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,
                            n_out, n_in, inner / 4, scale);

@@ -7,9 +7,10 @@ namespace segx {
 
 // Source coordinate of destination index d along one axis, exactly as ATen:
 //   src = max(scale * (d + 0.5) - 0.5, 0),  scale = n_in / n_out (float);  i0 = floor(src), i1 = min(i0+1, n_in-1), l = src - i0
+// scale < 0 selects align_corners=True with |scale| = (n_in - 1) / (n_out - 1):  src = |scale| * d
 struct Axis { int i0, i1; float l; };
 __device__ __forceinline__ Axis axis_src(int d, int n_in, float scale) {
-    float src = scale * ((float)d + 0.5f) - 0.5f;
+    float src = scale < 0.f ? -scale * (float)d : scale * ((float)d + 0.5f) - 0.5f;
     src = src < 0.f ? 0.f : src;
     Axis a; a.i0 = (int)src; if (a.i0 > n_in - 1) a.i0 = n_in - 1;
     a.i1 = a.i0 + (a.i0 < n_in - 1 ? 1 : 0); a.l = src - (float)a.i0;

@@ -887,9 +887,14 @@ def _dhw(shape):
     return (1,) + sp if len(sp) == 2 else sp
 
 
+def _corner_scale(n_in, n_out):
+    """src_scale argument of the one-axis resampling kernels for align_corners=True (negative = aligned corners, see segx.h)."""
+    return -((n_in - 1) / (n_out - 1)) if n_out > 1 and n_in > 1 else -1e-6
+
+
 class _InterpAdd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, base, size):
+    def forward(ctx, x, base, size, align_corners=False):
         L = segx.lib()
         x = _c(x)
         B, C = x.shape[:2]
@@ -897,7 +902,8 @@ class _InterpAdd(torch.autograd.Function):
         D, H, W = _dhw(size)
         base = _c(base) if base is not None else None
         axes = [(ax, n_in, n_out) for ax, (n_in, n_out) in enumerate(((d, D), (h, H), (w, W))) if n_in != n_out]
-        if D > 1 and axes:
+        ctx.align = bool(align_corners)
+        if (D > 1 or align_corners) and axes:
             # 3-D: one streaming pass per resized axis, innermost (smallest tensor) first, the lateral added in the last pass --
             # the same blends in the same order as the fused formula (bit-identical), at HBM rate instead of 1-2 TB/s
             cur, dims = x, [d, h, w]
@@ -910,9 +916,11 @@ class _InterpAdd(torch.autograd.Function):
                     inner *= dims[a]
                 last = k == len(axes) - 1
                 nxt = _empty(x, B, C, *size) if last else _empty(x, outer * n_out * inner)
-                L.interp_fwd_axis(cur, base if last else None, nxt, outer, n_in, n_out, inner)
+                L.interp_fwd_axis(cur, base if last else None, nxt, outer, n_in, n_out, inner, _corner_scale(n_in, n_out) if align_corners else 0.0)
                 cur, dims[ax] = nxt, n_out
             out = cur
+        elif align_corners:                                    # nothing to resample: identity (+ base)
+            out = x.clone() if base is None else x + base
         else:
             out = _empty(x, B, C, *size)
             L.interp_fwd(x, base, out, B * C, d, h, w, D, H, W)
@@ -939,15 +947,15 @@ class _InterpAdd(torch.autograd.Function):
                 for a in range(ax + 1, 3):
                     inner *= dims[a]
                 nxt = _empty(dy, outer * n_in * inner)
-                L.interp_bwd_axis(cur, nxt, outer, dims[ax], n_in, inner)
+                L.interp_bwd_axis(cur, nxt, outer, dims[ax], n_in, inner, _corner_scale(n_in, dims[ax]) if ctx.align else 0.0)
                 cur, dims[ax] = nxt, n_in
             dx = cur.view(xshape) if cur is not dy else dy.clone().view(xshape)
-        return dx, (dy if ctx.needs_input_grad[1] else None), None
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None
 
 
-def interp_linear(x, size, base=None):
-    """F.interpolate(x, size, mode='bilinear'/'trilinear', align_corners=False) (+ base): NC[D]HW in, NC[D']H'W' out."""
-    return _InterpAdd.apply(x, base, tuple(int(s) for s in size))
+def interp_linear(x, size, base=None, align_corners=False):
+    """F.interpolate(x, size, mode='bilinear'/'trilinear', align_corners=...) (+ base): NC[D]HW in, NC[D']H'W' out."""
+    return _InterpAdd.apply(x, base, tuple(int(s) for s in size), align_corners)
 
 
 class _InterpTokens(torch.autograd.Function):
@@ -1173,6 +1181,45 @@ def conv2d_dense(x, w, stride, pad):
     pad = (left, right, top, bottom) zero padding."""
     s = int(stride)
     return _Conv3d.apply(x.unsqueeze(2), w.unsqueeze(2), (1, s, s), ((0, 0), (int(pad[2]), int(pad[3])), (int(pad[0]), int(pad[1])))).squeeze(2)
+
+
+class _PlaneBias(torch.autograd.Function):
+    """y[b, c] = x[b, c] + bias[c] on NC* maps (the bias of a dense convolution that ran on the implicit-GEMM engine)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[:2]
+        S = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        L.plane_bias_add(x, _c(bias), y, B * C, C, S)
+        ctx.cfg = (B, C, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        B, C, S = ctx.cfg
+        dy = _c(dy)
+        db = None
+        if ctx.needs_input_grad[1]:
+            rs = _empty(dy, B * C)
+            L.rowsum(dy, rs, B * C, S)
+            db = _empty(dy, C)
+            L.colsum(rs, db, _empty(dy, L.colreduce_ws(B, C, 1)), B, C)
+        return dy, db
+
+
+def conv2d_bias(x, w, bias, pad=1, stride=1):
+    """nn.Conv2d(Cin, Cout, k, padding=pad) with bias (unet2d/unet_parts.py:16-20): implicit-GEMM convolution + per-channel bias pass."""
+    y = conv2d_dense(x, w, stride, (pad, pad, pad, pad))
+    return y if bias is None else _PlaneBias.apply(y, bias)
+
+
+def maxpool2d(x, k=2):
+    """nn.MaxPool2d(k) (stride k, no padding, floor): the 3-D max-pool kernels on a depth-1 volume."""
+    return _MaxPool3d.apply(x.unsqueeze(2), (1, k, k), (1, k, k), ((0, 0), (0, 0), (0, 0))).squeeze(2)
 
 
 # -------------------------------------------------------------------------------------------------

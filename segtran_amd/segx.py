@@ -264,6 +264,9 @@ class SegxLib:
     def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0):
         self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S))
 
+    def plane_bias_add(self, X, bias, Y, planes, C, S):
+        self._call('segx_plane_bias_add', X, X, bias, Y, planes, C, S)
+
     def plane_scale_add(self, X, gate, R, Y, planes, S):
         self._call('segx_plane_scale_add', X, X, gate, R, Y, planes, S)
 
@@ -451,7 +454,7 @@ _SIGS = {
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
-    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp',
+    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippfp', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppfp',
 }
 

@@ -276,6 +276,50 @@ def case_polyformer():
         save('polyformer_' + tag, **arrs)
 
 
+def case_unet():
+    """SURVEY 8(f) rank 4, host side: the U-Net the Polyformer layer is inserted into (networks/unet2d/unet_model.py, unet_parts.py), bilinear
+    decoder, in training mode (batch statistics, running-statistics updates; the layer's attention dropout off) and in evaluation mode, on a
+    map whose decoder needs the zero-pad branch of `Up` (H = 36 -> 18 -> 9 -> 4 -> 2: odd sizes on the way down)."""
+    R._install_stubs()
+    from networks.unet2d.unet_model import UNet
+    from argparse import Namespace
+    pargs = Namespace(polyformer_mode='source', num_attractors=16, num_modes=4, tie_qk_scheme='loose', qk_have_bias=True, pos_code_type='lsinu')
+    net = R.quiet(UNet, 3, 2, True, pargs)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(2, 3, 36, 48, generator=g)
+    G = torch.randn(2, 2, 36, 48, generator=g)
+    arrs = dict(X=X, G=G)
+    for mode in ('train', 'eval'):
+        net.load_state_dict(sd)
+        net.train(mode == 'train'); net.polyformer.eval()
+        net.zero_grad()
+        Xr = X.clone().requires_grad_(True)
+        Y = net(Xr); (Y * G).sum().backward()
+        sdg, running = req(sd), {}
+        Xo = X.clone().requires_grad_(True)
+        Yo = O.unet_forward(sdg, Xo, mode == 'train', True, 4, running); (Yo * G).sum().backward()
+        close(Yo, Y, 2e-5, 'unet %s logits' % mode); close(Xo.grad, Xr.grad, 2e-4, 'unet %s dX' % mode)
+        arrs.update({mode + ':Y': Y, mode + ':dX': Xr.grad})
+        rg = {k: p.grad for k, p in net.named_parameters()}
+        gscale = max(v.abs().max().item() for v in rg.values() if v is not None)
+        for k, v in rg.items():
+            if v is None:
+                continue
+            og = sdg[k].grad if sdg[k].grad is not None else torch.zeros_like(v)
+            assert (og - v).abs().max().item() <= 3e-4 * gscale, (mode, k, (og - v).abs().max().item(), gscale)
+            if mode == 'train':
+                arrs['train:grad:' + k] = sample(v, 512)
+        if mode == 'train':
+            new = net.state_dict()
+            for k, v in running.items():
+                close(v, new[k], 1e-5, 'unet ' + k)
+                arrs['train:stat:' + k] = new[k].clone()          # state_dict() hands out the live buffers
+            arrs['unused'] = np.array(sorted(k for k, v in rg.items() if v is None))
+    save('unet_poly', **arrs)
+
+
 def case_posbias():
     ss = R.ref_shared()
     g = torch.Generator().manual_seed(13)
@@ -841,7 +885,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullshape=case_fullshape, augment=case_augment, init=case_init)
 

@@ -341,3 +341,30 @@ def test_segtran2d_polyp_cfg3():
     assert abs(loss.item() - float(g['loss'])) < 1e-5
     loss.backward()
     _grad_check(g, tied_grads(sdg))
+
+
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_unet_polyformer_host(mode):
+    """the U-Net host restatement (oracle.unet_forward) against the reference UNet's fixture: logits, input gradient, parameter gradients and
+    the BatchNorm running statistics after one training-mode pass"""
+    g = golden('unet_poly')
+    shapes = {k[len('train:grad:'):]: None for k in g if k.startswith('train:grad:')}
+    from segtran_amd.networks.unet2d import UNet            # parameter shapes only (no kernels run)
+    from argparse import Namespace
+    net = UNet(3, 2, True, Namespace(polyformer_mode='source', num_attractors=16, num_modes=4, tie_qk_scheme='loose', qk_have_bias=True,
+                                     pos_code_type='lsinu'))
+    sd = req(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    assert set(shapes) <= set(sd)
+    X = g['X'].clone().requires_grad_(True)
+    running = {}
+    Y = O.unet_forward(sd, X, mode == 'train', True, 4, running)
+    assert_close(Y, g[mode + ':Y'], 2e-5, 'logits')
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g[mode + ':dX'], 2e-4, 'dX')
+    if mode == 'train':
+        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('train:grad:'))
+        for k, v in g.items():
+            if k.startswith('train:grad:'):
+                assert_close(sample(sd[k[len('train:grad:'):]].grad, 512), v, 3e-4, k, scale=gscale)
+            elif k.startswith('train:stat:'):
+                assert_close(running[k[len('train:stat:'):]], v, 1e-5, k)

@@ -1,0 +1,94 @@
+"""U-Net host of the Polyformer layer (reference code/networks/unet2d/): the new host-side ops against plain PyTorch, and
+the whole network against a fixture produced by the reference's own UNet (tests/golden/make_golden.py case_unet).  The ops run on the fiber
+emulator here; the whole network (2.4 GMAC forward, 7 with backward) runs on the HIP build, and on the emulator only with SEGX_SLOW_TESTS=1
+(evaluation-mode forward, ~4 minutes)."""
+import os
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+from test_modules import golden_on, assert_close
+from segtran_amd import functional as SF
+from segtran_amd.synth import synth_state_dict, sample
+
+
+def _rnd(*shape, seed=0):
+    return torch.randn(*shape, generator=torch.Generator(device='cpu').manual_seed(seed), device='cpu')
+
+
+@pytest.mark.parametrize('shape,size', [((2, 3, 4, 6), (8, 12)), ((1, 2, 3, 5), (6, 10)), ((2, 2, 5, 4), (9, 7)), ((1, 3, 1, 4), (1, 8))])
+def test_bilinear_align_corners_vs_torch(backend, shape, size):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (unet_parts.py:48) and general sizes: forward and adjoint."""
+    x = _rnd(*shape, seed=1).to(backend.dev).requires_grad_(True)
+    xr = x.detach().cpu().clone().requires_grad_(True)
+    y = SF.interp_linear(x, size, align_corners=True)
+    yr = F.interpolate(xr, size=size, mode='bilinear', align_corners=True)
+    assert_close(y, yr.detach(), 2e-6, 'fwd')
+    G = _rnd(*yr.shape, seed=2)
+    y.backward(G.to(backend.dev)); yr.backward(G)
+    assert_close(x.grad, xr.grad, 2e-6, 'bwd')
+
+
+def test_conv3x3_bias_and_maxpool2_vs_torch(backend):
+    x = _rnd(2, 5, 9, 11, seed=3).to(backend.dev).requires_grad_(True)
+    w = (0.2 * _rnd(7, 5, 3, 3, seed=4)).to(backend.dev).requires_grad_(True)
+    b = _rnd(7, seed=5).to(backend.dev).requires_grad_(True)
+    xr, wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, w, b))
+    y = SF.maxpool2d(SF.conv2d_bias(x, w, b, pad=1), 2)
+    yr = F.max_pool2d(F.conv2d(xr, wr, br, padding=1), 2)
+    assert y.shape == yr.shape == (2, 7, 4, 5)
+    assert_close(y, yr.detach(), 1e-5, 'fwd')
+    G = _rnd(*yr.shape, seed=6)
+    y.backward(G.to(backend.dev)); yr.backward(G)
+    for a, r, n in ((x, xr, 'dx'), (w, wr, 'dw'), (b, br, 'db')):
+        assert_close(a.grad, r.grad, 2e-5, n)
+
+
+def _build(dev):
+    from argparse import Namespace
+    from segtran_amd.networks.unet2d import UNet
+    pargs = Namespace(polyformer_mode='source', num_attractors=16, num_modes=4, tie_qk_scheme='loose', qk_have_bias=True, pos_code_type='lsinu')
+    net = UNet(3, 2, True, pargs)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    return net.to(dev), sd
+
+
+def test_unet_state_dict_keys_match_reference_fixture():
+    """the fixture's gradient / statistics names ARE the reference's parameter / buffer names"""
+    g = np.load(__import__('os').path.join(__import__('os').path.dirname(__file__), 'golden', 'unet_poly.npz'))
+    net, _ = _build('cpu')
+    params = {k for k, _ in net.named_parameters()}
+    ref_params = {k[len('train:grad:'):] for k in g.files if k.startswith('train:grad:')} | {str(k) for k in g['unused']}
+    assert params == ref_params
+    bufs = {k for k, _ in net.named_buffers() if 'num_batches' not in k}
+    assert {k[len('train:stat:'):] for k in g.files if k.startswith('train:stat:')} == bufs
+
+
+@pytest.mark.parametrize('mode', ['eval', 'train'])
+def test_unet_polyformer_vs_reference(backend, mode):
+    if backend.name == 'emu' and (mode == 'train' or not os.environ.get('SEGX_SLOW_TESTS')):
+        pytest.skip('the 36x48 fixture is 2.4 GMAC forward, ~7 with backward: device only (SEGX_SLOW_TESTS=1 runs the forward on the emulator)')
+    g = golden_on('unet_poly', backend.dev)
+    net, sd = _build(torch.get_default_device())
+    net.train(mode == 'train'); net.polyformer.eval()                     # the layer's attention dropout off, as in the fixture
+    X = g['X'].clone().requires_grad_(backend.name != 'emu')
+    Y = net(X)
+    assert_close(Y, g[mode + ':Y'], 5e-5, 'logits')
+    if backend.name == 'emu':
+        return
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g[mode + ':dX'], 3e-4, 'dX')
+    if mode == 'train':
+        grads = dict(net.named_parameters())
+        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('train:grad:'))
+        for k, v in g.items():
+            if k.startswith('train:grad:'):
+                p = grads[k[len('train:grad:'):]]
+                assert p.grad is not None, k
+                assert_close(sample(p.grad, 512), v, 5e-4, k, scale=gscale)
+            elif k.startswith('train:stat:'):
+                assert_close(net.state_dict()[k[len('train:stat:'):]], v, 2e-5, k)
+        for k in g['unused']:
+            assert grads[str(k)].grad is None, k
+        assert all(int(m.num_batches_tracked) == 1 for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
