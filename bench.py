@@ -142,6 +142,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     """W warm-up steps, EXACTLY `steps` timed steps inside a barrier + synchronize bracket (max over ranks), engine launches profiled."""
     from segtran_amd import engine, segx, dist as sdist, functional as SF
     from segtran_amd.networks import segtran_shared as ss
+    from segtran_amd.efficientnet.model import MBConvBlock
     c = engine.CONFIGS[cfg_name]
     B = c['bs']
     torch.manual_seed(1234)
@@ -151,6 +152,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         # exact re-associations of consecutive linear maps (same function, same parameter gradients): attention projections applied
         # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
         ss.CrossAttFeatTrans.reassociate_projections = reassociated
+        MBConvBlock.gate_in_weights = reassociated                 # squeeze-excite gate folded into the projection weights
         net_.fuse_output_tail = reassociated
         if hasattr(net_, 'fuse_input_bridge'):
             net_.fuse_input_bridge = reassociated          # 3-D: in_bridge_to3 composed into the stem filters

@@ -184,7 +184,7 @@ int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const f
 int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
                          int B, int C, int64_t S, float eps, int act, void* stream);
 /* backward of the above: dX, dw[C], db[C]; training != 0 differentiates through the batch statistics.
- * gate / dpool (both or neither; [B*C]): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c], efficientnet/model.py:110) and dY is the
+ * gate / dpool ([B*C]; gate needs dpool, dpool alone = gate of one): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c], efficientnet/model.py:110) and dY is the
  * gradient w.r.t. Z: the kernels then use dY * gate[b][c] + dpool[b][c] * inv_S in place of dY (dpool = gradient w.r.t. the pooled sums' mean),
  * which replaces a pass that would write that tensor (same for the reduce / apply halves below) */
 int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -213,6 +213,11 @@ int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B
  * Y = X * gate[plane];  out[plane] = sum_s A*B;  dX = dY * gate[plane] + dpool[plane] */
 int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream);
 /* Y = X * gate[plane] + R: MBConv skip connection with the per-sample drop_connect scale (model.py:118-122) */
+/* Squeeze-excite gate folded into the projection weights (exact re-association of efficientnet/model.py:110-113: project_conv(y * gate) ==
+ * pointwise convolution of y with per-sample weights): Wb[b][m][k] = W[m][k] * gate[b][k].  bwd, from the per-sample weight gradient dWb
+ * [B][M][K]: dW[m][k] = sum_b dWb * gate, dgate[b][k] = sum_m dWb * W (= sum over the plane of dz * y in the unfused form) */
+int segx_gate_weights_fwd(const float* W, const float* gate, float* Wb, int B, int M, int K, void* stream);
+int segx_gate_weights_bwd(const float* dWb, const float* W, const float* gate, float* dW, float* dgate, int B, int M, int K, void* stream);
 /* Y[p][s] = X[p][s] + bias[p % C]: the bias of a dense k x k convolution run on the implicit-GEMM engine (nn.Conv2d(..., 3, padding=1) of the
  * U-Net host, unet2d/unet_parts.py:16-20); in place allowed */
 int segx_plane_bias_add(const float* X, const float* bias, float* Y, int64_t planes, int C, int64_t S, void* stream);

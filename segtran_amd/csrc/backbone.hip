@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     // squeeze-excite behind this BatchNorm (bn_act_se): the incoming gradient is dz (w.r.t. y * gate); dy = dz * gate[plane] + dpool[plane] / S is
     // formed on the fly instead of being written by a pass of its own (plane_scale_bwd)
-    const float gt = gate ? gate[(int64_t)bb * C + c] : 1.0f, dp = gate ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
+    const float gt = gate ? gate[(int64_t)bb * C + c] : 1.0f, dp = dpool ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
     const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
     const int nsl = gridDim.z;
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S) {
     const int bc = blockIdx.y, c = bc % C;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
-    const float gt = gate ? gate[bc] : 1.0f, dp = gate ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
+    const float gt = gate ? gate[bc] : 1.0f, dp = dpool ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
     const float k1 = db[c] * inv_n, k2 = dw[c] * inv_n, sc = wc * rstd;
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
     if ((S & 3) == 0) {
@@ -542,6 +542,40 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_rows_kernel(const float* __r
 }
 
 // =================================================================================================
+// Squeeze-excite gate folded into the projection weights (exact re-association of efficientnet/model.py:110-113):
+//   project_conv(y * gate[b, :, None, None]) == conv1x1 of y with the per-sample weights Wb[b][m][k] = W[m][k] * gate[b][k]
+// so the gated activation is never written or read.  Backward, from the per-sample weight gradient dWb the GEMM returns:
+//   dW[m][k] = sum_b dWb[b][m][k] * gate[b][k] ;   dgate[b][k] = sum_m dWb[b][m][k] * W[m][k]
+// (the second is sum_s dz * y of the unfused form, with the sum over the plane done by the weight-gradient GEMM)
+// =================================================================================================
+__global__ __launch_bounds__(256) void gate_weights_fwd_kernel(const float* __restrict__ W, const float* __restrict__ gate, float* __restrict__ Wb,
+                                                               int K, int64_t MK) {
+    const float* g = gate + (int64_t)blockIdx.y * K; float* o = Wb + (int64_t)blockIdx.y * MK;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MK; i += (int64_t)gridDim.x * 256) o[i] = W[i] * g[i % K];
+}
+__global__ __launch_bounds__(256) void gate_weights_bwd_w_kernel(const float* __restrict__ dWb, const float* __restrict__ gate, float* __restrict__ dW,
+                                                                 int B, int K, int64_t MK) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= MK) return;
+    const int k = (int)(i % K);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dWb[(int64_t)b * MK + i] * gate[(int64_t)b * K + k];
+    dW[i] = s;
+}
+// thread = column k of sample b (consecutive threads read consecutive floats of a row), rows in order
+__global__ __launch_bounds__(256) void gate_weights_bwd_g_kernel(const float* __restrict__ dWb, const float* __restrict__ W, float* __restrict__ dgate,
+                                                                 int M, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float* d = dWb + (int64_t)blockIdx.y * M * K;
+    float s0 = 0.f, s1 = 0.f;
+    int m = 0;
+    for (; m + 1 < M; m += 2) { s0 += d[(int64_t)m * K + k] * W[(int64_t)m * K + k]; s1 += d[(int64_t)(m + 1) * K + k] * W[(int64_t)(m + 1) * K + k]; }
+    if (m < M) s0 += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
+    dgate[(int64_t)blockIdx.y * K + k] = s0 + s1;
+}
+
+// =================================================================================================
 // Squeeze-excite plane ops (efficientnet/model.py:105-110): y = x * gate[b,c] ; dgate[b,c] = sum_s dy * x ;
 // dx = dy * gate + dpool[b,c]   (dpool = gradient of the mean pooled value, already divided by S)
 // =================================================================================================
@@ -701,7 +735,7 @@ extern "C" int segx_bn_act_fwd_pool(const float* X, const float* mean, const flo
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
                                       const float* gate, const float* dpool, float inv_S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd_reduce: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_reduce: bad args");
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     return check_launch("segx_bn_act_bwd_reduce");
@@ -709,7 +743,7 @@ extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const flo
 extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                      const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
                                      float inv_n, const float* gate, const float* dpool, float inv_S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd_apply: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_apply: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
     hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n,
                        gate, dpool, inv_S);
@@ -718,7 +752,7 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
 extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
                                const float* gate, const float* dpool, float inv_S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (!gate == !dpool), "segx_bn_act_bwd: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
@@ -854,6 +888,19 @@ extern "C" int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* 
     dim3 grid(strips, B * C);
     SEGX_DW_DISPATCH(dwconv_wgrad_rows_kernel, dY, X, part, C, H, Wd, OH, OW, pad_t, pad_l, g.tiles_x, g.tiles_x * g.tiles_y, g.txw_log2);
     return check_launch("segx_dwconv2d_bwd_weight");
+}
+extern "C" int segx_gate_weights_fwd(const float* W, const float* gate, float* Wb, int B, int M, int K, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(W && gate && Wb && B > 0 && B <= 65535 && M > 0 && K > 0, "segx_gate_weights_fwd: bad args");
+    const int64_t MK = (int64_t)M * K;
+    hipLaunchKernelGGL(gate_weights_fwd_kernel, dim3((unsigned)i64min(1024, (MK + 255) / 256), B), dim3(256), 0, stream, W, gate, Wb, K, MK);
+    return check_launch("segx_gate_weights_fwd");
+}
+extern "C" int segx_gate_weights_bwd(const float* dWb, const float* W, const float* gate, float* dW, float* dgate, int B, int M, int K, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dWb && W && gate && dW && dgate && B > 0 && B <= 65535 && M > 0 && K > 0, "segx_gate_weights_bwd: bad args");
+    const int64_t MK = (int64_t)M * K;
+    hipLaunchKernelGGL(gate_weights_bwd_w_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, stream, dWb, gate, dW, B, K, MK);
+    hipLaunchKernelGGL(gate_weights_bwd_g_kernel, dim3((K + 255) / 256, B), dim3(256), 0, stream, dWb, W, dgate, M, K);
+    return check_launch("segx_gate_weights_bwd");
 }
 extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && gate && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale: bad args");

@@ -95,13 +95,19 @@ class MBConvBlock(nn.Module):
         self._project_conv = Conv2dStaticSamePadding(oup, cout, 1, image_size=math.ceil(image_size / s), bias=False)
         self._bn2 = nn.BatchNorm2d(cout, momentum=BN_MOM, eps=BN_EPS)
 
+    gate_in_weights = True     # False: the reference's op order (gate applied to the activation, model.py:110), as a separate pass
+
     def forward(self, inputs, drop_connect_rate=None):
         x = inputs
         if self.expand_ratio != 1:
             x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
-        x = SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH,
-                         self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
-        x = SF.bn_act(self._project_conv(x), self._bn2, SF.ACT_NONE)
+        se = (self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
+        if MBConvBlock.gate_in_weights:
+            # squeeze-excite gate folded into the projection weights (per-sample weights; the gated tensor is never written)
+            y, gate = SF.bn_act_gate(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se)
+            x = SF.bn_act(SF.conv1x1_gated(y, self._project_conv.weight, gate), self._bn2, SF.ACT_NONE)
+        else:
+            x = SF.bn_act(self._project_conv(SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se)), self._bn2, SF.ACT_NONE)
         if self.stride == 1 and self.input_filters == self.output_filters:
             scale = None
             if drop_connect_rate and self.training:                      # utils.py:129-154, per-sample stochastic depth

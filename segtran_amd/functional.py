@@ -807,6 +807,90 @@ class _BNActSE(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
 
 
+class _BNActGate(torch.autograd.Function):
+    """BatchNorm + activation with the squeeze-excite gate computed from the same pass: returns (y, gate [B, C]) -- y is NOT multiplied by the
+    gate; the caller folds the gate into the weights of the pointwise convolution that follows (conv1x1_gated), so neither y * gate nor its
+    gradient is ever materialised.  Backward takes (dy, dgate): dgate -> squeeze-excite MLP -> dpool, and BatchNorm backward on dy + dpool / S."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act, w1, b1, w2, b2):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        S = x.numel() // (B * C)
+        Cs = w1.shape[0]
+        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
+        y = torch.empty_like(x)
+        pooled = _empty(x, B * C)
+        L.bn_act_fwd_pool(x, mean, var, w, b, y, pooled, _empty(x, B * C * 64), B, C, S, eps, act)
+        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
+        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
+        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
+        ctx.cfg = (B, C, S, eps, act, training, n)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), Cs)
+        ctx.save_for_backward(x, mean, var, w, b, p, hpre, gate, W1, W2)
+        return y, gate
+
+    @staticmethod
+    def backward(ctx, dy, dgate):
+        L = segx.lib()
+        x, mean, var, w, b, p, hpre, gate, W1, W2 = ctx.saved_tensors
+        B, C, S = ctx.cfg[:3]
+        w1s, w2s, Cs = ctx.shapes
+        dpool = _empty(x, B * C)
+        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
+        L.se_gate_bwd(_c(dgate).reshape(-1), gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
+        dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg, None, dpool, 1.0)
+        return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
+
+
+def bn_act_gate(x, bn, act, w1, b1, w2, b2):
+    """(bn_act(x, bn, act), squeeze-excite gate of it [B, C]) from one pass (see _BNActGate); pair with conv1x1_gated."""
+    if bn.training and bn.num_batches_tracked is not None:
+        if _bn_ticks is not None:
+            _bn_ticks.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return _BNActGate.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
+
+
+class _GateWeights(torch.autograd.Function):
+    """Wb[b] = W * gate[b][None, :] (the squeeze-excite gate folded into pointwise-convolution weights) and its chain rule."""
+
+    @staticmethod
+    def forward(ctx, W, gate):
+        L = segx.lib()
+        W, gate = _c(W), _c(gate)
+        M, K = W.shape
+        B = gate.shape[0]
+        Wb = _empty(W, B, M, K)
+        L.gate_weights_fwd(W, gate, Wb, B, M, K)
+        ctx.save_for_backward(W, gate)
+        return Wb
+
+    @staticmethod
+    def backward(ctx, dWb):
+        L = segx.lib()
+        W, gate = ctx.saved_tensors
+        M, K = W.shape
+        B = gate.shape[0]
+        dW, dgate = torch.empty_like(W), torch.empty_like(gate)
+        L.gate_weights_bwd(_c(dWb), W, gate, dW, dgate, B, M, K)
+        return dW, dgate
+
+
+def conv1x1_gated(x, weight, gate):
+    """conv1x1(x * gate[:, :, None, None], weight) computed as the pointwise convolution of x with per-sample weights weight * gate[b]
+    (exact re-association; efficientnet/model.py:110-113): one GEMM per sample with its own A matrix; autograd returns the per-sample weight
+    gradient, from which _GateWeights derives dW and dgate -- no gated activation, no plane-dot pass."""
+    B, Cin = x.shape[0], x.shape[1]
+    S = x.numel() // (B * Cin)
+    Cout = weight.shape[0]
+    Wb = _GateWeights.apply(weight.reshape(Cout, Cin), gate)
+    spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1))
+    return bgemm(Wb, x, spec)
+
+
 def bn_act_se(x, bn, act, w1, b1, w2, b2):
     """squeeze_excite(bn_act(x, bn, act), w1, b1, w2, b2), fused (see _BNActSE)."""
     if bn.training and bn.num_batches_tracked is not None:

@@ -264,6 +264,12 @@ class SegxLib:
     def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0):
         self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S))
 
+    def gate_weights_fwd(self, W, gate, Wb, B, M, K):
+        self._call('segx_gate_weights_fwd', W, W, gate, Wb, B, M, K)
+
+    def gate_weights_bwd(self, dWb, W, gate, dW, dgate, B, M, K):
+        self._call('segx_gate_weights_bwd', W, dWb, W, gate, dW, dgate, B, M, K)
+
     def plane_bias_add(self, X, bias, Y, planes, C, S):
         self._call('segx_plane_bias_add', X, X, bias, Y, planes, C, S)
 
@@ -454,7 +460,7 @@ _SIGS = {
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
-    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp',
+    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippfp', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppfp',
 }
 

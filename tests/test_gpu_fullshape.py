@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from segtran_amd import engine, functional as SF
+from segtran_amd.efficientnet.model import MBConvBlock
 from segtran_amd.synth import sample, synth_brats, synth_image2d, synth_fundus_mask
 from util import golden
 
@@ -77,6 +78,7 @@ def test_fullshape_eval_every_label(cfg, engine_sel):
 def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)      # the size gate keeps its default (4096 rows)
+    monkeypatch.setattr(MBConvBlock, 'gate_in_weights', reassociated)
     g = golden('full_' + cfg)
     c = engine.CONFIGS[cfg]
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)

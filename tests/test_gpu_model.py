@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from segtran_amd import engine, functional as SF
+from segtran_amd.efficientnet.model import MBConvBlock
 from segtran_amd.synth import sample, synth_brats, synth_image2d
 from util import golden, golden_json, assert_close
 
@@ -51,6 +52,7 @@ def _grads_vs_golden(net, g, tol=1e-3, referee=False):
 def test_segtran2d_vs_reference(tag, cfg, train, fused_tail, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', fused_tail)      # both re-associations on, or neither
+    monkeypatch.setattr(MBConvBlock, 'gate_in_weights', fused_tail)                        # ... and the squeeze-excite gate in the projection weights
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)                  # the fixtures are small; the product's size threshold is 4096 rows
     g = golden(tag)
     c = dict(engine.CONFIGS[cfg], size=(64, 64))

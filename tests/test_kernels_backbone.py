@@ -120,6 +120,38 @@ def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
+@pytest.mark.parametrize('B,C,Cs,Co,H,W', [(3, 12, 4, 10, 9, 7), (2, 70, 9, 24, 4, 5), (2, 8, 2, 136, 12, 12)])
+@pytest.mark.parametrize('training', [True, False])
+def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, training):
+    """MBConv tail as the product runs it: BatchNorm + swish with the squeeze-excite gate from the same pass (bn_act_gate), then the projection as
+    a pointwise convolution with per-sample weights W * gate[b] (conv1x1_gated) -- against BatchNorm -> swish -> squeeze-excite -> conv in PyTorch."""
+    bn, ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        for m in (bn, ref):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=1)); m.bias.copy_(0.2 * rnd(C, seed=2))
+            m.running_mean.copy_(0.1 * rnd(C, seed=3)); m.running_var.copy_(1 + 0.1 * rnd(C, seed=4).abs())
+    bn.train(training); ref.train(training)
+    x = (rnd(B, C, H, W, seed=30) * 1.3 + 0.2).requires_grad_(True)
+    ps = [rnd(Cs, C, 1, 1, seed=31, scale=0.5), rnd(Cs, seed=32, scale=0.1), rnd(C, Cs, 1, 1, seed=33, scale=0.5), rnd(C, seed=34, scale=0.1),
+          rnd(Co, C, 1, 1, seed=35, scale=0.3)]
+    ps = [p.requires_grad_(True) for p in ps]
+    y, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *ps[:4])
+    out = SF.conv1x1_gated(y, ps[4], gate)
+    xr = x.detach().clone().requires_grad_(True)
+    pr = [p.detach().clone().requires_grad_(True) for p in ps]
+    yr = _act(ref(xr), 1)
+    sq = F.conv2d(F.adaptive_avg_pool2d(yr, 1), pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
+    outr = F.conv2d(torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * yr, pr[4])
+    close(out, outr.detach())
+    G = rnd(B, Co, H, W, seed=36)
+    out.backward(G); outr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+    close(bn.weight.grad, ref.weight.grad, 1e-4); close(bn.bias.grad, ref.bias.grad, 1e-4)
+    for a, r in zip(ps, pr):
+        close(a.grad, r.grad, 1e-4)
+    close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
+
+
 @pytest.mark.parametrize('shape', [(2, 16, 6, 10), (3, 8, 3, 4, 5), (1, 24, 9, 9)])
 def test_group_norm(backend, shape):
     C = shape[1]
