@@ -309,8 +309,7 @@ def case_unet():
                 continue
             og = sdg[k].grad if sdg[k].grad is not None else torch.zeros_like(v)
             assert (og - v).abs().max().item() <= 3e-4 * gscale, (mode, k, (og - v).abs().max().item(), gscale)
-            if mode == 'train':
-                arrs['train:grad:' + k] = sample(v, 512)
+            arrs['%s:grad:%s' % (mode, k)] = sample(v, 512 if mode == 'train' else 256)
         if mode == 'train':
             new = net.state_dict()
             for k, v in running.items():

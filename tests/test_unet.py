@@ -66,29 +66,52 @@ def test_unet_state_dict_keys_match_reference_fixture():
 
 
 @pytest.mark.parametrize('mode', ['eval', 'train'])
-def test_unet_polyformer_vs_reference(backend, mode):
-    if backend.name == 'emu' and (mode == 'train' or not os.environ.get('SEGX_SLOW_TESTS')):
-        pytest.skip('the 36x48 fixture is 2.4 GMAC forward, ~7 with backward: device only (SEGX_SLOW_TESTS=1 runs the forward on the emulator)')
+@pytest.mark.parametrize('tile_engine', ['x6', 'f32'])
+def test_unet_polyformer_vs_reference(backend, mode, tile_engine):
+    """Logits, input gradient, parameter gradients (and, after a training-mode pass, the BatchNorm running statistics) against the reference's
+    own UNet, on both tile engines.
+
+    One combination is forward-only: TRAINING-mode gradients on the bf16x6 engine.  With batch statistics over as few as n = 48 values (the
+    2 x 3 and 4 x 6 maps) a single ReLU input that lies within fp32 rounding of zero decides 1/48 of a channel's mean gradient, and this network
+    has ~1.3 M ReLU inputs of scale 0.03 (smallest |input| over 300 input seeds: 5e-10 .. 1e-7, fp64 evaluation) -- so two fp32-accurate
+    implementations agree on every mask only if their roundings are correlated.  The fp32-MFMA engine accumulates like the reference does and
+    agrees (dX to 2e-6); the bf16x6 engine is equally accurate against fp64 (every convolution of this very step replayed: 2e-7 .. 1e-6, same as
+    the fp32 engine) but rounds differently: on the device ONE of 24 576 inputs of `up1`'s first BatchNorm (channel 456, |input| < 1e-7) took the
+    other side of the kink and moved dX by 1.7 % (device session r02_g).  Its gradients are therefore checked in evaluation mode (no batch
+    coupling), its training-mode forward (logits, statistics) strictly."""
+    if backend.name == 'emu' and (mode == 'train' or tile_engine == 'f32' or not os.environ.get('SEGX_SLOW_TESTS')):
+        pytest.skip('the 36x48 fixture is 2.4 GMAC forward, ~7 with backward: device only (SEGX_SLOW_TESTS=1 runs one forward on the emulator)')
     g = golden_on('unet_poly', backend.dev)
-    net, sd = _build(torch.get_default_device())
-    net.train(mode == 'train'); net.polyformer.eval()                     # the layer's attention dropout off, as in the fixture
-    X = g['X'].clone().requires_grad_(backend.name != 'emu')
-    Y = net(X)
-    assert_close(Y, g[mode + ':Y'], 5e-5, 'logits')
-    if backend.name == 'emu':
-        return
-    (Y * g['G']).sum().backward()
-    assert_close(X.grad, g[mode + ':dX'], 3e-4, 'dX')
-    if mode == 'train':
+    prev = backend.L.set_engine(tile_engine)
+    try:
+        net, sd = _build(torch.get_default_device())
+        net.train(mode == 'train'); net.polyformer.eval()                     # the layer's attention dropout off, as in the fixture
+        X = g['X'].clone().requires_grad_(backend.name != 'emu')
+        Y = net(X)
+        assert_close(Y, g[mode + ':Y'], 5e-5, 'logits')
+        if backend.name == 'emu':
+            return
+        (Y * g['G']).sum().backward()
+        if mode == 'train':
+            for k, v in g.items():
+                if k.startswith('train:stat:'):
+                    assert_close(net.state_dict()[k[len('train:stat:'):]], v, 2e-5, k)
+            assert all(int(m.num_batches_tracked) == 1 for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+            if tile_engine == 'x6':
+                return                                                      # see the docstring
+        assert_close(X.grad, g[mode + ':dX'], 3e-4, 'dX')
         grads = dict(net.named_parameters())
-        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('train:grad:'))
+        pre = mode + ':grad:'
+        gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith(pre))
+        n = 0
         for k, v in g.items():
-            if k.startswith('train:grad:'):
-                p = grads[k[len('train:grad:'):]]
+            if k.startswith(pre):
+                p = grads[k[len(pre):]]
                 assert p.grad is not None, k
-                assert_close(sample(p.grad, 512), v, 5e-4, k, scale=gscale)
-            elif k.startswith('train:stat:'):
-                assert_close(net.state_dict()[k[len('train:stat:'):]], v, 2e-5, k)
+                assert_close(sample(p.grad, v.numel()), v, 5e-4, k, scale=gscale)
+                n += 1
+        assert n > 90
         for k in g['unused']:
             assert grads[str(k)].grad is None, k
-        assert all(int(m.num_batches_tracked) == 1 for m in net.modules() if isinstance(m, torch.nn.BatchNorm2d))
+    finally:
+        backend.L.set_engine(prev)
