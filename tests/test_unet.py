@@ -82,7 +82,9 @@ def test_unet_polyformer_vs_reference(backend, mode, tile_engine):
     if backend.name == 'emu' and (mode == 'train' or tile_engine == 'f32' or not os.environ.get('SEGX_SLOW_TESTS')):
         pytest.skip('the 36x48 fixture is 2.4 GMAC forward, ~7 with backward: device only (SEGX_SLOW_TESTS=1 runs one forward on the emulator)')
     g = golden_on('unet_poly', backend.dev)
-    prev = backend.L.set_engine(tile_engine)
+    from segtran_amd import segx
+    L = segx.lib() if backend.name == 'hip' else backend.L        # the handle the autograd layer uses (the fixture resets the product's)
+    prev = L.set_engine(tile_engine)
     try:
         net, sd = _build(torch.get_default_device())
         net.train(mode == 'train'); net.polyformer.eval()                     # the layer's attention dropout off, as in the fixture
@@ -114,4 +116,4 @@ def test_unet_polyformer_vs_reference(backend, mode, tile_engine):
         for k in g['unused']:
             assert grads[str(k)].grad is None, k
     finally:
-        backend.L.set_engine(prev)
+        L.set_engine(prev)
