@@ -562,17 +562,22 @@ __global__ __launch_bounds__(256) void gate_weights_bwd_w_kernel(const float* __
     for (int b = 0; b < B; ++b) s += dWb[(int64_t)b * MK + i] * gate[(int64_t)b * K + k];
     dW[i] = s;
 }
-// thread = column k of sample b (consecutive threads read consecutive floats of a row), rows in order
+// workgroup = 64 columns of sample b x 4 row lanes (rows m = lane, lane + 4, ...: consecutive threads read consecutive floats of a row);
+// the four partial sums are added in lane order through LDS
 __global__ __launch_bounds__(256) void gate_weights_bwd_g_kernel(const float* __restrict__ dWb, const float* __restrict__ W, float* __restrict__ dgate,
                                                                  int M, int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const float* d = dWb + (int64_t)blockIdx.y * M * K;
-    float s0 = 0.f, s1 = 0.f;
-    int m = 0;
-    for (; m + 1 < M; m += 2) { s0 += d[(int64_t)m * K + k] * W[(int64_t)m * K + k]; s1 += d[(int64_t)(m + 1) * K + k] * W[(int64_t)(m + 1) * K + k]; }
-    if (m < M) s0 += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
-    dgate[(int64_t)blockIdx.y * K + k] = s0 + s1;
+    __shared__ float part[256];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (k < K) {
+        const float* d = dWb + (int64_t)blockIdx.y * M * K;
+#pragma unroll 4
+        for (int m = rl; m < M; m += 4) s += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && k < K) dgate[(int64_t)blockIdx.y * K + k] = (part[col] + part[64 + col]) + (part[128 + col] + part[192 + col]);
 }
 
 // =================================================================================================
@@ -899,7 +904,7 @@ extern "C" int segx_gate_weights_bwd(const float* dWb, const float* W, const flo
     SEGX_STREAM; SEGX_REQUIRE(dWb && W && gate && dW && dgate && B > 0 && B <= 65535 && M > 0 && K > 0, "segx_gate_weights_bwd: bad args");
     const int64_t MK = (int64_t)M * K;
     hipLaunchKernelGGL(gate_weights_bwd_w_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, stream, dWb, gate, dW, B, K, MK);
-    hipLaunchKernelGGL(gate_weights_bwd_g_kernel, dim3((K + 255) / 256, B), dim3(256), 0, stream, dWb, W, dgate, M, K);
+    hipLaunchKernelGGL(gate_weights_bwd_g_kernel, dim3((K + 63) / 64, B), dim3(256), 0, stream, dWb, W, dgate, M, K);
     return check_launch("segx_gate_weights_bwd");
 }
 extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream_) {

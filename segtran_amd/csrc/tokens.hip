@@ -693,6 +693,11 @@ extern "C" int segx_layernorm_bwd(const float* dY, const float* X, const float* 
 extern "C" int64_t segx_colreduce_ws_floats(int64_t rows, int64_t C, int nout) { return (int64_t)nout * chunks_for(rows) * C; }
 extern "C" int segx_colsum(const float* X, float* out, float* ws, int64_t rows, int64_t C, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && out && ws && rows > 0 && C > 0, "segx_colsum: bad args");
+    if (rows <= 64) {          // few rows (per-sample partials, depthwise weight-gradient chunks): one pass straight into `out`, no second launch
+        hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), 1), dim3(256), 0, stream, X, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, out, rows, C, 0, 1);
+        return check_launch("segx_colsum");
+    }
     const int nch = chunks_for(rows);
     hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, X, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, ws, rows, C, 0, nch);
