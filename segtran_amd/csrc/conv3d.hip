@@ -613,58 +613,64 @@ __global__ __launch_bounds__(256) void label_nhot_kernel(const void* __restrict_
 // =================================================================================================
 struct PoolGeom { int ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw; };
 
-// TKD/TKH/TKW > 0: compile-time window (fully unrolled scan); 0: runtime window.  One thread per output; 32-bit index math inside a
-// plane (the host checks plane sizes < 2^31), one 64-bit division per thread for the plane.
+// TKD/TKH/TKW > 0: compile-time window (fully unrolled scan); 0: runtime window.  One thread per output; grid (chunks of a plane, planes):
+// no 64-bit division, and the (od, oh, ow) decomposition is two multiply-high divisions (the generic integer divisions of the first version
+// made these kernels ALU-bound: 0.9 ms for a 268 MB plane set that streams in 0.1 ms).
 template <int TKD, int TKH, int TKW>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg,
-                                                            PoolGeom q, int64_t planes) {
+                                                            PoolGeom q, int64_t planes, FastDiv dOHW, FastDiv dOW) {
     const int KD = TKD ? TKD : q.KD, KH = TKH ? TKH : q.KH, KW = TKW ? TKW : q.KW;
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ohw = q.OH * q.OW;
-    const int64_t total = planes * osz;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / osz; const int r = (int)(idx - p * osz);
-        const int od = r / ohw, r2 = r - od * ohw, oh = r2 / q.OW, ow = r2 - oh * q.OW;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
         const float* x = X + p * isz;
-        const int d0 = od * q.sd - q.pd, h0 = oh * q.sh - q.ph, w0 = ow * q.sw - q.pw;
-        float best = -INFINITY; int bi = -1;
+        for (int r = blockIdx.x * 256 + threadIdx.x; r < osz; r += gridDim.x * 256) {
+            const int od = fdiv(r, dOHW), r2 = r - od * ohw, oh = fdiv(r2, dOW), ow = r2 - oh * q.OW;
+            const int d0 = od * q.sd - q.pd, h0 = oh * q.sh - q.ph, w0 = ow * q.sw - q.pw;
+            float best = -INFINITY; int bi = -1;
 #pragma unroll
-        for (int kd = 0; kd < KD; ++kd) {
-            const int id = d0 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
+            for (int kd = 0; kd < KD; ++kd) {
+                const int id = d0 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
 #pragma unroll
-            for (int kh = 0; kh < KH; ++kh) {
-                const int ih = h0 + kh; const bool okh = okd && (unsigned)ih < (unsigned)q.IH;
-                const int rowbase = (id * q.IH + ih) * q.IW;
+                for (int kh = 0; kh < KH; ++kh) {
+                    const int ih = h0 + kh; const bool okh = okd && (unsigned)ih < (unsigned)q.IH;
+                    const int rowbase = (id * q.IH + ih) * q.IW;
 #pragma unroll
-                for (int kw = 0; kw < KW; ++kw) {
-                    const int iw = w0 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
-                    const int li = rowbase + iw;
-                    const float v = in ? x[li] : 0.f;                      // zero padding
-                    if (v > best || v != v) { best = v; bi = in ? li : -1; }
+                    for (int kw = 0; kw < KW; ++kw) {
+                        const int iw = w0 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
+                        const int li = rowbase + iw;
+                        const float v = in ? x[li] : 0.f;                      // zero padding
+                        if (v > best || v != v) { best = v; bi = in ? li : -1; }
+                    }
                 }
             }
+            Y[p * osz + r] = best; arg[p * osz + r] = bi;
         }
-        Y[idx] = best; arg[idx] = bi;
     }
 }
-// gather form: an input cell sums the gradients of the windows whose arg-max it is
+// gather form: an input cell sums the gradients of the windows whose arg-max it is.  S2 = true: strides (1 or 2, 2, 2) known at compile time
+// (the down-sampling pools of I3D: the window-range divisions become shifts); grid (chunks of a plane, planes), multiply-high decomposition.
+template <bool S2>
 __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
-                                                            PoolGeom q, int64_t planes) {
+                                                            PoolGeom q, int64_t planes, FastDiv dIHW, FastDiv dIW) {
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ihw = q.IH * q.IW;
-    const int64_t total = planes * isz;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t p = idx / isz; const int li = (int)(idx - p * isz);
-        const int id = li / ihw, r = li - id * ihw, ih = r / q.IW, iw = r - ih * q.IW;
+    const int sd = q.sd, sh = S2 ? 2 : q.sh, sw = S2 ? 2 : q.sw;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
         const float* g = dY + p * osz; const int* a = arg + p * osz;
-        float acc = 0.f;
-        // windows covering (id,ih,iw): od in [ceil((id+pd-KD+1)/sd), floor((id+pd)/sd)]
-        const int d1 = min((id + q.pd) / q.sd, q.OD - 1), h1 = min((ih + q.ph) / q.sh, q.OH - 1), w1 = min((iw + q.pw) / q.sw, q.OW - 1);
-        const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw + q.pw - q.KW + 1;
-        const int d0 = dn > 0 ? (dn + q.sd - 1) / q.sd : 0, h0 = hn > 0 ? (hn + q.sh - 1) / q.sh : 0, w0 = wn > 0 ? (wn + q.sw - 1) / q.sw : 0;
-        for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {
-            const int rowo = (od * q.OH + oh) * q.OW;
-            for (int ow = w0; ow <= w1; ++ow) if (a[rowo + ow] == li) acc += g[rowo + ow];
+        for (int li = blockIdx.x * 256 + threadIdx.x; li < isz; li += gridDim.x * 256) {
+            const int id = fdiv(li, dIHW), r = li - id * ihw, ih = fdiv(r, dIW), iw = r - ih * q.IW;
+            float acc = 0.f;
+            // windows covering (id,ih,iw): od in [ceil((id+pd-KD+1)/sd), floor((id+pd)/sd)]
+            const int d1 = min(sd == 1 ? id + q.pd : sd == 2 ? (id + q.pd) >> 1 : (id + q.pd) / sd, q.OD - 1);
+            const int h1 = min((ih + q.ph) / sh, q.OH - 1), w1 = min((iw + q.pw) / sw, q.OW - 1);
+            const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw + q.pw - q.KW + 1;
+            const int d0 = dn > 0 ? (sd == 1 ? dn : sd == 2 ? (dn + 1) >> 1 : (dn + sd - 1) / sd) : 0;
+            const int h0 = hn > 0 ? (hn + sh - 1) / sh : 0, w0 = wn > 0 ? (wn + sw - 1) / sw : 0;
+            for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {
+                const int rowo = (od * q.OH + oh) * q.OW;
+                for (int ow = w0; ow <= w1; ++ow) if (a[rowo + ow] == li) acc += g[rowo + ow];
+            }
+            dX[p * isz + li] = acc;
         }
-        dX[idx] = acc;
     }
 }
 
@@ -891,11 +897,14 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.OD * q.OH * q.OW;
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_fwd: plane too large");
-    const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
-    if (q.KD == 3 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<3, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
-    else if (q.KD == 1 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<1, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
-    else if (q.KD == 2 && q.KH == 2 && q.KW == 2) hipLaunchKernelGGL((maxpool3d_fwd_kernel<2, 2, 2>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
-    else hipLaunchKernelGGL((maxpool3d_fwd_kernel<0, 0, 0>), grid, dim3(256), 0, stream, X, Y, arg, q, planes);
+    (void)total;
+    const int osz = q.OD * q.OH * q.OW;
+    const dim3 grid((unsigned)i64min(4096, (osz + 255) / 256), (unsigned)i64min(65535, planes));
+    const FastDiv dOHW = make_fastdiv(q.OH * q.OW), dOW = make_fastdiv(q.OW);
+    if (q.KD == 3 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<3, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
+    else if (q.KD == 1 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<1, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
+    else if (q.KD == 2 && q.KH == 2 && q.KW == 2) hipLaunchKernelGGL((maxpool3d_fwd_kernel<2, 2, 2>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
+    else hipLaunchKernelGGL((maxpool3d_fwd_kernel<0, 0, 0>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
     return check_launch("segx_maxpool3d_fwd");
 }
 extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream_) {
@@ -908,7 +917,12 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
         hipLaunchKernelGGL(maxpool3d_bwd_s1k3_kernel, dim3((unsigned)(td * th * tw), (unsigned)planes), dim3(256), 0, stream, dY, arg, dX, q, th, tw);
         return check_launch("segx_maxpool3d_bwd");
     }
-    hipLaunchKernelGGL(maxpool3d_bwd_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dY, arg, dX, q, planes);
+    (void)total;
+    const int isz = q.ID * q.IH * q.IW;
+    const dim3 grid((unsigned)i64min(4096, (isz + 255) / 256), (unsigned)i64min(65535, planes));
+    const FastDiv dIHW = make_fastdiv(q.IH * q.IW), dIW = make_fastdiv(q.IW);
+    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2)) hipLaunchKernelGGL((maxpool3d_bwd_kernel<true>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
+    else hipLaunchKernelGGL((maxpool3d_bwd_kernel<false>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
     return check_launch("segx_maxpool3d_bwd");
 }
 /* wt_ws: Cout*Cin*KV floats of scratch (the filters are re-laid out tap-major once per call) */

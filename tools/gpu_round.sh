@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $ROOT
 rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|gfx" > $OUT/box.txt
 if [ "$MODE" = full ] || [ "$MODE" = quick ]; then
-  timeout 1200 python -m pytest tests -m gpu -q -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
+  timeout 1500 python -m pytest tests -m gpu -q --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
 fi
 if [ "$MODE" != micro ]; then
@@ -22,12 +22,18 @@ if [ "$MODE" != micro ]; then
     cut -c1-200 $OUT/bench_${CFG}_f32.json
   done
 fi
+if [ "$MODE" != micro ]; then
+  # the launch-bound configuration eagerly and as one hipGraph per step
+  for G in "" "--graph"; do
+    timeout 600 python bench.py --config cfg1 $G --no-brats --no-cpu-baseline --single-order > $OUT/bench_cfg1${G}.json 2> $OUT/bench_cfg1${G}.err; cut -c1-200 $OUT/bench_cfg1${G}.json
+  done
+fi
 if [ "$MODE" = full ] || [ "$MODE" = micro ]; then
   timeout 600 python tools/gemm_bench.py 8 tiles > $OUT/gemm_bench_tiles.txt 2>&1; tail -5 $OUT/gemm_bench_tiles.txt
 fi
 if [ "$MODE" = bench ] || [ "$MODE" = micro ]; then ls -la $OUT; exit 0; fi
 cd /tmp && export TMPDIR=/tmp
-for CFG in cfg2 cfg4; do
+for CFG in cfg2 cfg4 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$CFG -o $CFG -- python $ROOT/bench.py --config $CFG --steps 3 --warmup 2 --no-brats --no-cpu-baseline --single-order > $OUT/prof_$CFG.log 2>&1
   find $OUT/prof_$CFG -name '*kernel_stats.csv' -exec cp {} $OUT/${CFG}_kernel_stats.csv \;
   find $OUT/prof_$CFG -name '*agent_info.csv' -exec cp {} $OUT/agent_info.csv \;
