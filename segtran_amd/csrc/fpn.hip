@@ -179,24 +179,36 @@ __global__ __launch_bounds__(256) void interp_bwd_kernel(const float* __restrict
 // one-axis adjoint on a tensor viewed as [outer, n, inner]: the separable form of interp_bwd_kernel (three cheap passes
 // instead of one pass with prod(2*scale+1) candidates per cell -- 10x faster for the x4 trilinear up-sampling of the 3-D FPN)
 __global__ __launch_bounds__(256) void interp_bwd_axis_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
-                                                              int n_out, int n_in, int64_t inner, float scale) {
-    const int64_t total = outer * n_in * inner;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t in_ = idx % inner; const int64_t r = idx / inner; const int i = (int)(r % n_in); const int64_t o = r / n_in;
+                                                              int n_out, int n_in, int inner, FastDiv divInner, FastDiv divPer, float scale) {
+    // flat grid over outer * n_in * inner cells; as in the forward kernel the (slice, cell) split of a workgroup's first element is one
+    // uniform 64-bit division, the per-thread remainder 32-bit multiply-high divisions (per = n_in * inner < 2^31: host check)
+    const int per = n_in * inner;
+    const int64_t total = outer * per;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i = fdiv(e, divInner), in_ = e - i * inner;
         int lo, hi; cand_range(i, n_out, scale, lo, hi);
         const float* g = dout + (o * n_out) * inner + in_;
         float acc = 0.f;
         for (int d = lo; d <= hi; ++d) acc += axis_weight(i, d, n_in, scale) * g[(int64_t)d * inner];
-        din[idx] = acc;
+        din[o * per + e] = acc;
     }
 }
 
 // float4 over the inner (contiguous) extent: the candidate range and the blend weights depend on the axis index only
 __global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
-                                                               int n_out, int n_in, int64_t inner4, float scale) {
-    const int64_t total = outer * n_in * inner4;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int64_t in_ = idx % inner4; const int64_t r = idx / inner4; const int i = (int)(r % n_in); const int64_t o = r / n_in;
+                                                               int n_out, int n_in, int inner4, FastDiv divInner, FastDiv divPer, float scale) {
+    const int per = n_in * inner4;
+    const int64_t total = outer * per;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i = fdiv(e, divInner), in_ = e - i * inner4;
         int lo, hi; cand_range(i, n_out, scale, lo, hi);
         const float4* g = reinterpret_cast<const float4*>(dout) + (o * n_out) * inner4 + in_;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __re
             const float4 v = g[(int64_t)d * inner4];
             acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
         }
-        reinterpret_cast<float4*>(din)[idx] = acc;
+        reinterpret_cast<float4*>(din)[o * per + e] = acc;
     }
 }
 
@@ -430,11 +442,13 @@ extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_
     SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n_out > 0 && n_in > 0 && inner > 0, "segx_interp_linear_bwd_axis: bad args");
     const int64_t total = outer * n_in * inner;
     const float scale = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;
-    if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0)
+    SEGX_REQUIRE((int64_t)n_in * inner < 2147483647LL - 256, "segx_interp_linear_bwd_axis: slice too large");
+    if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0) {
+        const int in4 = (int)(inner / 4);
         hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,
-                           n_out, n_in, inner / 4, scale);
-    else
-        hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(65536, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out,
-                           n_in, inner, scale);
+                           n_out, n_in, in4, make_fastdiv(in4), make_fastdiv(n_in * in4), scale);
+    } else
+        hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out,
+                           n_in, (int)inner, make_fastdiv((int)inner), make_fastdiv((int)(n_in * inner)), scale);
     return check_launch("segx_interp_linear_bwd_axis");
 }
