@@ -143,6 +143,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     from segtran_amd import engine, segx, dist as sdist, functional as SF
     from segtran_amd.networks import segtran_shared as ss
     from segtran_amd.efficientnet.model import MBConvBlock
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
     c = engine.CONFIGS[cfg_name]
     B = c['bs']
     torch.manual_seed(1234)
@@ -153,6 +154,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         # after the contraction with the attractor-side operand, class projection composed into the out-FPN bridge weights
         ss.CrossAttFeatTrans.reassociate_projections = reassociated
         MBConvBlock.gate_in_weights = reassociated                 # squeeze-excite gate folded into the projection weights
+        InceptionModule.fuse_reductions = reassociated             # 3-D: the two 1x1x1 reductions of an Inception module as one convolution + one BatchNorm
         net_.fuse_output_tail = reassociated
         if hasattr(net_, 'fuse_input_bridge'):
             net_.fuse_input_bridge = reassociated          # 3-D: in_bridge_to3 composed into the stem filters

@@ -311,6 +311,14 @@ int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, i
 int segx_conv3d_bwd_weight_packed(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
                                   float* workspace, void* stream);
 int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int KV, void* stream);
+/* Channel-slice forms of the packed convolutions: the two 3x3x3 convolutions of an Inception module (aj_i3d.py:112-141: b1b(b1a(x)), b2b(b2a(x)))
+ * read their inputs as channel slices of ONE tensor produced by the fused b1a | b2a pointwise convolution + BatchNorm, and their backward-data
+ * passes (segx_conv3d_fwd_packed_bs on dY with the transposed filters) write slices of one gradient tensor.  X / Y / dY point at the first channel of
+ * the slice; *_bstride = distance between samples in floats (0 = dense); pointers 16-byte aligned */
+int segx_conv3d_fwd_packed_bs(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                              int64_t x_bstride, int64_t y_bstride, void* stream);
+int segx_conv3d_bwd_weight_packed_bs(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk, float* workspace,
+                                     int64_t dy_bstride, int64_t x_bstride, void* stream);
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
 int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws /* Cout*Cin*KV floats of scratch */, int B, int Cout,
                                 const int* geom, void* stream);

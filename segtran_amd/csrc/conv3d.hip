@@ -767,8 +767,9 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
  * workspace (splitk*B*Cout*P floats), reduced deterministically -- for the low-resolution Inception stages whose position grid alone
  * cannot fill the GPU (192 x 588 x 10368: 40 workgroups un-split) */
+// x_bs / y_bs: batch strides (floats) of X / Y when they are channel slices of wider NC... tensors; 0 = dense
 static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace, bool packed,
-                           hipStream_t stream) {
+                           hipStream_t stream, int64_t x_bs = 0, int64_t y_bs = 0) {
     SEGX_REQUIRE(X && W && Y && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_fwd: bad args");
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int K = q.Cin * q.KD * q.KH * q.KW;
@@ -778,7 +779,7 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     if (splitk < 1) splitk = 1;
     SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_fwd: split-K needs a workspace");
     GemmArgs g; g.A = W; g.B = X; g.C = Y;
-    g.a_b0 = 0; g.a_m = K; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * P; g.c_m = P;
+    g.a_b0 = 0; g.a_m = K; g.b_b0 = x_bs ? x_bs : (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = y_bs ? y_bs : (int64_t)Cout * P; g.c_m = P;
     fill_common(g, Cout, (int)P, K, B, splitk, workspace);
     const bool vec = aligned16c(W) && K % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
@@ -798,7 +799,7 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, Y,
-                       (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
+                       (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, y_bs ? y_bs : (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
                        (int64_t)0, (int64_t)0, total);
     return check_launch("segx_conv3d_fwd/reduce");
 }
@@ -827,7 +828,7 @@ extern "C" int segx_conv3d_flip_weights(const float* W, float* Wt, int Cout, int
 }
 /* dWb[b][Cout][Cin*KV] per-sample weight gradients (sum over b with segx_colsum); workspace: splitk*B*Cout*Cin*KV floats when splitk > 1 */
 static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk, float* workspace,
-                             bool packed, hipStream_t stream) {
+                             bool packed, hipStream_t stream, int64_t dy_bs = 0, int64_t x_bs = 0) {
     SEGX_REQUIRE(dY && X && dWb && geom && B > 0 && Cout > 0 && B <= 65535, "segx_conv3d_bwd_weight: bad args");
     const ConvGeom q = make_geom(geom);
     const int64_t P = (int64_t)q.OD * q.OH * q.OW; const int N = q.Cin * q.KD * q.KH * q.KW;
@@ -837,7 +838,7 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     if (splitk < 1) splitk = 1;
     SEGX_REQUIRE(splitk == 1 || workspace, "segx_conv3d_bwd_weight: split-K needs a workspace");
     GemmArgs g; g.A = dY; g.B = X; g.C = dWb;
-    g.a_b0 = (int64_t)Cout * P; g.a_m = P; g.b_b0 = (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * N; g.c_m = N;
+    g.a_b0 = dy_bs ? dy_bs : (int64_t)Cout * P; g.a_m = P; g.b_b0 = x_bs ? x_bs : (int64_t)q.Cin * q.ID * q.IH * q.IW; g.c_b0 = (int64_t)Cout * N; g.c_m = N;
     fill_common(g, Cout, N, (int)P, B, splitk, workspace);
     const bool vec = aligned16c(dY) && P % 4 == 0, small = conv_small(Cout);
     if (small) g.tiles_m = ceil_div(Cout, CfgCout64::BM);
@@ -878,6 +879,18 @@ extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dW
 extern "C" int segx_conv3d_bwd_weight_packed(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
                                              float* workspace, void* stream_) {
     return conv3d_wgrad_impl(dY, X, dWb, B, Cout, geom, splitk, workspace, true, (hipStream_t)stream_);
+}
+/* Channel-slice forms (Inception branches reading / writing slices of a wider NCDHW tensor without a copy): X is the first channel of the slice
+ * inside a tensor whose samples lie x_bstride floats apart, likewise Y / dY; every pointer 16-byte aligned; 0 = dense */
+extern "C" int segx_conv3d_fwd_packed_bs(const float* X, const float* Wp, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
+                                         int64_t x_bstride, int64_t y_bstride, void* stream_) {
+    SEGX_REQUIRE(x_bstride >= 0 && y_bstride >= 0 && aligned16c(X) && aligned16c(Y), "segx_conv3d_fwd_packed_bs: bad strides / alignment");
+    return conv3d_fwd_impl(X, Wp, Y, B, Cout, geom, splitk, workspace, true, (hipStream_t)stream_, x_bstride, y_bstride);
+}
+extern "C" int segx_conv3d_bwd_weight_packed_bs(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,
+                                                float* workspace, int64_t dy_bstride, int64_t x_bstride, void* stream_) {
+    SEGX_REQUIRE(dy_bstride >= 0 && x_bstride >= 0 && aligned16c(X) && aligned16c(dY), "segx_conv3d_bwd_weight_packed_bs: bad strides / alignment");
+    return conv3d_wgrad_impl(dY, X, dWb, B, Cout, geom, splitk, workspace, true, (hipStream_t)stream_, dy_bstride, x_bstride);
 }
 extern "C" int segx_conv3d_unpack_wgrad(const float* dWp, float* dW, int Cout, int Cin, int KV, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dWp && dW && Cout > 0 && Cin > 0 && Cin % 8 == 0 && KV > 0, "segx_conv3d_unpack_wgrad: bad args");

@@ -681,6 +681,28 @@ def bn_act(x, bn, act=ACT_NONE):
     return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act)
 
 
+def bn_act_multi(x, bns, act=ACT_NONE):
+    """BatchNorm (+ activation) of SEVERAL BatchNorm modules in one pass: x's channels are the concatenation of the modules' channels (the outputs
+    of convolutions that were run as one convolution with concatenated filters).  BatchNorm is per channel, so this is exactly the separate
+    layers -- with one statistics pass, one apply pass and, when synchronised, ONE exchange for all of them.  Same momentum / eps required."""
+    mom, eps, training = float(bns[0].momentum), float(bns[0].eps), bns[0].training
+    assert all(float(b.momentum) == mom and float(b.eps) == eps and b.training == training for b in bns)
+    w, b = torch.cat([m.weight for m in bns]), torch.cat([m.bias for m in bns])
+    rm, rv = torch.cat([m.running_mean for m in bns]), torch.cat([m.running_var for m in bns])
+    y = _BNAct.apply(x, w, b, rm, rv, training, mom, eps, act)
+    if training:
+        sizes = [m.num_features for m in bns]
+        with torch.no_grad():
+            torch._foreach_copy_([m.running_mean for m in bns] + [m.running_var for m in bns], list(rm.split(sizes)) + list(rv.split(sizes)))
+        for m in bns:
+            if m.num_batches_tracked is not None:
+                if _bn_ticks is not None:
+                    _bn_ticks.append(m.num_batches_tracked)
+                else:
+                    m.num_batches_tracked.add_(1)
+    return y
+
+
 class _DWConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, stride, pad):
@@ -1178,6 +1200,77 @@ class _Conv3d(torch.autograd.Function):
                 L.conv3d_unpack_wgrad(dwp, dw, Cout, Cin, KV)
             dw = dw.view_as(w)
         return dx, dw, None, None
+
+
+class _Conv3dSlices(torch.autograd.Function):
+    """Stride-1 'same' convolutions over DISJOINT channel slices of one NCDHW tensor t (slice i = the next w_i.shape[1] channels), without copying
+    the slices out: the implicit-GEMM kernels take the slice pointer and t's sample stride (segx_conv3d_*_bs), and in backward each transposed
+    convolution writes its slice of ONE gradient tensor (every element written exactly once: no zero fill, no gradient adds).  Used by the
+    Inception module whose two 1x1x1 reductions run as one convolution + one BatchNorm (aj_i3d.py:112-141)."""
+
+    @staticmethod
+    def forward(ctx, t, *ws):
+        L = segx.lib()
+        t = _c(t)
+        B, Ct, D, H, W = t.shape
+        vol = D * H * W
+        ys, geoms, c0 = [], [], 0
+        for w in ws:
+            w = _c(w)
+            Cout, Cin, KD, KH, KW = w.shape
+            assert Cin % 8 == 0 and Cout % 8 == 0 and KD % 2 == KH % 2 == KW % 2 == 1, 'slice convolutions: channel counts in multiples of 8, odd windows'
+            geom = (Cin, D, H, W, D, H, W, KD, KH, KW, 1, 1, 1, KD // 2, KH // 2, KW // 2)
+            y = _empty(t, B, Cout, D, H, W)
+            sk = L.conv3d_splitk(B, Cout, geom, False)
+            wp = torch.empty_like(w)
+            L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
+            L.conv3d_fwd(t[:, c0:], wp, y, B, Cout, geom, sk, _empty(t, sk * y.numel()) if sk > 1 else None, packed=True, x_bs=Ct * vol)
+            ys.append(y); geoms.append(geom); c0 += Cin
+        assert c0 == Ct, 'the slices must cover the tensor'
+        ctx.geoms = geoms
+        ctx.save_for_backward(t, *ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        L = segx.lib()
+        t, ws = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        B, Ct, D, H, W = t.shape
+        vol = D * H * W
+        dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
+        dws, c0 = [], 0
+        for i, (w, dy, geom) in enumerate(zip(ws, dys, ctx.geoms)):
+            Cout, Cin, KD, KH, KW = w.shape
+            KV = KD * KH * KW
+            dy = _c(dy)
+            if dt is not None:
+                wt = torch.empty_like(w)
+                g2 = (Cout, D, H, W, D, H, W, KD, KH, KW, 1, 1, 1, KD // 2, KH // 2, KW // 2)
+                sk = L.conv3d_splitk(B, Cin, g2, False)
+                L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
+                L.conv3d_fwd(dy, wt, dt[:, c0:], B, Cin, g2, sk, _empty(t, sk * B * Cin * vol) if sk > 1 else None, packed=True, y_bs=Ct * vol)
+            dw = None
+            if ctx.needs_input_grad[1 + i]:
+                N = Cin * KV
+                sk = L.conv3d_splitk(B, Cout, geom, True)
+                dwb = _empty(t, B, Cout * N)
+                L.conv3d_bwd_weight(dy, t[:, c0:], dwb, B, Cout, geom, sk, _empty(t, sk * B * Cout * N) if sk > 1 else None, packed=True, x_bs=Ct * vol)
+                if B > 1:
+                    dwp = _empty(t, Cout * N)
+                    L.colsum(dwb, dwp, _empty(t, L.colreduce_ws(B, Cout * N, 1)), B, Cout * N)
+                else:
+                    dwp = dwb
+                dw = _empty(t, Cout * N)
+                L.conv3d_unpack_wgrad(dwp, dw, Cout, Cin, KV)
+                dw = dw.view_as(w)
+            dws.append(dw)
+            c0 += Cin
+        return (dt,) + tuple(dws)
+
+
+def conv3d_slices(t, *weights):
+    """(conv3d_same(t[:, :c1], w1), conv3d_same(t[:, c1:c1+c2], w2), ...) for stride-1 odd-window convolutions, reading the slices in place."""
+    return _Conv3dSlices.apply(t, *weights)
 
 
 def conv3d_same(x, w, stride=(1, 1, 1)):

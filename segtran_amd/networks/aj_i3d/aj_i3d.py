@@ -63,7 +63,18 @@ class InceptionModule(nn.Module):
         self.b3b = Unit3D(in_channels, o[5], name=name + '/Branch_3/Conv3d_0b_1x1')
         self.name = name
 
+    fuse_reductions = True     # False: the reference's op order (four independent branches)
+
     def forward(self, x):
+        if InceptionModule.fuse_reductions:
+            # The two 1x1x1 reductions b1a | b2a (16 .. 192 filters each: skinny GEMMs on their own) as ONE pointwise convolution with the
+            # concatenated filters and ONE BatchNorm + ReLU over the concatenated channels (per-channel: exactly the two layers; one synchronised
+            # exchange instead of two), the 3x3x3 convolutions reading their channel slices of that tensor in place (SF.conv3d_slices): x is read
+            # once instead of twice, its gradient arrives as one tensor instead of two.
+            w12 = torch.cat([self.b1a.conv3d.weight, self.b2a.conv3d.weight], dim=0)
+            t = SF.bn_act_multi(SF.conv1x1(x, w12), [self.b1a.bn, self.b2a.bn], SF.ACT_RELU)
+            y1, y2 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight)
+            return torch.cat([self.b0(x), SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x))], dim=1)
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
 
 

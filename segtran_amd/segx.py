@@ -359,12 +359,17 @@ class SegxLib:
     def conv3d_splitk(self, B, Cout, geom, wgrad):
         return int(self.c.segx_conv3d_splitk(B, Cout, self._geom(geom), 1 if wgrad else 0))
 
-    def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None, packed=False):
+    def conv3d_fwd(self, X, W, Y, B, Cout, geom, splitk=1, ws=None, packed=False, x_bs=0, y_bs=0):
+        """x_bs / y_bs (packed only): X / Y are channel slices of wider tensors whose samples lie that many floats apart (0 = dense)."""
         self._chk_t(X, W, Y, ws)
         P = geom[4] * geom[5] * geom[6]; K = geom[0] * geom[7] * geom[8] * geom[9]
-        fn = self.c.segx_conv3d_fwd_packed if packed else self.c.segx_conv3d_fwd
-        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk),
-                         lambda: fn(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y)))
+        if x_bs or y_bs:
+            assert packed
+            call = lambda: self.c.segx_conv3d_fwd_packed_bs(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), int(x_bs), int(y_bs), self.stream(Y))
+        else:
+            fn = self.c.segx_conv3d_fwd_packed if packed else self.c.segx_conv3d_fwd
+            call = lambda: fn(_ptr(X), _ptr(W), _ptr(Y), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(Y))
+        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk), call)
         self.check(rc, 'segx_conv3d_fwd')
 
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
@@ -394,13 +399,18 @@ class SegxLib:
     def conv3d_flip_weights(self, W, Wt, Cout, Cin, KV):
         self._call('segx_conv3d_flip_weights', W, W, Wt, Cout, Cin, KV)
 
-    def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws, packed=False):
+    def conv3d_bwd_weight(self, dY, X, dWb, B, Cout, geom, splitk, ws, packed=False, dy_bs=0, x_bs=0):
         self._chk_t(dY, X, dWb, ws)
         g = [int(v) for v in geom]
         N, P = g[0] * g[7] * g[8] * g[9], g[4] * g[5] * g[6]
-        fn = self.c.segx_conv3d_bwd_weight_packed if packed else self.c.segx_conv3d_bwd_weight
-        rc = self._timed(dWb, 2.0 * B * Cout * P * N, ('conv3d_wgrad', Cout, N, P, B, splitk),
-                         lambda: fn(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(dWb)))
+        if dy_bs or x_bs:
+            assert packed
+            call = lambda: self.c.segx_conv3d_bwd_weight_packed_bs(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), int(dy_bs), int(x_bs),
+                                                                   self.stream(dWb))
+        else:
+            fn = self.c.segx_conv3d_bwd_weight_packed if packed else self.c.segx_conv3d_bwd_weight
+            call = lambda: fn(_ptr(dY), _ptr(X), _ptr(dWb), B, Cout, self._geom(geom), splitk, _ptr(ws), self.stream(dWb))
+        rc = self._timed(dWb, 2.0 * B * Cout * P * N, ('conv3d_wgrad', Cout, N, P, B, splitk), call)
         self.check(rc, 'segx_conv3d_bwd_weight')
 
     def conv3d_unpack_wgrad(self, dWp, dW, Cout, Cin, KV):
@@ -454,7 +464,7 @@ _SIGS = {
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
-    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
+    'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',

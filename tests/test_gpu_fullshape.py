@@ -16,6 +16,7 @@ import torch
 
 from segtran_amd import engine, functional as SF
 from segtran_amd.efficientnet.model import MBConvBlock
+from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
 from segtran_amd.synth import sample, synth_brats, synth_image2d, synth_fundus_mask
 from util import golden
 
@@ -79,6 +80,7 @@ def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypat
     from segtran_amd.networks import segtran_shared as ss
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)      # the size gate keeps its default (4096 rows)
     monkeypatch.setattr(MBConvBlock, 'gate_in_weights', reassociated)
+    monkeypatch.setattr(InceptionModule, 'fuse_reductions', reassociated)
     g = golden('full_' + cfg)
     c = engine.CONFIGS[cfg]
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)

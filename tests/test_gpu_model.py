@@ -7,6 +7,7 @@ import torch
 
 from segtran_amd import engine, functional as SF
 from segtran_amd.efficientnet.model import MBConvBlock
+from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
 from segtran_amd.synth import sample, synth_brats, synth_image2d
 from util import golden, golden_json, assert_close
 
@@ -163,6 +164,7 @@ def test_segtran3d_vs_reference(tag, train, fused_tail, monkeypatch):
     c = dict(engine.CONFIGS['cfg4'], size=(112, 112, 16))
     net = engine.build_model(c, DEV, dropout_prob=0.0, attractors=int(g['A']))
     net.fuse_output_tail = net.fuse_input_bridge = fused_tail      # reference op order: neither the output head nor the input bridge is composed
+    monkeypatch.setattr(InceptionModule, 'fuse_reductions', fused_tail)                # ... and four independent Inception branches
     net.train() if train else net.eval()
     x, lab = synth_brats(1, 112, 112, 16, 1337)
     assert torch.equal(sample(x), g['x_sample'])

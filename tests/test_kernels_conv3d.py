@@ -170,3 +170,40 @@ def test_input_bridge_composed_into_the_stem(backend):
     G = rnd(*y.shape, seed=75)
     y.backward(G); yr.backward(G)
     close(ws.grad, wsr.grad, 1e-4); close(wb.grad, wbr.grad, 1e-4); close(bb.grad, bbr.grad, 1e-4)
+
+
+@pytest.mark.parametrize('training', [True, False])
+def test_inception_module_fused_reductions_equal_the_four_branches(backend, training):
+    """InceptionModule with the b1a | b2a reductions run as one pointwise convolution + one BatchNorm and the 3x3x3 convolutions reading channel
+    slices in place (segx_conv3d_*_bs) == the reference's four independent branches: output, input gradient, every parameter gradient and the
+    running statistics of all six BatchNorm layers."""
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
+    import copy
+    torch.manual_seed(5)
+    a = InceptionModule(24, [16, 16, 24, 8, 16, 8], 'm')
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(rnd(*p.shape, seed=int(p.numel()) % 97) * (0.2 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 else 0.0))
+    b = copy.deepcopy(a)
+    dev = torch.get_default_device()
+    a.to(dev).train(training); b.to(dev).train(training)
+    x = rnd(2, 24, 3, 5, 8, seed=81).requires_grad_(True); xr = x.detach().clone().requires_grad_(True)
+    prev = InceptionModule.fuse_reductions
+    try:
+        InceptionModule.fuse_reductions = True
+        y = a(x)
+        InceptionModule.fuse_reductions = False
+        yr = b(xr)
+    finally:
+        InceptionModule.fuse_reductions = prev
+    close(y, yr.detach(), 1e-5)
+    G = rnd(*y.shape, seed=82)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        close(p.grad, q.grad, 2e-4)
+    for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        if u.dtype.is_floating_point:
+            close(u, v, 1e-5)
+        else:
+            assert int(u) == int(v), k
