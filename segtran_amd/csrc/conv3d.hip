@@ -647,6 +647,49 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_kernel(const float* __restr
         }
     }
 }
+// Stride-1 pools with a 3 x 3 in-plane window (the Inception branch pools, TKD = 3; TKD = 1: a (1,3,3) pool), OW % 4 == 0: a thread owns FOUR adjacent
+// outputs.  Per window row it loads the six inputs under them once (one aligned float4 + the two neighbours) instead of 4 x 3, and the bounds
+// tests are per row, not per tap; the scan order (d, h, w, first maximum wins) per output is unchanged.
+template <int TKD>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg,
+                                                                 PoolGeom q, int64_t planes, FastDiv dOHW4, FastDiv dOW4) {
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ow4 = q.OW >> 2, ohw4 = q.OH * ow4, osz4 = q.OD * ohw4;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* x = X + p * isz;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < osz4; e += gridDim.x * 256) {
+            const int od = fdiv(e, dOHW4), r = e - od * ohw4, oh = fdiv(r, dOW4), ow0 = (r - oh * ow4) << 2;
+            const int d0 = od - q.pd, h0 = oh - q.ph, w0 = ow0 - 1;                      // pw = 1 (host check)
+            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int bi[4] = {-1, -1, -1, -1};
+            const bool inl = w0 >= 0, inr = ow0 + 4 < q.IW;
+#pragma unroll
+            for (int kd = 0; kd < TKD; ++kd) {
+                const int id = d0 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = h0 + kh; const bool ok = okd && (unsigned)ih < (unsigned)q.IH;
+                    const int rowbase = ((ok ? id : 0) * q.IH + (ok ? ih : 0)) * q.IW;
+                    const float4 m = *reinterpret_cast<const float4*>(x + rowbase + ow0);
+                    float v[6]; bool in[6];
+                    in[0] = ok && inl; in[5] = ok && inr; in[1] = in[2] = in[3] = in[4] = ok;
+                    v[0] = in[0] ? x[rowbase + (inl ? w0 : 0)] : 0.f; v[5] = in[5] ? x[rowbase + (inr ? ow0 + 4 : 0)] : 0.f;
+                    v[1] = ok ? m.x : 0.f; v[2] = ok ? m.y : 0.f; v[3] = ok ? m.z : 0.f; v[4] = ok ? m.w : 0.f;      // zero padding
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float val = v[j + kw];
+                            if (val > best[j] || val != val) { best[j] = val; bi[j] = in[j + kw] ? rowbase + w0 + j + kw : -1; }
+                        }
+                }
+            }
+            const int64_t o = p * osz + (od * q.OH + oh) * q.OW + ow0;
+            *reinterpret_cast<float4*>(Y + o) = make_float4(best[0], best[1], best[2], best[3]);
+            *reinterpret_cast<int4*>(arg + o) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+        }
+    }
+}
+
 // gather form: an input cell sums the gradients of the windows whose arg-max it is.  S2 = true: strides (1 or 2, 2, 2) known at compile time
 // (the down-sampling pools of I3D: the window-range divisions become shifts); grid (chunks of a plane, planes), multiply-high decomposition.
 template <bool S2>
@@ -670,6 +713,35 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
                 for (int ow = w0; ow <= w1; ++ow) if (a[rowo + ow] == li) acc += g[rowo + ow];
             }
             dX[p * isz + li] = acc;
+        }
+    }
+}
+
+// In-plane stride 2 (the down-sampling pools: windows 3 or 2 wide), IW % 4 == 0: a thread owns FOUR adjacent input cells and one float4 store.
+// Their covering windows are <= 3 columns x 2 rows x 2 slices; a window's arg-max can only be one of the cells it covers, so "arg - li0 in [0, 4)"
+// is the whole test -- 6 .. 12 probes for four cells instead of 16 .. 32, no per-cell range arithmetic.  Accumulation order (od, oh, ow) as in the
+// generic gather.
+__global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
+                                                                 PoolGeom q, int64_t planes, FastDiv dIHW4, FastDiv dIW4) {
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, iw4 = q.IW >> 2, ihw4 = q.IH * iw4, isz4 = q.ID * ihw4;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* g = dY + p * osz; const int* a = arg + p * osz;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < isz4; e += gridDim.x * 256) {
+            const int id = fdiv(e, dIHW4), r = e - id * ihw4, ih = fdiv(r, dIW4), iw0 = (r - ih * iw4) << 2;
+            const int li0 = (id * q.IH + ih) * q.IW + iw0;
+            const int d1 = min(q.sd == 1 ? id + q.pd : (id + q.pd) >> 1, q.OD - 1), h1 = min((ih + q.ph) >> 1, q.OH - 1), w1 = min((iw0 + 3 + q.pw) >> 1, q.OW - 1);
+            const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw0 + q.pw - q.KW + 1;
+            const int d0 = dn > 0 ? (q.sd == 1 ? dn : (dn + 1) >> 1) : 0, h0 = hn > 0 ? (hn + 1) >> 1 : 0, w0 = wn > 0 ? (wn + 1) >> 1 : 0;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {
+                const int rowo = (od * q.OH + oh) * q.OW;
+                for (int ow = w0; ow <= w1; ++ow) {
+                    const int j = a[rowo + ow] - li0;
+                    const float gv = g[rowo + ow];
+                    a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
+                }
+            }
+            *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(a0, a1, a2, a3);
         }
     }
 }
@@ -914,7 +986,14 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
     const int osz = q.OD * q.OH * q.OW;
     const dim3 grid((unsigned)i64min(4096, (osz + 255) / 256), (unsigned)i64min(65535, planes));
     const FastDiv dOHW = make_fastdiv(q.OH * q.OW), dOW = make_fastdiv(q.OW);
-    if (q.KD == 3 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<3, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
+    const bool s1w4 = q.sd == 1 && q.sh == 1 && q.sw == 1 && q.KH == 3 && q.KW == 3 && q.pw == 1 && q.OW == q.IW && q.OW % 4 == 0 && q.OW >= 4 &&
+                      (int64_t)q.ID * q.IH * q.IW % 4 == 0 && osz % 4 == 0 && aligned16c(X) && aligned16c(Y) && aligned16c(arg);
+    if (s1w4 && (q.KD == 3 || q.KD == 1)) {
+        const int ow4 = q.OW / 4;
+        const dim3 grid4((unsigned)i64min(4096, (osz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
+        if (q.KD == 3) hipLaunchKernelGGL((maxpool3d_fwd_s1w4_kernel<3>), grid4, dim3(256), 0, stream, X, Y, arg, q, planes, make_fastdiv(q.OH * ow4), make_fastdiv(ow4));
+        else hipLaunchKernelGGL((maxpool3d_fwd_s1w4_kernel<1>), grid4, dim3(256), 0, stream, X, Y, arg, q, planes, make_fastdiv(q.OH * ow4), make_fastdiv(ow4));
+    } else if (q.KD == 3 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<3, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
     else if (q.KD == 1 && q.KH == 3 && q.KW == 3) hipLaunchKernelGGL((maxpool3d_fwd_kernel<1, 3, 3>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
     else if (q.KD == 2 && q.KH == 2 && q.KW == 2) hipLaunchKernelGGL((maxpool3d_fwd_kernel<2, 2, 2>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
     else hipLaunchKernelGGL((maxpool3d_fwd_kernel<0, 0, 0>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
@@ -934,7 +1013,11 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const int isz = q.ID * q.IH * q.IW;
     const dim3 grid((unsigned)i64min(4096, (isz + 255) / 256), (unsigned)i64min(65535, planes));
     const FastDiv dIHW = make_fastdiv(q.IH * q.IW), dIW = make_fastdiv(q.IW);
-    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2)) hipLaunchKernelGGL((maxpool3d_bwd_kernel<true>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
+    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2) && q.IW % 4 == 0 && isz % 4 == 0 && aligned16c(dX) && q.KW <= 3 && q.KH <= 3 && q.KD <= 3) {
+        const int iw4 = q.IW / 4;
+        const dim3 grid4((unsigned)i64min(4096, (isz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
+        hipLaunchKernelGGL(maxpool3d_bwd_s2w4_kernel, grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
+    } else if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2)) hipLaunchKernelGGL((maxpool3d_bwd_kernel<true>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
     else hipLaunchKernelGGL((maxpool3d_bwd_kernel<false>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
     return check_launch("segx_maxpool3d_bwd");
 }
