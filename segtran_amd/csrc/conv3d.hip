@@ -746,6 +746,47 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __
     }
 }
 
+// Stride-1 pools with a 3 x 3 in-plane window, IW % 4 == 0: FOUR adjacent input cells per thread.  The windows that can cover them are six columns
+// (ow = iw0 - 1 .. iw0 + 4: one aligned int4 / float4 + the two neighbours per window row) x 3 rows x TKD slices; column t can only be the arg-max
+// of cells t - 2 .. t, so each probe is "arg - li0 == j" for at most three j.  Same (od, oh, ow) accumulation order as the other gathers; no LDS.
+template <int TKD>
+__global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
+                                                                 PoolGeom q, int64_t planes, FastDiv dIHW4, FastDiv dIW4) {
+    const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, iw4 = q.IW >> 2, ihw4 = q.IH * iw4, isz4 = q.ID * ihw4;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* g = dY + p * osz; const int* a = arg + p * osz;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < isz4; e += gridDim.x * 256) {
+            const int id = fdiv(e, dIHW4), r = e - id * ihw4, ih = fdiv(r, dIW4), iw0 = (r - ih * iw4) << 2;
+            const int li0 = (id * q.IH + ih) * q.IW + iw0;
+            const bool inl = iw0 >= 1, inr = iw0 + 4 < q.OW;                 // OW == IW, pw == 1 (host check): window column ow covers cells ow - 1 .. ow + 1
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int z = 0; z < TKD; ++z) {
+                const int od = id + q.pd - (TKD - 1) + z; const bool okd = (unsigned)od < (unsigned)q.OD;
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const int oh = ih + q.ph - 2 + y; const bool ok = okd && (unsigned)oh < (unsigned)q.OH;
+                    const int rowo = ((ok ? od : 0) * q.OH + (ok ? oh : 0)) * q.OW;
+                    const int4 am = *reinterpret_cast<const int4*>(a + rowo + iw0);
+                    const float4 gm = *reinterpret_cast<const float4*>(g + rowo + iw0);
+                    int av[6]; float gv[6];
+                    av[0] = a[rowo + (inl ? iw0 - 1 : 0)]; gv[0] = (ok && inl) ? g[rowo + (inl ? iw0 - 1 : 0)] : 0.f;
+                    av[5] = a[rowo + (inr ? iw0 + 4 : 0)]; gv[5] = (ok && inr) ? g[rowo + (inr ? iw0 + 4 : 0)] : 0.f;
+                    av[1] = am.x; av[2] = am.y; av[3] = am.z; av[4] = am.w;
+                    gv[1] = ok ? gm.x : 0.f; gv[2] = ok ? gm.y : 0.f; gv[3] = ok ? gm.z : 0.f; gv[4] = ok ? gm.w : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        const int j = av[t] - li0;
+#pragma unroll
+                        for (int c = (t >= 2 ? t - 2 : 0); c <= (t <= 3 ? t : 3); ++c) acc[c] += j == c ? gv[t] : 0.f;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+}
+
 // Stride-1 3x3x3 pools (the Inception branch pools, 10 of the 12 per step): a workgroup owns a 4 x 8 x 32 tile of input cells and stages
 // the arg-max indices and gradients of the 6 x 10 x 34 windows that can cover it in LDS once; each cell then probes its 27 windows
 // there (same od, oh, ow order as the generic gather).  The generic kernel issued those 27 probes against L1/L2: 1 TB/s (r01-j PMC).
@@ -1004,6 +1045,14 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.ID * q.IH * q.IW;
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
+    if ((q.KD == 3 || q.KD == 1) && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pw == 1 && q.OW == q.IW && q.OH == q.IH && q.IW % 4 == 0 &&
+        q.IW >= 4 && (int64_t)q.ID * q.IH * q.IW % 4 == 0 && (int64_t)q.OD * q.OH * q.OW % 4 == 0 && aligned16c(dX) && aligned16c(dY) && aligned16c(arg)) {
+        const int iw4 = q.IW / 4; const int64_t isz4 = (int64_t)q.ID * q.IH * iw4;
+        const dim3 grid4((unsigned)i64min(4096, (isz4 + 255) / 256), (unsigned)i64min(65535, planes));
+        if (q.KD == 3) hipLaunchKernelGGL((maxpool3d_bwd_s1w4_kernel<3>), grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
+        else hipLaunchKernelGGL((maxpool3d_bwd_s1w4_kernel<1>), grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
+        return check_launch("segx_maxpool3d_bwd");
+    }
     if (q.KD == 3 && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && planes <= 65535) {
         const int td = ceil_div(q.ID, MP_TD), th = ceil_div(q.IH, MP_TH), tw = ceil_div(q.IW, MP_TW);
         hipLaunchKernelGGL(maxpool3d_bwd_s1k3_kernel, dim3((unsigned)(td * th * tw), (unsigned)planes), dim3(256), 0, stream, dY, arg, dX, q, th, tw);
