@@ -654,9 +654,14 @@ template <int TKD>
 __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg,
                                                                  PoolGeom q, int64_t planes, FastDiv dOHW4, FastDiv dOW4) {
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ow4 = q.OW >> 2, ohw4 = q.OH * ow4, osz4 = q.OD * ohw4;
+    const int lane = threadIdx.x & 63;
     for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
         const float* x = X + p * isz;
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < osz4; e += gridDim.x * 256) {
+        // whole waves iterate together (the two neighbour columns come from the adjacent lanes' float4 by cross-lane moves -- the load unit, not HBM,
+        // was the limit with two extra scalar loads per row); lanes past the end work on the last group and do not store
+        for (int e0 = blockIdx.x * 256 + (threadIdx.x & ~63); e0 < osz4; e0 += gridDim.x * 256) {
+            const bool live = e0 + lane < osz4;
+            const int e = live ? e0 + lane : osz4 - 1;
             const int od = fdiv(e, dOHW4), r = e - od * ohw4, oh = fdiv(r, dOW4), ow0 = (r - oh * ow4) << 2;
             const int d0 = od - q.pd, h0 = oh - q.ph, w0 = ow0 - 1;                      // pw = 1 (host check)
             float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -670,9 +675,14 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __
                     const int ih = h0 + kh; const bool ok = okd && (unsigned)ih < (unsigned)q.IH;
                     const int rowbase = ((ok ? id : 0) * q.IH + (ok ? ih : 0)) * q.IW;
                     const float4 m = *reinterpret_cast<const float4*>(x + rowbase + ow0);
+                    // left / right neighbour columns: the adjacent quad of the same row lives in the adjacent lane (consecutive lanes = consecutive
+                    // quads; a row starts where inl is false) -- except at the wave's first / last lane, which load them
+                    float vl = __shfl_up(m.w, 1), vr = __shfl_down(m.x, 1);
+                    if (lane == 0 && inl) vl = x[rowbase + w0];
+                    if (lane == 63 && inr) vr = x[rowbase + ow0 + 4];
                     float v[6]; bool in[6];
                     in[0] = ok && inl; in[5] = ok && inr; in[1] = in[2] = in[3] = in[4] = ok;
-                    v[0] = in[0] ? x[rowbase + (inl ? w0 : 0)] : 0.f; v[5] = in[5] ? x[rowbase + (inr ? ow0 + 4 : 0)] : 0.f;
+                    v[0] = in[0] ? vl : 0.f; v[5] = in[5] ? vr : 0.f;
                     v[1] = ok ? m.x : 0.f; v[2] = ok ? m.y : 0.f; v[3] = ok ? m.z : 0.f; v[4] = ok ? m.w : 0.f;      // zero padding
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -683,9 +693,11 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __
                         }
                 }
             }
-            const int64_t o = p * osz + (od * q.OH + oh) * q.OW + ow0;
-            *reinterpret_cast<float4*>(Y + o) = make_float4(best[0], best[1], best[2], best[3]);
-            *reinterpret_cast<int4*>(arg + o) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+            if (live) {
+                const int64_t o = p * osz + (od * q.OH + oh) * q.OW + ow0;
+                *reinterpret_cast<float4*>(Y + o) = make_float4(best[0], best[1], best[2], best[3]);
+                *reinterpret_cast<int4*>(arg + o) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+            }
         }
     }
 }
@@ -753,9 +765,12 @@ template <int TKD>
 __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
                                                                  PoolGeom q, int64_t planes, FastDiv dIHW4, FastDiv dIW4) {
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, iw4 = q.IW >> 2, ihw4 = q.IH * iw4, isz4 = q.ID * ihw4;
+    const int lane = threadIdx.x & 63;
     for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
         const float* g = dY + p * osz; const int* a = arg + p * osz;
-        for (int e = blockIdx.x * 256 + threadIdx.x; e < isz4; e += gridDim.x * 256) {
+        for (int e0 = blockIdx.x * 256 + (threadIdx.x & ~63); e0 < isz4; e0 += gridDim.x * 256) {     // whole waves (cross-lane neighbour columns, as in the forward)
+            const bool live = e0 + lane < isz4;
+            const int e = live ? e0 + lane : isz4 - 1;
             const int id = fdiv(e, dIHW4), r = e - id * ihw4, ih = fdiv(r, dIW4), iw0 = (r - ih * iw4) << 2;
             const int li0 = (id * q.IH + ih) * q.IW + iw0;
             const bool inl = iw0 >= 1, inr = iw0 + 4 < q.OW;                 // OW == IW, pw == 1 (host check): window column ow covers cells ow - 1 .. ow + 1
@@ -769,9 +784,13 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __
                     const int rowo = ((ok ? od : 0) * q.OH + (ok ? oh : 0)) * q.OW;
                     const int4 am = *reinterpret_cast<const int4*>(a + rowo + iw0);
                     const float4 gm = *reinterpret_cast<const float4*>(g + rowo + iw0);
+                    int al = __shfl_up(am.w, 1), ar = __shfl_down(am.x, 1);
+                    float gl = __shfl_up(gm.w, 1), gr = __shfl_down(gm.x, 1);
+                    if (lane == 0 && inl) { al = a[rowo + iw0 - 1]; gl = g[rowo + iw0 - 1]; }
+                    if (lane == 63 && inr) { ar = a[rowo + iw0 + 4]; gr = g[rowo + iw0 + 4]; }
                     int av[6]; float gv[6];
-                    av[0] = a[rowo + (inl ? iw0 - 1 : 0)]; gv[0] = (ok && inl) ? g[rowo + (inl ? iw0 - 1 : 0)] : 0.f;
-                    av[5] = a[rowo + (inr ? iw0 + 4 : 0)]; gv[5] = (ok && inr) ? g[rowo + (inr ? iw0 + 4 : 0)] : 0.f;
+                    av[0] = al; gv[0] = (ok && inl) ? gl : 0.f;
+                    av[5] = ar; gv[5] = (ok && inr) ? gr : 0.f;
                     av[1] = am.x; av[2] = am.y; av[3] = am.z; av[4] = am.w;
                     gv[1] = ok ? gm.x : 0.f; gv[2] = ok ? gm.y : 0.f; gv[3] = ok ? gm.z : 0.f; gv[4] = ok ? gm.w : 0.f;
 #pragma unroll
@@ -782,7 +801,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __
                     }
                 }
             }
-            *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (live) *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
 }

@@ -43,7 +43,8 @@ def test_conv3d_same(backend, B, Cin, Cout, size, k, stride):
                                            ((3, 5, 6), (3, 3, 3), (1, 1, 1)), ((6, 11, 37), (3, 3, 3), (1, 1, 1)),      # several LDS tiles per plane
                                            ((4, 7, 9), (1, 3, 3), (1, 1, 1)), ((5, 9, 10), (3, 3, 3), (3, 3, 3)),      # generic-stride gather
                                            ((3, 6, 12), (1, 3, 3), (1, 2, 2)), ((4, 8, 8), (2, 2, 2), (2, 2, 2)), ((5, 7, 16), (3, 3, 3), (2, 2, 2)),      # four-cell stride-2 gather
-                                           ((3, 5, 8), (3, 3, 3), (1, 1, 1)), ((4, 6, 12), (1, 3, 3), (1, 1, 1)), ((2, 3, 4), (3, 3, 3), (1, 1, 1))])      # four-output stride-1 scan
+                                           ((3, 5, 8), (3, 3, 3), (1, 1, 1)), ((4, 6, 12), (1, 3, 3), (1, 1, 1)), ((2, 3, 4), (3, 3, 3), (1, 1, 1)),      # four-output stride-1 scan
+                                           ((6, 16, 40), (3, 3, 3), (1, 1, 1))])      # ... over several waves (neighbour columns across lanes and at wave edges)
 def test_maxpool3d_same(backend, size, k, stride):
     x = torch.relu(rnd(2, 3, *size, seed=4)).requires_grad_(True)          # post-ReLU inputs as in I3D (incl. exact zeros)
     y = SF.maxpool3d_same(x, k, stride)
