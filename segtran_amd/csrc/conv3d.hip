@@ -219,6 +219,7 @@ struct ConvFwdLoaderB6 {
 // and 16 rows; the bf16 fragments need eight consecutive k (positions) of one row, so here a thread owns the position octet k0 + 8 (tid & 3) ..
 // + 7 and the TWO rows (tid >> 2) and 64 + (tid >> 2): the eight positions are decoded once (incrementally: ow, carry into oh, od) and serve
 // both rows; 16 lanes x 4 octets of a wave read 16 channels x 32 consecutive positions (128-byte runs wherever the octets stay in one image row).
+struct __attribute__((aligned(4))) F4u { float x, y, z, w; };       // 16 bytes at dword alignment (global_load_dwordx4 needs no more)
 template <bool FASTW>
 struct ConvWgradLoaderB6 {
     static constexpr int NREG = 16;
@@ -262,9 +263,22 @@ struct ConvWgradLoaderB6 {
                 hi = hi > 8 ? 8 : hi; hi = hi > npos ? npos : hi;
                 if (!rok || hi < lo) { lo = 0; hi = 0; }
                 const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                const float* src = X + (m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0);
+                if (q.sw == 1 && iw0 >= -1 && iw0 + 7 <= q.IW) {
+                    // unit stride, window offset -1 / 0 / +1 (every 3-wide 'same' convolution): the row's eight floats as TWO dword-aligned 16-byte
+                    // loads from a start clamped into the row, shifted by one register where the window sticks out (those j are masked anyway).
+                    // Eight scalar gathers per row made this loader load-unit-bound: 64 scattered dwords per instruction, 16 instructions per k-tile
+                    // (the 64-row tile ran at 67 TFLOP/s against 117 for the 128-row tile with the same loader).
+                    const int base = iw0 < 0 ? 0 : (iw0 + 8 > q.IW ? q.IW - 8 : iw0), sh = iw0 - base;
+                    const float* rowp = X + (m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + base : 0);
+                    const F4u u0 = *reinterpret_cast<const F4u*>(rowp), u1 = *reinterpret_cast<const F4u*>(rowp + 4);
+                    const float v[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) r[8 * h + j] = src[(((m >> j) & 1u) ? j : (m ? lo : 0)) * q.sw];
+                    for (int j = 0; j < 8; ++j) r[8 * h + j] = sh == 0 ? v[j] : (sh < 0 ? v[j > 0 ? j - 1 : 0] : v[j < 7 ? j + 1 : 7]);
+                } else {
+                    const float* src = X + (m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[8 * h + j] = src[(((m >> j) & 1u) ? j : (m ? lo : 0)) * q.sw];
+                }
                 okmask |= m << (8 * h);
             }
             return okmask;
@@ -893,7 +907,7 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && !conv_small(Cout)) || g_conv_x6_wgrad_all));
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -983,7 +997,7 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // small (64-row A tile): the B-side gather of a 128-column tile then feeds half the matrix work -- VALU-bound (r02_d: 65 TFLOP/s at Cout 192 against
     // 94 on the fp32 engine; r02_e: the 64-filter composed stem 70 against 85) -- the 64-row tile stays on the fp32 engine
     const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;          // geometry: the row-of-eight loader applies
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && !small) || g_conv_x6_wgrad_all)) {
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
         ++g_x6_launches;
         if (fastw) {
             if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);

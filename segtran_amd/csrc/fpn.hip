@@ -367,7 +367,7 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 1) { g_interp_variant = value; return 0; }
     if (knob == 2) { segx::g_conv_small_policy = value; return 0; }
     if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; const int prev = segx::g_engine; segx::g_engine = value; return prev; }
-    if (knob == 7) { segx::g_conv_x6_wgrad_all = value ? 1 : 0; return 0; }
+    if (knob == 7) { if (value < 0 || value > 2) return -1; segx::g_conv_x6_wgrad_all = value; return 0; }
     if (knob == 6) { if (value < 0 || value > 7) return -1; segx::g_x6_variant = value; return 0; }
     if (knob == 5) { const int n = segx::g_x6_launches; segx::g_x6_launches = 0; return n; }
     return -1;
