@@ -907,7 +907,7 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -991,13 +991,13 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
 #define SEGX_CONV_WG(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
                                   else hipLaunchKernelGGL((conv3d_wgrad_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
-    // bf16x6 engine: where the eight positions of a thread are eight floats of one input row (OW % 8 == 0: the 56 x 56 stages,
-    // 2/3 of the weight-gradient FLOPs of I3D); elsewhere its per-position gather decode costs more VALU time than the six-fold
-    // faster matrix instruction saves (measured r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays
-    // small (64-row A tile): the B-side gather of a 128-column tile then feeds half the matrix work -- VALU-bound (r02_d: 65 TFLOP/s at Cout 192 against
-    // 94 on the fp32 engine; r02_e: the 64-filter composed stem 70 against 85) -- the 64-row tile stays on the fp32 engine
+    // bf16x6 engine: where the eight positions of a thread are eight floats of one input row (OW % 8 == 0: the 56 x 56 stages, 2/3 of the
+    // weight-gradient FLOPs of I3D); elsewhere its per-position gather decode costs more VALU time than the six-fold faster matrix instruction
+    // saves (r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays.  With unit stride along W the row's eight floats
+    // are two 16-byte loads (r02_l: 128-row tile 117 -> 153 TFLOP/s, 64-row tile 65 -> 119 against 92 on the fp32 engine); the strided case
+    // (the stride-2 composed stem, 64 filters) keeps eight gathers per row and, on the 64-row tile, stays on the fp32 engine (66 against 83).
     const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;          // geometry: the row-of-eight loader applies
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
         ++g_x6_launches;
         if (fastw) {
             if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
