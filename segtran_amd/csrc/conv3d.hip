@@ -263,25 +263,19 @@ struct ConvWgradLoaderB6 {
                 hi = hi > 8 ? 8 : hi; hi = hi > npos ? npos : hi;
                 if (!rok || hi < lo) { lo = 0; hi = 0; }
                 const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                // The row's gathers as dword-aligned 16-byte loads starting AT iw0 (two for unit stride, four for stride 2, every other float used): where
-                // the window sticks out of the row the extra floats are the neighbouring rows' (inside the sample: read, then masked), so only the
-                // first / last floats of the whole sample need the scalar form.  Eight scalar gathers per row made this loader load-unit-bound: 64
-                // scattered dwords per instruction, 16 instructions per k-tile (64-row tile: 67 TFLOP/s against 117 for the 128-row tile, same loader).
+                // Unit stride: the row's eight gathers as TWO dword-aligned 16-byte loads starting AT iw0; where the window sticks out of the row the extra
+                // floats are the neighbouring rows' (inside the sample: read, then masked), so only the first / last floats of the whole sample need the
+                // scalar form.  Eight scalar gathers per row made this loader load-unit-bound: 64 scattered dwords per instruction, 16 instructions per
+                // k-tile (64-row tile: 67 TFLOP/s against 117 for the 128-row tile with the same loader; now 119 / 153).  Stride 2 keeps the gathers:
+                // reading 16 floats to use 8 doubles the cache traffic of the 343-tap stem (measured: no gain, 66 TFLOP/s either way).
                 const int64_t off = m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0;
-                if (q.sw <= 2 && off >= 0 && off + 8 * q.sw <= (int64_t)q.Cin * chan) {
+                if (q.sw == 1 && off >= 0 && off + 8 <= (int64_t)q.Cin * chan) {
                     const float* rowp = X + off;
-                    if (q.sw == 1) {
-                        const F4u u0 = *reinterpret_cast<const F4u*>(rowp), u1 = *reinterpret_cast<const F4u*>(rowp + 4);
-                        r[8 * h] = u0.x; r[8 * h + 1] = u0.y; r[8 * h + 2] = u0.z; r[8 * h + 3] = u0.w;
-                        r[8 * h + 4] = u1.x; r[8 * h + 5] = u1.y; r[8 * h + 6] = u1.z; r[8 * h + 7] = u1.w;
-                    } else {
-                        const F4u u0 = *reinterpret_cast<const F4u*>(rowp), u1 = *reinterpret_cast<const F4u*>(rowp + 4);
-                        const F4u u2 = *reinterpret_cast<const F4u*>(rowp + 8), u3 = *reinterpret_cast<const F4u*>(rowp + 12);
-                        r[8 * h] = u0.x; r[8 * h + 1] = u0.z; r[8 * h + 2] = u1.x; r[8 * h + 3] = u1.z;
-                        r[8 * h + 4] = u2.x; r[8 * h + 5] = u2.z; r[8 * h + 6] = u3.x; r[8 * h + 7] = u3.z;
-                    }
+                    const F4u u0 = *reinterpret_cast<const F4u*>(rowp), u1 = *reinterpret_cast<const F4u*>(rowp + 4);
+                    r[8 * h] = u0.x; r[8 * h + 1] = u0.y; r[8 * h + 2] = u0.z; r[8 * h + 3] = u0.w;
+                    r[8 * h + 4] = u1.x; r[8 * h + 5] = u1.y; r[8 * h + 6] = u1.z; r[8 * h + 7] = u1.w;
                 } else {
-                    const float* src = X + (m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0);
+                    const float* src = X + off;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) r[8 * h + j] = src[(((m >> j) & 1u) ? j : (m ? lo : 0)) * q.sw];
                 }
@@ -913,7 +907,7 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || q.sw <= 2 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -1003,7 +997,7 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // are two 16-byte loads (r02_l: 128-row tile 117 -> 153 TFLOP/s, 64-row tile 65 -> 119 against 92 on the fp32 engine); the strided case
     // (the stride-2 composed stem, 64 filters) keeps eight gathers per row and, on the 64-row tile, stays on the fp32 engine (66 against 83).
     const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;          // geometry: the row-of-eight loader applies
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw <= 2 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
+    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
         ++g_x6_launches;
         if (fastw) {
             if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
