@@ -250,6 +250,35 @@ struct ConvWgradLoaderB6 {
         }
         unsigned okmask = 0;
         if (FASTW) {
+            if (q.OW % 8 != 0) {
+                // OW % 4 == 0 only (the 28-wide stages): the octet is TWO quads of four consecutive ow, the second possibly on the next output row --
+                // each quad is one 16-byte load per (channel, tap) row with its own (id, ih) test and interval of valid j (unit stride: host check)
+                const int npos = kend - p0;
+                int odq[2] = {od, od}, ohq[2] = {oh, oh}, owq[2] = {ow, ow + 4};
+                if (owq[1] >= q.OW) { owq[1] -= q.OW; if (++ohq[1] == q.OH) { ohq[1] = 0; ++odq[1]; } }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int qd = 0; qd < 2; ++qd) {
+                        const int id = odq[qd] * q.sd - q.pd + kd[h], ih = ohq[qd] * q.sh - q.ph + kh[h], iw0 = owq[qd] - q.pw + kw[h];
+                        const int left = npos - 4 * qd;
+                        const bool rok = left > 0 && cb[h] >= 0 && (unsigned)id < (unsigned)q.ID && (unsigned)ih < (unsigned)q.IH;
+                        int lo = iw0 < 0 ? -iw0 : 0, hi = q.IW - iw0;
+                        hi = hi > 4 ? 4 : hi; hi = hi > left ? left : hi;
+                        if (!rok || hi < lo || lo > 4) { lo = 0; hi = 0; }
+                        const unsigned m = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                        const int64_t off = m ? (int64_t)cb[h] + ((int64_t)id * q.IH + ih) * q.IW + iw0 : 0;
+                        if (off >= 0 && off + 4 <= (int64_t)q.Cin * chan) {
+                            const F4u u = *reinterpret_cast<const F4u*>(X + off);
+                            r[8 * h + 4 * qd] = u.x; r[8 * h + 4 * qd + 1] = u.y; r[8 * h + 4 * qd + 2] = u.z; r[8 * h + 4 * qd + 3] = u.w;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) r[8 * h + 4 * qd + j] = X[off + (((m >> j) & 1u) ? j : (m ? lo : 0))];
+                        }
+                        okmask |= m << (8 * h + 4 * qd);
+                    }
+                return okmask;
+            }
             // OW % 8 == 0, unit stride along W, octets aligned to 8: the eight positions are eight consecutive ow of ONE output row, so the eight
             // gathers of a row are eight consecutive floats of one input row -- one address, one (id, ih) test and an interval of valid j per row
             const int npos = kend - p0;                                // < 8 only in the last k-tile (P % 8 != 0 cannot happen: OW % 8 == 0)
@@ -907,7 +936,7 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && ((q.OW % 8 == 0 && (!conv_small(Cout) || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (((q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && (!conv_small(Cout) || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -996,7 +1025,7 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // saves (r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays.  With unit stride along W the row's eight floats
     // are two 16-byte loads (r02_l: 128-row tile 117 -> 153 TFLOP/s, 64-row tile 65 -> 119 against 92 on the fp32 engine); the strided case
     // (the stride-2 composed stem, 64 filters) keeps eight gathers per row and, on the 64-row tile, stays on the fp32 engine (66 against 83).
-    const bool fastw = q.OW % 8 == 0 && g.k_chunk % 8 == 0;          // geometry: the row-of-eight loader applies
+    const bool fastw = (q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && g.k_chunk % 8 == 0;          // geometry: the row-of-eight (or two-quads) loader applies
     if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
         ++g_x6_launches;
         if (fastw) {

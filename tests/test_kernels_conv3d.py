@@ -123,14 +123,16 @@ def test_nonzero_mask_and_label_maps(backend):
                                                       (2, 16, 16, (5, 7, 7), (1, 3, 3), (1, 1, 1)), (1, 8, 8, (6, 8, 8), (3, 3, 3), (2, 2, 2)),
                                                       (1, 8, 72, (4, 6, 10), (3, 3, 3), (1, 1, 1)), (2, 16, 24, (3, 5, 8), (3, 3, 3), (1, 1, 1)),
                                                       (1, 8, 16, (2, 3, 16), (1, 3, 3), (1, 1, 1)), (1, 8, 96, (2, 3, 8), (3, 3, 3), (1, 1, 1)),
-                                                      (2, 8, 16, (3, 6, 32), (3, 3, 3), (2, 2, 2)), (1, 8, 24, (2, 4, 32), (1, 5, 5), (1, 2, 2))])
+                                                      (2, 8, 16, (3, 6, 32), (3, 3, 3), (2, 2, 2)), (1, 8, 24, (2, 4, 32), (1, 5, 5), (1, 2, 2)),
+                                                      (1, 8, 16, (2, 3, 12), (3, 3, 3), (1, 1, 1)), (2, 16, 72, (2, 5, 20), (3, 3, 3), (1, 1, 1)), (1, 8, 136, (3, 2, 28), (1, 3, 3), (1, 1, 1))])
 @pytest.mark.parametrize('wgrad_all', [0, 1], ids=['wgrad-x6-fast-rows', 'wgrad-x6-everywhere'])
 def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride, wgrad_all):
     """Forward, backward-data and backward-weight convolutions (packed contraction order) through the implicit GEMM on the bf16x6 engine:
     same loaders on the global side, operands split into bf16 planes on their way into LDS.  Position counts that are not multiples of
     8 / 32 and rows that wrap inside a thread's position octet (OW = 5, 7, 9, 10) exercise the incremental decode of the weight-gradient loader;
     OW = 8 / 16 its row-of-eight fast path (the one the product uses: rows read with 16-byte loads at stride 1 and 2 -- the last two cases --, windows
-    sticking out of the row on both sides, the first / last floats of a sample through the scalar form)."""
+    sticking out of the row on both sides, the first / last floats of a sample through the scalar form; OW = 12 / 20 / 28: the two-quad form whose
+    second quad may lie on the next output row)."""
     L = backend.L
     prev = L.set_engine('x6')
     L.c.segx_tune(7, wgrad_all)          # 1: also the general (per-position decode) weight-gradient gather; 0: only rows of 8 consecutive floats (OW % 8 == 0)
