@@ -261,7 +261,8 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
 /* tuning / bisecting knobs (results are identical for every setting): knob 1 = interp_linear_fwd kernel (0 auto, 1 scalar, 2 float4 rows);
  * knob 4 = tile engine of segx_gemm_f32 and the
  * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4;
- * knob 7 = 1: the weight gradient of every packed 3-D convolution on the bf16x6 engine (default: only where OW % 8 == 0 and the W stride is 1);
+ * knob 7: weight gradients of the packed 3-D convolutions on the bf16x6 engine -- 0 (default): where the loader reads whole rows (OW % 8 == 0, or OW % 4 == 0
+ * at unit W stride) and the tile is not the strided 64-row case; 1: every one (also the per-position gather); 2: every whole-row case (also the strided 64-row tile);
  * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
  * NOT the GEMM); knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
