@@ -61,6 +61,57 @@ def _case_sync_bn(rank, world, ret):
     sdist.disable_sync_batchnorm()
 
 
+def _case_sync_bn_fused(rank, world, ret):
+    """the fused BatchNorm forms under synchronised BN: bn_act_multi (two layers, ONE exchange) and bn_act_gate + conv1x1_gated (MBConv tail)"""
+    import torch.nn.functional as F
+    from segtran_amd import functional as SF, dist as sdist
+    sdist.enable_sync_batchnorm()
+    g = torch.Generator().manual_seed(1)
+    ok = True
+    # --- two BatchNorm layers over concatenated channels
+    x_full = torch.randn(4, 10, 3, 4, 5, generator=g) * 1.3 + 0.2; G_full = torch.randn(4, 10, 3, 4, 5, generator=g)
+    refs = [torch.nn.BatchNorm3d(c, eps=1e-3, momentum=0.01) for c in (6, 4)]
+    with torch.no_grad():
+        for m in refs:
+            m.weight.copy_(1 + 0.1 * torch.randn(m.num_features, generator=g)); m.bias.copy_(0.1 * torch.randn(m.num_features, generator=g))
+    mine = [torch.nn.BatchNorm3d(c, eps=1e-3, momentum=0.01) for c in (6, 4)]
+    for a, b in zip(mine, refs):
+        a.load_state_dict(b.state_dict())
+    xr = x_full.clone().requires_grad_(True)
+    yr = torch.cat([F.relu(refs[0](xr[:, :6])), F.relu(refs[1](xr[:, 6:]))], 1); yr.backward(G_full)
+    sl = slice(2 * rank, 2 * rank + 2)
+    x = x_full[sl].clone().requires_grad_(True)
+    y = SF.bn_act_multi(x, mine, SF.ACT_RELU); y.backward(G_full[sl])
+    ok &= torch.allclose(y, yr[sl], atol=2e-5) and torch.allclose(x.grad, xr.grad[sl], atol=2e-5)
+    for a, b in zip(mine, refs):
+        wg = a.weight.grad.clone(); dist.all_reduce(wg)
+        ok &= torch.allclose(wg, b.weight.grad, atol=1e-4) and torch.allclose(a.running_mean, b.running_mean, atol=1e-6) and torch.allclose(a.running_var, b.running_var, atol=1e-6)
+        ok &= int(a.num_batches_tracked) == 1
+    # --- BatchNorm + swish + squeeze-excite gate folded into the projection weights
+    C, Cs, Co = 12, 4, 10
+    x_full = torch.randn(4, C, 6, 5, generator=g) * 1.2 + 0.1; G_full = torch.randn(4, Co, 6, 5, generator=g)
+    ps = [0.5 * torch.randn(Cs, C, 1, 1, generator=g), 0.1 * torch.randn(Cs, generator=g), 0.5 * torch.randn(C, Cs, 1, 1, generator=g), 0.1 * torch.randn(C, generator=g),
+          0.3 * torch.randn(Co, C, 1, 1, generator=g)]
+    ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01); bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.1 * torch.randn(C, generator=g)); ref.bias.copy_(0.1 * torch.randn(C, generator=g))
+    bn.load_state_dict(ref.state_dict())
+    xr = x_full.clone().requires_grad_(True); pr = [p.clone().requires_grad_(True) for p in ps]
+    yr = ref(xr); yr = yr * torch.sigmoid(yr)
+    sq = F.conv2d(F.adaptive_avg_pool2d(yr, 1), pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
+    outr = F.conv2d(torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * yr, pr[4]); outr.backward(G_full)
+    x = x_full[sl].clone().requires_grad_(True); pm = [p.clone().requires_grad_(True) for p in ps]
+    yy, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *pm[:4])
+    out = SF.conv1x1_gated(yy, pm[4], gate); out.backward(G_full[sl])
+    ok &= torch.allclose(out, outr[sl], atol=3e-5) and torch.allclose(x.grad, xr.grad[sl], atol=3e-5)
+    for a, b in zip(pm, pr):
+        ga = a.grad.clone(); dist.all_reduce(ga)
+        ok &= torch.allclose(ga, b.grad, atol=2e-4)
+    ok &= torch.allclose(bn.running_var, ref.running_var, atol=1e-6)
+    ret[rank] = bool(ok)
+    sdist.disable_sync_batchnorm()
+
+
 def _case_dp_step_views(rank, world, ret):
     _case_dp_step(rank, world, ret, gather=False)
 
@@ -110,6 +161,11 @@ def _case_dp_step(rank, world, ret, gather=True):
 
 def test_sync_batchnorm_matches_full_batch():
     assert _run('_case_sync_bn') == {0: True, 1: True}
+
+
+def test_sync_batchnorm_fused_forms_match_full_batch():
+    res = _run('_case_sync_bn_fused')
+    assert res == {0: True, 1: True}, res
 
 
 def test_data_parallel_step_matches_single_process():
