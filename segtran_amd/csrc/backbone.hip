@@ -8,6 +8,7 @@
 #include "common.h"
 
 namespace segx {
+int g_dw_strip_outputs = 1024;        // segx_tune(8, v): outputs per strip of the depthwise weight gradient (see dw_wgrad_strips)
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
@@ -796,10 +797,13 @@ Dw4Grid dw4_grid(int OW) {
     while (l < 6 && (4 << l) < OW) ++l;
     return {l, (OW + (4 << l) - 1) / (4 << l)};
 }
-// strips per plane for the weight gradient: ~8K outputs per strip, at most 16 (depends on the output size only)
+// strips per plane for the weight gradient (depends on the output size only): one wave per (plane, strip).  ~1K outputs per strip (one tile of the
+// float4 kernel), at most 32: with 8K per strip the early MBConv stages (128 x 128 planes, 144 channels, batch 6) launched 1.7 waves per SIMD and
+// the kernel ran latency-bound at half the HBM rate (segx_tune knob 8 = outputs per strip, for A/B)
 int dw_wgrad_strips(int OH, int OW) {
-    const int64_t n = ((int64_t)OH * OW + 8191) / 8192;
-    return (int)(n < 1 ? 1 : n > 16 ? 16 : n);
+    using segx::g_dw_strip_outputs;
+    const int64_t n = ((int64_t)OH * OW + g_dw_strip_outputs - 1) / g_dw_strip_outputs;
+    return (int)(n < 1 ? 1 : n > 32 ? 32 : n);
 }
 bool dw4_ok(const void* a, const void* b, int W, int OW) {
     return W % 4 == 0 && OW % 4 == 0 && W >= 4 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 15) == 0;
