@@ -8,7 +8,7 @@
 #include "common.h"
 
 namespace segx {
-int g_dw_strip_outputs = 1024;        // segx_tune(8, v): outputs per strip of the depthwise weight gradient (see dw_wgrad_strips)
+int g_dw_strip_outputs = 8192;        // segx_tune(8, v): outputs per strip of the depthwise weight gradient (see dw_wgrad_strips)
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
@@ -797,9 +797,9 @@ Dw4Grid dw4_grid(int OW) {
     while (l < 6 && (4 << l) < OW) ++l;
     return {l, (OW + (4 << l) - 1) / (4 << l)};
 }
-// strips per plane for the weight gradient (depends on the output size only): one wave per (plane, strip).  ~1K outputs per strip (one tile of the
-// float4 kernel), at most 32: with 8K per strip the early MBConv stages (128 x 128 planes, 144 channels, batch 6) launched 1.7 waves per SIMD and
-// the kernel ran latency-bound at half the HBM rate (segx_tune knob 8 = outputs per strip, for A/B)
+// strips per plane for the weight gradient (depends on the output size only): one wave per (plane, strip), ~8K outputs per strip, at most 32.
+// More, smaller strips (1K outputs: 8x the waves on the early 128 x 128 stages) were measured 0.3 ms/step SLOWER on cfg2 (r02_r, same box,
+// segx_tune knob 8): the partial-sum rows and their column sums grow with the strip count, the kernel itself does not speed up.
 int dw_wgrad_strips(int OH, int OW) {
     using segx::g_dw_strip_outputs;
     const int64_t n = ((int64_t)OH * OW + g_dw_strip_outputs - 1) / g_dw_strip_outputs;
