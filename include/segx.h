@@ -263,7 +263,6 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * implicit-GEMM convolutions (SEGX_ENGINE_*: same results to fp32 rounding, see above); returns the previous value of knob 4;
  * knob 7: weight gradients of the packed 3-D convolutions on the bf16x6 engine -- 0 (default): where the loader reads whole rows (OW % 8 == 0, or OW % 4 == 0
  * at unit W stride) and the tile is not the strided 64-row case; 1: every one (also the per-position gather); 2: every whole-row case (also the strided 64-row tile);
- * knob 9 = position-quad form of the bf16x6 forward / backward-data convolution loader (1 default, 0 = one position per thread);
  * knob 8 = outputs per strip of the depthwise weight gradient (default 8192; >= 256);
  * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
  * NOT the GEMM); knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */

@@ -14,12 +14,10 @@ namespace segx {
 
 extern int g_engine;
 extern int g_x6_launches;
-int g_conv_fwd_quad = 1;              // segx_tune(9, v): position-quad form of the bf16x6 forward / backward-data loader (0 = one position per thread)
 int g_conv_x6_wgrad_all = 0;          // segx_tune(7, 1): weight gradients of EVERY packed convolution on the bf16x6 engine (tests of the general gather path)
 
 struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
-    int flags;        // host-set: bit 0 = the bf16x6 forward loader may use its position-quad form (segx_tune knob 9)
 };
 
 // ---- forward / backward-data: B(n = output position, k = (ci, tap)) ------------------------------------------------
@@ -194,67 +192,11 @@ struct ConvWgradLoaderB {
 // ---- the same B operands for the bf16x6 engine (gemm_x6.h) -------------------------------------------------------------------------------
 // forward / backward-data: the PACK8 gather already hands a thread two groups of EIGHT consecutive k of ONE position -- exactly one 16-byte
 // bf16 chunk per plane each: the global side is ConvFwdLoaderB<true>::load unchanged, the LDS side is two split-and-store calls.
-struct __attribute__((aligned(4))) F4u { float x, y, z, w; };       // 16 bytes at dword alignment (global_load_dwordx4 needs no more)
-template <bool QUAD>
 struct ConvFwdLoaderB6 {
     static constexpr int NREG = 4 * NP;
     ConvFwdLoaderB<true> inner;
-    // Position-quad form (unit W stride, OW % 4 == 0, window <= 8 wide): a thread owns FOUR adjacent output positions (quad tid >> 3 of the tile's 32)
-    // and FOUR consecutive k (4 (tid & 7) ..: four channels of one (channel block, tap)), so its 16 values are four dword-aligned 16-byte loads --
-    // the lanes of a wave read eight full 128-byte lines per instruction -- instead of 16 dword gathers (the load unit, not HBM, limits the
-    // one-position form: 16 instructions of 64 dwords per k-tile, see the weight-gradient loader).  LDS stores: row 4 q + j takes the thread's
-    // four k as one 8-byte write per plane; store s handles j = (s + q) & 3, which spreads a half-wave over all banks (bank model: conflict-free).
-    static constexpr bool quad = QUAD;
-    bool qlive;
-    int qoff;                           // window origin of the quad's first position inside a channel volume (may be negative: padding)
-    unsigned qmd, qmh, qmw;             // validity: bit kd / bit kh / bit (8 j + kw)
-    __device__ __forceinline__ ConvFwdLoaderB6(const float* X_, const ConvGeom& q_, int n0, int P) : inner(X_, q_, n0, P) {
-        const ConvGeom& q = inner.q;
-        qlive = false; qoff = 0; qmd = qmh = qmw = 0;
-        if (quad) {
-            const int n = n0 + 4 * (threadIdx.x >> 3);
-            qlive = n < P;                                           // P % 4 == 0 (OW % 4 == 0): the quad is inside or outside as a whole
-            const int nn = qlive ? n : 0;
-            const int od = nn / (q.OH * q.OW), r = nn - od * q.OH * q.OW, oh = r / q.OW, ow = r - oh * q.OW;
-            const int bd = od * q.sd - q.pd, bh = oh * q.sh - q.ph, bw = ow - q.pw;
-            qoff = (bd * q.IH + bh) * q.IW + bw;
-            for (int i = 0; i < q.KD; ++i) qmd |= ((unsigned)(bd + i) < (unsigned)q.ID ? 1u : 0u) << i;
-            for (int i = 0; i < q.KH; ++i) qmh |= ((unsigned)(bh + i) < (unsigned)q.IH ? 1u : 0u) << i;
-            for (int j = 0; j < 4; ++j)
-                for (int i = 0; i < q.KW; ++i) qmw |= ((unsigned)(bw + j + i) < (unsigned)q.IW ? 1u : 0u) << (8 * j + i);
-        }
-    }
+    __device__ __forceinline__ ConvFwdLoaderB6(const float* X_, const ConvGeom& q_, int n0, int P) : inner(X_, q_, n0, P) {}
     __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int tid) const {
-        if (quad) {
-            const ConvGeom& q = inner.q;
-            const int KV = q.KD * q.KH * q.KW, KHW = q.KH * q.KW, chan = q.ID * q.IH * q.IW;
-            const int kb = k0 + 4 * (tid & 7);
-            const bool kok = kb < kend;
-            const int blk = (kok ? kb : 0) >> 3, cj0 = kb & 4;
-            const int cb = fdiv(blk, inner.dKV), t = blk - cb * KV, kd = fdiv(t, inner.dKHW), t2 = t - kd * KHW, kh = fdiv(t2, inner.dKW), kw = t2 - kh * q.KW;
-            const bool rowok = kok && qlive && ((qmd >> kd) & (qmh >> kh) & 1u) != 0u;
-            const unsigned wm = rowok ? (qmw >> kw) : 0u;
-            const unsigned m4 = (wm & 1u) | ((wm >> 7) & 2u) | ((wm >> 14) & 4u) | ((wm >> 21) & 8u);        // bit j: position j reads inside the row
-            const int poff = m4 ? qoff + (kd * q.IH + kh) * q.IW + kw : 0;
-            const float* p = inner.X + (int64_t)(cb * 8 + cj0) * chan;
-            // the 16 bytes always come from inside the channel volume: at its first / last floats the load starts at the clamped offset and the
-            // registers are shifted (the elements that fall outside are masked positions anyway)
-            const int base = poff < 0 ? 0 : (poff + 4 > chan ? chan - 4 : poff), sh = poff - base;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const F4u u = *reinterpret_cast<const F4u*>(p + (int64_t)c * chan + base);
-                r[4 * c] = u.x; r[4 * c + 1] = u.y; r[4 * c + 2] = u.z; r[4 * c + 3] = u.w;
-            }
-            if (sh != 0) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float v0 = r[4 * c], v1 = r[4 * c + 1], v2 = r[4 * c + 2], v3 = r[4 * c + 3];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const int e = j + sh; r[4 * c + j] = e == 0 ? v0 : e == 1 ? v1 : e == 2 ? v2 : v3; }
-                }
-            }
-            return m4 | (m4 << 4) | (m4 << 8) | (m4 << 12);
-        }
         float4 t4[NP];
         const unsigned ok = inner.load(t4, k0, kend, tid);
 #pragma unroll
@@ -262,22 +204,6 @@ struct ConvFwdLoaderB6 {
         return ok;
     }
     __device__ __forceinline__ void store6(float (&r)[NREG], unsigned okmask, unsigned char* __restrict__ P, int tid) const {
-        if (quad) {
-            const int kg = tid & 7, pq = tid >> 3;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int j = (s + pq) & 3;
-                const bool ok = (okmask >> j) & 1u;
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float x = j == 0 ? r[4 * c] : j == 1 ? r[4 * c + 1] : j == 2 ? r[4 * c + 2] : r[4 * c + 3];
-                    v[c] = ok ? x : 0.f;
-                }
-                x6_store4<X6Plane<128>::bytes>(P, x6_off(4 * pq + j, kg >> 1) + ((kg & 1) << 3), v[0], v[1], v[2], v[3]);
-            }
-            return;
-        }
         const int n = tid & 127, c0 = (tid >> 7) * 2;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -293,6 +219,7 @@ struct ConvFwdLoaderB6 {
 // and 16 rows; the bf16 fragments need eight consecutive k (positions) of one row, so here a thread owns the position octet k0 + 8 (tid & 3) ..
 // + 7 and the TWO rows (tid >> 2) and 64 + (tid >> 2): the eight positions are decoded once (incrementally: ow, carry into oh, od) and serve
 // both rows; 16 lanes x 4 octets of a wave read 16 channels x 32 consecutive positions (128-byte runs wherever the octets stay in one image row).
+struct __attribute__((aligned(4))) F4u { float x, y, z, w; };       // 16 bytes at dword alignment (global_load_dwordx4 needs no more)
 template <bool FASTW>
 struct ConvWgradLoaderB6 {
     static constexpr int NREG = 16;
@@ -441,13 +368,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_wgrad_kernel(GemmArgs g, ConvGe
 }
 
 // the packed convolutions on the bf16x6 engine (float4-legal weights / dY: the host checks)
-template <class Cfg, int WPE, bool QUAD>
+template <class Cfg, int WPE>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_fwd_x6_kernel(GemmArgs g, ConvGeom q) {
     static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
     __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES];
     const TileCoord t = tile_coord<Cfg>(g);
     const DenseLoader6<true, Cfg::BM> la{g.A, g.a_m, 1, t.m0, g.M};                  // packed weights [Cout][Cin*KV]
-    const ConvFwdLoaderB6<QUAD> lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);      // X[b]
+    const ConvFwdLoaderB6 lb(g.B + (int64_t)t.zb * g.b_b0, q, t.n0, g.N);            // X[b]
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
@@ -975,7 +902,6 @@ using namespace segx;
 static ConvGeom make_geom(const int* g) {
     ConvGeom q; q.Cin = g[0]; q.ID = g[1]; q.IH = g[2]; q.IW = g[3]; q.OD = g[4]; q.OH = g[5]; q.OW = g[6];
     q.KD = g[7]; q.KH = g[8]; q.KW = g[9]; q.sd = g[10]; q.sh = g[11]; q.sw = g[12]; q.pd = g[13]; q.ph = g[14]; q.pw = g[15];
-    q.flags = g_conv_fwd_quad;
     return q;
 }
 static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk, float* workspace) {
@@ -1037,12 +963,8 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
                                    else hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
     if (packed && vec && g_engine == SEGX_ENGINE_BF16X6) {          // bf16x6 engine (gemm_x6.h): same tiles, same grid, same split-K slabs
         ++g_x6_launches;
-        // position-quad loader (four 16-byte loads per thread and k-tile) where a quad of output positions is four consecutive input floats
-        const bool quad = (q.flags & 1) && q.sw == 1 && q.OW % 4 == 0 && q.KW <= 8 && q.KD <= 32 && q.KH <= 32 && aligned16c(X);
-        if (small) { if (quad) hipLaunchKernelGGL((conv3d_fwd_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
-                     else hipLaunchKernelGGL((conv3d_fwd_x6_kernel<CfgCout64, 4, false>), grid, dim3(256), 0, stream, g, q); }
-        else { if (quad) hipLaunchKernelGGL((conv3d_fwd_x6_kernel<Cfg128, 3, true>), grid, dim3(256), 0, stream, g, q);
-               else hipLaunchKernelGGL((conv3d_fwd_x6_kernel<Cfg128, 3, false>), grid, dim3(256), 0, stream, g, q); }
+        if (small) hipLaunchKernelGGL((conv3d_fwd_x6_kernel<CfgCout64, 4>), grid, dim3(256), 0, stream, g, q);
+        else hipLaunchKernelGGL((conv3d_fwd_x6_kernel<Cfg128, 3>), grid, dim3(256), 0, stream, g, q);
     } else if (small && vec) SEGX_CONV_FWD(true, CfgCout64);
     else if (small) SEGX_CONV_FWD(false, CfgCout64);
     else if (vec) SEGX_CONV_FWD(true, Cfg128);
