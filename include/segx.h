@@ -38,7 +38,7 @@ enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bia
  * error vs fp64 1.2e-6 against 1.0e-6), used for float4-legal operands with more than 48 rows on both sides; everything else stays on F32 */
 enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
-       SEGX_TILE_256x128 = 6 /* bf16x6 engine only */ };
+       SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7 /* 6, 7: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h */ };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
     int64_t a_b0, a_b1, a_m, a_k;
@@ -265,7 +265,8 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * at unit W stride) and the tile is not the strided 64-row case; 1: every one (also the per-position gather); 2: every whole-row case (also the strided 64-row tile);
  * knob 8 = outputs per strip of the depthwise weight gradient (default 8192; >= 256);
  * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
- * NOT the GEMM); knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
+ * NOT the GEMM); knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
+ * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);

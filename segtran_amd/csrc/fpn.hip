@@ -352,7 +352,7 @@ extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64
     return check_launch("segx_dropout");
 }
 static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
-namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; extern int g_conv_x6_wgrad_all; extern int g_dw_strip_outputs; }
+namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; extern int g_conv_x6_wgrad_all; extern int g_dw_strip_outputs; extern int g_ws_grid; }
 __global__ void rng_advance_kernel(uint64_t* base, uint64_t span) { if (threadIdx.x == 0 && blockIdx.x == 0) *base += span; }
 /* Device-side base of every dropout Philox stream: each kernel adds *base to the `offset` it was launched with.  A train step captured into a
  * hipGraph replays the SAME offsets; advancing *base by the step's span (segx_rng_advance, itself a captured launch) gives every replay fresh
@@ -370,6 +370,7 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 8) { if (value < 256) return -1; segx::g_dw_strip_outputs = value; return 0; }
     if (knob == 7) { if (value < 0 || value > 2) return -1; segx::g_conv_x6_wgrad_all = value; return 0; }
     if (knob == 6) { if (value < 0 || value > 7) return -1; segx::g_x6_variant = value; return 0; }
+    if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; segx::g_ws_grid = value; return 0; }
     if (knob == 5) { const int n = segx::g_x6_launches; segx::g_x6_launches = 0; return n; }
     return -1;
 }

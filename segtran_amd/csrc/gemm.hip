@@ -18,7 +18,7 @@
 //   row-contiguous operand -> float4 along rows, float4 LDS stores.
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
-#include "gemm_x6.h"
+#include "gemm_x6ws.h"
 
 namespace segx {
 
@@ -44,6 +44,13 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void gemm_x6_kern
     f32x16 acc[Cfg::MI][Cfg::NJ];
     gemm_mainloop_x6<Cfg, DenseLoader6<AKC, Cfg::BM>, DenseLoader6<BKC, Cfg::BN>, VAR>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<EPI, Cfg>(acc, g, t);
+}
+
+// The wave-specialised persistent form (gemm_x6ws.h): 512 threads, one workgroup per CU (144 / 96 KB of LDS), grid = min(items, 256).
+template <class Cfg, bool AKC, bool BKC, int EPI, int PRIO = 0>
+__global__ __launch_bounds__(512) void gemm_x6ws_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6WsLds<Cfg>::BYTES];
+    x6ws_body<Cfg, DenseMk6<Cfg, AKC, BKC>, EPI, PRIO>(g, DenseMk6<Cfg, AKC, BKC>{}, lds);
 }
 
 // Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.
@@ -101,6 +108,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
 int g_engine = SEGX_ENGINE_F32;            // segx_tune(4, v): which tile engine the eligible GEMMs / convolutions run on
 int g_x6_variant = 0;                      // segx_tune(6, v): bench-only variants of the 128 x 128 k-contiguous kernel (gemm_x6.h)
+int g_ws_grid = 256;                       // segx_tune(9, v): workgroups of a persistent (wave-specialised) launch: one per CU; tests shrink it to force long item streams
 int g_x6_launches = 0;                     // segx_tune(5, 0): launches that ran on the bf16x6 engine since the last query (tests / sessions)
 // bf16x6 engine: float4-legal operands, neither side skinny (those GEMMs are HBM-bound and stream through the 32-row fp32 tiles)
 static bool x6_eligible(int M, int N, bool vec) { return g_engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
@@ -172,7 +180,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = d->bias_mode ? d->bias : nullptr; g.aux = d->epilogue == SEGX_EPI_GELU ? d->aux : nullptr;
     g.gmax = d->gmax;
-    g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1;
+    g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1; g.nbatch = d->nb0 * d->nb1;
     g.a_b0 = d->a_b0; g.a_b1 = d->a_b1; g.a_m = d->a_m; g.a_k = d->a_k;
     g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;
     g.c_b0 = d->c_b0; g.c_b1 = d->c_b1; g.c_m = d->c_m; g.bias_b1 = d->bias_b1; g.bias_b0 = d->bias_b0;
@@ -188,17 +196,20 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.c_split = (int64_t)nbatch * d->M * d->N;
     g.slab = breduce ? 1 : 0;
     if (splitk > 1 || breduce) g.C = d->workspace;
-    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_256x128 && (d->tile != SEGX_TILE_256x128 || g_engine == SEGX_ENGINE_BF16X6), "segx_gemm_f32: bad tile %d", d->tile);
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS128x128, "segx_gemm_f32: bad tile %d", d->tile);
+    const bool ws_tile = d->tile == SEGX_TILE_256x128 || d->tile == SEGX_TILE_WS128x128;
+    SEGX_REQUIRE(!ws_tile || g_engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
     int tile = d->tile;
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
     bool x6 = x6_eligible(d->M, d->N, vec) && (!gelu || akc) &&
-              (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64 || tile == SEGX_TILE_256x128);
+              (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64 || ws_tile);
     if (tile == SEGX_TILE_AUTO) {
         int sk_unused = 1;
         if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, &tile, &sk_unused);
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
-    if (!vec || gelu || (tile == SEGX_TILE_256x128 && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile is built
+    const bool ws = x6 && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x128);
+    if (!vec || (gelu && !ws) || (ws_tile && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile (and the wave-specialised ones) are built
 
     dim3 block(256);
     using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
@@ -218,24 +229,45 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else SEGX_LAUNCH6(CFG, false, false, SEGX_EPI_NONE, W);               \
     } while (0)
         using Cfg256x128 = TileCfg<2, 2, 4, 2>;
+        // persistent launch: one workgroup per CU, a multiple of eight (one run of items per XCD and round)
+#define SEGX_LAUNCHWS(CFG, AK, BK, E)                                                                      \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
+        SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
+        const int G = (int)i64min(g_ws_grid, (items + 7) / 8 * 8);                                              \
+        if (g_x6_variant == 1) hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 1>), dim3(G), dim3(512), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g);  \
+    } while (0)
+#define SEGX_LAUNCHWS_LAYOUT(CFG)                                                          \
+    do {                                                                                   \
+        if (gelu) { if (bkc) SEGX_LAUNCHWS(CFG, true, true, SEGX_EPI_GELU); else SEGX_LAUNCHWS(CFG, true, false, SEGX_EPI_GELU); } \
+        else if (akc && bkc) SEGX_LAUNCHWS(CFG, true, true, SEGX_EPI_NONE);                \
+        else if (akc && !bkc) SEGX_LAUNCHWS(CFG, true, false, SEGX_EPI_NONE);              \
+        else if (!akc && bkc) SEGX_LAUNCHWS(CFG, false, true, SEGX_EPI_NONE);              \
+        else SEGX_LAUNCHWS(CFG, false, false, SEGX_EPI_NONE);                              \
+    } while (0)
 #define SEGX_LAUNCH6V(V, W)                                                                                \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
         hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
-        if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
+        if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_LAYOUT(Cfg256x128);
+        else if (tile == SEGX_TILE_WS128x128) SEGX_LAUNCHWS_LAYOUT(Cfg128);
+        else if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
         else if (g_x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
             switch (g_x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 2: SEGX_LAUNCH6V(2, 3); break; case 3: SEGX_LAUNCH6V(3, 3); break;
                                     case 4: SEGX_LAUNCH6V(4, 3); break; case 5: SEGX_LAUNCH6V(5, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;
                                     default: SEGX_LAUNCH6V(0, 2); break; }      // 7: the product schedule at two waves per SIMD (what the split-early schedule is compared with)
         }
-        else if (tile == SEGX_TILE_256x128) SEGX_LAUNCH6_LAYOUT(Cfg256x128, 2);
         else if (tile == SEGX_TILE_64x64) SEGX_LAUNCH6_LAYOUT(Cfg64, 5);
         else if (tile == SEGX_TILE_64x128) SEGX_LAUNCH6_LAYOUT(Cfg64x128, 4);
         else SEGX_LAUNCH6_LAYOUT(Cfg128, 3);
 #undef SEGX_LAUNCH6
 #undef SEGX_LAUNCH6V
 #undef SEGX_LAUNCH6_LAYOUT
+#undef SEGX_LAUNCHWS
+#undef SEGX_LAUNCHWS_LAYOUT
     } else
 #define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \
     do {                                                                                                   \

@@ -28,6 +28,7 @@ struct GemmArgs {
     const float* A; const float* B; float* C;
     const float* bias; float* aux; float* gmax;
     int M, N, K, nb1;
+    int nbatch;                     // nb0 * nb1 (the persistent kernels of gemm_x6ws.h walk the batch themselves)
     int64_t a_b0, a_b1, a_m, a_k;
     int64_t b_b0, b_b1, b_n, b_k;
     int64_t c_b0, c_b1, c_m;

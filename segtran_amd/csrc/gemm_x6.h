@@ -38,6 +38,20 @@ template <int ROWS> struct X6Plane { static constexpr int bytes = ROWS * X6_ROWB
 // (x0, x1) -> three packed bf16 pairs (element 0 in the low half): x = hi + mid + lo, each step rounded to nearest even
 struct Split2 { unsigned h, m, l; };
 __device__ __forceinline__ Split2 split3_pair(float x0, float x1) {
+#if defined(SEGX_X6_SPLIT_SCALAR) && SEGX_X6_SPLIT_SCALAR
+    // bench build (tools/ws_bench.py): the two residual subtractions as scalar v_sub_f32 instead of v_pk_add_f32 (same values)
+    const f32v2 v0 = {x0, x1};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16v2));
+    float a0 = x0 - __uint_as_float(hb << 16), a1 = x1 - __uint_as_float(hb & 0xFFFF0000u);
+    SEGX_PIN(a0);
+    const f32v2 v1 = {a0, a1};
+    const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16v2));
+    float b0 = a0 - __uint_as_float(mb << 16), b1 = a1 - __uint_as_float(mb & 0xFFFF0000u);
+    SEGX_PIN(b0);
+    const f32v2 v2 = {b0, b1};
+    Split2 o; o.h = hb; o.m = mb; o.l = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16v2));
+    return o;
+#endif
     const f32v2 v = {x0, x1};
     const bf16v2 h = __builtin_convertvector(v, bf16v2);
     const f32v2 r1 = v - __builtin_convertvector(h, f32v2);
@@ -162,7 +176,7 @@ struct DenseLoader6<false, ROWS> {
         return okmask;
     }
     __device__ __forceinline__ void store6(float (&r)[NREG], unsigned okmask, unsigned char* __restrict__ P, int tid) const {
-        const unsigned full = (1u << NREG) - 1u;
+        const unsigned full = NREG >= 32 ? 0xFFFFFFFFu : ((1u << (NREG & 31)) - 1u);
         if (okmask != full) {
 #pragma unroll
             for (int e = 0; e < NREG; ++e) r[e] = ((okmask >> e) & 1u) ? r[e] : 0.f;
@@ -187,7 +201,7 @@ struct DenseLoader6<false, ROWS> {
     }
     struct Packed { Packed8 g8[KQ >= 8 ? KQ / 4 : 1]; Packed4 g4[2]; };       // KQ 16: 2 rows x 2 octets; 8: 2 rows x 1 octet; 4: 2 rows x 1 quad
     __device__ __forceinline__ void split6(float (&r)[NREG], unsigned okmask, Packed& pk) const {
-        const unsigned full = (1u << NREG) - 1u;
+        const unsigned full = NREG >= 32 ? 0xFFFFFFFFu : ((1u << (NREG & 31)) - 1u);
         if (okmask != full) {
 #pragma unroll
             for (int e = 0; e < NREG; ++e) r[e] = ((okmask >> e) & 1u) ? r[e] : 0.f;

@@ -205,7 +205,7 @@ def _x6_case(L, dev, M, N, K, akc, bkc, nb=1, sk=1, tile=segx.TILE_AUTO, seed=0,
     return A, B, C
 
 
-@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x128, segx.TILE_64x64, segx.TILE_256x128])
+@pytest.mark.parametrize('tile', [segx.TILE_128x128, segx.TILE_64x128, segx.TILE_64x64, segx.TILE_256x128, segx.TILE_WS128x128])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk', [(200, 136, 72, True, True, 1), (132, 260, 100, True, False, 1), (132, 84, 200, False, False, 3),
                                               (68, 68, 64, False, True, 2), (256, 128, 32, False, False, 1), (52, 64, 8, True, False, 1)])
 def test_x6_engine_matches_fp64_every_tile_and_layout(backend, tile, M, N, K, akc, bkc, sk):
@@ -295,4 +295,51 @@ def test_x6_split_early_schedule_gives_the_same_result(backend):
         assert (out[0].double() - _ref(A, B)).abs().max().item() < 3e-6 * _ref(A, B).abs().max().item()
     finally:
         L.c.segx_tune(6, 0)
+        L.set_engine(prev)
+
+
+@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128])
+@pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(520, 264, 104, True, True, 1, 3), (300, 392, 72, True, False, 2, 2), (260, 136, 200, False, False, 3, 2),
+                                                 (264, 260, 96, False, True, 1, 2)])
+def test_x6_wave_specialised_persistent_stream(backend, tile, M, N, K, akc, bkc, sk, nb):
+    """gemm_x6ws.h: producers / consumers of a persistent workgroup walk a STREAM of work items (here 8 workgroups for 12-72 items, ragged
+    edges, batches, split-K slabs and a tail stage K % 32 != 0): results must equal the 4-wave bf16x6 kernel bit for bit (same products,
+    same order per accumulator) and fp64 to fp32 rounding."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    try:
+        assert L.c.segx_tune(9, 8) == 0
+        L.x6_launches()
+        bias = torch.randn(N, generator=torch.Generator(device='cpu').manual_seed(2), device='cpu').to(backend.dev)
+        A, B, C = _x6_case(L, backend.dev, M, N, K, akc, bkc, nb=nb, sk=sk, tile=tile, alpha=0.25, bias=bias, bias_mode=segx.BIAS_N, seed=5)
+        assert L.x6_launches() == 1
+        _, _, C0 = _x6_case(L, backend.dev, M, N, K, akc, bkc, nb=nb, sk=sk, tile=segx.TILE_128x128, alpha=0.25, bias=bias, bias_mode=segx.BIAS_N, seed=5)
+    finally:
+        L.c.segx_tune(9, 256)
+        L.set_engine(prev)
+    ref = 0.25 * _ref(A, B) + bias.double()[None, None, :]
+    assert (C.double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    assert torch.equal(C, C0)
+
+
+def test_x6_wave_specialised_gelu_epilogue(backend):
+    L = backend.L
+    dev = backend.dev
+    prev = L.set_engine('x6')
+    try:
+        Mo, R, F = 2, 300, 136
+        g = torch.Generator(device='cpu').manual_seed(6)
+        H = torch.randn(Mo, R, F, generator=g, device='cpu').to(dev); W = (torch.randn(Mo, F, F, generator=g, device='cpu') * 0.3).to(dev)
+        b = torch.randn(Mo, F, generator=g, device='cpu').to(dev)
+        outs = []
+        for tile in (segx.TILE_128x128, segx.TILE_256x128, segx.TILE_WS128x128):
+            Y = torch.zeros(Mo, R, F, device=dev); T = torch.zeros(Mo, R, F, device=dev)
+            L.gemm(H, W, Y, R, F, F, (0, R * F, F, 1), (0, F * F, F, 1), (0, R * F, F), nb=(1, Mo), bias=b, bias_mode=segx.BIAS_N, bias_b1=F,
+                   epilogue=segx.EPI_GELU, aux=T, dropout_p=0.25, seed=3, offset=8, tile=tile)
+            outs.append((Y, T))
+        Tref = torch.einsum('mrf,mgf->mrg', H.double(), W.double()) + b[:, None, :].double()
+        assert (outs[0][1].double() - Tref).abs().max().item() < (1e-5 if backend.name == 'hip' else 4e-5)    # the emulator's bf16 MFMA is a sequential fmaf chain
+        for Y, T in outs[1:]:
+            assert torch.equal(T, outs[0][1]) and torch.equal(Y, outs[0][0])
+    finally:
         L.set_engine(prev)
