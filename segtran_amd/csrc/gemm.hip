@@ -208,7 +208,11 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, &tile, &sk_unused);
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
-    const bool ws = x6 && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x128);
+    // the wave-specialised kernels address an operand through 32-bit byte offsets from a per-item base and take whole 32-k stages only
+    const int64_t a_span = akc ? (int64_t)d->M * d->a_m : (int64_t)d->K * d->a_k, b_span = bkc ? (int64_t)d->N * d->b_n : (int64_t)d->K * d->b_k;
+    const bool ws_ok = d->K % BKT == 0 && a_span < (1LL << 29) && b_span < (1LL << 29);
+    if (ws_tile && !ws_ok) tile = SEGX_TILE_128x128;
+    const bool ws = x6 && ws_ok && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x128);
     if (!vec || (gelu && !ws) || (ws_tile && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile (and the wave-specialised ones) are built
 
     dim3 block(256);
@@ -236,8 +240,13 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
         SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
         const int G = (int)i64min(g_ws_grid, (items + 7) / 8 * 8);                                              \
-        if (g_x6_variant == 1) hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 1>), dim3(G), dim3(512), 0, stream, g); \
-        else hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g);  \
+        switch (E == SEGX_EPI_NONE && AK && BK ? g_x6_variant : (g_x6_variant == 1 ? 1 : 0)) {              \
+        case 1: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 1>), dim3(G), dim3(512), 0, stream, g); break; \
+        case 2: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 2 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
+        case 3: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 3 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
+        case 4: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 4 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
+        case 5: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 5 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
+        default: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g); } \
     } while (0)
 #define SEGX_LAUNCHWS_LAYOUT(CFG)                                                          \
     do {                                                                                   \

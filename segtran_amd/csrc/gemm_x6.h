@@ -35,20 +35,38 @@ __device__ __forceinline__ int x6_swz(int row) { return ((row >> 2) & 1) | ((((r
 __device__ __forceinline__ int x6_off(int row, int chunk) { return row * X6_ROWB + ((chunk ^ x6_swz(row)) << 4); }
 template <int ROWS> struct X6Plane { static constexpr int bytes = ROWS * X6_ROWB; };
 
+#ifndef SEGX_X6_SPLIT
+#define SEGX_X6_SPLIT 1            // 0: v_pk_add_f32 residuals (r02), 1: scalar v_sub_f32 residuals (product), 2: v_dot2c_f32_bf16 residuals (bench)
+#endif
 // (x0, x1) -> three packed bf16 pairs (element 0 in the low half): x = hi + mid + lo, each step rounded to nearest even
 struct Split2 { unsigned h, m, l; };
 __device__ __forceinline__ Split2 split3_pair(float x0, float x1) {
-#if defined(SEGX_X6_SPLIT_SCALAR) && SEGX_X6_SPLIT_SCALAR
-    // bench build (tools/ws_bench.py): the two residual subtractions as scalar v_sub_f32 instead of v_pk_add_f32 (same values)
+#if SEGX_X6_SPLIT == 1
+    // the two residual subtractions as scalar v_sub_f32: v_pk_add_f32 issues at a fraction of the plain-VALU rate (r03_a: the wave-specialised
+    // kernel's producers went 179 -> 219 TFLOP/s on 24576 x 1792 x 1792 with eleven plain instructions per pair instead of nine with two packed adds)
     const f32v2 v0 = {x0, x1};
     const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16v2));
     float a0 = x0 - __uint_as_float(hb << 16), a1 = x1 - __uint_as_float(hb & 0xFFFF0000u);
-    SEGX_PIN(a0);
+    SEGX_PIN(a0);                                            // keeps the SLP vectoriser from re-packing the pair
     const f32v2 v1 = {a0, a1};
     const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16v2));
     float b0 = a0 - __uint_as_float(mb << 16), b1 = a1 - __uint_as_float(mb & 0xFFFF0000u);
     SEGX_PIN(b0);
     const f32v2 v2 = {b0, b1};
+    Split2 o; o.h = hb; o.m = mb; o.l = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16v2));
+    return o;
+#elif SEGX_X6_SPLIT == 2
+    // bench build: residual = x - bf16 element through v_dot2c_f32_bf16 with the constants (-1, 0) / (0, -1): no expansion of the packed pair
+    const f32v2 v0 = {x0, x1};
+    const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16v2));
+    float a0 = x0, a1 = x1;
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a0) : "v"(hb), "v"(0x0000BF80u));
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a1) : "v"(hb), "v"(0xBF800000u));
+    const f32v2 v1 = {a0, a1};
+    const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16v2));
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a0) : "v"(mb), "v"(0x0000BF80u));
+    asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a1) : "v"(mb), "v"(0xBF800000u));
+    const f32v2 v2 = {a0, a1};
     Split2 o; o.h = hb; o.m = mb; o.l = __builtin_bit_cast(unsigned, __builtin_convertvector(v2, bf16v2));
     return o;
 #endif

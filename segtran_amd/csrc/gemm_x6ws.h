@@ -92,13 +92,44 @@ struct X6WsStream {
             if (t.kbeg < t.kend) { mk.make(g, t, la, lb, ptid); k = t.kbeg; kend = t.kend; valid = true; return; }
         }
     }
+    // past the end of the stream (valid = false) the loaders and (k, kend) keep the last stage's values: loads issued from them are legal
     __device__ __forceinline__ void next(const GemmArgs& g, const MK& mk, int pos, int G, int total) {
-        k += BKT;
-        if (k >= kend) { ++r; open(g, mk, pos, G, total); }
+        if (!valid) return;
+        if (k + BKT >= kend) { ++r; open(g, mk, pos, G, total); }
+        else k += BKT;
     }
 };
 
-// EPI as gemm_epilogue.  PRIO: 1 = consumers run at raised wave priority (bench knob).
+// a producer's register set -> the three-plane LDS images of one stage (VAR: the bench ablations of x6ws_body)
+template <int VAR, class Cfg, class LA, class LB>
+__device__ __forceinline__ void x6ws_put(const LA& la, const LB& lb, float (&ra)[LA::NREG], float (&rb)[LB::NREG], unsigned oka, unsigned okb,
+                                         unsigned char* __restrict__ P, int ptid) {
+    if (VAR == 2) {                                        // stores of the same width and count without the conversion arithmetic
+        unsigned* wa = reinterpret_cast<unsigned*>(P) + ptid * 2;
+#pragma unroll
+        for (int e = 0; e + 1 < LA::NREG; e += 2) {
+            uint2 w; w.x = __float_as_uint(ra[e]); w.y = __float_as_uint(ra[e + 1]);
+            *reinterpret_cast<uint2*>(wa + 512 * (e / 2)) = w;
+            if ((e & 2) == 0) *reinterpret_cast<uint2*>(wa + 512 * (e / 2) + 256) = w;
+        }
+        unsigned* wb = reinterpret_cast<unsigned*>(P + X6Lds<Cfg>::A_BYTES) + ptid * 2;
+#pragma unroll
+        for (int e = 0; e + 1 < LB::NREG; e += 2) {
+            uint2 w; w.x = __float_as_uint(rb[e]); w.y = __float_as_uint(rb[e + 1]);
+            *reinterpret_cast<uint2*>(wb + 512 * (e / 2)) = w;
+            if ((e & 2) == 0) *reinterpret_cast<uint2*>(wb + 512 * (e / 2) + 256) = w;
+        }
+    } else if (VAR == 4 || VAR == 5) {                     // keep the loaded values alive without storing them
+#pragma unroll
+        for (int e = 0; e < LA::NREG; ++e) asm volatile("" :: "v"(ra[e]));
+#pragma unroll
+        for (int e = 0; e < LB::NREG; ++e) asm volatile("" :: "v"(rb[e]));
+    } else { la.store6(ra, oka, P, ptid); lb.store6(rb, okb, P + X6Lds<Cfg>::A_BYTES, ptid); }
+}
+
+// EPI as gemm_epilogue.  PRIO (segx_tune knob 6; results are only defined for 0 and 1): 1 = consumers run at raised wave priority; ablations that
+// price the producers' parts: 2 = no split arithmetic (raw bits stored), 3 = no global loads after a work item's first stage, 4 = no LDS stores,
+// 5 = producers only keep the barrier count (what the consumers reach alone).
 template <class Cfg, class MK, int EPI, int PRIO = 0>
 __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsigned char* __restrict__ lds) {
     using LA = typename MK::LA; using LB = typename MK::LB;
@@ -107,27 +138,42 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
     const int G = gridDim.x, pos = ws_round_pos(blockIdx.x, G);
     const int total = g.tiles_m * g.tiles_n * g.nbatch * g.splitk;
     if (wave >= 4) {
-        // ---- producers: global -> registers -> split -> LDS, one stage ahead of the consumers ------------------------------------------
+        // ---- producers: global -> registers -> split -> LDS ----------------------------------------------------------------------------
+        // Two register sets.  After barrier s (consumers start on stage s) a producer FIRST issues the global loads of stage s+2 into the
+        // free set and THEN splits / stores stage s+1 from the other one: a load has a whole stage time to land.  Loads and stores are
+        // UNCONDITIONAL (past the end of the stream they re-read / re-write the last stage: harmless): a load inside a branch makes hipcc's
+        // s_waitcnt bookkeeping merge "issued" with "not issued" at the join and wait for the NEWEST loads before every split (r03_c: 167
+        // TFLOP/s, slower than one register set); straight-line issue gives the counted `vmcnt(loads of one stage)` this schedule needs.
+        // The stream's step to the next work item (X6WsStream::next) is scalar-only control flow without memory instructions.
+        // The loaders' store6 must not depend on loader state other than the thread index (true for every loader of the library).
         const int ptid = threadIdx.x - 256;
         X6WsStream<Cfg, MK> st; st.r = 0; st.ptid = ptid; st.open(g, mk, pos, G, total);
         if (!st.valid) return;
-        float ra[LA::NREG], rb[LB::NREG];
-        unsigned oka = st.la.load6(ra, st.k, st.kend, ptid), okb = st.lb.load6(rb, st.k, st.kend, ptid);
-        st.la.store6(ra, oka, lds, ptid); st.lb.store6(rb, okb, lds + A_BYTES, ptid);                   // stage 0 -> buffer 0
+        float a0[LA::NREG], b0[LB::NREG], a1[LA::NREG], b1[LB::NREG];
+        unsigned oka0, okb0, oka1, okb1;
+        oka0 = st.la.load6(a0, st.k, st.kend, ptid); okb0 = st.lb.load6(b0, st.k, st.kend, ptid);
+        int r_seen = st.r;
         st.next(g, mk, pos, G, total);
-        if (st.valid) { oka = st.la.load6(ra, st.k, st.kend, ptid); okb = st.lb.load6(rb, st.k, st.kend, ptid); }
+        bool have1 = st.valid, have0;
+        oka1 = st.la.load6(a1, st.k, st.kend, ptid); okb1 = st.lb.load6(b1, st.k, st.kend, ptid);
+        r_seen = st.r; st.next(g, mk, pos, G, total);
+        x6ws_put<PRIO, Cfg>(st.la, st.lb, a0, b0, oka0, okb0, lds, ptid);        // stage 0 -> buffer 0
         int par = 0;
-        bool pending = true;                               // a stored stage the consumers have not been released onto yet
-        while (pending) {
-            SEGX_LDS_BARRIER();                            // stage in buffer `par` is complete; buffer par ^ 1 has been read to the end
-            par ^= 1; pending = false;
-            if (st.valid) {
-                unsigned char* const P = lds + par * STAGE;
-                st.la.store6(ra, oka, P, ptid); st.lb.store6(rb, okb, P + A_BYTES, ptid);
-                pending = true;
-                st.next(g, mk, pos, G, total);
-                if (st.valid) { oka = st.la.load6(ra, st.k, st.kend, ptid); okb = st.lb.load6(rb, st.k, st.kend, ptid); }
-            }
+        for (;;) {
+            SEGX_LDS_BARRIER();                            // the stage in buffer `par` is complete; buffer par ^ 1 has been read to the end
+            par ^= 1;
+            if (!have1) break;
+            have0 = st.valid;
+            if (!((PRIO == 3 || PRIO == 5) && st.r == r_seen)) { oka0 = st.la.load6(a0, st.k, st.kend, ptid); okb0 = st.lb.load6(b0, st.k, st.kend, ptid); }
+            r_seen = st.r; st.next(g, mk, pos, G, total);
+            if (PRIO != 5) x6ws_put<PRIO, Cfg>(st.la, st.lb, a1, b1, oka1, okb1, lds + par * STAGE, ptid);
+            SEGX_LDS_BARRIER();
+            par ^= 1;
+            if (!have0) break;
+            have1 = st.valid;
+            if (!((PRIO == 3 || PRIO == 5) && st.r == r_seen)) { oka1 = st.la.load6(a1, st.k, st.kend, ptid); okb1 = st.lb.load6(b1, st.k, st.kend, ptid); }
+            r_seen = st.r; st.next(g, mk, pos, G, total);
+            if (PRIO != 5) x6ws_put<PRIO, Cfg>(st.la, st.lb, a0, b0, oka0, okb0, lds + par * STAGE, ptid);
         }
         return;
     }
@@ -162,15 +208,32 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
 // Same thread -> element maps and LDS stores as DenseLoader6 (gemm_x6.h), but everything that does not change along k is computed ONCE per
 // work item: a wave-uniform operand base (SGPRs) plus one 32-bit byte offset per piece (VGPRs) -- a stage's loads are `global_load ... v_off, s[base]`
 // with no address arithmetic on the vector pipe, which belongs to the split.  Only the last stage of a contraction whose length is not a
-// multiple of 32 takes the clamped path.  (The host sends operands whose offsets do not fit 31 bits to the 4-wave kernels.)
+// multiple of 32 would need a clamped path: the host sends those shapes, and operands whose offsets do not fit 31 bits, to the 4-wave kernels.
 template <bool KC, int ROWS> struct WsDense6;
+// A wave-uniform base pointer moved to SGPRs (it IS the same in every lane; hipcc cannot always prove it) and typed as a GLOBAL-address-space
+// pointer, plus a 32-bit per-lane byte offset: the load takes the `global_load v_dst, v_offset, s[base]` form -- no 64-bit address arithmetic on
+// the vector pipe.  (A pointer rebuilt from integers without the address space becomes a flat pointer: flat_load waits on two counters.)
+#ifndef SEGX_GLOBAL
+#define SEGX_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef const char SEGX_GLOBAL* ws_gptr;
+__device__ __forceinline__ ws_gptr ws_uniform_base(const void* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = SEGX_WAVE_UNIFORM((unsigned)u), hi = SEGX_WAVE_UNIFORM((unsigned)(u >> 32));
+    return (ws_gptr)(((uint64_t)hi << 32) | lo);
+}
+template <class V> __device__ __forceinline__ V ws_load(ws_gptr base, unsigned byte_off) {
+    return *reinterpret_cast<const V SEGX_GLOBAL*>(base + byte_off);
+}
 
+// The contraction range of every work item is a multiple of the 32-k stage (the host sends other shapes to the 4-wave kernels), so a stage
+// has no k edge: no clamped path whose loads hipcc would merge with these (and give both VGPR addresses).
 template <int ROWS>
 struct WsDense6<true, ROWS> : DenseLoader6<true, ROWS> {                     // k-contiguous: piece i -> row (ptid >> 3) + 32 i, floats 4 (ptid & 7) .. + 3
     using Base = DenseLoader6<true, ROWS>;
     static constexpr int NPT = Base::NPT, NREG = Base::NREG;
     unsigned off[NPT]; unsigned rowmask;
-    __device__ __forceinline__ void begin(const float* b, int64_t s_row_, int row0_, int rows_, int ptid) {
+    __device__ __forceinline__ void begin(const float* b, int64_t s_row_, int64_t, int row0_, int rows_, int ptid) {
         this->base = b; this->s_row = s_row_; this->s_k = 1; this->row0 = row0_; this->rows = rows_;
         rowmask = 0u;
 #pragma unroll
@@ -181,25 +244,14 @@ struct WsDense6<true, ROWS> : DenseLoader6<true, ROWS> {                     // 
             rowmask |= ok ? (0xFu << (4 * i)) : 0u;
         }
     }
-    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int ptid) const {
-        if (kend - k0 >= BKT) {
-            const char* b = reinterpret_cast<const char*>(this->base + k0);
-#pragma unroll
-            for (int i = 0; i < NPT; ++i) {
-                const float4 v = *reinterpret_cast<const float4*>(b + off[i]);
-                r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
-            }
-            return rowmask;
-        }
-        const int kk = k0 + ((ptid & 7) << 2);
-        const bool kok = kk < kend;                                          // K % 4 == 0: a float4 is inside or outside as a whole
-        const char* b = reinterpret_cast<const char*>(this->base + (kok ? kk : kend - 4) - ((ptid & 7) << 2));
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr b = ws_uniform_base(this->base + k0);
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
-            const float4 v = *reinterpret_cast<const float4*>(b + off[i]);
+            const f32x4 v = ws_load<f32x4>(b, off[i]);
             r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
         }
-        return kok ? rowmask : 0u;
+        return rowmask;
     }
 };
 
@@ -207,35 +259,22 @@ template <int ROWS>
 struct WsDense6<false, ROWS> : DenseLoader6<false, ROWS> {                    // row-contiguous: rows 2 rp, 2 rp + 1 (one 8-byte load per k), KQ consecutive k
     using Base = DenseLoader6<false, ROWS>;
     static constexpr int KQ = Base::KQ, NREG = Base::NREG, RP = Base::RP;
-    unsigned off; bool rok;
-    __device__ __forceinline__ void begin(const float* b, int64_t s_k_, int row0_, int rows_, int ptid) {
+    unsigned off[KQ]; bool rok;                                               // byte offset of (row pair, k = k0 + KQ (ptid / RP) + j) from row k0 of the operand
+    __device__ __forceinline__ void begin(const float* b, int64_t, int64_t s_k_, int row0_, int rows_, int ptid) {
         this->base = b; this->s_row = 1; this->s_k = s_k_; this->row0 = row0_; this->rows = rows_;
         const int row = row0_ + 2 * (ptid % RP);
         rok = row < rows_;                                                   // rows % 4 == 0 and row even: the pair is inside or outside together
-        off = (unsigned)(((int64_t)(KQ * (ptid / RP)) * s_k_ + (rok ? row : rows_ - 2)) << 2);
-    }
-    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int kend, int ptid) const {
-        if (kend - k0 >= BKT) {
-            const float* bk = this->base + (int64_t)k0 * this->s_k;          // wave-uniform; one scalar add per k below
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) {
-                const float2 v = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(bk + (int64_t)j * this->s_k) + off);
-                r[2 * j] = v.x; r[2 * j + 1] = v.y;
-            }
-            return rok ? ((KQ == 16) ? 0xFFFFFFFFu : ((1u << NREG) - 1u)) : 0u;
-        }
-        const int kb = k0 + KQ * (ptid / RP);
-        const char* b = reinterpret_cast<const char*>(this->base) + (off - (unsigned)(((int64_t)(KQ * (ptid / RP)) * this->s_k) << 2));   // row part only
-        unsigned okmask = 0;
+        for (int j = 0; j < KQ; ++j) off[j] = (unsigned)(((int64_t)(KQ * (ptid / RP) + j) * s_k_ + (rok ? row : rows_ - 2)) << 2);
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr bk = ws_uniform_base(this->base + (int64_t)k0 * this->s_k);
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
-            const int k = kb + j;
-            const bool ok = rok && k < kend;
-            const float2 v = *reinterpret_cast<const float2*>(b + (((int64_t)(k < kend ? k : kend - 1) * this->s_k) << 2));
+            const f32v2 v = ws_load<f32v2>(bk, off[j]);
             r[2 * j] = v.x; r[2 * j + 1] = v.y;
-            okmask |= (ok ? 3u : 0u) << (2 * j);
         }
-        return okmask;
+        return rok ? ((KQ == 16) ? 0xFFFFFFFFu : ((1u << (NREG & 31)) - 1u)) : 0u;
     }
 };
 
@@ -243,8 +282,8 @@ template <class Cfg, bool AKC, bool BKC>
 struct DenseMk6 {
     using LA = WsDense6<AKC, Cfg::BM>; using LB = WsDense6<BKC, Cfg::BN>;
     __device__ __forceinline__ void make(const GemmArgs& g, const TileCoord& t, LA& la, LB& lb, int ptid) const {
-        la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, AKC ? g.a_m : g.a_k, t.m0, g.M, ptid);
-        lb.begin(g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, BKC ? g.b_n : g.b_k, t.n0, g.N, ptid);
+        la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M, ptid);
+        lb.begin(g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N, ptid);
     }
 };
 

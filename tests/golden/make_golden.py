@@ -778,12 +778,16 @@ def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
 def case_fullshape():
     """BASELINE.json shapes at batch 1: label bits of the whole map, full-size gradients, fp64 referee.
     Sub-cases: full_cfg2 full_cfg3 full_cfg4 full_cfg5 (python make_golden.py fullshape full_cfg4 ...)."""
-    want = [a for a in sys.argv[2:] if a.startswith('full_')] or ['full_cfg2', 'full_cfg3', 'full_cfg4', 'full_cfg5']
+    want = [a for a in sys.argv[2:] if a.startswith('full_')] or ['full_cfg2', 'full_cfg3', 'full_cfg4', 'full_cfg5', 'full_cfg2_b2', 'full_cfg4_b2']
     for tag in want:
-        if tag in ('full_cfg2', 'full_cfg3'):
-            S, task = (512, 'fundus') if tag == 'full_cfg2' else (352, 'polyp')
-            x = synth_image2d(1, S, 1337)
-            mask = synth_fundus_mask(1, S, 1338)
+        # *_b2 (VERDICT r02 item 1): the same shapes at BATCH 2 -- train-mode BatchNorm statistics over two samples, (B, M) batch strides of
+        # the attention GEMMs, and B x N token rows above the product's re-association gate at cfg4 (2 x 2352 rows)
+        B = 2 if tag.endswith('_b2') else 1
+        base = tag[:-3] if B == 2 else tag
+        if base in ('full_cfg2', 'full_cfg3'):
+            S, task = (512, 'fundus') if base == 'full_cfg2' else (352, 'polyp')
+            x = synth_image2d(B, S, 1337)
+            mask = synth_fundus_mask(B, S, 1338)
             if task == 'polyp':
                 mask = mask[:, :1].repeat(1, 3, 1, 1)
                 nhot, pw = O.polyp_map_mask(mask), O.bce_pos_weight([0., 1.])
@@ -792,8 +796,8 @@ def case_fullshape():
             nc = 3 if task == 'fundus' else 2
             _full_one(tag, 2, lambda: R.ref_segtran2d(num_classes=nc, dropout_prob=0), x, nhot.float(), pw, [1792, 1792, 896, 448], FULL_GRAD_KEYS_2D)
         else:
-            size, tl = ((112, 112, 96), 1) if tag == 'full_cfg4' else ((128, 128, 128), 2)
-            x, lab = synth_brats(1, *size, 1337)
+            size, tl = ((112, 112, 96), 1) if base == 'full_cfg4' else ((128, 128, 128), 2)
+            x, lab = synth_brats(B, *size, 1337)
             nhot, pw = O.brats_map_label(lab), O.bce_pos_weight([0., 3., 1., 1.75])
             _full_one(tag, 3, lambda: R.ref_segtran3d(num_translayers=tl, compress=(1,) * (tl + 1), dropout_prob=0), x, nhot.float(), pw,
                       [1024] * (tl + 1), FULL_GRAD_KEYS_3D)

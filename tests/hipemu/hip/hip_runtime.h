@@ -27,6 +27,7 @@
 #define SEGX_MIN_WAVES_PER_SIMD(n)      /* register-budget hint: meaningless on the host */
 #define SEGX_PIN(x) ((void)0)            /* code-motion fence on a register value: meaningless on the host */
 #define SEGX_LDS_BARRIER() __syncthreads()   /* s_waitcnt lgkmcnt(0); s_barrier of the wave-specialised kernels (gemm_x6ws.h) */
+#define SEGX_GLOBAL                      /* address_space(1) of the device build */
 #define SEGX_WAVE_UNIFORM(x) (x)         /* v_readfirstlane of a value that is uniform over the wave */
 #define __constant__ static
 

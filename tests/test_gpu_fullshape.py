@@ -1,4 +1,4 @@
-"""GPU (-m gpu): parity at the BASELINE.json SHAPES (batch 1) against fixtures produced by the real reference on the CPU
+"""GPU (-m gpu): parity at the BASELINE.json SHAPES (batch 1, and batch 2 for cfg2 / cfg4) against fixtures produced by the real reference on the CPU
 (tests/golden/make_golden.py case_fullshape): cfg2 512 x 512, cfg3 352 x 352, cfg4 112 x 112 x 96, cfg5 128^3 (two layers, 1024 attractors).
 
   * eval forward: every hardened label of the WHOLE map is compared (the fixture stores the packed bits of all logits); a mismatch is
@@ -25,16 +25,22 @@ DEV = torch.device('cuda', 0)
 LABEL_MARGIN = 1e-5
 
 
-def _inputs(cfg):
+def _inputs(cfg, B=1):
     c = engine.CONFIGS[cfg]
     if c['dim'] == 2:
         S = c['size'][0]
-        x = synth_image2d(1, S, 1337)
-        m = synth_fundus_mask(1, S, 1338)
+        x = synth_image2d(B, S, 1337)
+        m = synth_fundus_mask(B, S, 1338)
         if c['task'] == 'polyp':
             m = m[:, :1].repeat(1, 3, 1, 1)
         return x, m
-    return synth_brats(1, *c['size'], 1337)
+    return synth_brats(B, *c['size'], 1337)
+
+
+def _case(case):
+    """'cfg4' -> ('cfg4', 1, 'full_cfg4'); 'cfg4_b2' -> ('cfg4', 2, 'full_cfg4_b2') (the batch-2 fixtures of VERDICT r02 item 1)"""
+    cfg = case[:-3] if case.endswith('_b2') else case
+    return cfg, (2 if case.endswith('_b2') else 1), 'full_' + case
 
 
 @pytest.fixture
@@ -50,12 +56,13 @@ def engine_sel(request):
 
 
 @pytest.mark.parametrize('engine_sel', ['x6', 'f32'], indirect=True)
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
-def test_fullshape_eval_every_label(cfg, engine_sel):
-    g = golden('full_' + cfg)
+@pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2'])
+def test_fullshape_eval_every_label(case, engine_sel):
+    cfg, B, tag = _case(case)
+    g = golden(tag)
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)
     net.eval()
-    x, _ = _inputs(cfg)
+    x, _ = _inputs(cfg, B)
     with torch.no_grad():
         y = net(x.to(DEV)).cpu()
     assert list(y.shape) == g['shape'].tolist()
@@ -73,15 +80,24 @@ def test_fullshape_eval_every_label(cfg, engine_sel):
     assert (y.reshape(-1)[near] - g['near_val']).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize('engine_sel,reassociated', [('x6', True), ('x6', False), ('f32', True)], indirect=['engine_sel'],
-                         ids=['x6-reassociated', 'x6-reference-op-order', 'f32-reassociated'])
-@pytest.mark.parametrize('cfg', ['cfg2', 'cfg3', 'cfg4', 'cfg5'])
-def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypatch):
+# gate: 'default' = the product's size gate (>= 4096 token rows = B x N: at batch 1 cfg3 / cfg4 keep the reference order inside the
+# transformer); 'bench' = gate 0, i.e. the re-associated transformer path that bench.py's batches (6 x 1936, 4 x 2352 rows) take -- the
+# folded key / value projections and FFN mid map at N = 1936 / 2352, A = 256 / 1024.  The *_b2 cases run it at batch 2
+# through the default gate (2 x 2352 >= 4096).
+@pytest.mark.parametrize('engine_sel,reassociated,gate', [('x6', True, 'default'), ('x6', True, 'bench'), ('x6', False, 'default'), ('f32', True, 'bench')],
+                         indirect=['engine_sel'], ids=['x6-reassociated', 'x6-reassociated-bench-gate', 'x6-reference-op-order', 'f32-reassociated-bench-gate'])
+@pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2'])
+def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
-    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)      # the size gate keeps its default (4096 rows)
+    cfg, B, tag = _case(case)
+    if gate == 'bench' and cfg in ('cfg2', 'cfg5') and engine_sel == 'x6':
+        pytest.skip('N = 4096 tokens: the default gate already takes the re-associated path at batch 1')
+    monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)
+    if gate == 'bench':
+        monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)
     monkeypatch.setattr(MBConvBlock, 'gate_in_weights', reassociated)
     monkeypatch.setattr(InceptionModule, 'fuse_reductions', reassociated)
-    g = golden('full_' + cfg)
+    g = golden(tag)
     c = engine.CONFIGS[cfg]
     net = engine.build_model(cfg, DEV, dropout_prob=0.0)
     net.fuse_output_tail = reassociated
@@ -90,7 +106,7 @@ def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypat
     if c['dim'] == 2:
         net.backbone.drop_connect_rate = 0.0
     net.train()
-    x, raw = _inputs(cfg)
+    x, raw = _inputs(cfg, B)
     y = net(x.to(DEV))
     lerr = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits']).abs().max().item()
     lerr64 = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits64']).abs().max().item()
@@ -120,4 +136,4 @@ def test_fullshape_train_step_gradients(cfg, reassociated, engine_sel, monkeypat
     assert n >= 25
     for k in g['unused']:                                  # N3
         assert named[str(k)].grad is None, k
-    print('%s %s: worst |hip - ref32| / gscale = %.2e (%s)' % (cfg, 'reassoc' if reassociated else 'ref-order', worst[0], worst[1]))
+    print('%s %s gate=%s: worst |hip - ref32| / gscale = %.2e (%s)' % (case, 'reassoc' if reassociated else 'ref-order', gate, worst[0], worst[1]))

@@ -17,6 +17,16 @@ def main():
             a = agg[name.split('(')[0][:120]][cn]
             a[0] += 1; a[1] += float(cv)
     out = {k: {c: {'launches': n, 'mean': t / n, 'total': t} for c, (n, t) in v.items()} for k, v in agg.items()}
+    # kernel durations, when the pass also ran with --kernel-trace (effective clock = GRBM_GUI_ACTIVE per XCD / duration)
+    tfiles = [] if src.endswith('.csv') else glob.glob(os.path.join(src, '**', '*kernel_trace.csv'), recursive=True)
+    dur = defaultdict(lambda: [0, 0.0])
+    for f in tfiles:
+        for r in csv.DictReader(open(f)):
+            name = (r.get('Kernel_Name') or '').split('(')[0][:120]
+            d = dur[name]; d[0] += 1; d[1] += float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+    for k, (n, t) in dur.items():
+        if k in out:
+            out[k]['duration_ns'] = {'launches': n, 'mean': t / n, 'total': t}
     top = dict(sorted(out.items(), key=lambda kv: -max(x['total'] for x in kv[1].values()))[:40])
     js = json.dumps(top, indent=1)
     if len(sys.argv) > 2:

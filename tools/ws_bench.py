@@ -31,12 +31,19 @@ SHAPES = {
                  ('pw 1632->272', 272, 1024, 1632, True, False, 6, 1, False), ('pw 272->1632', 1632, 1024, 272, True, False, 6, 1, False),
                  ('pw 448->1792', 1792, 1024, 448, True, False, 6, 1, False), ('head 6144x1792x1792', 6144, 1792, 1792, True, True, 1, 1, False),
                  ('3d fpn 192->480', 480, 150528, 192, True, False, 4, 1, False), ('3d outfpn 832 comp', 832, 37632, 480, True, False, 4, 1, False)],
+    'ablate': [('group_linear fwd NT', 24576, 1792, 1792, True, True, 4, 1, False), ('scores QK^T NT', 4096, 256, 1792, True, True, 24, 1, False),
+               ('P.V', 4096, 1792, 256, True, True, 24, 1, False), ('square 8192', 8192, 8192, 8192, True, True, 1, 1, False)],
     'pmc': [('group_linear fwd NT', 24576, 1792, 1792, True, True, 4, 1, False), ('scores QK^T', 4096, 256, 1792, True, False, 24, 1, False),
             ('P.V', 4096, 1792, 256, True, True, 24, 1, False)],
 }
 if which == 'pmc':
     LIBS = {'prod': LIBS['prod']}
-ARMS = [('prod', 1, 0), ('prod', 6, 0), ('prod', 6, 1), ('prod', 7, 0)] + [(n, 6, 0) for n in LIBS if n != 'prod'] + [(n, 7, 0) for n in LIBS if n != 'prod']
+    PMC_ARMS = [('prod', 1, 0), ('prod', 6, 0), ('prod', 6, 5), ('prod', 7, 0), ('prod', 7, 5)]
+ARMS = [('prod', 1, 0), ('prod', 6, 0), ('prod', 7, 0)] + [(n, 6, 0) for n in LIBS if n != 'prod']
+if which == 'pmc':
+    ARMS = PMC_ARMS
+if which == 'ablate':                                     # knob 6 on the wave-specialised kernel: 2 no split math, 3 no global loads, 4 no LDS stores, 5 consumers alone
+    ARMS = [('prod', 6, v) for v in (0, 1, 2, 3, 4, 5)] + [('prod', 7, v) for v in (0, 2, 5)]
 
 
 def make(M, N, K, akc, bkc, nb, sk, gelu):
@@ -65,6 +72,12 @@ for sh in SHAPES[which]:
             times.pop(arm); print('  skip', arm, str(e)[:80])
         L.c.segx_tune(6, 0)
     torch.cuda.synchronize()
+    if which == 'main':                                    # every library computes the same values (the split variants are exact re-expressions)
+        ref = None
+        for n, L in LIBS.items():
+            args[2].fill_(float('nan')); L.gemm(*args, tile=6, **kw); torch.cuda.synchronize()
+            if ref is None: ref = args[2].clone()
+            elif not torch.equal(ref, args[2]): print('  !! library %s differs from prod: max |d| = %.3e' % (n, (ref - args[2]).abs().max().item()))
     for r in range(rounds):
         for arm in list(times):
             L = LIBS[arm[0]]
