@@ -2,7 +2,7 @@
 """bench.py -- train-step throughput of the MI355X-native Segtran hot path (BASELINE.json metric).
 
 `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it under torch.distributed.run (one rank per GPU over
-RCCL).  A step is the full train step: forward -> BCE+Dice -> backward -> gradient all-reduce -> global clip + BertAdam, fp32 results,
+RCCL); started WITHOUT a launcher (`WORLD_SIZE` unset) it spawns the N ranks itself (self_spawn).  A step is the full train step: forward -> BCE+Dice -> backward -> gradient all-reduce -> global clip + BertAdam, fp32 results,
 train mode with the reference's dropout 0.2, synthetic inputs / name-hashed synthetic weights (no network), inputs resident in HBM
 before the timed region.  Rank 0 prints ONE JSON line:
 
@@ -37,9 +37,10 @@ WORKLOADS = {'cfg1': 'REFUGE fundus 2D, segtran eff-b4, translayers 1, 256x256, 
              'cfg5': 'BraTS 3D, segtran i3d, translayers 2, attractors 1024, 128x128x128 x4 modalities, bs 4/GPU'}
 
 
-def cpu_baseline(cfg_name, threads):
-    """oracle/ (CPU restatement of the reference, kind='port') timed on the host cores: ONE full train step
-    (fwd + loss + bwd + global clip + BertAdam) at batch 1 of the same shapes/weights.  Bounded: ~10-30 s."""
+def _cpu_steps(cfg_name, batch, threads, n_timed, budget_s):
+    """oracle/ (CPU restatement of the reference, kind='port'): full train steps (fwd + loss + bwd + global clip + BertAdam) at `batch`
+    samples of cfg_name's shapes / synthetic weights on the host cores: ONE untimed warm-up step (the first iterations of the reference's own
+    CPU path run 2-3x slower while the allocators warm up), then up to n_timed timed steps within budget_s seconds."""
     from oracle import segtran_oracle as O
     from segtran_amd import engine
     from segtran_amd.synth import synth_state_dict
@@ -49,32 +50,59 @@ def cpu_baseline(cfg_name, threads):
     sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
     del net
     sd = {k: (v.requires_grad_(True) if v.is_floating_point() and 'running' not in k else v) for k, v in sd.items()}
-    x, raw = engine.synth_batch(cfg_name, 1, 'cpu')
+    x, raw = engine.synth_batch(cfg_name, batch, 'cpu')
     mask = engine.map_mask(c['task'], raw)
     pw, _ = engine.loss_weights(c['task'], 'cpu')
     dims = [1792 if c['dim'] == 2 else 1024]
     for r in c['compress'][1:]:
         dims.append(dims[-1] // r)
-    t0 = time.time()
-    if c['dim'] == 2:
-        y = O.segtran2d_forward(sd, x, dims, training=True)
-    else:
-        y = O.segtran3d_forward(sd, x, dims, training=True)
-    loss = O.seg_loss(y, mask, pw)[0]
-    loss.backward()
     keys = [k for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and '.key.' not in k]
-    grads = [sd[k].grad for k in keys]
-    with torch.no_grad():
-        O.global_clip_([g for g in grads if g is not None], 0.1)
-        O.bertadam_step([sd[k] for k in keys], grads, [dict() for _ in keys], 2e-4,
-                        [1e-5 if 'backbone' in k else 1e-4 for k in keys], 0.05, 10000)
-    dt = time.time() - t0
-    return {'value': round(1.0 / dt, 4), 'unit': 'images/s' if c['dim'] == 2 else 'volumes/s', 'cores': threads, 'kind': 'port',
-            'sample': '1 full train step (fwd+loss+bwd+clip+BertAdam) of oracle/segtran_oracle.py at batch 1, same %s '
-                      'shapes and weights, dropout-free, %.1f s' % (cfg_name, dt)}
+    states = [dict() for _ in keys]
+    fwd = O.segtran2d_forward if c['dim'] == 2 else O.segtran3d_forward
+
+    def one():
+        t0 = time.time()
+        for k in keys:
+            sd[k].grad = None
+        y = fwd(sd, x, dims, training=True)
+        loss = O.seg_loss(y, mask, pw)[0]
+        loss.backward()
+        grads = [sd[k].grad for k in keys]
+        with torch.no_grad():
+            O.global_clip_([g for g in grads if g is not None], 0.1)
+            O.bertadam_step([sd[k] for k in keys], grads, states, 2e-4, [1e-5 if 'backbone' in k else 1e-4 for k in keys], 0.05, 10000)
+        return time.time() - t0
+    t_start = time.time()
+    warm = one()
+    times = []
+    while len(times) < n_timed and (not times or time.time() - t_start + times[-1] < budget_s):
+        times.append(one())
+    med = statistics.median(times)
+    return {'value': round(batch / med, 4), 'unit': 'images/s' if c['dim'] == 2 else 'volumes/s', 'batch': batch, 'steps_timed': len(times),
+            's_per_step_median': round(med, 3), 's_per_step_all': [round(t, 3) for t in times], 's_warmup_step': round(warm, 3)}
 
 
-def run_cpu_baseline(cfg_name, limit_s=240):
+def cpu_baseline(cfg_name, threads):
+    """SURVEY.md 8(d) / BASELINE.md section 4: the metric configuration at batch 1 (the `value`), plus cfg1 at its full batch (>= 3 warm steps,
+    median) and the other family's batch-1 step (cfg4 when the metric is 2-D).  ~60-90 s of CPU work in a child process with a hard limit."""
+    main = _cpu_steps(cfg_name, 1, threads, 3, 45.0)
+    out = {'value': main['value'], 'unit': main['unit'], 'cores': threads, 'kind': 'port',
+           'sample': 'median of %d warm full train steps (fwd+loss+bwd+clip+BertAdam, one untimed warm-up step before) of oracle/segtran_oracle.py '
+                     'at batch 1 of the %s shapes and synthetic weights, dropout-free: %.2f s/step (warm-up step %.2f s)'
+                     % (main['steps_timed'], cfg_name, main['s_per_step_median'], main['s_warmup_step']),
+           'detail': {cfg_name + '_bs1': main}}
+    try:
+        from segtran_amd import engine
+        out['detail']['cfg1_bs%d' % engine.CONFIGS['cfg1']['bs']] = _cpu_steps('cfg1', engine.CONFIGS['cfg1']['bs'], threads, 3, 30.0)
+        other = 'cfg4' if engine.CONFIGS[cfg_name]['dim'] == 2 else 'cfg2'
+        out['detail'][other + '_bs1'] = _cpu_steps(other, 1, threads, 2, 40.0)
+    except Exception as e:                                       # the secondary samples must never cost the primary one
+        out['detail']['error'] = repr(e)[:160]
+    out['reference_code_8core_cfg1'] = '0.43 images/s (the reference itself on the survey container, BASELINE.md section 3)'
+    return out
+
+
+def run_cpu_baseline(cfg_name, limit_s=420):
     """The CPU leg runs in a child process with a hard time limit so that it can never cost the bench line.
     Threads: physical cores, capped at 64 (PyTorch CPU ops stop scaling -- and oversubscribe -- beyond that)."""
     import subprocess
@@ -196,6 +224,21 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
     other = None
+    with_h2d = None
+    if world == 1 and not graphed and not args.single_order:
+        # SURVEY.md 8(d) starts the step at the H2D copy of a pre-generated batch: the same step fed from a PINNED host batch, copy on the step's
+        # stream inside the timed region (no loader thread hiding it).  Reported beside `value`, which keeps the inputs resident in HBM.
+        xh, rh = x.cpu().pin_memory(), raw.cpu().pin_memory()
+        kk = max(3, min(10, steps // 4))
+        for i in range(kk + 2):
+            if i == 2:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            x.copy_(xh, non_blocking=True); raw.copy_(rh, non_blocking=True)
+            step(x, raw)
+        torch.cuda.synchronize()
+        hd = (time.perf_counter() - t1) / kk
+        with_h2d = {'value': round(B / hd, 3), 'ms_per_step': round(hd * 1e3, 2), 'steps': kk, 'batch_bytes': xh.numel() * xh.element_size() + rh.numel() * rh.element_size(),
+                    'note': 'pinned host batch copied H2D on the step stream inside the timed region (PCIe-inclusive rate; not `value`)'}
     if graphed:
         step.close()
     if world == 1 and other_order and not args.single_order and not graphed:   # the same step in the OTHER operation order, outside the timed region
@@ -236,7 +279,9 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
                       'op_order': ('reference' if args.reference_op_order else 're-associated') + ' (DESIGN.md 5b: exact re-association of '
                                   'consecutive linear maps; every layer, parameter and gradient is computed)',
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
-                          None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)}},
+                          None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)},
+                      'with_h2d_copy': with_h2d,
+                      'ranks': world, 'collective_backend': (torch.distributed.get_backend() + ' (RCCL)' if world > 1 else None)},
            'roofline': roof}
     if rank == 0:
         print('[bench] %s: %.1f ms/step (median %.1f), %.2f %s, engine %.1f TFLOP/s' % (cfg_name, res['ms_per_step'], med, res['value'], unit, achieved),
@@ -263,6 +308,22 @@ def run_graph_replay(args):
         return {'error': 'timeout'}
 
 
+def self_spawn(n):
+    """`python bench.py --gpus N` without a launcher in front (WORLD_SIZE unset): re-run this command line as N ranks, one per GPU, under
+    torch.distributed.run on 127.0.0.1 (what the driver does for N > 1).  Rank 0 of the child job prints the one JSON line; its `n_gpus` and
+    `config.ranks` say how many ranks actually ran.  Returns the job's exit code."""
+    import socket
+    if torch.cuda.is_available() and torch.cuda.device_count() < n and not os.environ.get('SEGX_BENCH_SHARE_GPU'):
+        print('bench.py --gpus %d: only %d GPU(s) visible; refusing to report a %d-GPU number from fewer devices' % (n, torch.cuda.device_count(), n),
+              file=sys.stderr)
+        return 2
+    sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cpu-baseline-only', default=None, help=argparse.SUPPRESS)
@@ -284,12 +345,17 @@ def main():
         print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.threads)))
         return
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_spawn(args.gpus))               # `python bench.py --gpus N` on its own: start the N ranks here
     from segtran_amd import segx, dist as sdist
     rank, local, world = sdist.init_distributed()
-    assert world == max(1, args.gpus) or world == 1, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    assert world == max(1, args.gpus), 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    dev = torch.device('cuda', local)
+    if world > 1 and torch.cuda.device_count() < world and not os.environ.get('SEGX_BENCH_SHARE_GPU'):
+        raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU; SEGX_BENCH_SHARE_GPU=1 lets test ranks share a device)'
+                         % (world, torch.cuda.device_count()))
+    dev = torch.device('cuda', local % torch.cuda.device_count() if os.environ.get('SEGX_BENCH_SHARE_GPU') else local)
     torch.cuda.set_device(dev)
     L = segx.lib()
     L.set_engine(args.engine)

@@ -5,8 +5,11 @@
  * Conventions
  *  - plain device pointers + sizes; fp32 everywhere (the reference computes in fp32).
  *  - the library never allocates / frees / retains device memory: caller passes outputs + workspace.
- *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*), is re-entrant across
- *    streams and has no mutable global state.
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and is re-entrant across streams and threads (the
+ *    main thread and autograd's backward thread call in concurrently).  The library's only process-wide state is CONFIGURATION a caller
+ *    sets through segx_tune / segx_set_rng_base -- atomics that no compute call ever writes (defaults such as the tile engine, tuning
+ *    knobs whose every setting gives identical results, one launch counter) -- plus the per-thread error text; what a call should do
+ *    differently from the defaults travels in its arguments (segx_gemm_desc.engine / .tile / .splitk).
  *  - return 0 = ok, <0 = invalid argument (see segx_last_error), >0 = HIP error code.
  */
 #ifndef SEGX_H
@@ -37,6 +40,8 @@ enum { SEGX_BIAS_NONE = 0, SEGX_BIAS_N = 1 /* bias[n] */, SEGX_BIAS_M = 2 /* bia
  * SEGX_ENGINE_BF16X6 = fp32 operands split in registers into three bf16 planes, six v_mfma_f32_32x32x16_bf16 per block (fp32-equivalent:
  * error vs fp64 1.2e-6 against 1.0e-6), used for float4-legal operands with more than 48 rows on both sides; everything else stays on F32 */
 enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
+/* per-call engine selector of segx_gemm_desc.engine: 0 (a zero-initialised desc) = the process default set by segx_tune knob 4 */
+enum { SEGX_ENGINE_SEL_DEFAULT = 0, SEGX_ENGINE_SEL_F32 = 1, SEGX_ENGINE_SEL_BF16X6 = 2 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
        SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7 /* 6, 7: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h */ };
 typedef struct {
@@ -59,6 +64,7 @@ typedef struct {
     int32_t batch_reduce;             /* 1: C [M][N] = alpha * sum over ALL nb0*nb1 batch members (and split-K slabs) of A_z B_z^T (+ bias): the gradient of an
                                        * operand shared by the batch (conv weights) in ONE deterministic reduction; needs workspace =
                                        * max(1, splitk)*nb0*nb1*M*N floats, EPI_NONE, no gmax; c_b0 / c_b1 are ignored */
+    int32_t engine;                   /* SEGX_ENGINE_SEL_*: the tile engine of THIS call (0 = process default) */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are
@@ -264,8 +270,9 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 7: weight gradients of the packed 3-D convolutions on the bf16x6 engine -- 0 (default): where the loader reads whole rows (OW % 8 == 0, or OW % 4 == 0
  * at unit W stride) and the tile is not the strided 64-row case; 1: every one (also the per-position gather); 2: every whole-row case (also the strided 64-row tile);
  * knob 8 = outputs per strip of the depthwise weight gradient (default 8192; >= 256);
- * knob 6 = bench-only variant of the 128 x 128 bf16x6 kernel (0 = product; 1 = raised wave priority in the MFMA phase; 2..5 = ablations whose results are
- * NOT the GEMM); knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
+ * knob 6 = schedule variant of the bf16x6 kernels with IDENTICAL results (0 = product; 1 = raised wave priority in the MFMA phase / of the consumer
+ * waves; 6 = split-early schedule, 7 = product schedule at two waves per SIMD); the ablation variants 2..5, whose results are NOT the GEMM, exist only
+ * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,

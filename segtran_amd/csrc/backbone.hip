@@ -8,7 +8,6 @@
 #include "common.h"
 
 namespace segx {
-int g_dw_strip_outputs = 8192;        // segx_tune(8, v): outputs per strip of the depthwise weight gradient (see dw_wgrad_strips)
 
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
@@ -801,7 +800,7 @@ Dw4Grid dw4_grid(int OW) {
 // More, smaller strips (1K outputs: 8x the waves on the early 128 x 128 stages) were measured 0.3 ms/step SLOWER on cfg2 (r02_r, same box,
 // segx_tune knob 8): the partial-sum rows and their column sums grow with the strip count, the kernel itself does not speed up.
 int dw_wgrad_strips(int OH, int OW) {
-    using segx::g_dw_strip_outputs;
+    const int g_dw_strip_outputs = segx::kget(segx::knobs().dw_strip_outputs);
     const int64_t n = ((int64_t)OH * OW + g_dw_strip_outputs - 1) / g_dw_strip_outputs;
     return (int)(n < 1 ? 1 : n > 32 ? 32 : n);
 }

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include "../../include/segx.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -108,6 +109,24 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+
+// ---- process-wide configuration (segx_tune) ----------------------------------------------------------------------------------------------
+// The ONLY mutable state of the library besides the thread-local error text and the registered dropout-stream base: default policies a
+// caller sets once (which tile engine eligible GEMMs / convolutions use, tuning knobs whose every setting gives the same results) and one
+// statistics counter.  All of it is std::atomic: entry points are called from the main thread AND autograd's backward thread, on any number
+// of streams.  A call never writes a knob; per-call choices (segx_gemm_desc.engine / .tile / .splitk) override the defaults.
+struct Knobs {
+    std::atomic<int> engine{SEGX_ENGINE_F32};       // knob 4: default tile engine
+    std::atomic<int> x6_variant{0};                 // knob 6: schedule variants of the bf16x6 kernels (0 product; ablations only in SEGX_BENCH builds)
+    std::atomic<int> x6_launches{0};                // knob 5: launches that ran on the bf16x6 engine since the last query
+    std::atomic<int> ws_grid{256};                  // knob 9: workgroups of a persistent (wave-specialised) launch
+    std::atomic<int> conv_x6_wgrad_all{0};          // knob 7
+    std::atomic<int> dw_strip_outputs{8192};        // knob 8
+    std::atomic<int> interp_variant{0};             // knob 1
+    std::atomic<int> conv_small_policy{0};          // knob 2
+};
+inline Knobs& knobs() { static Knobs k; return k; }
+inline int kget(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }
 
 // host-side: device pointer every dropout launch hands to its kernel (segx_set_rng_base); one instance for the whole library
 inline const uint64_t*& rng_base() { static const uint64_t* p = nullptr; return p; }

@@ -12,9 +12,6 @@
 
 namespace segx {
 
-extern int g_engine;
-extern int g_x6_launches;
-int g_conv_x6_wgrad_all = 0;          // segx_tune(7, 1): weight gradients of EVERY packed convolution on the bf16x6 engine (tests of the general gather path)
 
 struct ConvGeom {
     int Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw;
@@ -891,8 +888,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1k3_kernel(const float* __
 }
 
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-int g_conv_small_policy = 0;          // segx_tune(2, v): 0 = 64-row tile when Cout % 128 in [1, 64]; 1 = only when Cout <= 64 (measured 1 % slower)
-static bool conv_small(int Cout) { return g_conv_small_policy == 1 ? Cout <= 64 : (Cout % 128 >= 1 && Cout % 128 <= 64); }
+static bool conv_small(int Cout) { return kget(knobs().conv_small_policy) == 1 ? Cout <= 64 : (Cout % 128 >= 1 && Cout % 128 <= 64); }
 
 }  // namespace segx
 
@@ -935,8 +931,8 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     const int64_t P = (int64_t)q.OD * q.OH * q.OW, CK = (int64_t)q.Cin * q.KD * q.KH * q.KW;
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
-    const bool packed = q.Cin % 8 == 0, x6 = g_engine == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (((q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && (!conv_small(Cout) || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1));
+    const bool packed = q.Cin % 8 == 0, x6 = kget(knobs().engine) == SEGX_ENGINE_BF16X6 && packed;
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (((q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && (!conv_small(Cout) || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -961,8 +957,8 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     dim3 grid(g.tiles_m * g.tiles_n, B, splitk);
 #define SEGX_CONV_FWD(V, CFG) do { if (packed) hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, true>), grid, dim3(256), 0, stream, g, q); \
                                    else hipLaunchKernelGGL((conv3d_fwd_kernel<V, CFG, false>), grid, dim3(256), 0, stream, g, q); } while (0)
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6) {          // bf16x6 engine (gemm_x6.h): same tiles, same grid, same split-K slabs
-        ++g_x6_launches;
+    if (packed && vec && kget(knobs().engine) == SEGX_ENGINE_BF16X6) {          // bf16x6 engine (gemm_x6.h): same tiles, same grid, same split-K slabs
+        knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
         if (small) hipLaunchKernelGGL((conv3d_fwd_x6_kernel<CfgCout64, 4>), grid, dim3(256), 0, stream, g, q);
         else hipLaunchKernelGGL((conv3d_fwd_x6_kernel<Cfg128, 3>), grid, dim3(256), 0, stream, g, q);
     } else if (small && vec) SEGX_CONV_FWD(true, CfgCout64);
@@ -1026,8 +1022,8 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // are two 16-byte loads (r02_l: 128-row tile 117 -> 153 TFLOP/s, 64-row tile 65 -> 119 against 92 on the fp32 engine); the strided case
     // (the stride-2 composed stem, 64 filters) keeps eight gathers per row and, on the 64-row tile, stays on the fp32 engine (66 against 83).
     const bool fastw = (q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && g.k_chunk % 8 == 0;          // geometry: the row-of-eight (or two-quads) loader applies
-    if (packed && vec && g_engine == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || g_conv_x6_wgrad_all == 2)) || g_conv_x6_wgrad_all == 1)) {
-        ++g_x6_launches;
+    if (packed && vec && kget(knobs().engine) == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1)) {
+        knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
         if (fastw) {
             if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
             else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, true>), grid, dim3(256), 0, stream, g, q);

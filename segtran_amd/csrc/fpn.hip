@@ -351,8 +351,6 @@ extern "C" int segx_dropout(const float* x, float* y, int64_t n, float p, uint64
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)i64min(1 << 20, (n / 4 + 256) / 256)), dim3(256), 0, stream, x, y, n, p, 1.0f / (1.0f - p), seed, offset, segx::rng_base());
     return check_launch("segx_dropout");
 }
-static int g_interp_variant = 0;      // segx_tune(1, v): 0 = auto, 1 = element-per-thread kernel, 2 = float4 row kernel (bench / bisect only)
-namespace segx { extern int g_conv_small_policy; extern int g_engine; extern int g_x6_launches; extern int g_x6_variant; extern int g_conv_x6_wgrad_all; extern int g_dw_strip_outputs; extern int g_ws_grid; }
 __global__ void rng_advance_kernel(uint64_t* base, uint64_t span) { if (threadIdx.x == 0 && blockIdx.x == 0) *base += span; }
 /* Device-side base of every dropout Philox stream: each kernel adds *base to the `offset` it was launched with.  A train step captured into a
  * hipGraph replays the SAME offsets; advancing *base by the step's span (segx_rng_advance, itself a captured launch) gives every replay fresh
@@ -364,14 +362,19 @@ extern "C" int segx_rng_advance(uint64_t* base, uint64_t span, void* stream_) {
     return check_launch("segx_rng_advance");
 }
 extern "C" int segx_tune(int knob, int value) {
-    if (knob == 1) { g_interp_variant = value; return 0; }
-    if (knob == 2) { segx::g_conv_small_policy = value; return 0; }
-    if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; const int prev = segx::g_engine; segx::g_engine = value; return prev; }
-    if (knob == 8) { if (value < 256) return -1; segx::g_dw_strip_outputs = value; return 0; }
-    if (knob == 7) { if (value < 0 || value > 2) return -1; segx::g_conv_x6_wgrad_all = value; return 0; }
-    if (knob == 6) { if (value < 0 || value > 7) return -1; segx::g_x6_variant = value; return 0; }
-    if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; segx::g_ws_grid = value; return 0; }
-    if (knob == 5) { const int n = segx::g_x6_launches; segx::g_x6_launches = 0; return n; }
+    segx::Knobs& k = segx::knobs();
+    if (knob == 1) { k.interp_variant = value; return 0; }
+    if (knob == 2) { k.conv_small_policy = value; return 0; }
+    if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; return k.engine.exchange(value); }
+    if (knob == 8) { if (value < 256) return -1; k.dw_strip_outputs = value; return 0; }
+    if (knob == 7) { if (value < 0 || value > 2) return -1; k.conv_x6_wgrad_all = value; return 0; }
+#ifdef SEGX_BENCH
+    if (knob == 6) { if (value < 0 || value > 7) return -1; k.x6_variant = value; return 0; }      // 2..5: ablations whose results are NOT the GEMM
+#else
+    if (knob == 6) { if (value != 0 && value != 1 && value != 6 && value != 7) return -1; k.x6_variant = value; return 0; }
+#endif
+    if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
+    if (knob == 5) { return k.x6_launches.exchange(0); }
     return -1;
 }
 // RandomResizedCrop (datasets3d.py:611-665) as ONE gather pass: the volume is (virtually) resampled to (D, H, W) with the trilinear
@@ -395,7 +398,7 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");
     const int64_t total = planes * D * H * W;
     const bool al = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
-    if (g_interp_variant != 1 && W % 4 == 0 && W <= 1024 && al && planes <= 65535 && (int64_t)d * h * w < 2147483647LL && (int64_t)D * H < 2147483647LL) {
+    if (segx::kget(segx::knobs().interp_variant) != 1 && W % 4 == 0 && W <= 1024 && al && planes <= 65535 && (int64_t)d * h * w < 2147483647LL && (int64_t)D * H < 2147483647LL) {
         const int w4 = W / 4, rpb = 256 / w4;
         hipLaunchKernelGGL(interp_fwd_rows_kernel, dim3((unsigned)((D * H + rpb - 1) / rpb), (unsigned)planes), dim3(256), 0, stream, in, base, out,
                            make_dims(d, h, w, D, H, W), w4, rpb, make_fastdiv(H), make_fastdiv(w4));

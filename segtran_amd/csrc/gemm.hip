@@ -106,22 +106,40 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Whole-GEMM quantisation matters (784 workgroups on 768 slots take two rounds, not 1.02), and so do padded edge tiles, which
 // the workgroup count already contains.  Step times are the measured ~112 TFLOP/s of the engine expressed per k-tile.
 // splitk_fixed > 0: the caller has already chosen the split factor; 0: choose it too.  vec = false: only the default tile is built.
-int g_engine = SEGX_ENGINE_F32;            // segx_tune(4, v): which tile engine the eligible GEMMs / convolutions run on
-int g_x6_variant = 0;                      // segx_tune(6, v): bench-only variants of the 128 x 128 k-contiguous kernel (gemm_x6.h)
-int g_ws_grid = 256;                       // segx_tune(9, v): workgroups of a persistent (wave-specialised) launch: one per CU; tests shrink it to force long item streams
-int g_x6_launches = 0;                     // segx_tune(5, 0): launches that ran on the bf16x6 engine since the last query (tests / sessions)
 // bf16x6 engine: float4-legal operands, neither side skinny (those GEMMs are HBM-bound and stream through the 32-row fp32 tiles)
-static bool x6_eligible(int M, int N, bool vec) { return g_engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
-static void plan6(int M, int N, int K, int nbatch, bool gelu, bool may_split, int splitk_fixed, int* tile, int* splitk) {
+// the engine of ONE call: segx_gemm_desc.engine (SEGX_ENGINE_SEL_F32 / _BF16X6) or, at SEGX_ENGINE_SEL_DEFAULT, the process default (segx_tune knob 4)
+static int call_engine(const segx_gemm_desc* d) {
+    return d->engine == SEGX_ENGINE_SEL_F32 ? SEGX_ENGINE_F32 : d->engine == SEGX_ENGINE_SEL_BF16X6 ? SEGX_ENGINE_BF16X6 : kget(knobs().engine);
+}
+static bool x6_eligible(int engine, int M, int N, bool vec) { return engine == SEGX_ENGINE_BF16X6 && vec && M > 48 && N > 48; }
+// ws_ok: the wave-specialised persistent kernels may run this GEMM (whole 32-k stages, 32-bit operand offsets; no fused GELU: its epilogue
+// runs on four of the eight waves there and measured 63 against 91 TFLOP/s)
+// nrc = number of row-contiguous operands (0..2): their loaders cost the 4-wave kernels 9 % / 34 % per k-tile (r03_f: 201 / 185 / 150 TFLOP/s for
+// NT / NN / TN at 24576 x 1792 x 1792), the wave-specialised ones 1 % / 5 % (220 / 218 / 198 incl. the slab reduction)
+static void plan6(int M, int N, int K, int nbatch, bool gelu, bool may_split, int splitk_fixed, bool ws_ok, int nrc, int* tile, int* splitk) {
     double best_t = -1.0;
+    const float f4 = nrc == 0 ? 1.0f : nrc == 1 ? 1.09f : 1.34f, fws = nrc == 0 ? 1.0f : nrc == 1 ? 1.01f : 1.05f;
     for (const TileInfo6& c6 : kTiles6) {
         if (gelu && c6.id != SEGX_TILE_128x128) continue;                  // the fused GELU epilogue is built for the default tile
-        const TileInfo c{c6.id, c6.bm, c6.bn, c6.wg_per_cu, c6.ktile_us, c6.fixed_us};
+        const TileInfo c{c6.id, c6.bm, c6.bn, c6.wg_per_cu, c6.ktile_us * f4, c6.fixed_us};
         double t; int sk;
         if (splitk_fixed > 0 || !may_split) { sk = splitk_fixed > 0 ? splitk_fixed : 1; t = model_us(c, M, N, K, nbatch, sk); }
         else sk = best_splitk(c, M, N, K, nbatch, &t);
         if (best_t < 0.0 || t < best_t * 0.97) { best_t = t; *tile = c.id; *splitk = sk; }
     }
+    if (!ws_ok || gelu) return;
+    for (const TileInfo6& w6 : kTilesWs) {
+        const TileInfo6 c6{w6.id, w6.bm, w6.bn, w6.wg_per_cu, w6.ktile_us * fws, w6.fixed_us};
+        double t; int sk;
+        if (splitk_fixed > 0 || !may_split) { sk = splitk_fixed > 0 ? splitk_fixed : 1; t = model_us_ws(c6, M, N, K, nbatch, sk, kget(knobs().ws_grid)); }
+        else sk = best_splitk_ws(c6, M, N, K, nbatch, kget(knobs().ws_grid), &t);
+        if (t < best_t * 0.97) { best_t = t; *tile = c6.id; *splitk = sk; }
+    }
+}
+static bool gemm_ws_ok(const segx_gemm_desc* d) {
+    const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
+    const int64_t a_span = akc ? (int64_t)d->M * d->a_m : (int64_t)d->K * d->a_k, b_span = bkc ? (int64_t)d->N * d->b_n : (int64_t)d->K * d->b_k;
+    return d->K % BKT == 0 && a_span < (1LL << 29) && b_span < (1LL << 29);
 }
 static void plan(int M, int N, int K, int nbatch, bool vec, bool may_split, int splitk_fixed, int* tile, int* splitk) {
     const TileInfo* cand[3]; int nc = 0;
@@ -154,7 +172,7 @@ extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_de
     const bool plain = d->epilogue == SEGX_EPI_NONE;
     int t = SEGX_TILE_128x128, sk = 1;
     const bool vec = gemm_vec_ok(A, B, d);
-    if (x6_eligible(d->M, d->N, vec) && (plain || d->a_k == 1)) plan6(d->M, d->N, d->K, d->nb0 * d->nb1, !plain, plain && !d->gmax, 0, &t, &sk);
+    if (x6_eligible(call_engine(d), d->M, d->N, vec) && (plain || d->a_k == 1)) plan6(d->M, d->N, d->K, d->nb0 * d->nb1, !plain, plain && !d->gmax, 0, gemm_ws_ok(d), (d->a_k != 1) + (d->b_k != 1), &t, &sk);
     else plan(d->M, d->N, d->K, d->nb0 * d->nb1, vec && plain, plain && !d->gmax, 0, &t, &sk);
     *tile = t; *splitk = sk;
     return 0;
@@ -198,19 +216,21 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     if (splitk > 1 || breduce) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS128x128, "segx_gemm_f32: bad tile %d", d->tile);
     const bool ws_tile = d->tile == SEGX_TILE_256x128 || d->tile == SEGX_TILE_WS128x128;
-    SEGX_REQUIRE(!ws_tile || g_engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
+    SEGX_REQUIRE(d->engine >= SEGX_ENGINE_SEL_DEFAULT && d->engine <= SEGX_ENGINE_SEL_BF16X6, "segx_gemm_f32: bad engine selector %d", d->engine);
+    const int engine = call_engine(d);
+    SEGX_REQUIRE(!ws_tile || engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
+    const int x6_variant = kget(knobs().x6_variant);
     int tile = d->tile;
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
-    bool x6 = x6_eligible(d->M, d->N, vec) && (!gelu || akc) &&
+    // the wave-specialised kernels address an operand through 32-bit byte offsets from a per-item base and take whole 32-k stages only
+    const bool ws_ok = gemm_ws_ok(d);
+    bool x6 = x6_eligible(engine, d->M, d->N, vec) && (!gelu || akc) &&
               (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64 || ws_tile);
     if (tile == SEGX_TILE_AUTO) {
         int sk_unused = 1;
-        if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, &tile, &sk_unused);
+        if (x6) plan6(d->M, d->N, d->K, nbatch, gelu, false, splitk, ws_ok, (!akc) + (!bkc), &tile, &sk_unused);
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
-    // the wave-specialised kernels address an operand through 32-bit byte offsets from a per-item base and take whole 32-k stages only
-    const int64_t a_span = akc ? (int64_t)d->M * d->a_m : (int64_t)d->K * d->a_k, b_span = bkc ? (int64_t)d->N * d->b_n : (int64_t)d->K * d->b_k;
-    const bool ws_ok = d->K % BKT == 0 && a_span < (1LL << 29) && b_span < (1LL << 29);
     if (ws_tile && !ws_ok) tile = SEGX_TILE_128x128;
     const bool ws = x6 && ws_ok && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x128);
     if (!vec || (gelu && !ws) || (ws_tile && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile (and the wave-specialised ones) are built
@@ -219,7 +239,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     using Cfg64 = TileCfg<2, 2, 1, 1>; using Cfg128x32 = TileCfg<4, 1, 1, 1>; using Cfg32x128 = TileCfg<1, 4, 1, 1>;
     using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (x6) {
-        ++g_x6_launches;
+        knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
 #define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
@@ -233,20 +253,29 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else SEGX_LAUNCH6(CFG, false, false, SEGX_EPI_NONE, W);               \
     } while (0)
         using Cfg256x128 = TileCfg<2, 2, 4, 2>;
-        // persistent launch: one workgroup per CU, a multiple of eight (one run of items per XCD and round)
-#define SEGX_LAUNCHWS(CFG, AK, BK, E)                                                                      \
-    do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
-        const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
-        SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
-        const int G = (int)i64min(g_ws_grid, (items + 7) / 8 * 8);                                              \
-        switch (E == SEGX_EPI_NONE && AK && BK ? g_x6_variant : (g_x6_variant == 1 ? 1 : 0)) {              \
+        // persistent launch: one workgroup per CU, a multiple of eight (one run of items per XCD and round).  Variant 1 = consumers at raised wave
+        // priority (same results); the ablation variants 2..5 (results are NOT the GEMM) exist in -DSEGX_BENCH builds only (tools/build_variant.py)
+#ifdef SEGX_BENCH
+#define SEGX_WS_VARIANTS(CFG, AK, BK, E)                                                                   \
+        switch (E == SEGX_EPI_NONE && AK && BK ? x6_variant : (x6_variant == 1 ? 1 : 0)) {                 \
         case 1: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 1>), dim3(G), dim3(512), 0, stream, g); break; \
         case 2: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 2 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
         case 3: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 3 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
         case 4: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 4 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
         case 5: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, (E == SEGX_EPI_NONE && AK && BK) ? 5 : 0>), dim3(G), dim3(512), 0, stream, g); break; \
-        default: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g); } \
+        default: hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g); }
+#else
+#define SEGX_WS_VARIANTS(CFG, AK, BK, E)                                                                   \
+        if (x6_variant == 1) hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 1>), dim3(G), dim3(512), 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6ws_kernel<CFG, AK, BK, E, 0>), dim3(G), dim3(512), 0, stream, g);
+#endif
+#define SEGX_LAUNCHWS(CFG, AK, BK, E)                                                                      \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
+        SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
+        const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);                                              \
+        SEGX_WS_VARIANTS(CFG, AK, BK, E)                                                                    \
     } while (0)
 #define SEGX_LAUNCHWS_LAYOUT(CFG)                                                          \
     do {                                                                                   \
@@ -264,10 +293,12 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_LAYOUT(Cfg256x128);
         else if (tile == SEGX_TILE_WS128x128) SEGX_LAUNCHWS_LAYOUT(Cfg128);
         else if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
-        else if (g_x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
-            switch (g_x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 2: SEGX_LAUNCH6V(2, 3); break; case 3: SEGX_LAUNCH6V(3, 3); break;
-                                    case 4: SEGX_LAUNCH6V(4, 3); break; case 5: SEGX_LAUNCH6V(5, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;
-                                    default: SEGX_LAUNCH6V(0, 2); break; }      // 7: the product schedule at two waves per SIMD (what the split-early schedule is compared with)
+        else if (x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
+            switch (x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;
+#ifdef SEGX_BENCH
+                                  case 2: SEGX_LAUNCH6V(2, 3); break; case 3: SEGX_LAUNCH6V(3, 3); break; case 4: SEGX_LAUNCH6V(4, 3); break; case 5: SEGX_LAUNCH6V(5, 3); break;
+#endif
+                                  default: SEGX_LAUNCH6V(0, 2); break; }      // 7: the product schedule at two waves per SIMD (what the split-early schedule is compared with)
         }
         else if (tile == SEGX_TILE_64x64) SEGX_LAUNCH6_LAYOUT(Cfg64, 5);
         else if (tile == SEGX_TILE_64x128) SEGX_LAUNCH6_LAYOUT(Cfg64x128, 4);
@@ -276,6 +307,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
 #undef SEGX_LAUNCH6V
 #undef SEGX_LAUNCH6_LAYOUT
 #undef SEGX_LAUNCHWS
+#undef SEGX_WS_VARIANTS
 #undef SEGX_LAUNCHWS_LAYOUT
     } else
 #define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \

@@ -395,10 +395,11 @@ __device__ __forceinline__ void gemm_mainloop_x6(f32x16 (&acc)[Cfg::MI][Cfg::NJ]
 
 // host-side cost model of this engine (same form as kTiles / model_us of gemm_core.h; constants from the r02 device sweeps)
 struct TileInfo6 { int id, bm, bn, wg_per_cu; float ktile_us, fixed_us; };
-// r02_a sweep (24576 x 1792 x 1792 x 4: 3.54 / 4.03 / 4.54 ms on 14 / 21 / 28 rounds of 56 k-tiles): 4.5 / 3.4 / 2.9 us per k-tile and round
-static const TileInfo6 kTiles6[] = {{SEGX_TILE_128x128, 128, 128, 3, 4.5f, 4.0f},
-                                    {SEGX_TILE_64x128, 64, 128, 4, 3.4f, 2.5f},
-                                    {SEGX_TILE_64x64, 64, 64, 6, 2.9f, 1.5f}};
+// r03_f sweep with the scalar-subtraction split (24576 x 1792 x 1792 x 4: 3.14 ms on 14 rounds of 56 k-tiles; 8192^3: 5.55 ms on 5.6 rounds of 256):
+// 3.9 us per k-tile and round + 8 us per workgroup for 128 x 128; the smaller tiles scaled from the r02_a sweep (3.4 / 2.9 at 4.5)
+static const TileInfo6 kTiles6[] = {{SEGX_TILE_128x128, 128, 128, 3, 3.9f, 8.0f},
+                                    {SEGX_TILE_64x128, 64, 128, 4, 3.0f, 3.0f},
+                                    {SEGX_TILE_64x64, 64, 64, 6, 2.6f, 2.0f}};
 inline double model_us6(const TileInfo6& ti, int M, int N, int K, int nbatch, int sk) {
     const TileInfo t{ti.id, ti.bm, ti.bn, ti.wg_per_cu, ti.ktile_us, ti.fixed_us};
     return model_us(t, M, N, K, nbatch, sk);

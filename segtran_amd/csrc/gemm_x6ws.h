@@ -287,8 +287,27 @@ struct DenseMk6 {
     }
 };
 
-// host-side cost model (same form as kTiles6; ONE workgroup per CU): constants from the r03 device sweep
-static const TileInfo6 kTilesWs[] = {{SEGX_TILE_256x128, 256, 128, 1, 1.45f, 3.0f},
-                                     {SEGX_TILE_WS128x128, 128, 128, 1, 0.80f, 2.0f}};
+// host-side cost model: a persistent launch of one workgroup per CU walks ceil(items / 256) rounds of work items, each costing
+// k-tiles x stage time + a per-tile epilogue (consumers only: the matrix pipe idles while a finished tile is written).  Constants from the
+// r03_f device sweep: 256 x 128: 24576 x 1792 x 1792 x 4 = 21 rounds x 56 stages in 2.87 ms, 8192^3 = 8 x 256 in 4.78 ms, K = 256 tiles 29 us;
+// 128 x 128: 42 x 56 in 3.33 ms, 16 x 256 in 5.77 ms.
+static const TileInfo6 kTilesWs[] = {{SEGX_TILE_256x128, 256, 128, 1, 2.3f, 12.0f},
+                                     {SEGX_TILE_WS128x128, 128, 128, 1, 1.4f, 4.0f}};
+inline double model_us_ws(const TileInfo6& ti, int M, int N, int K, int nbatch, int sk, int grid) {
+    const int64_t items = (int64_t)ceil_div(M, ti.bm) * ceil_div(N, ti.bn) * nbatch * sk;
+    const int kt = ceil_div(ceil_div(K, sk), BKT);
+    const int64_t rounds = (items + grid - 1) / grid;
+    return (double)rounds * (kt * ti.ktile_us + ti.fixed_us) + 3.0 + (sk == 1 ? 0.0 : (double)sk * M * N * nbatch * 8.0 / 3.0e6);
+}
+inline int best_splitk_ws(const TileInfo6& ti, int M, int N, int K, int nbatch, int grid, double* t_out) {
+    int best = 1; double best_t = model_us_ws(ti, M, N, K, nbatch, 1, grid);
+    if (K >= 1024)
+        for (int sk = 2; sk <= 128 && K / sk >= 256; ++sk) {
+            const double t = model_us_ws(ti, M, N, K, nbatch, sk, grid);
+            if (t < best_t * 0.97) { best = sk; best_t = t; }
+        }
+    *t_out = best_t;
+    return best;
+}
 
 }  // namespace segx

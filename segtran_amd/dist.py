@@ -164,17 +164,33 @@ def reduce_scalars(t, group=None):
     return t
 
 
+_HOST_GROUPS = {}
+
+
+def _host_group(group=None):
+    """A gloo twin of `group` for tiny host-side agreements (created collectively on first use): its collectives never touch the GPU streams."""
+    if dist.get_backend(group) == 'gloo':
+        return group
+    key = id(group)
+    if key not in _HOST_GROUPS:
+        ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
+        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo')
+    return _HOST_GROUPS[key]
+
+
 def check_equal_batch(n, group=None):
     """Every rank must hold the same per-GPU batch (train2d.py:791 `bs // world_size`): the gradient AVG all-reduce, the synchronised
-    BatchNorm merge and its backward all weight the ranks equally.  One tiny all-gather, called by TrainStep only when the local batch
-    size changes (first step, a ragged last batch of a user-supplied iterator) -- raises instead of silently mis-weighting."""
+    BatchNorm merge and its backward all weight the ranks equally.  Called by TrainStep on EVERY step and on EVERY rank -- collective-safe: a
+    check entered only by the ranks whose batch changed (a ragged last batch) would be matched with the other ranks' next collective.  One
+    2-float MAX all-reduce of (n, -n) on a host-side (gloo) group: no device synchronisation, ~0.1 ms of host time per step."""
     if not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return
-    sizes = [None] * dist.get_world_size(group)
-    dist.all_gather_object(sizes, int(n), group=group)
-    if len(set(sizes)) != 1:
-        raise RuntimeError('data-parallel step with unequal per-rank batch sizes %s: gradients and synchronised BatchNorm statistics would be '
-                           'mis-weighted (drop or pad the ragged batch, as DistributedSampler does)' % sizes)
+    t = torch.tensor([float(n), -float(n)], dtype=torch.float32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_host_group(group))
+    hi, lo = t.tolist()
+    if hi != -lo:
+        raise RuntimeError('data-parallel step with unequal per-rank batch sizes (between %d and %d, this rank %d): gradients and synchronised '
+                           'BatchNorm statistics would be mis-weighted (drop or pad the ragged batch, as DistributedSampler does)' % (-lo, hi, n))
 
 
 def enable_sync_batchnorm(group=None, force=False):

@@ -114,7 +114,7 @@ class TrainStep:
         (train3d.py:713-715 RandomResizedCrop under --randscale)."""
         self.net, self.opt, self.task, self.reducer = net, optimizer, task, reducer
         self.dice_w, self.exclusive, self.augment = float(dice_w), bool(exclusive), augment
-        if reducer is None and hasattr(optimizer, 'release_flat_grads') and optimizer.step_count == 0:
+        if reducer is None and hasattr(optimizer, 'release_flat_grads') and getattr(optimizer, '_tabs', None) is None:
             optimizer.release_flat_grads()          # single process: no flat bucket needed, no per-parameter accumulate kernels
         dev = next(net.parameters()).device
         self.pos_weight, self.class_w = loss_weights(task, dev)
@@ -122,10 +122,11 @@ class TrainStep:
         self._bs = None
 
     def __call__(self, x, raw_mask):
-        if self.reducer is not None and x.shape[0] != self._bs:
+        if self.reducer is not None:
+            # EVERY step, on every rank: a ragged last batch shows up on SOME ranks only, and a check entered by those alone would pair its
+            # collective with the others' gradient / BatchNorm collectives (hang or garbage instead of the intended error)
             from .dist import check_equal_batch
             check_equal_batch(x.shape[0], self.reducer.group)
-            self._bs = x.shape[0]
         mask = map_mask(self.task, raw_mask, self.exclusive)
         if self.augment is not None:
             x, mask = self.augment(x, mask)

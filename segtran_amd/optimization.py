@@ -201,7 +201,10 @@ class BertAdam(Optimizer):
         """Same wire format as the reference BertAdam (torch.optim state_dict with 'step' / 'next_m' / 'next_v' per parameter), built from
         the flat moment buffers; parameters that never received a gradient carry no state, as in the reference (N3)."""
         ps = self._all_params()
-        active = self._active if self._tabs is not None else [True] * len(ps)
+        if self._tabs is not None:
+            active = self._active
+        else:                                            # loaded but not stepped yet: a parameter is trained iff the loaded moments are non-zero (N3)
+            active = [bool(self.flat_v[off:off + n].any()) if self.step_count > 0 else True for (off, n) in self.slices]
         self.state.clear()
         if self.step_count > 0:
             for (p, _), (off, n), a in zip(ps, self.slices, active):
@@ -255,6 +258,7 @@ class BertAdam(Optimizer):
         ps = self._all_params()
         self._lr_host = torch.tensor([g['lr'] for _, g in ps], dtype=torch.float32, device='cpu')
         self._lr_pinned = [torch.empty_like(self._lr_host).pin_memory() for _ in range(4)] if self.flat_m.is_cuda else None
+        self._lr_events = [None] * 4                    # per pinned slot: the event recorded after its H2D copy (the host may run replays ahead)
         self._lr_slot = 0
         self._graph_ptrs = torch.empty(len(ps), dtype=torch.int64, device='cpu')
         if self.flat_m.is_cuda:
@@ -263,15 +267,33 @@ class BertAdam(Optimizer):
 
     def prepare_replay(self, advance=True):
         g = self.param_groups[0]
+        self._refresh_graph_lr_wd()
         sched = SCHEDULES[g['schedule']](self.step_count / g['t_total'], g['warmup']) if g['t_total'] != -1 else 1.0
         if self._lr_pinned is None:
             self._tabs['lr'].copy_(self._lr_host * sched)
         else:
-            buf = self._lr_pinned[self._lr_slot]; self._lr_slot = (self._lr_slot + 1) % len(self._lr_pinned)
+            # a pinned slot is rewritten only after the copy that last read it has executed: replays are enqueued far faster than the device
+            # runs them (bench.py --graph loops without synchronising), and an unguarded ring of four would hand later steps' rates to earlier ones
+            i = self._lr_slot; self._lr_slot = (i + 1) % len(self._lr_pinned)
+            if self._lr_events[i] is not None:
+                self._lr_events[i].synchronize()
+            buf = self._lr_pinned[i]
             torch.mul(self._lr_host, sched, out=buf)
             self._tabs['lr'].copy_(buf, non_blocking=True)
+            if self._lr_events[i] is None:
+                self._lr_events[i] = torch.cuda.Event()
+            self._lr_events[i].record()
         if advance:
             self.step_count += 1
+
+    def _refresh_graph_lr_wd(self):
+        """Graph mode: param_group edits (lr / weight_decay, load_state_dict) reach the device tables here -- step() no longer runs _sync_lr_wd."""
+        ps = self._all_params()
+        key = tuple((g['lr'], g['weight_decay']) for _, g in ps)
+        if key != getattr(self, '_graph_lrwd_key', None):
+            self._lr_host = torch.tensor([g['lr'] for _, g in ps], dtype=torch.float32, device='cpu')
+            self._tabs['wd'].copy_(torch.tensor([g['weight_decay'] for _, g in ps], dtype=torch.float32, device='cpu').to(self._tabs['wd'].device))
+            self._graph_lrwd_key = key
 
     @torch.no_grad()
     def step(self, closure=None, global_grad_clip=None):

@@ -27,7 +27,7 @@ class GemmDesc(ctypes.Structure):
                 ('alpha', c_f), ('epilogue', c_i), ('bias_mode', c_i), ('bias_b1', c_l),
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
-                ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i)]
+                ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i), ('engine', c_i)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
@@ -105,11 +105,12 @@ class SegxLib:
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
              bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
-             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False):
+             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
         a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
         splitk = 0: take tile and split factor from segx_gemm_plan and allocate the slab workspace here.
-        batch_reduce: C is ONE [M, N] matrix = the sum over all batch members (see segx_gemm_desc.batch_reduce)."""
+        batch_reduce: C is ONE [M, N] matrix = the sum over all batch members (see segx_gemm_desc.batch_reduce).
+        engine: None = the process default (set_engine), 'f32' / 'x6' = the tile engine of THIS call (segx_gemm_desc.engine)."""
         self._chk_t(A, B, C, bias, aux, gmax, workspace)
         d = GemmDesc()
         d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
@@ -125,6 +126,7 @@ class SegxLib:
             tile, splitk = t.value, sk.value
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if (splitk > 1 or batch_reduce) else None
         d.batch_reduce = 1 if batch_reduce else 0
+        d.engine = 0 if engine is None else 1 + self.ENGINES[engine]
         d.splitk, d.workspace = splitk, _ptr(workspace)
         d.tile = self.force_tile if self.force_tile is not None else tile
         if self.gemm_prof is not None and C.is_cuda:

@@ -219,20 +219,34 @@ def run(args, cfg, batches=None):
     # network): without them the default fails loudly instead of training something else.  --synthweights (this mirror only) selects
     # the name-hashed synthetic weights that bench.py and the parity fixtures use.
     synth = bool(getattr(args, 'synth_weights', False)) and not args.checkpoint_path
-    pretrained = bool(args.use_pretrained) and not synth and not args.checkpoint_path
+    pretrained = bool(args.use_pretrained) and not synth
+    build = lambda pre: engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=synth,      # noqa: E731
+                                           use_pretrained=pre, **arch_overrides(args))
     try:
-        net = engine.build_model(cfg, dev, dropout_prob=args.dropout_prob, attractors=args.num_attractors, synth=synth,
-                                 use_pretrained=pretrained, **arch_overrides(args))
+        net = build(pretrained)
     except RuntimeError as e:
         if 'pretrained' not in str(e):
             raise
-        raise SystemExit('%s\n(use --nopretrain for a random initialisation, --synthweights for the synthetic benchmark weights, or --cp)' % e)
+        if not args.checkpoint_path:
+            raise SystemExit('%s\n(use --nopretrain for a random initialisation, --synthweights for the synthetic benchmark weights, or --cp)' % e)
+        # The reference builds the pretrained network first and overlays the checkpoint (train2d.py:1028-1077), so tensors a partial checkpoint
+        # misses stay pretrained.  Without the published files (no network here) a --cp run starts from the model's own initialisation instead:
+        # say so -- load_model reports how many tensors the checkpoint covered.
+        logging.warning('%s -- building without the pretrained backbone; tensors missing from --cp keep their random initialisation', e)
+        net = build(False)
     if synth:
         logging.warning('--synthweights: training starts from SYNTHETIC name-hashed weights (segtran_amd/synth.py), not from a pretrained backbone')
-    iter_num = load_model(net, args, args.checkpoint_path) if args.checkpoint_path else 0
+    # The optimizer exists BEFORE the checkpoint is read, as in the reference (train2d.py:1066-1077, train3d.py:652-660): a checkpoint that carries
+    # 'optim_state' restores the moments and the schedule position.  (The reference's own save_model comments 'optim_state' out -- train2d.py:644,
+    # train3d.py:412 -- so its checkpoints restart the moments; a 3-D resume then continues the iteration count, a 2-D one restarts it.)
+    opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
+                                decay=args.decay, grad_clip=args.grad_clip)
+    load_optim = dim_of(cfg) == 3 or (getattr(args, 'polyformer_mode', None) is None and getattr(args, 'opt_filters', None) is None
+                                      and getattr(args, 'adversarial_mode', None) is None)           # train2d.py:1076; train3d.py:397 always
+    iter_num = load_model(net, args, args.checkpoint_path, optimizer=opt, load_optim_state=load_optim) if args.checkpoint_path else 0
     if dim_of(cfg) == 2:
         iter_num = 0                                                      # train2d.py:1074-1081 (`continue_iter = False`): 2-D always restarts the count
-    # 3-D resumes from the checkpoint's iteration (train3d.py:658-661): the LR schedule position (BertAdam's step count) follows it
+    # 3-D resumes from the checkpoint's iteration (train3d.py:658-661)
     sdist.enable_sync_batchnorm()
     if getattr(args, 'tune_bn_only', False):
         if batches is None:
@@ -240,10 +254,8 @@ def run(args, cfg, batches=None):
             batches = iter(lambda: fixed, None)
         return tune_bn(net, args, batches, dev, ckpt_dir, is_master)
     net.train()
-    opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
-                                decay=args.decay, grad_clip=args.grad_clip)
-    if iter_num > 0:
-        opt.step_count = iter_num                 # the reference's schedule reads `iter_num / t_total` from the optimizer state it reloads
+    if iter_num > 0 and opt.step_count == 0:
+        opt.step_count = iter_num                 # no optimizer state in the checkpoint: keep the LR schedule at the resumed iteration (moments restart)
     reducer = sdist.GradReducer(opt) if world > 1 else None
     augment = None
     if dim_of(cfg) == 3 and getattr(args, 'randscale', 0):              # train3d.py:524-527, 713-715

@@ -54,3 +54,27 @@ def test_product_refuses_cpu_tensors_and_missing_library(tmp_path):
         L.layernorm_fwd(torch.zeros(4, 8), None, None, torch.zeros(4, 8), torch.zeros(4), torch.zeros(4), 4, 8, 1e-12)
     with pytest.raises(RuntimeError, match='not built'):
         segx.SegxLib(str(tmp_path / 'nope.so'))
+
+
+def test_gemm_desc_layout_matches_header():
+    """ctypes mirror of segx_gemm_desc: same fields in the same order as include/segx.h (a silent mismatch would shift every later field)."""
+    hdr = open(os.path.join(ROOT, 'include', 'segx.h')).read()
+    body = re.search(r'typedef struct \{(.*?)\} segx_gemm_desc;', hdr, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = []
+    for stmt in body.split(';'):
+        stmt = stmt.strip()
+        if not stmt:
+            continue
+        decl = re.sub(r'^(const\s+)?(int32_t|int64_t|uint64_t|float)\s*\*?', '', stmt)
+        names += [n.strip().lstrip('*').strip() for n in decl.split(',')]
+    assert names == [f[0] for f in segx.GemmDesc._fields_], (names, [f[0] for f in segx.GemmDesc._fields_])
+
+
+def test_product_library_rejects_the_ablation_variants():
+    """include/segx.h: knob 6 values 2..5 (kernels whose results are NOT the GEMM) exist in -DSEGX_BENCH builds only."""
+    from segtran_amd.build import build
+    L = segx.SegxLib(build())
+    for v in (2, 3, 4, 5):
+        assert L.c.segx_tune(6, v) == -1
+    assert L.c.segx_tune(6, 1) == 0 and L.c.segx_tune(6, 0) == 0

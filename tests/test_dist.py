@@ -159,6 +159,27 @@ def _case_dp_step(rank, world, ret, gather=True):
     ret[rank] = bool(ok and len(red.buckets) > 1 and torch.allclose(s, torch.tensor([0.5, 1.0])))
 
 
+def _case_ragged_batch(rank, world, ret):
+    """a ragged last batch on ONE rank only.  The check runs on every rank every step, so both ranks raise (instead of the
+    ragged rank's check pairing with the other rank's gradient collective)."""
+    from segtran_amd import dist as sdist
+    sdist.check_equal_batch(4)                               # equal: passes on both
+    try:
+        sdist.check_equal_batch(3 if rank == 1 else 4)       # rank 1 holds a short batch; rank 0's batch did NOT change
+        ret[rank] = 'no error'
+    except RuntimeError as e:
+        ret[rank] = 'raised: ' + str(e)[:60]
+    t = torch.ones(3) * (rank + 1)                           # the groups are still in step: a following collective pairs up correctly
+    dist.all_reduce(t)
+    ret['sum%d' % rank] = float(t[0])
+
+
+def test_unequal_per_rank_batch_raises_on_every_rank():
+    out = _run('_case_ragged_batch')
+    assert out[0].startswith('raised') and out[1].startswith('raised'), out
+    assert out['sum0'] == 3.0 and out['sum1'] == 3.0
+
+
 def test_sync_batchnorm_matches_full_batch():
     assert _run('_case_sync_bn') == {0: True, 1: True}
 

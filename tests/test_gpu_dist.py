@@ -18,7 +18,7 @@ def test_bench_two_ranks_share_one_gpu():
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   SEGX_DIST_BACKEND='gloo')
+                   SEGX_DIST_BACKEND='gloo', SEGX_BENCH_SHARE_GPU='1')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg1', '--steps', '3', '--warmup', '2'],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT))
     outs = [p.communicate(timeout=600) for p in procs]
@@ -30,6 +30,24 @@ def test_bench_two_ranks_share_one_gpu():
     assert res['n_gpus'] == 2 and res['config']['global_batch'] == 4 and res['config']['parallelism'] == 'dp2'
     assert res['value'] > 0 and res['config']['final_loss'] == res['config']['final_loss']
     assert 'cpu_baseline' not in res                       # N = 1 only
+
+
+def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start N ranks itself (here: two gloo ranks sharing the box's
+    one GPU) and report n_gpus = the ranks that ran; without the sharing override it must REFUSE rather than print a one-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--config', 'cfg1', '--steps', '3', '--warmup', '2']
+    p = subprocess.run(cmd, env=dict(env, SEGX_DIST_BACKEND='gloo', SEGX_BENCH_SHARE_GPU='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['ranks'] == 2 and res['config']['parallelism'] == 'dp2' and res['value'] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        q = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=300)
+        assert q.returncode != 0 and not [l for l in q.stdout.decode().splitlines() if l.startswith('{')]
+        assert 'GPU(s) visible' in q.stderr.decode()
 
 
 def test_rccl_backend_world_of_one_runs_every_collective():

@@ -399,3 +399,46 @@ def test_graphed_train_step_matches_eager_and_draws_fresh_dropout_masks(tile_eng
     L.set_rng_base(base); L.dropout(v, y0, 4096, 0.3, 99, 0); L.set_rng_base(None)
     L.dropout(v, y1, 4096, 0.3, 99, 1024)
     assert torch.equal(y0, y1) and 0.2 < (y0 == 0).float().mean().item() < 0.4
+
+
+# ---- the HIP backbones stand-alone against the reference's own endpoint tensors -------------------------------
+def _load_prefixed(net, prefix):
+    from segtran_amd.synth import synth_state_dict
+    sd = synth_state_dict({prefix + k: tuple(v.shape) for k, v in net.state_dict().items()})      # the fixture generators hash the PREFIXED names
+    net.load_state_dict({k[len(prefix):]: v for k, v in sd.items()})
+    return net
+
+
+def test_hip_efficientnet_b4_endpoints_vs_reference_fixture():
+    """efficientnet/model.py:240-283 (extract_endpoints) on the HIP kernels, eval mode, the two fixture sizes (64 x 64 and the non-square 96 x 64:
+    quirk N6's nominal-geometry pads (0,1) / (2,2) / (0,1) / (1,2) at the four stride-2 depthwise convolutions), all five endpoints against
+    the tensors the real reference produced (tests/golden/effnet_b4.npz), not the oracle."""
+    from segtran_amd.efficientnet.model import EfficientNet
+    g = golden('effnet_b4')
+    net = _load_prefixed(EfficientNet.from_name('efficientnet-b4', stem_stride=1), 'backbone.').to(DEV).eval()
+    assert net.endpoint_blk_indices == [int(v) for v in g['endpoint_blk']]
+    for tag in 'ab':
+        with torch.no_grad():
+            ep = net.extract_endpoints(g['x_' + tag].to(DEV))
+        for i in range(5):
+            f = ep['reduction_%d' % (i + 1)].cpu()
+            assert list(f.shape) == g['%s_shape%d' % (tag, i)].tolist()
+            want = g['%s_ep%d' % (tag, i)]
+            got = f if want.numel() == f.numel() else sample(f, 16384)
+            assert_close(got.reshape(-1), want.reshape(-1), 1e-4, 'effnet %s ep%d' % (tag, i))
+
+
+def test_hip_i3d_features_vs_reference_fixture():
+    """aj_i3d.py:325-333 (extract_features) on the HIP kernels at the minimum legal size 16 x 112 x 112 (N7: dynamic 'same' pads, zero-padded
+    max-pools), five endpoints against the real reference's tensors (tests/golden/i3d.npz)."""
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionI3d
+    g = golden('i3d')
+    x = synth_image2d(1, 16 * 112, int(g['x_seed']), 112).view(1, 3, 16, 112, 112)
+    assert torch.equal(sample(x), g['x_sample'])
+    net = _load_prefixed(InceptionI3d(do_pool1=False), 'backbone.').to(DEV).eval()
+    with torch.no_grad():
+        fd = net.extract_features(x.to(DEV))
+    for i, n in enumerate(['MaxPool3d_2a_3x3', 'Conv3d_2c_3x3', 'Mixed_3c', 'Mixed_4f', 'Mixed_5c']):
+        f = fd[n].cpu()
+        assert list(f.shape) == g['shape%d' % i].tolist()
+        assert_close(sample(f, 32768), g['ep%d' % i], 1e-4, 'i3d ' + n)

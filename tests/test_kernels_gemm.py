@@ -343,3 +343,43 @@ def test_x6_wave_specialised_gelu_epilogue(backend):
             assert torch.equal(T, outs[0][1]) and torch.equal(Y, outs[0][0])
     finally:
         L.set_engine(prev)
+
+
+@pytest.mark.gpu
+def test_gemm_is_reentrant_across_threads_streams_and_engines():
+    """include/segx.h conventions: two host threads, each on its own stream, call segx_gemm_f32 concurrently -- one with
+    desc.engine = f32, one with desc.engine = bf16x6 -- while the process default stays untouched; every result equals the serial one."""
+    import threading
+    from segtran_amd import segx as sx
+    L = sx.lib()
+    dev = torch.device('cuda', 0)
+    default = L.set_engine('f32'); L.set_engine(default)
+    g = torch.Generator(device='cpu').manual_seed(3)
+    M, N, K = 512, 384, 256
+    A = torch.randn(M, K, generator=g).to(dev); B = torch.randn(N, K, generator=g).to(dev)
+    ref = {}
+    for eng in ('f32', 'x6'):
+        C = torch.empty(M, N, device=dev)
+        L.gemm(A, B, C, M, N, K, (0, 0, K, 1), (0, 0, K, 1), (0, 0, N), engine=eng)
+        ref[eng] = C.clone()
+    torch.cuda.synchronize()
+    assert not torch.equal(ref['f32'], ref['x6'])           # different engines, different fp32 rounding: the selector is honoured
+    errs = []
+
+    def work(eng):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(50):
+                    C = torch.empty(M, N, device=dev)
+                    L.gemm(A, B, C, M, N, K, (0, 0, K, 1), (0, 0, K, 1), (0, 0, N), engine=eng)
+                    if not torch.equal(C, ref[eng]):
+                        errs.append(eng)
+            st.synchronize()
+        except Exception as e:                               # noqa: BLE001
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(e,)) for e in ('f32', 'x6', 'x6', 'f32')]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs[:3]
+    prev = L.set_engine(default)
+    assert prev == default                                   # no call changed the process default

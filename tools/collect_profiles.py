@@ -5,7 +5,7 @@ import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
-ENGINE = ('gemm_f32_kernel', 'gemm_x6_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel', 'conv3d_fwd_x6_kernel', 'conv3d_wgrad_x6_kernel')
+ENGINE = ('gemm_f32_kernel', 'gemm_x6_kernel', 'gemm_x6ws_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel', 'conv3d_fwd_x6_kernel', 'conv3d_wgrad_x6_kernel')
 
 
 def engine_traffic(cfg):
@@ -60,7 +60,7 @@ traffic = {}
 for name in sorted(os.listdir(src)):
     if name.endswith(('.json', '.csv', '.txt', '.log')) and not name.startswith(('prof_', 'pmc_')) and not name.endswith('.log') or name.endswith('_by_kernel.json'):
         shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
-for cfg in ('cfg2', 'cfg4'):
+for cfg in ('cfg2', 'cfg4', 'cfg5'):
     t = engine_traffic(cfg)
     if t:
         json.dump(t, open(os.path.join(dst, '%s_pmc_engine_traffic_%s.json' % (tag, cfg)), 'w'), indent=1)

@@ -40,7 +40,7 @@ for CFG in cfg2 cfg4 cfg5; do
   rm -rf $OUT/prof_$CFG
 done
 if [ "$MODE" = full ]; then
-  for CFG in cfg2 cfg4; do
+  for CFG in cfg2 cfg4 cfg5; do
     for PMC in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
       NAME=$(echo $PMC | cut -d' ' -f1)
       timeout 600 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_${CFG}_$NAME -o pmc -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-brats --no-cpu-baseline --single-order > $OUT/pmc_${CFG}_$NAME.log 2>&1
