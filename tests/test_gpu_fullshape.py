@@ -90,8 +90,6 @@ def test_fullshape_eval_every_label(case, engine_sel):
 def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     cfg, B, tag = _case(case)
-    if gate == 'bench' and cfg in ('cfg2', 'cfg5') and engine_sel == 'x6':
-        pytest.skip('N = 4096 tokens: the default gate already takes the re-associated path at batch 1')
     monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_projections', reassociated)
     if gate == 'bench':
         monkeypatch.setattr(ss.CrossAttFeatTrans, 'reassociate_min_rows', 0)
