@@ -289,6 +289,32 @@ int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, 
  * geom (int32[12]) = {d, h, w, D, H, W, od, oh, ow, oz, oy, ox}; (oz, oy, ox) = crop start minus front pad, in the resampled grid */
 int segx_resized_crop3d(const float* X, float* Y, int64_t planes, const int* geom, void* stream);
 int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
+/* ---------------------------------------------------------------------------------------------
+ * Data augmentation on the device (augment.hip).  The reference transforms each sample on the CPU in DataLoader workers (numpy / imgaug /
+ * torchvision); here a batch resident in HBM is transformed by one-pass kernels, the random parameters drawn on the host.
+ * ------------------------------------------------------------------------------------------- */
+/* Axis-permuting gather with zero padding: RandomRotFlip + RandomCrop of the 3-D trainer (dataloaders/datasets3d.py:547-579, 491-545) composed
+ * into ONE pass; Fliplr / Flipud / Rot90 / CropAndPad / PadToFixedSize / CropToFixedSize of the 2-D pipeline (train_util.py:34-53) with I0 = O0 = 1.
+ * X [planes, I0, I1, I2] -> Y [planes, O0, O1, O2]: Y[p][o] = X[p][i], i[src[a]] = sgn[a] > 0 ? o_a + off[a] : off[a] - o_a, 0 where i falls
+ * outside.  geom (int32[15]) = {I0, I1, I2, O0, O1, O2, src0, src1, src2, sgn0, sgn1, sgn2, off0, off1, off2}; src is a permutation of (0, 1, 2) */
+int segx_axis_gather(const float* X, float* Y, int64_t planes, const int* geom, void* stream);
+/* RandomNoise (datasets3d.py:581-597): Y = X + (clip(sigma z, -2 sigma, 2 sigma) + mu) * (nonzero_only ? X != 0 : 1), z ~ N(0, 1) -- `noise` [n]
+ * when given (parity tests inject the reference's field), else Box-Muller on the Philox stream (seed, offset); offset % 4 == 0 */
+int segx_add_noise(const float* X, const float* noise, float* Y, int64_t n, float mu, float sigma, int nonzero_only, uint64_t seed, uint64_t offset,
+                   void* stream);
+/* iaa.Resize / the keep_size resize of iaa.CropAndPad (train_util.py:31-37), cv2.resize conventions: X [planes, h, w] -> Y [planes, H, W];
+ * mode 0 nearest (segmentation maps), 1 bilinear, 2 bicubic (A = -0.75, replicated border: imgaug's default for images); quantize = 1 rounds and
+ * clamps to [0, 255] (the uint8 image the reference carries between augmenters) */
+int segx_resize2d(const float* X, float* Y, int64_t planes, int h, int w, int H, int W, int mode, int quantize, void* stream);
+/* transforms.ColorJitter / iaa.Grayscale(alpha) on channels-first RGB X [B, 3, HW] (train_util.py:53-60): Y = f X + (1 - f) D with a per-sample
+ * factor[B]; mode 0 brightness (D = 0), 1 contrast (D = pivot[b] = mean luma, segx_gray_mean), 2 saturation (D = luma), 3 grayscale-alpha
+ * (f = 1 - alpha, D = luma); luma = 0.299 R + 0.587 G + 0.114 B; quantize = 1: uint8 rounding as PIL / imgaug apply it */
+int segx_color_blend(const float* X, float* Y, int B, int64_t HW, int mode, const float* factor, const float* pivot, int quantize, void* stream);
+int64_t segx_gray_mean_ws_floats(int B, int64_t HW);
+int segx_gray_mean(const float* X, float* mean, float* ws, int B, int64_t HW, int quantize, void* stream);
+/* transforms.ToTensor + Normalize (train_util.py:101-105): Y[b][c] = (X[b][c] * scale - mean[c]) / std[c] */
+int segx_normalize(const float* X, float* Y, int B, int C, int64_t HW, float scale, const float* mean, const float* std, void* stream);
+
 /* separable form: adjoint along ONE axis of a tensor viewed as [outer, n_out, inner] -> [outer, n_in, inner] */
 int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_t outer, int n_out, int n_in, int64_t inner, float src_scale,
                                 void* stream);

@@ -1,6 +1,87 @@
-"""On-device label map and augmentation of the 3D train step (mirror of reference code/dataloaders/datasets3d.py:16-40, 611-665).
+"""On-device label map and augmentation of the 3D train step (mirror of reference code/dataloaders/datasets3d.py:16-40, 491-597, 611-665).
 The reference hard-codes device='cuda' (N8); here the label's own device is used."""
+import numpy as np
 import torch
+
+
+# ---- per-sample transforms of the 3-D trainer (train3d.py:571-578: RandomRotFlip -> RandomCrop -> ToTensor; RandomNoise is commented out
+# there but shipped).  Same `sample = {'image': [C, H, W, D] or [H, W, D], 'mask': [H, W, D]}` protocol and the SAME draws from numpy's
+# global generator in the same order as the reference, so np.random.seed(s) reproduces its crops / rotations / flips; the arrays are DEVICE
+# tensors and every geometric transform is one gather (functional.AxisMap -> segx_axis_gather).  Chained RandomRotFlip + RandomCrop can be
+# fused into a single pass with `RotFlipCrop`.
+def _maps(sample):
+    from .. import functional as SF
+    image, mask = sample['image'], sample['mask']
+    assert image.dim() == mask.dim() or image.dim() == mask.dim() + 1
+    return SF.AxisMap(image.shape[-3:]), SF.AxisMap(mask.shape[-3:])
+
+
+class RandomRotFlip(object):
+    """reference datasets3d.py:547-579: rotate by k * 90 degrees in the (H, W) plane, then flip along a random axis."""
+
+    def draw(self):
+        k = np.random.randint(0, 4)
+        axis = np.random.randint(0, 3)
+        return k, axis
+
+    def extend(self, maps, k, axis):
+        for m in maps:
+            m.rot90(k, axes=(0, 1)).flip(axis)
+
+    def __call__(self, sample):
+        mi, mm = _maps(sample)
+        self.extend((mi, mm), *self.draw())
+        return {'image': mi.apply(sample['image']), 'mask': mm.apply(sample['mask'])}
+
+
+class RandomCrop(object):
+    """reference datasets3d.py:491-545: zero-pad by (out - n) // 2 + 3 per side where an axis is not larger than the patch, then a random crop."""
+
+    def __init__(self, output_size):
+        self.output_size = tuple(int(v) for v in output_size)
+
+    def draw(self, shape):
+        o = self.output_size
+        pads = (0, 0, 0)
+        if shape[0] <= o[0] or shape[1] <= o[1] or shape[2] <= o[2]:
+            pads = tuple(max((o[a] - shape[a]) // 2 + 3, 0) for a in range(3))
+        h, w, d = (shape[a] + 2 * pads[a] for a in range(3))
+        h1 = np.random.randint(0, h - o[0]); w1 = np.random.randint(0, w - o[1]); d1 = np.random.randint(0, d - o[2])
+        return pads, (h1, w1, d1)
+
+    def extend(self, maps, pads, starts):
+        for m in maps:
+            m.window([s - p for s, p in zip(starts, pads)], self.output_size)
+
+    def __call__(self, sample):
+        mi, mm = _maps(sample)
+        self.extend((mi, mm), *self.draw(mm.O))
+        return {'image': mi.apply(sample['image']), 'mask': mm.apply(sample['mask'])}
+
+
+class RotFlipCrop(object):
+    """RandomRotFlip followed by RandomCrop (the trainer's composition) as ONE gather per tensor: same draws in the same order."""
+
+    def __init__(self, output_size):
+        self.rf, self.rc = RandomRotFlip(), RandomCrop(output_size)
+
+    def __call__(self, sample):
+        mi, mm = _maps(sample)
+        self.rf.extend((mi, mm), *self.rf.draw())
+        self.rc.extend((mi, mm), *self.rc.draw(mm.O))
+        return {'image': mi.apply(sample['image']), 'mask': mm.apply(sample['mask'])}
+
+
+class RandomNoise(object):
+    """reference datasets3d.py:581-597: image += clip(sigma * randn, +-2 sigma) + mu on the non-zero voxels.  The normal field comes from the
+    device Philox stream (functional.manual_seed); pass `noise=` to __call__ to inject a given field (numpy's stream cannot be reproduced)."""
+
+    def __init__(self, mu=0, sigma=0.1, nonzero_only=True):
+        self.mu, self.sigma, self.nonzero_only = mu, sigma, nonzero_only
+
+    def __call__(self, sample, noise=None):
+        from .. import functional as SF
+        return {'image': SF.add_noise(sample['image'], self.mu, self.sigma, self.nonzero_only, noise), 'mask': sample['mask']}
 
 
 def RandomResizedCrop(volume, mask, out_size, crop_percents, isotropic=True):

@@ -1446,6 +1446,110 @@ def resized_crop3d(x, resized, out_size, offset):
 
 
 # -------------------------------------------------------------------------------------------------
+# Data augmentation on the device (augment.hip): no autograd; random parameters are drawn by the callers (dataloaders/)
+# -------------------------------------------------------------------------------------------------
+class AxisMap:
+    """A composition of flips / rot90s / crops / zero pads of the three trailing axes of a tensor, applied by ONE gather (segx_axis_gather).
+    State: for each INPUT axis b the output axis p[b] that feeds it, a sign and an offset (i_b = s[b] * o_{p[b]} + t[b]), plus the current
+    output extents.  Every method returns self (chainable); out-of-range reads are zeros (that is what padding is)."""
+
+    def __init__(self, shape):
+        self.I = [int(v) for v in shape]
+        self.O = list(self.I)
+        self.p, self.s, self.t = [0, 1, 2], [1, 1, 1], [0, 0, 0]
+
+    def flip(self, axis):
+        for b in range(3):
+            if self.p[b] == axis:
+                self.t[b] += self.s[b] * (self.O[axis] - 1); self.s[b] = -self.s[b]
+        return self
+
+    def rot90(self, k=1, axes=(0, 1)):
+        """numpy.rot90(m, k, axes): one step is new[i][j] = cur[j][n1 - 1 - i] on the two axes"""
+        a0, a1 = axes
+        for _ in range(k % 4):
+            n1 = self.O[a1]
+            for b in range(3):
+                if self.p[b] == a0:
+                    self.p[b] = a1
+                elif self.p[b] == a1:
+                    self.p[b] = a0; self.t[b] += self.s[b] * (n1 - 1); self.s[b] = -self.s[b]
+            self.O[a0], self.O[a1] = self.O[a1], self.O[a0]
+        return self
+
+    def window(self, start, size):
+        """crop (start >= 0) and / or zero-pad (start < 0, or size beyond the extent): new[o] = cur[o + start]"""
+        for a in range(3):
+            for b in range(3):
+                if self.p[b] == a:
+                    self.t[b] += self.s[b] * int(start[a])
+            self.O[a] = int(size[a])
+        return self
+
+    def geom(self):
+        src, sgn, off = [0] * 3, [1] * 3, [0] * 3
+        for b in range(3):
+            src[self.p[b]], sgn[self.p[b]], off[self.p[b]] = b, self.s[b], self.t[b]
+        return tuple(self.I) + tuple(self.O) + tuple(src) + tuple(sgn) + tuple(off)
+
+    def apply(self, x):
+        """x [..., I0, I1, I2] -> [..., O0, O1, O2]"""
+        L = segx.lib()
+        xs = _c(x.detach().float())
+        assert list(xs.shape[-3:]) == self.I, (tuple(xs.shape), self.I)
+        y = torch.empty(tuple(xs.shape[:-3]) + tuple(self.O), dtype=torch.float32, device=xs.device)
+        L.axis_gather(xs, y, max(1, xs.numel() // (self.I[0] * self.I[1] * self.I[2])), self.geom())
+        return y
+
+
+def add_noise(x, mu=0.0, sigma=0.1, nonzero_only=True, noise=None):
+    """RandomNoise (datasets3d.py:581-597) on the device; `noise`: a standard-normal field to use instead of the Philox stream (parity tests)."""
+    L = segx.lib()
+    xs = _c(x.detach().float())
+    y = torch.empty_like(xs)
+    seed, off = _Rng.reserve(xs.numel())
+    L.add_noise(xs, None if noise is None else _c(noise.float()), y, mu, sigma, nonzero_only, seed, off)
+    return y
+
+
+def resize2d(x, size, mode='cubic', quantize=False):
+    """[..., h, w] -> [..., H, W] with cv2.resize conventions (imgaug's Resize / keep_size): mode 'nearest' | 'linear' | 'cubic'"""
+    L = segx.lib()
+    xs = _c(x.detach().float())
+    h, w = xs.shape[-2:]
+    y = torch.empty(tuple(xs.shape[:-2]) + (int(size[0]), int(size[1])), dtype=torch.float32, device=xs.device)
+    L.resize2d(xs, y, max(1, xs.numel() // (h * w)), h, w, int(size[0]), int(size[1]), {'nearest': 0, 'linear': 1, 'cubic': 2}[mode], quantize)
+    return y
+
+
+def color_blend(x, mode, factor, quantize=True):
+    """x [B, 3, H, W] (0..255 scale); mode 'brightness' | 'contrast' | 'saturation' | 'grayscale' (factor = 1 - alpha); factor [B] tensor"""
+    L = segx.lib()
+    xs = _c(x.detach().float())
+    B, HW = xs.shape[0], xs.shape[2] * xs.shape[3]
+    m = {'brightness': 0, 'contrast': 1, 'saturation': 2, 'grayscale': 3}[mode]
+    f = _c(factor.to(xs.device, torch.float32))
+    pivot = None
+    if m == 1:
+        pivot = torch.empty(B, dtype=torch.float32, device=xs.device)
+        L.gray_mean(xs, pivot, B, HW, quantize)
+    y = torch.empty_like(xs)
+    L.color_blend(xs, y, B, HW, m, f, pivot, quantize)
+    return y
+
+
+def normalize(x, mean, std, scale=1.0 / 255.0):
+    """transforms.ToTensor + Normalize: (x * scale - mean[c]) / std[c]; x [B, C, H, W]"""
+    L = segx.lib()
+    xs = _c(x.detach().float())
+    B, C = xs.shape[:2]
+    y = torch.empty_like(xs)
+    L.normalize(xs, y, B, C, xs.numel() // (B * C), scale, torch.as_tensor(mean, dtype=torch.float32, device=xs.device),
+                torch.as_tensor(std, dtype=torch.float32, device=xs.device))
+    return y
+
+
+# -------------------------------------------------------------------------------------------------
 # Evaluation path (infer.hip): no autograd, everything under torch.no_grad()
 # -------------------------------------------------------------------------------------------------
 def window_accum(scores, acc, cnt, origin):
