@@ -47,14 +47,14 @@ class Augment2d:
         """one sample [C, h, w] -> [C, tgt_h, tgt_w]; mode 'cubic' (image, quantised) or 'nearest' (segmentation map)"""
         q = mode == 'cubic'
         H, W = self.tgt_h, self.tgt_w
-        x = x[None] if x.dim() == 3 else x
+        ap = lambda m, t: m.apply(t.unsqueeze(1)).squeeze(1)          # noqa: E731  [C, h, w] as C planes of extent (1, h, w)
         if tuple(x.shape[-2:]) != (H, W):
             x = SF.resize2d(x, (H, W), mode, q)
         if p['crop'] is not None:
             # iaa.CropAndPad(percent): negative = crop, positive = zero pad, per side, in pixels of the current size; keep_size resizes back
             t, r, b, l = (int(round(f * n)) for f, n in zip(p['crop'], (H, W, H, W)))
             m = SF.AxisMap((1, H, W)).window((0, -t, -l), (1, H + t + b, W + l + r))
-            x = SF.resize2d(m.apply(x), (H, W), mode, q)
+            x = SF.resize2d(ap(m, x), (H, W), mode, q)
         m = SF.AxisMap((1,) + tuple(x.shape[-2:]))
         if p['fliplr']:
             m.flip(2)
@@ -69,7 +69,7 @@ class Augment2d:
             hp, wp = h2 + py, w2 + px
             cy, cx = int(round((hp - H) * p['pad_pos'][1])), int(round((wp - W) * p['pad_pos'][0]))
             m.window((0, cy - top, cx - left), (1, H, W))
-        return m.apply(x)[0] if (p['fliplr'] or p['flipud'] or p['rot90'] or (h2, w2) != (H, W)) else x[0]
+        return ap(m, x) if (p['fliplr'] or p['flipud'] or p['rot90'] or (h2, w2) != (H, W)) else x
 
     def photometric(self, img, params):
         """batch [B, 3, H, W] on the 0..255 scale -> normalised float batch"""

@@ -72,6 +72,18 @@ class RotFlipCrop(object):
         return {'image': mi.apply(sample['image']), 'mask': mm.apply(sample['mask'])}
 
 
+def collate_augmented(samples, patch_size, noise=None):
+    """The DataLoader side of train3d.py:571-578 + the default collate for a list of per-sample dicts ALREADY on the device:
+    RandomRotFlip -> RandomCrop(patch_size) as one gather per tensor (optionally RandomNoise), stacked to
+    (volumes [B, C, *patch], labels [B, *patch]) -- what TrainStep takes.  Draws come from numpy's global generator, sample by sample."""
+    tf = RotFlipCrop(patch_size)
+    out = [tf(s) for s in samples]
+    if noise is not None:
+        out = [noise(s) for s in out]
+    vol = torch.stack([s['image'] if s['image'].dim() == 4 else s['image'][None] for s in out])
+    return vol, torch.stack([s['mask'] for s in out])
+
+
 class RandomNoise(object):
     """reference datasets3d.py:581-597: image += clip(sigma * randn, +-2 sigma) + mu on the non-zero voxels.  The normal field comes from the
     device Philox stream (functional.manual_seed); pass `noise=` to __call__ to inject a given field (numpy's stream cannot be reproduced)."""

@@ -558,7 +558,7 @@ def _ref_functions(relpath, names, extra=None):
     ns = dict(torch=R.cpu_torch(), np=np, F=torch.nn.functional, math=math)
     ns.update(extra or {})
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name in names:
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names:
             exec(compile(ast.Module([node], []), relpath, 'exec'), ns)
     return ns
 
@@ -844,6 +844,44 @@ def case_augment():
     save('augment', **arrs)
 
 
+def case_augment3d():
+    """The 3-D trainer's per-sample transforms (train3d.py:571-578) produced by the REFERENCE's own classes (datasets3d.py:491-597, pure
+    numpy, exec-ed from the reference file): RandomRotFlip -> RandomCrop for seeds that cover every rotation count, every flip axis, the
+    padding branch and a volume without a modality axis; RandomNoise with the standard-normal field it drew stored beside the result."""
+    f3 = _ref_functions('dataloaders/datasets3d.py', ['RandomCrop', 'RandomRotFlip', 'RandomNoise'], extra=dict(pdb=None))
+    rs = np.random.RandomState(5)
+    img = rs.randn(3, 13, 11, 9).astype(np.float32)
+    img[:, :2] = 0                                               # exact zeros: RandomNoise(nonzero_only) leaves them alone
+    lab = rs.randint(0, 4, (13, 11, 9)).astype(np.float32)
+    arrs = dict(image=img, mask=lab)
+    seen_k, seen_ax = set(), set()
+    cases = []
+    for seed in range(12):
+        for tag, out in (('crop', (8, 7, 6)), ('pad', (8, 12, 6))):          # 'pad': W = 11 <= 12 -> the zero-padding branch on every axis
+            np.random.seed(seed)
+            k, ax = np.random.randint(0, 4), np.random.randint(0, 3)
+            seen_k.add(k); seen_ax.add(ax)
+            np.random.seed(seed)
+            smp = f3['RandomCrop'](out)(f3['RandomRotFlip']()({'image': img, 'mask': lab}))
+            assert smp['image'].shape == (3,) + out and smp['mask'].shape == out
+            arrs['rfc_img_%d_%s' % (seed, tag)] = np.ascontiguousarray(smp['image']); arrs['rfc_msk_%d_%s' % (seed, tag)] = np.ascontiguousarray(smp['mask'])
+            cases.append((seed, tag))
+    assert seen_k == {0, 1, 2, 3} and seen_ax == {0, 1, 2}
+    arrs['rfc_seeds'] = np.array(sorted({c[0] for c in cases}))
+    # single-modality volume ([H, W, D] image): rot90 / flip act on axes (0, 1) / axis directly
+    np.random.seed(3)
+    smp = f3['RandomCrop']((8, 7, 6))(f3['RandomRotFlip']()({'image': img[0], 'mask': lab}))
+    arrs['rfc1_img'] = np.ascontiguousarray(smp['image']); arrs['rfc1_msk'] = np.ascontiguousarray(smp['mask'])
+    # RandomNoise: the reference draws np.random.randn(*image.shape) first
+    for nz in (1, 0):
+        np.random.seed(21)
+        z = np.random.randn(*img.shape)
+        np.random.seed(21)
+        out = f3['RandomNoise'](mu=0.05, sigma=0.1, nonzero_only=bool(nz))({'image': img, 'mask': lab})['image']
+        arrs['noise_z'] = z.astype(np.float32); arrs['noise_out_%d' % nz] = out.astype(np.float32)
+    save('augment3d', **arrs)
+
+
 def _tensor_digest(t):
     f = t.detach().double().reshape(-1)
     return np.concatenate([[f.sum().item(), (f * f).sum().item()], sample(t, 8).double().numpy()[:8], np.zeros(max(0, 8 - min(8, f.numel())))])[:10]
@@ -890,7 +928,7 @@ def case_keys():
 
 CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
-             fullshape=case_fullshape, augment=case_augment, init=case_init)
+             fullshape=case_fullshape, augment=case_augment, augment3d=case_augment3d, init=case_init)
 
 if __name__ == '__main__':
     todo = [a for a in sys.argv[1:] if a in CASES] or list(CASES)        # further arguments select sub-cases (see case_seg3d)
