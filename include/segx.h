@@ -171,7 +171,7 @@ int segx_mt_gather(const void* const* src, void* const* dst, const int64_t* size
 /* ---------------------------------------------------------------------------------------------
  * Backbone kernels (backbone.hip): BatchNorm(+activation), depthwise convolution, squeeze-excite plane ops.
  * Tensors are NC[D]HW fp32; S = product of the spatial dims; a (sample, channel) plane is contiguous.
- * act: 0 none, 1 swish (efficientnet/utils.py:64-79), 2 ReLU (aj_i3d.py:95-96).
+ * act: 0 none, 1 swish (efficientnet/utils.py:64-79), 2 ReLU (aj_i3d.py:95-96), 3 LeakyReLU(0.2) (networks/discriminator.py:14-21).
  * ------------------------------------------------------------------------------------------- */
 /* training-mode batch statistics (biased var) per channel; also updates running stats (momentum, unbiased var) when
  * run_mean/run_var are non-NULL.  nn.BatchNorm2d/3d at efficientnet/model.py:54,64,78,177,221 and aj_i3d.py:65. */
@@ -298,6 +298,10 @@ int segx_interp_linear_bwd(const float* dout, float* din, int64_t planes, int d,
  * X [planes, I0, I1, I2] -> Y [planes, O0, O1, O2]: Y[p][o] = X[p][i], i[src[a]] = sgn[a] > 0 ? o_a + off[a] : off[a] - o_a, 0 where i falls
  * outside.  geom (int32[15]) = {I0, I1, I2, O0, O1, O2, src0, src1, src2, sgn0, sgn1, sgn2, off0, off1, off2}; src is a permutation of (0, 1, 2) */
 int segx_axis_gather(const float* X, float* Y, int64_t planes, const int* geom, void* stream);
+/* nn.ConvTranspose2d(k = 2, s = 2) of the U-Net's bilinear=False decoder (networks/unet2d/unet_parts.py:53) = pointwise convolution onto
+ * 4 Cout channels (segx_gemm_f32) + this re-arrangement: X [4 planes, h, w] -> Y [planes, 2h, 2w], Y[p][2i+a][2j+c] = X[4p+2a+c][i][j];
+ * inverse = 1: the adjoint, X [planes, 2h, 2w] -> Y [4 planes, h, w] */
+int segx_pixel_shuffle2(const float* X, float* Y, int64_t planes, int h, int w, int inverse, void* stream);
 /* RandomNoise (datasets3d.py:581-597): Y = X + (clip(sigma z, -2 sigma, 2 sigma) + mu) * (nonzero_only ? X != 0 : 1), z ~ N(0, 1) -- `noise` [n]
  * when given (parity tests inject the reference's field), else Box-Muller on the Philox stream (seed, offset); offset % 4 == 0 */
 int segx_add_noise(const float* X, const float* noise, float* Y, int64_t n, float mu, float sigma, int nonzero_only, uint64_t seed, uint64_t offset,

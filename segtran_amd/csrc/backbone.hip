@@ -9,16 +9,17 @@
 
 namespace segx {
 
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_LEAKY = 3 /* nn.LeakyReLU(0.2): the domain discriminator, networks/discriminator.py:14-21 */ };
 
 __device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_fwd(float u, int act) {
-    return act == ACT_SWISH ? u * sigm(u) : act == ACT_RELU ? fmaxf(u, 0.f) : u;
+    return act == ACT_SWISH ? u * sigm(u) : act == ACT_RELU ? fmaxf(u, 0.f) : act == ACT_LEAKY ? (u > 0.f ? u : 0.2f * u) : u;
 }
 // d act(u) / du   (swish: efficientnet/utils.py:64-79)
 __device__ __forceinline__ float act_grad(float u, int act) {
     if (act == ACT_SWISH) { const float s = sigm(u); return s * (1.0f + u * (1.0f - s)); }
     if (act == ACT_RELU) return u > 0.f ? 1.0f : 0.f;
+    if (act == ACT_LEAKY) return u > 0.f ? 1.0f : 0.2f;
     return 1.0f;
 }
 
@@ -722,7 +723,7 @@ extern "C" int segx_bn_merge_stats(const float* all, float* mean, float* var, fl
 }
 extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
                                int B, int C, int64_t S, float eps, int act, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 2, "segx_bn_act_fwd: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3, "segx_bn_act_fwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd: more than 65535 (sample, channel) planes");
     hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, (float*)nullptr, C, S, eps, act);
     return check_launch("segx_bn_act_fwd");
@@ -730,7 +731,7 @@ extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* v
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
 extern "C" int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
                                     int B, int C, int64_t S, float eps, int act, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && pooled && ws && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 2, "segx_bn_act_fwd_pool: bad args");
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && pooled && ws && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3, "segx_bn_act_fwd_pool: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd_pool: more than 65535 (sample, channel) planes");
     const int nch = plane_chunks(S, 8);
     hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3(nch, B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, ws, C, S, eps, act);

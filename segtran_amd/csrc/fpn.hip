@@ -393,6 +393,30 @@ __global__ __launch_bounds__(256) void resized_crop3d_kernel(const float* __rest
     }
 }
 
+// nn.ConvTranspose2d(kernel 2, stride 2) = pointwise convolution onto 4 Cout channels + this re-arrangement (unet_parts.py:53, the
+// bilinear=False decoder): Y[p][2 i + a][2 j + c] = X[4 p + 2 a + c][i][j] (F.pixel_shuffle with r = 2); inverse = 1 runs it backwards
+// (Y[4 p + 2 a + c][i][j] = X[p][2 i + a][2 j + c]: the gradient).  A thread handles the 2 x 2 output cell of one input position pair.
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t planes, int h, int w, int inverse) {
+    const int64_t hw = (int64_t)h * w, total = planes * hw;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pl = idx / hw; const int r = (int)(idx - pl * hw), i = r / w, j = r - i * w;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int64_t small = (4 * pl + 2 * a + c) * hw + r, big = pl * 4 * hw + (int64_t)(2 * i + a) * (2 * w) + 2 * j + c;
+                if (inverse) Y[small] = X[big]; else Y[big] = X[small];
+            }
+    }
+}
+extern "C" int segx_pixel_shuffle2(const float* X, float* Y, int64_t planes, int h, int w, int inverse, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    SEGX_REQUIRE(X && Y && planes > 0 && h > 0 && w > 0, "segx_pixel_shuffle2: bad args");
+    const int64_t total = planes * h * w;
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, X, Y, planes, h, w, inverse);
+    return check_launch("segx_pixel_shuffle2");
+}
+
 extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                                       void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(in && out && planes > 0 && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp_linear_fwd: bad args");

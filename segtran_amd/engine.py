@@ -57,14 +57,56 @@ def build_model(cfg, device, dropout_prob=None, attractors=None, synth=True, **o
     return net.to(device)
 
 
-def init_optimizer(net, c_or_task, t_total=10000, warmup_steps=500, lr=None, decay=None, grad_clip=None):
-    """4 param groups as train2d.py:513-545: names containing 'backbone' get decay x 0.1."""
+def polyformer_optimized_params(net, poly_opt_mode, is_segtran=True, adda=False):
+    """train2d.py:463-503: which parameters a --polyformer source|target run optimises.  poly_opt_mode: 'allnet' or a comma list of
+    'allpoly' (every Squeeze-and-Expansion / Polyformer layer), 'inator' (the in-squeeze attention), 'k' / 'v' / 'q' (its key / value / query
+    projections), 'h' (the U-Net's class projection); the domain discriminator (unless ADDA) and the reconstruction head ride along."""
+    import itertools
+    if poly_opt_mode == 'allnet':
+        return [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    layers = net.voxel_fusion.translayers if is_segtran else net.polyformer.polyformer_layers
+    pick = {'allpoly': lambda: [layers.named_parameters()],
+            'inator': lambda: [t.in_ator_trans.named_parameters() for t in layers],
+            'k': lambda: [t.in_ator_trans.key.named_parameters() for t in layers],
+            'v': lambda: [t.in_ator_trans.out_trans.first_linear.named_parameters() for t in layers],
+            'q': lambda: [t.in_ator_trans.query.named_parameters() for t in layers],
+            'h': lambda: [net.outc.named_parameters()]}
+    chosen = []
+    for mode in poly_opt_mode.split(','):
+        if mode not in pick:
+            raise ValueError('unknown polyformer optimisation mode %r' % mode)
+        chosen += pick[mode]()
+    params = list(itertools.chain.from_iterable(chosen))
+    if getattr(net, 'discriminator', None) is not None and not adda:
+        params += list(net.discriminator.named_parameters())
+    if getattr(net, 'recon', None) is not None:
+        params += list(net.recon.named_parameters())
+    return params
+
+
+def init_optimizer(net, c_or_task, t_total=10000, warmup_steps=500, lr=None, decay=None, grad_clip=None, polyformer_mode=None, poly_opt_mode='allpoly',
+                   bn_opt_scheme=None, adda=False):
+    """Param groups as train2d.py:448-557: names containing 'backbone' get decay x 0.1, names containing 'alphas' lr x 100 without decay.
+    polyformer_mode ('source' | 'target'): only the parameters polyformer_optimized_params selects are optimised and weight decay is 0
+    (:463-464); bn_opt_scheme='affine' adds every BatchNorm2d's affine parameters (:505-511)."""
     lr = DEFAULTS['lr'] if lr is None else lr
     decay = DEFAULTS['decay'] if decay is None else decay
-    named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    if polyformer_mode:
+        decay = 0
+        named = polyformer_optimized_params(net, poly_opt_mode, hasattr(net, 'voxel_fusion'), adda)
+    else:
+        named = [(n, p) for n, p in net.named_parameters() if p.requires_grad]
+    if bn_opt_scheme == 'affine':
+        have = {id(p) for _, p in named}
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                named += [(n, p) for n, p in m.named_parameters() if id(p) not in have]
     low = [p for n, p in named if 'backbone' in n]
-    normal = [p for n, p in named if 'backbone' not in n]
+    high = [p for n, p in named if 'backbone' not in n and 'alphas' in n]
+    normal = [p for n, p in named if 'backbone' not in n and 'alphas' not in n]
     groups = [dict(params=normal, weight_decay=decay, lr=lr), dict(params=low, weight_decay=decay * 0.1, lr=lr)]
+    if high:
+        groups.append(dict(params=high, weight_decay=0.0, lr=lr * 100))
     warmup_steps = min(warmup_steps, t_total // 2)
     return BertAdam(groups, lr=lr, warmup=warmup_steps / t_total, t_total=t_total, weight_decay=decay,
                     global_grad_clip=DEFAULTS['grad_clip'] if grad_clip is None else grad_clip)

@@ -591,7 +591,7 @@ def seg_loss(logits, mask_nhot, pos_weight, class_w, dice_w=0.5):
 # -------------------------------------------------------------------------------------------------
 # Backbone ops (backbone.hip): BatchNorm + activation, depthwise conv, squeeze-excite
 # -------------------------------------------------------------------------------------------------
-ACT_NONE, ACT_SWISH, ACT_RELU = 0, 1, 2
+ACT_NONE, ACT_SWISH, ACT_RELU, ACT_LEAKY = 0, 1, 2, 3
 _bn_stats_sync = None        # set by segtran_amd.dist for data-parallel runs: merges (mean, var, count) across ranks
 _bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair of the BN backward
 
@@ -1179,10 +1179,29 @@ class _Conv3d(torch.autograd.Function):
                 else:
                     L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
                     L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws)
-            else:
-                # strided transposed convolution (only the 7x7x7 stride-2 stem, 3 input channels): direct gather kernel
+            elif Cin <= 4:
+                # strided transposed convolution onto <= 4 channels (the 7x7x7 stride-2 I3D stem): direct gather kernel
                 dx = torch.empty_like(x)
                 L.conv3d_bwd_data_direct(dy, w, dx, B, Cout, geom)
+            else:
+                # general strided case (the 4x4 stride-2 convolutions of the domain discriminator): dY with stride-1 zeros inserted, then the
+                # stride-1 transposed convolution on the tile engine (positions beyond the dilated extent read the zero padding)
+                sd, sh, sw = ctx.stride
+                DD, DH, DW = (OD - 1) * sd + 1, (OH - 1) * sh + 1, (OW - 1) * sw + 1
+                dyd = dy.new_zeros(B, Cout, DD, DH, DW)
+                dyd[:, :, ::sd, ::sh, ::sw] = dy
+                wt = _empty(x, Cin, Cout, KD, KH, KW)
+                (pd, _), (ph, _), (pw, _) = ctx.pads
+                g2 = (Cout, DD, DH, DW, ID, IH, IW, KD, KH, KW, 1, 1, 1, KD - 1 - pd, KH - 1 - ph, KW - 1 - pw)
+                dx = torch.empty_like(x)
+                sk = L.conv3d_splitk(B, Cin, g2, False)
+                ws = _empty(x, sk * dx.numel()) if sk > 1 else None
+                if Cout % 8 == 0:
+                    L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
+                    L.conv3d_fwd(dyd, wt, dx, B, Cin, g2, sk, ws, packed=True)
+                else:
+                    L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
+                    L.conv3d_fwd(dyd, wt, dx, B, Cin, g2, sk, ws)
         if ctx.needs_input_grad[1]:
             P, N = OD * OH * OW, Cin * KV
             sk = L.conv3d_splitk(B, Cout, geom, True)
@@ -1392,6 +1411,36 @@ def conv2d_bias(x, w, bias, pad=1, stride=1):
     """nn.Conv2d(Cin, Cout, k, padding=pad) with bias (unet2d/unet_parts.py:16-20): implicit-GEMM convolution + per-channel bias pass."""
     y = conv2d_dense(x, w, stride, (pad, pad, pad, pad))
     return y if bias is None else _PlaneBias.apply(y, bias)
+
+
+class _PixelShuffle2(torch.autograd.Function):
+    """[B, 4 C, h, w] -> [B, C, 2h, 2w] (F.pixel_shuffle, r = 2); backward = the inverse re-arrangement"""
+    @staticmethod
+    def forward(ctx, x):
+        L = segx.lib()
+        x = _c(x)
+        B, C4, h, w = x.shape
+        y = _empty(x, B, C4 // 4, 2 * h, 2 * w)
+        L.pixel_shuffle2(x, y, B * (C4 // 4), h, w, 0)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        dy = _c(dy)
+        B, C, H, W = dy.shape
+        dx = _empty(dy, B, 4 * C, H // 2, W // 2)
+        L.pixel_shuffle2(dy, dx, B * C, H // 2, W // 2, 1)
+        return dx
+
+
+def conv_transpose2x2(x, weight, bias=None):
+    """nn.ConvTranspose2d(Cin, Cout, kernel_size=2, stride=2) (unet_parts.py:53): non-overlapping, so it is a pointwise convolution onto the
+    4 Cout channels (co, a, c) -- on the tile engine -- followed by the 2 x 2 re-arrangement.  weight [Cin, Cout, 2, 2], bias [Cout]."""
+    cin, cout = weight.shape[0], weight.shape[1]
+    wr = weight.permute(1, 2, 3, 0).reshape(4 * cout, cin)                   # rows (co, a, c): the pixel-shuffle channel order
+    br = None if bias is None else bias.repeat_interleave(4)
+    return _PixelShuffle2.apply(conv1x1(x, wr.reshape(4 * cout, cin, 1, 1), br))
 
 
 def maxpool2d(x, k=2):

@@ -5,7 +5,7 @@ Same constructor, attributes and `state_dict` keys as the reference (`inc.double
 `up1.conv.double_conv.0.bias`, `outc.conv.weight`, `polyformer.polyformer_layers.0...`), so a reference checkpoint loads as is.  All arithmetic
 runs on libsegx: the 3x3 convolutions on the implicit-GEMM tile engine (depth-1 volumes), BatchNorm + ReLU as one pass, the 2x2 max-pool on the
 pooling kernels, the x2 bilinear up-sampling with align_corners=True on the one-axis resampling kernels, the class projection as a pointwise GEMM.
-torch.cat / F.pad only move memory.  bilinear=False (transposed convolutions) is not built."""
+torch.cat / F.pad only move memory.  bilinear=False: the 2 x 2 stride-2 transposed convolutions run as pointwise GEMMs + a re-arrangement pass."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -43,17 +43,23 @@ class Down(nn.Module):
 
 
 class Up(nn.Module):
-    """x2 bilinear up-sampling (align_corners=True) of the deeper map, zero-pad to the skip's size, concat [skip, up], DoubleConv with
-    in_channels // 2 middle channels (unet_parts.py:44-70)."""
+    """x2 up-sampling of the deeper map -- bilinear (align_corners=True) or, with bilinear=False, nn.ConvTranspose2d(k 2, s 2) --, zero-pad to
+    the skip's size, concat [skip, up], DoubleConv (unet_parts.py:44-70)."""
 
     def __init__(self, in_channels, out_channels, bilinear=True):
         super().__init__()
-        if not bilinear:
-            raise NotImplementedError('Up(bilinear=False): the transposed-convolution decoder is not built')
-        self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        self.bilinear = bilinear
+        if bilinear:
+            self.conv = DoubleConv(in_channels, out_channels, in_channels // 2)
+        else:                                      # unet_parts.py:52-54: transposed convolution (same `up.weight` / `up.bias` keys), full-width DoubleConv
+            self.up = nn.ConvTranspose2d(in_channels, in_channels // 2, kernel_size=2, stride=2)
+            self.conv = DoubleConv(in_channels, out_channels)
 
     def forward(self, x1, x2):
-        x1 = SF.interp_linear(x1, (2 * x1.shape[2], 2 * x1.shape[3]), align_corners=True)
+        if self.bilinear:
+            x1 = SF.interp_linear(x1, (2 * x1.shape[2], 2 * x1.shape[3]), align_corners=True)
+        else:
+            x1 = SF.conv_transpose2x2(x1, self.up.weight, self.up.bias)
         dy, dx = x2.shape[2] - x1.shape[2], x2.shape[3] - x1.shape[3]
         if dy or dx:
             x1 = F.pad(x1, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])

@@ -319,6 +319,46 @@ def case_unet():
     save('unet_poly', **arrs)
 
 
+def case_unet_deconv():
+    """UNet(bilinear=False): the transposed-convolution decoder (unet_parts.py:52-54), evaluation mode, no Polyformer layer."""
+    R._install_stubs()
+    from networks.unet2d.unet_model import UNet
+    net = R.quiet(UNet, 3, 2, False, None)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.eval()
+    g = torch.Generator().manual_seed(78)
+    X = torch.randn(2, 3, 32, 48, generator=g).requires_grad_(True)
+    G = torch.randn(2, 2, 32, 48, generator=g)
+    Y = net(X); (Y * G).sum().backward()
+    arrs = dict(X=X.detach(), G=G, Y=Y.detach(), dX=X.grad)
+    for k, p_ in net.named_parameters():
+        arrs['grad:' + k] = sample(p_.grad, 256)
+    save('unet_deconv', **arrs)
+
+
+def case_discriminator():
+    """Domain discriminator of the adversarial few-shot recipe (networks/discriminator.py + revgrad.py; train2d.py:876-926): training mode
+    (batch statistics in the four BatchNorm layers), gradient reversal at the input."""
+    R._install_stubs()
+    from networks.discriminator import Discriminator
+    net = Discriminator(8, num_classes=1, do_revgrad=True, num_base_chan=8)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net.train()
+    g = torch.Generator().manual_seed(79)
+    X = torch.randn(3, 8, 32, 32, generator=g).requires_grad_(True)
+    G = torch.randn(3, 1, generator=g)
+    Y = net(X); (Y * G).sum().backward()
+    arrs = dict(X=X.detach(), G=G, Y=Y.detach(), dX=X.grad, keys=np.array(list(net.state_dict().keys())))
+    for k, p_ in net.named_parameters():
+        arrs['grad:' + k] = p_.grad.clone()
+    for k, v in net.state_dict().items():
+        if 'running' in k:
+            arrs['stat:' + k] = v.clone()
+    save('discriminator', **arrs)
+
+
 def case_posbias():
     ss = R.ref_shared()
     g = torch.Generator().manual_seed(13)
@@ -926,7 +966,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, unet_deconv=case_unet_deconv, discriminator=case_discriminator, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullshape=case_fullshape, augment=case_augment, augment3d=case_augment3d, init=case_init)
 

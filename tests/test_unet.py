@@ -44,6 +44,89 @@ def test_conv3x3_bias_and_maxpool2_vs_torch(backend):
         assert_close(a.grad, r.grad, 2e-5, n)
 
 
+def test_conv_transpose2x2_vs_torch(backend):
+    """nn.ConvTranspose2d(k 2, s 2) (unet_parts.py:53) as pointwise GEMM + re-arrangement: forward, dX, dW, db against F.conv_transpose2d."""
+    x = _rnd(2, 8, 5, 7, seed=11).to(backend.dev).requires_grad_(True)
+    w = (0.3 * _rnd(8, 4, 2, 2, seed=12)).to(backend.dev).requires_grad_(True)
+    b = _rnd(4, seed=13).to(backend.dev).requires_grad_(True)
+    xr, wr, br = (t.detach().cpu().clone().requires_grad_(True) for t in (x, w, b))
+    y = SF.conv_transpose2x2(x, w, b)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    assert y.shape == yr.shape == (2, 4, 10, 14)
+    assert_close(y, yr.detach(), 1e-5, 'fwd')
+    G = _rnd(*yr.shape, seed=14)
+    y.backward(G.to(backend.dev)); yr.backward(G)
+    for a, r, n in ((x, xr, 'dx'), (w, wr, 'dw'), (b, br, 'db')):
+        assert_close(a.grad, r.grad, 2e-5, n)
+
+
+@pytest.mark.gpu
+def test_unet_transposed_conv_decoder_vs_reference():
+    """UNet(bilinear=False) (unet_model.py:17-27 with factor 1, unet_parts.py:52-54) against the reference's own network in evaluation mode:
+    logits, input gradient, every parameter gradient (tests/golden/unet_deconv.npz, make_golden.py case_unet_deconv)."""
+    from segtran_amd.networks.unet2d import UNet
+    dev = torch.device('cuda', 0)
+    g = golden_on('unet_deconv', dev)
+    net = UNet(3, 2, False, None)
+    sd = synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()})
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    X = g['X'].clone().requires_grad_(True)
+    Y = net(X)
+    assert_close(Y, g['Y'], 5e-5, 'logits')
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g['dX'], 3e-4, 'dX')
+    grads = dict(net.named_parameters())
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('grad:'))
+    n = 0
+    for k, v in g.items():
+        if k.startswith('grad:'):
+            assert_close(sample(grads[k[5:]].grad, v.numel()), v, 5e-4, k, scale=gscale); n += 1
+    assert n == len(grads)
+
+
+def test_discriminator_and_gradient_reversal_vs_reference(backend):
+    """networks/discriminator.py + revgrad.py (the adversarial branch of the few-shot recipe, train2d.py:876-926, 1259-1284) against the
+    reference's own module in training mode: scores, the REVERSED input gradient, parameter gradients, BatchNorm running statistics; same
+    state_dict keys (the reversal layer shifts the Sequential indices by one, as in the reference)."""
+    from segtran_amd.networks.discriminator import Discriminator
+    g = golden_on('discriminator', backend.dev)
+    net = Discriminator(8, num_classes=1, do_revgrad=True, num_base_chan=8)
+    assert list(net.state_dict().keys()) == [str(k) for k in np.load(os.path.join(os.path.dirname(__file__), 'golden', 'discriminator.npz'))['keys']]
+    net.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}))
+    net = net.to(backend.dev).train()
+    X = g['X'].clone().requires_grad_(True)
+    Y = net(X)
+    assert_close(Y, g['Y'], 5e-5, 'scores')
+    (Y * g['G']).sum().backward()
+    assert_close(X.grad, g['dX'], 5e-4, 'dX (reversed)')
+    grads = dict(net.named_parameters())
+    gscale = max(v.abs().max().item() for k, v in g.items() if k.startswith('grad:'))
+    for k, v in g.items():
+        if k.startswith('grad:'):
+            assert_close(grads[k[5:]].grad, v, 5e-4, k, scale=gscale)
+        if k.startswith('stat:'):
+            assert_close(net.state_dict()[k[5:]], v, 2e-5, k)
+
+
+def test_polyformer_mode_selects_the_reference_parameter_sets():
+    """train2d.py:463-503 (host logic): --polyformer source|target optimises only the chosen pieces of the Squeeze-and-Expansion layers."""
+    from argparse import Namespace
+    from segtran_amd import engine
+    from segtran_amd.networks.unet2d import UNet
+    pargs = Namespace(polyformer_mode='source', num_attractors=16, num_modes=4, tie_qk_scheme='loose', qk_have_bias=True, pos_code_type='lsinu')
+    net = UNet(3, 2, True, pargs)
+    net.discriminator, net.recon = None, None
+    names = lambda mode: sorted(n for n, _ in engine.polyformer_optimized_params(net, mode, is_segtran=False))      # noqa: E731
+    layer = net.polyformer.polyformer_layers[0]
+    assert names('k') == sorted(n for n, _ in layer.in_ator_trans.key.named_parameters())
+    assert names('k,v') == sorted([n for n, _ in layer.in_ator_trans.key.named_parameters()] + [n for n, _ in layer.in_ator_trans.out_trans.first_linear.named_parameters()])
+    assert len(names('allpoly')) == len(list(net.polyformer.polyformer_layers.named_parameters())) and len(names('allnet')) == len(list(net.parameters()))
+    assert names('h') == ['conv.bias', 'conv.weight']
+    opt = engine.init_optimizer(net, 'fundus', polyformer_mode='target', poly_opt_mode='k')
+    assert sum(len(gp['params']) for gp in opt.param_groups) == len(names('k')) and all(gp['weight_decay'] == 0 for gp in opt.param_groups)
+
+
 def _build(dev):
     from argparse import Namespace
     from segtran_amd.networks.unet2d import UNet
