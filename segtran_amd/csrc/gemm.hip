@@ -19,6 +19,7 @@
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
 #include "gemm_x6ws.h"
+#include "gemm_tuned.h"
 
 namespace segx {
 
@@ -172,6 +173,16 @@ extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_de
     const bool plain = d->epilogue == SEGX_EPI_NONE;
     int t = SEGX_TILE_128x128, sk = 1;
     const bool vec = gemm_vec_ok(A, B, d);
+    if (plain && !d->gmax && x6_eligible(call_engine(d), d->M, d->N, vec)) {
+        // measured choices first (gemm_tuned.h); a wave-specialised entry still needs its preconditions (they hold for the shapes it was measured on)
+        const int nbt = d->nb0 * d->nb1; const bool akc_ = d->a_k == 1, bkc_ = d->b_k == 1;
+        for (const TunedGemm& e : kTunedGemm)
+            if (e.M == d->M && e.N == d->N && e.K == d->K && e.nb == nbt && (e.akc != 0) == akc_ && (e.bkc != 0) == bkc_) {
+                if ((e.tile == SEGX_TILE_256x128 || e.tile == SEGX_TILE_WS128x128) && !gemm_ws_ok(d)) break;
+                *tile = e.tile; *splitk = e.splitk;
+                return 0;
+            }
+    }
     if (x6_eligible(call_engine(d), d->M, d->N, vec) && (plain || d->a_k == 1)) plan6(d->M, d->N, d->K, d->nb0 * d->nb1, !plain, plain && !d->gmax, 0, gemm_ws_ok(d), (d->a_k != 1) + (d->b_k != 1), &t, &sk);
     else plan(d->M, d->N, d->K, d->nb0 * d->nb1, vec && plain, plain && !d->gmax, 0, &t, &sk);
     *tile = t; *splitk = sk;

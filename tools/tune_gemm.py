@@ -1,0 +1,85 @@
+"""Measured tile / split-K choices for the GEMM shapes of the BASELINE configurations (GPU box):
+    python tools/tune_gemm.py <shapes.txt> [<shapes.txt> ...] > gpurun_out/<tag>/tune_gemm.txt
+reads the `[bench] (M, N, K, batch, A_kcontig, B_kcontig, splitk, tile, 'x6')` lines bench.py prints under SEGX_BENCH_VERBOSE=2, times every
+bf16x6 tile (4-wave 128x128 / 64x128 / 64x64, wave-specialised 256x128 / 128x128) x a few split-K factors per unique shape with HIP events,
+and prints one line per shape: the planner's choice and time, the best choice and time.  tools/tune_table.py turns the output into
+segtran_amd/csrc/gemm_tuned.h (entries where the measured best beats the cost model's pick by > 4 %), which segx_gemm_plan consults first.
+The cost model stays the fallback for every shape that is not in the table."""
+import os, re, sys, statistics, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from segtran_amd import segx
+
+L = segx.lib()
+L.set_engine('x6')
+dev = torch.device('cuda', 0)
+g = torch.Generator(device='cpu').manual_seed(0)
+shapes = {}
+for path in sys.argv[1:]:
+    for l in open(path):
+        m = re.match(r"\[bench\]\s+\((\d+), (\d+), (\d+), (\d+), (True|False), (True|False), (\d+), (\d+), 'x6'\)\s+(\d+)\s+([\d.]+)", l)
+        if m:
+            M, N, K, nb = (int(m.group(i)) for i in (1, 2, 3, 4))
+            key = (M, N, K, nb, m.group(5) == 'True', m.group(6) == 'True')
+            shapes[key] = shapes.get(key, 0.0) + float(m.group(10))
+print('# %d unique bf16x6 GEMM shapes' % len(shapes), flush=True)
+BUF = {}
+
+
+def buf(n):
+    if n not in BUF:
+        BUF[n] = torch.randn(n, generator=g).to(dev)
+    return BUF[n]
+
+
+def timeit(M, N, K, nb, akc, bkc, tile, sk, reps=3):
+    A, B = buf(nb * M * K), buf(nb * N * K)
+    C = torch.empty(nb * M * N, device=dev)
+    a = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+    b = (0, N * K, K, 1) if bkc else (0, N * K, 1, N)
+    ws = torch.empty(sk * nb * M * N, device=dev) if sk > 1 else None
+    try:
+        L.gemm(A, B, C, M, N, K, a, b, (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile)
+    except RuntimeError:
+        return None
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(4):
+            L.gemm(A, B, C, M, N, K, a, b, (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile)
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / 4)
+    return statistics.median(ts)
+
+
+for key, ms_total in sorted(shapes.items(), key=lambda kv: -kv[1]):
+    M, N, K, nb, akc, bkc = key
+    if 4.0 * nb * (M * K + N * K + 3 * M * N) > 24e9:
+        continue
+    # the planner's own pick
+    import ctypes
+    d = segx.GemmDesc(); d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, 1, nb
+    d.a_b0, d.a_b1, d.a_m, d.a_k = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+    d.b_b0, d.b_b1, d.b_n, d.b_k = (0, N * K, K, 1) if bkc else (0, N * K, 1, N)
+    d.c_b0, d.c_b1, d.c_m = 0, M * N, N; d.alpha = 1.0
+    t0, s0 = ctypes.c_int(0), ctypes.c_int(0)
+    A0 = buf(nb * M * K); B0 = buf(nb * N * K)
+    L.c.segx_gemm_plan(ctypes.c_void_p(A0.data_ptr()), ctypes.c_void_p(B0.data_ptr()), ctypes.byref(d), ctypes.byref(t0), ctypes.byref(s0))
+    base = timeit(M, N, K, nb, akc, bkc, t0.value, s0.value)
+    sks = sorted({1, s0.value} | {s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 128 and K >= 512})
+    best = (base, t0.value, s0.value)
+    for tile in (1, 5, 2, 6, 7):
+        if tile in (6, 7) and K % 32:
+            continue
+        for sk in sks:
+            if sk > 1 and 4.0 * sk * nb * M * N > 6e9:
+                continue
+            if (tile, sk) == (t0.value, s0.value):
+                continue
+            t = timeit(M, N, K, nb, akc, bkc, tile, sk)
+            if t is not None and t < best[0]:
+                best = (t, tile, sk)
+    fl = 2.0 * M * N * K * nb
+    print('shape %d %d %d %d %d %d  plan tile %d sk %d %.4f ms %.1f TF  best tile %d sk %d %.4f ms %.1f TF  gain %.3f' % (
+        M, N, K, nb, int(akc), int(bkc), t0.value, s0.value, base, fl / base / 1e9, best[1], best[2], best[0], fl / best[0] / 1e9, base / best[0]), flush=True)
