@@ -61,18 +61,24 @@ struct ConvFwdLoaderB {
         const int kbase = k0 + (tid >> 7) * (BKT / 2);               // wave-uniform
         float* v = reinterpret_cast<float*>(&r[0]);
         if (PACK8) {
+            // r03: the (channel block, tap) decode runs on the SCALAR unit (kbase is wave-uniform: readfirstlane), and a gather is
+            // `global_load_dword v, v_off, s[base]` -- SGPR base = X + (8 cb + j) channels, ONE per-thread byte offset (window origin + tap, or 0
+            // where the tap falls into the padding) for the eight loads of a (block, tap) pair.  The 64-bit per-gather address chain and the
+            // per-lane decode were ~75 of the ~380 vector instructions a thread issued per k-tile against 48 matrix instructions (VALU-bound).
             const int chan = q.ID * plane;                           // channel stride
+            const int kb0 = SEGX_WAVE_UNIFORM(kbase);
 #pragma unroll
             for (int sub = 0; sub < BKT / 16; ++sub) {
-                const int kb = kbase + 8 * sub;                      // multiple of 8: one (channel block, tap) pair
+                const int kb = kb0 + 8 * sub;                        // multiple of 8: one (channel block, tap) pair
                 const bool kok = kb < kend;
                 const int blk = (kok ? kb : 0) >> 3;
                 const int cb = fdiv(blk, dKV), t = blk - cb * KV, kd = fdiv(t, dKHW), t2 = t - kd * KHW, kh = fdiv(t2, dKW), kw = t2 - kh * q.KW;
                 const unsigned bit = single ? (mk0 >> t) & 1u : ((mk0 >> kd) & (mk1 >> kh) & (mk2 >> kw)) & 1u;
                 const bool ok = kok && bit != 0u;
-                const float* p = X + (int64_t)(cb * 8) * chan + (ok ? pos_off + (kd * q.IH + kh) * q.IW + kw : 0);
+                const unsigned voff = ok ? (unsigned)(pos_off + (kd * q.IH + kh) * q.IW + kw) << 2 : 0u;
+                const ws_gptr b = ws_uniform_base(X + (int64_t)(cb * 8) * chan);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[8 * sub + j] = p[(int64_t)j * chan];
+                for (int j = 0; j < 8; ++j) v[8 * sub + j] = ws_load<float>(b + (int64_t)j * chan * 4, voff);
                 okmask |= (ok ? 0xFFu : 0u) << (8 * sub);
             }
             return okmask;
@@ -205,8 +211,9 @@ struct ConvFwdLoaderB6 {
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             float v[8];
+            const bool ok = ((okmask >> (8 * sub)) & 1u) != 0u;        // the eight k of a (channel block, tap) pair are inside or outside together
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = ((okmask >> (8 * sub + j)) & 1u) ? r[8 * sub + j] : 0.f;
+            for (int j = 0; j < 8; ++j) v[j] = ok ? r[8 * sub + j] : 0.f;
             x6_store8<X6Plane<128>::bytes>(P, x6_off(n, c0 + sub), v);
         }
     }

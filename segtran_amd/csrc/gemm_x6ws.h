@@ -23,9 +23,6 @@
 #ifndef SEGX_LDS_BARRIER
 #define SEGX_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
-#ifndef SEGX_WAVE_UNIFORM
-#define SEGX_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#endif
 
 namespace segx {
 
@@ -210,22 +207,6 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
 // with no address arithmetic on the vector pipe, which belongs to the split.  Only the last stage of a contraction whose length is not a
 // multiple of 32 would need a clamped path: the host sends those shapes, and operands whose offsets do not fit 31 bits, to the 4-wave kernels.
 template <bool KC, int ROWS> struct WsDense6;
-// A wave-uniform base pointer moved to SGPRs (it IS the same in every lane; hipcc cannot always prove it) and typed as a GLOBAL-address-space
-// pointer, plus a 32-bit per-lane byte offset: the load takes the `global_load v_dst, v_offset, s[base]` form -- no 64-bit address arithmetic on
-// the vector pipe.  (A pointer rebuilt from integers without the address space becomes a flat pointer: flat_load waits on two counters.)
-#ifndef SEGX_GLOBAL
-#define SEGX_GLOBAL __attribute__((address_space(1)))
-#endif
-typedef const char SEGX_GLOBAL* ws_gptr;
-__device__ __forceinline__ ws_gptr ws_uniform_base(const void* p) {
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const unsigned lo = SEGX_WAVE_UNIFORM((unsigned)u), hi = SEGX_WAVE_UNIFORM((unsigned)(u >> 32));
-    return (ws_gptr)(((uint64_t)hi << 32) | lo);
-}
-template <class V> __device__ __forceinline__ V ws_load(ws_gptr base, unsigned byte_off) {
-    return *reinterpret_cast<const V SEGX_GLOBAL*>(base + byte_off);
-}
-
 // The contraction range of every work item is a multiple of the 32-k stage (the host sends other shapes to the 4-wave kernels), so a stage
 // has no k edge: no clamped path whose loads hipcc would merge with these (and give both VGPR addresses).
 template <int ROWS>
