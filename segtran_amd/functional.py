@@ -1245,7 +1245,7 @@ class _Conv3dSlices(torch.autograd.Function):
             L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
             L.conv3d_fwd(t[:, c0:], wp, y, B, Cout, geom, sk, _empty(t, sk * y.numel()) if sk > 1 else None, packed=True, x_bs=Ct * vol)
             ys.append(y); geoms.append(geom); c0 += Cin
-        assert c0 == Ct, 'the slices must cover the tensor'
+        assert c0 <= Ct, 'the slices exceed the tensor'      # channels beyond the last slice (another consumer's, e.g. Inception branch 0) get a zero gradient here
         ctx.geoms = geoms
         ctx.save_for_backward(t, *ws)
         return tuple(ys)
@@ -1257,6 +1257,9 @@ class _Conv3dSlices(torch.autograd.Function):
         B, Ct, D, H, W = t.shape
         vol = D * H * W
         dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
+        covered = sum(int(w.shape[1]) for w in ws)
+        if dt is not None and covered < Ct:
+            dt[:, covered:].zero_()
         dws, c0 = [], 0
         for i, (w, dy, geom) in enumerate(zip(ws, dys, ctx.geoms)):
             Cout, Cin, KD, KH, KW = w.shape

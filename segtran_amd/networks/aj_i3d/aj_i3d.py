@@ -71,10 +71,14 @@ class InceptionModule(nn.Module):
             # concatenated filters and ONE BatchNorm + ReLU over the concatenated channels (per-channel: exactly the two layers; one synchronised
             # exchange instead of two), the 3x3x3 convolutions reading their channel slices of that tensor in place (SF.conv3d_slices): x is read
             # once instead of twice, its gradient arrives as one tensor instead of two.
-            w12 = torch.cat([self.b1a.conv3d.weight, self.b2a.conv3d.weight], dim=0)
-            t = SF.bn_act_multi(SF.conv1x1(x, w12), [self.b1a.bn, self.b2a.bn], SF.ACT_RELU)
+            # r03: branch 0's own 1x1x1 convolution joins them (its filters LAST, so the slices of the 3x3x3 convolutions still start at channel 0):
+            # the three pointwise convolutions of the module's input are ONE GEMM, their three BatchNorm layers one statistics / apply pass and one
+            # synchronised exchange; branch 0's output is the tail slice of that tensor.
+            w120 = torch.cat([self.b1a.conv3d.weight, self.b2a.conv3d.weight, self.b0.conv3d.weight], dim=0)
+            t = SF.bn_act_multi(SF.conv1x1(x, w120), [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU)
             y1, y2 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight)
-            return torch.cat([self.b0(x), SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x))], dim=1)
+            o12 = self.b1a.conv3d.weight.shape[0] + self.b2a.conv3d.weight.shape[0]
+            return torch.cat([t[:, o12:], SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x))], dim=1)
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
 
 
