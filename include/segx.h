@@ -43,7 +43,8 @@ enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
 /* per-call engine selector of segx_gemm_desc.engine: 0 (a zero-initialised desc) = the process default set by segx_tune knob 4 */
 enum { SEGX_ENGINE_SEL_DEFAULT = 0, SEGX_ENGINE_SEL_F32 = 1, SEGX_ENGINE_SEL_BF16X6 = 2 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
-       SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7 /* 6, 7: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h */ };
+       SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7, SEGX_TILE_WS128x256 = 8, SEGX_TILE_WS64x256 = 9
+       /* 6..9: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h (M x N of the workgroup tile) */ };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
     int64_t a_b0, a_b1, a_m, a_k;

@@ -178,7 +178,7 @@ extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_de
         const int nbt = d->nb0 * d->nb1; const bool akc_ = d->a_k == 1, bkc_ = d->b_k == 1;
         for (const TunedGemm& e : kTunedGemm)
             if (e.M == d->M && e.N == d->N && e.K == d->K && e.nb == nbt && (e.akc != 0) == akc_ && (e.bkc != 0) == bkc_) {
-                if ((e.tile == SEGX_TILE_256x128 || e.tile == SEGX_TILE_WS128x128) && !gemm_ws_ok(d)) break;
+                if (e.tile >= SEGX_TILE_256x128 && !gemm_ws_ok(d)) break;
                 *tile = e.tile; *splitk = e.splitk;
                 return 0;
             }
@@ -225,8 +225,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.c_split = (int64_t)nbatch * d->M * d->N;
     g.slab = breduce ? 1 : 0;
     if (splitk > 1 || breduce) g.C = d->workspace;
-    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS128x128, "segx_gemm_f32: bad tile %d", d->tile);
-    const bool ws_tile = d->tile == SEGX_TILE_256x128 || d->tile == SEGX_TILE_WS128x128;
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS64x256, "segx_gemm_f32: bad tile %d", d->tile);
+    const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS64x256;
     SEGX_REQUIRE(d->engine >= SEGX_ENGINE_SEL_DEFAULT && d->engine <= SEGX_ENGINE_SEL_BF16X6, "segx_gemm_f32: bad engine selector %d", d->engine);
     const int engine = call_engine(d);
     SEGX_REQUIRE(!ws_tile || engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
@@ -243,7 +243,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
     if (ws_tile && !ws_ok) tile = SEGX_TILE_128x128;
-    const bool ws = x6 && ws_ok && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x128);
+    const bool ws = x6 && ws_ok && tile >= SEGX_TILE_256x128 && tile <= SEGX_TILE_WS64x256;
     if (!vec || (gelu && !ws) || (ws_tile && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile (and the wave-specialised ones) are built
 
     dim3 block(256);
@@ -301,8 +301,11 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
         hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
+        using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>;      // few output channels x many positions (backbone pointwise convolutions)
         if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_LAYOUT(Cfg256x128);
         else if (tile == SEGX_TILE_WS128x128) SEGX_LAUNCHWS_LAYOUT(Cfg128);
+        else if (tile == SEGX_TILE_WS128x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg128x256);
+        else if (tile == SEGX_TILE_WS64x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg64x256);
         else if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
         else if (x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
             switch (x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;

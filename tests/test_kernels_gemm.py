@@ -298,7 +298,7 @@ def test_x6_split_early_schedule_gives_the_same_result(backend):
         L.set_engine(prev)
 
 
-@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128])
+@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128, segx.TILE_WS128x256, segx.TILE_WS64x256])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(520, 264, 96, True, True, 1, 3), (300, 392, 128, True, False, 2, 2), (260, 136, 192, False, False, 3, 2),
                                                  (264, 260, 96, False, True, 1, 2), (264, 136, 104, True, True, 1, 2)])
 def test_x6_wave_specialised_persistent_stream(backend, tile, M, N, K, akc, bkc, sk, nb):

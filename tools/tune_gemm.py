@@ -1,7 +1,7 @@
 """Measured tile / split-K choices for the GEMM shapes of the BASELINE configurations (GPU box):
     python tools/tune_gemm.py <shapes.txt> [<shapes.txt> ...] > gpurun_out/<tag>/tune_gemm.txt
 reads the `[bench] (M, N, K, batch, A_kcontig, B_kcontig, splitk, tile, 'x6')` lines bench.py prints under SEGX_BENCH_VERBOSE=2, times every
-bf16x6 tile (4-wave 128x128 / 64x128 / 64x64, wave-specialised 256x128 / 128x128) x a few split-K factors per unique shape with HIP events,
+bf16x6 tile (4-wave 128x128 / 64x128 / 64x64, wave-specialised 256x128 / 128x128 / 128x256 / 64x256) x a few split-K factors per unique shape with HIP events,
 and prints one line per shape: the planner's choice and time, the best choice and time.  tools/tune_table.py turns the output into
 segtran_amd/csrc/gemm_tuned.h (entries where the measured best beats the cost model's pick by > 4 %), which segx_gemm_plan consults first.
 The cost model stays the fallback for every shape that is not in the table."""
@@ -69,8 +69,8 @@ for key, ms_total in sorted(shapes.items(), key=lambda kv: -kv[1]):
     base = timeit(M, N, K, nb, akc, bkc, t0.value, s0.value)
     sks = sorted({1, s0.value} | {s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 128 and K >= 512})
     best = (base, t0.value, s0.value)
-    for tile in (1, 5, 2, 6, 7):
-        if tile in (6, 7) and K % 32:
+    for tile in (1, 5, 2, 6, 7, 8, 9):
+        if tile >= 6 and K % 32:
             continue
         for sk in sks:
             if sk > 1 and 4.0 * sk * nb * M * N > 6e9:
