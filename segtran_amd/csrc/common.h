@@ -95,6 +95,16 @@ __device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint64_t offset,
     const u32x4 r = philox4(seed, (offset + idx0) >> 2);
     return make_float4(keep_of(r.x, p, inv_keep), keep_of(r.y, p, inv_keep), keep_of(r.z, p, inv_keep), keep_of(r.w, p, inv_keep));
 }
+// Quad form for the MFMA epilogue (a lane owns ONE column of 4 consecutive rows; the 4 lanes of a quad own 4 consecutive columns = one
+// counter per row): lane q of the quad generates the counter of row q, every lane then picks word (lane & 3) of row Q's counter from
+// quad lane Q (DPP quad_perm broadcast -- all 64 lanes must be active).  A quarter of the Philox work of the scalar form, same bits.
+#ifndef SEGX_QUAD_BCAST
+#define SEGX_QUAD_BCAST(v, Q) ((unsigned)__builtin_amdgcn_mov_dpp((int)(v), (Q) * 0x55, 0xf, 0xf, true))
+#endif
+template <int Q> __device__ __forceinline__ unsigned quad_pick(const u32x4& r, unsigned sel) {
+    const unsigned x = SEGX_QUAD_BCAST(r.x, Q), y = SEGX_QUAD_BCAST(r.y, Q), z = SEGX_QUAD_BCAST(r.z, Q), w = SEGX_QUAD_BCAST(r.w, Q);
+    return sel == 0 ? x : sel == 1 ? y : sel == 2 ? z : w;
+}
 // scalar form for kernels whose lanes own scattered elements (MFMA epilogue, column reductions)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
     const u32x4 r = philox4(seed, (offset + idx) >> 2);

@@ -47,6 +47,21 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void gemm_x6_kern
     gemm_epilogue<EPI, Cfg>(acc, g, t);
 }
 
+// The 4-wave kernel with the LEAN operand loaders of gemm_x6ws.h (one uniform base per k-tile + a 32-bit offset per piece computed once per tile:
+// no per-k-tile address arithmetic on the vector pipe -- ~80 of the ~280 vector instructions a thread issued per k-tile).  Whole 32-k tiles and
+// 32-bit operand offsets only (gemm_ws_ok): the host keeps gemm_x6_kernel for everything else.
+template <class Cfg, bool AKC, bool BKC, int EPI, int WPE>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void gemm_x6_lean_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES];
+    const TileCoord t = tile_coord<Cfg>(g);
+    WsDense6<AKC, Cfg::BM> la; WsDense6<BKC, Cfg::BN> lb;
+    la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M, threadIdx.x);
+    lb.begin(g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N, threadIdx.x);
+    f32x16 acc[Cfg::MI][Cfg::NJ];
+    gemm_mainloop_x6<Cfg, WsDense6<AKC, Cfg::BM>, WsDense6<BKC, Cfg::BN>, 0>(acc, la, lb, t.kbeg, t.kend, lds);
+    gemm_epilogue<EPI, Cfg>(acc, g, t);
+}
+
 // The wave-specialised persistent form (gemm_x6ws.h): 512 threads, one workgroup per CU (144 / 96 KB of LDS), grid = min(items, 256).
 template <class Cfg, bool AKC, bool BKC, int EPI, int PRIO = 0>
 __global__ __launch_bounds__(512) void gemm_x6ws_kernel(GemmArgs g) {
@@ -251,10 +266,16 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     using Cfg64x128 = TileCfg<2, 2, 1, 2>;
     if (x6) {
         knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
+#ifdef SEGX_NO_LEAN                                     // bench-only A/B build (tools/build_variant.py)
+#define SEGX_LEAN4 false
+#else
+#define SEGX_LEAN4 true
+#endif
 #define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
-        hipLaunchKernelGGL((gemm_x6_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+        if (SEGX_LEAN4 && ws_ok) hipLaunchKernelGGL((gemm_x6_lean_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+        else hipLaunchKernelGGL((gemm_x6_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
 #define SEGX_LAUNCH6_LAYOUT(CFG, W)                                          \
     do {                                                                     \

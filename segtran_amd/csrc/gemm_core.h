@@ -258,6 +258,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
     const uint64_t roff = g.offset + ((EPI == SEGX_EPI_GELU && g.dropout_p > 0.f && g.rbase) ? *g.rbase : 0);
     const bool full = (m0 + Cfg::BM <= g.M) && (n0 + Cfg::BN <= g.N);
+    const uint64_t ebase = roff + (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1);         // stream position of this matrix's element (0, 0)
+    const bool quad_rng = ((ebase | (uint64_t)ldc) & 3) == 0;                     // a quad's 4 columns share one Philox counter (wave-uniform)
     float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -268,18 +270,30 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
             const float bn = (bias_n && col_ok) ? bias[col] : 0.f;
             const int rbase = m0 + wm * (32 * MI) + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                const bool ok = full || (col_ok && row < g.M);
-                float v = acc[i][j][r] * alpha + bn;
-                if (bias_m) v += ok ? bias[row] : 0.f;
-                if (EPI == SEGX_EPI_GELU) {
-                    if (ok) AUX[(int64_t)row * ldc + col] = v;
-                    v = gelu_erf(v);
-                    if (g.dropout_p > 0.f)
-                        v *= dropout_scale(g.seed, roff, (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1) + (uint64_t)row * ldc + col, g.dropout_p, inv_keep);   // element offset in C: what segx_gelu_bwd regenerates
+            for (int rg = 0; rg < 4; ++rg) {
+                float keep[4] = {1.f, 1.f, 1.f, 1.f};
+                if (EPI == SEGX_EPI_GELU && g.dropout_p > 0.f) {                      // element offset in C: what segx_gelu_bwd regenerates
+                    if (quad_rng) {
+                        const u32x4 pr = philox4(g.seed, (ebase + (uint64_t)(rbase + 8 * rg + (lane & 3)) * ldc + (col & ~3)) >> 2);
+                        keep[0] = keep_of(quad_pick<0>(pr, lane & 3), g.dropout_p, inv_keep); keep[1] = keep_of(quad_pick<1>(pr, lane & 3), g.dropout_p, inv_keep);
+                        keep[2] = keep_of(quad_pick<2>(pr, lane & 3), g.dropout_p, inv_keep); keep[3] = keep_of(quad_pick<3>(pr, lane & 3), g.dropout_p, inv_keep);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) keep[q] = dropout_scale(g.seed, 0, ebase + (uint64_t)(rbase + 8 * rg + q) * ldc + col, g.dropout_p, inv_keep);
+                    }
                 }
-                if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = rg * 4 + q, row = rbase + q + 8 * rg;
+                    const bool ok = full || (col_ok && row < g.M);
+                    float v = acc[i][j][r] * alpha + bn;
+                    if (bias_m) v += ok ? bias[row] : 0.f;
+                    if (EPI == SEGX_EPI_GELU) {
+                        if (ok) AUX[(int64_t)row * ldc + col] = v;
+                        v = gelu_erf(v) * keep[q];
+                    }
+                    if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
+                }
             }
         }
     }

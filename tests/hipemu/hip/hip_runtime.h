@@ -29,6 +29,7 @@
 #define SEGX_LDS_BARRIER() __syncthreads()   /* s_waitcnt lgkmcnt(0); s_barrier of the wave-specialised kernels (gemm_x6ws.h) */
 #define SEGX_GLOBAL                      /* address_space(1) of the device build */
 #define SEGX_WAVE_UNIFORM(x) (x)         /* v_readfirstlane of a value that is uniform over the wave */
+#define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define __constant__ static
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };

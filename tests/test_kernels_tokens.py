@@ -218,17 +218,25 @@ def test_gelu_bwd(backend):
     close(dT, Tr.grad, 1e-5)
 
 
-def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask(backend):
-    """The GEMM epilogue (scattered MFMA lanes) and gelu_bwd (float4 lanes) must regenerate the same mask."""
+@pytest.mark.parametrize('engine', ['f32', 'x6'])
+@pytest.mark.parametrize('Fd,offset', [(36, 8), (36, 12), (35, 8), (64, 4096)])
+def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask(backend, engine, Fd, offset):
+    """The GEMM epilogue (scattered MFMA lanes) and gelu_bwd (float4 lanes) must regenerate the same mask: the epilogue's quad form (one Philox
+    counter per 4 lanes, stream position and row length multiples of 4) and its per-lane form (row length not a multiple of 4) alike."""
     from segtran_amd import segx
     Lb = backend.L
-    R, Fd, p = 70, 36, 0.3
-    H = rnd(R, Fd, seed=32); W = rnd(Fd, Fd, seed=33) * 0.3
+    R, p = 72, 0.3
+    H = rnd(R, 64, seed=32); W = rnd(Fd, 64, seed=33) * 0.3
     Y = torch.zeros(R, Fd); T = torch.zeros(R, Fd)
-    Lb.gemm(H, W, Y, R, Fd, Fd, (0, 0, Fd, 1), (0, 0, Fd, 1), (0, 0, Fd), epilogue=segx.EPI_GELU, aux=T, dropout_p=p, seed=3, offset=8)
+    Lb.set_engine(engine)
+    try:
+        Lb.gemm(H, W, Y, R, Fd, 64, (0, 0, 64, 1), (0, 0, 64, 1), (0, 0, Fd), epilogue=segx.EPI_GELU, aux=T, dropout_p=p, seed=3, offset=offset)
+    finally:
+        Lb.set_engine(segx.DEFAULT_ENGINE)
     k = torch.empty(R * Fd)
-    Lb.gelu_bwd(torch.ones(R * Fd), torch.full((R * Fd,), 30.0), k, R * Fd, p, 3, 8)
+    Lb.gelu_bwd(torch.ones(R * Fd), torch.full((R * Fd,), 30.0), k, R * Fd, p, 3, offset)
     close(Y, F.gelu(T) * k.view(R, Fd), 1e-5)
+    assert 0.2 < (k == 0).float().mean().item() < 0.4
 
 
 @pytest.mark.parametrize('shape,R', [((5, 6), 2), ((3, 4, 2), 1), ((4, 4), 7)])

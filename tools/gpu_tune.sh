@@ -4,7 +4,7 @@
 set -u
 TAG=${1:-r03_t}; ROOT=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT; cd $ROOT
-for CFG in cfg1 cfg3; do
+for CFG in cfg1 cfg3; do  [ -f profiles/r03_w_shapes_$CFG.txt ] && cp profiles/r03_w_shapes_$CFG.txt $OUT/shapes_$CFG.txt && continue
   SEGX_BENCH_VERBOSE=2 timeout 300 python bench.py --config $CFG --steps 3 --warmup 2 --no-brats --no-cpu-baseline --single-order > $OUT/bench_$CFG.json 2> $OUT/shapes_$CFG.txt
 done
 timeout 1500 python tools/tune_gemm.py profiles/r03_i_bench_default_shapes.txt $OUT/shapes_cfg1.txt $OUT/shapes_cfg3.txt > $OUT/tune_gemm.txt 2> $OUT/tune_gemm.err
