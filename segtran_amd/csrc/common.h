@@ -105,6 +105,19 @@ template <int Q> __device__ __forceinline__ unsigned quad_pick(const u32x4& r, u
     const unsigned x = SEGX_QUAD_BCAST(r.x, Q), y = SEGX_QUAD_BCAST(r.y, Q), z = SEGX_QUAD_BCAST(r.z, Q), w = SEGX_QUAD_BCAST(r.w, Q);
     return sel == 0 ? x : sel == 1 ? y : sel == 2 ? z : w;
 }
+// 4 x 4 transpose inside every lane quad (two DPP exchanges: lane ^ 1, lane ^ 2): in, lane i holds v[j] = element (j, i); out, v[j] = element (i, j).
+// The MFMA epilogue turns "one column of 4 rows per lane" into "4 consecutive columns of one row per lane" with it: one 16-byte store instead of
+// four 4-byte stores (the store tail of a short contraction is bound by the number of store instructions, MI355X_MICROARCH.md).  All lanes active.
+#ifndef SEGX_QUAD_XOR
+#define SEGX_QUAD_XOR(v, X) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (X) == 1 ? 0xB1 : 0x4E, 0xf, 0xf, true))
+#endif
+__device__ __forceinline__ void quad_transpose4(float (&v)[4], bool odd1, bool odd2) {
+    float s, r;
+    s = odd1 ? v[0] : v[1]; r = SEGX_QUAD_XOR(s, 1); v[0] = odd1 ? r : v[0]; v[1] = odd1 ? v[1] : r;
+    s = odd1 ? v[2] : v[3]; r = SEGX_QUAD_XOR(s, 1); v[2] = odd1 ? r : v[2]; v[3] = odd1 ? v[3] : r;
+    s = odd2 ? v[0] : v[2]; r = SEGX_QUAD_XOR(s, 2); v[0] = odd2 ? r : v[0]; v[2] = odd2 ? v[2] : r;
+    s = odd2 ? v[1] : v[3]; r = SEGX_QUAD_XOR(s, 2); v[1] = odd2 ? r : v[1]; v[3] = odd2 ? v[3] : r;
+}
 // scalar form for kernels whose lanes own scattered elements (MFMA epilogue, column reductions)
 __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t offset, uint64_t idx, float p, float inv_keep) {
     const u32x4 r = philox4(seed, (offset + idx) >> 2);

@@ -243,7 +243,9 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
 }
 
 // MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int EPI, class Cfg = Cfg128>
+// VST: 16-byte stores through quad_transpose4 where the output allows (the 4-wave kernels: +3..4 % on short contractions; the wave-specialised
+// kernels keep 4-byte stores -- their one consumer wave per SIMD pays the transposes' dependent DPP chains in full, r03_z: -4..9 %)
+template <int EPI, class Cfg = Cfg128, bool VST = true>
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::NJ], const GemmArgs& g, const TileCoord& t) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -260,6 +262,8 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     const bool full = (m0 + Cfg::BM <= g.M) && (n0 + Cfg::BN <= g.N);
     const uint64_t ebase = roff + (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1);         // stream position of this matrix's element (0, 0)
     const bool quad_rng = ((ebase | (uint64_t)ldc) & 3) == 0;                     // a quad's 4 columns share one Philox counter (wave-uniform)
+    // 16-byte stores (quad_transpose4): row length and extent multiples of 4 (a quad of columns is wholly inside or outside), 16-byte aligned bases
+    const bool vec_st = VST && (((uint64_t)ldc | (uint64_t)g.N) & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | (EPI == SEGX_EPI_GELU ? reinterpret_cast<uintptr_t>(AUX) : 0)) & 15) == 0;
     float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -282,17 +286,31 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
                         for (int q = 0; q < 4; ++q) keep[q] = dropout_scale(g.seed, 0, ebase + (uint64_t)(rbase + 8 * rg + q) * ldc + col, g.dropout_p, inv_keep);
                     }
                 }
+                float pre[4], out[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int r = rg * 4 + q, row = rbase + q + 8 * rg;
                     const bool ok = full || (col_ok && row < g.M);
                     float v = acc[i][j][r] * alpha + bn;
                     if (bias_m) v += ok ? bias[row] : 0.f;
-                    if (EPI == SEGX_EPI_GELU) {
-                        if (ok) AUX[(int64_t)row * ldc + col] = v;
-                        v = gelu_erf(v) * keep[q];
+                    pre[q] = v;
+                    if (EPI == SEGX_EPI_GELU) v = gelu_erf(v) * keep[q];
+                    out[q] = v;
+                    if (ok) vmax = fmaxf(vmax, v);
+                    if (!vec_st && ok) {
+                        if (EPI == SEGX_EPI_GELU) AUX[(int64_t)row * ldc + col] = pre[q];
+                        C[(int64_t)row * ldc + col] = v;
                     }
-                    if (ok) { vmax = fmaxf(vmax, v); C[(int64_t)row * ldc + col] = v; }
+                }
+                if (vec_st) {                              // lane (quad, i): row rbase + 8 rg + i, columns (col & ~3) .. + 3
+                    const int row = rbase + 8 * rg + (lane & 3), col0 = col & ~3;
+                    const bool ok = full || (col0 < g.N && row < g.M);
+                    quad_transpose4(out, lane & 1, lane & 2);
+                    if (EPI == SEGX_EPI_GELU) {
+                        quad_transpose4(pre, lane & 1, lane & 2);
+                        if (ok) *reinterpret_cast<float4*>(AUX + (int64_t)row * ldc + col0) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+                    }
+                    if (ok) *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col0) = make_float4(out[0], out[1], out[2], out[3]);
                 }
             }
         }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
             x6ws_stage_mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
             par ^= 1;
         }
-        gemm_epilogue<EPI, Cfg>(acc, g, t);               // an empty split-K slab writes zeros
+        gemm_epilogue<EPI, Cfg, false>(acc, g, t);        // an empty split-K slab writes zeros
     }
 }
 

@@ -30,6 +30,7 @@
 #define SEGX_GLOBAL                      /* address_space(1) of the device build */
 #define SEGX_WAVE_UNIFORM(x) (x)         /* v_readfirstlane of a value that is uniform over the wave */
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
+#define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
 #define __constant__ static
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };

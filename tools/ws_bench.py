@@ -37,6 +37,9 @@ SHAPES = {
              ('P.V', 4096, 1792, 256, True, True, 24, 1, False), ('attn small 4096x896x256', 4096, 896, 256, True, False, 24, 1, False),
              ('l3 linear 448', 24576, 448, 448, True, True, 4, 1, False), ('dW small TN', 448, 448, 24576, False, False, 4, 8, False),
              ('scores QK^T', 4096, 256, 1792, True, False, 24, 1, False), ('fusion GELU P.(vW)', 4096, 1792, 256, True, False, 24, 1, True)],
+    'k256': [('P.V', 4096, 1792, 256, True, True, 24, 1, False), ('fusion GELU P.(vW)', 4096, 1792, 256, True, False, 24, 1, True),
+             ('attn small 4096x896x256', 4096, 896, 256, True, False, 24, 1, False), ('K=512', 4096, 1792, 512, True, True, 24, 1, False),
+             ('scores QK^T', 4096, 256, 1792, True, False, 24, 1, False)],
     'ablate': [('group_linear fwd NT', 24576, 1792, 1792, True, True, 4, 1, False), ('scores QK^T NT', 4096, 256, 1792, True, True, 24, 1, False),
                ('P.V', 4096, 1792, 256, True, True, 24, 1, False), ('square 8192', 8192, 8192, 8192, True, True, 1, 1, False)],
     'pmc': [('group_linear fwd NT', 24576, 1792, 1792, True, True, 4, 1, False), ('scores QK^T', 4096, 256, 1792, True, False, 24, 1, False),
@@ -50,6 +53,8 @@ if which == 'pmc':
     ARMS = PMC_ARMS
 if which == 'lean':                                       # 4-wave kernels: lean loaders (prod) against the per-k-tile address form (variant 'nolean')
     ARMS = [(n, t, 0) for t in (1, 5, 2) for n in ('prod', 'nolean') if n in LIBS]
+if which == 'k256':                                       # short contractions: product tiles against any variant builds present
+    ARMS = [('prod', 1, 0), ('prod', 6, 0), ('prod', 7, 0)] + [(n, t, 0) for n in LIBS if n != 'prod' for t in (1, 6)]
 if which == 'ablate':                                     # knob 6 on the wave-specialised kernel: 2 no split math, 3 no global loads, 4 no LDS stores, 5 consumers alone
     ARMS = [('prod', 6, v) for v in (0, 1, 2, 3, 4, 5)] + [('prod', 7, v) for v in (0, 2, 5)]
 
