@@ -10,6 +10,11 @@ from segtran_amd.dataloaders import datasets3d as D3
 from util import golden, assert_close
 
 
+def cpu(v):
+    """Expected values live on the host (the hip backend makes cuda the default device)."""
+    return torch.tensor(v, device='cpu')
+
+
 def test_rotflip_crop_3d_vs_reference_classes(backend):
     """RandomRotFlip -> RandomCrop (train3d.py:571-578): same numpy seed -> same rotation count, flip axis, pads and crop offsets as the
     reference, bit-identical voxels; as two transforms and as the fused single gather."""
@@ -69,13 +74,13 @@ def test_resize2d_known_answers(backend):
     dev = backend.dev
     x = torch.arange(16, dtype=torch.float32).reshape(1, 4, 4).to(dev)
     # nearest, cv2 convention floor(dst * in / out): 4 -> 2 picks rows / columns 0 and 2; 2x up-sampling repeats
-    assert torch.equal(SF.resize2d(x, (2, 2), 'nearest').cpu(), torch.tensor([[[0., 2.], [8., 10.]]]))
+    assert torch.equal(SF.resize2d(x, (2, 2), 'nearest').cpu(), cpu([[[0., 2.], [8., 10.]]]))
     assert torch.equal(SF.resize2d(x, (8, 8), 'nearest').cpu()[0, ::2, ::2], x.cpu()[0])
     for mode in ('nearest', 'linear', 'cubic'):                # identity size: every mode returns the input
         assert_close(SF.resize2d(x, (4, 4), mode), x, 1e-6, mode)
     # linear, half-pixel centres: 2x down-sampling of a ramp averages pixel pairs
-    assert_close(SF.resize2d(x, (2, 2), 'linear'), torch.tensor([[[2.5, 4.5], [10.5, 12.5]]]), 1e-6, 'linear down')
-    big = torch.randn(2, 9, 7, generator=torch.Generator().manual_seed(1))
+    assert_close(SF.resize2d(x, (2, 2), 'linear'), cpu([[[2.5, 4.5], [10.5, 12.5]]]), 1e-6, 'linear down')
+    big = torch.randn(2, 9, 7, generator=torch.Generator(device='cpu').manual_seed(1), device='cpu')
     ref = torch.nn.functional.interpolate(big[None], size=(13, 11), mode='bilinear', align_corners=False)[0]
     assert_close(SF.resize2d(big.to(dev), (13, 11), 'linear'), ref, 1e-5, 'linear vs F.interpolate')
     # cubic, A = -0.75: cv2.INTER_CUBIC and PyTorch's 'bicubic' share the kernel, the half-pixel convention and the replicated border
@@ -83,7 +88,7 @@ def test_resize2d_known_answers(backend):
     assert_close(SF.resize2d(big.to(dev), (13, 11), 'cubic'), ref, 1e-5, 'cubic vs F.interpolate')
     # a constant image stays constant; quantisation rounds and clamps to the uint8 range
     c = torch.full((1, 5, 6), 200.0, device=dev)
-    assert torch.equal(SF.resize2d(c, (9, 4), 'cubic', quantize=True).cpu(), torch.full((1, 9, 4), 200.0))
+    assert torch.equal(SF.resize2d(c, (9, 4), 'cubic', quantize=True).cpu(), torch.full((1, 9, 4), 200.0, device='cpu'))
     edge = torch.tensor([[[0., 255., 0., 255.]]], device=dev).repeat(1, 4, 1)
     q = SF.resize2d(edge, (4, 9), 'cubic', quantize=True).cpu()
     assert q.min() >= 0 and q.max() <= 255 and torch.equal(q, q.round())
@@ -96,9 +101,9 @@ def test_color_ops_and_normalize_known_answers(backend):
     luma = [0.299 * 10 + 0.587 * 20 + 0.114 * 30, 0.299 * 200 + 0.587 * 100 + 0.114 * 50]   # 18.15, 124.2
     f = torch.tensor([1.5])
     # brightness: f * x, rounded, clamped at 255
-    assert torch.equal(SF.color_blend(img, 'brightness', f).cpu().reshape(3, 2), torch.tensor([[15., 255.], [30., 150.], [45., 75.]]))
+    assert torch.equal(SF.color_blend(img, 'brightness', f).cpu().reshape(3, 2), cpu([[15., 255.], [30., 150.], [45., 75.]]))
     # saturation: f * x + (1 - f) * round(luma)
-    lq = torch.tensor([float(int(luma[0] + 0.5)), float(int(luma[1] + 0.5))])
+    lq = cpu([float(int(luma[0] + 0.5)), float(int(luma[1] + 0.5))])
     exp = ((1.5 * px - 0.5 * lq[None, :]) + 0.5).floor().clamp(0, 255)
     assert torch.equal(SF.color_blend(img, 'saturation', f).cpu().reshape(3, 2), exp)
     # contrast: pivot = int(mean of the rounded luma image + 0.5) = int((18 + 124) / 2 + 0.5) = 71
@@ -107,14 +112,14 @@ def test_color_ops_and_normalize_known_answers(backend):
     assert torch.equal(SF.color_blend(img, 'contrast', f).cpu().reshape(3, 2), exp)
     # grayscale alpha 0.25 (factor = 0.75), float arithmetic without quantisation
     y = SF.color_blend(img, 'grayscale', torch.tensor([0.75]), quantize=False).cpu().reshape(3, 2)
-    assert_close(y, 0.75 * px + 0.25 * torch.tensor([luma, luma, luma]), 1e-6, 'grayscale')
+    assert_close(y, 0.75 * px + 0.25 * cpu([luma, luma, luma]), 1e-6, 'grayscale')
     # identity factors leave the image alone; per-sample factors are independent
     two = img.repeat(2, 1, 1, 1)
     out = SF.color_blend(two, 'brightness', torch.tensor([1.0, 0.5])).cpu()
     assert torch.equal(out[0], img.cpu()[0]) and torch.equal(out[1], (img.cpu()[0] * 0.5 + 0.5).floor())
     # ToTensor + Normalize
     n = SF.normalize(img, (0.5, 0.4, 0.3), (0.2, 0.25, 0.5)).cpu().reshape(3, 2)
-    exp = (px / 255.0 - torch.tensor([[0.5], [0.4], [0.3]])) / torch.tensor([[0.2], [0.25], [0.5]])
+    exp = (px / 255.0 - cpu([[0.5], [0.4], [0.3]])) / cpu([[0.2], [0.25], [0.5]])
     assert_close(n, exp, 1e-6, 'normalize')
 
 
