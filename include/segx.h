@@ -66,11 +66,23 @@ typedef struct {
                                        * operand shared by the batch (conv weights) in ONE deterministic reduction; needs workspace =
                                        * max(1, splitk)*nb0*nb1*M*N floats, EPI_NONE, no gmax; c_b0 / c_b1 are ignored */
     int32_t engine;                   /* SEGX_ENGINE_SEL_*: the tile engine of THIS call (0 = process default) */
+    const void* b_planes;             /* optional: the B operand split ahead of time by segx_x6_presplit(B, N, K, b_n, b_k, nb0, nb1, b_b0, b_b1, ...) -- a
+                                       * speed hint for a B that many row tiles share (a weight matrix: otherwise every workgroup that stages it splits
+                                       * it again).  Used by the wave-specialised 256x128 / 128x256 bf16x6 kernels with a plain epilogue; every other
+                                       * path reads B itself, which must stay valid.  Results are bit-identical either way. */
+    int64_t bp_b0, bp_b1;             /* batch strides of b_planes in bf16 elements (3*N*K per matrix; 0 = shared) */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are
  * ignored): callers that want split-K size the workspace from *splitk and pass both back through the desc. */
 int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
+/* The three-plane bf16 image of an fp32 operand for segx_gemm_desc.b_planes (bf16x6 engine): W is nb0 x nb1 matrices of rows x K floats
+ * with element strides (s_b0, s_b1, s_row, s_k), one of s_row / s_k equal to 1, K % 8 == 0; planes receives, per matrix, [3][rows][K] bf16
+ * (x = hi + mid + lo, each step rounded to nearest even: the split the kernels otherwise do in registers), matrices in (z0, z1) order:
+ * segx_x6_presplit_elems(rows, K, nb0, nb1) 2-byte elements, 16-byte aligned.  The reference has no counterpart (its GEMMs are torch.matmul,
+ * segtran_shared.py:414-449, 559-567); this removes the per-workgroup re-split of shared weights. */
+int64_t segx_x6_presplit_elems(int rows, int K, int nb0, int nb1);
+int segx_x6_presplit(const float* W, int rows, int K, int64_t s_row, int64_t s_k, int nb0, int nb1, int64_t s_b0, int64_t s_b1, void* planes, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------

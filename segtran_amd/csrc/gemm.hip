@@ -69,6 +69,38 @@ __global__ __launch_bounds__(512) void gemm_x6ws_kernel(GemmArgs g) {
     x6ws_body<Cfg, DenseMk6<Cfg, AKC, BKC>, EPI, PRIO>(g, DenseMk6<Cfg, AKC, BKC>{}, lds);
 }
 
+// ... with the B operand split ahead of time (segx_x6_presplit; WsPre6): plain epilogue, whole 32-k stages, 256- or 128-row B tiles
+template <class Cfg, bool AKC>
+__global__ __launch_bounds__(512) void gemm_x6ws_pre_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[X6WsLds<Cfg>::BYTES];
+    x6ws_body<Cfg, PreMk6<Cfg, AKC>, SEGX_EPI_NONE, 0>(g, PreMk6<Cfg, AKC>{}, lds);
+}
+
+// fp32 operand [nb][rows][K] (any of the two unit-stride layouts) -> three bf16 planes [nb][plane][rows][K], k contiguous: x = hi + mid + lo with the
+// rounding of split3_pair.  A thread owns 8 consecutive k of one row.  Threads run along k for k-contiguous input (coalesced loads and stores), along the
+// rows for row-contiguous input (coalesced loads, 16-byte stores one row apart: weights only, a few MB).
+__global__ __launch_bounds__(256) void x6_presplit_kernel(const float* __restrict__ W, unsigned short* __restrict__ P, int rows, int K, int64_t s_row, int64_t s_k,
+                                                          int nb1, int64_t s_b0, int64_t s_b1, int64_t per_batch) {
+    const int kch = K >> 3;
+    const int z = blockIdx.y, z0 = z / nb1, z1 = z - z0 * nb1;
+    const float* __restrict__ w = W + z0 * s_b0 + z1 * s_b1;
+    unsigned short* __restrict__ o = P + (int64_t)z * 3 * per_batch;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < per_batch / 8; idx += (int64_t)gridDim.x * blockDim.x) {
+        int row, kc;
+        if (s_k == 1) { row = (int)(idx / kch); kc = (int)(idx - (int64_t)row * kch); }
+        else { kc = (int)(idx / rows); row = (int)(idx - (int64_t)kc * rows); }
+        float v[8];
+        const float* src = w + (int64_t)row * s_row + (int64_t)(kc * 8) * s_k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)j * s_k];
+        const Split2 a = split3_pair(v[0], v[1]), b = split3_pair(v[2], v[3]), c = split3_pair(v[4], v[5]), d = split3_pair(v[6], v[7]);
+        const int64_t e = (int64_t)row * K + kc * 8;
+        *reinterpret_cast<uint4*>(o + e) = make_uint4(a.h, b.h, c.h, d.h);
+        *reinterpret_cast<uint4*>(o + per_batch + e) = make_uint4(a.m, b.m, c.m, d.m);
+        *reinterpret_cast<uint4*>(o + 2 * per_batch + e) = make_uint4(a.l, b.l, c.l, d.l);
+    }
+}
+
 // Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,
@@ -239,6 +271,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     const int nbatch = d->nb0 * d->nb1;
     g.c_split = (int64_t)nbatch * d->M * d->N;
     g.slab = breduce ? 1 : 0;
+    g.Bp = nullptr; g.bp_plane = g.bp_b0 = g.bp_b1 = 0;
     if (splitk > 1 || breduce) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS64x256, "segx_gemm_f32: bad tile %d", d->tile);
     const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS64x256;
@@ -323,7 +356,23 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
         using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>;      // few output channels x many positions (backbone pointwise convolutions)
-        if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_LAYOUT(Cfg256x128);
+        // pre-split B operand (segx_x6_presplit): the wave-specialised 256 x 128 / 128 x 256 kernels with a copy-only B loader; anything else ignores the planes
+        const bool pre = d->b_planes && ws && !gelu && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x256);
+        if (pre) {
+            g.Bp = static_cast<const unsigned short*>(d->b_planes); g.bp_plane = (int64_t)d->N * d->K; g.bp_b0 = d->bp_b0; g.bp_b1 = d->bp_b1;
+#define SEGX_LAUNCHWS_PRE(CFG)                                                                             \
+    do {                                                                                                   \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
+        SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
+        const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);                             \
+        if (akc) hipLaunchKernelGGL((gemm_x6ws_pre_kernel<CFG, true>), dim3(G), dim3(512), 0, stream, g);  \
+        else hipLaunchKernelGGL((gemm_x6ws_pre_kernel<CFG, false>), dim3(G), dim3(512), 0, stream, g);     \
+    } while (0)
+            if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_PRE(Cfg256x128); else SEGX_LAUNCHWS_PRE(Cfg128x256);
+#undef SEGX_LAUNCHWS_PRE
+        }
+        else if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_LAYOUT(Cfg256x128);
         else if (tile == SEGX_TILE_WS128x128) SEGX_LAUNCHWS_LAYOUT(Cfg128);
         else if (tile == SEGX_TILE_WS128x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg128x256);
         else if (tile == SEGX_TILE_WS64x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg64x256);
@@ -400,4 +449,20 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         rc = check_launch("segx_gemm_f32/splitk_reduce");
     }
     return rc;
+}
+
+extern "C" int64_t segx_x6_presplit_elems(int rows, int K, int nb0, int nb1) { return (int64_t)nb0 * nb1 * 3 * rows * K; }
+
+extern "C" int segx_x6_presplit(const float* W, int rows, int K, int64_t s_row, int64_t s_k, int nb0, int nb1, int64_t s_b0, int64_t s_b1, void* planes,
+                                void* stream_) {
+    using namespace segx;
+    SEGX_REQUIRE(W && planes, "segx_x6_presplit: null pointer");
+    SEGX_REQUIRE(rows > 0 && K > 0 && K % 8 == 0 && nb0 > 0 && nb1 > 0, "segx_x6_presplit: rows=%d K=%d (a multiple of 8) nb=%dx%d", rows, K, nb0, nb1);
+    SEGX_REQUIRE(s_row == 1 || s_k == 1, "segx_x6_presplit: the operand needs a unit stride (s_row=%lld s_k=%lld)", (long long)s_row, (long long)s_k);
+    SEGX_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "segx_x6_presplit: planes must be 16-byte aligned");
+    const int64_t per_batch = (int64_t)rows * K;
+    const int64_t blocks = (per_batch / 8 + 255) / 256;
+    hipLaunchKernelGGL(x6_presplit_kernel, dim3((unsigned)i64min(blocks, 65536), nb0 * nb1), dim3(256), 0, (hipStream_t)stream_, W,
+                       static_cast<unsigned short*>(planes), rows, K, s_row, s_k, nb1, s_b0, s_b1, per_batch);
+    return check_launch("segx_x6_presplit");
 }

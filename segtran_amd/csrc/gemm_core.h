@@ -39,6 +39,7 @@ struct GemmArgs {
     float dropout_p; uint64_t seed, offset; const uint64_t* rbase;     // rbase: device-side base added to offset (segx_set_rng_base)
     int k_chunk;                    // split-K: this launch covers k in [z_k*k_chunk, min(K, (z_k+1)*k_chunk))
     int splitk; int64_t c_split;    // slab stride in the workspace
+    const unsigned short* Bp; int64_t bp_plane, bp_b0, bp_b1;   // B operand pre-split into three bf16 planes (segx_x6_presplit), element strides; NULL = none
     int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
 };
 

@@ -268,6 +268,62 @@ struct DenseMk6 {
     }
 };
 
+// B operand split ahead of time (segx_x6_presplit: three bf16 planes [plane][row][K], k contiguous, the same rounding as split3_pair): a producer moves
+// 16-byte chunks (8 k of one row and plane) global -> registers -> LDS with NO arithmetic.  The split is what the producers cannot hide (§5c-r3 of
+// without it the kernel runs at the consumers-alone rate); a weight matrix is otherwise re-split by every workgroup that stages it
+// (the 1792 x 1792 weights of a 24576-row projection: 96 to 192 times per launch).  Same LDS image as the in-kernel split, hence bit-identical results.
+template <int ROWS>
+struct WsPre6 {
+    static constexpr int NPP = ROWS * 4 / 256;              // 16-byte pieces per thread and plane (piece f = ptid + 256 i: row f / 4, chunk f % 4)
+    static constexpr int NREG = 3 * NPP * 4;
+    const unsigned short* base; int64_t plane;               // plane stride in elements
+    unsigned off[NPP]; unsigned rowmask;
+    __device__ __forceinline__ void begin(const unsigned short* b, int64_t plane_, int K, int row0, int rows, int ptid) {
+        base = b; plane = plane_; rowmask = 0u;
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) {
+            const int f = ptid + 256 * i, row = row0 + (f >> 2);
+            const bool ok = row < rows;
+            off[i] = (unsigned)((((int64_t)(ok ? row : rows - 1)) * K + ((f & 3) << 3)) << 1);
+            rowmask |= ok ? (1u << i) : 0u;
+        }
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const ws_gptr b = ws_uniform_base(base + p * plane + k0);
+#pragma unroll
+            for (int i = 0; i < NPP; ++i) {
+                const f32x4 v = ws_load<f32x4>(b, off[i]);
+                r[4 * (p * NPP + i)] = v.x; r[4 * (p * NPP + i) + 1] = v.y; r[4 * (p * NPP + i) + 2] = v.z; r[4 * (p * NPP + i) + 3] = v.w;
+            }
+        }
+        return rowmask;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned okmask, unsigned char* __restrict__ P, int ptid) const {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < NPP; ++i) {
+                const int f = ptid + 256 * i, e = 4 * (p * NPP + i);
+                const bool ok = (okmask >> i) & 1u;
+                uint4 w;
+                w.x = ok ? __float_as_uint(r[e]) : 0u; w.y = ok ? __float_as_uint(r[e + 1]) : 0u;
+                w.z = ok ? __float_as_uint(r[e + 2]) : 0u; w.w = ok ? __float_as_uint(r[e + 3]) : 0u;
+                *reinterpret_cast<uint4*>(P + p * X6Plane<ROWS>::bytes + x6_off(f >> 2, f & 3)) = w;
+            }
+    }
+};
+
+template <class Cfg, bool AKC>
+struct PreMk6 {
+    using LA = WsDense6<AKC, Cfg::BM>; using LB = WsPre6<Cfg::BN>;
+    __device__ __forceinline__ void make(const GemmArgs& g, const TileCoord& t, LA& la, LB& lb, int ptid) const {
+        la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M, ptid);
+        lb.begin(g.Bp + t.z0 * g.bp_b0 + t.z1 * g.bp_b1, g.bp_plane, g.K, t.n0, g.N, ptid);
+    }
+};
+
 // host-side cost model: a persistent launch of one workgroup per CU walks ceil(items / 256) rounds of work items, each costing
 // k-tiles x stage time + a per-tile epilogue (consumers only: the matrix pipe idles while a finished tile is written).  Constants from the
 // r03_f device sweep: 256 x 128: 24576 x 1792 x 1792 x 4 = 21 rounds x 56 stages in 2.87 ms, 8192^3 = 8 x 256 in 4.78 ms, K = 256 tiles 29 us;

@@ -27,7 +27,8 @@ class GemmDesc(ctypes.Structure):
                 ('alpha', c_f), ('epilogue', c_i), ('bias_mode', c_i), ('bias_b1', c_l),
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
-                ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i), ('engine', c_i)]
+                ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i), ('engine', c_i),
+                ('b_planes', c_p), ('bp_b0', c_l), ('bp_b1', c_l)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
@@ -55,7 +56,7 @@ class SegxLib:
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
-            fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk')) else c_i
+            fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk', '_elems')) else c_i
 
     # ---- tile engine -------------------------------------------------------------------------
     ENGINES = {'f32': 0, 'x6': 1}
@@ -105,12 +106,15 @@ class SegxLib:
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
              bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
-             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None):
+             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None, b_planes=None):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
         a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
         splitk = 0: take tile and split factor from segx_gemm_plan and allocate the slab workspace here.
         batch_reduce: C is ONE [M, N] matrix = the sum over all batch members (see segx_gemm_desc.batch_reduce).
-        engine: None = the process default (set_engine), 'f32' / 'x6' = the tile engine of THIS call (segx_gemm_desc.engine)."""
+        engine: None = the process default (set_engine), 'f32' / 'x6' = the tile engine of THIS call (segx_gemm_desc.engine).
+        b_planes: (planes tensor from x6_presplit(B ...), bp_b0, bp_b1) -- B split ahead of time (segx_gemm_desc.b_planes).  Bit-identical results;
+        measured (tools/pre_bench.py, profiles/r03_ad_pre_bench.txt): +-0 on the 1792-wide projections, +5..9 % on 896-wide ones on the 256 x 128
+        kernel (which the planner no longer picks for them), so the model code does not use it."""
         self._chk_t(A, B, C, bias, aux, gmax, workspace)
         d = GemmDesc()
         d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
@@ -120,6 +124,9 @@ class SegxLib:
         d.alpha, d.epilogue, d.bias_mode, d.bias_b1, d.bias_b0 = alpha, epilogue, bias_mode, bias_b1, bias_b0
         d.bias, d.aux, d.gmax = _ptr(bias), _ptr(aux), _ptr(gmax)
         d.dropout_p, d.seed, d.offset = dropout_p, seed, offset
+        if b_planes is not None:
+            self._chk_t(b_planes[0])
+            d.b_planes, d.bp_b0, d.bp_b1 = _ptr(b_planes[0]), b_planes[1], b_planes[2]
         if splitk == 0:
             t, sk = c_i(0), c_i(0)
             self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
@@ -142,6 +149,16 @@ class SegxLib:
         else:
             rc = self.c.segx_gemm_f32(_ptr(A), _ptr(B), _ptr(C), ctypes.byref(d), self.stream(C))
         self.check(rc, 'segx_gemm_f32')
+
+    def x6_presplit(self, W, rows, K, s_row, s_k, nb=(1, 1), s_b=(0, 0)):
+        """Three-plane bf16 image of an fp32 operand (segx_x6_presplit) for gemm(b_planes=...): returns (planes, bp_b0, bp_b1).  A batch dimension
+        with stride 0 (operand shared over it) is split once."""
+        e0, e1 = (nb[0] if s_b[0] else 1), (nb[1] if s_b[1] else 1)
+        planes = torch.empty(self.c.segx_x6_presplit_elems(rows, K, e0, e1), dtype=torch.int16, device=W.device)
+        self._chk_t(W)
+        self.check(self.c.segx_x6_presplit(_ptr(W), rows, K, s_row, s_k, e0, e1, s_b[0], s_b[1], _ptr(planes), self.stream(W)), 'segx_x6_presplit')
+        per = 3 * rows * K
+        return planes, (e1 * per if s_b[0] else 0), (per if s_b[1] else 0)
 
     # ---- token row kernels (tokens.hip) ---------------------------------------------------------
     def _call(self, name, ref, *args):
@@ -491,6 +508,7 @@ _SIGS = {
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
+    'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
     'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',

@@ -66,7 +66,7 @@ def test_gemm_desc_layout_matches_header():
         stmt = stmt.strip()
         if not stmt:
             continue
-        decl = re.sub(r'^(const\s+)?(int32_t|int64_t|uint64_t|float)\s*\*?', '', stmt)
+        decl = re.sub(r'^(const\s+)?(int32_t|int64_t|uint64_t|float|void)\s*\*?', '', stmt)
         names += [n.strip().lstrip('*').strip() for n in decl.split(',')]
     assert names == [f[0] for f in segx.GemmDesc._fields_], (names, [f[0] for f in segx.GemmDesc._fields_])
 

@@ -322,6 +322,70 @@ def test_x6_wave_specialised_persistent_stream(backend, tile, M, N, K, akc, bkc,
     assert torch.equal(C, C0)
 
 
+def _split3_host(x):
+    """x = hi + mid + lo in bf16, each step rounded to nearest even (what split3_pair does in registers); returns the three int16 bit planes."""
+    x = x.detach().float().cpu()
+    hi = x.to(torch.bfloat16); r1 = x - hi.float()
+    mid = r1.to(torch.bfloat16); r2 = r1 - mid.float()
+    lo = r2.to(torch.bfloat16)
+    return [t.view(torch.int16) for t in (hi, mid, lo)]
+
+
+@pytest.mark.parametrize('kcontig', [True, False])
+def test_x6_presplit_planes_are_the_kernel_split(backend, kcontig):
+    """segx_x6_presplit: [nb][3][rows][K] bf16 planes of an fp32 operand in either unit-stride layout, batch strides, a shared (stride-0) batch dim;
+    bit-identical to the round-to-nearest-even three-way split done on the host."""
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(3)
+    rows, K, nb = 20, 48, 3
+    W = torch.randn(nb, rows, K, generator=g, device='cpu') * torch.logspace(-3, 3, K, device='cpu')[None, None, :]
+    Wd = (W if kcontig else W.transpose(1, 2).contiguous()).to(backend.dev)
+    s_row, s_k = (K, 1) if kcontig else (1, rows)
+    planes, b0, b1 = L.x6_presplit(Wd, rows, K, s_row, s_k, nb=(2, nb), s_b=(0, rows * K))
+    assert (b0, b1) == (0, 3 * rows * K) and planes.numel() == nb * 3 * rows * K
+    got = planes.cpu().view(nb, 3, rows, K)
+    for z in range(nb):
+        for p, ref in enumerate(_split3_host(W[z])):
+            assert torch.equal(got[z, p], ref), (z, p)
+    hi, mid, lo = (got[:, p].view(torch.bfloat16).double() for p in range(3))
+    assert ((hi + mid + lo) - W.double()).abs().max() <= 2.0 ** -23 * W.abs().max()
+
+
+@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x256])
+@pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb,shared', [(300, 392, 128, True, True, 1, 2, False), (264, 520, 96, False, True, 2, 3, True),
+                                                        (260, 136, 192, True, False, 1, 2, False), (520, 264, 64, False, False, 3, 2, True)])
+def test_x6_presplit_b_operand_gives_identical_results(backend, tile, M, N, K, akc, bkc, sk, nb, shared):
+    """segx_gemm_desc.b_planes: the wave-specialised kernels with the B operand split ahead of time (copy-only B loader) against the same kernels
+    splitting B in registers -- the LDS image is the same, so the results must agree bit for bit; ragged N (clamped rows), batches with their own
+    or a shared B, split-K slabs, both layouts of A and of the fp32 B the planes are made from."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    try:
+        assert L.c.segx_tune(9, 8) == 0
+        g = torch.Generator(device='cpu').manual_seed(M + N + K)
+        A = torch.randn(nb, M, K, generator=g, device='cpu').to(backend.dev)
+        B = (torch.randn(1 if shared else nb, N, K, generator=g, device='cpu') * 0.3).to(backend.dev)
+        Am = A if akc else A.transpose(1, 2).contiguous()
+        Bm = B if bkc else B.transpose(1, 2).contiguous()
+        a_str = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+        b_str = (0, 0 if shared else N * K, K, 1) if bkc else (0, 0 if shared else N * K, 1, N)
+        out = []
+        for pre in (False, True):
+            C = torch.full((nb, M, N), float('nan'), device=backend.dev)
+            ws = torch.empty(sk * nb * M * N, device=backend.dev) if sk > 1 else None
+            planes = L.x6_presplit(Bm, N, K, b_str[2], b_str[3], nb=(1, nb), s_b=(b_str[0], b_str[1])) if pre else None
+            L.x6_launches()
+            L.gemm(Am, Bm, C, M, N, K, a_str, b_str, (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile, alpha=0.5, b_planes=planes)
+            assert L.x6_launches() == 1
+            out.append(C)
+    finally:
+        L.c.segx_tune(9, 256)
+        L.set_engine(prev)
+    ref = 0.5 * _ref(A, B.expand(nb, N, K))
+    assert (out[0].double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    assert torch.equal(out[0], out[1])
+
+
 def test_x6_wave_specialised_gelu_epilogue(backend):
     L = backend.L
     dev = backend.dev
