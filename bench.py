@@ -308,6 +308,23 @@ def run_graph_replay(args):
         return {'error': 'timeout'}
 
 
+def run_f16x3_opt_in(args):
+    """The same configuration with SEGX_F16X3=1 (segtran_amd/segx.py: the largest GEMMs in the two-plane fp16 scheme of gemm_h3.h, three matrix
+    instructions per block product instead of six), in a child process.  An opt-in figure beside `value`, never `value`: DESIGN.md 5c-r3."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
+           '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order']
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT, env=dict(os.environ, SEGX_F16X3='1'))
+        line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+        if out.returncode != 0 or not line:
+            return {'error': 'rc %d: %s' % (out.returncode, out.stderr.decode()[-200:])}
+        r = json.loads(line[-1])
+        return dict({k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median')}, final_loss=r['config'].get('final_loss'),
+                    note='SEGX_F16X3=1: GEMMs of >= 2e11 multiply-adds on the wave-specialised kernels run as f16x3 (row-scaled two-plane fp16 split); not `value`')
+    except subprocess.TimeoutExpired:
+        return {'error': 'timeout'}
+
+
 def self_spawn(n):
     """`python bench.py --gpus N` without a launcher in front (WORLD_SIZE unset): re-run this command line as N ranks, one per GPU, under
     torch.distributed.run on 127.0.0.1 (what the driver does for N > 1).  Rank 0 of the child job prints the one JSON line; its `n_gpus` and
@@ -378,6 +395,8 @@ def main():
         res['cpu_baseline'] = run_cpu_baseline(args.config)
     if world == 1 and not args.graph and not args.single_order:
         res['config']['hipgraph_replay'] = run_graph_replay(args)
+        if args.engine == 'x6' and not os.environ.get('SEGX_F16X3'):
+            res['config']['f16x3_opt_in'] = run_f16x3_opt_in(args)
     print(json.dumps(res), flush=True)
 
 

@@ -1,0 +1,184 @@
+// gemm_h3.h -- "f16x3": the wave-specialised persistent GEMM of gemm_x6ws.h with a TWO-plane fp16 image and THREE matrix instructions per block
+// product instead of three bf16 planes and six.
+//
+// Arithmetic.  Every operand row (the index that is NOT contracted) gets a power-of-two scale s (h3_rowmax / h3_scales kernels: the row's largest
+// magnitude lands in [2^14, 2^15), inside fp16's range).  The scaled value splits into two fp16 numbers x s = h + l: h = fp16(x s) (11 significand bits,
+// round to nearest even), l = fp16(x s - h) (the next 11 bits; exact subtraction).  |x s - h - l| <= 2^-24 |x s| as long as l is a normal fp16, i.e.
+// for every element within 2^-17 of its row's maximum; smaller elements keep an ABSOLUTE error of 2^-25 in scaled units = 2^-40 of the row maximum.
+// A block product is v_mfma_f32_32x32x16_f16 on (h.l, l.h, h.h), small terms first; every fp16 x fp16 product is exact in fp32 (22 bits), the
+// accumulation is fp32, the dropped l.l term is 2^-24 relative.  The epilogue multiplies by the inverse scales (exact).  So the result carries the
+// same error bound as the bf16x6 scheme, 2^-23 sum |a||b|, plus a block-floating-point term 2^-39 (max_row|a| sum|b| + max_row|b| sum|a|) that only
+// matters when an operand row spans more than 2^15 in magnitude AND the other operand is large exactly where it is small.
+// Why: the bf16x6 kernels are bound by the clock the chip sustains under dense matrix-pipe load (the same kernel runs 223 TFLOP/s
+// on random operands and 298 on zeros); half the matrix instructions per product is the one lever left.  Roof: 2.5 PFLOP/s / 3 = 833 TFLOP/s.
+//
+// LDS image per operand: two planes [plane][row][32 k] of fp16, the row / chunk swizzle of gemm_x6.h.  Loaders: the thread -> element maps of
+// WsDense6 plus the row scales of the thread's pieces (see H3Dense).
+#pragma once
+#include "gemm_x6ws.h"
+
+namespace segx {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16v2 __attribute__((ext_vector_type(2)));
+
+// (x0, x1), already scaled -> two packed fp16 pairs (element 0 in the low half)
+struct SplitH { unsigned h, l; };
+__device__ __forceinline__ SplitH h3_split_pair(float x0, float x1) {
+    const f32v2 v0 = {x0, x1};
+    const f16v2 hv = __builtin_convertvector(v0, f16v2);
+    float a0 = x0 - (float)hv.x, a1 = x1 - (float)hv.y;
+    SEGX_PIN(a0);
+    const f32v2 v1 = {a0, a1};
+    SplitH o; o.h = __builtin_bit_cast(unsigned, hv); o.l = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, f16v2));
+    return o;
+}
+template <int PLANE_BYTES>
+__device__ __forceinline__ void h3_store8(unsigned char* __restrict__ P, int off, const float (&v)[8]) {
+    const SplitH a = h3_split_pair(v[0], v[1]), b = h3_split_pair(v[2], v[3]), c = h3_split_pair(v[4], v[5]), d = h3_split_pair(v[6], v[7]);
+    *reinterpret_cast<uint4*>(P + off) = make_uint4(a.h, b.h, c.h, d.h);
+    *reinterpret_cast<uint4*>(P + PLANE_BYTES + off) = make_uint4(a.l, b.l, c.l, d.l);
+}
+template <int PLANE_BYTES>
+__device__ __forceinline__ void h3_store4(unsigned char* __restrict__ P, int off, float v0, float v1, float v2, float v3) {
+    const SplitH a = h3_split_pair(v0, v1), b = h3_split_pair(v2, v3);
+    uint2 h, l; h.x = a.h; h.y = b.h; l.x = a.l; l.y = b.l;
+    *reinterpret_cast<uint2*>(P + off) = h;
+    *reinterpret_cast<uint2*>(P + PLANE_BYTES + off) = l;
+}
+
+template <class Cfg> struct H3Lds { static constexpr int A_BYTES = 2 * X6Plane<Cfg::BM>::bytes, B_BYTES = 2 * X6Plane<Cfg::BN>::bytes, BYTES = A_BYTES + B_BYTES; };
+
+// one 32-k stage of a consumer wave: three products per accumulator, small terms first; consecutive matrix instructions go to different accumulators
+template <class Cfg>
+__device__ __forceinline__ void h3_stage_mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_, const unsigned char* __restrict__ LB_,
+                                              int arow, int brow, int kh) {
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ, PA = X6Plane<Cfg::BM>::bytes, PB = X6Plane<Cfg::BN>::bytes;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int chunk = 2 * s + kh;
+        f16x8 b[NJ][2];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) b[j][p] = *reinterpret_cast<const f16x8*>(LB_ + p * PB + x6_off(brow + 32 * j, chunk));
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            f16x8 a[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[p] = *reinterpret_cast<const f16x8*>(LA_ + p * PA + x6_off(arow + 32 * i, chunk));
+#define SEGX_H3_P(PA_, PB_)                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[PA_], b[j][PB_], acc[i][j], 0, 0, 0);
+            SEGX_H3_P(0, 1) SEGX_H3_P(1, 0) SEGX_H3_P(0, 0)
+#undef SEGX_H3_P
+        }
+    }
+}
+
+struct H3WsEngine {
+    static constexpr bool SCALED = true;
+    template <class Cfg> struct Lds { static constexpr int A_BYTES = H3Lds<Cfg>::A_BYTES, STAGE = H3Lds<Cfg>::BYTES; };
+    template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
+                                                                     const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {
+        h3_stage_mfma<Cfg>(acc, LA_, LB_, arow, brow, kh);
+    }
+};
+
+// ---- loaders: WsDense6's maps + row scales in the register set ------------------------------------------------------------------------------
+template <bool KC, int ROWS> struct H3Dense;
+
+// Row scales travel in the REGISTER SET (store6 runs on the stream's loader, which may already describe a later work item, so it must not read
+// loader state).  One scale per piece and stage would double the load instructions (r03_ae: the producers became the bottleneck), so the scale array
+// is stored PERMUTED -- index(row) = (row % 32) * R32 + row / 32, R32 = 8 * ceil(rows / 256) -- which puts the scales of a thread's pieces (rows
+// 32 apart) side by side: two 16-byte loads for a 256-row tile, one for 128 rows.  Rows past the edge hold scale 0 (h3_scales_kernel), which zeroes
+// the clamped duplicates without a mask.
+__host__ __device__ inline int h3_r32(int rows) { return 8 * ((rows + 255) / 256); }
+
+template <int ROWS>
+struct H3Dense<true, ROWS> {                                  // k-contiguous: piece f = ptid + 256 i -> row f / 8, four consecutive k at 4 (f % 8)
+    static constexpr int NPT = ROWS * BKT / 1024, NREG = 5 * NPT;
+    const float* base; const float* scale;
+    unsigned off[NPT], soff;
+    __device__ __forceinline__ void begin(const float* b, int64_t s_row, int64_t, int row0, int rows, const float* scale_, int ptid) {
+        base = b; scale = scale_;
+        soff = (unsigned)(((ptid >> 3) * h3_r32(rows) + (row0 >> 5)) << 2);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int row = row0 + (ptid >> 3) + 32 * i;
+            off[i] = (unsigned)(((int64_t)(row < rows ? row : rows - 1) * s_row + ((ptid & 7) << 2)) << 2);
+        }
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr b = ws_uniform_base(base + k0), sb = ws_uniform_base(scale);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const f32x4 v = ws_load<f32x4>(b, off[i]);
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < NPT / 4; ++i) {
+            const f32x4 v = ws_load<f32x4>(sb, soff + 16 * i);
+            r[4 * NPT + 4 * i] = v.x; r[4 * NPT + 4 * i + 1] = v.y; r[4 * NPT + 4 * i + 2] = v.z; r[4 * NPT + 4 * i + 3] = v.w;
+        }
+        return 0u;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = ptid + 256 * i, row = f >> 3, kc = f & 7;
+            const float s_ = r[4 * NPT + i];
+            h3_store4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), r[4 * i] * s_, r[4 * i + 1] * s_, r[4 * i + 2] * s_, r[4 * i + 3] * s_);
+        }
+    }
+};
+
+template <int ROWS>
+struct H3Dense<false, ROWS> {                                 // row-contiguous: rows 2 rp, 2 rp + 1 (one 8-byte load per k), KQ = ROWS / 16 consecutive k
+    static_assert(ROWS == 256 || ROWS == 128, "row-contiguous f16x3 loader: 128 or 256 rows");
+    static constexpr int KQ = ROWS / 16, RP = ROWS / 2, NREG = 2 * KQ + 2;
+    const float* base; const float* scale; int64_t s_k;
+    unsigned off[KQ], soff0, soff1;
+    __device__ __forceinline__ void begin(const float* b, int64_t, int64_t s_k_, int row0, int rows, const float* scale_, int ptid) {
+        base = b; scale = scale_; s_k = s_k_;
+        const int row = row0 + 2 * (ptid % RP);
+        const bool rok = row < rows;                          // rows % 4 == 0 and row even: the pair is inside or outside together
+        soff0 = (unsigned)(((row & 31) * h3_r32(rows) + (row >> 5)) << 2);
+        soff1 = (unsigned)((((row + 1) & 31) * h3_r32(rows) + ((row + 1) >> 5)) << 2);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) off[j] = (unsigned)(((int64_t)(KQ * (ptid / RP) + j) * s_k_ + (rok ? row : rows - 2)) << 2);
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr bk = ws_uniform_base(base + (int64_t)k0 * s_k), sb = ws_uniform_base(scale);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const f32v2 v = ws_load<f32v2>(bk, off[j]);
+            r[2 * j] = v.x; r[2 * j + 1] = v.y;
+        }
+        r[2 * KQ] = ws_load<float>(sb, soff0); r[2 * KQ + 1] = ws_load<float>(sb, soff1);
+        return 0u;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
+        const int row = 2 * (ptid % RP), kg = ptid / RP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float s_ = r[2 * KQ + e];
+#pragma unroll
+            for (int h = 0; h < KQ / 8; ++h) {
+                const float v[8] = {r[16 * h + e] * s_, r[16 * h + 2 + e] * s_, r[16 * h + 4 + e] * s_, r[16 * h + 6 + e] * s_,
+                                    r[16 * h + 8 + e] * s_, r[16 * h + 10 + e] * s_, r[16 * h + 12 + e] * s_, r[16 * h + 14 + e] * s_};
+                h3_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, (KQ / 8) * kg + h), v);
+            }
+        }
+    }
+};
+
+template <class Cfg, bool AKC, bool BKC>
+struct H3Mk {
+    using LA = H3Dense<AKC, Cfg::BM>; using LB = H3Dense<BKC, Cfg::BN>;
+    __device__ __forceinline__ void make(const GemmArgs& g, const TileCoord& t, LA& la, LB& lb, int ptid) const {
+        la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M, g.sa + (int64_t)t.zb * 32 * h3_r32(g.M), ptid);
+        lb.begin(g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N, g.sb + (int64_t)t.zb * 32 * h3_r32(g.N), ptid);
+    }
+};
+
+}  // namespace segx

@@ -68,7 +68,11 @@ __device__ __forceinline__ void x6ws_stage_mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ],
             // accumulators so that none waits for its predecessor's result
 #define SEGX_X6WS_P(PA_, PB_)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA_], b[j][PB_], acc[i][j], 0, 0, 0);
+#ifdef SEGX_PROBE_3MFMA                                   // bench-only speed probe of a two-plane / three-product engine (results are NOT the GEMM)
+            SEGX_X6WS_P(0, 1) SEGX_X6WS_P(1, 0) SEGX_X6WS_P(0, 0)
+#else
             SEGX_X6WS_P(0, 2) SEGX_X6WS_P(2, 0) SEGX_X6WS_P(1, 1) SEGX_X6WS_P(0, 1) SEGX_X6WS_P(1, 0) SEGX_X6WS_P(0, 0)
+#endif
 #undef SEGX_X6WS_P
         }
     }
@@ -97,8 +101,18 @@ struct X6WsStream {
     }
 };
 
+// What x6ws_body needs to know about the numeric scheme of the LDS image: bf16x6 here, the two-plane fp16 scheme in gemm_h3.h
+struct X6WsEngine {
+    static constexpr bool SCALED = false;
+    template <class Cfg> struct Lds { static constexpr int A_BYTES = X6Lds<Cfg>::A_BYTES, STAGE = X6Lds<Cfg>::BYTES; };
+    template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
+                                                                     const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {
+        x6ws_stage_mfma<Cfg>(acc, LA_, LB_, arow, brow, kh);
+    }
+};
+
 // a producer's register set -> the three-plane LDS images of one stage (VAR: the bench ablations of x6ws_body)
-template <int VAR, class Cfg, class LA, class LB>
+template <int VAR, class Cfg, class LA, class LB, int A_BYTES_ = X6Lds<Cfg>::A_BYTES>
 __device__ __forceinline__ void x6ws_put(const LA& la, const LB& lb, float (&ra)[LA::NREG], float (&rb)[LB::NREG], unsigned oka, unsigned okb,
                                          unsigned char* __restrict__ P, int ptid) {
     if (VAR == 2) {                                        // stores of the same width and count without the conversion arithmetic
@@ -109,7 +123,7 @@ __device__ __forceinline__ void x6ws_put(const LA& la, const LB& lb, float (&ra)
             *reinterpret_cast<uint2*>(wa + 512 * (e / 2)) = w;
             if ((e & 2) == 0) *reinterpret_cast<uint2*>(wa + 512 * (e / 2) + 256) = w;
         }
-        unsigned* wb = reinterpret_cast<unsigned*>(P + X6Lds<Cfg>::A_BYTES) + ptid * 2;
+        unsigned* wb = reinterpret_cast<unsigned*>(P + A_BYTES_) + ptid * 2;
 #pragma unroll
         for (int e = 0; e + 1 < LB::NREG; e += 2) {
             uint2 w; w.x = __float_as_uint(rb[e]); w.y = __float_as_uint(rb[e + 1]);
@@ -121,16 +135,16 @@ __device__ __forceinline__ void x6ws_put(const LA& la, const LB& lb, float (&ra)
         for (int e = 0; e < LA::NREG; ++e) asm volatile("" :: "v"(ra[e]));
 #pragma unroll
         for (int e = 0; e < LB::NREG; ++e) asm volatile("" :: "v"(rb[e]));
-    } else { la.store6(ra, oka, P, ptid); lb.store6(rb, okb, P + X6Lds<Cfg>::A_BYTES, ptid); }
+    } else { la.store6(ra, oka, P, ptid); lb.store6(rb, okb, P + A_BYTES_, ptid); }
 }
 
 // EPI as gemm_epilogue.  PRIO (segx_tune knob 6; results are only defined for 0 and 1): 1 = consumers run at raised wave priority; ablations that
 // price the producers' parts: 2 = no split arithmetic (raw bits stored), 3 = no global loads after a work item's first stage, 4 = no LDS stores,
 // 5 = producers only keep the barrier count (what the consumers reach alone).
-template <class Cfg, class MK, int EPI, int PRIO = 0>
+template <class Cfg, class MK, int EPI, int PRIO = 0, class EN = X6WsEngine>
 __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsigned char* __restrict__ lds) {
     using LA = typename MK::LA; using LB = typename MK::LB;
-    constexpr int STAGE = X6WsLds<Cfg>::STAGE, A_BYTES = X6Lds<Cfg>::A_BYTES;
+    constexpr int STAGE = EN::template Lds<Cfg>::STAGE, A_BYTES = EN::template Lds<Cfg>::A_BYTES;
     const int wave = SEGX_WAVE_UNIFORM((int)(threadIdx.x >> 6));
     const int G = gridDim.x, pos = ws_round_pos(blockIdx.x, G);
     const int total = g.tiles_m * g.tiles_n * g.nbatch * g.splitk;
@@ -154,7 +168,7 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
         bool have1 = st.valid, have0;
         oka1 = st.la.load6(a1, st.k, st.kend, ptid); okb1 = st.lb.load6(b1, st.k, st.kend, ptid);
         r_seen = st.r; st.next(g, mk, pos, G, total);
-        x6ws_put<PRIO, Cfg>(st.la, st.lb, a0, b0, oka0, okb0, lds, ptid);        // stage 0 -> buffer 0
+        x6ws_put<PRIO, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, a0, b0, oka0, okb0, lds, ptid);        // stage 0 -> buffer 0
         int par = 0;
         for (;;) {
             SEGX_LDS_BARRIER();                            // the stage in buffer `par` is complete; buffer par ^ 1 has been read to the end
@@ -163,14 +177,14 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
             have0 = st.valid;
             if (!((PRIO == 3 || PRIO == 5) && st.r == r_seen)) { oka0 = st.la.load6(a0, st.k, st.kend, ptid); okb0 = st.lb.load6(b0, st.k, st.kend, ptid); }
             r_seen = st.r; st.next(g, mk, pos, G, total);
-            if (PRIO != 5) x6ws_put<PRIO, Cfg>(st.la, st.lb, a1, b1, oka1, okb1, lds + par * STAGE, ptid);
+            if (PRIO != 5) x6ws_put<PRIO, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, a1, b1, oka1, okb1, lds + par * STAGE, ptid);
             SEGX_LDS_BARRIER();
             par ^= 1;
             if (!have0) break;
             have1 = st.valid;
             if (!((PRIO == 3 || PRIO == 5) && st.r == r_seen)) { oka1 = st.la.load6(a1, st.k, st.kend, ptid); okb1 = st.lb.load6(b1, st.k, st.kend, ptid); }
             r_seen = st.r; st.next(g, mk, pos, G, total);
-            if (PRIO != 5) x6ws_put<PRIO, Cfg>(st.la, st.lb, a0, b0, oka0, okb0, lds + par * STAGE, ptid);
+            if (PRIO != 5) x6ws_put<PRIO, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, a0, b0, oka0, okb0, lds + par * STAGE, ptid);
         }
         return;
     }
@@ -194,9 +208,10 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
         for (int kt = t.kbeg; kt < t.kend; kt += BKT) {
             SEGX_LDS_BARRIER();
             const unsigned char* const P = lds + par * STAGE;
-            x6ws_stage_mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
+            EN::template mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
             par ^= 1;
         }
+        if (EN::SCALED) acc_unscale<Cfg>(acc, g, t);
         gemm_epilogue<EPI, Cfg, false>(acc, g, t);        // an empty split-K slab writes zeros
     }
 }

@@ -31,6 +31,7 @@
 #define SEGX_WAVE_UNIFORM(x) (x)         /* v_readfirstlane of a value that is uniform over the wave */
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
+#define SEGX_LOAD_FENCE() ((void)0)                       /* compiler-only fence of the device build */
 #define __constant__ static
 
 struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
@@ -144,6 +145,19 @@ inline f32x16_ mfma_32x32x16bf16(bf16x8_ a, bf16x8_ b, f32x16_ c, int, int, int)
         c[r] = acc; }
     wave_sync(); return c;
 }
+// v_mfma_f32_32x32x16_f16 (gfx950): the operand layout of the bf16 form with fp16 elements (products exact in fp32, k-ordered fp32 accumulation)
+typedef _Float16 f16x8_ __attribute__((ext_vector_type(8)));
+inline f32x16_ mfma_32x32x16f16(f16x8_ a, f16x8_ b, f32x16_ c, int, int, int) {
+    Wave& w = wave(); int l = S.cur->lane;
+    for (int e = 0; e < 8; ++e) { _Float16 x = a[e], y = b[e]; unsigned short ux, uy; memcpy(&ux, &x, 2); memcpy(&uy, &y, 2); w.sa[l][e] = ux; w.sb[l][e] = uy; }
+    wave_sync();
+    int j = l & 31;
+    auto h2f = [](unsigned short u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+    for (int r = 0; r < 16; ++r) { int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5); float acc = c[r];
+        for (int k = 0; k < 16; ++k) acc = fmaf(h2f(w.sa[i + 32 * (k >> 3)][k & 7]), h2f(w.sb[j + 32 * (k >> 3)][k & 7]), acc);
+        c[r] = acc; }
+    wave_sync(); return c;
+}
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r = D[i=4*(l>>4)+r][j=l&15].
 inline f32x4_ mfma_16x16x4f32(float a, float b, f32x4_ c, int, int, int) {
     Wave& w = wave(); int l = S.cur->lane;
@@ -175,6 +189,7 @@ static inline void __syncthreads() { hipemu::block_sync(); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_32x32x16bf16
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16 hipemu::mfma_32x32x16f16
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)

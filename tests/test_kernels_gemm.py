@@ -386,6 +386,46 @@ def test_x6_presplit_b_operand_gives_identical_results(backend, tile, M, N, K, a
     assert torch.equal(out[0], out[1])
 
 
+@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x256])
+@pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(300, 392, 128, True, True, 1, 2), (264, 520, 96, False, True, 2, 2), (260, 136, 192, True, False, 1, 2),
+                                                 (520, 264, 64, False, False, 3, 2)])
+def test_f16x3_scheme_matches_fp64_with_wide_ranging_rows(backend, tile, M, N, K, akc, bkc, sk, nb):
+    """gemm_h3.h: two fp16 planes + three matrix instructions per block product on the wave-specialised kernels, operand rows scaled by powers of two.
+    Rows of very different magnitude (1e-9 .. 1e+6: far outside fp16's range without the scales), all four layouts, ragged edges, batches, split-K,
+    alpha and bias: error against fp64 at fp32-rounding level, measured per output ROW against that row's own scale (a global bound would hide a
+    small row computed badly)."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    try:
+        assert L.c.segx_tune(9, 8) == 0
+        g = torch.Generator(device='cpu').manual_seed(M + 2 * N + K)
+        A = torch.randn(nb, M, K, generator=g, device='cpu') * torch.logspace(-9, 6, M, device='cpu')[None, :, None]
+        B = torch.randn(nb, N, K, generator=g, device='cpu') * torch.logspace(3, -6, N, device='cpu')[None, :, None]
+        bias = torch.randn(N, generator=g, device='cpu').to(backend.dev)
+        Ad, Bd = A.to(backend.dev), B.to(backend.dev)
+        Am = Ad if akc else Ad.transpose(1, 2).contiguous()
+        Bm = Bd if bkc else Bd.transpose(1, 2).contiguous()
+        a_str = (0, M * K, K, 1) if akc else (0, M * K, 1, M)
+        b_str = (0, N * K, K, 1) if bkc else (0, N * K, 1, N)
+        out = []
+        for h3 in (True, False):
+            C = torch.full((nb, M, N), float('nan'), device=backend.dev)
+            ws = torch.empty(sk * nb * M * N, device=backend.dev) if sk > 1 else None
+            L.x6_launches()
+            L.gemm(Am, Bm, C, M, N, K, a_str, b_str, (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile, alpha=0.5, bias=bias,
+                   bias_mode=segx.BIAS_N, f16x3=h3)
+            assert L.x6_launches() == 1
+            out.append(C.cpu().double())
+    finally:
+        L.c.segx_tune(9, 256)
+        L.set_engine(prev)
+    ref = 0.5 * _ref(A, B) + bias.cpu().double()[None, None, :]
+    mag = 0.5 * (A.double().abs() @ B.double().abs().transpose(-1, -2)) + bias.cpu().double().abs()[None, None, :]     # sum |a||b|: the scale of the rounding
+    e3, e6 = (((C - ref).abs() / mag).max().item() for C in out)
+    # both schemes sit at the rounding noise of the fp32 accumulation (K / 2 * 2^-24 worst case); the fp16 scheme must not be worse than the bf16 one
+    assert e6 < 1e-6 and e3 < 1e-6 and e3 < 2 * e6 + 1e-7, (e3, e6)
+
+
 def test_x6_wave_specialised_gelu_epilogue(backend):
     L = backend.L
     dev = backend.dev
