@@ -77,6 +77,7 @@ __device__ __forceinline__ void h3_stage_mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
 
 struct H3WsEngine {
     static constexpr bool SCALED = true;
+    static constexpr int NSETS = 3;
     template <class Cfg> struct Lds { static constexpr int A_BYTES = H3Lds<Cfg>::A_BYTES, STAGE = H3Lds<Cfg>::BYTES; };
     template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
                                                                      const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {

@@ -104,6 +104,7 @@ struct X6WsStream {
 // What x6ws_body needs to know about the numeric scheme of the LDS image: bf16x6 here, the two-plane fp16 scheme in gemm_h3.h
 struct X6WsEngine {
     static constexpr bool SCALED = false;
+    static constexpr int NSETS = 2;                          // register sets of a producer (see x6ws_body)
     template <class Cfg> struct Lds { static constexpr int A_BYTES = X6Lds<Cfg>::A_BYTES, STAGE = X6Lds<Cfg>::BYTES; };
     template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
                                                                      const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {
@@ -160,6 +161,33 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
         const int ptid = threadIdx.x - 256;
         X6WsStream<Cfg, MK> st; st.r = 0; st.ptid = ptid; st.open(g, mk, pos, G, total);
         if (!st.valid) return;
+        if (EN::NSETS == 3) {
+            // THREE register sets: the loads of stage s+3 are issued before stage s+1 is split, so a load has TWO stage times to land.  With two sets
+            // a stage cannot be shorter than the memory latency under load (~1.7 us here), which is what bounds a scheme with half the matrix work.
+            float p0[LA::NREG], q0[LB::NREG], p1[LA::NREG], q1[LB::NREG], p2[LA::NREG], q2[LB::NREG];
+            unsigned m0, n0, m1, n1, m2, n2;
+            bool v0, v1, v2;
+            m0 = st.la.load6(p0, st.k, st.kend, ptid); n0 = st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            v1 = st.valid; m1 = st.la.load6(p1, st.k, st.kend, ptid); n1 = st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            v2 = st.valid; m2 = st.la.load6(p2, st.k, st.kend, ptid); n2 = st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p0, q0, m0, n0, lds, ptid);
+            int par3 = 0;
+            for (;;) {
+                SEGX_LDS_BARRIER(); par3 ^= 1;
+                if (!v1) break;
+                v0 = st.valid; m0 = st.la.load6(p0, st.k, st.kend, ptid); n0 = st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p1, q1, m1, n1, lds + par3 * STAGE, ptid);
+                SEGX_LDS_BARRIER(); par3 ^= 1;
+                if (!v2) break;
+                v1 = st.valid; m1 = st.la.load6(p1, st.k, st.kend, ptid); n1 = st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p2, q2, m2, n2, lds + par3 * STAGE, ptid);
+                SEGX_LDS_BARRIER(); par3 ^= 1;
+                if (!v0) break;
+                v2 = st.valid; m2 = st.la.load6(p2, st.k, st.kend, ptid); n2 = st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p0, q0, m0, n0, lds + par3 * STAGE, ptid);
+            }
+            return;
+        }
         float a0[LA::NREG], b0[LB::NREG], a1[LA::NREG], b1[LB::NREG];
         unsigned oka0, okb0, oka1, okb1;
         oka0 = st.la.load6(a0, st.k, st.kend, ptid); okb0 = st.lb.load6(b0, st.k, st.kend, ptid);
