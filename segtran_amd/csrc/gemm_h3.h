@@ -110,6 +110,9 @@ struct H3Dense<true, ROWS> {                                  // k-contiguous: p
         }
     }
     __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+#ifdef SEGX_PROBE_SAMEK                                      // bench-only probe (results are NOT the GEMM): every stage re-reads k-tile 0 or 1 (cache-hot operands)
+        k0 &= 32;
+#endif
         const ws_gptr b = ws_uniform_base(base + k0), sb = ws_uniform_base(scale);
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
@@ -149,6 +152,9 @@ struct H3Dense<false, ROWS> {                                 // row-contiguous:
         for (int j = 0; j < KQ; ++j) off[j] = (unsigned)(((int64_t)(KQ * (ptid / RP) + j) * s_k_ + (rok ? row : rows - 2)) << 2);
     }
     __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+#ifdef SEGX_PROBE_SAMEK
+        k0 &= 32;
+#endif
         const ws_gptr bk = ws_uniform_base(base + (int64_t)k0 * s_k), sb = ws_uniform_base(scale);
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
