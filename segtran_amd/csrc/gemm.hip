@@ -311,6 +311,9 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = d->bias_mode ? d->bias : nullptr; g.aux = d->epilogue == SEGX_EPI_GELU ? d->aux : nullptr;
     g.gmax = d->gmax;
+#ifdef SEGX_PROBE_TIMING
+    g.aux = d->aux;                                   // bench-only: the cycle-stamp buffer of gemm_x6ws.h
+#endif
     g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1; g.nbatch = d->nb0 * d->nb1;
     g.a_b0 = d->a_b0; g.a_b1 = d->a_b1; g.a_m = d->a_m; g.a_k = d->a_k;
     g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;

@@ -77,12 +77,16 @@ __device__ __forceinline__ void h3_stage_mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
 
 struct H3WsEngine {
     static constexpr bool SCALED = true;
-    static constexpr int NSETS = 3;
+    static constexpr int NSETS = 3;                          // three register sets, loads interleaved with the split (x6ws_body)
     template <class Cfg> struct Lds { static constexpr int A_BYTES = H3Lds<Cfg>::A_BYTES, STAGE = H3Lds<Cfg>::BYTES; };
     template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
                                                                      const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {
         h3_stage_mfma<Cfg>(acc, LA_, LB_, arow, brow, kh);
     }
+    // one producer stage: loads of (ax, bx) at k0 dealt out between the split-and-store groups of (ay, by) -> LDS images PA / PB
+    template <class LA, class LB>
+    static __device__ __forceinline__ void stage(const LA& la, const LB& lb, float (&ax)[LA::NREG], float (&bx)[LB::NREG], float (&ay)[LA::NREG],
+                                                 float (&by)[LB::NREG], int k0, unsigned char* __restrict__ PA, unsigned char* __restrict__ PB, int ptid);
 };
 
 // ---- loaders: WsDense6's maps + row scales in the register set ------------------------------------------------------------------------------
@@ -128,11 +132,19 @@ struct H3Dense<true, ROWS> {                                  // k-contiguous: p
     }
     __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
 #pragma unroll
-        for (int i = 0; i < NPT; ++i) {
-            const int f = ptid + 256 * i, row = f >> 3, kc = f & 7;
-            const float s_ = r[4 * NPT + i];
-            h3_store4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), r[4 * i] * s_, r[4 * i + 1] * s_, r[4 * i + 2] * s_, r[4 * i + 3] * s_);
-        }
+        for (int i = 0; i < NPT; ++i) store_step(r, i, P, ptid);
+    }
+    // step form (h3_interleave): NL load instructions, NS split-and-store groups
+    static constexpr int NL = NPT + NPT / 4, NS = NPT;
+    __device__ __forceinline__ void bases(int k0, ws_gptr& b, ws_gptr& sb) const { b = ws_uniform_base(base + k0); sb = ws_uniform_base(scale); }
+    __device__ __forceinline__ void load_step(float (&r)[NREG], int i, ws_gptr b, ws_gptr sb) const {
+        const f32x4 v = i < NPT ? ws_load<f32x4>(b, off[i < NPT ? i : 0]) : ws_load<f32x4>(sb, soff + 16 * (i - NPT));
+        r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;       // data pieces 0 .. NPT-1, then the scale quads: the same register order
+    }
+    __device__ __forceinline__ void store_step(float (&r)[NREG], int i, unsigned char* __restrict__ P, int ptid) const {
+        const int f = ptid + 256 * i, row = f >> 3, kc = f & 7;
+        const float s_ = r[4 * NPT + i];
+        h3_store4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), r[4 * i] * s_, r[4 * i + 1] * s_, r[4 * i + 2] * s_, r[4 * i + 3] * s_);
     }
 };
 
@@ -165,19 +177,57 @@ struct H3Dense<false, ROWS> {                                 // row-contiguous:
         return 0u;
     }
     __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
-        const int row = 2 * (ptid % RP), kg = ptid / RP;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float s_ = r[2 * KQ + e];
-#pragma unroll
-            for (int h = 0; h < KQ / 8; ++h) {
-                const float v[8] = {r[16 * h + e] * s_, r[16 * h + 2 + e] * s_, r[16 * h + 4 + e] * s_, r[16 * h + 6 + e] * s_,
-                                    r[16 * h + 8 + e] * s_, r[16 * h + 10 + e] * s_, r[16 * h + 12 + e] * s_, r[16 * h + 14 + e] * s_};
-                h3_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, (KQ / 8) * kg + h), v);
-            }
-        }
+        for (int i = 0; i < NS; ++i) store_step(r, i, P, ptid);
+    }
+    static constexpr int NL = KQ + 2, NS = KQ / 4;             // loads: KQ row pairs + 2 scales; stores: (row e, octet h) groups, e = i / (KQ / 8)
+    __device__ __forceinline__ void bases(int k0, ws_gptr& b, ws_gptr& sb) const { b = ws_uniform_base(base + (int64_t)k0 * s_k); sb = ws_uniform_base(scale); }
+    __device__ __forceinline__ void load_step(float (&r)[NREG], int i, ws_gptr b, ws_gptr sb) const {
+        if (i < KQ) { const f32v2 v = ws_load<f32v2>(b, off[i < KQ ? i : 0]); r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+        else r[2 * KQ + (i - KQ)] = ws_load<float>(sb, i == KQ ? soff0 : soff1);
+    }
+    __device__ __forceinline__ void store_step(float (&r)[NREG], int i, unsigned char* __restrict__ P, int ptid) const {
+        const int row = 2 * (ptid % RP), kg = ptid / RP, e = i / (KQ / 8), h = i % (KQ / 8);
+        const float s_ = r[2 * KQ + e];
+        const float v[8] = {r[16 * h + e] * s_, r[16 * h + 2 + e] * s_, r[16 * h + 4 + e] * s_, r[16 * h + 6 + e] * s_,
+                            r[16 * h + 8 + e] * s_, r[16 * h + 10 + e] * s_, r[16 * h + 12 + e] * s_, r[16 * h + 14 + e] * s_};
+        h3_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, (KQ / 8) * kg + h), v);
     }
 };
+
+// EXPERIMENT (-DSEGX_H3_INTERLEAVE; r03_ag): one producer stage of one operand with the load instructions of register set `rx` (a later stage) dealt out
+// between the split-and-store groups of set `ry`.  Cycle stamps (tools/ws_timing.py) had shown a producer stage = 1060 cycles issuing 15 loads + 1884
+// splitting; interleaved it is 2850: the ~70 cycles a wave spends per 1-KB load instruction are ISSUE time, not queueing, and do not overlap with the same
+// wave's arithmetic.  Kept for the record; the product uses load6 + store6.
+template <class LD>
+__device__ __forceinline__ void h3_interleave(const LD& ld, float (&rx)[LD::NREG], float (&ry)[LD::NREG], int k0, unsigned char* __restrict__ P, int ptid) {
+    ws_gptr b, sb;
+    ld.bases(k0, b, sb);
+    constexpr int LPS = (LD::NL + LD::NS - 1) / LD::NS;
+#pragma unroll
+    for (int st = 0; st < LD::NS; ++st) {
+#pragma unroll
+        for (int l = 0; l < LPS; ++l)
+            if (st * LPS + l < LD::NL) ld.load_step(rx, st * LPS + l, b, sb);
+        ld.store_step(ry, st, P, ptid);
+        // keeps the next group's loads behind this group's LDS stores.  NOT __builtin_amdgcn_sched_barrier(0): with it this pattern (loads into one register
+        // set dealt out between the consumers of another) produced wrong results on the device for the 256-row k-contiguous loader (r03_ag: correct
+        // without the builtin, correct with all loads first, wrong with both) -- a compiler-only memory fence gives the order without it
+        SEGX_LOAD_FENCE();
+    }
+}
+
+template <class LA, class LB>
+__device__ __forceinline__ void H3WsEngine::stage(const LA& la, const LB& lb, float (&ax)[LA::NREG], float (&bx)[LB::NREG], float (&ay)[LA::NREG],
+                                                  float (&by)[LB::NREG], int k0, unsigned char* __restrict__ PA, unsigned char* __restrict__ PB, int ptid) {
+#if defined(SEGX_H3_INTERLEAVE)                               // experiment (r03_ag): not faster -- see h3_interleave
+    h3_interleave(la, ax, ay, k0, PA, ptid);
+    h3_interleave(lb, bx, by, k0, PB, ptid);
+#else
+    la.load6(ax, k0, 0, ptid); lb.load6(bx, k0, 0, ptid);
+    la.store6(ay, 0u, PA, ptid); lb.store6(by, 0u, PB, ptid);
+#endif
+}
 
 template <class Cfg, bool AKC, bool BKC>
 struct H3Mk {

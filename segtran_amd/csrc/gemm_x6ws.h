@@ -101,6 +101,16 @@ struct X6WsStream {
     }
 };
 
+// bench-only cycle stamps (-DSEGX_PROBE_TIMING, tools/ws_timing.py): lane 0 of one consumer and one producer wave of workgroup 0 writes s_memtime at the
+// phase boundaries of its first 48 stages into the buffer passed as desc.aux
+#ifdef SEGX_PROBE_TIMING
+#define SEGX_TSTAMP(role, stage, slot)                                                                                         \
+    do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (stage) < 48 && g.aux)                                               \
+             reinterpret_cast<unsigned long long*>(g.aux)[((role) * 48 + (stage)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SEGX_TSTAMP(role, stage, slot) ((void)0)
+#endif
+
 // What x6ws_body needs to know about the numeric scheme of the LDS image: bf16x6 here, the two-plane fp16 scheme in gemm_h3.h
 struct X6WsEngine {
     static constexpr bool SCALED = false;
@@ -161,30 +171,35 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
         const int ptid = threadIdx.x - 256;
         X6WsStream<Cfg, MK> st; st.r = 0; st.ptid = ptid; st.open(g, mk, pos, G, total);
         if (!st.valid) return;
-        if (EN::NSETS == 3) {
-            // THREE register sets: the loads of stage s+3 are issued before stage s+1 is split, so a load has TWO stage times to land.  With two sets
-            // a stage cannot be shorter than the memory latency under load (~1.7 us here), which is what bounds a scheme with half the matrix work.
+        if constexpr (EN::NSETS == 3) {
+            // THREE register sets and an interleaved stage (the engine's `stage` deals the load instructions of set X -- stage s+3 -- out between the
+            // split-and-store groups of set Y -- stage s+1): a load has two stage times to land and the load path drains under the arithmetic.
             float p0[LA::NREG], q0[LB::NREG], p1[LA::NREG], q1[LB::NREG], p2[LA::NREG], q2[LB::NREG];
-            unsigned m0, n0, m1, n1, m2, n2;
             bool v0, v1, v2;
-            m0 = st.la.load6(p0, st.k, st.kend, ptid); n0 = st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-            v1 = st.valid; m1 = st.la.load6(p1, st.k, st.kend, ptid); n1 = st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-            v2 = st.valid; m2 = st.la.load6(p2, st.k, st.kend, ptid); n2 = st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-            x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p0, q0, m0, n0, lds, ptid);
+            st.la.load6(p0, st.k, st.kend, ptid); st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            v1 = st.valid; st.la.load6(p1, st.k, st.kend, ptid); st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            v2 = st.valid;
+            EN::stage(st.la, st.lb, p2, q2, p0, q0, st.k, lds, lds + A_BYTES, ptid);                       // loads of stage 2 under the split of stage 0
+            st.next(g, mk, pos, G, total);
             int par3 = 0;
+            int tst = 0; (void)tst;
             for (;;) {
+                if (wave == 4) SEGX_TSTAMP(1, tst, 0);
                 SEGX_LDS_BARRIER(); par3 ^= 1;
+                if (wave == 4) SEGX_TSTAMP(1, tst, 1);
                 if (!v1) break;
-                v0 = st.valid; m0 = st.la.load6(p0, st.k, st.kend, ptid); n0 = st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p1, q1, m1, n1, lds + par3 * STAGE, ptid);
+                v0 = st.valid; EN::stage(st.la, st.lb, p0, q0, p1, q1, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
+                if (wave == 4) SEGX_TSTAMP(1, tst, 3);
+                st.next(g, mk, pos, G, total);
+                ++tst;
                 SEGX_LDS_BARRIER(); par3 ^= 1;
                 if (!v2) break;
-                v1 = st.valid; m1 = st.la.load6(p1, st.k, st.kend, ptid); n1 = st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p2, q2, m2, n2, lds + par3 * STAGE, ptid);
+                v1 = st.valid; EN::stage(st.la, st.lb, p1, q1, p2, q2, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
+                st.next(g, mk, pos, G, total);
                 SEGX_LDS_BARRIER(); par3 ^= 1;
                 if (!v0) break;
-                v2 = st.valid; m2 = st.la.load6(p2, st.k, st.kend, ptid); n2 = st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-                x6ws_put<0, Cfg, typename MK::LA, typename MK::LB, A_BYTES>(st.la, st.lb, p0, q0, m0, n0, lds + par3 * STAGE, ptid);
+                v2 = st.valid; EN::stage(st.la, st.lb, p2, q2, p0, q0, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
+                st.next(g, mk, pos, G, total);
             }
             return;
         }
@@ -234,9 +249,12 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         for (int kt = t.kbeg; kt < t.kend; kt += BKT) {
+            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 0);
             SEGX_LDS_BARRIER();
+            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 1);
             const unsigned char* const P = lds + par * STAGE;
             EN::template mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
+            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 2);
             par ^= 1;
         }
         if (EN::SCALED) acc_unscale<Cfg>(acc, g, t);
