@@ -320,7 +320,7 @@ def run_f16x3_opt_in(args):
             return {'error': 'rc %d: %s' % (out.returncode, out.stderr.decode()[-200:])}
         r = json.loads(line[-1])
         return dict({k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median')}, final_loss=r['config'].get('final_loss'),
-                    note='SEGX_F16X3=1: GEMMs of >= 2e11 multiply-adds on the wave-specialised kernels run as f16x3 (row-scaled two-plane fp16 split); not `value`')
+                    note='SEGX_F16X3=1: GEMMs of >= 6e10 multiply-adds on the wave-specialised kernels run as f16x3 (row-scaled two-plane fp16 split); not `value`')
     except subprocess.TimeoutExpired:
         return {'error': 'timeout'}
 

@@ -52,10 +52,10 @@ class SegxLib:
         self.emulated = 'emu' in os.path.basename(path)
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
         # opt-in (SEGX_F16X3=1): planned GEMMs that land on the wave-specialised 256x128 / 128x256 kernels with a plain epilogue and at least
-        # f16x3_min_macs multiply-adds run in the two-plane fp16 scheme (segx_gemm_desc.h3_ws, gemm_h3.h: +19 % on the 24576 x 1792 x 1792 x 4
-        # projections incl. the row-scale pre-pass; below ~2e11 multiply-adds the pre-pass eats the gain).  Off by default: DESIGN.md 5c-r3.
+        # f16x3_min_macs multiply-adds run in the two-plane fp16 scheme (segx_gemm_desc.h3_ws, gemm_h3.h: +22..26 % on the 24576 x 1792 x 1792 x 4
+        # projections incl. the row-scale pre-pass; below ~6e10 multiply-adds the pre-pass eats the gain).  Off by default: DESIGN.md 5c-r3.
         self.f16x3_auto = os.environ.get('SEGX_F16X3', '0') == '1'
-        self.f16x3_min_macs = 2.0e11
+        self.f16x3_min_macs = 6.0e10
         self.f16x3_launches = 0
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
@@ -139,6 +139,8 @@ class SegxLib:
             tile, splitk = t.value, sk.value
             if self.f16x3_auto and float(M) * N * K * nb[0] * nb[1] >= self.f16x3_min_macs:
                 f16x3 = True
+                if tile == TILE_256x128 and a_strides[3] == 1 and M >= 8192 and N % 256 == 0:
+                    tile = TILE_WS128x256                     # r03_ag: the 128 x 256 tile is 3..10 % faster in this scheme when A is k-contiguous
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if (splitk > 1 or batch_reduce) else None
         d.batch_reduce = 1 if batch_reduce else 0
         if f16x3 and tile in (TILE_256x128, TILE_WS128x256) and epilogue == EPI_NONE:
