@@ -309,6 +309,30 @@ __global__ __launch_bounds__(256) void colreduce_stage1(const float* __restrict_
     ws[(int64_t)chunk * C + c] = s0;
     if (mode == 1) ws[((int64_t)nchunks + chunk) * C + c] = s1;
 }
+// four adjacent columns per thread (16-byte loads): wide tensors only (C >= 1024: enough threads per row chunk), same sums in the same order per column
+__global__ __launch_bounds__(256) void colreduce_stage1_v4(const float* __restrict__ A, const float* __restrict__ X, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, float* __restrict__ ws, int64_t rows, int64_t C,
+                                                           int mode, int nchunks) {
+    const int64_t c = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+    const int chunk = blockIdx.y;
+    const int64_t per = (rows + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(rows, r0 + per);
+    if (c >= C) return;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (mode == 0) {
+#pragma unroll 8
+        for (int64_t r = r0; r < r1; ++r) { const float4 a = *reinterpret_cast<const float4*>(A + r * C + c); s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+    } else {
+#pragma unroll 4
+        for (int64_t r = r0; r < r1; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(A + r * C + c), x = *reinterpret_cast<const float4*>(X + r * C + c);
+            const float m = mean[r], rs = rstd[r];
+            s0.x += a.x * ((x.x - m) * rs); s0.y += a.y * ((x.y - m) * rs); s0.z += a.z * ((x.z - m) * rs); s0.w += a.w * ((x.w - m) * rs);
+            s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+        }
+    }
+    *reinterpret_cast<float4*>(ws + (int64_t)chunk * C + c) = s0;
+    if (mode == 1) *reinterpret_cast<float4*>(ws + ((int64_t)nchunks + chunk) * C + c) = s1;
+}
 __global__ __launch_bounds__(256) void colreduce_stage2(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
                                                         float* __restrict__ out2, int64_t C, int nchunks, int nout) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -726,16 +750,20 @@ extern "C" int segx_layernorm_bwd(const float* dY, const float* X, const float* 
     return check_launch("segx_layernorm_bwd");
 }
 extern "C" int64_t segx_colreduce_ws_floats(int64_t rows, int64_t C, int nout) { return (int64_t)nout * chunks_for(rows) * C; }
+// stage 1 of a column reduction: the four-column form for wide, 16-byte aligned tensors, the column-per-thread form otherwise
+static void launch_colreduce1(hipStream_t stream, const float* A, const float* X, const float* mean, const float* rstd, float* ws, int64_t rows, int64_t C, int mode, int nch) {
+    const bool v4 = C >= 1024 && C % 4 == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0;
+    if (v4) hipLaunchKernelGGL(colreduce_stage1_v4, dim3((unsigned)((C / 4 + 255) / 256), nch), dim3(256), 0, stream, A, X, mean, rstd, ws, rows, C, mode, nch);
+    else hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, A, X, mean, rstd, ws, rows, C, mode, nch);
+}
 extern "C" int segx_colsum(const float* X, float* out, float* ws, int64_t rows, int64_t C, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && out && ws && rows > 0 && C > 0, "segx_colsum: bad args");
     if (rows <= 64) {          // few rows (per-sample partials, depthwise weight-gradient chunks): one pass straight into `out`, no second launch
-        hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), 1), dim3(256), 0, stream, X, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, out, rows, C, 0, 1);
+        launch_colreduce1(stream, X, nullptr, nullptr, nullptr, out, rows, C, 0, 1);
         return check_launch("segx_colsum");
     }
     const int nch = chunks_for(rows);
-    hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, X, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, ws, rows, C, 0, nch);
+    launch_colreduce1(stream, X, nullptr, nullptr, nullptr, ws, rows, C, 0, nch);
     hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)ws, out, (float*)nullptr, (float*)nullptr, C, nch, 1);
     return check_launch("segx_colsum");
 }
@@ -743,7 +771,7 @@ extern "C" int segx_ln_param_grad(const float* dY, const float* X, const float* 
                                   int64_t rows, int C, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && rstd && dw && db && ws && rows > 0 && C > 0, "segx_ln_param_grad: bad args");
     const int nch = chunks_for(rows);
-    hipLaunchKernelGGL(colreduce_stage1, dim3((unsigned)((C + 255) / 256), nch), dim3(256), 0, stream, dY, X, mean, rstd, ws, rows, (int64_t)C, 1, nch);
+    launch_colreduce1(stream, dY, X, mean, rstd, ws, rows, (int64_t)C, 1, nch);
     hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, stream, (const float*)ws, dw, db, (float*)nullptr, (int64_t)C, nch, 2);
     return check_launch("segx_ln_param_grad");
 }

@@ -82,6 +82,28 @@ def test_layernorm_fwd_bwd_param_grads(backend, rows, C, affine):
         close(dw, wr.grad, 2e-5); close(db, br.grad, 2e-5)
 
 
+@pytest.mark.parametrize('rows', [40, 300])
+def test_wide_column_reductions_take_the_four_column_form(backend, rows):
+    """C >= 1024, C % 4 == 0: colreduce_stage1_v4 (16-byte loads, four columns per thread) for the plain column sum (one-pass form at <= 64 rows, two stages
+    above) and for the LayerNorm parameter gradients; a column's partial sums are formed in the same order as in the one-column form, so a width just
+    below the switch (which takes the one-column kernel) must give bit-identical columns."""
+    Lb = backend.L
+    C = 1028
+    X = rnd(rows, C, seed=70); dY = rnd(rows, C, seed=71)
+    out = torch.empty(C); ws = torch.empty(Lb.colreduce_ws(rows, C, 1))
+    Lb.colsum(X, out, ws, rows, C)
+    close(out, X.double().sum(0).float(), 1e-5)
+    Xn = X[:, :1020].contiguous(); outn = torch.empty(1020); wsn = torch.empty(Lb.colreduce_ws(rows, 1020, 1))
+    Lb.colsum(Xn, outn, wsn, rows, 1020)                                   # 1020 < 1024: the one-column kernel
+    assert torch.equal(out[:1020].cpu(), outn.cpu())
+    mean = X.mean(1).contiguous(); rstd = (1.0 / (X.var(1, unbiased=False) + 1e-5).sqrt()).contiguous()
+    dw = torch.empty(C); db = torch.empty(C); ws2 = torch.empty(Lb.colreduce_ws(rows, C, 2))
+    Lb.ln_param_grad(dY, X, mean, rstd, dw, db, ws2, rows, C)
+    xhat = (X - mean[:, None]) * rstd[:, None]
+    close(dw, (dY.double() * xhat.double()).sum(0).float(), 1e-5)
+    close(db, dY.double().sum(0).float(), 1e-5)
+
+
 def test_colsum_and_sum(backend):
     Lb = backend.L
     X = rnd(1000, 70, seed=9)
