@@ -207,6 +207,10 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     torch.cuda.synchronize()
     L.gemm_prof = None if graphed else []
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    # the per-launch profiling events are ~700 Python objects per step: a generation-2 collection in the middle of the timed region stalls the host for
+    # tens of milliseconds (r03_af / r03_ak: one 116..120-ms step among fifty 75-ms ones).  Collect now, keep the collector out of the timed region.
+    import gc
+    gc.collect(); gc.disable()
     t0 = time.perf_counter()
     ev[0].record()
     for i in range(steps):
@@ -217,6 +221,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     prof, L.gemm_prof = (L.gemm_prof or []), None
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     if world > 1:
