@@ -374,6 +374,7 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 6) { if (value != 0 && value != 1 && value != 6 && value != 7) return -1; k.x6_variant = value; return 0; }
 #endif
     if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
+    if (knob == 10) { if (value != 8 && value != 16) return -1; k.h3_waves = value; return 0; }
     if (knob == 5) { return k.x6_launches.exchange(0); }
     return -1;
 }

@@ -84,6 +84,14 @@ __global__ __launch_bounds__(512) void gemm_h3ws_kernel(GemmArgs g) {
     x6ws_body<Cfg, H3Mk<Cfg, AKC, BKC>, SEGX_EPI_NONE, 0, H3WsEngine>(g, H3Mk<Cfg, AKC, BKC>{}, lds);
 }
 
+// ... its 16-wave form (gemm_h3.h: eight consumer + eight producer waves on the 256 x 128 tile; segx_tune knob 10)
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(1024) void gemm_h3ws16_kernel(GemmArgs g) {
+    using Cfg = Cfg16w;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * H3Lds<Cfg>::BYTES];
+    h3ws16_body<Cfg, H3Mk16<Cfg, AKC, BKC>>(g, H3Mk16<Cfg, AKC, BKC>{}, lds);
+}
+
 // Row maxima of |X| for the f16x3 scales: mx[z][row] = bits of max_k |X[z][row][k]| (non-negative floats order like their bit patterns).
 // k-contiguous operand: one wave per row, 16-byte loads along k.  Row-contiguous operand: one thread per row (coalesced over the rows), the k range cut
 // into gridDim.y slices merged with atomicMax (order-independent, hence deterministic); mx is zeroed before.
@@ -115,8 +123,8 @@ __global__ __launch_bounds__(256) void h3_rowmax_rc_kernel(const float* __restri
 }
 // mx -> fwd[z][32 * R32] (permuted: H3Dense; entries past `rows` are 0) and inv[z][rows]: s = 2^(14 - floor(log2 max)) (the row's maximum lands in
 // [2^14, 2^15)) and 1 / s; an all-zero (or non-finite) row gets 1
-__global__ __launch_bounds__(256) void h3_scales_kernel(const unsigned* __restrict__ mx, float* __restrict__ fwd, float* __restrict__ inv, int rows, int nb) {
-    const int r32 = h3_r32(rows), padded = 32 * r32;
+__global__ __launch_bounds__(256) void h3_scales_kernel(const unsigned* __restrict__ mx, float* __restrict__ fwd, float* __restrict__ inv, int rows, int nb, int G) {
+    const int r32 = h3_rg(rows, G), padded = G * r32;          // G = rows per permutation granule: 32 (8-wave kernels), 64 (16-wave kernel)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)padded * nb) return;
     const int z = (int)(i / padded), row = (int)(i - (int64_t)z * padded);
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256) void h3_scales_kernel(const unsigned* __restri
         s = __uint_as_float((unsigned)(127 + k) << 23);
         inv[(int64_t)z * rows + row] = __uint_as_float((unsigned)(127 - k) << 23);
     }
-    fwd[(int64_t)z * padded + (row & 31) * r32 + (row >> 5)] = s;
+    fwd[(int64_t)z * padded + (row % G) * r32 + row / G] = s;
 }
 
 // fp32 operand [nb][rows][K] (any of the two unit-stride layouts) -> three bf16 planes [nb][plane][rows][K], k contiguous: x = hi + mid + lo with the
@@ -432,8 +440,10 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
             if (bkc) hipLaunchKernelGGL(h3_rowmax_kc_kernel, dim3(ceil_div(d->N, 4), nbatch), dim3(256), 0, stream, B, d->N, d->K, d->b_n, d->b_b0, d->b_b1, d->nb1, mxb);
             else hipLaunchKernelGGL(h3_rowmax_rc_kernel, dim3(ceil_div(d->N, 256), (int)i64min(64, ceil_div(d->K, 64)), nbatch), dim3(256), 0, stream, B, d->N, d->K, d->b_k,
                                     d->b_b0, d->b_b1, d->nb1, mxb);
-            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->M) * nbatch, (int64_t)256)), dim3(256), 0, stream, mx, sa, sai, d->M, nbatch);
-            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->N) * nbatch, (int64_t)256)), dim3(256), 0, stream, mxb, sb, sbi, d->N, nbatch);
+            const bool w16 = kget(knobs().h3_waves) == 16 && tile == SEGX_TILE_256x128;      // the 16-wave form (knob 10): 64-row permutation granules
+            const int gran = w16 ? 64 : 32;
+            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->M) * nbatch, (int64_t)256)), dim3(256), 0, stream, mx, sa, sai, d->M, nbatch, gran);
+            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->N) * nbatch, (int64_t)256)), dim3(256), 0, stream, mxb, sb, sbi, d->N, nbatch, gran);
             g.sa = sa; g.sb = sb; g.sai = sai; g.sbi = sbi;
 #define SEGX_LAUNCHWS_H3(CFG, AK, BK)                                                                      \
     do {                                                                                                   \
@@ -448,7 +458,18 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         if (akc && bkc) SEGX_LAUNCHWS_H3(CFG, true, true); else if (akc) SEGX_LAUNCHWS_H3(CFG, true, false);    \
         else if (bkc) SEGX_LAUNCHWS_H3(CFG, false, true); else SEGX_LAUNCHWS_H3(CFG, false, false);        \
     } while (0)
-            if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_H3_LAYOUT(Cfg256x128); else SEGX_LAUNCHWS_H3_LAYOUT(Cfg128x256);
+            if (w16) {
+                using Cfg16 = Cfg16w;
+                g.tiles_m = ceil_div(d->M, Cfg16::BM); g.tiles_n = ceil_div(d->N, Cfg16::BN);
+                const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;
+                SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");
+                const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);
+                if (akc && bkc) hipLaunchKernelGGL((gemm_h3ws16_kernel<true, true>), dim3(G), dim3(1024), 0, stream, g);
+                else if (akc) hipLaunchKernelGGL((gemm_h3ws16_kernel<true, false>), dim3(G), dim3(1024), 0, stream, g);
+                else if (bkc) hipLaunchKernelGGL((gemm_h3ws16_kernel<false, true>), dim3(G), dim3(1024), 0, stream, g);
+                else hipLaunchKernelGGL((gemm_h3ws16_kernel<false, false>), dim3(G), dim3(1024), 0, stream, g);
+            }
+            else if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_H3_LAYOUT(Cfg256x128); else SEGX_LAUNCHWS_H3_LAYOUT(Cfg128x256);
 #undef SEGX_LAUNCHWS_H3_LAYOUT
 #undef SEGX_LAUNCHWS_H3
         }

@@ -238,4 +238,169 @@ struct H3Mk {
     }
 };
 
+// =================================================================================================================================================
+// The 16-wave form (r03 cycle stamps: the 8-wave f16x3 kernel is bound by its four producer waves, whose ~70-cycle load issues and split arithmetic are
+// serial within a wave): the same 256 x 128 tile over EIGHT consumer waves (64 x 64 each: 64 accumulator registers) and EIGHT producer waves (half the
+// loads and half the split each), 1024 threads = 4 waves per SIMD = 128 VGPRs per wave; three producer register sets; two 48-KB LDS stages.
+// Selected with segx_tune knob 10 = 16.  BUILT AND EMULATOR-VERIFIED AT THE END OF ROUND 3, NOT YET MEASURED ON THE DEVICE (the round's GPU budget was spent):
+// the default stays the 8-wave kernel.
+// =================================================================================================================================================
+// TileCfg (gemm_core.h) is pinned to four waves per workgroup; the 16-wave kernel's tile: 8 consumer waves 4 x 2, each 2 x 2 blocks of 32 x 32
+struct Cfg16w {
+    static constexpr int WM = 4, WN = 2, MI = 2, NJ = 2;
+    static constexpr int BM = WM * MI * 32, BN = WN * NJ * 32;
+};
+__host__ __device__ inline int h3_rg(int rows, int G) { return ((rows + 255) / 256) * (256 / G); }     // granules per permuted row of the scale array
+
+template <bool KC, int ROWS, int PT> struct H3DenseP;        // PT producer threads; scale permutation granule G = PT / 8 rows
+
+template <int ROWS, int PT>
+struct H3DenseP<true, ROWS, PT> {                            // k-contiguous: piece f = ptid + PT i -> row f / 8, four consecutive k at 4 (f % 8)
+    static constexpr int NPT = ROWS * BKT / (4 * PT), NREG = 5 * NPT, G = PT / 8;
+    static_assert(NPT == 4 || NPT == 2, "H3DenseP<true>: 4 or 2 pieces per thread");
+    const float* base; const float* scale;
+    unsigned off[NPT], soff;
+    __device__ __forceinline__ void begin(const float* b, int64_t s_row, int64_t, int row0, int rows, const float* scale_, int ptid) {
+        base = b; scale = scale_;
+        soff = (unsigned)(((ptid >> 3) * h3_rg(rows, G) + row0 / G) << 2);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int row = row0 + (ptid >> 3) + G * i;
+            off[i] = (unsigned)(((int64_t)(row < rows ? row : rows - 1) * s_row + ((ptid & 7) << 2)) << 2);
+        }
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr b = ws_uniform_base(base + k0), sb = ws_uniform_base(scale);
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const f32x4 v = ws_load<f32x4>(b, off[i]);
+            r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w;
+        }
+        if (NPT == 4) { const f32x4 v = ws_load<f32x4>(sb, soff); r[16] = v.x; r[17] = v.y; r[18] = v.z; r[19] = v.w; }
+        else { const f32v2 v = ws_load<f32v2>(sb, soff); r[4 * NPT] = v.x; r[4 * NPT + 1] = v.y; }
+        return 0u;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            const int f = ptid + PT * i, row = f >> 3, kc = f & 7;
+            const float s_ = r[4 * NPT + i];
+            h3_store4<X6Plane<ROWS>::bytes>(P, x6_off(row, kc >> 1) + ((kc & 1) << 3), r[4 * i] * s_, r[4 * i + 1] * s_, r[4 * i + 2] * s_, r[4 * i + 3] * s_);
+        }
+    }
+};
+
+template <int ROWS, int PT>
+struct H3DenseP<false, ROWS, PT> {                           // row-contiguous: rows 2 rp, 2 rp + 1, KQ consecutive k from KQ (ptid / RP)
+    static constexpr int RP = ROWS / 2, KPP = PT / RP, KQ = BKT / KPP, NREG = 2 * KQ + 2, G = PT / 8;
+    static_assert(KQ == 8 || KQ == 4, "H3DenseP<false>: 8 or 4 consecutive k per thread");
+    const float* base; const float* scale; int64_t s_k;
+    unsigned off[KQ], soff0, soff1;
+    __device__ __forceinline__ void begin(const float* b, int64_t, int64_t s_k_, int row0, int rows, const float* scale_, int ptid) {
+        base = b; scale = scale_; s_k = s_k_;
+        const int row = row0 + 2 * (ptid % RP);
+        const bool rok = row < rows;                          // rows % 4 == 0 and row even: the pair is inside or outside together
+        const int rg = h3_rg(rows, G);
+        soff0 = (unsigned)(((row % G) * rg + row / G) << 2);
+        soff1 = (unsigned)((((row + 1) % G) * rg + (row + 1) / G) << 2);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) off[j] = (unsigned)(((int64_t)(KQ * (ptid / RP) + j) * s_k_ + (rok ? row : rows - 2)) << 2);
+    }
+    __device__ __forceinline__ unsigned load6(float (&r)[NREG], int k0, int, int) const {
+        const ws_gptr bk = ws_uniform_base(base + (int64_t)k0 * s_k), sb = ws_uniform_base(scale);
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            const f32v2 v = ws_load<f32v2>(bk, off[j]);
+            r[2 * j] = v.x; r[2 * j + 1] = v.y;
+        }
+        r[2 * KQ] = ws_load<float>(sb, soff0); r[2 * KQ + 1] = ws_load<float>(sb, soff1);
+        return 0u;
+    }
+    __device__ __forceinline__ void store6(float (&r)[NREG], unsigned, unsigned char* __restrict__ P, int ptid) const {
+        const int row = 2 * (ptid % RP), kg = ptid / RP;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float s_ = r[2 * KQ + e];
+            if (KQ == 8) {
+                const float v[8] = {r[e] * s_, r[2 + e] * s_, r[4 + e] * s_, r[6 + e] * s_, r[8 + e] * s_, r[10 + e] * s_, r[12 + e] * s_, r[14 + e] * s_};
+                h3_store8<X6Plane<ROWS>::bytes>(P, x6_off(row + e, kg), v);
+            } else {
+                h3_store4<X6Plane<ROWS>::bytes>(P, x6_off(row + e, kg >> 1) + ((kg & 1) << 3), r[e] * s_, r[2 + e] * s_, r[4 + e] * s_, r[6 + e] * s_);
+            }
+        }
+    }
+};
+
+template <class Cfg, bool AKC, bool BKC>
+struct H3Mk16 {
+    using LA = H3DenseP<AKC, Cfg::BM, 512>; using LB = H3DenseP<BKC, Cfg::BN, 512>;
+    __device__ __forceinline__ void make(const GemmArgs& g, const TileCoord& t, LA& la, LB& lb, int ptid) const {
+        la.begin(g.A + t.z0 * g.a_b0 + t.z1 * g.a_b1, g.a_m, g.a_k, t.m0, g.M, g.sa + (int64_t)t.zb * 64 * h3_rg(g.M, 64), ptid);
+        lb.begin(g.B + t.z0 * g.b_b0 + t.z1 * g.b_b1, g.b_n, g.b_k, t.n0, g.N, g.sb + (int64_t)t.zb * 64 * h3_rg(g.N, 64), ptid);
+    }
+};
+
+// the persistent body of x6ws_body for 8 consumer + 8 producer waves (Cfg = Cfg16w: 256 x 128, a consumer wave owns 64 x 64)
+template <class Cfg, class MK>
+__device__ __forceinline__ void h3ws16_body(const GemmArgs& g, const MK& mk, unsigned char* __restrict__ lds) {
+    using LA = typename MK::LA; using LB = typename MK::LB;
+    static_assert(Cfg::WM * Cfg::WN == 8, "h3ws16_body: eight consumer waves");
+    constexpr int STAGE = H3Lds<Cfg>::BYTES, A_BYTES = H3Lds<Cfg>::A_BYTES;
+    const int wave = SEGX_WAVE_UNIFORM((int)(threadIdx.x >> 6));
+    const int G = gridDim.x, pos = ws_round_pos(blockIdx.x, G);
+    const int total = g.tiles_m * g.tiles_n * g.nbatch * g.splitk;
+    if (wave >= 8) {
+        // producers: the three-set schedule of x6ws_body (loads of stage s+3 issued before stage s+1 is split)
+        const int ptid = threadIdx.x - 512;
+        X6WsStream<Cfg, MK> st; st.r = 0; st.ptid = ptid; st.open(g, mk, pos, G, total);
+        if (!st.valid) return;
+        float p0[LA::NREG], q0[LB::NREG], p1[LA::NREG], q1[LB::NREG], p2[LA::NREG], q2[LB::NREG];
+        bool v0, v1, v2;
+        st.la.load6(p0, st.k, st.kend, ptid); st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+        v1 = st.valid; st.la.load6(p1, st.k, st.kend, ptid); st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+        v2 = st.valid; st.la.load6(p2, st.k, st.kend, ptid); st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+        st.la.store6(p0, 0u, lds, ptid); st.lb.store6(q0, 0u, lds + A_BYTES, ptid);
+        int par = 0;
+        for (;;) {
+            SEGX_LDS_BARRIER(); par ^= 1;
+            if (!v1) break;
+            v0 = st.valid; st.la.load6(p0, st.k, st.kend, ptid); st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            st.la.store6(p1, 0u, lds + par * STAGE, ptid); st.lb.store6(q1, 0u, lds + par * STAGE + A_BYTES, ptid);
+            SEGX_LDS_BARRIER(); par ^= 1;
+            if (!v2) break;
+            v1 = st.valid; st.la.load6(p1, st.k, st.kend, ptid); st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            st.la.store6(p2, 0u, lds + par * STAGE, ptid); st.lb.store6(q2, 0u, lds + par * STAGE + A_BYTES, ptid);
+            SEGX_LDS_BARRIER(); par ^= 1;
+            if (!v0) break;
+            v2 = st.valid; st.la.load6(p2, st.k, st.kend, ptid); st.lb.load6(q2, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
+            st.la.store6(p0, 0u, lds + par * STAGE, ptid); st.lb.store6(q0, 0u, lds + par * STAGE + A_BYTES, ptid);
+        }
+        return;
+    }
+    constexpr int MI = Cfg::MI, NJ = Cfg::NJ;
+    const int lane = threadIdx.x & 63, wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+    const int arow = wm * (32 * MI) + (lane & 31), brow = wn * (32 * NJ) + (lane & 31), kh = lane >> 5;
+    int par = 0;
+    for (int r = 0;; ++r) {
+        const int item = r * G + pos;
+        if (item >= total) break;
+        const TileCoord t = ws_item_coord<Cfg>(g, item);
+        f32x16 acc[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+        for (int kt = t.kbeg; kt < t.kend; kt += BKT) {
+            SEGX_LDS_BARRIER();
+            const unsigned char* const P = lds + par * STAGE;
+            h3_stage_mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
+            par ^= 1;
+        }
+        acc_unscale<Cfg>(acc, g, t);
+        gemm_epilogue<SEGX_EPI_NONE, Cfg, false>(acc, g, t);
+    }
+}
+
 }  // namespace segx

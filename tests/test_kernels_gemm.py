@@ -386,18 +386,18 @@ def test_x6_presplit_b_operand_gives_identical_results(backend, tile, M, N, K, a
     assert torch.equal(out[0], out[1])
 
 
-@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x256])
+@pytest.mark.parametrize('tile,waves', [(segx.TILE_256x128, 8), (segx.TILE_WS128x256, 8), (segx.TILE_256x128, 16)])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(300, 392, 128, True, True, 1, 2), (264, 520, 96, False, True, 2, 2), (260, 136, 192, True, False, 1, 2),
                                                  (520, 264, 64, False, False, 3, 2)])
-def test_f16x3_scheme_matches_fp64_with_wide_ranging_rows(backend, tile, M, N, K, akc, bkc, sk, nb):
+def test_f16x3_scheme_matches_fp64_with_wide_ranging_rows(backend, tile, waves, M, N, K, akc, bkc, sk, nb):
     """gemm_h3.h: two fp16 planes + three matrix instructions per block product on the wave-specialised kernels, operand rows scaled by powers of two.
     Rows of very different magnitude (1e-9 .. 1e+6: far outside fp16's range without the scales), all four layouts, ragged edges, batches, split-K,
     alpha and bias: error against fp64 at fp32-rounding level, measured per output ROW against that row's own scale (a global bound would hide a
-    small row computed badly)."""
+    small row computed badly).  waves = 16: the eight-consumer / eight-producer workgroup of the 256 x 128 tile (segx_tune knob 10)."""
     L = backend.L
     prev = L.set_engine('x6')
     try:
-        assert L.c.segx_tune(9, 8) == 0
+        assert L.c.segx_tune(9, 8) == 0 and L.c.segx_tune(10, waves) == 0
         g = torch.Generator(device='cpu').manual_seed(M + 2 * N + K)
         A = torch.randn(nb, M, K, generator=g, device='cpu') * torch.logspace(-9, 6, M, device='cpu')[None, :, None]
         B = torch.randn(nb, N, K, generator=g, device='cpu') * torch.logspace(3, -6, N, device='cpu')[None, :, None]
@@ -417,7 +417,7 @@ def test_f16x3_scheme_matches_fp64_with_wide_ranging_rows(backend, tile, M, N, K
             assert L.x6_launches() == 1
             out.append(C.cpu().double())
     finally:
-        L.c.segx_tune(9, 256)
+        L.c.segx_tune(9, 256); L.c.segx_tune(10, 8)
         L.set_engine(prev)
     ref = 0.5 * _ref(A, B) + bias.cpu().double()[None, None, :]
     mag = 0.5 * (A.double().abs() @ B.double().abs().transpose(-1, -2)) + bias.cpu().double().abs()[None, None, :]     # sum |a||b|: the scale of the rounding
