@@ -291,7 +291,7 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 8 = outputs per strip of the depthwise weight gradient (default 8192; >= 256);
  * knob 6 = schedule variant of the bf16x6 kernels with IDENTICAL results (0 = product; 1 = raised wave priority in the MFMA phase / of the consumer
  * waves; 6 = split-early schedule, 7 = product schedule at two waves per SIMD); the ablation variants 2..5, whose results are NOT the GEMM, exist only
- * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8); knob 10 = waves of the f16x3 workgroup (segx_gemm_desc.h3_ws): 8 (default) or 16 (eight consumer + eight producer waves on the 256x128 tile; emulator-verified, not yet measured);
+ * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8); knob 10 = waves of the f16x3 workgroup (segx_gemm_desc.h3_ws): 8 (default) or 16 (eight consumer + eight producer waves on the 256x128 tile; measured: no gain);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,

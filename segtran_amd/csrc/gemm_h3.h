@@ -242,8 +242,9 @@ struct H3Mk {
 // The 16-wave form (r03 cycle stamps: the 8-wave f16x3 kernel is bound by its four producer waves, whose ~70-cycle load issues and split arithmetic are
 // serial within a wave): the same 256 x 128 tile over EIGHT consumer waves (64 x 64 each: 64 accumulator registers) and EIGHT producer waves (half the
 // loads and half the split each), 1024 threads = 4 waves per SIMD = 128 VGPRs per wave; three producer register sets; two 48-KB LDS stages.
-// Selected with segx_tune knob 10 = 16.  BUILT AND EMULATOR-VERIFIED AT THE END OF ROUND 3, NOT YET MEASURED ON THE DEVICE (the round's GPU budget was spent):
-// the default stays the 8-wave kernel.
+// Selected with segx_tune knob 10 = 16.  Measured once at the end of round 3: correct, and NOT faster than the 8-wave kernel (2.58 vs 2.54 ms on
+// 24576 x 1792 x 1792 x 4) -- the limit is the CU's vector-load rate (48 KB of fp32 operands per stage at ~16 B/clk), not the number of waves issuing loads
+// (DESIGN.md 5c-r3).  Kept, off by default, as the measured counter-example; the default stays the 8-wave kernel.
 // =================================================================================================================================================
 // TileCfg (gemm_core.h) is pinned to four waves per workgroup; the 16-wave kernel's tile: 8 consumer waves 4 x 2, each 2 x 2 blocks of 32 x 32
 struct Cfg16w {
