@@ -12,7 +12,9 @@ before the timed region.  Rank 0 prints ONE JSON line:
   * `"brats"`: the 3-D half of the metric measured the same way in the same process (own `roofline`): cfg4 (BraTS 112 x 112 x 96, bs 4, one
     layer, BASELINE configs[3]) at N = 1, and cfg5 (128^3, 4 volumes per GPU, two layers, BASELINE configs[4]: the configuration the
     >= 6x scaling target is stated on) at every N;
-  * `roofline`: the dominant kernel family = the tile engine (dense + implicit-GEMM kernels); `cpu_baseline`: the oracle on the host cores.
+  * `"polyp"` (N > 1 only): BASELINE configs[2], polyp 352 x 352, at 6 images per GPU and with the reference's global batch 6 split over the ranks;
+  * `roofline`: the dominant kernel family (with `by_shape`: the twelve engine shapes with the most time, and `attention_gemms`: the mode-batched
+    squeezed-attention QK^T / P.V GEMMs) = the tile engine (dense + implicit-GEMM kernels); `cpu_baseline`: the oracle on the host cores.
 `--config cfgN` makes another BASELINE configuration the main measurement; `--engine f32` times the fp32-MFMA engine instead of bf16x6.
 """
 import argparse
@@ -116,7 +118,7 @@ def run_cpu_baseline(cfg_name, limit_s=420):
         return {'value': None, 'unit': 'images/s', 'cores': threads, 'kind': 'port', 'sample': 'failed: %s' % repr(e)[:160]}
 
 
-def engine_roofline(prof, steps, cfg_name, engine_name):
+def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
     """Roofline of the dominant kernel family: every launch of the tile engine inside the timed region is bracketed by HIP events on the
     launch stream (segx.SegxLib.gemm / _timed); achieved = algorithmic FLOPs of those launches / their summed durations."""
     traffic = tnote = None
@@ -158,7 +160,26 @@ def engine_roofline(prof, steps, cfg_name, engine_name):
         dom = stat['f32']
         roof = {'bound': 'mfma', 'kernel': 'segx fp32-MFMA tile engine: gemm_f32_kernel + conv3d_{fwd,wgrad}_kernel (v_mfma_f32_32x32x2_f32)',
                 'achieved': dom['tflops'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / PEAK_F32_MFMA_TFLOPS, 4)}
-    roof.update({'traffic': traffic, 'traffic_note': tnote, 'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
+    # per-shape figures of the dominant engine (the driver's line witnesses the per-kernel claims): the twelve shapes with the
+    # most time, plus the squeezed-attention score / value GEMMs (mode-batched: batch = 4 modes x samples, one side = the attractors)
+    agg = {}
+    for pr in (sel['x6'] if engine_name == 'x6' else sel['f32']):
+        a = agg.setdefault(pr[3], [0, 0.0, 0.0]); a[0] += 1; a[1] += pr[0].elapsed_time(pr[1]); a[2] += pr[2]
+    peak_ = PEAK_BF16_MFMA_TFLOPS / 6.0 if engine_name == 'x6' else PEAK_F32_MFMA_TFLOPS
+
+    def row(shp, v):
+        n, t, fl = v
+        tf = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
+        r = {'launches_per_step': round(n / max(1, steps), 2), 'ms_per_step': round(t / max(1, steps), 3), 'tflops': round(tf, 1), 'frac': round(tf / peak_, 3)}
+        if isinstance(shp[0], str):
+            r.update(kind=shp[0], M=shp[1], N=shp[2], K=shp[3], batch=shp[4])
+        else:
+            r.update(kind='gemm', M=shp[0], N=shp[1], K=shp[2], batch=shp[3], a_kcontig=bool(shp[4]), b_kcontig=bool(shp[5]), splitk=shp[6], tile=shp[7])
+        return r
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
+    by_shape = [row(k, v) for k, v in ranked[:12]]
+    attn = [row(k, v) for k, v in ranked if not isinstance(k[0], str) and mode_batch and k[3] == mode_batch][:10]
+    roof.update({'by_shape': by_shape, 'attention_gemms': attn, 'traffic': traffic, 'traffic_note': tnote, 'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
                  'launches_per_step': dom['launches_per_step'], 'gemm_ms_per_step': dom['ms_per_step'], 'gemm_tflop_per_step': dom['tflop_per_step'],
                  'all_engine_launches': {'launches_per_step': len(prof) // max(1, steps), 'ms_per_step': round(ms / max(1, steps), 2),
                                          'tflop_per_step': round(flops / max(1, steps) / 1e12, 3), 'tflops': round(achieved, 2)},
@@ -166,14 +187,14 @@ def engine_roofline(prof, steps, cfg_name, engine_name):
     return roof, achieved
 
 
-def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
+def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, batch=None):
     """W warm-up steps, EXACTLY `steps` timed steps inside a barrier + synchronize bracket (max over ranks), engine launches profiled."""
     from segtran_amd import engine, segx, dist as sdist, functional as SF
     from segtran_amd.networks import segtran_shared as ss
     from segtran_amd.efficientnet.model import MBConvBlock
     from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
     c = engine.CONFIGS[cfg_name]
-    B = c['bs']
+    B = batch or c['bs']
     torch.manual_seed(1234)
     SF.manual_seed(1234 + rank)
 
@@ -211,17 +232,19 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     # tens of milliseconds (r03_af / r03_ak: one 116..120-ms step among fifty 75-ms ones).  Collect now, keep the collector out of the timed region.
     import gc
     gc.collect(); gc.disable()
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(steps):
-        loss = step(x, raw)
-        ev[i + 1].record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    gc.enable()
+    try:
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(steps):
+            loss = step(x, raw)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        gc.enable()
     prof, L.gemm_prof = (L.gemm_prof or []), None
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     if world > 1:
@@ -263,7 +286,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     del step, opt, net, reducer
     torch.cuda.empty_cache()
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
-    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine) if (rank == 0 and prof) else (None, 0.0)
+    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine, mode_batch=4 * B) if (rank == 0 and prof) else (None, 0.0)
     if rank == 0 and os.environ.get('SEGX_BENCH_VERBOSE'):
         agg = {}
         for e0, e1, fl, shp, x6 in prof:
@@ -294,11 +317,11 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True):
     return res
 
 
-def run_graph_replay(args):
+def run_graph_replay(args, config=None):
     """The same configuration replayed as ONE captured hipGraph per step (engine.GraphedTrainStep), in a child process after everything else has been
     measured: a capture problem can then cost this extra block only, never the line.  Not the headline: `value` stays the eager step, whose engine
     launches carry the HIP events the roofline is computed from."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--graph', '--config', args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
+    cmd = [sys.executable, os.path.abspath(__file__), '--graph', '--config', config or args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
            '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order']
     if args.reference_op_order:
         cmd.append('--reference-op-order')
@@ -309,23 +332,6 @@ def run_graph_replay(args):
             return {'error': 'rc %d: %s' % (out.returncode, out.stderr.decode()[-200:])}
         r = json.loads(line[-1])
         return {k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'ms_per_step_min_max')}
-    except subprocess.TimeoutExpired:
-        return {'error': 'timeout'}
-
-
-def run_f16x3_opt_in(args):
-    """The same configuration with SEGX_F16X3=1 (segtran_amd/segx.py: the largest GEMMs in the two-plane fp16 scheme of gemm_h3.h, three matrix
-    instructions per block product instead of six), in a child process.  An opt-in figure beside `value`, never `value`: DESIGN.md 5c-r3."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
-           '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order']
-    try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240, cwd=ROOT, env=dict(os.environ, SEGX_F16X3='1'))
-        line = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
-        if out.returncode != 0 or not line:
-            return {'error': 'rc %d: %s' % (out.returncode, out.stderr.decode()[-200:])}
-        r = json.loads(line[-1])
-        return dict({k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median')}, final_loss=r['config'].get('final_loss'),
-                    note='SEGX_F16X3=1: GEMMs of >= 6e10 multiply-adds on the wave-specialised kernels run as f16x3 (row-scaled two-plane fp16 split); not `value`')
     except subprocess.TimeoutExpired:
         return {'error': 'timeout'}
 
@@ -394,14 +400,23 @@ def main():
             brats[cfg] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median',
                                              'value_at_median', 'config', 'roofline')}
         res['brats'] = brats
+    if not args.no_brats and args.config == 'cfg2' and world > 1:
+        # BASELINE configs[2]: polyp 352 x 352 data-parallel (quoted on 4 GPUs) -- at 6 images per GPU like the other blocks (weak scaling) AND with the
+        # reference's semantics, where --bs 6 is the GLOBAL batch split over the ranks (train2d.py:791: 6 // 4 = 1 image per rank, a launch-bound step)
+        k3, w3 = max(10, args.steps // 2), max(3, args.warmup // 2)
+        polyp = {}
+        for tag, bsz in (('cfg3_bs6_per_gpu', 6), ('cfg3_global_bs6', max(1, 6 // world))):
+            r = measure('cfg3', args, k3, w3, rank, world, dev, other_order=False, batch=bsz)
+            polyp[tag] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'value_at_median', 'config')}
+        res['polyp'] = polyp
     if rank != 0:
         return
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = run_cpu_baseline(args.config)
     if world == 1 and not args.graph and not args.single_order:
         res['config']['hipgraph_replay'] = run_graph_replay(args)
-        if args.engine == 'x6' and not os.environ.get('SEGX_F16X3'):
-            res['config']['f16x3_opt_in'] = run_f16x3_opt_in(args)
+        if args.config == 'cfg2':                      # the launch-bound configuration (256 x 256, bs 2) as one graph: where capture matters most
+            res['config']['hipgraph_replay_cfg1'] = run_graph_replay(args, config='cfg1')
     print(json.dumps(res), flush=True)
 
 

@@ -71,11 +71,6 @@ typedef struct {
                                        * it again).  Used by the wave-specialised 256x128 / 128x256 bf16x6 kernels with a plain epilogue; every other
                                        * path reads B itself, which must stay valid.  Results are bit-identical either way. */
     int64_t bp_b0, bp_b1;             /* batch strides of b_planes in bf16 elements (3*N*K per matrix; 0 = shared) */
-    float* h3_ws;                     /* optional: segx_gemm_h3_ws_floats(M, N, nb0, nb1) floats of scratch.  When given AND the call lands on a
-                                       * wave-specialised 256x128 / 128x256 bf16x6 kernel with a plain epilogue, the product is evaluated in the
-                                       * "f16x3" scheme instead (gemm_h3.h): operand rows scaled by powers of two into fp16's range, two fp16
-                                       * planes, THREE matrix instructions per block product; error bound 2^-23 sum|a||b| + a block-floating-point
-                                       * term 2^-39 (max_row|a| sum|b| + max_row|b| sum|a|).  NULL (the default): bf16x6. */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are
@@ -87,7 +82,6 @@ int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int*
  * segx_x6_presplit_elems(rows, K, nb0, nb1) 2-byte elements, 16-byte aligned.  The reference has no counterpart (its GEMMs are torch.matmul,
  * segtran_shared.py:414-449, 559-567); this removes the per-workgroup re-split of shared weights. */
 int64_t segx_x6_presplit_elems(int rows, int K, int nb0, int nb1);
-int64_t segx_gemm_h3_ws_floats(int M, int N, int nb0, int nb1);       /* size of segx_gemm_desc.h3_ws */
 int segx_x6_presplit(const float* W, int rows, int K, int64_t s_row, int64_t s_k, int nb0, int nb1, int64_t s_b0, int64_t s_b1, void* planes, void* stream);
 
 
@@ -291,7 +285,7 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 8 = outputs per strip of the depthwise weight gradient (default 8192; >= 256);
  * knob 6 = schedule variant of the bf16x6 kernels with IDENTICAL results (0 = product; 1 = raised wave priority in the MFMA phase / of the consumer
  * waves; 6 = split-early schedule, 7 = product schedule at two waves per SIMD); the ablation variants 2..5, whose results are NOT the GEMM, exist only
- * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8); knob 10 = waves of the f16x3 workgroup (segx_gemm_desc.h3_ws): 8 (default) or 16 (eight consumer + eight producer waves on the 256x128 tile; measured: no gain);
+ * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,

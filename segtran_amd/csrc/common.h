@@ -141,7 +141,6 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 struct Knobs {
     std::atomic<int> engine{SEGX_ENGINE_F32};       // knob 4: default tile engine
     std::atomic<int> x6_variant{0};                 // knob 6: schedule variants of the bf16x6 kernels (0 product; ablations only in SEGX_BENCH builds)
-    std::atomic<int> h3_waves{8};                   // knob 10: waves of the f16x3 workgroup (8; 16 = the eight-consumer / eight-producer form of gemm_h3.h)
     std::atomic<int> x6_launches{0};                // knob 5: launches that ran on the bf16x6 engine since the last query
     std::atomic<int> ws_grid{256};                  // knob 9: workgroups of a persistent (wave-specialised) launch
     std::atomic<int> conv_x6_wgrad_all{0};          // knob 7

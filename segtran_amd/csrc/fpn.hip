@@ -363,8 +363,9 @@ extern "C" int segx_rng_advance(uint64_t* base, uint64_t span, void* stream_) {
 }
 extern "C" int segx_tune(int knob, int value) {
     segx::Knobs& k = segx::knobs();
-    if (knob == 1) { k.interp_variant = value; return 0; }
-    if (knob == 2) { k.conv_small_policy = value; return 0; }
+    // every knob accepts only the settings the product suite exercises (tests/): an unknown value is an error, never a silent new code path
+    if (knob == 1) { if (value < 0 || value > 2) return -1; k.interp_variant = value; return 0; }
+    if (knob == 2) { if (value != 0 && value != 1) return -1; k.conv_small_policy = value; return 0; }
     if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; return k.engine.exchange(value); }
     if (knob == 8) { if (value < 256) return -1; k.dw_strip_outputs = value; return 0; }
     if (knob == 7) { if (value < 0 || value > 2) return -1; k.conv_x6_wgrad_all = value; return 0; }
@@ -374,7 +375,6 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 6) { if (value != 0 && value != 1 && value != 6 && value != 7) return -1; k.x6_variant = value; return 0; }
 #endif
     if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
-    if (knob == 10) { if (value != 8 && value != 16) return -1; k.h3_waves = value; return 0; }
     if (knob == 5) { return k.x6_launches.exchange(0); }
     return -1;
 }

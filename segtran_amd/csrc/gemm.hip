@@ -19,7 +19,6 @@
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
 #include "gemm_x6ws.h"
-#include "gemm_h3.h"
 #include "gemm_tuned.h"
 
 namespace segx {
@@ -75,68 +74,6 @@ template <class Cfg, bool AKC>
 __global__ __launch_bounds__(512) void gemm_x6ws_pre_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[X6WsLds<Cfg>::BYTES];
     x6ws_body<Cfg, PreMk6<Cfg, AKC>, SEGX_EPI_NONE, 0>(g, PreMk6<Cfg, AKC>{}, lds);
-}
-
-// ... in the two-plane fp16 scheme of gemm_h3.h ("f16x3": three matrix instructions per block product), operands scaled per row by g.sa / g.sb
-template <class Cfg, bool AKC, bool BKC>
-__global__ __launch_bounds__(512) void gemm_h3ws_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * H3Lds<Cfg>::BYTES];
-    x6ws_body<Cfg, H3Mk<Cfg, AKC, BKC>, SEGX_EPI_NONE, 0, H3WsEngine>(g, H3Mk<Cfg, AKC, BKC>{}, lds);
-}
-
-// ... its 16-wave form (gemm_h3.h: eight consumer + eight producer waves on the 256 x 128 tile; segx_tune knob 10)
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(1024) void gemm_h3ws16_kernel(GemmArgs g) {
-    using Cfg = Cfg16w;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * H3Lds<Cfg>::BYTES];
-    h3ws16_body<Cfg, H3Mk16<Cfg, AKC, BKC>>(g, H3Mk16<Cfg, AKC, BKC>{}, lds);
-}
-
-// Row maxima of |X| for the f16x3 scales: mx[z][row] = bits of max_k |X[z][row][k]| (non-negative floats order like their bit patterns).
-// k-contiguous operand: one wave per row, 16-byte loads along k.  Row-contiguous operand: one thread per row (coalesced over the rows), the k range cut
-// into gridDim.y slices merged with atomicMax (order-independent, hence deterministic); mx is zeroed before.
-__global__ __launch_bounds__(256) void h3_rowmax_kc_kernel(const float* __restrict__ X, int rows, int K, int64_t s_row, int64_t s_b0, int64_t s_b1, int nb1,
-                                                          unsigned* __restrict__ mx) {
-    const int z = blockIdx.y, z0 = z / nb1, z1 = z - z0 * nb1, lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* __restrict__ x = X + z0 * s_b0 + z1 * s_b1 + (int64_t)row * s_row;
-    float m = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
-        const float4 v = *reinterpret_cast<const float4*>(x + k);
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
-    }
-    m = wave_max(m);
-    if (lane == 0) mx[(int64_t)z * rows + row] = __float_as_uint(m);
-}
-__global__ __launch_bounds__(256) void h3_rowmax_rc_kernel(const float* __restrict__ X, int rows, int K, int64_t s_k, int64_t s_b0, int64_t s_b1, int nb1,
-                                                          unsigned* __restrict__ mx) {
-    const int z = blockIdx.z, z0 = z / nb1, z1 = z - z0 * nb1;
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= rows) return;
-    const int per = (K + gridDim.y - 1) / gridDim.y, k0 = blockIdx.y * per, k1 = (k0 + per < K) ? k0 + per : K;
-    const float* __restrict__ x = X + z0 * s_b0 + z1 * s_b1 + row;
-    float m = 0.f;
-#pragma unroll 4
-    for (int k = k0; k < k1; ++k) m = fmaxf(m, fabsf(x[(int64_t)k * s_k]));
-    atomicMax(mx + (int64_t)z * rows + row, __float_as_uint(m));
-}
-// mx -> fwd[z][32 * R32] (permuted: H3Dense; entries past `rows` are 0) and inv[z][rows]: s = 2^(14 - floor(log2 max)) (the row's maximum lands in
-// [2^14, 2^15)) and 1 / s; an all-zero (or non-finite) row gets 1
-__global__ __launch_bounds__(256) void h3_scales_kernel(const unsigned* __restrict__ mx, float* __restrict__ fwd, float* __restrict__ inv, int rows, int nb, int G) {
-    const int r32 = h3_rg(rows, G), padded = G * r32;          // G = rows per permutation granule: 32 (8-wave kernels), 64 (16-wave kernel)
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)padded * nb) return;
-    const int z = (int)(i / padded), row = (int)(i - (int64_t)z * padded);
-    float s = 0.f;
-    if (row < rows) {
-        const int e = (int)((mx[(int64_t)z * rows + row] >> 23) & 0xFFu);      // biased exponent of the maximum
-        int k = (e == 0 || e == 255) ? 0 : 14 - (e - 127);
-        k = k < -100 ? -100 : (k > 100 ? 100 : k);
-        s = __uint_as_float((unsigned)(127 + k) << 23);
-        inv[(int64_t)z * rows + row] = __uint_as_float((unsigned)(127 - k) << 23);
-    }
-    fwd[(int64_t)z * padded + (row % G) * r32 + row / G] = s;
 }
 
 // fp32 operand [nb][rows][K] (any of the two unit-stride layouts) -> three bf16 planes [nb][plane][rows][K], k contiguous: x = hi + mid + lo with the
@@ -319,9 +256,6 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = d->bias_mode ? d->bias : nullptr; g.aux = d->epilogue == SEGX_EPI_GELU ? d->aux : nullptr;
     g.gmax = d->gmax;
-#ifdef SEGX_PROBE_TIMING
-    g.aux = d->aux;                                   // bench-only: the cycle-stamp buffer of gemm_x6ws.h
-#endif
     g.M = d->M; g.N = d->N; g.K = d->K; g.nb1 = d->nb1; g.nbatch = d->nb0 * d->nb1;
     g.a_b0 = d->a_b0; g.a_b1 = d->a_b1; g.a_m = d->a_m; g.a_k = d->a_k;
     g.b_b0 = d->b_b0; g.b_b1 = d->b_b1; g.b_n = d->b_n; g.b_k = d->b_k;
@@ -337,7 +271,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     const int nbatch = d->nb0 * d->nb1;
     g.c_split = (int64_t)nbatch * d->M * d->N;
     g.slab = breduce ? 1 : 0;
-    g.Bp = nullptr; g.bp_plane = g.bp_b0 = g.bp_b1 = 0; g.sa = g.sb = g.sai = g.sbi = nullptr;
+    g.Bp = nullptr; g.bp_plane = g.bp_b0 = g.bp_b1 = 0;
     if (splitk > 1 || breduce) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS64x256, "segx_gemm_f32: bad tile %d", d->tile);
     const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS64x256;
@@ -423,57 +357,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     } while (0)
         using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>;      // few output channels x many positions (backbone pointwise convolutions)
         // pre-split B operand (segx_x6_presplit): the wave-specialised 256 x 128 / 128 x 256 kernels with a copy-only B loader; anything else ignores the planes
-        const bool h3 = d->h3_ws && ws && !gelu && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x256) ; 
-        const bool pre = !h3 && d->b_planes && ws && !gelu && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x256);
-        if (h3) {
-            // f16x3: row scales of both operands (three small launches), then the two-plane kernel
-            // workspace: permuted scales of A and B, their inverses, the row maxima
-            float* const sa = d->h3_ws; float* const sb = sa + (int64_t)nbatch * 32 * h3_r32(d->M);
-            float* const sai = sb + (int64_t)nbatch * 32 * h3_r32(d->N); float* const sbi = sai + (int64_t)nbatch * d->M;
-            unsigned* const mx = reinterpret_cast<unsigned*>(sbi + (int64_t)nbatch * d->N);
-            const int64_t nmx = (int64_t)nbatch * ((int64_t)d->M + d->N);
-            if (hipMemsetAsync(mx, 0, nmx * sizeof(unsigned), stream) != hipSuccess) return fail(1, "segx_gemm_f32: hipMemsetAsync failed");
-            if (akc) hipLaunchKernelGGL(h3_rowmax_kc_kernel, dim3(ceil_div(d->M, 4), nbatch), dim3(256), 0, stream, A, d->M, d->K, d->a_m, d->a_b0, d->a_b1, d->nb1, mx);
-            else hipLaunchKernelGGL(h3_rowmax_rc_kernel, dim3(ceil_div(d->M, 256), (int)i64min(64, ceil_div(d->K, 64)), nbatch), dim3(256), 0, stream, A, d->M, d->K, d->a_k,
-                                    d->a_b0, d->a_b1, d->nb1, mx);
-            unsigned* const mxb = mx + (int64_t)nbatch * d->M;
-            if (bkc) hipLaunchKernelGGL(h3_rowmax_kc_kernel, dim3(ceil_div(d->N, 4), nbatch), dim3(256), 0, stream, B, d->N, d->K, d->b_n, d->b_b0, d->b_b1, d->nb1, mxb);
-            else hipLaunchKernelGGL(h3_rowmax_rc_kernel, dim3(ceil_div(d->N, 256), (int)i64min(64, ceil_div(d->K, 64)), nbatch), dim3(256), 0, stream, B, d->N, d->K, d->b_k,
-                                    d->b_b0, d->b_b1, d->nb1, mxb);
-            const bool w16 = kget(knobs().h3_waves) == 16 && tile == SEGX_TILE_256x128;      // the 16-wave form (knob 10): 64-row permutation granules
-            const int gran = w16 ? 64 : 32;
-            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->M) * nbatch, (int64_t)256)), dim3(256), 0, stream, mx, sa, sai, d->M, nbatch, gran);
-            hipLaunchKernelGGL(h3_scales_kernel, dim3((unsigned)ceil_div((int64_t)32 * h3_r32(d->N) * nbatch, (int64_t)256)), dim3(256), 0, stream, mxb, sb, sbi, d->N, nbatch, gran);
-            g.sa = sa; g.sb = sb; g.sai = sai; g.sbi = sbi;
-#define SEGX_LAUNCHWS_H3(CFG, AK, BK)                                                                      \
-    do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
-        const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
-        SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
-        const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);                             \
-        hipLaunchKernelGGL((gemm_h3ws_kernel<CFG, AK, BK>), dim3(G), dim3(512), 0, stream, g);             \
-    } while (0)
-#define SEGX_LAUNCHWS_H3_LAYOUT(CFG)                                                                       \
-    do {                                                                                                   \
-        if (akc && bkc) SEGX_LAUNCHWS_H3(CFG, true, true); else if (akc) SEGX_LAUNCHWS_H3(CFG, true, false);    \
-        else if (bkc) SEGX_LAUNCHWS_H3(CFG, false, true); else SEGX_LAUNCHWS_H3(CFG, false, false);        \
-    } while (0)
-            if (w16) {
-                using Cfg16 = Cfg16w;
-                g.tiles_m = ceil_div(d->M, Cfg16::BM); g.tiles_n = ceil_div(d->N, Cfg16::BN);
-                const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;
-                SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");
-                const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);
-                if (akc && bkc) hipLaunchKernelGGL((gemm_h3ws16_kernel<true, true>), dim3(G), dim3(1024), 0, stream, g);
-                else if (akc) hipLaunchKernelGGL((gemm_h3ws16_kernel<true, false>), dim3(G), dim3(1024), 0, stream, g);
-                else if (bkc) hipLaunchKernelGGL((gemm_h3ws16_kernel<false, true>), dim3(G), dim3(1024), 0, stream, g);
-                else hipLaunchKernelGGL((gemm_h3ws16_kernel<false, false>), dim3(G), dim3(1024), 0, stream, g);
-            }
-            else if (tile == SEGX_TILE_256x128) SEGX_LAUNCHWS_H3_LAYOUT(Cfg256x128); else SEGX_LAUNCHWS_H3_LAYOUT(Cfg128x256);
-#undef SEGX_LAUNCHWS_H3_LAYOUT
-#undef SEGX_LAUNCHWS_H3
-        }
-        else if (pre) {
+        const bool pre = d->b_planes && ws && !gelu && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x256);
+        if (pre) {
             g.Bp = static_cast<const unsigned short*>(d->b_planes); g.bp_plane = (int64_t)d->N * d->K; g.bp_b0 = d->bp_b0; g.bp_b1 = d->bp_b1;
 #define SEGX_LAUNCHWS_PRE(CFG)                                                                             \
     do {                                                                                                   \
@@ -567,7 +452,6 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
 }
 
 extern "C" int64_t segx_x6_presplit_elems(int rows, int K, int nb0, int nb1) { return (int64_t)nb0 * nb1 * 3 * rows * K; }
-extern "C" int64_t segx_gemm_h3_ws_floats(int M, int N, int nb0, int nb1) { return (int64_t)nb0 * nb1 * (32 * (segx::h3_r32(M) + segx::h3_r32(N)) + 2 * ((int64_t)M + N)); }
 
 extern "C" int segx_x6_presplit(const float* W, int rows, int K, int64_t s_row, int64_t s_k, int nb0, int nb1, int64_t s_b0, int64_t s_b1, void* planes,
                                 void* stream_) {

@@ -39,8 +39,6 @@ struct GemmArgs {
     float dropout_p; uint64_t seed, offset; const uint64_t* rbase;     // rbase: device-side base added to offset (segx_set_rng_base)
     int k_chunk;                    // split-K: this launch covers k in [z_k*k_chunk, min(K, (z_k+1)*k_chunk))
     int splitk; int64_t c_split;    // slab stride in the workspace
-    const float* sa; const float* sb;    // f16x3 kernels (gemm_h3.h): power-of-two row scales of A / B per batch member, permuted layout (H3Dense)
-    const float* sai; const float* sbi;  // ... and their inverses, [batch][M] / [batch][N]
     const unsigned short* Bp; int64_t bp_plane, bp_b0, bp_b1;   // B operand pre-split into three bf16 planes (segx_x6_presplit), element strides; NULL = none
     int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
 };
@@ -248,35 +246,6 @@ __device__ __forceinline__ void gemm_mainloop(f32x16 (&acc)[Cfg::MI][Cfg::NJ], c
 // MFMA C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 // VST: 16-byte stores through quad_transpose4 where the output allows (the 4-wave kernels: +3..4 % on short contractions; the wave-specialised
 // kernels keep 4-byte stores -- their one consumer wave per SIMD pays the transposes' dependent DPP chains in full, r03_z: -4..9 %)
-#ifndef SEGX_LOAD_FENCE
-#define SEGX_LOAD_FENCE() asm volatile("" ::: "memory")
-#endif
-// f16x3 kernels (gemm_h3.h): the accumulators hold (diag(sa) A)(diag(sb) B)^T; multiply by the inverse row / column scales (powers of two: exact)
-// before the common epilogue.  Clamped indices: unconditional loads, 16 + 1 values live at a time.
-template <class Cfg>
-__device__ __forceinline__ void acc_unscale(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const GemmArgs& g, const TileCoord& t) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / Cfg::WN, wn = wave % Cfg::WN;
-    const float* __restrict__ ri = g.sai + (int64_t)t.zb * g.M;
-    const float* __restrict__ ci = g.sbi + (int64_t)t.zb * g.N;
-#pragma unroll
-    for (int i = 0; i < Cfg::MI; ++i) {
-        float rinv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = t.m0 + wm * (32 * Cfg::MI) + i * 32 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
-            rinv[r] = ri[row < g.M ? row : g.M - 1];
-        }
-#pragma unroll
-        for (int j = 0; j < Cfg::NJ; ++j) {
-            const int col = t.n0 + wn * (32 * Cfg::NJ) + j * 32 + (lane & 31);
-            const float cinv = ci[col < g.N ? col : g.N - 1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] *= rinv[r] * cinv;
-        }
-        SEGX_LOAD_FENCE();                                     // keeps the next block's 16 loads from being hoisted above this one (register budget)
-    }
-}
-
 template <int EPI, class Cfg = Cfg128, bool VST = true>
 __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::NJ], const GemmArgs& g, const TileCoord& t) {
     constexpr int MI = Cfg::MI, NJ = Cfg::NJ;

@@ -68,11 +68,7 @@ __device__ __forceinline__ void x6ws_stage_mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ],
             // accumulators so that none waits for its predecessor's result
 #define SEGX_X6WS_P(PA_, PB_)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA_], b[j][PB_], acc[i][j], 0, 0, 0);
-#ifdef SEGX_PROBE_3MFMA                                   // bench-only speed probe of a two-plane / three-product engine (results are NOT the GEMM)
-            SEGX_X6WS_P(0, 1) SEGX_X6WS_P(1, 0) SEGX_X6WS_P(0, 0)
-#else
             SEGX_X6WS_P(0, 2) SEGX_X6WS_P(2, 0) SEGX_X6WS_P(1, 1) SEGX_X6WS_P(0, 1) SEGX_X6WS_P(1, 0) SEGX_X6WS_P(0, 0)
-#endif
 #undef SEGX_X6WS_P
         }
     }
@@ -98,27 +94,6 @@ struct X6WsStream {
         if (!valid) return;
         if (k + BKT >= kend) { ++r; open(g, mk, pos, G, total); }
         else k += BKT;
-    }
-};
-
-// bench-only cycle stamps (-DSEGX_PROBE_TIMING, tools/ws_timing.py): lane 0 of one consumer and one producer wave of workgroup 0 writes s_memtime at the
-// phase boundaries of its first 48 stages into the buffer passed as desc.aux
-#ifdef SEGX_PROBE_TIMING
-#define SEGX_TSTAMP(role, stage, slot)                                                                                         \
-    do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (stage) < 48 && g.aux)                                               \
-             reinterpret_cast<unsigned long long*>(g.aux)[((role) * 48 + (stage)) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define SEGX_TSTAMP(role, stage, slot) ((void)0)
-#endif
-
-// What x6ws_body needs to know about the numeric scheme of the LDS image: bf16x6 here, the two-plane fp16 scheme in gemm_h3.h
-struct X6WsEngine {
-    static constexpr bool SCALED = false;
-    static constexpr int NSETS = 2;                          // register sets of a producer (see x6ws_body)
-    template <class Cfg> struct Lds { static constexpr int A_BYTES = X6Lds<Cfg>::A_BYTES, STAGE = X6Lds<Cfg>::BYTES; };
-    template <class Cfg> static __device__ __forceinline__ void mfma(f32x16 (&acc)[Cfg::MI][Cfg::NJ], const unsigned char* __restrict__ LA_,
-                                                                     const unsigned char* __restrict__ LB_, int arow, int brow, int kh) {
-        x6ws_stage_mfma<Cfg>(acc, LA_, LB_, arow, brow, kh);
     }
 };
 
@@ -152,10 +127,10 @@ __device__ __forceinline__ void x6ws_put(const LA& la, const LB& lb, float (&ra)
 // EPI as gemm_epilogue.  PRIO (segx_tune knob 6; results are only defined for 0 and 1): 1 = consumers run at raised wave priority; ablations that
 // price the producers' parts: 2 = no split arithmetic (raw bits stored), 3 = no global loads after a work item's first stage, 4 = no LDS stores,
 // 5 = producers only keep the barrier count (what the consumers reach alone).
-template <class Cfg, class MK, int EPI, int PRIO = 0, class EN = X6WsEngine>
+template <class Cfg, class MK, int EPI, int PRIO = 0>
 __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsigned char* __restrict__ lds) {
     using LA = typename MK::LA; using LB = typename MK::LB;
-    constexpr int STAGE = EN::template Lds<Cfg>::STAGE, A_BYTES = EN::template Lds<Cfg>::A_BYTES;
+    constexpr int STAGE = X6Lds<Cfg>::BYTES, A_BYTES = X6Lds<Cfg>::A_BYTES;
     const int wave = SEGX_WAVE_UNIFORM((int)(threadIdx.x >> 6));
     const int G = gridDim.x, pos = ws_round_pos(blockIdx.x, G);
     const int total = g.tiles_m * g.tiles_n * g.nbatch * g.splitk;
@@ -171,38 +146,6 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
         const int ptid = threadIdx.x - 256;
         X6WsStream<Cfg, MK> st; st.r = 0; st.ptid = ptid; st.open(g, mk, pos, G, total);
         if (!st.valid) return;
-        if constexpr (EN::NSETS == 3) {
-            // THREE register sets and an interleaved stage (the engine's `stage` deals the load instructions of set X -- stage s+3 -- out between the
-            // split-and-store groups of set Y -- stage s+1): a load has two stage times to land and the load path drains under the arithmetic.
-            float p0[LA::NREG], q0[LB::NREG], p1[LA::NREG], q1[LB::NREG], p2[LA::NREG], q2[LB::NREG];
-            bool v0, v1, v2;
-            st.la.load6(p0, st.k, st.kend, ptid); st.lb.load6(q0, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-            v1 = st.valid; st.la.load6(p1, st.k, st.kend, ptid); st.lb.load6(q1, st.k, st.kend, ptid); st.next(g, mk, pos, G, total);
-            v2 = st.valid;
-            EN::stage(st.la, st.lb, p2, q2, p0, q0, st.k, lds, lds + A_BYTES, ptid);                       // loads of stage 2 under the split of stage 0
-            st.next(g, mk, pos, G, total);
-            int par3 = 0;
-            int tst = 0; (void)tst;
-            for (;;) {
-                if (wave == 4) SEGX_TSTAMP(1, tst, 0);
-                SEGX_LDS_BARRIER(); par3 ^= 1;
-                if (wave == 4) SEGX_TSTAMP(1, tst, 1);
-                if (!v1) break;
-                v0 = st.valid; EN::stage(st.la, st.lb, p0, q0, p1, q1, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
-                if (wave == 4) SEGX_TSTAMP(1, tst, 3);
-                st.next(g, mk, pos, G, total);
-                ++tst;
-                SEGX_LDS_BARRIER(); par3 ^= 1;
-                if (!v2) break;
-                v1 = st.valid; EN::stage(st.la, st.lb, p1, q1, p2, q2, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
-                st.next(g, mk, pos, G, total);
-                SEGX_LDS_BARRIER(); par3 ^= 1;
-                if (!v0) break;
-                v2 = st.valid; EN::stage(st.la, st.lb, p2, q2, p0, q0, st.k, lds + par3 * STAGE, lds + par3 * STAGE + A_BYTES, ptid);
-                st.next(g, mk, pos, G, total);
-            }
-            return;
-        }
         float a0[LA::NREG], b0[LB::NREG], a1[LA::NREG], b1[LB::NREG];
         unsigned oka0, okb0, oka1, okb1;
         oka0 = st.la.load6(a0, st.k, st.kend, ptid); okb0 = st.lb.load6(b0, st.k, st.kend, ptid);
@@ -249,15 +192,11 @@ __device__ __forceinline__ void x6ws_body(const GemmArgs& g, const MK& mk, unsig
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
         for (int kt = t.kbeg; kt < t.kend; kt += BKT) {
-            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 0);
             SEGX_LDS_BARRIER();
-            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 1);
             const unsigned char* const P = lds + par * STAGE;
-            EN::template mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
-            if (wave == 0 && r == 0) SEGX_TSTAMP(0, (kt - t.kbeg) / BKT, 2);
+            x6ws_stage_mfma<Cfg>(acc, P, P + A_BYTES, arow, brow, kh);
             par ^= 1;
         }
-        if (EN::SCALED) acc_unscale<Cfg>(acc, g, t);
         gemm_epilogue<EPI, Cfg, false>(acc, g, t);        // an empty split-K slab writes zeros
     }
 }

@@ -48,6 +48,9 @@ class GradReducer:
         if gather:
             optimizer.use_gathered_grads()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # the host-side (gloo) twin of the group for check_equal_batch, created HERE: dist.new_group is collective over the DEFAULT group, and the
+        # reducer is constructed by every rank at the same point of the program (a lazy creation inside the first check would hang a strict sub-group)
+        self.host_group = _host_group(group) if dist.is_initialized() and self.world > 1 else None
         step = max(1, int(bucket_mb * 1024 * 1024 // 4))
         # buckets of WHOLE parameters (flat range a:b, parameter range i0:i1), closed once they reach bucket_mb
         self.buckets, a, i0 = [], 0, 0
@@ -164,21 +167,21 @@ def reduce_scalars(t, group=None):
     return t
 
 
-_HOST_GROUPS = {}
+_HOST_GROUPS = {}                  # group object (None = the default group) -> its gloo twin; the key keeps the group alive, so it cannot be recycled
 
 
 def _host_group(group=None):
-    """A gloo twin of `group` for tiny host-side agreements (created collectively on first use): its collectives never touch the GPU streams."""
+    """A gloo twin of `group` for tiny host-side agreements: its collectives never touch the GPU streams.  dist.new_group is collective over the
+    whole DEFAULT group -- call this where every rank passes (GradReducer.__init__ does), not from inside a sub-group's step."""
     if dist.get_backend(group) == 'gloo':
         return group
-    key = id(group)
-    if key not in _HOST_GROUPS:
+    if group not in _HOST_GROUPS:
         ranks = list(range(dist.get_world_size())) if group is None else dist.get_process_group_ranks(group)
-        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend='gloo')
-    return _HOST_GROUPS[key]
+        _HOST_GROUPS[group] = dist.new_group(ranks=ranks, backend='gloo')
+    return _HOST_GROUPS[group]
 
 
-def check_equal_batch(n, group=None):
+def check_equal_batch(n, group=None, host_group=None):
     """Every rank must hold the same per-GPU batch (train2d.py:791 `bs // world_size`): the gradient AVG all-reduce, the synchronised
     BatchNorm merge and its backward all weight the ranks equally.  Called by TrainStep on EVERY step and on EVERY rank -- collective-safe: a
     check entered only by the ranks whose batch changed (a ragged last batch) would be matched with the other ranks' next collective.  One
@@ -186,7 +189,7 @@ def check_equal_batch(n, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) <= 1:
         return
     t = torch.tensor([float(n), -float(n)], dtype=torch.float32)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=_host_group(group))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=host_group if host_group is not None else _host_group(group))
     hi, lo = t.tolist()
     if hi != -lo:
         raise RuntimeError('data-parallel step with unequal per-rank batch sizes (between %d and %d, this rank %d): gradients and synchronised '

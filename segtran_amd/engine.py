@@ -104,9 +104,10 @@ def init_optimizer(net, c_or_task, t_total=10000, warmup_steps=500, lr=None, dec
     low = [p for n, p in named if 'backbone' in n]
     high = [p for n, p in named if 'backbone' not in n and 'alphas' in n]
     normal = [p for n, p in named if 'backbone' not in n and 'alphas' not in n]
-    groups = [dict(params=normal, weight_decay=decay, lr=lr), dict(params=low, weight_decay=decay * 0.1, lr=lr)]
-    if high:
-        groups.append(dict(params=high, weight_decay=0.0, lr=lr * 100))
+    # ALWAYS the reference's four groups in its order -- normal, low_decay, (empty) no_decay, high_lr (train2d.py:536-541, train3d.py:334-339) -- so
+    # that a reference checkpoint's 'optim_state' (four param_groups) loads through Optimizer.load_state_dict, which matches groups by position
+    groups = [dict(params=normal, weight_decay=decay, lr=lr), dict(params=low, weight_decay=decay * 0.1, lr=lr),
+              dict(params=[], weight_decay=0.0, lr=lr), dict(params=high, weight_decay=0.0, lr=lr * 100)]
     warmup_steps = min(warmup_steps, t_total // 2)
     return BertAdam(groups, lr=lr, warmup=warmup_steps / t_total, t_total=t_total, weight_decay=decay,
                     global_grad_clip=DEFAULTS['grad_clip'] if grad_clip is None else grad_clip)
@@ -168,7 +169,7 @@ class TrainStep:
             # EVERY step, on every rank: a ragged last batch shows up on SOME ranks only, and a check entered by those alone would pair its
             # collective with the others' gradient / BatchNorm collectives (hang or garbage instead of the intended error)
             from .dist import check_equal_batch
-            check_equal_batch(x.shape[0], self.reducer.group)
+            check_equal_batch(x.shape[0], self.reducer.group, self.reducer.host_group)
         mask = map_mask(self.task, raw_mask, self.exclusive)
         if self.augment is not None:
             x, mask = self.augment(x, mask)

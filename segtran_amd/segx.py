@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
                 ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i), ('engine', c_i),
-                ('b_planes', c_p), ('bp_b0', c_l), ('bp_b1', c_l), ('h3_ws', c_p)]
+                ('b_planes', c_p), ('bp_b0', c_l), ('bp_b1', c_l)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
@@ -51,12 +51,6 @@ class SegxLib:
         self.c.segx_version.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
-        # opt-in (SEGX_F16X3=1): planned GEMMs that land on the wave-specialised 256x128 / 128x256 kernels with a plain epilogue and at least
-        # f16x3_min_macs multiply-adds run in the two-plane fp16 scheme (segx_gemm_desc.h3_ws, gemm_h3.h: +22..26 % on the 24576 x 1792 x 1792 x 4
-        # projections incl. the row-scale pre-pass; below ~6e10 multiply-adds the pre-pass eats the gain).  Off by default: DESIGN.md 5c-r3.
-        self.f16x3_auto = os.environ.get('SEGX_F16X3', '0') == '1'
-        self.f16x3_min_macs = 6.0e10
-        self.f16x3_launches = 0
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
         kinds = {'p': c_p, 'i': c_i, 'l': c_l, 'f': c_f, 'u': c_u}
         for name, sig in _SIGS.items():
@@ -112,7 +106,7 @@ class SegxLib:
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
              bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
-             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None, b_planes=None, f16x3=False):
+             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None, b_planes=None):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
         a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
         splitk = 0: take tile and split factor from segx_gemm_plan and allocate the slab workspace here.
@@ -133,21 +127,13 @@ class SegxLib:
         if b_planes is not None:
             self._chk_t(b_planes[0])
             d.b_planes, d.bp_b0, d.bp_b1 = _ptr(b_planes[0]), b_planes[1], b_planes[2]
+        d.engine = 0 if engine is None else 1 + self.ENGINES[engine]        # before planning: the plan is made for the engine of THIS call
+        d.batch_reduce = 1 if batch_reduce else 0
         if splitk == 0:
             t, sk = c_i(0), c_i(0)
             self.check(self.c.segx_gemm_plan(_ptr(A), _ptr(B), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)), 'segx_gemm_plan')
             tile, splitk = t.value, sk.value
-            if self.f16x3_auto and float(M) * N * K * nb[0] * nb[1] >= self.f16x3_min_macs:
-                f16x3 = True
-                if tile == TILE_256x128 and a_strides[3] == 1 and M >= 8192 and N % 256 == 0:
-                    tile = TILE_WS128x256                     # r03_ag: the 128 x 256 tile is 3..10 % faster in this scheme when A is k-contiguous
             workspace = torch.empty(splitk * nb[0] * nb[1] * M * N, dtype=torch.float32, device=C.device) if (splitk > 1 or batch_reduce) else None
-        d.batch_reduce = 1 if batch_reduce else 0
-        if f16x3 and tile in (TILE_256x128, TILE_WS128x256) and epilogue == EPI_NONE:
-            h3ws = torch.empty(self.c.segx_gemm_h3_ws_floats(M, N, nb[0], nb[1]), dtype=torch.float32, device=C.device)
-            d.h3_ws = _ptr(h3ws)
-            self.f16x3_launches += 1
-        d.engine = 0 if engine is None else 1 + self.ENGINES[engine]
         d.splitk, d.workspace = splitk, _ptr(workspace)
         d.tile = self.force_tile if self.force_tile is not None else tile
         if self.gemm_prof is not None and C.is_cuda:
@@ -522,7 +508,7 @@ _SIGS = {
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
-    'segx_gemm_h3_ws_floats': 'iiii', 'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
+    'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
     'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',

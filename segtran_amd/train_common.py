@@ -191,8 +191,9 @@ def load_model(net, args, path, optimizer=None, load_optim_state=False):
     net.load_state_dict(own)
     if load_optim_state and optimizer is not None and optim_state is not None and not dropped:      # :629-635
         optimizer.load_state_dict(optim_state)
-        args.lr_warmup_steps = 0
-        logging.info('LR Warm up reset to 0 iters.')
+        args.lr_warmup_steps = 0                  # the reference's bookkeeping (train2d.py:633-635); the optimizer built above keeps ITS warm-up: what
+        logging.info('optimizer state restored: schedule position %d (args.lr_warmup_steps set to 0 as in the reference)',     # continues is the loaded position
+                     getattr(optimizer, 'step_count', 0))
     logging.info("Model loaded from '%s' (%d/%d tensors)", path, len(keep), len(own))
     return cp_iter
 
@@ -239,8 +240,10 @@ def run(args, cfg, batches=None):
     # The optimizer exists BEFORE the checkpoint is read, as in the reference (train2d.py:1066-1077, train3d.py:652-660): a checkpoint that carries
     # 'optim_state' restores the moments and the schedule position.  (The reference's own save_model comments 'optim_state' out -- train2d.py:644,
     # train3d.py:412 -- so its checkpoints restart the moments; a 3-D resume then continues the iteration count, a 2-D one restarts it.)
-    opt = engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
-                                decay=args.decay, grad_clip=args.grad_clip)
+    # --tunebn never takes an optimizer step: no flat moment / gradient buffers (3x the parameter memory) and no gradient hooks for it.
+    tune_only = bool(getattr(args, 'tune_bn_only', False))
+    opt = None if tune_only else engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
+                                                       decay=args.decay, grad_clip=args.grad_clip)
     load_optim = dim_of(cfg) == 3 or (getattr(args, 'polyformer_mode', None) is None and getattr(args, 'opt_filters', None) is None
                                       and getattr(args, 'adversarial_mode', None) is None)           # train2d.py:1076; train3d.py:397 always
     iter_num = load_model(net, args, args.checkpoint_path, optimizer=opt, load_optim_state=load_optim) if args.checkpoint_path else 0
@@ -248,7 +251,7 @@ def run(args, cfg, batches=None):
         iter_num = 0                                                      # train2d.py:1074-1081 (`continue_iter = False`): 2-D always restarts the count
     # 3-D resumes from the checkpoint's iteration (train3d.py:658-661)
     sdist.enable_sync_batchnorm()
-    if getattr(args, 'tune_bn_only', False):
+    if tune_only:
         if batches is None:
             fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
             batches = iter(lambda: fixed, None)

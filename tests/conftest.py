@@ -11,6 +11,22 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: full-size CPU checks')
+    config.addinivalue_line('markers', 'experimental: kernels / code paths that are NOT on the product path (bench-only builds, opt-in schemes); never part '
+                                       'of a plain `-m gpu` / `-m "not gpu"` run -- select them with SEGX_EXPERIMENTAL=1 (they then run LAST)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """an experiment must not be able to turn the product suite red.  Tests marked `experimental` are deselected unless
+    SEGX_EXPERIMENTAL=1, and when selected they are moved behind every product test (so `-x` stops there only after the product has been judged)."""
+    exp = [it for it in items if it.get_closest_marker('experimental')]
+    if not exp:
+        return
+    keep = [it for it in items if not it.get_closest_marker('experimental')]
+    if os.environ.get('SEGX_EXPERIMENTAL') == '1':
+        items[:] = keep + exp
+    else:
+        config.hook.pytest_deselected(items=exp)
+        items[:] = keep
 
 
 class _Backend:

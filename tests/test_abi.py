@@ -78,3 +78,6 @@ def test_product_library_rejects_the_ablation_variants():
     for v in (2, 3, 4, 5):
         assert L.c.segx_tune(6, v) == -1
     assert L.c.segx_tune(6, 1) == 0 and L.c.segx_tune(6, 0) == 0
+    # knobs reject what the product suite does not cover: unknown knob ids and out-of-range settings
+    for knob, v in ((1, 3), (2, 2), (7, 3), (8, 10), (9, 12), (10, 16), (10, 8), (11, 0)):
+        assert L.c.segx_tune(knob, v) == -1, (knob, v)

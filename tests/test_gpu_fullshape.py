@@ -48,19 +48,15 @@ def engine_sel(request):
     from segtran_amd import segx
     L = segx.lib()
     name = request.param
-    prev = L.set_engine('x6' if name == 'x6h3' else name)
-    prev_h3 = (L.f16x3_auto, L.f16x3_min_macs)
-    if name == 'x6h3':                               # every GEMM on the wave-specialised 256 x 128 / 128 x 256 kernels in the two-plane fp16 scheme (gemm_h3.h)
-        L.f16x3_auto, L.f16x3_min_macs, L.f16x3_launches = True, 0.0, 0
+    prev = L.set_engine(name)
     L.x6_launches()
     yield name
-    if name in ('x6', 'x6h3'):
+    if name == 'x6':
         assert L.x6_launches() > 50, 'the bf16x6 engine did not run'
-    L.f16x3_auto, L.f16x3_min_macs = prev_h3
     L.set_engine(prev)
 
 
-@pytest.mark.parametrize('engine_sel', ['x6', 'f32', 'x6h3'], indirect=True)
+@pytest.mark.parametrize('engine_sel', ['x6', 'f32'], indirect=True)
 @pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2'])
 def test_fullshape_eval_every_label(case, engine_sel):
     cfg, B, tag = _case(case)
@@ -89,10 +85,8 @@ def test_fullshape_eval_every_label(case, engine_sel):
 # transformer); 'bench' = gate 0, i.e. the re-associated transformer path that bench.py's batches (6 x 1936, 4 x 2352 rows) take -- the
 # folded key / value projections and FFN mid map at N = 1936 / 2352, A = 256 / 1024.  The *_b2 cases run it at batch 2
 # through the default gate (2 x 2352 >= 4096).
-@pytest.mark.parametrize('engine_sel,reassociated,gate', [('x6', True, 'default'), ('x6', True, 'bench'), ('x6', False, 'default'), ('f32', True, 'bench'),
-                                                          ('x6h3', True, 'bench')],
-                         indirect=['engine_sel'], ids=['x6-reassociated', 'x6-reassociated-bench-gate', 'x6-reference-op-order', 'f32-reassociated-bench-gate',
-                                                       'x6-f16x3-reassociated-bench-gate'])
+@pytest.mark.parametrize('engine_sel,reassociated,gate', [('x6', True, 'default'), ('x6', True, 'bench'), ('x6', False, 'default'), ('f32', True, 'bench')],
+                         indirect=['engine_sel'], ids=['x6-reassociated', 'x6-reassociated-bench-gate', 'x6-reference-op-order', 'f32-reassociated-bench-gate'])
 @pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2'])
 def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
@@ -141,7 +135,4 @@ def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, mo
     assert n >= 25
     for k in g['unused']:                                  # N3
         assert named[str(k)].grad is None, k
-    if engine_sel == 'x6h3' and case in ('cfg2', 'cfg2_b2', 'cfg5'):   # 4096+ token rows at 1792 / 1024 features: the wave-specialised kernels are in use
-        from segtran_amd import segx
-        assert segx.lib().f16x3_launches > 0, 'no GEMM took the f16x3 kernels'
     print('%s %s gate=%s engine=%s: worst |hip - ref32| / gscale = %.2e (%s)' % (case, 'reassoc' if reassociated else 'ref-order', gate, engine_sel, worst[0], worst[1]))

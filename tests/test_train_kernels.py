@@ -140,3 +140,40 @@ def test_bertadam_follows_param_group_edits_and_rejects_mixed_schedules(backend)
     bad.zero_grad(); (a.sum() + b.sum()).backward()
     with pytest.raises(ValueError, match="share 'b1'"):
         bad.step()
+
+
+def test_reference_format_optimizer_state_with_four_groups_loads_through_load_model(backend, tmp_path):
+    """the reference ALWAYS writes four param_groups -- normal, low_decay, an empty no_decay, high_lr (train2d.py:536-541) -- and
+    torch matches groups by position, so init_optimizer must emit the same four (it emitted two or three and `--cp` with a reference 'optim_state'
+    raised "different number of parameter groups").  A checkpoint in the reference's wire format goes through train_common.load_model here."""
+    import argparse
+    from segtran_amd import engine, train_common
+    dev = backend.dev
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = torch.nn.Linear(4, 4)
+            self.head = torch.nn.Linear(4, 2)
+    torch.manual_seed(0)
+    net = Net().to(dev)
+    opt = engine.init_optimizer(net, 'fundus', t_total=100, warmup_steps=10)
+    assert [len(g['params']) for g in opt.param_groups] == [2, 2, 0, 0]
+    assert [g['weight_decay'] for g in opt.param_groups[:2]] == [opt.defaults['weight_decay'], opt.defaults['weight_decay'] * 0.1]
+    # what the reference's BertAdam.state_dict() holds after 7 steps: per-parameter {'step', 'next_m', 'next_v'}, four groups by position
+    names = ['head.weight', 'head.bias', 'backbone.weight', 'backbone.bias']
+    ps = dict(net.named_parameters())
+    g = torch.Generator(device='cpu').manual_seed(5)
+    state = {i: dict(step=7, next_m=torch.randn(ps[n].shape, generator=g), next_v=torch.rand(ps[n].shape, generator=g)) for i, n in enumerate(names)}
+    base = dict(schedule='warmup_linear', warmup=0.1, t_total=100, b1=0.9, b2=0.999, e=1e-6, max_grad_norm=0.05)
+    groups = [dict(base, params=[0, 1], weight_decay=1e-4, lr=2e-4), dict(base, params=[2, 3], weight_decay=1e-5, lr=2e-4),
+              dict(base, params=[], weight_decay=0.0, lr=2e-4), dict(base, params=[], weight_decay=0.0, lr=2e-2)]
+    path = str(tmp_path / 'iter_7.pth')
+    torch.save({'iter_num': 7, 'model': {k: v.cpu() for k, v in net.state_dict().items()}, 'optim_state': dict(state=state, param_groups=groups)}, path)
+    args = argparse.Namespace(net='unet', lr_warmup_steps=10)
+    assert train_common.load_model(net, args, path, optimizer=opt, load_optim_state=True) == 7
+    assert opt.step_count == 7 and args.lr_warmup_steps == 0
+    for i, n in enumerate(names):
+        off, cnt = opt.slices[[id(p) for p, _ in opt._all_params()].index(id(ps[n]))]
+        assert torch.equal(opt.flat_m[off:off + cnt].cpu(), state[i]['next_m'].reshape(-1)), n
+        assert torch.equal(opt.flat_v[off:off + cnt].cpu(), state[i]['next_v'].reshape(-1)), n
