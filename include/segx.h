@@ -210,13 +210,48 @@ int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const fl
                     float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
                     const float* gate, const float* dpool, float inv_S, void* stream);
 /* the two halves of segx_bn_act_bwd, for synchronised BatchNorm: reduce gives the LOCAL sums dw = sum du*xhat,
- * db = sum du; after an all-reduce of both, apply uses the GLOBAL sums and inv_n = 1 / (global element count) */
+ * db = sum du; after an all-reduce of both, apply uses the GLOBAL sums and inv_n = 1 / (global element count); dc_p / seed / offset: the
+ * drop_connect scale of segx_bn_act_fwd2 (0: none) */
 int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                            float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
-                           const float* gate, const float* dpool, float inv_S, void* stream);
+                           const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream);
 int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                           const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
-                          float inv_n, const float* gate, const float* dpool, float inv_S, void* stream);
+                          float inv_n, const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream);
+/* r04 -- training-mode BatchNorm in two launches (statistics partials, then ONE pass that finishes the statistics, normalises, activates and
+ * optionally pools / scales / adds the skip input).  Replaces the nn.BatchNorm2d/3d forward of efficientnet/model.py:96-116 and aj_i3d.py:65-97
+ * together with the ops around it in an MBConv block (swish :98,:102; squeeze-excite pooling :106; drop_connect + skip add :118-122).
+ *   parts: [C][nparts] float4 records (n, mean, M2, -) of disjoint runs covering the B*S elements of each channel; Chan et al.'s merge makes the
+ *   result independent of how a producer cut the data.  segx_bn_stats_partial writes nparts = segx_bn_nparts(B, S) per channel; the buffer
+ *   must hold segx_bn_parts_floats(B, C) floats, 16-byte aligned.  (For a producer's own partials with nparts > 256 the buffer needs C*4 more.)
+ *   parts == NULL: mean / var are INPUTS (running statistics: eval mode / synchronised BatchNorm after the merge); otherwise they are OUTPUTS
+ *   (saved for the backward pass) and run_mean / run_var (optional) are updated with momentum and the unbiased variance.
+ *   psum (optional): [B*C][segx_plane_chunks(S)] partial sums of Y per plane (the squeeze-excite pooling; segx_se_fwd2 adds the chunks up).
+ *   resid (optional): Y = act(bn(X)) * dcs[sample] + resid, dcs = drop_connect keep scale of the sample (0 or 1/(1-dc_p), Philox element
+ *   `sample` of stream (seed, offset): efficientnet/utils.py:129-154); dc_p = 0: plain skip add. */
+int64_t segx_plane_chunks(int64_t S);
+int64_t segx_bn_nparts(int B, int64_t S);
+int64_t segx_bn_parts_floats(int B, int C);
+int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream);
+int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
+                     const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
+                     int B, int C, int64_t S, float eps, int act, void* stream);
+/* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
+ * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C) floats */
+int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                     float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
+                     const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream);
+/* r04 -- the squeeze-excite excitation of an MBConv block (efficientnet/model.py:105-113) in 2 + 3 launches.
+ * fwd: p = (sum of the nch pooling chunks psum[B*C][nch]) * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2); and, when Wproj [M][C] is
+ *      given, the gate folded into per-sample projection weights Wb[b][m][k] = Wproj[m][k] * gate[b][k] (see segx_gate_weights_fwd).
+ * bwd: from dWb [B][M][C] (the per-sample weight gradient of the projection GEMM) -- or from dgate [B][C] when Wproj / dWb are NULL --:
+ *      dpool (= dL/d pooled sum, already times inv_S), dW1, db1, dW2, db2 and dWproj[m][k] = sum_b dWb * gate.  ws: segx_se_ws2_floats(B, C, Cs) floats */
+int segx_se_fwd2(const float* psum, int nch, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2, const float* Wproj,
+                 float* p, float* hpre, float* gate, float* Wb, int B, int C, int Cs, int M, void* stream);
+int64_t segx_se_ws2_floats(int B, int C, int Cs);
+int segx_se_bwd2(const float* dWb, const float* Wproj, const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1,
+                 const float* W2, float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* dWproj, float* ws,
+                 int B, int C, int Cs, int M, void* stream);
 /* depthwise k x k convolution (k in {3,5}, stride in {1,2}) with explicit top/left zero padding (static 'same'
  * padding N6, efficientnet/utils.py:248-275): Y[b,c,oy,ox] = sum w[c,ky,kx] X[b,c,oy*s+ky-pad_t, ox*s+kx-pad_l] */
 int segx_dwconv2d_fwd(const float* X, const float* W, float* Y, int B, int C, int H, int Wd, int OH, int OW, int k, int stride,

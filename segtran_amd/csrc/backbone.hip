@@ -23,6 +23,20 @@ __device__ __forceinline__ float act_grad(float u, int act) {
     return 1.0f;
 }
 
+// per-sample drop_connect scale (efficientnet/utils.py:129-154: floor(keep + U[0,1)) / keep): element `sample` of the Philox stream (seed, offset)
+__device__ __forceinline__ float drop_connect_scale(float p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase, int sample) {
+    if (!(p > 0.f)) return 1.0f;
+    return dropout_scale(seed, 0, offset + (rbase ? *rbase : 0) + (uint64_t)sample, p, 1.0f / (1.0f - p));
+}
+// the same for plain sums: ws[c][nparts] pairs (a, q)
+__device__ __forceinline__ void bn_fold_sums(const float* __restrict__ ws, int c, int nparts, float& a, float& q) {
+    const int lane = threadIdx.x & 63;
+    const float2* p = reinterpret_cast<const float2*>(ws) + (int64_t)c * nparts;
+    a = 0.f; q = 0.f;
+    for (int i = lane; i < nparts; i += 64) { const float2 v = p[i]; a += v.x; q += v.y; }
+    a = wave_sum(a); q = wave_sum(q);
+}
+
 // =================================================================================================
 // BatchNorm statistics: per channel over (B, S).  Shifted sums around a per-channel pivot (the channel's
 // first element) keep E[d^2] - E[d]^2 free of catastrophic cancellation.  Stage 1: grid (C, B, slabs).
@@ -129,13 +143,15 @@ __global__ __launch_bounds__(256) void plane_chunk_sum_kernel(const float* __res
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                          const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
                                                          float* __restrict__ ws, int C, int64_t S, float eps, int act,
-                                                         const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S) {
+                                                         const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S,
+                                                         float dc_p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase) {
     __shared__ float red[4];
     const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     // squeeze-excite behind this BatchNorm (bn_act_se): the incoming gradient is dz (w.r.t. y * gate); dy = dz * gate[plane] + dpool[plane] / S is
-    // formed on the fly instead of being written by a pass of its own (plane_scale_bwd)
-    const float gt = gate ? gate[(int64_t)bb * C + c] : 1.0f, dp = dpool ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
+    // formed on the fly instead of being written by a pass of its own (plane_scale_bwd).  dc_p > 0: the output was scaled by the sample's
+    // drop_connect factor before the skip add (bn_act_fwd2_kernel): the same factor multiplies the incoming gradient
+    const float gt = (gate ? gate[(int64_t)bb * C + c] : 1.0f) * drop_connect_scale(dc_p, seed, offset, rbase, bb), dp = dpool ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
     const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
     const int nsl = gridDim.z;
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
@@ -165,16 +181,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage2(const float* __restrict
     for (int i = 0; i < B * nsl; ++i) { a += ws[((int64_t)c * B * nsl + i) * 2]; q += ws[((int64_t)c * B * nsl + i) * 2 + 1]; }
     db[c] = a; dw[c] = q;
 }
-// dx = w * rstd * (du - [training] (db + xhat * dw) / n)
+// dx = w * rstd * (du - [training] (db + xhat * dw) / n).  FOLD: the sums come as stage-1 partials ws[c][nparts] (a = sum du, q = sum du * xhat) and
+// are added up here (bn_fold_sums); the workgroup of (chunk 0, sample 0) writes them out as the parameter gradients db_out / dw_out.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                         const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
                                                         const float* __restrict__ dw, const float* __restrict__ db, float* __restrict__ dX,
                                                         int C, int64_t S, float eps, int act, float inv_n /* 0 in eval mode */,
-                                                        const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S) {
+                                                        const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S,
+                                                        float dc_p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase,
+                                                        const float* __restrict__ ws, int nparts, float* __restrict__ dw_out, float* __restrict__ db_out) {
     const int bc = blockIdx.y, c = bc % C;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
-    const float gt = gate ? gate[bc] : 1.0f, dp = dpool ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
-    const float k1 = db[c] * inv_n, k2 = dw[c] * inv_n, sc = wc * rstd;
+    const float gt = (gate ? gate[bc] : 1.0f) * drop_connect_scale(dc_p, seed, offset, rbase, bc / C), dp = dpool ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
+    float sdb, sdw;
+    if (FOLD) {
+        bn_fold_sums(ws, c, nparts, sdb, sdw);
+        if (blockIdx.x == 0 && bc < C && threadIdx.x == 0) { db_out[c] = sdb; dw_out[c] = sdw; }
+    } else { sdb = db[c]; sdw = dw[c]; }
+    const float k1 = sdb * inv_n, k2 = sdw * inv_n, sc = wc * rstd;
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
     if ((S & 3) == 0) {
         for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
@@ -190,6 +215,132 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
             const float xh = (x[s] - m) * rstd, du = (g[s] * gt + dp) * act_grad(xh * wc + bc_, act);
             d[s] = sc * (du - k1 - xh * k2);
         }
+    }
+}
+
+// =================================================================================================
+// r04: training-mode BatchNorm (+ activation, + squeeze-excite pooling, + drop_connect scale and skip add) in TWO launches instead of four / six.
+//   launch 1 writes statistics PARTIALS -- (n, mean, M2) of a run of elements, around the run's own first element, so no cancellation --
+//   launch 2 (the apply pass) merges the partials of its channel itself (Chan et al.: exact for any split of the data) before it streams the
+//   plane: the one-thread-per-channel finalisation kernels (96 + 96 launches of ~5 us per cfg2 step) are gone, and because a partial carries its
+//   own pivot, ANY producer of the tensor can emit them (bn_stats_partial_kernel here; the depthwise convolution's epilogue: dw4 STATS).
+// Backward: the (sum du, sum du * xhat) partials of stage 1 are summed by the apply pass the same way.
+// =================================================================================================
+struct BnPart { float n, mean, m2; };
+__device__ __forceinline__ BnPart bn_merge(const BnPart& lo, const BnPart& hi) {
+    BnPart r;
+    r.n = lo.n + hi.n;
+    const float inv = r.n > 0.f ? 1.0f / r.n : 0.f, d = hi.mean - lo.mean;
+    r.mean = lo.mean + d * (hi.n * inv);
+    r.m2 = lo.m2 + hi.m2 + d * d * (lo.n * hi.n * inv);
+    return r;
+}
+// a run's shifted sums (a = sum (x - pivot), q = sum (x - pivot)^2 over n elements) as a partial
+__device__ __forceinline__ BnPart bn_part_of(float n, float a, float q, float pivot) {
+    BnPart r; r.n = n;
+    const float md = n > 0.f ? a / n : 0.f;
+    r.mean = pivot + md; r.m2 = fmaxf(q - a * md, 0.f);
+    return r;
+}
+// All partials of channel c (parts[c][nparts] as float4 (n, mean, M2, -)) merged by ONE wave; every wave of a workgroup does it redundantly (no LDS,
+// no barrier).  Lane l folds partials l, l + 64, ... in index order, then a butterfly in which both partners merge (lower lane, higher lane): the
+// result is bit-identical in every lane, every wave and every workgroup.
+__device__ __forceinline__ BnPart bn_fold(const float* __restrict__ parts, int c, int nparts) {
+    const int lane = threadIdx.x & 63;
+    const float4* p = reinterpret_cast<const float4*>(parts) + (int64_t)c * nparts;
+    BnPart s; s.n = 0.f; s.mean = 0.f; s.m2 = 0.f;
+    for (int i = lane; i < nparts; i += 64) { const float4 v = p[i]; BnPart t; t.n = v.x; t.mean = v.y; t.m2 = v.z; s = bn_merge(s, t); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        BnPart t; t.n = __shfl_xor(s.n, o); t.mean = __shfl_xor(s.mean, o); t.m2 = __shfl_xor(s.m2, o);
+        s = (lane & o) ? bn_merge(t, s) : bn_merge(s, t);
+    }
+    return s;
+}
+// launch 1: grid (C, B, slabs) as bn_stats_stage1; parts[c][b * nsl + slab]
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ X, float* __restrict__ parts, int C, int64_t S) {
+    __shared__ float red[4];
+    const int c = blockIdx.x, b = blockIdx.y, slab = blockIdx.z, nsl = gridDim.z;
+    const float* x = X + ((int64_t)b * C + c) * S;
+    const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
+    const float pivot = s0 < S ? x[s0] : 0.f;
+    float a = 0.f, q = 0.f;
+    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
+#pragma unroll 4
+        for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(x + s);
+            const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
+            a += (d0 + d1) + (d2 + d3); q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    } else {
+        for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
+    }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) {
+        const BnPart r = bn_part_of((float)(s1 > s0 ? s1 - s0 : 0), a, q, pivot);
+        reinterpret_cast<float4*>(parts)[((int64_t)c * gridDim.y + b) * nsl + slab] = make_float4(r.n, r.mean, r.m2, 0.f);
+    }
+}
+// many partials per channel (a producer with small tiles on a large map): merge them once, one wave per channel, into parts_out[c][1]
+__global__ __launch_bounds__(256) void bn_parts_merge_kernel(const float* __restrict__ parts, float* __restrict__ parts_out, int C, int nparts) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= C) return;
+    const BnPart s = bn_fold(parts, c, nparts);
+    if ((threadIdx.x & 63) == 0) reinterpret_cast<float4*>(parts_out)[c] = make_float4(s.n, s.mean, s.m2, 0.f);
+}
+struct BnFwdArgs {
+    const float* X; const float* w; const float* b; float* Y;
+    const float* parts; int nparts;              // training: statistics partials (bn_fold); NULL: use mean / var as given (running statistics)
+    float* mean; float* var;                     // training: OUT (saved for backward); else IN
+    float* run_mean; float* run_var; float momentum;
+    float* psum;                                 // POOL: psum[plane][chunk] = sum of this chunk's outputs (the squeeze-excite pooling, model.py:106)
+    const float* resid;                          // y = act(bn(x)) * dcs[sample] + resid   (MBConv skip connection, model.py:118-122); NULL: none
+    float dc_p; uint64_t seed, offset; const uint64_t* rbase;
+    int C; int64_t S; float eps; int act;
+};
+// launch 2: grid (chunks, B * C).  The workgroup of (chunk 0, sample 0) also writes mean / var and updates the running statistics.
+template <bool POOL>
+__global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
+    __shared__ float red[4];
+    const int bc = blockIdx.y, C = g.C, c = bc % C, bb = bc / C;
+    const int64_t S = g.S;
+    float m, v;
+    if (g.parts) {
+        const BnPart st = bn_fold(g.parts, c, g.nparts);
+        m = st.mean; v = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
+        if (blockIdx.x == 0 && bb == 0 && threadIdx.x == 0) {
+            g.mean[c] = m; g.var[c] = v;
+            if (g.run_mean) {
+                g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * m;
+                g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * (st.m2 / fmaxf(st.n - 1.0f, 1.0f));
+            }
+        }
+    } else { m = g.mean[c]; v = g.var[c]; }
+    const float sc = rsqrtf(v + g.eps) * g.w[c], sh = g.b[c] - m * sc;
+    const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, bb);
+    const float* x = g.X + (int64_t)bc * S; float* y = g.Y + (int64_t)bc * S;
+    const float* r = g.resid ? g.resid + (int64_t)bc * S : nullptr;
+    const int act = g.act;
+    float acc = 0.f;
+    if ((S & 3) == 0) {
+        for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + s);
+            float4 o;
+            o.x = act_fwd(xv.x * sc + sh, act); o.y = act_fwd(xv.y * sc + sh, act); o.z = act_fwd(xv.z * sc + sh, act); o.w = act_fwd(xv.w * sc + sh, act);
+            if (r) { const float4 rv = *reinterpret_cast<const float4*>(r + s); o.x = o.x * dcs + rv.x; o.y = o.y * dcs + rv.y; o.z = o.z * dcs + rv.z; o.w = o.w * dcs + rv.w; }
+            *reinterpret_cast<float4*>(y + s) = o;
+            if (POOL) acc += (o.x + o.y) + (o.z + o.w);
+        }
+    } else {
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+            float o = act_fwd(x[s] * sc + sh, act);
+            if (r) o = o * dcs + r[s];
+            y[s] = o; if (POOL) acc += o;
+        }
+    }
+    if (POOL) {
+        acc = block_sum<4>(acc, red);
+        if (threadIdx.x == 0) g.psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
     }
 }
 
@@ -699,6 +850,112 @@ __global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restr
     if (c == 0) db1[j] = s1;
 }
 
+// ---- r04: the same excitation MLP in fewer launches (32 MBConv blocks x 10 micro-kernels of 4..24 us were 2.9 ms of a 76-ms cfg2 step) ---------
+// forward  : se_hidden2 (reads the pooling CHUNKS of bn_act_fwd2_kernel<POOL> directly: no chunk-sum launch) -> se_gate_weights (gate + the
+//            gate folded into the per-sample projection weights, one launch): 2 launches instead of 5
+// backward : se_bwd_gate (dgate from the per-sample weight gradient, dz2, hidden partials over 64-channel chunks) -> se_bwd_pool_kernel ->
+//            se_wgrad_all (dW1, db1, dW2, db2 AND the projection weight gradient dW): 3 launches instead of 5
+constexpr int SE2_CHUNK = 64;
+// hpre[b][j] = b1[j] + sum_c W1[j][c] * p[b][c], p = (sum of the plane's nch pooling chunks) / S; also p (kept for the weight gradients).  grid (ceil(Cs/4), B)
+__global__ __launch_bounds__(256) void se_hidden2_kernel(const float* __restrict__ psum, int nch, float inv_S, const float* __restrict__ W1,
+                                                         const float* __restrict__ b1, float* __restrict__ p_out, float* __restrict__ hpre_out, int C, int Cs) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float* ps = psum + (int64_t)b * C * nch;
+    if (blockIdx.x == 0)
+        for (int c = threadIdx.x; c < C; c += 256) { float a = 0.f; for (int k = 0; k < nch; ++k) a += ps[(int64_t)c * nch + k]; p_out[(int64_t)b * C + c] = a * inv_S; }
+    if (j >= Cs) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { float a = 0.f; for (int k = 0; k < nch; ++k) a += ps[(int64_t)c * nch + k]; s += W1[(int64_t)j * C + c] * (a * inv_S); }
+    s = wave_sum(s);
+    if (lane == 0) hpre_out[(int64_t)b * Cs + j] = s + b1[j];
+}
+// gate[b][k] = sigmoid(b2[k] + sum_j W2[k][j] swish(hpre[b][j])) for the 64 channels k of this workgroup, then Wb[b][m][k] = W[m][k] * gate[b][k] for every
+// output row m of the projection (efficientnet/model.py:110-113 re-associated).  grid (ceil(K / 64), B); W may be NULL (gate only)
+__global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __restrict__ hpre, const float* __restrict__ W2, const float* __restrict__ b2,
+                                                              const float* __restrict__ W, float* __restrict__ gate, float* __restrict__ Wb,
+                                                              int K, int Cs, int M) {
+    __shared__ float gsh[SE2_CHUNK];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, k0 = blockIdx.x * SE2_CHUNK;
+    for (int kk = wv; kk < SE2_CHUNK; kk += 4) {
+        const int k = k0 + kk;
+        float s = 0.f;
+        if (k < K) for (int j = lane; j < Cs; j += 64) { const float hp = hpre[(int64_t)b * Cs + j]; s += W2[(int64_t)k * Cs + j] * (hp * sigm(hp)); }
+        s = wave_sum(s);
+        if (lane == 0) {
+            const float gt = k < K ? sigm(s + b2[k]) : 0.f;
+            gsh[kk] = gt;
+            if (k < K) gate[(int64_t)b * K + k] = gt;
+        }
+    }
+    __syncthreads();
+    if (!W) return;
+    const int k = k0 + lane;
+    if (k >= K) return;
+    const float gt = gsh[lane];
+    float* o = Wb + (int64_t)b * M * K;
+    for (int m = wv; m < M; m += 4) o[(int64_t)m * K + k] = W[(int64_t)m * K + k] * gt;
+}
+// dgate[b][k] = sum_m dWb[b][m][k] W[m][k] (W == NULL: dgate is given), dz2 = dgate * gate * (1 - gate), part[b][chunk][j] = sum_{k in chunk} dz2[k] W2[k][j].
+// grid (ceil(K / 64), B): 64 columns x 4 row lanes, the four partial sums added in lane order through LDS (as gate_weights_bwd_g_kernel)
+__global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restrict__ dWb, const float* __restrict__ W, const float* __restrict__ dgate_in,
+                                                          const float* __restrict__ gate, const float* __restrict__ W2, float* __restrict__ dz2_out,
+                                                          float* __restrict__ part, int M, int K, int Cs) {
+    __shared__ float sh[256];
+    __shared__ float dz[SE2_CHUNK];
+    const int b = blockIdx.y, col = threadIdx.x & 63, rl = threadIdx.x >> 6, k0 = blockIdx.x * SE2_CHUNK, k = k0 + col;
+    float s = 0.f;
+    if (W && k < K) {
+        const float* d = dWb + (int64_t)b * M * K;
+#pragma unroll 4
+        for (int m = rl; m < M; m += 4) s += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0) {
+        float v = 0.f;
+        if (k < K) {
+            const float dg = W ? (sh[col] + sh[64 + col]) + (sh[128 + col] + sh[192 + col]) : dgate_in[(int64_t)b * K + k];
+            const float gt = gate[(int64_t)b * K + k];
+            v = dg * gt * (1.0f - gt);
+            dz2_out[(int64_t)b * K + k] = v;
+        }
+        dz[col] = v;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < Cs; j += 256) {
+        const int n = min(SE2_CHUNK, K - k0);
+        float a = 0.f;
+        for (int i = 0; i < n; ++i) a += dz[i] * W2[(int64_t)(k0 + i) * Cs + j];
+        part[((int64_t)b * gridDim.x + blockIdx.x) * Cs + j] = a;
+    }
+}
+// every weight gradient of the block's squeeze-excite part in one launch: idx < C * Cs: (dW1, dW2, db1, db2) as se_gate_wgrad_kernel; then M * K
+// elements of dW[m][k] = sum_b dWb[b][m][k] gate[b][k] (as gate_weights_bwd_w_kernel; skipped when dWb == NULL)
+__global__ __launch_bounds__(256) void se_wgrad_all_kernel(const float* __restrict__ dz2, const float* __restrict__ dhpre, const float* __restrict__ p,
+                                                           const float* __restrict__ hpre, float* __restrict__ dW1, float* __restrict__ db1,
+                                                           float* __restrict__ dW2, float* __restrict__ db2, const float* __restrict__ dWb,
+                                                           const float* __restrict__ gate, float* __restrict__ dW, int B, int C, int Cs, int64_t MK) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, n1 = (int64_t)C * Cs;
+    if (idx < n1) {
+        const int c = (int)(idx / Cs), j = (int)(idx % Cs);
+        float a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float hp = hpre[(int64_t)b * Cs + j], dz = dz2[(int64_t)b * C + c], dh = dhpre[(int64_t)b * Cs + j];
+            a2 += dz * (hp * sigm(hp)); a1 += dh * p[(int64_t)b * C + c]; s2 += dz; s1 += dh;
+        }
+        dW2[(int64_t)c * Cs + j] = a2; dW1[(int64_t)j * C + c] = a1;
+        if (j == 0) db2[c] = s2;
+        if (c == 0) db1[j] = s1;
+        return;
+    }
+    const int64_t i = idx - n1;
+    if (!dWb || i >= MK) return;
+    const int k = (int)(i % C);
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dWb[(int64_t)b * MK + i] * gate[(int64_t)b * C + k];
+    dW[i] = s;
+}
+
 static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1, i64min(64, (S + 256 * per_thread - 1) / (256 * per_thread))); }
 
 }  // namespace segx
@@ -740,19 +997,20 @@ extern "C" int segx_bn_act_fwd_pool(const float* X, const float* mean, const flo
 }
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
-                                      const float* gate, const float* dpool, float inv_S, void* stream_) {
+                                      const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_reduce: bad args");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset,
+                       rng_base());
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     return check_launch("segx_bn_act_bwd_reduce");
 }
 extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                      const float* sum_dw, const float* sum_db, float* dX, int B, int C, int64_t S, float eps, int act,
-                                     float inv_n, const float* gate, const float* dpool, float inv_S, void* stream_) {
+                                     float inv_n, const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_apply: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n,
-                       gate, dpool, inv_S);
+    hipLaunchKernelGGL((bn_act_bwd_apply<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n,
+                       gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
     return check_launch("segx_bn_act_bwd_apply");
 }
 extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -760,12 +1018,84 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
                                const float* gate, const float* dpool, float inv_S, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0,
+                       (const uint64_t*)nullptr);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
-    hipLaunchKernelGGL(bn_act_bwd_apply, dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
-                       (const float*)db, dX, C, S, eps, act, inv_n, gate, dpool, inv_S);
+    hipLaunchKernelGGL((bn_act_bwd_apply<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
+                       (const float*)db, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, (const float*)nullptr, 0,
+                       (float*)nullptr, (float*)nullptr);
     return check_launch("segx_bn_act_bwd");
+}
+
+// ---- r04: two-launch training BatchNorm (bn_stats_partial_kernel / a producer's partials -> bn_act_fwd2_kernel) ------------------------------
+extern "C" int64_t segx_plane_chunks(int64_t S) { return plane_chunks(S, 8); }
+extern "C" int64_t segx_bn_nparts(int B, int64_t S) { return (int64_t)B * bn_slabs(S); }
+extern "C" int64_t segx_bn_parts_floats(int B, int C) { return ((int64_t)B * BN_SLABS + 1) * C * 4; }
+extern "C" int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && parts && B > 0 && B <= 65535 && C > 0 && S > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_bn_stats_partial: bad args");
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, parts, C, S);
+    return check_launch("segx_bn_stats_partial");
+}
+extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
+                                const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
+                                int B, int C, int64_t S, float eps, int act, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3 && (!run_mean == !run_var), "segx_bn_act_fwd2: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd2: more than 65535 (sample, channel) planes");
+    SEGX_REQUIRE(!parts || (nparts > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0), "segx_bn_act_fwd2: bad partials");
+    SEGX_REQUIRE(dc_p >= 0.f && dc_p < 1.f && (dc_p == 0.f || resid), "segx_bn_act_fwd2: drop_connect needs the skip input and 0 <= p < 1");
+    BnFwdArgs g;
+    g.X = X; g.w = w; g.b = b; g.Y = Y; g.parts = parts; g.nparts = nparts; g.mean = mean; g.var = var; g.run_mean = run_mean; g.run_var = run_var;
+    g.momentum = momentum; g.psum = psum; g.resid = resid; g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base();
+    g.C = C; g.S = S; g.eps = eps; g.act = act;
+    if (parts && nparts > 256) {
+        // a producer with many small tiles: one merge launch, the apply pass then folds ONE partial per channel.  The merged partials live behind the
+        // producer's (the caller sized the buffer for nparts + 1 per channel).
+        float* merged = const_cast<float*>(parts) + (int64_t)C * nparts * 4;
+        hipLaunchKernelGGL(bn_parts_merge_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, parts, merged, C, nparts);
+        g.parts = merged; g.nparts = 1;
+    }
+    const dim3 grid(plane_chunks(S, 8), B * C);
+    if (psum) hipLaunchKernelGGL((bn_act_fwd2_kernel<true>), grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((bn_act_fwd2_kernel<false>), grid, dim3(256), 0, stream, g);
+    return check_launch("segx_bn_act_fwd2");
+}
+extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
+                                float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
+                                const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd2: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
+    const int nsl = bn_slabs(S);
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, nsl), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset, rng_base());
+    const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
+    hipLaunchKernelGGL((bn_act_bwd_apply<true>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)nullptr,
+                       (const float*)nullptr, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)ws, B * nsl, dw, db);
+    return check_launch("segx_bn_act_bwd2");
+}
+// ---- r04: squeeze-excite in 2 + 3 launches ------------------------------------------------------------------------------------------------------
+extern "C" int segx_se_fwd2(const float* psum, int nch, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2, const float* Wproj,
+                            float* p, float* hpre, float* gate, float* Wb, int B, int C, int Cs, int M, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(psum && nch > 0 && W1 && b1 && W2 && b2 && p && hpre && gate && B > 0 && C > 0 && Cs > 0 && (!Wproj || (Wb && M > 0)), "segx_se_fwd2: bad args");
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_fwd2: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    hipLaunchKernelGGL(se_hidden2_kernel, dim3((Cs + 3) / 4, B), dim3(256), 0, stream, psum, nch, inv_S, W1, b1, p, hpre, C, Cs);
+    hipLaunchKernelGGL(se_gate_weights_kernel, dim3((C + SE2_CHUNK - 1) / SE2_CHUNK, B), dim3(256), 0, stream, (const float*)hpre, W2, b2, Wproj, gate, Wb, C, Cs, M);
+    return check_launch("segx_se_fwd2");
+}
+extern "C" int64_t segx_se_ws2_floats(int B, int C, int Cs) { return (int64_t)B * (C + Cs) + (int64_t)B * ((C + SE2_CHUNK - 1) / SE2_CHUNK) * Cs; }
+extern "C" int segx_se_bwd2(const float* dWb, const float* Wproj, const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1,
+                            const float* W2, float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* dWproj, float* ws,
+                            int B, int C, int Cs, int M, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(gate && hpre && p && W1 && W2 && dpool && dW1 && db1 && dW2 && db2 && ws && B > 0 && C > 0 && Cs > 0, "segx_se_bwd2: bad args");
+    SEGX_REQUIRE((dWb && Wproj && dWproj && M > 0) || (!dWb && !Wproj && dgate), "segx_se_bwd2: either (dWb, Wproj, dWproj, M) or dgate");
+    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_bwd2: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
+    const int nchunks = (C + SE2_CHUNK - 1) / SE2_CHUNK;
+    float* dz2 = ws; float* dhpre = ws + (int64_t)B * C; float* part = dhpre + (int64_t)B * Cs;
+    hipLaunchKernelGGL(se_bwd_gate_kernel, dim3(nchunks, B), dim3(256), 0, stream, dWb, Wproj, dgate, gate, W2, dz2, part, M, C, Cs);
+    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, (const float*)part, hpre, W1, inv_S, dhpre, dpool, C, Cs, nchunks);
+    const int64_t MK = dWb ? (int64_t)M * C : 0, total = (int64_t)C * Cs + MK;
+    hipLaunchKernelGGL(se_wgrad_all_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const float*)dz2, (const float*)dhpre, p, hpre,
+                       dW1, db1, dW2, db2, dWb, gate, dWproj, B, C, Cs, MK);
+    return check_launch("segx_se_bwd2");
 }
 
 #define SEGX_DW_DISPATCH(KERNEL, ...)                                                                          \

@@ -9,8 +9,8 @@ model.py:169-178, utils.py:248-275), same endpoint rule (endpoints are the INPUT
 Kernel status: every 1x1 convolution (127 of the 160 convs of B4) runs on libsegx's MFMA GEMM; the 32 depthwise
 k3/k5 convolutions, BatchNorm+swish (fused), the squeeze-excite pooling/gating planes and the drop_connect+skip add
 run on libsegx's HBM-bound kernels (backbone.hip); the dense 3x3 stem is an implicit GEMM on the MFMA engine
-(conv3d.hip with depth 1); the squeeze-excite excitation MLP has its own one-workgroup-per-sample kernels.  No ATen
-arithmetic is left in this file (only the per-sample drop_connect random draw, a [B]-sized tensor).
+(conv3d.hip with depth 1); the squeeze-excite excitation MLP has its own wave-per-dot-product kernels.  No ATen
+arithmetic is left in this file: the drop_connect draw and the skip add happen inside the last BatchNorm pass of a block.
 """
 import math
 import torch
@@ -102,19 +102,17 @@ class MBConvBlock(nn.Module):
         if self.expand_ratio != 1:
             x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
         se = (self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
+        skip = self.stride == 1 and self.input_filters == self.output_filters
+        # drop_connect (utils.py:129-154, per-sample stochastic depth) and the skip add ride on the last BatchNorm pass: the sample's keep scale is
+        # drawn inside the kernels from the library's Philox stream (H3: the reference's torch.rand stream cannot be matched anyway)
+        rate = float(drop_connect_rate) if (skip and drop_connect_rate and self.training) else 0.0
         if MBConvBlock.gate_in_weights:
             # squeeze-excite gate folded into the projection weights (per-sample weights; the gated tensor is never written)
-            y, gate = SF.bn_act_gate(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se)
-            x = SF.bn_act(SF.conv1x1_gated(y, self._project_conv.weight, gate), self._bn2, SF.ACT_NONE)
+            y, Wb = SF.bn_act_gate_weights(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se, self._project_conv.weight)
+            x = SF.conv1x1_per_sample(y, Wb)
         else:
-            x = SF.bn_act(self._project_conv(SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se)), self._bn2, SF.ACT_NONE)
-        if self.stride == 1 and self.input_filters == self.output_filters:
-            scale = None
-            if drop_connect_rate and self.training:                      # utils.py:129-154, per-sample stochastic depth
-                keep = 1 - drop_connect_rate
-                scale = torch.floor(keep + torch.rand([x.shape[0]], dtype=x.dtype, device=x.device)) / keep
-            x = SF.skip_add(x, inputs, scale)
-        return x
+            x = self._project_conv(SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se))
+        return SF.bn_act(x, self._bn2, SF.ACT_NONE, resid=inputs if skip else None, drop_connect=rate)
 
 
 class EfficientNet(nn.Module):

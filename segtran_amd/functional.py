@@ -596,25 +596,35 @@ _bn_stats_sync = None        # set by segtran_amd.dist for data-parallel runs: m
 _bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair of the BN backward
 
 
-def _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S):
-    """(mean, var, n) the BatchNorm normalises with: batch statistics (merged over the ranks when synchronised) or the running ones."""
+def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=False, resid=None, dc=(0.0, 0, 0)):
+    """BatchNorm (+ activation, + squeeze-excite pooling chunks, + drop_connect scale and skip add) -> (y, mean, var, n, psum, nch).
+    Training, one process: TWO launches (segx_bn_stats_partial, segx_bn_act_fwd2 -- the apply pass merges the statistics partials itself).
+    Synchronised: local statistics -> ONE all-gather -> merge kernel -> the same apply pass on the merged statistics.  Eval: the apply pass alone."""
+    y = torch.empty_like(x)
+    nch = L.plane_chunks(S) if pool else 0
+    psum = _empty(x, B * C * nch) if pool else None
+    dc_p, seed, off = dc
     if not training:
-        return run_mean, run_var, B * S
+        L.bn_act_fwd2(x, None, 0, run_mean, run_var, None, None, 0.0, w, b, y, psum, resid, 0.0, 0, 0, B, C, S, eps, act)
+        return y, run_mean, run_var, B * S, psum, nch
+    mean, var = _empty(x, C), _empty(x, C)
     if _bn_stats_sync is None:
-        mean, var = _empty(x, C), _empty(x, C)
-        L.bn_stats(x, mean, var, run_mean, run_var, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
-        return mean, var, B * S
+        parts = _empty(x, L.bn_parts_floats(B, C))
+        L.bn_stats_partial(x, parts, B, C, S)
+        L.bn_act_fwd2(x, parts, L.bn_nparts(B, S), mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+        return y, mean, var, B * S, psum, nch
     # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
     loc = _empty(x, 2 * C)
     L.bn_stats(x, loc[:C], loc[C:], None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
     allv, world = _bn_stats_sync(loc)
-    mean, var = _empty(x, C), _empty(x, C)
     L.bn_merge_stats(allv, mean, var, run_mean, run_var, world, C, B * S, momentum)
-    return mean, var, B * S * world
+    L.bn_act_fwd2(x, None, 0, mean, var, None, None, 0.0, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+    return y, mean, var, B * S * world, psum, nch
 
 
-def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_S=0.0):
-    """dx, dw, db of BatchNorm + activation; gate / dpool: a squeeze-excite gate sits behind it (see segx_bn_act_bwd)."""
+def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_S=0.0, dc=(0.0, 0, 0)):
+    """dx, dw, db of BatchNorm + activation; gate / dpool: a squeeze-excite gate sits behind it (see segx_bn_act_bwd); dc: the drop_connect scale
+    of the forward multiplies dy.  One process: two launches (segx_bn_act_bwd2: the apply pass sums the reduction partials itself)."""
     B, C, S, eps, act, training, n = cfg
     dx = torch.empty_like(x)
     if training and _bn_grad_sync is not None:
@@ -622,26 +632,30 @@ def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_
         # The parameter gradients stay the LOCAL sums (the flat-gradient all-reduce averages them like every other gradient).
         both = _empty(x, 2 * C)
         dw, db = both[:C], both[C:]
-        L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, gate, dpool, inv_S)
+        L.bn_act_bwd_reduce(dy, x, mean, var, w, b, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, gate, dpool, inv_S, *dc)
         glob = _bn_grad_sync(both)
-        L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n, gate, dpool, inv_S)
+        L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n, gate, dpool, inv_S, *dc)
     else:
         dw, db = _empty(x, C), _empty(x, C)
-        L.bn_act_bwd(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S)
+        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S, *dc)
     return dx, dw, db
 
 
 class _BNAct(torch.autograd.Function):
+    """y = act(batch_norm(x)) [* drop_connect scale of the sample + resid]: the BatchNorm of every backbone layer; with `resid` also the tail of an
+    MBConv block (efficientnet/model.py:116-122) -- the per-sample scale is drawn inside the kernels from the Philox stream, nothing is stored."""
+
     @staticmethod
-    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act):
+    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act, resid, dc_p):
         L = segx.lib()
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         S = x.numel() // (B * C)
-        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
-        y = torch.empty_like(x)
-        L.bn_act_fwd(x, mean, var, w, b, y, B, C, S, eps, act)
+        resid = _c(resid) if resid is not None else None
+        dc = (dc_p,) + _Rng.reserve(B) if (dc_p > 0 and training and resid is not None) else (0.0, 0, 0)
+        y, mean, var, n, _, _ = _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, resid=resid, dc=dc)
         ctx.cfg = (B, C, S, eps, act, training, n)
+        ctx.dc, ctx.has_resid = dc, resid is not None
         ctx.save_for_backward(x, mean, var, w, b)
         return y
 
@@ -649,8 +663,9 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         L = segx.lib()
         x, mean, var, w, b = ctx.saved_tensors
-        dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg)
-        return dx, dw, db, None, None, None, None, None, None
+        dy = _c(dy)
+        dx, dw, db = _bn_act_backward(L, dy, x, mean, var, w, b, ctx.cfg, dc=ctx.dc)
+        return dx, dw, db, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
 
 
 _bn_ticks = None          # a list while a model forward defers the `num_batches_tracked += 1` of its BatchNorm layers (defer_bn_ticks)
@@ -671,14 +686,20 @@ def flush_bn_ticks():
         torch._foreach_add_(ticks, 1)
 
 
-def bn_act(x, bn, act=ACT_NONE):
-    """nn.BatchNorm2d/3d module `bn` (parameter container) followed by an activation, fused."""
+def _bn_tick(bn):
     if bn.training and bn.num_batches_tracked is not None:
         if _bn_ticks is not None:
             _bn_ticks.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
-    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act)
+
+
+def bn_act(x, bn, act=ACT_NONE, resid=None, drop_connect=0.0):
+    """nn.BatchNorm2d/3d module `bn` (parameter container) followed by an activation, fused; resid / drop_connect: + the MBConv skip connection
+    (y * drop_connect scale of the sample + resid) in the same pass."""
+    _bn_tick(bn)
+    return _BNAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, resid,
+                        float(drop_connect or 0.0))
 
 
 def bn_act_multi(x, bns, act=ACT_NONE):
@@ -689,7 +710,7 @@ def bn_act_multi(x, bns, act=ACT_NONE):
     assert all(float(b.momentum) == mom and float(b.eps) == eps and b.training == training for b in bns)
     w, b = torch.cat([m.weight for m in bns]), torch.cat([m.bias for m in bns])
     rm, rv = torch.cat([m.running_mean for m in bns]), torch.cat([m.running_var for m in bns])
-    y = _BNAct.apply(x, w, b, rm, rv, training, mom, eps, act)
+    y = _BNAct.apply(x, w, b, rm, rv, training, mom, eps, act, None, 0.0)
     if training:
         sizes = [m.num_features for m in bns]
         with torch.no_grad():
@@ -787,6 +808,30 @@ def squeeze_excite(x, w1, b1, w2, b2):
     return _SqueezeExcite.apply(x, w1, b1, w2, b2)
 
 
+def _se_excite(L, x, psum, nch, S, w1, b1, w2, b2, Wproj=None):
+    """The excitation MLP on the pooling chunks of the BatchNorm pass (segx_se_fwd2, two launches): -> (p, hpre, gate, W1, W2, Wb or None)."""
+    B, C = x.shape[0], x.shape[1]
+    Cs = w1.shape[0]
+    W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
+    p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
+    M = Wproj.shape[0] if Wproj is not None else 0
+    Wb = _empty(x, B, M, C) if Wproj is not None else None
+    L.se_fwd2(psum, nch, 1.0 / S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M)
+    return p, hpre, gate, W1, W2, Wb
+
+
+def _se_excite_backward(L, x, dWb, Wproj, dgate, gate, hpre, p, W1, W2, S):
+    """-> (dpool, dW1, db1, dW2, db2, dWproj) from the per-sample projection weight gradient dWb (or from dgate): segx_se_bwd2, three launches."""
+    B, C = gate.shape
+    Cs = hpre.shape[1]
+    dpool = _empty(x, B * C)
+    dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
+    dWproj = torch.empty_like(Wproj) if Wproj is not None else None
+    M = Wproj.shape[0] if Wproj is not None else 0
+    L.se_bwd2(dWb, Wproj, dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, dWproj, _empty(x, L.se_ws2(B, C, Cs)), B, C, Cs, M)
+    return dpool, dW1, db1, dW2, db2, dWproj
+
+
 class _BNActSE(torch.autograd.Function):
     """squeeze_excite(bn_act(x)) as ONE op (MBConvBlock.forward, efficientnet/model.py:101-110): the squeeze-excite pooling comes out of the
     BatchNorm + swish pass (no separate plane-sum pass over y), and in backward the gate's product rule -- dy = dz * gate + dpool / S -- is
@@ -798,18 +843,12 @@ class _BNActSE(torch.autograd.Function):
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         S = x.numel() // (B * C)
-        Cs = w1.shape[0]
-        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
-        y = torch.empty_like(x)
-        pooled = _empty(x, B * C)
-        L.bn_act_fwd_pool(x, mean, var, w, b, y, pooled, _empty(x, B * C * 64), B, C, S, eps, act)
-        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
-        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
-        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
+        y, mean, var, n, psum, nch = _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=True)
+        p, hpre, gate, W1, W2, _ = _se_excite(L, x, psum, nch, S, w1, b1, w2, b2)
         z = torch.empty_like(x)
         L.plane_scale(y, gate, z, B * C, S)
         ctx.cfg = (B, C, S, eps, act, training, n)
-        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), Cs)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
         ctx.save_for_backward(x, mean, var, w, b, y, p, hpre, gate, W1, W2)
         return z
 
@@ -818,13 +857,11 @@ class _BNActSE(torch.autograd.Function):
         L = segx.lib()
         x, mean, var, w, b, y, p, hpre, gate, W1, W2 = ctx.saved_tensors
         B, C, S = ctx.cfg[:3]
-        w1s, w2s, Cs = ctx.shapes
+        w1s, w2s = ctx.shapes
         dz = _c(dz)
         dgate = _empty(x, B * C)
         L.plane_dot(dz, y, dgate, B * C, S)
-        dpool = _empty(x, B * C)
-        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
-        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
+        dpool, dW1, db1, dW2, db2, _ = _se_excite_backward(L, x, None, None, dgate, gate, hpre, p, W1, W2, S)
         dx, dw, db = _bn_act_backward(L, dz, x, mean, var, w, b, ctx.cfg, gate.reshape(-1), dpool, 1.0)
         return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
 
@@ -840,16 +877,10 @@ class _BNActGate(torch.autograd.Function):
         x = _c(x)
         B, C = x.shape[0], x.shape[1]
         S = x.numel() // (B * C)
-        Cs = w1.shape[0]
-        mean, var, n = _bn_batch_stats(L, x, run_mean, run_var, training, momentum, B, C, S)
-        y = torch.empty_like(x)
-        pooled = _empty(x, B * C)
-        L.bn_act_fwd_pool(x, mean, var, w, b, y, pooled, _empty(x, B * C * 64), B, C, S, eps, act)
-        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
-        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
-        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
+        y, mean, var, n, psum, nch = _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=True)
+        p, hpre, gate, W1, W2, _ = _se_excite(L, x, psum, nch, S, w1, b1, w2, b2)
         ctx.cfg = (B, C, S, eps, act, training, n)
-        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), Cs)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
         ctx.save_for_backward(x, mean, var, w, b, p, hpre, gate, W1, W2)
         return y, gate
 
@@ -857,23 +888,65 @@ class _BNActGate(torch.autograd.Function):
     def backward(ctx, dy, dgate):
         L = segx.lib()
         x, mean, var, w, b, p, hpre, gate, W1, W2 = ctx.saved_tensors
-        B, C, S = ctx.cfg[:3]
-        w1s, w2s, Cs = ctx.shapes
-        dpool = _empty(x, B * C)
-        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
-        L.se_gate_bwd(_c(dgate).reshape(-1), gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
+        S = ctx.cfg[2]
+        w1s, w2s = ctx.shapes
+        dpool, dW1, db1, dW2, db2, _ = _se_excite_backward(L, x, None, None, _c(dgate).reshape(-1), gate, hpre, p, W1, W2, S)
         dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg, None, dpool, 1.0)
         return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
 
 
 def bn_act_gate(x, bn, act, w1, b1, w2, b2):
     """(bn_act(x, bn, act), squeeze-excite gate of it [B, C]) from one pass (see _BNActGate); pair with conv1x1_gated."""
-    if bn.training and bn.num_batches_tracked is not None:
-        if _bn_ticks is not None:
-            _bn_ticks.append(bn.num_batches_tracked)
-        else:
-            bn.num_batches_tracked.add_(1)
+    _bn_tick(bn)
     return _BNActGate.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
+
+
+class _BNActGateW(torch.autograd.Function):
+    """The middle of an MBConv block (efficientnet/model.py:100-113) up to the operands of its projection GEMM: BatchNorm + swish of the depthwise
+    output, the squeeze-excite gate from the same pass, and the gate folded straight into per-sample projection weights
+    Wb[b] = W_project * gate[b] (exact re-association).  Returns (y, Wb): project_conv(y * gate) == conv1x1_per_sample(y, Wb).
+    Forward: 4 launches (statistics partials, apply + pooling chunks, hidden layer, gate + weights); backward from (dy, dWb): 3 + 2."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act, w1, b1, w2, b2, Wproj):
+        L = segx.lib()
+        x = _c(x)
+        B, C = x.shape[0], x.shape[1]
+        S = x.numel() // (B * C)
+        Wp = _c(Wproj.reshape(Wproj.shape[0], C))
+        y, mean, var, n, psum, nch = _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=True)
+        p, hpre, gate, W1, W2, Wb = _se_excite(L, x, psum, nch, S, w1, b1, w2, b2, Wp)
+        ctx.cfg = (B, C, S, eps, act, training, n)
+        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), tuple(Wproj.shape))
+        ctx.save_for_backward(x, mean, var, w, b, p, hpre, gate, W1, W2, Wp)
+        return y, Wb
+
+    @staticmethod
+    def backward(ctx, dy, dWb):
+        L = segx.lib()
+        x, mean, var, w, b, p, hpre, gate, W1, W2, Wp = ctx.saved_tensors
+        S = ctx.cfg[2]
+        w1s, w2s, wps = ctx.shapes
+        dWb = _c(dWb) if dWb is not None else torch.zeros(gate.shape[0], Wp.shape[0], Wp.shape[1], dtype=torch.float32, device=x.device)
+        dpool, dW1, db1, dW2, db2, dWp = _se_excite_backward(L, x, dWb, Wp, None, gate, hpre, p, W1, W2, S)
+        dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg, None, dpool, 1.0)
+        return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2, dWp.view(wps)
+
+
+def bn_act_gate_weights(x, bn, act, w1, b1, w2, b2, proj_weight):
+    """(bn_act(x, bn, act), per-sample projection weights [B, Cout, C] carrying the squeeze-excite gate) -- see _BNActGateW; pair with conv1x1_per_sample."""
+    _bn_tick(bn)
+    return _BNActGateW.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2,
+                             proj_weight)
+
+
+def conv1x1_per_sample(x, Wb):
+    """Pointwise convolution with one weight matrix per sample: y[b] = Wb[b] x[b]  (Wb [B, Cout, Cin]); one batched GEMM, A strided over the batch."""
+    B, Cin = x.shape[0], x.shape[1]
+    S = x.numel() // (B * Cin)
+    Cout = Wb.shape[1]
+    spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1))
+    return bgemm(Wb, x, spec)
 
 
 class _GateWeights(torch.autograd.Function):
@@ -915,11 +988,7 @@ def conv1x1_gated(x, weight, gate):
 
 def bn_act_se(x, bn, act, w1, b1, w2, b2):
     """squeeze_excite(bn_act(x, bn, act), w1, b1, w2, b2), fused (see _BNActSE)."""
-    if bn.training and bn.num_batches_tracked is not None:
-        if _bn_ticks is not None:
-            _bn_ticks.append(bn.num_batches_tracked)
-        else:
-            bn.num_batches_tracked.add_(1)
+    _bn_tick(bn)
     return _BNActSE.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
 
 

@@ -56,7 +56,7 @@ class SegxLib:
         for name, sig in _SIGS.items():
             fn = getattr(self.c, name)
             fn.argtypes = [kinds[k] for k in sig]
-            fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk', '_elems')) else c_i
+            fn.restype = c_l if name.endswith(('_floats', '_rows', '_splitk', '_elems', '_chunks', '_nparts')) else c_i
 
     # ---- tile engine -------------------------------------------------------------------------
     ENGINES = {'f32': 0, 'x6': 1}
@@ -259,6 +259,34 @@ class SegxLib:
     def bn_act_fwd_pool(self, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act):
         self._call('segx_bn_act_fwd_pool', X, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act)
 
+    # ---- r04: two-launch training BatchNorm, squeeze-excite in 2 + 3 launches -----------------------
+    def plane_chunks(self, S):
+        return int(self.c.segx_plane_chunks(S))
+
+    def bn_nparts(self, B, S):
+        return int(self.c.segx_bn_nparts(B, S))
+
+    def bn_parts_floats(self, B, C):
+        return int(self.c.segx_bn_parts_floats(B, C))
+
+    def bn_stats_partial(self, X, parts, B, C, S):
+        self._call('segx_bn_stats_partial', X, X, parts, B, C, S)
+
+    def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act):
+        self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act)
+
+    def bn_act_bwd2(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
+        self._call('segx_bn_act_bwd2', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate, dpool, float(inv_S), float(dc_p), seed, offset)
+
+    def se_fwd2(self, psum, nch, inv_S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M):
+        self._call('segx_se_fwd2', gate, psum, nch, inv_S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M)
+
+    def se_ws2(self, B, C, Cs):
+        return int(self.c.segx_se_ws2_floats(B, C, Cs))
+
+    def se_bwd2(self, dWb, Wproj, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, dWproj, ws, B, C, Cs, M):
+        self._call('segx_se_bwd2', gate, dWb, Wproj, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, dWproj, ws, B, C, Cs, M)
+
     def dwconv2d_fwd(self, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl):
         self._call('segx_dwconv2d_fwd', X, X, W, Y, B, C, H, Wd, OH, OW, k, stride, pt, pl)
 
@@ -277,11 +305,11 @@ class SegxLib:
     def bn_merge_stats(self, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum):
         self._call('segx_bn_merge_stats', allv, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum)
 
-    def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate=None, dpool=None, inv_S=0.0):
-        self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate, dpool, float(inv_S))
+    def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
+        self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate, dpool, float(inv_S), float(dc_p), seed, offset)
 
-    def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0):
-        self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S))
+    def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
+        self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S), float(dc_p), seed, offset)
 
     def gate_weights_fwd(self, W, gate, Wb, B, M, K):
         self._call('segx_gate_weights_fwd', W, W, gate, Wb, B, M, K)
@@ -517,7 +545,10 @@ _SIGS = {
     'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
-    'segx_bn_act_bwd_reduce': 'pppppppppiilfippfp', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppfp',
+    'segx_plane_chunks': 'l', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
+    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuup',
+    'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
+    'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',
 }
 
 _LIB = None

@@ -120,9 +120,10 @@ def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
-@pytest.mark.parametrize('B,C,Cs,Co,H,W', [(3, 12, 4, 10, 9, 7), (2, 70, 9, 24, 4, 5), (2, 8, 2, 136, 12, 12)])
+@pytest.mark.parametrize('B,C,Cs,Co,H,W', [(3, 12, 4, 10, 9, 7), (2, 70, 9, 24, 4, 5), (2, 8, 2, 136, 12, 12), (2, 150, 70, 7, 3, 4)])   # last: 3 gate chunks, Cs > one wave
 @pytest.mark.parametrize('training', [True, False])
-def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, training):
+@pytest.mark.parametrize('one_op', [True, False], ids=['gate-and-weights-in-one-op', 'gate-then-weights'])
+def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, training, one_op):
     """MBConv tail as the product runs it: BatchNorm + swish with the squeeze-excite gate from the same pass (bn_act_gate), then the projection as
     a pointwise convolution with per-sample weights W * gate[b] (conv1x1_gated) -- against BatchNorm -> swish -> squeeze-excite -> conv in PyTorch."""
     bn, ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
@@ -135,8 +136,12 @@ def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, tra
     ps = [rnd(Cs, C, 1, 1, seed=31, scale=0.5), rnd(Cs, seed=32, scale=0.1), rnd(C, Cs, 1, 1, seed=33, scale=0.5), rnd(C, seed=34, scale=0.1),
           rnd(Co, C, 1, 1, seed=35, scale=0.3)]
     ps = [p.requires_grad_(True) for p in ps]
-    y, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *ps[:4])
-    out = SF.conv1x1_gated(y, ps[4], gate)
+    if one_op:          # what MBConvBlock runs (r04): the gate goes straight into the per-sample weights, one autograd node
+        y, Wb = SF.bn_act_gate_weights(x, bn, SF.ACT_SWISH, *ps)
+        out = SF.conv1x1_per_sample(y, Wb)
+    else:
+        y, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *ps[:4])
+        out = SF.conv1x1_gated(y, ps[4], gate)
     xr = x.detach().clone().requires_grad_(True)
     pr = [p.detach().clone().requires_grad_(True) for p in ps]
     yr = _act(ref(xr), 1)
@@ -150,6 +155,59 @@ def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, tra
     for a, r in zip(ps, pr):
         close(a.grad, r.grad, 1e-4)
     close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
+
+
+@pytest.mark.parametrize('shape', [(6, 5, 6, 10), (5, 3, 36, 36), (4, 2, 130, 130)])
+@pytest.mark.parametrize('rate', [0.0, 0.5])
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_with_skip_add_and_drop_connect(backend, shape, rate, training):
+    """The tail of an MBConv block in one pass (efficientnet/model.py:116-122): y = bn(x) * drop_connect scale of the sample + inputs.  The scale is
+    drawn inside the kernel (0 or 1 / keep per sample); it is recovered from the output and must then explain the output AND every gradient:
+    forward and backward regenerate the same draw, the skip input's gradient is the incoming one."""
+    B, C = shape[:2]
+    bn, ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        for m in (bn, ref):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=1)); m.bias.copy_(0.2 * rnd(C, seed=2))
+            m.running_mean.copy_(0.1 * rnd(C, seed=3)); m.running_var.copy_(1 + 0.1 * rnd(C, seed=4).abs())
+    bn.train(training); ref.train(training)
+    x = (rnd(*shape, seed=40) * 1.7 + 0.4).requires_grad_(True)
+    r = rnd(*shape, seed=41).requires_grad_(True)
+    SF.manual_seed(77)
+    y = SF.bn_act(x, bn, SF.ACT_NONE, resid=r, drop_connect=rate if training else 0.0)
+    xr, rr = x.detach().clone().requires_grad_(True), r.detach().clone().requires_grad_(True)
+    br = ref(xr)
+    keep = 1.0 - rate
+    with torch.no_grad():          # per-sample scale recovered from the first element of each sample
+        scale = ((y - r).reshape(B, -1)[:, 0] / br.reshape(B, -1)[:, 0]).detach()
+    if rate == 0.0 or not training:
+        assert torch.allclose(scale, torch.ones(B), atol=1e-4)
+        scale = torch.ones(B)
+    else:
+        assert all(abs(v) < 1e-4 or abs(v - 1 / keep) < 1e-3 for v in scale.tolist()), scale
+        scale = torch.where(scale.abs() < 0.5, torch.zeros(B), torch.full((B,), 1 / keep))
+    yr = br * scale.view(B, 1, 1, 1) + rr
+    close(y, yr.detach())
+    G = rnd(*shape, seed=42)
+    y.backward(G); yr.backward(G)
+    close(x.grad, xr.grad, 1e-4); close(r.grad, rr.grad, 1e-6)
+    close(bn.weight.grad, ref.weight.grad, 1e-4); close(bn.bias.grad, ref.bias.grad, 1e-4)
+    close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
+
+
+def test_drop_connect_draws_differ_between_calls_and_follow_the_seed(backend):
+    B, C = 16, 2
+    bn = torch.nn.BatchNorm2d(C).train()
+    x, r = rnd(B, C, 4, 4, seed=50), torch.zeros(B, C, 4, 4)
+
+    def draw():
+        with torch.no_grad():
+            y = SF.bn_act(x, bn, SF.ACT_NONE, resid=r, drop_connect=0.5)
+        return (y.reshape(B, -1).abs().sum(1) > 0)
+    SF.manual_seed(5); a1, a2 = draw(), draw()
+    SF.manual_seed(5); b1 = draw()
+    assert torch.equal(a1, b1) and not torch.equal(a1, a2)
+    assert 0 < int(a1.sum()) + int(a2.sum()) < 2 * B          # some samples kept, some dropped
 
 
 @pytest.mark.parametrize('shape', [(2, 16, 6, 10), (3, 8, 3, 4, 5), (1, 24, 9, 9)])
