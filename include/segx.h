@@ -224,12 +224,16 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  *   parts: [C][nparts] float4 records (n, mean, M2, -) of disjoint runs covering the B*S elements of each channel; Chan et al.'s merge makes the
  *   result independent of how a producer cut the data.  segx_bn_stats_partial writes nparts = segx_bn_nparts(B, S) per channel; the buffer
  *   must hold segx_bn_parts_floats(B, C) floats, 16-byte aligned.  (For a producer's own partials with nparts > 256 the buffer needs C*4 more.)
+ *   nparts == 0 with parts given = AUTO: the library computes the statistics itself, using `parts` as scratch -- in ONE launch for the whole
+ *   layer when a channel's B planes fit one team's registers (S <= 4096 floats, B <= 8: "channel-resident", 79 of EfficientNet-B4's 96 layers at
+ *   512 x 512), else segx_bn_stats_partial + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
  *   parts == NULL: mean / var are INPUTS (running statistics: eval mode / synchronised BatchNorm after the merge); otherwise they are OUTPUTS
  *   (saved for the backward pass) and run_mean / run_var (optional) are updated with momentum and the unbiased variance.
  *   psum (optional): [B*C][segx_plane_chunks(S)] partial sums of Y per plane (the squeeze-excite pooling; segx_se_fwd2 adds the chunks up).
  *   resid (optional): Y = act(bn(X)) * dcs[sample] + resid, dcs = drop_connect keep scale of the sample (0 or 1/(1-dc_p), Philox element
  *   `sample` of stream (seed, offset): efficientnet/utils.py:129-154); dc_p = 0: plain skip add. */
 int64_t segx_plane_chunks(int64_t S);
+int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats);
 int64_t segx_bn_nparts(int B, int64_t S);
 int64_t segx_bn_parts_floats(int B, int C);
 int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream);
@@ -237,7 +241,8 @@ int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean
                      const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                      int B, int C, int64_t S, float eps, int act, void* stream);
 /* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
- * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C) floats */
+ * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C) floats.
+ * training != 0 and a channel-resident shape: ONE launch (x and dy read once). */
 int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                      float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
                      const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream);

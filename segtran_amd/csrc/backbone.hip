@@ -345,6 +345,156 @@ __global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
 }
 
 // =================================================================================================
+// r04: CHANNEL-RESIDENT BatchNorm for small planes.  79 of EfficientNet-B4's 96 BatchNorm layers at 512 x 512 / batch 6 work on planes of <= 4096
+// floats (down to 16 x 16); their nine tensor passes move 1.5 ms worth of bytes per step but took ~11 ms: one workgroup per (sample, channel)
+// plane means up to 16 128 workgroups of 256 threads for 256 floats each, in four launches forward and backward.  Here a TEAM of threads (one
+// wave: four channels per workgroup; or the whole workgroup) owns ONE channel with all its B planes in registers:
+//   forward : load once -> mean -> variance around the mean (two passes over registers: exact, no pivot needed) -> normalise / activate /
+//             drop_connect scale + skip add / squeeze-excite pooling -> store.      ONE launch, 1 read + 1 write  (was 2 launches, 2 reads + 1 write)
+//   backward: load x and dy once -> du, xhat in registers -> the two channel sums -> dx.   ONE launch, 2 reads + 1 write  (was 2 launches, 4 + 1)
+// A lane owns float4 j = lane + TEAM * k (k < KP) of every plane b < BMAX (predicated on b < B and j < S / 4), so the plane of a register is a
+// compile-time index and S needs no special form beyond S % 4 == 0.
+// =================================================================================================
+template <int TEAM> __device__ __forceinline__ float team_sum(float v, float* red) { return TEAM == 64 ? wave_sum(v) : block_sum<4>(v, red); }
+
+template <int TEAM, int KP, int BMAX, bool POOL>
+__global__ __launch_bounds__(256) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
+    __shared__ float red[4];
+    const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
+    const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+    if (TEAM == 64 && c >= g.C) return;                        // whole waves leave together; no workgroup barrier in the wave-team form
+    const int C = g.C, S4 = (int)(g.S >> 2);
+    const int64_t S = g.S;
+    float4 v[BMAX][KP];
+    float s = 0.f;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = tl + TEAM * k;
+            const bool ok = b < B && j < S4;
+            v[b][k] = ok ? *reinterpret_cast<const float4*>(g.X + ((int64_t)b * C + c) * S + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[b][k].x + v[b][k].y) + (v[b][k].z + v[b][k].w);
+        }
+    const float n = (float)B * (float)S;
+    const float m = team_sum<TEAM>(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const bool ok = b < B && tl + TEAM * k < S4;
+            const float d0 = v[b][k].x - m, d1 = v[b][k].y - m, d2 = v[b][k].z - m, d3 = v[b][k].w - m;
+            q += ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+        }
+    q = team_sum<TEAM>(q, red);
+    const float var = q / n;
+    if (tl == 0) {
+        g.mean[c] = m; g.var[c] = var;
+        if (g.run_mean) {
+            g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * m;
+            g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * (q / fmaxf(n - 1.0f, 1.0f));
+        }
+    }
+    const float sc = rsqrtf(var + g.eps) * g.w[c], sh = g.b[c] - m * sc;
+    const int act = g.act;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        if (b >= B) break;
+        const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
+        const int64_t base = ((int64_t)b * C + c) * S;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = tl + TEAM * k;
+            if (j < S4) {
+                float4 o;
+                o.x = act_fwd(v[b][k].x * sc + sh, act); o.y = act_fwd(v[b][k].y * sc + sh, act);
+                o.z = act_fwd(v[b][k].z * sc + sh, act); o.w = act_fwd(v[b][k].w * sc + sh, act);
+                if (g.resid) {
+                    const float4 rv = *reinterpret_cast<const float4*>(g.resid + base + 4 * j);
+                    o.x = o.x * dcs + rv.x; o.y = o.y * dcs + rv.y; o.z = o.z * dcs + rv.z; o.w = o.w * dcs + rv.w;
+                }
+                *reinterpret_cast<float4*>(g.Y + base + 4 * j) = o;
+                if (POOL) acc += (o.x + o.y) + (o.z + o.w);
+            }
+        }
+        if (POOL) {
+            acc = team_sum<TEAM>(acc, red);
+            if (tl == 0) g.psum[(int64_t)b * C + c] = acc;          // ONE chunk per plane (segx_bn_pool_chunks)
+        }
+    }
+}
+
+struct BnBwdArgs {
+    const float* dY; const float* X; const float* mean; const float* var; const float* w; const float* b;
+    float* dX; float* dw; float* db;
+    const float* gate; const float* dpool; float inv_S;
+    float dc_p; uint64_t seed, offset; const uint64_t* rbase;
+    int C; int64_t S; float eps; int act;
+};
+template <int TEAM, int KP, int BMAX>
+__global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {
+    __shared__ float red[4];
+    const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
+    const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+    if (TEAM == 64 && c >= g.C) return;
+    const int C = g.C, S4 = (int)(g.S >> 2), act = g.act;
+    const int64_t S = g.S;
+    const float rstd = rsqrtf(g.var[c] + g.eps), m = g.mean[c], wc = g.w[c], bc_ = g.b[c];
+    float4 h[BMAX][KP], d[BMAX][KP];          // xhat, du
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        const bool bok = b < B;
+        const int pl = (bok ? b : 0) * C + c;
+        const float gt = (g.gate ? g.gate[pl] : 1.0f) * drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b), dp = g.dpool ? g.dpool[pl] * g.inv_S : 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = tl + TEAM * k;
+            const bool ok = bok && j < S4;
+            const int64_t o = (int64_t)pl * S + 4 * (ok ? j : 0);
+            const float4 xv = *reinterpret_cast<const float4*>(g.X + o), gv = *reinterpret_cast<const float4*>(g.dY + o);
+            float4 hh, dd;
+            hh.x = (xv.x - m) * rstd; hh.y = (xv.y - m) * rstd; hh.z = (xv.z - m) * rstd; hh.w = (xv.w - m) * rstd;
+            dd.x = (gv.x * gt + dp) * act_grad(hh.x * wc + bc_, act); dd.y = (gv.y * gt + dp) * act_grad(hh.y * wc + bc_, act);
+            dd.z = (gv.z * gt + dp) * act_grad(hh.z * wc + bc_, act); dd.w = (gv.w * gt + dp) * act_grad(hh.w * wc + bc_, act);
+            if (!ok) { dd = make_float4(0.f, 0.f, 0.f, 0.f); hh = dd; }
+            h[b][k] = hh; d[b][k] = dd;
+            a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
+        }
+    }
+    a = team_sum<TEAM>(a, red); q = team_sum<TEAM>(q, red);
+    if (tl == 0) { g.db[c] = a; g.dw[c] = q; }
+    const float inv_n = 1.0f / ((float)B * (float)S), k1 = a * inv_n, k2 = q * inv_n, sc = wc * rstd;
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        if (b >= B) break;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int j = tl + TEAM * k;
+            if (j < S4) {
+                float4 o;
+                o.x = sc * (d[b][k].x - k1 - h[b][k].x * k2); o.y = sc * (d[b][k].y - k1 - h[b][k].y * k2);
+                o.z = sc * (d[b][k].z - k1 - h[b][k].z * k2); o.w = sc * (d[b][k].w - k1 - h[b][k].w * k2);
+                *reinterpret_cast<float4*>(g.dX + ((int64_t)b * C + c) * S + 4 * j) = o;
+            }
+        }
+    }
+}
+// which channel-resident form serves (B planes of S floats) -- 0 none, else TEAM * 16 + KP packed: registers per lane <= cap float4 (forward: x; backward: xhat + du)
+static inline int bn_res_form(int B, int64_t S, bool backward) {
+    if ((S & 3) || B < 1 || B > 8 || S > 8192) return 0;
+    const int S4 = (int)(S >> 2);
+    const int kw = (S4 + 63) / 64, kb = (S4 + 255) / 256;
+    const int capw = backward ? 1 : 2, capb = backward ? 2 : 4;          // per-plane float4 per lane; x BMAX = 8 planes (6 for the largest backward form)
+    if (kw <= capw) return 64 * 16 + (kw <= 1 ? 1 : 2);
+    if (kb <= capb) return 256 * 16 + (kb <= 1 ? 1 : kb <= 2 ? 2 : 4);
+    if (backward && kb <= 4 && B <= 6) return 256 * 16 + 4;
+    return 0;
+}
+
+// =================================================================================================
 // Depthwise convolution (efficientnet/model.py:100, groups == channels), static TF-'same' padding (N6):
 //   y[b,c,oy,ox] = sum_{ky,kx} w[c,ky,kx] * x[b,c,oy*S+ky-pt, ox*S+kx-pl]
 // HBM-bound (one read of x, one write of y).  A thread owns ONE output column and DW_TY consecutive output rows and
@@ -1030,6 +1180,8 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
 
 // ---- r04: two-launch training BatchNorm (bn_stats_partial_kernel / a producer's partials -> bn_act_fwd2_kernel) ------------------------------
 extern "C" int64_t segx_plane_chunks(int64_t S) { return plane_chunks(S, 8); }
+/* pooling chunks per plane that segx_bn_act_fwd2 writes into psum: auto_stats != 0 = the call computes the statistics itself (parts given, nparts = 0) */
+extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) { return (auto_stats && bn_res_form(B, S, false)) ? 1 : plane_chunks(S, 8); }
 extern "C" int64_t segx_bn_nparts(int B, int64_t S) { return (int64_t)B * bn_slabs(S); }
 extern "C" int64_t segx_bn_parts_floats(int B, int C) { return ((int64_t)B * BN_SLABS + 1) * C * 4; }
 extern "C" int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream_) {
@@ -1042,12 +1194,33 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
                                 int B, int C, int64_t S, float eps, int act, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3 && (!run_mean == !run_var), "segx_bn_act_fwd2: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd2: more than 65535 (sample, channel) planes");
-    SEGX_REQUIRE(!parts || (nparts > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0), "segx_bn_act_fwd2: bad partials");
+    SEGX_REQUIRE(!parts || (nparts >= 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0), "segx_bn_act_fwd2: bad partials");
     SEGX_REQUIRE(dc_p >= 0.f && dc_p < 1.f && (dc_p == 0.f || resid), "segx_bn_act_fwd2: drop_connect needs the skip input and 0 <= p < 1");
     BnFwdArgs g;
     g.X = X; g.w = w; g.b = b; g.Y = Y; g.parts = parts; g.nparts = nparts; g.mean = mean; g.var = var; g.run_mean = run_mean; g.run_var = run_var;
     g.momentum = momentum; g.psum = psum; g.resid = resid; g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base();
     g.C = C; g.S = S; g.eps = eps; g.act = act;
+    if (parts && nparts == 0) {
+        // AUTO: the library computes the batch statistics itself -- channel-resident (one launch) where the channel's B planes fit a team's registers,
+        // otherwise partials into `parts` (segx_bn_parts_floats) + the folding apply pass below
+        const int form = bn_res_form(B, S, false);
+        if (form) {
+            g.parts = nullptr;
+            const int team = form >> 4, kp = form & 15;
+            const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
+#define SEGX_BN_RES(T, K)                                                                                                          \
+            if (team == T && kp == K) {                                                                                            \
+                if (psum) hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, true>), rgrid, dim3(256), 0, stream, g, B);            \
+                else hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, false>), rgrid, dim3(256), 0, stream, g, B);                \
+                return check_launch("segx_bn_act_fwd2/resident");                                                                   \
+            }
+            SEGX_BN_RES(64, 1) SEGX_BN_RES(64, 2) SEGX_BN_RES(256, 1) SEGX_BN_RES(256, 2) SEGX_BN_RES(256, 4)
+#undef SEGX_BN_RES
+            return fail(-1, "segx_bn_act_fwd2: no resident form %d", form);
+        }
+        hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, const_cast<float*>(parts), C, S);
+        g.nparts = nparts = B * bn_slabs(S);
+    }
     if (parts && nparts > 256) {
         // a producer with many small tiles: one merge launch, the apply pass then folds ONE partial per channel.  The merged partials live behind the
         // producer's (the caller sized the buffer for nparts + 1 per channel).
@@ -1065,6 +1238,19 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
                                 const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd2: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
+    const int form = training ? bn_res_form(B, S, true) : 0;
+    if (form) {
+        BnBwdArgs g;
+        g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
+        g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act;
+        const int team = form >> 4, kp = form & 15;
+        const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
+        if (team == 64) hipLaunchKernelGGL((bn_act_bwd_res_kernel<64, 1, 8>), rgrid, dim3(256), 0, stream, g, B);
+        else if (kp == 1) hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 1, 8>), rgrid, dim3(256), 0, stream, g, B);
+        else if (kp == 2) hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 2, 8>), rgrid, dim3(256), 0, stream, g, B);
+        else hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 4, 6>), rgrid, dim3(256), 0, stream, g, B);
+        return check_launch("segx_bn_act_bwd2/resident");
+    }
     const int nsl = bn_slabs(S);
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, nsl), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset, rng_base());
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;

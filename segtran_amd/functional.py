@@ -601,7 +601,8 @@ def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, 
     Training, one process: TWO launches (segx_bn_stats_partial, segx_bn_act_fwd2 -- the apply pass merges the statistics partials itself).
     Synchronised: local statistics -> ONE all-gather -> merge kernel -> the same apply pass on the merged statistics.  Eval: the apply pass alone."""
     y = torch.empty_like(x)
-    nch = L.plane_chunks(S) if pool else 0
+    auto = training and _bn_stats_sync is None              # the library computes the statistics itself (channel-resident: one launch for the layer)
+    nch = L.bn_pool_chunks(B, S, auto) if pool else 0
     psum = _empty(x, B * C * nch) if pool else None
     dc_p, seed, off = dc
     if not training:
@@ -610,8 +611,7 @@ def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, 
     mean, var = _empty(x, C), _empty(x, C)
     if _bn_stats_sync is None:
         parts = _empty(x, L.bn_parts_floats(B, C))
-        L.bn_stats_partial(x, parts, B, C, S)
-        L.bn_act_fwd2(x, parts, L.bn_nparts(B, S), mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+        L.bn_act_fwd2(x, parts, 0, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
         return y, mean, var, B * S, psum, nch
     # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
     loc = _empty(x, 2 * C)

@@ -263,6 +263,9 @@ class SegxLib:
     def plane_chunks(self, S):
         return int(self.c.segx_plane_chunks(S))
 
+    def bn_pool_chunks(self, B, S, auto_stats):
+        return int(self.c.segx_bn_pool_chunks(B, S, 1 if auto_stats else 0))
+
     def bn_nparts(self, B, S):
         return int(self.c.segx_bn_nparts(B, S))
 
@@ -545,7 +548,7 @@ _SIGS = {
     'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
-    'segx_plane_chunks': 'l', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
+    'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
     'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuup',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',

@@ -21,7 +21,10 @@ def _act(u, act):
     return u * torch.sigmoid(u) if act == 1 else F.relu(u) if act == 2 else u
 
 
-@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 4, 3, 4, 5), (2, 7, 8, 8), (1, 2, 130, 130)])      # last: two reduction slabs per plane
+# (1, 2, 130, 130): two reduction slabs per plane (statistics partials + folding apply pass); the others: the channel-resident forms (r04) -- one wave per
+# channel with 1 / 2 float4 per lane and plane, the workgroup per channel with 1 / 2 / 4 -- and their limits (B > 8, S % 4 != 0, B = 7 at S = 4096 backward)
+@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 4, 3, 4, 5), (2, 7, 8, 8), (1, 2, 130, 130), (6, 3, 16, 32), (5, 2, 32, 32), (3, 2, 40, 48),
+                                   (6, 2, 64, 64), (7, 2, 64, 64), (9, 2, 8, 8), (2, 3, 11, 11), (8, 5, 16, 16)])
 @pytest.mark.parametrize('act', [0, 1, 2])
 @pytest.mark.parametrize('training', [True, False])
 def test_bn_act(backend, shape, act, training):
@@ -89,7 +92,7 @@ def test_squeeze_excite(backend, B, C, Cs, H, W):
         close(a.grad, r.grad, 1e-4)
 
 
-@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 70, 9, 4, 5), (1, 3, 2, 130, 130)])      # last: several chunks per plane
+@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 70, 9, 4, 5), (1, 3, 2, 130, 130), (6, 9, 3, 32, 32), (6, 5, 2, 16, 24)])      # third: several chunks per plane
 @pytest.mark.parametrize('training', [True, False])
 def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
     """The one-op form an MBConv block uses (BatchNorm + swish with the squeeze-excite pooling in the same pass, the gate's product rule applied
@@ -157,7 +160,7 @@ def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, tra
     close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
 
 
-@pytest.mark.parametrize('shape', [(6, 5, 6, 10), (5, 3, 36, 36), (4, 2, 130, 130)])
+@pytest.mark.parametrize('shape', [(6, 5, 6, 10), (5, 3, 36, 36), (4, 2, 130, 130), (6, 2, 64, 64), (6, 6, 16, 16)])
 @pytest.mark.parametrize('rate', [0.0, 0.5])
 @pytest.mark.parametrize('training', [True, False])
 def test_bn_with_skip_add_and_drop_connect(backend, shape, rate, training):

@@ -455,7 +455,7 @@ def test_planned_gemm_honours_the_per_call_engine_under_the_opposite_default(bac
     try:
         g = torch.Generator(device='cpu').manual_seed(11)
         M, N, K = 512, 384, 512                              # large enough for the planner to pick a wave-specialised tile on the bf16x6 engine
-        A = torch.randn(M, K, generator=g).to(dev); B = torch.randn(N, K, generator=g).to(dev)
+        A = torch.randn(M, K, generator=g, device='cpu').to(dev); B = torch.randn(N, K, generator=g, device='cpu').to(dev)
         C = torch.empty(M, N, device=dev)
         L.x6_launches()
         L.gemm(A, B, C, M, N, K, (0, 0, K, 1), (0, 0, K, 1), (0, 0, N), splitk=0, engine=eng)
