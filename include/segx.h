@@ -71,6 +71,10 @@ typedef struct {
                                        * it again).  Used by the wave-specialised 256x128 / 128x256 bf16x6 kernels with a plain epilogue; every other
                                        * path reads B itself, which must stay valid.  Results are bit-identical either way. */
     int64_t bp_b0, bp_b1;             /* batch strides of b_planes in bf16 elements (3*N*K per matrix; 0 = shared) */
+    const float* resid;               /* optional: C = alpha * A B^T (+ bias) + resid, resid laid out exactly like C (c_b0, c_b1, c_m).  Plain epilogue only
+                                       * (no GELU, no gmax, no batch_reduce); with split-K it is added by the slab reduction.  Used for the gradient of a
+                                       * tensor with two consumers -- the input of an MBConv block feeds the expansion convolution AND the skip connection
+                                       * (efficientnet/model.py:96,118-122): dX = W^T dY + d(skip) in ONE launch instead of a GEMM and an add */
 } segx_gemm_desc;
 int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream);
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are

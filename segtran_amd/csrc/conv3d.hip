@@ -911,7 +911,7 @@ static void fill_common(GemmArgs& g, int M, int N, int K, int nbatch, int splitk
     g.bias = nullptr; g.aux = nullptr; g.gmax = nullptr; g.nb1 = 1; g.bias_b1 = 0; g.bias_b0 = 0; g.alpha = 1.0f; g.epilogue = SEGX_EPI_NONE; g.bias_mode = SEGX_BIAS_NONE;
     g.a_b1 = g.b_b1 = g.c_b1 = 0; g.b_n = g.b_k = 0; g.a_k = 1; g.vecA = g.vecB = 0;
     g.M = M; g.N = N; g.K = K; g.tiles_m = ceil_div(M, BM); g.tiles_n = ceil_div(N, BN);
-    g.dropout_p = 0.f; g.seed = g.offset = 0; g.rbase = nullptr; g.splitk = splitk; g.slab = 0;
+    g.dropout_p = 0.f; g.seed = g.offset = 0; g.rbase = nullptr; g.splitk = splitk; g.slab = 0; g.resid = nullptr;
     g.k_chunk = splitk == 1 ? K : ceil_div(ceil_div(K, splitk), BKT) * BKT;
     g.c_split = (int64_t)nbatch * M * N;
     if (splitk > 1) g.C = workspace;
@@ -978,7 +978,7 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     const int64_t total = g.c_split;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, Y,
                        (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, y_bs ? y_bs : (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
-                       (int64_t)0, (int64_t)0, total);
+                       (int64_t)0, (int64_t)0, total, (const float*)nullptr);
     return check_launch("segx_conv3d_fwd/reduce");
 }
 extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
@@ -1046,7 +1046,7 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     const int64_t total = g.c_split;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, dWb,
                        (const float*)nullptr, Cout, N, 1, splitk, g.c_split, (int64_t)Cout * N, (int64_t)0, (int64_t)N, 1.0f, (int)SEGX_BIAS_NONE,
-                       (int64_t)0, (int64_t)0, total);
+                       (int64_t)0, (int64_t)0, total, (const float*)nullptr);
     return check_launch("segx_conv3d_bwd_weight/reduce");
 }
 extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,

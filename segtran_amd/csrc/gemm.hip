@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void x6_presplit_kernel(const float* __restric
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,
                                                             int64_t c_b0, int64_t c_b1, int64_t c_m, float alpha,
-                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total) {
+                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total, const float* __restrict__ resid) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(idx % N);
         const int64_t t = idx / N;
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         const int z0 = zb / nb1, z1 = zb - z0 * nb1;
         if (bias_mode == SEGX_BIAS_N) s += bias[z0 * bias_b0 + z1 * bias_b1 + col];
         else if (bias_mode == SEGX_BIAS_M) s += bias[z0 * bias_b0 + z1 * bias_b1 + row];
-        C[z0 * c_b0 + z1 * c_b1 + (int64_t)row * c_m + col] = s;
+        const int64_t o = z0 * c_b0 + z1 * c_b1 + (int64_t)row * c_m + col;
+        C[o] = resid ? s + resid[o] : s;
     }
 }
 // The same reduction for MANY slabs over a SMALL output (batch_reduce of the skinny weight gradients: 6 x 63 slabs of 24 x 144 floats): the slab
@@ -272,6 +273,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.c_split = (int64_t)nbatch * d->M * d->N;
     g.slab = breduce ? 1 : 0;
     g.Bp = nullptr; g.bp_plane = g.bp_b0 = g.bp_b1 = 0;
+    g.resid = d->resid;
+    SEGX_REQUIRE(!d->resid || (d->epilogue == SEGX_EPI_NONE && !breduce && !d->gmax), "segx_gemm_f32: resid needs a plain epilogue (no GELU, no batch_reduce, no gmax)");
     if (splitk > 1 || breduce) g.C = d->workspace;
     SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS64x256, "segx_gemm_f32: bad tile %d", d->tile);
     const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS64x256;
@@ -438,14 +441,14 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
                                d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
         else
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                               d->M, d->N, 1, nslabs, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total);
+                               d->M, d->N, 1, nslabs, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total, (const float*)nullptr);
         return check_launch("segx_gemm_f32/batch_reduce");
     }
     if (splitk > 1) {
         const int64_t total = g.c_split;
         const int blocks = (int)i64min(2048, (total + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                           d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, d->bias_b0, total);
+                           d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, d->bias_b0, total, d->resid);
         rc = check_launch("segx_gemm_f32/splitk_reduce");
     }
     return rc;

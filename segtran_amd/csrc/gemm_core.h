@@ -41,6 +41,7 @@ struct GemmArgs {
     int splitk; int64_t c_split;    // slab stride in the workspace
     const unsigned short* Bp; int64_t bp_plane, bp_b0, bp_b1;   // B operand pre-split into three bf16 planes (segx_x6_presplit), element strides; NULL = none
     int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
+    const float* resid;             // C = alpha * A B^T (+ bias) + resid, resid laid out like C (plain epilogue; split-K adds it in the slab reduction)
 };
 
 // Load this thread's ROWS*BKT/1024 float4 pieces of a ROWS x BKT operand tile into registers.
@@ -258,6 +259,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     const float* bias = (g.bias && !split) ? g.bias + z0 * g.bias_b0 + z1 * g.bias_b1 : nullptr;
     const bool bias_n = bias && g.bias_mode == SEGX_BIAS_N, bias_m = bias && g.bias_mode == SEGX_BIAS_M;
     float* AUX = (EPI == SEGX_EPI_GELU) ? g.aux + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;
+    const float* RES = (EPI == SEGX_EPI_NONE && g.resid && !split) ? g.resid + z0 * g.c_b0 + z1 * g.c_b1 : nullptr;     // wave-uniform
     const float inv_keep = g.dropout_p > 0.f ? 1.0f / (1.0f - g.dropout_p) : 1.0f;
     const uint64_t roff = g.offset + ((EPI == SEGX_EPI_GELU && g.dropout_p > 0.f && g.rbase) ? *g.rbase : 0);
     const bool full = (m0 + Cfg::BM <= g.M) && (n0 + Cfg::BN <= g.N);
@@ -301,7 +303,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
                     if (ok) vmax = fmaxf(vmax, v);
                     if (!vec_st && ok) {
                         if (EPI == SEGX_EPI_GELU) AUX[(int64_t)row * ldc + col] = pre[q];
-                        C[(int64_t)row * ldc + col] = v;
+                        C[(int64_t)row * ldc + col] = RES ? v + RES[(int64_t)row * ldc + col] : v;
                     }
                 }
                 if (vec_st) {                              // lane (quad, i): row rbase + 8 rg + i, columns (col & ~3) .. + 3
@@ -312,7 +314,10 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
                         quad_transpose4(pre, lane & 1, lane & 2);
                         if (ok) *reinterpret_cast<float4*>(AUX + (int64_t)row * ldc + col0) = make_float4(pre[0], pre[1], pre[2], pre[3]);
                     }
-                    if (ok) *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col0) = make_float4(out[0], out[1], out[2], out[3]);
+                    if (ok) {
+                        if (RES) { const float4 rv = *reinterpret_cast<const float4*>(RES + (int64_t)row * ldc + col0); out[0] += rv.x; out[1] += rv.y; out[2] += rv.z; out[3] += rv.w; }
+                        *reinterpret_cast<float4*>(C + (int64_t)row * ldc + col0) = make_float4(out[0], out[1], out[2], out[3]);
+                    }
                 }
             }
         }
@@ -361,6 +366,6 @@ inline int best_splitk(const TileInfo& ti, int M, int N, int K, int nbatch, doub
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
                                                             int M, int N, int nb1, int splitk, int64_t c_split,
                                                             int64_t c_b0, int64_t c_b1, int64_t c_m, float alpha,
-                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total);
+                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total, const float* resid);
 
 }  // namespace segx

@@ -57,9 +57,9 @@ class Conv2dStaticSamePadding(nn.Conv2d):
         self.static_pad = (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
         self.pointwise = (kh == 1 and kw == 1 and sh == 1 and sw == 1 and self.groups == 1)
 
-    def forward(self, x):
+    def forward(self, x, pass_input=False):
         if self.pointwise:
-            return SF.conv1x1(x, self.weight, self.bias)                 # libsegx MFMA GEMM
+            return SF.conv1x1(x, self.weight, self.bias, pass_input=pass_input)       # libsegx MFMA GEMM
         if self.groups == self.in_channels and self.groups == self.out_channels and self.bias is None:
             return SF.dwconv2d(x, self.weight, self.stride[0], self.static_pad)   # libsegx depthwise stencil
         assert self.groups == 1 and self.bias is None and self.dilation == (1, 1)
@@ -98,11 +98,16 @@ class MBConvBlock(nn.Module):
     gate_in_weights = True     # False: the reference's op order (gate applied to the activation, model.py:110), as a separate pass
 
     def forward(self, inputs, drop_connect_rate=None):
-        x = inputs
-        if self.expand_ratio != 1:
-            x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
-        se = (self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
+        x = skip_in = inputs
         skip = self.stride == 1 and self.input_filters == self.output_filters
+        if self.expand_ratio != 1:
+            # with a skip connection `inputs` has two consumers: the second one goes through the alias the GEMM op returns, so that its gradient is
+            # added inside the expansion's dX GEMM instead of by an accumulation kernel of autograd's (25 blocks of B4)
+            x = self._expand_conv(x, pass_input=skip)
+            if skip:
+                x, skip_in = x
+            x = SF.bn_act(x, self._bn0, SF.ACT_SWISH)
+        se = (self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
         # drop_connect (utils.py:129-154, per-sample stochastic depth) and the skip add ride on the last BatchNorm pass: the sample's keep scale is
         # drawn inside the kernels from the library's Philox stream (H3: the reference's torch.rand stream cannot be matched anyway)
         rate = float(drop_connect_rate) if (skip and drop_connect_rate and self.training) else 0.0
@@ -112,7 +117,7 @@ class MBConvBlock(nn.Module):
             x = SF.conv1x1_per_sample(y, Wb)
         else:
             x = self._project_conv(SF.bn_act_se(self._depthwise_conv(x), self._bn1, SF.ACT_SWISH, *se))
-        return SF.bn_act(x, self._bn2, SF.ACT_NONE, resid=inputs if skip else None, drop_connect=rate)
+        return SF.bn_act(x, self._bn2, SF.ACT_NONE, resid=skip_in if skip else None, drop_connect=rate)
 
 
 class EfficientNet(nn.Module):

@@ -56,8 +56,9 @@ def _run_gemm(L, A, B, C, M, N, K, a, b, c, nb, alpha, **kw):
     L.gemm(A, B, C, M, N, K, a, b, c, nb=nb, alpha=alpha, splitk=0, **kw)
 
 
-def _grad_operand(L, dC, other, s, which, like):
-    """Gradient of operand `which` ('a' or 'b') of spec s.  `other` is the other operand."""
+def _grad_operand(L, dC, other, s, which, like, resid=None):
+    """Gradient of operand `which` ('a' or 'b') of spec s.  `other` is the other operand.  resid (same shape as `like`, operand not shared over
+    a batch dim): added to the gradient inside the GEMM launch (segx_gemm_desc.resid)."""
     nb = s.nb
     if which == 'a':
         rows, cols, st, ost = s.M, s.K, s.a, s.b      # dA(m,k) = alpha sum_n dC(m,n) B(n,k)
@@ -65,6 +66,7 @@ def _grad_operand(L, dC, other, s, which, like):
         rows, cols, st, ost = s.N, s.K, s.b, s.a      # dB(n,k) = alpha sum_m dC(m,n) A(m,k)
     inner = s.N if which == 'a' else s.M
     bcast = [(st[i] == 0 and nb[i] > 1) for i in (0, 1)]
+    assert resid is None or (not any(bcast) and like.is_contiguous() and resid.is_contiguous() and resid.shape == like.shape)
     partial = any(bcast) and not all(bcast[i] or nb[i] == 1 for i in (0, 1))
     if partial:
         # shared across ONE batch dim while the other one walks it (attractors shared by the batch, split into modes: Polyformer's
@@ -117,10 +119,11 @@ def _grad_operand(L, dC, other, s, which, like):
     else:
         dc_as_rows = (s.c[0], s.c[1], 1, s.c[2])       # (n, inner=m)
         oth = (ost[0], ost[1], ost[3], ost[2])         # A as (k, inner=m): row stride a_k, inner stride a_m
+    kw = dict(resid=resid) if resid is not None else {}
     if k_contig:    # out[rows][cols=k]
-        _run_gemm(L, dC, other, tgt, rows, cols, inner, dc_as_rows, oth, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+        _run_gemm(L, dC, other, tgt, rows, cols, inner, dc_as_rows, oth, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha, **kw)
     else:           # out^T[k][rows]
-        _run_gemm(L, other, dC, tgt, cols, rows, inner, oth, dc_as_rows, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha)
+        _run_gemm(L, other, dC, tgt, cols, rows, inner, oth, dc_as_rows, (tgt_b[0], tgt_b[1], row_stride), nb, s.alpha, **kw)
     if any(bcast):
         assert all(bcast[i] or nb[i] == 1 for i in (0, 1)), 'partial batch broadcast is not supported'
         nbt = nb[0] * nb[1]
@@ -133,8 +136,12 @@ def _grad_operand(L, dC, other, s, which, like):
 
 
 class _BGemm(torch.autograd.Function):
+    """pass_b: also return the B operand as a second output (an alias).  A caller that needs B twice -- the input of an MBConv block feeds the
+    expansion convolution AND the skip connection -- uses the alias for the second consumer: autograd then hands BOTH gradients to this node,
+    and the second one is added inside the dB GEMM (segx_gemm_desc.resid) instead of by a separate accumulation kernel."""
+
     @staticmethod
-    def forward(ctx, A, B, bias, spec, gmax, gelu, drop_p):
+    def forward(ctx, A, B, bias, spec, gmax, gelu, drop_p, pass_b=False):
         L = segx.lib()
         s = spec
         A, B = _c(A), _c(B)
@@ -150,14 +157,20 @@ class _BGemm(torch.autograd.Function):
         _run_gemm(L, A, B, C, s.M, s.N, s.K, s.a, s.b, s.c, s.nb, s.alpha, **kw)
         ctx.spec, ctx.gelu, ctx.drop = s, gelu, (drop_p, seed, off)
         ctx.has_bias = bias is not None
+        ctx.pass_b = pass_b
+        ctx.set_materialize_grads(False)                      # an unused output's gradient arrives as None, not as a zero tensor
         ctx.save_for_backward(A, B, T)
+        if pass_b:
+            return C, B.view_as(B)
         return C
 
     @staticmethod
-    def backward(ctx, dC):
+    def backward(ctx, dC, dB_alias=None):
         L = segx.lib()
         A, B, T = ctx.saved_tensors
         s = ctx.spec
+        if dC is None:                                       # only the alias was used
+            return None, dB_alias, None, None, None, None, None, None
         dC = _c(dC)
         if ctx.gelu:
             p, seed, off = ctx.drop
@@ -165,11 +178,11 @@ class _BGemm(torch.autograd.Function):
             L.gelu_bwd(dC, T, dT, dC.numel(), p, seed, off)
             dC = dT
         dA = _grad_operand(L, dC, B, s, 'a', A) if ctx.needs_input_grad[0] else None
-        dB = _grad_operand(L, dC, A, s, 'b', B) if ctx.needs_input_grad[1] else None
+        dB = _grad_operand(L, dC, A, s, 'b', B, resid=_c(dB_alias) if dB_alias is not None else None) if ctx.needs_input_grad[1] else None
         dbias = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = _bias_grad(L, dC, s)
-        return dA, dB, dbias, None, None, None, None
+        return dA, dB, dbias, None, None, None, None, None
 
 
 def _bias_grad(L, dC, s):
@@ -522,14 +535,18 @@ def transpose12(x):
 # Pointwise (1x1 / 1x1x1) convolution on NC[D]HW tensors = one batched GEMM, no layout change:
 #   Y[b][co][s] = sum_ci W[co][ci] X[b][ci][s] + bias[co]      (s = flattened spatial index, contiguous)
 # -------------------------------------------------------------------------------------------------
-def conv1x1(x, weight, bias=None):
-    """x [B, Cin, *spatial]; weight [Cout, Cin, 1, 1(, 1)] (nn.Conv2d / nn.Conv3d layout)."""
+def conv1x1(x, weight, bias=None, pass_input=False):
+    """x [B, Cin, *spatial]; weight [Cout, Cin, 1, 1(, 1)] (nn.Conv2d / nn.Conv3d layout).  pass_input: -> (y, x_alias); route a second use of x
+    (a skip connection) through x_alias and its gradient is added inside the dX GEMM (see _BGemm)."""
     B, Cin = x.shape[0], x.shape[1]
     S = x.numel() // (B * Cin)
     Cout = weight.shape[0]
     spec = GemmSpec(Cout, S, Cin, (0, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S),
                     (B, Cout) + tuple(x.shape[2:]), nb=(B, 1), bias_mode=BIAS_M)
-    return bgemm(weight.reshape(Cout, Cin), x, spec, bias=bias)
+    if pass_input and x.is_contiguous() and x.requires_grad and torch.is_grad_enabled():
+        return _BGemm.apply(weight.reshape(Cout, Cin), x, bias, spec, None, False, 0.0, True)
+    y = bgemm(weight.reshape(Cout, Cin), x, spec, bias=bias)
+    return (y, x) if pass_input else y
 
 
 def conv1x1_tokens(tokens, grid_shape, weight):

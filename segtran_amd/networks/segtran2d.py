@@ -149,7 +149,7 @@ class Segtran2d(SegtranInitWeights):
         cur = SF.bn_act(cur, self.in_bn4b) if self.in_fpn_use_bn else SF.group_norm(cur, self.in_gn4b)
         cur = self.in_fpn_bridgeconv(cur)
         H2, W2 = cur.shape[2:]
-        vfeat = cur.permute(0, 2, 3, 1).reshape(B, H2 * W2, self.trans_in_dim)
+        vfeat = SF.transpose12(cur.reshape(B, self.trans_in_dim, H2 * W2))             # NCHW map -> channels-last tokens [B, N, C] (LDS-tiled, both ways)
         return vfeat, nonzero_mask.reshape(B, -1), H2, W2
 
     def out_fpn_forward(self, feats, vfeat_fused, B0):

@@ -164,7 +164,7 @@ class Segtran3d(SegtranInitWeights):
         cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
         m = (_up(nonzero_mask.unsqueeze(1), dp).squeeze(1) >= 0.5)
         B, Fd, D2, H2, W2 = cur.shape
-        vfeat = cur.permute(0, 2, 3, 4, 1).reshape(B, -1, Fd)
+        vfeat = SF.transpose12(cur.reshape(B, Fd, D2 * H2 * W2))                    # NCDHW map -> channels-last tokens [B, N, C] (LDS-tiled, both ways)
         return vfeat, m.reshape(B, -1), D2, H2, W2
 
     def out_fpn_forward(self, feats, vfeat_fused):

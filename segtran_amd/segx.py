@@ -28,7 +28,7 @@ class GemmDesc(ctypes.Structure):
                 ('bias', c_p), ('aux', c_p), ('gmax', c_p),
                 ('dropout_p', c_f), ('seed', c_u), ('offset', c_u),
                 ('splitk', c_i), ('workspace', c_p), ('tile', c_i), ('bias_b0', c_l), ('batch_reduce', c_i), ('engine', c_i),
-                ('b_planes', c_p), ('bp_b0', c_l), ('bp_b1', c_l)]
+                ('b_planes', c_p), ('bp_b0', c_l), ('bp_b1', c_l), ('resid', c_p)]
 
 
 EPI_NONE, EPI_GELU = 0, 1
@@ -106,7 +106,7 @@ class SegxLib:
     # ---- GEMM -----------------------------------------------------------------------------------
     def gemm(self, A, B, C, M, N, K, a_strides, b_strides, c_strides, nb=(1, 1), alpha=1.0, bias=None,
              bias_mode=BIAS_NONE, bias_b1=0, bias_b0=0, epilogue=EPI_NONE, aux=None, gmax=None, dropout_p=0.0, seed=0,
-             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None, b_planes=None):
+             offset=0, splitk=1, workspace=None, tile=TILE_AUTO, batch_reduce=False, engine=None, b_planes=None, resid=None):
         """C[z][m][n] = epi(alpha * sum_k A[z][m][k] B[z][n][k] + bias).  Strides in elements:
         a_strides = (b0, b1, m, k); b_strides = (b0, b1, n, k); c_strides = (b0, b1, m).
         splitk = 0: take tile and split factor from segx_gemm_plan and allocate the slab workspace here.
@@ -115,8 +115,9 @@ class SegxLib:
         b_planes: (planes tensor from x6_presplit(B ...), bp_b0, bp_b1) -- B split ahead of time (segx_gemm_desc.b_planes).  Bit-identical results;
         measured (tools/pre_bench.py, profiles/r03_ad_pre_bench.txt): +-0 on the 1792-wide projections, +5..9 % on 896-wide ones on the 256 x 128
         kernel (which the planner no longer picks for them), so the model code does not use it."""
-        self._chk_t(A, B, C, bias, aux, gmax, workspace)
+        self._chk_t(A, B, C, bias, aux, gmax, workspace, resid)
         d = GemmDesc()
+        d.resid = _ptr(resid)
         d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
         d.a_b0, d.a_b1, d.a_m, d.a_k = a_strides
         d.b_b0, d.b_b1, d.b_n, d.b_k = b_strides

@@ -504,3 +504,56 @@ def test_gemm_is_reentrant_across_threads_streams_and_engines():
     assert not errs, errs[:3]
     prev = L.set_engine(default)
     assert prev == default                                   # no call changed the process default
+
+
+@pytest.mark.parametrize('engine', ['f32', 'x6'])
+@pytest.mark.parametrize('M,N,K,nb,sk,tile', [(130, 72, 64, 2, 1, segx.TILE_AUTO), (96, 200, 40, 1, 1, segx.TILE_AUTO), (64, 260, 96, 3, 2, segx.TILE_128x128),
+                                               (300, 392, 128, 2, 1, segx.TILE_256x128), (33, 70, 17, 2, 1, segx.TILE_AUTO)])
+def test_gemm_residual_epilogue(backend, engine, M, N, K, nb, sk, tile):
+    """segx_gemm_desc.resid: C = alpha A B^T + bias + resid in one launch (with split-K: in the slab reduction) -- what carries the skip connection's
+    gradient into the expansion convolution's dX GEMM.  16-byte and 4-byte store paths (N % 4), ragged edges, batches, the wave-specialised tile."""
+    L = backend.L
+    if tile == segx.TILE_256x128 and engine != 'x6':
+        pytest.skip('wave-specialised tiles exist on the bf16x6 engine only')
+    prev = L.set_engine(engine)
+    try:
+        g = torch.Generator(device='cpu').manual_seed(M + N + K)
+        A = torch.randn(nb, M, K, generator=g, device='cpu'); B = torch.randn(nb, N, K, generator=g, device='cpu')
+        R = torch.randn(nb, M, N, generator=g, device='cpu'); bias = torch.randn(N, generator=g, device='cpu')
+        Ad, Bd, Rd, bd = (t.to(backend.dev) for t in (A, B, R, bias))
+        C = torch.full((nb, M, N), float('nan'), device=backend.dev)
+        ws = torch.empty(sk * nb * M * N, device=backend.dev) if sk > 1 else None
+        L.gemm(Ad, Bd, C, M, N, K, (0, M * K, K, 1), (0, N * K, K, 1), (0, M * N, N), nb=(1, nb), splitk=sk, workspace=ws, tile=tile, alpha=0.5, bias=bd,
+               bias_mode=segx.BIAS_N, resid=Rd)
+        ref = 0.5 * _ref(A, B) + bias.double()[None, None, :] + R.double()
+        assert (C.cpu().double() - ref).abs().max().item() < 3e-6 * max(1.0, ref.abs().max().item())
+    finally:
+        L.set_engine(prev)
+
+
+def test_second_consumer_gradient_rides_on_the_dx_gemm(backend):
+    """conv1x1(pass_input=True): the alias output carries a second use of the input (the MBConv skip connection); both gradients reach the GEMM node
+    and are summed inside its dX launch -- equal to plain autograd accumulation."""
+    from segtran_amd import functional as SF
+    dev = backend.dev
+    g = torch.Generator(device='cpu').manual_seed(9)
+    x0 = torch.randn(2, 8, 6, 10, generator=g, device='cpu').to(dev)
+    W = torch.randn(12, 8, 1, 1, generator=g, device='cpu').to(dev).requires_grad_(True)
+    G1 = torch.randn(2, 12, 6, 10, generator=g, device='cpu').to(dev); G2 = torch.randn(2, 8, 6, 10, generator=g, device='cpu').to(dev)
+    outs = []
+    for passed in (True, False):
+        x = x0.clone().requires_grad_(True)
+        h = x * 1.0                                           # a non-leaf input, as inside the network
+        if passed:
+            y, h2 = SF.conv1x1(h, W, pass_input=True)
+            assert h2.data_ptr() == h.data_ptr()
+        else:
+            y, h2 = SF.conv1x1(h, W), h
+        W.grad = None
+        ((y * G1).sum() + (h2 * G2).sum()).backward()
+        outs.append((x.grad.clone(), W.grad.clone()))
+    assert torch.allclose(outs[0][0], outs[1][0], atol=1e-5) and torch.allclose(outs[0][1], outs[1][1], atol=1e-5)
+    x = x0.clone().requires_grad_(True)                      # alias unused: no residual, plain gradient
+    y, _ = SF.conv1x1(x * 1.0, W, pass_input=True)
+    (y * G1).sum().backward()
+    assert torch.allclose(x.grad, outs[0][0] - G2, atol=1e-5)
