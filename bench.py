@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_TBS = 8.0                  # same guide: HBM3E ~8 TB/s (TFLOP/s per FLOP/byte)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: bf16 MFMA dense (32x32x16); the bf16x6 engine issues 6 of them per fp32-equivalent block product
 WORKLOADS = {'cfg1': 'REFUGE fundus 2D, segtran eff-b4, translayers 1, 256x256, bs 2/GPU',
              'cfg2': 'REFUGE fundus 2D, segtran eff-b4, translayers 3, layercompress 1,1,2,2, 512x512, bs 6/GPU',
@@ -167,10 +168,24 @@ def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
         a = agg.setdefault(pr[3], [0, 0.0, 0.0]); a[0] += 1; a[1] += pr[0].elapsed_time(pr[1]); a[2] += pr[2]
     peak_ = PEAK_BF16_MFMA_TFLOPS / 6.0 if engine_name == 'x6' else PEAK_F32_MFMA_TFLOPS
 
+    def shape_bytes(shp):
+        """algorithmic bytes of ONE launch of this shape (operands read once, result written once; an operand shared by the batch counted once)"""
+        if isinstance(shp[0], str):
+            _, M_, N_, K_, B_ = shp[:5]
+            return 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] == 'conv3d_fwd' else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
+        M_, N_, K_, nb_ = shp[:4]
+        small, big = min(M_ * K_, N_ * K_), max(M_ * K_, N_ * K_)
+        return 4.0 * (nb_ * (big + M_ * N_) + (small if nb_ > 1 and small * 8 <= big else nb_ * small))      # a much smaller operand = the shared weights
+
     def row(shp, v):
         n, t, fl = v
         tf = fl / (t * 1e-3) / 1e12 if t > 0 else 0.0
-        r = {'launches_per_step': round(n / max(1, steps), 2), 'ms_per_step': round(t / max(1, steps), 3), 'tflops': round(tf, 1), 'frac': round(tf / peak_, 3)}
+        by = shape_bytes(shp)
+        ai = (fl / n) / by                                                  # FLOP per algorithmic byte
+        roof = min(peak_, ai * PEAK_HBM_TBS)                                # TFLOP/s the shape can reach: matrix pipe or HBM, whichever binds first
+        r = {'launches_per_step': round(n / max(1, steps), 2), 'ms_per_step': round(t / max(1, steps), 3), 'tflops': round(tf, 1), 'frac': round(tf / peak_, 3),
+             'flop_per_byte': round(ai, 1), 'bound': 'mfma' if roof >= peak_ else 'hbm', 'roof_tflops': round(roof, 1), 'frac_of_roof': round(tf / roof, 3),
+             'gbs': round(by * n / (t * 1e-3) / 1e9) if t > 0 else 0}
         if isinstance(shp[0], str):
             r.update(kind=shp[0], M=shp[1], N=shp[2], K=shp[3], batch=shp[4])
         else:
@@ -179,6 +194,13 @@ def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
     ranked = sorted(agg.items(), key=lambda kv: -kv[1][1])
     by_shape = [row(k, v) for k, v in ranked[:12]]
     attn = [row(k, v) for k, v in ranked if not isinstance(k[0], str) and mode_batch and k[3] == mode_batch][:10]
+    # how much of the dominant engine's time sits in launches whose ALGORITHMIC intensity puts them under the HBM roof, not the matrix pipe's (the
+    # 24..272-channel pointwise convolutions of the backbone at 512 x 512 / 256 x 256 planes): `frac` above prices them against the matrix pipe all the same
+    t_all = sum(v[1] for v in agg.values())
+    t_hbm = sum(v[1] for k, v in agg.items() if min(peak_, (v[2] / v[0]) / shape_bytes(k) * PEAK_HBM_TBS) < peak_)
+    roof['hbm_bound_share_of_engine_time'] = round(t_hbm / t_all, 3) if t_all > 0 else 0.0
+    roof['time_weighted_frac_of_applicable_roof'] = round(sum(v[1] * ((v[2] / (v[1] * 1e-3) / 1e12) / min(peak_, (v[2] / v[0]) / shape_bytes(k) * PEAK_HBM_TBS))
+                                                              for k, v in agg.items() if v[1] > 0) / t_all, 3) if t_all > 0 else 0.0
     roof.update({'by_shape': by_shape, 'attention_gemms': attn, 'traffic': traffic, 'traffic_note': tnote, 'algorithmic_bytes_per_launch': round(alg_bytes / max(1, len(prof))),
                  'launches_per_step': dom['launches_per_step'], 'gemm_ms_per_step': dom['ms_per_step'], 'gemm_tflop_per_step': dom['tflop_per_step'],
                  'all_engine_launches': {'launches_per_step': len(prof) // max(1, steps), 'ms_per_step': round(ms / max(1, steps), 2),

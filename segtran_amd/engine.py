@@ -185,6 +185,111 @@ class TrainStep:
         return loss
 
 
+def attach_adversarial(net, adversarial_mode, num_classes, num_feat_dis_in_chan=64, adda=False, recon_w=0.0, device=None, num_base_chan=32):
+    """train2d.py:876-882, 923-926, 1044-1045: the domain discriminator (input: the network's last feature map, `--adv feat`, or the soft masks,
+    `--adv mask`; gradient reversal in front unless ADDA trains it with its own optimizer) and the optional 1x1 reconstruction head, attached to
+    the network as `net.discriminator` / `net.recon` (None when unused), so that checkpoints and polyformer_optimized_params see them."""
+    from .networks.discriminator import Discriminator
+    dev = device or next(net.parameters()).device
+    net.discriminator = None
+    if adversarial_mode:
+        if adversarial_mode not in ('feat', 'mask'):
+            raise ValueError("--adv must be 'feat' or 'mask' (train2d.py:88-90), got %r" % adversarial_mode)
+        chan = num_classes if adversarial_mode == 'mask' else num_feat_dis_in_chan
+        net.discriminator = Discriminator(chan, num_classes=1, do_revgrad=not adda, num_base_chan=num_base_chan).to(dev)
+    net.recon = torch.nn.Conv2d(num_feat_dis_in_chan, 3, kernel_size=1).to(dev) if recon_w > 0 else None
+    if hasattr(net, 'keep_feature_maps'):
+        net.keep_feature_maps = bool(adversarial_mode) or recon_w > 0            # the loop reads net.feature_maps[-1]
+    return net
+
+
+def domain_adversarial_loss(net, adversarial_mode, image_batch, source_image_batch, outputs_soft, out_size, adda=False, discriminator_optim=None):
+    """The unsupervised half of the few-shot domain-adaptation step, train2d.py:1259-1284, to be called right after `outputs = net(image_batch)`:
+    the target batch's feature map is still in net.feature_maps[-1]; the SOURCE batch then goes through the network (overwriting it); source
+    rows come first in the mixed batch and carry label 0, target rows label 1; the discriminator sees the feature maps (`feat`) or the soft masks
+    resampled to the mask size (`mask`); unweighted BCE-with-logits.  ADDA (:1278-1283): the discriminator takes its own optimizer step on this
+    loss first (graph retained), and the loss handed back -- the one the generator is trained on -- is the same scores against INVERTED labels.
+    Returns (domain_loss, source_outputs)."""
+    F = torch.nn.functional
+    target_feat = net.feature_maps[-1]
+    source_outputs = net(source_image_batch)
+    source_feat = net.feature_maps[-1]
+    mix = len(image_batch) + len(source_image_batch)
+    domain_labels = torch.ones((mix, 1), device=image_batch.device)
+    domain_labels[:len(source_image_batch)] = 0
+    if adversarial_mode == 'feat':
+        mix_dom_feat = torch.cat([source_feat, target_feat], dim=0)
+    elif adversarial_mode == 'mask':
+        so = source_outputs if tuple(source_outputs.shape[2:]) == tuple(out_size) else SF.interp_linear(source_outputs, tuple(out_size))
+        mix_dom_feat = torch.cat([torch.sigmoid(so), outputs_soft], dim=0)
+    else:
+        raise ValueError(adversarial_mode)
+    domain_scores = net.discriminator(mix_dom_feat)
+    domain_loss = F.binary_cross_entropy_with_logits(domain_scores, domain_labels)
+    if adda:
+        discriminator_optim.zero_grad()
+        domain_loss.backward(retain_graph=True)
+        discriminator_optim.step()
+        domain_loss = F.binary_cross_entropy_with_logits(domain_scores, 1 - domain_labels)
+    return domain_loss, source_outputs
+
+
+class AdversarialTrainStep:
+    """One step of the few-shot / adversarial recipe of train2d.py (--adv feat|mask [--adda] [--reconweight]; :1147-1186 batches, :1204-1257 supervised
+    part and reconstruction, :1259-1284 domain loss, :1314-1326 total loss, clip, step) as host control flow over the same kernels as TrainStep.
+
+    step(image, raw_mask, target_unsup_image, source_image): the supervised batch (may be None with supervised_w == 0) is concatenated IN FRONT of
+    the unsupervised target batch (:1166-1170); losses are computed on the first SUP_B rows only (:1228-1241); every loss term keeps the
+    reference's weight: loss = SUPERVISED_W * ((1 - DICE_W) ce + DICE_W dice) + DOMAIN_LOSS_W * domain + RECON_W * recon."""
+
+    def __init__(self, net, optimizer, task, adversarial_mode, adda=False, discriminator_optim=None, supervised_w=1.0, domain_w=0.002, recon_w=0.0,
+                 dice_w=0.5, exclusive=False):
+        if adversarial_mode and getattr(net, 'discriminator', None) is None:
+            raise ValueError('attach_adversarial(net, ...) first: the network carries no discriminator')
+        if adda and discriminator_optim is None:
+            raise ValueError('--adda trains the discriminator with its own optimizer (train2d.py:1070-1073)')
+        self.net, self.opt, self.task, self.mode, self.adda, self.dis_opt = net, optimizer, task, adversarial_mode, bool(adda), discriminator_optim
+        self.sup_w, self.dom_w, self.recon_w, self.dice_w, self.exclusive = float(supervised_w), float(domain_w), float(recon_w), float(dice_w), bool(exclusive)
+        for o in (optimizer, discriminator_optim):
+            if o is not None and hasattr(o, 'release_flat_grads') and getattr(o, '_tabs', None) is None:
+                o.release_flat_grads()
+        dev = next(net.parameters()).device
+        self.pos_weight, self.class_w = loss_weights(task, dev)
+        self.stats = self.parts = None
+
+    def __call__(self, image, raw_mask, target_unsup_image, source_image):
+        F = torch.nn.functional
+        sup_b = 0 if image is None else len(image)
+        if self.mode:
+            batch = torch.cat([image, target_unsup_image], dim=0) if (self.sup_w > 0 and image is not None) else target_unsup_image
+            if not (self.sup_w > 0 and image is not None):
+                sup_b = 0
+        else:
+            batch = image
+        out = self.net(batch)
+        zero = torch.zeros((), device=batch.device)
+        sup_loss, out_size = zero, tuple(out.shape[2:])
+        if self.sup_w > 0 and sup_b > 0:
+            mask = map_mask(self.task, raw_mask, self.exclusive)
+            out_size = tuple(mask.shape[2:])
+            if tuple(out.shape[2:]) != out_size:
+                out = SF.interp_linear(out, out_size)                                  # :1219
+            sup_loss, self.stats = SF.seg_loss(out[:sup_b].contiguous(), mask, self.pos_weight, self.class_w, self.dice_w)
+        recon_loss = zero
+        if self.recon_w > 0:                                                           # before the source pass overwrites the feature map (:1251-1257)
+            recon_loss = F.mse_loss(batch, self.net.recon(self.net.feature_maps[-1]))
+        domain_loss = zero
+        if self.mode:
+            domain_loss, _ = domain_adversarial_loss(self.net, self.mode, batch, source_image, torch.sigmoid(out) if self.mode == 'mask' else None,
+                                                     out_size, self.adda, self.dis_opt)
+        loss = self.sup_w * sup_loss + self.dom_w * domain_loss + self.recon_w * recon_loss       # :1314-1318
+        self.parts = dict(supervised=sup_loss.detach(), domain=domain_loss.detach(), recon=recon_loss.detach())
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return loss
+
+
 class GraphedTrainStep:
     """One train step captured into a hipGraph and replayed (single process): ~2300 launches (cfg2) / ~1500 (cfg1) become one graph launch,
     which removes the host from the step -- what the small per-GPU batches need (cfg1 at batch 2 is launch-bound when run eagerly).

@@ -21,7 +21,7 @@ import torch
 
 from . import engine, dist as sdist, functional as SF
 
-UNSUPPORTED = {'polyformer_mode': None, 'adversarial_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
+UNSUPPORTED = {'polyformer_mode': None, 'use_global_bias': False, 'ablate_multihead': False,
                'use_attn_consist_loss': False}
 
 
@@ -66,6 +66,15 @@ def common_flags(p, dim):
     p.add_argument('--outdrop', dest='out_fpn_do_dropout', action='store_true')
     p.add_argument('--inbn', dest='in_fpn_use_bn', action='store_true')
     p.add_argument('--nofeatup', dest='bb_feat_upsize', action='store_false')
+    if dim == 2:          # the few-shot / adversarial recipe (train2d.py:87-107); file datasets are out of scope: the source / target batches are synthetic
+        p.add_argument('--adv', dest='adversarial_mode', type=str, default=None, choices=[None, 'none', 'feat', 'mask'])
+        p.add_argument('--featdisinchan', dest='num_feat_dis_in_chan', type=int, default=64)
+        p.add_argument('--sourcebs', dest='source_batch_size', type=int, default=-1)
+        p.add_argument('--targetbs', dest='target_unsup_batch_size', type=int, default=-1)
+        p.add_argument('--domweight', dest='DOMAIN_LOSS_W', type=float, default=0.002)
+        p.add_argument('--supweight', dest='SUPERVISED_W', type=float, default=1)
+        p.add_argument('--reconweight', dest='RECON_W', type=float, default=0)
+        p.add_argument('--adda', dest='adda', action='store_true')
     p.add_argument('--tunebn', dest='tune_bn_only', action='store_true', help='only refresh the BatchNorm statistics of the first backbone stages')
     p.add_argument('--logiter', type=int, default=50, help='host-side logging period (each log line synchronises the device)')
     p.add_argument('--synthweights', dest='synth_weights', action='store_true',
@@ -80,6 +89,8 @@ def finalize_args(args, dim):
     for k, v in UNSUPPORTED.items():
         if getattr(args, k, v) != v:
             raise SystemExit('--%s selects a reference feature outside the MI355X hot path (SURVEY.md 8(f))' % k)
+    if getattr(args, 'adversarial_mode', None) == 'none':                  # train2d.py:263-264
+        args.adversarial_mode = None
     if args.opt not in (None, 'adamw'):
         raise SystemExit("segtran default optimiser is BertAdam ('adamw' in the reference's table); other --opt values are not built")
     d = engine.DEFAULTS
@@ -240,6 +251,11 @@ def run(args, cfg, batches=None):
     # The optimizer exists BEFORE the checkpoint is read, as in the reference (train2d.py:1066-1077, train3d.py:652-660): a checkpoint that carries
     # 'optim_state' restores the moments and the schedule position.  (The reference's own save_model comments 'optim_state' out -- train2d.py:644,
     # train3d.py:412 -- so its checkpoints restart the moments; a 3-D resume then continues the iteration count, a 2-D one restarts it.)
+    adv = getattr(args, 'adversarial_mode', None) if dim_of(cfg) == 2 else None
+    if adv or getattr(args, 'RECON_W', 0) > 0:                            # train2d.py:876-882, 923-926, 1044-1045: discriminator / reconstruction head ride on the network
+        if world > 1:
+            raise SystemExit('--adv / --reconweight: the adversarial recipe is mirrored for one process (its two optimizers are not bucketed)')
+        engine.attach_adversarial(net, adv, cfg['num_classes'], args.num_feat_dis_in_chan, getattr(args, 'adda', False), args.RECON_W, dev)
     # --tunebn never takes an optimizer step: no flat moment / gradient buffers (3x the parameter memory) and no gradient hooks for it.
     tune_only = bool(getattr(args, 'tune_bn_only', False))
     opt = None if tune_only else engine.init_optimizer(net, args.task_name, t_total=args.maxiter, warmup_steps=args.lr_warmup_steps, lr=args.lr,
@@ -265,15 +281,31 @@ def run(args, cfg, batches=None):
         from .dataloaders.datasets3d import RandomResizedCrop
         crop_percents, out_size = (-args.randscale, args.randscale), tuple(cfg['size'])
         augment = lambda x, m: RandomResizedCrop(x, m, out_size, crop_percents)     # noqa: E731
-    step = engine.TrainStep(net, opt, args.task_name, reducer, dice_w=args.MAX_DICE_W,
-                            exclusive=getattr(args, 'use_exclusive_masks', False), augment=augment)
-    if batches is None:
-        fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
-        batches = iter(lambda: fixed, None)
+    if adv or getattr(args, 'RECON_W', 0) > 0:
+        from .optimization import BertAdam
+        dis_opt = None
+        if adv and args.adda:                                             # train2d.py:1070-1073
+            dis_opt = BertAdam(net.discriminator.parameters(), lr=args.lr, warmup=min(args.lr_warmup_steps, args.maxiter // 2) / args.maxiter,
+                               t_total=args.maxiter, weight_decay=args.decay)
+        step = engine.AdversarialTrainStep(net, opt, args.task_name, adv, adda=getattr(args, 'adda', False), discriminator_optim=dis_opt,
+                                           supervised_w=args.SUPERVISED_W, domain_w=args.DOMAIN_LOSS_W, recon_w=args.RECON_W, dice_w=args.MAX_DICE_W,
+                                           exclusive=getattr(args, 'use_exclusive_masks', False))
+        if batches is None:
+            sb = args.source_batch_size if args.source_batch_size > 0 else args.batch_size
+            tb = args.target_unsup_batch_size if args.target_unsup_batch_size > 0 else args.batch_size
+            fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank) + \
+                (engine.synth_batch(cfg, tb, dev, seed=args.seed + 101)[0], engine.synth_batch(cfg, sb, dev, seed=args.seed + 202)[0])
+            batches = iter(lambda: fixed, None)                           # (image, mask, unsupervised target images, source images), train2d.py:1147-1170
+    else:
+        step = engine.TrainStep(net, opt, args.task_name, reducer, dice_w=args.MAX_DICE_W,
+                                exclusive=getattr(args, 'use_exclusive_masks', False), augment=augment)
+        if batches is None:
+            fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
+            batches = iter(lambda: fixed, None)
     t0 = time.time()
-    for x, raw in batches:
+    for batch in batches:
         iter_num += 1
-        step(x.to(dev, non_blocking=True), raw.to(dev, non_blocking=True))
+        step(*(t.to(dev, non_blocking=True) for t in batch))
         if iter_num % args.logiter == 0 or iter_num == args.maxiter:
             stats = sdist.reduce_scalars(step.stats.detach())            # ONE collective for all logged scalars (C3)
             if is_master:

@@ -364,6 +364,95 @@ def case_discriminator():
     save('discriminator', **arrs)
 
 
+class _ToyNet(torch.nn.Module):
+    """stand-in for the segmentation network in the adversarial-loop fixture: 3 -> Cf feature map (kept in feature_maps[-1], as the networks of the
+    recipe do) -> class scores; plain torch, so the reference's loop statements and the product's mirror can both drive it"""
+
+    def __init__(self, Cf=8, nc=3):
+        super().__init__()
+        self.body = torch.nn.Conv2d(3, Cf, 3, padding=1)
+        self.head = torch.nn.Conv2d(Cf, nc, 1)
+        self.feature_maps, self.discriminator, self.recon = [], None, None
+
+    def forward(self, x):
+        f = torch.tanh(self.body(x))
+        self.feature_maps = [f]
+        return self.head(f)
+
+
+def _ref_loop_block(start_marker, end_marker):
+    """the statements of the reference's training loop between two marker lines (train2d.py is a script: its loop cannot be imported), dedented;
+    compiled and executed at generation time only -- nothing of it is stored"""
+    import textwrap
+    src = open('/root/reference/code/train2d.py').read()
+    a = src.index(start_marker)
+    b = src.index(end_marker, a) + len(end_marker)
+    return textwrap.dedent(src[src.rfind('\n', 0, a) + 1:b])
+
+
+# The ADDA branch steps the discriminator IN PLACE between two backward passes over one graph: autograd saved parameter STORAGE, so the second pass
+# mixes the old activations with the new weights.  The mirror (whose fused BatchNorm + LeakyReLU backward recomputes the activation slope from the
+# live affine parameters) reproduces that artifact only to first order in the learning rate -- and BatchNorm's backward projection amplifies it.  So
+# the branch is pinned in two runs: learning rate 1e-3 -> the discriminator's weights after its own step, the (pre-step) domain loss and the total;
+# learning rate 0 -> every gradient of the second pass (control flow: zero_grad, backward with the graph retained, step, inverted labels).
+ADDA_LRS = {'adda': 1e-3, 'adda0': 0.0}
+
+
+def case_adversarial():
+    """the few-shot / adversarial step of train2d.py.  The reference's OWN statements -- :1259-1286 (target and source
+    feature maps, mixed batch, domain labels, discriminator, BCE, the ADDA discriminator step and label inversion) and :1314-1318 (the weighted
+    total) -- are executed on a toy network + the reference Discriminator / BertAdam for --adv feat|mask x --adda on|off; stored: inputs, the toy
+    network's weights, the domain loss, the total loss, every gradient after `loss.backward()` and the ADDA-updated discriminator weights."""
+    import argparse
+    R._install_stubs()
+    from networks.discriminator import Discriminator
+    BertAdam = R.ref_bertadam()
+    dom_block = _ref_loop_block('            if args.adversarial_mode:\n                target_feat', '                domain_loss = 0\n')
+    tot_block = _ref_loop_block('            supervised_loss = (1 - DICE_W) * total_ce_loss', '            loss = args.SUPERVISED_W * supervised_loss + unsup_loss\n')
+    g = torch.Generator().manual_seed(97)
+    image = torch.randn(2, 3, 32, 32, generator=g)                      # (supervised +) unsupervised target rows
+    source = torch.randn(3, 3, 32, 32, generator=g)
+    arrs = dict(image=image, source=source)
+    torch.manual_seed(5)
+    toy0 = _ToyNet()
+    for k, v in toy0.state_dict().items():
+        arrs['toy:' + k] = v.clone()
+    for mode in ('feat', 'mask'):
+        for variant in ('revgrad', 'adda', 'adda0'):
+            adda = variant != 'revgrad'
+            tag = '%s_%s' % (mode, variant)
+            net = _ToyNet(); net.load_state_dict(toy0.state_dict())
+            dis = Discriminator(8 if mode == 'feat' else 3, num_classes=1, do_revgrad=not adda, num_base_chan=8)
+            dis.load_state_dict(synth_state_dict({k: tuple(v.shape) for k, v in dis.state_dict().items()}))
+            dis.train()
+            net.discriminator = dis
+            args = argparse.Namespace(adversarial_mode=mode, adda=adda, device='cpu', VCDR_W=0.0, ATTNCONSIST_W=0.0, DOMAIN_LOSS_W=0.002, RECON_W=0.0,
+                                      SUPERVISED_W=1.0)
+            mask_batch = torch.zeros(2, 3, 64, 64)                     # only its size is used here (:1271)
+            outputs = torch.nn.functional.interpolate(net(image), size=mask_batch.shape[2:], mode='bilinear', align_corners=False)
+            ns = dict(args=args, net=net, image_batch=image, source_image_batch=source, mask_batch=mask_batch, outputs_soft=torch.sigmoid(outputs),
+                      unweighted_bce_loss_func=torch.nn.BCEWithLogitsLoss(), torch=torch, F=torch.nn.functional,
+                      discriminator_optim=BertAdam(dis.parameters(), lr=ADDA_LRS[variant], warmup=-1, t_total=-1, weight_decay=0.0) if adda else None)
+            exec(compile(dom_block, 'train2d.py:1259-1286', 'exec'), ns)
+            ns.update(DICE_W=0.5, total_ce_loss=outputs.square().mean(), total_dice_loss=outputs.abs().mean(), vcdr_loss=0, attn_consist_loss=0, recon_loss=0)
+            exec(compile(tot_block, 'train2d.py:1314-1318', 'exec'), ns)
+            net.zero_grad()
+            if not adda:
+                dis.zero_grad()
+            ns['loss'].backward()
+            arrs[tag + ':domain_loss'] = ns['domain_loss'].detach(); arrs[tag + ':loss'] = ns['loss'].detach()
+            if variant != 'adda':
+                for k, p_ in net.named_parameters():
+                    if not k.startswith('discriminator.'):
+                        arrs[tag + ':toygrad:' + k] = p_.grad.clone()
+                for k, p_ in dis.named_parameters():
+                    arrs[tag + ':disgrad:' + k] = p_.grad.clone()
+            else:
+                for k, p_ in dis.named_parameters():
+                    arrs[tag + ':disparam:' + k] = p_.detach().clone()   # after the discriminator's optimizer step
+    save('adversarial', **arrs)
+
+
 def case_posbias():
     ss = R.ref_shared()
     g = torch.Generator().manual_seed(13)
@@ -971,7 +1060,7 @@ def case_keys():
     print('  wrote state_dict_keys.json')
 
 
-CASES = dict(squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, unet_deconv=case_unet_deconv, discriminator=case_discriminator, effnet=case_effnet, i3d=case_i3d,
+CASES = dict(adversarial=case_adversarial, squeeze=case_squeeze, fusion=case_fusion, fusion_nosqueeze=case_fusion_nosqueeze, fusion_mince=case_fusion_mince, posbias=case_posbias, eval=case_eval, polyformer=case_polyformer, unet=case_unet, unet_deconv=case_unet_deconv, discriminator=case_discriminator, effnet=case_effnet, i3d=case_i3d,
              seg2d=case_seg2d, seg2d_polyp=case_seg2d_polyp, seg2d_mince=case_seg2d_mince, seg2d_inbn=case_seg2d_inbn, seg3d=case_seg3d, loss=case_loss, bertadam=case_bertadam, keys=case_keys,
              fullshape=case_fullshape, augment=case_augment, augment3d=case_augment3d, init=case_init)
 

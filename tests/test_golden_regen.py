@@ -10,7 +10,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, 'golden')
-SMALL = ['init', 'loss', 'bertadam', 'posbias', 'squeeze', 'fusion', 'augment3d']       # seconds each on 8 threads
+SMALL = ['init', 'loss', 'bertadam', 'posbias', 'squeeze', 'fusion', 'augment3d', 'adversarial']       # seconds each on 8 threads
 
 pytestmark = pytest.mark.skipif(not os.path.isdir('/root/reference/code'), reason='the reference is only present in the build container')
 
