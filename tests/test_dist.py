@@ -48,7 +48,8 @@ def _case_sync_bn(rank, world, ret):
     bn.load_state_dict(ref_bn.state_dict())
     xr = x_full.clone().requires_grad_(True)
     yr = ref_bn(xr); yr = yr * torch.sigmoid(yr); yr.backward(G_full)
-    sl = slice(2 * rank, 2 * rank + 2)
+    per = 4 // world
+    sl = slice(per * rank, per * rank + per)
     x = x_full[sl].clone().requires_grad_(True)
     y = SF.bn_act(x, bn, SF.ACT_SWISH)
     y.backward(G_full[sl])
@@ -136,7 +137,7 @@ def _case_dp_step(rank, world, ret, gather=True):
         return m
 
     g = torch.Generator().manual_seed(1)
-    X = torch.randn(2, 12, 32, generator=g); T = torch.randn(2, 12, 32, generator=g)
+    X = torch.randn(world, 12, 32, generator=g); T = torch.randn(world, 12, 32, generator=g)
     # single-process reference over the full batch: THREE steps (step 1 arms the overlapped reducer, steps 2-3 run it)
     ref = make()
     oref = BertAdam([dict(params=list(ref.parameters()), weight_decay=1e-4, lr=1e-2)], lr=1e-2, warmup=0.1, t_total=10, global_grad_clip=0.1)
@@ -156,7 +157,7 @@ def _case_dp_step(rank, world, ret, gather=True):
     live = sum(1 for need in red._need if need > 0)
     ok = ok and in_bwd[0] == 0 and in_bwd[1] == live and in_bwd[2] == live and 0 < live <= len(red.buckets)   # every live bucket left during backward
     s = sdist.reduce_scalars(torch.tensor([float(rank), 1.0]))
-    ret[rank] = bool(ok and len(red.buckets) > 1 and torch.allclose(s, torch.tensor([0.5, 1.0])))
+    ret[rank] = bool(ok and len(red.buckets) > 1 and torch.allclose(s, torch.tensor([(world - 1) / 2.0, 1.0])))
 
 
 def _case_ragged_batch(rank, world, ret):
@@ -195,3 +196,10 @@ def test_data_parallel_step_matches_single_process():
 
 def test_data_parallel_step_with_view_gradients():
     assert _run('_case_dp_step_views') == {0: True, 1: True}
+
+
+def test_four_ranks_sync_batchnorm_and_data_parallel_step():
+    """nothing above world size 2 had run.  Four gloo ranks, one sample each: the synchronised BatchNorm merge over four
+    shards (all-gather of [2C] + Chan merge) and the bucketed gradient averaging reproduce the single-process full-batch results."""
+    assert _run('_case_sync_bn', world=4) == {r: True for r in range(4)}
+    assert _run('_case_dp_step', world=4) == {r: True for r in range(4)}
