@@ -246,10 +246,11 @@ int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean
                      int B, int C, int64_t S, float eps, int act, void* stream);
 /* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
  * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C) floats.
- * training != 0 and a channel-resident shape: ONE launch (x and dy read once). */
+ * training != 0 and a channel-resident shape: ONE launch (x and dy read once).  dy_bs: batch stride of dY in floats (0 = dense, C * S): the gradient of
+ * one operand of a channel concatenation (an Inception module's branches, aj_i3d.py:139-141) is read in place from the concatenation's gradient. */
 int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                      float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                     const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream);
+                     const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, void* stream);
 /* r04 -- the squeeze-excite excitation of an MBConv block (efficientnet/model.py:105-113) in 2 + 3 launches.
  * fwd: p = (sum of the nch pooling chunks psum[B*C][nch]) * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2); and, when Wproj [M][C] is
  *      given, the gate folded into per-sample projection weights Wb[b][m][k] = Wproj[m][k] * gate[b][k] (see segx_gate_weights_fwd).

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
                                                          const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
                                                          float* __restrict__ ws, int C, int64_t S, float eps, int act,
                                                          const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S,
-                                                         float dc_p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase) {
+                                                         float dc_p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase, int64_t dy_bs) {
     __shared__ float red[4];
     const int c = blockIdx.x, bb = blockIdx.y, slab = blockIdx.z;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict
     // formed on the fly instead of being written by a pass of its own (plane_scale_bwd).  dc_p > 0: the output was scaled by the sample's
     // drop_connect factor before the skip add (bn_act_fwd2_kernel): the same factor multiplies the incoming gradient
     const float gt = (gate ? gate[(int64_t)bb * C + c] : 1.0f) * drop_connect_scale(dc_p, seed, offset, rbase, bb), dp = dpool ? dpool[(int64_t)bb * C + c] * inv_S : 0.f;
-    const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + ((int64_t)bb * C + c) * S;
+    const float* x = X + ((int64_t)bb * C + c) * S; const float* g = dY + (int64_t)bb * dy_bs + (int64_t)c * S;      // dY: a channel slice of a wider tensor (dy_bs = its batch stride)
     const int nsl = gridDim.z;
     const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
     float a = 0.f, q = 0.f;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
                                                         int C, int64_t S, float eps, int act, float inv_n /* 0 in eval mode */,
                                                         const float* __restrict__ gate, const float* __restrict__ dpool, float inv_S,
                                                         float dc_p, uint64_t seed, uint64_t offset, const uint64_t* __restrict__ rbase,
-                                                        const float* __restrict__ ws, int nparts, float* __restrict__ dw_out, float* __restrict__ db_out) {
+                                                        const float* __restrict__ ws, int nparts, float* __restrict__ dw_out, float* __restrict__ db_out, int64_t dy_bs) {
     const int bc = blockIdx.y, c = bc % C;
     const float rstd = rsqrtf(var[c] + eps), m = mean[c], wc = w[c], bc_ = b[c];
     const float gt = (gate ? gate[bc] : 1.0f) * drop_connect_scale(dc_p, seed, offset, rbase, bc / C), dp = dpool ? dpool[bc] * inv_S : 0.f;       // see bn_act_bwd_stage1
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
         if (blockIdx.x == 0 && bc < C && threadIdx.x == 0) { db_out[c] = sdb; dw_out[c] = sdw; }
     } else { sdb = db[c]; sdw = dw[c]; }
     const float k1 = sdb * inv_n, k2 = sdw * inv_n, sc = wc * rstd;
-    const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
+    const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)(bc / C) * dy_bs + (int64_t)c * S; float* d = dX + (int64_t)bc * S;
     if ((S & 3) == 0) {
         for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
             const float4 xv = *reinterpret_cast<const float4*>(x + s), gv = *reinterpret_cast<const float4*>(g + s);
@@ -432,6 +432,7 @@ struct BnBwdArgs {
     const float* gate; const float* dpool; float inv_S;
     float dc_p; uint64_t seed, offset; const uint64_t* rbase;
     int C; int64_t S; float eps; int act;
+    int64_t dy_bs;                               // batch stride of dY (a channel slice of a wider tensor reads in place); C * S when dense
 };
 template <int TEAM, int KP, int BMAX>
 __global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B)
         for (int k = 0; k < KP; ++k) {
             const int j = tl + TEAM * k;
             const bool ok = bok && j < S4;
-            const int64_t o = (int64_t)pl * S + 4 * (ok ? j : 0);
-            const float4 xv = *reinterpret_cast<const float4*>(g.X + o), gv = *reinterpret_cast<const float4*>(g.dY + o);
+            const int64_t o = (int64_t)pl * S + 4 * (ok ? j : 0), og = (int64_t)(bok ? b : 0) * g.dy_bs + (int64_t)c * S + 4 * (ok ? j : 0);
+            const float4 xv = *reinterpret_cast<const float4*>(g.X + o), gv = *reinterpret_cast<const float4*>(g.dY + og);
             float4 hh, dd;
             hh.x = (xv.x - m) * rstd; hh.y = (xv.y - m) * rstd; hh.z = (xv.z - m) * rstd; hh.w = (xv.w - m) * rstd;
             dd.x = (gv.x * gt + dp) * act_grad(hh.x * wc + bc_, act); dd.y = (gv.y * gt + dp) * act_grad(hh.y * wc + bc_, act);
@@ -1150,7 +1151,7 @@ extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const flo
                                       const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_reduce: bad args");
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset,
-                       rng_base());
+                       rng_base(), (int64_t)C * S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     return check_launch("segx_bn_act_bwd_reduce");
 }
@@ -1160,7 +1161,7 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && sum_dw && sum_db && dX && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd_apply: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd_apply: more than 65535 (sample, channel) planes");
     hipLaunchKernelGGL((bn_act_bwd_apply<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, sum_dw, sum_db, dX, C, S, eps, act, inv_n,
-                       gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr);
+                       gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr, (int64_t)C * S);
     return check_launch("segx_bn_act_bwd_apply");
 }
 extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -1169,12 +1170,12 @@ extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mea
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
     hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0,
-                       (const uint64_t*)nullptr);
+                       (const uint64_t*)nullptr, (int64_t)C * S);
     hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
     hipLaunchKernelGGL((bn_act_bwd_apply<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
                        (const float*)db, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, (const float*)nullptr, 0,
-                       (float*)nullptr, (float*)nullptr);
+                       (float*)nullptr, (float*)nullptr, (int64_t)C * S);
     return check_launch("segx_bn_act_bwd");
 }
 
@@ -1235,14 +1236,16 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
 }
 extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                 float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                                const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
+                                const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd2: bad args");
+    if (dy_bs == 0) dy_bs = (int64_t)C * S;
+    SEGX_REQUIRE(dy_bs >= (int64_t)C * S && ((S & 3) != 0 || (dy_bs & 3) == 0), "segx_bn_act_bwd2: bad dY batch stride %lld", (long long)dy_bs);
     SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
     const int form = training ? bn_res_form(B, S, true) : 0;
     if (form) {
         BnBwdArgs g;
         g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
-        g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act;
+        g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
         const int team = form >> 4, kp = form & 15;
         const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
         if (team == 64) hipLaunchKernelGGL((bn_act_bwd_res_kernel<64, 1, 8>), rgrid, dim3(256), 0, stream, g, B);
@@ -1252,10 +1255,10 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
         return check_launch("segx_bn_act_bwd2/resident");
     }
     const int nsl = bn_slabs(S);
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, nsl), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset, rng_base());
+    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, nsl), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, dc_p, seed, offset, rng_base(), dy_bs);
     const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
     hipLaunchKernelGGL((bn_act_bwd_apply<true>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)nullptr,
-                       (const float*)nullptr, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)ws, B * nsl, dw, db);
+                       (const float*)nullptr, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)ws, B * nsl, dw, db, dy_bs);
     return check_launch("segx_bn_act_bwd2");
 }
 // ---- r04: squeeze-excite in 2 + 3 launches ------------------------------------------------------------------------------------------------------

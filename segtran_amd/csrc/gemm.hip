@@ -185,7 +185,12 @@ static void plan6(int M, int N, int K, int nbatch, bool gelu, bool may_split, in
         if (t < best_t * 0.97) { best_t = t; *tile = c6.id; *splitk = sk; }
     }
 }
-static bool gemm_ws_ok(const segx_gemm_desc* d) {
+static bool gemm_lean_ok(const segx_gemm_desc* d);
+// a residual operand keeps the call on the 4-wave kernels: their epilogue reads it as 16-byte quads next to the 16-byte stores, the wave-specialised
+// kernels' 4-byte epilogue would read it scalar (r04_c: the 160 x 4096 x 960 x 6 dX GEMM 0.47 -> 0.76 ms/step with the residual on the 256 x 128 tile)
+static bool gemm_ws_ok(const segx_gemm_desc* d) { return !d->resid && gemm_lean_ok(d); }
+// whole 32-k stages and 32-bit operand offsets: what the lean loaders (4-wave lean kernels, wave-specialised kernels) need
+static bool gemm_lean_ok(const segx_gemm_desc* d) {
     const bool akc = (d->a_k == 1), bkc = (d->b_k == 1);
     const int64_t a_span = akc ? (int64_t)d->M * d->a_m : (int64_t)d->K * d->a_k, b_span = bkc ? (int64_t)d->N * d->b_n : (int64_t)d->K * d->b_k;
     return d->K % BKT == 0 && a_span < (1LL << 29) && b_span < (1LL << 29);
@@ -285,7 +290,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     int tile = d->tile;
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
     // the wave-specialised kernels address an operand through 32-bit byte offsets from a per-item base and take whole 32-k stages only
-    const bool ws_ok = gemm_ws_ok(d);
+    const bool ws_ok = gemm_ws_ok(d), lean_ok = gemm_lean_ok(d);
     bool x6 = x6_eligible(engine, d->M, d->N, vec) && (!gelu || akc) &&
               (tile == SEGX_TILE_AUTO || tile == SEGX_TILE_128x128 || tile == SEGX_TILE_64x128 || tile == SEGX_TILE_64x64 || ws_tile);
     if (tile == SEGX_TILE_AUTO) {
@@ -310,7 +315,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
 #define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
     do {                                                                                                   \
         g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
-        if (SEGX_LEAN4 && ws_ok) hipLaunchKernelGGL((gemm_x6_lean_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
+        if (SEGX_LEAN4 && lean_ok) hipLaunchKernelGGL((gemm_x6_lean_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_x6_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
 #define SEGX_LAUNCH6_LAYOUT(CFG, W)                                          \

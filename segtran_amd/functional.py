@@ -639,12 +639,25 @@ def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, 
     return y, mean, var, B * S * world, psum, nch
 
 
+def _plane_strided(dy, S):
+    """(tensor, batch stride) under which the BatchNorm backward kernels read dy: dense -> (dy, 0); a channel slice of a wider tensor whose (sample,
+    channel) planes are contiguous -- one operand's share of a channel concatenation's gradient (torch.cat's backward hands out narrow() views) ->
+    (dy, its batch stride), read in place; anything else -> a contiguous copy."""
+    if dy.is_contiguous():
+        return dy, 0
+    if dy.dim() >= 3 and dy.stride(1) == S and dy[0].is_contiguous() and dy.stride(0) % 4 == 0 and dy.storage_offset() % 4 == 0 and S % 4 == 0:
+        return dy, dy.stride(0)
+    return dy.contiguous(), 0
+
+
 def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_S=0.0, dc=(0.0, 0, 0)):
     """dx, dw, db of BatchNorm + activation; gate / dpool: a squeeze-excite gate sits behind it (see segx_bn_act_bwd); dc: the drop_connect scale
     of the forward multiplies dy.  One process: two launches (segx_bn_act_bwd2: the apply pass sums the reduction partials itself)."""
     B, C, S, eps, act, training, n = cfg
     dx = torch.empty_like(x)
+    dy, dy_bs = _plane_strided(dy, S)
     if training and _bn_grad_sync is not None:
+        dy = _c(dy)
         # synchronised BN: local sums written into one [2C] buffer -> ONE all-reduce -> apply with the global sums / global count.
         # The parameter gradients stay the LOCAL sums (the flat-gradient all-reduce averages them like every other gradient).
         both = _empty(x, 2 * C)
@@ -654,7 +667,7 @@ def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_
         L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n, gate, dpool, inv_S, *dc)
     else:
         dw, db = _empty(x, C), _empty(x, C)
-        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S, *dc)
+        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S, *dc, dy_bs=dy_bs)
     return dx, dw, db
 
 
@@ -680,8 +693,7 @@ class _BNAct(torch.autograd.Function):
     def backward(ctx, dy):
         L = segx.lib()
         x, mean, var, w, b = ctx.saved_tensors
-        dy = _c(dy)
-        dx, dw, db = _bn_act_backward(L, dy, x, mean, var, w, b, ctx.cfg, dc=ctx.dc)
+        dx, dw, db = _bn_act_backward(L, dy, x, mean, var, w, b, ctx.cfg, dc=ctx.dc)      # dy may be a channel slice of a concatenation's gradient: read in place
         return dx, dw, db, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
 
 
@@ -1314,9 +1326,10 @@ class _Conv3dSlices(torch.autograd.Function):
     Inception module whose two 1x1x1 reductions run as one convolution + one BatchNorm (aj_i3d.py:112-141)."""
 
     @staticmethod
-    def forward(ctx, t, *ws):
+    def forward(ctx, t, with_tail, *ws):
         L = segx.lib()
         t = _c(t)
+        ctx.with_tail = bool(with_tail)
         B, Ct, D, H, W = t.shape
         vol = D * H * W
         ys, geoms, c0 = [], [], 0
@@ -1331,9 +1344,14 @@ class _Conv3dSlices(torch.autograd.Function):
             L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
             L.conv3d_fwd(t[:, c0:], wp, y, B, Cout, geom, sk, _empty(t, sk * y.numel()) if sk > 1 else None, packed=True, x_bs=Ct * vol)
             ys.append(y); geoms.append(geom); c0 += Cin
-        assert c0 <= Ct, 'the slices exceed the tensor'      # channels beyond the last slice (another consumer's, e.g. Inception branch 0) get a zero gradient here
+        assert c0 <= Ct, 'the slices exceed the tensor'      # channels beyond the last slice (another consumer's, e.g. Inception branch 0)
         ctx.geoms = geoms
         ctx.save_for_backward(t, *ws)
+        ctx.set_materialize_grads(False)
+        if ctx.with_tail:
+            # the channels no convolution reads leave as one more output (a view): their consumer's gradient comes back to THIS node and is written into
+            # the tail of dt -- instead of a zero fill here plus autograd's slice-backward (zeros + copy) and a full-size accumulation add
+            return tuple(ys) + (t[:, c0:],)
         return tuple(ys)
 
     @staticmethod
@@ -1344,13 +1362,17 @@ class _Conv3dSlices(torch.autograd.Function):
         vol = D * H * W
         dt = torch.empty_like(t) if ctx.needs_input_grad[0] else None
         covered = sum(int(w.shape[1]) for w in ws)
+        d_tail = dys[len(ws)] if ctx.with_tail else None
         if dt is not None and covered < Ct:
-            dt[:, covered:].zero_()
+            if d_tail is not None:
+                dt[:, covered:].copy_(d_tail)
+            else:
+                dt[:, covered:].zero_()
         dws, c0 = [], 0
         for i, (w, dy, geom) in enumerate(zip(ws, dys, ctx.geoms)):
             Cout, Cin, KD, KH, KW = w.shape
             KV = KD * KH * KW
-            dy = _c(dy)
+            dy = _c(dy) if dy is not None else torch.zeros(B, Cout, D, H, W, dtype=torch.float32, device=t.device)
             if dt is not None:
                 wt = torch.empty_like(w)
                 g2 = (Cout, D, H, W, D, H, W, KD, KH, KW, 1, 1, 1, KD // 2, KH // 2, KW // 2)
@@ -1358,7 +1380,7 @@ class _Conv3dSlices(torch.autograd.Function):
                 L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
                 L.conv3d_fwd(dy, wt, dt[:, c0:], B, Cin, g2, sk, _empty(t, sk * B * Cin * vol) if sk > 1 else None, packed=True, y_bs=Ct * vol)
             dw = None
-            if ctx.needs_input_grad[1 + i]:
+            if ctx.needs_input_grad[2 + i]:
                 N = Cin * KV
                 sk = L.conv3d_splitk(B, Cout, geom, True)
                 dwb = _empty(t, B, Cout * N)
@@ -1373,12 +1395,14 @@ class _Conv3dSlices(torch.autograd.Function):
                 dw = dw.view_as(w)
             dws.append(dw)
             c0 += Cin
-        return (dt,) + tuple(dws)
+        return (dt, None) + tuple(dws)
 
 
-def conv3d_slices(t, *weights):
-    """(conv3d_same(t[:, :c1], w1), conv3d_same(t[:, c1:c1+c2], w2), ...) for stride-1 odd-window convolutions, reading the slices in place."""
-    return _Conv3dSlices.apply(t, *weights)
+def conv3d_slices(t, *weights, with_tail=False):
+    """(conv3d_same(t[:, :c1], w1), conv3d_same(t[:, c1:c1+c2], w2), ...) for stride-1 odd-window convolutions, reading the slices in place.
+    with_tail: one more output, the channels behind the last slice (a view of t) -- route their consumer through it and its gradient is written
+    into t's gradient by this node (no zero fill, no slice-backward copy, no accumulation add)."""
+    return _Conv3dSlices.apply(t, with_tail, *weights)
 
 
 def conv3d_same(x, w, stride=(1, 1, 1)):

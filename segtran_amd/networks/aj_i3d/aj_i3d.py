@@ -74,11 +74,15 @@ class InceptionModule(nn.Module):
             # r03: branch 0's own 1x1x1 convolution joins them (its filters LAST, so the slices of the 3x3x3 convolutions still start at channel 0):
             # the three pointwise convolutions of the module's input are ONE GEMM, their three BatchNorm layers one statistics / apply pass and one
             # synchronised exchange; branch 0's output is the tail slice of that tensor.
+            # r04: no accumulation kernels of autograd's around the module -- (a) x has two consumers (this convolution, the pooling branch): the second
+            # goes through the alias the GEMM op returns, its gradient is added inside the dX GEMM; (b) branch 0's slice of t leaves through
+            # conv3d_slices (its gradient is written into t's gradient there); (c) the concatenation's gradient is read IN PLACE by the BatchNorm
+            # backward kernels of the four branches (channel slices with a batch stride: no contiguous copies).
             w120 = torch.cat([self.b1a.conv3d.weight, self.b2a.conv3d.weight, self.b0.conv3d.weight], dim=0)
-            t = SF.bn_act_multi(SF.conv1x1(x, w120), [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU)
-            y1, y2 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight)
-            o12 = self.b1a.conv3d.weight.shape[0] + self.b2a.conv3d.weight.shape[0]
-            return torch.cat([t[:, o12:], SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x))], dim=1)
+            t, x2 = SF.conv1x1(x, w120, pass_input=True)
+            t = SF.bn_act_multi(t, [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU)
+            y1, y2, y0 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight, with_tail=True)
+            return torch.cat([y0, SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x2))], dim=1)
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
 
 

@@ -279,8 +279,15 @@ class SegxLib:
     def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act):
         self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act)
 
-    def bn_act_bwd2(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
-        self._call('segx_bn_act_bwd2', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate, dpool, float(inv_S), float(dc_p), seed, offset)
+    def bn_act_bwd2(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0, dy_bs=0):
+        """dy_bs: batch stride of dY in floats when dY is a channel slice of a wider tensor (its (sample, channel) planes contiguous); 0 = dense"""
+        self._chk_t(dY, X, mean, var, w, b, dX, dw, db, ws, gate, dpool)
+        for t in (X, mean, var, w, b, dX, dw, db, ws):
+            assert t.is_contiguous()
+        assert dy_bs or dY.is_contiguous()
+        rc = self.c.segx_bn_act_bwd2(_ptr(dY), _ptr(X), _ptr(mean), _ptr(var), _ptr(w), _ptr(b), _ptr(dX), _ptr(dw), _ptr(db), _ptr(ws), B, C, S, eps, act, training,
+                                     _ptr(gate), _ptr(dpool), float(inv_S), float(dc_p), seed, offset, int(dy_bs), self.stream(X))
+        self.check(rc, 'segx_bn_act_bwd2')
 
     def se_fwd2(self, psum, nch, inv_S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M):
         self._call('segx_se_fwd2', gate, psum, nch, inv_S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M)
@@ -550,7 +557,7 @@ _SIGS = {
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
     'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
-    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuup',
+    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuulp',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',
 }

@@ -316,3 +316,24 @@ def test_composed_output_head_equals_reference_op_order(backend, grid):
     y.backward(G); yr.backward(G)
     for a, b in zip((cur, tok, Wb, bb, Wo, bo), ref_in):
         close(a.grad, b.grad, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(3, 4, 6, 10), (6, 2, 32, 32), (2, 3, 130, 132)])       # channel-resident wave form, workgroup form, two-launch form
+def test_bn_backward_reads_a_concatenation_gradient_in_place(backend, shape):
+    """torch.cat's backward hands every operand a narrow() view of the concatenation's gradient; the BatchNorm backward kernels read such a channel
+    slice in place (batch stride = the wide tensor's) instead of through a contiguous copy -- the four branches of an Inception module."""
+    B, C = shape[:2]
+    bns = [torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01) for _ in range(2)]
+    refs = [torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01) for _ in range(2)]
+    with torch.no_grad():
+        for i, (m, r) in enumerate(zip(bns, refs)):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=60 + i)); m.bias.copy_(0.2 * rnd(C, seed=62 + i)); r.load_state_dict(m.state_dict())
+    xs = [(rnd(*shape, seed=64 + i) * 1.3 + 0.2).requires_grad_(True) for i in range(2)]
+    xr = [x.detach().clone().requires_grad_(True) for x in xs]
+    out = torch.cat([SF.bn_act(x, m, SF.ACT_RELU) for x, m in zip(xs, bns)], dim=1)
+    outr = torch.cat([F.relu(r(x)) for x, r in zip(xr, refs)], dim=1)
+    close(out, outr.detach())
+    G = rnd(B, 2 * C, *shape[2:], seed=66)
+    out.backward(G); outr.backward(G)
+    for x, r, m, rm in zip(xs, xr, bns, refs):
+        close(x.grad, r.grad, 1e-4); close(m.weight.grad, rm.weight.grad, 1e-4); close(m.bias.grad, rm.bias.grad, 1e-4)

@@ -1,0 +1,27 @@
+#!/bin/bash
+# One measurement session of round 4 (run through gpurun from the repo root): tools/gpu_session.sh <tag> [tests|notests]
+# full -m gpu suite, smoke, the driver's bench line, cfg1 eagerly and as one hipGraph, rocprofv3 kernel stats + per-dispatch traces of cfg2 / cfg4 / cfg5.
+set -u
+TAG=${1:-r04_x}; MODE=${2:-tests}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|gfx" > $OUT/box.txt
+if [ "$MODE" = tests ]; then
+  timeout 1500 python -m pytest tests -m gpu -x -q --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
+fi
+SEGX_BENCH_VERBOSE=2 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default_shapes.txt; cut -c1-300 $OUT/bench_default.json
+for G in "" "--graph"; do
+  timeout 300 python bench.py --config cfg1 $G --no-brats --no-cpu-baseline --single-order > $OUT/bench_cfg1${G}.json 2> $OUT/bench_cfg1${G}.err; cut -c1-200 $OUT/bench_cfg1${G}.json
+done
+cd /tmp && export TMPDIR=/tmp
+for CFG in cfg2 cfg4 cfg5; do
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$CFG -o $CFG -- python $ROOT/bench.py --config $CFG --steps 2 --warmup 2 --no-brats --no-cpu-baseline --single-order > $OUT/prof_$CFG.log 2>&1
+  find $OUT/prof_$CFG -name '*kernel_stats.csv' -exec cp {} $OUT/${CFG}_kernel_stats.csv \;
+  find $OUT/prof_$CFG -name '*kernel_trace.csv' -exec cp {} $OUT/${CFG}_kernel_trace.csv \;
+  find $OUT/prof_$CFG -name '*agent_info.csv' -exec cp {} $OUT/agent_info.csv \;
+  rm -rf $OUT/prof_$CFG
+done
+ls -la $OUT
