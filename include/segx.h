@@ -271,6 +271,10 @@ int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, in
 /* partial weight gradients part[B * rows][C][k*k], rows = segx_dwconv2d_wgrad_rows(OH, OW) row strips per sample;
  * dW = segx_colsum over the B*rows rows (deterministic two-stage sum, no atomics) */
 int64_t segx_dwconv2d_wgrad_rows(int OH, int OW);
+/* r04: the weight gradient dW [C][k*k] in ONE launch where a channel's B planes are one workgroup's work (B <= 8, <= 8192 outputs per plane, the float4
+ * layout): returns 1 when done, 0 when the shape needs the two-stage form above (nothing launched), < 0 on error */
+int segx_dwconv2d_bwd_weight_direct(const float* dY, const float* X, float* dW, int B, int C, int H, int Wd, int OH, int OW, int k,
+                                    int stride, int pad_t, int pad_l, void* stream);
 int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B, int C, int H, int Wd, int OH, int OW, int k,
                              int stride, int pad_t, int pad_l, void* stream);
 /* squeeze-excite plane ops (efficientnet/model.py:105-110) on [planes = B*C, S]:
@@ -333,6 +337,11 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
+/* r04: the trilinear up-sampling (+ lateral add) of the 3-D feature pyramid (segtran3d.py:304,319,351,364,384) and its adjoint as ONE pass each
+ * (source tile staged in LDS): same numbers as the separable passes (same blend order).  Returns 1 when launched, 0 when the shape needs the separable
+ * passes (nothing launched: an axis shrinks or grows by more than 2, a 2-D map, W % 4 != 0, more than 65535 planes), < 0 on error. */
+int segx_interp3d_fwd_fused(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
+int segx_interp3d_bwd_fused(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);
 /* forward along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chained x -> y -> z it is

@@ -631,21 +631,13 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_rows4_k
 // weight gradient, float4 variant: ONE WAVE per (plane, strip); it walks every strips-th tile of the plane ((64 >> tpr_log2)
 // row groups x 4 rows x (4 << tpr_log2) columns), then reduces its K*K sums with wave shuffles -- no LDS, no barrier.
 constexpr int DWG_TY = 4;
+// one wave's walk over every strips-th tile of a plane: acc[ky][kx] += sum over the wave's outputs of dy * x(window)
 template <int K, int ST, int PL>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_wgrad4_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
-                                                            int C, int H, int W, int OH, int OW, int pt, int tiles_x, int ntiles, int tpr_log2,
-                                                            int strips, int64_t nwork) {
+__device__ __forceinline__ void dw4_wgrad_walk(float (&acc)[K * K], const float* __restrict__ x, const float* __restrict__ g, int H, int W, int OH, int OW, int pt,
+                                               int tiles_x, int ntiles, int tpr_log2, int strip, int strips, int lane) {
     constexpr int NV = Dw4<K, ST>::NV;
     static_assert(PL <= 4 && 4 + 3 * ST + K - 1 - PL < 4 * NV, "window does not fit the loaded float4s");
-    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (wid >= nwork) return;                                   // whole waves leave together
-    const int64_t plane = wid / strips;
-    const int strip = (int)(wid - plane * strips), b = (int)(plane / C), c = (int)(plane - (int64_t)b * C);
-    const int lane = threadIdx.x & 63, lr = lane & ((1 << tpr_log2) - 1), rg = lane >> tpr_log2, nrg = 64 >> tpr_log2;
-    const float* x = X + plane * H * W; const float* g = dY + plane * OH * OW;
-    float acc[K * K];
-#pragma unroll
-    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    const int lr = lane & ((1 << tpr_log2) - 1), rg = lane >> tpr_log2, nrg = 64 >> tpr_log2;
     for (int tile = strip; tile < ntiles; tile += strips) {
         const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
         const int ox = ((txi << tpr_log2) + lr) * 4, oy0 = (tyi * nrg + rg) * DWG_TY;
@@ -687,11 +679,52 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_wgrad4_
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+}
+template <int K, int ST, int PL>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_wgrad4_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ part,
+                                                            int C, int H, int W, int OH, int OW, int pt, int tiles_x, int ntiles, int tpr_log2,
+                                                            int strips, int64_t nwork) {
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    if (wid >= nwork) return;                                   // whole waves leave together
+    const int64_t plane = wid / strips;
+    const int strip = (int)(wid - plane * strips), b = (int)(plane / C), c = (int)(plane - (int64_t)b * C);
+    const int lane = threadIdx.x & 63;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    dw4_wgrad_walk<K, ST, PL>(acc, X + plane * H * W, dY + plane * OH * OW, H, W, OH, OW, pt, tiles_x, ntiles, tpr_log2, strip, strips, lane);
     float* o = part + (((int64_t)b * strips + strip) * C + c) * (K * K);
 #pragma unroll
     for (int i = 0; i < K * K; ++i) {
         const float sw = wave_sum(acc[i]);
         if (lane == 0) o[i] = sw;
+    }
+}
+// r04: planes that one wave walks alone (strips == 1: <= 8192 outputs, 22 of EfficientNet-B4's 32 depthwise layers at 512 x 512) and B <= 8: ONE workgroup of
+// eight waves per CHANNEL, wave b on sample b; the B partial filters are added in sample order through LDS and the workgroup writes dw[c] itself --
+// no [B][C][K*K] partial tensor, no column-sum launches behind it (two per layer).
+template <int K, int ST, int PL>
+__global__ __launch_bounds__(512) void dwconv_wgrad4c_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ dW,
+                                                             int B, int C, int H, int W, int OH, int OW, int pt, int tiles_x, int ntiles, int tpr_log2) {
+    __shared__ float red[8][K * K];
+    const int c = blockIdx.x, b = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    if (b < B) {
+        const int64_t plane = (int64_t)b * C + c;
+        dw4_wgrad_walk<K, ST, PL>(acc, X + plane * H * W, dY + plane * OH * OW, H, W, OH, OW, pt, tiles_x, ntiles, tpr_log2, 0, 1, lane);
+    }
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        const float sw = wave_sum(acc[i]);
+        if (lane == 0) red[b][i] = sw;
+    }
+    __syncthreads();
+    if (threadIdx.x < K * K) {
+        float t = 0.f;
+        for (int q = 0; q < B; ++q) t += red[q][threadIdx.x];
+        dW[(int64_t)c * (K * K) + threadIdx.x] = t;
     }
 }
 
@@ -1403,6 +1436,25 @@ extern "C" int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX
     dim3 grid(tx * ty, B * C);
     SEGX_DW_DISPATCH(dwconv_bwd_data_kernel, dY, W, dX, C, H, Wd, OH, OW, pad_t, pad_l, tx);
     return check_launch("segx_dwconv2d_bwd_data");
+}
+/* weight gradient WITHOUT the partial tensor where one workgroup per channel can do it (returns 1 and writes dW [C][k*k]); returns 0 when the shape
+ * needs the two-stage form (segx_dwconv2d_bwd_weight + segx_colsum), < 0 on error */
+extern "C" int segx_dwconv2d_bwd_weight_direct(const float* dY, const float* X, float* dW, int B, int C, int H, int Wd, int OH, int OW,
+                                               int k, int stride, int pad_t, int pad_l, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && dW && B > 0 && C > 0 && OH > 0 && OW > 0, "segx_dwconv2d_bwd_weight_direct: bad args");
+    if (B > 8 || dw_wgrad_strips(OH, OW) != 1 || !dw4_ok(dY, X, Wd, OW)) return 0;
+    const Dw4Grid g = dw4_grid(OW);
+    const int rows = (64 >> g.tpr_log2) * segx::DWG_TY, ntiles = g.tiles_x * ((OH + rows - 1) / rows);
+#define SEGX_DW4C(KK, SS, PP)                                                                                                       \
+    if (k == KK && stride == SS && pad_l == PP) {                                                                                    \
+        hipLaunchKernelGGL((segx::dwconv_wgrad4c_kernel<KK, SS, PP>), dim3(C), dim3(512), 0, stream, dY, X, dW, B, C, H, Wd, OH, OW,  \
+                           pad_t, g.tiles_x, ntiles, g.tpr_log2);                                                                     \
+        const int rc = check_launch("segx_dwconv2d_bwd_weight_direct");                                                               \
+        return rc ? (rc > 0 ? -rc - 1000 : rc) : 1;                                                                                  \
+    }
+    SEGX_DW4C(3, 1, 1) SEGX_DW4C(5, 1, 2) SEGX_DW4C(3, 2, 0) SEGX_DW4C(3, 2, 1) SEGX_DW4C(5, 2, 1) SEGX_DW4C(5, 2, 2)
+#undef SEGX_DW4C
+    return 0;
 }
 /* rows of `part` per sample (see segx_dwconv2d_bwd_weight) */
 extern "C" int64_t segx_dwconv2d_wgrad_rows(int OH, int OW) { return OH > 0 && OW > 0 ? dw_wgrad_strips(OH, OW) : 0; }

@@ -779,11 +779,12 @@ class _DWConv(torch.autograd.Function):
             dx = torch.empty_like(x)
             L.dwconv2d_bwd_data(dy, w, dx, B, C, H, W, OH, OW, k, stride, pt, pl)
         if ctx.needs_input_grad[1]:
-            rows = B * L.dwconv2d_wgrad_rows(OH, OW)
-            part = _empty(x, rows, C * k * k)
-            L.dwconv2d_bwd_weight(dy, x, part, B, C, H, W, OH, OW, k, stride, pt, pl)
             dw = _empty(x, C * k * k)
-            L.colsum(part, dw, _empty(x, L.colreduce_ws(rows, C * k * k, 1)), rows, C * k * k)
+            if not L.dwconv2d_bwd_weight_direct(dy, x, dw, B, C, H, W, OH, OW, k, stride, pt, pl):      # one launch where a channel is one workgroup's work
+                rows = B * L.dwconv2d_wgrad_rows(OH, OW)
+                part = _empty(x, rows, C * k * k)
+                L.dwconv2d_bwd_weight(dy, x, part, B, C, H, W, OH, OW, k, stride, pt, pl)
+                L.colsum(part, dw, _empty(x, L.colreduce_ws(rows, C * k * k, 1)), rows, C * k * k)
             dw = dw.view_as(w)
         return dx, dw, None, None
 
@@ -1107,7 +1108,14 @@ class _InterpAdd(torch.autograd.Function):
         base = _c(base) if base is not None else None
         axes = [(ax, n_in, n_out) for ax, (n_in, n_out) in enumerate(((d, D), (h, H), (w, W))) if n_in != n_out]
         ctx.align = bool(align_corners)
-        if (D > 1 or align_corners) and axes:
+        out = None
+        if D > 1 and axes and not align_corners:               # r04: one pass (source tile in LDS) where every axis up-samples by at most 2
+            out = _empty(x, B, C, *size)
+            if not L.interp3d_fwd_fused(x, base, out, B * C, d, h, w, D, H, W):
+                out = None
+        if out is not None:
+            pass
+        elif (D > 1 or align_corners) and axes:
             # 3-D: one streaming pass per resized axis, innermost (smallest tensor) first, the lateral added in the last pass --
             # the same blends in the same order as the fused formula (bit-identical), at HBM rate instead of 1-2 TB/s
             cur, dims = x, [d, h, w]
@@ -1137,7 +1145,11 @@ class _InterpAdd(torch.autograd.Function):
         planes, d, h, w, D, H, W, xshape = ctx.cfg
         dy = _c(dy)
         dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and D > 1 and not ctx.align and (d, h, w) != (D, H, W):
+            dx = _empty(dy, *xshape)
+            if not L.interp3d_bwd_fused(dy, dx, planes, d, h, w, D, H, W):
+                dx = None
+        if ctx.needs_input_grad[0] and dx is None:
             # separable adjoint, one pass per resized axis, OUTERMOST axis first: the passes over the big tensors then have a long
             # contiguous inner extent (float4 kernel); the scalar innermost-axis pass runs last, on the smallest tensor
             cur, dims = dy, [D, H, W]

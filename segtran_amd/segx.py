@@ -304,6 +304,14 @@ class SegxLib:
     def dwconv2d_bwd_data(self, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl):
         self._call('segx_dwconv2d_bwd_data', dY, dY, W, dX, B, C, H, Wd, OH, OW, k, stride, pt, pl)
 
+    def dwconv2d_bwd_weight_direct(self, dY, X, dW, B, C, H, Wd, OH, OW, k, stride, pt, pl):
+        """-> True when dW was computed in one launch (segx_dwconv2d_bwd_weight_direct), False when the shape needs the two-stage form"""
+        self._chk_t(dY, X, dW)
+        rc = self.c.segx_dwconv2d_bwd_weight_direct(_ptr(dY), _ptr(X), _ptr(dW), B, C, H, Wd, OH, OW, k, stride, pt, pl, self.stream(X))
+        if rc < 0:
+            self.check(rc, 'segx_dwconv2d_bwd_weight_direct')
+        return rc == 1
+
     def dwconv2d_wgrad_rows(self, OH, OW):
         return int(self.c.segx_dwconv2d_wgrad_rows(OH, OW))
 
@@ -350,6 +358,21 @@ class SegxLib:
         self._call('segx_plane_scale_bwd', dY, dY, gate, dpool, dX, planes, S)
 
     # ---- feature-pyramid kernels (fpn.hip) ----------------------------------------------------------
+    def interp3d_fwd_fused(self, x, base, out, planes, d, h, w, D, H, W):
+        """-> True when the one-pass trilinear kernel ran (segx_interp3d_fwd_fused), False when the shape needs the separable passes"""
+        self._chk_t(x, base, out)
+        rc = self.c.segx_interp3d_fwd_fused(_ptr(x), _ptr(base), _ptr(out), planes, d, h, w, D, H, W, self.stream(x))
+        if rc < 0:
+            self.check(rc, 'segx_interp3d_fwd_fused')
+        return rc == 1
+
+    def interp3d_bwd_fused(self, dout, din, planes, d, h, w, D, H, W):
+        self._chk_t(dout, din)
+        rc = self.c.segx_interp3d_bwd_fused(_ptr(dout), _ptr(din), planes, d, h, w, D, H, W, self.stream(dout))
+        if rc < 0:
+            self.check(rc, 'segx_interp3d_bwd_fused')
+        return rc == 1
+
     def gn_ws(self, B, C, G):
         return int(self.c.segx_gn_ws_floats(B, C, G))
 
@@ -544,7 +567,7 @@ _SIGS = {
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
-    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
+    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp3d_fwd_fused': 'pppliiiiiip', 'segx_interp3d_bwd_fused': 'ppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
@@ -554,7 +577,7 @@ _SIGS = {
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
     'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
     'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
-    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
+    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
     'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
     'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
     'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuulp',
