@@ -337,11 +337,13 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
 int segx_tune(int knob, int value);
-/* r04: the trilinear up-sampling (+ lateral add) of the 3-D feature pyramid (segtran3d.py:304,319,351,364,384) and its adjoint as ONE pass each
- * (source tile staged in LDS): same numbers as the separable passes (same blend order).  Returns 1 when launched, 0 when the shape needs the separable
- * passes (nothing launched: an axis shrinks or grows by more than 2, a 2-D map, W % 4 != 0, more than 65535 planes), < 0 on error. */
-int segx_interp3d_fwd_fused(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
-int segx_interp3d_bwd_fused(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream);
+/* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
+ * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)
+ * after the x pass, with the lateral added in the same pass; and the adjoint (z and y before the x pass).  Same blends in the same order as the
+ * one-axis passes chained -> the same numbers, 21 instead of 29 coarse-tensor sizes of traffic forward, 13 instead of 21 backward. */
+int segx_interp_linear_fwd_axis2(const float* in, const float* base, float* out, int64_t outer, int n1_in, int n1_out, int n2_in, int n2_out,
+                                 int64_t inner, void* stream);
+int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64_t outer, int n1_out, int n1_in, int n2_out, int n2_in, int64_t inner, void* stream);
 int segx_interp_linear_fwd(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W,
                            void* stream);
 /* forward along ONE axis of a tensor viewed as [outer, n_in, inner] -> [outer, n_out, inner] (+ base).  Chained x -> y -> z it is

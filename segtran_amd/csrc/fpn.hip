@@ -255,115 +255,69 @@ __global__ __launch_bounds__(256) void interp_fwd_axis_kernel(const float* __res
 }
 
 // =================================================================================================
-// r04: trilinear up-sampling (+ lateral) of the 3-D FPN as ONE pass each way.  The separable form above moves 29 coarse-tensor sizes per 2 x 2 x 2
-// up-sampling forward (x: 1 + 2, y: 2 + 4, z: 4 + 8 + the 8 of the lateral) and 21 backward; with the source tile of an output tile staged in LDS the
-// forward reads the coarse tensor once, the lateral once and writes the fine tensor once (17), the adjoint reads the fine gradient once and writes
-// the coarse one (9).  The blends happen in the same order as in the separable passes (x, then y, then z; adjoint: z, then y, then x), so the
-// results are the same numbers.  Conditions (host): every axis up-samples by at most 2 (0.5 <= n_in / n_out <= 1), W % 4 == 0, align_corners = False.
+// r04: the two OUTER axes of a trilinear resampling in one streaming pass.  The separable form moves 29 coarse-tensor sizes per 2 x 2 x 2 up-sampling
+// forward (x: 1 + 2, y: 2 + 4, z: 4 + 8 + the lateral's 8) and 21 backward; with y and z in one pass over [outer, n1, n2, inner] (inner = the contiguous
+// x extent, float4) it is 21 forward (x: 3, yz: 2 + 8 + 8) and 13 backward (zy: 8 + 2, x: 3): the 2 x 2 source rows of an output row are re-read from
+// L2, not HBM.  Same blends in the same order (y before z; adjoint: z before y) -> the same numbers as the one-axis passes.  (A fully fused kernel with
+// the source tile in LDS was built and measured first, r04_d: 1.35 ms against 0.93 for the separable passes forward and 8 ms backward -- bound by its LDS
+// gathers and per-candidate weight arithmetic, not by bytes.  Removed.)
 // =================================================================================================
-constexpr int IT_TZ = 8, IT_TY = 16, IT_TX = 32;                       // output tile of the forward kernel / fine-gradient region of the adjoint
-constexpr int IT_SZ = IT_TZ + 2, IT_SY = IT_TY + 2, IT_SX = IT_TX + 2;  // its source tile (scale <= 1: at most tile + 2 per axis)
-__global__ __launch_bounds__(256) void interp3d_fwd_tile_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
-                                                                InterpDims q, int tiles_y, int tiles_x) {
-    __shared__ float src[IT_SZ * IT_SY * IT_SX];
-    const int64_t p = blockIdx.y;
-    int t = blockIdx.x;
-    const int txi = t % tiles_x; t /= tiles_x;
-    const int tyi = t % tiles_y, tzi = t / tiles_y;
-    const int z0 = tzi * IT_TZ, y0 = tyi * IT_TY, x0 = txi * IT_TX;
-    const int zl = min(z0 + IT_TZ, q.D) - 1, yl = min(y0 + IT_TY, q.H) - 1, xl = min(x0 + IT_TX, q.W) - 1;
-    const int sz0 = axis_src(z0, q.d, q.sd).i0, sy0 = axis_src(y0, q.h, q.sh).i0, sx0 = axis_src(x0, q.w, q.sw).i0;
-    const int nz = axis_src(zl, q.d, q.sd).i1 - sz0 + 1, ny = axis_src(yl, q.h, q.sh).i1 - sy0 + 1, nx = axis_src(xl, q.w, q.sw).i1 - sx0 + 1;
-    const float* s = in + p * ((int64_t)q.d * q.h * q.w);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = wave; row < nz * ny; row += 4) {                      // a wave per source row: (zz, yy) is wave-uniform, the lanes run along x
-        const int zz = row / ny, yy = row - zz * ny;
-        if (lane < nx) src[(zz * IT_SY + yy) * IT_SX + lane] = s[((int64_t)(sz0 + zz) * q.h + (sy0 + yy)) * q.w + sx0 + lane];
-    }
-    __syncthreads();
-    const int tx4 = threadIdx.x & 7, ty = (threadIdx.x >> 3) & 15, tzp = threadIdx.x >> 7;
-    const int y = y0 + ty, x = x0 + 4 * tx4;
-    if (y >= q.H || x >= q.W) return;
-    const Axis ay = axis_src(y, q.h, q.sh);
-    Axis ax[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { ax[j] = axis_src(x + j, q.w, q.sw); ax[j].i0 -= sx0; ax[j].i1 -= sx0; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int z = z0 + tzp * 4 + k;
-        if (z >= q.D) break;
-        const Axis az = axis_src(z, q.d, q.sd);
-        const float* r00 = src + ((az.i0 - sz0) * IT_SY + (ay.i0 - sy0)) * IT_SX; const float* r01 = src + ((az.i0 - sz0) * IT_SY + (ay.i1 - sy0)) * IT_SX;
-        const float* r10 = src + ((az.i1 - sz0) * IT_SY + (ay.i0 - sy0)) * IT_SX; const float* r11 = src + ((az.i1 - sz0) * IT_SY + (ay.i1 - sy0)) * IT_SX;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float l = ax[j].l; const int i0 = ax[j].i0, i1 = ax[j].i1;
-            const float c00 = r00[i0] * (1.f - l) + r00[i1] * l, c01 = r01[i0] * (1.f - l) + r01[i1] * l;
-            const float c10 = r10[i0] * (1.f - l) + r10[i1] * l, c11 = r11[i0] * (1.f - l) + r11[i1] * l;
-            v[j] = (c00 * (1.f - ay.l) + c01 * ay.l) * (1.f - az.l) + (c10 * (1.f - ay.l) + c11 * ay.l) * az.l;
-        }
-        const int64_t o = ((p * q.D + z) * q.H + y) * q.W + x;
-        if (base) { const float4 bv = *reinterpret_cast<const float4*>(base + o); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
-        *reinterpret_cast<float4*>(out + o) = make_float4(v[0], v[1], v[2], v[3]);
+__global__ __launch_bounds__(256) void interp_fwd_axis2_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                               int n1_in, int n1_out, int n2_in, int n2_out, int inner4, FastDiv divInner, FastDiv divRow,
+                                                               FastDiv divPer, float s1, float s2, int64_t outer) {
+    const int row = n2_out * inner4, per = n1_out * row;                    // float4 elements per output slice of axis 1 / per outer index
+    const int64_t total = outer * per, in_per = (int64_t)n1_in * n2_in * inner4;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
+        const Axis a1 = axis_src(i1, n1_in, s1), a2 = axis_src(i2, n2_in, s2);
+        const float4* s = reinterpret_cast<const float4*>(in) + o * in_per + c;
+        const float4 v00 = s[((int64_t)a1.i0 * n2_in + a2.i0) * inner4], v01 = s[((int64_t)a1.i0 * n2_in + a2.i1) * inner4];
+        const float4 v10 = s[((int64_t)a1.i1 * n2_in + a2.i0) * inner4], v11 = s[((int64_t)a1.i1 * n2_in + a2.i1) * inner4];
+        const float l1 = a1.l, l2 = a2.l;
+        float4 rr;
+        rr.x = (v00.x * (1.f - l2) + v01.x * l2) * (1.f - l1) + (v10.x * (1.f - l2) + v11.x * l2) * l1;
+        rr.y = (v00.y * (1.f - l2) + v01.y * l2) * (1.f - l1) + (v10.y * (1.f - l2) + v11.y * l2) * l1;
+        rr.z = (v00.z * (1.f - l2) + v01.z * l2) * (1.f - l1) + (v10.z * (1.f - l2) + v11.z * l2) * l1;
+        rr.w = (v00.w * (1.f - l2) + v01.w * l2) * (1.f - l1) + (v10.w * (1.f - l2) + v11.w * l2) * l1;
+        const int64_t ob = o * per + e;
+        if (base) { const float4 bv = reinterpret_cast<const float4*>(base)[ob]; rr.x += bv.x; rr.y += bv.y; rr.z += bv.z; rr.w += bv.w; }
+        reinterpret_cast<float4*>(out)[ob] = rr;
     }
 }
-// exact first / last output index that input cells [i_first, i_last] of an axis were blended into (cand_range is conservative: trim its zero weights)
-__device__ __forceinline__ void axis_cover(int i_first, int i_last, int n_out, int n_in, float scale, int& lo, int& hi) {
-    int l2, h2;
-    cand_range(i_first, n_out, scale, lo, h2);
-    while (lo < h2 && axis_weight(i_first, lo, n_in, scale) == 0.f) ++lo;
-    cand_range(i_last, n_out, scale, l2, hi);
-    while (hi > l2 && axis_weight(i_last, hi, n_in, scale) == 0.f) --hi;
-}
-constexpr int IB_TZ = 4, IB_TY = 8, IB_TX = 16;                          // coarse cells per workgroup of the adjoint (two per thread, along z)
-__global__ __launch_bounds__(256) void interp3d_bwd_tile_kernel(const float* __restrict__ dout, float* __restrict__ din, InterpDims q, int tiles_y, int tiles_x) {
-    __shared__ float reg[IT_SZ * IT_SY * IT_SX];                          // (2 * 4 + 2) x (2 * 8 + 2) x (2 * 16 + 2) at most (scale >= 0.5)
-    const int64_t p = blockIdx.y;
-    int t = blockIdx.x;
-    const int txi = t % tiles_x; t /= tiles_x;
-    const int tyi = t % tiles_y, tzi = t / tiles_y;
-    const int z0 = tzi * IB_TZ, y0 = tyi * IB_TY, x0 = txi * IB_TX;
-    int rz0, rz1, ry0, ry1, rx0, rx1;
-    axis_cover(z0, min(z0 + IB_TZ, q.d) - 1, q.D, q.d, q.sd, rz0, rz1);
-    axis_cover(y0, min(y0 + IB_TY, q.h) - 1, q.H, q.h, q.sh, ry0, ry1);
-    axis_cover(x0, min(x0 + IB_TX, q.w) - 1, q.W, q.w, q.sw, rx0, rx1);
-    const int nz = rz1 - rz0 + 1, ny = ry1 - ry0 + 1, nx = rx1 - rx0 + 1;
-    const float* g = dout + p * ((int64_t)q.D * q.H * q.W);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int row = wave; row < nz * ny; row += 4) {
-        const int zz = row / ny, yy = row - zz * ny;
-        if (lane < nx) reg[(zz * IT_SY + yy) * IT_SX + lane] = g[((int64_t)(rz0 + zz) * q.H + (ry0 + yy)) * q.W + rx0 + lane];
-    }
-    __syncthreads();
-    const int ix = x0 + (threadIdx.x & 15), iy = y0 + ((threadIdx.x >> 4) & 7);
-    if (ix >= q.w || iy >= q.h) return;
-    int xa, xb, ya, yb;
-    cand_range(ix, q.W, q.sw, xa, xb); cand_range(iy, q.H, q.sh, ya, yb);
-    xa = max(xa, rx0); xb = min(xb, rx1); ya = max(ya, ry0); yb = min(yb, ry1);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int iz = z0 + (threadIdx.x >> 7) * 2 + k;
-        if (iz >= q.d) break;
-        int za, zb;
-        cand_range(iz, q.D, q.sd, za, zb);
-        za = max(za, rz0); zb = min(zb, rz1);
-        float acc = 0.f;
-        for (int X = xa; X <= xb; ++X) {                                 // the separable adjoint's order: z sums innermost, then y, then x
-            const float wx = axis_weight(ix, X, q.w, q.sw);
-            if (wx == 0.f) continue;
-            float colacc = 0.f;
-            for (int Y = ya; Y <= yb; ++Y) {
-                const float wy = axis_weight(iy, Y, q.h, q.sh);
-                if (wy == 0.f) continue;
-                const float* col = reg + (Y - ry0) * IT_SX + (X - rx0);
-                float rowacc = 0.f;
-                for (int Z = za; Z <= zb; ++Z) rowacc += axis_weight(iz, Z, q.d, q.sd) * col[(Z - rz0) * (IT_SY * IT_SX)];
-                colacc += wy * rowacc;
+// adjoint of the pass above: din[o][i1][i2] = sum_{d2} w2(d2) * (sum_{d1} w1(d1) * dout[o][d1][d2]) -- axis 1 (the outer one) innermost, as the one-axis
+// passes run (outermost axis first).  Only candidates with a non-zero weight are loaded (cand_range is conservative: 8 per axis for 4 contributors).
+__global__ __launch_bounds__(256) void interp_bwd_axis2_kernel(const float* __restrict__ dout, float* __restrict__ din, int n1_out, int n1_in, int n2_out,
+                                                               int n2_in, int inner4, FastDiv divInner, FastDiv divRow, FastDiv divPer, float s1, float s2,
+                                                               int64_t outer) {
+    const int row = n2_in * inner4, per = n1_in * row;
+    const int64_t total = outer * per, out_per = (int64_t)n1_out * n2_out * inner4;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
+        int lo1, hi1, lo2, hi2;
+        cand_range(i1, n1_out, s1, lo1, hi1); cand_range(i2, n2_out, s2, lo2, hi2);
+        const float4* g = reinterpret_cast<const float4*>(dout) + o * out_per + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int d2 = lo2; d2 <= hi2; ++d2) {
+            const float w2 = axis_weight(i2, d2, n2_in, s2);
+            if (w2 == 0.f) continue;
+            float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int d1 = lo1; d1 <= hi1; ++d1) {
+                const float w1 = axis_weight(i1, d1, n1_in, s1);
+                if (w1 == 0.f) continue;
+                const float4 v = g[((int64_t)d1 * n2_out + d2) * inner4];
+                col.x += w1 * v.x; col.y += w1 * v.y; col.z += w1 * v.z; col.w += w1 * v.w;
             }
-            acc += wx * colacc;
+            acc.x += w2 * col.x; acc.y += w2 * col.y; acc.z += w2 * col.z; acc.w += w2 * col.w;
         }
-        din[((p * q.d + iz) * q.h + iy) * q.w + ix] = acc;
+        reinterpret_cast<float4*>(din)[o * per + e] = acc;
     }
 }
 
@@ -546,27 +500,27 @@ extern "C" int segx_interp_linear_fwd(const float* in, const float* base, float*
     return check_launch("segx_interp_linear_fwd");
 }
 /* forward along one axis: in [outer, n_in, inner] -> out [outer, n_out, inner] (+ base, same shape as out) */
-// fused 3-D forms (interp3d_*_tile_kernel): 1 when launched, 0 when the shape needs the separable passes (nothing launched), < 0 on error
-static bool interp3d_tile_ok(int d, int h, int w, int D, int H, int W, int64_t planes) {
-    return planes > 0 && planes <= 65535 && d <= D && h <= H && w <= W && 2 * d >= D && 2 * h >= H && 2 * w >= W && (d < D || h < H || w < W) && D > 1;
+// two outer axes in one pass (interp_{fwd,bwd}_axis2_kernel): tensors [outer, n1, n2, inner] with inner % 4 == 0 and 16-byte aligned pointers
+extern "C" int segx_interp_linear_fwd_axis2(const float* in, const float* base, float* out, int64_t outer, int n1_in, int n1_out, int n2_in, int n2_out,
+                                            int64_t inner, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(in && out && outer > 0 && n1_in > 0 && n1_out > 0 && n2_in > 0 && n2_out > 0 && inner > 0 && inner % 4 == 0, "segx_interp_linear_fwd_axis2: bad args");
+    SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0, "segx_interp_linear_fwd_axis2: alignment");
+    const int64_t in4 = inner / 4, per = (int64_t)n1_out * n2_out * in4, total = outer * per;
+    SEGX_REQUIRE(per < 2147483647LL - 256 && (int64_t)n1_in * n2_in * in4 < 2147483647LL, "segx_interp_linear_fwd_axis2: slice too large");
+    hipLaunchKernelGGL(interp_fwd_axis2_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, in, base, out, n1_in, n1_out, n2_in,
+                       n2_out, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_out * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
+                       (float)n2_in / (float)n2_out, outer);
+    return check_launch("segx_interp_linear_fwd_axis2");
 }
-extern "C" int segx_interp3d_fwd_fused(const float* in, const float* base, float* out, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(in && out && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp3d_fwd_fused: bad args");
-    if (!interp3d_tile_ok(d, h, w, D, H, W, planes) || W % 4 != 0 || ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) != 0) return 0;
-    const int tz = (D + IT_TZ - 1) / IT_TZ, ty = (H + IT_TY - 1) / IT_TY, tx = (W + IT_TX - 1) / IT_TX;
-    if ((int64_t)tz * ty * tx > 2147483647LL) return 0;
-    hipLaunchKernelGGL(interp3d_fwd_tile_kernel, dim3((unsigned)(tz * ty * tx), (unsigned)planes), dim3(256), 0, stream, in, base, out, make_dims(d, h, w, D, H, W), ty, tx);
-    const int rc = check_launch("segx_interp3d_fwd_fused");
-    return rc ? (rc > 0 ? -rc - 1000 : rc) : 1;
-}
-extern "C" int segx_interp3d_bwd_fused(const float* dout, float* din, int64_t planes, int d, int h, int w, int D, int H, int W, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dout && din && d > 0 && h > 0 && w > 0 && D > 0 && H > 0 && W > 0, "segx_interp3d_bwd_fused: bad args");
-    if (!interp3d_tile_ok(d, h, w, D, H, W, planes)) return 0;
-    const int tz = (d + IB_TZ - 1) / IB_TZ, ty = (h + IB_TY - 1) / IB_TY, tx = (w + IB_TX - 1) / IB_TX;
-    if ((int64_t)tz * ty * tx > 2147483647LL) return 0;
-    hipLaunchKernelGGL(interp3d_bwd_tile_kernel, dim3((unsigned)(tz * ty * tx), (unsigned)planes), dim3(256), 0, stream, dout, din, make_dims(d, h, w, D, H, W), ty, tx);
-    const int rc = check_launch("segx_interp3d_bwd_fused");
-    return rc ? (rc > 0 ? -rc - 1000 : rc) : 1;
+extern "C" int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64_t outer, int n1_out, int n1_in, int n2_out, int n2_in, int64_t inner, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n1_in > 0 && n1_out > 0 && n2_in > 0 && n2_out > 0 && inner > 0 && inner % 4 == 0, "segx_interp_linear_bwd_axis2: bad args");
+    SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0, "segx_interp_linear_bwd_axis2: alignment");
+    const int64_t in4 = inner / 4, per = (int64_t)n1_in * n2_in * in4, total = outer * per;
+    SEGX_REQUIRE(per < 2147483647LL - 256 && (int64_t)n1_out * n2_out * in4 < 2147483647LL, "segx_interp_linear_bwd_axis2: slice too large");
+    hipLaunchKernelGGL(interp_bwd_axis2_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, n1_out, n1_in, n2_out,
+                       n2_in, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_in * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
+                       (float)n2_in / (float)n2_out, outer);
+    return check_launch("segx_interp_linear_bwd_axis2");
 }
 extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
                                            float src_scale, void* stream_) {

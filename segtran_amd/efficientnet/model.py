@@ -101,12 +101,10 @@ class MBConvBlock(nn.Module):
         x = skip_in = inputs
         skip = self.stride == 1 and self.input_filters == self.output_filters
         if self.expand_ratio != 1:
-            # with a skip connection `inputs` has two consumers: the second one goes through the alias the GEMM op returns, so that its gradient is
-            # added inside the expansion's dX GEMM instead of by an accumulation kernel of autograd's (25 blocks of B4)
-            x = self._expand_conv(x, pass_input=skip)
-            if skip:
-                x, skip_in = x
-            x = SF.bn_act(x, self._bn0, SF.ACT_SWISH)
+            # (`inputs` has two consumers when there is a skip connection.  Routing the second through the GEMM op's input alias -- its gradient added
+            # inside the expansion's dX GEMM, SF.conv1x1(pass_input=True), what the Inception modules do -- was measured here, r04_d: the residual keeps
+            # those dX GEMMs off the wave-specialised tiles, +0.40 ms/step of GEMM time against 0.24 ms of accumulation adds saved.  Not used.)
+            x = SF.bn_act(self._expand_conv(x), self._bn0, SF.ACT_SWISH)
         se = (self._se_reduce.weight, self._se_reduce.bias, self._se_expand.weight, self._se_expand.bias)
         # drop_connect (utils.py:129-154, per-sample stochastic depth) and the skip add ride on the last BatchNorm pass: the sample's keep scale is
         # drawn inside the kernels from the library's Philox stream (H3: the reference's torch.rand stream cannot be matched anyway)

@@ -1108,13 +1108,15 @@ class _InterpAdd(torch.autograd.Function):
         base = _c(base) if base is not None else None
         axes = [(ax, n_in, n_out) for ax, (n_in, n_out) in enumerate(((d, D), (h, H), (w, W))) if n_in != n_out]
         ctx.align = bool(align_corners)
-        out = None
-        if D > 1 and axes and not align_corners:               # r04: one pass (source tile in LDS) where every axis up-samples by at most 2
+        if d != D and h != H and not align_corners and W % 4 == 0:
+            # r04: the x pass (if any), then y AND z in ONE streaming pass with the lateral added (segx_interp_linear_fwd_axis2): 21 instead of 29
+            # coarse-tensor sizes of traffic for a 2 x 2 x 2 up-sampling, the same blends in the same order
+            cur = x
+            if w != W:
+                cur = _empty(x, B * C * d * h * W)
+                L.interp_fwd_axis(x, None, cur, B * C * d * h, w, W, 1, 0.0)
             out = _empty(x, B, C, *size)
-            if not L.interp3d_fwd_fused(x, base, out, B * C, d, h, w, D, H, W):
-                out = None
-        if out is not None:
-            pass
+            L.interp_fwd_axis2(cur, base, out, B * C, d, D, h, H, W)
         elif (D > 1 or align_corners) and axes:
             # 3-D: one streaming pass per resized axis, innermost (smallest tensor) first, the lateral added in the last pass --
             # the same blends in the same order as the fused formula (bit-identical), at HBM rate instead of 1-2 TB/s
@@ -1145,10 +1147,14 @@ class _InterpAdd(torch.autograd.Function):
         planes, d, h, w, D, H, W, xshape = ctx.cfg
         dy = _c(dy)
         dx = None
-        if ctx.needs_input_grad[0] and D > 1 and not ctx.align and (d, h, w) != (D, H, W):
-            dx = _empty(dy, *xshape)
-            if not L.interp3d_bwd_fused(dy, dx, planes, d, h, w, D, H, W):
-                dx = None
+        if ctx.needs_input_grad[0] and d != D and h != H and not ctx.align and W % 4 == 0:
+            cur = _empty(dy, planes * d * h * W)               # z and y adjoints in one pass, then x (13 instead of 21 coarse-tensor sizes)
+            L.interp_bwd_axis2(dy, cur, planes, D, d, H, h, W)
+            if w != W:
+                nxt = _empty(dy, planes * d * h * w)
+                L.interp_bwd_axis(cur, nxt, planes * d * h, W, w, 1, 0.0)
+                cur = nxt
+            dx = cur.view(xshape)
         if ctx.needs_input_grad[0] and dx is None:
             # separable adjoint, one pass per resized axis, OUTERMOST axis first: the passes over the big tensors then have a long
             # contiguous inner extent (float4 kernel); the scalar innermost-axis pass runs last, on the smallest tensor

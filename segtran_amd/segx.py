@@ -358,20 +358,11 @@ class SegxLib:
         self._call('segx_plane_scale_bwd', dY, dY, gate, dpool, dX, planes, S)
 
     # ---- feature-pyramid kernels (fpn.hip) ----------------------------------------------------------
-    def interp3d_fwd_fused(self, x, base, out, planes, d, h, w, D, H, W):
-        """-> True when the one-pass trilinear kernel ran (segx_interp3d_fwd_fused), False when the shape needs the separable passes"""
-        self._chk_t(x, base, out)
-        rc = self.c.segx_interp3d_fwd_fused(_ptr(x), _ptr(base), _ptr(out), planes, d, h, w, D, H, W, self.stream(x))
-        if rc < 0:
-            self.check(rc, 'segx_interp3d_fwd_fused')
-        return rc == 1
+    def interp_fwd_axis2(self, inp, base, out, outer, n1_in, n1_out, n2_in, n2_out, inner):
+        self._call('segx_interp_linear_fwd_axis2', inp, inp, base, out, outer, n1_in, n1_out, n2_in, n2_out, inner)
 
-    def interp3d_bwd_fused(self, dout, din, planes, d, h, w, D, H, W):
-        self._chk_t(dout, din)
-        rc = self.c.segx_interp3d_bwd_fused(_ptr(dout), _ptr(din), planes, d, h, w, D, H, W, self.stream(dout))
-        if rc < 0:
-            self.check(rc, 'segx_interp3d_bwd_fused')
-        return rc == 1
+    def interp_bwd_axis2(self, dout, din, outer, n1_out, n1_in, n2_out, n2_in, inner):
+        self._call('segx_interp_linear_bwd_axis2', dout, dout, din, outer, n1_out, n1_in, n2_out, n2_in, inner)
 
     def gn_ws(self, B, C, G):
         return int(self.c.segx_gn_ws_floats(B, C, G))
@@ -567,7 +558,7 @@ _SIGS = {
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
-    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp3d_fwd_fused': 'pppliiiiiip', 'segx_interp3d_bwd_fused': 'ppliiiiiip', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
+    'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_fwd_axis2': 'pppliiiilp', 'segx_interp_linear_bwd_axis2': 'ppliiiilp', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',

@@ -232,8 +232,8 @@ def test_group_norm(backend, shape):
 @pytest.mark.parametrize('inshape,size', [((2, 3, 4, 5), (8, 10)), ((1, 2, 7, 7), (14, 14)), ((2, 2, 8, 6), (16, 24)), ((1, 3, 16, 16), (13, 9)),
                                           ((1, 2, 3, 4, 5), (6, 8, 10)), ((2, 2, 6, 7, 7), (12, 14, 14)), ((1, 2, 4, 3, 3), (4, 12, 12)),
                                           ((1, 2, 8, 5, 5), (4, 5, 5)), ((1, 1, 12, 14, 14), (48, 56, 56)),
-                                          # r04, the one-pass 3-D kernels (every axis x1 .. x2, W % 4 == 0): several tiles per axis with ragged edges, a
-                                          # non-integer ratio, an axis that is not resized; the x4 case above and W % 4 != 0 keep the separable passes
+                                          # r04, y and z in one pass (W % 4 == 0, both resized): ragged sizes, a non-integer ratio, x not resized; an axis that is not
+                                          # resized / W % 4 != 0 keep the one-axis passes
                                           ((2, 2, 9, 17, 20), (18, 34, 40)), ((1, 3, 5, 9, 12), (8, 16, 20)), ((1, 2, 6, 10, 36), (6, 20, 72)),
                                           ((1, 1, 3, 4, 6), (6, 8, 10))])
 @pytest.mark.parametrize('with_base', [False, True])
@@ -255,25 +255,22 @@ def test_interp_linear(backend, inshape, size, with_base):
         close(base.grad, br.grad, 1e-6)
 
 
-def test_one_pass_trilinear_equals_the_separable_passes(backend):
-    """segx_interp3d_{fwd,bwd}_fused against the three one-axis passes they replace: the same blends in the same order -> the same bits."""
+def test_two_axis_resampling_pass_equals_the_one_axis_passes(backend):
+    """segx_interp_linear_{fwd,bwd}_axis2 (y and z of a trilinear resampling in one pass) against the two one-axis passes they replace: the same
+    blends in the same order (the compiler may contract the multiply-adds differently: a few ulp)."""
     L = backend.L
     B, C, d, h, w, D, H, W = 2, 3, 9, 17, 20, 18, 34, 40
-    x, base, G = rnd(B, C, d, h, w, seed=90), rnd(B, C, D, H, W, seed=91), rnd(B, C, D, H, W, seed=92)
+    t1, base, G = rnd(B * C * d * h * W, seed=90), rnd(B, C, D, H, W, seed=91), rnd(B, C, D, H, W, seed=92)
     out = torch.empty(B, C, D, H, W)
-    assert L.interp3d_fwd_fused(x, base, out, B * C, d, h, w, D, H, W)
-    t1 = torch.empty(B * C * d * h * W); L.interp_fwd_axis(x, None, t1, B * C * d * h, w, W, 1, 0.0)
+    L.interp_fwd_axis2(t1, base, out, B * C, d, D, h, H, W)
     t2 = torch.empty(B * C * d * H * W); L.interp_fwd_axis(t1, None, t2, B * C * d, h, H, W, 0.0)
     ref = torch.empty(B, C, D, H, W); L.interp_fwd_axis(t2, base, ref, B * C, d, D, H * W, 0.0)
-    assert torch.equal(out, ref)
-    dx = torch.empty(B, C, d, h, w)
-    assert L.interp3d_bwd_fused(G, dx, B * C, d, h, w, D, H, W)
+    close(out, ref, 1e-6)
+    g12 = torch.empty(B * C * d * h * W)
+    L.interp_bwd_axis2(G, g12, B * C, D, d, H, h, W)
     g1 = torch.empty(B * C * d * H * W); L.interp_bwd_axis(G, g1, B * C, D, d, H * W, 0.0)
     g2 = torch.empty(B * C * d * h * W); L.interp_bwd_axis(g1, g2, B * C * d, H, h, W, 0.0)
-    g3 = torch.empty(B, C, d, h, w); L.interp_bwd_axis(g2, g3, B * C * d * h, W, w, 1, 0.0)
-    close(dx, g3, 1e-6)                                        # same terms, same nesting; the compiler may contract the multiply-adds differently
-    assert not L.interp3d_fwd_fused(x, None, torch.empty(B, C, 36, 34, 40), B * C, d, h, w, 36, 34, 40)      # x4 along one axis: separable passes
-    assert not L.interp3d_fwd_fused(x, None, torch.empty(B, C, D, H, 38), B * C, d, h, w, D, H, 38)          # W % 4 != 0
+    close(g12, g2, 1e-6)
 
 
 @pytest.mark.parametrize('shape,C,kw', [((7, 10), 6, dict(scale_factor=1. / 3)), ((7, 10), 8, dict(scale_factor=0.5)), ((8, 12), 5, dict(scale_factor=0.25)),

@@ -164,7 +164,7 @@ def test_reference_format_optimizer_state_with_four_groups_loads_through_load_mo
     names = ['head.weight', 'head.bias', 'backbone.weight', 'backbone.bias']
     ps = dict(net.named_parameters())
     g = torch.Generator(device='cpu').manual_seed(5)
-    state = {i: dict(step=7, next_m=torch.randn(ps[n].shape, generator=g), next_v=torch.rand(ps[n].shape, generator=g)) for i, n in enumerate(names)}
+    state = {i: dict(step=7, next_m=torch.randn(ps[n].shape, generator=g, device='cpu'), next_v=torch.rand(ps[n].shape, generator=g, device='cpu')) for i, n in enumerate(names)}
     base = dict(schedule='warmup_linear', warmup=0.1, t_total=100, b1=0.9, b2=0.999, e=1e-6, max_grad_norm=0.05)
     groups = [dict(base, params=[0, 1], weight_decay=1e-4, lr=2e-4), dict(base, params=[2, 3], weight_decay=1e-5, lr=2e-4),
               dict(base, params=[], weight_decay=0.0, lr=2e-4), dict(base, params=[], weight_decay=0.0, lr=2e-2)]
