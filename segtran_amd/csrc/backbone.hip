@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restr
 //            gate folded into the per-sample projection weights, one launch): 2 launches instead of 5
 // backward : se_bwd_gate (dgate from the per-sample weight gradient, dz2, hidden partials over 64-channel chunks) -> se_bwd_pool_kernel ->
 //            se_wgrad_all (dW1, db1, dW2, db2 AND the projection weight gradient dW): 3 launches instead of 5
-constexpr int SE2_CHUNK = 64;
+constexpr int SE2_CHUNK = 64, SE2_ROWS = 64;
 // hpre[b][j] = b1[j] + sum_c W1[j][c] * p[b][c], p = (sum of the plane's nch pooling chunks) / S; also p (kept for the weight gradients).  grid (ceil(Cs/4), B)
 __global__ __launch_bounds__(256) void se_hidden2_kernel(const float* __restrict__ psum, int nch, float inv_S, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, float* __restrict__ p_out, float* __restrict__ hpre_out, int C, int Cs) {
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
         if (lane == 0) {
             const float gt = k < K ? sigm(s + b2[k]) : 0.f;
             gsh[kk] = gt;
-            if (k < K) gate[(int64_t)b * K + k] = gt;
+            if (k < K && blockIdx.z == 0) gate[(int64_t)b * K + k] = gt;
         }
     }
     __syncthreads();
@@ -1077,7 +1077,11 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
     if (k >= K) return;
     const float gt = gsh[lane];
     float* o = Wb + (int64_t)b * M * K;
-    for (int m = wv; m < M; m += 4) o[(int64_t)m * K + k] = W[(int64_t)m * K + k] * gt;
+    // gridDim.z slabs of SE2_ROWS output rows: every slab recomputes the 64 gates (a few hundred cycles) so that the M x K scaling is spread over
+    // M / 64 times as many workgroups (r04_d: 24 us per layer with one workgroup per (64 columns, sample) -- latency-bound -- against 9.5 us for the two
+    // kernels this one replaces); slab 0 alone writes the gate
+    const int m1 = min(M, ((int)blockIdx.z + 1) * SE2_ROWS);
+    for (int m = (int)blockIdx.z * SE2_ROWS + wv; m < m1; m += 4) o[(int64_t)m * K + k] = W[(int64_t)m * K + k] * gt;
 }
 // dgate[b][k] = sum_m dWb[b][m][k] W[m][k] (W == NULL: dgate is given), dz2 = dgate * gate * (1 - gate), part[b][chunk][j] = sum_{k in chunk} dz2[k] W2[k][j].
 // grid (ceil(K / 64), B): 64 columns x 4 row lanes, the four partial sums added in lane order through LDS (as gate_weights_bwd_g_kernel)
@@ -1300,7 +1304,7 @@ extern "C" int segx_se_fwd2(const float* psum, int nch, float inv_S, const float
     SEGX_STREAM; SEGX_REQUIRE(psum && nch > 0 && W1 && b1 && W2 && b2 && p && hpre && gate && B > 0 && C > 0 && Cs > 0 && (!Wproj || (Wb && M > 0)), "segx_se_fwd2: bad args");
     SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_fwd2: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
     hipLaunchKernelGGL(se_hidden2_kernel, dim3((Cs + 3) / 4, B), dim3(256), 0, stream, psum, nch, inv_S, W1, b1, p, hpre, C, Cs);
-    hipLaunchKernelGGL(se_gate_weights_kernel, dim3((C + SE2_CHUNK - 1) / SE2_CHUNK, B), dim3(256), 0, stream, (const float*)hpre, W2, b2, Wproj, gate, Wb, C, Cs, M);
+    hipLaunchKernelGGL(se_gate_weights_kernel, dim3((C + SE2_CHUNK - 1) / SE2_CHUNK, B, Wproj ? (M + SE2_ROWS - 1) / SE2_ROWS : 1), dim3(256), 0, stream, (const float*)hpre, W2, b2, Wproj, gate, Wb, C, Cs, M);
     return check_launch("segx_se_fwd2");
 }
 extern "C" int64_t segx_se_ws2_floats(int B, int C, int Cs) { return (int64_t)B * (C + Cs) + (int64_t)B * ((C + SE2_CHUNK - 1) / SE2_CHUNK) * Cs; }

@@ -1,4 +1,4 @@
-"""Copy the summaries of a tools/gpu_round.sh session into profiles/ under the round tag and derive the MFMA-engine HBM traffic.
+"""Copy the summaries of a tools/gpu_session.sh (r04) / tools/gpu_round.sh session into profiles/ under the round tag and derive the MFMA-engine HBM traffic.
 python tools/collect_profiles.py <tag>      (build container, after gpurun merged gpurun_out/<tag>/)"""
 import json, os, shutil, sys
 
@@ -23,12 +23,12 @@ def engine_traffic(cfg):
             wk += v['WRITE_SIZE']['total']
     cal = None
     for k in F:                                                 # calibration kernel: reads == writes by construction
-        if 'bn_act_fwd_kernel' in k and k in W:
+        if 'gn_apply_kernel' in k and k in W:
             cal = (F[k]['FETCH_SIZE']['mean'] * 1024, W[k]['WRITE_SIZE']['mean'] * 1024)
     return {'source': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --config %s --steps 1 --warmup 1`, %s' % (cfg, tag),
             'kernels': ' + '.join(ENGINE), 'launches': n, 'fetch_kb_total_raw': fk, 'write_kb_total': wk,
             'correction': 'gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section): x2'
-                          + ('; calibration on bn_act_fwd_kernel (reads == writes): FETCH %.2f MB vs WRITE %.2f MB per launch' % (cal[0] / 1e6, cal[1] / 1e6) if cal else ''),
+                          + ('; calibration on gn_apply_kernel (reads == writes): FETCH %.2f MB vs WRITE %.2f MB per launch' % (cal[0] / 1e6, cal[1] / 1e6) if cal else ''),
             'traffic_bytes_per_launch': (2.0 * fk + wk) * 1024.0 / max(1, n)}
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One measurement session of round 4 (run through gpurun from the repo root): tools/gpu_session.sh <tag> [tests|notests]
+# One measurement session of round 4 (run through gpurun from the repo root): tools/gpu_session.sh <tag> [tests|notests] [pmc]
 # full -m gpu suite, smoke, the driver's bench line, cfg1 eagerly and as one hipGraph, rocprofv3 kernel stats + per-dispatch traces of cfg2 / cfg4 / cfg5.
 set -u
 TAG=${1:-r04_x}; MODE=${2:-tests}
@@ -24,4 +24,15 @@ for CFG in cfg2 cfg4 cfg5; do
   find $OUT/prof_$CFG -name '*agent_info.csv' -exec cp {} $OUT/agent_info.csv \;
   rm -rf $OUT/prof_$CFG
 done
+if [ "${3:-}" = pmc ]; then
+  # counter passes (own runs, --pmc only: no trace domains beside them), aggregated per kernel on the box
+  for CFG in cfg2 cfg4; do
+    for PMC in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
+      NAME=$(echo $PMC | cut -d' ' -f1)
+      timeout 400 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_${CFG}_$NAME -o pmc -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-brats --no-cpu-baseline --single-order > $OUT/pmc_${CFG}_$NAME.log 2>&1
+      python $ROOT/tools/pmc_summary.py $OUT/pmc_${CFG}_$NAME $OUT/pmc_${CFG}_${NAME}_by_kernel.json > /dev/null 2>&1
+      rm -rf $OUT/pmc_${CFG}_$NAME
+    done
+  done
+fi
 ls -la $OUT
