@@ -190,30 +190,13 @@ int segx_mt_gather(const void* const* src, void* const* dst, const int64_t* size
  * Tensors are NC[D]HW fp32; S = product of the spatial dims; a (sample, channel) plane is contiguous.
  * act: 0 none, 1 swish (efficientnet/utils.py:64-79), 2 ReLU (aj_i3d.py:95-96), 3 LeakyReLU(0.2) (networks/discriminator.py:14-21).
  * ------------------------------------------------------------------------------------------- */
-/* training-mode batch statistics (biased var) per channel; also updates running stats (momentum, unbiased var) when
- * run_mean/run_var are non-NULL.  nn.BatchNorm2d/3d at efficientnet/model.py:54,64,78,177,221 and aj_i3d.py:65. */
+/* scratch of the BatchNorm backward reductions: segx_bn_ws_floats(B, C) floats */
 int64_t segx_bn_ws_floats(int B, int C);
-int segx_bn_stats(const float* X, float* mean, float* var, float* run_mean, float* run_var, float* ws,
-                  int B, int C, int64_t S, float momentum, void* stream);
-/* synchronised BatchNorm (nn.SyncBatchNorm, train2d.py:1109): merge the all-gathered per-rank statistics all[world][2C] = (mean[C], biased
- * var[C]) of equally sized shards (n_per_rank samples each) into the global mean / biased var and update the running statistics */
-int segx_bn_merge_stats(const float* all, float* mean, float* var, float* run_mean, float* run_var, int world, int C, int64_t n_per_rank,
-                        float momentum, void* stream);
-/* y = act((x - mean) * rsqrt(var + eps) * w + b) with the given (batch or running) statistics */
-int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
-                    int B, int C, int64_t S, float eps, int act, void* stream);
-/* the same pass that also leaves pooled[b][c] = sum over the plane of Y -- the squeeze-excite pooling that follows BatchNorm + swish in an
- * MBConv block (efficientnet/model.py:104-106) without another pass over Y; ws: B*C*64 floats */
-int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
-                         int B, int C, int64_t S, float eps, int act, void* stream);
-/* backward of the above: dX, dw[C], db[C]; training != 0 differentiates through the batch statistics.
- * gate / dpool ([B*C]; gate needs dpool, dpool alone = gate of one): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c], efficientnet/model.py:110) and dY is the
- * gradient w.r.t. Z: the kernels then use dY * gate[b][c] + dpool[b][c] * inv_S in place of dY (dpool = gradient w.r.t. the pooled sums' mean),
- * which replaces a pass that would write that tensor (same for the reduce / apply halves below) */
-int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
-                    float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                    const float* gate, const float* dpool, float inv_S, void* stream);
-/* the two halves of segx_bn_act_bwd, for synchronised BatchNorm: reduce gives the LOCAL sums dw = sum du*xhat,
+/* Backward of BatchNorm (+ activation): dX, dw[C], db[C]; training != 0 differentiates through the batch statistics.  One process: segx_bn_act_bwd2 (below).
+ * gate / dpool ([B*C]; gate needs dpool, dpool alone = gate of one): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c],
+ * efficientnet/model.py:110) and dY is the gradient w.r.t. Z: the kernels then use dY * gate[b][c] + dpool[b][c] * inv_S in place of dY (dpool = gradient
+ * w.r.t. the pooled sums' mean), which replaces a pass that would write that tensor. */
+/* the two halves of the backward pass for synchronised BatchNorm (nn.SyncBatchNorm, train2d.py:1109): reduce gives the LOCAL sums dw = sum du*xhat,
  * db = sum du; after an all-reduce of both, apply uses the GLOBAL sums and inv_n = 1 / (global element count); dc_p / seed / offset: the
  * drop_connect scale of segx_bn_act_fwd2 (0: none) */
 int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -226,11 +209,11 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  * optionally pools / scales / adds the skip input).  Replaces the nn.BatchNorm2d/3d forward of efficientnet/model.py:96-116 and aj_i3d.py:65-97
  * together with the ops around it in an MBConv block (swish :98,:102; squeeze-excite pooling :106; drop_connect + skip add :118-122).
  *   parts: [C][nparts] float4 records (n, mean, M2, -) of disjoint runs covering the B*S elements of each channel; Chan et al.'s merge makes the
- *   result independent of how a producer cut the data.  segx_bn_stats_partial writes nparts = segx_bn_nparts(B, S) per channel; the buffer
- *   must hold segx_bn_parts_floats(B, C) floats, 16-byte aligned.  (For a producer's own partials with nparts > 256 the buffer needs C*4 more.)
+ *   result independent of how a producer cut the data (nparts > 0: a producer's own partials [C][nparts]; the buffer then needs C*4 more
+ *   floats behind them when nparts > 256).  The buffer holds segx_bn_parts_floats(B, C) floats, 16-byte aligned.
  *   nparts == 0 with parts given = AUTO: the library computes the statistics itself, using `parts` as scratch -- in ONE launch for the whole
- *   layer when a channel's B planes fit one team's registers (S <= 4096 floats, B <= 8: "channel-resident", 79 of EfficientNet-B4's 96 layers at
- *   512 x 512), else segx_bn_stats_partial + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
+ *   layer when a channel's B planes fit one team's registers (S <= 4096 floats, B <= 8: "channel-resident", 66 of EfficientNet-B4's 96 layers at
+ *   512 x 512 with the stride-1 stem), else a statistics-partials launch + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
  *   parts == NULL: mean / var are INPUTS (running statistics: eval mode / synchronised BatchNorm after the merge); otherwise they are OUTPUTS
  *   (saved for the backward pass) and run_mean / run_var (optional) are updated with momentum and the unbiased variance.
  *   psum (optional): [B*C][segx_plane_chunks(S)] partial sums of Y per plane (the squeeze-excite pooling; segx_se_fwd2 adds the chunks up).
@@ -238,9 +221,11 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  *   `sample` of stream (seed, offset): efficientnet/utils.py:129-154); dc_p = 0: plain skip add. */
 int64_t segx_plane_chunks(int64_t S);
 int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats);
-int64_t segx_bn_nparts(int B, int64_t S);
 int64_t segx_bn_parts_floats(int B, int C);
-int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream);
+/* synchronised BatchNorm (nn.SyncBatchNorm, train2d.py:1109), local half: ONE partial (n, mean, M2) per channel of this process's batch into part [C]
+ * float4 (ws: segx_bn_parts_floats(B, C) floats of scratch).  The ranks all-gather their partials into [ranks][C] float4 and hand them to
+ * segx_bn_act_fwd2 with nparts = -ranks: the apply pass merges them (Chan) itself and updates the running statistics -- no merge launch. */
+int segx_bn_stats_local(const float* X, float* part, float* ws, int B, int C, int64_t S, void* stream);
 int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                      const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                      int B, int C, int64_t S, float eps, int act, void* stream);
@@ -253,7 +238,8 @@ int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const f
                      const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, void* stream);
 /* r04 -- the squeeze-excite excitation of an MBConv block (efficientnet/model.py:105-113) in 2 + 3 launches.
  * fwd: p = (sum of the nch pooling chunks psum[B*C][nch]) * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2); and, when Wproj [M][C] is
- *      given, the gate folded into per-sample projection weights Wb[b][m][k] = Wproj[m][k] * gate[b][k] (see segx_gate_weights_fwd).
+ *      given, the gate folded into per-sample projection weights Wb[b][m][k] = Wproj[m][k] * gate[b][k] (exact re-association of
+ *      efficientnet/model.py:110-113: project_conv(y * gate) == pointwise convolution of y with per-sample weights).
  * bwd: from dWb [B][M][C] (the per-sample weight gradient of the projection GEMM) -- or from dgate [B][C] when Wproj / dWb are NULL --:
  *      dpool (= dL/d pooled sum, already times inv_S), dW1, db1, dW2, db2 and dWproj[m][k] = sum_b dWb * gate.  ws: segx_se_ws2_floats(B, C, Cs) floats */
 int segx_se_fwd2(const float* psum, int nch, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2, const float* Wproj,
@@ -278,27 +264,12 @@ int segx_dwconv2d_bwd_weight_direct(const float* dY, const float* X, float* dW, 
 int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* part, int B, int C, int H, int Wd, int OH, int OW, int k,
                              int stride, int pad_t, int pad_l, void* stream);
 /* squeeze-excite plane ops (efficientnet/model.py:105-110) on [planes = B*C, S]:
- * Y = X * gate[plane];  out[plane] = sum_s A*B;  dX = dY * gate[plane] + dpool[plane] */
+ * Y = X * gate[plane];  out[plane] = sum_s A*B   (the reference operation order of an MBConv block: MBConvBlock.gate_in_weights = False) */
 int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream);
-/* Y = X * gate[plane] + R: MBConv skip connection with the per-sample drop_connect scale (model.py:118-122) */
-/* Squeeze-excite gate folded into the projection weights (exact re-association of efficientnet/model.py:110-113: project_conv(y * gate) ==
- * pointwise convolution of y with per-sample weights): Wb[b][m][k] = W[m][k] * gate[b][k].  bwd, from the per-sample weight gradient dWb
- * [B][M][K]: dW[m][k] = sum_b dWb * gate, dgate[b][k] = sum_m dWb * W (= sum over the plane of dz * y in the unfused form) */
-int segx_gate_weights_fwd(const float* W, const float* gate, float* Wb, int B, int M, int K, void* stream);
-int segx_gate_weights_bwd(const float* dWb, const float* W, const float* gate, float* dW, float* dgate, int B, int M, int K, void* stream);
 /* Y[p][s] = X[p][s] + bias[p % C]: the bias of a dense k x k convolution run on the implicit-GEMM engine (nn.Conv2d(..., 3, padding=1) of the
  * U-Net host, unet2d/unet_parts.py:16-20); in place allowed */
 int segx_plane_bias_add(const float* X, const float* bias, float* Y, int64_t planes, int C, int64_t S, void* stream);
-int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream);
 int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream);
-int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream);
-/* squeeze-excite excitation MLP on the pooled vector: p = pooled_sum * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2)
- * (W1 [Cs,C], W2 [C,Cs]: the 1x1 convs _se_reduce / _se_expand).  bwd: dpool (= dL/dpooled_sum), dW1, db1, dW2, db2; ws: segx_se_ws_floats(B, C, Cs) floats */
-int segx_se_gate_fwd(const float* pooled_sum, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2,
-                     float* p, float* hpre, float* gate, int B, int C, int Cs, void* stream);
-int64_t segx_se_ws_floats(int B, int C, int Cs);   /* workspace of segx_se_gate_bwd */
-int segx_se_gate_bwd(const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1, const float* W2,
-                     float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws, int B, int C, int Cs, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Feature-pyramid kernels (fpn.hip)

@@ -38,107 +38,13 @@ __device__ __forceinline__ void bn_fold_sums(const float* __restrict__ ws, int c
 }
 
 // =================================================================================================
-// BatchNorm statistics: per channel over (B, S).  Shifted sums around a per-channel pivot (the channel's
-// first element) keep E[d^2] - E[d]^2 free of catastrophic cancellation.  Stage 1: grid (C, B, slabs).
+// BatchNorm (+ activation).  Forward: bn_stats_partial_kernel / bn_act_fwd2_kernel / the channel-resident forms further down (r04).  Backward:
+// per-channel reductions in slabs (stage 1: grid (C, B, slabs)), summed by the apply pass.
 // =================================================================================================
 constexpr int BN_SLABS = 8;               // upper bound (workspace size); the launches use bn_slabs(S) <= BN_SLABS = gridDim.z
 // slabs per plane: ~8K floats each, so a 32 x 32 plane is ONE fully populated workgroup instead of eight with 32 live threads
 static inline int bn_slabs(int64_t S) { const int64_t n = S / 8192; return (int)(n < 1 ? 1 : n > BN_SLABS ? BN_SLABS : n); }
 
-__global__ __launch_bounds__(256) void bn_stats_stage1(const float* __restrict__ X, float* __restrict__ ws, int C, int64_t S) {
-    __shared__ float red[4];
-    const int c = blockIdx.x, b = blockIdx.y, slab = blockIdx.z;
-    const float pivot = X[(int64_t)c * S];
-    const float* x = X + ((int64_t)b * C + c) * S;
-    const int nsl = gridDim.z;
-    const int64_t per = ((S + nsl - 1) / nsl + 3) / 4 * 4, s0 = slab * per, s1 = i64min(S, s0 + per);
-    float a = 0.f, q = 0.f;
-    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) & 15) == 0)) {
-#pragma unroll 4
-        for (int64_t s = s0 + 4 * threadIdx.x; s < s1; s += 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(x + s);
-            const float d0 = v.x - pivot, d1 = v.y - pivot, d2 = v.z - pivot, d3 = v.w - pivot;
-            a += (d0 + d1) + (d2 + d3); q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-        }
-    } else {
-        for (int64_t s = s0 + threadIdx.x; s < s1; s += 256) { const float d = x[s] - pivot; a += d; q += d * d; }
-    }
-    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (threadIdx.x == 0) { float* o = ws + (((int64_t)c * gridDim.y + b) * nsl + slab) * 2; o[0] = a; o[1] = q; }
-}
-// one thread per channel: mean, biased var (+ running-stat update with the unbiased var, momentum m)
-__global__ __launch_bounds__(256) void bn_stats_stage2(const float* __restrict__ X, const float* __restrict__ ws, float* __restrict__ mean,
-                                                       float* __restrict__ var, float* __restrict__ run_mean, float* __restrict__ run_var,
-                                                       int B, int C, int64_t S, float momentum, int nsl) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, q = 0.f;
-    for (int i = 0; i < B * nsl; ++i) { a += ws[((int64_t)c * B * nsl + i) * 2]; q += ws[((int64_t)c * B * nsl + i) * 2 + 1]; }
-    const float n = (float)B * (float)S, md = a / n;
-    const float m = X[(int64_t)c * S] + md, v = fmaxf(q / n - md * md, 0.f);
-    mean[c] = m; var[c] = v;
-    if (run_mean) {
-        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
-        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (v * n / fmaxf(n - 1.0f, 1.0f));
-    }
-}
-
-// Synchronised BatchNorm: merge the per-rank (mean, biased var) of `world` equally sized shards (Chan et al.) and update the running
-// statistics, one thread per channel.  all: [world][2C] = (mean[C], var[C]) per rank, n = samples per rank.
-__global__ __launch_bounds__(256) void bn_merge_stats_kernel(const float* __restrict__ all, float* __restrict__ mean, float* __restrict__ var,
-                                                             float* __restrict__ run_mean, float* __restrict__ run_var, int world, int C,
-                                                             float n, float momentum) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    float m = 0.f;
-    for (int r = 0; r < world; ++r) m += all[(int64_t)r * 2 * C + c];
-    m /= (float)world;
-    float v = 0.f;
-    for (int r = 0; r < world; ++r) { const float d = all[(int64_t)r * 2 * C + c] - m; v += all[(int64_t)r * 2 * C + C + c] + d * d; }
-    v /= (float)world;
-    mean[c] = m; var[c] = v;
-    if (run_mean) {
-        const float N = n * (float)world;
-        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
-        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * (v * N / fmaxf(N - 1.0f, 1.0f));
-    }
-}
-
-// y = act((x - mean) * rstd * w + b): grid (chunks, B*C).  POOL: also psum[plane][chunk] = sum of this chunk's outputs -- the squeeze-excite
-// pooling of the NEXT op (efficientnet/model.py:106) without another pass over y (fixed summation order: deterministic).
-template <bool POOL>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ X, const float* __restrict__ mean, const float* __restrict__ var,
-                                                         const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ Y,
-                                                         float* __restrict__ psum, int C, int64_t S, float eps, int act) {
-    __shared__ float red[4];
-    const int bc = blockIdx.y, c = bc % C;
-    const float sc = rsqrtf(var[c] + eps) * w[c], sh = b[c] - mean[c] * sc;
-    const float* x = X + (int64_t)bc * S; float* y = Y + (int64_t)bc * S;
-    float acc = 0.f;
-    if ((S & 3) == 0) {
-        for (int64_t s = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; s < S; s += (int64_t)gridDim.x * 1024) {
-            const float4 v = *reinterpret_cast<const float4*>(x + s);
-            float4 o;
-            o.x = act_fwd(v.x * sc + sh, act); o.y = act_fwd(v.y * sc + sh, act); o.z = act_fwd(v.z * sc + sh, act); o.w = act_fwd(v.w * sc + sh, act);
-            *reinterpret_cast<float4*>(y + s) = o;
-            if (POOL) acc += (o.x + o.y) + (o.z + o.w);
-        }
-    } else {
-        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) { const float o = act_fwd(x[s] * sc + sh, act); y[s] = o; if (POOL) acc += o; }
-    }
-    if (POOL) {
-        acc = block_sum<4>(acc, red);
-        if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
-    }
-}
-// pooled[plane] = sum over the chunks of a plane (<= 64), in chunk order
-__global__ __launch_bounds__(256) void plane_chunk_sum_kernel(const float* __restrict__ psum, float* __restrict__ pooled, int planes, int nch) {
-    const int pl = blockIdx.x * 256 + threadIdx.x;
-    if (pl >= planes) return;
-    float a = 0.f;
-    for (int i = 0; i < nch; ++i) a += psum[(int64_t)pl * nch + i];
-    pooled[pl] = a;
-}
 // backward reductions per channel: sums[c] = (sum du, sum du * xhat), du = dy * act'(u).  grid (C, B, slabs)
 __global__ __launch_bounds__(256) void bn_act_bwd_stage1(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                          const float* __restrict__ var, const float* __restrict__ w, const float* __restrict__ b,
@@ -245,11 +151,12 @@ __device__ __forceinline__ BnPart bn_part_of(float n, float a, float q, float pi
 // All partials of channel c (parts[c][nparts] as float4 (n, mean, M2, -)) merged by ONE wave; every wave of a workgroup does it redundantly (no LDS,
 // no barrier).  Lane l folds partials l, l + 64, ... in index order, then a butterfly in which both partners merge (lower lane, higher lane): the
 // result is bit-identical in every lane, every wave and every workgroup.
-__device__ __forceinline__ BnPart bn_fold(const float* __restrict__ parts, int c, int nparts) {
+__device__ __forceinline__ BnPart bn_fold(const float* __restrict__ parts, int c, int nparts, int64_t cstride = -1, int64_t istride = 1) {
+    // default layout parts[c][nparts]; (cstride, istride) = (1, C): parts[nparts][C] -- the all-gathered per-rank partials of synchronised BatchNorm
     const int lane = threadIdx.x & 63;
-    const float4* p = reinterpret_cast<const float4*>(parts) + (int64_t)c * nparts;
+    const float4* p = reinterpret_cast<const float4*>(parts) + (int64_t)c * (cstride < 0 ? nparts : cstride);
     BnPart s; s.n = 0.f; s.mean = 0.f; s.m2 = 0.f;
-    for (int i = lane; i < nparts; i += 64) { const float4 v = p[i]; BnPart t; t.n = v.x; t.mean = v.y; t.m2 = v.z; s = bn_merge(s, t); }
+    for (int i = lane; i < nparts; i += 64) { const float4 v = p[(int64_t)i * istride]; BnPart t; t.n = v.x; t.mean = v.y; t.m2 = v.z; s = bn_merge(s, t); }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         BnPart t; t.n = __shfl_xor(s.n, o); t.mean = __shfl_xor(s.mean, o); t.m2 = __shfl_xor(s.m2, o);
@@ -291,6 +198,7 @@ __global__ __launch_bounds__(256) void bn_parts_merge_kernel(const float* __rest
 struct BnFwdArgs {
     const float* X; const float* w; const float* b; float* Y;
     const float* parts; int nparts;              // training: statistics partials (bn_fold); NULL: use mean / var as given (running statistics)
+    int64_t part_cstride, part_istride;          // layout of parts: (-1, 1) = [C][nparts]; (1, C) = [nparts][C] (gathered per-rank partials)
     float* mean; float* var;                     // training: OUT (saved for backward); else IN
     float* run_mean; float* run_var; float momentum;
     float* psum;                                 // POOL: psum[plane][chunk] = sum of this chunk's outputs (the squeeze-excite pooling, model.py:106)
@@ -306,7 +214,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
     const int64_t S = g.S;
     float m, v;
     if (g.parts) {
-        const BnPart st = bn_fold(g.parts, c, g.nparts);
+        const BnPart st = bn_fold(g.parts, c, g.nparts, g.part_cstride, g.part_istride);
         m = st.mean; v = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
         if (blockIdx.x == 0 && bb == 0 && threadIdx.x == 0) {
             g.mean[c] = m; g.var[c] = v;
@@ -357,7 +265,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
 // =================================================================================================
 template <int TEAM> __device__ __forceinline__ float team_sum(float v, float* red) { return TEAM == 64 ? wave_sum(v) : block_sum<4>(v, red); }
 
-template <int TEAM, int KP, int BMAX, bool POOL>
+// STATS: stop after the statistics and leave ONE partial (n, mean, M2) per channel in g.psum[c] -- the local half of synchronised BatchNorm
+template <int TEAM, int KP, int BMAX, bool POOL, bool STATS = false>
 __global__ __launch_bounds__(256) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
     __shared__ float red[4];
     const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
@@ -388,6 +297,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd_res_kernel(BnFwdArgs g, int B)
             q += ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
         }
     q = team_sum<TEAM>(q, red);
+    if (STATS) {
+        if (tl == 0) reinterpret_cast<float4*>(g.psum)[c] = make_float4(n, m, q, 0.f);
+        return;
+    }
     const float var = q / n;
     if (tl == 0) {
         g.mean[c] = m; g.var[c] = var;
@@ -884,37 +797,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_rows_kernel(const float* __r
 //   dW[m][k] = sum_b dWb[b][m][k] * gate[b][k] ;   dgate[b][k] = sum_m dWb[b][m][k] * W[m][k]
 // (the second is sum_s dz * y of the unfused form, with the sum over the plane done by the weight-gradient GEMM)
 // =================================================================================================
-__global__ __launch_bounds__(256) void gate_weights_fwd_kernel(const float* __restrict__ W, const float* __restrict__ gate, float* __restrict__ Wb,
-                                                               int K, int64_t MK) {
-    const float* g = gate + (int64_t)blockIdx.y * K; float* o = Wb + (int64_t)blockIdx.y * MK;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MK; i += (int64_t)gridDim.x * 256) o[i] = W[i] * g[i % K];
-}
-__global__ __launch_bounds__(256) void gate_weights_bwd_w_kernel(const float* __restrict__ dWb, const float* __restrict__ gate, float* __restrict__ dW,
-                                                                 int B, int K, int64_t MK) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= MK) return;
-    const int k = (int)(i % K);
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dWb[(int64_t)b * MK + i] * gate[(int64_t)b * K + k];
-    dW[i] = s;
-}
 // workgroup = 64 columns of sample b x 4 row lanes (rows m = lane, lane + 4, ...: consecutive threads read consecutive floats of a row);
 // the four partial sums are added in lane order through LDS
-__global__ __launch_bounds__(256) void gate_weights_bwd_g_kernel(const float* __restrict__ dWb, const float* __restrict__ W, float* __restrict__ dgate,
-                                                                 int M, int K) {
-    __shared__ float part[256];
-    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + col;
-    float s = 0.f;
-    if (k < K) {
-        const float* d = dWb + (int64_t)blockIdx.y * M * K;
-#pragma unroll 4
-        for (int m = rl; m < M; m += 4) s += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
-    }
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (rl == 0 && k < K) dgate[(int64_t)blockIdx.y * K + k] = (part[col] + part[64 + col]) + (part[128 + col] + part[192 + col]);
-}
 
 // =================================================================================================
 // Squeeze-excite plane ops (efficientnet/model.py:105-110): y = x * gate[b,c] ; dgate[b,c] = sum_s dy * x ;
@@ -931,13 +815,6 @@ __global__ __launch_bounds__(256) void plane_bias_add_kernel(const float* __rest
     const float* x = X + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] + bv;
 }
-// y = x * gate[plane] + r   (MBConv skip connection with per-sample drop_connect scale, model.py:118-122)
-__global__ __launch_bounds__(256) void plane_scale_add_kernel(const float* __restrict__ X, const float* __restrict__ gate, const float* __restrict__ R,
-                                                              float* __restrict__ Y, int64_t S) {
-    const float gt = gate[blockIdx.y];
-    const float* x = X + (int64_t)blockIdx.y * S; const float* r = R + (int64_t)blockIdx.y * S; float* y = Y + (int64_t)blockIdx.y * S;
-    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * gt + r[s];
-}
 __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ A, const float* __restrict__ Bm, float* __restrict__ out, int64_t S) {
     __shared__ float red[4];
     const float* a = A + (int64_t)blockIdx.x * S; const float* b = Bm + (int64_t)blockIdx.x * S;
@@ -946,56 +823,11 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
-__global__ __launch_bounds__(256) void plane_scale_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ gate, const float* __restrict__ dpool,
-                                                              float* __restrict__ dX, int64_t S) {
-    const float gt = gate[blockIdx.y], dp = dpool[blockIdx.y];
-    const float* g = dY + (int64_t)blockIdx.y * S; float* d = dX + (int64_t)blockIdx.y * S;
-    for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) d[s] = g[s] * gt + dp;
-}
 
 // ---- squeeze-excite excitation MLP on the pooled [B, C] vector (efficientnet/model.py:106-110) -------------------
 //   p = pooled_sum / S ; hpre = W1 p + b1 ; h = swish(hpre) ; gate = sigmoid(W2 h + b2)
-// Every dot product is one WAVE reading a contiguous weight row (W1 [Cs][C], W2 [C][Cs]): B*Cs and B*C waves instead of the
-// earlier one-workgroup-per-sample kernel whose W2 walk was strided (84 us per layer at B = 6, latency bound).
-constexpr int SE_MAX_C = 4096, SE_MAX_CS = 256, SE_CCHUNK = 256;
-// hpre[b][j] = b1[j] + sum_c W1[j][c] * pooled_sum[b][c] / S ; also p[b][c] (kept for the weight gradients).  grid (ceil(Cs/4), B)
-__global__ __launch_bounds__(256) void se_hidden_kernel(const float* __restrict__ pooled_sum, float inv_S, const float* __restrict__ W1,
-                                                        const float* __restrict__ b1, float* __restrict__ p_out, float* __restrict__ hpre_out,
-                                                        int C, int Cs) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (blockIdx.x == 0) for (int c = threadIdx.x; c < C; c += 256) p_out[(int64_t)b * C + c] = pooled_sum[(int64_t)b * C + c] * inv_S;
-    if (j >= Cs) return;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += W1[(int64_t)j * C + c] * (pooled_sum[(int64_t)b * C + c] * inv_S);
-    s = wave_sum(s);
-    if (lane == 0) hpre_out[(int64_t)b * Cs + j] = s + b1[j];
-}
-// gate[b][c] = sigmoid(b2[c] + sum_j W2[c][j] * swish(hpre[b][j])).  grid (ceil(C/4), B)
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ hpre, const float* __restrict__ W2, const float* __restrict__ b2,
-                                                      float* __restrict__ gate, int C, int Cs) {
-    const int b = blockIdx.y, lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (c >= C) return;
-    float s = 0.f;
-    for (int j = lane; j < Cs; j += 64) { const float hp = hpre[(int64_t)b * Cs + j]; s += W2[(int64_t)c * Cs + j] * (hp * sigm(hp)); }
-    s = wave_sum(s);
-    if (lane == 0) gate[(int64_t)b * C + c] = sigm(s + b2[c]);
-}
-// backward.  dz2 = dgate * gate * (1 - gate) ; part[b][chunk][j] = sum_{c in chunk} dz2[b][c] * W2[c][j]   (thread = j: coalesced W2 rows)
-// grid (ceil(C / SE_CCHUNK), B), Cs <= 256 threads active
-__global__ __launch_bounds__(256) void se_bwd_hidden_partial_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                                    const float* __restrict__ W2, float* __restrict__ dz2_out,
-                                                                    float* __restrict__ part, int C, int Cs) {
-    __shared__ float dz[SE_CCHUNK];
-    const int b = blockIdx.y, c0 = blockIdx.x * SE_CCHUNK, j = threadIdx.x;
-    const int c = c0 + threadIdx.x;
-    if (c < C) { const float g = gate[(int64_t)b * C + c], v = dgate[(int64_t)b * C + c] * g * (1.0f - g); dz[threadIdx.x] = v; dz2_out[(int64_t)b * C + c] = v; }
-    __syncthreads();
-    if (j >= Cs) return;
-    const int n = min(SE_CCHUNK, C - c0);
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += dz[i] * W2[(int64_t)(c0 + i) * Cs + j];
-    part[((int64_t)b * gridDim.x + blockIdx.x) * Cs + j] = s;
-}
+// Every dot product is one WAVE reading a contiguous weight row (W1 [Cs][C], W2 [C][Cs]); the kernels are further down (r04: 2 + 3 launches).
+constexpr int SE_MAX_C = 4096, SE_MAX_CS = 256;
 // dhpre[b][j] = swish'(hpre) * sum_chunks part ; then dpool[b][c] = sum_j dhpre[b][j] * W1[j][c] / S.  grid (ceil(C/256), B); every
 // workgroup recomputes the (tiny) dhpre vector of its sample into LDS, workgroup 0 also writes it out
 __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restrict__ part, const float* __restrict__ hpre, const float* __restrict__ W1,
@@ -1016,22 +848,6 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
     float s = 0.f;
     for (int j = 0; j < Cs; ++j) s += dh[j] * W1[(int64_t)j * C + c];
     dpool[(int64_t)b * C + c] = s * inv_S;
-}
-// weight gradients (sums over the batch): thread per (c, j)
-__global__ __launch_bounds__(256) void se_gate_wgrad_kernel(const float* __restrict__ dz2, const float* __restrict__ dhpre, const float* __restrict__ p,
-                                                            const float* __restrict__ hpre, float* __restrict__ dW1, float* __restrict__ db1,
-                                                            float* __restrict__ dW2, float* __restrict__ db2, int B, int C, int Cs) {
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)C * Cs) return;
-    const int c = (int)(idx / Cs), j = (int)(idx % Cs);
-    float a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float hp = hpre[(int64_t)b * Cs + j], dz = dz2[(int64_t)b * C + c], dh = dhpre[(int64_t)b * Cs + j];
-        a2 += dz * (hp * sigm(hp)); a1 += dh * p[(int64_t)b * C + c]; s2 += dz; s1 += dh;
-    }
-    dW2[(int64_t)c * Cs + j] = a2; dW1[(int64_t)j * C + c] = a1;
-    if (j == 0) db2[c] = s2;
-    if (c == 0) db1[j] = s1;
 }
 
 // ---- r04: the same excitation MLP in fewer launches (32 MBConv blocks x 10 micro-kernels of 4..24 us were 2.9 ms of a 76-ms cfg2 step) ---------
@@ -1152,37 +968,7 @@ using namespace segx;
 #define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
 
 extern "C" int64_t segx_bn_ws_floats(int B, int C) { return (int64_t)B * C * BN_SLABS * 2; }
-extern "C" int segx_bn_stats(const float* X, float* mean, float* var, float* run_mean, float* run_var, float* ws,
-                             int B, int C, int64_t S, float momentum, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && ws && B > 0 && C > 0 && S > 0 && (!run_mean == !run_var), "segx_bn_stats: bad args");
-    SEGX_REQUIRE(B <= 65535, "segx_bn_stats: batch too large");
-    hipLaunchKernelGGL(bn_stats_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, ws, C, S);
-    hipLaunchKernelGGL(bn_stats_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, X, (const float*)ws, mean, var, run_mean, run_var, B, C, S, momentum, bn_slabs(S));
-    return check_launch("segx_bn_stats");
-}
-extern "C" int segx_bn_merge_stats(const float* all, float* mean, float* var, float* run_mean, float* run_var, int world, int C, int64_t n_per_rank,
-                                   float momentum, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(all && mean && var && world > 0 && C > 0 && n_per_rank > 0 && (!run_mean == !run_var), "segx_bn_merge_stats: bad args");
-    hipLaunchKernelGGL(bn_merge_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, all, mean, var, run_mean, run_var, world, C, (float)n_per_rank, momentum);
-    return check_launch("segx_bn_merge_stats");
-}
-extern "C" int segx_bn_act_fwd(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y,
-                               int B, int C, int64_t S, float eps, int act, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3, "segx_bn_act_fwd: bad args");
-    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL((bn_act_fwd_kernel<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, (float*)nullptr, C, S, eps, act);
-    return check_launch("segx_bn_act_fwd");
-}
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
-extern "C" int segx_bn_act_fwd_pool(const float* X, const float* mean, const float* var, const float* w, const float* b, float* Y, float* pooled, float* ws,
-                                    int B, int C, int64_t S, float eps, int act, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && pooled && ws && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3, "segx_bn_act_fwd_pool: bad args");
-    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd_pool: more than 65535 (sample, channel) planes");
-    const int nch = plane_chunks(S, 8);
-    hipLaunchKernelGGL((bn_act_fwd_kernel<true>), dim3(nch, B * C), dim3(256), 0, stream, X, mean, var, w, b, Y, ws, C, S, eps, act);
-    hipLaunchKernelGGL(plane_chunk_sum_kernel, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, pooled, B * C, nch);
-    return check_launch("segx_bn_act_fwd_pool");
-}
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
                                       const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, void* stream_) {
@@ -1201,43 +987,26 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
                        gate, dpool, inv_S, dc_p, seed, offset, rng_base(), (const float*)nullptr, 0, (float*)nullptr, (float*)nullptr, (int64_t)C * S);
     return check_launch("segx_bn_act_bwd_apply");
 }
-extern "C" int segx_bn_act_bwd(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
-                               float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                               const float* gate, const float* dpool, float inv_S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd: bad args");
-    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_bwd: more than 65535 (sample, channel) planes");
-    hipLaunchKernelGGL(bn_act_bwd_stage1, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, dY, X, mean, var, w, b, ws, C, S, eps, act, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0,
-                       (const uint64_t*)nullptr, (int64_t)C * S);
-    hipLaunchKernelGGL(bn_act_bwd_stage2, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, dw, db, B, C, bn_slabs(S));
-    const float inv_n = training ? 1.0f / ((float)B * (float)S) : 0.f;
-    hipLaunchKernelGGL((bn_act_bwd_apply<false>), dim3(plane_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, var, w, b, (const float*)dw,
-                       (const float*)db, dX, C, S, eps, act, inv_n, gate, dpool, inv_S, 0.f, (uint64_t)0, (uint64_t)0, (const uint64_t*)nullptr, (const float*)nullptr, 0,
-                       (float*)nullptr, (float*)nullptr, (int64_t)C * S);
-    return check_launch("segx_bn_act_bwd");
-}
 
 // ---- r04: two-launch training BatchNorm (bn_stats_partial_kernel / a producer's partials -> bn_act_fwd2_kernel) ------------------------------
 extern "C" int64_t segx_plane_chunks(int64_t S) { return plane_chunks(S, 8); }
 /* pooling chunks per plane that segx_bn_act_fwd2 writes into psum: auto_stats != 0 = the call computes the statistics itself (parts given, nparts = 0) */
 extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) { return (auto_stats && bn_res_form(B, S, false)) ? 1 : plane_chunks(S, 8); }
-extern "C" int64_t segx_bn_nparts(int B, int64_t S) { return (int64_t)B * bn_slabs(S); }
 extern "C" int64_t segx_bn_parts_floats(int B, int C) { return ((int64_t)B * BN_SLABS + 1) * C * 4; }
-extern "C" int segx_bn_stats_partial(const float* X, float* parts, int B, int C, int64_t S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && parts && B > 0 && B <= 65535 && C > 0 && S > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_bn_stats_partial: bad args");
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, parts, C, S);
-    return check_launch("segx_bn_stats_partial");
-}
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                                 int B, int C, int64_t S, float eps, int act, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3 && (!run_mean == !run_var), "segx_bn_act_fwd2: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd2: more than 65535 (sample, channel) planes");
-    SEGX_REQUIRE(!parts || (nparts >= 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0), "segx_bn_act_fwd2: bad partials");
+    SEGX_REQUIRE(!parts || (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_bn_act_fwd2: bad partials");
     SEGX_REQUIRE(dc_p >= 0.f && dc_p < 1.f && (dc_p == 0.f || resid), "segx_bn_act_fwd2: drop_connect needs the skip input and 0 <= p < 1");
     BnFwdArgs g;
     g.X = X; g.w = w; g.b = b; g.Y = Y; g.parts = parts; g.nparts = nparts; g.mean = mean; g.var = var; g.run_mean = run_mean; g.run_var = run_var;
     g.momentum = momentum; g.psum = psum; g.resid = resid; g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base();
-    g.C = C; g.S = S; g.eps = eps; g.act = act;
+    g.C = C; g.S = S; g.eps = eps; g.act = act; g.part_cstride = -1; g.part_istride = 1;
+    if (parts && nparts < 0) {                               // -nparts per-rank partials laid out [ranks][C] (segx_bn_stats_local on every rank, all-gathered)
+        g.nparts = nparts = -nparts; g.part_cstride = 1; g.part_istride = C;
+    }
     if (parts && nparts == 0) {
         // AUTO: the library computes the batch statistics itself -- channel-resident (one launch) where the channel's B planes fit a team's registers,
         // otherwise partials into `parts` (segx_bn_parts_floats) + the folding apply pass below
@@ -1259,7 +1028,7 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
         hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, B, bn_slabs(S)), dim3(256), 0, stream, X, const_cast<float*>(parts), C, S);
         g.nparts = nparts = B * bn_slabs(S);
     }
-    if (parts && nparts > 256) {
+    if (parts && nparts > 256 && g.part_istride == 1) {
         // a producer with many small tiles: one merge launch, the apply pass then folds ONE partial per channel.  The merged partials live behind the
         // producer's (the caller sized the buffer for nparts + 1 per channel).
         float* merged = const_cast<float*>(parts) + (int64_t)C * nparts * 4;
@@ -1270,6 +1039,26 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
     if (psum) hipLaunchKernelGGL((bn_act_fwd2_kernel<true>), grid, dim3(256), 0, stream, g);
     else hipLaunchKernelGGL((bn_act_fwd2_kernel<false>), grid, dim3(256), 0, stream, g);
     return check_launch("segx_bn_act_fwd2");
+}
+/* ONE partial (n, mean, M2) per channel of this process's batch: part [C] float4.  One launch where the channel fits a team's registers, else the
+ * slab partials (into ws: segx_bn_parts_floats) + one merge launch */
+extern "C" int segx_bn_stats_local(const float* X, float* part, float* ws, int B, int C, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && part && ws && B > 0 && B <= 65535 && C > 0 && S > 0 && ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0, "segx_bn_stats_local: bad args");
+    const int form = bn_res_form(B, S, false);
+    if (form) {
+        BnFwdArgs g; memset(&g, 0, sizeof(g));
+        g.X = X; g.psum = part; g.C = C; g.S = S;
+        const int team = form >> 4, kp = form & 15;
+        const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
+#define SEGX_BN_ST(T, K) if (team == T && kp == K) { hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, false, true>), rgrid, dim3(256), 0, stream, g, B); return check_launch("segx_bn_stats_local"); }
+        SEGX_BN_ST(64, 1) SEGX_BN_ST(64, 2) SEGX_BN_ST(256, 1) SEGX_BN_ST(256, 2) SEGX_BN_ST(256, 4)
+#undef SEGX_BN_ST
+        return fail(-1, "segx_bn_stats_local: no resident form %d", form);
+    }
+    const int nsl = bn_slabs(S);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(C, B, nsl), dim3(256), 0, stream, X, ws, C, S);
+    hipLaunchKernelGGL(bn_parts_merge_kernel, dim3((C + 3) / 4), dim3(256), 0, stream, (const float*)ws, part, C, B * nsl);
+    return check_launch("segx_bn_stats_local");
 }
 extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                 float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
@@ -1473,19 +1262,6 @@ extern "C" int segx_dwconv2d_bwd_weight(const float* dY, const float* X, float* 
     SEGX_DW_DISPATCH(dwconv_wgrad_rows_kernel, dY, X, part, C, H, Wd, OH, OW, pad_t, pad_l, g.tiles_x, g.tiles_x * g.tiles_y, g.txw_log2);
     return check_launch("segx_dwconv2d_bwd_weight");
 }
-extern "C" int segx_gate_weights_fwd(const float* W, const float* gate, float* Wb, int B, int M, int K, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(W && gate && Wb && B > 0 && B <= 65535 && M > 0 && K > 0, "segx_gate_weights_fwd: bad args");
-    const int64_t MK = (int64_t)M * K;
-    hipLaunchKernelGGL(gate_weights_fwd_kernel, dim3((unsigned)i64min(1024, (MK + 255) / 256), B), dim3(256), 0, stream, W, gate, Wb, K, MK);
-    return check_launch("segx_gate_weights_fwd");
-}
-extern "C" int segx_gate_weights_bwd(const float* dWb, const float* W, const float* gate, float* dW, float* dgate, int B, int M, int K, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dWb && W && gate && dW && dgate && B > 0 && B <= 65535 && M > 0 && K > 0, "segx_gate_weights_bwd: bad args");
-    const int64_t MK = (int64_t)M * K;
-    hipLaunchKernelGGL(gate_weights_bwd_w_kernel, dim3((unsigned)((MK + 255) / 256)), dim3(256), 0, stream, dWb, gate, dW, B, K, MK);
-    hipLaunchKernelGGL(gate_weights_bwd_g_kernel, dim3((K + 63) / 64, B), dim3(256), 0, stream, dWb, W, dgate, M, K);
-    return check_launch("segx_gate_weights_bwd");
-}
 extern "C" int segx_plane_scale(const float* X, const float* gate, float* Y, int64_t planes, int64_t S, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && gate && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale: bad args");
     hipLaunchKernelGGL(plane_scale_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, gate, Y, S);
@@ -1496,40 +1272,8 @@ extern "C" int segx_plane_bias_add(const float* X, const float* bias, float* Y, 
     hipLaunchKernelGGL(plane_bias_add_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, bias, Y, C, S);
     return check_launch("segx_plane_bias_add");
 }
-extern "C" int segx_plane_scale_add(const float* X, const float* gate, const float* R, float* Y, int64_t planes, int64_t S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(X && gate && R && Y && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_add: bad args");
-    hipLaunchKernelGGL(plane_scale_add_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, X, gate, R, Y, S);
-    return check_launch("segx_plane_scale_add");
-}
 extern "C" int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, int64_t S, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(A && Bm && out && planes > 0 && S > 0 && planes < 2147483647LL, "segx_plane_dot: bad args");
     hipLaunchKernelGGL(plane_dot_kernel, dim3((unsigned)planes), dim3(256), 0, stream, A, Bm, out, S);
     return check_launch("segx_plane_dot");
-}
-extern "C" int segx_plane_scale_bwd(const float* dY, const float* gate, const float* dpool, float* dX, int64_t planes, int64_t S, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dY && gate && dpool && dX && planes > 0 && S > 0 && planes <= 65535, "segx_plane_scale_bwd: bad args");
-    hipLaunchKernelGGL(plane_scale_bwd_kernel, dim3(plane_chunks(S, 8), (unsigned)planes), dim3(256), 0, stream, dY, gate, dpool, dX, S);
-    return check_launch("segx_plane_scale_bwd");
-}
-extern "C" int segx_se_gate_fwd(const float* pooled_sum, float inv_S, const float* W1, const float* b1, const float* W2, const float* b2,
-                                float* p, float* hpre, float* gate, int B, int C, int Cs, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(pooled_sum && W1 && b1 && W2 && b2 && p && hpre && gate && B > 0 && C > 0 && Cs > 0, "segx_se_gate_fwd: bad args");
-    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_gate_fwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
-    hipLaunchKernelGGL(se_hidden_kernel, dim3((Cs + 3) / 4, B), dim3(256), 0, stream, pooled_sum, inv_S, W1, b1, p, hpre, C, Cs);
-    hipLaunchKernelGGL(se_gate_kernel, dim3((C + 3) / 4, B), dim3(256), 0, stream, (const float*)hpre, W2, b2, gate, C, Cs);
-    return check_launch("segx_se_gate_fwd");
-}
-extern "C" int64_t segx_se_ws_floats(int B, int C, int Cs) { return (int64_t)B * (C + Cs) + (int64_t)B * ((C + SE_CCHUNK - 1) / SE_CCHUNK) * Cs; }
-extern "C" int segx_se_gate_bwd(const float* dgate, const float* gate, const float* hpre, const float* p, const float* W1, const float* W2,
-                                float inv_S, float* dpool, float* dW1, float* db1, float* dW2, float* db2, float* ws /* segx_se_ws_floats */,
-                                int B, int C, int Cs, void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dgate && gate && hpre && p && W1 && W2 && dpool && dW1 && db1 && dW2 && db2 && ws && B > 0 && C > 0 && Cs > 0, "segx_se_gate_bwd: bad args");
-    SEGX_REQUIRE(C <= SE_MAX_C && Cs <= SE_MAX_CS && B <= 65535, "segx_se_gate_bwd: C=%d / Cs=%d exceed %d / %d", C, Cs, SE_MAX_C, SE_MAX_CS);
-    const int nchunks = (C + SE_CCHUNK - 1) / SE_CCHUNK;
-    float* dz2 = ws; float* dhpre = ws + (int64_t)B * C; float* part = dhpre + (int64_t)B * Cs;
-    hipLaunchKernelGGL(se_bwd_hidden_partial_kernel, dim3(nchunks, B), dim3(256), 0, stream, dgate, gate, W2, dz2, part, C, Cs);
-    hipLaunchKernelGGL(se_bwd_pool_kernel, dim3((C + 255) / 256, B), dim3(256), 0, stream, (const float*)part, hpre, W1, inv_S, dhpre, dpool, C, Cs, nchunks);
-    hipLaunchKernelGGL(se_gate_wgrad_kernel, dim3((unsigned)(((int64_t)C * Cs + 255) / 256)), dim3(256), 0, stream, (const float*)dz2, (const float*)dhpre,
-                       p, hpre, dW1, db1, dW2, db2, B, C, Cs);
-    return check_launch("segx_se_gate_bwd");
 }

@@ -199,7 +199,7 @@ def check_equal_batch(n, group=None, host_group=None):
 def enable_sync_batchnorm(group=None, force=False):
     """Synchronised BatchNorm for libsegx's fused BN(+act) op (replaces nn.SyncBatchNorm, train2d.py:1109).
 
-    forward : ONE all-gather of [2C] floats per BN layer (mean, biased var), merged with Chan's formula by one kernel;
+    forward : ONE all-gather of [C] float4 partials (n, mean, M2) per BN layer, merged with Chan's formula inside the apply pass (no merge launch);
     backward: ONE all-reduce of [2C] floats (sum du*xhat, sum du); the apply kernel then uses the global sums / count.
     Parameter gradients stay LOCAL sums (the flat-gradient all-reduce averages them like every other gradient)."""
     from . import functional as SF
@@ -209,8 +209,8 @@ def enable_sync_batchnorm(group=None, force=False):
     world = dist.get_world_size(group)
 
     def stats_sync(loc):
-        """loc [2C] = this rank's (mean, biased var) -> (all [world, 2C], world).  Every rank holds the same per-GPU batch
-        (bs // world, train2d.py:791), so the counts need not travel and the merge (segx_bn_merge_stats) is one kernel."""
+        """loc [C] float4 = this rank's (n, mean, M2) partial per channel (segx_bn_stats_local) -> (all [world][C] float4, world): the BatchNorm
+        apply pass merges the ranks' partials itself (segx_bn_act_fwd2, nparts = -world); the counts travel with the partials."""
         allv = loc.new_empty(world * loc.numel())
         dist.all_gather_into_tensor(allv, loc, group=group)
         return allv, world

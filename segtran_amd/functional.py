@@ -630,12 +630,12 @@ def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, 
         parts = _empty(x, L.bn_parts_floats(B, C))
         L.bn_act_fwd2(x, parts, 0, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
         return y, mean, var, B * S, psum, nch
-    # synchronised BN: local (mean, var) written straight into the [2C] exchange buffer, ONE all-gather, ONE merge kernel
-    loc = _empty(x, 2 * C)
-    L.bn_stats(x, loc[:C], loc[C:], None, None, _empty(x, L.bn_ws(B, C)), B, C, S, momentum)
+    # synchronised BN: ONE local partial (n, mean, M2) per channel (one launch for channel-resident shapes), ONE all-gather of [C] float4, and the
+    # apply pass merges the ranks' partials itself (Chan) and updates the running statistics: 2-3 launches + 1 collective (r03: 5 + 1)
+    loc = _empty(x, 4 * C)
+    L.bn_stats_local(x, loc, _empty(x, L.bn_parts_floats(B, C)), B, C, S)
     allv, world = _bn_stats_sync(loc)
-    L.bn_merge_stats(allv, mean, var, run_mean, run_var, world, C, B * S, momentum)
-    L.bn_act_fwd2(x, None, 0, mean, var, None, None, 0.0, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+    L.bn_act_fwd2(x, allv, -world, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
     return y, mean, var, B * S * world, psum, nch
 
 
@@ -794,50 +794,6 @@ def dwconv2d(x, w, stride, pad):
     return _DWConv.apply(x, w, int(stride), tuple(int(p) for p in pad))
 
 
-class _SqueezeExcite(torch.autograd.Function):
-    """x * sigmoid(W2 swish(W1 mean_hw(x) + b1) + b2)   (efficientnet/model.py:105-110), all on libsegx: plane pooling /
-    scaling kernels plus one-workgroup-per-sample kernels for the [B, C]-sized excitation MLP and its gradients."""
-
-    @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
-        L = segx.lib()
-        x = _c(x)
-        B, C = x.shape[:2]
-        Cs = w1.shape[0]
-        S = x.numel() // (B * C)
-        pooled = _empty(x, B * C)
-        L.rowsum(x, pooled, B * C, S)
-        W1, W2 = _c(w1.reshape(Cs, C)), _c(w2.reshape(C, Cs))
-        p, hpre, gate = _empty(x, B, C), _empty(x, B, Cs), _empty(x, B, C)
-        L.se_gate_fwd(pooled, 1.0 / S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
-        y = torch.empty_like(x)
-        L.plane_scale(x, gate, y, B * C, S)
-        ctx.save_for_backward(x, p, hpre, gate, W1, W2)
-        ctx.shapes = (tuple(w1.shape), tuple(w2.shape), S)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        L = segx.lib()
-        x, p, hpre, gate, W1, W2 = ctx.saved_tensors
-        w1s, w2s, S = ctx.shapes
-        B, C = p.shape
-        Cs = hpre.shape[1]
-        dy = _c(dy)
-        dgate = _empty(x, B * C)
-        L.plane_dot(dy, x, dgate, B * C, S)
-        dpool = _empty(x, B * C)
-        dW1, db1, dW2, db2 = _empty(x, Cs, C), _empty(x, Cs), _empty(x, C, Cs), _empty(x, C)
-        L.se_gate_bwd(dgate, gate, hpre, p, W1, W2, 1.0 / S, dpool, dW1, db1, dW2, db2, _empty(x, L.se_ws(B, C, Cs)), B, C, Cs)
-        dx = torch.empty_like(x)
-        L.plane_scale_bwd(dy, gate, dpool, dx, B * C, S)
-        return dx, dW1.view(w1s), db1, dW2.view(w2s), db2
-
-
-def squeeze_excite(x, w1, b1, w2, b2):
-    return _SqueezeExcite.apply(x, w1, b1, w2, b2)
-
-
 def _se_excite(L, x, psum, nch, S, w1, b1, w2, b2, Wproj=None):
     """The excitation MLP on the pooling chunks of the BatchNorm pass (segx_se_fwd2, two launches): -> (p, hpre, gate, W1, W2, Wb or None)."""
     B, C = x.shape[0], x.shape[1]
@@ -896,41 +852,6 @@ class _BNActSE(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
 
 
-class _BNActGate(torch.autograd.Function):
-    """BatchNorm + activation with the squeeze-excite gate computed from the same pass: returns (y, gate [B, C]) -- y is NOT multiplied by the
-    gate; the caller folds the gate into the weights of the pointwise convolution that follows (conv1x1_gated), so neither y * gate nor its
-    gradient is ever materialised.  Backward takes (dy, dgate): dgate -> squeeze-excite MLP -> dpool, and BatchNorm backward on dy + dpool / S."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, run_mean, run_var, training, momentum, eps, act, w1, b1, w2, b2):
-        L = segx.lib()
-        x = _c(x)
-        B, C = x.shape[0], x.shape[1]
-        S = x.numel() // (B * C)
-        y, mean, var, n, psum, nch = _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=True)
-        p, hpre, gate, W1, W2, _ = _se_excite(L, x, psum, nch, S, w1, b1, w2, b2)
-        ctx.cfg = (B, C, S, eps, act, training, n)
-        ctx.shapes = (tuple(w1.shape), tuple(w2.shape))
-        ctx.save_for_backward(x, mean, var, w, b, p, hpre, gate, W1, W2)
-        return y, gate
-
-    @staticmethod
-    def backward(ctx, dy, dgate):
-        L = segx.lib()
-        x, mean, var, w, b, p, hpre, gate, W1, W2 = ctx.saved_tensors
-        S = ctx.cfg[2]
-        w1s, w2s = ctx.shapes
-        dpool, dW1, db1, dW2, db2, _ = _se_excite_backward(L, x, None, None, _c(dgate).reshape(-1), gate, hpre, p, W1, W2, S)
-        dx, dw, db = _bn_act_backward(L, _c(dy), x, mean, var, w, b, ctx.cfg, None, dpool, 1.0)
-        return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
-
-
-def bn_act_gate(x, bn, act, w1, b1, w2, b2):
-    """(bn_act(x, bn, act), squeeze-excite gate of it [B, C]) from one pass (see _BNActGate); pair with conv1x1_gated."""
-    _bn_tick(bn)
-    return _BNActGate.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
-
-
 class _BNActGateW(torch.autograd.Function):
     """The middle of an MBConv block (efficientnet/model.py:100-113) up to the operands of its projection GEMM: BatchNorm + swish of the depthwise
     output, the squeeze-excite gate from the same pass, and the gate folded straight into per-sample projection weights
@@ -979,79 +900,10 @@ def conv1x1_per_sample(x, Wb):
     return bgemm(Wb, x, spec)
 
 
-class _GateWeights(torch.autograd.Function):
-    """Wb[b] = W * gate[b][None, :] (the squeeze-excite gate folded into pointwise-convolution weights) and its chain rule."""
-
-    @staticmethod
-    def forward(ctx, W, gate):
-        L = segx.lib()
-        W, gate = _c(W), _c(gate)
-        M, K = W.shape
-        B = gate.shape[0]
-        Wb = _empty(W, B, M, K)
-        L.gate_weights_fwd(W, gate, Wb, B, M, K)
-        ctx.save_for_backward(W, gate)
-        return Wb
-
-    @staticmethod
-    def backward(ctx, dWb):
-        L = segx.lib()
-        W, gate = ctx.saved_tensors
-        M, K = W.shape
-        B = gate.shape[0]
-        dW, dgate = torch.empty_like(W), torch.empty_like(gate)
-        L.gate_weights_bwd(_c(dWb), W, gate, dW, dgate, B, M, K)
-        return dW, dgate
-
-
-def conv1x1_gated(x, weight, gate):
-    """conv1x1(x * gate[:, :, None, None], weight) computed as the pointwise convolution of x with per-sample weights weight * gate[b]
-    (exact re-association; efficientnet/model.py:110-113): one GEMM per sample with its own A matrix; autograd returns the per-sample weight
-    gradient, from which _GateWeights derives dW and dgate -- no gated activation, no plane-dot pass."""
-    B, Cin = x.shape[0], x.shape[1]
-    S = x.numel() // (B * Cin)
-    Cout = weight.shape[0]
-    Wb = _GateWeights.apply(weight.reshape(Cout, Cin), gate)
-    spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1))
-    return bgemm(Wb, x, spec)
-
-
 def bn_act_se(x, bn, act, w1, b1, w2, b2):
     """squeeze_excite(bn_act(x, bn, act), w1, b1, w2, b2), fused (see _BNActSE)."""
     _bn_tick(bn)
     return _BNActSE.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.training, float(bn.momentum), float(bn.eps), act, w1, b1, w2, b2)
-
-
-class _SkipAdd(torch.autograd.Function):
-    """y = x * scale[b] + r: the MBConv skip connection with the per-sample drop_connect scale, one pass."""
-
-    @staticmethod
-    def forward(ctx, x, scale_b, r):
-        L = segx.lib()
-        x, r = _c(x), _c(r)
-        B, C = x.shape[:2]
-        S = x.numel() // (B * C)
-        gate = scale_b.reshape(B, 1).expand(B, C).contiguous()
-        y = torch.empty_like(x)
-        L.plane_scale_add(x, gate, r, y, B * C, S)
-        ctx.save_for_backward(gate)
-        ctx.dims = (B * C, S)
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        L = segx.lib()
-        (gate,) = ctx.saved_tensors
-        dy = _c(dy)
-        dx = torch.empty_like(dy)
-        L.plane_scale(dy, gate, dx, *ctx.dims)
-        return dx, None, dy
-
-
-def skip_add(x, r, scale_b=None):
-    if scale_b is None:
-        scale_b = torch.ones(x.shape[0], dtype=torch.float32, device=x.device)
-    return _SkipAdd.apply(x, scale_b, r)
 
 
 # -------------------------------------------------------------------------------------------------

@@ -248,18 +248,6 @@ class SegxLib:
     def bn_ws(self, B, C):
         return int(self.c.segx_bn_ws_floats(B, C))
 
-    def bn_stats(self, X, mean, var, run_mean, run_var, ws, B, C, S, momentum):
-        self._call('segx_bn_stats', X, X, mean, var, run_mean, run_var, ws, B, C, S, momentum)
-
-    def bn_act_fwd(self, X, mean, var, w, b, Y, B, C, S, eps, act):
-        self._call('segx_bn_act_fwd', X, X, mean, var, w, b, Y, B, C, S, eps, act)
-
-    def bn_act_bwd(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0):
-        self._call('segx_bn_act_bwd', X, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate, dpool, float(inv_S))
-
-    def bn_act_fwd_pool(self, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act):
-        self._call('segx_bn_act_fwd_pool', X, X, mean, var, w, b, Y, pooled, ws, B, C, S, eps, act)
-
     # ---- r04: two-launch training BatchNorm, squeeze-excite in 2 + 3 launches -----------------------
     def plane_chunks(self, S):
         return int(self.c.segx_plane_chunks(S))
@@ -267,14 +255,11 @@ class SegxLib:
     def bn_pool_chunks(self, B, S, auto_stats):
         return int(self.c.segx_bn_pool_chunks(B, S, 1 if auto_stats else 0))
 
-    def bn_nparts(self, B, S):
-        return int(self.c.segx_bn_nparts(B, S))
-
     def bn_parts_floats(self, B, C):
         return int(self.c.segx_bn_parts_floats(B, C))
 
-    def bn_stats_partial(self, X, parts, B, C, S):
-        self._call('segx_bn_stats_partial', X, X, parts, B, C, S)
+    def bn_stats_local(self, X, part, ws, B, C, S):
+        self._call('segx_bn_stats_local', X, X, part, ws, B, C, S)
 
     def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act):
         self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act)
@@ -321,41 +306,17 @@ class SegxLib:
     def plane_scale(self, X, gate, Y, planes, S):
         self._call('segx_plane_scale', X, X, gate, Y, planes, S)
 
-    def bn_merge_stats(self, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum):
-        self._call('segx_bn_merge_stats', allv, allv, mean, var, run_mean, run_var, world, C, n_per_rank, momentum)
-
     def bn_act_bwd_reduce(self, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
         self._call('segx_bn_act_bwd_reduce', X, dY, X, mean, var, w, b, dw, db, ws, B, C, S, eps, act, gate, dpool, float(inv_S), float(dc_p), seed, offset)
 
     def bn_act_bwd_apply(self, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0):
         self._call('segx_bn_act_bwd_apply', X, dY, X, mean, var, w, b, sdw, sdb, dX, B, C, S, eps, act, inv_n, gate, dpool, float(inv_S), float(dc_p), seed, offset)
 
-    def gate_weights_fwd(self, W, gate, Wb, B, M, K):
-        self._call('segx_gate_weights_fwd', W, W, gate, Wb, B, M, K)
-
-    def gate_weights_bwd(self, dWb, W, gate, dW, dgate, B, M, K):
-        self._call('segx_gate_weights_bwd', W, dWb, W, gate, dW, dgate, B, M, K)
-
     def plane_bias_add(self, X, bias, Y, planes, C, S):
         self._call('segx_plane_bias_add', X, X, bias, Y, planes, C, S)
 
-    def plane_scale_add(self, X, gate, R, Y, planes, S):
-        self._call('segx_plane_scale_add', X, X, gate, R, Y, planes, S)
-
-    def se_gate_fwd(self, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs):
-        self._call('segx_se_gate_fwd', gate, pooled, inv_S, W1, b1, W2, b2, p, hpre, gate, B, C, Cs)
-
-    def se_ws(self, B, C, Cs):
-        return int(self.c.segx_se_ws_floats(B, C, Cs))
-
-    def se_gate_bwd(self, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs):
-        self._call('segx_se_gate_bwd', gate, dgate, gate, hpre, p, W1, W2, inv_S, dpool, dW1, db1, dW2, db2, ws, B, C, Cs)
-
     def plane_dot(self, A, B, out, planes, S):
         self._call('segx_plane_dot', A, A, B, out, planes, S)
-
-    def plane_scale_bwd(self, dY, gate, dpool, dX, planes, S):
-        self._call('segx_plane_scale_bwd', dY, dY, gate, dpool, dX, planes, S)
 
     # ---- feature-pyramid kernels (fpn.hip) ----------------------------------------------------------
     def interp_fwd_axis2(self, inp, base, out, outer, n1_in, n1_out, n2_in, n2_out, inner):
@@ -562,15 +523,15 @@ _SIGS = {
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
-    'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_bn_merge_stats': 'pppppiilfp', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_se_ws_floats': 'iii', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
-    'segx_bn_ws_floats': 'ii', 'segx_bn_stats': 'ppppppiilfp', 'segx_bn_act_fwd': 'ppppppiilfip',
-    'segx_bn_act_bwd': 'ppppppppppiilfiippfp', 'segx_bn_act_fwd_pool': 'ppppppppiilfip', 'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
+    'segx_bn_ws_floats': 'ii', 
+    'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
-    'segx_plane_scale_bwd': 'ppppllp', 'segx_se_gate_fwd': 'pfpppppppiiip', 'segx_se_gate_bwd': 'ppppppfppppppiiip', 'segx_plane_scale_add': 'ppppllp', 'segx_plane_bias_add': 'ppplilp', 'segx_gate_weights_fwd': 'pppiiip', 'segx_gate_weights_bwd': 'pppppiiip',
-    'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_nparts': 'il', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_partial': 'ppiilp',
+     'segx_plane_bias_add': 'ppplilp', 
+    'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_local': 'pppiilp',
     'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuulp',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',

@@ -63,7 +63,7 @@ def _case_sync_bn(rank, world, ret):
 
 
 def _case_sync_bn_fused(rank, world, ret):
-    """the fused BatchNorm forms under synchronised BN: bn_act_multi (two layers, ONE exchange) and bn_act_gate + conv1x1_gated (MBConv tail)"""
+    """the fused BatchNorm forms under synchronised BN: bn_act_multi (two layers, ONE exchange) and bn_act_gate_weights + conv1x1_per_sample (MBConv tail)"""
     import torch.nn.functional as F
     from segtran_amd import functional as SF, dist as sdist
     sdist.enable_sync_batchnorm()
@@ -102,8 +102,8 @@ def _case_sync_bn_fused(rank, world, ret):
     sq = F.conv2d(F.adaptive_avg_pool2d(yr, 1), pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
     outr = F.conv2d(torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * yr, pr[4]); outr.backward(G_full)
     x = x_full[sl].clone().requires_grad_(True); pm = [p.clone().requires_grad_(True) for p in ps]
-    yy, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *pm[:4])
-    out = SF.conv1x1_gated(yy, pm[4], gate); out.backward(G_full[sl])
+    yy, Wb = SF.bn_act_gate_weights(x, bn, SF.ACT_SWISH, *pm)
+    out = SF.conv1x1_per_sample(yy, Wb); out.backward(G_full[sl])
     ok &= torch.allclose(out, outr[sl], atol=3e-5) and torch.allclose(x.grad, xr.grad[sl], atol=3e-5)
     for a, b in zip(pm, pr):
         ga = a.grad.clone(); dist.all_reduce(ga)

@@ -73,26 +73,7 @@ def test_dwconv2d(backend, k, stride, pad, H, W):
     close(x.grad, xr.grad, 1e-4); close(w.grad, wr.grad, 1e-4)
 
 
-@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 300, 70, 4, 5)])      # second: 2 channel chunks, Cs > one wave
-def test_squeeze_excite(backend, B, C, Cs, H, W):
-    x = rnd(B, C, H, W, seed=10).requires_grad_(True)
-    ps = [rnd(Cs, C, 1, 1, seed=11, scale=0.5), rnd(Cs, seed=12, scale=0.1), rnd(C, Cs, 1, 1, seed=13, scale=0.5), rnd(C, seed=14, scale=0.1)]
-    ps = [p.requires_grad_(True) for p in ps]
-    y = SF.squeeze_excite(x, *ps)
-    xr = x.detach().clone().requires_grad_(True)
-    pr = [p.detach().clone().requires_grad_(True) for p in ps]
-    sq = F.adaptive_avg_pool2d(xr, 1)
-    sq = F.conv2d(sq, pr[0], pr[1]); sq = sq * torch.sigmoid(sq)
-    yr = torch.sigmoid(F.conv2d(sq, pr[2], pr[3])) * xr
-    close(y, yr.detach())
-    G = rnd(B, C, H, W, seed=15)
-    y.backward(G); yr.backward(G)
-    close(x.grad, xr.grad, 1e-4)
-    for a, r in zip(ps, pr):
-        close(a.grad, r.grad, 1e-4)
-
-
-@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 70, 9, 4, 5), (1, 3, 2, 130, 130), (6, 9, 3, 32, 32), (6, 5, 2, 16, 24)])      # third: several chunks per plane
+@pytest.mark.parametrize('B,C,Cs,H,W', [(3, 12, 4, 9, 7), (2, 70, 9, 4, 5), (1, 3, 2, 130, 130), (6, 9, 3, 32, 32), (6, 5, 2, 16, 24), (2, 300, 70, 4, 5)])      # third: several chunks per plane; last: Cs > one wave
 @pytest.mark.parametrize('training', [True, False])
 def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
     """The one-op form an MBConv block uses (BatchNorm + swish with the squeeze-excite pooling in the same pass, the gate's product rule applied
@@ -125,10 +106,10 @@ def test_bn_act_squeeze_excite_fused(backend, B, C, Cs, H, W, training):
 
 @pytest.mark.parametrize('B,C,Cs,Co,H,W', [(3, 12, 4, 10, 9, 7), (2, 70, 9, 24, 4, 5), (2, 8, 2, 136, 12, 12), (2, 150, 70, 7, 3, 4)])   # last: 3 gate chunks, Cs > one wave
 @pytest.mark.parametrize('training', [True, False])
-@pytest.mark.parametrize('one_op', [True, False], ids=['gate-and-weights-in-one-op', 'gate-then-weights'])
-def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, training, one_op):
-    """MBConv tail as the product runs it: BatchNorm + swish with the squeeze-excite gate from the same pass (bn_act_gate), then the projection as
-    a pointwise convolution with per-sample weights W * gate[b] (conv1x1_gated) -- against BatchNorm -> swish -> squeeze-excite -> conv in PyTorch."""
+def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, training):
+    """MBConv tail as the product runs it: BatchNorm + swish with the squeeze-excite gate from the same pass, written straight into per-sample projection
+    weights W * gate[b] (bn_act_gate_weights), then the projection as a pointwise convolution with those (conv1x1_per_sample) -- against
+    BatchNorm -> swish -> squeeze-excite -> conv in PyTorch."""
     bn, ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01), torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01)
     with torch.no_grad():
         for m in (bn, ref):
@@ -139,12 +120,8 @@ def test_se_gate_folded_into_projection_weights(backend, B, C, Cs, Co, H, W, tra
     ps = [rnd(Cs, C, 1, 1, seed=31, scale=0.5), rnd(Cs, seed=32, scale=0.1), rnd(C, Cs, 1, 1, seed=33, scale=0.5), rnd(C, seed=34, scale=0.1),
           rnd(Co, C, 1, 1, seed=35, scale=0.3)]
     ps = [p.requires_grad_(True) for p in ps]
-    if one_op:          # what MBConvBlock runs (r04): the gate goes straight into the per-sample weights, one autograd node
-        y, Wb = SF.bn_act_gate_weights(x, bn, SF.ACT_SWISH, *ps)
-        out = SF.conv1x1_per_sample(y, Wb)
-    else:
-        y, gate = SF.bn_act_gate(x, bn, SF.ACT_SWISH, *ps[:4])
-        out = SF.conv1x1_gated(y, ps[4], gate)
+    y, Wb = SF.bn_act_gate_weights(x, bn, SF.ACT_SWISH, *ps)
+    out = SF.conv1x1_per_sample(y, Wb)
     xr = x.detach().clone().requires_grad_(True)
     pr = [p.detach().clone().requires_grad_(True) for p in ps]
     yr = _act(ref(xr), 1)
