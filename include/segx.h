@@ -43,7 +43,8 @@ enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
 /* per-call engine selector of segx_gemm_desc.engine: 0 (a zero-initialised desc) = the process default set by segx_tune knob 4 */
 enum { SEGX_ENGINE_SEL_DEFAULT = 0, SEGX_ENGINE_SEL_F32 = 1, SEGX_ENGINE_SEL_BF16X6 = 2 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
-       SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7, SEGX_TILE_WS128x256 = 8, SEGX_TILE_WS64x256 = 9
+       SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7, SEGX_TILE_WS128x256 = 8, SEGX_TILE_WS64x256 = 9,
+       SEGX_TILE_WS96x256 = 10, SEGX_TILE_WS256x96 = 11   /* 96-row side: k-contiguous operand only (A for 96x256, B for 256x96); other layouts quietly take 128x128 */
        /* 6..9: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h (M x N of the workgroup tile) */ };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
@@ -80,6 +81,9 @@ int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc
 /* The library's own choice of workgroup tile and split-K factor for this problem (desc fields tile / splitk / workspace are
  * ignored): callers that want split-K size the workspace from *splitk and pass both back through the desc. */
 int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
+/* The cost model's pick alone, without the table of measured choices segx_gemm_plan consults first (csrc/gemm_tuned.h): what tools/tune_gemm.py compares
+ * its device sweep with when it decides which shapes need a table entry.  Not used on the step. */
+int segx_gemm_plan_model(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk);
 /* The three-plane bf16 image of an fp32 operand for segx_gemm_desc.b_planes (bf16x6 engine): W is nb0 x nb1 matrices of rows x K floats
  * with element strides (s_b0, s_b1, s_row, s_k), one of s_row / s_k equal to 1, K % 8 == 0; planes receives, per matrix, [3][rows][K] bf16
  * (x = hi + mid + lo, each step rounded to nearest even: the split the kernels otherwise do in registers), matrices in (z0, z1) order:

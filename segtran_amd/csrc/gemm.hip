@@ -220,13 +220,13 @@ static bool gemm_vec_ok(const float* A, const float* B, const segx_gemm_desc* d)
 }
 }  // namespace segx
 
-extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk) {
-    using namespace segx;
+namespace segx {
+static int gemm_plan_impl(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk, bool use_table) {
     SEGX_REQUIRE(A && B && d && tile && splitk && d->M > 0 && d->N > 0 && d->K > 0 && d->nb0 > 0 && d->nb1 > 0, "segx_gemm_plan: bad args");
     const bool plain = d->epilogue == SEGX_EPI_NONE;
     int t = SEGX_TILE_128x128, sk = 1;
     const bool vec = gemm_vec_ok(A, B, d);
-    if (plain && !d->gmax && x6_eligible(call_engine(d), d->M, d->N, vec)) {
+    if (use_table && plain && !d->gmax && x6_eligible(call_engine(d), d->M, d->N, vec)) {
         // measured choices first (gemm_tuned.h); a wave-specialised entry still needs its preconditions (they hold for the shapes it was measured on)
         const int nbt = d->nb0 * d->nb1; const bool akc_ = d->a_k == 1, bkc_ = d->b_k == 1;
         for (const TunedGemm& e : kTunedGemm)
@@ -241,6 +241,11 @@ extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_de
     *tile = t; *splitk = sk;
     return 0;
 }
+}  // namespace segx
+
+extern "C" int segx_gemm_plan(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk) { return segx::gemm_plan_impl(A, B, d, tile, splitk, true); }
+// the cost model's own pick, without the measured table (tools/tune_gemm.py compares every candidate with it to decide which shapes need a table entry)
+extern "C" int segx_gemm_plan_model(const float* A, const float* B, const segx_gemm_desc* d, int* tile, int* splitk) { return segx::gemm_plan_impl(A, B, d, tile, splitk, false); }
 
 extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const segx_gemm_desc* d, void* stream_) {
     using namespace segx;
@@ -281,8 +286,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.resid = d->resid;
     SEGX_REQUIRE(!d->resid || (d->epilogue == SEGX_EPI_NONE && !breduce && !d->gmax), "segx_gemm_f32: resid needs a plain epilogue (no GELU, no batch_reduce, no gmax)");
     if (splitk > 1 || breduce) g.C = d->workspace;
-    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS64x256, "segx_gemm_f32: bad tile %d", d->tile);
-    const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS64x256;
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS256x96, "segx_gemm_f32: bad tile %d", d->tile);
+    const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS256x96;
     SEGX_REQUIRE(d->engine >= SEGX_ENGINE_SEL_DEFAULT && d->engine <= SEGX_ENGINE_SEL_BF16X6, "segx_gemm_f32: bad engine selector %d", d->engine);
     const int engine = call_engine(d);
     SEGX_REQUIRE(!ws_tile || engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
@@ -299,7 +304,10 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else plan(d->M, d->N, d->K, nbatch, vec && !gelu, false, splitk, &tile, &sk_unused);
     }
     if (ws_tile && !ws_ok) tile = SEGX_TILE_128x128;
-    const bool ws = x6 && ws_ok && tile >= SEGX_TILE_256x128 && tile <= SEGX_TILE_WS64x256;
+    // the 96-row tiles (channel counts 272 / 160 / 192 / 672 / 960 of the backbone: 3 x 96 = 288 rows cover 272 where 3 x 128 compute 384) stage their 96-row
+    // side with the k-contiguous loader only (the row-contiguous one deals 64 / 128 / 256 rows over a workgroup); no fused GELU
+    if ((tile == SEGX_TILE_WS96x256 && (!akc || gelu)) || (tile == SEGX_TILE_WS256x96 && (!bkc || gelu))) tile = SEGX_TILE_128x128;
+    const bool ws = x6 && ws_ok && tile >= SEGX_TILE_256x128 && tile <= SEGX_TILE_WS256x96;
     if (!vec || (gelu && !ws) || (ws_tile && !x6)) tile = SEGX_TILE_128x128;       // odd shapes / fused GELU: only the default tile (and the wave-specialised ones) are built
 
     dim3 block(256);
@@ -363,7 +371,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
         hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
-        using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>;      // few output channels x many positions (backbone pointwise convolutions)
+        using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>; using Cfg96x256 = TileCfg<1, 4, 3, 2>; using Cfg256x96 = TileCfg<4, 1, 2, 3>;      // few output channels x many positions (backbone pointwise convolutions)
         // pre-split B operand (segx_x6_presplit): the wave-specialised 256 x 128 / 128 x 256 kernels with a copy-only B loader; anything else ignores the planes
         const bool pre = d->b_planes && ws && !gelu && (tile == SEGX_TILE_256x128 || tile == SEGX_TILE_WS128x256);
         if (pre) {
@@ -384,6 +392,8 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
         else if (tile == SEGX_TILE_WS128x128) SEGX_LAUNCHWS_LAYOUT(Cfg128);
         else if (tile == SEGX_TILE_WS128x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg128x256);
         else if (tile == SEGX_TILE_WS64x256 && !gelu) SEGX_LAUNCHWS_LAYOUT(Cfg64x256);
+        else if (tile == SEGX_TILE_WS96x256) { if (bkc) SEGX_LAUNCHWS(Cfg96x256, true, true, SEGX_EPI_NONE); else SEGX_LAUNCHWS(Cfg96x256, true, false, SEGX_EPI_NONE); }
+        else if (tile == SEGX_TILE_WS256x96) { if (akc) SEGX_LAUNCHWS(Cfg256x96, true, true, SEGX_EPI_NONE); else SEGX_LAUNCHWS(Cfg256x96, false, true, SEGX_EPI_NONE); }
         else if (gelu) { if (bkc) SEGX_LAUNCH6(Cfg128, true, true, SEGX_EPI_GELU, 3); else SEGX_LAUNCH6(Cfg128, true, false, SEGX_EPI_GELU, 3); }
         else if (x6_variant > 0 && akc && bkc && (tile == SEGX_TILE_128x128 || tile == SEGX_TILE_AUTO)) {
             switch (x6_variant) { case 1: SEGX_LAUNCH6V(1, 3); break; case 6: SEGX_LAUNCH6V(6, 2); break;

@@ -31,7 +31,7 @@ def test_ctypes_signatures_match_header():
     for name, sig in segx._SIGS.items():
         assert name in decl, name + ' missing from include/segx.h'
         assert decl[name] == sig, '%s: header %s vs binding %s' % (name, decl[name], sig)
-    extra = set(decl) - set(segx._SIGS) - {'segx_version', 'segx_last_error', 'segx_gemm_f32', 'segx_gemm_plan'}
+    extra = set(decl) - set(segx._SIGS) - {'segx_version', 'segx_last_error', 'segx_gemm_f32', 'segx_gemm_plan', 'segx_gemm_plan_model'}
     assert not extra, 'declared but unbound: %s' % sorted(extra)
 
 

@@ -298,12 +298,13 @@ def test_x6_split_early_schedule_gives_the_same_result(backend):
         L.set_engine(prev)
 
 
-@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128, segx.TILE_WS128x256, segx.TILE_WS64x256])
+@pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128, segx.TILE_WS128x256, segx.TILE_WS64x256, segx.TILE_WS96x256, segx.TILE_WS256x96])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(520, 264, 96, True, True, 1, 3), (300, 392, 128, True, False, 2, 2), (260, 136, 192, False, False, 3, 2),
                                                  (264, 260, 96, False, True, 1, 2), (264, 136, 104, True, True, 1, 2)])
 def test_x6_wave_specialised_persistent_stream(backend, tile, M, N, K, akc, bkc, sk, nb):
     """gemm_x6ws.h: producers / consumers of a persistent workgroup walk a STREAM of work items (here 8 workgroups for 12-72 items, ragged
-    edges, batches, split-K slabs; K = 104 is not a whole number of 32-k stages and must quietly take the 4-wave kernel): results must equal the 4-wave bf16x6 kernel bit for bit (same products,
+    edges, batches, split-K slabs; K = 104 is not a whole number of 32-k stages and must quietly take the 4-wave kernel, and so must a 96-row tile whose 96-row
+    side is a row-contiguous operand): results must equal the 4-wave bf16x6 kernel bit for bit (same products,
     same order per accumulator) and fp64 to fp32 rounding."""
     L = backend.L
     prev = L.set_engine('x6')

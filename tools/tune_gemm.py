@@ -1,8 +1,8 @@
 """Measured tile / split-K choices for the GEMM shapes of the BASELINE configurations (GPU box):
     python tools/tune_gemm.py <shapes.txt> [<shapes.txt> ...] > gpurun_out/<tag>/tune_gemm.txt
 reads the `[bench] (M, N, K, batch, A_kcontig, B_kcontig, splitk, tile, 'x6')` lines bench.py prints under SEGX_BENCH_VERBOSE=2, times every
-bf16x6 tile (4-wave 128x128 / 64x128 / 64x64, wave-specialised 256x128 / 128x128 / 128x256 / 64x256) x a few split-K factors per unique shape with HIP events,
-and prints one line per shape: the planner's choice and time, the best choice and time.  tools/tune_table.py turns the output into
+bf16x6 tile (4-wave 128x128 / 64x128 / 64x64, wave-specialised 256x128 / 128x128 / 128x256 / 64x256 / 96x256 / 256x96) x a few split-K factors per unique shape with HIP events,
+and prints one line per shape: the cost model's choice (segx_gemm_plan_model: the table of the previous sweep is NOT consulted) and its time, the best choice and time.  tools/tune_table.py turns the output into
 segtran_amd/csrc/gemm_tuned.h (entries where the measured best beats the cost model's pick by > 4 %), which segx_gemm_plan consults first.
 The cost model stays the fallback for every shape that is not in the table."""
 import os, re, sys, statistics, torch
@@ -86,11 +86,14 @@ for key, ms_total in sorted(shapes.items(), key=lambda kv: -kv[1]):
     d.c_b0, d.c_b1, d.c_m = 0, M * N, N; d.alpha = 1.0
     t0, s0 = ctypes.c_int(0), ctypes.c_int(0)
     A0 = buf(nb * M * K); B0 = buf(nb * N * K)
-    L.c.segx_gemm_plan(ctypes.c_void_p(A0.data_ptr()), ctypes.c_void_p(B0.data_ptr()), ctypes.byref(d), ctypes.byref(t0), ctypes.byref(s0))
-    sks = sorted({1, s0.value} | {s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 128 and K >= 512})
+    L.c.segx_gemm_plan_model(ctypes.c_void_p(A0.data_ptr()), ctypes.c_void_p(B0.data_ptr()), ctypes.byref(d), ctypes.byref(t0), ctypes.byref(s0))
+    t1, s1 = ctypes.c_int(0), ctypes.c_int(0)                 # what the library does today (table of the previous sweep first)
+    L.c.segx_gemm_plan(ctypes.c_void_p(A0.data_ptr()), ctypes.c_void_p(B0.data_ptr()), ctypes.byref(d), ctypes.byref(t1), ctypes.byref(s1))
+    cur = (t1.value, s1.value)
+    sks = sorted({1, s0.value, s1.value} | {s for s in (2, 3, 4, 6, 8, 12, 16, 24, 32) if K // s >= 128 and K >= 512})
     plan = (t0.value, s0.value)
-    cands = [plan] + [(tile, sk) for tile in (1, 5, 2, 6, 7, 8, 9) if not (tile >= 6 and K % 32) for sk in sks
-                      if not (sk > 1 and 4.0 * sk * nb * M * N > 6e9) and (tile, sk) != plan]
+    cands = [plan] + ([cur] if cur != plan else []) + [(tile, sk) for tile in (1, 5, 2, 6, 7, 8, 9) + ((10,) if akc else ()) + ((11,) if bkc else ()) if not (tile >= 6 and K % 32) for sk in sks
+                      if not (sk > 1 and 4.0 * sk * nb * M * N > 6e9) and (tile, sk) != plan and (tile, sk) != cur]
     res = sweep(M, N, K, nb, akc, bkc, cands)
     if plan not in res:
         continue
@@ -98,5 +101,6 @@ for key, ms_total in sorted(shapes.items(), key=lambda kv: -kv[1]):
     bc = min(res, key=res.get)
     best = (res[bc], bc[0], bc[1])
     fl = 2.0 * M * N * K * nb
-    print('shape %d %d %d %d %d %d  plan tile %d sk %d %.4f ms %.1f TF  best tile %d sk %d %.4f ms %.1f TF  gain %.3f' % (
-        M, N, K, nb, int(akc), int(bkc), t0.value, s0.value, base, fl / base / 1e9, best[1], best[2], best[0], fl / best[0] / 1e9, base / best[0]), flush=True)
+    print('shape %d %d %d %d %d %d  plan tile %d sk %d %.4f ms %.1f TF  best tile %d sk %d %.4f ms %.1f TF  gain %.3f  cur tile %d sk %d %.4f ms  weight %.2f' % (
+        M, N, K, nb, int(akc), int(bkc), t0.value, s0.value, base, fl / base / 1e9, best[1], best[2], best[0], fl / best[0] / 1e9, base / best[0],
+        cur[0], cur[1], res.get(cur, float('nan')), ms_total), flush=True)
