@@ -264,25 +264,91 @@ __global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
 // compile-time index and S needs no special form beyond S % 4 == 0.
 // =================================================================================================
 template <int TEAM> __device__ __forceinline__ float team_sum(float v, float* red) { return TEAM == 64 ? wave_sum(v) : block_sum<4>(v, red); }
+// ACT >= 0: the activation is a compile-time constant of the body (straight-line code); ACT < 0: the runtime value
+template <int ACT> __device__ __forceinline__ float act_fwd_c(float u, int act) { return act_fwd(u, ACT >= 0 ? ACT : act); }
+template <int ACT> __device__ __forceinline__ float act_grad_c(float u, int act) { return act_grad(u, ACT >= 0 ? ACT : act); }
+
+// r04-g: every load of a phase is issued before the first value is used.  The first version predicated each load (`ok ? *p : 0`) and switched on the
+// activation per element: hipcc turned that into branch + load + s_waitcnt vmcnt(0) per float4 -- 32 dependent HBM round trips per workgroup,
+// 27 us for a 98 KB channel however few channels the layer has (r04_e trace: 112 channels 27.4 us, 672 channels 28.7 us).  Now the loads go to
+// CLAMPED addresses unconditionally (the select happens after a scheduling barrier) and the normalise / activate / store phase is instantiated
+// per activation, so it is straight-line code.
+
+// normalise / activate / (drop_connect scale + skip) / store / pool for the planes held in v.  Addresses: a wave-uniform base per plane (SGPRs) + one
+// 32-bit byte offset per float4 of a lane (off[k], shared by all planes) -- no 64-bit address arithmetic or address registers on the vector pipe.
+template <int TEAM, int KP, int BMAX, bool POOL, int ACT, int RESID>      // RESID: 0 none, 1 skip connection, -1 decided at run time (g.resid)
+__device__ __forceinline__ void bn_res_apply(const BnFwdArgs& g, int B, const f32x4 (&v)[BMAX][KP], const unsigned (&off)[KP], float sc, float sh, int tl, int c, float* red) {
+    const int C = g.C, S4 = (int)(g.S >> 2), act = g.act;
+    const int64_t S = g.S;
+    f32x4 rv[2][KP];                                             // the skip connection's plane b + 1 is in flight while plane b is computed
+    const bool resid = RESID < 0 ? g.resid != nullptr : RESID != 0;
+    if (resid) {
+        const ws_gptr rb = ws_uniform_base(g.resid + (int64_t)c * S);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) rv[0][k] = ws_load<f32x4>(rb, off[k]);
+    }
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        if (b >= B) break;
+        const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
+        const ws_gptr_w yb = ws_uniform_base_w(g.Y + ((int64_t)b * C + c) * S);
+        if (resid && b + 1 < BMAX) {
+            const ws_gptr rb = ws_uniform_base(g.resid + ((int64_t)(b + 1 < B ? b + 1 : b) * C + c) * S);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) rv[(b + 1) & 1][k] = ws_load<f32x4>(rb, off[k]);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            f32x4 o;
+            o.x = act_fwd_c<ACT>(v[b][k].x * sc + sh, act); o.y = act_fwd_c<ACT>(v[b][k].y * sc + sh, act);
+            o.z = act_fwd_c<ACT>(v[b][k].z * sc + sh, act); o.w = act_fwd_c<ACT>(v[b][k].w * sc + sh, act);
+            if (resid) {
+                const f32x4 r = rv[b & 1][k];
+                o.x = o.x * dcs + r.x; o.y = o.y * dcs + r.y; o.z = o.z * dcs + r.z; o.w = o.w * dcs + r.w;
+            }
+            if (tl + TEAM * k < S4) {
+                ws_store<f32x4>(yb, off[k], o);
+                if (POOL) acc += (o.x + o.y) + (o.z + o.w);
+            }
+        }
+        if (POOL) {
+            acc = team_sum<TEAM>(acc, red);
+            if (tl == 0) g.psum[(int64_t)b * C + c] = acc;          // ONE chunk per plane (segx_bn_pool_chunks)
+        }
+        __builtin_amdgcn_sched_barrier(0);                       // one plane at a time: interleaving all planes' arithmetic costs registers (occupancy), buys nothing
+    }
+}
 
 // STATS: stop after the statistics and leave ONE partial (n, mean, M2) per channel in g.psum[c] -- the local half of synchronised BatchNorm
-template <int TEAM, int KP, int BMAX, bool POOL, bool STATS = false>
-__global__ __launch_bounds__(256) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
+// ACT / RESID are KERNEL parameters: one straight-line body per kernel.  (Branching inside one kernel into per-activation bodies made the register
+// allocator spill the resident planes at the loads: 832 bytes per lane in the largest backward form.)  ACT = -1 / RESID = -1: the run-time values.
+template <int TEAM, int KP, int BMAX, bool POOL, int ACT, int RESID, bool STATS = false>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : KP * BMAX <= 24 ? 3 : 2) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
     __shared__ float red[4];
     const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
     const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
     if (TEAM == 64 && c >= g.C) return;                        // whole waves leave together; no workgroup barrier in the wave-team form
     const int C = g.C, S4 = (int)(g.S >> 2);
     const int64_t S = g.S;
-    float4 v[BMAX][KP];
+    unsigned off[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { const int j = tl + TEAM * k; off[k] = 16u * (unsigned)(j < S4 ? j : 0); }
+    f32x4 v[BMAX][KP];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        const ws_gptr xb = ws_uniform_base(g.X + ((int64_t)(b < B ? b : 0) * C + c) * S);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) v[b][k] = ws_load<f32x4>(xb, off[k]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
     for (int b = 0; b < BMAX; ++b)
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int j = tl + TEAM * k;
-            const bool ok = b < B && j < S4;
-            v[b][k] = ok ? *reinterpret_cast<const float4*>(g.X + ((int64_t)b * C + c) * S + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = b < B && tl + TEAM * k < S4;
+            if (!ok) v[b][k] = f32x4{0.f, 0.f, 0.f, 0.f};
             s += (v[b][k].x + v[b][k].y) + (v[b][k].z + v[b][k].w);
         }
     const float n = (float)B * (float)S;
@@ -310,33 +376,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_res_kernel(BnFwdArgs g, int B)
         }
     }
     const float sc = rsqrtf(var + g.eps) * g.w[c], sh = g.b[c] - m * sc;
-    const int act = g.act;
-#pragma unroll
-    for (int b = 0; b < BMAX; ++b) {
-        if (b >= B) break;
-        const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
-        const int64_t base = ((int64_t)b * C + c) * S;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int j = tl + TEAM * k;
-            if (j < S4) {
-                float4 o;
-                o.x = act_fwd(v[b][k].x * sc + sh, act); o.y = act_fwd(v[b][k].y * sc + sh, act);
-                o.z = act_fwd(v[b][k].z * sc + sh, act); o.w = act_fwd(v[b][k].w * sc + sh, act);
-                if (g.resid) {
-                    const float4 rv = *reinterpret_cast<const float4*>(g.resid + base + 4 * j);
-                    o.x = o.x * dcs + rv.x; o.y = o.y * dcs + rv.y; o.z = o.z * dcs + rv.z; o.w = o.w * dcs + rv.w;
-                }
-                *reinterpret_cast<float4*>(g.Y + base + 4 * j) = o;
-                if (POOL) acc += (o.x + o.y) + (o.z + o.w);
-            }
-        }
-        if (POOL) {
-            acc = team_sum<TEAM>(acc, red);
-            if (tl == 0) g.psum[(int64_t)b * C + c] = acc;          // ONE chunk per plane (segx_bn_pool_chunks)
-        }
-    }
+    bn_res_apply<TEAM, KP, BMAX, POOL, ACT, RESID>(g, B, v, off, sc, sh, tl, c, red);
 }
 
 struct BnBwdArgs {
@@ -347,16 +387,12 @@ struct BnBwdArgs {
     int C; int64_t S; float eps; int act;
     int64_t dy_bs;                               // batch stride of dY (a channel slice of a wider tensor reads in place); C * S when dense
 };
-template <int TEAM, int KP, int BMAX>
-__global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {
-    __shared__ float red[4];
-    const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
-    const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
-    if (TEAM == 64 && c >= g.C) return;
+// (x, dy) in h / d  ->  (xhat, du) in place -> the two channel sums -> dx
+template <int TEAM, int KP, int BMAX, int ACT>
+__device__ __forceinline__ void bn_res_bwd_tail(const BnBwdArgs& g, int B, f32x4 (&h)[BMAX][KP], f32x4 (&d)[BMAX][KP], const unsigned (&off)[KP], int tl, int c, float* red) {
     const int C = g.C, S4 = (int)(g.S >> 2), act = g.act;
     const int64_t S = g.S;
     const float rstd = rsqrtf(g.var[c] + g.eps), m = g.mean[c], wc = g.w[c], bc_ = g.b[c];
-    float4 h[BMAX][KP], d[BMAX][KP];          // xhat, du
     float a = 0.f, q = 0.f;
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) {
@@ -365,18 +401,17 @@ __global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B)
         const float gt = (g.gate ? g.gate[pl] : 1.0f) * drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b), dp = g.dpool ? g.dpool[pl] * g.inv_S : 0.f;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int j = tl + TEAM * k;
-            const bool ok = bok && j < S4;
-            const int64_t o = (int64_t)pl * S + 4 * (ok ? j : 0), og = (int64_t)(bok ? b : 0) * g.dy_bs + (int64_t)c * S + 4 * (ok ? j : 0);
-            const float4 xv = *reinterpret_cast<const float4*>(g.X + o), gv = *reinterpret_cast<const float4*>(g.dY + og);
-            float4 hh, dd;
+            const bool ok = bok && tl + TEAM * k < S4;
+            const f32x4 xv = h[b][k], gv = d[b][k];
+            f32x4 hh, dd;
             hh.x = (xv.x - m) * rstd; hh.y = (xv.y - m) * rstd; hh.z = (xv.z - m) * rstd; hh.w = (xv.w - m) * rstd;
-            dd.x = (gv.x * gt + dp) * act_grad(hh.x * wc + bc_, act); dd.y = (gv.y * gt + dp) * act_grad(hh.y * wc + bc_, act);
-            dd.z = (gv.z * gt + dp) * act_grad(hh.z * wc + bc_, act); dd.w = (gv.w * gt + dp) * act_grad(hh.w * wc + bc_, act);
-            if (!ok) { dd = make_float4(0.f, 0.f, 0.f, 0.f); hh = dd; }
+            dd.x = (gv.x * gt + dp) * act_grad_c<ACT>(hh.x * wc + bc_, act); dd.y = (gv.y * gt + dp) * act_grad_c<ACT>(hh.y * wc + bc_, act);
+            dd.z = (gv.z * gt + dp) * act_grad_c<ACT>(hh.z * wc + bc_, act); dd.w = (gv.w * gt + dp) * act_grad_c<ACT>(hh.w * wc + bc_, act);
+            if (!ok) { dd = f32x4{0.f, 0.f, 0.f, 0.f}; hh = dd; }
             h[b][k] = hh; d[b][k] = dd;
             a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
         }
+        __builtin_amdgcn_sched_barrier(0);                       // one plane at a time (registers)
     }
     a = team_sum<TEAM>(a, red); q = team_sum<TEAM>(q, red);
     if (tl == 0) { g.db[c] = a; g.dw[c] = q; }
@@ -384,17 +419,40 @@ __global__ __launch_bounds__(256) void bn_act_bwd_res_kernel(BnBwdArgs g, int B)
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) {
         if (b >= B) break;
+        const ws_gptr_w ob = ws_uniform_base_w(g.dX + ((int64_t)b * C + c) * S);
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int j = tl + TEAM * k;
-            if (j < S4) {
-                float4 o;
+            if (tl + TEAM * k < S4) {
+                f32x4 o;
                 o.x = sc * (d[b][k].x - k1 - h[b][k].x * k2); o.y = sc * (d[b][k].y - k1 - h[b][k].y * k2);
                 o.z = sc * (d[b][k].z - k1 - h[b][k].z * k2); o.w = sc * (d[b][k].w - k1 - h[b][k].w * k2);
-                *reinterpret_cast<float4*>(g.dX + ((int64_t)b * C + c) * S + 4 * j) = o;
+                ws_store<f32x4>(ob, off[k], o);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
+}
+template <int TEAM, int KP, int BMAX, int ACT>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {
+    __shared__ float red[4];
+    const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
+    const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
+    if (TEAM == 64 && c >= g.C) return;
+    const int C = g.C, S4 = (int)(g.S >> 2);
+    const int64_t S = g.S;
+    unsigned off[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { const int j = tl + TEAM * k; off[k] = 16u * (unsigned)(j < S4 ? j : 0); }
+    f32x4 h[BMAX][KP], d[BMAX][KP];           // x, dy as loaded; then xhat, du
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) {
+        const int bb = b < B ? b : 0;
+        const ws_gptr xb = ws_uniform_base(g.X + ((int64_t)bb * C + c) * S), gb = ws_uniform_base(g.dY + (int64_t)bb * g.dy_bs + (int64_t)c * S);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { h[b][k] = ws_load<f32x4>(xb, off[k]); d[b][k] = ws_load<f32x4>(gb, off[k]); }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    bn_res_bwd_tail<TEAM, KP, BMAX, ACT>(g, B, h, d, off, tl, c, red);
 }
 // which channel-resident form serves (B planes of S floats) -- 0 none, else TEAM * 16 + KP packed: registers per lane <= cap float4 (forward: x; backward: xhat + du)
 static inline int bn_res_form(int B, int64_t S, bool backward) {
@@ -406,6 +464,26 @@ static inline int bn_res_form(int B, int64_t S, bool backward) {
     if (kb <= capb) return 256 * 16 + (kb <= 1 ? 1 : kb <= 2 ? 2 : 4);
     if (backward && kb <= 4 && B <= 6) return 256 * 16 + 4;
     return 0;
+}
+
+// The resident kernels exist per (activation, pooling, skip) combination the backbones use -- swish (+ pooling), none (+ skip), relu -- and once with
+// the run-time values for everything else.
+template <int T, int K, int BM>
+static void bn_res_launch_fwd(const BnFwdArgs& g, int B, dim3 grid, hipStream_t stream, bool pool) {
+    const bool resid = g.resid != nullptr;
+#define SEGX_BN_F(P, A, R) hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, BM, P, A, R>), grid, dim3(256), 0, stream, g, B)
+    if (pool) { if (!resid && g.act == ACT_SWISH) SEGX_BN_F(true, ACT_SWISH, 0); else SEGX_BN_F(true, -1, -1); }
+    else if (!resid && g.act == ACT_SWISH) SEGX_BN_F(false, ACT_SWISH, 0);
+    else if (g.act == ACT_NONE) { if (resid) SEGX_BN_F(false, ACT_NONE, 1); else SEGX_BN_F(false, ACT_NONE, 0); }
+    else if (!resid && g.act == ACT_RELU) SEGX_BN_F(false, ACT_RELU, 0);
+    else SEGX_BN_F(false, -1, -1);
+#undef SEGX_BN_F
+}
+template <int T, int K, int BM>
+static void bn_res_launch_bwd(const BnBwdArgs& g, int B, dim3 grid, hipStream_t stream) {
+#define SEGX_BN_B(A) hipLaunchKernelGGL((bn_act_bwd_res_kernel<T, K, BM, A>), grid, dim3(256), 0, stream, g, B)
+    if (g.act == ACT_SWISH) SEGX_BN_B(ACT_SWISH); else if (g.act == ACT_NONE) SEGX_BN_B(ACT_NONE); else if (g.act == ACT_RELU) SEGX_BN_B(ACT_RELU); else SEGX_BN_B(-1);
+#undef SEGX_BN_B
 }
 
 // =================================================================================================
@@ -1015,13 +1093,9 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
             g.parts = nullptr;
             const int team = form >> 4, kp = form & 15;
             const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
-#define SEGX_BN_RES(T, K)                                                                                                          \
-            if (team == T && kp == K) {                                                                                            \
-                if (psum) hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, true>), rgrid, dim3(256), 0, stream, g, B);            \
-                else hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, false>), rgrid, dim3(256), 0, stream, g, B);                \
-                return check_launch("segx_bn_act_fwd2/resident");                                                                   \
-            }
-            SEGX_BN_RES(64, 1) SEGX_BN_RES(64, 2) SEGX_BN_RES(256, 1) SEGX_BN_RES(256, 2) SEGX_BN_RES(256, 4)
+#define SEGX_BN_RES(T, K, BM) if (team == T && kp == K) { bn_res_launch_fwd<T, K, BM>(g, B, rgrid, stream, psum != nullptr); return check_launch("segx_bn_act_fwd2/resident"); }
+            if (B <= 6) SEGX_BN_RES(256, 4, 6)                   // 96 instead of 128 registers of planes: three workgroups per CU
+            SEGX_BN_RES(64, 1, 8) SEGX_BN_RES(64, 2, 8) SEGX_BN_RES(256, 1, 8) SEGX_BN_RES(256, 2, 8) SEGX_BN_RES(256, 4, 8)
 #undef SEGX_BN_RES
             return fail(-1, "segx_bn_act_fwd2: no resident form %d", form);
         }
@@ -1050,7 +1124,7 @@ extern "C" int segx_bn_stats_local(const float* X, float* part, float* ws, int B
         g.X = X; g.psum = part; g.C = C; g.S = S;
         const int team = form >> 4, kp = form & 15;
         const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
-#define SEGX_BN_ST(T, K) if (team == T && kp == K) { hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, false, true>), rgrid, dim3(256), 0, stream, g, B); return check_launch("segx_bn_stats_local"); }
+#define SEGX_BN_ST(T, K) if (team == T && kp == K) { hipLaunchKernelGGL((bn_act_fwd_res_kernel<T, K, 8, false, -1, 0, true>), rgrid, dim3(256), 0, stream, g, B); return check_launch("segx_bn_stats_local"); }
         SEGX_BN_ST(64, 1) SEGX_BN_ST(64, 2) SEGX_BN_ST(256, 1) SEGX_BN_ST(256, 2) SEGX_BN_ST(256, 4)
 #undef SEGX_BN_ST
         return fail(-1, "segx_bn_stats_local: no resident form %d", form);
@@ -1074,10 +1148,10 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
         g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
         const int team = form >> 4, kp = form & 15;
         const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
-        if (team == 64) hipLaunchKernelGGL((bn_act_bwd_res_kernel<64, 1, 8>), rgrid, dim3(256), 0, stream, g, B);
-        else if (kp == 1) hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 1, 8>), rgrid, dim3(256), 0, stream, g, B);
-        else if (kp == 2) hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 2, 8>), rgrid, dim3(256), 0, stream, g, B);
-        else hipLaunchKernelGGL((bn_act_bwd_res_kernel<256, 4, 6>), rgrid, dim3(256), 0, stream, g, B);
+        if (team == 64) bn_res_launch_bwd<64, 1, 8>(g, B, rgrid, stream);
+        else if (kp == 1) bn_res_launch_bwd<256, 1, 8>(g, B, rgrid, stream);
+        else if (kp == 2) bn_res_launch_bwd<256, 2, 8>(g, B, rgrid, stream);
+        else bn_res_launch_bwd<256, 4, 6>(g, B, rgrid, stream);
         return check_launch("segx_bn_act_bwd2/resident");
     }
     const int nsl = bn_slabs(S);

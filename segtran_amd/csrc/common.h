@@ -34,7 +34,35 @@ inline int check_launch(const char* what) {
 #ifndef SEGX_PIN
 #define SEGX_PIN(x) asm volatile("" : "+v"(x))
 #endif
+#ifndef SEGX_WAVE_UNIFORM
+#define SEGX_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 #define SEGX_REQUIRE(cond, ...) do { if (!(cond)) return segx::fail(-1, __VA_ARGS__); } while (0)
+
+// A wave-uniform base pointer moved to SGPRs (it IS the same in every lane; hipcc cannot always prove it) and typed as a GLOBAL-address-space
+// pointer, plus a 32-bit per-lane byte offset: the load takes the `global_load v_dst, v_offset, s[base]` form -- no 64-bit address arithmetic on
+// the vector pipe.  (A pointer rebuilt from integers without the address space becomes a flat pointer: flat_load waits on two counters.)
+#ifndef SEGX_GLOBAL
+#define SEGX_GLOBAL __attribute__((address_space(1)))
+#endif
+typedef const char SEGX_GLOBAL* ws_gptr;
+__device__ __forceinline__ ws_gptr ws_uniform_base(const void* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = SEGX_WAVE_UNIFORM((unsigned)u), hi = SEGX_WAVE_UNIFORM((unsigned)(u >> 32));
+    return (ws_gptr)(((uint64_t)hi << 32) | lo);
+}
+template <class V> __device__ __forceinline__ V ws_load(ws_gptr base, unsigned byte_off) {
+    return *reinterpret_cast<const V SEGX_GLOBAL*>(base + byte_off);
+}
+typedef char SEGX_GLOBAL* ws_gptr_w;
+__device__ __forceinline__ ws_gptr_w ws_uniform_base_w(void* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const unsigned lo = SEGX_WAVE_UNIFORM((unsigned)u), hi = SEGX_WAVE_UNIFORM((unsigned)(u >> 32));
+    return (ws_gptr_w)(((uint64_t)hi << 32) | lo);
+}
+template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsigned byte_off, V v) {
+    *reinterpret_cast<V SEGX_GLOBAL*>(base + byte_off) = v;
+}
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

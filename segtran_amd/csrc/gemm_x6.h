@@ -24,32 +24,13 @@
 #pragma once
 #include "gemm_core.h"
 
-#ifndef SEGX_WAVE_UNIFORM
-#define SEGX_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
-#endif
-
 namespace segx {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32v2 __attribute__((ext_vector_type(2)));
 
-// A wave-uniform base pointer moved to SGPRs (it IS the same in every lane; hipcc cannot always prove it) and typed as a GLOBAL-address-space
-// pointer, plus a 32-bit per-lane byte offset: the load takes the `global_load v_dst, v_offset, s[base]` form -- no 64-bit address arithmetic on
-// the vector pipe.  (A pointer rebuilt from integers without the address space becomes a flat pointer: flat_load waits on two counters.)
-#ifndef SEGX_GLOBAL
-#define SEGX_GLOBAL __attribute__((address_space(1)))
-#endif
-typedef const char SEGX_GLOBAL* ws_gptr;
-__device__ __forceinline__ ws_gptr ws_uniform_base(const void* p) {
-    const uint64_t u = reinterpret_cast<uint64_t>(p);
-    const unsigned lo = SEGX_WAVE_UNIFORM((unsigned)u), hi = SEGX_WAVE_UNIFORM((unsigned)(u >> 32));
-    return (ws_gptr)(((uint64_t)hi << 32) | lo);
-}
-template <class V> __device__ __forceinline__ V ws_load(ws_gptr base, unsigned byte_off) {
-    return *reinterpret_cast<const V SEGX_GLOBAL*>(base + byte_off);
-}
-
+// ws_gptr / ws_uniform_base / ws_load: common.h
 constexpr int X6_ROWB = 64;                         // bytes of one LDS row of one plane: 32 k of bf16
 __device__ __forceinline__ int x6_swz(int row) { return ((row >> 2) & 1) | ((((row >> 1) ^ (row >> 3)) & 1) << 1); }
 __device__ __forceinline__ int x6_off(int row, int chunk) { return row * X6_ROWB + ((chunk ^ x6_swz(row)) << 4); }
