@@ -976,9 +976,8 @@ static int conv3d_fwd_impl(const float* X, const float* W, float* Y, int B, int 
     int rc = check_launch("segx_conv3d_fwd");
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, Y,
-                       (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split, y_bs ? y_bs : (int64_t)Cout * P, (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE,
-                       (int64_t)0, (int64_t)0, total, (const float*)nullptr);
+    SEGX_SPLITK_REDUCE((unsigned)i64min(2048, (total + 255) / 256), stream, (const float*)workspace, Y, (const float*)nullptr, Cout, (int)P, 1, splitk, g.c_split,
+                       (y_bs ? y_bs : (int64_t)Cout * P), (int64_t)0, (int64_t)P, 1.0f, (int)SEGX_BIAS_NONE, (int64_t)0, (int64_t)0, total, (const float*)nullptr);
     return check_launch("segx_conv3d_fwd/reduce");
 }
 extern "C" int segx_conv3d_fwd(const float* X, const float* W, float* Y, int B, int Cout, const int* geom, int splitk, float* workspace,
@@ -1044,9 +1043,8 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     int rc = check_launch("segx_conv3d_bwd_weight");
     if (rc || splitk == 1) return rc;
     const int64_t total = g.c_split;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)workspace, dWb,
-                       (const float*)nullptr, Cout, N, 1, splitk, g.c_split, (int64_t)Cout * N, (int64_t)0, (int64_t)N, 1.0f, (int)SEGX_BIAS_NONE,
-                       (int64_t)0, (int64_t)0, total, (const float*)nullptr);
+    SEGX_SPLITK_REDUCE((unsigned)i64min(2048, (total + 255) / 256), stream, (const float*)workspace, dWb, (const float*)nullptr, Cout, N, 1, splitk, g.c_split,
+                       (int64_t)Cout * N, (int64_t)0, (int64_t)N, 1.0f, (int)SEGX_BIAS_NONE, (int64_t)0, (int64_t)0, total, (const float*)nullptr);
     return check_launch("segx_conv3d_bwd_weight/reduce");
 }
 extern "C" int segx_conv3d_bwd_weight(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk,

@@ -101,26 +101,6 @@ __global__ __launch_bounds__(256) void x6_presplit_kernel(const float* __restric
     }
 }
 
-// Split-K second stage: C = alpha * sum_s slab[s] (+ bias), deterministic slab order.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, const float* __restrict__ bias,
-                                                            int M, int N, int nb1, int splitk, int64_t c_split,
-                                                            int64_t c_b0, int64_t c_b1, int64_t c_m, float alpha,
-                                                            int bias_mode, int64_t bias_b1, int64_t bias_b0, int64_t total, const float* __restrict__ resid) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int col = (int)(idx % N);
-        const int64_t t = idx / N;
-        const int row = (int)(t % M);
-        const int zb = (int)(t / M);
-        float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += ws[(int64_t)k * c_split + idx];
-        s *= alpha;
-        const int z0 = zb / nb1, z1 = zb - z0 * nb1;
-        if (bias_mode == SEGX_BIAS_N) s += bias[z0 * bias_b0 + z1 * bias_b1 + col];
-        else if (bias_mode == SEGX_BIAS_M) s += bias[z0 * bias_b0 + z1 * bias_b1 + row];
-        const int64_t o = z0 * c_b0 + z1 * c_b1 + (int64_t)row * c_m + col;
-        C[o] = resid ? s + resid[o] : s;
-    }
-}
 // The same reduction for MANY slabs over a SMALL output (batch_reduce of the skinny weight gradients: 6 x 63 slabs of 24 x 144 floats): the slab
 // loop is dealt out over PARTS threads per output element (slab s -> part s % PARTS, each part in slab order) and the PARTS partial sums are
 // added in part order through LDS -- a fixed summation tree, so still deterministic; 256 / PARTS outputs per workgroup.
@@ -455,15 +435,15 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
             hipLaunchKernelGGL((slab_sum_parts_kernel<4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
                                d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
         else
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                               d->M, d->N, 1, nslabs, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha, d->bias_mode, (int64_t)0, (int64_t)0, total, (const float*)nullptr);
+            SEGX_SPLITK_REDUCE((unsigned)i64min(2048, (total + 255) / 256), stream, (const float*)d->workspace, C, g.bias, d->M, d->N, 1, nslabs, total, (int64_t)0, (int64_t)0, d->c_m, d->alpha,
+                               d->bias_mode, (int64_t)0, (int64_t)0, total, (const float*)nullptr);
         return check_launch("segx_gemm_f32/batch_reduce");
     }
     if (splitk > 1) {
         const int64_t total = g.c_split;
         const int blocks = (int)i64min(2048, (total + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
-                           d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, d->bias_b0, total, d->resid);
+        SEGX_SPLITK_REDUCE(blocks, stream, (const float*)d->workspace, C, g.bias, d->M, d->N, d->nb1, splitk, g.c_split, d->c_b0, d->c_b1, d->c_m, d->alpha, d->bias_mode, d->bias_b1, d->bias_b0,
+                           total, (const float*)d->resid);
         rc = check_launch("segx_gemm_f32/splitk_reduce");
     }
     return rc;

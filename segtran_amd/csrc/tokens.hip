@@ -515,38 +515,61 @@ __global__ __launch_bounds__(256) void posembed_bwd_kernel(const float* __restri
 //   Z [Mo, R, F] mode-major -> zn_m = LN(dropout(z_m)) ; s_m = zn_m . wa + ba ; pr = softmax_m(s) ; y = sum_m pr_m zn_m
 // stats: mean[Mo*R], rstd[Mo*R], prob[Mo*R]
 // =================================================================================================
+// r04-g: all MO rows of a token are requested before the first is used, and the LayerNorm / aggregation vectors come from LDS (staged once per
+// workgroup of four tokens) -- see modes_aggr_bwd_kernel.
 template <int NV4, int MO>
 __global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ lnw, const float* __restrict__ lnb,
                                                              const float* __restrict__ wa, const float* __restrict__ ba, float* __restrict__ Y,
                                                              float* __restrict__ stats, int64_t R, int F, float eps,
                                                              float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    __shared__ float4 sw[NV4 * 64], sb[NV4 * 64], sa[NV4 * 64];
     off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
-    const int64_t row = SEGX_ROW_ID();
-    if (row >= R) return;
+    const int64_t row_id = SEGX_ROW_ID();
+    const bool live = row_id < R;                                    // wave-uniform; a dead wave of the last workgroup works on row R - 1 and stores nothing
+    const int64_t row = live ? row_id : R - 1;
+    const int lane = threadIdx.x & 63, F4 = F >> 2;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    for (int idx = threadIdx.x; idx < NV4 * 64; idx += 256) {
+        const int c4 = idx < F4 ? idx : F4 - 1;
+        sw[idx] = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+        sb[idx] = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sa[idx] = reinterpret_cast<const float4*>(wa)[c4];
+    }
     Row<NV4> z[MO];
     float sc[MO];
 #pragma unroll
     for (int m = 0; m < MO; ++m) {
         const int64_t mr = (int64_t)m * R + row;
-        row_load(z[m], Z + mr * F, F);
-        if (p > 0.f) SEGX_FOR_ROW(i, c4, F) {
-            const float4 k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
-            SEGX_F4_OP(z[m].v[i], z[m].v[i].x * k.x, z[m].v[i].y * k.y, z[m].v[i].z * k.z, z[m].v[i].w * k.w);
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) { const int c4 = lane + 64 * i; z[m].v[i] = reinterpret_cast<const float4*>(Z + mr * F)[c4 < F4 ? c4 : F4 - 1]; }
+    }
+    const float ba0 = ba[0];
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const int64_t mr = (int64_t)m * R + row;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (!(c4 < F4)) z[m].v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else if (p > 0.f) {
+                const float4 k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
+                SEGX_F4_OP(z[m].v[i], z[m].v[i].x * k.x, z[m].v[i].y * k.y, z[m].v[i].z * k.z, z[m].v[i].w * k.w);
+            }
         }
         float mean = 0.f, rstd = 1.f;                     // lnw == NULL: aggregate the raw mode features (no-FFN branch, :452-457)
         if (lnw) row_stats(z[m], F, eps, mean, rstd);
         float s = 0.f;
         SEGX_FOR_ROW(i, c4, F) {
-            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 bb = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 aa = reinterpret_cast<const float4*>(wa)[c4];
+            const float4 ww = sw[c4], bb = sb[c4], aa = sa[c4];
             SEGX_F4_OP(z[m].v[i], (z[m].v[i].x - mean) * rstd * ww.x + bb.x, (z[m].v[i].y - mean) * rstd * ww.y + bb.y,
                        (z[m].v[i].z - mean) * rstd * ww.z + bb.z, (z[m].v[i].w - mean) * rstd * ww.w + bb.w);
             s += (z[m].v[i].x * aa.x + z[m].v[i].y * aa.y) + (z[m].v[i].z * aa.z + z[m].v[i].w * aa.w);
         }
-        sc[m] = wave_sum(s) + ba[0];
-        if ((threadIdx.x & 63) == 0) { stats[mr] = mean; stats[(int64_t)MO * R + mr] = rstd; }
+        sc[m] = wave_sum(s) + ba0;
+        if (lane == 0 && live) { stats[mr] = mean; stats[(int64_t)MO * R + mr] = rstd; }
+        __builtin_amdgcn_sched_barrier(0);
     }
     float mx = sc[0];
 #pragma unroll
@@ -560,42 +583,78 @@ __global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __rest
 #pragma unroll
     for (int m = 0; m < MO; ++m) {
         const float pr = sc[m] / den;
-        if ((threadIdx.x & 63) == 0) stats[(int64_t)2 * MO * R + (int64_t)m * R + row] = pr;
+        if (lane == 0 && live) stats[(int64_t)2 * MO * R + (int64_t)m * R + row] = pr;
         SEGX_FOR_ROW(i, c4, F) SEGX_F4_OP(y.v[i], y.v[i].x + z[m].v[i].x * pr, y.v[i].y + z[m].v[i].y * pr,
                                            y.v[i].z + z[m].v[i].z * pr, y.v[i].w + z[m].v[i].w * pr);
     }
-    row_store(y, Y + row * F, F);
+    if (live) row_store(y, Y + row * F, F);
 }
 
 // dZ and the per-(mode,row) score gradients ds (needed again by the parameter-gradient pass)
+// r04-g: the MO rows of a token stay in registers for both passes and ALL their loads are issued before the first use.  The first version re-read Z
+// in the second pass (2.3 GB at cfg2 where 1.6 are needed) and, worse, its predicated loads were fused with the loops that consume them: a wave
+// waited for every float4 separately -- 56 dependent round trips per token, 724 us for the 24576 x 4 x 1792 launch = what two waves per SIMD of
+// that chain take.  The LayerNorm / aggregation vectors (shared by the four rows of a workgroup) are staged in LDS once; the dropout keep mask
+// is applied to z in place and kept as one bit per element for the final multiply.
 template <int NV4, int MO>
 __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
                                                              float* __restrict__ dZ, float* __restrict__ dscore, int64_t R, int F,
                                                              float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    __shared__ float4 sw[NV4 * 64], sb[NV4 * 64], sa[NV4 * 64];
     off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
-    const int64_t row = SEGX_ROW_ID();
-    if (row >= R) return;
+    const int64_t row_id = SEGX_ROW_ID();
+    const bool live = row_id < R;                                    // wave-uniform; a dead wave of the last workgroup works on row R - 1 and stores nothing
+    const int64_t row = live ? row_id : R - 1;
+    const int lane = threadIdx.x & 63, F4 = F >> 2;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    Row<NV4> g; row_load(g, dY + row * F, F);
-    float dp[MO], pr[MO];
-    // pass 1: dp_m = dY . zn_m
+    for (int idx = threadIdx.x; idx < NV4 * 64; idx += 256) {
+        const int c4 = idx < F4 ? idx : F4 - 1;
+        sw[idx] = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
+        sb[idx] = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sa[idx] = reinterpret_cast<const float4*>(wa)[c4];
+    }
+    Row<NV4> g, z[MO];
+    float mean[MO], rstd[MO], pr[MO], dp[MO];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) { const int c4 = lane + 64 * i; g.v[i] = reinterpret_cast<const float4*>(dY + row * F)[c4 < F4 ? c4 : F4 - 1]; }
 #pragma unroll
     for (int m = 0; m < MO; ++m) {
         const int64_t mr = (int64_t)m * R + row;
-        const float mean = stats[mr], rstd = stats[(int64_t)MO * R + mr];
-        pr[m] = stats[(int64_t)2 * MO * R + mr];
-        Row<NV4> z; row_load(z, Z + mr * F, F);
+        mean[m] = stats[mr]; rstd[m] = stats[(int64_t)MO * R + mr]; pr[m] = stats[(int64_t)2 * MO * R + mr];
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) { const int c4 = lane + 64 * i; z[m].v[i] = reinterpret_cast<const float4*>(Z + mr * F)[c4 < F4 ? c4 : F4 - 1]; }
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned kbits[MO];
+    // pass 1: z -> zhat = (z * keep - mean) * rstd in place (0 outside the row);  dp_m = dY . (zhat * w + b)
+#pragma unroll
+    for (int m = 0; m < MO; ++m) {
+        const int64_t mr = (int64_t)m * R + row;
         float s = 0.f;
-        SEGX_FOR_ROW(i, c4, F) {
+        unsigned kb = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c4 = lane + 64 * i;
+            const bool ok = c4 < F4;
             float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
-            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 bb = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            s += (((z.v[i].x * k.x - mean) * rstd * ww.x + bb.x) * g.v[i].x + ((z.v[i].y * k.y - mean) * rstd * ww.y + bb.y) * g.v[i].y) +
-                 (((z.v[i].z * k.z - mean) * rstd * ww.z + bb.z) * g.v[i].z + ((z.v[i].w * k.w - mean) * rstd * ww.w + bb.w) * g.v[i].w);
+            if (p > 0.f) {
+                k = f4_keep(seed, off, (uint64_t)mr * F + (ok ? c4 : 0) * 4, p, ik);
+                if (NV4 <= 8) kb = (kb & ~(0xFu << (4 * i))) | ((k.x != 0.f ? 1u : 0u) | (k.y != 0.f ? 2u : 0u) | (k.z != 0.f ? 4u : 0u) | (k.w != 0.f ? 8u : 0u)) << (4 * i);
+            }
+            if (!ok) g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 ww = sw[c4], bb = sb[c4];
+            float4 zh;
+            zh.x = (z[m].v[i].x * k.x - mean[m]) * rstd[m]; zh.y = (z[m].v[i].y * k.y - mean[m]) * rstd[m];
+            zh.z = (z[m].v[i].z * k.z - mean[m]) * rstd[m]; zh.w = (z[m].v[i].w * k.w - mean[m]) * rstd[m];
+            if (!ok) zh = make_float4(0.f, 0.f, 0.f, 0.f);
+            z[m].v[i] = zh;
+            s += ok ? ((zh.x * ww.x + bb.x) * g.v[i].x + (zh.y * ww.y + bb.y) * g.v[i].y) + ((zh.z * ww.z + bb.z) * g.v[i].z + (zh.w * ww.w + bb.w) * g.v[i].w) : 0.f;
         }
+        kbits[m] = kb;
         dp[m] = wave_sum(s);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float dot = 0.f;
 #pragma unroll
@@ -604,28 +663,31 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
 #pragma unroll
     for (int m = 0; m < MO; ++m) {
         const int64_t mr = (int64_t)m * R + row;
-        const float mean = stats[mr], rstd = stats[(int64_t)MO * R + mr];
         const float ds = pr[m] * (dp[m] - dot);
-        if ((threadIdx.x & 63) == 0) dscore[mr] = ds;
-        Row<NV4> zh, d; row_load(zh, Z + mr * F, F);
+        if (lane == 0 && live) dscore[mr] = ds;
+        Row<NV4> d;
 #pragma unroll
-        for (int i = 0; i < NV4; ++i) d.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        Row<NV4> kk;
-        SEGX_FOR_ROW(i, c4, F) {
-            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
-            if (p > 0.f) k = f4_keep(seed, off, (uint64_t)mr * F + c4 * 4, p, ik);
-            kk.v[i] = k;
-            const float4 ww = lnw ? reinterpret_cast<const float4*>(lnw)[c4] : make_float4(1.f, 1.f, 1.f, 1.f);
-            const float4 aa = reinterpret_cast<const float4*>(wa)[c4];
-            SEGX_F4_OP(zh.v[i], (zh.v[i].x * k.x - mean) * rstd, (zh.v[i].y * k.y - mean) * rstd, (zh.v[i].z * k.z - mean) * rstd, (zh.v[i].w * k.w - mean) * rstd);
+        for (int i = 0; i < NV4; ++i) {
+            const int c4 = lane + 64 * i;
+            const float4 ww = sw[c4], aa = sa[c4];
             SEGX_F4_OP(d.v[i], (pr[m] * g.v[i].x + ds * aa.x) * ww.x, (pr[m] * g.v[i].y + ds * aa.y) * ww.y,
                        (pr[m] * g.v[i].z + ds * aa.z) * ww.z, (pr[m] * g.v[i].w + ds * aa.w) * ww.w);
+            if (!(c4 < F4)) d.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        if (lnw) ln_bwd_row(d, z[m], F, rstd[m]);
+        if (p > 0.f) {
 #pragma unroll
-        for (int i = 0; i < NV4; ++i) if (!(((threadIdx.x & 63) + 64 * i) * 4 < F)) zh.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (lnw) ln_bwd_row(d, zh, F, rstd);
-        SEGX_FOR_ROW(i, c4, F) SEGX_F4_OP(d.v[i], d.v[i].x * kk.v[i].x, d.v[i].y * kk.v[i].y, d.v[i].z * kk.v[i].z, d.v[i].w * kk.v[i].w);
-        row_store(d, dZ + mr * F, F);
+            for (int i = 0; i < NV4; ++i) {
+                float4 k;
+                if (NV4 <= 8) {
+                    const unsigned q = kbits[m] >> (4 * i);
+                    k = make_float4((q & 1u) ? ik : 0.f, (q & 2u) ? ik : 0.f, (q & 4u) ? ik : 0.f, (q & 8u) ? ik : 0.f);
+                } else k = f4_keep(seed, off, (uint64_t)mr * F + (lane + 64 * i < F4 ? lane + 64 * i : 0) * 4, p, ik);
+                SEGX_F4_OP(d.v[i], d.v[i].x * k.x, d.v[i].y * k.y, d.v[i].z * k.z, d.v[i].w * k.w);
+            }
+        }
+        if (live) row_store(d, dZ + mr * F, F);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

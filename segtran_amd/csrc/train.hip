@@ -100,7 +100,13 @@ __global__ __launch_bounds__(256) void mt_sumsq_kernel(MtTables T, int chunk, fl
     float s = 0.f;
     if (gbase) {
         const float* g = gbase + off;
-        for (int64_t i = threadIdx.x; i < n; i += 256) { const float x = g[i]; s += x * x; }
+        int64_t i0 = 0;
+        if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {      // 16-byte loads (a chunk starts on a multiple of `chunk` floats of an allocation; gradient VIEWS may not)
+            const int64_t n4 = n >> 2;
+            for (int64_t i = threadIdx.x; i < n4; i += 256) { const float4 x = reinterpret_cast<const float4*>(g)[i]; s += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w); }
+            i0 = n4 << 2;
+        }
+        for (int64_t i = i0 + threadIdx.x; i < n; i += 256) { const float x = g[i]; s += x * x; }
     }
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) chunk_ws[ch] = s;
@@ -143,14 +149,32 @@ __global__ __launch_bounds__(256) void mt_bertadam_kernel(MtTables T, int chunk,
     const int64_t off = T.chunk_off[ch], n = i64min(chunk, T.sizes[t] - off);
     float* p = T.params[t] + off; const float* g = T.grads[t] + off; float* m = T.m[t] + off; float* v = T.v[t] + off;
     const float c = coef[t], step = lr[t] * sched, decay = wd[t];
-    for (int64_t i = threadIdx.x; i < n; i += 256) {
-        const float gi = g[i] * c;
-        const float mi = m[i] * b1 + (1.0f - b1) * gi;
-        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+    // one element of the update (optimization.py:104-130); the same arithmetic in the 16-byte and the scalar loop
+    auto upd1 = [&](float gi, float& mi, float& vi, float& pi) {
+        gi *= c;
+        mi = mi * b1 + (1.0f - b1) * gi;
+        vi = vi * b2 + (1.0f - b2) * gi * gi;
         float upd = mi / (sqrtf(vi) + eps);
-        const float pi = p[i];
         if (decay > 0.f) upd += decay * pi;
-        p[i] = pi - step * upd; m[i] = mi; v[i] = vi;
+        pi = pi - step * upd;
+    };
+    int64_t i0 = 0;
+    if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
+        // r04-g: 16-byte accesses (the scalar loop moved 2.33 GB in 571 us = 4.1 TB/s, four 4-byte loads in flight per lane)
+        const int64_t n4 = n >> 2;
+        float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
+        float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+        for (int64_t i = threadIdx.x; i < n4; i += 256) {
+            const float4 gv = g4[i]; float4 mv = m4[i], vv = v4[i], pv = p4[i];
+            upd1(gv.x, mv.x, vv.x, pv.x); upd1(gv.y, mv.y, vv.y, pv.y); upd1(gv.z, mv.z, vv.z, pv.z); upd1(gv.w, mv.w, vv.w, pv.w);
+            p4[i] = pv; m4[i] = mv; v4[i] = vv;
+        }
+        i0 = n4 << 2;
+    }
+    for (int64_t i = i0 + threadIdx.x; i < n; i += 256) {
+        float mi = m[i], vi = v[i], pi = p[i];
+        upd1(g[i], mi, vi, pi);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 

@@ -67,7 +67,12 @@ struct State {
     dim3 grid, block; U3 bid; Fiber* cur; ucontext_t sched;
     int nthreads, bar_arrived; unsigned bar_gen;
     std::vector<Fiber> fibers; std::vector<Wave> waves; std::function<void()>* body;
+    unsigned long events = 0;        // barrier / wave releases, finished fibers, satisfied cross-block waits: "this block made progress"
+    bool spin_seen = false;          // a fiber of the running block is waiting for ANOTHER block (grid_spin_yield)
 };
+// A block that waits for other blocks (team barrier of the cooperative BatchNorm kernels): its fibers are kept aside while later blocks run.
+// __shared__ is static storage here, so such a kernel must not keep shared-memory state across the wait (the product kernels do not).
+struct Parked { std::vector<Fiber> fibers; std::vector<Wave> waves; U3 bid; int bar_arrived; unsigned bar_gen; int left; };
 inline State S;
 constexpr size_t STACK = 256 * 1024;
 
@@ -76,46 +81,90 @@ inline void trampoline() { (*S.body)(); S.cur->done = true; swapcontext(&S.cur->
 
 inline void block_sync() {
     unsigned g = S.bar_gen;
-    if (++S.bar_arrived == S.nthreads) { S.bar_arrived = 0; S.bar_gen++; }
+    if (++S.bar_arrived == S.nthreads) { S.bar_arrived = 0; S.bar_gen++; S.events++; }
     else while (S.bar_gen == g) yield();
 }
 inline Wave& wave() { return S.waves[S.cur->wave]; }
 inline void wave_sync() {
     Wave& w = wave(); unsigned g = w.gen;
-    if (++w.arrived == w.nlanes) { w.arrived = 0; w.gen++; }
+    if (++w.arrived == w.nlanes) { w.arrived = 0; w.gen++; S.events++; }
     else while (w.gen == g) yield();
 }
+// one poll of a condition another BLOCK will make true: the scheduler runs later blocks of the grid while this one waits
+inline void grid_spin_yield() { S.spin_seen = true; yield(); }
+inline void grid_spin_done() { S.events++; }
 
-template <class F> void launch(dim3 grid, dim3 block, F&& fn) {
-    std::function<void()> body = fn;
-    S.grid = grid; S.block = block; S.body = &body;
-    S.nthreads = block.x * block.y * block.z;
+inline void init_fibers(dim3 block) {
+    int nw = (S.nthreads + 63) / 64; S.waves.assign(nw, Wave());
     if ((int)S.fibers.size() < S.nthreads) {
         size_t old = S.fibers.size(); S.fibers.resize(S.nthreads);
         for (size_t i = old; i < S.fibers.size(); ++i) S.fibers[i].stack = (char*)malloc(STACK);
     }
-    int nw = (S.nthreads + 63) / 64; S.waves.assign(nw, Wave());
-    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
-        S.bid = U3{bx, by, bz}; S.bar_arrived = 0; S.bar_gen = 0;
-        for (int w = 0; w < nw; ++w) { S.waves[w].nlanes = std::min(64, S.nthreads - 64 * w); S.waves[w].arrived = 0; S.waves[w].gen = 0; }
+    S.bar_arrived = 0; S.bar_gen = 0;
+    for (int w = 0; w < nw; ++w) { S.waves[w].nlanes = std::min(64, S.nthreads - 64 * w); S.waves[w].arrived = 0; S.waves[w].gen = 0; }
+    for (int t = 0; t < S.nthreads; ++t) {
+        Fiber& f = S.fibers[t]; f.done = false;
+        f.tid = U3{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
+        f.lane = t & 63; f.wave = t >> 6;
+        getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())trampoline, 0);
+    }
+}
+// run the block whose state is in S until it finishes (true) or every live fiber is stuck behind a wait for another block (false)
+inline bool run_current(int& left) {
+    long guard = 0;
+    while (left > 0) {
+        const unsigned long ev0 = S.events; S.spin_seen = false;
         for (int t = 0; t < S.nthreads; ++t) {
-            Fiber& f = S.fibers[t]; f.done = false;
-            f.tid = U3{t % block.x, (t / block.x) % block.y, t / (block.x * block.y)};
-            f.lane = t & 63; f.wave = t >> 6;
-            getcontext(&f.ctx); f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = STACK; f.ctx.uc_link = nullptr;
-            makecontext(&f.ctx, (void (*)())trampoline, 0);
+            Fiber& f = S.fibers[t]; if (f.done) continue;
+            S.cur = &f; swapcontext(&S.sched, &f.ctx);
+            if (f.done) { --left; S.events++; }
         }
-        int left = S.nthreads, guard = 0;
-        while (left > 0) {
-            int progressed = 0;
-            for (int t = 0; t < S.nthreads; ++t) {
-                Fiber& f = S.fibers[t]; if (f.done) continue;
-                S.cur = &f; swapcontext(&S.sched, &f.ctx);
-                if (f.done) { --left; ++progressed; }
-            }
-            if (!progressed && ++guard > 100000000) { fprintf(stderr, "hipemu: deadlock (barrier divergence?)\n"); abort(); }
+        if (S.events == ev0) {
+            if (S.spin_seen) return false;
+            if (++guard > 100000000) { fprintf(stderr, "hipemu: deadlock (barrier divergence?)\n"); abort(); }
         }
     }
+    return true;
+}
+inline void park(std::vector<Parked>& parked, int left) {
+    Parked p; p.fibers.swap(S.fibers); p.waves.swap(S.waves); p.bid = S.bid; p.bar_arrived = S.bar_arrived; p.bar_gen = S.bar_gen; p.left = left;
+    parked.push_back(std::move(p));
+}
+// give every parked block a turn; finished ones hand their fiber stacks back to the pool
+inline bool retry_parked(std::vector<Parked>& parked, std::vector<std::vector<Fiber>>& pool) {
+    bool any = false;
+    for (size_t i = 0; i < parked.size();) {
+        Parked& p = parked[i];
+        std::vector<Fiber> keepf; std::vector<Wave> keepw; keepf.swap(S.fibers); keepw.swap(S.waves);
+        S.fibers.swap(p.fibers); S.waves.swap(p.waves); S.bid = p.bid; S.bar_arrived = p.bar_arrived; S.bar_gen = p.bar_gen;
+        int left = p.left;
+        const unsigned long ev0 = S.events;
+        const bool fin = run_current(left);
+        if (S.events != ev0) any = true;
+        if (fin) { pool.push_back(std::move(S.fibers)); S.fibers.clear(); S.fibers.swap(keepf); S.waves.swap(keepw); parked.erase(parked.begin() + i); }
+        else { p.fibers.swap(S.fibers); p.waves.swap(S.waves); p.bar_arrived = S.bar_arrived; p.bar_gen = S.bar_gen; p.left = left; S.fibers.swap(keepf); S.waves.swap(keepw); ++i; }
+    }
+    return any;
+}
+template <class F> void launch(dim3 grid, dim3 block, F&& fn) {
+    std::function<void()> body = fn;
+    S.grid = grid; S.block = block; S.body = &body;
+    S.nthreads = block.x * block.y * block.z;
+    std::vector<Parked> parked; std::vector<std::vector<Fiber>> pool;
+    for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+        if (S.fibers.empty() && !pool.empty()) { S.fibers.swap(pool.back()); pool.pop_back(); }
+        S.bid = U3{bx, by, bz};
+        init_fibers(block);
+        int left = S.nthreads;
+        if (!run_current(left)) { park(parked, left); retry_parked(parked, pool); }
+        else if (!parked.empty()) retry_parked(parked, pool);
+    }
+    long guard = 0;
+    while (!parked.empty()) {
+        if (!retry_parked(parked, pool) && ++guard > 1000000) { fprintf(stderr, "hipemu: deadlock (a block waits for another block that never arrives)\n"); abort(); }
+    }
+    for (auto& v : pool) for (auto& f : v) free(f.stack);     // the stacks of parked blocks; S.fibers keeps its own for the next launch
 }
 
 typedef float f32x16_ __attribute__((ext_vector_type(16)));
