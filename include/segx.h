@@ -310,7 +310,10 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 6 = schedule variant of the bf16x6 kernels with IDENTICAL results (0 = product; 1 = raised wave priority in the MFMA phase / of the consumer
  * waves; 6 = split-early schedule, 7 = product schedule at two waves per SIMD); the ablation variants 2..5, whose results are NOT the GEMM, exist only
  * in -DSEGX_BENCH builds (tools/build_variant.py) and are rejected by the product library; knob 9 = workgroups of a persistent launch of the wave-specialised bf16x6 kernels (default 256 = one per CU; a multiple of 8);
- * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count) */
+ * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count);
+ * knob 3 = form of training BatchNorm when the library computes the statistics itself (segx_bn_act_fwd2 with nparts == 0, segx_bn_act_bwd2): 0 (default) =
+ * channel-resident where a channel fits one workgroup, else a TEAM of workgroups per channel (one launch, the slabs stay in registers across a team barrier),
+ * else two launches; 1 = never teams; 2 = teams for every shape with S % 4 == 0 (tests).  Same results to fp32 summation order. */
 int segx_tune(int knob, int value);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
  * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)

@@ -454,6 +454,144 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
     __builtin_amdgcn_sched_barrier(0);
     bn_res_bwd_tail<TEAM, KP, BMAX, ACT>(g, B, h, d, off, tl, c, red);
 }
+// =================================================================================================
+// r04-h: TEAM BatchNorm for the planes that do not fit one workgroup (S >= 16384 floats at batch 6: 30 of EfficientNet-B4's 96 layers, but 5.6 of
+// the 8.5 GB one pass over all BatchNorm inputs moves).  A team of B * cpp workgroups owns a channel; a workgroup keeps ITS chunk of one plane
+// (256 x KP float4) in registers across a team barrier (common.h: team_arrive_and_wait):
+//   forward : load -> (n, mean, M2) of the chunk -> global partial -> barrier -> every member folds the team's partials (bn_fold: bit-identical in
+//             every workgroup) -> normalise / activate / skip / pool -> store.       1 read + 1 write   (two launches: 2 reads + 1 write)
+//   backward: load x, dy -> xhat, du in registers -> the chunk's two sums -> barrier -> the team's sums in member order -> dx.
+//                                                                                     2 reads + 1 write  (two launches: 4 reads + 1 write)
+// One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
+// =================================================================================================
+struct BnTeam { unsigned* ctr; float* parts; int B, cpp; };       // parts: float4 [C][B * cpp]
+constexpr int BN_TEAM_KP = 16;                                   // 256 x 16 float4 = 16384 floats per workgroup
+template <int KP, bool POOL, int ACT, int RESID>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
+    __shared__ float red[4];
+    const int TS = t.B * t.cpp, tl = threadIdx.x;
+    const int c = blockIdx.x / TS, r = blockIdx.x - c * TS, b = r / t.cpp, ch = r - b * t.cpp;
+    const int C = g.C, S4 = (int)(g.S >> 2), j0 = ch * 256 * KP, act = g.act;
+    const int64_t S = g.S, plane = ((int64_t)b * C + c) * S;
+    unsigned off[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { const int j = j0 + tl + 256 * k; off[k] = 16u * (unsigned)(j < S4 ? j : S4 - 1); }
+    f32x4 v[KP];
+    const ws_gptr xb = ws_uniform_base(g.X + plane);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) v[k] = ws_load<f32x4>(xb, off[k]);
+    __builtin_amdgcn_sched_barrier(0);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (!(j0 + tl + 256 * k < S4)) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const int left4 = S4 - j0;
+    const float n = 4.0f * (float)(left4 < 256 * KP ? left4 : 256 * KP);            // floats of this chunk
+    const float m = block_sum<4>(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const float d0 = v[k].x - m, d1 = v[k].y - m, d2 = v[k].z - m, d3 = v[k].w - m;
+        q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+    }
+    q = block_sum<4>(q, red);
+    if (tl == 0) reinterpret_cast<float4*>(t.parts)[(int64_t)c * TS + r] = make_float4(n, m, q, 0.f);
+    team_arrive_and_wait(t.ctr + c, (unsigned)TS);
+    const BnPart st = bn_fold(t.parts, c, TS);
+    const float mean = st.mean, var = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
+    if (r == 0 && tl == 0) {
+        g.mean[c] = mean; g.var[c] = var;
+        if (g.run_mean) {
+            g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * mean;
+            g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * (st.m2 / fmaxf(st.n - 1.0f, 1.0f));
+        }
+    }
+    const float sc = rsqrtf(var + g.eps) * g.w[c], sh = g.b[c] - mean * sc;
+    const bool resid = RESID < 0 ? g.resid != nullptr : RESID != 0;
+    const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
+    const ws_gptr_w yb = ws_uniform_base_w(g.Y + plane);
+    const ws_gptr rb = ws_uniform_base((resid ? g.resid : g.X) + plane);
+    float acc = 0.f;
+    constexpr int G = 4;                                         // the skip connection's float4 are requested G at a time
+#pragma unroll
+    for (int k0 = 0; k0 < KP; k0 += G) {
+        f32x4 rv[G];
+        if (resid) {
+#pragma unroll
+            for (int e = 0; e < G; ++e) rv[e] = ws_load<f32x4>(rb, off[k0 + e]);
+        }
+#pragma unroll
+        for (int e = 0; e < G; ++e) {
+            const int k = k0 + e;
+            f32x4 o;
+            o.x = act_fwd_c<ACT>(v[k].x * sc + sh, act); o.y = act_fwd_c<ACT>(v[k].y * sc + sh, act);
+            o.z = act_fwd_c<ACT>(v[k].z * sc + sh, act); o.w = act_fwd_c<ACT>(v[k].w * sc + sh, act);
+            if (resid) { o.x = o.x * dcs + rv[e].x; o.y = o.y * dcs + rv[e].y; o.z = o.z * dcs + rv[e].z; o.w = o.w * dcs + rv[e].w; }
+            if (j0 + tl + 256 * k < S4) {
+                ws_store<f32x4>(yb, off[k], o);
+                if (POOL) acc += (o.x + o.y) + (o.z + o.w);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (POOL) {
+        acc = block_sum<4>(acc, red);
+        if (tl == 0) g.psum[((int64_t)b * C + c) * t.cpp + ch] = acc;
+    }
+}
+template <int KP, int ACT>
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void bn_act_bwd_team_kernel(BnBwdArgs g, BnTeam t) {
+    __shared__ float red[4];
+    const int TS = t.B * t.cpp, tl = threadIdx.x;
+    const int c = blockIdx.x / TS, r = blockIdx.x - c * TS, b = r / t.cpp, ch = r - b * t.cpp;
+    const int C = g.C, S4 = (int)(g.S >> 2), j0 = ch * 256 * KP, act = g.act;
+    const int64_t S = g.S;
+    unsigned off[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { const int j = j0 + tl + 256 * k; off[k] = 16u * (unsigned)(j < S4 ? j : S4 - 1); }
+    f32x4 h[KP], d[KP];
+    const ws_gptr xb = ws_uniform_base(g.X + ((int64_t)b * C + c) * S), gb = ws_uniform_base(g.dY + (int64_t)b * g.dy_bs + (int64_t)c * S);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) { h[k] = ws_load<f32x4>(xb, off[k]); d[k] = ws_load<f32x4>(gb, off[k]); }
+    __builtin_amdgcn_sched_barrier(0);
+    const float rstd = rsqrtf(g.var[c] + g.eps), m = g.mean[c], wc = g.w[c], bc_ = g.b[c];
+    const int pl = b * C + c;
+    const float gt = (g.gate ? g.gate[pl] : 1.0f) * drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b), dp = g.dpool ? g.dpool[pl] * g.inv_S : 0.f;
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        const bool ok = j0 + tl + 256 * k < S4;
+        const f32x4 xv = h[k], gv = d[k];
+        f32x4 hh, dd;
+        hh.x = (xv.x - m) * rstd; hh.y = (xv.y - m) * rstd; hh.z = (xv.z - m) * rstd; hh.w = (xv.w - m) * rstd;
+        dd.x = (gv.x * gt + dp) * act_grad_c<ACT>(hh.x * wc + bc_, act); dd.y = (gv.y * gt + dp) * act_grad_c<ACT>(hh.y * wc + bc_, act);
+        dd.z = (gv.z * gt + dp) * act_grad_c<ACT>(hh.z * wc + bc_, act); dd.w = (gv.w * gt + dp) * act_grad_c<ACT>(hh.w * wc + bc_, act);
+        if (!ok) { dd = f32x4{0.f, 0.f, 0.f, 0.f}; hh = dd; }
+        h[k] = hh; d[k] = dd;
+        a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
+    }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (tl == 0) reinterpret_cast<float2*>(t.parts)[(int64_t)c * TS + r] = make_float2(a, q);
+    team_arrive_and_wait(t.ctr + c, (unsigned)TS);
+    // the team's sums in member order: the same numbers in every workgroup of the team
+    const float2* tp = reinterpret_cast<const float2*>(t.parts) + (int64_t)c * TS;
+    float A = 0.f, Q = 0.f;
+    for (int i = 0; i < TS; ++i) { const float2 p2 = tp[i]; A += p2.x; Q += p2.y; }
+    if (r == 0 && tl == 0) { g.db[c] = A; g.dw[c] = Q; }
+    const float inv_n = 1.0f / ((float)t.B * (float)S), k1 = A * inv_n, k2 = Q * inv_n, sc = wc * rstd;
+    const ws_gptr_w ob = ws_uniform_base_w(g.dX + ((int64_t)b * C + c) * S);
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+        if (j0 + tl + 256 * k < S4) {
+            f32x4 o;
+            o.x = sc * (d[k].x - k1 - h[k].x * k2); o.y = sc * (d[k].y - k1 - h[k].y * k2);
+            o.z = sc * (d[k].z - k1 - h[k].z * k2); o.w = sc * (d[k].w - k1 - h[k].w * k2);
+            ws_store<f32x4>(ob, off[k], o);
+        }
+    }
+}
 // which channel-resident form serves (B planes of S floats) -- 0 none, else TEAM * 16 + KP packed: registers per lane <= cap float4 (forward: x; backward: xhat + du)
 static inline int bn_res_form(int B, int64_t S, bool backward) {
     if ((S & 3) || B < 1 || B > 8 || S > 8192) return 0;
@@ -466,6 +604,39 @@ static inline int bn_res_form(int B, int64_t S, bool backward) {
     return 0;
 }
 
+// chunks per plane of the team form, 0 = not served: S % 4 == 0, a team of at most 128 workgroups, and it must pay (a plane of at least one full chunk)
+static inline int bn_team_cpp(int B, int64_t S) {
+    if ((S & 3) || B < 1 || S < 1024 * BN_TEAM_KP) return 0;
+    const int64_t cpp = (S / 4 + 256 * BN_TEAM_KP - 1) / (256 * BN_TEAM_KP);
+    return (cpp * B <= 128) ? (int)cpp : 0;
+}
+// policy (knob 3): which form serves training BatchNorm on (B, S) when the library computes the statistics itself: 2 resident, 1 team, 0 two launches
+static inline int bn_auto_form(int B, int64_t S, bool backward) {
+    const int path = kget(knobs().bn_path);
+    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4) return 1;                    // tests: the team form on small planes too (cpp = ceil)
+    if (bn_res_form(B, S, backward)) return 2;
+    if (path != 1 && bn_team_cpp(B, S)) return 1;
+    return 0;
+}
+static inline int bn_team_chunks(int B, int64_t S) { return (int)((S / 4 + 256 * BN_TEAM_KP - 1) / (256 * BN_TEAM_KP)); }
+
+template <int KP>
+static void bn_team_launch_fwd(const BnFwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream, bool pool) {
+    const bool resid = g.resid != nullptr;
+#define SEGX_BN_TF(P, A, R) hipLaunchKernelGGL((bn_act_fwd_team_kernel<KP, P, A, R>), grid, dim3(256), 0, stream, g, t)
+    if (pool) { if (!resid && g.act == ACT_SWISH) SEGX_BN_TF(true, ACT_SWISH, 0); else SEGX_BN_TF(true, -1, -1); }
+    else if (!resid && g.act == ACT_SWISH) SEGX_BN_TF(false, ACT_SWISH, 0);
+    else if (g.act == ACT_NONE) { if (resid) SEGX_BN_TF(false, ACT_NONE, 1); else SEGX_BN_TF(false, ACT_NONE, 0); }
+    else if (!resid && g.act == ACT_RELU) SEGX_BN_TF(false, ACT_RELU, 0);
+    else SEGX_BN_TF(false, -1, -1);
+#undef SEGX_BN_TF
+}
+template <int KP>
+static void bn_team_launch_bwd(const BnBwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream) {
+#define SEGX_BN_TB(A) hipLaunchKernelGGL((bn_act_bwd_team_kernel<KP, A>), grid, dim3(256), 0, stream, g, t)
+    if (g.act == ACT_SWISH) SEGX_BN_TB(ACT_SWISH); else if (g.act == ACT_NONE) SEGX_BN_TB(ACT_NONE); else if (g.act == ACT_RELU) SEGX_BN_TB(ACT_RELU); else SEGX_BN_TB(-1);
+#undef SEGX_BN_TB
+}
 // The resident kernels exist per (activation, pooling, skip) combination the backbones use -- swish (+ pooling), none (+ skip), relu -- and once with
 // the run-time values for everything else.
 template <int T, int K, int BM>
@@ -1045,7 +1216,7 @@ static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1
 using namespace segx;
 #define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
 
-extern "C" int64_t segx_bn_ws_floats(int B, int C) { return (int64_t)B * C * BN_SLABS * 2; }
+extern "C" int64_t segx_bn_ws_floats(int B, int C) { return i64max((int64_t)B * C * BN_SLABS * 2, (int64_t)C * (128 * 2 + 1)); }   /* two-launch slab sums, or a team's (sum, sum) pairs + arrival counters */
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
@@ -1069,8 +1240,11 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
 // ---- r04: two-launch training BatchNorm (bn_stats_partial_kernel / a producer's partials -> bn_act_fwd2_kernel) ------------------------------
 extern "C" int64_t segx_plane_chunks(int64_t S) { return plane_chunks(S, 8); }
 /* pooling chunks per plane that segx_bn_act_fwd2 writes into psum: auto_stats != 0 = the call computes the statistics itself (parts given, nparts = 0) */
-extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) { return (auto_stats && bn_res_form(B, S, false)) ? 1 : plane_chunks(S, 8); }
-extern "C" int64_t segx_bn_parts_floats(int B, int C) { return ((int64_t)B * BN_SLABS + 1) * C * 4; }
+extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) {
+    const int af = auto_stats ? bn_auto_form(B, S, false) : 0;
+    return af == 2 ? 1 : af == 1 ? bn_team_chunks(B, S) : plane_chunks(S, 8);
+}
+extern "C" int64_t segx_bn_parts_floats(int B, int C) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, (int64_t)C * (128 * 4 + 1)); }   /* slab partials, or a team's partials + arrival counters */
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                                 int B, int C, int64_t S, float eps, int act, void* stream_) {
@@ -1088,7 +1262,16 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
     if (parts && nparts == 0) {
         // AUTO: the library computes the batch statistics itself -- channel-resident (one launch) where the channel's B planes fit a team's registers,
         // otherwise partials into `parts` (segx_bn_parts_floats) + the folding apply pass below
-        const int form = bn_res_form(B, S, false);
+        const int af = bn_auto_form(B, S, false);
+        if (af == 1) {
+            BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = const_cast<float*>(parts); t.ctr = reinterpret_cast<unsigned*>(t.parts + (int64_t)C * B * t.cpp * 4);
+            SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
+            g.parts = nullptr;
+            if (hipMemsetAsync(t.ctr, 0, sizeof(unsigned) * C, stream) != hipSuccess) return fail(1, "segx_bn_act_fwd2: memset of the arrival counters failed");
+            bn_team_launch_fwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
+            return check_launch("segx_bn_act_fwd2/team");
+        }
+        const int form = af == 2 ? bn_res_form(B, S, false) : 0;
         if (form) {
             g.parts = nullptr;
             const int team = form >> 4, kp = form & 15;
@@ -1141,11 +1324,19 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     if (dy_bs == 0) dy_bs = (int64_t)C * S;
     SEGX_REQUIRE(dy_bs >= (int64_t)C * S && ((S & 3) != 0 || (dy_bs & 3) == 0), "segx_bn_act_bwd2: bad dY batch stride %lld", (long long)dy_bs);
     SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
-    const int form = training ? bn_res_form(B, S, true) : 0;
+    const int af = training ? bn_auto_form(B, S, true) : 0;
+    BnBwdArgs g;
+    g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
+    g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
+    if (af == 1) {
+        BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = ws; t.ctr = reinterpret_cast<unsigned*>(ws + (int64_t)C * B * t.cpp * 2);
+        SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
+        if (hipMemsetAsync(t.ctr, 0, sizeof(unsigned) * C, stream) != hipSuccess) return fail(1, "segx_bn_act_bwd2: memset of the arrival counters failed");
+        bn_team_launch_bwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
+        return check_launch("segx_bn_act_bwd2/team");
+    }
+    const int form = af == 2 ? bn_res_form(B, S, true) : 0;
     if (form) {
-        BnBwdArgs g;
-        g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
-        g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
         const int team = form >> 4, kp = form & 15;
         const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
         if (team == 64) bn_res_launch_bwd<64, 1, 8>(g, B, rgrid, stream);

@@ -64,6 +64,31 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
     *reinterpret_cast<V SEGX_GLOBAL*>(base + byte_off) = v;
 }
 
+// ---- team barrier: the workgroups of a TEAM (consecutive blockIdx.x) each add 1 to *ctr (zeroed before the launch) and wait until `expected`
+// have arrived.  Used by the cooperative BatchNorm kernels (backbone.hip): every member keeps its slab of a channel in registers across the wait,
+// which is what saves the second read.  Forward progress: a waiting workgroup needs its LATER team mates to be dispatched.  Workgroups are
+// dispatched in blockIdx order per XCD (round-robin over the eight XCDs), so when the next workgroup n of an XCD cannot start, every resident
+// workgroup there has a smaller index; those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as one XCD's
+// share of a team (team / 8 workgroups) is smaller than its resident slots (>= 64), which the host guarantees (team <= 128).  The spin is BOUNDED:
+// if the assumption were ever wrong the kernel produces wrong numbers (the parity tests fail) instead of hanging the device.
+#ifndef SEGX_TEAM_SPIN
+#define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(4)
+#define SEGX_TEAM_SPIN_DONE() ((void)0)
+#define SEGX_TEAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+__device__ __forceinline__ void team_arrive_and_wait(unsigned* ctr, unsigned expected) {
+    // the caller's thread 0 has written this workgroup's partial result to global memory
+    if (threadIdx.x == 0) {
+        __threadfence();                                   // release: the partial is visible device-wide (other XCDs' L2 included) before the count
+        atomicAdd(ctr, 1u);
+        unsigned spins = 0;
+        while (SEGX_TEAM_LOAD(ctr) < expected && ++spins < (1u << 20)) SEGX_TEAM_SPIN();
+        SEGX_TEAM_SPIN_DONE();
+    }
+    __syncthreads();
+    __threadfence();                                       // acquire, in every wave: the mates' partials are read from memory, not from a stale cache line
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -175,6 +200,7 @@ struct Knobs {
     std::atomic<int> dw_strip_outputs{8192};        // knob 8
     std::atomic<int> interp_variant{0};             // knob 1
     std::atomic<int> conv_small_policy{0};          // knob 2
+    std::atomic<int> bn_path{0};                    // knob 3: 0 = resident -> workgroup teams -> two launches; 1 = no teams; 2 = teams even where the resident form serves (tests)
 };
 inline Knobs& knobs() { static Knobs k; return k; }
 inline int kget(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }

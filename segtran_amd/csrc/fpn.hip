@@ -433,6 +433,7 @@ extern "C" int segx_tune(int knob, int value) {
     // every knob accepts only the settings the product suite exercises (tests/): an unknown value is an error, never a silent new code path
     if (knob == 1) { if (value < 0 || value > 2) return -1; k.interp_variant = value; return 0; }
     if (knob == 2) { if (value != 0 && value != 1) return -1; k.conv_small_policy = value; return 0; }
+    if (knob == 3) { if (value < 0 || value > 2) return -1; k.bn_path = value; return 0; }     // training BatchNorm: 0 resident -> teams -> two launches, 1 no teams, 2 teams everywhere
     if (knob == 4) { if (value != SEGX_ENGINE_F32 && value != SEGX_ENGINE_BF16X6) return -1; return k.engine.exchange(value); }
     if (knob == 8) { if (value < 256) return -1; k.dw_strip_outputs = value; return 0; }
     if (knob == 7) { if (value < 0 || value > 2) return -1; k.conv_x6_wgrad_all = value; return 0; }

@@ -1,6 +1,6 @@
 """Build tests/hipemu/build/libsegx_emu.so: the product's HIP sources compiled UNMODIFIED by the host
 clang++ against the fiber SIMT emulator in tests/hipemu/hip/hip_runtime.h (test infrastructure only)."""
-import os, subprocess, sys, glob, hashlib
+import os, subprocess, sys, glob, hashlib, fcntl
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -19,7 +19,14 @@ def build(verbose=False):
         h.update(open(d, 'rb').read())
     stamp = os.path.join(OUT, 'stamp')
     lib = os.path.join(OUT, 'libsegx_emu.so')
-    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
+    # one builder at a time (pytest-xdist workers start together): the others wait on the lock and find the finished library
+    with open(os.path.join(OUT, 'lock'), 'w') as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        return _build_locked(srcs, h.hexdigest(), stamp, lib, verbose)
+
+
+def _build_locked(srcs, digest, stamp, lib, verbose):
+    if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == digest:
         return lib
     objs = []
     procs = []
@@ -35,8 +42,9 @@ def build(verbose=False):
             raise RuntimeError('hipemu build failed for %s:\n%s' % (s, out))
         if verbose and out:
             print(out)
-    subprocess.check_call([CXX, '-shared', '-o', lib] + objs)
-    open(stamp, 'w').write(h.hexdigest())
+    subprocess.check_call([CXX, '-shared', '-o', lib + '.tmp'] + objs)
+    os.replace(lib + '.tmp', lib)                          # a reader never sees a half-written library
+    open(stamp, 'w').write(digest)
     return lib
 
 

@@ -175,6 +175,27 @@ def test_bn_with_skip_add_and_drop_connect(backend, shape, rate, training):
     close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
 
 
+@pytest.mark.parametrize('path', [1, 2])
+@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 3, 130, 132), (6, 2, 64, 64), (2, 4, 3, 4, 5)])
+def test_bn_forms_team_and_two_launch(backend, path, shape):
+    """segx_tune knob 3.  2 = the TEAM form on every shape (a team of B x chunks workgroups per channel keeps the channel in registers across a team
+    barrier -- on the emulator a block that waits for its mates is parked while later blocks run): one chunk per plane on the small shapes, two on
+    130 x 132; 1 = never teams (130 x 132 then takes the two-launch form the default no longer reaches).  Plain / relu / swish, the skip + drop_connect
+    tail and the squeeze-excite pooling variant must all match PyTorch in forward, backward and running statistics."""
+    L = backend.L
+    assert L.c.segx_tune(3, 7) < 0                      # unknown settings are refused
+    assert L.c.segx_tune(3, path) == 0
+    try:
+        for act in (0, 1, 2):
+            test_bn_act.__wrapped__(backend, shape, act, True) if hasattr(test_bn_act, '__wrapped__') else test_bn_act(backend, shape, act, True)
+        if len(shape) == 4:
+            test_bn_with_skip_add_and_drop_connect(backend, shape, 0.5, True)
+            B, C, H, W = shape
+            test_bn_act_squeeze_excite_fused(backend, B, C, 2, H, W, True)
+    finally:
+        assert L.c.segx_tune(3, 0) == 0
+
+
 def test_drop_connect_draws_differ_between_calls_and_follow_the_seed(backend):
     B, C = 16, 2
     bn = torch.nn.BatchNorm2d(C).train()
