@@ -164,6 +164,19 @@ __device__ __forceinline__ BnPart bn_fold(const float* __restrict__ parts, int c
     }
     return s;
 }
+// the same fold over partials written by OTHER workgroups of this launch (team BatchNorm): coherent loads (common.h: team_load)
+__device__ __forceinline__ BnPart bn_fold_team(const float* parts, int c, int nparts) {
+    const int lane = threadIdx.x & 63;
+    const float* p = parts + (int64_t)c * nparts * 4;
+    BnPart s; s.n = 0.f; s.mean = 0.f; s.m2 = 0.f;
+    for (int i = lane; i < nparts; i += 64) { BnPart t; t.n = team_load(p + 4 * i); t.mean = team_load(p + 4 * i + 1); t.m2 = team_load(p + 4 * i + 2); s = bn_merge(s, t); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        BnPart t; t.n = __shfl_xor(s.n, o); t.mean = __shfl_xor(s.mean, o); t.m2 = __shfl_xor(s.m2, o);
+        s = (lane & o) ? bn_merge(t, s) : bn_merge(s, t);
+    }
+    return s;
+}
 // launch 1: grid (C, B, slabs) as bn_stats_stage1; parts[c][b * nsl + slab]
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ X, float* __restrict__ parts, int C, int64_t S) {
     __shared__ float red[4];
@@ -497,9 +510,9 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_tea
         q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
     }
     q = block_sum<4>(q, red);
-    if (tl == 0) reinterpret_cast<float4*>(t.parts)[(int64_t)c * TS + r] = make_float4(n, m, q, 0.f);
+    if (tl == 0) { float* pp = t.parts + ((int64_t)c * TS + r) * 4; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
     team_arrive_and_wait(t.ctr + c, (unsigned)TS);
-    const BnPart st = bn_fold(t.parts, c, TS);
+    const BnPart st = bn_fold_team(t.parts, c, TS);
     const float mean = st.mean, var = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
     if (r == 0 && tl == 0) {
         g.mean[c] = mean; g.var[c] = var;
@@ -573,12 +586,12 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void bn_act_bwd_tea
         a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (tl == 0) reinterpret_cast<float2*>(t.parts)[(int64_t)c * TS + r] = make_float2(a, q);
+    if (tl == 0) { float* pp = t.parts + ((int64_t)c * TS + r) * 2; team_store(pp, a); team_store(pp + 1, q); }
     team_arrive_and_wait(t.ctr + c, (unsigned)TS);
     // the team's sums in member order: the same numbers in every workgroup of the team
-    const float2* tp = reinterpret_cast<const float2*>(t.parts) + (int64_t)c * TS;
+    const float* tp = t.parts + (int64_t)c * TS * 2;
     float A = 0.f, Q = 0.f;
-    for (int i = 0; i < TS; ++i) { const float2 p2 = tp[i]; A += p2.x; Q += p2.y; }
+    for (int i = 0; i < TS; ++i) { A += team_load(tp + 2 * i); Q += team_load(tp + 2 * i + 1); }
     if (r == 0 && tl == 0) { g.db[c] = A; g.dw[c] = Q; }
     const float inv_n = 1.0f / ((float)t.B * (float)S), k1 = A * inv_n, k2 = Q * inv_n, sc = wc * rstd;
     const ws_gptr_w ob = ws_uniform_base_w(g.dX + ((int64_t)b * C + c) * S);

@@ -71,22 +71,31 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
 // workgroup there has a smaller index; those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as one XCD's
 // share of a team (team / 8 workgroups) is smaller than its resident slots (>= 64), which the host guarantees (team <= 128).  The spin is BOUNDED:
 // if the assumption were ever wrong the kernel produces wrong numbers (the parity tests fail) instead of hanging the device.
+// Memory: everything the members exchange (partials, counter) is accessed with RELAXED AGENT-SCOPE ATOMICS -- on gfx942 / gfx950 these are the sc1
+// forms, coherent across the XCDs' L2s for their own locations -- and NO agent-scope fence is used: an agent-scope release / acquire is
+// buffer_wbl2 / buffer_inv sc1, i.e. a write-back / invalidate of the XCD's whole L2 per workgroup (r04_i: the first version did that and ran at
+// 0.8 TB/s).  The only ordering needed is "my partial is written before my count": s_waitcnt vmcnt(0) between the write-through (sc1) stores and the add
+// (hipcc drops a workgroup-scope fence here altogether, so the wait is spelled out).
 #ifndef SEGX_TEAM_SPIN
-#define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(4)
+#define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(2)
 #define SEGX_TEAM_SPIN_DONE() ((void)0)
 #define SEGX_TEAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SEGX_TEAM_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SEGX_TEAM_ADD(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define SEGX_TEAM_ORDER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")    /* the write-through stores above have been acknowledged */
 #endif
+__device__ __forceinline__ void team_store(float* p, float v) { SEGX_TEAM_STORE(p, v); }
+__device__ __forceinline__ float team_load(const float* p) { return SEGX_TEAM_LOAD(p); }
 __device__ __forceinline__ void team_arrive_and_wait(unsigned* ctr, unsigned expected) {
-    // the caller's thread 0 has written this workgroup's partial result to global memory
+    // the caller's thread 0 has written this workgroup's partial result with team_store
     if (threadIdx.x == 0) {
-        __threadfence();                                   // release: the partial is visible device-wide (other XCDs' L2 included) before the count
-        atomicAdd(ctr, 1u);
+        SEGX_TEAM_ORDER();
+        SEGX_TEAM_ADD(ctr, 1u);
         unsigned spins = 0;
         while (SEGX_TEAM_LOAD(ctr) < expected && ++spins < (1u << 20)) SEGX_TEAM_SPIN();
         SEGX_TEAM_SPIN_DONE();
     }
     __syncthreads();
-    __threadfence();                                       // acquire, in every wave: the mates' partials are read from memory, not from a stale cache line
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------

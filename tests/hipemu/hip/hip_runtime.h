@@ -31,7 +31,10 @@
 #define SEGX_WAVE_UNIFORM(x) (x)         /* v_readfirstlane of a value that is uniform over the wave */
 #define SEGX_TEAM_SPIN() hipemu::grid_spin_yield()      /* one poll of a team barrier: later blocks of the grid run meanwhile */
 #define SEGX_TEAM_SPIN_DONE() hipemu::grid_spin_done()
-#define SEGX_TEAM_LOAD(p) (*(volatile unsigned*)(p))
+#define SEGX_TEAM_LOAD(p) (*(p))
+#define SEGX_TEAM_STORE(p, v) (*(p) = (v))
+#define SEGX_TEAM_ADD(p, v) (*(p) += (v))
+#define SEGX_TEAM_ORDER() ((void)0)
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
 #define SEGX_LOAD_FENCE() ((void)0)                       /* compiler-only fence of the device build */
