@@ -194,8 +194,8 @@ int segx_mt_gather(const void* const* src, void* const* dst, const int64_t* size
  * Tensors are NC[D]HW fp32; S = product of the spatial dims; a (sample, channel) plane is contiguous.
  * act: 0 none, 1 swish (efficientnet/utils.py:64-79), 2 ReLU (aj_i3d.py:95-96), 3 LeakyReLU(0.2) (networks/discriminator.py:14-21).
  * ------------------------------------------------------------------------------------------- */
-/* scratch of the BatchNorm backward reductions: segx_bn_ws_floats(B, C) floats */
-int64_t segx_bn_ws_floats(int B, int C);
+/* scratch of the BatchNorm backward reductions: segx_bn_ws_floats(B, C, S) floats (S = 0: the two-launch forms only -- what segx_bn_act_bwd_reduce / _apply need) */
+int64_t segx_bn_ws_floats(int B, int C, int64_t S);
 /* Backward of BatchNorm (+ activation): dX, dw[C], db[C]; training != 0 differentiates through the batch statistics.  One process: segx_bn_act_bwd2 (below).
  * gate / dpool ([B*C]; gate needs dpool, dpool alone = gate of one): a squeeze-excite gate multiplies the BatchNorm output (Z = Y * gate[b][c],
  * efficientnet/model.py:110) and dY is the gradient w.r.t. Z: the kernels then use dY * gate[b][c] + dpool[b][c] * inv_S in place of dY (dpool = gradient
@@ -214,7 +214,7 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  * together with the ops around it in an MBConv block (swish :98,:102; squeeze-excite pooling :106; drop_connect + skip add :118-122).
  *   parts: [C][nparts] float4 records (n, mean, M2, -) of disjoint runs covering the B*S elements of each channel; Chan et al.'s merge makes the
  *   result independent of how a producer cut the data (nparts > 0: a producer's own partials [C][nparts]; the buffer then needs C*4 more
- *   floats behind them when nparts > 256).  The buffer holds segx_bn_parts_floats(B, C) floats, 16-byte aligned.
+ *   floats behind them when nparts > 256).  The buffer holds segx_bn_parts_floats(B, C, S) floats, 16-byte aligned.
  *   nparts == 0 with parts given = AUTO: the library computes the statistics itself, using `parts` as scratch -- in ONE launch for the whole
  *   layer when a channel's B planes fit one team's registers (S <= 4096 floats, B <= 8: "channel-resident", 66 of EfficientNet-B4's 96 layers at
  *   512 x 512 with the stride-1 stem), else a statistics-partials launch + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
@@ -225,16 +225,16 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  *   `sample` of stream (seed, offset): efficientnet/utils.py:129-154); dc_p = 0: plain skip add. */
 int64_t segx_plane_chunks(int64_t S);
 int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats);
-int64_t segx_bn_parts_floats(int B, int C);
+int64_t segx_bn_parts_floats(int B, int C, int64_t S);
 /* synchronised BatchNorm (nn.SyncBatchNorm, train2d.py:1109), local half: ONE partial (n, mean, M2) per channel of this process's batch into part [C]
- * float4 (ws: segx_bn_parts_floats(B, C) floats of scratch).  The ranks all-gather their partials into [ranks][C] float4 and hand them to
+ * float4 (ws: segx_bn_parts_floats(B, C, S) floats of scratch).  The ranks all-gather their partials into [ranks][C] float4 and hand them to
  * segx_bn_act_fwd2 with nparts = -ranks: the apply pass merges them (Chan) itself and updates the running statistics -- no merge launch. */
 int segx_bn_stats_local(const float* X, float* part, float* ws, int B, int C, int64_t S, void* stream);
 int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                      const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                      int B, int C, int64_t S, float eps, int act, void* stream);
 /* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
- * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C) floats.
+ * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C, S) floats.
  * training != 0 and a channel-resident shape: ONE launch (x and dy read once).  dy_bs: batch stride of dY in floats (0 = dense, C * S): the gradient of
  * one operand of a channel concatenation (an Inception module's branches, aj_i3d.py:139-141) is read in place from the concatenation's gradient. */
 int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,

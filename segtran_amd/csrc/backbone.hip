@@ -470,14 +470,14 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
 // =================================================================================================
 // r04-h: TEAM BatchNorm for the planes that do not fit one workgroup (S >= 16384 floats at batch 6: 30 of EfficientNet-B4's 96 layers, but 5.6 of
 // the 8.5 GB one pass over all BatchNorm inputs moves).  A team of B * cpp workgroups owns a channel; a workgroup keeps ITS chunk of one plane
-// (256 x KP float4) in registers across a team barrier (common.h: team_arrive_and_wait):
+// (256 x KP float4) in registers across a team exchange (common.h: team_exchange):
 //   forward : load -> (n, mean, M2) of the chunk -> global partial -> barrier -> every member folds the team's partials (bn_fold: bit-identical in
 //             every workgroup) -> normalise / activate / skip / pool -> store.       1 read + 1 write   (two launches: 2 reads + 1 write)
 //   backward: load x, dy -> xhat, du in registers -> the chunk's two sums -> barrier -> the team's sums in member order -> dx.
 //                                                                                     2 reads + 1 write  (two launches: 4 reads + 1 write)
 // One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
 // =================================================================================================
-struct BnTeam { unsigned* ctr; float* parts; int B, cpp; };       // parts: float4 [C][B * cpp]
+struct BnTeam { unsigned* ctr; float* parts; float* mbox; int B, cpp; };       // parts: [C][B * cpp][4] floats, mbox: [C][B * cpp][TEAM_MBOX], ctr: [C] (common.h: team_exchange)
 constexpr int BN_TEAM_KP = 16;                                   // 256 x 16 float4 = 16384 floats per workgroup
 template <int KP, bool POOL, int ACT, int RESID>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
@@ -510,9 +510,11 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_tea
         q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
     }
     q = block_sum<4>(q, red);
-    if (tl == 0) { float* pp = t.parts + ((int64_t)c * TS + r) * 4; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
-    team_arrive_and_wait(t.ctr + c, (unsigned)TS);
-    const BnPart st = bn_fold_team(t.parts, c, TS);
+    const TeamBufs tb{t.ctr + c, t.parts + (int64_t)c * TS * 4, t.mbox + (int64_t)c * TS * TEAM_MBOX};
+    if (tl == 0) { float* pp = tb.parts + r * 4; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
+    float res[3];
+    team_exchange(tb, r, TS, res, [](const float* parts, int members, float (&o)[3]) { const BnPart f = bn_fold_team(parts, 0, members); o[0] = f.n; o[1] = f.mean; o[2] = f.m2; });
+    BnPart st; st.n = res[0]; st.mean = res[1]; st.m2 = res[2];
     const float mean = st.mean, var = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
     if (r == 0 && tl == 0) {
         g.mean[c] = mean; g.var[c] = var;
@@ -586,12 +588,21 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void bn_act_bwd_tea
         a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (tl == 0) { float* pp = t.parts + ((int64_t)c * TS + r) * 2; team_store(pp, a); team_store(pp + 1, q); }
-    team_arrive_and_wait(t.ctr + c, (unsigned)TS);
-    // the team's sums in member order: the same numbers in every workgroup of the team
-    const float* tp = t.parts + (int64_t)c * TS * 2;
-    float A = 0.f, Q = 0.f;
-    for (int i = 0; i < TS; ++i) { A += team_load(tp + 2 * i); Q += team_load(tp + 2 * i + 1); }
+    const TeamBufs tb{t.ctr + c, t.parts + (int64_t)c * TS * 4, t.mbox + (int64_t)c * TS * TEAM_MBOX};
+    if (tl == 0) { float* pp = tb.parts + r * 4; team_store(pp, a); team_store(pp + 1, q); }
+    float res[3];
+    // the team's sums: lane l takes members l, l + 64 (team <= 128) in that order, then a symmetric butterfly -- the same bits in every lane and every run
+    team_exchange(tb, r, TS, res, [](const float* parts, int members, float (&o)[3]) {
+        const int lane = threadIdx.x & 63;
+        const bool h0 = lane < members, h1 = lane + 64 < members;
+        const float a0 = team_load(parts + 4 * (h0 ? lane : 0)), q0 = team_load(parts + 4 * (h0 ? lane : 0) + 1);
+        const float a1 = team_load(parts + 4 * (h1 ? lane + 64 : 0)), q1 = team_load(parts + 4 * (h1 ? lane + 64 : 0) + 1);
+        float A = (h0 ? a0 : 0.f) + (h1 ? a1 : 0.f), Q = (h0 ? q0 : 0.f) + (h1 ? q1 : 0.f);
+#pragma unroll
+        for (int o2 = 1; o2 < 64; o2 <<= 1) { A += __shfl_xor(A, o2); Q += __shfl_xor(Q, o2); }
+        o[0] = A; o[1] = Q; o[2] = 0.f;
+    });
+    const float A = res[0], Q = res[1];
     if (r == 0 && tl == 0) { g.db[c] = A; g.dw[c] = Q; }
     const float inv_n = 1.0f / ((float)t.B * (float)S), k1 = A * inv_n, k2 = Q * inv_n, sc = wc * rstd;
     const ws_gptr_w ob = ws_uniform_base_w(g.dX + ((int64_t)b * C + c) * S);
@@ -1229,7 +1240,11 @@ static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1
 using namespace segx;
 #define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
 
-extern "C" int64_t segx_bn_ws_floats(int B, int C) { return i64max((int64_t)B * C * BN_SLABS * 2, (int64_t)C * (128 * 2 + 1)); }   /* two-launch slab sums, or a team's (sum, sum) pairs + arrival counters */
+static inline int64_t bn_team_floats(int B, int C, int64_t S) {       // partial slots + mailboxes + counters of the team form, 0 where it cannot serve
+    if (S <= 0 || (S & 3) || (bn_team_chunks(B, S) * (int64_t)B) > 128) return 0;
+    return (int64_t)C * B * bn_team_chunks(B, S) * (4 + TEAM_MBOX) + C;
+}
+extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S)); }
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
@@ -1257,7 +1272,7 @@ extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) {
     const int af = auto_stats ? bn_auto_form(B, S, false) : 0;
     return af == 2 ? 1 : af == 1 ? bn_team_chunks(B, S) : plane_chunks(S, 8);
 }
-extern "C" int64_t segx_bn_parts_floats(int B, int C) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, (int64_t)C * (128 * 4 + 1)); }   /* slab partials, or a team's partials + arrival counters */
+extern "C" int64_t segx_bn_parts_floats(int B, int C, int64_t S) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, bn_team_floats(B, C, S)); }
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                                 int B, int C, int64_t S, float eps, int act, void* stream_) {
@@ -1277,10 +1292,11 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
         // otherwise partials into `parts` (segx_bn_parts_floats) + the folding apply pass below
         const int af = bn_auto_form(B, S, false);
         if (af == 1) {
-            BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = const_cast<float*>(parts); t.ctr = reinterpret_cast<unsigned*>(t.parts + (int64_t)C * B * t.cpp * 4);
+            BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = const_cast<float*>(parts); t.mbox = t.parts + (int64_t)C * B * t.cpp * 4;
+            t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
             SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
-            if (hipMemsetAsync(t.ctr, 0, sizeof(unsigned) * C, stream) != hipSuccess) return fail(1, "segx_bn_act_fwd2: memset of the arrival counters failed");
+            if (hipMemsetAsync(t.mbox, 0, sizeof(float) * ((int64_t)C * B * t.cpp * TEAM_MBOX + C), stream) != hipSuccess) return fail(1, "segx_bn_act_fwd2: memset of the mailboxes failed");
             bn_team_launch_fwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             return check_launch("segx_bn_act_fwd2/team");
         }
@@ -1342,9 +1358,9 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
     g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
     if (af == 1) {
-        BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = ws; t.ctr = reinterpret_cast<unsigned*>(ws + (int64_t)C * B * t.cpp * 2);
+        BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
-        if (hipMemsetAsync(t.ctr, 0, sizeof(unsigned) * C, stream) != hipSuccess) return fail(1, "segx_bn_act_bwd2: memset of the arrival counters failed");
+        if (hipMemsetAsync(t.mbox, 0, sizeof(float) * ((int64_t)C * B * t.cpp * TEAM_MBOX + C), stream) != hipSuccess) return fail(1, "segx_bn_act_bwd2: memset of the mailboxes failed");
         bn_team_launch_bwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         return check_launch("segx_bn_act_bwd2/team");
     }

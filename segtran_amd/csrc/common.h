@@ -64,20 +64,25 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
     *reinterpret_cast<V SEGX_GLOBAL*>(base + byte_off) = v;
 }
 
-// ---- team barrier: the workgroups of a TEAM (consecutive blockIdx.x) each add 1 to *ctr (zeroed before the launch) and wait until `expected`
-// have arrived.  Used by the cooperative BatchNorm kernels (backbone.hip): every member keeps its slab of a channel in registers across the wait,
-// which is what saves the second read.  Forward progress: a waiting workgroup needs its LATER team mates to be dispatched.  Workgroups are
-// dispatched in blockIdx order per XCD (round-robin over the eight XCDs), so when the next workgroup n of an XCD cannot start, every resident
-// workgroup there has a smaller index; those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as one XCD's
-// share of a team (team / 8 workgroups) is smaller than its resident slots (>= 64), which the host guarantees (team <= 128).  The spin is BOUNDED:
-// if the assumption were ever wrong the kernel produces wrong numbers (the parity tests fail) instead of hanging the device.
-// Memory: everything the members exchange (partials, counter) is accessed with RELAXED AGENT-SCOPE ATOMICS -- on gfx942 / gfx950 these are the sc1
-// forms, coherent across the XCDs' L2s for their own locations -- and NO agent-scope fence is used: an agent-scope release / acquire is
-// buffer_wbl2 / buffer_inv sc1, i.e. a write-back / invalidate of the XCD's whole L2 per workgroup (r04_i: the first version did that and ran at
-// 0.8 TB/s).  The only ordering needed is "my partial is written before my count": s_waitcnt vmcnt(0) between the write-through (sc1) stores and the add
-// (hipcc drops a workgroup-scope fence here altogether, so the wait is spelled out).
+// ---- team exchange: the workgroups of a TEAM (consecutive blockIdx.x) combine one small partial result each and all receive the combination.
+// Used by the team BatchNorm kernels (backbone.hip): every member keeps its slab of a channel in registers across the exchange, which is what saves
+// the second read.  Protocol (per team: a counter, one partial slot and one 64-byte MAILBOX per member, counter and mailboxes zeroed before the launch):
+//   member : partial -> its slot (write-through), wait for the stores, counter += 1 (the returned value tells the LAST arriver), then polls ITS OWN mailbox;
+//   last   : its first wave reads all partials, combines them (caller's functor: a fixed order, so every run gives the same bits) and posts the result
+//            into every member's mailbox (payload, wait, then the ready word).
+// r04_k: the first version let every member poll the shared counter -- 96 pollers and 96 adds on ONE address: the exchange took ~60 us of a 79 us
+// round (team form 1419 us where the same kernel without the wait takes 368 and the two-launch form 461).  A mailbox has one poller.
+// Memory: everything exchanged is accessed with RELAXED AGENT-SCOPE ATOMICS -- on gfx942 / gfx950 the sc1 forms, coherent across the XCDs' L2s for
+// their own locations -- and NO agent-scope fence: an agent-scope release / acquire is buffer_wbl2 / buffer_inv sc1, a write-back / invalidate of
+// the XCD's whole L2 per workgroup (r04_i: that version ran at 0.8 TB/s).  "Payload before flag" is an explicit s_waitcnt vmcnt(0) between
+// write-through stores (hipcc drops a workgroup-scope fence here altogether).
+// Forward progress: a waiting workgroup needs its LATER team mates to be dispatched.  Workgroups are dispatched in blockIdx order per XCD
+// (round-robin over the eight XCDs), so when the next workgroup n of an XCD cannot start, every resident workgroup there has a smaller index;
+// those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as one XCD's share of a team (team / 8) is smaller
+// than its resident slots (>= 64), which the host guarantees (team <= 128).  The poll is BOUNDED: if the assumption were ever wrong the kernel
+// produces wrong numbers (the parity tests fail) instead of hanging the device.
 #ifndef SEGX_TEAM_SPIN
-#define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(2)
+#define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(8)
 #define SEGX_TEAM_SPIN_DONE() ((void)0)
 #define SEGX_TEAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SEGX_TEAM_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -86,16 +91,41 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
 #endif
 __device__ __forceinline__ void team_store(float* p, float v) { SEGX_TEAM_STORE(p, v); }
 __device__ __forceinline__ float team_load(const float* p) { return SEGX_TEAM_LOAD(p); }
-__device__ __forceinline__ void team_arrive_and_wait(unsigned* ctr, unsigned expected) {
-    // the caller's thread 0 has written this workgroup's partial result with team_store
-    if (threadIdx.x == 0) {
-        SEGX_TEAM_ORDER();
-        SEGX_TEAM_ADD(ctr, 1u);
-        unsigned spins = 0;
-        while (SEGX_TEAM_LOAD(ctr) < expected && ++spins < (1u << 20)) SEGX_TEAM_SPIN();
-        SEGX_TEAM_SPIN_DONE();
+constexpr int TEAM_MBOX = 16;                              // floats per mailbox (one 64-byte line): payload 0..2, ready word 3
+struct TeamBufs { unsigned* ctr; float* parts; float* mbox; };   // of ONE team: parts [members][4], mbox [members][TEAM_MBOX]
+// Every thread of the workgroup calls this after thread 0 wrote the member's partial (floats 0..2 of its slot) with team_store.  `combine(parts,
+// members, out)` runs in the first wave of the last arriver and must leave the same out[0..2] in every lane.  Returns the combination in out[0..2].
+template <class Combine>
+__device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int members, float (&out)[3], Combine combine) {
+    if (threadIdx.x < 64) {
+        int last = 0;
+        if (threadIdx.x == 0) {
+            SEGX_TEAM_ORDER();
+            last = SEGX_TEAM_ADD(t.ctr, 1u) == (unsigned)(members - 1);
+        }
+        last = __shfl(last, 0);
+        if (last) {
+            float r[3];
+            combine(t.parts, members, r);
+            for (int i = threadIdx.x; i < members; i += 64) {
+                float* mb = t.mbox + (int64_t)i * TEAM_MBOX;
+                team_store(mb, r[0]); team_store(mb + 1, r[1]); team_store(mb + 2, r[2]);
+            }
+            SEGX_TEAM_ORDER();
+            for (int i = threadIdx.x; i < members; i += 64) team_store(t.mbox + (int64_t)i * TEAM_MBOX + 3, 1.0f);
+        }
+        if (threadIdx.x == 0) {
+            const float* flag = t.mbox + (int64_t)member * TEAM_MBOX + 3;
+            unsigned spins = 0;
+#ifndef SEGX_TEAM_NOWAIT                               // bench-only build (tools/build_variant.py): what the kernels cost without the wait (results are then wrong)
+            while (team_load(flag) == 0.f && ++spins < (1u << 20)) SEGX_TEAM_SPIN();
+#endif
+            SEGX_TEAM_SPIN_DONE();
+        }
     }
     __syncthreads();
+    const float* mb = t.mbox + (int64_t)member * TEAM_MBOX;
+    out[0] = team_load(mb); out[1] = team_load(mb + 1); out[2] = team_load(mb + 2);
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------

@@ -627,13 +627,13 @@ def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, 
         return y, run_mean, run_var, B * S, psum, nch
     mean, var = _empty(x, C), _empty(x, C)
     if _bn_stats_sync is None:
-        parts = _empty(x, L.bn_parts_floats(B, C))
+        parts = _empty(x, L.bn_parts_floats(B, C, S))
         L.bn_act_fwd2(x, parts, 0, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
         return y, mean, var, B * S, psum, nch
     # synchronised BN: ONE local partial (n, mean, M2) per channel (one launch for channel-resident shapes), ONE all-gather of [C] float4, and the
     # apply pass merges the ranks' partials itself (Chan) and updates the running statistics: 2-3 launches + 1 collective (r03: 5 + 1)
     loc = _empty(x, 4 * C)
-    L.bn_stats_local(x, loc, _empty(x, L.bn_parts_floats(B, C)), B, C, S)
+    L.bn_stats_local(x, loc, _empty(x, L.bn_parts_floats(B, C, S)), B, C, S)
     allv, world = _bn_stats_sync(loc)
     L.bn_act_fwd2(x, allv, -world, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
     return y, mean, var, B * S * world, psum, nch
@@ -667,7 +667,7 @@ def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_
         L.bn_act_bwd_apply(dy, x, mean, var, w, b, glob[:C], glob[C:], dx, B, C, S, eps, act, 1.0 / n, gate, dpool, inv_S, *dc)
     else:
         dw, db = _empty(x, C), _empty(x, C)
-        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S, *dc, dy_bs=dy_bs)
+        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, _empty(x, L.bn_ws(B, C, S)), B, C, S, eps, act, 1 if training else 0, gate, dpool, inv_S, *dc, dy_bs=dy_bs)
     return dx, dw, db
 
 

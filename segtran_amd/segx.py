@@ -246,8 +246,8 @@ class SegxLib:
         self._call('segx_seg_loss_bwd', logits, logits, mask, pw, cw, ws, gout, dlogits, B, C, S, dice_w)
 
     # ---- backbone kernels (backbone.hip) ------------------------------------------------------------
-    def bn_ws(self, B, C):
-        return int(self.c.segx_bn_ws_floats(B, C))
+    def bn_ws(self, B, C, S=0):
+        return int(self.c.segx_bn_ws_floats(B, C, S))
 
     # ---- r04: two-launch training BatchNorm, squeeze-excite in 2 + 3 launches -----------------------
     def plane_chunks(self, S):
@@ -256,8 +256,8 @@ class SegxLib:
     def bn_pool_chunks(self, B, S, auto_stats):
         return int(self.c.segx_bn_pool_chunks(B, S, 1 if auto_stats else 0))
 
-    def bn_parts_floats(self, B, C):
-        return int(self.c.segx_bn_parts_floats(B, C))
+    def bn_parts_floats(self, B, C, S=0):
+        return int(self.c.segx_bn_parts_floats(B, C, S))
 
     def bn_stats_local(self, X, part, ws, B, C, S):
         self._call('segx_bn_stats_local', X, X, part, ws, B, C, S)
@@ -528,11 +528,11 @@ _SIGS = {
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
-    'segx_bn_ws_floats': 'ii', 
+    'segx_bn_ws_floats': 'iil', 
     'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
      'segx_plane_bias_add': 'ppplilp', 
-    'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'ii', 'segx_bn_stats_local': 'pppiilp',
+    'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'iil', 'segx_bn_stats_local': 'pppiilp',
     'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuulp',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',
