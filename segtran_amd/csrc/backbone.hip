@@ -639,7 +639,9 @@ static inline int bn_auto_form(int B, int64_t S, bool backward) {
     const int path = kget(knobs().bn_path);
     if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4) return 1;                    // tests: the team form on small planes too (cpp = ceil)
     if (bn_res_form(B, S, backward)) return 2;
-    if (path != 1 && bn_team_cpp(B, S)) return 1;
+    // forward teams of more than 32 workgroups wait longer than the second read costs (r04_l, 144 channels of 512 x 512 at batch 6, team 96: 484 us either
+    // way; backward 521 against 779 us): those planes keep the two-launch forward
+    if (path != 1 && bn_team_cpp(B, S) && (backward || bn_team_cpp(B, S) * B <= 32)) return 1;
     return 0;
 }
 static inline int bn_team_chunks(int B, int64_t S) { return (int)((S / 4 + 256 * BN_TEAM_KP - 1) / (256 * BN_TEAM_KP)); }
