@@ -477,6 +477,11 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
 //                                                                                     2 reads + 1 write  (two launches: 4 reads + 1 write)
 // One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
 // =================================================================================================
+// counters and mailboxes of a team launch start at zero.  A kernel, not hipMemsetAsync: a captured memset node gave NaNs on replay (r04_m), kernel nodes are
+// what every other launch of the step is
+__global__ __launch_bounds__(256) void team_zero_kernel(float* __restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
 struct BnTeam { unsigned* ctr; float* parts; float* mbox; int B, cpp; };       // parts: [C][B * cpp][4] floats, mbox: [C][B * cpp][TEAM_MBOX], ctr: [C] (common.h: team_exchange)
 constexpr int BN_TEAM_KP = 16;                                   // 256 x 16 float4 = 16384 floats per workgroup
 template <int KP, bool POOL, int ACT, int RESID>
@@ -1298,7 +1303,7 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
             t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
             SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
-            if (hipMemsetAsync(t.mbox, 0, sizeof(float) * ((int64_t)C * B * t.cpp * TEAM_MBOX + C), stream) != hipSuccess) return fail(1, "segx_bn_act_fwd2: memset of the mailboxes failed");
+            { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
             bn_team_launch_fwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             return check_launch("segx_bn_act_fwd2/team");
         }
@@ -1362,7 +1367,7 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     if (af == 1) {
         BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
-        if (hipMemsetAsync(t.mbox, 0, sizeof(float) * ((int64_t)C * B * t.cpp * TEAM_MBOX + C), stream) != hipSuccess) return fail(1, "segx_bn_act_bwd2: memset of the mailboxes failed");
+        { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
         bn_team_launch_bwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         return check_launch("segx_bn_act_bwd2/team");
     }
