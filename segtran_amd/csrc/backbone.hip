@@ -483,21 +483,20 @@ __global__ __launch_bounds__(256) void team_zero_kernel(float* __restrict__ p, i
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
 }
 struct BnTeam { unsigned* ctr; float* parts; float* mbox; int B, cpp; };       // parts: [C][B * cpp][4] floats, mbox: [C][B * cpp][TEAM_MBOX], ctr: [C] (common.h: team_exchange)
-constexpr int BN_TEAM_KP = 16;                                   // 256 x 16 float4 = 16384 floats per workgroup
 template <int KP, bool POOL, int ACT, int RESID>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
     __shared__ float red[4];
     const int TS = t.B * t.cpp, tl = threadIdx.x;
     const int c = blockIdx.x / TS, r = blockIdx.x - c * TS, b = r / t.cpp, ch = r - b * t.cpp;
     const int C = g.C, S4 = (int)(g.S >> 2), j0 = ch * 256 * KP, act = g.act;
     const int64_t S = g.S, plane = ((int64_t)b * C + c) * S;
-    unsigned off[KP];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) { const int j = j0 + tl + 256 * k; off[k] = 16u * (unsigned)(j < S4 ? j : S4 - 1); }
+    // byte offset of float4 k of this lane inside the plane (clamped: loads past the plane re-read its last float4); recomputed where used -- KP registers of
+    // offsets would be a quarter of the 32-float4 form's budget
+    auto offk = [&](int k) { const int j = j0 + tl + 256 * k; return 16u * (unsigned)(j < S4 ? j : S4 - 1); };
     f32x4 v[KP];
     const ws_gptr xb = ws_uniform_base(g.X + plane);
 #pragma unroll
-    for (int k = 0; k < KP; ++k) v[k] = ws_load<f32x4>(xb, off[k]);
+    for (int k = 0; k < KP; ++k) v[k] = ws_load<f32x4>(xb, offk(k));
     __builtin_amdgcn_sched_barrier(0);
     float s = 0.f;
 #pragma unroll
@@ -540,7 +539,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_tea
         f32x4 rv[G];
         if (resid) {
 #pragma unroll
-            for (int e = 0; e < G; ++e) rv[e] = ws_load<f32x4>(rb, off[k0 + e]);
+            for (int e = 0; e < G; ++e) rv[e] = ws_load<f32x4>(rb, offk(k0 + e));
         }
 #pragma unroll
         for (int e = 0; e < G; ++e) {
@@ -550,7 +549,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(3) void bn_act_fwd_tea
             o.z = act_fwd_c<ACT>(v[k].z * sc + sh, act); o.w = act_fwd_c<ACT>(v[k].w * sc + sh, act);
             if (resid) { o.x = o.x * dcs + rv[e].x; o.y = o.y * dcs + rv[e].y; o.z = o.z * dcs + rv[e].z; o.w = o.w * dcs + rv[e].w; }
             if (j0 + tl + 256 * k < S4) {
-                ws_store<f32x4>(yb, off[k], o);
+                ws_store<f32x4>(yb, offk(k), o);
                 if (POOL) acc += (o.x + o.y) + (o.z + o.w);
             }
         }
@@ -633,24 +632,29 @@ static inline int bn_res_form(int B, int64_t S, bool backward) {
     return 0;
 }
 
-// chunks per plane of the team form, 0 = not served: S % 4 == 0, a team of at most 128 workgroups, and it must pay (a plane of at least one full chunk)
-static inline int bn_team_cpp(int B, int64_t S) {
-    if ((S & 3) || B < 1 || S < 1024 * BN_TEAM_KP) return 0;
-    const int64_t cpp = (S / 4 + 256 * BN_TEAM_KP - 1) / (256 * BN_TEAM_KP);
-    return (cpp * B <= 128) ? (int)cpp : 0;
+// float4 per lane of a team workgroup (chunk = 1024 x KP floats of ONE plane), 0 = the team form does not serve (B, S).  Backward: 16 (x and dy: 128
+// registers of state), teams up to 128 workgroups.  Forward: 16 while the team stays within 32 workgroups, else 32 (teams up to 64): a forward team
+// waits longer than the second read costs once it gets large (r04_l: 144 channels of 512 x 512 at batch 6 with 16 float4 per lane, team 96: 484 us
+// either way; backward 521 against 779 us).
+static inline int bn_team_chunks(int64_t S, int kp) { return (int)((S / 4 + 256 * kp - 1) / (256 * kp)); }
+static inline int bn_team_kp(int B, int64_t S, bool backward) {
+    if ((S & 3) || B < 1 || S < 16384) return 0;
+    if (backward) return (int64_t)bn_team_chunks(S, 16) * B <= 128 ? 16 : 0;
+    if ((int64_t)bn_team_chunks(S, 16) * B <= 32) return 16;
+    return (int64_t)bn_team_chunks(S, 32) * B <= 64 ? 32 : 0;
 }
-// policy (knob 3): which form serves training BatchNorm on (B, S) when the library computes the statistics itself: 2 resident, 1 team, 0 two launches
-static inline int bn_auto_form(int B, int64_t S, bool backward) {
+// policy (knob 3): which form serves training BatchNorm on (B, S) when the library computes the statistics itself: 2 resident, 1 team, 0 two launches;
+// *kp = float4 per lane of the team form
+static inline int bn_auto_form(int B, int64_t S, bool backward, int* kp = nullptr) {
     const int path = kget(knobs().bn_path);
-    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4) return 1;                    // tests: the team form on small planes too (cpp = ceil)
-    if (bn_res_form(B, S, backward)) return 2;
-    // forward teams of more than 32 workgroups wait longer than the second read costs (r04_l, 144 channels of 512 x 512 at batch 6, team 96: 484 us either
-    // way; backward 521 against 779 us): those planes keep the two-launch forward
-    if (path != 1 && bn_team_cpp(B, S) && (backward || bn_team_cpp(B, S) * B <= 32)) return 1;
-    return 0;
+    int k = 16;
+    int form = 0;
+    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= 128) form = 1;      // tests: the team form on small planes too
+    else if (bn_res_form(B, S, backward)) form = 2;
+    else if (path != 1 && (k = bn_team_kp(B, S, backward)) != 0) form = 1;
+    if (kp) *kp = form == 1 ? k : 0;
+    return form;
 }
-static inline int bn_team_chunks(int B, int64_t S) { return (int)((S / 4 + 256 * BN_TEAM_KP - 1) / (256 * BN_TEAM_KP)); }
-
 template <int KP>
 static void bn_team_launch_fwd(const BnFwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream, bool pool) {
     const bool resid = g.resid != nullptr;
@@ -1247,11 +1251,12 @@ static inline int plane_chunks(int64_t S, int per_thread) { return (int)i64max(1
 using namespace segx;
 #define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
 
-static inline int64_t bn_team_floats(int B, int C, int64_t S) {       // partial slots + mailboxes + counters of the team form, 0 where it cannot serve
-    if (S <= 0 || (S & 3) || (bn_team_chunks(B, S) * (int64_t)B) > 128) return 0;
-    return (int64_t)C * B * bn_team_chunks(B, S) * (4 + TEAM_MBOX) + C;
+static inline int64_t bn_team_floats(int B, int C, int64_t S, bool backward) {       // partial slots + mailboxes + counters of the team form, 0 where it does not serve
+    int kp = 0;
+    if (S <= 0 || bn_auto_form(B, S, backward, &kp) != 1) return 0;
+    return (int64_t)C * B * bn_team_chunks(S, kp) * (4 + TEAM_MBOX) + C;
 }
-extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S)); }
+extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S, true)); }
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                       float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act,
@@ -1276,10 +1281,11 @@ extern "C" int segx_bn_act_bwd_apply(const float* dY, const float* X, const floa
 extern "C" int64_t segx_plane_chunks(int64_t S) { return plane_chunks(S, 8); }
 /* pooling chunks per plane that segx_bn_act_fwd2 writes into psum: auto_stats != 0 = the call computes the statistics itself (parts given, nparts = 0) */
 extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) {
-    const int af = auto_stats ? bn_auto_form(B, S, false) : 0;
-    return af == 2 ? 1 : af == 1 ? bn_team_chunks(B, S) : plane_chunks(S, 8);
+    int kp = 0;
+    const int af = auto_stats ? bn_auto_form(B, S, false, &kp) : 0;
+    return af == 2 ? 1 : af == 1 ? bn_team_chunks(S, kp) : plane_chunks(S, 8);
 }
-extern "C" int64_t segx_bn_parts_floats(int B, int C, int64_t S) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, bn_team_floats(B, C, S)); }
+extern "C" int64_t segx_bn_parts_floats(int B, int C, int64_t S) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, bn_team_floats(B, C, S, false)); }
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
                                 int B, int C, int64_t S, float eps, int act, void* stream_) {
@@ -1297,14 +1303,16 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
     if (parts && nparts == 0) {
         // AUTO: the library computes the batch statistics itself -- channel-resident (one launch) where the channel's B planes fit a team's registers,
         // otherwise partials into `parts` (segx_bn_parts_floats) + the folding apply pass below
-        const int af = bn_auto_form(B, S, false);
+        int tkp = 0;
+        const int af = bn_auto_form(B, S, false, &tkp);
         if (af == 1) {
-            BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = const_cast<float*>(parts); t.mbox = t.parts + (int64_t)C * B * t.cpp * 4;
+            BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.parts = const_cast<float*>(parts); t.mbox = t.parts + (int64_t)C * B * t.cpp * 4;
             t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
             SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
             { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
-            bn_team_launch_fwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
+            if (tkp == 32) bn_team_launch_fwd<32>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
+            else bn_team_launch_fwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             return check_launch("segx_bn_act_fwd2/team");
         }
         const int form = af == 2 ? bn_res_form(B, S, false) : 0;
@@ -1360,15 +1368,16 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     if (dy_bs == 0) dy_bs = (int64_t)C * S;
     SEGX_REQUIRE(dy_bs >= (int64_t)C * S && ((S & 3) != 0 || (dy_bs & 3) == 0), "segx_bn_act_bwd2: bad dY batch stride %lld", (long long)dy_bs);
     SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
-    const int af = training ? bn_auto_form(B, S, true) : 0;
+    int tkp = 0;
+    const int af = training ? bn_auto_form(B, S, true, &tkp) : 0;
     BnBwdArgs g;
     g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
     g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
     if (af == 1) {
-        BnTeam t; t.B = B; t.cpp = bn_team_chunks(B, S); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
+        BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
         { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
-        bn_team_launch_bwd<BN_TEAM_KP>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
+        bn_team_launch_bwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         return check_launch("segx_bn_act_bwd2/team");
     }
     const int form = af == 2 ? bn_res_form(B, S, true) : 0;

@@ -175,8 +175,8 @@ def test_bn_with_skip_add_and_drop_connect(backend, shape, rate, training):
     close(bn.running_mean, ref.running_mean, 1e-5); close(bn.running_var, ref.running_var, 1e-5)
 
 
-@pytest.mark.parametrize('path', [1, 2])
-@pytest.mark.parametrize('shape', [(3, 5, 6, 10), (2, 3, 130, 132), (6, 2, 64, 64), (2, 4, 3, 4, 5)])
+@pytest.mark.parametrize('path,shape', [(p_, s_) for p_ in (1, 2) for s_ in [(3, 5, 6, 10), (2, 3, 130, 132), (6, 2, 64, 64), (2, 4, 3, 4, 5)]] +
+                         [(0, (6, 2, 320, 320))])    # default policy on a plane of 102400: forward teams of 6 x 4 workgroups with 32 float4 per lane, backward 6 x 7 with 16
 def test_bn_forms_team_and_two_launch(backend, path, shape):
     """segx_tune knob 3.  2 = the TEAM form on every shape (a team of B x chunks workgroups per channel keeps the channel in registers across a team
     barrier -- on the emulator a block that waits for its mates is parked while later blocks run): one chunk per plane on the small shapes, two on
