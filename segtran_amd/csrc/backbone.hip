@@ -1321,7 +1321,7 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
             const int team = form >> 4, kp = form & 15;
             const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
 #define SEGX_BN_RES(T, K, BM) if (team == T && kp == K) { bn_res_launch_fwd<T, K, BM>(g, B, rgrid, stream, psum != nullptr); return check_launch("segx_bn_act_fwd2/resident"); }
-            if (B <= 6) SEGX_BN_RES(256, 4, 6)                   // 96 instead of 128 registers of planes: three workgroups per CU
+            if (B <= 6) { SEGX_BN_RES(256, 4, 6) SEGX_BN_RES(256, 1, 6) }     // six planes: no registers (and no clamped re-reads) for planes 7 and 8
             SEGX_BN_RES(64, 1, 8) SEGX_BN_RES(64, 2, 8) SEGX_BN_RES(256, 1, 8) SEGX_BN_RES(256, 2, 8) SEGX_BN_RES(256, 4, 8)
 #undef SEGX_BN_RES
             return fail(-1, "segx_bn_act_fwd2: no resident form %d", form);
@@ -1385,6 +1385,7 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
         const int team = form >> 4, kp = form & 15;
         const dim3 rgrid(team == 64 ? (C + 3) / 4 : C);
         if (team == 64) bn_res_launch_bwd<64, 1, 8>(g, B, rgrid, stream);
+        else if (kp == 1 && B <= 6) bn_res_launch_bwd<256, 1, 6>(g, B, rgrid, stream);
         else if (kp == 1) bn_res_launch_bwd<256, 1, 8>(g, B, rgrid, stream);
         else if (kp == 2) bn_res_launch_bwd<256, 2, 8>(g, B, rgrid, stream);
         else bn_res_launch_bwd<256, 4, 6>(g, B, rgrid, stream);
