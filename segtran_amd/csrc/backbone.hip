@@ -1121,6 +1121,7 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
     const int b = blockIdx.y;
     for (int j = threadIdx.x; j < Cs; j += 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < nchunks; ++k) s += part[((int64_t)b * nchunks + k) * Cs + j];
         const float v = s * act_grad(hpre[(int64_t)b * Cs + j], ACT_SWISH);
         dh[j] = v;
@@ -1130,6 +1131,7 @@ __global__ __launch_bounds__(256) void se_bwd_pool_kernel(const float* __restric
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     float s = 0.f;
+#pragma unroll 16
     for (int j = 0; j < Cs; ++j) s += dh[j] * W1[(int64_t)j * C + c];
     dpool[(int64_t)b * C + c] = s * inv_S;
 }
@@ -1143,13 +1145,23 @@ constexpr int SE2_CHUNK = 64, SE2_ROWS = 64;
 // hpre[b][j] = b1[j] + sum_c W1[j][c] * p[b][c], p = (sum of the plane's nch pooling chunks) / S; also p (kept for the weight gradients).  grid (ceil(Cs/4), B)
 __global__ __launch_bounds__(256) void se_hidden2_kernel(const float* __restrict__ psum, int nch, float inv_S, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, float* __restrict__ p_out, float* __restrict__ hpre_out, int C, int Cs) {
+    // r04-p: the pooled means of the sample go through LDS once per workgroup (every wave used to re-add the pooling chunks of every channel it touched)
+    __shared__ float psh[SE_MAX_C];
     const int b = blockIdx.y, lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     const float* ps = psum + (int64_t)b * C * nch;
-    if (blockIdx.x == 0)
-        for (int c = threadIdx.x; c < C; c += 256) { float a = 0.f; for (int k = 0; k < nch; ++k) a += ps[(int64_t)c * nch + k]; p_out[(int64_t)b * C + c] = a * inv_S; }
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int k = 0; k < nch; ++k) a += ps[(int64_t)c * nch + k];
+        a *= inv_S;
+        psh[c] = a;
+        if (blockIdx.x == 0) p_out[(int64_t)b * C + c] = a;
+    }
+    __syncthreads();
     if (j >= Cs) return;
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) { float a = 0.f; for (int k = 0; k < nch; ++k) a += ps[(int64_t)c * nch + k]; s += W1[(int64_t)j * C + c] * (a * inv_S); }
+    const float* w1 = W1 + (int64_t)j * C;
+#pragma unroll 8
+    for (int c = lane; c < C; c += 64) s += w1[c] * psh[c];
     s = wave_sum(s);
     if (lane == 0) hpre_out[(int64_t)b * Cs + j] = s + b1[j];
 }
@@ -1158,18 +1170,30 @@ __global__ __launch_bounds__(256) void se_hidden2_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __restrict__ hpre, const float* __restrict__ W2, const float* __restrict__ b2,
                                                               const float* __restrict__ W, float* __restrict__ gate, float* __restrict__ Wb,
                                                               int K, int Cs, int M) {
+    // r04-p: lane = gate column, wave w takes the hidden units j = w, w + 4, ... (independent loads, a few round trips), the four partial sums are added in
+    // wave order through LDS.  Before, a wave worked through 16 columns one after the other, each a load -> wave_sum chain: 19 us per layer for kilobytes.
+    __shared__ float hsh[SE_MAX_CS];
+    __shared__ float psh[4][SE2_CHUNK];
     __shared__ float gsh[SE2_CHUNK];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6, k0 = blockIdx.x * SE2_CHUNK;
-    for (int kk = wv; kk < SE2_CHUNK; kk += 4) {
-        const int k = k0 + kk;
+    for (int j = threadIdx.x; j < Cs; j += 256) { const float hp = hpre[(int64_t)b * Cs + j]; hsh[j] = hp * sigm(hp); }
+    __syncthreads();
+    {
+        const int k = k0 + lane;
         float s = 0.f;
-        if (k < K) for (int j = lane; j < Cs; j += 64) { const float hp = hpre[(int64_t)b * Cs + j]; s += W2[(int64_t)k * Cs + j] * (hp * sigm(hp)); }
-        s = wave_sum(s);
-        if (lane == 0) {
-            const float gt = k < K ? sigm(s + b2[k]) : 0.f;
-            gsh[kk] = gt;
-            if (k < K && blockIdx.z == 0) gate[(int64_t)b * K + k] = gt;
+        if (k < K) {
+            const float* w2 = W2 + (int64_t)k * Cs;
+#pragma unroll 8
+            for (int j = wv; j < Cs; j += 4) s += w2[j] * hsh[j];
         }
+        psh[wv][lane] = s;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        const int k = k0 + lane;
+        const float gt = k < K ? sigm((((psh[0][lane] + psh[1][lane]) + psh[2][lane]) + psh[3][lane]) + b2[k]) : 0.f;
+        gsh[lane] = gt;
+        if (k < K && blockIdx.z == 0) gate[(int64_t)b * K + k] = gt;
     }
     __syncthreads();
     if (!W) return;
@@ -1181,6 +1205,7 @@ __global__ __launch_bounds__(256) void se_gate_weights_kernel(const float* __res
     // M / 64 times as many workgroups (r04_d: 24 us per layer with one workgroup per (64 columns, sample) -- latency-bound -- against 9.5 us for the two
     // kernels this one replaces); slab 0 alone writes the gate
     const int m1 = min(M, ((int)blockIdx.z + 1) * SE2_ROWS);
+#pragma unroll 4
     for (int m = (int)blockIdx.z * SE2_ROWS + wv; m < m1; m += 4) o[(int64_t)m * K + k] = W[(int64_t)m * K + k] * gt;
 }
 // dgate[b][k] = sum_m dWb[b][m][k] W[m][k] (W == NULL: dgate is given), dz2 = dgate * gate * (1 - gate), part[b][chunk][j] = sum_{k in chunk} dz2[k] W2[k][j].
@@ -1194,7 +1219,7 @@ __global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restric
     float s = 0.f;
     if (W && k < K) {
         const float* d = dWb + (int64_t)b * M * K;
-#pragma unroll 4
+#pragma unroll 16
         for (int m = rl; m < M; m += 4) s += d[(int64_t)m * K + k] * W[(int64_t)m * K + k];
     }
     sh[threadIdx.x] = s;
@@ -1213,6 +1238,7 @@ __global__ __launch_bounds__(256) void se_bwd_gate_kernel(const float* __restric
     for (int j = threadIdx.x; j < Cs; j += 256) {
         const int n = min(SE2_CHUNK, K - k0);
         float a = 0.f;
+#pragma unroll 16
         for (int i = 0; i < n; ++i) a += dz[i] * W2[(int64_t)(k0 + i) * Cs + j];
         part[((int64_t)b * gridDim.x + blockIdx.x) * Cs + j] = a;
     }
