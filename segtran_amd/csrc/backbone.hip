@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void team_zero_kernel(float* __restrict__ p, i
 }
 struct BnTeam { unsigned* ctr; float* parts; float* mbox; int B, cpp; };       // parts: [C][B * cpp][4] floats, mbox: [C][B * cpp][TEAM_MBOX], ctr: [C] (common.h: team_exchange)
 template <int KP, bool POOL, int ACT, int RESID>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
     __shared__ float red[4];
     const int TS = t.B * t.cpp, tl = threadIdx.x;
     const int c = blockIdx.x / TS, r = blockIdx.x - c * TS, b = r / t.cpp, ch = r - b * t.cpp;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 16 ? 3 : 2) void
     }
 }
 template <int KP, int ACT>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(2) void bn_act_bwd_team_kernel(BnBwdArgs g, BnTeam t) {
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 4 ? 4 : KP <= 8 ? 3 : 2) void bn_act_bwd_team_kernel(BnBwdArgs g, BnTeam t) {
     __shared__ float red[4];
     const int TS = t.B * t.cpp, tl = threadIdx.x;
     const int c = blockIdx.x / TS, r = blockIdx.x - c * TS, b = r / t.cpp, ch = r - b * t.cpp;
@@ -637,6 +637,7 @@ static inline int bn_res_form(int B, int64_t S, bool backward) {
 // waits longer than the second read costs once it gets large (r04_l: 144 channels of 512 x 512 at batch 6 with 16 float4 per lane, team 96: 484 us
 // either way; backward 521 against 779 us).
 static inline int bn_team_chunks(int64_t S, int kp) { return (int)((S / 4 + 256 * kp - 1) / (256 * kp)); }
+static inline int bn_team_kp_small(int64_t S) { return S <= 4096 ? 4 : S <= 8192 ? 8 : 16; }     // one chunk per plane: the smallest form that holds it
 static inline int bn_team_kp(int B, int64_t S, bool backward) {
     if ((S & 3) || B < 1 || S < 16384) return 0;
     if (backward) return (int64_t)bn_team_chunks(S, 16) * B <= 128 ? 16 : 0;
@@ -649,7 +650,7 @@ static inline int bn_auto_form(int B, int64_t S, bool backward, int* kp = nullpt
     const int path = kget(knobs().bn_path);
     int k = 16;
     int form = 0;
-    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= 128) form = 1;      // tests: the team form on small planes too
+    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= 128) { form = 1; k = bn_team_kp_small(S); }      // tests: the team form on small planes too
     else if (bn_res_form(B, S, backward)) form = 2;
     else if (path != 1 && (k = bn_team_kp(B, S, backward)) != 0) form = 1;
     if (kp) *kp = form == 1 ? k : 0;
@@ -1338,6 +1339,8 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
             g.parts = nullptr;
             { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
             if (tkp == 32) bn_team_launch_fwd<32>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
+            else if (tkp == 4) bn_team_launch_fwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
+            else if (tkp == 8) bn_team_launch_fwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             else bn_team_launch_fwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             return check_launch("segx_bn_act_fwd2/team");
         }
@@ -1403,7 +1406,9 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
         BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
         { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
-        bn_team_launch_bwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
+        if (tkp == 4) bn_team_launch_bwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
+        else if (tkp == 8) bn_team_launch_bwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
+        else bn_team_launch_bwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         return check_launch("segx_bn_act_bwd2/team");
     }
     const int form = af == 2 ? bn_res_form(B, S, true) : 0;

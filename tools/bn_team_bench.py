@@ -1,5 +1,5 @@
 """Training BatchNorm on the planes that do not fit one workgroup: the team form (segx_tune knob 3 = 0) against the two-launch form (knob 3 = 1), forward and
-backward, HIP events, on the three plane sizes of EfficientNet-B4 at 512 x 512 / batch 6.  python tools/bn_team_bench.py [libsegx variant .so]"""
+backward, HIP events, on the three large plane sizes of EfficientNet-B4 at 512 x 512 / batch 6; on the small ones the channel-resident form (default) against teams (knob 3 = 2).  python tools/bn_team_bench.py [libsegx variant .so]"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -19,7 +19,7 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for C, S in ((336, 16384), (192, 65536), (144, 262144)):
+for C, S in ((336, 16384), (192, 65536), (144, 262144), (960, 4096), (672, 4096), (1632, 1024)):
     x = torch.randn(B, C, S, device=dev); dy = torch.randn(B, C, S, device=dev)
     y = torch.empty_like(x); dx = torch.empty_like(x)
     w = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
@@ -28,7 +28,7 @@ for C, S in ((336, 16384), (192, 65536), (144, 262144)):
     dw, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
     parts = torch.empty(L.bn_parts_floats(B, C, S), device=dev); ws = torch.empty(L.bn_ws(B, C, S), device=dev)
     mb = B * C * S * 4 / 1e6
-    for path, name in ((1, 'two launches'), (0, 'team')):
+    for path, name in (((1, 'two launches'), (0, 'team')) if S >= 16384 else ((0, 'resident'), (2, 'team'))):
         assert L.c.segx_tune(3, path) == 0
         tf = timeit(lambda: L.bn_act_fwd2(x, parts, 0, mean, var, rm, rv, 0.01, w, b, y, None, None, 0.0, 0, 0, B, C, S, 1e-3, 1))
         tb = timeit(lambda: L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, ws, B, C, S, 1e-3, 1, 1))
