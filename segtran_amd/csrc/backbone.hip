@@ -651,7 +651,12 @@ static inline int bn_auto_form(int B, int64_t S, bool backward, int* kp = nullpt
     int k = 16;
     int form = 0;
     if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= 128) { form = 1; k = bn_team_kp_small(S); }      // tests: the team form on small planes too
-    else if (bn_res_form(B, S, backward)) form = 2;
+    else if (bn_res_form(B, S, backward)) {
+        form = 2;
+        // the largest backward resident form (six planes x 4 float4 of x AND dy per lane: 192 registers, two workgroups per CU) loses to a team of one
+        // workgroup per plane (r04_s: 960 channels of 64 x 64 at batch 6: 60.8 -> 49.9 us, 672 channels 40.4 -> 36.8; forward the resident form wins)
+        if (backward && path == 0 && bn_res_form(B, S, true) == 256 * 16 + 4 && (S & 3) == 0) { form = 1; k = bn_team_kp_small(S); }
+    }
     else if (path != 1 && (k = bn_team_kp(B, S, backward)) != 0) form = 1;
     if (kp) *kp = form == 1 ? k : 0;
     return form;

@@ -26,10 +26,10 @@ for C, S in ((336, 16384), (192, 65536), (144, 262144), (960, 4096), (672, 4096)
     mean, var = torch.empty(C, device=dev), torch.empty(C, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     dw, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    parts = torch.empty(L.bn_parts_floats(B, C, S), device=dev); ws = torch.empty(L.bn_ws(B, C, S), device=dev)
     mb = B * C * S * 4 / 1e6
     for path, name in (((1, 'two launches'), (0, 'team')) if S >= 16384 else ((0, 'resident'), (2, 'team'))):
         assert L.c.segx_tune(3, path) == 0
+        parts = torch.empty(L.bn_parts_floats(B, C, S), device=dev); ws = torch.empty(L.bn_ws(B, C, S), device=dev)     # sized under the form they serve
         tf = timeit(lambda: L.bn_act_fwd2(x, parts, 0, mean, var, rm, rv, 0.01, w, b, y, None, None, 0.0, 0, 0, B, C, S, 1e-3, 1))
         tb = timeit(lambda: L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, ws, B, C, S, 1e-3, 1, 1))
         print('C %4d S %6d %-12s fwd %7.1f us (%5.2f TB/s of 2 units)  bwd %7.1f us (%5.2f TB/s of 3 units)' % (C, S, name, tf, 2 * mb / tf, tb, 3 * mb / tb), flush=True)
