@@ -165,11 +165,11 @@ __device__ __forceinline__ BnPart bn_fold(const float* __restrict__ parts, int c
     return s;
 }
 // the same fold over partials written by OTHER workgroups of this launch (team BatchNorm): coherent loads (common.h: team_load)
-__device__ __forceinline__ BnPart bn_fold_team(const float* parts, int c, int nparts) {
+__device__ __forceinline__ BnPart bn_fold_team(const float* slots, int nparts) {
     const int lane = threadIdx.x & 63;
-    const float* p = parts + (int64_t)c * nparts * 4;
+    const float* p = slots;
     BnPart s; s.n = 0.f; s.mean = 0.f; s.m2 = 0.f;
-    for (int i = lane; i < nparts; i += 64) { BnPart t; t.n = team_load(p + 4 * i); t.mean = team_load(p + 4 * i + 1); t.m2 = team_load(p + 4 * i + 2); s = bn_merge(s, t); }
+    for (int i = lane; i < nparts; i += 64) { BnPart t; t.n = team_load(p + TEAM_SLOT * i); t.mean = team_load(p + TEAM_SLOT * i + 1); t.m2 = team_load(p + TEAM_SLOT * i + 2); s = bn_merge(s, t); }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
         BnPart t; t.n = __shfl_xor(s.n, o); t.mean = __shfl_xor(s.mean, o); t.m2 = __shfl_xor(s.m2, o);
@@ -477,12 +477,13 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
 //                                                                                     2 reads + 1 write  (two launches: 4 reads + 1 write)
 // One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
 // =================================================================================================
-// counters and mailboxes of a team launch start at zero.  A kernel, not hipMemsetAsync: a captured memset node gave NaNs on replay (r04_m), kernel nodes are
-// what every other launch of the step is
-__global__ __launch_bounds__(256) void team_zero_kernel(float* __restrict__ p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+// the tag of a team launch (common.h: team_exchange): unique per launch of this process, never (0, 0)
+static inline void team_next_tag(unsigned& lo, unsigned& hi) {
+    static std::atomic<uint64_t> n{1};
+    const uint64_t x = n.fetch_add(1, std::memory_order_relaxed);
+    lo = (unsigned)x; hi = (unsigned)(x >> 32) ^ 0x5EA70000u;
 }
-struct BnTeam { unsigned* ctr; float* parts; float* mbox; int B, cpp; };       // parts: [C][B * cpp][4] floats, mbox: [C][B * cpp][TEAM_MBOX], ctr: [C] (common.h: team_exchange)
+struct BnTeam { float* slots; float* mbox; unsigned tag_lo, tag_hi; int B, cpp; };       // slots: [C][B * cpp][TEAM_SLOT] floats, mbox: [C][B * cpp][TEAM_MBOX] (common.h: team_exchange)
 template <int KP, bool POOL, int ACT, int RESID>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
     __shared__ float red[4];
@@ -514,10 +515,10 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
         q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
     }
     q = block_sum<4>(q, red);
-    const TeamBufs tb{t.ctr + c, t.parts + (int64_t)c * TS * 4, t.mbox + (int64_t)c * TS * TEAM_MBOX};
-    if (tl == 0) { float* pp = tb.parts + r * 4; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
+    if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
     float res[3];
-    team_exchange(tb, r, TS, res, [](const float* parts, int members, float (&o)[3]) { const BnPart f = bn_fold_team(parts, 0, members); o[0] = f.n; o[1] = f.mean; o[2] = f.m2; });
+    team_exchange(tb, r, TS, res, [](const float* slots, int members, float (&o)[3]) { const BnPart f = bn_fold_team(slots, members); o[0] = f.n; o[1] = f.mean; o[2] = f.m2; });
     BnPart st; st.n = res[0]; st.mean = res[1]; st.m2 = res[2];
     const float mean = st.mean, var = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
     if (r == 0 && tl == 0) {
@@ -592,15 +593,15 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 4 ? 4 : KP <= 8 
         a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    const TeamBufs tb{t.ctr + c, t.parts + (int64_t)c * TS * 4, t.mbox + (int64_t)c * TS * TEAM_MBOX};
-    if (tl == 0) { float* pp = tb.parts + r * 4; team_store(pp, a); team_store(pp + 1, q); }
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
+    if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, a); team_store(pp + 1, q); }
     float res[3];
     // the team's sums: lane l takes members l, l + 64 (team <= 128) in that order, then a symmetric butterfly -- the same bits in every lane and every run
     team_exchange(tb, r, TS, res, [](const float* parts, int members, float (&o)[3]) {
         const int lane = threadIdx.x & 63;
         const bool h0 = lane < members, h1 = lane + 64 < members;
-        const float a0 = team_load(parts + 4 * (h0 ? lane : 0)), q0 = team_load(parts + 4 * (h0 ? lane : 0) + 1);
-        const float a1 = team_load(parts + 4 * (h1 ? lane + 64 : 0)), q1 = team_load(parts + 4 * (h1 ? lane + 64 : 0) + 1);
+        const float a0 = team_load(parts + TEAM_SLOT * (h0 ? lane : 0)), q0 = team_load(parts + TEAM_SLOT * (h0 ? lane : 0) + 1);
+        const float a1 = team_load(parts + TEAM_SLOT * (h1 ? lane + 64 : 0)), q1 = team_load(parts + TEAM_SLOT * (h1 ? lane + 64 : 0) + 1);
         float A = (h0 ? a0 : 0.f) + (h1 ? a1 : 0.f), Q = (h0 ? q0 : 0.f) + (h1 ? q1 : 0.f);
 #pragma unroll
         for (int o2 = 1; o2 < 64; o2 <<= 1) { A += __shfl_xor(A, o2); Q += __shfl_xor(Q, o2); }
@@ -1286,7 +1287,7 @@ using namespace segx;
 static inline int64_t bn_team_floats(int B, int C, int64_t S, bool backward) {       // partial slots + mailboxes + counters of the team form, 0 where it does not serve
     int kp = 0;
     if (S <= 0 || bn_auto_form(B, S, backward, &kp) != 1) return 0;
-    return (int64_t)C * B * bn_team_chunks(S, kp) * (4 + TEAM_MBOX) + C;
+    return (int64_t)C * B * bn_team_chunks(S, kp) * (TEAM_SLOT + TEAM_MBOX);
 }
 extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S, true)); }
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
@@ -1338,11 +1339,10 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
         int tkp = 0;
         const int af = bn_auto_form(B, S, false, &tkp);
         if (af == 1) {
-            BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.parts = const_cast<float*>(parts); t.mbox = t.parts + (int64_t)C * B * t.cpp * 4;
-            t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
+            BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = const_cast<float*>(parts); t.mbox = t.slots + (int64_t)C * B * t.cpp * TEAM_SLOT;
+            team_next_tag(t.tag_lo, t.tag_hi);
             SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
-            { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
             if (tkp == 32) bn_team_launch_fwd<32>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             else if (tkp == 4) bn_team_launch_fwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
             else if (tkp == 8) bn_team_launch_fwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
@@ -1408,9 +1408,9 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     g.dY = dY; g.X = X; g.mean = mean; g.var = var; g.w = w; g.b = b; g.dX = dX; g.dw = dw; g.db = db; g.gate = gate; g.dpool = dpool; g.inv_S = inv_S;
     g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
     if (af == 1) {
-        BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.parts = ws; t.mbox = ws + (int64_t)C * B * t.cpp * 4; t.ctr = reinterpret_cast<unsigned*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX);
+        BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = ws; t.mbox = ws + (int64_t)C * B * t.cpp * TEAM_SLOT;
+        team_next_tag(t.tag_lo, t.tag_hi);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
-        { const int64_t nz = (int64_t)C * B * t.cpp * TEAM_MBOX + C; hipLaunchKernelGGL(team_zero_kernel, dim3((unsigned)i64min(1024, (nz + 255) / 256)), dim3(256), 0, stream, t.mbox, nz); }
         if (tkp == 4) bn_team_launch_bwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         else if (tkp == 8) bn_team_launch_bwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         else bn_team_launch_bwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);

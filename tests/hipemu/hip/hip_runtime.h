@@ -33,7 +33,6 @@
 #define SEGX_TEAM_SPIN_DONE() hipemu::grid_spin_done()
 #define SEGX_TEAM_LOAD(p) (*(p))
 #define SEGX_TEAM_STORE(p, v) (*(p) = (v))
-#define SEGX_TEAM_ADD(p, v) atomicAdd((p), (v))    /* returns the OLD value, as __hip_atomic_fetch_add does */
 #define SEGX_TEAM_ORDER() ((void)0)
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
