@@ -478,16 +478,18 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
 // One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
 // =================================================================================================
 // the tag of a team launch (common.h: team_exchange): unique per launch of this process, never (0, 0)
-static inline unsigned long long team_next_tag() {
+static inline void team_next_tag(unsigned& lo, unsigned& hi) {
+    // splitmix64 of a launch counter: distinct per launch AND unlike what recycled memory holds.  (A plain counter is not: r04_v -- small integers left
+    // behind by int64 tensors matched the tags 1, 2, 3 ... of a fresh process and a member read its mailbox before it was posted.)
     static std::atomic<uint64_t> n{1};
-    for (;;) {                                             // splitmix64 of a launch counter: distinct AND unlike anything memory is likely to hold (small integers, float patterns)
+    for (;;) {
         uint64_t z = n.fetch_add(1, std::memory_order_relaxed) * 0x9E3779B97F4A7C15ull;
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
-        z &= 0xFFFFFFFFFFFFull;
-        if (z) return z;
+        lo = (unsigned)z; hi = (unsigned)(z >> 32);
+        if (lo && hi) return;
     }
 }
-struct BnTeam { unsigned long long* arrive; float* slots; float* mbox; unsigned long long tag; int B, cpp; };   // slots: [C][B * cpp][TEAM_SLOT], mbox: [C][B * cpp][TEAM_MBOX], arrive: [C] (common.h: team_exchange)
+struct BnTeam { float* slots; float* mbox; unsigned tag_lo, tag_hi; int B, cpp; };       // slots: [C][B * cpp][TEAM_SLOT] floats, mbox: [C][B * cpp][TEAM_MBOX] (common.h: team_exchange)
 template <int KP, bool POOL, int ACT, int RESID>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
     __shared__ float red[4];
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
         q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
     }
     q = block_sum<4>(q, red);
-    const TeamBufs tb{t.arrive + c, t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag};
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
     if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
     float res[3];
     team_exchange(tb, r, TS, res, [](const float* slots, int members, float (&o)[3]) { const BnPart f = bn_fold_team(slots, members); o[0] = f.n; o[1] = f.mean; o[2] = f.m2; });
@@ -597,7 +599,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 4 ? 4 : KP <= 8 
         a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    const TeamBufs tb{t.arrive + c, t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag};
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
     if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, a); team_store(pp + 1, q); }
     float res[3];
     // the team's sums: lane l takes members l, l + 64 (team <= 128) in that order, then a symmetric butterfly -- the same bits in every lane and every run
@@ -1291,7 +1293,7 @@ using namespace segx;
 static inline int64_t bn_team_floats(int B, int C, int64_t S, bool backward) {       // partial slots + mailboxes + counters of the team form, 0 where it does not serve
     int kp = 0;
     if (S <= 0 || bn_auto_form(B, S, backward, &kp) != 1) return 0;
-    return (int64_t)C * B * bn_team_chunks(S, kp) * (TEAM_SLOT + TEAM_MBOX) + 2 * (int64_t)C;
+    return (int64_t)C * B * bn_team_chunks(S, kp) * (TEAM_SLOT + TEAM_MBOX);
 }
 extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S, true)); }
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
@@ -1344,7 +1346,7 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
         const int af = bn_auto_form(B, S, false, &tkp);
         if (af == 1) {
             BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = const_cast<float*>(parts); t.mbox = t.slots + (int64_t)C * B * t.cpp * TEAM_SLOT;
-            t.arrive = reinterpret_cast<unsigned long long*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX); t.tag = team_next_tag();
+            team_next_tag(t.tag_lo, t.tag_hi);
             SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
             if (tkp == 32) bn_team_launch_fwd<32>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
@@ -1413,7 +1415,7 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
     if (af == 1) {
         BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = ws; t.mbox = ws + (int64_t)C * B * t.cpp * TEAM_SLOT;
-        t.arrive = reinterpret_cast<unsigned long long*>(t.mbox + (int64_t)C * B * t.cpp * TEAM_MBOX); t.tag = team_next_tag();
+        team_next_tag(t.tag_lo, t.tag_hi);
         SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
         if (tkp == 4) bn_team_launch_bwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
         else if (tkp == 8) bn_team_launch_bwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);

@@ -66,20 +66,20 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
 
 // ---- team exchange: the workgroups of a TEAM (consecutive blockIdx.x) combine one small partial result each and all receive the combination.
 // Used by the team BatchNorm kernels (backbone.hip): every member keeps its slab of a channel in registers across the exchange, which is what saves
-// the second read.  Protocol (per team: a 64-bit arrival word, one 32-byte SLOT and one 64-byte MAILBOX per member; NO initialisation of the buffers):
-//   member : partial -> its slot (write-through), wait for the stores, then ARRIVES: a compare-and-swap loop turns the arrival word into
-//            (launch tag, count + 1) -- a word that does not carry this launch's 48-bit tag counts as 0 -- and tells the LAST arriver; polls ITS OWN mailbox;
-//   last   : clears the arrival word, its first wave combines the partials (caller's functor: a fixed order, so every run gives the same bits) and posts
-//            the result into every member's mailbox (payload, wait, then the tag);
-//   member : reads the payload and clears its mailbox tag.
-// The tag is unique per launch (a host-side counter, never 0), so whatever the buffers held before -- another tensor's data, an earlier launch's words --
-// is not mistaken for this launch's (2^-48 per word); the words a launch tags it also clears, so a graph REPLAY, which re-uses the tag, starts clean.
-// What the protocol went through (tools/bn_team_bench.py): a shared counter polled by all members cost ~60 us of a 79-us round (96 pollers and 96 adds
-// on ONE address, r04_k); counter + mailboxes needed a zeroing launch per BatchNorm call (60 launches, 0.29 ms per cfg2 step, r04_p); a designated
-// combiner polling tagged slots needed no zeroing but waited 5-8 % longer on the large teams than the last arriver does (r04_u).
+// the second read.  Protocol (per team: one 32-byte SLOT and one 64-byte MAILBOX per member; NO initialisation of the buffers):
+//   member  : partial -> its slot (write-through), wait for the stores, then the launch's 64-bit TAG into the slot; polls ITS OWN mailbox for the tag;
+//   member 0: the lanes of its first wave poll one slot each until it carries the tag, combine the partials (caller's functor: a fixed order, so
+//             every run gives the same bits) and post the result into every member's mailbox (payload, wait, tag);
+//   member  : reads the payload, then clears the tags of its slot and mailbox (so a graph REPLAY, which re-uses the tag, starts from cleared words).
+// The tag is unique per launch (a mixed host-side counter, both words non-zero), so whatever the buffers held before -- another tensor's data, an earlier launch's tags --
+// cannot be mistaken for this launch's (2^-64 per word pair).  r04_k / r04_p: a shared arrival counter polled by all members cost ~60 us of a 79-us round
+// (96 pollers and 96 adds on ONE address); a counter for the last arriver + mailboxes worked but needed a zeroing launch per BatchNorm call
+// (60 launches, 0.29 ms per cfg2 step); an arrival WORD advanced by compare-and-swap (tag + count: no zeroing, last arriver known) serialised the
+// arrivals with retries (r04_v: 4.3 ms for the largest backward layer).  Here every polled address has one poller, nothing is zeroed and there is no
+// read-modify-write at all.
 // Memory: everything exchanged is accessed with RELAXED AGENT-SCOPE ATOMICS -- on gfx942 / gfx950 the sc1 forms, coherent across the XCDs' L2s for
 // their own locations -- and NO agent-scope fence: an agent-scope release / acquire is buffer_wbl2 / buffer_inv sc1, a write-back / invalidate of
-// the XCD's whole L2 per workgroup (r04_i: that version ran at 0.8 TB/s).  "Payload before tag / arrival" is an explicit s_waitcnt vmcnt(0) between
+// the XCD's whole L2 per workgroup (r04_i: that version ran at 0.8 TB/s).  "Payload before tag" is an explicit s_waitcnt vmcnt(0) between
 // write-through stores (hipcc drops a workgroup-scope fence here altogether).
 // Forward progress: a waiting workgroup needs its LATER team mates to be dispatched.  Workgroups are dispatched in blockIdx order per XCD
 // (round-robin over the eight XCDs), so when the next workgroup n of an XCD cannot start, every resident workgroup there has a smaller index;
@@ -91,39 +91,33 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
 #define SEGX_TEAM_SPIN_DONE() ((void)0)
 #define SEGX_TEAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SEGX_TEAM_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define SEGX_TEAM_CAS(p, expected, desired) __hip_atomic_compare_exchange_strong((p), &(expected), (desired), __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SEGX_TEAM_ORDER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")    /* the write-through stores above have been acknowledged */
 #endif
 __device__ __forceinline__ void team_store(float* p, float v) { SEGX_TEAM_STORE(p, v); }
 __device__ __forceinline__ float team_load(const float* p) { return SEGX_TEAM_LOAD(p); }
-constexpr int TEAM_SLOT = 8, TEAM_MBOX = 16;               // floats per slot (payload 0..2) and per mailbox (one 64-byte line: payload 0..2, tag 4..5)
+constexpr int TEAM_SLOT = 8, TEAM_MBOX = 16;               // floats per slot (payload 0..2, tag 4..5) and per mailbox (one 64-byte line: payload 0..2, tag 4..5)
 constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;
-struct TeamBufs { unsigned long long* arrive; float* slots; float* mbox; unsigned long long tag; };   // of ONE team; tag: 48 bits, never 0
-__device__ __forceinline__ void team_put_tag(float* line, unsigned long long tag) {
-    SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 4, (unsigned)tag); SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 5, (unsigned)(tag >> 32));
+struct TeamBufs { float* slots; float* mbox; unsigned tag_lo, tag_hi; };   // of ONE team: slots [members][TEAM_SLOT], mbox [members][TEAM_MBOX]
+__device__ __forceinline__ void team_put_tag(float* line, unsigned lo, unsigned hi) {
+    SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 4, lo); SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 5, hi);
 }
-__device__ __forceinline__ bool team_has_tag(const float* line, unsigned long long tag) {
-    return SEGX_TEAM_LOAD(reinterpret_cast<const unsigned*>(line) + 4) == (unsigned)tag && SEGX_TEAM_LOAD(reinterpret_cast<const unsigned*>(line) + 5) == (unsigned)(tag >> 32);
+__device__ __forceinline__ bool team_has_tag(const float* line, unsigned lo, unsigned hi) {
+    return SEGX_TEAM_LOAD(reinterpret_cast<const unsigned*>(line) + 4) == lo && SEGX_TEAM_LOAD(reinterpret_cast<const unsigned*>(line) + 5) == hi;
 }
 // Every thread of the workgroup calls this after thread 0 wrote the member's partial (floats 0..2 of its slot) with team_store.  `combine(slots,
-// members, out)` runs in the first wave of the last arriver (slot i at slots + i * TEAM_SLOT) and must leave the same out[0..2] in every lane.
+// members, out)` runs in the first wave of member 0 (slot i at slots + i * TEAM_SLOT) and must leave the same out[0..2] in every lane.
 template <class Combine>
 __device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int members, float (&out)[3], Combine combine) {
     if (threadIdx.x < 64) {
-        int last = 0;
-        if (threadIdx.x == 0) {
-            SEGX_TEAM_ORDER();
-            unsigned long long old = SEGX_TEAM_LOAD(t.arrive), nw;
-            unsigned cnt;
-            do {
-                cnt = (old >> 16) == t.tag ? (unsigned)(old & 0xFFFFu) : 0u;
-                nw = (t.tag << 16) | (unsigned long long)(cnt + 1u);
-            } while (!SEGX_TEAM_CAS(t.arrive, old, nw));
-            last = cnt + 1u == (unsigned)members;
-            if (last) SEGX_TEAM_STORE(t.arrive, 0ull);
-        }
-        last = __shfl(last, 0);
-        if (last) {
+        if (threadIdx.x == 0) { SEGX_TEAM_ORDER(); team_put_tag(t.slots + (int64_t)member * TEAM_SLOT, t.tag_lo, t.tag_hi); }
+        if (member == 0) {
+#ifndef SEGX_TEAM_NOWAIT                               // bench-only build (tools/build_variant.py): what the kernels cost without the waits (results are then wrong)
+            for (int i = threadIdx.x; i < members; i += 64) {
+                unsigned spins = 0;
+                while (!team_has_tag(t.slots + (int64_t)i * TEAM_SLOT, t.tag_lo, t.tag_hi) && ++spins < TEAM_SPIN_LIMIT) SEGX_TEAM_SPIN();
+                SEGX_TEAM_SPIN_DONE();
+            }
+#endif
             float r[3];
             combine(t.slots, members, r);
             for (int i = threadIdx.x; i < members; i += 64) {
@@ -131,12 +125,12 @@ __device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int
                 team_store(mb, r[0]); team_store(mb + 1, r[1]); team_store(mb + 2, r[2]);
             }
             SEGX_TEAM_ORDER();
-            for (int i = threadIdx.x; i < members; i += 64) team_put_tag(t.mbox + (int64_t)i * TEAM_MBOX, t.tag);
+            for (int i = threadIdx.x; i < members; i += 64) team_put_tag(t.mbox + (int64_t)i * TEAM_MBOX, t.tag_lo, t.tag_hi);
         }
         if (threadIdx.x == 0) {
-#ifndef SEGX_TEAM_NOWAIT                               // bench-only build (tools/build_variant.py): what the kernels cost without the wait (results are then wrong)
+#ifndef SEGX_TEAM_NOWAIT
             unsigned spins = 0;
-            while (!team_has_tag(t.mbox + (int64_t)member * TEAM_MBOX, t.tag) && ++spins < TEAM_SPIN_LIMIT) SEGX_TEAM_SPIN();
+            while (!team_has_tag(t.mbox + (int64_t)member * TEAM_MBOX, t.tag_lo, t.tag_hi) && ++spins < TEAM_SPIN_LIMIT) SEGX_TEAM_SPIN();
 #endif
             SEGX_TEAM_SPIN_DONE();
         }
@@ -144,8 +138,8 @@ __device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int
     __syncthreads();
     const float* mb = t.mbox + (int64_t)member * TEAM_MBOX;
     out[0] = team_load(mb); out[1] = team_load(mb + 1); out[2] = team_load(mb + 2);
-    __syncthreads();                                       // every thread has its copy before the tag is cleared
-    if (threadIdx.x == 0) team_put_tag(t.mbox + (int64_t)member * TEAM_MBOX, 0ull);
+    __syncthreads();                                       // every thread has its copy before the tags are cleared
+    if (threadIdx.x == 0) { team_put_tag(t.slots + (int64_t)member * TEAM_SLOT, 0u, 0u); team_put_tag(t.mbox + (int64_t)member * TEAM_MBOX, 0u, 0u); }
 }
 
 // ---- wave / block reductions (wave = 64 lanes) ------------------------------------------------

@@ -34,7 +34,6 @@
 #define SEGX_TEAM_LOAD(p) (*(p))
 #define SEGX_TEAM_STORE(p, v) (*(p) = (v))
 #define SEGX_TEAM_ORDER() ((void)0)
-#define SEGX_TEAM_CAS(p, expected, desired) (*(p) == (expected) ? (*(p) = (desired), true) : ((expected) = *(p), false))
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
 #define SEGX_LOAD_FENCE() ((void)0)                       /* compiler-only fence of the device build */
