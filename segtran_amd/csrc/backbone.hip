@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2
 //             every workgroup) -> normalise / activate / skip / pool -> store.       1 read + 1 write   (two launches: 2 reads + 1 write)
 //   backward: load x, dy -> xhat, du in registers -> the chunk's two sums -> barrier -> the team's sums in member order -> dx.
 //                                                                                     2 reads + 1 write  (two launches: 4 reads + 1 write)
-// One launch each (plus the memset of the C arrival counters).  Not used by the synchronised form (the exchange between ranks sits where the barrier is).
+// One launch each, nothing to initialise (the exchange marks its words with a per-launch tag).  Not used by the synchronised form (the exchange between ranks
+// sits where the team exchange is).
 // =================================================================================================
 // the tag of a team launch (common.h: team_exchange): unique per launch of this process, never (0, 0)
 static inline void team_next_tag(unsigned& lo, unsigned& hi) {
