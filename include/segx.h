@@ -217,7 +217,9 @@ int segx_bn_act_bwd_apply(const float* dY, const float* X, const float* mean, co
  *   floats behind them when nparts > 256).  The buffer holds segx_bn_parts_floats(B, C, S) floats, 16-byte aligned.
  *   nparts == 0 with parts given = AUTO: the library computes the statistics itself, using `parts` as scratch -- in ONE launch for the whole
  *   layer when a channel's B planes fit one team's registers (S <= 4096 floats, B <= 8: "channel-resident", 66 of EfficientNet-B4's 96 layers at
- *   512 x 512 with the stride-1 stem), else a statistics-partials launch + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
+ *   512 x 512 with the stride-1 stem); in ONE launch by a TEAM of B x chunks workgroups per channel for larger planes with S % 4 == 0 (each keeps its
+ *   chunk in registers while the partials are exchanged: 1 read + 1 write; forward teams up to 64 workgroups, backward up to 128; segx_tune knob 3);
+ *   else a statistics-partials launch + the folding apply pass.  segx_bn_pool_chunks(B, S, auto) = chunks per plane written to psum.
  *   parts == NULL: mean / var are INPUTS (running statistics: eval mode / synchronised BatchNorm after the merge); otherwise they are OUTPUTS
  *   (saved for the backward pass) and run_mean / run_var (optional) are updated with momentum and the unbiased variance.
  *   psum (optional): [B*C][segx_plane_chunks(S)] partial sums of Y per plane (the squeeze-excite pooling; segx_se_fwd2 adds the chunks up).
@@ -235,7 +237,7 @@ int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean
                      int B, int C, int64_t S, float eps, int act, void* stream);
 /* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
  * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C, S) floats.
- * training != 0 and a channel-resident shape: ONE launch (x and dy read once).  dy_bs: batch stride of dY in floats (0 = dense, C * S): the gradient of
+ * training != 0 and a channel-resident or team shape (see segx_bn_act_fwd2): ONE launch (x and dy read once).  dy_bs: batch stride of dY in floats (0 = dense, C * S): the gradient of
  * one operand of a channel concatenation (an Inception module's branches, aj_i3d.py:139-141) is read in place from the concatenation's gradient. */
 int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                      float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
