@@ -38,7 +38,11 @@ BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 
 def _ptr(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()       # a plain int: ctypes converts it for a c_void_p parameter without an object per argument
+
+
+# the current stream's handle without building a torch.cuda.Stream object per launch (a private but long-standing entry point; the public path is the fallback)
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 class SegxLib:
@@ -50,6 +54,10 @@ class SegxLib:
         self.c = ctypes.CDLL(path)
         self.c.segx_last_error.argtypes = [ctypes.c_char_p, c_i]
         self.c.segx_version.restype = c_i
+        for name in ('segx_gemm_f32', 'segx_gemm_plan', 'segx_gemm_plan_model'):     # (A, B, C | desc, desc | tile*, stream | splitk*): pointers all
+            fn = getattr(self.c, name)
+            fn.argtypes = [c_p] * 5
+            fn.restype = c_i
         self.emulated = 'emu' in os.path.basename(path)
         self.force_tile = None           # tools/gemm_bench.py: override the library's tile choice
         self.gemm_prof = None            # bench.py: list of (start_event, end_event, flops) per GEMM launch
@@ -85,8 +93,11 @@ class SegxLib:
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
         if t.is_cuda:
-            return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
-        return ctypes.c_void_p(0)
+            if _raw_stream is not None:
+                idx = t.device.index
+                return _raw_stream(idx if idx is not None else torch.cuda.current_device())
+            return torch.cuda.current_stream(t.device).cuda_stream
+        return 0
 
     def check(self, rc, what):
         if rc != 0:
@@ -165,13 +176,24 @@ class SegxLib:
     # ---- token row kernels (tokens.hip) ---------------------------------------------------------
     def _call(self, name, ref, *args):
         """args: tensors (-> device pointers), None (-> NULL) or python scalars; stream appended."""
-        ts = [a for a in args if isinstance(a, torch.Tensor)]
-        self._chk_t(*ts)
-        for t in ts:
-            assert t.is_contiguous(), name + ': non-contiguous tensor'
-        conv = [(_ptr(a) if isinstance(a, torch.Tensor) or a is None else a) for a in args]
+        conv = []
+        dev = None
+        hip = not self.emulated
+        for a in args:                                       # one pass: the checks of _chk_t + contiguity + pointer extraction
+            if isinstance(a, torch.Tensor):
+                if hip and not a.is_cuda:
+                    raise RuntimeError('libsegx (HIP) called with a CPU tensor')
+                if dev is None:
+                    dev = a.device
+                elif a.device != dev:
+                    raise AssertionError('tensors on different devices')
+                assert a.is_contiguous(), name + ': non-contiguous tensor'
+                conv.append(a.data_ptr())
+            else:
+                conv.append(a)
         rc = getattr(self.c, name)(*conv, self.stream(ref))
-        self.check(rc, name)
+        if rc:
+            self.check(rc, name)
 
     def colreduce_ws(self, rows, C, nout):
         return int(self.c.segx_colreduce_ws_floats(rows, C, nout))
