@@ -196,6 +196,39 @@ def test_bn_forms_team_and_two_launch(backend, path, shape):
         assert L.c.segx_tune(3, 0) == 0
 
 
+@pytest.mark.parametrize('fill', ['ones_bits', 'small_ints', 'previous_call'])
+def test_team_exchange_ignores_what_its_buffers_held(backend, fill):
+    """The team exchange marks its slots and mailboxes with a per-launch tag and zeroes nothing (common.h: team_exchange), so its scratch may hold anything:
+    all-ones bits, small int64 values (what recycled memory often holds -- sequential tags once matched them), or the words a previous call left behind.
+    Forward and backward results must equal, bit for bit, those computed with zero-filled scratch."""
+    L = backend.L
+    B, C, S = 2, 3, 130 * 132                                # two chunks per plane: teams of four workgroups
+    x, dy = rnd(B, C, S, seed=70) * 1.5 + 0.3, rnd(B, C, S, seed=71)
+    w, b = 1 + 0.2 * rnd(C, seed=72), 0.2 * rnd(C, seed=73)
+    npf, nws = L.bn_parts_floats(B, C, S), L.bn_ws(B, C, S)
+
+    def run(parts, ws):
+        y, dx = torch.empty_like(x), torch.empty_like(x)
+        mean, var, dw, db = (torch.empty(C, device=x.device) for _ in range(4))
+        L.bn_act_fwd2(x, parts, 0, mean, var, None, None, 0.0, w, b, y, None, None, 0.0, 0, 0, B, C, S, 1e-3, 1)
+        L.bn_act_bwd2(dy, x, mean, var, w, b, dx, dw, db, ws, B, C, S, 1e-3, 1, 1)
+        return y, mean, var, dx, dw, db
+
+    ref = run(torch.zeros(npf, device=x.device), torch.zeros(nws, device=x.device))
+    if fill == 'ones_bits':
+        parts = torch.full((npf,), -1, dtype=torch.int32, device=x.device).view(torch.float32)
+        ws = torch.full((nws,), -1, dtype=torch.int32, device=x.device).view(torch.float32)
+    elif fill == 'small_ints':
+        parts = (torch.arange(npf // 2 + 1, device=x.device, dtype=torch.int64) % 7).view(torch.float32)[:npf].clone()
+        ws = (torch.arange(nws // 2 + 1, device=x.device, dtype=torch.int64) % 5).view(torch.float32)[:nws].clone()
+    else:
+        parts, ws = torch.zeros(npf, device=x.device), torch.zeros(nws, device=x.device)
+        run(parts, ws)                                       # leaves its words behind; the next call gets a new tag
+    out = run(parts, ws)
+    for a, r in zip(out, ref):
+        assert torch.equal(a, r)
+
+
 def test_drop_connect_draws_differ_between_calls_and_follow_the_seed(backend):
     B, C = 16, 2
     bn = torch.nn.BatchNorm2d(C).train()
