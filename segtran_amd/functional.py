@@ -615,7 +615,8 @@ _bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair 
 
 def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=False, resid=None, dc=(0.0, 0, 0)):
     """BatchNorm (+ activation, + squeeze-excite pooling chunks, + drop_connect scale and skip add) -> (y, mean, var, n, psum, nch).
-    Training, one process: TWO launches (segx_bn_stats_partial, segx_bn_act_fwd2 -- the apply pass merges the statistics partials itself).
+    Training, one process: ONE call of segx_bn_act_fwd2 -- one launch where a channel fits a workgroup's or a team of workgroups' registers, else a
+    statistics-partials launch + the apply pass that merges them.
     Synchronised: local statistics -> ONE all-gather -> merge kernel -> the same apply pass on the merged statistics.  Eval: the apply pass alone."""
     y = torch.empty_like(x)
     auto = training and _bn_stats_sync is None              # the library computes the statistics itself (channel-resident: one launch for the layer)
