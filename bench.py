@@ -13,8 +13,10 @@ before the timed region.  Rank 0 prints ONE JSON line:
     layer, BASELINE configs[3]) at N = 1, and cfg5 (128^3, 4 volumes per GPU, two layers, BASELINE configs[4]: the configuration the
     >= 6x scaling target is stated on) at every N;
   * `"polyp"` (N > 1 only): BASELINE configs[2], polyp 352 x 352, at 6 images per GPU and with the reference's global batch 6 split over the ranks;
-  * `roofline`: the dominant kernel family (with `by_shape`: the twelve engine shapes with the most time, and `attention_gemms`: the mode-batched
-    squeezed-attention QK^T / P.V GEMMs) = the tile engine (dense + implicit-GEMM kernels); `cpu_baseline`: the oracle on the host cores.
+  * `roofline`: the dominant kernel family = the tile engine (dense + implicit-GEMM kernels), with `attention_gemms`: up to six of the mode-batched
+    squeezed-attention QK^T / P.V GEMMs as [M, N, K, batch, ms_per_step, TFLOP/s, frac]; `cpu_baseline`: the oracle on the host cores.
+The printed line is the COMPACT form (compact_line(): < 4 KB, the driver keeps an ~8 KB tail); the whole result -- `by_shape` (the twelve engine shapes
+with the most time, each with its FLOP per byte and applicable roof), notes, per-step extremes -- is written to bench_shapes.json beside this file.
 `--config cfgN` makes another BASELINE configuration the main measurement; `--engine f32` times the fp32-MFMA engine instead of bf16x6.
 """
 import argparse
@@ -318,7 +320,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
         for shp, (n, t, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
             print('[bench]   %-58s %4d %8.2f %7.1f' % (shp, n, t, fl / (t * 1e-3) / 1e12), file=sys.stderr)
     med = statistics.median(per_step)
-    res = {'metric': 'train-step %s (%s)' % (unit.replace('/s', '/sec'), cfg_name), 'value': round(world * B * steps / dt, 3), 'unit': unit,
+    res = {'metric': 'train-step %s (%s, %s op order)' % (unit.replace('/s', '/sec'), cfg_name, 'reference' if args.reference_op_order else 're-associated'), 'value': round(world * B * steps / dt, 3), 'unit': unit,
            'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': round(dt / steps * 1e3, 2),
            'ms_per_step_median': round(med, 2), 'value_at_median': round(world * B / (med * 1e-3), 3),
            'ms_per_step_min_max': [round(min(per_step), 2), round(max(per_step), 2)],
@@ -339,11 +341,11 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
     return res
 
 
-def run_graph_replay(args, config=None):
+def run_graph_replay(args, config=None, graph=True):
     """The same configuration replayed as ONE captured hipGraph per step (engine.GraphedTrainStep), in a child process after everything else has been
     measured: a capture problem can then cost this extra block only, never the line.  Not the headline: `value` stays the eager step, whose engine
     launches carry the HIP events the roofline is computed from."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--graph', '--config', config or args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
+    cmd = [sys.executable, os.path.abspath(__file__)] + (['--graph'] if graph else []) + ['--config', config or args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
            '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order']
     if args.reference_op_order:
         cmd.append('--reference-op-order')
@@ -353,9 +355,80 @@ def run_graph_replay(args, config=None):
         if out.returncode != 0 or not line:
             return {'error': 'rc %d: %s' % (out.returncode, out.stderr.decode()[-200:])}
         r = json.loads(line[-1])
-        return {k: r[k] for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'ms_per_step_min_max')}
+        return {k: r.get(k) for k in ('value', 'unit', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median')}
     except subprocess.TimeoutExpired:
         return {'error': 'timeout'}
+
+
+LINE_LIMIT = 4096           # the driver keeps an ~8 KB tail of stdout (BENCH_r04: a 24.9 KB line arrived without its head): the line stays under half of that
+_ATTN_NAMES = ('QK^T', 'P.V', 'dP', 'dV', 'P.(vW)', 'dS.K')
+
+
+def _short_roofline(roof, n_shapes=6):
+    """The scalars of a roofline block plus at most n_shapes attention GEMMs as compact arrays [M, N, K, batch, ms_per_step, TFLOP/s, frac]."""
+    if not roof:
+        return None
+    out = {k: roof.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
+    out['kernel'] = 'segx bf16x6 tile engine (gemm_x6* + conv3d_*_x6 kernels)' if 'bf16x6' in roof.get('kernel', '') else 'segx fp32-MFMA tile engine'
+    out['algorithmic_bytes'] = roof.get('algorithmic_bytes_per_launch')
+    out['launches'] = roof.get('launches_per_step')
+    out['ms_per_step'] = roof.get('gemm_ms_per_step')
+    out['traffic_src'] = (roof.get('traffic_note') or '').split('profiles/')[-1] or None
+    out['f32_remainder_ms'] = (roof.get('f32_engine_remainder') or roof.get('x6_engine_part') or {}).get('ms_per_step')
+    rows = roof.get('attention_gemms') or []
+    out['attention_gemms'] = {'cols': ['M', 'N', 'K', 'batch', 'ms_per_step', 'tflops', 'frac'],
+                              'rows': [[r['M'], r['N'], r['K'], r['batch'], r['ms_per_step'], r['tflops'], r['frac']] for r in rows[:n_shapes]]}
+    return out
+
+
+def compact_line(res):
+    """The ONE JSON line rank 0 prints: headline fields, `config`, the scalars of `roofline`, `cpu_baseline` (value + medians), the BraTS / polyp blocks as
+    value / ms_per_step / roofline.frac, and <= 6 attention GEMM rows.  Everything else (the per-shape tables, notes, per-step lists) goes to
+    bench_shapes.json beside this file.  tests/test_bench_line.py holds the size bound."""
+    c = res.get('config') or {}
+
+    def ms(d):
+        return None if not isinstance(d, dict) else (d.get('ms_per_step') if 'error' not in d else 'error')
+    other_key = 'reassociated_op_order' if 'reassociated_op_order' in c else 'reference_op_order'
+    line = {k: res.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'higher_is_better', 'scaling',
+                                    'vs_baseline', 'dtype', 'data')}
+    line['config'] = {'workload': c.get('workload'), 'global_batch': c.get('global_batch'), 'per_gpu_batch': c.get('per_gpu_batch'),
+                      'parallelism': c.get('parallelism'), 'dropout': c.get('dropout'), 'step': c.get('step'), 'final_loss': c.get('final_loss'),
+                      'op_order': (c.get('op_order') or '').split(' (')[0], other_key + '_ms': ms(c.get(other_key)),
+                      'with_h2d_copy_ms': ms(c.get('with_h2d_copy')), 'hipgraph_replay_ms': ms(c.get('hipgraph_replay')),
+                      'cfg1_hipgraph_ms': ms(c.get('hipgraph_replay_cfg1')), 'cfg1_eager_ms': ms(c.get('eager_cfg1')),
+                      'collective_backend': c.get('collective_backend'), 'overlap': c.get('overlap')}
+    line['roofline'] = _short_roofline(res.get('roofline'))
+    cb = res.get('cpu_baseline')
+    if cb:
+        line['cpu_baseline'] = {'value': cb.get('value'), 'unit': cb.get('unit'), 'cores': cb.get('cores'), 'kind': cb.get('kind'),
+                                'sample': (cb.get('sample') or '')[:200],
+                                's_per_step_median': {k: v.get('s_per_step_median') for k, v in (cb.get('detail') or {}).items() if isinstance(v, dict)}}
+    for blk in ('brats', 'polyp'):
+        if res.get(blk):
+            line[blk] = {}
+            for k, r in res[blk].items():
+                b = {'value': r.get('value'), 'unit': r.get('unit'), 'ms_per_step': r.get('ms_per_step'), 'ms_per_step_median': r.get('ms_per_step_median'),
+                     'steps': r.get('steps'), 'per_gpu_batch': (r.get('config') or {}).get('per_gpu_batch')}
+                if r.get('roofline'):
+                    rr = _short_roofline(r['roofline'], n_shapes=3)
+                    b['roofline'] = {kk: rr[kk] for kk in ('achieved', 'peak', 'frac', 'traffic', 'algorithmic_bytes', 'launches', 'ms_per_step')}
+                    b['roofline']['attention_gemms'] = rr['attention_gemms']['rows']
+                if (r.get('config') or {}).get('overlap'):
+                    b['overlap'] = r['config']['overlap']
+                line[blk][k] = b
+    line['full'] = 'bench_shapes.json'
+    s = json.dumps(line, separators=(',', ':'))
+    if len(s) > LINE_LIMIT:                 # never let a long note cost the record: drop the optional parts in order until the line fits
+        for path in (('roofline', 'attention_gemms'), ('cpu_baseline', 'sample'), ('brats',), ('polyp',)):
+            d = line
+            for k in path[:-1]:
+                d = d.get(k) or {}
+            d.pop(path[-1], None)
+            s = json.dumps(line, separators=(',', ':'))
+            if len(s) <= LINE_LIMIT:
+                break
+    return s
 
 
 def self_spawn(n):
@@ -439,7 +512,12 @@ def main():
         res['config']['hipgraph_replay'] = run_graph_replay(args)
         if args.config == 'cfg2':                      # the launch-bound configuration (256 x 256, bs 2) as one graph: where capture matters most
             res['config']['hipgraph_replay_cfg1'] = run_graph_replay(args, config='cfg1')
-    print(json.dumps(res), flush=True)
+            res['config']['eager_cfg1'] = run_graph_replay(args, config='cfg1', graph=False)    # the same step launched eagerly: host time of a small per-rank batch
+    try:                                               # the whole result (per-shape tables, notes, per-step lists) beside the line
+        json.dump(res, open(os.path.join(ROOT, 'bench_shapes.json'), 'w'), indent=1)
+    except OSError:
+        pass
+    print(compact_line(res), flush=True)
 
 
 if __name__ == '__main__':
