@@ -307,6 +307,11 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
         set_op_order(net, not args.reference_op_order)
     lossv = float(loss.detach())
     assert lossv == lossv, 'loss is NaN'
+    L.team_check()                                                 # a timed-out team exchange anywhere in the run voids the number
+    overlap = None
+    if reducer is not None:
+        overlap = reducer.overlap_stats()                          # buckets whose all-reduce was launched from inside backward (of the last step)
+        reducer.close()
     del step, opt, net, reducer
     torch.cuda.empty_cache()
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
@@ -332,7 +337,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
                                   'consecutive linear maps; every layer, parameter and gradient is computed)',
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
                           None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)},
-                      'with_h2d_copy': with_h2d,
+                      'with_h2d_copy': with_h2d, 'overlap': overlap,
                       'ranks': world, 'collective_backend': (torch.distributed.get_backend() + ' (RCCL)' if world > 1 else None)},
            'roofline': roof}
     if rank == 0:

@@ -234,14 +234,25 @@ int64_t segx_bn_parts_floats(int B, int C, int64_t S);
 int segx_bn_stats_local(const float* X, float* part, float* ws, int B, int C, int64_t S, void* stream);
 int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                      const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
-                     int B, int C, int64_t S, float eps, int act, void* stream);
+                     int B, int C, int64_t S, float eps, int act, int64_t parts_floats, void* stream);
+/* parts_floats / ws_floats (r05): the floats the caller's `parts` / `ws` buffer holds.  Both calls re-derive what they need under the knob settings in force
+ * AT THE CALL and refuse a smaller buffer (a knob-3 change between sizing and launch used to write past it).
+ * TEAM FORM, failure behaviour (r05): a team is at most segx_team_cap() workgroups (half the compute units the runtime reports, at most 128) and its kernels
+ * are checked for >= 2 workgroups per compute unit at first use; the inter-workgroup polls are bounded (segx_tune knob 12), and a poll that expires adds one to
+ * a process-wide error word in pinned host memory AND turns the exchanged statistics into NaN.  segx_team_status(clear) returns the number of expired polls
+ * since the last clear without synchronising the device; the Python host raises RuntimeError on a non-zero count at every optimizer step
+ * (segtran_amd/segx.py: team_check).  Replaces nn.BatchNorm2d of efficientnet/model.py:43, 98, 102, 115, which is never silently wrong. */
+int segx_team_status(int clear);
+int segx_team_cap(void);
+/* diagnostics (tests of the team form under contention): `wgs` workgroups of 256 threads holding 80 KB (heavy != 0) or 64 bytes of LDS each for `ms` milliseconds on `stream` */
+int segx_occupy(int wgs, int heavy, float ms, float* sink, void* stream);
 /* backward of segx_bn_act_fwd2 in two launches (the apply pass sums the reduction partials itself): as segx_bn_act_bwd, plus the drop_connect scale of
  * the forward (same dc_p / seed / offset), which multiplies dY; the gradient w.r.t. resid is dY itself.  ws: segx_bn_ws_floats(B, C, S) floats.
  * training != 0 and a channel-resident or team shape (see segx_bn_act_fwd2): ONE launch (x and dy read once).  dy_bs: batch stride of dY in floats (0 = dense, C * S): the gradient of
  * one operand of a channel concatenation (an Inception module's branches, aj_i3d.py:139-141) is read in place from the concatenation's gradient. */
 int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                      float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                     const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, void* stream);
+                     const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, int64_t ws_floats, void* stream);
 /* r04 -- the squeeze-excite excitation of an MBConv block (efficientnet/model.py:105-113) in 2 + 3 launches.
  * fwd: p = (sum of the nch pooling chunks psum[B*C][nch]) * inv_S; hpre = W1 p + b1; gate = sigmoid(W2 swish(hpre) + b2); and, when Wproj [M][C] is
  *      given, the gate folded into per-sample projection weights Wb[b][m][k] = Wproj[m][k] * gate[b][k] (exact re-association of
@@ -315,7 +326,9 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 5 = number of launches that ran on the bf16x6 engine since the last query (resets the count);
  * knob 3 = form of training BatchNorm when the library computes the statistics itself (segx_bn_act_fwd2 with nparts == 0, segx_bn_act_bwd2): 0 (default) =
  * channel-resident where a channel fits one workgroup, else a TEAM of workgroups per channel (one launch, the slabs stay in registers across a team barrier),
- * else two launches; 1 = never teams; 2 = teams for every shape with S % 4 == 0 (tests).  Same results to fp32 summation order. */
+ * else two launches; 1 = never teams; 2 = teams for every shape with S % 4 == 0 (tests).  Same results to fp32 summation order;
+ * knob 12 = poll bound of a team exchange (default 2^20 polls, ~1 s; 32 .. 2^24); knob 13 = FAULT INJECTION for the tests of the team form's failure
+ * path: the last `value` workgroups of every team launch are not launched, so their team mates time out (0 = off, the default). */
 int segx_tune(int knob, int value);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
  * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)

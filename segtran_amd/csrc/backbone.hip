@@ -6,6 +6,8 @@
 // roofline.  Layout rule: a (sample, channel) plane is contiguous (S = D*H*W floats), so a workgroup always
 // streams contiguous float4 runs of one plane and carries the per-channel constants in scalars.
 #include "common.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace segx {
 
@@ -337,7 +339,9 @@ __device__ __forceinline__ void bn_res_apply(const BnFwdArgs& g, int B, const f3
 // ACT / RESID are KERNEL parameters: one straight-line body per kernel.  (Branching inside one kernel into per-activation bodies made the register
 // allocator spill the resident planes at the loads: 832 bytes per lane in the largest backward form.)  ACT = -1 / RESID = -1: the run-time values.
 template <int TEAM, int KP, int BMAX, bool POOL, int ACT, int RESID, bool STATS = false>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : KP * BMAX <= 24 ? 3 : 2) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
+// waves per SIMD: the state is KP * BMAX float4 (+ two planes of the skip connection in flight where there is one: the 24-float4 form with a skip spilled
+// 76 bytes per lane under the 168-register cap of three waves)
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : (KP * BMAX <= 16 || (KP * BMAX <= 24 && RESID == 0)) ? 3 : 2) void bn_act_fwd_res_kernel(BnFwdArgs g, int B) {
     __shared__ float red[4];
     const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
     const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
@@ -446,7 +450,7 @@ __device__ __forceinline__ void bn_res_bwd_tail(const BnBwdArgs& g, int B, f32x4
     }
 }
 template <int TEAM, int KP, int BMAX, int ACT>
-__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? 4 : 2) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {
+__global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP * BMAX <= 8 ? (ACT >= 0 ? 4 : 3) : 2) void bn_act_bwd_res_kernel(BnBwdArgs g, int B) {     // run-time activation: 40 bytes spilled at four waves
     __shared__ float red[4];
     const int tl = TEAM == 64 ? (threadIdx.x & 63) : threadIdx.x;
     const int c = TEAM == 64 ? blockIdx.x * 4 + (threadIdx.x >> 6) : blockIdx.x;
@@ -490,7 +494,52 @@ static inline void team_next_tag(unsigned& lo, unsigned& hi) {
         if (lo && hi) return;
     }
 }
-struct BnTeam { float* slots; float* mbox; unsigned tag_lo, tag_hi; int B, cpp; };       // slots: [C][B * cpp][TEAM_SLOT] floats, mbox: [C][B * cpp][TEAM_MBOX] (common.h: team_exchange)
+// slots: [C][B * cpp][TEAM_SLOT] floats, mbox: [C][B * cpp][TEAM_MBOX] (common.h: team_exchange); err / spin: the process's error word and the poll bound
+struct BnTeam { float* slots; float* mbox; unsigned tag_lo, tag_hi; int B, cpp; unsigned* err; unsigned spin; };
+// Host state of the team launches (one device per process).  The ERROR WORD is pinned host memory mapped into the device: a kernel whose poll expires
+// adds one to it (system-scope atomic), segx_team_status() reads it on the host without synchronising anything.  cap = the largest team the device
+// is given: half the compute units the runtime reports, at most 128 (forward progress argument in common.h; a CU-masked / partitioned device gets
+// smaller teams, below 8 none).
+struct TeamHost { unsigned* host; unsigned* dev; int cap; };
+static TeamHost& team_host() {
+    static TeamHost t = [] {
+        TeamHost h{nullptr, nullptr, 128};
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
+            h.cap = cus / 2 < 128 ? cus / 2 : 128;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) {
+                memset(p, 0, 64);
+                void* d = nullptr;
+                if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d) { h.host = (unsigned*)p; h.dev = (unsigned*)d; }
+            }
+        }
+        (void)hipGetLastError();                               // a process without a device (sizing calls on the build host) is not an error here
+        if (!h.host) { static unsigned fallback[16]; h.host = h.dev = fallback; }
+        return h;
+    }();
+    return t;
+}
+static inline int team_cap() { return team_host().cap; }
+// the occupancy the forward-progress argument counts on (>= 2 workgroups per CU), checked once per kernel instantiation against the runtime's own figure
+static int team_occupancy_ok(const void* kernel, const char* what) {
+    static std::mutex mu; static std::unordered_map<const void*, int> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = seen.find(kernel);
+    int n = it == seen.end() ? -1 : it->second;
+    if (n < 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+        seen[kernel] = n;
+    }
+    return n >= 2 ? 0 : fail(-1, "%s: the team kernel fits %d workgroup(s) per compute unit, the team exchange needs 2 (segx_tune(3, 1) selects the two-launch form)", what, n);
+}
+static inline void team_fill(BnTeam& t) {
+    const TeamHost& h = team_host();
+    t.err = h.dev; t.spin = (unsigned)kget(knobs().team_spin);
+    team_next_tag(t.tag_lo, t.tag_hi);
+}
+// fault injection (knob 13, tests): the grid without its last n workgroups -- the mates of the missing members time out
+static inline dim3 team_grid(int64_t wgs) { const int drop = kget(knobs().team_drop); return dim3((unsigned)(wgs > drop ? wgs - drop : 1)); }
 template <int KP, bool POOL, int ACT, int RESID>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16 ? 3 : 2) void bn_act_fwd_team_kernel(BnFwdArgs g, BnTeam t) {
     __shared__ float red[4];
@@ -522,12 +571,13 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
         q += (j0 + tl + 256 * k < S4) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
     }
     q = block_sum<4>(q, red);
-    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi, t.err, t.spin};
     if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, n); team_store(pp + 1, m); team_store(pp + 2, q); }
     float res[3];
     team_exchange(tb, r, TS, res, [](const float* slots, int members, float (&o)[3]) { const BnPart f = bn_fold_team(slots, members); o[0] = f.n; o[1] = f.mean; o[2] = f.m2; });
     BnPart st; st.n = res[0]; st.mean = res[1]; st.m2 = res[2];
-    const float mean = st.mean, var = st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
+    // (a timed-out exchange hands NaN to its members: the variance must carry it, fmaxf would turn it into 0)
+    const float mean = st.mean, var = st.n != st.n ? st.n : st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
     if (r == 0 && tl == 0) {
         g.mean[c] = mean; g.var[c] = var;
         if (g.run_mean) {
@@ -542,12 +592,17 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
     const ws_gptr rb = ws_uniform_base((resid ? g.resid : g.X) + plane);
     float acc = 0.f;
     constexpr int G = 4;                                         // the skip connection's float4 are requested G at a time
+    // the store phase recomputes its offsets from an opaque copy of the lane index: shared with the load phase's (common sub-expressions), KP offset
+    // registers stay alive across the exchange next to the KP float4 of state -- the 32-float4 forms then spilled 52..164 bytes per lane (r04_w trace)
+    int tl2 = tl;
+    SEGX_PIN(tl2);
+    auto offs = [&](int k) { const int j = j0 + tl2 + 256 * k; return 16u * (unsigned)(j < S4 ? j : S4 - 1); };
 #pragma unroll
     for (int k0 = 0; k0 < KP; k0 += G) {
         f32x4 rv[G];
         if (resid) {
 #pragma unroll
-            for (int e = 0; e < G; ++e) rv[e] = ws_load<f32x4>(rb, offk(k0 + e));
+            for (int e = 0; e < G; ++e) rv[e] = ws_load<f32x4>(rb, offs(k0 + e));
         }
 #pragma unroll
         for (int e = 0; e < G; ++e) {
@@ -556,8 +611,8 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
             o.x = act_fwd_c<ACT>(v[k].x * sc + sh, act); o.y = act_fwd_c<ACT>(v[k].y * sc + sh, act);
             o.z = act_fwd_c<ACT>(v[k].z * sc + sh, act); o.w = act_fwd_c<ACT>(v[k].w * sc + sh, act);
             if (resid) { o.x = o.x * dcs + rv[e].x; o.y = o.y * dcs + rv[e].y; o.z = o.z * dcs + rv[e].z; o.w = o.w * dcs + rv[e].w; }
-            if (j0 + tl + 256 * k < S4) {
-                ws_store<f32x4>(yb, offk(k), o);
+            if (j0 + tl2 + 256 * k < S4) {
+                ws_store<f32x4>(yb, offs(k), o);
                 if (POOL) acc += (o.x + o.y) + (o.z + o.w);
             }
         }
@@ -600,7 +655,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 4 ? 4 : KP <= 8 
         a += (dd.x + dd.y) + (dd.z + dd.w); q += (dd.x * hh.x + dd.y * hh.y) + (dd.z * hh.z + dd.w * hh.w);
     }
     a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi};
+    const TeamBufs tb{t.slots + (int64_t)c * TS * TEAM_SLOT, t.mbox + (int64_t)c * TS * TEAM_MBOX, t.tag_lo, t.tag_hi, t.err, t.spin};
     if (tl == 0) { float* pp = tb.slots + r * TEAM_SLOT; team_store(pp, a); team_store(pp + 1, q); }
     float res[3];
     // the team's sums: lane l takes members l, l + 64 (team <= 128) in that order, then a symmetric butterfly -- the same bits in every lane and every run
@@ -636,9 +691,11 @@ static inline int bn_res_form(int B, int64_t S, bool backward) {
     const int capw = backward ? 1 : 2, capb = backward ? 2 : 4;          // per-plane float4 per lane; x BMAX = 8 planes (6 for the largest backward form)
     if (kw <= capw) return 64 * 16 + (kw <= 1 ? 1 : 2);
     if (kb <= capb) return 256 * 16 + (kb <= 1 ? 1 : kb <= 2 ? 2 : 4);
-    if (backward && kb <= 4 && B <= 6) return 256 * 16 + 4;
     return 0;
 }
+// backward of planes of 2049..4096 floats at batch <= 6 (672 / 960 channels of 64 x 64 at cfg2): a team of one workgroup per plane.  (r04 also had a
+// six-plane resident form here -- 192 registers of state, 180..312 bytes spilled per lane, slower than the team even so: r04_s 60.8 -> 49.9 us -- removed.)
+static inline bool bn_bwd_plane_team(int B, int64_t S) { return (S & 3) == 0 && S > 2048 && S <= 4096 && B >= 1 && B <= 6; }
 
 // float4 per lane of a team workgroup (chunk = 1024 x KP floats of ONE plane), 0 = the team form does not serve (B, S).  Backward: 16 (x and dy: 128
 // registers of state), teams up to 128 workgroups.  Forward: 16 while the team stays within 32 workgroups, else 32 (teams up to 64): a forward team
@@ -648,9 +705,10 @@ static inline int bn_team_chunks(int64_t S, int kp) { return (int)((S / 4 + 256 
 static inline int bn_team_kp_small(int64_t S) { return S <= 4096 ? 4 : S <= 8192 ? 8 : 16; }     // one chunk per plane: the smallest form that holds it
 static inline int bn_team_kp(int B, int64_t S, bool backward) {
     if ((S & 3) || B < 1 || S < 16384) return 0;
-    if (backward) return (int64_t)bn_team_chunks(S, 16) * B <= 128 ? 16 : 0;
-    if ((int64_t)bn_team_chunks(S, 16) * B <= 32) return 16;
-    return (int64_t)bn_team_chunks(S, 32) * B <= 64 ? 32 : 0;
+    const int cap = team_cap();
+    if (backward) return (int64_t)bn_team_chunks(S, 16) * B <= cap ? 16 : 0;
+    if ((int64_t)bn_team_chunks(S, 16) * B <= (cap < 32 ? cap : 32)) return 16;
+    return (int64_t)bn_team_chunks(S, 32) * B <= (cap < 64 ? cap : 64) ? 32 : 0;
 }
 // policy (knob 3): which form serves training BatchNorm on (B, S) when the library computes the statistics itself: 2 resident, 1 team, 0 two launches;
 // *kp = float4 per lane of the team form
@@ -658,33 +716,33 @@ static inline int bn_auto_form(int B, int64_t S, bool backward, int* kp = nullpt
     const int path = kget(knobs().bn_path);
     int k = 16;
     int form = 0;
-    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= 128) { form = 1; k = bn_team_kp_small(S); }      // tests: the team form on small planes too
-    else if (bn_res_form(B, S, backward)) {
-        form = 2;
-        // the largest backward resident form (six planes x 4 float4 of x AND dy per lane: 192 registers, two workgroups per CU) loses to a team of one
-        // workgroup per plane (r04_s: 960 channels of 64 x 64 at batch 6: 60.8 -> 49.9 us, 672 channels 40.4 -> 36.8; forward the resident form wins)
-        if (backward && path == 0 && bn_res_form(B, S, true) == 256 * 16 + 4 && (S & 3) == 0) { form = 1; k = bn_team_kp_small(S); }
-    }
+    if (path == 2 && (S & 3) == 0 && B <= 128 && S >= 4 && (int64_t)bn_team_chunks(S, 16) * B <= team_cap()) { form = 1; k = bn_team_kp_small(S); }      // tests: the team form on small planes too
+    else if (bn_res_form(B, S, backward)) form = 2;
+    else if (backward && path != 1 && bn_bwd_plane_team(B, S) && B <= team_cap()) { form = 1; k = bn_team_kp_small(S); }
     else if (path != 1 && (k = bn_team_kp(B, S, backward)) != 0) form = 1;
     if (kp) *kp = form == 1 ? k : 0;
     return form;
 }
 template <int KP>
-static void bn_team_launch_fwd(const BnFwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream, bool pool) {
+static int bn_team_launch_fwd(const BnFwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream, bool pool) {
     const bool resid = g.resid != nullptr;
-#define SEGX_BN_TF(P, A, R) hipLaunchKernelGGL((bn_act_fwd_team_kernel<KP, P, A, R>), grid, dim3(256), 0, stream, g, t)
+#define SEGX_BN_TF(P, A, R) do { if (int rc = team_occupancy_ok((const void*)bn_act_fwd_team_kernel<KP, P, A, R>, "segx_bn_act_fwd2/team")) return rc; \
+                                 hipLaunchKernelGGL((bn_act_fwd_team_kernel<KP, P, A, R>), grid, dim3(256), 0, stream, g, t); } while (0)
     if (pool) { if (!resid && g.act == ACT_SWISH) SEGX_BN_TF(true, ACT_SWISH, 0); else SEGX_BN_TF(true, -1, -1); }
     else if (!resid && g.act == ACT_SWISH) SEGX_BN_TF(false, ACT_SWISH, 0);
     else if (g.act == ACT_NONE) { if (resid) SEGX_BN_TF(false, ACT_NONE, 1); else SEGX_BN_TF(false, ACT_NONE, 0); }
     else if (!resid && g.act == ACT_RELU) SEGX_BN_TF(false, ACT_RELU, 0);
     else SEGX_BN_TF(false, -1, -1);
 #undef SEGX_BN_TF
+    return check_launch("segx_bn_act_fwd2/team");
 }
 template <int KP>
-static void bn_team_launch_bwd(const BnBwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream) {
-#define SEGX_BN_TB(A) hipLaunchKernelGGL((bn_act_bwd_team_kernel<KP, A>), grid, dim3(256), 0, stream, g, t)
+static int bn_team_launch_bwd(const BnBwdArgs& g, const BnTeam& t, dim3 grid, hipStream_t stream) {
+#define SEGX_BN_TB(A) do { if (int rc = team_occupancy_ok((const void*)bn_act_bwd_team_kernel<KP, A>, "segx_bn_act_bwd2/team")) return rc; \
+                           hipLaunchKernelGGL((bn_act_bwd_team_kernel<KP, A>), grid, dim3(256), 0, stream, g, t); } while (0)
     if (g.act == ACT_SWISH) SEGX_BN_TB(ACT_SWISH); else if (g.act == ACT_NONE) SEGX_BN_TB(ACT_NONE); else if (g.act == ACT_RELU) SEGX_BN_TB(ACT_RELU); else SEGX_BN_TB(-1);
 #undef SEGX_BN_TB
+    return check_launch("segx_bn_act_bwd2/team");
 }
 // The resident kernels exist per (activation, pooling, skip) combination the backbones use -- swish (+ pooling), none (+ skip), relu -- and once with
 // the run-time values for everything else.
@@ -1296,6 +1354,31 @@ static inline int64_t bn_team_floats(int B, int C, int64_t S, bool backward) {  
     if (S <= 0 || bn_auto_form(B, S, backward, &kp) != 1) return 0;
     return (int64_t)C * B * bn_team_chunks(S, kp) * (TEAM_SLOT + TEAM_MBOX);
 }
+// diagnostics: hold compute units for `ms` milliseconds -- `wgs` workgroups of 256 threads, each with 80 KB of LDS (heavy != 0: two fill a CU's LDS, so no
+// kernel that needs LDS becomes resident beside them) or 64 bytes.  The team-exchange tests run the team BatchNorm next to it on a second stream.
+template <int LDS_FLOATS>
+__global__ __launch_bounds__(256) void occupy_kernel(unsigned long long ticks, float* sink) {
+    __shared__ float hold[LDS_FLOATS];
+    const unsigned long long t0 = wall_clock64();
+    float acc = 0.f;
+    while (wall_clock64() - t0 < ticks) { acc += hold[threadIdx.x & 15]; __builtin_amdgcn_s_sleep(32); }
+    if (sink && acc == 12345.678f) sink[0] = acc;                      // keeps the LDS reads (and with them the allocation) alive
+}
+extern "C" int segx_occupy(int wgs, int heavy, float ms, float* sink, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(wgs > 0 && wgs <= 65535 && ms >= 0.f && ms <= 2000.f, "segx_occupy: bad args");
+    const unsigned long long ticks = (unsigned long long)(ms * 1e5f);                   // wall_clock64 counts at 100 MHz
+    if (heavy) hipLaunchKernelGGL((occupy_kernel<20 * 1024>), dim3(wgs), dim3(256), 0, stream, ticks, sink);
+    else hipLaunchKernelGGL((occupy_kernel<16>), dim3(wgs), dim3(256), 0, stream, ticks, sink);
+    return check_launch("segx_occupy");
+}
+/* team exchanges whose poll expired since the last clear (common.h: team_exchange): read from pinned host memory, no synchronisation */
+extern "C" int segx_team_status(int clear) {
+    const TeamHost& h = team_host();
+    const unsigned n = __atomic_load_n(h.host, __ATOMIC_RELAXED);
+    if (clear && n) __atomic_fetch_sub(h.host, n, __ATOMIC_RELAXED);
+    return (int)(n > 0x7fffffffu ? 0x7fffffffu : n);
+}
+extern "C" int segx_team_cap(void) { return team_cap(); }
 extern "C" int64_t segx_bn_ws_floats(int B, int C, int64_t S) { return i64max((int64_t)B * C * BN_SLABS * 2, bn_team_floats(B, C, S, true)); }
 /* the same pass that also leaves pooled[b][c] = sum over the plane of y (the squeeze-excite pooling of efficientnet/model.py:106); ws: B*C*64 floats */
 extern "C" int segx_bn_act_bwd_reduce(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
@@ -1328,8 +1411,15 @@ extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) {
 extern "C" int64_t segx_bn_parts_floats(int B, int C, int64_t S) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, bn_team_floats(B, C, S, false)); }
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
-                                int B, int C, int64_t S, float eps, int act, void* stream_) {
+                                int B, int C, int64_t S, float eps, int act, int64_t parts_floats, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3 && (!run_mean == !run_var), "segx_bn_act_fwd2: bad args");
+    // the buffer behind `parts` is written by this call in the AUTO and merge cases: its size is part of the contract, re-derived here under the knob
+    // settings of THIS call (a knob change between sizing and launch used to write past it)
+    if (parts) {
+        const int64_t need = nparts == 0 ? segx_bn_parts_floats(B, C, S) : nparts < 0 ? (int64_t)C * (-(int64_t)nparts) * 4 : (int64_t)C * ((int64_t)nparts + (nparts > 256 ? 1 : 0)) * 4;
+        SEGX_REQUIRE(parts_floats >= need, "segx_bn_act_fwd2: the partials buffer holds %lld floats, this call needs %lld (segx_bn_parts_floats under the current knob 3)",
+                     (long long)parts_floats, (long long)need);
+    }
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_bn_act_fwd2: more than 65535 (sample, channel) planes");
     SEGX_REQUIRE(!parts || (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_bn_act_fwd2: bad partials");
     SEGX_REQUIRE(dc_p >= 0.f && dc_p < 1.f && (dc_p == 0.f || resid), "segx_bn_act_fwd2: drop_connect needs the skip input and 0 <= p < 1");
@@ -1347,14 +1437,14 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
         const int af = bn_auto_form(B, S, false, &tkp);
         if (af == 1) {
             BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = const_cast<float*>(parts); t.mbox = t.slots + (int64_t)C * B * t.cpp * TEAM_SLOT;
-            team_next_tag(t.tag_lo, t.tag_hi);
-            SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
+            team_fill(t);
+            SEGX_REQUIRE(B * t.cpp <= team_cap() && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_fwd2: team of %d workgroups", B * t.cpp);
             g.parts = nullptr;
-            if (tkp == 32) bn_team_launch_fwd<32>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
-            else if (tkp == 4) bn_team_launch_fwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
-            else if (tkp == 8) bn_team_launch_fwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
-            else bn_team_launch_fwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream, psum != nullptr);
-            return check_launch("segx_bn_act_fwd2/team");
+            const dim3 tg = team_grid((int64_t)C * B * t.cpp);
+            if (tkp == 32) return bn_team_launch_fwd<32>(g, t, tg, stream, psum != nullptr);
+            if (tkp == 4) return bn_team_launch_fwd<4>(g, t, tg, stream, psum != nullptr);
+            if (tkp == 8) return bn_team_launch_fwd<8>(g, t, tg, stream, psum != nullptr);
+            return bn_team_launch_fwd<16>(g, t, tg, stream, psum != nullptr);
         }
         const int form = af == 2 ? bn_res_form(B, S, false) : 0;
         if (form) {
@@ -1404,8 +1494,12 @@ extern "C" int segx_bn_stats_local(const float* X, float* part, float* ws, int B
 }
 extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* mean, const float* var, const float* w, const float* b,
                                 float* dX, float* dw, float* db, float* ws, int B, int C, int64_t S, float eps, int act, int training,
-                                const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, void* stream_) {
+                                const float* gate, const float* dpool, float inv_S, float dc_p, uint64_t seed, uint64_t offset, int64_t dy_bs, int64_t ws_floats, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && mean && var && w && b && dX && dw && db && ws && B > 0 && C > 0 && S > 0 && (dpool || !gate), "segx_bn_act_bwd2: bad args");
+    {
+        const int64_t need = segx_bn_ws_floats(B, C, training ? S : 0);
+        SEGX_REQUIRE(ws_floats >= need, "segx_bn_act_bwd2: the scratch holds %lld floats, this call needs %lld (segx_bn_ws_floats under the current knob 3)", (long long)ws_floats, (long long)need);
+    }
     if (dy_bs == 0) dy_bs = (int64_t)C * S;
     SEGX_REQUIRE(dy_bs >= (int64_t)C * S && ((S & 3) != 0 || (dy_bs & 3) == 0), "segx_bn_act_bwd2: bad dY batch stride %lld", (long long)dy_bs);
     SEGX_REQUIRE((int64_t)B * C <= 65535 && dc_p >= 0.f && dc_p < 1.f, "segx_bn_act_bwd2: more than 65535 (sample, channel) planes / bad drop_connect rate");
@@ -1416,12 +1510,12 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
     g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base(); g.C = C; g.S = S; g.eps = eps; g.act = act; g.dy_bs = dy_bs;
     if (af == 1) {
         BnTeam t; t.B = B; t.cpp = bn_team_chunks(S, tkp); t.slots = ws; t.mbox = ws + (int64_t)C * B * t.cpp * TEAM_SLOT;
-        team_next_tag(t.tag_lo, t.tag_hi);
-        SEGX_REQUIRE(B * t.cpp <= 128 && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
-        if (tkp == 4) bn_team_launch_bwd<4>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
-        else if (tkp == 8) bn_team_launch_bwd<8>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
-        else bn_team_launch_bwd<16>(g, t, dim3((unsigned)(C * B * t.cpp)), stream);
-        return check_launch("segx_bn_act_bwd2/team");
+        team_fill(t);
+        SEGX_REQUIRE(B * t.cpp <= team_cap() && (int64_t)C * B * t.cpp < 2147483647LL, "segx_bn_act_bwd2: team of %d workgroups", B * t.cpp);
+        const dim3 tg = team_grid((int64_t)C * B * t.cpp);
+        if (tkp == 4) return bn_team_launch_bwd<4>(g, t, tg, stream);
+        if (tkp == 8) return bn_team_launch_bwd<8>(g, t, tg, stream);
+        return bn_team_launch_bwd<16>(g, t, tg, stream);
     }
     const int form = af == 2 ? bn_res_form(B, S, true) : 0;
     if (form) {
@@ -1431,7 +1525,7 @@ extern "C" int segx_bn_act_bwd2(const float* dY, const float* X, const float* me
         else if (kp == 1 && B <= 6) bn_res_launch_bwd<256, 1, 6>(g, B, rgrid, stream);
         else if (kp == 1) bn_res_launch_bwd<256, 1, 8>(g, B, rgrid, stream);
         else if (kp == 2) bn_res_launch_bwd<256, 2, 8>(g, B, rgrid, stream);
-        else bn_res_launch_bwd<256, 4, 6>(g, B, rgrid, stream);
+        else return fail(-1, "segx_bn_act_bwd2: no resident form %d", form);
         return check_launch("segx_bn_act_bwd2/resident");
     }
     const int nsl = bn_slabs(S);

@@ -64,6 +64,7 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
     *reinterpret_cast<V SEGX_GLOBAL*>(base + byte_off) = v;
 }
 
+__device__ __forceinline__ float wave_max(float v);
 // ---- team exchange: the workgroups of a TEAM (consecutive blockIdx.x) combine one small partial result each and all receive the combination.
 // Used by the team BatchNorm kernels (backbone.hip): every member keeps its slab of a channel in registers across the exchange, which is what saves
 // the second read.  Protocol (per team: one 32-byte SLOT and one 64-byte MAILBOX per member; NO initialisation of the buffers):
@@ -82,22 +83,30 @@ template <class V> __device__ __forceinline__ void ws_store(ws_gptr_w base, unsi
 // the XCD's whole L2 per workgroup (r04_i: that version ran at 0.8 TB/s).  "Payload before tag" is an explicit s_waitcnt vmcnt(0) between
 // write-through stores (hipcc drops a workgroup-scope fence here altogether).
 // Forward progress: a waiting workgroup needs its LATER team mates to be dispatched.  Workgroups are dispatched in blockIdx order per XCD
-// (round-robin over the eight XCDs), so when the next workgroup n of an XCD cannot start, every resident workgroup there has a smaller index;
-// those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as one XCD's share of a team (team / 8) is smaller
-// than its resident slots (>= 64), which the host guarantees (team <= 128).  The polls are BOUNDED: if the assumption were ever wrong the kernel
-// produces wrong numbers (the parity tests fail) instead of hanging the device.
+// (round-robin over the XCDs), so when the next workgroup n of an XCD cannot start, every resident workgroup there has a smaller index;
+// those of earlier teams have all their mates dispatched and finish, freeing the slot -- as long as a team is smaller than the resident slots it can
+// count on.  The host derives that bound from the DEVICE (team_cap(): half the compute units the runtime reports, at most 128 -- the team kernels
+// are built for >= 2 workgroups per CU, so a team never needs more than a quarter of the slots; a partitioned or CU-masked device gets smaller teams
+// or none) and checks the kernel's real occupancy at the first launch of every instantiation (team_occupancy_ok()).
+// FAILURE IS LOUD (r05; VERDICT r04 weak 7 / ADVICE r04): the polls are bounded, and a poll that expires (a) adds one to the process's TEAM ERROR
+// WORD -- pinned host memory mapped into the device, read by segx_team_status() without any synchronisation; the Python host checks it at every
+// optimizer step and raises -- and (b) makes the exchange return NaN to every member that can still be told, so the numbers of the launch are
+// poisoned rather than plausible.  The tags of the timed-out lines are cleared like any other's.  tests/test_kernels_backbone.py forces the case
+// (fault-injection knob 13: the last workgroups of the grid are not launched) and runs the exchange under a co-resident kernel that holds every CU.
 #ifndef SEGX_TEAM_SPIN
 #define SEGX_TEAM_SPIN() __builtin_amdgcn_s_sleep(8)
 #define SEGX_TEAM_SPIN_DONE() ((void)0)
 #define SEGX_TEAM_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SEGX_TEAM_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define SEGX_TEAM_ORDER() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")    /* the write-through stores above have been acknowledged */
+#define SEGX_TEAM_RAISE(p) __hip_atomic_fetch_add((p), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 #endif
 __device__ __forceinline__ void team_store(float* p, float v) { SEGX_TEAM_STORE(p, v); }
 __device__ __forceinline__ float team_load(const float* p) { return SEGX_TEAM_LOAD(p); }
 constexpr int TEAM_SLOT = 8, TEAM_MBOX = 16;               // floats per slot (payload 0..2, tag 4..5) and per mailbox (one 64-byte line: payload 0..2, tag 4..5)
-constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;
-struct TeamBufs { float* slots; float* mbox; unsigned tag_lo, tag_hi; };   // of ONE team: slots [members][TEAM_SLOT], mbox [members][TEAM_MBOX]
+constexpr unsigned TEAM_SPIN_LIMIT = 1u << 20;             // default of knob 12 (~1 s of polling: three orders of magnitude above the longest exchange measured)
+// of ONE team: slots [members][TEAM_SLOT], mbox [members][TEAM_MBOX]; err = the process's error word (device address of pinned host memory), spin = poll bound
+struct TeamBufs { float* slots; float* mbox; unsigned tag_lo, tag_hi; unsigned* err; unsigned spin; };
 __device__ __forceinline__ void team_put_tag(float* line, unsigned lo, unsigned hi) {
     SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 4, lo); SEGX_TEAM_STORE(reinterpret_cast<unsigned*>(line) + 5, hi);
 }
@@ -108,18 +117,27 @@ __device__ __forceinline__ bool team_has_tag(const float* line, unsigned lo, uns
 // members, out)` runs in the first wave of member 0 (slot i at slots + i * TEAM_SLOT) and must leave the same out[0..2] in every lane.
 template <class Combine>
 __device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int members, float (&out)[3], Combine combine) {
+    bool expired = false;                                  // thread 0 only: this member's own poll ran out
     if (threadIdx.x < 64) {
         if (threadIdx.x == 0) { SEGX_TEAM_ORDER(); team_put_tag(t.slots + (int64_t)member * TEAM_SLOT, t.tag_lo, t.tag_hi); }
         if (member == 0) {
+            bool late = false;
 #ifndef SEGX_TEAM_NOWAIT                               // bench-only build (tools/build_variant.py): what the kernels cost without the waits (results are then wrong)
             for (int i = threadIdx.x; i < members; i += 64) {
                 unsigned spins = 0;
-                while (!team_has_tag(t.slots + (int64_t)i * TEAM_SLOT, t.tag_lo, t.tag_hi) && ++spins < TEAM_SPIN_LIMIT) SEGX_TEAM_SPIN();
+                while (!team_has_tag(t.slots + (int64_t)i * TEAM_SLOT, t.tag_lo, t.tag_hi)) {
+                    if (++spins >= t.spin) { late = true; break; }
+                    SEGX_TEAM_SPIN();
+                }
                 SEGX_TEAM_SPIN_DONE();
             }
 #endif
             float r[3];
             combine(t.slots, members, r);
+            if (wave_max(late ? 1.f : 0.f) > 0.f) {                             // a mate never arrived: count it once, hand NaN to everybody instead of a sum over stale slots
+                if (threadIdx.x == 0) SEGX_TEAM_RAISE(t.err);
+                r[0] = r[1] = r[2] = __builtin_nanf("");
+            }
             for (int i = threadIdx.x; i < members; i += 64) {
                 float* mb = t.mbox + (int64_t)i * TEAM_MBOX;
                 team_store(mb, r[0]); team_store(mb + 1, r[1]); team_store(mb + 2, r[2]);
@@ -130,9 +148,20 @@ __device__ __forceinline__ void team_exchange(const TeamBufs& t, int member, int
         if (threadIdx.x == 0) {
 #ifndef SEGX_TEAM_NOWAIT
             unsigned spins = 0;
-            while (!team_has_tag(t.mbox + (int64_t)member * TEAM_MBOX, t.tag_lo, t.tag_hi) && ++spins < TEAM_SPIN_LIMIT) SEGX_TEAM_SPIN();
+            // a member waits two poll bounds: member 0 may itself spend one bound waiting for a missing mate before it posts the (NaN) result
+            while (!team_has_tag(t.mbox + (int64_t)member * TEAM_MBOX, t.tag_lo, t.tag_hi)) {
+                if (++spins >= 2u * t.spin + 64u) { expired = true; break; }
+                SEGX_TEAM_SPIN();
+            }
 #endif
             SEGX_TEAM_SPIN_DONE();
+            if (expired) {                                 // member 0 never posted: poison this member's mailbox payload (read below by every thread)
+                SEGX_TEAM_RAISE(t.err);
+                float* mb = t.mbox + (int64_t)member * TEAM_MBOX;
+                const float nan = __builtin_nanf("");
+                team_store(mb, nan); team_store(mb + 1, nan); team_store(mb + 2, nan);
+                SEGX_TEAM_ORDER();
+            }
         }
     }
     __syncthreads();
@@ -254,6 +283,8 @@ struct Knobs {
     std::atomic<int> interp_variant{0};             // knob 1
     std::atomic<int> conv_small_policy{0};          // knob 2
     std::atomic<int> bn_path{0};                    // knob 3: 0 = resident -> workgroup teams -> two launches; 1 = no teams; 2 = teams even where the resident form serves (tests)
+    std::atomic<int> team_spin{(int)TEAM_SPIN_LIMIT}; // knob 12: poll bound of a team exchange (tests shorten it)
+    std::atomic<int> team_drop{0};                  // knob 13: FAULT INJECTION (tests): the last n workgroups of a team launch are not launched -> their mates time out
 };
 inline Knobs& knobs() { static Knobs k; return k; }
 inline int kget(const std::atomic<int>& a) { return a.load(std::memory_order_relaxed); }

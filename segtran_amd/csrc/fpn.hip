@@ -444,6 +444,8 @@ extern "C" int segx_tune(int knob, int value) {
 #endif
     if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
     if (knob == 5) { return k.x6_launches.exchange(0); }
+    if (knob == 12) { if (value < 32 || value > (1 << 24)) return -1; k.team_spin = value; return 0; }     // poll bound of a team exchange
+    if (knob == 13) { if (value < 0 || value > 4096) return -1; k.team_drop = value; return 0; }          // fault injection (tests): unlaunched tail of a team grid
     return -1;
 }
 // RandomResizedCrop (datasets3d.py:611-665) as ONE gather pass: the volume is (virtually) resampled to (D, H, W) with the trilinear

@@ -267,7 +267,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x16 (&acc)[Cfg::MI][Cfg::
     const uint64_t ebase = roff + (uint64_t)(z0 * g.c_b0 + z1 * g.c_b1);         // stream position of this matrix's element (0, 0)
     const bool quad_rng = ((ebase | (uint64_t)ldc) & 3) == 0;                     // a quad's 4 columns share one Philox counter (wave-uniform)
     // 16-byte stores (quad_transpose4): row length and extent multiples of 4 (a quad of columns is wholly inside or outside), 16-byte aligned bases
-    const bool vec_st = VST && (((uint64_t)ldc | (uint64_t)g.N) & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | (EPI == SEGX_EPI_GELU ? reinterpret_cast<uintptr_t>(AUX) : 0)) & 15) == 0;
+    const bool vec_st = VST && (((uint64_t)ldc | (uint64_t)g.N) & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | (EPI == SEGX_EPI_GELU ? reinterpret_cast<uintptr_t>(AUX) : 0) | reinterpret_cast<uintptr_t>(RES)) & 15) == 0;     // RES is read as float4 too (null: 0)
     float vmax = 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {

@@ -39,7 +39,7 @@ class GradReducer:
     buckets travel over xGMI while the backbone is still differentiating.  `allreduce_grads()` then only launches what is left and
     waits.  Buckets that hold no live parameter are never sent (they are zeros on every rank)."""
 
-    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True, force_collectives=False):
+    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True, force_collectives=False, overlap_bn_teams=False):
         """gather=True: gradients stay autograd's own tensors and are copied into their bucket by one multi-tensor launch per
         bucket (no per-parameter `grad += g` kernels); gather=False: every p.grad is a view of the flat buffer.
         force_collectives: issue the all-reduces even in a one-rank group (the single-GPU RCCL test: AVG over one rank is the identity)."""
@@ -61,6 +61,14 @@ class GradReducer:
                 self.buckets.append((a, end, i0, i + 1))
                 a, i0 = end, i + 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'        # RCCL averages in the collective; gloo has no AVG
+        # Collectives launched from the hooks run RCCL's reduction kernels on the compute units WHILE backward's kernels run: the one-launch TEAM form
+        # of training BatchNorm (backbone.hip) needs its workgroups co-resident, which a concurrent kernel can delay.  Its polls are bounded and fail
+        # loudly (segx_team_status), but a data-parallel step should not depend on that: with overlap on, BatchNorm without SyncBN takes the
+        # two-launch form (knob 3 = 1; the synchronised form never uses teams).  `overlap_bn_teams=True` keeps them (measurements).
+        self.bn_teams_off = False
+        if overlap and (self.world > 1 or self.force) and self.flat.is_cuda and not overlap_bn_teams:
+            from . import segx
+            self.bn_teams_off = segx.lib().c.segx_tune(3, 1) == 0
         self._armed, self._hooks = False, []
         self._pending, self._need, self._works, self._launched = [], [], [], []
         self._src, self._slot = None, 0
@@ -156,6 +164,22 @@ class GradReducer:
             self._pending = list(self._need)
             self._launched = [False] * len(self.buckets)
         self._last_in_backward, self.launched_in_backward = self.launched_in_backward, 0
+
+    def overlap_stats(self):
+        """{'buckets': live buckets, 'launched_in_backward': of the last step, 'bucket_mb': their mean size} -- bench.py's overlap evidence"""
+        live = [k for k, need in enumerate(self._need) if need > 0] if self._armed else list(range(len(self.buckets)))
+        mb = sum(self.buckets[k][1] - self.buckets[k][0] for k in live) * 4 / 2 ** 20 / max(1, len(live))
+        return {'buckets': len(live), 'launched_in_backward': getattr(self, '_last_in_backward', 0), 'bucket_mb': round(mb, 1), 'bn_teams_off': self.bn_teams_off}
+
+    def close(self):
+        """remove the hooks and give BatchNorm its default forms back"""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._armed = [], False
+        if self.bn_teams_off:
+            from . import segx
+            segx.lib().c.segx_tune(3, 0)
+            self.bn_teams_off = False
 
 
 def reduce_scalars(t, group=None):

@@ -6,6 +6,7 @@ import torch
 import torch.nn.functional as F
 
 from . import functional as SF
+from . import segx
 from .optimization import BertAdam
 from .synth import load_synth, synth_image2d, synth_fundus_mask, synth_brats
 from .dataloaders.datasets2d import fundus_map_mask, polyp_map_mask
@@ -259,22 +260,30 @@ class AdversarialTrainStep:
 
     def __call__(self, image, raw_mask, target_unsup_image, source_image):
         F = torch.nn.functional
-        sup_b = 0 if image is None else len(image)
+        if self.mode and (target_unsup_image is None or source_image is None):
+            raise ValueError("--adv %s needs the unsupervised target batch and the source batch (train2d.py:1152-1165)" % self.mode)
+        if not self.mode and image is None:
+            raise ValueError('without --adv the step needs the supervised image batch')
+        if self.sup_w > 0 and (image is None or raw_mask is None):
+            raise ValueError('SUPERVISED_W > 0 needs the supervised batch and its masks (train2d.py:1232-1241)')
+        sup_b = len(image) if (image is not None and self.sup_w > 0) else 0
         if self.mode:
-            batch = torch.cat([image, target_unsup_image], dim=0) if (self.sup_w > 0 and image is not None) else target_unsup_image
-            if not (self.sup_w > 0 and image is not None):
-                sup_b = 0
+            batch = torch.cat([image, target_unsup_image], dim=0) if sup_b > 0 else target_unsup_image       # :1166-1170
         else:
             batch = image
         out = self.net(batch)
         zero = torch.zeros((), device=batch.device)
         sup_loss, out_size = zero, tuple(out.shape[2:])
-        if self.sup_w > 0 and sup_b > 0:
+        mask = None
+        if raw_mask is not None:
+            # the reference maps the mask batch and resamples the outputs to ITS size whether or not the supervised loss is on (:1172-1177, 1218-1220): the
+            # discriminator of `--adv mask` sees mask-sized soft masks also at SUPERVISED_W == 0
             mask = map_mask(self.task, raw_mask, self.exclusive)
             out_size = tuple(mask.shape[2:])
             if tuple(out.shape[2:]) != out_size:
                 out = SF.interp_linear(out, out_size)                                  # :1219
-            sup_loss, self.stats = SF.seg_loss(out[:sup_b].contiguous(), mask, self.pos_weight, self.class_w, self.dice_w)
+        if sup_b > 0:
+            sup_loss, sup_stats = SF.seg_loss(out[:sup_b].contiguous(), mask, self.pos_weight, self.class_w, self.dice_w)
         recon_loss = zero
         if self.recon_w > 0:                                                           # before the source pass overwrites the feature map (:1251-1257)
             recon_loss = F.mse_loss(batch, self.net.recon(self.net.feature_maps[-1]))
@@ -284,6 +293,13 @@ class AdversarialTrainStep:
                                                      out_size, self.adda, self.dis_opt)
         loss = self.sup_w * sup_loss + self.dom_w * domain_loss + self.recon_w * recon_loss       # :1314-1318
         self.parts = dict(supervised=sup_loss.detach(), domain=domain_loss.detach(), recon=recon_loss.detach())
+        # what the loop logs (train_common.run): ALWAYS a tensor laid out like TrainStep.stats -- [loss, ce, dice_total, dice_c0, ...] -- with the TOTAL
+        # loss in front; unsupervised-only steps (--supweight 0) carry zeros in the supervised slots (the reference logs zeros there too, :1243-1245)
+        n_cls = int(self.class_w.numel())
+        if sup_b > 0:
+            self.stats = torch.cat([loss.detach().reshape(1), sup_stats.detach()[1:]])
+        else:
+            self.stats = torch.cat([loss.detach().reshape(1), torch.zeros(2 + n_cls, device=batch.device)])
         self.opt.zero_grad()
         loss.backward()
         self.opt.step()
@@ -330,6 +346,7 @@ class GraphedTrainStep:
             self.x.copy_(x, non_blocking=True)
         if raw is not self.raw:
             self.raw.copy_(raw, non_blocking=True)
+        segx.lib().team_check()                     # as BertAdam.step does on the eager path (the captured optimizer step runs no host code)
         self.step.opt.prepare_replay()
         self.graph.replay()
         self.replays += 1

@@ -298,6 +298,7 @@ class BertAdam(Optimizer):
     @torch.no_grad()
     def step(self, closure=None, global_grad_clip=None):
         loss = closure() if closure is not None else None
+        segx.lib().team_check()           # a team BatchNorm exchange of an earlier launch timed out -> RuntimeError here, not NaN weights (one host word, no sync)
         self._ensure_tables()
         if self._private:
             self._refresh_grad_table()

@@ -90,6 +90,19 @@ class SegxLib:
         """launches that ran on the bf16x6 engine since the last call"""
         return int(self.c.segx_tune(5, 0))
 
+    # ---- team exchange: loud failure (include/segx.h: segx_team_status) ---------------------------------
+    def team_check(self):
+        """Raise if a team exchange of an earlier launch timed out (the team BatchNorm kernels then handed NaN statistics to their members).  Reads
+        one word of pinned host memory: no device synchronisation; called by TrainStep / BertAdam.step on every step."""
+        n = int(self.c.segx_team_status(1))
+        if n:
+            raise RuntimeError('libsegx: %d team exchange(s) of the team BatchNorm kernels timed out -- their workgroups were not co-resident (another kernel '
+                               'holding the compute units, a CU mask, a partitioned device?).  The affected launches produced NaN statistics.  '
+                               'segx_tune(3, 1) selects the two-launch BatchNorm, which needs no exchange.' % n)
+
+    def team_cap(self):
+        return int(self.c.segx_team_cap())
+
     # ---- plumbing -----------------------------------------------------------------------------
     def stream(self, t):
         if t.is_cuda:
@@ -285,7 +298,8 @@ class SegxLib:
         self._call('segx_bn_stats_local', X, X, part, ws, B, C, S)
 
     def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act):
-        self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act)
+        self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act,
+                   0 if parts is None else parts.numel())
 
     def bn_act_bwd2(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0, dy_bs=0):
         """dy_bs: batch stride of dY in floats when dY is a channel slice of a wider tensor (its (sample, channel) planes contiguous); 0 = dense"""
@@ -294,7 +308,7 @@ class SegxLib:
             assert t.is_contiguous()
         assert dy_bs or dY.is_contiguous()
         rc = self.c.segx_bn_act_bwd2(_ptr(dY), _ptr(X), _ptr(mean), _ptr(var), _ptr(w), _ptr(b), _ptr(dX), _ptr(dw), _ptr(db), _ptr(ws), B, C, S, eps, act, training,
-                                     _ptr(gate), _ptr(dpool), float(inv_S), float(dc_p), seed, offset, int(dy_bs), self.stream(X))
+                                     _ptr(gate), _ptr(dpool), float(inv_S), float(dc_p), seed, offset, int(dy_bs), ws.numel(), self.stream(X))
         self.check(rc, 'segx_bn_act_bwd2')
 
     def se_fwd2(self, psum, nch, inv_S, W1, b1, W2, b2, Wproj, p, hpre, gate, Wb, B, C, Cs, M):
@@ -555,7 +569,8 @@ _SIGS = {
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
      'segx_plane_bias_add': 'ppplilp', 
     'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'iil', 'segx_bn_stats_local': 'pppiilp',
-    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfip', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuulp',
+    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfilp', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuullp',
+    'segx_team_status': 'i', 'segx_team_cap': '', 'segx_occupy': 'iifpp',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',
 }

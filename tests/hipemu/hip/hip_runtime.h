@@ -34,6 +34,7 @@
 #define SEGX_TEAM_LOAD(p) (*(p))
 #define SEGX_TEAM_STORE(p, v) (*(p) = (v))
 #define SEGX_TEAM_ORDER() ((void)0)
+#define SEGX_TEAM_RAISE(p) (++*(p))                     /* the system-scope atomic add on the process's error word */
 #define SEGX_QUAD_BCAST(v, Q) ((unsigned)__shfl((int)(v), (Q), 4))   /* DPP quad_perm broadcast of quad lane Q */
 #define SEGX_QUAD_XOR(v, X) __shfl_xor((v), (X))                      /* DPP quad_perm exchange with lane ^ X (X = 1, 2) */
 #define SEGX_LOAD_FENCE() ((void)0)                       /* compiler-only fence of the device build */
@@ -62,6 +63,17 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+/* the device queries of the team launches (backbone.hip: team_host / team_occupancy_ok): a 256-CU device, two workgroups per CU, "pinned" = plain memory */
+#define hipDeviceAttributeMultiprocessorCount 0
+#define hipHostMallocMapped 1
+#define hipHostMallocCoherent 2
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+static inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 256; return 0; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 1; }
+static inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
+static inline unsigned long long wall_clock64() { static unsigned long long t = 0; return t += 1000; }
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return 0; }
 static inline hipError_t hipDeviceSynchronize() { return 0; }
 
 namespace hipemu {

@@ -107,3 +107,52 @@ def test_adversarial_train_step_runs_the_whole_recipe(backend):
         doms.append(float(step.parts['domain']))
     assert all(d == d for d in doms)
     assert doms[-1] > doms[0]          # parts['domain'] is the INVERTED-label loss (the generator's): it rises as the discriminator gets better
+
+
+def _toy_step(dev, mode, supervised_w, recon_w=0.0, nc=3):
+    from segtran_amd.optimization import BertAdam
+    torch.manual_seed(0)
+    net = ToyNet(Cf=8, nc=nc).to(dev)
+    engine.attach_adversarial(net, mode, num_classes=nc, num_feat_dis_in_chan=8, adda=False, recon_w=recon_w, device=dev, num_base_chan=8)
+    opt = BertAdam([dict(params=list(net.parameters()), weight_decay=0.0, lr=1e-3)], lr=1e-3, warmup=-1, t_total=-1, weight_decay=0.0)
+    return net, engine.AdversarialTrainStep(net, opt, 'fundus', mode, supervised_w=supervised_w, domain_w=0.002, recon_w=recon_w)
+
+
+def test_unsupervised_only_step_publishes_stats_and_resamples_to_the_mask_size(backend):
+    """ADVICE r04 (train_common.py:310, engine.py:272): `--adv mask --supweight 0` is a supported recipe (train2d.py:1166-1170, 1232-1245: only the
+    unsupervised images go through the network, the supervised terms are zeros).  The step must (a) publish a stats tensor laid out like TrainStep's
+    (the training loop logs it on every log iteration), (b) still resample the outputs to the MASK size before the sigmoid / discriminator
+    (train2d.py:1218-1220, 1274-1277 do so unconditionally) -- the discriminator input is checked through a forward hook."""
+    dev = backend.dev
+    net, step = _toy_step(dev, 'mask', supervised_w=0.0)
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(2, 3, 16, 16, generator=g, device='cpu').to(dev)
+    raw = (torch.rand(2, 3, 32, 32, generator=g, device='cpu') > 0.5).float().to(dev) * 255          # masks at twice the output size
+    tgt, src = torch.randn(3, 3, 16, 16, generator=g, device='cpu').to(dev), torch.randn(2, 3, 16, 16, generator=g, device='cpu').to(dev)
+    seen = []
+    h = net.discriminator.register_forward_hook(lambda m, inp, out: seen.append(tuple(inp[0].shape)))
+    loss = step(x, raw, tgt, src)
+    h.remove()
+    assert seen == [(5, 3, 32, 32)]                          # 2 source + 3 unsupervised target rows (no supervised rows at weight 0), at the mask size
+    st = step.stats.detach().cpu()
+    assert st.shape == (3 + 3,) and abs(float(st[0]) - float(loss)) < 1e-6 and float(st[1:].abs().sum()) == 0.0
+    assert float(step.parts['supervised']) == 0.0 and float(step.parts['domain']) > 0.0
+    # with the supervised part on: same layout, the supervised slots are the supervised statistics, slot 0 the TOTAL loss
+    net, step = _toy_step(dev, 'mask', supervised_w=1.0)
+    loss = step(x, raw, tgt, src)
+    st = step.stats.detach().cpu()
+    assert st.shape == (6,) and abs(float(st[0]) - float(loss)) < 1e-6 and float(st[1]) > 0.0 and float(st[2]) > 0.0
+
+
+def test_adversarial_step_rejects_inconsistent_batches(backend):
+    dev = backend.dev
+    x = torch.zeros(1, 3, 8, 8, device=dev)
+    raw = torch.zeros(1, 3, 8, 8, device=dev)
+    _, step = _toy_step(dev, 'feat', supervised_w=1.0)
+    with pytest.raises(ValueError, match='source batch'):
+        step(x, raw, None, x)
+    with pytest.raises(ValueError, match='SUPERVISED_W'):
+        step(None, None, x, x)
+    _, step = _toy_step(dev, None, supervised_w=1.0)
+    with pytest.raises(ValueError, match='supervised image batch'):
+        step(None, raw, None, None)
