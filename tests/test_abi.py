@@ -81,3 +81,28 @@ def test_product_library_rejects_the_ablation_variants():
     # knobs reject what the product suite does not cover: unknown knob ids and out-of-range settings
     for knob, v in ((1, 3), (2, 2), (7, 3), (8, 10), (9, 12), (10, 16), (10, 8), (11, 0)):
         assert L.c.segx_tune(knob, v) == -1, (knob, v)
+
+
+def test_no_shipped_kernel_spills_registers_beyond_the_known_gemm_tails():
+    """`Scratch_Size` of the shipped kernels.  segtran_amd/build.py compiles with -Rpass-analysis=kernel-resource-usage and keeps the
+    per-kernel figures in lib/resource_usage.json (same build as the .so: the stamp covers both).  Every kernel outside gemm.hip must have NO scratch
+    (r04: team / resident BatchNorm forms spilled 52-312 bytes per lane); the tile-engine kernels listed below spill a few registers around their
+    epilogues (outside the k-loop) -- the list is closed: a new spill, or a growing one, fails here."""
+    import json
+    from segtran_amd.build import build, OUT
+    build()
+    usage = json.load(open(os.path.join(OUT, 'resource_usage.json')))
+    assert len(usage) > 400                                   # every __global__ instantiation of the library reports
+    known = {'gemm_x6ws_kernel': 52, 'gemm_f32_kernel': 36, 'gemm_x6_kernel': 20, 'gemm_x6_lean_kernel': 20}
+    bad = []
+    for name, u in usage.items():
+        assert u['scratch'] >= 0 and u['vgprs'] > 0, name
+        if u['scratch'] == 0:
+            continue
+        fam = [k for k in known if ('4segx%d%sI' % (len(k), k)) in name]
+        if u['file'] != 'gemm.hip' or not fam or u['scratch'] > known[fam[0]]:
+            bad.append((name, u['file'], u['scratch']))
+    assert not bad, bad
+    # the team BatchNorm kernels keep >= 2 workgroups per CU resident (the forward-progress argument of common.h: team_exchange counts on it)
+    team = [u for n, u in usage.items() if 'bn_act_fwd_team_kernel' in n or 'bn_act_bwd_team_kernel' in n]
+    assert team and all(u['occupancy'] >= 2 and u['scratch'] == 0 for u in team)

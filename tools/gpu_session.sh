@@ -1,8 +1,8 @@
 #!/bin/bash
-# One measurement session of round 4 (run through gpurun from the repo root): tools/gpu_session.sh <tag> [tests|notests] [pmc]
-# full -m gpu suite, smoke, the driver's bench line, cfg1 eagerly and as one hipGraph, rocprofv3 kernel stats + per-dispatch traces of cfg2 / cfg4 / cfg5.
+# One measurement session (run through gpurun from the repo root): tools/gpu_session.sh <tag> [tests|notests] [pmc] [extra command ...]
+# full -m gpu suite, smoke, the driver's bench line (+ bench_shapes.json), rocprofv3 kernel stats + per-dispatch traces of cfg2 / cfg4 / cfg5, optional counter passes.
 set -u
-TAG=${1:-r04_x}; MODE=${2:-tests}
+TAG=${1:-r05_x}; MODE=${2:-tests}; PMCMODE=${3:-nopmc}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -12,10 +12,9 @@ if [ "$MODE" = tests ]; then
   timeout 1500 python -m pytest tests -m gpu -q --maxfail=25 --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?" >> $OUT/smoke.log; tail -2 $OUT/smoke.log
 fi
-SEGX_BENCH_VERBOSE=2 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default_shapes.txt; cut -c1-300 $OUT/bench_default.json
-for G in "" "--graph"; do
-  timeout 300 python bench.py --config cfg1 $G --no-brats --no-cpu-baseline --single-order > $OUT/bench_cfg1${G}.json 2> $OUT/bench_cfg1${G}.err; cut -c1-200 $OUT/bench_cfg1${G}.json
-done
+if [ $# -gt 3 ]; then shift 3; for CMD in "$@"; do echo "== $CMD" >> $OUT/extra.log; timeout 600 bash -c "$CMD" >> $OUT/extra.log 2>&1; done; tail -5 $OUT/extra.log; fi
+SEGX_BENCH_VERBOSE=2 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default_shapes.txt; wc -c $OUT/bench_default.json; cut -c1-400 $OUT/bench_default.json
+cp bench_shapes.json $OUT/bench_shapes.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 for CFG in cfg2 cfg4 cfg5; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$CFG -o $CFG -- python $ROOT/bench.py --config $CFG --steps 2 --warmup 2 --no-brats --no-cpu-baseline --single-order > $OUT/prof_$CFG.log 2>&1
@@ -24,9 +23,9 @@ for CFG in cfg2 cfg4 cfg5; do
   find $OUT/prof_$CFG -name '*agent_info.csv' -exec cp {} $OUT/agent_info.csv \;
   rm -rf $OUT/prof_$CFG
 done
-if [ "${3:-}" = pmc ]; then
+if [ "$PMCMODE" = pmc ]; then
   # counter passes (own runs, --pmc only: no trace domains beside them), aggregated per kernel on the box
-  for CFG in cfg2 cfg4; do
+  for CFG in cfg2 cfg4 cfg5; do
     for PMC in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
       NAME=$(echo $PMC | cut -d' ' -f1)
       timeout 400 rocprofv3 --pmc $PMC --output-format csv -d $OUT/pmc_${CFG}_$NAME -o pmc -- python $ROOT/bench.py --config $CFG --steps 1 --warmup 1 --no-brats --no-cpu-baseline --single-order > $OUT/pmc_${CFG}_$NAME.log 2>&1
