@@ -32,6 +32,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROF_EVERY = 5                      # engine launches carry HIP events on every 5th timed step (measure())
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_TBS = 8.0                  # same guide: HBM3E ~8 TB/s (TFLOP/s per FLOP/byte)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: bf16 MFMA dense (32x32x16); the bf16x6 engine issues 6 of them per fp32-equivalent block product
@@ -250,7 +251,12 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    L.gemm_prof = None if graphed else []
+    # HIP events bracket every engine launch of EVERY prof_every-th timed step (two event records per launch cost host time and a queue marker each:
+    # r04_w measured the same step at 67.2 ms without them -- H2D copies included -- and 68.9 ms with them on every step); the roofline is computed
+    # over those launches (10 of 50 steps by default; every step when fewer than 10 steps are timed: profiler runs)
+    prof_every = 1 if (steps < 10 or graphed) else PROF_EVERY
+    prof_list = None if graphed else []
+    prof_steps = 0
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     # the per-launch profiling events are ~700 Python objects per step: a generation-2 collection in the middle of the timed region stalls the host for
     # tens of milliseconds (r03_af / r03_ak: one 116..120-ms step among fifty 75-ms ones).  Collect now, keep the collector out of the timed region.
@@ -260,6 +266,9 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
         t0 = time.perf_counter()
         ev[0].record()
         for i in range(steps):
+            on = prof_list is not None and i % prof_every == 0
+            L.gemm_prof = prof_list if on else None
+            prof_steps += 1 if on else 0
             loss = step(x, raw)
             ev[i + 1].record()
         torch.cuda.synchronize()
@@ -269,7 +278,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
         dt = time.perf_counter() - t0
     finally:
         gc.enable()
-    prof, L.gemm_prof = (L.gemm_prof or []), None
+    prof, L.gemm_prof = (prof_list or []), None
     per_step = [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -315,7 +324,9 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
     del step, opt, net, reducer
     torch.cuda.empty_cache()
     unit = 'images/s' if c['dim'] == 2 else 'volumes/s'
-    roof, achieved = engine_roofline(prof, steps, cfg_name, args.engine, mode_batch=4 * B) if (rank == 0 and prof) else (None, 0.0)
+    roof, achieved = engine_roofline(prof, max(1, prof_steps), cfg_name, args.engine, mode_batch=4 * B) if (rank == 0 and prof) else (None, 0.0)
+    if roof:
+        roof['profiled_steps'] = '%d of %d timed steps (every %d%s)' % (prof_steps, steps, prof_every, 'th' if prof_every > 1 else '')
     if rank == 0 and os.environ.get('SEGX_BENCH_VERBOSE'):
         agg = {}
         for e0, e1, fl, shp, x6 in prof:
@@ -379,6 +390,7 @@ def _short_roofline(roof, n_shapes=6):
     out['launches'] = roof.get('launches_per_step')
     out['ms_per_step'] = roof.get('gemm_ms_per_step')
     out['traffic_src'] = (roof.get('traffic_note') or '').split('profiles/')[-1] or None
+    out['profiled_steps'] = roof.get('profiled_steps')
     out['f32_remainder_ms'] = (roof.get('f32_engine_remainder') or roof.get('x6_engine_part') or {}).get('ms_per_step')
     rows = roof.get('attention_gemms') or []
     out['attention_gemms'] = {'cols': ['M', 'N', 'K', 'batch', 'ms_per_step', 'tflops', 'frac'],
@@ -402,7 +414,7 @@ def compact_line(res):
                       'op_order': (c.get('op_order') or '').split(' (')[0], other_key + '_ms': ms(c.get(other_key)),
                       'with_h2d_copy_ms': ms(c.get('with_h2d_copy')), 'hipgraph_replay_ms': ms(c.get('hipgraph_replay')),
                       'cfg1_hipgraph_ms': ms(c.get('hipgraph_replay_cfg1')), 'cfg1_eager_ms': ms(c.get('eager_cfg1')),
-                      'collective_backend': c.get('collective_backend'), 'overlap': c.get('overlap')}
+                      'ranks': c.get('ranks'), 'collective_backend': c.get('collective_backend'), 'overlap': c.get('overlap')}
     line['roofline'] = _short_roofline(res.get('roofline'))
     cb = res.get('cpu_baseline')
     if cb:

@@ -43,6 +43,9 @@ def test_bench_gpus_2_without_a_launcher_spawns_its_own_ranks():
     assert len(lines) == 1
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['config']['ranks'] == 2 and res['config']['parallelism'] == 'dp2' and res['value'] > 0
+    assert len(lines[0]) < 4096                                # the driver keeps an ~8 KB tail of stdout
+    ov = res['config']['overlap']                              # overlap evidence: buckets whose all-reduce was launched from inside backward (last step)
+    assert ov['buckets'] >= 1 and 0 <= ov['launched_in_backward'] <= ov['buckets']
     import torch
     if torch.cuda.device_count() < 2:
         q = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=ROOT, timeout=300)
