@@ -61,6 +61,8 @@ def mfma_busy(cfg):
 
 traffic = {}
 for name in sorted(os.listdir(src)):
+    if name.endswith('_kernel_trace.csv'):
+        continue                                                  # per-dispatch traces (1 MB each) stay in gpurun_out/
     if name.endswith(('.json', '.csv', '.txt', '.log')) and not name.startswith(('prof_', 'pmc_')) and not name.endswith('.log') or name.endswith('_by_kernel.json'):
         shutil.copy(os.path.join(src, name), os.path.join(dst, '%s_%s' % (tag, name)))
 for cfg in ('cfg2', 'cfg4', 'cfg5'):
