@@ -296,8 +296,20 @@ int segx_plane_dot(const float* A, const float* Bm, float* out, int64_t planes, 
 int64_t segx_gn_ws_floats(int B, int C, int G);
 int segx_groupnorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd, float* ws,
                        int B, int C, int G, int64_t S, float eps, void* stream);
+/* plane_dx_sums (r05; may be NULL): [B * C] floats = the sum over every (sample, channel) plane of the dX this call writes, in closed form from the plane
+ * sums the backward computes anyway.  Where the normalised tensor was `conv1x1(...) + up(...)` (segtran3d.py:336-360, segtran2d.py:263-291) these are the
+ * convolution's bias gradient: the row-sum pass over the full-resolution gradient need not run. */
 int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX,
-                       float* dw, float* db, float* ws, int B, int C, int G, int64_t S, void* stream);
+                       float* dw, float* db, float* ws, int B, int C, int G, int64_t S, float* plane_dx_sums, void* stream);
+/* r05: GroupNorm statistics from partials left by the pass that WROTE the tensor.  segx_interp_linear_fwd_axis2_gn = segx_interp_linear_fwd_axis2 that also
+ * reduces what it writes to (count, mean, M2) partials per run of a (sample, group): parts [outer / cpg][nparts] float4, nparts =
+ * segx_interp_gn_nparts(n1_out * n2_out * inner / 4, cpg) (0 = shape not served: float4 per plane not a multiple of 256); segx_groupnorm_fwd_parts merges
+ * them (Chan) and applies the normalisation.  Replaces the statistics pass of nn.GroupNorm over the up-sampled pyramid levels (segtran3d.py:338-360). */
+int64_t segx_interp_gn_nparts(int64_t float4_per_plane, int cpg);
+int segx_interp_linear_fwd_axis2_gn(const float* in, const float* base, float* out, int64_t outer, int n1_in, int n1_out, int n2_in, int n2_out,
+                                    int64_t inner, int cpg, float* parts, int nparts, void* stream);
+int segx_groupnorm_fwd_parts(const float* X, const float* parts, int nparts, const float* w, const float* b, float* Y, float* mean, float* rstd,
+                             int B, int C, int G, int64_t S, float eps, void* stream);
 /* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);
  * out = interp(in) (+ base, the FPN lateral, when base != NULL).  bwd is the exact adjoint, computed as a gather. */
 /* PolyformerLayer glue (networks/polyformer.py:36-55): nn.AvgPool2d(2) on [planes, H, W] (+ adjoint) and the batched transpose
@@ -328,7 +340,9 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * channel-resident where a channel fits one workgroup, else a TEAM of workgroups per channel (one launch, the slabs stay in registers across a team barrier),
  * else two launches; 1 = never teams; 2 = teams for every shape with S % 4 == 0 (tests).  Same results to fp32 summation order;
  * knob 12 = poll bound of a team exchange (default 2^20 polls, ~1 s; 32 .. 2^24); knob 13 = FAULT INJECTION for the tests of the team form's failure
- * path: the last `value` workgroups of every team launch are not launched, so their team mates time out (0 = off, the default). */
+ * path: the last `value` workgroups of every team launch are not launched, so their team mates time out (0 = off, the default);
+ * knob 14 = slab-in-LDS form of the stride-1 3 x 3 x 3 'same' max-pools: 0 (default) where the four-cells-per-thread form does not apply (row length not a
+ * multiple of 4), 1 wherever a slab fits the LDS, 2 never.  Identical results. */
 int segx_tune(int knob, int value);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
  * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)

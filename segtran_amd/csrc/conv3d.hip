@@ -894,6 +894,104 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1k3_kernel(const float* __
     }
 }
 
+// r05: stride-1 3 x 3 x 3 'same' pools (the Inception branch pools: 10 of the 12 pools of a step) with a SLAB of the plane in LDS.  A workgroup owns
+// TD output slices of one (sample, channel) plane and stages the TD + 2 input slices under them (forward: x; backward: the window gradients and
+// arg-max indices) with whole-line float4 loads -- the plane is contiguous, so the copy is a linear one whatever the row length (rows of 14 or 7
+// floats defeat the four-outputs-per-thread forms above: r04_w measured 1.08 TB/s for the tile-with-halo gather and 2.5 TB/s for the per-output
+// scan on the 24 x 14 x 14 planes of cfg4).  The 27 taps / probes then run against LDS with consecutive lanes on consecutive cells.  Halo
+// re-reads: (TD + 2) / TD of ONE of the three streams (the neighbouring slab's lines are in the XCD's L2 when its workgroup runs beside this one).
+// Same scan order, "first maximum wins" rule, zero padding and (od, oh, ow) accumulation order as the kernels above: identical results.
+// CAP = floats of LDS per staged array (2048: planes of <= 2048 floats, one slab; 8192: everything else)
+template <int CAP>
+__global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg, PoolGeom q,
+                                                                 int TD, int nslab, FastDiv dHW, FastDiv dW) {
+    __shared__ __attribute__((aligned(16))) float sx[CAP];
+    const int64_t p = blockIdx.x / nslab;
+    const int slab = blockIdx.x - (int)p * nslab;
+    const int hw = q.IH * q.IW, isz = q.ID * hw;
+    const int d0 = slab * TD, d1 = min(d0 + TD, q.ID);               // output slices [d0, d1)
+    const int s0 = max(d0 - 1, 0), s1 = min(d1 + 1, q.ID);           // staged input slices [s0, s1)
+    const int base = s0 * hw, n = (s1 - s0) * hw;
+    const float* x = X + p * isz + base;
+    if ((((int64_t)p * isz + base) & 3) == 0) {                      // 16-byte aligned start (the tensor base is: host check)
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(sx)[i] = reinterpret_cast<const float4*>(x)[i];
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) sx[i] = x[i];
+    } else for (int i = threadIdx.x; i < n; i += 256) sx[i] = x[i];
+    __syncthreads();
+    const int cells = (d1 - d0) * hw;
+    for (int c = threadIdx.x; c < cells; c += 256) {
+        const int zd = fdiv(c, dHW), r2 = c - zd * hw, oh = fdiv(r2, dW), ow = r2 - oh * q.IW, od = d0 + zd;
+        float best = -INFINITY; int bi = -1;
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const int id = od - 1 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int ih = oh - 1 + kh; const bool okh = okd && (unsigned)ih < (unsigned)q.IH;
+                const int rowbase = (id * q.IH + ih) * q.IW;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int iw = ow - 1 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
+                    const int li = rowbase + iw;
+                    const float v = in ? sx[li - base] : 0.f;            // zero padding
+                    if (v > best || v != v) { best = v; bi = in ? li : -1; }
+                }
+            }
+        }
+        const int64_t o = p * isz + (int64_t)d0 * hw + c;
+        Y[o] = best; arg[o] = bi;
+    }
+}
+template <int CAP>
+__global__ __launch_bounds__(256) void maxpool3d_bwd_slab_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX, PoolGeom q,
+                                                                 int TD, int nslab, FastDiv dHW, FastDiv dW) {
+    __shared__ __attribute__((aligned(16))) float sg[CAP];
+    __shared__ __attribute__((aligned(16))) int sa[CAP];
+    const int64_t p = blockIdx.x / nslab;
+    const int slab = blockIdx.x - (int)p * nslab;
+    const int hw = q.IH * q.IW, isz = q.ID * hw;
+    const int d0 = slab * TD, d1 = min(d0 + TD, q.ID);               // input slices [d0, d1) of this workgroup
+    const int s0 = max(d0 - 1, 0), s1 = min(d1 + 1, q.ID);           // window slices that can cover them
+    const int base = s0 * hw, n = (s1 - s0) * hw;
+    const float* g = dY + p * isz + base; const int* a = arg + p * isz + base;
+    if ((((int64_t)p * isz + base) & 3) == 0) {
+        const int n4 = n >> 2;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            reinterpret_cast<float4*>(sg)[i] = reinterpret_cast<const float4*>(g)[i];
+            reinterpret_cast<int4*>(sa)[i] = reinterpret_cast<const int4*>(a)[i];
+        }
+        for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { sg[i] = g[i]; sa[i] = a[i]; }
+    } else for (int i = threadIdx.x; i < n; i += 256) { sg[i] = g[i]; sa[i] = a[i]; }
+    __syncthreads();
+    const int cells = (d1 - d0) * hw;
+    for (int c = threadIdx.x; c < cells; c += 256) {
+        const int zd = fdiv(c, dHW), r2 = c - zd * hw, ih = fdiv(r2, dW), iw = r2 - ih * q.IW, id = d0 + zd;
+        const int li = d0 * hw + c;
+        float acc = 0.f;
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+            const int od = id - 1 + z; const bool okd = (unsigned)od < (unsigned)q.ID;
+#pragma unroll
+            for (int y = 0; y < 3; ++y) {
+                const int oh = ih - 1 + y; const bool okh = okd && (unsigned)oh < (unsigned)q.IH;
+                const int rowo = (od * q.IH + oh) * q.IW - base;
+#pragma unroll
+                for (int xx = 0; xx < 3; ++xx) {
+                    const int ow = iw - 1 + xx;
+                    if (okh && (unsigned)ow < (unsigned)q.IW && sa[rowo + ow] == li) acc += sg[rowo + ow];
+                }
+            }
+        }
+        dX[p * isz + li] = acc;
+    }
+}
+// slices per slab for the slab pools: the largest TD with (TD + 2) slices <= cap floats, 0 = a slice does not fit
+static int pool_slab_td(const PoolGeom& q, int cap) { const int fit = cap / (q.IH * q.IW); return fit >= q.ID ? q.ID : fit >= 3 ? fit - 2 : 0; }
+static bool pool_is_s1k3_same(const PoolGeom& q) {
+    return q.KD == 3 && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pd == 1 && q.ph == 1 && q.pw == 1 && q.OD == q.ID && q.OH == q.IH && q.OW == q.IW;
+}
+
 static bool aligned16c(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool conv_small(int Cout) { return kget(knobs().conv_small_policy) == 1 ? Cout <= 64 : (Cout % 128 >= 1 && Cout % 128 <= 64); }
 
@@ -1092,6 +1190,18 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
     const FastDiv dOHW = make_fastdiv(q.OH * q.OW), dOW = make_fastdiv(q.OW);
     const bool s1w4 = q.sd == 1 && q.sh == 1 && q.sw == 1 && q.KH == 3 && q.KW == 3 && q.pw == 1 && q.OW == q.IW && q.OW % 4 == 0 && q.OW >= 4 &&
                       (int64_t)q.ID * q.IH * q.IW % 4 == 0 && osz % 4 == 0 && aligned16c(X) && aligned16c(Y) && aligned16c(arg);
+    // slab-in-LDS form (knob 14: 0 = where the four-outputs-per-thread form does not apply, 1 = wherever it fits, 2 = never)
+    const int slab_policy = kget(knobs().pool_slab);
+    if (pool_is_s1k3_same(q) && slab_policy != 2 && (slab_policy == 1 || !s1w4) && aligned16c(X)) {
+        const int isz = q.ID * q.IH * q.IW, cap = isz <= 2048 ? 2048 : 8192, td = pool_slab_td(q, cap);
+        if (td > 0 && planes * ceil_div(q.ID, td) < 2147483647LL) {
+            const int nslab = ceil_div(q.ID, td);
+            const dim3 sgrid((unsigned)(planes * nslab));
+            if (cap == 2048) hipLaunchKernelGGL((maxpool3d_fwd_slab_kernel<2048>), sgrid, dim3(256), 0, stream, X, Y, arg, q, td, nslab, make_fastdiv(q.IH * q.IW), make_fastdiv(q.IW));
+            else hipLaunchKernelGGL((maxpool3d_fwd_slab_kernel<8192>), sgrid, dim3(256), 0, stream, X, Y, arg, q, td, nslab, make_fastdiv(q.IH * q.IW), make_fastdiv(q.IW));
+            return check_launch("segx_maxpool3d_fwd/slab");
+        }
+    }
     if (s1w4 && (q.KD == 3 || q.KD == 1)) {
         const int ow4 = q.OW / 4;
         const dim3 grid4((unsigned)i64min(4096, (osz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
@@ -1108,8 +1218,20 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.ID * q.IH * q.IW;
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
-    if ((q.KD == 3 || q.KD == 1) && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pw == 1 && q.OW == q.IW && q.OH == q.IH && q.IW % 4 == 0 &&
-        q.IW >= 4 && (int64_t)q.ID * q.IH * q.IW % 4 == 0 && (int64_t)q.OD * q.OH * q.OW % 4 == 0 && aligned16c(dX) && aligned16c(dY) && aligned16c(arg)) {
+    const bool bs1w4 = (q.KD == 3 || q.KD == 1) && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pw == 1 && q.OW == q.IW && q.OH == q.IH && q.IW % 4 == 0 &&
+        q.IW >= 4 && (int64_t)q.ID * q.IH * q.IW % 4 == 0 && (int64_t)q.OD * q.OH * q.OW % 4 == 0 && aligned16c(dX) && aligned16c(dY) && aligned16c(arg);
+    const int slab_policy = kget(knobs().pool_slab);
+    if (pool_is_s1k3_same(q) && slab_policy != 2 && (slab_policy == 1 || !bs1w4) && aligned16c(dY) && aligned16c(arg)) {
+        const int isz = q.ID * q.IH * q.IW, cap = isz <= 2048 ? 2048 : 8192, td = pool_slab_td(q, cap);
+        if (td > 0 && planes * ceil_div(q.ID, td) < 2147483647LL) {
+            const int nslab = ceil_div(q.ID, td);
+            const dim3 sgrid((unsigned)(planes * nslab));
+            if (cap == 2048) hipLaunchKernelGGL((maxpool3d_bwd_slab_kernel<2048>), sgrid, dim3(256), 0, stream, dY, arg, dX, q, td, nslab, make_fastdiv(q.IH * q.IW), make_fastdiv(q.IW));
+            else hipLaunchKernelGGL((maxpool3d_bwd_slab_kernel<8192>), sgrid, dim3(256), 0, stream, dY, arg, dX, q, td, nslab, make_fastdiv(q.IH * q.IW), make_fastdiv(q.IW));
+            return check_launch("segx_maxpool3d_bwd/slab");
+        }
+    }
+    if (bs1w4) {
         const int iw4 = q.IW / 4; const int64_t isz4 = (int64_t)q.ID * q.IH * iw4;
         const dim3 grid4((unsigned)i64min(4096, (isz4 + 255) / 256), (unsigned)i64min(65535, planes));
         if (q.KD == 3) hipLaunchKernelGGL((maxpool3d_bwd_s1w4_kernel<3>), grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));

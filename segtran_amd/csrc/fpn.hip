@@ -49,31 +49,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const float* x = X + (int64_t)bc * S; float* y = Y + (int64_t)bc * S;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) y[s] = x[s] * sc + sh;
 }
-// per plane (b,c): psum[bc] = (sum dy, sum dy * xhat)
+// per plane (b,c): psum[3 bc ..] = (sum dy, sum dy * xhat, sum xhat)
 __global__ __launch_bounds__(256) void gn_bwd_plane_sums(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ psum, int C, int G, int64_t S) {
     __shared__ float red[4];
     const int bc = blockIdx.x, c = bc % C, bg = (bc / C) * G + c / (C / G);
     const float m = mean[bg], r = rstd[bg];
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S;
-    float a = 0.f, q = 0.f;
-    for (int64_t s = threadIdx.x; s < S; s += 256) { const float gv = g[s]; a += gv; q += gv * ((x[s] - m) * r); }
-    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
-    if (threadIdx.x == 0) { psum[2 * bc] = a; psum[2 * bc + 1] = q; }
+    float a = 0.f, q = 0.f, h = 0.f;
+    for (int64_t s = threadIdx.x; s < S; s += 256) { const float gv = g[s], xh = (x[s] - m) * r; a += gv; q += gv * xh; h += xh; }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red); h = block_sum<4>(h, red);
+    if (threadIdx.x == 0) { psum[3 * bc] = a; psum[3 * bc + 1] = q; psum[3 * bc + 2] = h; }
 }
-// tiny: group sums gsum[bg] = (sum_c w_c * psum0, sum_c w_c * psum1) ; dw[c] = sum_b psum1 ; db[c] = sum_b psum0
-__global__ __launch_bounds__(256) void gn_bwd_finalize(const float* __restrict__ psum, const float* __restrict__ w, float* __restrict__ gsum,
-                                                       float* __restrict__ dw, float* __restrict__ db, int B, int C, int G) {
+// tiny: group sums gsum[bg] = (sum_c w_c * psum0, sum_c w_c * psum1) ; dw[c] = sum_b psum1 ; db[c] = sum_b psum0 ; and (r05) the per-plane sums of the
+// input gradient the apply pass is about to write, in closed form:  sum_s dx[b,c,s] = rstd * (w_c * psum0 - S * k1 - k2 * psum2)  (k1, k2 as in gn_bwd_apply).
+// They are the bias gradient of the pointwise convolution that produced the normalised tensor (segtran3d.py:336-360: conv -> up + add -> GroupNorm): a
+// row-sum pass over a 2 - 3.5 GB tensor that need not run (rowsum_kernel: 0.63 / 1.1 ms of the cfg4 / cfg5 step).
+__global__ __launch_bounds__(256) void gn_bwd_finalize(const float* __restrict__ psum, const float* __restrict__ w, const float* __restrict__ rstd,
+                                                       float* __restrict__ gsum, float* __restrict__ dw, float* __restrict__ db, float* __restrict__ rsum,
+                                                       int B, int C, int G, float S) {
     const int t = blockIdx.x * 256 + threadIdx.x, cpg = C / G;
-    if (t < B * G) {
-        const int b = t / G, g = t % G;
+    if (t < B * C) {                                          // every plane's thread forms its group's two sums (cpg terms: redundant, but there is no exchange)
+        const int b = t / C, c = t - b * C, g = c / cpg, bg = b * G + g;
         float a = 0.f, q = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += w[c] * psum[2 * (b * C + c)]; q += w[c] * psum[2 * (b * C + c) + 1]; }
-        gsum[2 * t] = a; gsum[2 * t + 1] = q;
+        for (int cc = g * cpg; cc < (g + 1) * cpg; ++cc) { a += w[cc] * psum[3 * (b * C + cc)]; q += w[cc] * psum[3 * (b * C + cc) + 1]; }
+        if (c == g * cpg) { gsum[2 * bg] = a; gsum[2 * bg + 1] = q; }
+        if (rsum) {
+            const float inv_n = 1.0f / ((float)cpg * S), k1 = a * inv_n, k2 = q * inv_n;
+            rsum[t] = rstd[bg] * (w[c] * psum[3 * t] - S * k1 - k2 * psum[3 * t + 2]);
+        }
     }
     if (t < C) {
         float a = 0.f, q = 0.f;
-        for (int b = 0; b < B; ++b) { a += psum[2 * (b * C + t)]; q += psum[2 * (b * C + t) + 1]; }
+        for (int b = 0; b < B; ++b) { a += psum[3 * (b * C + t)]; q += psum[3 * (b * C + t) + 1]; }
         db[t] = a; dw[t] = q;
     }
 }
@@ -87,6 +95,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply(const float* __restrict__ dY
     const float* x = X + (int64_t)bc * S; const float* g = dY + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
     for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256)
         d[s] = r * (g[s] * wc - k1 - (x[s] - m) * r * k2);
+}
+
+// r05: GroupNorm statistics from PARTIALS written by the pass that produced the tensor (interp_fwd_axis2_stats_kernel below): parts[bg][P] float4 =
+// (count, mean, M2, -) of consecutive runs of the group's elements, merged with Chan's formula -- one wave per (sample, group): lane l folds
+// partials l, l + 64, ... in order, then a symmetric butterfly (the same bits in every lane and every run).
+struct GnPart { float n, mean, m2; };
+__device__ __forceinline__ GnPart gn_merge(const GnPart& a, const GnPart& b) {
+    const float n = a.n + b.n;
+    if (!(n > 0.f)) return GnPart{0.f, 0.f, 0.f};
+    const float d = b.mean - a.mean, f = b.n / n;
+    return GnPart{n, a.mean + d * f, a.m2 + b.m2 + d * d * a.n * f};
+}
+__global__ __launch_bounds__(256) void gn_stats_from_parts(const float* __restrict__ parts, int P, float* __restrict__ mean, float* __restrict__ rstd, int BG, float eps) {
+    const int bg = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (bg >= BG) return;
+    const float4* p = reinterpret_cast<const float4*>(parts) + (int64_t)bg * P;
+    GnPart s{0.f, 0.f, 0.f};
+    for (int i = lane; i < P; i += 64) { const float4 v = p[i]; s = gn_merge(s, GnPart{v.x, v.y, v.z}); }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        GnPart t{__shfl_xor(s.n, o), __shfl_xor(s.mean, o), __shfl_xor(s.m2, o)};
+        s = (lane & o) ? gn_merge(t, s) : gn_merge(s, t);          // the lower lane's partial first on both sides: identical operands, identical result
+    }
+    if (lane == 0) { mean[bg] = s.mean; rstd[bg] = rsqrtf(fmaxf(s.m2 / fmaxf(s.n, 1.f), 0.f) + eps); }
 }
 
 // =================================================================================================
@@ -288,6 +320,53 @@ __global__ __launch_bounds__(256) void interp_fwd_axis2_kernel(const float* __re
         reinterpret_cast<float4*>(out)[ob] = rr;
     }
 }
+// r05: the same pass, also leaving GroupNorm partials of what it writes.  A (sample, group) is a run of cpg planes = cpg * per float4; a workgroup owns CH
+// consecutive 256-float4 chunks of ONE run (grid (P, B * G), P * CH >= chunks of a run) and reduces them around a pivot (its first value) to one
+// (count, mean, M2) partial: the separate statistics pass over the 2 - 3.5 GB pyramid tensors (gn_stats_stage1: 0.6 / 1.0 ms of the cfg4 / cfg5 step) is gone.
+// Needs per % 256 == 0 (host check): a chunk never straddles two planes' worth of index arithmetic beyond what the plain kernel does.
+__global__ __launch_bounds__(256) void interp_fwd_axis2_stats_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                                     int n1_in, int n1_out, int n2_in, int n2_out, int inner4, FastDiv divInner, FastDiv divRow,
+                                                                     FastDiv divPer, float s1, float s2, int cpg, int CH, float* __restrict__ parts) {
+    __shared__ float red[4];
+    __shared__ float piv;
+    const int row = n2_out * inner4, per = n1_out * row;
+    const int64_t in_per = (int64_t)n1_in * n2_in * inner4;
+    const int bg = blockIdx.y, P = gridDim.x;
+    const int run_chunks = cpg * (per >> 8);                          // 256-float4 chunks of this (sample, group)
+    const int ch0 = blockIdx.x * CH, ch1 = min(ch0 + CH, run_chunks);
+    float a = 0.f, q = 0.f, pivot = 0.f;
+    for (int ch = ch0; ch < ch1; ++ch) {
+        const int e_run = (ch << 8) + threadIdx.x;                    // float4 index inside the run
+        const int pl = fdiv(e_run, divPer), e = e_run - pl * per;
+        const int64_t o = (int64_t)bg * cpg + pl;
+        const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
+        const Axis a1 = axis_src(i1, n1_in, s1), a2 = axis_src(i2, n2_in, s2);
+        const float4* s = reinterpret_cast<const float4*>(in) + o * in_per + c;
+        const float4 v00 = s[((int64_t)a1.i0 * n2_in + a2.i0) * inner4], v01 = s[((int64_t)a1.i0 * n2_in + a2.i1) * inner4];
+        const float4 v10 = s[((int64_t)a1.i1 * n2_in + a2.i0) * inner4], v11 = s[((int64_t)a1.i1 * n2_in + a2.i1) * inner4];
+        const float l1 = a1.l, l2 = a2.l;
+        float4 rr;
+        rr.x = (v00.x * (1.f - l2) + v01.x * l2) * (1.f - l1) + (v10.x * (1.f - l2) + v11.x * l2) * l1;
+        rr.y = (v00.y * (1.f - l2) + v01.y * l2) * (1.f - l1) + (v10.y * (1.f - l2) + v11.y * l2) * l1;
+        rr.z = (v00.z * (1.f - l2) + v01.z * l2) * (1.f - l1) + (v10.z * (1.f - l2) + v11.z * l2) * l1;
+        rr.w = (v00.w * (1.f - l2) + v01.w * l2) * (1.f - l1) + (v10.w * (1.f - l2) + v11.w * l2) * l1;
+        const int64_t ob = o * per + e;
+        if (base) { const float4 bv = reinterpret_cast<const float4*>(base)[ob]; rr.x += bv.x; rr.y += bv.y; rr.z += bv.z; rr.w += bv.w; }
+        reinterpret_cast<float4*>(out)[ob] = rr;
+        if (ch == ch0) {                                              // the pivot: this workgroup's first value (close to everything it will see)
+            if (threadIdx.x == 0) piv = rr.x;
+            __syncthreads();
+            pivot = piv;
+        }
+        const float d0 = rr.x - pivot, d1 = rr.y - pivot, d2 = rr.z - pivot, d3 = rr.w - pivot;
+        a += (d0 + d1) + (d2 + d3); q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    a = block_sum<4>(a, red); q = block_sum<4>(q, red);
+    if (threadIdx.x == 0) {
+        const float n = 1024.0f * (float)(ch1 > ch0 ? ch1 - ch0 : 0);
+        reinterpret_cast<float4*>(parts)[(int64_t)bg * P + blockIdx.x] = n > 0.f ? make_float4(n, pivot + a / n, fmaxf(q - a * a / n, 0.f), 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 // adjoint of the pass above: din[o][i1][i2] = sum_{d2} w2(d2) * (sum_{d1} w1(d1) * dout[o][d1][d2]) -- axis 1 (the outer one) innermost, as the one-axis
 // passes run (outermost axis first).  Only candidates with a non-zero weight are loaded (cand_range is conservative: 8 per axis for 4 contributors).
 __global__ __launch_bounds__(256) void interp_bwd_axis2_kernel(const float* __restrict__ dout, float* __restrict__ din, int n1_out, int n1_in, int n2_out,
@@ -354,7 +433,7 @@ static inline int fpn_chunks(int64_t S, int per_thread) { return (int)i64max(1, 
 using namespace segx;
 #define SEGX_STREAM hipStream_t stream = (hipStream_t)stream_
 
-extern "C" int64_t segx_gn_ws_floats(int B, int C, int G) { return (int64_t)B * G * GN_SLABS * 2 + (int64_t)2 * B * C + (int64_t)2 * B * G; }
+extern "C" int64_t segx_gn_ws_floats(int B, int C, int G) { return (int64_t)B * G * GN_SLABS * 2 + (int64_t)3 * B * C + (int64_t)2 * B * G; }
 extern "C" int segx_groupnorm_fwd(const float* X, const float* w, const float* b, float* Y, float* mean, float* rstd, float* ws,
                                   int B, int C, int G, int64_t S, float eps, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && w && b && Y && mean && rstd && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_groupnorm_fwd: bad args");
@@ -365,14 +444,23 @@ extern "C" int segx_groupnorm_fwd(const float* X, const float* w, const float* b
     hipLaunchKernelGGL(gn_apply_kernel, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, X, (const float*)mean, (const float*)rstd, w, b, Y, C, G, S);
     return check_launch("segx_groupnorm_fwd");
 }
+/* GroupNorm whose statistics come from partials left by the pass that wrote X (segx_interp_linear_fwd_axis2 with parts): parts [B * G][nparts] float4 */
+extern "C" int segx_groupnorm_fwd_parts(const float* X, const float* parts, int nparts, const float* w, const float* b, float* Y, float* mean, float* rstd,
+                                        int B, int C, int G, int64_t S, float eps, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && parts && nparts > 0 && w && b && Y && mean && rstd && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_groupnorm_fwd_parts: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_groupnorm_fwd_parts: more than 65535 planes / unaligned partials");
+    hipLaunchKernelGGL(gn_stats_from_parts, dim3((B * G + 3) / 4), dim3(256), 0, stream, parts, nparts, mean, rstd, B * G, eps);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, X, (const float*)mean, (const float*)rstd, w, b, Y, C, G, S);
+    return check_launch("segx_groupnorm_fwd_parts");
+}
+/* plane_dx_sums (may be NULL): [B * C] floats = sum over the plane of the dX this call writes (closed form from the plane sums: no extra pass) */
 extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX, float* dw,
-                                  float* db, float* ws, int B, int C, int G, int64_t S, void* stream_) {
+                                  float* db, float* ws, int B, int C, int G, int64_t S, float* plane_dx_sums, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && X && w && mean && rstd && dX && dw && db && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_groupnorm_bwd: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_groupnorm_bwd: more than 65535 planes");
-    float* psum = ws + (int64_t)B * G * GN_SLABS * 2; float* gsum = psum + (int64_t)2 * B * C;
+    float* psum = ws + (int64_t)B * G * GN_SLABS * 2; float* gsum = psum + (int64_t)3 * B * C;
     hipLaunchKernelGGL(gn_bwd_plane_sums, dim3(B * C), dim3(256), 0, stream, dY, X, mean, rstd, psum, C, G, S);
-    const int n = B * G > C ? B * G : C;
-    hipLaunchKernelGGL(gn_bwd_finalize, dim3((n + 255) / 256), dim3(256), 0, stream, (const float*)psum, w, gsum, dw, db, B, C, G);
+    hipLaunchKernelGGL(gn_bwd_finalize, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)psum, w, rstd, gsum, dw, db, plane_dx_sums, B, C, G, (float)S);
     hipLaunchKernelGGL(gn_bwd_apply, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, dY, X, mean, rstd, w, (const float*)gsum, dX, C, G, S);
     return check_launch("segx_groupnorm_bwd");
 }
@@ -444,6 +532,7 @@ extern "C" int segx_tune(int knob, int value) {
 #endif
     if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
     if (knob == 5) { return k.x6_launches.exchange(0); }
+    if (knob == 14) { if (value < 0 || value > 2) return -1; k.pool_slab = value; return 0; }
     if (knob == 12) { if (value < 32 || value > (1 << 24)) return -1; k.team_spin = value; return 0; }     // poll bound of a team exchange
     if (knob == 13) { if (value < 0 || value > 4096) return -1; k.team_drop = value; return 0; }          // fault injection (tests): unlaunched tail of a team grid
     return -1;
@@ -514,6 +603,27 @@ extern "C" int segx_interp_linear_fwd_axis2(const float* in, const float* base, 
                        n2_out, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_out * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
                        (float)n2_in / (float)n2_out, outer);
     return check_launch("segx_interp_linear_fwd_axis2");
+}
+/* r05: the same pass leaving GroupNorm partials of its output (cpg = channels per group; outer = B * C planes, planes of a group adjacent):
+ * parts [outer / cpg][nparts] float4 with nparts = segx_interp_gn_nparts(n1_out * n2_out * inner / 4, cpg) (0: this shape keeps the separate statistics pass) */
+static inline int interp_gn_ch(int64_t per4, int cpg) { const int64_t rc = (int64_t)cpg * (per4 >> 8); return (int)((rc + 255) / 256); }       // chunks per workgroup: <= 256 partials per group
+extern "C" int64_t segx_interp_gn_nparts(int64_t per4, int cpg) {
+    if (per4 <= 0 || cpg <= 0 || (per4 & 255) != 0 || (int64_t)cpg * per4 >= 2147483647LL - 256) return 0;
+    const int64_t rc = (int64_t)cpg * (per4 >> 8); const int ch = interp_gn_ch(per4, cpg);
+    return (rc + ch - 1) / ch;
+}
+extern "C" int segx_interp_linear_fwd_axis2_gn(const float* in, const float* base, float* out, int64_t outer, int n1_in, int n1_out, int n2_in, int n2_out,
+                                               int64_t inner, int cpg, float* parts, int nparts, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(in && out && parts && outer > 0 && n1_in > 0 && n1_out > 0 && n2_in > 0 && n2_out > 0 && inner > 0 && inner % 4 == 0 && cpg > 0 && outer % cpg == 0,
+                              "segx_interp_linear_fwd_axis2_gn: bad args");
+    SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base) | reinterpret_cast<uintptr_t>(parts)) & 15) == 0, "segx_interp_linear_fwd_axis2_gn: alignment");
+    const int64_t in4 = inner / 4, per = (int64_t)n1_out * n2_out * in4;
+    SEGX_REQUIRE((int64_t)n1_in * n2_in * in4 < 2147483647LL && outer / cpg <= 65535, "segx_interp_linear_fwd_axis2_gn: slice too large");
+    SEGX_REQUIRE(nparts > 0 && nparts == segx_interp_gn_nparts(per, cpg), "segx_interp_linear_fwd_axis2_gn: nparts %d is not segx_interp_gn_nparts(%lld, %d)", nparts, (long long)per, cpg);
+    hipLaunchKernelGGL(interp_fwd_axis2_stats_kernel, dim3((unsigned)nparts, (unsigned)(outer / cpg)), dim3(256), 0, stream, in, base, out, n1_in, n1_out, n2_in,
+                       n2_out, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_out * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
+                       (float)n2_in / (float)n2_out, cpg, interp_gn_ch(per, cpg), parts);
+    return check_launch("segx_interp_linear_fwd_axis2_gn");
 }
 extern "C" int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64_t outer, int n1_out, int n1_in, int n2_out, int n2_in, int64_t inner, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dout && din && outer > 0 && n1_in > 0 && n1_out > 0 && n2_in > 0 && n2_out > 0 && inner > 0 && inner % 4 == 0, "segx_interp_linear_bwd_axis2: bad args");

@@ -211,8 +211,10 @@ def _bias_grad(L, dC, s):
     # BIAS_M (conv-style, one bias per output row m): row sums, batch-summed
     assert s.bias_b1 == 0
     nbt = nb0 * nb1
-    rs = _empty(dC, nbt * s.M)
-    L.rowsum(dC, rs, nbt * s.M, s.N)
+    rs = getattr(dC, '_segx_plane_sums', None)         # left by _UpGN.backward on the gradient it hands to the lateral: the plane sums in closed form
+    if rs is None or rs.numel() != nbt * s.M or rs.device != dC.device:
+        rs = _empty(dC, nbt * s.M)
+        L.rowsum(dC, rs, nbt * s.M, s.N)
     if nbt == 1:
         return rs
     out = _empty(dC, s.M)
@@ -1001,13 +1003,7 @@ class _InterpAdd(torch.autograd.Function):
         dy = _c(dy)
         dx = None
         if ctx.needs_input_grad[0] and d != D and h != H and not ctx.align and W % 4 == 0:
-            cur = _empty(dy, planes * d * h * W)               # z and y adjoints in one pass, then x (13 instead of 21 coarse-tensor sizes)
-            L.interp_bwd_axis2(dy, cur, planes, D, d, H, h, W)
-            if w != W:
-                nxt = _empty(dy, planes * d * h * w)
-                L.interp_bwd_axis(cur, nxt, planes * d * h, W, w, 1, 0.0)
-                cur = nxt
-            dx = cur.view(xshape)
+            dx = _interp_bwd_yz_x(L, dy, planes, d, h, w, D, H, W).view(xshape)      # z and y adjoints in one pass, then x
         if ctx.needs_input_grad[0] and dx is None:
             # separable adjoint, one pass per resized axis, OUTERMOST axis first: the passes over the big tensors then have a long
             # contiguous inner extent (float4 kernel); the scalar innermost-axis pass runs last, on the smallest tensor
@@ -1026,6 +1022,81 @@ class _InterpAdd(torch.autograd.Function):
                 cur, dims[ax] = nxt, n_in
             dx = cur.view(xshape) if cur is not dy else dy.clone().view(xshape)
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None
+
+
+class _UpGN(torch.autograd.Function):
+    """group_norm(interp_linear(x, size, base)) of a pyramid level (segtran3d.py:336-360: `out_gnNb(out_fpnMN_conv3d(cur) + up(feat))`) as ONE node:
+    the y/z resampling pass that writes the level also leaves GroupNorm partials of it (segx_interp_linear_fwd_axis2_gn), so the statistics pass
+    over the 2 - 3.5 GB tensor is gone; the backward's plane sums give the per-plane sums of the gradient it returns for `base` in closed form
+    (segx_groupnorm_bwd plane_dx_sums), which the lateral convolution's bias gradient picks up (_bias_grad) instead of a row-sum pass.  Same blends in
+    the same order as the unfused ops; the statistics differ by fp32 summation order only (Chan merge of per-workgroup partials)."""
+
+    @staticmethod
+    def forward(ctx, x, base, w, b, size, G, eps, nparts):
+        L = segx.lib()
+        x, base = _c(x), _c(base)
+        B, C = x.shape[:2]
+        d, h, wd = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        cur = x
+        if wd != W:
+            cur = _empty(x, B * C * d * h * W)
+            L.interp_fwd_axis(x, None, cur, B * C * d * h, wd, W, 1, 0.0)
+        pre = _empty(x, B, C, *size)
+        parts = _empty(x, B * G * nparts * 4)
+        L.interp_fwd_axis2_gn(cur, base, pre, B * C, d, D, h, H, W, C // G, parts, nparts)
+        S = D * H * W
+        y = torch.empty_like(pre)
+        mean, rstd = _empty(x, B * G), _empty(x, B * G)
+        L.groupnorm_fwd_parts(pre, parts, nparts, w, b, y, mean, rstd, B, C, G, S, eps)
+        ctx.cfg = (B, C, G, S, d, h, wd, D, H, W, tuple(x.shape))
+        ctx.save_for_backward(pre, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        pre, w, mean, rstd = ctx.saved_tensors
+        B, C, G, S, d, h, wd, D, H, W, xshape = ctx.cfg
+        dpre = torch.empty_like(pre)
+        dw, db = _empty(pre, C), _empty(pre, C)
+        rsum = _empty(pre, B * C)
+        L.groupnorm_bwd(_c(dy), pre, w, mean, rstd, dpre, dw, db, _empty(pre, L.gn_ws(B, C, G)), B, C, G, S, rsum)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _interp_bwd_yz_x(L, dpre, B * C, d, h, wd, D, H, W).view(xshape)
+        dbase = None
+        if ctx.needs_input_grad[1]:
+            dbase = dpre
+            dbase._segx_plane_sums = rsum                    # sum over every (sample, channel) plane of dbase: the lateral convolution's bias gradient (_bias_grad)
+        return dx, dbase, dw, db, None, None, None, None
+
+
+def _interp_bwd_yz_x(L, dy, planes, d, h, w, D, H, W):
+    """adjoint of the x pass + fused y/z pass: z and y in one pass, then x (13 instead of 21 coarse-tensor sizes)"""
+    cur = _empty(dy, planes * d * h * W)
+    L.interp_bwd_axis2(dy, cur, planes, D, d, H, h, W)
+    if w != W:
+        nxt = _empty(dy, planes * d * h * w)
+        L.interp_bwd_axis(cur, nxt, planes * d * h, W, w, 1, 0.0)
+        cur = nxt
+    return cur
+
+
+def up_group_norm(x, size, base, gn):
+    """gn(F.interpolate(x, size, mode='trilinear') + base): the fused node where the level is up-sampled along both outer axes, W % 4 == 0 and the plane
+    splits into whole 1024-float chunks; the two plain ops otherwise (2-D maps, odd sizes)."""
+    size = tuple(int(s) for s in size)
+    G = int(gn.num_groups)
+    if base is not None and x.dim() == 5:
+        d, h, _ = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        C = x.shape[1]
+        if d != D and h != H and W % 4 == 0 and C % G == 0 and tuple(base.shape) == (x.shape[0], C) + size:
+            nparts = segx.lib().interp_gn_nparts(D * H * (W // 4), C // G)
+            if nparts > 0:
+                return _UpGN.apply(x, base, gn.weight, gn.bias, size, G, float(gn.eps), nparts)
+    return group_norm(interp_linear(x, size, base), gn)
 
 
 def interp_linear(x, size, base=None, align_corners=False):

@@ -157,8 +157,10 @@ class Segtran3d(SegtranInitWeights):
 
     def in_fpn_forward(self, feats, nonzero_mask):
         f3, f4 = feats[3], feats[4]
-        cur = _up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3))
-        cur = SF.bn_act(cur, self.in_bn4b) if self.in_fpn_use_bn else SF.group_norm(cur, self.in_gn4b)
+        if self.in_fpn_use_bn:
+            cur = SF.bn_act(_up(f4, f3.shape[2:], base=self.in_fpn34_conv(f3)), self.in_bn4b)
+        else:
+            cur = SF.up_group_norm(f4, f3.shape[2:], self.in_fpn34_conv(f3), self.in_gn4b)
         cur = self.in_fpn_bridgeconv(cur)
         dp = [cur.shape[2] // self.D_pool_K, cur.shape[3], cur.shape[4]]
         cur = _up(cur, dp)                                                        # depth pooling by interpolation (:319)
@@ -168,8 +170,8 @@ class Segtran3d(SegtranInitWeights):
         return vfeat, m.reshape(B, -1), D2, H2, W2
 
     def out_fpn_forward(self, feats, vfeat_fused):
-        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv3d(feats[1])), self.out_gn2b)
-        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv3d(cur)), self.out_gn3b)
+        cur = SF.up_group_norm(feats[2], feats[1].shape[2:], self.out_fpn12_conv3d(feats[1]), self.out_gn2b)
+        cur = SF.up_group_norm(feats[3], cur.shape[2:], self.out_fpn23_conv3d(cur), self.out_gn3b)
         out = _up(vfeat_fused, cur.shape[2:], base=self.out_fpn_bridgeconv3d(cur))
         if self.D_pool_K > 1:
             out = _up(out, [out.shape[2] * self.D_pool_K, out.shape[3], out.shape[4]])
@@ -184,8 +186,8 @@ class Segtran3d(SegtranInitWeights):
         rounding aside -- and the 1024-channel maps at the out-FPN resolution (2 x 2.5 GB at cfg4), the 832 -> 1024 bridge GEMMs
         over 150528 voxels (fwd / bwd-data / bwd-weight) and their resampling passes never exist.  Reference op order
         (:364-367, :381-386, :490): `fuse_output_tail = False`."""
-        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv3d(feats[1])), self.out_gn2b)
-        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv3d(cur)), self.out_gn3b)
+        cur = SF.up_group_norm(feats[2], feats[1].shape[2:], self.out_fpn12_conv3d(feats[1]), self.out_gn2b)
+        cur = SF.up_group_norm(feats[3], cur.shape[2:], self.out_fpn23_conv3d(cur), self.out_gn3b)
         wo, bo = self.out_conv3d.weight, self.out_conv3d.bias
         if isinstance(self.out_fpn_bridgeconv3d, nn.Identity):
             lateral = SF.conv1x1(cur, wo, bo)

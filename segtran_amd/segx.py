@@ -368,8 +368,17 @@ class SegxLib:
     def groupnorm_fwd(self, X, w, b, Y, mean, rstd, ws, B, C, G, S, eps):
         self._call('segx_groupnorm_fwd', X, X, w, b, Y, mean, rstd, ws, B, C, G, S, eps)
 
-    def groupnorm_bwd(self, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S):
-        self._call('segx_groupnorm_bwd', X, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S)
+    def groupnorm_bwd(self, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S, plane_dx_sums=None):
+        self._call('segx_groupnorm_bwd', X, dY, X, w, mean, rstd, dX, dw, db, ws, B, C, G, S, plane_dx_sums)
+
+    def interp_gn_nparts(self, per4, cpg):
+        return int(self.c.segx_interp_gn_nparts(int(per4), int(cpg)))
+
+    def interp_fwd_axis2_gn(self, x, base, out, outer, n1_in, n1_out, n2_in, n2_out, inner, cpg, parts, nparts):
+        self._call('segx_interp_linear_fwd_axis2_gn', x, x, base, out, outer, n1_in, n1_out, n2_in, n2_out, inner, cpg, parts, nparts)
+
+    def groupnorm_fwd_parts(self, X, parts, nparts, w, b, Y, mean, rstd, B, C, G, S, eps):
+        self._call('segx_groupnorm_fwd_parts', X, X, parts, nparts, w, b, Y, mean, rstd, B, C, G, S, eps)
 
     def interp_fwd(self, inp, base, out, planes, d, h, w, D, H, W):
         self._call('segx_interp_linear_fwd', inp, inp, base, out, planes, d, h, w, D, H, W)
@@ -555,7 +564,8 @@ _SIGS = {
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
-    'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilp',
+    'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilpp',
+    'segx_interp_gn_nparts': 'li', 'segx_interp_linear_fwd_axis2_gn': 'pppliiiilipip', 'segx_groupnorm_fwd_parts': 'ppipppppiiilfp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_fwd_axis2': 'pppliiiilp', 'segx_interp_linear_bwd_axis2': 'ppliiiilp', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',

@@ -388,6 +388,77 @@ def test_group_norm(backend, shape):
     close(x.grad, xr.grad, 1e-4); close(gn.weight.grad, ref.weight.grad, 1e-4); close(gn.bias.grad, ref.bias.grad, 1e-4)
 
 
+
+def test_group_norm_backward_also_returns_the_plane_sums_of_its_input_gradient(backend):
+    """segx_groupnorm_bwd(plane_dx_sums): sum over every (sample, channel) plane of dX in closed form from the plane sums (no extra pass) == dX summed."""
+    L = backend.L
+    B, C, G, S = 3, 16, 4, 6 * 10 * 7
+    x, dy = rnd(B, C, S, seed=30) * 1.4 + 0.6, rnd(B, C, S, seed=31)
+    w, b = 1 + 0.3 * rnd(C, seed=32), 0.2 * rnd(C, seed=33)
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(B * G), torch.empty(B * G)
+    L.groupnorm_fwd(x, w, b, y, mean, rstd, torch.empty(L.gn_ws(B, C, G)), B, C, G, S, 1e-5)
+    dw, db, rs = torch.empty(C), torch.empty(C), torch.full((B * C,), float('nan'))
+    L.groupnorm_bwd(dy, x, w, mean, rstd, dx, dw, db, torch.empty(L.gn_ws(B, C, G)), B, C, G, S, rs)
+    ref = dx.double().sum(dim=2).reshape(-1)
+    assert float((rs.double() - ref).abs().max()) <= 2e-5 * float(dx.abs().sum(dim=2).max())        # plane sums cancel: compare against the planes' absolute mass
+    dx2 = torch.empty_like(x)
+    L.groupnorm_bwd(dy, x, w, mean, rstd, dx2, dw, db, torch.empty(L.gn_ws(B, C, G)), B, C, G, S)       # without the extra output: same dX
+    assert torch.equal(dx, dx2)
+
+
+# (d, h, w) -> (D, H, W) with D * H * W / 4 a multiple of 256 (whole 1024-float chunks per plane: the fused form); the last case is not (falls back to the two ops)
+@pytest.mark.parametrize('B,C,G,insize,size', [(2, 8, 4, (4, 8, 8), (8, 16, 16)), (1, 16, 8, (2, 8, 16), (4, 16, 32)), (2, 8, 2, (8, 4, 4), (16, 8, 16)),
+                                               (1, 8, 4, (3, 5, 6), (6, 10, 12))])
+def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradient(backend, B, C, G, insize, size):
+    """SF.up_group_norm (r05): gn(trilinear-up(x) + conv1x1(f)) with the GroupNorm partials produced by the resampling pass and the lateral convolution's
+    bias gradient taken from the backward's plane sums.  Against PyTorch (F.interpolate + nn.GroupNorm + nn.Conv3d): outputs and EVERY gradient -- x, the
+    lateral's input, weight and bias, the GroupNorm affine -- and the row-sum kernel must not have been launched on the fused path."""
+    L = backend.L
+    Cf = 6
+    gn, ref_gn = torch.nn.GroupNorm(G, C), torch.nn.GroupNorm(G, C)
+    conv = torch.nn.Conv3d(Cf, C, 1)
+    with torch.no_grad():
+        for m in (gn, ref_gn):
+            m.weight.copy_(1 + 0.2 * rnd(C, seed=41)); m.bias.copy_(0.2 * rnd(C, seed=42))
+        conv.weight.copy_(0.4 * rnd(C, Cf, 1, 1, 1, seed=43)); conv.bias.copy_(0.3 * rnd(C, seed=44))
+    x = (rnd(B, C, *insize, seed=45) + 0.5).requires_grad_(True)
+    f = rnd(B, Cf, *size, seed=46).requires_grad_(True)
+    xr, fr = x.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    wr, br = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    calls = []
+    orig = L.rowsum
+    L.rowsum = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        y = SF.up_group_norm(x, size, SF.conv1x1(f, conv.weight, conv.bias), gn)
+        Gd = rnd(*y.shape, seed=47)
+        y.backward(Gd)
+    finally:
+        L.rowsum = orig
+    yr = ref_gn(F.interpolate(xr, size=size, mode='trilinear', align_corners=False) + F.conv3d(fr, wr, br))
+    yr.backward(Gd)
+    fused = L.interp_gn_nparts(size[0] * size[1] * size[2] // 4, C // G) > 0
+    assert fused == (size != (6, 10, 12)) and (len(calls) == 0) == fused
+    close(y, yr.detach(), 2e-5)
+    close(x.grad, xr.grad, 1e-4); close(f.grad, fr.grad, 1e-4)
+    close(conv.weight.grad, wr.grad, 1e-4); close(conv.bias.grad, br.grad, 2e-4)
+    close(gn.weight.grad, ref_gn.weight.grad, 1e-4); close(gn.bias.grad, ref_gn.bias.grad, 1e-4)
+
+
+def test_group_norm_partials_of_a_badly_centred_tensor(backend):
+    """The partials are sums around a per-workgroup pivot merged with Chan's formula: a level whose mean is 1000 standard deviations away from zero must
+    still normalise to unit variance (a plain sum / sum-of-squares form loses every digit of the variance there)."""
+    B, C, G = 1, 8, 2
+    gn = torch.nn.GroupNorm(G, C)
+    x = rnd(B, C, 4, 8, 8, seed=50) * 1e-2
+    base = rnd(B, C, 8, 16, 16, seed=51) * 1e-2 + 10.0
+    y = SF.up_group_norm(x, (8, 16, 16), base, gn)
+    yr = torch.nn.functional.group_norm(F.interpolate(x.double(), size=(8, 16, 16), mode='trilinear', align_corners=False) + base.double(), G, gn.weight.double(), gn.bias.double(), gn.eps)
+    assert float((y.double() - yr).abs().max()) < 2e-3            # fp32 input rounding at |x| = 10 with std 1e-2 bounds what ANY fp32 kernel can do: ~1e-6 / 1e-2 relative
+    v = y.reshape(B, G, -1).var(dim=2, unbiased=False)          # var / (var + eps) with var ~ 1.3e-4 (the blend of the up-sampled part included) and eps = 1e-5
+    assert 0.85 < float(v.min()) and float(v.max()) < 1.0
+
+
 @pytest.mark.parametrize('inshape,size', [((2, 3, 4, 5), (8, 10)), ((1, 2, 7, 7), (14, 14)), ((2, 2, 8, 6), (16, 24)), ((1, 3, 16, 16), (13, 9)),
                                           ((1, 2, 3, 4, 5), (6, 8, 10)), ((2, 2, 6, 7, 7), (12, 14, 14)), ((1, 2, 4, 3, 3), (4, 12, 12)),
                                           ((1, 2, 8, 5, 5), (4, 5, 5)), ((1, 1, 12, 14, 14), (48, 56, 56)),

@@ -57,6 +57,36 @@ def test_maxpool3d_same(backend, size, k, stride):
     close(x.grad, xr.grad, 1e-6)
 
 
+
+# (24, 14, 14) / (12, 7, 7): the Mixed_4 / Mixed_5 planes of cfg4 (rows of 14 / 7 floats: whole plane = one slab); (48, 28, 28): Mixed_3 of cfg4 in slabs of
+# 8 slices + halo; (32, 16, 16): Mixed_4 of cfg5 = exactly 8192 floats; (20, 32, 32): slabs of 6; (5, 9, 11) / (3, 3, 5): odd sizes whose slabs start off a
+# 16-byte boundary (scalar staging); (9, 90, 91): a slice alone fills the LDS budget (8190 of 8192 floats: no slab form, falls through to the other kernels)
+@pytest.mark.parametrize('policy', [0, 1, 2])
+@pytest.mark.parametrize('size', [(24, 14, 14), (12, 7, 7), (48, 28, 28), (32, 16, 16), (20, 32, 32), (5, 9, 11), (3, 3, 5), (9, 90, 91)])
+def test_maxpool3d_stride1_slab_form(backend, size, policy):
+    """segx_tune knob 14: the slab-in-LDS form of the stride-1 3 x 3 x 3 'same' pools (0: where the four-cells-per-thread form does not apply, 1: wherever a
+    slab fits, 2: never) -- outputs, arg-max routing and gradients identical to F.max_pool3d under every policy, NaN and all-zero windows included."""
+    L = backend.L
+    if backend.name == 'emu' and size[0] * size[1] * size[2] > 12000 and policy != 1:
+        pytest.skip('large planes on the emulator: the slab policy only (the other kernels are covered at small sizes)')
+    assert L.c.segx_tune(14, 3) < 0
+    assert L.c.segx_tune(14, policy) == 0
+    try:
+        x = torch.relu(rnd(2, 2, *size, seed=14))
+        x[0, 0, :2] = 0.0                                      # whole windows of zeros: the first tap (or the padding) wins
+        x[1, 1, size[0] // 2, size[1] // 2, size[2] // 2] = float('nan')
+        x = x.requires_grad_(True)
+        y = SF.maxpool3d_same(x, (3, 3, 3), (1, 1, 1))
+        xr = x.detach().clone().requires_grad_(True)
+        yr = F.max_pool3d(F.pad(xr, (1, 1, 1, 1, 1, 1)), 3, 1)
+        assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yr.detach(), nan=-7.0))
+        G = rnd(*y.shape, seed=15)
+        y.backward(G); yr.backward(G)
+        assert torch.equal(x.grad, xr.grad)
+    finally:
+        assert L.c.segx_tune(14, 0) == 0
+
+
 @pytest.mark.parametrize('Cout,k', [(40, (3, 3, 3)), (130, (1, 3, 3)), (8, (7, 7, 7))])
 def test_conv3d_forward_split_k(backend, Cout, k):
     """Forward with the contraction split over 3 slabs (the low-resolution Inception stages) == un-split result; both the
