@@ -913,9 +913,16 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __
     const int s0 = max(d0 - 1, 0), s1 = min(d1 + 1, q.ID);           // staged input slices [s0, s1)
     const int base = s0 * hw, n = (s1 - s0) * hw;
     const float* x = X + p * isz + base;
-    if ((((int64_t)p * isz + base) & 3) == 0) {                      // 16-byte aligned start (the tensor base is: host check)
+    if ((((int64_t)p * isz + base) & 3) == 0 && n >= 4) {            // 16-byte aligned start (the tensor base is: host check)
+        // every load of the slab is in flight before the first LDS store (a load + store loop is one HBM round trip per iteration: r05_b measured the
+        // first version of this kernel at 0.6 - 1.6 TB/s); addresses past the slab are clamped, their stores predicated
         const int n4 = n >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) reinterpret_cast<float4*>(sx)[i] = reinterpret_cast<const float4*>(x)[i];
+        constexpr int NL = CAP / 1024;
+        float4 v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const int i = threadIdx.x + 256 * k; v[k] = reinterpret_cast<const float4*>(x)[i < n4 ? i : (n4 > 0 ? n4 - 1 : 0)]; }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const int i = threadIdx.x + 256 * k; if (i < n4) reinterpret_cast<float4*>(sx)[i] = v[k]; }
         for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) sx[i] = x[i];
     } else for (int i = threadIdx.x; i < n; i += 256) sx[i] = x[i];
     __syncthreads();
@@ -955,11 +962,19 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_slab_kernel(const float* __
     const int s0 = max(d0 - 1, 0), s1 = min(d1 + 1, q.ID);           // window slices that can cover them
     const int base = s0 * hw, n = (s1 - s0) * hw;
     const float* g = dY + p * isz + base; const int* a = arg + p * isz + base;
-    if ((((int64_t)p * isz + base) & 3) == 0) {
-        const int n4 = n >> 2;
-        for (int i = threadIdx.x; i < n4; i += 256) {
-            reinterpret_cast<float4*>(sg)[i] = reinterpret_cast<const float4*>(g)[i];
-            reinterpret_cast<int4*>(sa)[i] = reinterpret_cast<const int4*>(a)[i];
+    if ((((int64_t)p * isz + base) & 3) == 0 && n >= 4) {
+        const int n4 = n >> 2;                                       // all loads in flight before the first LDS store (see the forward kernel)
+        constexpr int NL = CAP / 1024;
+        float4 vg[NL]; int4 va[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = threadIdx.x + 256 * k, ic = i < n4 ? i : (n4 > 0 ? n4 - 1 : 0);
+            vg[k] = reinterpret_cast<const float4*>(g)[ic]; va[k] = reinterpret_cast<const int4*>(a)[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n4) { reinterpret_cast<float4*>(sg)[i] = vg[k]; reinterpret_cast<int4*>(sa)[i] = va[k]; }
         }
         for (int i = (n4 << 2) + threadIdx.x; i < n; i += 256) { sg[i] = g[i]; sa[i] = a[i]; }
     } else for (int i = threadIdx.x; i < n; i += 256) { sg[i] = g[i]; sa[i] = a[i]; }
@@ -1221,6 +1236,7 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const bool bs1w4 = (q.KD == 3 || q.KD == 1) && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pw == 1 && q.OW == q.IW && q.OH == q.IH && q.IW % 4 == 0 &&
         q.IW >= 4 && (int64_t)q.ID * q.IH * q.IW % 4 == 0 && (int64_t)q.OD * q.OH * q.OW % 4 == 0 && aligned16c(dX) && aligned16c(dY) && aligned16c(arg);
     const int slab_policy = kget(knobs().pool_slab);
+    // default: the slab gather where neither the four-cells-per-thread form applies ... (measured, tools/pool_bench.py, profiles/r05_*_pool_bench.txt)
     if (pool_is_s1k3_same(q) && slab_policy != 2 && (slab_policy == 1 || !bs1w4) && aligned16c(dY) && aligned16c(arg)) {
         const int isz = q.ID * q.IH * q.IW, cap = isz <= 2048 ? 2048 : 8192, td = pool_slab_td(q, cap);
         if (td > 0 && planes * ceil_div(q.ID, td) < 2147483647LL) {

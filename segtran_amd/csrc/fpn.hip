@@ -230,6 +230,48 @@ __global__ __launch_bounds__(256) void interp_bwd_axis_kernel(const float* __res
     }
 }
 
+// r05: the CONTIGUOUS axis itself (inner == 1: the x pass of the pyramid's trilinear up-sampling, 109 -> 436 MB at cfg5), n_out % 4 == 0.
+// Forward: a thread writes FOUR adjacent outputs as one float4 (the writes are 4/5 of the pass's bytes; the scalar form ran at 1.9 TB/s).  Backward: a
+// thread reads the candidates of its cell as aligned float4s of the output row (the reads are 4/5 of the bytes; scalar: 1.7 TB/s).  Same blend
+// expressions / the same ascending candidate order with the same weights (zero-weight candidates included) as the scalar kernels: identical bits.
+__global__ __launch_bounds__(256) void interp_fwd_x4_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
+                                                            int n_in, int n_out4, FastDiv divQ, float scale, int64_t rows) {
+    const int64_t total = rows * n_out4;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t r0 = b0 / n_out4;
+        const int e0 = (int)(b0 - r0 * n_out4) + threadIdx.x, qr = fdiv(e0, divQ);
+        const int64_t row = r0 + qr; const int j = e0 - qr * n_out4;
+        if (row >= rows) continue;
+        const float* s = in + row * n_in;
+        float v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const Axis a = axis_src(4 * j + t, n_in, scale); v[t] = s[a.i0] * (1.f - a.l) + s[a.i1] * a.l; }
+        const int64_t o = row * n_out4 + j;
+        if (base) { const float4 bv = reinterpret_cast<const float4*>(base)[o]; v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
+        reinterpret_cast<float4*>(out)[o] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+__global__ __launch_bounds__(256) void interp_bwd_x4_kernel(const float* __restrict__ dout, float* __restrict__ din, int n_out, int n_in, FastDiv divN,
+                                                            float scale, int64_t rows) {
+    const int64_t total = rows * n_in;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t r0 = b0 / n_in;
+        const int e0 = (int)(b0 - r0 * n_in) + threadIdx.x, qr = fdiv(e0, divN);
+        const int64_t row = r0 + qr; const int i = e0 - qr * n_in;
+        if (row >= rows) continue;
+        int lo, hi; cand_range(i, n_out, scale, lo, hi);
+        const float4* g4 = reinterpret_cast<const float4*>(dout + row * n_out);
+        float acc = 0.f;
+        for (int d4 = lo & ~3; d4 <= hi; d4 += 4) {
+            const float4 v = g4[d4 >> 2];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { const int d = d4 + t; if (d >= lo && d <= hi) acc += axis_weight(i, d, n_in, scale) * e[t]; }
+        }
+        din[row * n_in + i] = acc;
+    }
+}
+
 // float4 over the inner (contiguous) extent: the candidate range and the blend weights depend on the axis index only
 __global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
                                                                int n_out, int n_in, int inner4, FastDiv divInner, FastDiv divPer, float scale) {
@@ -640,6 +682,12 @@ extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, f
     SEGX_STREAM; SEGX_REQUIRE(in && out && outer > 0 && outer <= 2147483647LL && n_in > 0 && n_out > 0 && inner > 0 && (int64_t)n_out * inner < 2147483647LL,
                               "segx_interp_linear_fwd_axis: bad args");
     const bool vec = inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0;
+    if (inner == 1 && n_out % 4 == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(base)) & 15) == 0) {      // the contiguous axis itself: four outputs per thread
+        const float sc = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;
+        const int n4 = n_out / 4;
+        hipLaunchKernelGGL(interp_fwd_x4_kernel, dim3((unsigned)i64min(1 << 20, (outer * n4 + 255) / 256)), dim3(256), 0, stream, in, base, out, n_in, n4, make_fastdiv(n4), sc, outer);
+        return check_launch("segx_interp_linear_fwd_axis/x4");
+    }
     const int in_ = (int)(vec ? inner / 4 : inner);
     const int64_t per = (int64_t)n_out * in_;
     const int64_t total = outer * per;
@@ -675,6 +723,10 @@ extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_
     const int64_t total = outer * n_in * inner;
     const float scale = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;
     SEGX_REQUIRE((int64_t)n_in * inner < 2147483647LL - 256, "segx_interp_linear_bwd_axis: slice too large");
+    if (inner == 1 && n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) {        // the contiguous axis itself: candidates read as aligned float4s of the output row
+        hipLaunchKernelGGL(interp_bwd_x4_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, n_out, n_in, make_fastdiv(n_in), scale, outer);
+        return check_launch("segx_interp_linear_bwd_axis/x4");
+    }
     if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0) {
         const int in4 = (int)(inner / 4);
         hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,

@@ -426,15 +426,17 @@ def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradie
     f = rnd(B, Cf, *size, seed=46).requires_grad_(True)
     xr, fr = x.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
     wr, br = conv.weight.detach().clone().requires_grad_(True), conv.bias.detach().clone().requires_grad_(True)
+    from segtran_amd import segx
+    Lf = segx.lib()                                            # the instance the autograd layer calls (on the device not the fixture's object)
     calls = []
-    orig = L.rowsum
-    L.rowsum = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    orig = Lf.rowsum
+    Lf.rowsum = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
         y = SF.up_group_norm(x, size, SF.conv1x1(f, conv.weight, conv.bias), gn)
         Gd = rnd(*y.shape, seed=47)
         y.backward(Gd)
     finally:
-        L.rowsum = orig
+        del Lf.rowsum
     yr = ref_gn(F.interpolate(xr, size=size, mode='trilinear', align_corners=False) + F.conv3d(fr, wr, br))
     yr.backward(Gd)
     fused = L.interp_gn_nparts(size[0] * size[1] * size[2] // 4, C // G) > 0
@@ -483,6 +485,31 @@ def test_interp_linear(backend, inshape, size, with_base):
     close(x.grad, xr.grad, 1e-5)
     if with_base:
         close(base.grad, br.grad, 1e-6)
+
+
+
+@pytest.mark.parametrize('w,W,align', [(16, 64, False), (5, 20, False), (7, 12, False), (40, 16, False), (9, 36, True), (3, 8, False), (1, 4, False)])
+@pytest.mark.parametrize('with_base', [False, True])
+def test_contiguous_axis_pass_with_float4_access(backend, w, W, align, with_base):
+    """r05: segx_interp_linear_{fwd,bwd}_axis with inner == 1 and n_out % 4 == 0 (the x pass of the pyramid's up-sampling) -- four outputs per thread forward,
+    aligned float4 candidate reads backward -- against F.interpolate along the last axis: x4 and non-integer ratios, a down-sampling, align_corners, base add."""
+    L = backend.L
+    rows = 37
+    x = rnd(rows, w, seed=60)
+    base = rnd(rows, W, seed=61) if with_base else None
+    scale = 0.0 if not align else -((w - 1) / (W - 1))
+    out = torch.empty(rows, W)
+    L.interp_fwd_axis(x, base, out, rows, w, W, 1, scale)
+    ref = F.interpolate(x.double().view(1, rows, w), size=W, mode='linear', align_corners=align).view(rows, W)
+    if with_base:
+        ref = ref + base.double()
+    assert float((out.double() - ref).abs().max()) < 2e-6 * max(1.0, float(ref.abs().max()))
+    G = rnd(rows, W, seed=62)
+    dx = torch.empty(rows, w)
+    L.interp_bwd_axis(G, dx, rows, W, w, 1, scale)
+    xr = x.double().clone().requires_grad_(True)
+    F.interpolate(xr.view(1, rows, w), size=W, mode='linear', align_corners=align).backward(G.double().view(1, rows, W))
+    assert float((dx.double() - xr.grad).abs().max()) < 2e-6 * max(1.0, float(xr.grad.abs().max()))
 
 
 def test_two_axis_resampling_pass_equals_the_one_axis_passes(backend):

@@ -82,7 +82,10 @@ def test_maxpool3d_stride1_slab_form(backend, size, policy):
         assert torch.equal(torch.nan_to_num(y, nan=-7.0), torch.nan_to_num(yr.detach(), nan=-7.0))
         G = rnd(*y.shape, seed=15)
         y.backward(G); yr.backward(G)
-        assert torch.equal(x.grad, xr.grad)
+        if x.is_cuda:
+            close(x.grad, xr.grad, 1e-6)                       # ATen's device backward accumulates with atomics: the order of a cell's <= 27 terms is not fixed there
+        else:
+            assert torch.equal(x.grad, xr.grad)
     finally:
         assert L.c.segx_tune(14, 0) == 0
 
