@@ -725,8 +725,11 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __
                     // left / right neighbour columns: the adjacent quad of the same row lives in the adjacent lane (consecutive lanes = consecutive
                     // quads; a row starts where inl is false) -- except at the wave's first / last lane, which load them
                     float vl = __shfl_up(m.w, 1), vr = __shfl_down(m.x, 1);
-                    if (lane == 0 && inl) vl = x[rowbase + w0];
-                    if (lane == 63 && inr) vr = x[rowbase + ow0 + 4];
+                    // r05: ONE unconditional load per lane instead of two loads under branches (lane 0 fetches its left neighbour, lane 63 its right one, the others
+                    // re-read their own first element: an L1 hit) -- a branch with a load inside stalls the whole unrolled row sequence at every row
+                    const float xe = x[rowbase + ((lane == 0 && inl) ? w0 : (lane == 63 && inr) ? ow0 + 4 : ow0)];
+                    if (lane == 0 && inl) vl = xe;
+                    if (lane == 63 && inr) vr = xe;
                     float v[6]; bool in[6];
                     in[0] = ok && inl; in[5] = ok && inr; in[1] = in[2] = in[3] = in[4] = ok;
                     v[0] = in[0] ? vl : 0.f; v[5] = in[5] ? vr : 0.f;
@@ -792,13 +795,25 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __
             const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw0 + q.pw - q.KW + 1;
             const int d0 = dn > 0 ? (q.sd == 1 ? dn : (dn + 1) >> 1) : 0, h0 = hn > 0 ? (hn + 1) >> 1 : 0, w0 = wn > 0 ? (wn + 1) >> 1 : 0;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {
-                const int rowo = (od * q.OH + oh) * q.OW;
-                for (int ow = w0; ow <= w1; ++ow) {
-                    const int j = a[rowo + ow] - li0;
-                    const float gv = g[rowo + ow];
-                    a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
-                }
+            // r05: the <= 2 x 2 x 3 covering windows as a FIXED probe set -- clamped addresses, all index / gradient loads requested before the first use, validity as
+            // a select -- instead of three nested loops with run-time bounds whose loads each waited for the previous one (same (od, oh, ow) order of the sums)
+            int jv[12]; float gvv[12];
+#pragma unroll
+            for (int zz = 0; zz < 2; ++zz)
+#pragma unroll
+                for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                    for (int xx = 0; xx < 3; ++xx) {
+                        const int od = d0 + zz, oh = h0 + yy, ow = w0 + xx, t = (zz * 2 + yy) * 3 + xx;
+                        const bool okp = od <= d1 && oh <= h1 && ow <= w1;
+                        const int o = okp ? (od * q.OH + oh) * q.OW + ow : 0;
+                        jv[t] = okp ? a[o] - li0 : -1;
+                        gvv[t] = g[o];
+                    }
+#pragma unroll
+            for (int t = 0; t < 12; ++t) {
+                const int j = jv[t]; const float gv = gvv[t];
+                a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
             }
             *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(a0, a1, a2, a3);
         }
@@ -833,8 +848,10 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __
                     const float4 gm = *reinterpret_cast<const float4*>(g + rowo + iw0);
                     int al = __shfl_up(am.w, 1), ar = __shfl_down(am.x, 1);
                     float gl = __shfl_up(gm.w, 1), gr = __shfl_down(gm.x, 1);
-                    if (lane == 0 && inl) { al = a[rowo + iw0 - 1]; gl = g[rowo + iw0 - 1]; }
-                    if (lane == 63 && inr) { ar = a[rowo + iw0 + 4]; gr = g[rowo + iw0 + 4]; }
+                    const int eo = rowo + ((lane == 0 && inl) ? iw0 - 1 : (lane == 63 && inr) ? iw0 + 4 : iw0);       // one unconditional edge load per array (see the forward)
+                    const int ae = a[eo]; const float ge = g[eo];
+                    if (lane == 0 && inl) { al = ae; gl = ge; }
+                    if (lane == 63 && inr) { ar = ae; gr = ge; }
                     int av[6]; float gv[6];
                     av[0] = al; gv[0] = (ok && inl) ? gl : 0.f;
                     av[5] = ar; gv[5] = (ok && inr) ? gr : 0.f;
@@ -929,7 +946,7 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __
     const int cells = (d1 - d0) * hw;
     for (int c = threadIdx.x; c < cells; c += 256) {
         const int zd = fdiv(c, dHW), r2 = c - zd * hw, oh = fdiv(r2, dW), ow = r2 - oh * q.IW, od = d0 + zd;
-        float best = -INFINITY; int bi = -1;
+        int lis[27]; bool ins[27]; float vs[27];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             const int id = od - 1 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
@@ -939,12 +956,19 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __
                 const int rowbase = (id * q.IH + ih) * q.IW;
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow - 1 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
-                    const int li = rowbase + iw;
-                    const float v = in ? sx[li - base] : 0.f;            // zero padding
-                    if (v > best || v != v) { best = v; bi = in ? li : -1; }
+                    const int iw = ow - 1 + kw, t = (kd * 3 + kh) * 3 + kw;
+                    ins[t] = okh && (unsigned)iw < (unsigned)q.IW;
+                    lis[t] = rowbase + iw;
                 }
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 27; ++t) vs[t] = sx[ins[t] ? lis[t] - base : 0];      // all 27 taps requested back to back (clamped addresses)
+        float best = -INFINITY; int bi = -1;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const float v = ins[t] ? vs[t] : 0.f;                                  // zero padding
+            if (v > best || v != v) { best = v; bi = ins[t] ? lis[t] : -1; }
         }
         const int64_t o = p * isz + (int64_t)d0 * hw + c;
         Y[o] = best; arg[o] = bi;
@@ -983,7 +1007,9 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_slab_kernel(const float* __
     for (int c = threadIdx.x; c < cells; c += 256) {
         const int zd = fdiv(c, dHW), r2 = c - zd * hw, ih = fdiv(r2, dW), iw = r2 - ih * q.IW, id = d0 + zd;
         const int li = d0 * hw + c;
-        float acc = 0.f;
+        // branch-free: the 27 index words, then the 27 gradients (clamped addresses), are requested back to back and selected afterwards.  (r05_b / r05_c: the
+        // first form -- `if (in range && sa[o] == li) acc += sg[o]` -- compiled to 27 x 2 DEPENDENT LDS round trips under branches: 0.6 TB/s.)
+        int off[27]; bool ok[27];
 #pragma unroll
         for (int z = 0; z < 3; ++z) {
             const int od = id - 1 + z; const bool okd = (unsigned)od < (unsigned)q.ID;
@@ -993,11 +1019,20 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_slab_kernel(const float* __
                 const int rowo = (od * q.IH + oh) * q.IW - base;
 #pragma unroll
                 for (int xx = 0; xx < 3; ++xx) {
-                    const int ow = iw - 1 + xx;
-                    if (okh && (unsigned)ow < (unsigned)q.IW && sa[rowo + ow] == li) acc += sg[rowo + ow];
+                    const int ow = iw - 1 + xx, t = (z * 3 + y) * 3 + xx;
+                    ok[t] = okh && (unsigned)ow < (unsigned)q.IW;
+                    off[t] = ok[t] ? rowo + ow : 0;
                 }
             }
         }
+        int av[27]; float gv[27];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) av[t] = sa[off[t]];
+#pragma unroll
+        for (int t = 0; t < 27; ++t) gv[t] = sg[off[t]];
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) acc += (ok[t] && av[t] == li) ? gv[t] : 0.f;      // (od, oh, ow) order, as every other gather
         dX[p * isz + li] = acc;
     }
 }
@@ -1263,7 +1298,8 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const int isz = q.ID * q.IH * q.IW;
     const dim3 grid((unsigned)i64min(4096, (isz + 255) / 256), (unsigned)i64min(65535, planes));
     const FastDiv dIHW = make_fastdiv(q.IH * q.IW), dIW = make_fastdiv(q.IW);
-    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2) && q.IW % 4 == 0 && isz % 4 == 0 && aligned16c(dX) && q.KW <= 3 && q.KH <= 3 && q.KD <= 3) {
+    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2) && q.IW % 4 == 0 && isz % 4 == 0 && aligned16c(dX) && q.KW <= 3 && q.KH <= 3 && q.KD <= 3 &&
+        (q.KD + q.sd - 1) / q.sd <= 2) {                      // the kernel probes a fixed 2 x 2 x 3 window set
         const int iw4 = q.IW / 4;
         const dim3 grid4((unsigned)i64min(4096, (isz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
         hipLaunchKernelGGL(maxpool3d_bwd_s2w4_kernel, grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));

@@ -442,6 +442,104 @@ __global__ __launch_bounds__(256) void interp_bwd_axis2_kernel(const float* __re
     }
 }
 
+// r05: the same adjoint with the contributing outputs of a cell as a FIXED list.  cand_range is conservative (2 f + 4 candidates per axis for an f-fold
+// up-sampling, 2 f of them with a non-zero weight) and the kernel above walks it with `if (w == 0) continue` around every load: 64 weight evaluations and 16
+// loads, each under its own branch, per cell at f = 2 -- the loads of one cell waited for each other (3.3 TB/s over the cfg5 pyramid).  Here a lane first
+// collects the <= MAXC contributors (index, weight) of each axis in ascending order -- the order the loop above adds them in -- then requests the MAXC float4
+// of one d2 column back to back (indices past the list repeat its first entry with weight 0: x + 0 * v == x) and blends.  Same sums in the same order.
+// MAXC = 4 serves ratios up to 2, MAXC = 8 up to 4; anything else keeps the kernel above (host check: interp_contributors).
+template <int MAXC>
+__global__ __launch_bounds__(256) void interp_bwd_axis2_fixed_kernel(const float* __restrict__ dout, float* __restrict__ din, int n1_out, int n1_in, int n2_out,
+                                                                     int n2_in, int inner4, FastDiv divInner, FastDiv divRow, FastDiv divPer, float s1, float s2,
+                                                                     int64_t outer) {
+    const int row = n2_in * inner4, per = n1_in * row;
+    const int64_t total = outer * per, out_per = (int64_t)n1_out * n2_out * inner4;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
+        int lo1, hi1, lo2, hi2;
+        cand_range(i1, n1_out, s1, lo1, hi1); cand_range(i2, n2_out, s2, lo2, hi2);
+        int d1s[MAXC], d2s[MAXC]; float w1s[MAXC], w2s[MAXC];
+        int c1 = 0, c2 = 0;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { d1s[k] = lo1; w1s[k] = 0.f; d2s[k] = lo2; w2s[k] = 0.f; }
+        for (int d = lo1; d <= hi1; ++d) {                   // <= 2 f + 4 weight evaluations per axis, no loads
+            const float w = axis_weight(i1, d, n1_in, s1);
+            if (w != 0.f && c1 < MAXC) {
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) if (k == c1) { d1s[k] = d; w1s[k] = w; }
+                ++c1;
+            }
+        }
+        for (int d = lo2; d <= hi2; ++d) {
+            const float w = axis_weight(i2, d, n2_in, s2);
+            if (w != 0.f && c2 < MAXC) {
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) if (k == c2) { d2s[k] = d; w2s[k] = w; }
+                ++c2;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { if (k >= c1) d1s[k] = d1s[0]; if (k >= c2) d2s[k] = d2s[0]; }
+        const float4* g = reinterpret_cast<const float4*>(dout) + o * out_per + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k2 = 0; k2 < MAXC; ++k2) {
+            float4 v[MAXC];
+#pragma unroll
+            for (int k1 = 0; k1 < MAXC; ++k1) v[k1] = g[((int64_t)d1s[k1] * n2_out + d2s[k2]) * inner4];
+            float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k1 = 0; k1 < MAXC; ++k1) { const float w1 = w1s[k1]; col.x += w1 * v[k1].x; col.y += w1 * v[k1].y; col.z += w1 * v[k1].z; col.w += w1 * v[k1].w; }
+            const float w2 = w2s[k2];
+            acc.x += w2 * col.x; acc.y += w2 * col.y; acc.z += w2 * col.z; acc.w += w2 * col.w;
+        }
+        reinterpret_cast<float4*>(din)[o * per + e] = acc;
+    }
+}
+// upper bound of the outputs one input cell contributes to along an axis resampled n_in -> n_out (align_corners = False): src(d) within (i - 1, i + 1)
+static inline int interp_contributors(int n_in, int n_out) { return n_out <= n_in ? 3 : (int)((2LL * n_out + n_in - 1) / n_in); }      // ceil(2 f), f = n_out / n_in
+// one-axis form of the fixed-list adjoint (float4 over the contiguous inner extent)
+template <int MAXC>
+__global__ __launch_bounds__(256) void interp_bwd_axis4_fixed_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
+                                                                     int n_out, int n_in, int inner4, FastDiv divInner, FastDiv divPer, float scale) {
+    const int per = n_in * inner4;
+    const int64_t total = outer * per;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t ob0 = b0 / per;
+        const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
+        const int64_t o = ob0 + qo; const int e = e0 - qo * per;
+        if (o >= outer) continue;
+        const int i = fdiv(e, divInner), in_ = e - i * inner4;
+        int lo, hi; cand_range(i, n_out, scale, lo, hi);
+        int ds[MAXC]; float ws[MAXC];
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { ds[k] = lo; ws[k] = 0.f; }
+        for (int d = lo; d <= hi; ++d) {
+            const float w = axis_weight(i, d, n_in, scale);
+            if (w != 0.f && cnt < MAXC) {
+#pragma unroll
+                for (int k = 0; k < MAXC; ++k) if (k == cnt) { ds[k] = d; ws[k] = w; }
+                ++cnt;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) if (k >= cnt) ds[k] = ds[0];
+        const float4* g = reinterpret_cast<const float4*>(dout) + (o * n_out) * inner4 + in_;
+        float4 v[MAXC];
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) v[k] = g[(int64_t)ds[k] * inner4];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) { const float w = ws[k]; acc.x += w * v[k].x; acc.y += w * v[k].y; acc.z += w * v[k].z; acc.w += w * v[k].w; }
+        reinterpret_cast<float4*>(din)[o * per + e] = acc;
+    }
+}
+
 // nn.AvgPool2d(2) (PolyformerLayer.pool2x, polyformer.py:28,40): [planes, H, W] -> [planes, H/2, W/2] (floor), and its adjoint
 __global__ __launch_bounds__(256) void avgpool2_fwd_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t planes, int H, int W) {
     const int OH = H / 2, OW = W / 2; const int64_t total = planes * OH * OW;
@@ -672,9 +770,14 @@ extern "C" int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64
     SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0, "segx_interp_linear_bwd_axis2: alignment");
     const int64_t in4 = inner / 4, per = (int64_t)n1_in * n2_in * in4, total = outer * per;
     SEGX_REQUIRE(per < 2147483647LL - 256 && (int64_t)n1_out * n2_out * in4 < 2147483647LL, "segx_interp_linear_bwd_axis2: slice too large");
-    hipLaunchKernelGGL(interp_bwd_axis2_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, n1_out, n1_in, n2_out,
-                       n2_in, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_in * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
-                       (float)n2_in / (float)n2_out, outer);
+    const int nc = interp_contributors(n1_in, n1_out) > interp_contributors(n2_in, n2_out) ? interp_contributors(n1_in, n1_out) : interp_contributors(n2_in, n2_out);
+    const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
+#define SEGX_AXIS2_ARGS dout, din, n1_out, n1_in, n2_out, n2_in, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_in * in4)), make_fastdiv((int)per), \
+                        (float)n1_in / (float)n1_out, (float)n2_in / (float)n2_out, outer
+    if (nc <= 4 && kget(knobs().interp_variant) != 1) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<4>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    else if (nc <= 8 && kget(knobs().interp_variant) != 1) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<8>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    else hipLaunchKernelGGL(interp_bwd_axis2_kernel, grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+#undef SEGX_AXIS2_ARGS
     return check_launch("segx_interp_linear_bwd_axis2");
 }
 extern "C" int segx_interp_linear_fwd_axis(const float* in, const float* base, float* out, int64_t outer, int n_in, int n_out, int64_t inner,
@@ -729,7 +832,11 @@ extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_
     }
     if (inner % 4 == 0 && ((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0) {
         const int in4 = (int)(inner / 4);
-        hipLaunchKernelGGL(interp_bwd_axis4_kernel, dim3((unsigned)i64min(1 << 20, (total / 4 + 255) / 256)), dim3(256), 0, stream, dout, din, outer,
+        const dim3 g4((unsigned)i64min(1 << 20, (total / 4 + 255) / 256));
+        const int nc = src_scale == 0.f && kget(knobs().interp_variant) != 1 ? interp_contributors(n_in, n_out) : 99;      // the fixed-list form: plain size-ratio resampling only
+        if (nc <= 4) hipLaunchKernelGGL((interp_bwd_axis4_fixed_kernel<4>), g4, dim3(256), 0, stream, dout, din, outer, n_out, n_in, in4, make_fastdiv(in4), make_fastdiv(n_in * in4), scale);
+        else if (nc <= 8) hipLaunchKernelGGL((interp_bwd_axis4_fixed_kernel<8>), g4, dim3(256), 0, stream, dout, din, outer, n_out, n_in, in4, make_fastdiv(in4), make_fastdiv(n_in * in4), scale);
+        else hipLaunchKernelGGL(interp_bwd_axis4_kernel, g4, dim3(256), 0, stream, dout, din, outer,
                            n_out, n_in, in4, make_fastdiv(in4), make_fastdiv(n_in * in4), scale);
     } else
         hipLaunchKernelGGL(interp_bwd_axis_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, outer, n_out,

@@ -23,6 +23,10 @@ from util import golden
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 LABEL_MARGIN = 1e-5
+# fp64 referee: where the fp32 reference itself is further than the tolerance from the fp64 truth, the HIP result may be at most REFEREE x as far from
+# the truth as the fp32 reference is (r04: 3; r05: 1.5 after the full-shape runs of session r05_d passed at 1.5 on both engines and both op orders)
+import os as _os
+REFEREE = float(_os.environ.get('SEGX_REFEREE_FACTOR', '3'))
 
 
 def _inputs(cfg, B=1):
@@ -110,7 +114,7 @@ def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, mo
     lerr = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits']).abs().max().item()
     lerr64 = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits64']).abs().max().item()
     ref64 = (g['train_logits'] - g['train_logits64']).abs().max().item()
-    assert lerr < 1e-3 and (lerr <= 2e-4 * float(g['absmax']) or lerr64 <= 3 * ref64), (lerr, lerr64, ref64)
+    assert lerr < 1e-3 and (lerr <= 2e-4 * float(g['absmax']) or lerr64 <= REFEREE * ref64), (lerr, lerr64, ref64)
     pw, cw = engine.loss_weights(c['task'], DEV)
     loss, _ = SF.seg_loss(y, engine.map_mask(c['task'], raw.to(DEV)), pw, cw)
     assert abs(loss.item() - float(g['loss'])) < 5e-5, (loss.item(), float(g['loss']))
@@ -129,7 +133,7 @@ def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, mo
         v64 = g['grad64:' + name].reshape(-1)
         e64 = (got - v64).abs().max().item() / gscale
         r64 = (v.reshape(-1) - v64).abs().max().item() / gscale
-        assert e32 <= 1e-3 or e64 <= 3 * r64, '%s: |hip - ref32| = %.2e, |hip - fp64| = %.2e, |ref32 - fp64| = %.2e (of the gradient scale)' % (name, e32, e64, r64)
+        assert e32 <= 1e-3 or e64 <= REFEREE * r64, '%s: |hip - ref32| = %.2e, |hip - fp64| = %.2e, |ref32 - fp64| = %.2e (of the gradient scale)' % (name, e32, e64, r64)
         worst = max(worst, (e32, name))
         n += 1
     assert n >= 25

@@ -13,6 +13,10 @@ from util import golden, golden_json, assert_close
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
+# fp64 referee: where the fp32 reference itself is further than the tolerance from the fp64 truth, the HIP result may be at most REFEREE x as far from
+# the truth as the fp32 reference is (r04: 3; r05: 1.5 after the full-shape runs of session r05_d passed at 1.5 on both engines and both op orders)
+import os as _os
+REFEREE = float(_os.environ.get('SEGX_REFEREE_FACTOR', '3'))
 
 
 @pytest.fixture(params=['x6', 'f32'], autouse=True)
@@ -38,7 +42,7 @@ def _grads_vs_golden(net, g, tol=1e-3, referee=False):
         if referee and 'grad64:' + k[5:] in g:
             got, v, v64 = got.detach().cpu().reshape(-1), v.reshape(-1), g['grad64:' + k[5:]].reshape(-1)
             e32, e64, r64 = [(a - b).abs().max().item() / gscale for a, b in ((got, v), (got, v64), (v, v64))]
-            assert e32 <= tol or e64 <= 3 * r64, '%s: |hip - ref32| %.2e, |hip - fp64| %.2e, |ref32 - fp64| %.2e of the gradient scale' % (k[5:], e32, e64, r64)
+            assert e32 <= tol or e64 <= REFEREE * r64, '%s: |hip - ref32| %.2e, |hip - fp64| %.2e, |ref32 - fp64| %.2e of the gradient scale' % (k[5:], e32, e64, r64)
         else:
             assert_close(got.reshape(-1), v.reshape(-1), tol, k[5:], scale=gscale)
         n += 1

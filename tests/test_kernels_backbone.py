@@ -512,6 +512,27 @@ def test_contiguous_axis_pass_with_float4_access(backend, w, W, align, with_base
     assert float((dx.double() - xr.grad).abs().max()) < 2e-6 * max(1.0, float(xr.grad.abs().max()))
 
 
+
+@pytest.mark.parametrize('d,h,D,H', [(4, 6, 8, 12), (3, 5, 12, 20), (5, 4, 7, 9), (6, 8, 3, 4), (2, 3, 18, 27)])
+def test_fixed_contributor_adjoints_equal_the_candidate_loops_bit_for_bit(backend, d, h, D, H):
+    """r05: interp_bwd_axis2_fixed / interp_bwd_axis4_fixed collect a cell's contributing outputs first and then load them back to back; the loops they replace
+    (segx_tune knob 1 = 1 keeps them) walk a conservative candidate range with a branch per load.  Same contributors, same order, same weights: identical
+    bits -- at ratios 2 and 4 (the pyramid), a non-integer ratio, a down-sampling, and ratio 9 (more than 8 contributors: the loop form serves both)."""
+    L = backend.L
+    planes, W = 3, 8
+    G = rnd(planes, D, H, W, seed=95)
+    outs = {}
+    for variant in (0, 1):
+        assert L.c.segx_tune(1, variant) == 0
+        try:
+            g2 = torch.empty(planes * d * h * W); L.interp_bwd_axis2(G, g2, planes, D, d, H, h, W)
+            g1 = torch.empty(planes * d * H * W); L.interp_bwd_axis(G, g1, planes, D, d, H * W, 0.0)
+            outs[variant] = (g2, g1)
+        finally:
+            assert L.c.segx_tune(1, 0) == 0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_two_axis_resampling_pass_equals_the_one_axis_passes(backend):
     """segx_interp_linear_{fwd,bwd}_axis2 (y and z of a trilinear resampling in one pass) against the two one-axis passes they replace: the same
     blends in the same order (the compiler may contract the multiply-adds differently: a few ulp)."""
