@@ -342,7 +342,8 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * knob 12 = poll bound of a team exchange (default 2^20 polls, ~1 s; 32 .. 2^24); knob 13 = FAULT INJECTION for the tests of the team form's failure
  * path: the last `value` workgroups of every team launch are not launched, so their team mates time out (0 = off, the default);
  * knob 14 = slab-in-LDS form of the stride-1 3 x 3 x 3 'same' max-pools: 0 (default) where the four-cells-per-thread form does not apply (row length not a
- * multiple of 4), 1 wherever a slab fits the LDS, 2 never.  Identical results. */
+ * multiple of 4), 1 wherever a slab fits the LDS, 2 never; knob 15 = the same pools with rows of a multiple of 4 floats: 1 (default) a thread keeps its four
+ * cells for up to eight slices and slides along the depth (a third of the row loads), 0 = one slice per thread.  Identical results for every setting. */
 int segx_tune(int knob, int value);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
  * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)
@@ -454,7 +455,9 @@ int segx_label_nhot(const void* labels, float* out, int B, int Cin, int64_t S, i
 /* MaxPool3dSamePadding (aj_i3d.py:6-30): zero 'same' padding then max-pool.  geom (int32[15]) =
  * {ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw}; arg = arg-max index per output (-1 = a padded zero won) */
 int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t planes, const int* geom, void* stream);
-int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream);
+/* addend (r05; may be NULL; strided pools only): a tensor of dX's shape added to the result in the same pass -- the gradient of the pooled tensor's other
+ * consumers where it is also a feature-pyramid endpoint (segtran3d.py:436-441 feats[1..3]): autograd's accumulation kernel (read + read + write) need not run. */
+int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, const float* addend, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sliding-window evaluation path (infer.hip)

@@ -725,11 +725,8 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __
                     // left / right neighbour columns: the adjacent quad of the same row lives in the adjacent lane (consecutive lanes = consecutive
                     // quads; a row starts where inl is false) -- except at the wave's first / last lane, which load them
                     float vl = __shfl_up(m.w, 1), vr = __shfl_down(m.x, 1);
-                    // r05: ONE unconditional load per lane instead of two loads under branches (lane 0 fetches its left neighbour, lane 63 its right one, the others
-                    // re-read their own first element: an L1 hit) -- a branch with a load inside stalls the whole unrolled row sequence at every row
-                    const float xe = x[rowbase + ((lane == 0 && inl) ? w0 : (lane == 63 && inr) ? ow0 + 4 : ow0)];
-                    if (lane == 0 && inl) vl = xe;
-                    if (lane == 63 && inr) vr = xe;
+                    if (lane == 0 && inl) vl = x[rowbase + w0];
+                    if (lane == 63 && inr) vr = x[rowbase + ow0 + 4];
                     float v[6]; bool in[6];
                     in[0] = ok && inl; in[5] = ok && inr; in[1] = in[2] = in[3] = in[4] = ok;
                     v[0] = in[0] ? vl : 0.f; v[5] = in[5] ? vr : 0.f;
@@ -752,11 +749,128 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4_kernel(const float* __
     }
 }
 
+// r05: the 3 x 3 x 3 stride-1 pool (pd = ph = pw = 1, O == I) SLIDING ALONG DEPTH.  The four-outputs-per-thread kernel above requests nine float4 rows per output
+// quad and is bound by the rate at which the CU accepts load instructions, not by HBM (r05_c: 1.9 TB/s; one more load per row took it to 1.4).  Here a thread owns the
+// same quad for TD consecutive output slices and walks the TD + 2 input slices under them once: per input slice three rows are loaded and reduced to the slice's
+// (max, arg-max) for the four outputs -- the 3 x 3 in-plane scan in its usual order --, which then enters the three output slices it belongs to in scan order
+// (as kd = 0 of slice s + 1, kd = 1 of s, kd = 2 of s - 1; `v > best || v != v` at both levels: the first maximum still wins, a NaN still takes over as in the
+// flat scan).  3 (TD + 2) / TD row loads per output quad instead of 9, and 48 instead of 108 compare-selects.  Identical outputs and indices.
+__global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4d_kernel(const float* __restrict__ X, float* __restrict__ Y, int* __restrict__ arg,
+                                                                  PoolGeom q, int64_t planes, int TD, int nchunk, FastDiv dOHW4, FastDiv dOW4) {
+    const int osz = q.OD * q.OH * q.OW, ow4 = q.OW >> 2, ohw4 = q.OH * ow4, per = nchunk * ohw4;
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* x = X + p * osz;
+        for (int e0 = blockIdx.x * 256 + (threadIdx.x & ~63); e0 < per; e0 += gridDim.x * 256) {        // whole waves (neighbour columns across lanes)
+            const bool live = e0 + lane < per;
+            const int e = live ? e0 + lane : per - 1;
+            const int ck = fdiv(e, dOHW4), r = e - ck * ohw4, oh = fdiv(r, dOW4), ow0 = (r - oh * ow4) << 2;
+            const int d0 = ck * TD, d1 = min(d0 + TD, q.OD), w0 = ow0 - 1;
+            const bool inl = w0 >= 0, inr = ow0 + 4 < q.IW;
+            float b0[4], b1[4]; int i0[4], i1[4];                 // output slices s - 1 (waiting for kd = 2) and s (waiting for kd = 1, 2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { b0[j] = b1[j] = -INFINITY; i0[j] = i1[j] = -1; }
+            for (int sl = d0 - 1; sl <= d1; ++sl) {
+                const bool okd = (unsigned)sl < (unsigned)q.ID;
+                float sv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int si[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int ih = oh - 1 + kh; const bool ok = okd && (unsigned)ih < (unsigned)q.IH;
+                    const int rowbase = ((ok ? sl : 0) * q.IH + (ok ? ih : 0)) * q.IW;
+                    const float4 m = *reinterpret_cast<const float4*>(x + rowbase + ow0);
+                    float vl = __shfl_up(m.w, 1), vr = __shfl_down(m.x, 1);
+                    if (lane == 0 && inl) vl = x[rowbase + w0];
+                    if (lane == 63 && inr) vr = x[rowbase + ow0 + 4];
+                    float v[6]; bool in[6];
+                    in[0] = ok && inl; in[5] = ok && inr; in[1] = in[2] = in[3] = in[4] = ok;
+                    v[0] = in[0] ? vl : 0.f; v[5] = in[5] ? vr : 0.f;
+                    v[1] = ok ? m.x : 0.f; v[2] = ok ? m.y : 0.f; v[3] = ok ? m.z : 0.f; v[4] = ok ? m.w : 0.f;      // zero padding
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float val = v[j + kw];
+                            if (val > sv[j] || val != val) { sv[j] = val; si[j] = in[j + kw] ? rowbase + w0 + j + kw : -1; }
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (sv[j] > b0[j] || sv[j] != sv[j]) { b0[j] = sv[j]; i0[j] = si[j]; }                 // kd = 2 of output slice sl - 1: complete
+                    if (sv[j] > b1[j] || sv[j] != sv[j]) { b1[j] = sv[j]; i1[j] = si[j]; }                 // kd = 1 of output slice sl
+                }
+                if (live && sl - 1 >= d0 && sl - 1 < d1) {
+                    const int64_t o = p * osz + ((sl - 1) * q.OH + oh) * q.OW + ow0;
+                    *reinterpret_cast<float4*>(Y + o) = make_float4(b0[0], b0[1], b0[2], b0[3]);
+                    *reinterpret_cast<int4*>(arg + o) = make_int4(i0[0], i0[1], i0[2], i0[3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                      // rotate: slice sl becomes "sl - 1"; slice sl + 1 starts with this input slice as its kd = 0
+                    b0[j] = b1[j]; i0[j] = i1[j];
+                    const bool take = sv[j] > -INFINITY || sv[j] != sv[j];
+                    b1[j] = take ? sv[j] : -INFINITY; i1[j] = take ? si[j] : -1;
+                }
+            }
+        }
+    }
+}
+// ... and its gather: a thread owns four adjacent input cells for TD consecutive slices and walks the TD + 2 window slices that can cover them once (three rows of
+// (arg, gradient) per slice, six window columns each); a window slice s feeds the cells of slices s + 1, s, s - 1 -- so a cell still receives its windows in
+// (od, oh, ow) order.  6 (TD + 2) / TD row loads per cell quad instead of 18.
+__global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4d_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
+                                                                  PoolGeom q, int64_t planes, int TD, int nchunk, FastDiv dIHW4, FastDiv dIW4) {
+    const int isz = q.ID * q.IH * q.IW, iw4 = q.IW >> 2, ihw4 = q.IH * iw4, per = nchunk * ihw4, hw = q.IH * q.IW;
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
+        const float* g = dY + p * isz; const int* a = arg + p * isz;
+        for (int e0 = blockIdx.x * 256 + (threadIdx.x & ~63); e0 < per; e0 += gridDim.x * 256) {
+            const bool live = e0 + lane < per;
+            const int e = live ? e0 + lane : per - 1;
+            const int ck = fdiv(e, dIHW4), r = e - ck * ihw4, ih = fdiv(r, dIW4), iw0 = (r - ih * iw4) << 2;
+            const int d0 = ck * TD, d1 = min(d0 + TD, q.ID);
+            const int lrow = ih * q.IW + iw0;                       // li0 of cell slice d = d * hw + lrow
+            const bool inl = iw0 >= 1, inr = iw0 + 4 < q.OW;
+            float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};       // cell slices s - 1 (waiting for its last window slice) and s
+            for (int sl = d0 - 1; sl <= d1; ++sl) {
+                const bool okd = (unsigned)sl < (unsigned)q.OD;
+                float a2[4] = {0.f, 0.f, 0.f, 0.f};                 // cell slice sl + 1: this window slice is its first
+                const int lm = (sl - 1) * hw + lrow, lc = lm + hw, lp = lc + hw;        // li0 of the cell slices sl - 1, sl, sl + 1
+#pragma unroll
+                for (int y = 0; y < 3; ++y) {
+                    const int oh = ih - 1 + y; const bool ok = okd && (unsigned)oh < (unsigned)q.OH;
+                    const int rowo = ((ok ? sl : 0) * q.OH + (ok ? oh : 0)) * q.OW;
+                    const int4 am = *reinterpret_cast<const int4*>(a + rowo + iw0);
+                    const float4 gm = *reinterpret_cast<const float4*>(g + rowo + iw0);
+                    int al = __shfl_up(am.w, 1), ar = __shfl_down(am.x, 1);
+                    float gl = __shfl_up(gm.w, 1), gr = __shfl_down(gm.x, 1);
+                    if (lane == 0 && inl) { al = a[rowo + iw0 - 1]; gl = g[rowo + iw0 - 1]; }
+                    if (lane == 63 && inr) { ar = a[rowo + iw0 + 4]; gr = g[rowo + iw0 + 4]; }
+                    int av[6]; float gv[6];
+                    av[0] = al; gv[0] = (ok && inl) ? gl : 0.f;
+                    av[5] = ar; gv[5] = (ok && inr) ? gr : 0.f;
+                    av[1] = am.x; av[2] = am.y; av[3] = am.z; av[4] = am.w;
+                    gv[1] = ok ? gm.x : 0.f; gv[2] = ok ? gm.y : 0.f; gv[3] = ok ? gm.z : 0.f; gv[4] = ok ? gm.w : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) {
+                        const int jm = av[t] - lm, jc = av[t] - lc, jp = av[t] - lp;
+#pragma unroll
+                        for (int c = (t >= 2 ? t - 2 : 0); c <= (t <= 3 ? t : 3); ++c) {
+                            a0[c] += jm == c ? gv[t] : 0.f; a1[c] += jc == c ? gv[t] : 0.f; a2[c] += jp == c ? gv[t] : 0.f;
+                        }
+                    }
+                }
+                if (live && sl - 1 >= d0 && sl - 1 < d1) *reinterpret_cast<float4*>(dX + p * isz + lm) = make_float4(a0[0], a0[1], a0[2], a0[3]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { a0[c] = a1[c]; a1[c] = a2[c]; }
+            }
+        }
+    }
+}
+
 // gather form: an input cell sums the gradients of the windows whose arg-max it is.  S2 = true: strides (1 or 2, 2, 2) known at compile time
 // (the down-sampling pools of I3D: the window-range divisions become shifts); grid (chunks of a plane, planes), multiply-high decomposition.
 template <bool S2>
 __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
-                                                            PoolGeom q, int64_t planes, FastDiv dIHW, FastDiv dIW) {
+                                                            PoolGeom q, int64_t planes, FastDiv dIHW, FastDiv dIW, const float* __restrict__ addend) {
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, ihw = q.IH * q.IW;
     const int sd = q.sd, sh = S2 ? 2 : q.sh, sw = S2 ? 2 : q.sw;
     for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
@@ -774,7 +888,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
                 const int rowo = (od * q.OH + oh) * q.OW;
                 for (int ow = w0; ow <= w1; ++ow) if (a[rowo + ow] == li) acc += g[rowo + ow];
             }
-            dX[p * isz + li] = acc;
+            dX[p * isz + li] = addend ? addend[p * isz + li] + acc : acc;
         }
     }
 }
@@ -784,7 +898,7 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_kernel(const float* __restr
 // is the whole test -- 6 .. 12 probes for four cells instead of 16 .. 32, no per-cell range arithmetic.  Accumulation order (od, oh, ow) as in the
 // generic gather.
 __global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __restrict__ dY, const int* __restrict__ arg, float* __restrict__ dX,
-                                                                 PoolGeom q, int64_t planes, FastDiv dIHW4, FastDiv dIW4) {
+                                                                 PoolGeom q, int64_t planes, FastDiv dIHW4, FastDiv dIW4, const float* __restrict__ addend) {
     const int osz = q.OD * q.OH * q.OW, isz = q.ID * q.IH * q.IW, iw4 = q.IW >> 2, ihw4 = q.IH * iw4, isz4 = q.ID * ihw4;
     for (int64_t p = blockIdx.y; p < planes; p += gridDim.y) {
         const float* g = dY + p * osz; const int* a = arg + p * osz;
@@ -814,6 +928,10 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __
             for (int t = 0; t < 12; ++t) {
                 const int j = jv[t]; const float gv = gvv[t];
                 a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
+            }
+            if (addend) {                                        // r05: the gradient of the input's OTHER consumers (the pooled tensor is an FPN endpoint), added here
+                const float4 ad = *reinterpret_cast<const float4*>(addend + p * isz + li0);          // instead of by an accumulation kernel of autograd's (2.4 GB of traffic at cfg5)
+                a0 += ad.x; a1 += ad.y; a2 += ad.z; a3 += ad.w;
             }
             *reinterpret_cast<float4*>(dX + p * isz + li0) = make_float4(a0, a1, a2, a3);
         }
@@ -848,10 +966,8 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4_kernel(const float* __
                     const float4 gm = *reinterpret_cast<const float4*>(g + rowo + iw0);
                     int al = __shfl_up(am.w, 1), ar = __shfl_down(am.x, 1);
                     float gl = __shfl_up(gm.w, 1), gr = __shfl_down(gm.x, 1);
-                    const int eo = rowo + ((lane == 0 && inl) ? iw0 - 1 : (lane == 63 && inr) ? iw0 + 4 : iw0);       // one unconditional edge load per array (see the forward)
-                    const int ae = a[eo]; const float ge = g[eo];
-                    if (lane == 0 && inl) { al = ae; gl = ge; }
-                    if (lane == 63 && inr) { ar = ae; gr = ge; }
+                    if (lane == 0 && inl) { al = a[rowo + iw0 - 1]; gl = g[rowo + iw0 - 1]; }
+                    if (lane == 63 && inr) { ar = a[rowo + iw0 + 4]; gr = g[rowo + iw0 + 4]; }
                     int av[6]; float gv[6];
                     av[0] = al; gv[0] = (ok && inl) ? gl : 0.f;
                     av[5] = ar; gv[5] = (ok && inr) ? gr : 0.f;
@@ -946,7 +1062,7 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __
     const int cells = (d1 - d0) * hw;
     for (int c = threadIdx.x; c < cells; c += 256) {
         const int zd = fdiv(c, dHW), r2 = c - zd * hw, oh = fdiv(r2, dW), ow = r2 - oh * q.IW, od = d0 + zd;
-        int lis[27]; bool ins[27]; float vs[27];
+        float best = -INFINITY; int bi = -1;                  // (requesting all 27 taps before the compare chain measured SLOWER here: 96 against 70 us on 24 x 14 x 14, r05_d)
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
             const int id = od - 1 + kd; const bool okd = (unsigned)id < (unsigned)q.ID;
@@ -956,19 +1072,12 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_slab_kernel(const float* __
                 const int rowbase = (id * q.IH + ih) * q.IW;
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const int iw = ow - 1 + kw, t = (kd * 3 + kh) * 3 + kw;
-                    ins[t] = okh && (unsigned)iw < (unsigned)q.IW;
-                    lis[t] = rowbase + iw;
+                    const int iw = ow - 1 + kw; const bool in = okh && (unsigned)iw < (unsigned)q.IW;
+                    const int li = rowbase + iw;
+                    const float v = in ? sx[li - base] : 0.f;            // zero padding
+                    if (v > best || v != v) { best = v; bi = in ? li : -1; }
                 }
             }
-        }
-#pragma unroll
-        for (int t = 0; t < 27; ++t) vs[t] = sx[ins[t] ? lis[t] - base : 0];      // all 27 taps requested back to back (clamped addresses)
-        float best = -INFINITY; int bi = -1;
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-            const float v = ins[t] ? vs[t] : 0.f;                                  // zero padding
-            if (v > best || v != v) { best = v; bi = ins[t] ? lis[t] : -1; }
         }
         const int64_t o = p * isz + (int64_t)d0 * hw + c;
         Y[o] = best; arg[o] = bi;
@@ -1252,6 +1361,13 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
             return check_launch("segx_maxpool3d_fwd/slab");
         }
     }
+    if (s1w4 && q.KD == 3 && pool_is_s1k3_same(q) && kget(knobs().pool_dslide) != 0 && q.ID >= 4) {           // r05: sliding along depth (knob 15 = 0 keeps the per-slice form)
+        const int ow4 = q.OW / 4, td = q.ID >= 16 ? 8 : q.ID >= 8 ? 4 : 2, nchunk = ceil_div(q.ID, td);
+        const int64_t per = (int64_t)nchunk * q.OH * ow4;
+        const dim3 gridd((unsigned)i64min(4096, (per + 255) / 256), (unsigned)i64min(65535, planes));
+        hipLaunchKernelGGL(maxpool3d_fwd_s1w4d_kernel, gridd, dim3(256), 0, stream, X, Y, arg, q, planes, td, nchunk, make_fastdiv(q.OH * ow4), make_fastdiv(ow4));
+        return check_launch("segx_maxpool3d_fwd/s1w4d");
+    }
     if (s1w4 && (q.KD == 3 || q.KD == 1)) {
         const int ow4 = q.OW / 4;
         const dim3 grid4((unsigned)i64min(4096, (osz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
@@ -1263,8 +1379,9 @@ extern "C" int segx_maxpool3d_fwd(const float* X, float* Y, int* arg, int64_t pl
     else hipLaunchKernelGGL((maxpool3d_fwd_kernel<0, 0, 0>), grid, dim3(256), 0, stream, X, Y, arg, q, planes, dOHW, dOW);
     return check_launch("segx_maxpool3d_fwd");
 }
-extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, void* stream_) {
+extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, int64_t planes, const int* geom, const float* addend, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(dY && arg && dX && geom && planes > 0, "segx_maxpool3d_bwd: bad args");
+    SEGX_REQUIRE(!addend || (reinterpret_cast<uintptr_t>(addend) & 15) == 0, "segx_maxpool3d_bwd: unaligned addend");
     const PoolGeom q = make_pool(geom);
     const int64_t total = planes * q.ID * q.IH * q.IW;
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
@@ -1281,6 +1398,13 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
             else hipLaunchKernelGGL((maxpool3d_bwd_slab_kernel<8192>), sgrid, dim3(256), 0, stream, dY, arg, dX, q, td, nslab, make_fastdiv(q.IH * q.IW), make_fastdiv(q.IW));
             return check_launch("segx_maxpool3d_bwd/slab");
         }
+    }
+    if (bs1w4 && q.KD == 3 && pool_is_s1k3_same(q) && kget(knobs().pool_dslide) != 0 && q.ID >= 4) {
+        const int iw4 = q.IW / 4, td = q.ID >= 16 ? 8 : q.ID >= 8 ? 4 : 2, nchunk = ceil_div(q.ID, td);
+        const int64_t per = (int64_t)nchunk * q.IH * iw4;
+        const dim3 gridd((unsigned)i64min(4096, (per + 255) / 256), (unsigned)i64min(65535, planes));
+        hipLaunchKernelGGL(maxpool3d_bwd_s1w4d_kernel, gridd, dim3(256), 0, stream, dY, arg, dX, q, planes, td, nchunk, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
+        return check_launch("segx_maxpool3d_bwd/s1w4d");
     }
     if (bs1w4) {
         const int iw4 = q.IW / 4; const int64_t isz4 = (int64_t)q.ID * q.IH * iw4;
@@ -1302,9 +1426,9 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
         (q.KD + q.sd - 1) / q.sd <= 2) {                      // the kernel probes a fixed 2 x 2 x 3 window set
         const int iw4 = q.IW / 4;
         const dim3 grid4((unsigned)i64min(4096, (isz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
-        hipLaunchKernelGGL(maxpool3d_bwd_s2w4_kernel, grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
-    } else if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2)) hipLaunchKernelGGL((maxpool3d_bwd_kernel<true>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
-    else hipLaunchKernelGGL((maxpool3d_bwd_kernel<false>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW);
+        hipLaunchKernelGGL(maxpool3d_bwd_s2w4_kernel, grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4), addend);
+    } else if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2)) hipLaunchKernelGGL((maxpool3d_bwd_kernel<true>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW, addend);
+    else hipLaunchKernelGGL((maxpool3d_bwd_kernel<false>), grid, dim3(256), 0, stream, dY, arg, dX, q, planes, dIHW, dIW, addend);
     return check_launch("segx_maxpool3d_bwd");
 }
 /* wt_ws: Cout*Cin*KV floats of scratch (the filters are re-laid out tap-major once per call) */

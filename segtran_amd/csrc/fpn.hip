@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void interp_fwd_axis2_kernel(const float* __re
 // consecutive 256-float4 chunks of ONE run (grid (P, B * G), P * CH >= chunks of a run) and reduces them around a pivot (its first value) to one
 // (count, mean, M2) partial: the separate statistics pass over the 2 - 3.5 GB pyramid tensors (gn_stats_stage1: 0.6 / 1.0 ms of the cfg4 / cfg5 step) is gone.
 // Needs per % 256 == 0 (host check): a chunk never straddles two planes' worth of index arithmetic beyond what the plain kernel does.
+template <bool TWO>                                                   // TWO = false: axis 1 is not resized (n1_in == n1_out): the one-axis blend, half the source reads
 __global__ __launch_bounds__(256) void interp_fwd_axis2_stats_kernel(const float* __restrict__ in, const float* __restrict__ base, float* __restrict__ out,
                                                                      int n1_in, int n1_out, int n2_in, int n2_out, int inner4, FastDiv divInner, FastDiv divRow,
                                                                      FastDiv divPer, float s1, float s2, int cpg, int CH, float* __restrict__ parts) {
@@ -382,16 +383,23 @@ __global__ __launch_bounds__(256) void interp_fwd_axis2_stats_kernel(const float
         const int pl = fdiv(e_run, divPer), e = e_run - pl * per;
         const int64_t o = (int64_t)bg * cpg + pl;
         const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
-        const Axis a1 = axis_src(i1, n1_in, s1), a2 = axis_src(i2, n2_in, s2);
+        const Axis a2 = axis_src(i2, n2_in, s2);
         const float4* s = reinterpret_cast<const float4*>(in) + o * in_per + c;
-        const float4 v00 = s[((int64_t)a1.i0 * n2_in + a2.i0) * inner4], v01 = s[((int64_t)a1.i0 * n2_in + a2.i1) * inner4];
-        const float4 v10 = s[((int64_t)a1.i1 * n2_in + a2.i0) * inner4], v11 = s[((int64_t)a1.i1 * n2_in + a2.i1) * inner4];
-        const float l1 = a1.l, l2 = a2.l;
+        const float l2 = a2.l;
         float4 rr;
-        rr.x = (v00.x * (1.f - l2) + v01.x * l2) * (1.f - l1) + (v10.x * (1.f - l2) + v11.x * l2) * l1;
-        rr.y = (v00.y * (1.f - l2) + v01.y * l2) * (1.f - l1) + (v10.y * (1.f - l2) + v11.y * l2) * l1;
-        rr.z = (v00.z * (1.f - l2) + v01.z * l2) * (1.f - l1) + (v10.z * (1.f - l2) + v11.z * l2) * l1;
-        rr.w = (v00.w * (1.f - l2) + v01.w * l2) * (1.f - l1) + (v10.w * (1.f - l2) + v11.w * l2) * l1;
+        if (TWO) {
+            const Axis a1 = axis_src(i1, n1_in, s1);
+            const float4 v00 = s[((int64_t)a1.i0 * n2_in + a2.i0) * inner4], v01 = s[((int64_t)a1.i0 * n2_in + a2.i1) * inner4];
+            const float4 v10 = s[((int64_t)a1.i1 * n2_in + a2.i0) * inner4], v11 = s[((int64_t)a1.i1 * n2_in + a2.i1) * inner4];
+            const float l1 = a1.l;
+            rr.x = (v00.x * (1.f - l2) + v01.x * l2) * (1.f - l1) + (v10.x * (1.f - l2) + v11.x * l2) * l1;
+            rr.y = (v00.y * (1.f - l2) + v01.y * l2) * (1.f - l1) + (v10.y * (1.f - l2) + v11.y * l2) * l1;
+            rr.z = (v00.z * (1.f - l2) + v01.z * l2) * (1.f - l1) + (v10.z * (1.f - l2) + v11.z * l2) * l1;
+            rr.w = (v00.w * (1.f - l2) + v01.w * l2) * (1.f - l1) + (v10.w * (1.f - l2) + v11.w * l2) * l1;
+        } else {                                                      // the blend of interp_fwd_axis_kernel<true> along axis 2 (slice i1 of the source = slice i1 of the output)
+            const float4 v0 = s[((int64_t)i1 * n2_in + a2.i0) * inner4], v1 = s[((int64_t)i1 * n2_in + a2.i1) * inner4];
+            rr = make_float4(v0.x * (1.f - l2) + v1.x * l2, v0.y * (1.f - l2) + v1.y * l2, v0.z * (1.f - l2) + v1.z * l2, v0.w * (1.f - l2) + v1.w * l2);
+        }
         const int64_t ob = o * per + e;
         if (base) { const float4 bv = reinterpret_cast<const float4*>(base)[ob]; rr.x += bv.x; rr.y += bv.y; rr.z += bv.z; rr.w += bv.w; }
         reinterpret_cast<float4*>(out)[ob] = rr;
@@ -447,8 +455,8 @@ __global__ __launch_bounds__(256) void interp_bwd_axis2_kernel(const float* __re
 // loads, each under its own branch, per cell at f = 2 -- the loads of one cell waited for each other (3.3 TB/s over the cfg5 pyramid).  Here a lane first
 // collects the <= MAXC contributors (index, weight) of each axis in ascending order -- the order the loop above adds them in -- then requests the MAXC float4
 // of one d2 column back to back (indices past the list repeat its first entry with weight 0: x + 0 * v == x) and blends.  Same sums in the same order.
-// MAXC = 4 serves ratios up to 2, MAXC = 8 up to 4; anything else keeps the kernel above (host check: interp_contributors).
-template <int MAXC>
+// A list of 4 serves ratios up to 2, of 8 up to 4 (chosen per axis); anything else keeps the kernel above (host check: interp_contributors).
+template <int MAXC1, int MAXC2>
 __global__ __launch_bounds__(256) void interp_bwd_axis2_fixed_kernel(const float* __restrict__ dout, float* __restrict__ din, int n1_out, int n1_in, int n2_out,
                                                                      int n2_in, int inner4, FastDiv divInner, FastDiv divRow, FastDiv divPer, float s1, float s2,
                                                                      int64_t outer) {
@@ -462,38 +470,42 @@ __global__ __launch_bounds__(256) void interp_bwd_axis2_fixed_kernel(const float
         const int i1 = fdiv(e, divRow), r = e - i1 * row, i2 = fdiv(r, divInner), c = r - i2 * inner4;
         int lo1, hi1, lo2, hi2;
         cand_range(i1, n1_out, s1, lo1, hi1); cand_range(i2, n2_out, s2, lo2, hi2);
-        int d1s[MAXC], d2s[MAXC]; float w1s[MAXC], w2s[MAXC];
+        int d1s[MAXC1], d2s[MAXC2]; float w1s[MAXC1], w2s[MAXC2];
         int c1 = 0, c2 = 0;
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) { d1s[k] = lo1; w1s[k] = 0.f; d2s[k] = lo2; w2s[k] = 0.f; }
+        for (int k = 0; k < MAXC1; ++k) { d1s[k] = lo1; w1s[k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < MAXC2; ++k) { d2s[k] = lo2; w2s[k] = 0.f; }
         for (int d = lo1; d <= hi1; ++d) {                   // <= 2 f + 4 weight evaluations per axis, no loads
             const float w = axis_weight(i1, d, n1_in, s1);
-            if (w != 0.f && c1 < MAXC) {
+            if (w != 0.f && c1 < MAXC1) {
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k) if (k == c1) { d1s[k] = d; w1s[k] = w; }
+                for (int k = 0; k < MAXC1; ++k) if (k == c1) { d1s[k] = d; w1s[k] = w; }
                 ++c1;
             }
         }
         for (int d = lo2; d <= hi2; ++d) {
             const float w = axis_weight(i2, d, n2_in, s2);
-            if (w != 0.f && c2 < MAXC) {
+            if (w != 0.f && c2 < MAXC2) {
 #pragma unroll
-                for (int k = 0; k < MAXC; ++k) if (k == c2) { d2s[k] = d; w2s[k] = w; }
+                for (int k = 0; k < MAXC2; ++k) if (k == c2) { d2s[k] = d; w2s[k] = w; }
                 ++c2;
             }
         }
 #pragma unroll
-        for (int k = 0; k < MAXC; ++k) { if (k >= c1) d1s[k] = d1s[0]; if (k >= c2) d2s[k] = d2s[0]; }
+        for (int k = 0; k < MAXC1; ++k) if (k >= c1) d1s[k] = d1s[0];
+#pragma unroll
+        for (int k = 0; k < MAXC2; ++k) if (k >= c2) d2s[k] = d2s[0];
         const float4* g = reinterpret_cast<const float4*>(dout) + o * out_per + c;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int k2 = 0; k2 < MAXC; ++k2) {
-            float4 v[MAXC];
+        for (int k2 = 0; k2 < MAXC2; ++k2) {
+            float4 v[MAXC1];
 #pragma unroll
-            for (int k1 = 0; k1 < MAXC; ++k1) v[k1] = g[((int64_t)d1s[k1] * n2_out + d2s[k2]) * inner4];
+            for (int k1 = 0; k1 < MAXC1; ++k1) v[k1] = g[((int64_t)d1s[k1] * n2_out + d2s[k2]) * inner4];
             float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int k1 = 0; k1 < MAXC; ++k1) { const float w1 = w1s[k1]; col.x += w1 * v[k1].x; col.y += w1 * v[k1].y; col.z += w1 * v[k1].z; col.w += w1 * v[k1].w; }
+            for (int k1 = 0; k1 < MAXC1; ++k1) { const float w1 = w1s[k1]; col.x += w1 * v[k1].x; col.y += w1 * v[k1].y; col.z += w1 * v[k1].z; col.w += w1 * v[k1].w; }
             const float w2 = w2s[k2];
             acc.x += w2 * col.x; acc.y += w2 * col.y; acc.z += w2 * col.z; acc.w += w2 * col.w;
         }
@@ -673,6 +685,7 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 9) { if (value < 8 || value > 4096 || value % 8) return -1; k.ws_grid = value; return 0; }
     if (knob == 5) { return k.x6_launches.exchange(0); }
     if (knob == 14) { if (value < 0 || value > 2) return -1; k.pool_slab = value; return 0; }
+    if (knob == 15) { if (value != 0 && value != 1) return -1; k.pool_dslide = value; return 0; }
     if (knob == 12) { if (value < 32 || value > (1 << 24)) return -1; k.team_spin = value; return 0; }     // poll bound of a team exchange
     if (knob == 13) { if (value < 0 || value > 4096) return -1; k.team_drop = value; return 0; }          // fault injection (tests): unlaunched tail of a team grid
     return -1;
@@ -760,9 +773,11 @@ extern "C" int segx_interp_linear_fwd_axis2_gn(const float* in, const float* bas
     const int64_t in4 = inner / 4, per = (int64_t)n1_out * n2_out * in4;
     SEGX_REQUIRE((int64_t)n1_in * n2_in * in4 < 2147483647LL && outer / cpg <= 65535, "segx_interp_linear_fwd_axis2_gn: slice too large");
     SEGX_REQUIRE(nparts > 0 && nparts == segx_interp_gn_nparts(per, cpg), "segx_interp_linear_fwd_axis2_gn: nparts %d is not segx_interp_gn_nparts(%lld, %d)", nparts, (long long)per, cpg);
-    hipLaunchKernelGGL(interp_fwd_axis2_stats_kernel, dim3((unsigned)nparts, (unsigned)(outer / cpg)), dim3(256), 0, stream, in, base, out, n1_in, n1_out, n2_in,
-                       n2_out, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_out * in4)), make_fastdiv((int)per), (float)n1_in / (float)n1_out,
-                       (float)n2_in / (float)n2_out, cpg, interp_gn_ch(per, cpg), parts);
+#define SEGX_AX2S_ARGS in, base, out, n1_in, n1_out, n2_in, n2_out, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_out * in4)), make_fastdiv((int)per), \
+                       (float)n1_in / (float)n1_out, (float)n2_in / (float)n2_out, cpg, interp_gn_ch(per, cpg), parts
+    if (n1_in != n1_out) hipLaunchKernelGGL((interp_fwd_axis2_stats_kernel<true>), dim3((unsigned)nparts, (unsigned)(outer / cpg)), dim3(256), 0, stream, SEGX_AX2S_ARGS);
+    else hipLaunchKernelGGL((interp_fwd_axis2_stats_kernel<false>), dim3((unsigned)nparts, (unsigned)(outer / cpg)), dim3(256), 0, stream, SEGX_AX2S_ARGS);
+#undef SEGX_AX2S_ARGS
     return check_launch("segx_interp_linear_fwd_axis2_gn");
 }
 extern "C" int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64_t outer, int n1_out, int n1_in, int n2_out, int n2_in, int64_t inner, void* stream_) {
@@ -770,12 +785,15 @@ extern "C" int segx_interp_linear_bwd_axis2(const float* dout, float* din, int64
     SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(din)) & 15) == 0, "segx_interp_linear_bwd_axis2: alignment");
     const int64_t in4 = inner / 4, per = (int64_t)n1_in * n2_in * in4, total = outer * per;
     SEGX_REQUIRE(per < 2147483647LL - 256 && (int64_t)n1_out * n2_out * in4 < 2147483647LL, "segx_interp_linear_bwd_axis2: slice too large");
-    const int nc = interp_contributors(n1_in, n1_out) > interp_contributors(n2_in, n2_out) ? interp_contributors(n1_in, n1_out) : interp_contributors(n2_in, n2_out);
+    const int nc1 = interp_contributors(n1_in, n1_out), nc2 = interp_contributors(n2_in, n2_out);
+    const bool fixed = kget(knobs().interp_variant) != 1 && nc1 <= 8 && nc2 <= 8;
     const dim3 grid((unsigned)i64min(1 << 20, (total + 255) / 256));
 #define SEGX_AXIS2_ARGS dout, din, n1_out, n1_in, n2_out, n2_in, (int)in4, make_fastdiv((int)in4), make_fastdiv((int)(n2_in * in4)), make_fastdiv((int)per), \
                         (float)n1_in / (float)n1_out, (float)n2_in / (float)n2_out, outer
-    if (nc <= 4 && kget(knobs().interp_variant) != 1) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<4>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
-    else if (nc <= 8 && kget(knobs().interp_variant) != 1) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<8>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    if (fixed && nc1 <= 4 && nc2 <= 4) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<4, 4>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    else if (fixed && nc1 <= 4) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<4, 8>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    else if (fixed && nc2 <= 4) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<8, 4>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
+    else if (fixed) hipLaunchKernelGGL((interp_bwd_axis2_fixed_kernel<8, 8>), grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
     else hipLaunchKernelGGL(interp_bwd_axis2_kernel, grid, dim3(256), 0, stream, SEGX_AXIS2_ARGS);
 #undef SEGX_AXIS2_ARGS
     return check_launch("segx_interp_linear_bwd_axis2");

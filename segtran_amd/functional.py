@@ -1073,9 +1073,12 @@ class _UpGN(torch.autograd.Function):
 
 
 def _interp_bwd_yz_x(L, dy, planes, d, h, w, D, H, W):
-    """adjoint of the x pass + fused y/z pass: z and y in one pass, then x (13 instead of 21 coarse-tensor sizes)"""
+    """adjoint of the x pass + fused y/z pass: z and y in one pass, then x (13 instead of 21 coarse-tensor sizes); d == D: the y adjoint alone"""
     cur = _empty(dy, planes * d * h * W)
-    L.interp_bwd_axis2(dy, cur, planes, D, d, H, h, W)
+    if d == D:
+        L.interp_bwd_axis(dy, cur, planes * D, H, h, W, 0.0)
+    else:
+        L.interp_bwd_axis2(dy, cur, planes, D, d, H, h, W)
     if w != W:
         nxt = _empty(dy, planes * d * h * w)
         L.interp_bwd_axis(cur, nxt, planes * d * h, W, w, 1, 0.0)
@@ -1092,7 +1095,7 @@ def up_group_norm(x, size, base, gn):
         d, h, _ = _dhw(x.shape[2:])
         D, H, W = _dhw(size)
         C = x.shape[1]
-        if d != D and h != H and W % 4 == 0 and C % G == 0 and tuple(base.shape) == (x.shape[0], C) + size:
+        if h != H and W % 4 == 0 and C % G == 0 and tuple(base.shape) == (x.shape[0], C) + size:        # y resized (z too, or not: the 64 x 32 x 32 -> 64^3 level)
             nparts = segx.lib().interp_gn_nparts(D * H * (W // 4), C // G)
             if nparts > 0:
                 return _UpGN.apply(x, base, gn.weight, gn.bias, size, G, float(gn.eps), nparts)
@@ -1395,8 +1398,13 @@ def bridge_input(x, Cc=8):
 
 
 class _MaxPool3d(torch.autograd.Function):
+    """pass_input: also return the input as a second output (an alias).  Where the pooled tensor has other consumers -- the I3D endpoints feats[1..3] feed the next
+    backbone stage through a strided pool AND the feature pyramid (segtran3d.py:436-441) -- they read the alias: autograd then hands their summed gradient to THIS
+    node, and the pool's backward kernel adds it while it writes dX (segx_maxpool3d_bwd addend) instead of autograd running an accumulation kernel over two
+    full-size tensors (0.68 ms of the cfg5 step)."""
+
     @staticmethod
-    def forward(ctx, x, kernel, stride, pads):
+    def forward(ctx, x, kernel, stride, pads, pass_input=False):
         L = segx.lib()
         x = _c(x)
         B, C, ID, IH, IW = x.shape
@@ -1409,22 +1417,37 @@ class _MaxPool3d(torch.autograd.Function):
         geom = (ID, IH, IW, OD, OH, OW) + tuple(kernel) + tuple(stride) + (pd, ph, pw)
         L.maxpool3d_fwd(x, y, arg, B * C, geom)
         ctx.geom, ctx.xshape = geom, tuple(x.shape)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(arg)
+        if pass_input:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dalias=None):
         L = segx.lib()
         (arg,) = ctx.saved_tensors
+        if dy is None:                                           # only the alias was used
+            return dalias, None, None, None, None
         dx = _empty(dy, *ctx.xshape)
-        L.maxpool3d_bwd(_c(dy), arg, dx, ctx.xshape[0] * ctx.xshape[1], ctx.geom)
-        return dx, None, None, None
+        addend = None
+        if dalias is not None:
+            addend = _c(dalias)
+            if tuple(ctx.geom[9:12]) == (1, 1, 1) or addend.data_ptr() % 16:      # the stride-1 kernels take no addend
+                addend = None
+        L.maxpool3d_bwd(_c(dy), arg, dx, ctx.xshape[0] * ctx.xshape[1], ctx.geom, addend)
+        if dalias is not None and addend is None:
+            dx = dx + dalias
+        return dx, None, None, None, None
 
 
-def maxpool3d_same(x, kernel, stride):
-    """MaxPool3dSamePadding (aj_i3d.py:6-30)."""
+def maxpool3d_same(x, kernel, stride, pass_input=False):
+    """MaxPool3dSamePadding (aj_i3d.py:6-30).  pass_input: -> (y, x_alias), see _MaxPool3d."""
     kernel, stride = tuple(int(k) for k in kernel), tuple(int(s) for s in stride)
-    return _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride))
+    if pass_input and x.requires_grad and torch.is_grad_enabled():
+        return _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride), True)
+    y = _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride))
+    return (y, x) if pass_input else y
 
 
 def conv2d_dense(x, w, stride, pad):

@@ -18,8 +18,8 @@ from ... import functional as SF
 
 
 class MaxPool3dSamePadding(nn.MaxPool3d):
-    def forward(self, x):
-        return SF.maxpool3d_same(x, self.kernel_size, self.stride)             # libsegx: zero 'same' padding + max-pool
+    def forward(self, x, pass_input=False):
+        return SF.maxpool3d_same(x, self.kernel_size, self.stride, pass_input)  # libsegx: zero 'same' padding + max-pool (pass_input: -> (y, alias of x))
 
 
 class Unit3D(nn.Module):
@@ -119,12 +119,20 @@ class InceptionI3d(nn.Module):
 
     def extract_features(self, x, stem_conv_out=None):
         """stem_conv_out: output of the (bias-free) stem convolution computed by the caller; `x` is then not read."""
-        feat = {}
+        feat, prev = {}, None
         for name in self.VALID_ENDPOINTS:
             if name in self.end_points:
+                m = self._modules[name]
                 if name == 'Conv3d_1a_7x7' and stem_conv_out is not None:
-                    x = self._modules[name](None, conv_out=stem_conv_out)
+                    x = m(None, conv_out=stem_conv_out)
+                elif isinstance(m, MaxPool3dSamePadding) and prev in self.pyramid_endpoints and tuple(m.stride) != (1, 1, 1):
+                    # the pooled tensor is also an endpoint the feature pyramid reads (segtran3d.py:436-441): the pyramid gets an alias, so that its gradient
+                    # reaches the pool's backward kernel and is added there (SF._MaxPool3d) -- no accumulation kernel over two full-size tensors
+                    x, feat[prev] = m(x, pass_input=True)
                 else:
-                    x = self._modules[name](x)
+                    x = m(x)
                 feat[name] = x
+                prev = name
         return feat
+
+    pyramid_endpoints = ('Conv3d_2c_3x3', 'Mixed_3c', 'Mixed_4f')      # feats[1..3] of Segtran3d (each is followed by a strided pool)

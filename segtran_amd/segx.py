@@ -524,9 +524,10 @@ class SegxLib:
         rc = self.c.segx_maxpool3d_fwd(_ptr(X), _ptr(Y), _ptr(arg), planes, self._geom(geom), self.stream(Y))
         self.check(rc, 'segx_maxpool3d_fwd')
 
-    def maxpool3d_bwd(self, dY, arg, dX, planes, geom):
-        self._chk_t(dY, arg, dX)
-        rc = self.c.segx_maxpool3d_bwd(_ptr(dY), _ptr(arg), _ptr(dX), planes, self._geom(geom), self.stream(dX))
+    def maxpool3d_bwd(self, dY, arg, dX, planes, geom, addend=None):
+        self._chk_t(dY, arg, dX, addend)
+        assert addend is None or (addend.is_contiguous() and addend.shape == dX.shape)
+        rc = self.c.segx_maxpool3d_bwd(_ptr(dY), _ptr(arg), _ptr(dX), planes, self._geom(geom), _ptr(addend), self.stream(dX))
         self.check(rc, 'segx_maxpool3d_bwd')
 
     def dropout(self, x, y, n, p, seed, offset):
@@ -573,7 +574,7 @@ _SIGS = {
     'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
-    'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplpp',
+    'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplppp',
     'segx_bn_ws_floats': 'iil', 
     'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',

@@ -409,6 +409,8 @@ def test_group_norm_backward_also_returns_the_plane_sums_of_its_input_gradient(b
 
 # (d, h, w) -> (D, H, W) with D * H * W / 4 a multiple of 256 (whole 1024-float chunks per plane: the fused form); the last case is not (falls back to the two ops)
 @pytest.mark.parametrize('B,C,G,insize,size', [(2, 8, 4, (4, 8, 8), (8, 16, 16)), (1, 16, 8, (2, 8, 16), (4, 16, 32)), (2, 8, 2, (8, 4, 4), (16, 8, 16)),
+                                               (2, 8, 4, (8, 8, 8), (8, 16, 16)), (1, 8, 2, (4, 4, 32), (4, 16, 32)),      # depth (and width) not resized: the out_gn2b level
+
                                                (1, 8, 4, (3, 5, 6), (6, 10, 12))])
 def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradient(backend, B, C, G, insize, size):
     """SF.up_group_norm (r05): gn(trilinear-up(x) + conv1x1(f)) with the GroupNorm partials produced by the resampling pass and the lateral convolution's

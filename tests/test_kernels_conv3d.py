@@ -90,6 +90,70 @@ def test_maxpool3d_stride1_slab_form(backend, size, policy):
         assert L.c.segx_tune(14, 0) == 0
 
 
+
+
+@pytest.mark.parametrize('size', [(4, 5, 8), (5, 6, 12), (9, 7, 16), (16, 8, 8), (17, 9, 20), (48, 6, 28), (3, 5, 8), (6, 16, 40)])
+def test_maxpool3d_stride1_depth_sliding_form(backend, size):
+    """segx_tune knob 15: the stride-1 3 x 3 x 3 pools with W % 4 == 0 slide along the depth (a thread keeps its four cells for 2 / 4 / 8 slices and reduces each
+    input slice once) -- outputs, arg-max indices and gradients identical, bit for bit, to the one-slice-per-thread form (knob 15 = 0) and equal to
+    F.max_pool3d; chunk boundaries (D not a multiple of the chunk), D < 4 (falls back), zero windows and a NaN included."""
+    L = backend.L
+    x0 = torch.relu(rnd(2, 2, *size, seed=34))
+    x0[0, 0, :2] = 0.0
+    x0[1, 1, size[0] // 2, size[1] // 2, size[2] // 2] = float('nan')
+    x0[1, 0, -1, -1, -1] = float('nan')
+    B, C = 2, 2
+    D, H, W = size
+    geom = (D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+    G = rnd(B, C, *size, seed=35)
+    outs = {}
+    assert L.c.segx_tune(15, 2) < 0
+    for knob in (1, 0):
+        assert L.c.segx_tune(15, knob) == 0
+        try:
+            y, arg, dx = torch.empty_like(x0), torch.empty(x0.shape, dtype=torch.int32), torch.empty_like(x0)
+            L.maxpool3d_fwd(x0, y, arg, B * C, geom)
+            L.maxpool3d_bwd(G, arg, dx, B * C, geom)
+            outs[knob] = (y, arg, dx)
+        finally:
+            assert L.c.segx_tune(15, 1) == 0
+    assert torch.equal(torch.nan_to_num(outs[1][0], nan=-7.0), torch.nan_to_num(outs[0][0], nan=-7.0))
+    assert torch.equal(outs[1][1], outs[0][1]) and torch.equal(outs[1][2], outs[0][2])
+    xr = x0.clone().requires_grad_(True)
+    yr = F.max_pool3d(F.pad(xr, (1, 1, 1, 1, 1, 1)), 3, 1)
+    assert torch.equal(torch.nan_to_num(outs[1][0], nan=-7.0), torch.nan_to_num(yr.detach(), nan=-7.0))
+    yr.backward(G)
+    close(outs[1][2], xr.grad, 1e-6)
+
+
+@pytest.mark.parametrize('size,k,stride', [((4, 8, 8), (1, 3, 3), (1, 2, 2)), ((6, 8, 16), (3, 3, 3), (2, 2, 2)), ((4, 6, 8), (2, 2, 2), (2, 2, 2)), ((5, 7, 9), (3, 3, 3), (2, 2, 2)),
+                                           ((3, 5, 8), (3, 3, 3), (1, 1, 1))])
+def test_maxpool3d_with_input_alias_adds_the_other_consumers_gradient_in_its_backward(backend, size, k, stride):
+    """r05: maxpool3d_same(x, pass_input=True) -> (y, alias): a second consumer of x reads the alias; its gradient reaches the pool node and is added by the
+    backward KERNEL (segx_maxpool3d_bwd addend; four-cell and generic strided gathers) -- or, for a stride-1 pool, by one torch add.  Same numbers as
+    two independent consumers of x, bit for bit (the sum has two terms)."""
+    x = torch.relu(rnd(2, 3, *size, seed=24)).requires_grad_(True)
+    y, xa = SF.maxpool3d_same(x, k, stride, pass_input=True)
+    other = (xa * xa).sum() * 0.5 + xa.sum()
+    G = rnd(*y.shape, seed=25)
+    (y * G).sum().backward(retain_graph=True) if False else ((y * G).sum() + other).backward()
+    xr = x.detach().clone().requires_grad_(True)
+    yr = SF.maxpool3d_same(xr, k, stride)
+    ((yr * G).sum() + (xr * xr).sum() * 0.5 + xr.sum()).backward()
+    assert torch.equal(y, yr.detach()) and torch.equal(x.grad, xr.grad)
+    # only the alias used / only the pooled output used
+    x2 = x.detach().clone().requires_grad_(True)
+    y2, xa2 = SF.maxpool3d_same(x2, k, stride, pass_input=True)
+    (xa2 * 3.0).sum().backward()
+    assert torch.equal(x2.grad, torch.full_like(x2, 3.0))
+    x3 = x.detach().clone().requires_grad_(True)
+    y3, _ = SF.maxpool3d_same(x3, k, stride, pass_input=True)
+    (y3 * G).sum().backward()
+    x4 = x.detach().clone().requires_grad_(True)
+    (SF.maxpool3d_same(x4, k, stride) * G).sum().backward()
+    assert torch.equal(x3.grad, x4.grad)
+
+
 @pytest.mark.parametrize('Cout,k', [(40, (3, 3, 3)), (130, (1, 3, 3)), (8, (7, 7, 7))])
 def test_conv3d_forward_split_k(backend, Cout, k):
     """Forward with the contraction split over 3 slabs (the low-resolution Inception stages) == un-split result; both the
