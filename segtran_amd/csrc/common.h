@@ -295,6 +295,13 @@ inline int kget(const std::atomic<int>& a) { return a.load(std::memory_order_rel
 inline const uint64_t*& rng_base() { static const uint64_t* p = nullptr; return p; }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// Workgroup b of a launch of n runs on XCD b % 8 (observed dispatch order; used for speed only).  xcd_block gives each XCD a CONTIGUOUS run of the launch's
+// logical blocks (bijective for any n), so workgroups that re-read each other's lines -- neighbouring slices of a resampling adjoint, halo rows -- share one
+// XCD's L2 instead of fetching the same line into several (r05_e: the yz adjoint of the 3.5-GB pyramid level moved 14 GB, 4x its input, at the HBM roof).
+__device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned n) {
+    const unsigned q = n >> 3, r = n & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 __host__ __device__ inline int64_t i64min(int64_t a, int64_t b) { return a < b ? a : b; }
 __host__ __device__ inline int64_t i64max(int64_t a, int64_t b) { return a > b ? a : b; }
 

@@ -770,7 +770,8 @@ __global__ __launch_bounds__(256) void maxpool3d_fwd_s1w4d_kernel(const float* _
             float b0[4], b1[4]; int i0[4], i1[4];                 // output slices s - 1 (waiting for kd = 2) and s (waiting for kd = 1, 2)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { b0[j] = b1[j] = -INFINITY; i0[j] = i1[j] = -1; }
-            for (int sl = d0 - 1; sl <= d1; ++sl) {
+            for (int ks = 0; ks < TD + 2; ++ks) {                 // the SAME trip count in every lane (the neighbour columns travel across lanes): slices past d1 store nothing
+                const int sl = d0 - 1 + ks;
                 const bool okd = (unsigned)sl < (unsigned)q.ID;
                 float sv[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}; int si[4] = {-1, -1, -1, -1};
 #pragma unroll
@@ -830,7 +831,8 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s1w4d_kernel(const float* _
             const int lrow = ih * q.IW + iw0;                       // li0 of cell slice d = d * hw + lrow
             const bool inl = iw0 >= 1, inr = iw0 + 4 < q.OW;
             float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};       // cell slices s - 1 (waiting for its last window slice) and s
-            for (int sl = d0 - 1; sl <= d1; ++sl) {
+            for (int ks = 0; ks < TD + 2; ++ks) {                 // the SAME trip count in every lane (the neighbour columns travel across lanes): slices past d1 store nothing
+                const int sl = d0 - 1 + ks;
                 const bool okd = (unsigned)sl < (unsigned)q.OD;
                 float a2[4] = {0.f, 0.f, 0.f, 0.f};                 // cell slice sl + 1: this window slice is its first
                 const int lm = (sl - 1) * hw + lrow, lc = lm + hw, lp = lc + hw;        // li0 of the cell slices sl - 1, sl, sl + 1
@@ -909,25 +911,13 @@ __global__ __launch_bounds__(256) void maxpool3d_bwd_s2w4_kernel(const float* __
             const int dn = id + q.pd - q.KD + 1, hn = ih + q.ph - q.KH + 1, wn = iw0 + q.pw - q.KW + 1;
             const int d0 = dn > 0 ? (q.sd == 1 ? dn : (dn + 1) >> 1) : 0, h0 = hn > 0 ? (hn + 1) >> 1 : 0, w0 = wn > 0 ? (wn + 1) >> 1 : 0;
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            // r05: the <= 2 x 2 x 3 covering windows as a FIXED probe set -- clamped addresses, all index / gradient loads requested before the first use, validity as
-            // a select -- instead of three nested loops with run-time bounds whose loads each waited for the previous one (same (od, oh, ow) order of the sums)
-            int jv[12]; float gvv[12];
-#pragma unroll
-            for (int zz = 0; zz < 2; ++zz)
-#pragma unroll
-                for (int yy = 0; yy < 2; ++yy)
-#pragma unroll
-                    for (int xx = 0; xx < 3; ++xx) {
-                        const int od = d0 + zz, oh = h0 + yy, ow = w0 + xx, t = (zz * 2 + yy) * 3 + xx;
-                        const bool okp = od <= d1 && oh <= h1 && ow <= w1;
-                        const int o = okp ? (od * q.OH + oh) * q.OW + ow : 0;
-                        jv[t] = okp ? a[o] - li0 : -1;
-                        gvv[t] = g[o];
-                    }
-#pragma unroll
-            for (int t = 0; t < 12; ++t) {
-                const int j = jv[t]; const float gv = gvv[t];
-                a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
+            for (int od = d0; od <= d1; ++od) for (int oh = h0; oh <= h1; ++oh) {        // (a fixed 2 x 2 x 3 probe set with clamped addresses measured slower: 323 against 259 us, r05_d)
+                const int rowo = (od * q.OH + oh) * q.OW;
+                for (int ow = w0; ow <= w1; ++ow) {
+                    const int j = a[rowo + ow] - li0;
+                    const float gv = g[rowo + ow];
+                    a0 += j == 0 ? gv : 0.f; a1 += j == 1 ? gv : 0.f; a2 += j == 2 ? gv : 0.f; a3 += j == 3 ? gv : 0.f;
+                }
             }
             if (addend) {                                        // r05: the gradient of the input's OTHER consumers (the pooled tensor is an FPN endpoint), added here
                 const float4 ad = *reinterpret_cast<const float4*>(addend + p * isz + li0);          // instead of by an accumulation kernel of autograd's (2.4 GB of traffic at cfg5)
@@ -1422,8 +1412,7 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     const int isz = q.ID * q.IH * q.IW;
     const dim3 grid((unsigned)i64min(4096, (isz + 255) / 256), (unsigned)i64min(65535, planes));
     const FastDiv dIHW = make_fastdiv(q.IH * q.IW), dIW = make_fastdiv(q.IW);
-    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2) && q.IW % 4 == 0 && isz % 4 == 0 && aligned16c(dX) && q.KW <= 3 && q.KH <= 3 && q.KD <= 3 &&
-        (q.KD + q.sd - 1) / q.sd <= 2) {                      // the kernel probes a fixed 2 x 2 x 3 window set
+    if (q.sh == 2 && q.sw == 2 && (q.sd == 1 || q.sd == 2) && q.IW % 4 == 0 && isz % 4 == 0 && aligned16c(dX) && q.KW <= 3 && q.KH <= 3 && q.KD <= 3 ) {
         const int iw4 = q.IW / 4;
         const dim3 grid4((unsigned)i64min(4096, (isz / 4 + 255) / 256), (unsigned)i64min(65535, planes));
         hipLaunchKernelGGL(maxpool3d_bwd_s2w4_kernel, grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4), addend);

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void interp_bwd_axis2_fixed_kernel(const float
                                                                      int64_t outer) {
     const int row = n2_in * inner4, per = n1_in * row;
     const int64_t total = outer * per, out_per = (int64_t)n1_out * n2_out * inner4;
-    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+    for (int64_t b0 = (int64_t)xcd_block(blockIdx.x, gridDim.x) * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {      // XCD-contiguous runs of blocks (common.h)
         const int64_t ob0 = b0 / per;
         const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
         const int64_t o = ob0 + qo; const int e = e0 - qo * per;
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void interp_bwd_axis4_fixed_kernel(const float
                                                                      int n_out, int n_in, int inner4, FastDiv divInner, FastDiv divPer, float scale) {
     const int per = n_in * inner4;
     const int64_t total = outer * per;
-    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+    for (int64_t b0 = (int64_t)xcd_block(blockIdx.x, gridDim.x) * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {      // XCD-contiguous runs of blocks (common.h)
         const int64_t ob0 = b0 / per;
         const int e0 = (int)(b0 - ob0 * per) + threadIdx.x, qo = fdiv(e0, divPer);
         const int64_t o = ob0 + qo; const int e = e0 - qo * per;
