@@ -846,7 +846,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_rows4_k
                                                            int64_t ngroups) {
     constexpr int NV = Dw4<K, ST>::NV;
     static_assert(PL <= 4 && 4 + 3 * ST + K - 1 - PL < 4 * NV, "window does not fit the loaded float4s");
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> tpr_log2;
+    const int64_t gid = ((int64_t)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) >> tpr_log2;      // XCD-contiguous runs of workgroups (common.h): halo rows shared with the next row group stay in ONE XCD's L2
     if (gid >= ngroups) return;
     const int gpp = tiles_x * tiles_y;
     const int64_t plane = gid / gpp;
@@ -1009,7 +1009,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(4) void dwconv_bwd4s2_
                                                                                    int tiles_x, int tiles_y, int tpr_log2, int64_t ngroups) {
     constexpr int CY = dw_floor_half(PT - K + 1), NQ = (DWB_TY - 1 + PT) / 2 - CY + 1;       // dy rows under 4 dx rows
     static_assert(4 + dw_floor_half(PL - K + 1) >= 0 && 4 + (7 + PL) / 2 < 12, "window does not fit the loaded float4s");
-    const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> tpr_log2;
+    const int64_t gid = ((int64_t)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) >> tpr_log2;      // XCD-contiguous runs of workgroups (common.h): halo rows shared with the next row group stay in ONE XCD's L2
     if (gid >= ngroups) return;
     const int gpp = tiles_x * tiles_y;
     const int64_t plane = gid / gpp;

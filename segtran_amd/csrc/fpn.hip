@@ -272,6 +272,44 @@ __global__ __launch_bounds__(256) void interp_bwd_x4_kernel(const float* __restr
     }
 }
 
+// r05 (second form of the backward x pass): the candidate range and the weights of a cell depend on its column i only, so a thread keeps ONE column for
+// ROWS consecutive rows: the <= 4 x NQ weights (zero where an element of the covered float4s is not a contributor) are evaluated once, and a row costs NQ
+// float4 loads, 4 NQ multiply-adds and a store.  (The per-cell form above evaluates 12 blend weights -- ~200 vector instructions -- per output float:
+// 1.8 TB/s, ALU-bound, r05_f.)  Same terms in the same ascending order with the same weights as interp_bwd_x4_kernel: identical bits.
+template <int NQ, int ROWS>
+__global__ __launch_bounds__(256) void interp_bwd_xcol_kernel(const float* __restrict__ dout, float* __restrict__ din, int n_out, int n_in, FastDiv divN,
+                                                              float scale, int64_t rows) {
+    const int64_t groups = (rows + ROWS - 1) / ROWS, total = groups * n_in;
+    for (int64_t b0 = (int64_t)blockIdx.x * 256; b0 < total; b0 += (int64_t)gridDim.x * 256) {
+        const int64_t g0 = b0 / n_in;
+        const int e0 = (int)(b0 - g0 * n_in) + threadIdx.x, qg = fdiv(e0, divN);
+        const int64_t grp = g0 + qg; const int i = e0 - qg * n_in;
+        if (grp >= groups) continue;
+        int lo, hi; cand_range(i, n_out, scale, lo, hi);
+        const int lo4 = lo & ~3;
+        float w[4 * NQ];
+#pragma unroll
+        for (int t = 0; t < 4 * NQ; ++t) { const int d = lo4 + t; w[t] = (d >= lo && d <= hi) ? axis_weight(i, d, n_in, scale) : 0.f; }
+        const int q0 = lo4 >> 2, qmax = (n_out >> 2) - 1;
+        int qi[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) qi[k] = q0 + k <= qmax ? q0 + k : qmax;          // float4s past the row: clamped, their weights are 0
+        const int64_t r0 = grp * ROWS;
+#pragma unroll
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int64_t row = r0 + rr < rows ? r0 + rr : rows - 1;
+            const float4* g4 = reinterpret_cast<const float4*>(dout + row * n_out);
+            float4 v[NQ];
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) v[k] = g4[qi[k]];
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) { acc += w[4 * k] * v[k].x; acc += w[4 * k + 1] * v[k].y; acc += w[4 * k + 2] * v[k].z; acc += w[4 * k + 3] * v[k].w; }
+            if (r0 + rr < rows) din[row * n_in + i] = acc;
+        }
+    }
+}
+
 // float4 over the inner (contiguous) extent: the candidate range and the blend weights depend on the axis index only
 __global__ __launch_bounds__(256) void interp_bwd_axis4_kernel(const float* __restrict__ dout, float* __restrict__ din, int64_t outer,
                                                                int n_out, int n_in, int inner4, FastDiv divInner, FastDiv divPer, float scale) {
@@ -845,6 +883,14 @@ extern "C" int segx_interp_linear_bwd_axis(const float* dout, float* din, int64_
     const float scale = src_scale != 0.f ? src_scale : (float)n_in / (float)n_out;
     SEGX_REQUIRE((int64_t)n_in * inner < 2147483647LL - 256, "segx_interp_linear_bwd_axis: slice too large");
     if (inner == 1 && n_out % 4 == 0 && (reinterpret_cast<uintptr_t>(dout) & 15) == 0) {        // the contiguous axis itself: candidates read as aligned float4s of the output row
+        // float4s one cell's candidate range can touch: cand_range spans 2 f + 4 outputs (f = n_out / n_in), plus up to 3 for the alignment of its first one
+        // (hi - lo + 1 <= 2 f + 5, + 3 for the alignment of lo: <= ceil((ceil(2 f) + 8) / 4) float4s)
+        const int span4 = src_scale == 0.f && n_out >= n_in ? (int)(((2LL * n_out + n_in - 1) / n_in + 8 + 3) / 4) : 99;
+        if (span4 <= 4 && outer >= 8 && kget(knobs().interp_variant) != 1) {
+            const int64_t tot = ((outer + 7) / 8) * n_in;
+            hipLaunchKernelGGL((interp_bwd_xcol_kernel<4, 8>), dim3((unsigned)i64min(1 << 20, (tot + 255) / 256)), dim3(256), 0, stream, dout, din, n_out, n_in, make_fastdiv(n_in), scale, outer);
+            return check_launch("segx_interp_linear_bwd_axis/xcol");
+        }
         hipLaunchKernelGGL(interp_bwd_x4_kernel, dim3((unsigned)i64min(1 << 20, (total + 255) / 256)), dim3(256), 0, stream, dout, din, n_out, n_in, make_fastdiv(n_in), scale, outer);
         return check_launch("segx_interp_linear_bwd_axis/x4");
     }

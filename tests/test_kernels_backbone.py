@@ -529,10 +529,15 @@ def test_fixed_contributor_adjoints_equal_the_candidate_loops_bit_for_bit(backen
         try:
             g2 = torch.empty(planes * d * h * W); L.interp_bwd_axis2(G, g2, planes, D, d, H, h, W)
             g1 = torch.empty(planes * d * H * W); L.interp_bwd_axis(G, g1, planes, D, d, H * W, 0.0)
-            outs[variant] = (g2, g1)
+            gx = torch.empty(planes * D * H * (W // 4)) if W % 4 == 0 else None          # the contiguous axis (x4 / column-per-thread forms vs the per-cell form)
+            if gx is not None:
+                L.interp_bwd_axis(G, gx, planes * D * H, W, W // 4, 1, 0.0)
+            gy = torch.empty(planes * D * H * (W // 2)); L.interp_bwd_axis(G, gy, planes * D * H, W, W // 2, 1, 0.0)
+            outs[variant] = (g2, g1, gx, gy)
         finally:
             assert L.c.segx_tune(1, 0) == 0
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
 
 
 def test_two_axis_resampling_pass_equals_the_one_axis_passes(backend):
