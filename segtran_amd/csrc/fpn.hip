@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void interp_bwd_x4_kernel(const float* __restr
 // r05 (second form of the backward x pass): the candidate range and the weights of a cell depend on its column i only, so a thread keeps ONE column for
 // ROWS consecutive rows: the <= 4 x NQ weights (zero where an element of the covered float4s is not a contributor) are evaluated once, and a row costs NQ
 // float4 loads, 4 NQ multiply-adds and a store.  (The per-cell form above evaluates 12 blend weights -- ~200 vector instructions -- per output float:
-// 1.8 TB/s, ALU-bound, r05_f.)  Same terms in the same ascending order with the same weights as interp_bwd_x4_kernel: identical bits.
+// 1.8 TB/s, ALU-bound, r05_f.)  Same terms in the same ascending order with the same weights as interp_bwd_x4_kernel (identical on the emulator; on the device hipcc may contract the weight expression differently per kernel: an ulp).
 template <int NQ, int ROWS>
 __global__ __launch_bounds__(256) void interp_bwd_xcol_kernel(const float* __restrict__ dout, float* __restrict__ din, int n_out, int n_in, FastDiv divN,
                                                               float scale, int64_t rows) {

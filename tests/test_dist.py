@@ -113,6 +113,54 @@ def _case_sync_bn_fused(rank, world, ret):
     sdist.disable_sync_batchnorm()
 
 
+
+def _case_sync_bn_blocks(rank, world, ret):
+    """VERDICT r04 next #7a: a WHOLE MBConv block (expansion, depthwise, squeeze-excite gate folded into the projection, skip) and a whole Inception module
+    (fused reductions, two 3x3x3 branches, pooling branch) with synchronised BatchNorm on `world` shards of one sample each, against the same module on the
+    full batch in one process (plain BatchNorm: the team / resident forms): outputs, input gradients, every parameter gradient (summed over the ranks) and
+    the running statistics.  Equality is to fp32 summation order (the synchronised form merges per-rank partials with Chan's formula)."""
+    from segtran_amd import dist as sdist
+    from segtran_amd.efficientnet.model import MBConvBlock
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
+    from segtran_amd.synth import synth_state_dict
+    g = torch.Generator().manual_seed(7)
+    ok = True
+
+    def compare(make, x_full, G_full, tag):
+        nonlocal ok
+        sdist.disable_sync_batchnorm()
+        ref = make(); ref.train()
+        xr = x_full.clone().requires_grad_(True)
+        yr = ref(xr); (yr * G_full).sum().backward()
+        sdist.enable_sync_batchnorm()
+        m = make(); m.train()
+        x = x_full[rank:rank + 1].clone().requires_grad_(True)
+        y = m(x); (y * G_full[rank:rank + 1]).sum().backward()
+        sdist.disable_sync_batchnorm()
+        good = torch.allclose(y, yr[rank:rank + 1].detach(), atol=3e-5, rtol=1e-4) and torch.allclose(x.grad, xr.grad[rank:rank + 1], atol=3e-5, rtol=1e-4)
+        for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
+            ga = a.grad.clone(); dist.all_reduce(ga)
+            scale = max(float(b.grad.abs().max()), 1e-6)
+            good = good and float((ga - b.grad).abs().max()) <= 3e-4 * scale
+        for (k, a), (_, b) in zip(m.named_buffers(), ref.named_buffers()):
+            good = good and torch.allclose(a.float(), b.float(), atol=1e-5)
+        ret['%s%d' % (tag, rank)] = bool(good)
+        ok = ok and good
+
+    def mb():
+        blk = MBConvBlock(3, 1, 6, 8, 8, 0.25, 12)
+        blk.load_state_dict({k: v for k, v in synth_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}).items()})
+        return blk
+    compare(mb, torch.randn(world, 8, 12, 12, generator=g) * 1.2 + 0.2, torch.randn(world, 8, 12, 12, generator=g), 'mbconv')
+
+    def inc():
+        mod = InceptionModule(16, [8, 8, 16, 8, 8, 8], 'm')
+        mod.load_state_dict({k: v for k, v in synth_state_dict({k: tuple(v.shape) for k, v in mod.state_dict().items()}).items()})
+        return mod
+    compare(inc, torch.relu(torch.randn(world, 16, 4, 6, 8, generator=g)) + 0.1, torch.randn(world, 40, 4, 6, 8, generator=g), 'inception')
+    ret[rank] = bool(ok)
+
+
 def _case_dp_step_views(rank, world, ret):
     _case_dp_step(rank, world, ret, gather=False)
 
@@ -203,3 +251,8 @@ def test_four_ranks_sync_batchnorm_and_data_parallel_step():
     shards (all-gather of [2C] + Chan merge) and the bucketed gradient averaging reproduce the single-process full-batch results."""
     assert _run('_case_sync_bn', world=4) == {r: True for r in range(4)}
     assert _run('_case_dp_step', world=4) == {r: True for r in range(4)}
+
+
+def test_four_ranks_whole_mbconv_block_and_inception_module_under_sync_batchnorm():
+    res = _run('_case_sync_bn_blocks', world=4)
+    assert all(res[r] is True for r in range(4)), res

@@ -24,9 +24,10 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device('cuda', 0)
 LABEL_MARGIN = 1e-5
 # fp64 referee: where the fp32 reference itself is further than the tolerance from the fp64 truth, the HIP result may be at most REFEREE x as far from
-# the truth as the fp32 reference is (r04: 3; r05: 1.5 after the full-shape runs of session r05_d passed at 1.5 on both engines and both op orders)
+# the truth as the fp32 reference is (r04: 3; r05: 2.25 -- session r05_g logged all 62 gradients that needed the referee on both engines and op orders,
+# profiles/r05_g_referee.txt: the largest ratio is 2.06, the stem BatchNorm weight of the small cfg4 fixture on the fp32 engine; 1.5 fails 14 of them)
 import os as _os
-REFEREE = float(_os.environ.get('SEGX_REFEREE_FACTOR', '3'))
+REFEREE = float(_os.environ.get('SEGX_REFEREE_FACTOR', '2.25'))
 
 
 def _referee_log(name, e32, e64, r64):
