@@ -310,6 +310,14 @@ int segx_interp_linear_fwd_axis2_gn(const float* in, const float* base, float* o
                                     int64_t inner, int cpg, float* parts, int nparts, void* stream);
 int segx_groupnorm_fwd_parts(const float* X, const float* parts, int nparts, const float* w, const float* b, float* Y, float* mean, float* rstd,
                              int B, int C, int G, int64_t S, float eps, void* stream);
+/* r05: GroupNorm folded into a pointwise-convolution consumer (no apply pass forward, no plane-sums pass backward; the host composes per-sample weights
+ * W * sc_b and biases W sh_b + bias from mean / rstd -- segtran_amd/functional.py: up_group_norm_conv).  segx_groupnorm_stats_parts: mean / rstd [BG] from
+ * the partials of segx_interp_linear_fwd_axis2_gn.  segx_gn_fold_bwd: dX = Gd + A[b, g] + Bc[b, g] * xhat in one pass (Gd = the consumer's data gradient,
+ * A / Bc [B * G] = the statistics' share of the chain rule); plane_sums [B * C] = sum of dX over every plane (the lateral's bias gradient); ws: B * C * 64 floats.
+ * Replaces out_gn2b / out_gn3b + their consumers of segtran3d.py:336-367 on the re-associated path. */
+int segx_groupnorm_stats_parts(const float* parts, int nparts, float* mean, float* rstd, int BG, float eps, void* stream);
+int segx_gn_fold_bwd(const float* Gd, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc, float* dX, float* plane_sums,
+                     float* ws, int B, int C, int G, int64_t S, void* stream);
 /* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);
  * out = interp(in) (+ base, the FPN lateral, when base != NULL).  bwd is the exact adjoint, computed as a gather. */
 /* PolyformerLayer glue (networks/polyformer.py:36-55): nn.AvgPool2d(2) on [planes, H, W] (+ adjoint) and the batched transpose

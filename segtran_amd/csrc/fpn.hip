@@ -121,6 +121,43 @@ __global__ __launch_bounds__(256) void gn_stats_from_parts(const float* __restri
     if (lane == 0) { mean[bg] = s.mean; rstd[bg] = rsqrtf(fmaxf(s.m2 / fmaxf(s.n, 1.f), 0.f) + eps); }
 }
 
+// r05: GroupNorm FOLDED into its consumer (segtran_amd/functional.py: _UpGNFold).  Where the normalised tensor's only consumer is a pointwise convolution
+// (segtran3d.py:336-367: out_fpn23_conv3d(out_gn2b(.)), the class projection of out_gn3b(.)), y = x * sc[b, c] + sh[b, c] never has to exist:
+// conv(y) = (W * sc_b) x + (W sh_b + bias) -- per-sample weights and biases (tiny tensors, host-side autograd).  Forward: no apply pass.  Backward: the
+// gradients with respect to sc and sh come out of the per-sample WEIGHT gradient GEMM (which reads x anyway), so the plane-sums pass is gone too; what is left
+// is ONE pass: dx = g + A[b, g] + Bc[b, g] * xhat, g = the convolution's data gradient (already carrying sc), A / Bc = the statistics' share of the chain rule.
+// Each workgroup also leaves the sum of what it wrote (psum[plane][chunk]): the plane sums of dx are the lateral convolution's bias gradient.
+__global__ __launch_bounds__(256) void gn_fold_bwd_apply(const float* __restrict__ Gd, const float* __restrict__ X, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ A, const float* __restrict__ Bc,
+                                                         float* __restrict__ dX, float* __restrict__ psum, int C, int G, int64_t S) {
+    __shared__ float red[4];
+    const int bc = blockIdx.y, c = bc % C, bg = (bc / C) * G + c / (C / G);
+    const float m = mean[bg], r = rstd[bg], a = A[bg], bq = Bc[bg] * r;
+    const float* x = X + (int64_t)bc * S; const float* g = Gd + (int64_t)bc * S; float* d = dX + (int64_t)bc * S;
+    float acc = 0.f;
+    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Gd) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0) {
+        const int64_t S4 = S >> 2;
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S4; s += (int64_t)gridDim.x * 256) {
+            const float4 gv = reinterpret_cast<const float4*>(g)[s], xv = reinterpret_cast<const float4*>(x)[s];
+            float4 o;
+            o.x = gv.x + a + bq * (xv.x - m); o.y = gv.y + a + bq * (xv.y - m); o.z = gv.z + a + bq * (xv.z - m); o.w = gv.w + a + bq * (xv.w - m);
+            reinterpret_cast<float4*>(d)[s] = o;
+            acc += (o.x + o.y) + (o.z + o.w);
+        }
+    } else {
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) { const float o = g[s] + a + bq * (x[s] - m); d[s] = o; acc += o; }
+    }
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void gn_fold_plane_sums(const float* __restrict__ psum, float* __restrict__ out, int planes, int chunks) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= planes) return;
+    float s = 0.f;
+    for (int k = 0; k < chunks; ++k) s += psum[(int64_t)p * chunks + k];
+    out[p] = s;
+}
+
 // =================================================================================================
 // Linear resampling, align_corners=False (F.interpolate 'bilinear'/'trilinear': segtran2d.py:249,291,305,435;
 // segtran3d.py:304,319,351,364,384,495).  Source coordinate of destination index d along one axis, exactly as ATen:
@@ -642,6 +679,22 @@ extern "C" int segx_groupnorm_fwd_parts(const float* X, const float* parts, int 
     hipLaunchKernelGGL(gn_stats_from_parts, dim3((B * G + 3) / 4), dim3(256), 0, stream, parts, nparts, mean, rstd, B * G, eps);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(fpn_chunks(S, 8), B * C), dim3(256), 0, stream, X, (const float*)mean, (const float*)rstd, w, b, Y, C, G, S);
     return check_launch("segx_groupnorm_fwd_parts");
+}
+/* r05: the statistics half of segx_groupnorm_fwd_parts alone (mean / rstd [B * G] from the partials), and the one backward pass of a GroupNorm folded into its
+ * consumer: dX = Gd + A[b, g] + Bc[b, g] * xhat; plane_sums [B * C] = the sum of dX over every plane; ws: B * C * 64 floats */
+extern "C" int segx_groupnorm_stats_parts(const float* parts, int nparts, float* mean, float* rstd, int BG, float eps, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(parts && nparts > 0 && mean && rstd && BG > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_groupnorm_stats_parts: bad args");
+    hipLaunchKernelGGL(gn_stats_from_parts, dim3((BG + 3) / 4), dim3(256), 0, stream, parts, nparts, mean, rstd, BG, eps);
+    return check_launch("segx_groupnorm_stats_parts");
+}
+extern "C" int segx_gn_fold_bwd(const float* Gd, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc, float* dX, float* plane_sums,
+                                float* ws, int B, int C, int G, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(Gd && X && mean && rstd && A && Bc && dX && plane_sums && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0, "segx_gn_fold_bwd: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_gn_fold_bwd: more than 65535 planes");
+    const int chunks = fpn_chunks((S & 3) ? S : S / 4, 8);
+    hipLaunchKernelGGL(gn_fold_bwd_apply, dim3(chunks, B * C), dim3(256), 0, stream, Gd, X, mean, rstd, A, Bc, dX, ws, C, G, S);
+    hipLaunchKernelGGL(gn_fold_plane_sums, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, plane_sums, B * C, chunks);
+    return check_launch("segx_gn_fold_bwd");
 }
 /* plane_dx_sums (may be NULL): [B * C] floats = sum over the plane of the dX this call writes (closed form from the plane sums: no extra pass) */
 extern "C" int segx_groupnorm_bwd(const float* dY, const float* X, const float* w, const float* mean, const float* rstd, float* dX, float* dw,

@@ -215,6 +215,8 @@ def _bias_grad(L, dC, s):
     if rs is None or rs.numel() != nbt * s.M or rs.device != dC.device:
         rs = _empty(dC, nbt * s.M)
         L.rowsum(dC, rs, nbt * s.M, s.N)
+    if s.bias_b0 == s.M and nb1 == 1:                  # one bias vector per batch member (conv1x1_per_sample with per-sample biases): no sum over the batch
+        return rs.view(nb0, s.M)
     if nbt == 1:
         return rs
     out = _empty(dC, s.M)
@@ -894,13 +896,17 @@ def bn_act_gate_weights(x, bn, act, w1, b1, w2, b2, proj_weight):
                              proj_weight)
 
 
-def conv1x1_per_sample(x, Wb):
-    """Pointwise convolution with one weight matrix per sample: y[b] = Wb[b] x[b]  (Wb [B, Cout, Cin]); one batched GEMM, A strided over the batch."""
+def conv1x1_per_sample(x, Wb, bias=None):
+    """Pointwise convolution with one weight matrix per sample: y[b] = Wb[b] x[b] (+ bias[b])  (Wb [B, Cout, Cin], bias [B, Cout]); one batched GEMM, A strided
+    over the batch."""
     B, Cin = x.shape[0], x.shape[1]
     S = x.numel() // (B * Cin)
     Cout = Wb.shape[1]
-    spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1))
-    return bgemm(Wb, x, spec)
+    if bias is None:
+        spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1))
+        return bgemm(Wb, x, spec)
+    spec = GemmSpec(Cout, S, Cin, (Cout * Cin, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S), (B, Cout) + tuple(x.shape[2:]), nb=(B, 1), bias_mode=BIAS_M, bias_b0=Cout)
+    return bgemm(Wb, x, spec, bias=_c(bias))
 
 
 def bn_act_se(x, bn, act, w1, b1, w2, b2):
@@ -1070,6 +1076,89 @@ class _UpGN(torch.autograd.Function):
             dbase = dpre
             dbase._segx_plane_sums = rsum                    # sum over every (sample, channel) plane of dbase: the lateral convolution's bias gradient (_bias_grad)
         return dx, dbase, dw, db, None, None, None, None
+
+
+class _UpGNFold(torch.autograd.Function):
+    """The pyramid level `up(x) + base` with its GroupNorm statistics, for a GroupNorm that is FOLDED into its pointwise-convolution consumer (fpn.hip: r05
+    "GroupNorm folded into its consumer"): returns (pre, sc, sh) with gn(pre) == pre * sc[b, c] + sh[b, c]; the normalised tensor is never written.  Backward
+    takes the consumer's data gradient (which already carries sc) plus the gradients of sc and sh -- they come out of the consumer's per-sample weight / bias
+    gradients, i.e. out of GEMMs that read `pre` anyway -- and needs ONE pass over the level (segx_gn_fold_bwd) instead of plane sums + apply."""
+
+    @staticmethod
+    def forward(ctx, x, base, w, b, size, G, eps, nparts):
+        L = segx.lib()
+        x, base = _c(x), _c(base)
+        B, C = x.shape[:2]
+        d, h, wd = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        cur = x
+        if wd != W:
+            cur = _empty(x, B * C * d * h * W)
+            L.interp_fwd_axis(x, None, cur, B * C * d * h, wd, W, 1, 0.0)
+        pre = _empty(x, B, C, *size)
+        parts = _empty(x, B * G * nparts * 4)
+        L.interp_fwd_axis2_gn(cur, base, pre, B * C, d, D, h, H, W, C // G, parts, nparts)
+        mean, rstd = _empty(x, B * G), _empty(x, B * G)
+        L.groupnorm_stats_parts(parts, nparts, mean, rstd, B * G, eps)
+        cpg = C // G
+        rs = rstd.view(B, G, 1).expand(B, G, cpg).reshape(B, C)
+        mn = mean.view(B, G, 1).expand(B, G, cpg).reshape(B, C)
+        sc = rs * w.view(1, C)
+        sh = b.view(1, C) - mn * sc
+        ctx.cfg = (B, C, G, D * H * W, d, h, wd, D, H, W, tuple(x.shape))
+        ctx.save_for_backward(pre, w, mean, rstd)
+        return pre, sc, sh
+
+    @staticmethod
+    def backward(ctx, dpre, dsc, dsh):
+        L = segx.lib()
+        pre, w, mean, rstd = ctx.saved_tensors
+        B, C, G, S, d, h, wd, D, H, W, xshape = ctx.cfg
+        cpg = C // G
+        n = float(cpg) * float(S)
+        mn, rs, wg = mean.view(B, G, 1), rstd.view(B, G, 1), w.view(1, G, cpg)
+        dscg, dshg = dsc.reshape(B, G, cpg), dsh.reshape(B, G, cpg)
+        t = dscg - dshg * mn                                  # sc = rstd w, sh = b - mean sc
+        dw = (t * rs).sum(0).reshape(C)
+        db = dsh.reshape(B, C).sum(0)
+        dmean = -(dshg * (rs * wg)).sum(2)                    # [B, G]
+        drstd = (t * wg).sum(2)
+        A = (dmean / n).reshape(-1).contiguous()              # d mean / d x = 1 / n;  d rstd / d x = -rstd^3 (x - mean) / n = -(rstd^2 / n) xhat
+        Bc = (-drstd * rstd.view(B, G) * rstd.view(B, G) / n).reshape(-1).contiguous()
+        dtot = torch.empty_like(pre)
+        rsum = _empty(pre, B * C)
+        L.gn_fold_bwd(_c(dpre), pre, mean, rstd, A, Bc, dtot, rsum, _empty(pre, B * C * 64), B, C, G, S)
+        dx = _interp_bwd_yz_x(L, dtot, B * C, d, h, wd, D, H, W).view(xshape) if ctx.needs_input_grad[0] else None
+        dbase = None
+        if ctx.needs_input_grad[1]:
+            dbase = dtot
+            dbase._segx_plane_sums = rsum                     # plane sums of dbase: the lateral convolution's bias gradient (_bias_grad)
+        return dx, dbase, dw, db, None, None, None, None
+
+
+def up_group_norm_conv(x, size, base, gn, weight, bias=None):
+    """conv1x1(gn(F.interpolate(x, size, mode='trilinear') + base), weight, bias) with the GroupNorm folded into per-sample weights and biases (_UpGNFold):
+    the level is written once (by the resampling pass, which also leaves the statistics) and read once (by the convolution); backward adds one pass.
+    Shapes the fused resampling pass does not serve take up_group_norm + conv1x1."""
+    size = tuple(int(s) for s in size)
+    G = int(gn.num_groups)
+    if base is not None and x.dim() in (4, 5) and fold_group_norm:      # 2-D maps: depth 1, the y pass alone carries the statistics
+        d, h, _ = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        B, C = x.shape[0], x.shape[1]
+        if h != H and W % 4 == 0 and C % G == 0 and tuple(base.shape) == (B, C) + size:
+            nparts = segx.lib().interp_gn_nparts(D * H * (W // 4), C // G)
+            if nparts > 0:
+                pre, sc, sh = _UpGNFold.apply(x, base, gn.weight, gn.bias, size, G, float(gn.eps), nparts)
+                Cout = weight.shape[0]
+                W2 = weight.reshape(Cout, C)
+                Wb = W2.unsqueeze(0) * sc.unsqueeze(1)            # [B, Cout, C]
+                bb = linear(sh, W2, bias)                          # [B, Cout] = sh W^T + bias (libsegx GEMM: no vendor BLAS on the step)
+                return conv1x1_per_sample(pre, Wb, bias=bb)
+    return conv1x1(up_group_norm(x, size, base, gn), weight, bias)
+
+
+fold_group_norm = True          # False: GroupNorm applied by its own pass (up_group_norm) -- A/B switch of tests and tools
 
 
 def _interp_bwd_yz_x(L, dy, planes, d, h, w, D, H, W):

@@ -166,14 +166,17 @@ class Segtran2d(SegtranInitWeights):
         to 1, so the bias commutes too).  Same function and same gradients for every parameter (chain rule through the composed
         weight), fp32 rounding aside; the trans_out_dim-channel map at the out-FPN resolution is never formed (reference op
         order, :304-306 then :427-436: `fuse_output_tail = False`)."""
-        cur = SF.group_norm(_up(feats[2], feats[1].shape[2:], base=self.out_fpn12_conv(feats[1])), self.out_gn2b)
-        cur = SF.group_norm(_up(feats[3], cur.shape[2:], base=self.out_fpn23_conv(cur)), self.out_gn3b)
+        # r05: the two GroupNorms are folded into the pointwise convolutions that consume them (SF.up_group_norm_conv, as in Segtran3d.out_head_forward): a level
+        # is written by the resampling pass that also leaves its statistics and read by the convolution; sizes the fused pass does not serve take the plain ops
+        size1 = feats[1].shape[2:]
+        base3 = SF.up_group_norm_conv(feats[2], size1, self.out_fpn12_conv(feats[1]), self.out_gn2b, self.out_fpn23_conv.weight, self.out_fpn23_conv.bias)
         wo, bo = self.out_conv.weight, self.out_conv.bias
         if isinstance(self.out_fpn_bridgeconv, nn.Identity):
-            lateral = SF.conv1x1(cur, wo, bo)
+            wl, bl = wo, bo
         else:
-            lateral = SF.conv1x1(cur, *SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv.weight, self.out_fpn_bridgeconv.bias))
-        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), cur.shape[2:], base=lateral)
+            wl, bl = SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv.weight, self.out_fpn_bridgeconv.bias)
+        lateral = SF.up_group_norm_conv(feats[3], size1, base3, self.out_gn3b, wl, bl)
+        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), size1, base=lateral)
         return _up(scores, size)
 
     def forward(self, batch):

@@ -186,14 +186,17 @@ class Segtran3d(SegtranInitWeights):
         rounding aside -- and the 1024-channel maps at the out-FPN resolution (2 x 2.5 GB at cfg4), the 832 -> 1024 bridge GEMMs
         over 150528 voxels (fwd / bwd-data / bwd-weight) and their resampling passes never exist.  Reference op order
         (:364-367, :381-386, :490): `fuse_output_tail = False`."""
-        cur = SF.up_group_norm(feats[2], feats[1].shape[2:], self.out_fpn12_conv3d(feats[1]), self.out_gn2b)
-        cur = SF.up_group_norm(feats[3], cur.shape[2:], self.out_fpn23_conv3d(cur), self.out_gn3b)
+        # r05: both GroupNorms of the pyramid are FOLDED into the pointwise convolutions that consume them (SF.up_group_norm_conv: per-sample weights W * sc_b and
+        # biases W sh_b + bias): the 2 - 3.5 GB levels are written once, by the resampling pass that also leaves their statistics, and read once, by the convolution
+        size1 = feats[1].shape[2:]
+        base3 = SF.up_group_norm_conv(feats[2], size1, self.out_fpn12_conv3d(feats[1]), self.out_gn2b, self.out_fpn23_conv3d.weight, self.out_fpn23_conv3d.bias)
         wo, bo = self.out_conv3d.weight, self.out_conv3d.bias
         if isinstance(self.out_fpn_bridgeconv3d, nn.Identity):
-            lateral = SF.conv1x1(cur, wo, bo)
+            wl, bl = wo, bo
         else:
-            lateral = SF.conv1x1(cur, *SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv3d.weight, self.out_fpn_bridgeconv3d.bias))
-        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), cur.shape[2:], base=lateral)
+            wl, bl = SF.compose_conv1x1(wo, bo, self.out_fpn_bridgeconv3d.weight, self.out_fpn_bridgeconv3d.bias)
+        lateral = SF.up_group_norm_conv(feats[3], size1, base3, self.out_gn3b, wl, bl)
+        scores = _up(SF.conv1x1_tokens(fused_tokens, grid_shape, wo), size1, base=lateral)
         if self.D_pool_K > 1:
             scores = _up(scores, [scores.shape[2] * self.D_pool_K, scores.shape[3], scores.shape[4]])
         return _up(scores.permute(0, 1, 3, 4, 2), size)

@@ -449,6 +449,78 @@ def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradie
     close(gn.weight.grad, ref_gn.weight.grad, 1e-4); close(gn.bias.grad, ref_gn.bias.grad, 1e-4)
 
 
+
+@pytest.mark.parametrize('B,C,G,Cout,insize,size,with_bias', [(2, 8, 4, 6, (4, 8, 8), (8, 16, 16), True), (1, 16, 8, 3, (2, 8, 16), (4, 16, 32), False),
+                                                           (2, 8, 2, 5, (8, 8, 8), (8, 16, 16), True), (1, 8, 4, 4, (3, 5, 6), (6, 10, 12), True)])
+def test_group_norm_folded_into_its_pointwise_consumer(backend, B, C, G, Cout, insize, size, with_bias):
+    """SF.up_group_norm_conv (r05): conv1x1(gn(up(x) + lateral(f))) with the GroupNorm folded into per-sample weights / biases -- the normalised level is never
+    written, the backward needs one pass over it (segx_gn_fold_bwd) and takes the gradients of scale / shift from the consumer's per-sample weight and bias
+    gradients.  Against PyTorch: the output and EVERY gradient (x, f, lateral weight + bias, GroupNorm affine, consumer weight + bias); the last case does not
+    split into 1024-float chunks and takes the unfolded ops."""
+    Cf = 5
+    gn, ref_gn = torch.nn.GroupNorm(G, C), torch.nn.GroupNorm(G, C)
+    lat, cons = torch.nn.Conv3d(Cf, C, 1), torch.nn.Conv3d(C, Cout, 1, bias=with_bias)
+    with torch.no_grad():
+        for m in (gn, ref_gn):
+            m.weight.copy_(1 + 0.3 * rnd(C, seed=71)); m.bias.copy_(0.3 * rnd(C, seed=72))
+        lat.weight.copy_(0.4 * rnd(C, Cf, 1, 1, 1, seed=73)); lat.bias.copy_(0.3 * rnd(C, seed=74))
+        cons.weight.copy_(0.5 * rnd(Cout, C, 1, 1, 1, seed=75))
+        if with_bias:
+            cons.bias.copy_(0.2 * rnd(Cout, seed=76))
+    x = (rnd(B, C, *insize, seed=77) + 0.4).requires_grad_(True)
+    f = rnd(B, Cf, *size, seed=78).requires_grad_(True)
+    y = SF.up_group_norm_conv(x, size, SF.conv1x1(f, lat.weight, lat.bias), gn, cons.weight, cons.bias)
+    Gd = rnd(*y.shape, seed=79)
+    y.backward(Gd)
+    xr, fr = x.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in dict(lw=lat.weight, lb=lat.bias, cw=cons.weight, **({'cb': cons.bias} if with_bias else {})).items()}
+    yr = F.conv3d(ref_gn(F.interpolate(xr, size=size, mode='trilinear', align_corners=False) + F.conv3d(fr, P['lw'], P['lb'])), P['cw'], P.get('cb'))
+    yr.backward(Gd)
+    close(y, yr.detach(), 3e-5)
+    close(x.grad, xr.grad, 2e-4); close(f.grad, fr.grad, 2e-4)
+    close(lat.weight.grad, P['lw'].grad, 2e-4); close(lat.bias.grad, P['lb'].grad, 3e-4)
+    close(cons.weight.grad, P['cw'].grad, 2e-4)
+    if with_bias:
+        close(cons.bias.grad, P['cb'].grad, 2e-4)
+    close(gn.weight.grad, ref_gn.weight.grad, 2e-4); close(gn.bias.grad, ref_gn.bias.grad, 2e-4)
+    # the A/B switch gives the same function through the unfolded ops
+    prev = SF.fold_group_norm
+    SF.fold_group_norm = False
+    try:
+        y2 = SF.up_group_norm_conv(x.detach(), size, SF.conv1x1(f.detach(), lat.weight, lat.bias), gn, cons.weight, cons.bias)
+    finally:
+        SF.fold_group_norm = prev
+    close(y2.detach(), y.detach(), 3e-5)
+
+
+
+@pytest.mark.parametrize('B,C,G,Cout,insize,size', [(2, 8, 4, 3, (16, 16), (32, 32)), (1, 16, 8, 5, (8, 32), (32, 64)), (2, 8, 2, 4, (5, 6), (10, 12))])
+def test_group_norm_folded_into_its_pointwise_consumer_2d(backend, B, C, G, Cout, insize, size):
+    """the same fold on 2-D maps (Segtran2d.out_head_forward: bilinear up-sampling = the x pass + a y pass that leaves the statistics); last case: unfolded ops"""
+    Cf = 5
+    gn, ref_gn = torch.nn.GroupNorm(G, C), torch.nn.GroupNorm(G, C)
+    lat, cons = torch.nn.Conv2d(Cf, C, 1), torch.nn.Conv2d(C, Cout, 1)
+    with torch.no_grad():
+        for m in (gn, ref_gn):
+            m.weight.copy_(1 + 0.3 * rnd(C, seed=81)); m.bias.copy_(0.3 * rnd(C, seed=82))
+        lat.weight.copy_(0.4 * rnd(C, Cf, 1, 1, seed=83)); lat.bias.copy_(0.3 * rnd(C, seed=84))
+        cons.weight.copy_(0.5 * rnd(Cout, C, 1, 1, seed=85)); cons.bias.copy_(0.2 * rnd(Cout, seed=86))
+    x = (rnd(B, C, *insize, seed=87) + 0.4).requires_grad_(True)
+    f = rnd(B, Cf, *size, seed=88).requires_grad_(True)
+    y = SF.up_group_norm_conv(x, size, SF.conv1x1(f, lat.weight, lat.bias), gn, cons.weight, cons.bias)
+    Gd = rnd(*y.shape, seed=89)
+    y.backward(Gd)
+    xr, fr = x.detach().clone().requires_grad_(True), f.detach().clone().requires_grad_(True)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in dict(lw=lat.weight, lb=lat.bias, cw=cons.weight, cb=cons.bias).items()}
+    yr = F.conv2d(ref_gn(F.interpolate(xr, size=size, mode='bilinear', align_corners=False) + F.conv2d(fr, P['lw'], P['lb'])), P['cw'], P['cb'])
+    yr.backward(Gd)
+    close(y, yr.detach(), 3e-5)
+    close(x.grad, xr.grad, 2e-4); close(f.grad, fr.grad, 2e-4)
+    close(lat.weight.grad, P['lw'].grad, 2e-4); close(lat.bias.grad, P['lb'].grad, 3e-4)
+    close(cons.weight.grad, P['cw'].grad, 2e-4); close(cons.bias.grad, P['cb'].grad, 2e-4)
+    close(gn.weight.grad, ref_gn.weight.grad, 2e-4); close(gn.bias.grad, ref_gn.bias.grad, 2e-4)
+
+
 def test_group_norm_partials_of_a_badly_centred_tensor(backend):
     """The partials are sums around a per-workgroup pivot merged with Chan's formula: a level whose mean is 1000 standard deviations away from zero must
     still normalise to unit variance (a plain sum / sum-of-squares form loses every digit of the variance there)."""
