@@ -254,6 +254,44 @@ struct ConvWgradLoaderB6 {
         }
         unsigned okmask = 0;
         if (FASTW) {
+            if (q.OW % 4 != 0) {
+                // r05 -- stride 1 with 'same' geometry (I == O in every axis: the 3 x 3 x 3 Inception convolutions), any row length >= 7 (the 14- and 7-wide stages of
+                // cfg4, which used to stay on the fp32 engine): output position p reads input element p + tap offset, so the octet's eight gathers are eight
+                // CONSECUTIVE floats even where the octet wraps onto the next output row -- two dword-aligned 16-byte loads -- and only the validity differs: one
+                // interval of valid columns per output row the octet touches (at most two rows: OW >= 7), each with its own (id, ih) test.
+                const int npos = kend - p0;
+                const int len1 = q.OW - ow < 8 ? q.OW - ow : 8;                  // positions of the octet on its first output row
+                int od2 = od, oh2 = oh + 1;
+                if (oh2 == q.OH) { oh2 = 0; ++od2; }
+                const unsigned live = npos >= 8 ? 0xFFu : npos > 0 ? (1u << npos) - 1u : 0u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int dk = kd[h] - q.pd, hk = kh[h] - q.ph, wk = kw[h] - q.pw;
+                    const bool r1 = (unsigned)(od + dk) < (unsigned)q.ID && (unsigned)(oh + hk) < (unsigned)q.IH;
+                    const bool r2 = (unsigned)(od2 + dk) < (unsigned)q.ID && (unsigned)(oh2 + hk) < (unsigned)q.IH;
+                    int lo1 = -(ow + wk), hi1 = q.IW - (ow + wk);                // valid j on the first row: 0 <= ow + j + wk < IW
+                    lo1 = lo1 < 0 ? 0 : lo1; hi1 = hi1 > len1 ? len1 : hi1;
+                    int lo2 = len1 - wk, hi2 = len1 + q.IW - wk;                  // on the second row: 0 <= (j - len1) + wk < IW
+                    lo2 = lo2 < len1 ? len1 : lo2; hi2 = hi2 > 8 ? 8 : hi2;
+                    unsigned m = 0;
+                    if (r1 && hi1 > lo1) m |= ((1u << hi1) - 1u) & ~((1u << lo1) - 1u);
+                    if (r2 && hi2 > lo2) m |= ((1u << hi2) - 1u) & ~((1u << lo2) - 1u);
+                    m &= live;
+                    if (cb[h] < 0) m = 0;
+                    const int64_t off = m ? (int64_t)cb[h] + pp + ((int64_t)dk * q.IH + hk) * q.IW + wk : 0;
+                    if (off >= 0 && off + 8 <= (int64_t)q.Cin * chan) {
+                        const F4u u0 = *reinterpret_cast<const F4u*>(X + off), u1 = *reinterpret_cast<const F4u*>(X + off + 4);
+                        r[8 * h] = u0.x; r[8 * h + 1] = u0.y; r[8 * h + 2] = u0.z; r[8 * h + 3] = u0.w;
+                        r[8 * h + 4] = u1.x; r[8 * h + 5] = u1.y; r[8 * h + 6] = u1.z; r[8 * h + 7] = u1.w;
+                    } else {                                                      // the first / last floats of the whole sample: only the valid elements are touched
+                        const int first = m ? __builtin_ctz(m) : 0;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) r[8 * h + j] = X[off + (((m >> j) & 1u) ? j : first)];
+                    }
+                    okmask |= m << (8 * h);
+                }
+                return okmask;
+            }
             if (q.OW % 8 != 0) {
                 // OW % 4 == 0 only (the 28-wide stages): the octet is TWO quads of four consecutive ow, the second possibly on the next output row --
                 // each quad is one 16-byte load per (channel, tap) row with its own (id, ih) test and interval of valid j (unit stride: host check)
@@ -1186,7 +1224,9 @@ extern "C" int64_t segx_conv3d_splitk(int B, int Cout, const int* geom, int wgra
     if (P <= 0 || P >= 2147483647LL || CK <= 0 || CK >= 2147483647LL) return 1;
     // which engine the launch will take (same tests as conv3d_fwd_impl / conv3d_wgrad_impl; the pointer alignment is the allocator's 256 B)
     const bool packed = q.Cin % 8 == 0, x6 = kget(knobs().engine) == SEGX_ENGINE_BF16X6 && packed;
-    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (((q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && (!conv_small(Cout) || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1));
+    const bool same1 = q.sd == 1 && q.sh == 1 && q.sw == 1 && q.ID == q.OD && q.IH == q.OH && q.IW == q.OW && q.OW >= 7 && q.OW % 4 != 0 &&
+                       2 * q.pd == q.KD - 1 && 2 * q.ph == q.KH - 1 && 2 * q.pw == q.KW - 1;
+    if (wgrad) return conv_splitk(Cout, (int)CK, (int)P, B, x6 && P % 4 == 0 && (((q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1) || same1) && (!conv_small(Cout) || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1));
     return conv_splitk(Cout, (int)P, (int)CK, B, x6 && CK % 4 == 0);
 }
 /* geom = {Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW, sd, sh, sw, pd, ph, pw} (front pads); splitk > 1: K = Cin*KV split over slabs in
@@ -1274,7 +1314,10 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     // saves (r02_a: 63 against 96 TFLOP/s), and the fp32 engine's position-per-thread loader stays.  With unit stride along W the row's eight floats
     // are two 16-byte loads (r02_l: 128-row tile 117 -> 153 TFLOP/s, 64-row tile 65 -> 119 against 92 on the fp32 engine); the strided case
     // (the stride-2 composed stem, 64 filters) keeps eight gathers per row and, on the 64-row tile, stays on the fp32 engine (66 against 83).
-    const bool fastw = (q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1)) && g.k_chunk % 8 == 0;          // geometry: the row-of-eight (or two-quads) loader applies
+    // r05: stride-1 'same' geometry with rows of >= 7 floats that are not a multiple of 4 (the 14- / 7-wide Inception stages of cfg4): the contiguous-octet form
+    const bool same1 = q.sd == 1 && q.sh == 1 && q.sw == 1 && q.ID == q.OD && q.IH == q.OH && q.IW == q.OW && q.OW >= 7 && q.OW % 4 != 0 &&
+                       2 * q.pd == q.KD - 1 && 2 * q.ph == q.KH - 1 && 2 * q.pw == q.KW - 1;
+    const bool fastw = (q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1) || same1) && g.k_chunk % 8 == 0;          // geometry: the row-of-eight (two-quads, contiguous-octet) loader applies
     if (packed && vec && kget(knobs().engine) == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1)) {
         knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
         if (fastw) {
