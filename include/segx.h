@@ -316,6 +316,10 @@ int segx_groupnorm_fwd_parts(const float* X, const float* parts, int nparts, con
  * A / Bc [B * G] = the statistics' share of the chain rule); plane_sums [B * C] = sum of dX over every plane (the lateral's bias gradient); ws: B * C * 64 floats.
  * Replaces out_gn2b / out_gn3b + their consumers of segtran3d.py:336-367 on the re-associated path. */
 int segx_groupnorm_stats_parts(const float* parts, int nparts, float* mean, float* rstd, int BG, float eps, void* stream);
+/* segx_gn_fold_bwd_proj: the same pass where the consumer projects onto NC <= 8 channels (the class projection): Gd is not materialised, the kernel forms
+ * sum_o Wb[b][o][c] * dOut[b][o][s] itself (dOut [B][NC][S], Wb [B][NC][C]) */
+int segx_gn_fold_bwd_proj(const float* dOut, const float* Wb, int NC, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc,
+                          float* dX, float* plane_sums, float* ws, int B, int C, int G, int64_t S, void* stream);
 int segx_gn_fold_bwd(const float* Gd, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc, float* dX, float* plane_sums,
                      float* ws, int B, int C, int G, int64_t S, void* stream);
 /* F.interpolate(mode='bilinear'|'trilinear', align_corners=False) from [planes, d, h, w] to [planes, D, H, W] (2-D: d = D = 1);

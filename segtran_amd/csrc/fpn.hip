@@ -150,6 +150,47 @@ __global__ __launch_bounds__(256) void gn_fold_bwd_apply(const float* __restrict
     acc = block_sum<4>(acc, red);
     if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
 }
+// The same pass where the consumer is a projection onto NC <= 8 channels (the class projection behind out_gn3b): its data gradient
+// g[b, c, s] = sum_o Wb[b, o, c] dOut[b, o, s] is formed HERE from the NC-channel gradient (a few MB per sample: L2-resident across the planes of the sample)
+// instead of being written as a full-size tensor by a K = NC GEMM (3.5 GB at cfg5: 0.86 ms to write, 0.6 ms to read back).
+template <int NC>
+__global__ __launch_bounds__(256) void gn_fold_bwd_apply_proj(const float* __restrict__ dOut, const float* __restrict__ Wb, const float* __restrict__ X,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ A,
+                                                              const float* __restrict__ Bc, float* __restrict__ dX, float* __restrict__ psum, int C, int G, int64_t S) {
+    __shared__ float red[4];
+    const int bc = blockIdx.y, b = bc / C, c = bc - b * C, bg = b * G + c / (C / G);
+    const float m = mean[bg], r = rstd[bg], a = A[bg], bq = Bc[bg] * r;
+    float w[NC];
+#pragma unroll
+    for (int o = 0; o < NC; ++o) w[o] = Wb[((int64_t)b * NC + o) * C + c];
+    const float* x = X + (int64_t)bc * S; const float* go = dOut + (int64_t)b * NC * S; float* d = dX + (int64_t)bc * S;
+    float acc = 0.f;
+    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dOut) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0) {
+        const int64_t S4 = S >> 2;
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S4; s += (int64_t)gridDim.x * 256) {
+            float4 gv[NC];
+#pragma unroll
+            for (int o = 0; o < NC; ++o) gv[o] = reinterpret_cast<const float4*>(go + (int64_t)o * S)[s];
+            const float4 xv = reinterpret_cast<const float4*>(x)[s];
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int o = 0; o < NC; ++o) { g.x += w[o] * gv[o].x; g.y += w[o] * gv[o].y; g.z += w[o] * gv[o].z; g.w += w[o] * gv[o].w; }
+            float4 ov;
+            ov.x = g.x + a + bq * (xv.x - m); ov.y = g.y + a + bq * (xv.y - m); ov.z = g.z + a + bq * (xv.z - m); ov.w = g.w + a + bq * (xv.w - m);
+            reinterpret_cast<float4*>(d)[s] = ov;
+            acc += (ov.x + ov.y) + (ov.z + ov.w);
+        }
+    } else {
+        for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
+            float g = 0.f;
+#pragma unroll
+            for (int o = 0; o < NC; ++o) g += w[o] * go[(int64_t)o * S + s];
+            const float ov = g + a + bq * (x[s] - m); d[s] = ov; acc += ov;
+        }
+    }
+    acc = block_sum<4>(acc, red);
+    if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
+}
 __global__ __launch_bounds__(256) void gn_fold_plane_sums(const float* __restrict__ psum, float* __restrict__ out, int planes, int chunks) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= planes) return;
@@ -686,6 +727,20 @@ extern "C" int segx_groupnorm_stats_parts(const float* parts, int nparts, float*
     SEGX_STREAM; SEGX_REQUIRE(parts && nparts > 0 && mean && rstd && BG > 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0, "segx_groupnorm_stats_parts: bad args");
     hipLaunchKernelGGL(gn_stats_from_parts, dim3((BG + 3) / 4), dim3(256), 0, stream, parts, nparts, mean, rstd, BG, eps);
     return check_launch("segx_groupnorm_stats_parts");
+}
+/* ... with the consumer's data gradient formed on the fly: dOut [B][NC][S] (NC <= 8), Wb [B][NC][C] per-sample weights */
+extern "C" int segx_gn_fold_bwd_proj(const float* dOut, const float* Wb, int NC, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc,
+                                     float* dX, float* plane_sums, float* ws, int B, int C, int G, int64_t S, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dOut && Wb && X && mean && rstd && A && Bc && dX && plane_sums && ws && B > 0 && C > 0 && G > 0 && C % G == 0 && S > 0 && NC >= 1 && NC <= 8,
+                              "segx_gn_fold_bwd_proj: bad args");
+    SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_gn_fold_bwd_proj: more than 65535 planes");
+    const int chunks = fpn_chunks((S & 3) ? S : S / 4, 8);
+    const dim3 grid(chunks, B * C);
+#define SEGX_GNP(N) case N: hipLaunchKernelGGL((gn_fold_bwd_apply_proj<N>), grid, dim3(256), 0, stream, dOut, Wb, X, mean, rstd, A, Bc, dX, ws, C, G, S); break;
+    switch (NC) { SEGX_GNP(1) SEGX_GNP(2) SEGX_GNP(3) SEGX_GNP(4) SEGX_GNP(5) SEGX_GNP(6) SEGX_GNP(7) SEGX_GNP(8) }
+#undef SEGX_GNP
+    hipLaunchKernelGGL(gn_fold_plane_sums, dim3((B * C + 255) / 256), dim3(256), 0, stream, (const float*)ws, plane_sums, B * C, chunks);
+    return check_launch("segx_gn_fold_bwd_proj");
 }
 extern "C" int segx_gn_fold_bwd(const float* Gd, const float* X, const float* mean, const float* rstd, const float* A, const float* Bc, float* dX, float* plane_sums,
                                 float* ws, int B, int C, int G, int64_t S, void* stream_) {

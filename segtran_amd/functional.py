@@ -1078,6 +1078,23 @@ class _UpGN(torch.autograd.Function):
         return dx, dbase, dw, db, None, None, None, None
 
 
+def _gn_fold_stat_grads(dsc, dsh, w, mean, rstd, B, C, G, S):
+    """From the gradients of sc = rstd w and sh = b - mean sc ([B, C] each): GroupNorm's parameter gradients and the two per-(sample, group) coefficients of the
+    statistics' share of the input gradient, dx += A + Bc * xhat  (d mean / d x = 1 / n;  d rstd / d x = -rstd^3 (x - mean) / n = -(rstd^2 / n) xhat)."""
+    cpg = C // G
+    n = float(cpg) * float(S)
+    mn, rs, wg = mean.view(B, G, 1), rstd.view(B, G, 1), w.view(1, G, cpg)
+    dscg, dshg = dsc.reshape(B, G, cpg), dsh.reshape(B, G, cpg)
+    t = dscg - dshg * mn
+    dw = (t * rs).sum(0).reshape(C)
+    db = dsh.reshape(B, C).sum(0)
+    dmean = -(dshg * (rs * wg)).sum(2)                        # [B, G]
+    drstd = (t * wg).sum(2)
+    A = (dmean / n).reshape(-1).contiguous()
+    Bc = (-drstd * rstd.view(B, G) * rstd.view(B, G) / n).reshape(-1).contiguous()
+    return dw, db, A, Bc
+
+
 class _UpGNFold(torch.autograd.Function):
     """The pyramid level `up(x) + base` with its GroupNorm statistics, for a GroupNorm that is FOLDED into its pointwise-convolution consumer (fpn.hip: r05
     "GroupNorm folded into its consumer"): returns (pre, sc, sh) with gn(pre) == pre * sc[b, c] + sh[b, c]; the normalised tensor is never written.  Backward
@@ -1114,17 +1131,7 @@ class _UpGNFold(torch.autograd.Function):
         L = segx.lib()
         pre, w, mean, rstd = ctx.saved_tensors
         B, C, G, S, d, h, wd, D, H, W, xshape = ctx.cfg
-        cpg = C // G
-        n = float(cpg) * float(S)
-        mn, rs, wg = mean.view(B, G, 1), rstd.view(B, G, 1), w.view(1, G, cpg)
-        dscg, dshg = dsc.reshape(B, G, cpg), dsh.reshape(B, G, cpg)
-        t = dscg - dshg * mn                                  # sc = rstd w, sh = b - mean sc
-        dw = (t * rs).sum(0).reshape(C)
-        db = dsh.reshape(B, C).sum(0)
-        dmean = -(dshg * (rs * wg)).sum(2)                    # [B, G]
-        drstd = (t * wg).sum(2)
-        A = (dmean / n).reshape(-1).contiguous()              # d mean / d x = 1 / n;  d rstd / d x = -rstd^3 (x - mean) / n = -(rstd^2 / n) xhat
-        Bc = (-drstd * rstd.view(B, G) * rstd.view(B, G) / n).reshape(-1).contiguous()
+        dw, db, A, Bc = _gn_fold_stat_grads(dsc, dsh, w, mean, rstd, B, C, G, S)
         dtot = torch.empty_like(pre)
         rsum = _empty(pre, B * C)
         L.gn_fold_bwd(_c(dpre), pre, mean, rstd, A, Bc, dtot, rsum, _empty(pre, B * C * 64), B, C, G, S)
@@ -1134,6 +1141,71 @@ class _UpGNFold(torch.autograd.Function):
             dbase = dtot
             dbase._segx_plane_sums = rsum                     # plane sums of dbase: the lateral convolution's bias gradient (_bias_grad)
         return dx, dbase, dw, db, None, None, None, None
+
+
+class _UpGNFoldProj(torch.autograd.Function):
+    """_UpGNFold + its consumer in ONE node, for a consumer that projects onto NC <= 8 channels (the class projection): out = (W * sc_b) pre + (W sh_b + bias).
+    Backward never writes the consumer's full-size data gradient: segx_gn_fold_bwd_proj forms sum_o Wb[b, o, c] dOut[b, o, s] while it makes its one pass
+    over the level (at cfg5 a 3.5-GB tensor the K = 4 GEMM took 0.86 ms to write and the pass 0.6 ms to read back)."""
+
+    @staticmethod
+    def forward(ctx, x, base, w, b, weight, bias, size, G, eps, nparts):
+        L = segx.lib()
+        x, base = _c(x), _c(base)
+        B, C = x.shape[:2]
+        d, h, wd = _dhw(x.shape[2:])
+        D, H, W = _dhw(size)
+        S = D * H * W
+        cur = x
+        if wd != W:
+            cur = _empty(x, B * C * d * h * W)
+            L.interp_fwd_axis(x, None, cur, B * C * d * h, wd, W, 1, 0.0)
+        pre = _empty(x, B, C, *size)
+        parts = _empty(x, B * G * nparts * 4)
+        L.interp_fwd_axis2_gn(cur, base, pre, B * C, d, D, h, H, W, C // G, parts, nparts)
+        mean, rstd = _empty(x, B * G), _empty(x, B * G)
+        L.groupnorm_stats_parts(parts, nparts, mean, rstd, B * G, eps)
+        cpg = C // G
+        NC = weight.shape[0]
+        W2 = _c(weight.reshape(NC, C))
+        sc = rstd.view(B, G, 1).expand(B, G, cpg).reshape(B, C) * w.view(1, C)
+        sh = b.view(1, C) - mean.view(B, G, 1).expand(B, G, cpg).reshape(B, C) * sc
+        Wb = (W2.unsqueeze(0) * sc.unsqueeze(1)).contiguous()                        # [B, NC, C]
+        bb = (sh.unsqueeze(1) * W2.unsqueeze(0)).sum(2)                              # [B, NC]
+        if bias is not None:
+            bb = bb + bias.view(1, NC)
+        bb = bb.contiguous()
+        out = _empty(x, B, NC, *size)
+        _run_gemm(L, Wb, pre, out, NC, S, C, (NC * C, 0, C, 1), (C * S, 0, 1, S), (NC * S, 0, S), (B, 1), 1.0, bias=bb, bias_mode=BIAS_M, bias_b0=NC)
+        ctx.cfg = (B, C, G, S, NC, d, h, wd, D, H, W, tuple(x.shape), tuple(weight.shape), bias is not None)
+        ctx.save_for_backward(pre, w, mean, rstd, W2, Wb, sc, sh)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = segx.lib()
+        pre, w, mean, rstd, W2, Wb, sc, sh = ctx.saved_tensors
+        B, C, G, S, NC, d, h, wd, D, H, W, xshape, wshape, has_bias = ctx.cfg
+        dout = _c(dout)
+        dbb = _empty(pre, B * NC)
+        L.rowsum(dout, dbb, B * NC, S)
+        dbb = dbb.view(B, NC)
+        dWb = _empty(pre, B, NC, C)                                                  # per-sample weight gradient: dOut[b] pre[b]^T (contraction over the voxels)
+        _run_gemm(L, dout, pre, dWb, NC, C, S, (NC * S, 0, S, 1), (C * S, 0, S, 1), (NC * C, 0, C), (B, 1), 1.0)
+        dsc = (dWb * W2.unsqueeze(0)).sum(1)                                         # [B, C]
+        dsh = (dbb.unsqueeze(2) * W2.unsqueeze(0)).sum(1)
+        dW2 = (dWb * sc.unsqueeze(1)).sum(0) + (dbb.unsqueeze(2) * sh.unsqueeze(1)).sum(0)
+        dbias = dbb.sum(0) if has_bias else None
+        dw, db, A, Bc = _gn_fold_stat_grads(dsc, dsh, w, mean, rstd, B, C, G, S)
+        dtot = torch.empty_like(pre)
+        rsum = _empty(pre, B * C)
+        L.gn_fold_bwd_proj(dout, Wb, NC, pre, mean, rstd, A, Bc, dtot, rsum, _empty(pre, B * C * 64), B, C, G, S)
+        dx = _interp_bwd_yz_x(L, dtot, B * C, d, h, wd, D, H, W).view(xshape) if ctx.needs_input_grad[0] else None
+        dbase = None
+        if ctx.needs_input_grad[1]:
+            dbase = dtot
+            dbase._segx_plane_sums = rsum
+        return dx, dbase, dw, db, dW2.view(wshape), dbias, None, None, None, None
 
 
 def up_group_norm_conv(x, size, base, gn, weight, bias=None):
@@ -1149,8 +1221,10 @@ def up_group_norm_conv(x, size, base, gn, weight, bias=None):
         if h != H and W % 4 == 0 and C % G == 0 and tuple(base.shape) == (B, C) + size:
             nparts = segx.lib().interp_gn_nparts(D * H * (W // 4), C // G)
             if nparts > 0:
-                pre, sc, sh = _UpGNFold.apply(x, base, gn.weight, gn.bias, size, G, float(gn.eps), nparts)
                 Cout = weight.shape[0]
+                if Cout <= 8:                                      # a projection onto a few channels: the whole level + consumer as one node (no full-size data gradient)
+                    return _UpGNFoldProj.apply(x, base, gn.weight, gn.bias, weight, bias, size, G, float(gn.eps), nparts)
+                pre, sc, sh = _UpGNFold.apply(x, base, gn.weight, gn.bias, size, G, float(gn.eps), nparts)
                 W2 = weight.reshape(Cout, C)
                 Wb = W2.unsqueeze(0) * sc.unsqueeze(1)            # [B, Cout, C]
                 bb = linear(sh, W2, bias)                          # [B, Cout] = sh W^T + bias (libsegx GEMM: no vendor BLAS on the step)

@@ -450,13 +450,14 @@ def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradie
 
 
 
-@pytest.mark.parametrize('B,C,G,Cout,insize,size,with_bias', [(2, 8, 4, 6, (4, 8, 8), (8, 16, 16), True), (1, 16, 8, 3, (2, 8, 16), (4, 16, 32), False),
+@pytest.mark.parametrize('B,C,G,Cout,insize,size,with_bias', [(2, 8, 4, 12, (4, 8, 8), (8, 16, 16), True), (2, 8, 4, 6, (4, 8, 8), (8, 16, 16), True), (1, 16, 8, 3, (2, 8, 16), (4, 16, 32), False), (1, 16, 8, 9, (2, 8, 16), (4, 16, 32), False),
                                                            (2, 8, 2, 5, (8, 8, 8), (8, 16, 16), True), (1, 8, 4, 4, (3, 5, 6), (6, 10, 12), True)])
 def test_group_norm_folded_into_its_pointwise_consumer(backend, B, C, G, Cout, insize, size, with_bias):
     """SF.up_group_norm_conv (r05): conv1x1(gn(up(x) + lateral(f))) with the GroupNorm folded into per-sample weights / biases -- the normalised level is never
     written, the backward needs one pass over it (segx_gn_fold_bwd) and takes the gradients of scale / shift from the consumer's per-sample weight and bias
-    gradients.  Against PyTorch: the output and EVERY gradient (x, f, lateral weight + bias, GroupNorm affine, consumer weight + bias); the last case does not
-    split into 1024-float chunks and takes the unfolded ops."""
+    gradients.  Against PyTorch: the output and EVERY gradient (x, f, lateral weight + bias, GroupNorm affine, consumer weight + bias); Cout <= 8 takes the one-node form whose backward builds the consumer's
+    data gradient on the fly (_UpGNFoldProj), Cout > 8 the (level, scale, shift) node + a per-sample GEMM; the last case does not split into 1024-float chunks
+    and takes the unfolded ops."""
     Cf = 5
     gn, ref_gn = torch.nn.GroupNorm(G, C), torch.nn.GroupNorm(G, C)
     lat, cons = torch.nn.Conv3d(Cf, C, 1), torch.nn.Conv3d(C, Cout, 1, bias=with_bias)
@@ -494,7 +495,7 @@ def test_group_norm_folded_into_its_pointwise_consumer(backend, B, C, G, Cout, i
 
 
 
-@pytest.mark.parametrize('B,C,G,Cout,insize,size', [(2, 8, 4, 3, (16, 16), (32, 32)), (1, 16, 8, 5, (8, 32), (32, 64)), (2, 8, 2, 4, (5, 6), (10, 12))])
+@pytest.mark.parametrize('B,C,G,Cout,insize,size', [(2, 8, 4, 3, (16, 16), (32, 32)), (2, 8, 4, 10, (16, 16), (32, 32)), (1, 16, 8, 5, (8, 32), (32, 64)), (2, 8, 2, 4, (5, 6), (10, 12))])
 def test_group_norm_folded_into_its_pointwise_consumer_2d(backend, B, C, G, Cout, insize, size):
     """the same fold on 2-D maps (Segtran2d.out_head_forward: bilinear up-sampling = the x pass + a y pass that leaves the statistics); last case: unfolded ops"""
     Cf = 5
