@@ -224,7 +224,7 @@ struct ConvFwdLoaderB6 {
 // + 7 and the TWO rows (tid >> 2) and 64 + (tid >> 2): the eight positions are decoded once (incrementally: ow, carry into oh, od) and serve
 // both rows; 16 lanes x 4 octets of a wave read 16 channels x 32 consecutive positions (128-byte runs wherever the octets stay in one image row).
 struct __attribute__((aligned(4))) F4u { float x, y, z, w; };       // 16 bytes at dword alignment (global_load_dwordx4 needs no more)
-template <bool FASTW>
+template <int FASTW>                                          // 0: per-position decode; 1: rows of eight / two quads (OW % 8 == 0, OW % 4 == 0); 2: contiguous octet (stride-1 'same', r05)
 struct ConvWgradLoaderB6 {
     static constexpr int NREG = 16;
     const float* X; ConvGeom q; FastDiv dOHW, dOW, dSW;
@@ -253,8 +253,8 @@ struct ConvWgradLoaderB6 {
             kd[h] = tp & 1023; kh[h] = (tp >> 10) & 1023; kw[h] = tp >> 20;
         }
         unsigned okmask = 0;
-        if (FASTW) {
-            if (q.OW % 4 != 0) {
+        if (FASTW == 2) {
+            {
                 // r05 -- stride 1 with 'same' geometry (I == O in every axis: the 3 x 3 x 3 Inception convolutions), any row length >= 7 (the 14- and 7-wide stages of
                 // cfg4, which used to stay on the fp32 engine): output position p reads input element p + tap offset, so the octet's eight gathers are eight
                 // CONSECUTIVE floats even where the octet wraps onto the next output row -- two dword-aligned 16-byte loads -- and only the validity differs: one
@@ -292,6 +292,8 @@ struct ConvWgradLoaderB6 {
                 }
                 return okmask;
             }
+        }
+        if (FASTW == 1) {
             if (q.OW % 8 != 0) {
                 // OW % 4 == 0 only (the 28-wide stages): the octet is TWO quads of four consecutive ow, the second possibly on the next output row --
                 // each quad is one 16-byte load per (channel, tap) row with its own (id, ih) test and interval of valid j (unit stride: host check)
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_fwd_x
     gemm_mainloop_x6<Cfg>(acc, la, lb, t.kbeg, t.kend, lds);
     gemm_epilogue<SEGX_EPI_NONE, Cfg>(acc, g, t);
 }
-template <class Cfg, int WPE, bool FASTW>
+template <class Cfg, int WPE, int FASTW>
 __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_wgrad_x6_kernel(GemmArgs g, ConvGeom q) {
     static_assert(Cfg::BN == 128, "conv loaders fill 128 columns");
     __shared__ __attribute__((aligned(16))) unsigned char lds[X6Lds<Cfg>::BYTES + 128];
@@ -1320,11 +1322,14 @@ static int conv3d_wgrad_impl(const float* dY, const float* X, float* dWb, int B,
     const bool fastw = (q.OW % 8 == 0 || (q.OW % 4 == 0 && q.sw == 1) || same1) && g.k_chunk % 8 == 0;          // geometry: the row-of-eight (two-quads, contiguous-octet) loader applies
     if (packed && vec && kget(knobs().engine) == SEGX_ENGINE_BF16X6 && ((fastw && (!small || q.sw == 1 || kget(knobs().conv_x6_wgrad_all) == 2)) || kget(knobs().conv_x6_wgrad_all) == 1)) {
         knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
-        if (fastw) {
-            if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, true>), grid, dim3(256), 0, stream, g, q);
-            else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, true>), grid, dim3(256), 0, stream, g, q);
-        } else if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, false>), grid, dim3(256), 0, stream, g, q);
-        else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, false>), grid, dim3(256), 0, stream, g, q);
+        if (fastw && same1) {                                   // the contiguous-octet loader has its own instantiation (in one kernel with the row forms it spilled 12 bytes)
+            if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, 2>), grid, dim3(256), 0, stream, g, q);
+            else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, 2>), grid, dim3(256), 0, stream, g, q);
+        } else if (fastw) {
+            if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, 1>), grid, dim3(256), 0, stream, g, q);
+            else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, 1>), grid, dim3(256), 0, stream, g, q);
+        } else if (small) hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<CfgCout64, 4, 0>), grid, dim3(256), 0, stream, g, q);
+        else hipLaunchKernelGGL((conv3d_wgrad_x6_kernel<Cfg128, 3, 0>), grid, dim3(256), 0, stream, g, q);
     } else if (small && vec) SEGX_CONV_WG(true, CfgCout64);
     else if (small) SEGX_CONV_WG(false, CfgCout64);
     else if (vec) SEGX_CONV_WG(true, Cfg128);
