@@ -153,43 +153,73 @@ __global__ __launch_bounds__(256) void gn_fold_bwd_apply(const float* __restrict
 // The same pass where the consumer is a projection onto NC <= 8 channels (the class projection behind out_gn3b): its data gradient
 // g[b, c, s] = sum_o Wb[b, o, c] dOut[b, o, s] is formed HERE from the NC-channel gradient (a few MB per sample: L2-resident across the planes of the sample)
 // instead of being written as a full-size tensor by a K = NC GEMM (3.5 GB at cfg5: 0.86 ms to write, 0.6 ms to read back).
+// A workgroup serves CB = 8 consecutive channels of one sample over the same spatial chunk: the NC-channel gradient is loaded ONCE per position and applied to the
+// eight planes (one plane per workgroup re-read it from L2 for each of the 832 channels: 13 GB of L2 traffic at cfg5, 3.9 TB/s of useful bytes -- r05_k).
 template <int NC>
 __global__ __launch_bounds__(256) void gn_fold_bwd_apply_proj(const float* __restrict__ dOut, const float* __restrict__ Wb, const float* __restrict__ X,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ A,
                                                               const float* __restrict__ Bc, float* __restrict__ dX, float* __restrict__ psum, int C, int G, int64_t S) {
+    constexpr int CB = 8;
     __shared__ float red[4];
-    const int bc = blockIdx.y, b = bc / C, c = bc - b * C, bg = b * G + c / (C / G);
-    const float m = mean[bg], r = rstd[bg], a = A[bg], bq = Bc[bg] * r;
-    float w[NC];
+    const int cblocks = (C + CB - 1) / CB;
+    const int b = blockIdx.y / cblocks, c0 = (blockIdx.y - b * cblocks) * CB;
+    const int cpg = C / G;
+    float w[CB][NC], m[CB], a[CB], bq[CB];
 #pragma unroll
-    for (int o = 0; o < NC; ++o) w[o] = Wb[((int64_t)b * NC + o) * C + c];
-    const float* x = X + (int64_t)bc * S; const float* go = dOut + (int64_t)b * NC * S; float* d = dX + (int64_t)bc * S;
-    float acc = 0.f;
-    if ((S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dOut) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0) {
+    for (int j = 0; j < CB; ++j) {
+        const int c = c0 + j < C ? c0 + j : C - 1, bg = b * G + c / cpg;
+        m[j] = mean[bg]; a[j] = A[bg]; bq[j] = Bc[bg] * rstd[bg];
+#pragma unroll
+        for (int o = 0; o < NC; ++o) w[j][o] = Wb[((int64_t)b * NC + o) * C + c];
+    }
+    const float* go = dOut + (int64_t)b * NC * S;
+    float acc[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) acc[j] = 0.f;
+    const bool vec = (S & 3) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dOut) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0;
+    if (vec) {
         const int64_t S4 = S >> 2;
         for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S4; s += (int64_t)gridDim.x * 256) {
             float4 gv[NC];
 #pragma unroll
             for (int o = 0; o < NC; ++o) gv[o] = reinterpret_cast<const float4*>(go + (int64_t)o * S)[s];
-            const float4 xv = reinterpret_cast<const float4*>(x)[s];
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int o = 0; o < NC; ++o) { g.x += w[o] * gv[o].x; g.y += w[o] * gv[o].y; g.z += w[o] * gv[o].z; g.w += w[o] * gv[o].w; }
-            float4 ov;
-            ov.x = g.x + a + bq * (xv.x - m); ov.y = g.y + a + bq * (xv.y - m); ov.z = g.z + a + bq * (xv.z - m); ov.w = g.w + a + bq * (xv.w - m);
-            reinterpret_cast<float4*>(d)[s] = ov;
-            acc += (ov.x + ov.y) + (ov.z + ov.w);
+            for (int j = 0; j < CB; ++j) {
+                if (c0 + j >= C) break;
+                const int64_t pl = ((int64_t)b * C + c0 + j) * S;
+                const float4 xv = reinterpret_cast<const float4*>(X + pl)[s];
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int o = 0; o < NC; ++o) { g.x += w[j][o] * gv[o].x; g.y += w[j][o] * gv[o].y; g.z += w[j][o] * gv[o].z; g.w += w[j][o] * gv[o].w; }
+                float4 ov;
+                ov.x = g.x + a[j] + bq[j] * (xv.x - m[j]); ov.y = g.y + a[j] + bq[j] * (xv.y - m[j]);
+                ov.z = g.z + a[j] + bq[j] * (xv.z - m[j]); ov.w = g.w + a[j] + bq[j] * (xv.w - m[j]);
+                reinterpret_cast<float4*>(dX + pl)[s] = ov;
+                acc[j] += (ov.x + ov.y) + (ov.z + ov.w);
+            }
         }
     } else {
         for (int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x; s < S; s += (int64_t)gridDim.x * 256) {
-            float g = 0.f;
+            float gv[NC];
 #pragma unroll
-            for (int o = 0; o < NC; ++o) g += w[o] * go[(int64_t)o * S + s];
-            const float ov = g + a + bq * (x[s] - m); d[s] = ov; acc += ov;
+            for (int o = 0; o < NC; ++o) gv[o] = go[(int64_t)o * S + s];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                if (c0 + j >= C) break;
+                const int64_t pl = ((int64_t)b * C + c0 + j) * S;
+                float g = 0.f;
+#pragma unroll
+                for (int o = 0; o < NC; ++o) g += w[j][o] * gv[o];
+                const float ov = g + a[j] + bq[j] * (X[pl + s] - m[j]);
+                dX[pl + s] = ov; acc[j] += ov;
+            }
         }
     }
-    acc = block_sum<4>(acc, red);
-    if (threadIdx.x == 0) psum[(int64_t)bc * gridDim.x + blockIdx.x] = acc;
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const float t = block_sum<4>(acc[j], red);
+        if (threadIdx.x == 0 && c0 + j < C) psum[((int64_t)b * C + c0 + j) * gridDim.x + blockIdx.x] = t;
+    }
 }
 __global__ __launch_bounds__(256) void gn_fold_plane_sums(const float* __restrict__ psum, float* __restrict__ out, int planes, int chunks) {
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -735,7 +765,7 @@ extern "C" int segx_gn_fold_bwd_proj(const float* dOut, const float* Wb, int NC,
                               "segx_gn_fold_bwd_proj: bad args");
     SEGX_REQUIRE((int64_t)B * C <= 65535, "segx_gn_fold_bwd_proj: more than 65535 planes");
     const int chunks = fpn_chunks((S & 3) ? S : S / 4, 8);
-    const dim3 grid(chunks, B * C);
+    const dim3 grid(chunks, B * ((C + 7) / 8));                  // a workgroup = one spatial chunk of EIGHT consecutive channels
 #define SEGX_GNP(N) case N: hipLaunchKernelGGL((gn_fold_bwd_apply_proj<N>), grid, dim3(256), 0, stream, dOut, Wb, X, mean, rstd, A, Bc, dX, ws, C, G, S); break;
     switch (NC) { SEGX_GNP(1) SEGX_GNP(2) SEGX_GNP(3) SEGX_GNP(4) SEGX_GNP(5) SEGX_GNP(6) SEGX_GNP(7) SEGX_GNP(8) }
 #undef SEGX_GNP
