@@ -460,6 +460,9 @@ int segx_stem_compose_bwd(const float* dWc, const float* Ws, const float* Wb, co
 /* x [B][Cb][H][W][D] -> y [B][Cc][D][H][W]: depth moved in front (segtran3d.py:422), channel Cb = 1, channels above it = 0 */
 int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc, int H, int W, int D, void* stream);
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
+/* r05: get_mask(in_bridge_to3(batch)) of segtran3d.py:420-425 without materialising the bridged image: X = the raw batch [B][Cb][H][W][D], Wb [C3][Cb] / bb [C3]
+ * (NULL: no bias) = the 1x1x1 bridge convolution; out [B][D/kd][H/kh][W/kw] (the permuted (D, H, W) order the network works in) */
+int segx_bridge_mask(const float* X, const float* Wb, const float* bb, float* out, int B, int Cb, int C3, int H, int W, int D, int kd, int kh, int kw, void* stream);
 int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream);
 /* in-step label -> n-hot maps (datasets2d.py:90-139,200-223; datasets3d.py:16-40): mode 0 fundus uint8 [B,Cin,S] -> [B,3,S];
  * 1 polyp uint8 -> [B,2,S]; 2 brats int32 [B,S] -> [B,4,S]; 3 fundus with exclusive=True (--exclusive: disc = ch0 without the cup) */

@@ -612,6 +612,37 @@ __global__ __launch_bounds__(256) void nonzero_mask_kernel(const float* __restri
     }
 }
 
+// r05: the foreground mask of the BRIDGED image (segtran3d.py:420-425: get_mask(in_bridge_to3(batch))) straight from the raw batch [B][Cb][H][W][D]: one wave per
+// pooled cell (kd x kh x kw voxels, pooled over the permuted (D, H, W) order), every voxel's C3 bridge outputs formed in the GEMM's own order (an ascending-k
+// fmaf chain, then + bias) and tested for |y| > 0.  The pooled average is positive iff one of its non-negative terms is, so the mask equals the one computed from
+// the materialised bridge output -- which cost a K = 4 GEMM at 0.5 TFLOP/s, a permuting copy and a 768-load-per-thread pooling kernel (0.57 ms of the cfg5 step).
+__global__ __launch_bounds__(256) void bridge_mask_kernel(const float* __restrict__ X, const float* __restrict__ Wb, const float* __restrict__ bb, float* __restrict__ out,
+                                                          int B, int Cb, int C3, int H, int W, int D, int kd, int kh, int kw) {
+    const int OD = D / kd, OH = H / kh, OW = W / kw;
+    const int64_t cells = (int64_t)B * OD * OH * OW;
+    const int lane = threadIdx.x & 63;
+    const int64_t chan = (int64_t)H * W * D;
+    for (int64_t cell = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); cell < cells; cell += (int64_t)gridDim.x * 4) {
+        int64_t r = cell; const int ow = (int)(r % OW); r /= OW; const int oh = (int)(r % OH); r /= OH; const int od = (int)(r % OD); const int b = (int)(r / OD);
+        const float* xb = X + (int64_t)b * Cb * chan;
+        float any = 0.f, nan = 0.f;
+        const int win = kd * kh * kw;
+        for (int t = lane; t < win; t += 64) {
+            const int z = t % kd, q = t / kd, xx = q % kw, y = q / kw;                   // z (the raw layout's contiguous axis) fastest
+            const int64_t off = ((int64_t)(oh * kh + y) * W + (ow * kw + xx)) * D + od * kd + z;
+            for (int c = 0; c < C3; ++c) {
+                float acc = 0.f;
+                for (int k = 0; k < Cb; ++k) acc = fmaf(Wb[c * Cb + k], xb[(int64_t)k * chan + off], acc);
+                const float yv = acc + (bb ? bb[c] : 0.f);
+                any = fmaxf(any, fabsf(yv) > 0.f ? 1.f : 0.f);
+                nan = fmaxf(nan, yv != yv ? 1.f : 0.f);                                    // a NaN makes the pooled average NaN, and NaN > 0 is false
+            }
+        }
+        any = wave_max(any); nan = wave_max(nan);
+        if (lane == 0) out[cell] = nan > 0.f ? 0.f : any;
+    }
+}
+
 // ---- input bridge composed into the I3D stem (segtran3d.py:420-423 `in_bridge_to3` = Conv3d(4 -> 3, 1x1x1, bias) feeding Conv3d_1a_7x7) ------------
 // Two consecutive LINEAR maps: stem(pad0(Wb x + b)) = conv(pad0([x, 1, 0...]), Wc) with Wc[o][d][t] = sum_c Ws[o][c][t] Wb[c][d] for d < Cb,
 // Wc[o][Cb][t] = sum_c Ws[o][c][t] b[c] (the bias rides on a constant-one channel, which the zero 'same' padding switches off outside the
@@ -1521,6 +1552,14 @@ extern "C" int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc
     SEGX_STREAM; SEGX_REQUIRE(X && Y && B > 0 && Cb > 0 && Cc > Cb && H > 0 && W > 0 && D > 0 && (int64_t)B * Cc <= 65535 && H <= 65535, "segx_bridge_input: bad args");
     hipLaunchKernelGGL(bridge_input_kernel, dim3((unsigned)(((W + 31) / 32) * ((D + 31) / 32)), (unsigned)H, (unsigned)(B * Cc)), dim3(256), 0, stream, X, Y, Cb, Cc, H, W, D);
     return check_launch("segx_bridge_input");
+}
+/* X: the raw batch [B][Cb][H][W][D]; Wb [C3][Cb], bb [C3] (or NULL): the input bridge; out [B][D/kd][H/kh][W/kw] = 1 where the bridged image is not identically 0
+ * inside the (kd, kh, kw) cell of the permuted (D, H, W) volume */
+extern "C" int segx_bridge_mask(const float* X, const float* Wb, const float* bb, float* out, int B, int Cb, int C3, int H, int W, int D, int kd, int kh, int kw, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(X && Wb && out && B > 0 && Cb > 0 && C3 > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "segx_bridge_mask: bad args");
+    const int64_t cells = (int64_t)B * (D / kd) * (H / kh) * (W / kw);
+    hipLaunchKernelGGL(bridge_mask_kernel, dim3((unsigned)i64min(1 << 20, (cells + 3) / 4)), dim3(256), 0, stream, X, Wb, bb, out, B, Cb, C3, H, W, D, kd, kh, kw);
+    return check_launch("segx_bridge_mask");
 }
 extern "C" int segx_nonzero_mask(const float* X, float* out, int B, int C, int D, int H, int W, int kd, int kh, int kw, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && out && B > 0 && C > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "segx_nonzero_mask: bad args");

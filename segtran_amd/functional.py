@@ -1704,6 +1704,18 @@ def nonzero_mask(x, pool):
     return out if x.dim() == 5 else out[:, 0]
 
 
+def bridge_mask(batch, weight, bias, pool):
+    """nonzero_mask(conv1x1(batch, weight, bias).permute(0, 1, 4, 2, 3), pool) for the raw 3-D batch [B, Cb, H, W, D] without the bridged image: see segx_bridge_mask."""
+    L = segx.lib()
+    x = _c(batch.detach())
+    B, Cb, H, W, D = x.shape
+    C3 = weight.shape[0]
+    kd, kh, kw = (int(v) for v in pool)
+    out = _empty(x, B, D // kd, H // kh, W // kw)
+    L.bridge_mask(x, _c(weight.detach().reshape(C3, Cb)), None if bias is None else bias.detach(), out, B, Cb, C3, H, W, D, kd, kh, kw)
+    return out
+
+
 def label_nhot(labels, mode, exclusive=False):
     """mode 'fundus' | 'polyp' (uint8 [B,Cin,*S]) | 'brats' (integer [B,*S]) -> float n-hot [B,C,*S].
     exclusive (fundus only, train2d.py --exclusive): the disc channel excludes the cup (datasets2d.py:110-111)."""

@@ -220,8 +220,8 @@ class Segtran3d(SegtranInitWeights):
             # volume exactly like the padded bridge output).  Same function and, through SF.stem_compose's chain rule, the same gradient for
             # every parameter; what disappears is the stride-2 transposed convolution onto the 3-channel image (5.4 ms of the cfg4 step) and
             # the bridge's own backward GEMMs.  The foreground mask still needs the bridged image itself (:425) -- forward only.
-            with torch.no_grad():
-                nonzero_mask = self.get_mask(self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3))
+            with torch.no_grad():      # r05: straight from the raw batch (SF.bridge_mask): no K = 4 GEMM, no permuting copy of the bridged image
+                nonzero_mask = SF.bridge_mask(batch, self.in_bridge_to3.weight, self.in_bridge_to3.bias, self.mask_pool.kernel_size)
             wc = SF.stem_compose(stem.conv3d.weight, self.in_bridge_to3.weight, self.in_bridge_to3.bias, 8)
             fd = self.backbone.extract_features(None, stem_conv_out=SF.conv3d_same(SF.bridge_input(batch, 8), wc, stem._stride))
         else:

@@ -386,6 +386,9 @@ class SegxLib:
     def gn_fold_bwd_proj(self, dOut, Wb, NC, X, mean, rstd, A, Bc, dX, plane_sums, ws, B, C, G, S):
         self._call('segx_gn_fold_bwd_proj', X, dOut, Wb, NC, X, mean, rstd, A, Bc, dX, plane_sums, ws, B, C, G, S)
 
+    def bridge_mask(self, X, Wb, bb, out, B, Cb, C3, H, W, D, kd, kh, kw):
+        self._call('segx_bridge_mask', X, X, Wb, bb, out, B, Cb, C3, H, W, D, kd, kh, kw)
+
     def groupnorm_fwd_parts(self, X, parts, nparts, w, b, Y, mean, rstd, B, C, G, S, eps):
         self._call('segx_groupnorm_fwd_parts', X, X, parts, nparts, w, b, Y, mean, rstd, B, C, G, S, eps)
 
@@ -576,7 +579,7 @@ _SIGS = {
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilpp',
     'segx_interp_gn_nparts': 'li', 'segx_interp_linear_fwd_axis2_gn': 'pppliiiilipip', 'segx_groupnorm_fwd_parts': 'ppipppppiiilfp',
-    'segx_groupnorm_stats_parts': 'pippifp', 'segx_gn_fold_bwd': 'pppppppppiiilp', 'segx_gn_fold_bwd_proj': 'ppippppppppiiilp',
+    'segx_groupnorm_stats_parts': 'pippifp', 'segx_gn_fold_bwd': 'pppppppppiiilp', 'segx_bridge_mask': 'ppppiiiiiiiiip', 'segx_gn_fold_bwd_proj': 'ppippppppppiiilp',
     'segx_interp_linear_fwd': 'pppliiiiiip', 'segx_interp_linear_fwd_axis2': 'pppliiiilp', 'segx_interp_linear_bwd_axis2': 'ppliiiilp', 'segx_interp_linear_bwd': 'ppliiiiiip', 'segx_interp_linear_bwd_axis': 'ppliilfp',
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',

@@ -216,6 +216,31 @@ def test_nonzero_mask_and_label_maps(backend):
     assert torch.equal(SF.label_nhot(lab.to(backend.dev), 'brats').cpu(), O.brats_map_label(lab).cpu())
 
 
+@pytest.mark.parametrize('bias', [False, True], ids=['no-bias', 'bias'])
+def test_bridge_mask_equals_mask_of_bridged_image(backend, bias):
+    """r05: get_mask(in_bridge_to3(batch)) (segtran3d.py:420-425) straight from the raw batch [B, Cb, H, W, D] equals the mask of the materialised, permuted bridge
+    output: cells the brain does not reach are exactly 0 in every modality, a cell alive only in a modality the bridge gives no weight is background, and a NaN voxel makes its cell background (NaN > 0 is false)."""
+    B, Cb, H, W, D, pool = 2, 4, 16, 24, 8, (4, 8, 8)
+    x = rnd(B, Cb, H, W, D, seed=61)
+    x[:, :, :8, :8] = 0; x[1, :, 8:, 16:, 4:] = 0
+    w = rnd(3, Cb, 1, 1, 1, seed=62)
+    w[:, 3] = 0
+    x[0, :3, 8:, 8:16, :4] = 0                                                           # only the modality no bridge channel reads is alive in this cell
+    x[1, 0, 3, 12, 1] = float('nan')
+    b = rnd(3, seed=63) if bias else None
+    if bias: b[1:] = 0
+    m = SF.bridge_mask(x, w, b, pool)
+    y = SF.conv1x1(x, w.reshape(3, Cb), b).permute(0, 1, 4, 2, 3)
+    ref = SF.nonzero_mask(y, pool)
+    assert m.shape == ref.shape == (B, D // 4, H // 8, W // 8)
+    assert torch.equal(m, ref)
+    assert torch.equal(ref, (F.avg_pool3d(y.abs(), pool).sum(dim=1) > 0).float())
+    if not bias:
+        assert m[0, 0, 1, 1] == 0 and m[:, :, 0, 0].sum() == 0 and m[1, 0, 0, 1] == 0 and m.sum() > 0
+    else:
+        assert m[0, 0, 1, 1] == 1                                                          # the bias alone makes the cancelled cell foreground, as in the reference
+
+
 @pytest.mark.parametrize('B,Cin,Cout,size,k,stride', [(2, 8, 12, (4, 6, 5), (3, 3, 3), (1, 1, 1)), (1, 24, 140, (3, 9, 9), (3, 3, 3), (1, 1, 1)),
                                                       (2, 16, 16, (5, 7, 7), (1, 3, 3), (1, 1, 1)), (1, 8, 8, (6, 8, 8), (3, 3, 3), (2, 2, 2)),
                                                       (1, 8, 72, (4, 6, 10), (3, 3, 3), (1, 1, 1)), (2, 16, 24, (3, 5, 8), (3, 3, 3), (1, 1, 1)),
