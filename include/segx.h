@@ -234,8 +234,10 @@ int64_t segx_bn_parts_floats(int B, int C, int64_t S);
 int segx_bn_stats_local(const float* X, float* part, float* ws, int B, int C, int64_t S, void* stream);
 int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                      const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
-                     int B, int C, int64_t S, float eps, int act, int64_t parts_floats, void* stream);
-/* parts_floats / ws_floats (r05): the floats the caller's `parts` / `ws` buffer holds.  Both calls re-derive what they need under the knob settings in force
+                     int B, int C, int64_t S, float eps, int act, int64_t parts_floats, int64_t y_bs, void* stream);
+/* y_bs (r05): 0 = Y is dense [B][C][S]; else Y is a channel slice of a wider [B][Ctot][S] tensor and y_bs its batch stride in floats (>= C * S, a multiple of 4;
+ * S % 4 == 0, Y 16-byte aligned): the branch of a channel concatenation (aj_i3d.py:118, the Inception module's torch.cat) written where it belongs.
+ * parts_floats / ws_floats (r05): the floats the caller's `parts` / `ws` buffer holds.  Both calls re-derive what they need under the knob settings in force
  * AT THE CALL and refuse a smaller buffer (a knob-3 change between sizing and launch used to write past it).
  * TEAM FORM, failure behaviour (r05): a team is at most segx_team_cap() workgroups (half the compute units the runtime reports, at most 128) and its kernels
  * are checked for >= 2 workgroups per compute unit at first use; the inter-workgroup polls are bounded (segx_tune knob 12), and a poll that expires adds one to

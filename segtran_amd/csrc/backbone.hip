@@ -220,6 +220,7 @@ struct BnFwdArgs {
     const float* resid;                          // y = act(bn(x)) * dcs[sample] + resid   (MBConv skip connection, model.py:118-122); NULL: none
     float dc_p; uint64_t seed, offset; const uint64_t* rbase;
     int C; int64_t S; float eps; int act;
+    int64_t y_bs;                                // floats between consecutive samples of Y: C * S (dense) or the batch stride of the wider tensor Y is a channel slice of
 };
 // launch 2: grid (chunks, B * C).  The workgroup of (chunk 0, sample 0) also writes mean / var and updates the running statistics.
 template <bool POOL>
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd2_kernel(BnFwdArgs g) {
     } else { m = g.mean[c]; v = g.var[c]; }
     const float sc = rsqrtf(v + g.eps) * g.w[c], sh = g.b[c] - m * sc;
     const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, bb);
-    const float* x = g.X + (int64_t)bc * S; float* y = g.Y + (int64_t)bc * S;
+    const float* x = g.X + (int64_t)bc * S; float* y = g.Y + (int64_t)bb * g.y_bs + (int64_t)c * S;
     const float* r = g.resid ? g.resid + (int64_t)bc * S : nullptr;
     const int act = g.act;
     float acc = 0.f;
@@ -306,7 +307,7 @@ __device__ __forceinline__ void bn_res_apply(const BnFwdArgs& g, int B, const f3
     for (int b = 0; b < BMAX; ++b) {
         if (b >= B) break;
         const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
-        const ws_gptr_w yb = ws_uniform_base_w(g.Y + ((int64_t)b * C + c) * S);
+        const ws_gptr_w yb = ws_uniform_base_w(g.Y + (int64_t)b * g.y_bs + (int64_t)c * S);
         if (resid && b + 1 < BMAX) {
             const ws_gptr rb = ws_uniform_base(g.resid + ((int64_t)(b + 1 < B ? b + 1 : b) * C + c) * S);
 #pragma unroll
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
     const float sc = rsqrtf(var + g.eps) * g.w[c], sh = g.b[c] - mean * sc;
     const bool resid = RESID < 0 ? g.resid != nullptr : RESID != 0;
     const float dcs = drop_connect_scale(g.dc_p, g.seed, g.offset, g.rbase, b);
-    const ws_gptr_w yb = ws_uniform_base_w(g.Y + plane);
+    const ws_gptr_w yb = ws_uniform_base_w(g.Y + (int64_t)b * g.y_bs + (int64_t)c * S);
     const ws_gptr rb = ws_uniform_base((resid ? g.resid : g.X) + plane);
     float acc = 0.f;
     constexpr int G = 4;                                         // the skip connection's float4 are requested G at a time
@@ -1411,8 +1412,11 @@ extern "C" int64_t segx_bn_pool_chunks(int B, int64_t S, int auto_stats) {
 extern "C" int64_t segx_bn_parts_floats(int B, int C, int64_t S) { return i64max(((int64_t)B * BN_SLABS + 1) * C * 4, bn_team_floats(B, C, S, false)); }
 extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, float* mean, float* var, float* run_mean, float* run_var, float momentum,
                                 const float* w, const float* b, float* Y, float* psum, const float* resid, float dc_p, uint64_t seed, uint64_t offset,
-                                int B, int C, int64_t S, float eps, int act, int64_t parts_floats, void* stream_) {
+                                int B, int C, int64_t S, float eps, int act, int64_t parts_floats, int64_t y_bs, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && mean && var && w && b && Y && B > 0 && C > 0 && S > 0 && act >= 0 && act <= 3 && (!run_mean == !run_var), "segx_bn_act_fwd2: bad args");
+    // y_bs != 0: Y is a channel slice of a wider [B][Ctot][S] tensor (a branch of a channel concatenation written in place): planes contiguous, 16-byte aligned
+    SEGX_REQUIRE(y_bs == 0 || (y_bs >= (int64_t)C * S && (y_bs & 3) == 0 && (S & 3) == 0 && (reinterpret_cast<uintptr_t>(Y) & 15) == 0),
+                 "segx_bn_act_fwd2: an output slice needs S %% 4 == 0, a batch stride that is a multiple of 4 floats and >= C * S, and a 16-byte aligned base");
     // the buffer behind `parts` is written by this call in the AUTO and merge cases: its size is part of the contract, re-derived here under the knob
     // settings of THIS call (a knob change between sizing and launch used to write past it)
     if (parts) {
@@ -1426,7 +1430,7 @@ extern "C" int segx_bn_act_fwd2(const float* X, const float* parts, int nparts, 
     BnFwdArgs g;
     g.X = X; g.w = w; g.b = b; g.Y = Y; g.parts = parts; g.nparts = nparts; g.mean = mean; g.var = var; g.run_mean = run_mean; g.run_var = run_var;
     g.momentum = momentum; g.psum = psum; g.resid = resid; g.dc_p = dc_p; g.seed = seed; g.offset = offset; g.rbase = rng_base();
-    g.C = C; g.S = S; g.eps = eps; g.act = act; g.part_cstride = -1; g.part_istride = 1;
+    g.C = C; g.S = S; g.eps = eps; g.act = act; g.part_cstride = -1; g.part_istride = 1; g.y_bs = y_bs ? y_bs : (int64_t)C * S;
     if (parts && nparts < 0) {                               // -nparts per-rank partials laid out [ranks][C] (segx_bn_stats_local on every rank, all-gathered)
         g.nparts = nparts = -nparts; g.part_cstride = 1; g.part_istride = C;
     }

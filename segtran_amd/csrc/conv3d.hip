@@ -1553,11 +1553,70 @@ extern "C" int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc
     hipLaunchKernelGGL(bridge_input_kernel, dim3((unsigned)(((W + 31) / 32) * ((D + 31) / 32)), (unsigned)H, (unsigned)(B * Cc)), dim3(256), 0, stream, X, Y, Cb, Cc, H, W, D);
     return check_launch("segx_bridge_input");
 }
+// The same mask with the batch read in whole D rows (the raw layout's contiguous axis) instead of kd-float segments: one workgroup per (sample, oh, ow) column of
+// cells, wave w takes the window rows y = w, w + 4, ..; lane l holds depth positions l, l + 64, .. (D <= 256) of every (y, x) it visits, so a wave's load is one
+// contiguous row of D floats (cfg4: 384 bytes; the cell-per-wave form fetched sixteen 16-byte segments 384 bytes apart per instruction: 0.3 TB/s).  The kd depth
+// positions of a cell are neighbouring lanes (kd a power of two <= 64): a butterfly folds them.  Four modalities onto three channels (BraTS), else the form above.
+__global__ __launch_bounds__(256) void bridge_mask_rows_kernel(const float* __restrict__ X, const float* __restrict__ Wb, const float* __restrict__ bb, float* __restrict__ out,
+                                                               int B, int H, int W, int D, int kd, int kh, int kw) {
+    constexpr int CB = 4, C3 = 3, DI = 4;
+    __shared__ float s_any[4][64 * DI], s_nan[4][64 * DI];
+    const int OD = D / kd, OH = H / kh, OW = W / kw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int r = blockIdx.x; const int ow = r % OW; r /= OW; const int oh = r % OH; const int b = r / OH;
+    float w[C3][CB], bias[C3];
+#pragma unroll
+    for (int c = 0; c < C3; ++c) {
+        bias[c] = bb ? bb[c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < CB; ++k) w[c][k] = Wb[c * CB + k];
+    }
+    const int64_t chan = (int64_t)H * W * D;
+    const float* xb = X + (int64_t)b * CB * chan;
+    float any[DI], nan[DI];
+#pragma unroll
+    for (int i = 0; i < DI; ++i) { any[i] = 0.f; nan[i] = 0.f; }
+    for (int t = wv; t < kh * kw; t += 4) {
+        const int y = t / kw, xx = t - y * kw;
+        const float* row = xb + ((int64_t)(oh * kh + y) * W + (ow * kw + xx)) * D;
+        float v[CB][DI];
+#pragma unroll
+        for (int k = 0; k < CB; ++k)
+#pragma unroll
+            for (int i = 0; i < DI; ++i) { const int d = lane + 64 * i; v[k][i] = d < D ? row[(int64_t)k * chan + d] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < DI; ++i) {
+            if (lane + 64 * i >= D) continue;
+#pragma unroll
+            for (int c = 0; c < C3; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < CB; ++k) acc = fmaf(w[c][k], v[k][i], acc);
+                const float yv = acc + bias[c];
+                any[i] = fmaxf(any[i], fabsf(yv) > 0.f ? 1.f : 0.f);
+                nan[i] = fmaxf(nan[i], yv != yv ? 1.f : 0.f);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < DI; ++i) { s_any[wv][lane + 64 * i] = any[i]; s_nan[wv][lane + 64 * i] = nan[i]; }
+    __syncthreads();
+    const int d = threadIdx.x;                                                 // 256 threads = the 256 depth positions this form serves
+    float a = fmaxf(fmaxf(s_any[0][d], s_any[1][d]), fmaxf(s_any[2][d], s_any[3][d])), n = fmaxf(fmaxf(s_nan[0][d], s_nan[1][d]), fmaxf(s_nan[2][d], s_nan[3][d]));
+    if (d >= OD * kd) { a = 0.f; n = 0.f; }                                    // depth positions behind the last whole cell
+    for (int o = 1; o < kd; o <<= 1) { a = fmaxf(a, __shfl_xor(a, o)); n = fmaxf(n, __shfl_xor(n, o)); }
+    if (d < OD * kd && (d & (kd - 1)) == 0) out[(((int64_t)b * OD + d / kd) * OH + oh) * OW + ow] = n > 0.f ? 0.f : a;
+}
+
 /* X: the raw batch [B][Cb][H][W][D]; Wb [C3][Cb], bb [C3] (or NULL): the input bridge; out [B][D/kd][H/kh][W/kw] = 1 where the bridged image is not identically 0
  * inside the (kd, kh, kw) cell of the permuted (D, H, W) volume */
 extern "C" int segx_bridge_mask(const float* X, const float* Wb, const float* bb, float* out, int B, int Cb, int C3, int H, int W, int D, int kd, int kh, int kw, void* stream_) {
     SEGX_STREAM; SEGX_REQUIRE(X && Wb && out && B > 0 && Cb > 0 && C3 > 0 && kd > 0 && kh > 0 && kw > 0 && D >= kd && H >= kh && W >= kw, "segx_bridge_mask: bad args");
     const int64_t cells = (int64_t)B * (D / kd) * (H / kh) * (W / kw);
+    if (Cb == 4 && C3 == 3 && D <= 256 && kd <= 64 && (kd & (kd - 1)) == 0 && (int64_t)B * (H / kh) * (W / kw) < 2147483647LL) {
+        hipLaunchKernelGGL(bridge_mask_rows_kernel, dim3((unsigned)((int64_t)B * (H / kh) * (W / kw))), dim3(256), 0, stream, X, Wb, bb, out, B, H, W, D, kd, kh, kw);
+        return check_launch("segx_bridge_mask/rows");
+    }
     hipLaunchKernelGGL(bridge_mask_kernel, dim3((unsigned)i64min(1 << 20, (cells + 3) / 4)), dim3(256), 0, stream, X, Wb, bb, out, B, Cb, C3, H, W, D, kd, kh, kw);
     return check_launch("segx_bridge_mask");
 }

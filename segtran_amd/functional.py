@@ -617,30 +617,32 @@ _bn_stats_sync = None        # set by segtran_amd.dist for data-parallel runs: m
 _bn_grad_sync = None         # idem: all-reduces the (sum du*xhat, sum du) pair of the BN backward
 
 
-def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=False, resid=None, dc=(0.0, 0, 0)):
+def _bn_forward(L, x, w, b, run_mean, run_var, training, momentum, eps, act, B, C, S, pool=False, resid=None, dc=(0.0, 0, 0), out=None):
     """BatchNorm (+ activation, + squeeze-excite pooling chunks, + drop_connect scale and skip add) -> (y, mean, var, n, psum, nch).
     Training, one process: ONE call of segx_bn_act_fwd2 -- one launch where a channel fits a workgroup's or a team of workgroups' registers, else a
     statistics-partials launch + the apply pass that merges them.
-    Synchronised: local statistics -> ONE all-gather -> merge kernel -> the same apply pass on the merged statistics.  Eval: the apply pass alone."""
-    y = torch.empty_like(x)
+    Synchronised: local statistics -> ONE all-gather -> merge kernel -> the same apply pass on the merged statistics.  Eval: the apply pass alone.
+    out: a channel slice [B, C, ...] of a wider tensor (planes contiguous, see _slice_writable) that receives y in place of a fresh tensor."""
+    y = torch.empty_like(x) if out is None else out
+    y_bs = 0 if out is None else out.stride(0)
     auto = training and _bn_stats_sync is None              # the library computes the statistics itself (channel-resident: one launch for the layer)
     nch = L.bn_pool_chunks(B, S, auto) if pool else 0
     psum = _empty(x, B * C * nch) if pool else None
     dc_p, seed, off = dc
     if not training:
-        L.bn_act_fwd2(x, None, 0, run_mean, run_var, None, None, 0.0, w, b, y, psum, resid, 0.0, 0, 0, B, C, S, eps, act)
+        L.bn_act_fwd2(x, None, 0, run_mean, run_var, None, None, 0.0, w, b, y, psum, resid, 0.0, 0, 0, B, C, S, eps, act, y_bs=y_bs)
         return y, run_mean, run_var, B * S, psum, nch
     mean, var = _empty(x, C), _empty(x, C)
     if _bn_stats_sync is None:
         parts = _empty(x, L.bn_parts_floats(B, C, S))
-        L.bn_act_fwd2(x, parts, 0, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+        L.bn_act_fwd2(x, parts, 0, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act, y_bs=y_bs)
         return y, mean, var, B * S, psum, nch
     # synchronised BN: ONE local partial (n, mean, M2) per channel (one launch for channel-resident shapes), ONE all-gather of [C] float4, and the
     # apply pass merges the ranks' partials itself (Chan) and updates the running statistics: 2-3 launches + 1 collective (r03: 5 + 1)
     loc = _empty(x, 4 * C)
     L.bn_stats_local(x, loc, _empty(x, L.bn_parts_floats(B, C, S)), B, C, S)
     allv, world = _bn_stats_sync(loc)
-    L.bn_act_fwd2(x, allv, -world, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act)
+    L.bn_act_fwd2(x, allv, -world, mean, var, run_mean, run_var, momentum, w, b, y, psum, resid, dc_p, seed, off, B, C, S, eps, act, y_bs=y_bs)
     return y, mean, var, B * S * world, psum, nch
 
 
@@ -700,6 +702,72 @@ class _BNAct(torch.autograd.Function):
         x, mean, var, w, b = ctx.saved_tensors
         dx, dw, db = _bn_act_backward(L, dy, x, mean, var, w, b, ctx.cfg, dc=ctx.dc)      # dy may be a channel slice of a concatenation's gradient: read in place
         return dx, dw, db, None, None, None, None, None, None, (dy if ctx.has_resid else None), None
+
+
+def _slice_writable(view, S):
+    """May a BatchNorm forward kernel write this channel slice of a wider tensor in place (segx_bn_act_fwd2 y_bs)?  Planes contiguous and 16-byte aligned."""
+    return (S % 4 == 0 and view.stride(1) == S and view[0].is_contiguous() and view.stride(0) % 4 == 0 and view.storage_offset() % 4 == 0
+            and view.data_ptr() % 16 == 0)
+
+
+class _BNActCat(torch.autograd.Function):
+    """torch.cat([head, act(bn_1(x_1)), ..., act(bn_n(x_n))], dim=1) -- the tail of an Inception module (aj_i3d.py:101-118) -- with every BatchNorm writing its
+    channels where they belong in the concatenation (segx_bn_act_fwd2 y_bs) instead of into a tensor of its own that a copy kernel then moves: one pass over each
+    branch less, forward.  Backward is what autograd did with the separate nodes: each BatchNorm reads its channel slice of the concatenation's gradient in place
+    (_plane_strided), the head's gradient is the narrow view torch.cat's backward hands out."""
+
+    @staticmethod
+    def forward(ctx, head, training, act, *flat):
+        L = segx.lib()
+        n = len(flat) // 7
+        xs = [_c(flat[7 * i]) for i in range(n)]
+        B, c0 = head.shape[0], head.shape[1]
+        sp = tuple(head.shape[2:])
+        S = 1
+        for v in sp:
+            S *= int(v)
+        Cs = [int(x.shape[1]) for x in xs]
+        out = _empty(head, B, c0 + sum(Cs), *sp)
+        out[:, :c0].copy_(head)
+        saved, cfgs, off = [], [], c0
+        for i in range(n):
+            x, (w, b, rm, rv, mom, eps) = xs[i], flat[7 * i + 1:7 * i + 7]
+            assert x.shape[0] == B and tuple(x.shape[2:]) == sp
+            dst = out[:, off:off + Cs[i]]
+            if _slice_writable(dst, S):
+                _, mean, var, cnt, _, _ = _bn_forward(L, x, w, b, rm, rv, training, mom, eps, act, B, Cs[i], S, out=dst)
+            else:                                                                          # rows that are not float4 multiples: a tensor of its own + the copy
+                y, mean, var, cnt, _, _ = _bn_forward(L, x, w, b, rm, rv, training, mom, eps, act, B, Cs[i], S)
+                dst.copy_(y)
+            saved += [x, mean, var, w, b]
+            cfgs.append((B, Cs[i], S, eps, act, training, cnt))
+            off += Cs[i]
+        ctx.cfgs, ctx.c0 = cfgs, c0
+        ctx.save_for_backward(*saved)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = segx.lib()
+        sv = ctx.saved_tensors
+        grads, off = [], ctx.c0
+        for i, cfg in enumerate(ctx.cfgs):
+            x, mean, var, w, b = sv[5 * i:5 * i + 5]
+            dx, dw, db = _bn_act_backward(L, dout[:, off:off + cfg[1]], x, mean, var, w, b, cfg)
+            grads += [dx, dw, db, None, None, None, None]
+            off += cfg[1]
+        return (dout[:, :ctx.c0], None, None) + tuple(grads)
+
+
+def bn_act_cat(head, branches, act=ACT_NONE):
+    """cat([head] + [act(bn(x)) for x, bn in branches], dim=1); `bn` = nn.BatchNorm2d/3d modules (parameter containers), all in the same mode."""
+    flat = []
+    for x, bn in branches:
+        _bn_tick(bn)
+        flat += [x, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.momentum), float(bn.eps)]
+    training = branches[0][1].training
+    assert all(bn.training == training for _, bn in branches)
+    return _BNActCat.apply(head, training, act, *flat)
 
 
 _bn_ticks = None          # a list while a model forward defers the `num_batches_tracked += 1` of its BatchNorm layers (defer_bn_ticks)

@@ -64,6 +64,7 @@ class InceptionModule(nn.Module):
         self.name = name
 
     fuse_reductions = True     # False: the reference's op order (four independent branches)
+    cat_in_place = True        # False: torch.cat assembles the module's output (tests: the two forms agree bit for bit)
 
     def forward(self, x):
         if InceptionModule.fuse_reductions:
@@ -82,6 +83,11 @@ class InceptionModule(nn.Module):
             t, x2 = SF.conv1x1(x, w120, pass_input=True)
             t = SF.bn_act_multi(t, [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU)
             y1, y2, y0 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight, with_tail=True)
+            if InceptionModule.cat_in_place:
+                # r05: the three BatchNorm + ReLU passes that end branches 1..3 write their channels straight into the concatenation (SF.bn_act_cat): torch.cat
+                # copied every branch once more (four strided copy kernels per module, 0.6-0.8 ms of a cfg4 / cfg5 step); only branch 0's slice is still copied
+                y3 = SF.conv1x1(self.b3a(x2), self.b3b.conv3d.weight, self.b3b.conv3d.bias)
+                return SF.bn_act_cat(y0, [(y1, self.b1b.bn), (y2, self.b2b.bn), (y3, self.b3b.bn)], SF.ACT_RELU)
             return torch.cat([y0, SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x2))], dim=1)
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
 

@@ -297,9 +297,14 @@ class SegxLib:
     def bn_stats_local(self, X, part, ws, B, C, S):
         self._call('segx_bn_stats_local', X, X, part, ws, B, C, S)
 
-    def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act):
+    def bn_act_fwd2(self, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, dc_p, seed, offset, B, C, S, eps, act, y_bs=0):
+        """y_bs: batch stride of Y in floats when Y is a channel slice of a wider tensor (its (sample, channel) planes contiguous); 0 = dense"""
+        if y_bs:
+            self._chk_t(Y)
+            assert Y.device == X.device and Y.dtype == torch.float32 and Y.stride(1) == S and Y.stride(0) == y_bs and Y[0].is_contiguous()
+            Y = Y.data_ptr()                                     # a strided view: the pointer and the stride are the contract
         self._call('segx_bn_act_fwd2', X, X, parts, nparts, mean, var, run_mean, run_var, momentum, w, b, Y, psum, resid, float(dc_p), seed, offset, B, C, S, eps, act,
-                   0 if parts is None else parts.numel())
+                   0 if parts is None else parts.numel(), int(y_bs))
 
     def bn_act_bwd2(self, dY, X, mean, var, w, b, dX, dw, db, ws, B, C, S, eps, act, training, gate=None, dpool=None, inv_S=0.0, dc_p=0.0, seed=0, offset=0, dy_bs=0):
         """dy_bs: batch stride of dY in floats when dY is a channel slice of a wider tensor (its (sample, channel) planes contiguous); 0 = dense"""
@@ -593,7 +598,7 @@ _SIGS = {
     'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
      'segx_plane_bias_add': 'ppplilp', 
     'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'iil', 'segx_bn_stats_local': 'pppiilp',
-    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfilp', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuullp',
+    'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfillp', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuullp',
     'segx_team_status': 'i', 'segx_team_cap': '', 'segx_occupy': 'iifpp',
     'segx_se_fwd2': 'pifpppppppppiiiip', 'segx_se_ws2_floats': 'iii', 'segx_se_bwd2': 'ppppppppfpppppppiiiip',
     'segx_bn_act_bwd_reduce': 'pppppppppiilfippffuup', 'segx_bn_act_bwd_apply': 'pppppppppiilfifppffuup',

@@ -721,3 +721,66 @@ def test_bn_backward_reads_a_concatenation_gradient_in_place(backend, shape):
     out.backward(G); outr.backward(G)
     for x, r, m, rm in zip(xs, xr, bns, refs):
         close(x.grad, r.grad, 1e-4); close(m.weight.grad, rm.weight.grad, 1e-4); close(m.bias.grad, rm.bias.grad, 1e-4)
+
+
+@pytest.mark.parametrize('path,shape', [(0, (3, 4, 6, 10)), (0, (6, 2, 32, 32)), (1, (2, 3, 130, 132)), (2, (2, 3, 130, 132)), (2, (2, 4, 3, 4, 4)), (0, (2, 4, 3, 4, 5)),
+                                        (0, (2, 3, 5, 7))])
+@pytest.mark.parametrize('training', [True, False])
+def test_bn_branches_write_their_slices_of_the_concatenation(backend, path, shape, training):
+    """r05: SF.bn_act_cat = torch.cat([head, relu(bn_1(x_1)), relu(bn_2(x_2)), relu(bn_3(x_3))], 1) with every BatchNorm kernel form (wave- / workgroup-resident, team:
+    knob 3 = 2, two launches: knob 3 = 1, eval) writing its channels into the concatenation (segx_bn_act_fwd2 y_bs); planes that are not float4 multiples (5 x 7) keep
+    the copy.  Bit-equal to the separate ops in forward, running statistics and every gradient (the backward IS the separate ops'); the head may be a strided slice."""
+    L = backend.L
+    B, C = shape[:2]
+    Cs = (C, C + 4, 2 * C)
+    bn_cls = torch.nn.BatchNorm3d if len(shape) == 5 else torch.nn.BatchNorm2d
+    def layers():
+        ms = [bn_cls(c, eps=1e-3, momentum=0.01) for c in Cs]
+        with torch.no_grad():
+            for i, m in enumerate(ms):
+                m.weight.copy_(1 + 0.2 * rnd(m.num_features, seed=160 + i)); m.bias.copy_(0.2 * rnd(m.num_features, seed=163 + i))
+                m.running_mean.copy_(0.1 * rnd(m.num_features, seed=166 + i)); m.running_var.copy_(1 + 0.1 * rnd(m.num_features, seed=169 + i).abs())
+            for m in ms:
+                m.train(training)
+        return ms
+    wide = rnd(B, 8, *shape[2:], seed=172)
+    def inputs():
+        return [(rnd(B, c, *shape[2:], seed=173 + i) * 1.3 + 0.2).requires_grad_(True) for i, c in enumerate(Cs)], wide.detach().clone().requires_grad_(True)
+    assert L.c.segx_tune(3, path) == 0
+    try:
+        bns, (xs, wd) = layers(), inputs()
+        out = SF.bn_act_cat(wd[:, 3:8], list(zip(xs, bns)), SF.ACT_RELU)
+        refs, (xr, wr) = layers(), inputs()
+        outr = torch.cat([wr[:, 3:8]] + [SF.bn_act(x, m, SF.ACT_RELU) for x, m in zip(xr, refs)], dim=1)
+        assert out.shape == outr.shape and out.is_contiguous()
+        assert torch.equal(out, outr)
+        for m, r in zip(bns, refs):
+            assert torch.equal(m.running_mean, r.running_mean) and torch.equal(m.running_var, r.running_var) and m.num_batches_tracked == r.num_batches_tracked
+        G = rnd(*out.shape, seed=180)
+        out.backward(G); outr.backward(G)
+        assert torch.equal(wd.grad, wr.grad) and wd.grad[:, :3].abs().sum() == 0
+        for x, r, m, rm in zip(xs, xr, bns, refs):
+            assert torch.equal(x.grad, r.grad) and torch.equal(m.weight.grad, rm.weight.grad) and torch.equal(m.bias.grad, rm.bias.grad)
+        # and against PyTorch itself
+        tb = layers()
+        xt = [x.detach().clone().requires_grad_(True) for x in xs]
+        outt = torch.cat([wide[:, 3:8]] + [F.relu(m(x)) for x, m in zip(xt, tb)], dim=1)
+        close(out, outt.detach())
+        outt.backward(G)
+        for x, t in zip(xs, xt):
+            close(x.grad, t.grad, 1e-4)
+    finally:
+        assert L.c.segx_tune(3, 0) == 0
+
+
+def test_bn_forward_refuses_an_output_slice_it_cannot_write_in_quads(backend):
+    L = backend.L
+    B, C, S = 2, 3, 35
+    x = rnd(B, C, S, seed=181)
+    wide = torch.zeros(B, 8, S)
+    w, b = torch.ones(C), torch.zeros(C)
+    mean, var = torch.empty(C), torch.empty(C)
+    parts = torch.empty(L.bn_parts_floats(B, C, S))
+    with pytest.raises(Exception, match='output slice'):
+        L.c.segx_bn_act_fwd2(x.data_ptr(), parts.data_ptr(), 0, mean.data_ptr(), var.data_ptr(), None, None, 0.0, w.data_ptr(), b.data_ptr(), wide[:, 4:7].data_ptr(), None, None,
+                             0.0, 0, 0, B, C, S, 1e-3, 0, parts.numel(), 8 * S, L.stream(x)) and L.check(-1, 'segx_bn_act_fwd2')

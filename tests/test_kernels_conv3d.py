@@ -216,16 +216,17 @@ def test_nonzero_mask_and_label_maps(backend):
     assert torch.equal(SF.label_nhot(lab.to(backend.dev), 'brats').cpu(), O.brats_map_label(lab).cpu())
 
 
+@pytest.mark.parametrize('Cb,D', [(4, 8), (4, 72), (4, 260), (3, 8)], ids=['rows', 'rows-two-loads', 'cells-deep', 'cells-3-modalities'])
 @pytest.mark.parametrize('bias', [False, True], ids=['no-bias', 'bias'])
-def test_bridge_mask_equals_mask_of_bridged_image(backend, bias):
+def test_bridge_mask_equals_mask_of_bridged_image(backend, bias, Cb, D):
     """r05: get_mask(in_bridge_to3(batch)) (segtran3d.py:420-425) straight from the raw batch [B, Cb, H, W, D] equals the mask of the materialised, permuted bridge
     output: cells the brain does not reach are exactly 0 in every modality, a cell alive only in a modality the bridge gives no weight is background, and a NaN voxel makes its cell background (NaN > 0 is false)."""
-    B, Cb, H, W, D, pool = 2, 4, 16, 24, 8, (4, 8, 8)
+    B, H, W, pool = 2, 16, 24, (4, 8, 8)                                                # D rows of <= 256 floats with 4 modalities: the row form; else one wave per cell
     x = rnd(B, Cb, H, W, D, seed=61)
     x[:, :, :8, :8] = 0; x[1, :, 8:, 16:, 4:] = 0
     w = rnd(3, Cb, 1, 1, 1, seed=62)
-    w[:, 3] = 0
-    x[0, :3, 8:, 8:16, :4] = 0                                                           # only the modality no bridge channel reads is alive in this cell
+    w[:, Cb - 1] = 0
+    x[0, :Cb - 1, 8:, 8:16, :4] = 0                                                           # only the modality no bridge channel reads is alive in this cell
     x[1, 0, 3, 12, 1] = float('nan')
     b = rnd(3, seed=63) if bias else None
     if bias: b[1:] = 0
@@ -299,6 +300,36 @@ def test_input_bridge_composed_into_the_stem(backend):
     G = rnd(*y.shape, seed=75)
     y.backward(G); yr.backward(G)
     close(ws.grad, wsr.grad, 1e-4); close(wb.grad, wbr.grad, 1e-4); close(bb.grad, bbr.grad, 1e-4)
+
+
+@pytest.mark.parametrize('training', [True, False])
+@pytest.mark.parametrize('size', [(3, 5, 8), (3, 5, 7)], ids=['quad-planes', 'odd-planes'])
+def test_inception_module_branches_write_the_concatenation_in_place(backend, training, size, monkeypatch):
+    """r05: the module's output assembled by the branches' BatchNorm kernels (SF.bn_act_cat, cat_in_place) against torch.cat of the same branch tensors: output,
+    input gradient, every parameter gradient and every buffer bit for bit (planes of 3 x 5 x 7 floats cannot be written in quads and keep the copy)."""
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
+    import copy
+    a = InceptionModule(24, [16, 16, 24, 8, 16, 8], 'm')
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(rnd(*p.shape, seed=int(p.numel()) % 97) * (0.2 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 else 0.0))
+    b = copy.deepcopy(a)
+    dev = torch.get_default_device()
+    a.to(dev).train(training); b.to(dev).train(training)
+    x = rnd(2, 24, *size, seed=83).requires_grad_(True); xr = x.detach().clone().requires_grad_(True)
+    monkeypatch.setattr(InceptionModule, 'fuse_reductions', True)
+    monkeypatch.setattr(InceptionModule, 'cat_in_place', True)
+    y = a(x)
+    monkeypatch.setattr(InceptionModule, 'cat_in_place', False)
+    yr = b(xr)
+    assert torch.equal(y, yr)
+    G = rnd(*y.shape, seed=84)
+    y.backward(G); yr.backward(G)
+    assert torch.equal(x.grad, xr.grad)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(u, v), k
 
 
 @pytest.mark.parametrize('training', [True, False])
