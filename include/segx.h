@@ -359,6 +359,9 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * multiple of 4), 1 wherever a slab fits the LDS, 2 never; knob 15 = the same pools with rows of a multiple of 4 floats: 1 (default) a thread keeps its four
  * cells for up to eight slices and slides along the depth (a third of the row loads), 0 = one slice per thread.  Identical results for every setting. */
 int segx_tune(int knob, int value);
+/* r06: the value a knob holds now (knobs 1-4, 6-9, 12-15; -1 for an unknown knob and for the counter knob 5): a caller that changes a process-wide default for its own
+ * lifetime (dist.GradReducer: knob 3) reads it first and puts it back instead of assuming the default */
+int segx_tune_get(int knob);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read
  * and written as float4; align_corners = False): the y and z axes of the 3-D feature pyramid's trilinear up-sampling (segtran3d.py:304,319,351,364,384)
  * after the x pass, with the lateral added in the same pass; and the adjoint (z and y before the x pass).  Same blends in the same order as the
@@ -450,6 +453,21 @@ int segx_conv3d_fwd_packed_bs(const float* X, const float* Wp, float* Y, int B, 
                               int64_t x_bstride, int64_t y_bstride, void* stream);
 int segx_conv3d_bwd_weight_packed_bs(const float* dY, const float* X, float* dWb, int B, int Cout, const int* geom, int splitk, float* workspace,
                                      int64_t dy_bstride, int64_t x_bstride, void* stream);
+/* r06 -- the 3 x 3 x 3, stride-1, 'same' convolutions (Unit3D, aj_i3d.py:75-97; every spatial convolution of the Inception modules, :198-273) with an LDS-RESIDENT
+ * INPUT HALO on the bf16x6 engine (conv3d_halo.hip): a workgroup owns 128 outputs (4 x 4 x 8 or 8 x 4 x 4) x 64 / 128 / 192 output channels, stages the halo of 8 input
+ * channels once (split into the three bf16 planes once per voxel) and takes the 27 taps as shifted fragment reads; the filters arrive pre-split from
+ * segx_conv3d_halo_pack.  Same products and fp32 accumulation as the im2col form of segx_conv3d_fwd_packed, other summation order.
+ *   segx_conv3d_halo_ok      1 when the geometry (geom as above) is served: KD = KH = KW = 3, strides 1, pads 1, extents equal, Cin % 8 == 0, the process default
+ *                            engine is bf16x6, knob 16 is on, the 4 x 4 x 8 / 8 x 4 x 4 tiling pads the extent by at most half and has >= knob 17 tiles over the batch;
+ *   segx_conv3d_halo_wq_floats  size of the packed filter bank Wq in 4-byte units (the caller allocates a float tensor): ceil(C / 8) * 7 * 3 * O * 16;
+ *   segx_conv3d_halo_pack    W [Cout][Cin][27] -> Wq; mode 0: forward (O = Cout rows, C = Cin contracted), mode 1: backward-data (O = Cin rows, C = Cout contracted,
+ *                            taps flipped) -- the data gradient is segx_conv3d_halo_fwd on dY with that bank;
+ *   segx_conv3d_halo_fwd     Y[b][Cout][D][H][W]; x_bstride / y_bstride: distance between samples in floats (0 = dense; channel slices of wider tensors as in
+ *                            segx_conv3d_fwd_packed_bs); mtile: 0 = chosen by the library, 64 / 128 / 192 = output channels per workgroup (measurements). */
+int segx_conv3d_halo_ok(int B, int Cout, const int* geom);
+int64_t segx_conv3d_halo_wq_floats(int O, int C);
+int segx_conv3d_halo_pack(const float* W, void* Wq, int O, int C, int mode, void* stream);
+int segx_conv3d_halo_fwd(const float* X, const void* Wq, float* Y, int B, int Cout, const int* geom, int64_t x_bstride, int64_t y_bstride, int mtile, void* stream);
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
 int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws /* Cout*Cin*KV floats of scratch */, int B, int Cout,
                                 const int* geom, void* stream);

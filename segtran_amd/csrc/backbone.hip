@@ -497,23 +497,23 @@ static inline void team_next_tag(unsigned& lo, unsigned& hi) {
 }
 // slots: [C][B * cpp][TEAM_SLOT] floats, mbox: [C][B * cpp][TEAM_MBOX] (common.h: team_exchange); err / spin: the process's error word and the poll bound
 struct BnTeam { float* slots; float* mbox; unsigned tag_lo, tag_hi; int B, cpp; unsigned* err; unsigned spin; };
-// Host state of the team launches (one device per process).  The ERROR WORD is pinned host memory mapped into the device: a kernel whose poll expires
-// adds one to it (system-scope atomic), segx_team_status() reads it on the host without synchronising anything.  cap = the largest team the device
-// is given: half the compute units the runtime reports, at most 128 (forward progress argument in common.h; a CU-masked / partitioned device gets
-// smaller teams, below 8 none).
-struct TeamHost { unsigned* host; unsigned* dev; int cap; };
+// Host state of the team launches.  The ERROR WORD is ONE word of pinned host memory per process, PORTABLE and mapped (every device of the process can add to
+// it): a kernel whose poll expires adds one (system-scope atomic), segx_team_status() reads it on the host without synchronising anything.  cap = the largest
+// team a device is given: half the compute units the runtime reports FOR THE DEVICE THAT IS CURRENT AT THE CALL (cached per device id), at most 128 (forward
+// progress argument in common.h; a CU-masked / partitioned device gets smaller teams, below 8 none).  r06: the cap used to be taken once from
+// whichever device was current at the first call -- possibly a sizing call before set_device -- and the word was not portable.
+#ifndef hipHostMallocPortable
+#define hipHostMallocPortable 0
+#endif
+struct TeamHost { unsigned* host; unsigned* dev; };
 static TeamHost& team_host() {
     static TeamHost t = [] {
-        TeamHost h{nullptr, nullptr, 128};
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) {
-            h.cap = cus / 2 < 128 ? cus / 2 : 128;
-            void* p = nullptr;
-            if (hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) {
-                memset(p, 0, 64);
-                void* d = nullptr;
-                if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d) { h.host = (unsigned*)p; h.dev = (unsigned*)d; }
-            }
+        TeamHost h{nullptr, nullptr};
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess && p) {
+            memset(p, 0, 64);
+            void* d = nullptr;
+            if (hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d) { h.host = (unsigned*)p; h.dev = (unsigned*)d; }
         }
         (void)hipGetLastError();                               // a process without a device (sizing calls on the build host) is not an error here
         if (!h.host) { static unsigned fallback[16]; h.host = h.dev = fallback; }
@@ -521,7 +521,21 @@ static TeamHost& team_host() {
     }();
     return t;
 }
-static inline int team_cap() { return team_host().cap; }
+static int team_cap() {
+    constexpr int MAXDEV = 64;
+    static std::atomic<int> caps[MAXDEV];                      // 0 = not asked yet
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 128; }
+    if (dev < 0 || dev >= MAXDEV) dev = 0;
+    int c = caps[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
+        c = 128;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) c = cus / 2 < 128 ? cus / 2 : 128;
+        else (void)hipGetLastError();
+        caps[dev].store(c > 0 ? c : 1, std::memory_order_relaxed);
+    }
+    return c;
+}
 // the occupancy the forward-progress argument counts on (>= 2 workgroups per CU), checked once per kernel instantiation against the runtime's own figure
 static int team_occupancy_ok(const void* kernel, const char* what) {
     static std::mutex mu; static std::unordered_map<const void*, int> seen;
@@ -581,7 +595,7 @@ __global__ __launch_bounds__(256) SEGX_MIN_WAVES_PER_SIMD(KP <= 8 ? 4 : KP <= 16
     const float mean = st.mean, var = st.n != st.n ? st.n : st.n > 0.f ? fmaxf(st.m2 / st.n, 0.f) : 0.f;
     if (r == 0 && tl == 0) {
         g.mean[c] = mean; g.var[c] = var;
-        if (g.run_mean) {
+        if (g.run_mean && st.n == st.n) {                         // a timed-out exchange (n = NaN) poisons this step's output, NOT the running statistics a later checkpoint would keep
             g.run_mean[c] = (1.0f - g.momentum) * g.run_mean[c] + g.momentum * mean;
             g.run_var[c] = (1.0f - g.momentum) * g.run_var[c] + g.momentum * (st.m2 / fmaxf(st.n - 1.0f, 1.0f));
         }

@@ -1456,9 +1456,10 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
     SEGX_REQUIRE((int64_t)q.ID * q.IH * q.IW < 2147483647LL && (int64_t)q.OD * q.OH * q.OW < 2147483647LL, "segx_maxpool3d_bwd: plane too large");
     const bool bs1w4 = (q.KD == 3 || q.KD == 1) && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && q.pw == 1 && q.OW == q.IW && q.OH == q.IH && q.IW % 4 == 0 &&
         q.IW >= 4 && (int64_t)q.ID * q.IH * q.IW % 4 == 0 && (int64_t)q.OD * q.OH * q.OW % 4 == 0 && aligned16c(dX) && aligned16c(dY) && aligned16c(arg);
+    const bool plain = addend == nullptr;            // the stride-1 forms below do not read `addend`: with one, the generic gather at the end (which honours it) serves
     const int slab_policy = kget(knobs().pool_slab);
     // default: the slab gather where neither the four-cells-per-thread form applies ... (measured, tools/pool_bench.py, profiles/r05_*_pool_bench.txt)
-    if (pool_is_s1k3_same(q) && slab_policy != 2 && (slab_policy == 1 || !bs1w4) && aligned16c(dY) && aligned16c(arg)) {
+    if (plain && pool_is_s1k3_same(q) && slab_policy != 2 && (slab_policy == 1 || !bs1w4) && aligned16c(dY) && aligned16c(arg)) {
         const int isz = q.ID * q.IH * q.IW, cap = isz <= 2048 ? 2048 : 8192, td = pool_slab_td(q, cap);
         if (td > 0 && planes * ceil_div(q.ID, td) < 2147483647LL) {
             const int nslab = ceil_div(q.ID, td);
@@ -1468,21 +1469,21 @@ extern "C" int segx_maxpool3d_bwd(const float* dY, const int* arg, float* dX, in
             return check_launch("segx_maxpool3d_bwd/slab");
         }
     }
-    if (bs1w4 && q.KD == 3 && pool_is_s1k3_same(q) && kget(knobs().pool_dslide) != 0 && q.ID >= 4) {
+    if (plain && bs1w4 && q.KD == 3 && pool_is_s1k3_same(q) && kget(knobs().pool_dslide) != 0 && q.ID >= 4) {
         const int iw4 = q.IW / 4, td = q.ID >= 16 ? 8 : q.ID >= 8 ? 4 : 2, nchunk = ceil_div(q.ID, td);
         const int64_t per = (int64_t)nchunk * q.IH * iw4;
         const dim3 gridd((unsigned)i64min(4096, (per + 255) / 256), (unsigned)i64min(65535, planes));
         hipLaunchKernelGGL(maxpool3d_bwd_s1w4d_kernel, gridd, dim3(256), 0, stream, dY, arg, dX, q, planes, td, nchunk, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
         return check_launch("segx_maxpool3d_bwd/s1w4d");
     }
-    if (bs1w4) {
+    if (plain && bs1w4) {
         const int iw4 = q.IW / 4; const int64_t isz4 = (int64_t)q.ID * q.IH * iw4;
         const dim3 grid4((unsigned)i64min(4096, (isz4 + 255) / 256), (unsigned)i64min(65535, planes));
         if (q.KD == 3) hipLaunchKernelGGL((maxpool3d_bwd_s1w4_kernel<3>), grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
         else hipLaunchKernelGGL((maxpool3d_bwd_s1w4_kernel<1>), grid4, dim3(256), 0, stream, dY, arg, dX, q, planes, make_fastdiv(q.IH * iw4), make_fastdiv(iw4));
         return check_launch("segx_maxpool3d_bwd");
     }
-    if (q.KD == 3 && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && planes <= 65535) {
+    if (plain && q.KD == 3 && q.KH == 3 && q.KW == 3 && q.sd == 1 && q.sh == 1 && q.sw == 1 && planes <= 65535) {
         const int td = ceil_div(q.ID, MP_TD), th = ceil_div(q.IH, MP_TH), tw = ceil_div(q.IW, MP_TW);
         hipLaunchKernelGGL(maxpool3d_bwd_s1k3_kernel, dim3((unsigned)(td * th * tw), (unsigned)planes), dim3(256), 0, stream, dY, arg, dX, q, th, tw);
         return check_launch("segx_maxpool3d_bwd");

@@ -862,9 +862,31 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 5) { return k.x6_launches.exchange(0); }
     if (knob == 14) { if (value < 0 || value > 2) return -1; k.pool_slab = value; return 0; }
     if (knob == 15) { if (value != 0 && value != 1) return -1; k.pool_dslide = value; return 0; }
+    if (knob == 16) { if (value != 0 && value != 1) return -1; k.conv_halo = value; return 0; }
+    if (knob == 17) { if (value < 1 || value > (1 << 24)) return -1; k.conv_halo_min_tiles = value; return 0; }
     if (knob == 12) { if (value < 32 || value > (1 << 24)) return -1; k.team_spin = value; return 0; }     // poll bound of a team exchange
     if (knob == 13) { if (value < 0 || value > 4096) return -1; k.team_drop = value; return 0; }          // fault injection (tests): unlaunched tail of a team grid
     return -1;
+}
+extern "C" int segx_tune_get(int knob) {
+    const segx::Knobs& k = segx::knobs();
+    switch (knob) {
+        case 1: return segx::kget(k.interp_variant);
+        case 2: return segx::kget(k.conv_small_policy);
+        case 3: return segx::kget(k.bn_path);
+        case 4: return segx::kget(k.engine);
+        case 6: return segx::kget(k.x6_variant);
+        case 7: return segx::kget(k.conv_x6_wgrad_all);
+        case 8: return segx::kget(k.dw_strip_outputs);
+        case 9: return segx::kget(k.ws_grid);
+        case 12: return segx::kget(k.team_spin);
+        case 13: return segx::kget(k.team_drop);
+        case 14: return segx::kget(k.pool_slab);
+        case 15: return segx::kget(k.pool_dslide);
+        case 16: return segx::kget(k.conv_halo);
+        case 17: return segx::kget(k.conv_halo_min_tiles);
+        default: return -1;
+    }
 }
 // RandomResizedCrop (datasets3d.py:611-665) as ONE gather pass: the volume is (virtually) resampled to (D, H, W) with the trilinear
 // align_corners=False rule, zero-padded, and a window of (od, oh, ow) voxels is cut out at offset (oz, oy, ox) measured in the resampled,

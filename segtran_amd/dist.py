@@ -65,10 +65,13 @@ class GradReducer:
         # of training BatchNorm (backbone.hip) needs its workgroups co-resident, which a concurrent kernel can delay.  Its polls are bounded and fail
         # loudly (segx_team_status), but a data-parallel step should not depend on that: with overlap on, BatchNorm without SyncBN takes the
         # two-launch form (knob 3 = 1; the synchronised form never uses teams).  `overlap_bn_teams=True` keeps them (measurements).
-        self.bn_teams_off = False
+        self.bn_teams_off, self._bn_path_prev = False, 0
         if overlap and (self.world > 1 or self.force) and self.flat.is_cuda and not overlap_bn_teams:
             from . import segx
-            self.bn_teams_off = segx.lib().c.segx_tune(3, 1) == 0
+            c = segx.lib().c
+            self._bn_path_prev = c.segx_tune_get(3)                 # whatever SEGX_TUNE / a bench loop / a test put there: restored by close(), left alone unless it is the default
+            if self._bn_path_prev == 0:
+                self.bn_teams_off = c.segx_tune(3, 1) == 0
         self._armed, self._hooks = False, []
         self._pending, self._need, self._works, self._launched = [], [], [], []
         self._src, self._slot = None, 0
@@ -178,7 +181,7 @@ class GradReducer:
         self._hooks, self._armed = [], False
         if self.bn_teams_off:
             from . import segx
-            segx.lib().c.segx_tune(3, 0)
+            segx.lib().c.segx_tune(3, self._bn_path_prev)
             self.bn_teams_off = False
 
 

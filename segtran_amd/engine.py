@@ -352,6 +352,13 @@ class GraphedTrainStep:
         self.replays += 1
         return self.loss
 
+    def check(self):
+        """Call at a synchronisation point (logging, before saving a checkpoint): the captured optimizer step runs no host code, so a team exchange that timed out
+        inside the LAST replay has already applied its NaN gradients -- this raises then, and the model must be reloaded from the last good checkpoint (the
+        BatchNorm running statistics are not touched by a failed exchange, the weights and moments are)."""
+        torch.cuda.current_stream().synchronize()
+        segx.lib().team_check()
+
     @property
     def stats(self):
         return self.step.stats

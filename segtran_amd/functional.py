@@ -185,6 +185,24 @@ class _BGemm(torch.autograd.Function):
         return dA, dB, dbias, None, None, None, None, None
 
 
+def _tag_plane_sums(dbase, rsum, B, C, S):
+    """_UpGN* hand the lateral convolution's bias gradient (the sums over every (sample, channel) plane of `dbase`) along with `dbase` itself.  The tag is bound
+    to the tensor's CONTENTS and LAYOUT -- version counter, storage address, (B, C, S) -- so that a hook / scaling / clipping that touches the gradient in place,
+    or a consumer with another plane layout, makes `_take_plane_sums` ignore it (the bare attribute was trusted on numel and device alone)."""
+    dbase._segx_plane_sums = (rsum, dbase._version, dbase.data_ptr(), (int(B), int(C), int(S)))
+
+
+def _take_plane_sums(dC, nbt, M, N):
+    tag = getattr(dC, '_segx_plane_sums', None)
+    if tag is None:
+        return None
+    del dC._segx_plane_sums                            # one consumer: a second BIAS_M GEMM reached by the same tensor object computes its own row sums
+    rs, version, ptr, bcs = tag
+    if version != dC._version or ptr != dC.data_ptr() or bcs != (int(nbt), int(M), int(N)) or not dC.is_contiguous() or rs.device != dC.device:
+        return None
+    return rs
+
+
 def _bias_grad(L, dC, s):
     """Only the layouts the model uses: C contiguous [nb0, nb1, M, N] (or [M, N])."""
     nb0, nb1 = s.nb
@@ -211,8 +229,8 @@ def _bias_grad(L, dC, s):
     # BIAS_M (conv-style, one bias per output row m): row sums, batch-summed
     assert s.bias_b1 == 0
     nbt = nb0 * nb1
-    rs = getattr(dC, '_segx_plane_sums', None)         # left by _UpGN.backward on the gradient it hands to the lateral: the plane sums in closed form
-    if rs is None or rs.numel() != nbt * s.M or rs.device != dC.device:
+    rs = _take_plane_sums(dC, nbt, s.M, s.N)           # left by _UpGN*.backward on the gradient they hand to the lateral: the plane sums in closed form
+    if rs is None:
         rs = _empty(dC, nbt * s.M)
         L.rowsum(dC, rs, nbt * s.M, s.N)
     if s.bias_b0 == s.M and nb1 == 1:                  # one bias vector per batch member (conv1x1_per_sample with per-sample biases): no sum over the batch
@@ -1142,7 +1160,7 @@ class _UpGN(torch.autograd.Function):
         dbase = None
         if ctx.needs_input_grad[1]:
             dbase = dpre
-            dbase._segx_plane_sums = rsum                    # sum over every (sample, channel) plane of dbase: the lateral convolution's bias gradient (_bias_grad)
+            _tag_plane_sums(dbase, rsum, B, C, S)            # sum over every (sample, channel) plane of dbase: the lateral convolution's bias gradient (_bias_grad)
         return dx, dbase, dw, db, None, None, None, None
 
 
@@ -1207,7 +1225,7 @@ class _UpGNFold(torch.autograd.Function):
         dbase = None
         if ctx.needs_input_grad[1]:
             dbase = dtot
-            dbase._segx_plane_sums = rsum                     # plane sums of dbase: the lateral convolution's bias gradient (_bias_grad)
+            _tag_plane_sums(dbase, rsum, B, C, S)             # plane sums of dbase: the lateral convolution's bias gradient (_bias_grad)
         return dx, dbase, dw, db, None, None, None, None
 
 
@@ -1272,7 +1290,7 @@ class _UpGNFoldProj(torch.autograd.Function):
         dbase = None
         if ctx.needs_input_grad[1]:
             dbase = dtot
-            dbase._segx_plane_sums = rsum
+            _tag_plane_sums(dbase, rsum, B, C, S)
         return dx, dbase, dw, db, dW2.view(wshape), dbias, None, None, None, None
 
 
@@ -1416,6 +1434,11 @@ class _Conv3d(torch.autograd.Function):
         OW = (IW + pw + pwb - KW) // stride[2] + 1
         y = _empty(x, B, Cout, OD, OH, OW)
         geom = (Cin, ID, IH, IW, OD, OH, OW, KD, KH, KW) + tuple(stride) + (pd, ph, pw)
+        if L.conv3d_halo_ok(B, Cout, geom):  # r06: 3 x 3 x 3 stride-1 'same' on the LDS-resident-halo kernel (conv3d_halo.hip); filters pre-split once per call
+            L.conv3d_halo_fwd(x, L.conv3d_halo_pack(w, Cout, Cin, 0), y, B, Cout, geom)
+            ctx.geom, ctx.stride, ctx.pads = geom, tuple(stride), pads
+            ctx.save_for_backward(x, w)
+            return y
         sk = L.conv3d_splitk(B, Cout, geom, False)
         ws = _empty(x, sk * y.numel()) if sk > 1 else None
         if Cin % 8 == 0:                    # packed contraction order: one tap decode per eight gathers (see conv3d.hip)
@@ -1445,14 +1468,17 @@ class _Conv3d(torch.autograd.Function):
                 (pd, _), (ph, _), (pw, _) = ctx.pads
                 g2 = (Cout, OD, OH, OW, ID, IH, IW, KD, KH, KW, 1, 1, 1, KD - 1 - pd, KH - 1 - ph, KW - 1 - pw)
                 dx = torch.empty_like(x)
-                sk = L.conv3d_splitk(B, Cin, g2, False)
-                ws = _empty(x, sk * dx.numel()) if sk > 1 else None
-                if Cout % 8 == 0:
-                    L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
-                    L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws, packed=True)
+                if L.conv3d_halo_ok(B, Cin, g2):
+                    L.conv3d_halo_fwd(dy, L.conv3d_halo_pack(w, Cin, Cout, 1), dx, B, Cin, g2)
                 else:
-                    L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
-                    L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws)
+                    sk = L.conv3d_splitk(B, Cin, g2, False)
+                    ws = _empty(x, sk * dx.numel()) if sk > 1 else None
+                    if Cout % 8 == 0:
+                        L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
+                        L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws, packed=True)
+                    else:
+                        L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
+                        L.conv3d_fwd(dy, wt, dx, B, Cin, g2, sk, ws)
             elif Cin <= 4:
                 # strided transposed convolution onto <= 4 channels (the 7x7x7 stride-2 I3D stem): direct gather kernel
                 dx = torch.empty_like(x)
@@ -1515,10 +1541,13 @@ class _Conv3dSlices(torch.autograd.Function):
             assert Cin % 8 == 0 and Cout % 8 == 0 and KD % 2 == KH % 2 == KW % 2 == 1, 'slice convolutions: channel counts in multiples of 8, odd windows'
             geom = (Cin, D, H, W, D, H, W, KD, KH, KW, 1, 1, 1, KD // 2, KH // 2, KW // 2)
             y = _empty(t, B, Cout, D, H, W)
-            sk = L.conv3d_splitk(B, Cout, geom, False)
-            wp = torch.empty_like(w)
-            L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
-            L.conv3d_fwd(t[:, c0:], wp, y, B, Cout, geom, sk, _empty(t, sk * y.numel()) if sk > 1 else None, packed=True, x_bs=Ct * vol)
+            if L.conv3d_halo_ok(B, Cout, geom):
+                L.conv3d_halo_fwd(t[:, c0:], L.conv3d_halo_pack(w, Cout, Cin, 0), y, B, Cout, geom, x_bs=Ct * vol)
+            else:
+                sk = L.conv3d_splitk(B, Cout, geom, False)
+                wp = torch.empty_like(w)
+                L.conv3d_pack_weights(w, wp, Cout, Cin, KD * KH * KW, 0)
+                L.conv3d_fwd(t[:, c0:], wp, y, B, Cout, geom, sk, _empty(t, sk * y.numel()) if sk > 1 else None, packed=True, x_bs=Ct * vol)
             ys.append(y); geoms.append(geom); c0 += Cin
         assert c0 <= Ct, 'the slices exceed the tensor'      # channels beyond the last slice (another consumer's, e.g. Inception branch 0)
         ctx.geoms = geoms
@@ -1550,11 +1579,14 @@ class _Conv3dSlices(torch.autograd.Function):
             KV = KD * KH * KW
             dy = _c(dy) if dy is not None else torch.zeros(B, Cout, D, H, W, dtype=torch.float32, device=t.device)
             if dt is not None:
-                wt = torch.empty_like(w)
                 g2 = (Cout, D, H, W, D, H, W, KD, KH, KW, 1, 1, 1, KD // 2, KH // 2, KW // 2)
-                sk = L.conv3d_splitk(B, Cin, g2, False)
-                L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
-                L.conv3d_fwd(dy, wt, dt[:, c0:], B, Cin, g2, sk, _empty(t, sk * B * Cin * vol) if sk > 1 else None, packed=True, y_bs=Ct * vol)
+                if L.conv3d_halo_ok(B, Cin, g2):
+                    L.conv3d_halo_fwd(dy, L.conv3d_halo_pack(w, Cin, Cout, 1), dt[:, c0:], B, Cin, g2, y_bs=Ct * vol)
+                else:
+                    wt = torch.empty_like(w)
+                    sk = L.conv3d_splitk(B, Cin, g2, False)
+                    L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
+                    L.conv3d_fwd(dy, wt, dt[:, c0:], B, Cin, g2, sk, _empty(t, sk * B * Cin * vol) if sk > 1 else None, packed=True, y_bs=Ct * vol)
             dw = None
             if ctx.needs_input_grad[2 + i]:
                 N = Cin * KV

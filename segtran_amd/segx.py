@@ -492,6 +492,23 @@ class SegxLib:
         rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_fwd', Cout, P, K, B, splitk), call)
         self.check(rc, 'segx_conv3d_fwd')
 
+    # ---- 3 x 3 x 3 stride-1 'same' convolutions with an LDS-resident halo (conv3d_halo.hip, r06) ----
+    def conv3d_halo_ok(self, B, Cout, geom):
+        return bool(self.c.segx_conv3d_halo_ok(B, Cout, self._geom(geom)))
+
+    def conv3d_halo_pack(self, W, O, C, mode):
+        """W [Cout][Cin][3][3][3] -> the pre-split (three bf16 planes) filter bank of the halo kernels; mode 0 forward (O = Cout, C = Cin), 1 backward-data (O = Cin, C = Cout)"""
+        Wq = torch.empty(int(self.c.segx_conv3d_halo_wq_floats(O, C)), dtype=torch.float32, device=W.device)
+        self._call('segx_conv3d_halo_pack', Wq, W, Wq, O, C, mode)
+        return Wq
+
+    def conv3d_halo_fwd(self, X, Wq, Y, B, Cout, geom, x_bs=0, y_bs=0, mtile=0):
+        self._chk_t(X, Wq, Y)
+        P = geom[4] * geom[5] * geom[6]; K = geom[0] * 27
+        call = lambda: self.c.segx_conv3d_halo_fwd(_ptr(X), _ptr(Wq), _ptr(Y), B, Cout, self._geom(geom), int(x_bs), int(y_bs), int(mtile), self.stream(Y))
+        rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_halo_fwd', Cout, P, K, B, 1), call)
+        self.check(rc, 'segx_conv3d_halo_fwd')
+
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
         wt = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
         self._chk_t(dY, W, dX)
@@ -589,8 +606,9 @@ _SIGS = {
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
-    'segx_tune': 'ii', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_tune_get': 'i', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
+    'segx_conv3d_halo_ok': 'iip', 'segx_conv3d_halo_wq_floats': 'ii', 'segx_conv3d_halo_pack': 'ppiiip', 'segx_conv3d_halo_fwd': 'pppiipllip',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplppp',
     'segx_bn_ws_floats': 'iil', 

@@ -303,6 +303,14 @@ def run(args, cfg, batches=None):
             fixed = engine.synth_batch(cfg, args.batch_size, dev, seed=args.seed + rank)
             batches = iter(lambda: fixed, None)
     t0 = time.time()
+    try:
+        return _train_loop(net, args, step, opt, batches, dev, iter_num, is_master, ckpt_dir, t0)
+    finally:
+        if reducer is not None:
+            reducer.close()                       # hooks off, BatchNorm's process-wide form back to what it was
+
+
+def _train_loop(net, args, step, opt, batches, dev, iter_num, is_master, ckpt_dir, t0):
     for batch in batches:
         iter_num += 1
         step(*(t.to(dev, non_blocking=True) for t in batch))

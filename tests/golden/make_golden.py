@@ -11,7 +11,7 @@ Runs ONLY in the build container (the reference does not exist on the GPU box). 
 Fixtures are DATA (inputs / expected outputs); no reference source is stored.
 Usage:  python tests/golden/make_golden.py [case ...]
 """
-import os, sys, json, hashlib, copy
+import os, re, sys, json, hashlib, copy
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -847,7 +847,7 @@ def _force_double_inputs(net):
         m.register_forward_pre_hook(hook)
 
 
-def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
+def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True, train_only=False):
     """One BASELINE shape at batch 1: (a) eval forward -> packed label bits of EVERY logit + the near-zero logits, (b) one
     dropout-free train-mode step (batch statistics in every BatchNorm, drop_connect off) -> loss + sampled parameter gradients,
     both from the real reference in fp32, plus the same two runs of the same reference modules in fp64 as referee."""
@@ -855,16 +855,18 @@ def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
     t0 = time.time()
     net = build(); sd = load_synth(net)
     fwd_o = O.segtran2d_forward if dim == 2 else O.segtran3d_forward
-    net.eval()
-    with torch.no_grad():
-        y = R.quiet(net, x)
-        yo = fwd_o(sd, x, dims)
-    close(yo, y, 5e-5, tag + ' eval logits (oracle)')
-    arrs = dict(shape=np.array(y.shape), absmax=y.abs().max(), logits=sample(y, 65536)[::4], labels=np.packbits((y > 0).numpy().reshape(-1)))
-    flat = y.reshape(-1)
-    near = torch.nonzero(flat.abs() < NEAR0).reshape(-1)
-    arrs['near_idx'] = near.to(torch.int32); arrs['near_val'] = flat[near]
-    print('    %s eval fwd done %.0fs, %d logits with |y| < %g, min |y| %.2e' % (tag, time.time() - t0, near.numel(), NEAR0, flat.abs().min().item()))
+    arrs = {}
+    if not train_only:
+        net.eval()
+        with torch.no_grad():
+            y = R.quiet(net, x)
+            yo = fwd_o(sd, x, dims)
+        close(yo, y, 5e-5, tag + ' eval logits (oracle)')
+        arrs = dict(shape=np.array(y.shape), absmax=y.abs().max(), logits=sample(y, 65536)[::4], labels=np.packbits((y > 0).numpy().reshape(-1)))
+        flat = y.reshape(-1)
+        near = torch.nonzero(flat.abs() < NEAR0).reshape(-1)
+        arrs['near_idx'] = near.to(torch.int32); arrs['near_val'] = flat[near]
+        print('    %s eval fwd done %.0fs, %d logits with |y| < %g, min |y| %.2e' % (tag, time.time() - t0, near.numel(), NEAR0, flat.abs().min().item()))
     # train step
     net.train()
     if dim == 2:
@@ -874,6 +876,8 @@ def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
     rg = dict(net.named_parameters())
     gscale = max(p.grad.abs().max().item() for p in rg.values() if p.grad is not None)
     arrs.update(train_logits=sample(yt, 65536)[::4], loss=loss.detach(), gscale=np.array(gscale))
+    if train_only:
+        arrs.update(shape=np.array(yt.shape), absmax=yt.detach().abs().max())
     keys = [k for k in grad_keys if k in rg and rg[k].grad is not None]
     for k in keys:
         arrs['grad:' + k] = sample(rg[k].grad)
@@ -882,18 +886,21 @@ def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
     save(tag, **arrs)                 # the fp32 part is complete: keep it even if the (slow) referee below is interrupted
     if referee64:
         # the SAME reference modules in double precision: tells which side is off when fp32 results disagree
+        del net, yt, loss
+        import gc; gc.collect()
         net64 = build(); net64.load_state_dict(sd); net64 = net64.double()
         _force_double_inputs(net64)
         if dim == 2:
             net64.backbone._global_params = net64.backbone._global_params._replace(drop_connect_rate=0.0)
-        net64.eval()
-        with torch.no_grad():
-            y64 = R.quiet(net64, x.double())
-        f64 = y64.reshape(-1)
-        arrs['near_val64'] = f64[near]
-        arrs['logits64'] = sample(y64, 65536)[::4]
-        arrs['ref32_vs_64_logit_err'] = (y.double() - y64).abs().max()
-        arrs['ref32_label_flips_vs_64'] = np.array(int(((y > 0) != (y64 > 0)).sum()))
+        if not train_only:
+            net64.eval()
+            with torch.no_grad():
+                y64 = R.quiet(net64, x.double())
+            f64 = y64.reshape(-1)
+            arrs['near_val64'] = f64[near]
+            arrs['logits64'] = sample(y64, 65536)[::4]
+            arrs['ref32_vs_64_logit_err'] = (y.double() - y64).abs().max()
+            arrs['ref32_label_flips_vs_64'] = np.array(int(((y > 0) != (y64 > 0)).sum()))
         net64.train()
         yt64 = R.quiet(net64, x.double())
         l64 = O.seg_loss(yt64, nhot.double(), pw.double())[0]; l64.backward()
@@ -905,19 +912,25 @@ def _full_one(tag, dim, build, x, nhot, pw, dims, grad_keys, referee64=True):
             worst = max(worst, (rg64[k].grad - rg[k].grad.double()).abs().max().item() / gscale)
         arrs['ref32_vs_64_grad_err'] = np.array(worst)
         print('    %s fp64 referee done %.0fs: fp32 reference vs fp64: logits %.2e, %d label flips, gradients %.2e of gscale'
-              % (tag, time.time() - t0, arrs['ref32_vs_64_logit_err'].item(), int(arrs['ref32_label_flips_vs_64']), worst))
+              % (tag, time.time() - t0, float(arrs.get('ref32_vs_64_logit_err', float('nan'))), int(arrs.get('ref32_label_flips_vs_64', -1)), worst))
     save(tag, **arrs)
 
 
 def case_fullshape():
     """BASELINE.json shapes at batch 1: label bits of the whole map, full-size gradients, fp64 referee.
-    Sub-cases: full_cfg2 full_cfg3 full_cfg4 full_cfg5 (python make_golden.py fullshape full_cfg4 ...)."""
+    Sub-cases: full_cfg2 full_cfg3 full_cfg4 full_cfg5 (python make_golden.py fullshape full_cfg4 ...).
+    r06: full_cfg2_b6 / full_cfg4_b4 = the exact batches bench.py times (reference train2d.py:1147-1245 at --bs 6, train3d.py at --bs 4).
+    At those batches only the dropout-free TRAIN step of the fp32 reference fits the 64-GiB build container (the eval pass + oracle pass of cfg2 at batch 6 grew
+    past 58 GiB and was stopped; the fp64 referee needs twice the fp32 step): `train_only` fixtures hold loss, sampled train-mode logits and the sampled gradients
+    (fp32 reference and, where the container's memory allows the fp64 train step, the fp64 referee columns), no label bits.  They are generated
+    explicitly (`python make_golden.py fullshape full_cfg2_b6 full_cfg4_b4`, ~1 h of 8 cores), not by the default case list."""
     want = [a for a in sys.argv[2:] if a.startswith('full_')] or ['full_cfg2', 'full_cfg3', 'full_cfg4', 'full_cfg5', 'full_cfg2_b2', 'full_cfg4_b2']
     for tag in want:
         # *_b2 (VERDICT r02 item 1): the same shapes at BATCH 2 -- train-mode BatchNorm statistics over two samples, (B, M) batch strides of
         # the attention GEMMs, and B x N token rows above the product's re-association gate at cfg4 (2 x 2352 rows)
-        B = 2 if tag.endswith('_b2') else 1
-        base = tag[:-3] if B == 2 else tag
+        mb = re.search(r'_b(\d+)$', tag)               # *_b6 / *_b4 (VERDICT r05 item 4a): the batches bench.py times (cfg2 bs 6, cfg4 bs 4)
+        B = int(mb.group(1)) if mb else 1
+        base = tag[:mb.start()] if mb else tag
         if base in ('full_cfg2', 'full_cfg3'):
             S, task = (512, 'fundus') if base == 'full_cfg2' else (352, 'polyp')
             x = synth_image2d(B, S, 1337)
@@ -928,13 +941,13 @@ def case_fullshape():
             else:
                 nhot, pw = O.fundus_map_mask(mask), O.bce_pos_weight([0., 1., 2.])
             nc = 3 if task == 'fundus' else 2
-            _full_one(tag, 2, lambda: R.ref_segtran2d(num_classes=nc, dropout_prob=0), x, nhot.float(), pw, [1792, 1792, 896, 448], FULL_GRAD_KEYS_2D)
+            _full_one(tag, 2, lambda: R.ref_segtran2d(num_classes=nc, dropout_prob=0), x, nhot.float(), pw, [1792, 1792, 896, 448], FULL_GRAD_KEYS_2D, train_only=B >= 4)
         else:
             size, tl = ((112, 112, 96), 1) if base == 'full_cfg4' else ((128, 128, 128), 2)
             x, lab = synth_brats(B, *size, 1337)
             nhot, pw = O.brats_map_label(lab), O.bce_pos_weight([0., 3., 1., 1.75])
             _full_one(tag, 3, lambda: R.ref_segtran3d(num_translayers=tl, compress=(1,) * (tl + 1), dropout_prob=0), x, nhot.float(), pw,
-                      [1024] * (tl + 1), FULL_GRAD_KEYS_3D)
+                      [1024] * (tl + 1), FULL_GRAD_KEYS_3D, train_only=B >= 4)
 
 
 def case_augment():

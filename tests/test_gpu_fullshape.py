@@ -1,4 +1,4 @@
-"""GPU (-m gpu): parity at the BASELINE.json SHAPES (batch 1, and batch 2 for cfg2 / cfg4) against fixtures produced by the real reference on the CPU
+"""GPU (-m gpu): parity at the BASELINE.json SHAPES (batch 1, batch 2 for cfg2 / cfg4, and -- train step -- the benchmarked batches 6 / 4 of cfg2 / cfg4) against fixtures produced by the real reference on the CPU
 (tests/golden/make_golden.py case_fullshape): cfg2 512 x 512, cfg3 352 x 352, cfg4 112 x 112 x 96, cfg5 128^3 (two layers, 1024 attractors).
 
   * eval forward: every hardened label of the WHOLE map is compared (the fixture stores the packed bits of all logits); a mismatch is
@@ -51,9 +51,11 @@ def _inputs(cfg, B=1):
 
 
 def _case(case):
-    """'cfg4' -> ('cfg4', 1, 'full_cfg4'); 'cfg4_b2' -> ('cfg4', 2, 'full_cfg4_b2') (the batch-2 fixtures of VERDICT r02 item 1)"""
-    cfg = case[:-3] if case.endswith('_b2') else case
-    return cfg, (2 if case.endswith('_b2') else 1), 'full_' + case
+    """'cfg4' -> ('cfg4', 1, 'full_cfg4'); 'cfg4_b2' -> ('cfg4', 2, 'full_cfg4_b2') (the batch-2 fixtures of VERDICT r02 item 1); 'cfg2_b6' / 'cfg4_b4' (r06, VERDICT r05
+    item 4a): the batches bench.py times -- train-step fixtures only (make_golden.py case_fullshape: the eval + oracle passes at those batches do not fit the container)"""
+    import re
+    m = re.search(r'_b(\d+)$', case)
+    return (case[:m.start()] if m else case), (int(m.group(1)) if m else 1), 'full_' + case
 
 
 @pytest.fixture
@@ -100,7 +102,7 @@ def test_fullshape_eval_every_label(case, engine_sel):
 # through the default gate (2 x 2352 >= 4096).
 @pytest.mark.parametrize('engine_sel,reassociated,gate', [('x6', True, 'default'), ('x6', True, 'bench'), ('x6', False, 'default'), ('f32', True, 'bench')],
                          indirect=['engine_sel'], ids=['x6-reassociated', 'x6-reassociated-bench-gate', 'x6-reference-op-order', 'f32-reassociated-bench-gate'])
-@pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2'])
+@pytest.mark.parametrize('case', ['cfg2', 'cfg3', 'cfg4', 'cfg5', 'cfg2_b2', 'cfg4_b2', 'cfg2_b6', 'cfg4_b4'])
 def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, monkeypatch):
     from segtran_amd.networks import segtran_shared as ss
     cfg, B, tag = _case(case)
@@ -120,9 +122,10 @@ def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, mo
     net.train()
     x, raw = _inputs(cfg, B)
     y = net(x.to(DEV))
+    has64 = 'train_logits64' in g                          # the fp64 referee columns (absent from a train-only fixture generated without them: then the plain bars hold)
     lerr = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits']).abs().max().item()
-    lerr64 = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits64']).abs().max().item()
-    ref64 = (g['train_logits'] - g['train_logits64']).abs().max().item()
+    lerr64 = (sample(y.detach().cpu(), 65536)[::4] - g['train_logits64']).abs().max().item() if has64 else float('inf')
+    ref64 = (g['train_logits'] - g['train_logits64']).abs().max().item() if has64 else 0.0
     assert lerr < 1e-3 and (lerr <= 2e-4 * float(g['absmax']) or lerr64 <= REFEREE * ref64), (lerr, lerr64, ref64)
     pw, cw = engine.loss_weights(c['task'], DEV)
     loss, _ = SF.seg_loss(y, engine.map_mask(c['task'], raw.to(DEV)), pw, cw)
@@ -139,9 +142,9 @@ def test_fullshape_train_step_gradients(case, reassociated, gate, engine_sel, mo
         assert got is not None, name
         got = sample(got.cpu()) if got.numel() != v.numel() else got.cpu().reshape(-1)
         e32 = (got - v.reshape(-1)).abs().max().item() / gscale
-        v64 = g['grad64:' + name].reshape(-1)
-        e64 = (got - v64).abs().max().item() / gscale
-        r64 = (v.reshape(-1) - v64).abs().max().item() / gscale
+        v64 = g['grad64:' + name].reshape(-1) if has64 else None
+        e64 = (got - v64).abs().max().item() / gscale if has64 else float('inf')
+        r64 = (v.reshape(-1) - v64).abs().max().item() / gscale if has64 else 0.0
         _referee_log(name, e32, e64, r64)
         assert e32 <= 1e-3 or e64 <= REFEREE * r64, '%s: |hip - ref32| = %.2e, |hip - fp64| = %.2e, |ref32 - fp64| = %.2e (of the gradient scale)' % (name, e32, e64, r64)
         worst = max(worst, (e32, name))

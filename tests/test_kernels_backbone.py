@@ -235,12 +235,12 @@ def _team_case(dev, seed=80, B=2, C=3, S=130 * 132):
     return x, dy, w, b
 
 
-def _team_run(L, x, dy, w, b, act=1):
+def _team_run(L, x, dy, w, b, act=1, run=None):
     B, C, S = x.shape
     y, dx = torch.empty_like(x), torch.empty_like(x)
     mean, var, dw, db = (torch.empty(C, device=x.device) for _ in range(4))
     parts, ws = torch.zeros(L.bn_parts_floats(B, C, S), device=x.device), torch.zeros(L.bn_ws(B, C, S), device=x.device)
-    L.bn_act_fwd2(x, parts, 0, mean, var, None, None, 0.0, w, b, y, None, None, 0.0, 0, 0, B, C, S, 1e-3, act)
+    L.bn_act_fwd2(x, parts, 0, mean, var, run[0] if run else None, run[1] if run else None, 0.1 if run else 0.0, w, b, y, None, None, 0.0, 0, 0, B, C, S, 1e-3, act)
     L.bn_act_bwd2(dy, x, mean.nan_to_num(0.0), var.nan_to_num(1.0), w, b, dx, dw, db, ws, B, C, S, 1e-3, act, 1)
     if x.is_cuda:
         torch.cuda.synchronize()
@@ -273,6 +273,11 @@ def test_team_exchange_that_times_out_fails_loudly(backend):
         with pytest.raises(RuntimeError, match='team exchange'):
             L.team_check()
         assert L.c.segx_team_status(0) == 0                    # team_check cleared the word
+        # the failed exchange must not reach the RUNNING statistics (a checkpoint written after the RuntimeError would keep them)
+        rm, rv = torch.zeros(C, device=x.device), torch.ones(C, device=x.device)
+        _team_run(L, x, dy, w, b, run=(rm, rv))
+        assert L.c.segx_team_status(1) >= 2
+        assert torch.isfinite(rm).all() and torch.isfinite(rv).all() and rm[C - 1] == 0 and rv[C - 1] == 1 and (rm[:C - 1] != 0).all()
         # the training loop's hook: BertAdam.step() checks the word before it touches the weights
         _team_run(L, x, dy, w, b)
         from segtran_amd.optimization import BertAdam
@@ -448,6 +453,30 @@ def test_up_group_norm_fused_level_matches_the_two_ops_and_feeds_the_bias_gradie
     close(conv.weight.grad, wr.grad, 1e-4); close(conv.bias.grad, br.grad, 2e-4)
     close(gn.weight.grad, ref_gn.weight.grad, 1e-4); close(gn.bias.grad, ref_gn.bias.grad, 1e-4)
 
+
+
+def test_plane_sums_are_dropped_when_the_gradient_is_touched_in_place(backend):
+    """the plane sums that _UpGN*.backward attach to the gradient of the lateral are bound to its version counter, storage and (B, C, S): a hook that
+    rescales that gradient IN PLACE must make the lateral's bias gradient come from the row-sum kernel again (the stale closed-form sums were used before)."""
+    B, C, G, Cf, insize, size = 2, 8, 4, 6, (4, 8, 8), (8, 16, 16)
+    gn = torch.nn.GroupNorm(G, C)
+    conv = torch.nn.Conv3d(Cf, C, 1)
+    with torch.no_grad():
+        conv.weight.copy_(0.4 * rnd(C, Cf, 1, 1, 1, seed=43)); conv.bias.copy_(0.3 * rnd(C, seed=44))
+    x = (rnd(B, C, *insize, seed=45) + 0.5).requires_grad_(True)
+    f = rnd(B, Cf, *size, seed=46).requires_grad_(True)
+    grads = {}
+    for scale in (None, 3.0):
+        for t in (x, f, conv.weight, conv.bias):
+            t.grad = None
+        base = SF.conv1x1(f, conv.weight, conv.bias)
+        if scale is not None:
+            base.register_hook(lambda g: (g.mul_(scale), None)[1])          # in place, returns None: autograd hands the SAME (modified) tensor on
+        y = SF.up_group_norm(x, size, base, gn)
+        y.backward(rnd(*y.shape, seed=47))
+        grads[scale] = (conv.bias.grad.clone(), conv.weight.grad.clone())
+    close(grads[3.0][1], 3.0 * grads[None][1], 1e-5)
+    close(grads[3.0][0], 3.0 * grads[None][0], 1e-5)
 
 
 @pytest.mark.parametrize('B,C,G,Cout,insize,size,with_bias', [(2, 8, 4, 12, (4, 8, 8), (8, 16, 16), True), (2, 8, 4, 6, (4, 8, 8), (8, 16, 16), True), (1, 16, 8, 3, (2, 8, 16), (4, 16, 32), False), (1, 16, 8, 9, (2, 8, 16), (4, 16, 32), False),

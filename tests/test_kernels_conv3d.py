@@ -154,6 +154,24 @@ def test_maxpool3d_with_input_alias_adds_the_other_consumers_gradient_in_its_bac
     assert torch.equal(x3.grad, x4.grad)
 
 
+@pytest.mark.parametrize('size', [(4, 5, 8), (6, 7, 7), (12, 16, 16)])
+def test_maxpool3d_bwd_honours_addend_for_stride_1_pools_through_the_abi(backend, size):
+    """segx_maxpool3d_bwd(..., addend) with a stride-1 pool used to take a kernel that never reads `addend` and return rc 0; now such a call is served
+    by the gather that adds it: dX == dX(without addend) + addend, bit for bit (two terms)."""
+    L = backend.L
+    B, C = 2, 2
+    D, H, W = size
+    geom = (D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+    x = torch.relu(rnd(B, C, *size, seed=71))
+    G, add = rnd(B, C, *size, seed=72), rnd(B, C, *size, seed=73)
+    y, arg = torch.empty_like(x), torch.empty(x.shape, dtype=torch.int32)
+    L.maxpool3d_fwd(x, y, arg, B * C, geom)
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    L.maxpool3d_bwd(G, arg, dx0, B * C, geom)
+    L.maxpool3d_bwd(G, arg, dx1, B * C, geom, add)
+    assert torch.equal(dx1, dx0 + add)
+
+
 @pytest.mark.parametrize('Cout,k', [(40, (3, 3, 3)), (130, (1, 3, 3)), (8, (7, 7, 7))])
 def test_conv3d_forward_split_k(backend, Cout, k):
     """Forward with the contraction split over 3 slabs (the low-resolution Inception stages) == un-split result; both the
@@ -276,6 +294,75 @@ def test_conv3d_on_the_bf16x6_engine(backend, B, Cin, Cout, size, k, stride, wgr
         assert L.x6_launches() >= 1                      # the engine really ran (forward; the backward passes where their operands are float4-legal)
     finally:
         L.c.segx_tune(7, 0)
+        L.set_engine(prev)
+
+
+# (B, Cin, Cout, size): W % 8 == 0 -> 4 x 4 x 8 tiles, W % 4 == 0 and D % 8 == 0 -> 8 x 4 x 4 tiles; Cout 24 / 72 / 136 / 200: the 64-, 128- and 192-row tiles with a
+# partial last tile; Cin 8 / 16 / 24: one, two, three channel blocks; several tiles along every axis (halo rows of neighbours, zero padding at all six faces)
+@pytest.mark.parametrize('B,Cin,Cout,size,mtile', [(2, 8, 24, (4, 4, 8), 0), (1, 16, 72, (8, 8, 16), 0), (1, 24, 136, (4, 8, 8), 0), (1, 8, 200, (4, 4, 8), 0),
+                                                   (2, 16, 40, (8, 4, 4), 0), (1, 8, 72, (16, 8, 12), 0), (1, 24, 136, (8, 4, 4), 0), (1, 8, 200, (8, 8, 4), 192),
+                                                   (1, 8, 72, (4, 4, 8), 64), (1, 16, 200, (8, 4, 4), 128),
+                                                   (1, 8, 24, (8, 7, 14), 0), (2, 16, 72, (11, 8, 8), 0), (1, 8, 40, (7, 11, 15), 0), (1, 8, 24, (24, 14, 14), 0)])      # edge tiles beyond the extent (masked)
+def test_conv3d_halo_kernel_forward_and_data_gradient(backend, B, Cin, Cout, size, mtile):
+    """r06: the LDS-resident-halo form of the 3 x 3 x 3 stride-1 'same' convolutions (conv3d_halo.hip) through the C ABI -- forward with the pre-split filter bank
+    of pack mode 0 and the data gradient (the same kernel on pack mode 1) against F.conv3d and its autograd; channel-slice operands (sample strides) included."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    assert L.c.segx_tune(17, 1) == 0
+    try:
+        D, H, W = size
+        geom = (Cin, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+        assert L.conv3d_halo_ok(B, Cout, geom)
+        assert not L.conv3d_halo_ok(B, Cout, (Cin, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 0)) and not L.conv3d_halo_ok(B, Cout, (Cin + 4,) + geom[1:])
+        assert not L.conv3d_halo_ok(B, Cout, (Cin, 5, 10, 11, 5, 10, 11) + geom[7:])          # tiles would be > 1.5 x the extent
+        x = rnd(B, Cin + 8, *size, seed=81)                       # the convolution reads channels 8.. of a wider tensor (x_bs = its sample stride)
+        w = rnd(Cout, Cin, 3, 3, 3, seed=82) * 0.2
+        y = torch.full((B, Cout + 3, D, H, W), 7.0)               # ... and writes channels 3.. of a wider one (y_bs)
+        L.x6_launches()
+        L.conv3d_halo_fwd(x[:, 8:], L.conv3d_halo_pack(w, Cout, Cin, 0), y[:, 3:], B, Cout, geom, x_bs=(Cin + 8) * D * H * W, y_bs=(Cout + 3) * D * H * W, mtile=mtile)
+        assert L.x6_launches() == 1
+        xr = x[:, 8:].clone().requires_grad_(True)
+        yr = F.conv3d(xr, w, None, 1, 1)
+        close(y[:, 3:], yr.detach(), 1e-5)
+        assert torch.equal(y[:, :3], torch.full((B, 3, D, H, W), 7.0))      # nothing written outside the slice
+        G = rnd(B, Cout, *size, seed=83)
+        yr.backward(G)
+        g2 = (Cout, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+        dx = torch.empty(B, Cin, D, H, W)
+        L.conv3d_halo_fwd(G, L.conv3d_halo_pack(w, Cin, Cout, 1), dx, B, Cin, g2, mtile=0)
+        close(dx, xr.grad, 1e-5)
+    finally:
+        assert L.c.segx_tune(17, 256) == 0
+        L.set_engine(prev)
+
+
+def test_conv3d_same_takes_the_halo_kernel_where_it_applies(backend):
+    """SF.conv3d_same / SF.conv3d_slices route eligible layers (knob 16 on, >= knob 17 tiles) through the halo kernel -- same results as with the knob off."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    outs = {}
+    try:
+        for halo in (1, 0):
+            assert L.c.segx_tune(16, halo) == 0 and L.c.segx_tune(17, 1) == 0
+            x = rnd(1, 24, 4, 8, 8, seed=91).requires_grad_(True)
+            w1, w2 = (rnd(16, 8, 3, 3, 3, seed=92) * 0.2).requires_grad_(True), (rnd(24, 16, 3, 3, 3, seed=93) * 0.2).requires_grad_(True)
+            calls = []
+            from segtran_amd import segx
+            Lf = segx.lib()                                           # the instance the autograd layer calls (on the device not the fixture's object)
+            orig = Lf.conv3d_halo_fwd
+            Lf.conv3d_halo_fwd = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+            try:
+                y1, y2 = SF.conv3d_slices(x, w1, w2)
+                y3 = SF.conv3d_same(y2, w2[:, :8].repeat(1, 3, 1, 1, 1).contiguous())
+                (y1.sum() * 0.5 + (y3 * y3).sum()).backward()
+            finally:
+                del Lf.conv3d_halo_fwd
+            assert len(calls) == (6 if halo else 0)                  # three forward + three data-gradient launches
+            outs[halo] = (y1.detach(), y3.detach(), x.grad.clone(), w1.grad.clone(), w2.grad.clone())
+        for a, b in zip(outs[1], outs[0]):
+            close(a, b, 2e-5)
+    finally:
+        assert L.c.segx_tune(16, 1) == 0 and L.c.segx_tune(17, 256) == 0
         L.set_engine(prev)
 
 
