@@ -468,6 +468,13 @@ int segx_conv3d_halo_ok(int B, int Cout, const int* geom);
 int64_t segx_conv3d_halo_wq_floats(int O, int C);
 int segx_conv3d_halo_pack(const float* W, void* Wq, int O, int C, int mode, void* stream);
 int segx_conv3d_halo_fwd(const float* X, const void* Wq, float* Y, int B, int Cout, const int* geom, int64_t x_bstride, int64_t y_bstride, int mtile, void* stream);
+/* weight gradient of the same convolutions with the halo resident (three x-shifted windows per halo row, so that a lane's eight consecutive output positions are 16 aligned
+ * bytes for every tap): dW [Cout][Cin][27], summed over the batch, from dY [B][Cout][D][H][W] and X [B][Cin][D][H][W].  A workgroup owns 128 / 192 output channels x
+ * (8 input channels x 27 taps) and streams over its share of the 4 x 4 x 8 spatial blocks; the K-split slabs (ws: segx_conv3d_halo_wgrad_ws_floats floats) are reduced
+ * in split order by a second launch (deterministic).  segx_conv3d_halo_wgrad_ok: the conditions of segx_conv3d_halo_ok for rows of eight outputs. */
+int segx_conv3d_halo_wgrad_ok(int B, int Cout, const int* geom);
+int64_t segx_conv3d_halo_wgrad_ws_floats(int B, int Cout, const int* geom);
+int segx_conv3d_halo_wgrad(const float* dY, const float* X, float* dW, float* ws, int B, int Cout, const int* geom, int64_t dy_bstride, int64_t x_bstride, void* stream);
 /* backward-data of a STRIDED convolution by direct gather (the stride-2 7x7x7 stem onto 3 channels); geom as above */
 int segx_conv3d_bwd_data_direct(const float* dY, const float* W, float* dX, float* wt_ws /* Cout*Cin*KV floats of scratch */, int B, int Cout,
                                 const int* geom, void* stream);

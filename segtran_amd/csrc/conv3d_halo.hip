@@ -260,6 +260,276 @@ __global__ __launch_bounds__(256) void conv3d_halo_pack_kernel(const float* __re
     }
 }
 
+
+// ---- backward-weight with a resident halo -----------------------------------------------------------------------------------------------------------
+// dW[co][ci][tap] = sum over (sample, position p) dY[co][p] X[ci][p + tap - 1]: M = output channels, N = (tap, ci), K = positions.  A workgroup owns 32 NW output
+// channels x (28 taps x 8 input channels = 224 columns: seven 32-column MFMA blocks, one of the 28 taps a zero phantom) and STREAMS over its share of the 128-output
+// spatial blocks (4 x 4 x 8; K-split over workgroups, deterministic slab reduction afterwards), accumulating in registers (7 x 16 per lane).  Per spatial block
+//   * the halo of its 8 input channels is staged ONCE as three x-SHIFTED WINDOWS per halo row (x - 1 .. x + 6, x .. x + 7, x + 1 .. x + 8: the eight k-values of a
+//     lane are eight consecutive output positions along W, i.e. 16 contiguous bytes of bf16 -- a tap's kw shift would otherwise land a fragment on a 2-byte
+//     boundary), split into the three planes once per voxel: [channel][kw][halo row (d, h)] slots of 16 B;
+//   * dY arrives in tiles of OCT position octets (rows (d, h) of the block) x 32 NW channels in the gemm_x6.h row image;
+//   * the fragment of (tap, channel) for octet (dz, dy) is ONE ds_read_b128 at slot  ci * CS + kw * KS + (dz + kd) * 6 + (dy + kh).
+// The same im2col-free structure as the forward kernel; the im2col weight gradient gathered 16 scalars or two unaligned 16-byte rows per thread and k-tile and
+// split every element once per TAP (27 x) -- 114 - 133 TFLOP/s on the large layers (r05_zb).
+// Bank rule: with CS = 115 (odd) the eight channels of a tap cover eight slots that are distinct mod 8, and the taps are PAIRED so that the slot offsets of a pair
+// differ by 8 mod 16 (kw * 39 + kd * 6 + kh; table below, found by tools/halo_banks.py --search): the 16 lanes of a ds_read_b128 group -- eight channels of
+// each tap of a pair, dealt to the lane groups by halo_row_of<8> -- hit sixteen distinct 16-byte slots.
+struct HaloW {
+    static constexpr int RS = 6, KS = 39, CS = 115;
+    static constexpr int PX = 8 * CS * 16;                           // bytes of one plane of the window image
+    static constexpr int ROWS = 36, ITEMS = 8 * ROWS;                // (channel, halo row) staging items per spatial block
+};
+// column block j (0..6), tap-in-block i (0..3) -> tap kd * 9 + kh * 3 + kw (27 = phantom): lanes with i = 0 / 2 share one ds_read_b128 group, i = 1 / 3 the other
+__host__ __device__ constexpr int halo_wtap(int j, int i) {
+    constexpr int P[14][2] = {{0, 4}, {1, 5}, {2, 9}, {3, 7}, {6, 20}, {8, 15}, {10, 14}, {11, 18}, {12, 16}, {13, 17}, {19, 23}, {21, 25}, {22, 26}, {24, 27}};
+    return P[2 * j + (i & 1)][i >> 1];
+}
+__host__ __device__ constexpr int halo_wtap_slot(int tap) {        // slot offset of a tap inside a channel's window image (phantom: tap 24's partner position)
+    return tap > 26 ? 2 * HaloW::RS + 2 + 8 : (tap % 3) * HaloW::KS + (tap / 9) * HaloW::RS + (tap / 3) % 3;
+}
+struct HaloWArgs {
+    const float* dY; const float* X; float* ws;
+    int Cin, Cout, D, H, W, B;
+    int64_t dy_bs, x_bs;
+    int ntd, nth, ntw, nmt, ncb, nsplit, nsb;                        // spatial tiles per axis, output-channel tiles, channel blocks, K-splits, spatial blocks in all (B * ntd * nth * ntw)
+};
+
+// Waves: NS row slices of 32 output channels x 2 column halves (blocks 0-3 | 4-6): 2 NS waves, 128 NS threads.  Wave w = slice w % NS, half w / NS, so that waves w
+// and w + 4 -- which the hardware places on the same SIMD -- are a four-block and a three-block wave wherever NS is a multiple of 4 (NS = 6: 11 vs 10 blocks per SIMD).
+// The first version (one wave per slice, all seven blocks: 112 accumulator registers, two waves per SIMD) spent 27 % of its wave cycles parked at barriers / vmcnt and
+// kept the matrix pipe 37 % busy (r06_pw1 counters; the forward kernel: 12 % and 72 %); twice the waves halve every thread's staging work and double the cover.
+template <int NS, int OCT, int WPE, bool V4>
+__global__ __launch_bounds__(128 * NS) SEGX_MIN_WAVES_PER_SIMD(WPE) void conv3d_halo_wgrad_x6_kernel(HaloWArgs g) {
+    constexpr int T = 128 * NS, BM = 32 * NS, PA = BM * 16 * OCT, PX = HaloW::PX, NPIECE = (BM * 2 * OCT + T - 1) / T, XI = (HaloW::ITEMS + T - 1) / T, STEPS = OCT / 2;
+    static_assert(BM * 2 * OCT % T == 0 || BM * 2 * OCT < T, "dY pieces divide over the threads");
+    static_assert(OCT == 2 || OCT == 4, "dY tiles of two or four position octets");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PX + 3 * PA];
+    unsigned char* const LX = lds;                                   // windows: [plane][channel][kw][halo row] x 16 B
+    unsigned char* const LA_ = lds + 3 * PX;                         // dY tile: [plane][row][8 OCT k]: OCT = 4 the gemm_x6.h image; OCT = 2 rows of 32 B, chunk ^ bit 4 of the row
+    auto aoff = [](int row, int chunk) { return OCT == 4 ? x6_off(row, chunk) : row * 32 + ((chunk ^ ((row >> 4) & 1)) << 4); };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kh = lane >> 5;
+    const int slice = SEGX_WAVE_UNIFORM(wave % NS), half = SEGX_WAVE_UNIFORM(wave / NS);
+    unsigned l = xcd_block(blockIdx.x, gridDim.x);                   // channel blocks of one (split, channel tile) are neighbours: they stream the same dY through one L2
+    const int cb = (int)(l % (unsigned)g.ncb); l /= (unsigned)g.ncb;
+    const int mt = (int)(l % (unsigned)g.nmt); const int split = (int)(l / (unsigned)g.nmt);
+    const int m0 = mt * BM;
+    const int sb_lo = (int)((int64_t)g.nsb * split / g.nsplit), sb_hi = (int)((int64_t)g.nsb * (split + 1) / g.nsplit);
+    const int plane = g.H * g.W;
+    const int64_t chan = (int64_t)g.D * plane;
+    // ---- per-lane fragment addresses: A row; B: (tap-in-block, channel) of this lane in each of the seven column blocks
+    const int arow = slice * 32 + (lane & 31);
+    int ti, ci;
+    halo_row_of<8>(lane & 31, ti, ci);
+    const int lbase = (ci * HaloW::CS + kh) * 16;                    // + kh: the odd octet of a step is the next row (dy + 1)
+    // slot offset of this lane's tap in column block j (recomputed where used: seven more live registers would not fit the 168 of three waves per SIMD at NW = 6)
+    const unsigned tsh = 8u * (unsigned)ti;
+    // slot offsets of the four taps of column block j, packed into one constant and picked by a per-lane shift (a ?: chain became branches in the loop); the block of
+    // a wave is 4 half + jj: the constant is chosen on the scalar unit
+    auto bpack = [](int j) {
+        return (unsigned)halo_wtap_slot(halo_wtap(j, 0)) | ((unsigned)halo_wtap_slot(halo_wtap(j, 1)) << 8) | ((unsigned)halo_wtap_slot(halo_wtap(j, 2)) << 16) |
+               ((unsigned)halo_wtap_slot(halo_wtap(j, 3)) << 24);
+    };
+    auto btap = [&](int jj) {
+        const unsigned packed = half ? bpack(jj < 3 ? 4 + jj : 6) : bpack(jj);
+        return (int)(((packed >> tsh) & 255u) << 4);
+    };
+    // ---- staging maps.  dY piece f = tid + T i -> row f / (2 OCT), quarter q = f % (2 OCT): octet-in-tile q >> 1, floats 4 (q & 1) .. + 3 of the octet.
+    // Element offset of a piece = [clamped channel * chan + (q >> 1) * W + 4 (q & 1)] (ainv: per lane, loop-invariant) + a wave-uniform part per (block, tile);
+    // rows past Cout re-read the last channel (their accumulators are never stored).
+    int arow_s[NPIECE], aq[NPIECE], ainv[NPIECE];
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) {
+        const int f0 = tid + T * i, f = f0 < BM * 2 * OCT ? f0 : f0 - BM * 2 * OCT;      // (fewer pieces than threads: the surplus threads re-stage the first pieces with the same values)
+        arow_s[i] = f / (2 * OCT); aq[i] = f % (2 * OCT);
+        const int co = m0 + arow_s[i] < g.Cout ? m0 + arow_s[i] : g.Cout - 1;
+        ainv[i] = co * (int)chan + (aq[i] >> 1) * g.W + 4 * (aq[i] & 1);
+    }
+    // X item f = tid + T i -> channel f / 36, halo row f % 36 = hz * 6 + hy.  Its offsets are RECOMPUTED from an opaque copy of the thread index where they are used
+    // (once per spatial block): kept live across the matrix phase they were spilled, and the reload's s_waitcnt vmcnt(0) sat right behind the dY prefetch (r06_d ISA)
+    auto xitem = [&](int i, int& c, int& hz, int& hy) {
+        int t2 = tid;
+        SEGX_PIN(t2);
+        const int f = t2 + T * i;
+        c = f / HaloW::ROWS; const int hr = f - c * HaloW::ROWS; hz = hr / 6; hy = hr - hz * 6;
+        return f < HaloW::ITEMS;
+    };
+    f32x16 acc[4];                                                  // column blocks 4 half + jj (the second half uses three)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // (validity masks are RECOMPUTED at store time from the block coordinates, which still describe the data in flight: two fewer live registers per staged piece)
+    float areg[NPIECE][4];
+    float xreg[XI][10];
+    int d0 = 0, h0 = 0, w0 = 0, bb = 0;                              // spatial block being LOADED (the loads run one tile ahead of the matrix work)
+    auto set_block = [&](int sb) {
+        int r = sb;
+        const int tw = r % g.ntw; r /= g.ntw;
+        const int th = r % g.nth; r /= g.nth;
+        const int td = r % g.ntd; bb = r / g.ntd;
+        d0 = td * 4; h0 = th * 4; w0 = tw * 8;
+    };
+    auto load_x = [&]() {                                            // the halo rows of block (bb, d0, h0, w0): ten floats x = w0 - 1 .. w0 + 8 each
+        const float* const Xc = g.X + (int64_t)bb * g.x_bs + (int64_t)cb * 8 * chan;     // wave-uniform; everything per lane is a 32-bit element offset (< 2^31: host check)
+        const int ubase = ((d0 - 1) * g.H + (h0 - 1)) * g.W + (w0 - 1);                   // wave-uniform (may be negative: added to xinv before use)
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int c, hz, hy;
+            const bool has = xitem(i, c, hz, hy);
+            const bool rok = has && (unsigned)(d0 - 1 + hz) < (unsigned)g.D && (unsigned)(h0 - 1 + hy) < (unsigned)g.H;
+            const int roff = c * (int)chan + (hz * g.H + hy) * g.W + ubase;
+#pragma unroll
+            for (int e = 0; e < 10; ++e) {
+                const bool ok = rok && (unsigned)(w0 - 1 + e) < (unsigned)g.W;
+                xreg[i][e] = Xc[ok ? roff + e : 0];
+            }
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            int c, hz, hy;
+            const bool has = xitem(i, c, hz, hy);
+            const int hr = hz * 6 + hy;
+            if (has) {
+                const bool rok = (unsigned)(d0 - 1 + hz) < (unsigned)g.D && (unsigned)(h0 - 1 + hy) < (unsigned)g.H;
+                float v[10];
+#pragma unroll
+                for (int e = 0; e < 10; ++e) v[e] = (rok && (unsigned)(w0 - 1 + e) < (unsigned)g.W) ? xreg[i][e] : 0.f;
+                Split2 s[5];
+#pragma unroll
+                for (int e = 0; e < 5; ++e) s[e] = split3_pair(v[2 * e], v[2 * e + 1]);
+                unsigned char* const dst = LX + (c * HaloW::CS + hr) * 16;
+#define SEGX_HALO_WIN(PL, FIELD)                                                                                                                         \
+                {                                                                                                                                        \
+                    const unsigned p0 = s[0].FIELD, p1 = s[1].FIELD, p2 = s[2].FIELD, p3 = s[3].FIELD, p4 = s[4].FIELD;                                  \
+                    *reinterpret_cast<uvec4*>(dst + (PL) * PX) = uvec4{p0, p1, p2, p3};                                               /* x - 1 .. x + 6 */ \
+                    *reinterpret_cast<uvec4*>(dst + (PL) * PX + HaloW::KS * 16) =                                                                        \
+                        uvec4{(p0 >> 16) | (p1 << 16), (p1 >> 16) | (p2 << 16), (p2 >> 16) | (p3 << 16), (p3 >> 16) | (p4 << 16)};    /* x .. x + 7 */     \
+                    *reinterpret_cast<uvec4*>(dst + (PL) * PX + 2 * HaloW::KS * 16) = uvec4{p1, p2, p3, p4};                          /* x + 1 .. x + 8 */ \
+                }
+                SEGX_HALO_WIN(0, h) SEGX_HALO_WIN(1, m) SEGX_HALO_WIN(2, l)
+#undef SEGX_HALO_WIN
+            }
+        }
+    };
+    auto load_a = [&](int kt) {                                      // dY tile kt of block (bb, d0, h0, w0): octet kt * OCT + (q >> 1) = (dz, dy) with dz = (kt * OCT) / 4 (wave-uniform)
+        const float* const Yc = g.dY + (int64_t)bb * g.dy_bs;
+        const int zd = d0 + ((kt * OCT) >> 2), zh0 = h0 + ((kt * OCT) & 3);
+        const int ubase = (zd * g.H + zh0) * g.W + w0;
+        const bool dok = zd < g.D;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const bool rok = dok && zh0 + (aq[i] >> 1) < g.H;
+            const int xq = w0 + 4 * (aq[i] & 1), roff = ainv[i] + ubase;
+            if (V4) {                                                // W % 4 == 0 and 16-byte aligned samples: the four floats are inside the row together
+                const bool ok = rok && xq < g.W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Yc + (ok ? roff : 0));
+                areg[i][0] = v.x; areg[i][1] = v.y; areg[i][2] = v.z; areg[i][3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool ok = rok && xq + e < g.W;
+                    areg[i][e] = Yc[ok ? roff + e : 0];
+                }
+            }
+        }
+    };
+    auto store_a = [&](int kt) {                                     // kt: the tile these registers were loaded for (the caller's current tile)
+        const int zd = d0 + ((kt * OCT) >> 2), zh0 = h0 + ((kt * OCT) & 3);
+        const bool dok = zd < g.D;
+#pragma unroll
+        for (int i = 0; i < NPIECE; ++i) {
+            const bool rok = dok && zh0 + (aq[i] >> 1) < g.H;
+            const int xq = w0 + 4 * (aq[i] & 1);
+            x6_store4<PA>(LA_, aoff(arow_s[i], aq[i] >> 1) + ((aq[i] & 1) << 3), (rok && xq < g.W) ? areg[i][0] : 0.f, (rok && xq + 1 < g.W) ? areg[i][1] : 0.f,
+                          (rok && xq + 2 < g.W) ? areg[i][2] : 0.f, (rok && xq + 3 < g.W) ? areg[i][3] : 0.f);
+        }
+    };
+
+    constexpr int KT = 16 / OCT;                                     // dY tiles per spatial block
+    if (sb_lo < sb_hi) {
+        set_block(sb_lo);
+        load_x();
+        load_a(0);
+    }
+    for (int sb = sb_lo; sb < sb_hi; ++sb) {
+        for (int kt = 0; kt < KT; ++kt) {
+            __syncthreads();                                         // the previous tile's fragments (and at kt == 0 the previous block's windows) have been read
+            if (kt == 0) store_x();
+            store_a(kt);
+            __syncthreads();
+            // prefetch, UNCONDITIONALLY (the last iteration re-reads its own tile): the next dY tile; after the first tile of a block the next block's halo rows
+            const bool last_kt = kt == KT - 1;
+            if (last_kt) { set_block(sb + 1 < sb_hi ? sb + 1 : sb); load_x(); }
+            load_a(last_kt ? 0 : kt + 1);
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                // octets of this step: 2 s + kh of tile kt  ->  (dz, dy) = ((kt * OCT + 2 s) / 4, (kt * OCT + 2 s) % 4 + kh): the row offset of the even octet + kh (in bbase)
+                const int oc = kt * OCT + 2 * s, rowoff = ((oc >> 2) * HaloW::RS + (oc & 3)) * 16;
+                bf16x8 a[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(LA_ + p * PA + aoff(arow, 2 * s + kh));
+#define SEGX_HALO_WBLOCK(JJ, J)                                                                                                                 \
+                {                                                                                                                               \
+                    bf16x8 b[3];                                                                                                                \
+                    _Pragma("unroll") for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(LX + p * PX + lbase + btap(J) + rowoff); \
+                    f32x16 c = acc[JJ];                                                                                                         \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);                                                        \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);                                                        \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);                                                        \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);                                                        \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);                                                        \
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);                                                        \
+                    acc[JJ] = c;                                                                                                                \
+                }
+                SEGX_HALO_WBLOCK(0, 0) SEGX_HALO_WBLOCK(1, 1) SEGX_HALO_WBLOCK(2, 2)
+                if (half == 0) {                                     // the three-block half has no fourth block (the empty asm keeps hipcc from speculating the six MFMAs into both halves)
+                    asm volatile("" ::: "memory");
+                    SEGX_HALO_WBLOCK(3, 3)
+                }
+#undef SEGX_HALO_WBLOCK
+            }
+        }
+    }
+    // ---- this split's partial sums: ws[split][co][cb][224]; lane = column 32 j + (lane & 31), rows 8 (r >> 2) + 4 kh + (r & 3) of the wave's 32 channels
+    float* const out = g.ws + (((int64_t)split * g.Cout) * g.ncb + cb) * 224;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * half + jj;
+        if (j < 7) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + slice * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                if (co < g.Cout) out[(int64_t)co * g.ncb * 224 + 32 * j + (lane & 31)] = acc[jj][r];
+            }
+        }
+    }
+}
+
+// dW[co][ci][t] = sum over splits of ws[split][co][ci / 8][column of (t, ci % 8)] -- in split order (deterministic)
+__global__ __launch_bounds__(256) void conv3d_halo_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dW, int Cout, int Cin, int nsplit) {
+    const int ncb = Cin / 8;
+    const int64_t total = (int64_t)Cout * ncb * 224;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int col = (int)(idx % 224); const int64_t rc = idx / 224;              // (co, cb)
+        const int cb = (int)(rc % ncb), co = (int)(rc / ncb);
+        const int j = col >> 5, r = col & 31, g4 = r >> 2;
+        const int ti = (0x32230110u >> (4 * g4)) & 15, ci = (r & 3) + (((0xCCu >> g4) & 1) << 2);       // halo_row_of<8>
+        int tap = 27;
+#pragma unroll
+        for (int jj = 0; jj < 7; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) if (jj == j && ii == ti) tap = halo_wtap(jj, ii);
+        if (tap > 26) continue;
+        float sum = 0.f;
+        for (int s = 0; s < nsplit; ++s) sum += ws[(int64_t)s * total + idx];
+        dW[((int64_t)co * Cin + cb * 8 + ci) * 27 + tap] = sum;
+    }
+}
+
 }  // namespace segx
 
 using namespace segx;
@@ -341,4 +611,62 @@ extern "C" int segx_conv3d_halo_fwd(const float* X, const void* Wq, float* Y, in
     else SEGX_HALO_LAUNCH(3, 2);
 #undef SEGX_HALO_LAUNCH
     return check_launch("segx_conv3d_halo_fwd");
+}
+
+/* r06 -- weight gradient of the same convolutions with a resident halo: dW [Cout][Cin][27] (summed over the batch) from dY [B][Cout][D][H][W] and X [B][Cin][D][H][W];
+ * ws: segx_conv3d_halo_wgrad_ws_floats(B, Cout, geom) floats of scratch (K-split slabs, reduced in split order); dy_bs / x_bs: sample strides in floats (0 = dense) */
+static int halo_wgrad_plan(int B, int Cout, int Cin, int D, int H, int W, int* nw, int* nmt, int* nsplit, int* nsb) {
+    const int64_t tiles = (int64_t)ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 8) * B;
+    if (tiles <= 0 || tiles >= 2147483647LL) return -1;
+    const int r128 = ceil_div(Cout, 128) * 128, r192 = ceil_div(Cout, 192) * 192;
+    *nw = r192 < r128 || (r192 == r128 && Cout > 128) ? 6 : 4;
+    *nmt = ceil_div(Cout, 32 * *nw);                                   // nw = row slices of 32 channels per workgroup (4: 512 threads, 6: 768)
+    const int units = *nmt * (Cin / 8);                               // workgroups per K-split
+    // resident workgroups: two per CU for the 512-thread form, one for the 768-thread form.  The grid must not spill into a part-filled extra round (r06_e: 516
+    // workgroups on 512 slots ran 4 of them alone, at twice the time): 512-thread form one round, 768-thread form two full rounds
+    int sp = 512 / units;
+    if (sp > tiles) sp = (int)tiles;
+    if (sp < 1) sp = 1;
+    *nsplit = sp; *nsb = (int)tiles;
+    return 0;
+}
+extern "C" int64_t segx_conv3d_halo_wgrad_ws_floats(int B, int Cout, const int* geom) {
+    if (!halo_geom_ok(geom) || B <= 0 || Cout <= 0) return 0;
+    int nw, nmt, nsplit, nsb;
+    if (halo_wgrad_plan(B, Cout, geom[0], geom[1], geom[2], geom[3], &nw, &nmt, &nsplit, &nsb)) return 0;
+    return (int64_t)nsplit * Cout * (geom[0] / 8) * 224;
+}
+/* 1 when segx_conv3d_halo_wgrad serves the layer (the conditions of segx_conv3d_halo_ok with rows of 8 outputs: W padded to a multiple of 8 by at most half) */
+extern "C" int segx_conv3d_halo_wgrad_ok(int B, int Cout, const int* geom) {
+    if (!halo_geom_ok(geom) || B <= 0 || Cout <= 0 || kget(knobs().engine) != SEGX_ENGINE_BF16X6 || kget(knobs().conv_halo) == 0) return 0;
+    const int D = geom[1], H = geom[2], W = geom[3];
+    if ((int64_t)geom[0] * D * H * W >= 2147483647LL || (int64_t)Cout * D * H * W >= 2147483647LL || W % 4 != 0) return 0;      // rows of whole float4 (16-byte dY loads)
+    const int64_t tiles = (int64_t)ceil_div(D, 4) * ceil_div(H, 4) * ceil_div(W, 8);
+    if (tiles * 128 > (int64_t)D * H * W * 3 / 2) return 0;
+    // r06_f (tools/conv_bench.py wgrad): 1.15 - 1.5 x the im2col form on every layer with Cin * Cout >= 3072 at >= 256 tiles; the 16 -> 32 ... 32 -> 64 channel
+    // convolutions of the second Inception branch (one or two workgroups per K-split, hundreds of slabs) run 0.45 - 0.65 x and keep the im2col form
+    if ((int64_t)geom[0] * Cout < (kget(knobs().conv_halo_min_tiles) <= 1 ? 1 : 3072)) return 0;
+    return tiles * B >= kget(knobs().conv_halo_min_tiles) ? 1 : 0;
+}
+extern "C" int segx_conv3d_halo_wgrad(const float* dY, const float* X, float* dW, float* ws, int B, int Cout, const int* geom, int64_t dy_bs, int64_t x_bs, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && dW && ws && B > 0 && Cout > 0 && halo_geom_ok(geom), "segx_conv3d_halo_wgrad: bad args (3 x 3 x 3, stride 1, 'same', Cin %% 8 == 0 only)");
+    const int Cin = geom[0], D = geom[1], H = geom[2], W = geom[3];
+    SEGX_REQUIRE((int64_t)Cin * D * H * W < 2147483647LL && (int64_t)Cout * D * H * W < 2147483647LL, "segx_conv3d_halo_wgrad: sample too large");
+    HaloWArgs g; g.dY = dY; g.X = X; g.ws = ws; g.Cin = Cin; g.Cout = Cout; g.D = D; g.H = H; g.W = W; g.B = B;
+    g.dy_bs = dy_bs ? dy_bs : (int64_t)Cout * D * H * W; g.x_bs = x_bs ? x_bs : (int64_t)Cin * D * H * W;
+    g.ntd = ceil_div(D, 4); g.nth = ceil_div(H, 4); g.ntw = ceil_div(W, 8); g.ncb = Cin / 8;
+    int nw;
+    SEGX_REQUIRE(halo_wgrad_plan(B, Cout, Cin, D, H, W, &nw, &g.nmt, &g.nsplit, &g.nsb) == 0, "segx_conv3d_halo_wgrad: grid too large");
+    const int64_t wgs = (int64_t)g.nsplit * g.nmt * g.ncb;
+    SEGX_REQUIRE(wgs < 2147483647LL, "segx_conv3d_halo_wgrad: grid too large");
+    knobs().x6_launches.fetch_add(1, std::memory_order_relaxed);
+    const bool v4 = W % 4 == 0 && g.dy_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(dY) & 15) == 0;
+    SEGX_REQUIRE(v4, "segx_conv3d_halo_wgrad: W %% 4 == 0 and 16-byte aligned dY samples only (segx_conv3d_halo_wgrad_ok)");
+    if (nw == 6) hipLaunchKernelGGL((conv3d_halo_wgrad_x6_kernel<6, 4, 3, true>), dim3((unsigned)wgs), dim3(768), 0, stream, g);
+    else hipLaunchKernelGGL((conv3d_halo_wgrad_x6_kernel<4, 4, 4, true>), dim3((unsigned)wgs), dim3(512), 0, stream, g);
+    int rc = check_launch("segx_conv3d_halo_wgrad");
+    if (rc) return rc;
+    const int64_t total = (int64_t)Cout * g.ncb * 224;
+    hipLaunchKernelGGL(conv3d_halo_wgrad_reduce_kernel, dim3((unsigned)i64min(2048, (total + 255) / 256)), dim3(256), 0, stream, (const float*)ws, dW, Cout, Cin, g.nsplit);
+    return check_launch("segx_conv3d_halo_wgrad/reduce");
 }

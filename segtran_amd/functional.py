@@ -1502,7 +1502,10 @@ class _Conv3d(torch.autograd.Function):
                 else:
                     L.conv3d_flip_weights(w, wt, Cout, Cin, KV)
                     L.conv3d_fwd(dyd, wt, dx, B, Cin, g2, sk, ws)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and L.conv3d_halo_wgrad_ok(B, Cout, geom):
+            dw = torch.empty_like(w)
+            L.conv3d_halo_wgrad(dy, x, dw, B, Cout, geom)
+        elif ctx.needs_input_grad[1]:
             P, N = OD * OH * OW, Cin * KV
             sk = L.conv3d_splitk(B, Cout, geom, True)
             ws = _empty(x, sk * B * Cout * N) if sk > 1 else None
@@ -1588,7 +1591,10 @@ class _Conv3dSlices(torch.autograd.Function):
                     L.conv3d_pack_weights(w, wt, Cin, Cout, KV, 1)
                     L.conv3d_fwd(dy, wt, dt[:, c0:], B, Cin, g2, sk, _empty(t, sk * B * Cin * vol) if sk > 1 else None, packed=True, y_bs=Ct * vol)
             dw = None
-            if ctx.needs_input_grad[2 + i]:
+            if ctx.needs_input_grad[2 + i] and L.conv3d_halo_wgrad_ok(B, Cout, geom):
+                dw = torch.empty_like(w)
+                L.conv3d_halo_wgrad(dy, t[:, c0:], dw, B, Cout, geom, x_bs=Ct * vol)
+            elif ctx.needs_input_grad[2 + i]:
                 N = Cin * KV
                 sk = L.conv3d_splitk(B, Cout, geom, True)
                 dwb = _empty(t, B, Cout * N)

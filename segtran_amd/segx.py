@@ -509,6 +509,18 @@ class SegxLib:
         rc = self._timed(Y, 2.0 * B * Cout * P * K, ('conv3d_halo_fwd', Cout, P, K, B, 1), call)
         self.check(rc, 'segx_conv3d_halo_fwd')
 
+    def conv3d_halo_wgrad_ok(self, B, Cout, geom):
+        return bool(self.c.segx_conv3d_halo_wgrad_ok(B, Cout, self._geom(geom)))
+
+    def conv3d_halo_wgrad(self, dY, X, dW, B, Cout, geom, dy_bs=0, x_bs=0):
+        """dW [Cout, Cin, 3, 3, 3] (summed over the batch) of a 3 x 3 x 3 stride-1 'same' convolution, resident-halo form"""
+        self._chk_t(dY, X, dW)
+        ws = torch.empty(int(self.c.segx_conv3d_halo_wgrad_ws_floats(B, Cout, self._geom(geom))), dtype=torch.float32, device=dW.device)
+        P = geom[4] * geom[5] * geom[6]; N = geom[0] * 27
+        call = lambda: self.c.segx_conv3d_halo_wgrad(_ptr(dY), _ptr(X), _ptr(dW), _ptr(ws), B, Cout, self._geom(geom), int(dy_bs), int(x_bs), self.stream(dW))
+        rc = self._timed(dW, 2.0 * B * Cout * P * N, ('conv3d_halo_wgrad', Cout, N, P, B, 1), call)
+        self.check(rc, 'segx_conv3d_halo_wgrad')
+
     def conv3d_bwd_data_direct(self, dY, W, dX, B, Cout, geom):
         wt = torch.empty(W.numel(), dtype=torch.float32, device=W.device)
         self._chk_t(dY, W, dX)
@@ -608,7 +620,7 @@ _SIGS = {
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
     'segx_tune': 'ii', 'segx_tune_get': 'i', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
-    'segx_conv3d_halo_ok': 'iip', 'segx_conv3d_halo_wq_floats': 'ii', 'segx_conv3d_halo_pack': 'ppiiip', 'segx_conv3d_halo_fwd': 'pppiipllip',
+    'segx_conv3d_halo_ok': 'iip', 'segx_conv3d_halo_wq_floats': 'ii', 'segx_conv3d_halo_pack': 'ppiiip', 'segx_conv3d_halo_fwd': 'pppiipllip', 'segx_conv3d_halo_wgrad_ok': 'iip', 'segx_conv3d_halo_wgrad_ws_floats': 'iip', 'segx_conv3d_halo_wgrad': 'ppppiipllp',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplppp',
     'segx_bn_ws_floats': 'iil', 

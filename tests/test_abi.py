@@ -94,12 +94,17 @@ def test_no_shipped_kernel_spills_registers_beyond_the_known_gemm_tails():
     usage = json.load(open(os.path.join(OUT, 'resource_usage.json')))
     assert len(usage) > 400                                   # every __global__ instantiation of the library reports
     known = {'gemm_x6ws_kernel': 52, 'gemm_f32_kernel': 36, 'gemm_x6_kernel': 20, 'gemm_x6_lean_kernel': 20}
+    # r06: the 6-wave (192 output channels) form of the resident-halo weight gradient sits at the 168 registers of three waves per SIMD (112 of them accumulators) and keeps
+    # ten loop-invariant staging offsets in scratch (reloaded once per 42-MFMA tile); the 4-wave form and the forward kernels have none
+    known_other = {('conv3d_halo.hip', 'conv3d_halo_wgrad_x6_kernelILi6E'): 48}
     bad = []
     for name, u in usage.items():
         assert u['scratch'] >= 0 and u['vgprs'] > 0, name
         if u['scratch'] == 0:
             continue
         fam = [k for k in known if ('4segx%d%sI' % (len(k), k)) in name]
+        if any(u['file'] == f and k in name and u['scratch'] <= cap for (f, k), cap in known_other.items()):
+            continue
         if u['file'] != 'gemm.hip' or not fam or u['scratch'] > known[fam[0]]:
             bad.append((name, u['file'], u['scratch']))
     assert not bad, bad

@@ -336,6 +336,37 @@ def test_conv3d_halo_kernel_forward_and_data_gradient(backend, B, Cin, Cout, siz
         L.set_engine(prev)
 
 
+# Cout 40 / 136: the 4-wave (128-row) form with a partial tile / two tiles; Cout 192 / 200: the 6-wave (192-row) form (+ a second, mostly empty tile); Cin 8 / 16 / 24;
+# W = 8 / 16 / 24: whole octets; W = 12 and ragged D / H: masked edge octets and blocks (W % 4 == 0 throughout: dY is read in 16-byte pieces)
+@pytest.mark.parametrize('B,Cin,Cout,size', [(2, 8, 40, (4, 4, 8)), (1, 16, 136, (8, 8, 16)), (1, 8, 192, (4, 8, 8)), (2, 24, 200, (4, 4, 8)), (1, 16, 40, (8, 4, 24)),
+                                             (1, 8, 40, (8, 8, 12)), (2, 16, 72, (7, 8, 16)), (1, 8, 192, (7, 7, 8)), (3, 8, 24, (12, 12, 8))])
+def test_conv3d_halo_weight_gradient(backend, B, Cin, Cout, size):
+    """r06: dW of the 3 x 3 x 3 stride-1 'same' convolutions with the halo resident as three x-shifted windows (conv3d_halo.hip), K-split over workgroups + deterministic
+    slab reduction, against autograd's weight gradient of F.conv3d; X read as a channel slice of a wider tensor (x_bs)."""
+    L = backend.L
+    prev = L.set_engine('x6')
+    assert L.c.segx_tune(17, 1) == 0
+    try:
+        D, H, W = size
+        geom = (Cin, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+        assert L.conv3d_halo_wgrad_ok(B, Cout, geom)
+        xw = rnd(B, Cin + 8, *size, seed=101)
+        dy = rnd(B, Cout, *size, seed=102)
+        w = (rnd(Cout, Cin, 3, 3, 3, seed=103) * 0.2).requires_grad_(True)
+        F.conv3d(xw[:, 8:], w, None, 1, 1).backward(dy)
+        dw = torch.full_like(w, 7.0)
+        L.x6_launches()
+        L.conv3d_halo_wgrad(dy, xw[:, 8:], dw, B, Cout, geom, x_bs=(Cin + 8) * D * H * W)
+        assert L.x6_launches() == 1
+        close(dw, w.grad, 2e-5)
+        dw2 = torch.empty_like(w)
+        L.conv3d_halo_wgrad(dy, xw[:, 8:], dw2, B, Cout, geom, x_bs=(Cin + 8) * D * H * W)
+        assert torch.equal(dw, dw2)                                   # deterministic: fixed split order
+    finally:
+        assert L.c.segx_tune(17, 256) == 0
+        L.set_engine(prev)
+
+
 def test_conv3d_same_takes_the_halo_kernel_where_it_applies(backend):
     """SF.conv3d_same / SF.conv3d_slices route eligible layers (knob 16 on, >= knob 17 tiles) through the halo kernel -- same results as with the knob off."""
     L = backend.L
@@ -357,7 +388,7 @@ def test_conv3d_same_takes_the_halo_kernel_where_it_applies(backend):
                 (y1.sum() * 0.5 + (y3 * y3).sum()).backward()
             finally:
                 del Lf.conv3d_halo_fwd
-            assert len(calls) == (6 if halo else 0)                  # three forward + three data-gradient launches
+            assert len(calls) == (6 if halo else 0)                  # three forward + three data-gradient launches (the weight gradients: conv3d_halo_wgrad)
             outs[halo] = (y1.detach(), y3.detach(), x.grad.clone(), w1.grad.clone(), w2.grad.clone())
         for a, b in zip(outs[1], outs[0]):
             close(a, b, 2e-5)

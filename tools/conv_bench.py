@@ -66,5 +66,44 @@ def main():
     L.c.segx_tune(17, 256)
 
 
+def wgrad():
+    """weight gradients: resident-halo form against the im2col kernels (+ their batch sum and un-packing launches)"""
+    which = sys.argv[2] if len(sys.argv) > 2 else 'all'
+    B = 4
+    g = torch.Generator(device='cpu').manual_seed(0)
+    L.c.segx_tune(17, 1)
+    for cfg in (['cfg4', 'cfg5'] if which == 'all' else [which]):
+        for name, Cin, Cout in LAYERS:
+            D, H, W = SIZES[cfg][STAGE[name[0]]]
+            geom = (Cin, D, H, W, D, H, W, 3, 3, 3, 1, 1, 1, 1, 1, 1)
+            x = torch.randn(B, Cin, D, H, W, generator=g).to(dev)
+            dy = torch.randn(B, Cout, D, H, W, generator=g).to(dev)
+            N = Cin * 27
+            flops = 2.0 * B * Cout * D * H * W * N
+            sk = L.conv3d_splitk(B, Cout, geom, True)
+            ws = torch.empty(sk * B * Cout * N, device=dev) if sk > 1 else None
+            dwb = torch.empty(B, Cout * N, device=dev); dwp = torch.empty(Cout * N, device=dev); dw0 = torch.empty(Cout * N, device=dev)
+            cw = torch.empty(L.colreduce_ws(B, Cout * N, 1), device=dev)
+
+            def old():
+                L.conv3d_bwd_weight(dy, x, dwb, B, Cout, geom, sk, ws, packed=True)
+                L.colsum(dwb, dwp, cw, B, Cout * N)
+                L.conv3d_unpack_wgrad(dwp, dw0, Cout, Cin, 27)
+            t0 = timed(old)
+            line = '%s %-7s wgrad Cin %3d Cout %3d %2dx%2dx%2d | im2col(sk %2d) %7.3f ms %6.1f TF' % (cfg, name, Cin, Cout, D, H, W, sk, t0, flops / t0 / 1e9)
+            if L.conv3d_halo_wgrad_ok(B, Cout, geom):
+                dw1 = torch.empty(Cout, Cin, 3, 3, 3, device=dev)
+                t1 = timed(lambda: L.conv3d_halo_wgrad(dy, x, dw1, B, Cout, geom))
+                err = (dw1.reshape(-1) - dw0).abs().max().item() / max(dw0.abs().max().item(), 1e-20)
+                line += ' | halo %7.3f ms %6.1f TF%s' % (t1, flops / t1 / 1e9, '' if err < 2e-5 else ' MISMATCH %.1e' % err)
+            else:
+                line += ' | halo: not served'
+            print(line, flush=True)
+    L.c.segx_tune(17, 256)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'wgrad':
+        wgrad()
+        sys.exit(0)
     main()
