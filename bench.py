@@ -357,12 +357,12 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
     return res
 
 
-def run_graph_replay(args, config=None, graph=True):
+def run_graph_replay(args, config=None, graph=True, batch=0):
     """The same configuration replayed as ONE captured hipGraph per step (engine.GraphedTrainStep), in a child process after everything else has been
     measured: a capture problem can then cost this extra block only, never the line.  Not the headline: `value` stays the eager step, whose engine
     launches carry the HIP events the roofline is computed from."""
     cmd = [sys.executable, os.path.abspath(__file__)] + (['--graph'] if graph else []) + ['--config', config or args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
-           '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order']
+           '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order'] + (['--batch', str(batch)] if batch else [])
     if args.reference_op_order:
         cmd.append('--reference-op-order')
     try:
@@ -412,7 +412,8 @@ def compact_line(res):
     line['config'] = {'workload': c.get('workload'), 'global_batch': c.get('global_batch'), 'per_gpu_batch': c.get('per_gpu_batch'),
                       'parallelism': c.get('parallelism'), 'dropout': c.get('dropout'), 'step': c.get('step'), 'final_loss': c.get('final_loss'),
                       'op_order': (c.get('op_order') or '').split(' (')[0], other_key + '_ms': ms(c.get(other_key)),
-                      'with_h2d_copy_ms': ms(c.get('with_h2d_copy')), 'hipgraph_replay_ms': ms(c.get('hipgraph_replay')),
+                      other_key + '_value': (c.get(other_key) or {}).get('value') if isinstance(c.get(other_key), dict) else None,      # the like-for-like figure beside `value`
+                      'with_h2d_copy_ms': ms(c.get('with_h2d_copy')), 'with_h2d_copy_value': (c.get('with_h2d_copy') or {}).get('value') if isinstance(c.get('with_h2d_copy'), dict) else None, 'hipgraph_replay_ms': ms(c.get('hipgraph_replay')),
                       'cfg1_hipgraph_ms': ms(c.get('hipgraph_replay_cfg1')), 'cfg1_eager_ms': ms(c.get('eager_cfg1')),
                       'ranks': c.get('ranks'), 'collective_backend': c.get('collective_backend'), 'overlap': c.get('overlap')}
     line['roofline'] = _short_roofline(res.get('roofline'))
@@ -474,6 +475,7 @@ def main():
     ap.add_argument('--config', default='cfg2', help='BASELINE config of the MAIN measurement (cfg2 = metric default)')
     ap.add_argument('--engine', default=os.environ.get('SEGX_ENGINE', 'x6'), choices=['x6', 'f32'],
                     help="tile engine: 'x6' = bf16x6 (default), 'f32' = v_mfma_f32_32x32x2_f32 everywhere")
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch of the MAIN measurement (0 = the configuration\'s own)')
     ap.add_argument('--graph', action='store_true', help='replay the step as one captured hipGraph (single GPU; no per-launch roofline)')
     ap.add_argument('--no-brats', action='store_true', help='skip the secondary BraTS block(s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -502,7 +504,7 @@ def main():
     for kv in filter(None, os.environ.get('SEGX_TUNE', '').split(',')):       # e.g. SEGX_TUNE=2:1 (bisecting knobs, see segx_tune)
         k, v = kv.split(':'); L.c.segx_tune(int(k), int(v))
 
-    res = measure(args.config, args, args.steps, args.warmup, rank, world, dev)
+    res = measure(args.config, args, args.steps, args.warmup, rank, world, dev, batch=args.batch or None)
     res = dict(res, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic')
     if not args.no_brats and args.config == 'cfg2':
         k2, w2 = max(10, args.steps // 2), max(3, args.warmup // 2)
@@ -521,8 +523,19 @@ def main():
             r = measure('cfg3', args, k3, w3, rank, world, dev, other_order=False, batch=bsz)
             polyp[tag] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'value_at_median', 'config')}
         res['polyp'] = polyp
+    if not args.no_brats and args.config == 'cfg2' and world == 1 and not args.graph:
+        # r06: BASELINE configs[2] on ONE GPU as well -- 6 images per step, and the reference's per-rank step of `--bs 6` on 4 ranks
+        # (train2d.py:791: 6 // 4 = 1 image per rank; launch-bound: eager and replayed as one hipGraph)
+        k3, w3 = max(10, args.steps // 2), max(3, args.warmup // 2)
+        polyp = {}
+        for tag, bsz in (('cfg3_bs6', 6), ('cfg3_bs1_per_rank_of_4', 1)):
+            r = measure('cfg3', args, k3, w3, rank, world, dev, other_order=False, batch=bsz)
+            polyp[tag] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'value_at_median', 'config')}
+        res['polyp'] = polyp
     if rank != 0:
         return
+    if world == 1 and not args.no_brats and args.config == 'cfg2' and not args.graph and not args.single_order:
+        res['polyp']['cfg3_bs1_hipgraph'] = run_graph_replay(args, config='cfg3', batch=1)
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = run_cpu_baseline(args.config)
     if world == 1 and not args.graph and not args.single_order:

@@ -39,7 +39,7 @@ class GradReducer:
     buckets travel over xGMI while the backbone is still differentiating.  `allreduce_grads()` then only launches what is left and
     waits.  Buckets that hold no live parameter are never sent (they are zeros on every rank)."""
 
-    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True, force_collectives=False, overlap_bn_teams=False):
+    def __init__(self, optimizer, bucket_mb=64, group=None, overlap=True, gather=True, force_collectives=False, overlap_bn_teams=True):
         """gather=True: gradients stay autograd's own tensors and are copied into their bucket by one multi-tensor launch per
         bucket (no per-parameter `grad += g` kernels); gather=False: every p.grad is a view of the flat buffer.
         force_collectives: issue the all-reduces even in a one-rank group (the single-GPU RCCL test: AVG over one rank is the identity)."""
@@ -61,10 +61,12 @@ class GradReducer:
                 self.buckets.append((a, end, i0, i + 1))
                 a, i0 = end, i + 1
         self._avg = dist.is_initialized() and dist.get_backend(group) == 'nccl'        # RCCL averages in the collective; gloo has no AVG
-        # Collectives launched from the hooks run RCCL's reduction kernels on the compute units WHILE backward's kernels run: the one-launch TEAM form
-        # of training BatchNorm (backbone.hip) needs its workgroups co-resident, which a concurrent kernel can delay.  Its polls are bounded and fail
-        # loudly (segx_team_status), but a data-parallel step should not depend on that: with overlap on, BatchNorm without SyncBN takes the
-        # two-launch form (knob 3 = 1; the synchronised form never uses teams).  `overlap_bn_teams=True` keeps them (measurements).
+        # Collectives launched from the hooks run RCCL's reduction kernels on the compute units WHILE backward's kernels run.  The one-launch TEAM form of training
+        # BatchNorm (backbone.hip; only reached WITHOUT synchronised BatchNorm -- the synchronised form never uses teams) needs its workgroups co-resident, which a
+        # concurrent kernel can delay but not prevent: a team is at most half the CUs' worth of workgroups at two resident workgroups per CU (team_cap), RCCL's
+        # channels hold a few dozen, and the polls are bounded and fail loudly (segx_team_status -> RuntimeError at the optimizer step).  r06:
+        # the teams therefore STAY on by default -- the per-rank step keeps the 1 + 1 / 2 + 1 pass structure of the one-GPU step; r05 switched them off whenever
+        # overlap was on (3 ms per cfg2 step).  `overlap_bn_teams=False` restores that (two-launch form, knob 3 = 1) for a stack where the check does fail.
         self.bn_teams_off, self._bn_path_prev = False, 0
         if overlap and (self.world > 1 or self.force) and self.flat.is_cuda and not overlap_bn_teams:
             from . import segx

@@ -748,11 +748,34 @@ class _BNActCat(torch.autograd.Function):
         out = _empty(head, B, c0 + sum(Cs), *sp)
         out[:, :c0].copy_(head)
         saved, cfgs, off = [], [], c0
+        # r06 (reference train2d.py:1109 nn.SyncBatchNorm, one exchange per LAYER): the branch-final BatchNorms of an Inception module are
+        # independent of each other, so their synchronised statistics travel in ONE all-gather (and their backward sums in ONE all-reduce): with the fused head
+        # (bn_act_multi) a module costs 2 + 2 collectives instead of 4 + 4 (6 + 6 in the reference's layer-by-layer form)
+        presync = None
+        if training and _bn_stats_sync is not None and n > 1:
+            loc = _empty(head, 4 * sum(Cs))
+            o4 = 0
+            for i in range(n):
+                L.bn_stats_local(xs[i], loc[o4:o4 + 4 * Cs[i]], _empty(head, L.bn_parts_floats(B, Cs[i], S)), B, Cs[i], S)
+                o4 += 4 * Cs[i]
+            allv, world = _bn_stats_sync(loc)
+            allv, presync, o4 = allv.view(world, -1), [], 0
+            for i in range(n):
+                presync.append((allv[:, o4:o4 + 4 * Cs[i]].contiguous().view(-1), world))      # [world][C_i] float4: what segx_bn_act_fwd2 merges (nparts = -world)
+                o4 += 4 * Cs[i]
         for i in range(n):
             x, (w, b, rm, rv, mom, eps) = xs[i], flat[7 * i + 1:7 * i + 7]
             assert x.shape[0] == B and tuple(x.shape[2:]) == sp
             dst = out[:, off:off + Cs[i]]
-            if _slice_writable(dst, S):
+            if presync is not None:
+                ok = _slice_writable(dst, S)
+                y = dst if ok else torch.empty_like(x)
+                mean, var = _empty(x, Cs[i]), _empty(x, Cs[i])
+                L.bn_act_fwd2(x, presync[i][0], -presync[i][1], mean, var, rm, rv, mom, w, b, y, None, None, 0.0, 0, 0, B, Cs[i], S, eps, act, y_bs=dst.stride(0) if ok else 0)
+                if not ok:
+                    dst.copy_(y)
+                cnt = B * S * presync[i][1]
+            elif _slice_writable(dst, S):
                 _, mean, var, cnt, _, _ = _bn_forward(L, x, w, b, rm, rv, training, mom, eps, act, B, Cs[i], S, out=dst)
             else:                                                                          # rows that are not float4 multiples: a tensor of its own + the copy
                 y, mean, var, cnt, _, _ = _bn_forward(L, x, w, b, rm, rv, training, mom, eps, act, B, Cs[i], S)
@@ -769,6 +792,26 @@ class _BNActCat(torch.autograd.Function):
         L = segx.lib()
         sv = ctx.saved_tensors
         grads, off = [], ctx.c0
+        if ctx.cfgs and ctx.cfgs[0][5] and _bn_grad_sync is not None and len(ctx.cfgs) > 1:
+            # synchronised: the local (sum du * xhat, sum du) pairs of all branches in ONE buffer -> ONE all-reduce -> the apply passes (see forward)
+            Ct = sum(cfg[1] for cfg in ctx.cfgs)
+            both = _empty(dout, 2 * Ct)
+            dys, o2 = [], 0
+            for i, cfg in enumerate(ctx.cfgs):
+                x, mean, var, w, b = sv[5 * i:5 * i + 5]
+                B, C, S, eps, act, training, n = cfg
+                dy = _c(dout[:, off:off + C])
+                L.bn_act_bwd_reduce(dy, x, mean, var, w, b, both[o2:o2 + C], both[o2 + C:o2 + 2 * C], _empty(x, L.bn_ws(B, C)), B, C, S, eps, act, None, None, 0.0, 0.0, 0, 0)
+                dys.append(dy); o2 += 2 * C; off += C
+            glob, o2 = _bn_grad_sync(both), 0
+            for i, cfg in enumerate(ctx.cfgs):
+                x, mean, var, w, b = sv[5 * i:5 * i + 5]
+                B, C, S, eps, act, training, n = cfg
+                dx = torch.empty_like(x)
+                L.bn_act_bwd_apply(dys[i], x, mean, var, w, b, glob[o2:o2 + C], glob[o2 + C:o2 + 2 * C], dx, B, C, S, eps, act, 1.0 / n, None, None, 0.0, 0.0, 0, 0)
+                grads += [dx, both[o2:o2 + C], both[o2 + C:o2 + 2 * C], None, None, None, None]
+                o2 += 2 * C
+            return (dout[:, :ctx.c0], None, None) + tuple(grads)
         for i, cfg in enumerate(ctx.cfgs):
             x, mean, var, w, b = sv[5 * i:5 * i + 5]
             dx, dw, db = _bn_act_backward(L, dout[:, off:off + cfg[1]], x, mean, var, w, b, cfg)

@@ -135,8 +135,18 @@ def _case_sync_bn_blocks(rank, world, ret):
         sdist.enable_sync_batchnorm()
         m = make(); m.train()
         x = x_full[rank:rank + 1].clone().requires_grad_(True)
-        y = m(x); (y * G_full[rank:rank + 1]).sum().backward()
+        counts = {'gather': 0, 'reduce': 0}
+        og, orr = dist.all_gather_into_tensor, dist.all_reduce
+        dist.all_gather_into_tensor = lambda *a, **k: (counts.__setitem__('gather', counts['gather'] + 1), og(*a, **k))[1]
+        dist.all_reduce = lambda *a, **k: (counts.__setitem__('reduce', counts['reduce'] + 1), orr(*a, **k))[1]
+        try:
+            y = m(x); (y * G_full[rank:rank + 1]).sum().backward()
+        finally:
+            dist.all_gather_into_tensor, dist.all_reduce = og, orr
         sdist.disable_sync_batchnorm()
+        # r06: collectives per block -- Inception module: 2 statistics exchanges forward (fused head; the three branch-final BatchNorms
+        # together) + 2 backward (the reference's nn.SyncBatchNorm: 6 + 6); MBConv block: its three BatchNorms depend on each other in sequence: 3 + 3
+        ret['%s_collectives%d' % (tag, rank)] = (counts['gather'], counts['reduce'])
         good = torch.allclose(y, yr[rank:rank + 1].detach(), atol=3e-5, rtol=1e-4) and torch.allclose(x.grad, xr.grad[rank:rank + 1], atol=3e-5, rtol=1e-4)
         for (k, a), (_, b) in zip(m.named_parameters(), ref.named_parameters()):
             ga = a.grad.clone(); dist.all_reduce(ga)
@@ -256,3 +266,6 @@ def test_four_ranks_sync_batchnorm_and_data_parallel_step():
 def test_four_ranks_whole_mbconv_block_and_inception_module_under_sync_batchnorm():
     res = _run('_case_sync_bn_blocks', world=4)
     assert all(res[r] is True for r in range(4)), res
+    for r in range(4):
+        assert tuple(res['inception_collectives%d' % r]) == (2, 2), res          # one exchange for the fused head, one for the three branch-final BatchNorms, each way
+        assert tuple(res['mbconv_collectives%d' % r]) == (3, 3), res             # sequentially dependent layers: one each
