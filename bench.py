@@ -137,7 +137,7 @@ def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
         shp = pr[3]
         if isinstance(shp[0], str):                             # conv3d: (tag, M, N, K, B, ...): weights + activation + output
             _, M_, N_, K_, B_ = shp[:5]
-            alg_bytes += 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] == 'conv3d_fwd' else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
+            alg_bytes += 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] in ('conv3d_fwd', 'conv3d_halo_fwd') else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
         else:
             M_, N_, K_, nb_ = shp[:4]
             alg_bytes += 4.0 * nb_ * (M_ * K_ + N_ * K_ + M_ * N_)
@@ -154,7 +154,7 @@ def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
         dom = stat['x6']
         peak = PEAK_BF16_MFMA_TFLOPS / 6.0
         roof = {'bound': 'mfma',
-                'kernel': 'segx bf16x6 tile engine: gemm_x6_kernel + conv3d_{fwd,wgrad}_x6_kernel (fp32 operands split in registers into 3 bf16 '
+                'kernel': 'segx bf16x6 tile engine: gemm_x6* + conv3d_{fwd,wgrad}_x6 + conv3d_halo_{fwd,wgrad}_x6 kernels (fp32 operands split in registers into 3 bf16 '
                           'planes, 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block: fp32-equivalent results)',
                 'achieved': dom['tflops'], 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(dom['tflops'] / peak, 4),
                 'peak_note': 'fp32-equivalent TFLOP/s: bf16 dense MFMA peak 2500 / 6 instructions per block product; executed bf16 MFMA rate = '
@@ -175,7 +175,7 @@ def engine_roofline(prof, steps, cfg_name, engine_name, mode_batch=None):
         """algorithmic bytes of ONE launch of this shape (operands read once, result written once; an operand shared by the batch counted once)"""
         if isinstance(shp[0], str):
             _, M_, N_, K_, B_ = shp[:5]
-            return 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] == 'conv3d_fwd' else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
+            return 4.0 * (M_ * K_ + B_ * (N_ * K_ / 27.0 + M_ * N_)) if shp[0] in ('conv3d_fwd', 'conv3d_halo_fwd') else 4.0 * B_ * (M_ * K_ + N_ * K_ / 27.0 + M_ * N_)
         M_, N_, K_, nb_ = shp[:4]
         small, big = min(M_ * K_, N_ * K_), max(M_ * K_, N_ * K_)
         return 4.0 * (nb_ * (big + M_ * N_) + (small if nb_ > 1 and small * 8 <= big else nb_ * small))      # a much smaller operand = the shared weights
@@ -385,7 +385,7 @@ def _short_roofline(roof, n_shapes=6):
     if not roof:
         return None
     out = {k: roof.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic')}
-    out['kernel'] = 'segx bf16x6 tile engine (gemm_x6* + conv3d_*_x6 kernels)' if 'bf16x6' in roof.get('kernel', '') else 'segx fp32-MFMA tile engine'
+    out['kernel'] = 'segx bf16x6 tile engine (gemm_x6* + conv3d_*_x6 + conv3d_halo_*_x6 kernels)' if 'bf16x6' in roof.get('kernel', '') else 'segx fp32-MFMA tile engine'
     out['algorithmic_bytes'] = roof.get('algorithmic_bytes_per_launch')
     out['launches'] = roof.get('launches_per_step')
     out['ms_per_step'] = roof.get('gemm_ms_per_step')
