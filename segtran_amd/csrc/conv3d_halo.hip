@@ -575,7 +575,7 @@ extern "C" int segx_conv3d_halo_ok(int B, int Cout, const int* geom) {
     if (all >= full) return 1;
     // between 5/8 of a tile per CU and one (cfg4's 24 x 14 x 14 stage: 192 tiles at batch 4): only where 64-row workgroups still fill two rounds of the chip or the
     // contraction is too short for the im2col kernels' split-K to pay (r06_b, tools/conv_bench.py: 1.1 - 2 x there, 0.8 - 0.95 x on the long-K data gradients)
-    return all * 8 >= full * 5 && (all * ceil_div(Cout, 64) >= 2 * full || geom[0] <= 64) ? 1 : 0;
+    return all * 8 >= full * 5 && ((all * ceil_div(Cout, 64) >= 2 * full && geom[0] <= 192) || geom[0] <= 64) ? 1 : 0;      // (Cin > 192: the 288 / 320 -> 144 / 160 data gradients, 0.9 x in the step, r06_i)
 }
 /* size of the pre-split filter bank in FLOATS (4-byte units of a float tensor the caller allocates): ceil(C / 8) channel blocks x 7 tap quads x 3 planes x O rows x 64 B */
 extern "C" int64_t segx_conv3d_halo_wq_floats(int O, int C) { return O > 0 && C > 0 ? (int64_t)((C + 7) / 8) * 7 * 3 * O * 16 : 0; }

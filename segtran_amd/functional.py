@@ -4,6 +4,7 @@ when a test has installed the fiber-emulated build of the same kernels through `
 """
 import math
 import torch
+import torch.nn.functional as F
 from . import segx
 from .segx import EPI_NONE, EPI_GELU, BIAS_NONE, BIAS_N, BIAS_M
 
@@ -1697,6 +1698,48 @@ class _StemCompose(torch.autograd.Function):
 
 def stem_compose(stem_weight, bridge_weight, bridge_bias, Cc=8):
     return _StemCompose.apply(stem_weight, bridge_weight, bridge_bias, int(Cc))
+
+
+_stem_masks = {}
+
+
+def _stem_axis_mask(n_in, k, stride, pad_front, device):
+    """[n_out, k] 0/1: tap k of output o reads input stride * o + k - pad_front inside [0, n_in) -- the taps the zero padding does NOT switch off"""
+    key = (n_in, k, stride, pad_front, str(device))
+    m = _stem_masks.get(key)
+    if m is None:
+        n_out = (n_in + stride - 1) // stride
+        i = torch.arange(n_out).view(-1, 1) * stride + torch.arange(k).view(1, -1) - pad_front
+        m = ((i >= 0) & (i < n_in)).float().to(device)
+        _stem_masks[key] = m
+    return m
+
+
+def stem_bridge_conv_s2d(batch, stem_weight, bridge_weight, bridge_bias, stride=(2, 2, 2)):
+    """Conv3d_1a_7x7(in_bridge_to3(batch)) (segtran3d.py:420-423 + aj_i3d.py:75-97: a 1x1x1 convolution with bias onto 3 channels, then the 7 x 7 x 7 stride-2
+    'same' stem) for the raw batch [B, Cb, H, W, D] (2 Cb = 8) as ONE stride-(2, 2, 1) convolution with a 7 x 7 x 4 window over a SPACE-TO-DEPTH image along W:
+        x2[b][2 c + j][d][h][u] = x[b][c][d][h][2 u + j - 2]          (u = ow + kw', tap kw = 2 kw' + j; zero outside the volume)
+        w2[o][2 c + j][kd][kh][kw'] = sum_c3 Ws[o][c3][kd][kh][2 kw' + j] Wb[c3][c]      (kw = 7 does not exist: zero)
+    plus the bridge's bias as a bias MAP: sum over the taps the zero padding leaves on of V[o][tap] = sum_c3 Ws[o][c3][tap] bb[c3] -- 4 x 4 x 4 border classes of
+    output positions, contracted axis by axis with 0/1 masks.  Exactly the products of the composed 8-channel form of r02 (SF.stem_compose: [x, 1, 0, 0, 0] -> 64)
+    in another order, without its three all-zero channels and its constant channel: K = 8 * 196 = 1568 instead of 8 * 343 = 2744 (-43 % of the stem's FLOPs),
+    unit stride along W -- 16-byte row loads in the weight-gradient loader, which therefore runs on the bf16x6 engine (the stride-2 form stayed on the fp32
+    engine at 81 TFLOP/s) -- and every parameter gradient through autograd's chain rule over the small tensors (einsum / pad / permute of <= 64 x 8 x 343 floats)."""
+    B, Cb, H, W, D = batch.shape
+    O, C3, KD, KH, KW = stem_weight.shape
+    assert tuple(stride) == (2, 2, 2) and (KD, KH, KW) == (7, 7, 7) and 2 * Cb == 8 and W % 2 == 0 and H % 2 == 0 and D % 2 == 0
+    wb = bridge_weight.reshape(C3, Cb)
+    wc = torch.einsum('octuv,cd->odtuv', stem_weight, wb)                                   # [O, Cb, 7, 7, 7]
+    w2 = F.pad(wc, (0, 1)).view(O, Cb, KD, KH, 4, 2).permute(0, 1, 5, 2, 3, 4).reshape(O, 2 * Cb, KD, KH, 4).contiguous()
+    # conv axes (D, H, W) = (batch's last axis, H, W): [B, Cb, D, H, W] padded along W by 2 in front (the 'same' front pad) and 4 behind (window end), then W -> (U, 2)
+    U = W // 2 + 3
+    x = F.pad(batch.detach().permute(0, 1, 4, 2, 3), (2, 4))
+    x2 = x.reshape(B, Cb, D, H, U, 2).permute(0, 1, 5, 2, 3, 4).reshape(B, 2 * Cb, D, H, U).contiguous()
+    y = _Conv3d.apply(x2, w2, (2, 2, 1), ((2, 3), (2, 3), (0, 0)))
+    v = torch.einsum('octuv,c->otuv', stem_weight, bridge_bias)                             # the bias seen through each tap
+    md, mh, mw = (_stem_axis_mask(n, 7, 2, 2, batch.device) for n in (D, H, W))
+    bias_map = torch.einsum('otuv,dt,hu,wv->odhw', v, md, mh, mw)                           # [O, OD, OH, OW]: only a shell of three voxels differs from the interior value
+    return y + bias_map.unsqueeze(0)
 
 
 def bridge_input(x, Cc=8):

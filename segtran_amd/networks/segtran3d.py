@@ -10,6 +10,7 @@ backward-data / backward-weight), 'same' max pools, GroupNorm, the trilinear res
 Two exact re-associations of consecutive linear maps are on by default (switches `fuse_output_tail`, `fuse_input_bridge`; both orders are
 parity-tested): the class projection composed into the out-FPN bridge, and the 4 -> 3 input bridge composed into the stem filters.
 """
+import os as _os
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -133,6 +134,7 @@ class Segtran3d(SegtranInitWeights):
         self.out_fpn_do_dropout = config.out_fpn_do_dropout      # --outdrop (:392-394)
         self.fuse_output_tail = True                             # see out_head_forward
         self.fuse_input_bridge = True                            # see _forward: in_bridge_to3 composed into the stem filters
+        self.stem_space_to_depth = _os.environ.get('SEGX_STEM_S2D', '1') != '0'      # r06: ... as a stride-(2, 2, 1) convolution over a space-to-depth image (False: r02's 8-channel stride-2 form)
         self.num_classes = config.num_classes
         self.do_out_fpn = True
         self.out_fpn_out_dim = self.out_feat_dim = self.trans_out_dim
@@ -222,8 +224,14 @@ class Segtran3d(SegtranInitWeights):
             # the bridge's own backward GEMMs.  The foreground mask still needs the bridged image itself (:425) -- forward only.
             with torch.no_grad():      # r05: straight from the raw batch (SF.bridge_mask): no K = 4 GEMM, no permuting copy of the bridged image
                 nonzero_mask = SF.bridge_mask(batch, self.in_bridge_to3.weight, self.in_bridge_to3.bias, self.mask_pool.kernel_size)
-            wc = SF.stem_compose(stem.conv3d.weight, self.in_bridge_to3.weight, self.in_bridge_to3.bias, 8)
-            fd = self.backbone.extract_features(None, stem_conv_out=SF.conv3d_same(SF.bridge_input(batch, 8), wc, stem._stride))
+            if self.stem_space_to_depth and 2 * C == 8 and stem._stride == (2, 2, 2) and stem._kernel_shape == (7, 7, 7):
+                # r06: the same composition WITHOUT its three all-zero channels and its constant channel, on a space-to-depth image along W (SF.stem_bridge_conv_s2d):
+                # -43 % of the stem's FLOPs, unit stride along W (its weight gradient moves from the fp32 engine onto the bf16x6 engine)
+                conv_out = SF.stem_bridge_conv_s2d(batch, stem.conv3d.weight, self.in_bridge_to3.weight, self.in_bridge_to3.bias, stem._stride)
+            else:
+                wc = SF.stem_compose(stem.conv3d.weight, self.in_bridge_to3.weight, self.in_bridge_to3.bias, 8)
+                conv_out = SF.conv3d_same(SF.bridge_input(batch, 8), wc, stem._stride)
+            fd = self.backbone.extract_features(None, stem_conv_out=conv_out)
         else:
             rgb = self.in_bridge_to3(batch).permute(0, 1, 4, 2, 3)                # [B,3,D,H,W]  (reference op order: fuse_input_bridge = False)
             nonzero_mask = self.get_mask(rgb)

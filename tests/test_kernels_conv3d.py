@@ -397,6 +397,35 @@ def test_conv3d_same_takes_the_halo_kernel_where_it_applies(backend):
         L.set_engine(prev)
 
 
+@pytest.mark.parametrize('engine', ['f32', 'x6'])
+@pytest.mark.parametrize('B,H,W,D', [(2, 8, 12, 6), (1, 6, 16, 8)])
+def test_stem_and_bridge_as_one_space_to_depth_convolution(backend, engine, B, H, W, D):
+    """r06: Conv3d_1a_7x7(in_bridge_to3(batch)) as ONE stride-(2, 2, 1) 7 x 7 x 4 convolution over the space-to-depth image along W + the bias map through the zero
+    padding (SF.stem_bridge_conv_s2d) == the two-step computation in PyTorch: output (border voxels included: the bias must not leak into the padding) and the
+    gradients of the stem filters, the bridge weight and the bridge bias."""
+    L = backend.L
+    prev = L.set_engine(engine)
+    try:
+        batch = rnd(B, 4, H, W, D, seed=111)
+        ws = (rnd(8, 3, 7, 7, 7, seed=112) * 0.1).requires_grad_(True)
+        wb = (rnd(3, 4, 1, 1, 1, seed=113) * 0.5).requires_grad_(True)
+        bb = (rnd(3, seed=114) * 0.5).requires_grad_(True)
+        y = SF.stem_bridge_conv_s2d(batch, ws, wb, bb)
+        G = rnd(*y.shape, seed=115)
+        y.backward(G)
+        got = [t.grad.clone() for t in (ws, wb, bb)]
+        for t in (ws, wb, bb):
+            t.grad = None
+        rgb = F.conv3d(batch.permute(0, 1, 4, 2, 3), wb, bb)
+        yr = F.conv3d(F.pad(rgb, (2, 3, 2, 3, 2, 3)), ws, None, 2)
+        yr.backward(G)
+        close(y, yr.detach(), 2e-5)
+        for a, t in zip(got, (ws, wb, bb)):
+            close(a, t.grad, 1e-4)
+    finally:
+        L.set_engine(prev)
+
+
 def test_input_bridge_composed_into_the_stem(backend):
     """in_bridge_to3 (Conv3d 4 -> 3, 1x1x1, bias) followed by the stride-2 'same' stem convolution == ONE convolution of [x, 1, 0, 0, 0] with the
     composed 8-channel filters (segx_stem_compose_fwd / segx_bridge_input): forward, and the gradients of the stem filters, the bridge weight and
