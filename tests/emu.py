@@ -8,6 +8,9 @@ sys.path.insert(0, os.path.join(HERE, 'hipemu'))
 
 @functools.lru_cache(None)
 def emu_lib():
-    import build_emu
     from segtran_amd.segx import SegxLib
+    override = os.environ.get('SEGX_EMU_LIB')              # e.g. an AddressSanitizer build of the same sources (run with the ASan runtime preloaded)
+    if override:
+        return SegxLib(override)
+    import build_emu
     return SegxLib(build_emu.build())
