@@ -44,8 +44,11 @@ enum { SEGX_ENGINE_F32 = 0, SEGX_ENGINE_BF16X6 = 1 };
 enum { SEGX_ENGINE_SEL_DEFAULT = 0, SEGX_ENGINE_SEL_F32 = 1, SEGX_ENGINE_SEL_BF16X6 = 2 };
 enum { SEGX_TILE_AUTO = 0, SEGX_TILE_128x128 = 1, SEGX_TILE_64x64 = 2, SEGX_TILE_128x32 = 3, SEGX_TILE_32x128 = 4, SEGX_TILE_64x128 = 5,
        SEGX_TILE_256x128 = 6, SEGX_TILE_WS128x128 = 7, SEGX_TILE_WS128x256 = 8, SEGX_TILE_WS64x256 = 9,
-       SEGX_TILE_WS96x256 = 10, SEGX_TILE_WS256x96 = 11   /* 96-row side: k-contiguous operand only (A for 96x256, B for 256x96); other layouts quietly take 128x128 */
-       /* 6..9: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h (M x N of the workgroup tile) */ };
+       SEGX_TILE_WS96x256 = 10, SEGX_TILE_WS256x96 = 11,  /* 96-row side: k-contiguous operand only (A for 96x256, B for 256x96); other layouts quietly take 128x128 */
+       /* 6..11: bf16x6 engine only -- the wave-specialised persistent kernels of gemm_x6ws.h (M x N of the workgroup tile) */
+       SEGX_TILE_SKINNY_NT = 12  /* what segx_gemm_plan returns for a batch_reduce product of two k-contiguous operands, one of <= 32 rows and one of <= 192, over a long K
+                                    (the weight gradients of the backbone's first pointwise convolutions, efficientnet/model.py:96, 113): one streaming pass, the batch summed
+                                    inside the kernel, splitk x nbatch slabs (gemm_skinny.hip); any other call that names it quietly takes the planner's tile */ };
 typedef struct {
     int32_t M, N, K, nb0, nb1;
     int64_t a_b0, a_b1, a_m, a_k;

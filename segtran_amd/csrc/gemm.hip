@@ -19,6 +19,7 @@
 // All four combinations (NT: linear fwd / QK^T, NN: P.V, dX = dY.W; TN: dW = dY^T.X; TT) are
 // instantiated, so no operand is ever materialised transposed in HBM.
 #include "gemm_x6ws.h"
+#include "gemm_skinny.h"
 #include "gemm_tuned.h"
 
 namespace segx {
@@ -198,6 +199,17 @@ static bool gemm_vec_ok(const float* A, const float* B, const segx_gemm_desc* d)
                       ((bkc ? d->K : d->N) % 4 == 0);
     return vecA && vecB;
 }
+// the streaming skinny weight gradient (gemm_skinny.hip): batch-reduced, both operands k-contiguous and float4-legal, plain epilogue, one side <= 32 rows;
+// slabs = the largest multiple of the batch size under the persistent grid (the caller's workspace is splitk x nbatch slabs)
+static int skinny_nt_splitk(const float* A, const float* B, const segx_gemm_desc* d) {
+    if (!kget(knobs().skinny_nt) || !d->batch_reduce || d->epilogue != SEGX_EPI_NONE || d->gmax || d->resid || d->a_k != 1 || d->b_k != 1) return 0;
+    if (!gemm_vec_ok(A, B, d)) return 0;
+    const int nbatch = d->nb0 * d->nb1;
+    const int sk = (int)i64max(1, (int64_t)kget(knobs().ws_grid) * skinny_nt_wgs_per_cu(d->M, d->N) / nbatch);
+    if (!skinny_nt_shape_ok(d->M, d->N, d->K, nbatch, sk * nbatch)) return 0;
+    if ((int64_t)d->M * d->a_m >= (1LL << 31) || (int64_t)d->N * d->b_n >= (1LL << 31)) return 0;          // 32-bit row offsets inside a member
+    return sk;
+}
 }  // namespace segx
 
 namespace segx {
@@ -206,6 +218,7 @@ static int gemm_plan_impl(const float* A, const float* B, const segx_gemm_desc* 
     const bool plain = d->epilogue == SEGX_EPI_NONE;
     int t = SEGX_TILE_128x128, sk = 1;
     const bool vec = gemm_vec_ok(A, B, d);
+    if (const int ssk = skinny_nt_splitk(A, B, d)) { *tile = SEGX_TILE_SKINNY_NT; *splitk = ssk; return 0; }
     if (use_table && plain && !d->gmax && x6_eligible(call_engine(d), d->M, d->N, vec)) {
         // measured choices first (gemm_tuned.h); a wave-specialised entry still needs its preconditions (they hold for the shapes it was measured on)
         const int nbt = d->nb0 * d->nb1; const bool akc_ = d->a_k == 1, bkc_ = d->b_k == 1;
@@ -266,13 +279,32 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     g.resid = d->resid;
     SEGX_REQUIRE(!d->resid || (d->epilogue == SEGX_EPI_NONE && !breduce && !d->gmax), "segx_gemm_f32: resid needs a plain epilogue (no GELU, no batch_reduce, no gmax)");
     if (splitk > 1 || breduce) g.C = d->workspace;
-    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_WS256x96, "segx_gemm_f32: bad tile %d", d->tile);
+    SEGX_REQUIRE(d->tile >= SEGX_TILE_AUTO && d->tile <= SEGX_TILE_SKINNY_NT, "segx_gemm_f32: bad tile %d", d->tile);
     const bool ws_tile = d->tile >= SEGX_TILE_256x128 && d->tile <= SEGX_TILE_WS256x96;
     SEGX_REQUIRE(d->engine >= SEGX_ENGINE_SEL_DEFAULT && d->engine <= SEGX_ENGINE_SEL_BF16X6, "segx_gemm_f32: bad engine selector %d", d->engine);
     const int engine = call_engine(d);
     SEGX_REQUIRE(!ws_tile || engine == SEGX_ENGINE_BF16X6, "segx_gemm_f32: tile %d exists on the bf16x6 engine only", d->tile);
     const int x6_variant = kget(knobs().x6_variant);
     int tile = d->tile;
+    if (tile == SEGX_TILE_SKINNY_NT) {
+        // the plan's slab count travels as splitk; anything the streaming kernel does not serve quietly takes the planner's tile (like the 96-row tiles)
+        const int ssk = skinny_nt_splitk(A, B, d);
+        if (ssk > 0 && splitk <= ssk) {
+            const int nslabs = splitk * d->nb0 * d->nb1;
+            int rc = launch_skinny_nt(A, B, static_cast<float*>(d->workspace), d->M, d->N, d->K, d->nb0, d->nb1, d->a_b0, d->a_b1, d->a_m, d->b_b0, d->b_b1, d->b_n,
+                                      nslabs, stream);
+            if (rc) return rc;
+            const int64_t total = (int64_t)d->M * d->N;
+            if (total * 16 <= 512 * 1024 && nslabs >= 16)
+                hipLaunchKernelGGL((slab_sum_parts_kernel<16>), dim3((unsigned)((total + 15) / 16)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                                   d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
+            else
+                hipLaunchKernelGGL((slab_sum_parts_kernel<4>), dim3((unsigned)((total + 63) / 64)), dim3(256), 0, stream, (const float*)d->workspace, C, g.bias,
+                                   d->M, d->N, nslabs, total, d->c_m, d->alpha, d->bias_mode);
+            return check_launch("segx_gemm_f32/skinny_nt_reduce");
+        }
+        tile = SEGX_TILE_AUTO;
+    }
     const bool gelu = d->epilogue == SEGX_EPI_GELU;
     // the wave-specialised kernels address an operand through 32-bit byte offsets from a per-item base and take whole 32-k stages only
     const bool ws_ok = gemm_ws_ok(d), lean_ok = gemm_lean_ok(d);

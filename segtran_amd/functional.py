@@ -1724,21 +1724,26 @@ def stem_bridge_conv_s2d(batch, stem_weight, bridge_weight, bridge_bias, stride=
     output positions, contracted axis by axis with 0/1 masks.  Exactly the products of the composed 8-channel form of r02 (SF.stem_compose: [x, 1, 0, 0, 0] -> 64)
     in another order, without its three all-zero channels and its constant channel: K = 8 * 196 = 1568 instead of 8 * 343 = 2744 (-43 % of the stem's FLOPs),
     unit stride along W -- 16-byte row loads in the weight-gradient loader, which therefore runs on the bf16x6 engine (the stride-2 form stayed on the fp32
-    engine at 81 TFLOP/s) -- and every parameter gradient through autograd's chain rule over the small tensors (einsum / pad / permute of <= 64 x 8 x 343 floats)."""
+    engine at 81 TFLOP/s) -- and every parameter gradient through autograd's chain rule over the small tensors (SF.linear / pad / permute of <= 64 x 8 x 343 floats)."""
     B, Cb, H, W, D = batch.shape
     O, C3, KD, KH, KW = stem_weight.shape
     assert tuple(stride) == (2, 2, 2) and (KD, KH, KW) == (7, 7, 7) and 2 * Cb == 8 and W % 2 == 0 and H % 2 == 0 and D % 2 == 0
-    wb = bridge_weight.reshape(C3, Cb)
-    wc = torch.einsum('octuv,cd->odtuv', stem_weight, wb)                                   # [O, Cb, 7, 7, 7]
+    # the small contractions run on the tile engine too (SF.linear: differentiable, no vendor GEMM on the step -- torch.einsum would hand them to hipBLASLt)
+    taps = stem_weight.permute(0, 2, 3, 4, 1).reshape(O * KD * KH * KW, C3)                # [(o, kd, kh, kw), c3]
+    wc = linear(taps, bridge_weight.reshape(C3, Cb).t()).view(O, KD, KH, KW, Cb).permute(0, 4, 1, 2, 3)   # [O, Cb, 7, 7, 7] = sum_c3 Ws[o][c3][tap] Wb[c3][c]
     w2 = F.pad(wc, (0, 1)).view(O, Cb, KD, KH, 4, 2).permute(0, 1, 5, 2, 3, 4).reshape(O, 2 * Cb, KD, KH, 4).contiguous()
     # conv axes (D, H, W) = (batch's last axis, H, W): [B, Cb, D, H, W] padded along W by 2 in front (the 'same' front pad) and 4 behind (window end), then W -> (U, 2)
     U = W // 2 + 3
     x = F.pad(batch.detach().permute(0, 1, 4, 2, 3), (2, 4))
     x2 = x.reshape(B, Cb, D, H, U, 2).permute(0, 1, 5, 2, 3, 4).reshape(B, 2 * Cb, D, H, U).contiguous()
     y = _Conv3d.apply(x2, w2, (2, 2, 1), ((2, 3), (2, 3), (0, 0)))
-    v = torch.einsum('octuv,c->otuv', stem_weight, bridge_bias)                             # the bias seen through each tap
+    v = linear(taps, bridge_bias.view(1, C3)).view(O, KD, KH, KW)                           # the bias seen through each tap
     md, mh, mw = (_stem_axis_mask(n, 7, 2, 2, batch.device) for n in (D, H, W))
-    bias_map = torch.einsum('otuv,dt,hu,wv->odhw', v, md, mh, mw)                           # [O, OD, OH, OW]: only a shell of three voxels differs from the interior value
+    # bias_map[o][d][h][w] = sum_{t,u,v} v[o][t][u][v] md[d][t] mh[h][u] mw[w][v], one axis at a time (the contracted axis moved last, the W axis contracted last so
+    # that the result lands in [O, OD, OH, OW] order): only a shell of three voxels differs from the interior value
+    s = linear(v.permute(0, 2, 3, 1), md)                                                   # [O, kh, kw, OD]
+    s = linear(s.permute(0, 3, 2, 1), mh)                                                   # [O, OD, kw, OH]
+    bias_map = linear(s.permute(0, 1, 3, 2), mw)                                            # [O, OD, OH, OW]
     return y + bias_map.unsqueeze(0)
 
 

@@ -33,7 +33,7 @@ class GemmDesc(ctypes.Structure):
 
 EPI_NONE, EPI_GELU = 0, 1
 (TILE_AUTO, TILE_128x128, TILE_64x64, TILE_128x32, TILE_32x128, TILE_64x128, TILE_256x128, TILE_WS128x128, TILE_WS128x256, TILE_WS64x256,
- TILE_WS96x256, TILE_WS256x96) = range(12)
+ TILE_WS96x256, TILE_WS256x96, TILE_SKINNY_NT) = range(13)
 BIAS_NONE, BIAS_N, BIAS_M = 0, 1, 2
 
 

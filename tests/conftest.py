@@ -15,6 +15,15 @@ def pytest_configure(config):
                                        'of a plain `-m gpu` / `-m "not gpu"` run -- select them with SEGX_EXPERIMENTAL=1 (they then run LAST)')
 
 
+def pytest_sessionstart(session):
+    """The PyTorch side of every comparison runs on ATen's own kernels, not on MIOpen.  With MIOpen enabled the REFERENCE backward of
+    test_bn_act_squeeze_excite_fused[2-70-9-4-5] (BatchNorm2d on 2 x 70 x 4 x 5 / a pointwise conv2d on a [B, C, 1, 1] tensor) died with an illegal memory access whenever
+    the whole -m gpu suite ran in front of it (sessions r06_k / r06_l; with blocking launches the fault sits in a C++ autograd node: r06_m) and passed when its file ran
+    alone -- an allocator-layout-dependent fault outside the product.  The product never calls MIOpen; the switch only selects which ATen kernels form the references."""
+    import torch
+    torch.backends.cudnn.enabled = False
+
+
 def pytest_collection_modifyitems(config, items):
     """an experiment must not be able to turn the product suite red.  Tests marked `experimental` are deselected unless
     SEGX_EXPERIMENTAL=1, and when selected they are moved behind every product test (so `-x` stops there only after the product has been judged)."""

@@ -6,16 +6,6 @@ import torch.nn.functional as F
 from segtran_amd import functional as SF
 
 
-@pytest.fixture(autouse=True)
-def _aten_native_reference():
-    """The PyTorch side of these comparisons runs on ATen's own CUDA kernels, not on MIOpen: with MIOpen enabled the REFERENCE backward of
-    test_bn_act_squeeze_excite_fused[2-70-9-4-5] (BatchNorm2d on 2 x 70 x 4 x 5 / a pointwise conv2d on a [B, C, 1, 1] tensor) died with an illegal memory access whenever the
-    whole -m gpu suite ran in front of it (sessions r06_k / r06_l; with blocking launches the fault sits in a C++ autograd node, r06_m), and passed when the file ran
-    alone -- an allocator-layout-dependent fault outside the product.  The product never calls MIOpen; the flag only changes which ATen kernels form the reference."""
-    with torch.backends.cudnn.flags(enabled=False):
-        yield
-
-
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator(device='cpu').manual_seed(seed + sum(shape))
     return (torch.randn(*shape, generator=g, device='cpu') * scale).to(torch.get_default_device())

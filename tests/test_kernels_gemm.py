@@ -1,4 +1,5 @@
 """CPU: segtran_amd/csrc/gemm.hip executed lane-by-lane on the fiber emulator vs torch fp64."""
+import ctypes
 import pytest
 import torch
 from segtran_amd import segx
@@ -126,6 +127,48 @@ def test_gemm_batch_reduce_sums_over_the_batch(backend, nb, sk, M, N):
            splitk=sk, workspace=ws, batch_reduce=True)
     ref = 0.5 * torch.einsum('xymk,xynk->mn', A.double(), B.double()) + bias.double()[None]
     assert (C.double() - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item() / 10)
+
+
+@pytest.mark.parametrize('nb,M,N,K', [((2, 1), 192, 32, 2048), ((3, 1), 144, 24, 1024), ((2, 1), 32, 192, 2048), ((3, 2), 24, 48, 1024), ((4, 1), 24, 24, 3072),
+                                      ((2, 1), 3, 160, 2048), ((2, 1), 56, 32, 4096), ((2, 1), 100, 7, 2048), ((1, 1), 128, 32, 4096)])
+def test_gemm_skinny_weight_gradient_streams(backend, nb, M, N, K):
+    """gemm_skinny.hip (segx_gemm_plan -> SEGX_TILE_SKINNY_NT): the batch-reduced product of two k-contiguous operands, one of <= 32 rows, over a long K -- the weight
+    gradients of the backbone's first pointwise convolutions (efficientnet/model.py:96, 113) -- in one streaming pass with the batch walked inside the kernel; against
+    fp64, and against the tile kernels' split-K slabs (knob 18 = 0) which it replaces.  A persistent grid of 8 (knob 9) keeps the emulator run short and makes every
+    workgroup cross a batch-member boundary or end inside one."""
+    L = backend.L
+    g = torch.Generator(device='cpu').manual_seed(11 + M + N)
+    A = torch.randn(nb[0], nb[1], M, K, generator=g, device='cpu').to(backend.dev)
+    B = torch.randn(nb[0], nb[1], N, K, generator=g, device='cpu').to(backend.dev)
+    bias = torch.randn(M, generator=g, device='cpu').to(backend.dev)
+    ref = 0.25 * torch.einsum('xymk,xynk->mn', A.double(), B.double()).cpu() + bias.double().cpu()[:, None]
+    args = (M, N, K, (nb[1] * M * K, M * K, K, 1), (nb[1] * N * K, N * K, K, 1), (0, 0, N))
+    out = {}
+    assert L.c.segx_tune(9, 8) == 0
+    try:
+        for knob in (1, 0):
+            assert L.c.segx_tune(18, knob) == 0
+            d = segx.GemmDesc()
+            d.M, d.N, d.K, d.nb0, d.nb1 = M, N, K, nb[0], nb[1]
+            d.a_b0, d.a_b1, d.a_m, d.a_k = args[3]; d.b_b0, d.b_b1, d.b_n, d.b_k = args[4]
+            d.batch_reduce = 1
+            t, sk = ctypes.c_int(0), ctypes.c_int(0)
+            assert L.c.segx_gemm_plan(A.data_ptr(), B.data_ptr(), ctypes.byref(d), ctypes.byref(t), ctypes.byref(sk)) == 0
+            assert (t.value == segx.TILE_SKINNY_NT) == (knob == 1), (t.value, sk.value)
+            C = torch.full((M, N), float('nan'))
+            L.gemm(A, B, C, *args, nb=nb, alpha=0.25, bias=bias, bias_mode=segx.BIAS_M, splitk=0, batch_reduce=True)
+            out[knob] = C.double().cpu()
+            assert (out[knob] - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    finally:
+        assert L.c.segx_tune(18, 1) == 0 and L.c.segx_tune(9, 256) == 0
+    assert (out[1] - out[0]).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    # a caller that names the tile for a product the kernel does not serve (K not a multiple of 64) quietly gets the planner's tile
+    A2, B2 = A[..., :K - 4].contiguous(), B[..., :K - 4].contiguous()
+    C2 = torch.zeros(M, N); ws = torch.zeros(nb[0] * nb[1] * M * N)
+    L.gemm(A2, B2, C2, M, N, K - 4, (nb[1] * M * (K - 4), M * (K - 4), K - 4, 1), (nb[1] * N * (K - 4), N * (K - 4), K - 4, 1), (0, 0, N), nb=nb, splitk=1, workspace=ws,
+           tile=segx.TILE_SKINNY_NT, batch_reduce=True)
+    ref2 = torch.einsum('xymk,xynk->mn', A2.double(), B2.double()).cpu()
+    assert (C2.double().cpu() - ref2).abs().max().item() < 2e-5 * max(1.0, ref2.abs().max().item())
 
 
 def test_gemm_rejects_bad_strides(backend):

@@ -7,7 +7,7 @@ tag = sys.argv[1]
 src, dst = os.path.join(ROOT, 'gpurun_out', tag), os.path.join(ROOT, 'profiles')
 # every kernel whose launches bench.py brackets with events (segx.SegxLib.gemm / conv3d: `roofline.algorithmic_bytes` averages over all of them).  r04 left out
 # gemm_x6_lean_kernel ('gemm_x6_kernel' is not a substring of it): 134 of 456 launches at cfg2 were missing from the traffic and matrix-pipe figures.
-ENGINE = ('gemm_f32_kernel', 'gemm_x6_kernel', 'gemm_x6_lean_kernel', 'gemm_x6ws_kernel', 'gemm_x6ws_pre_kernel', 'gemm_stream_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel',
+ENGINE = ('gemm_f32_kernel', 'gemm_skinny_nt_kernel', 'gemm_x6_kernel', 'gemm_x6_lean_kernel', 'gemm_x6ws_kernel', 'gemm_x6ws_pre_kernel', 'gemm_stream_kernel', 'conv3d_fwd_kernel', 'conv3d_wgrad_kernel',
           'conv3d_fwd_x6_kernel', 'conv3d_wgrad_x6_kernel', 'conv3d_halo_fwd_x6_kernel', 'conv3d_halo_wgrad_x6_kernel')
 
 
