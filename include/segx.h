@@ -158,6 +158,14 @@ int segx_modes_aggr_bwd(const float* dY, const float* Z, const float* lnw, const
 int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa,
                                const float* stats, const float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws,
                                int Mo, int64_t R, int F, float p, uint64_t seed, uint64_t offset, void* stream);
+/* The whole backward of the expansion tail in ONE pass over Z and dY (round 6): dZ, dscore AND the three parameter gradients (dlnw, dlnb, dwa; the reference
+ * gets them from autograd over LayerNorm :273-274 and LearnedSoftAggregate :318-325).  Four modes and F <= 2048: every wave adds its tokens' column terms into
+ * LDS vectors of its own, a workgroup writes one chunk of ws, a second launch adds the chunks in a fixed order (deterministic; no second read of Z, no regenerated
+ * dropout mask).  Anything else runs segx_modes_aggr_bwd + segx_modes_aggr_param_grad.  ws: segx_modes_aggr_bwd_all_ws_floats(Mo, R, F) floats. */
+int64_t segx_modes_aggr_bwd_all_ws_floats(int Mo, int64_t R, int F);
+int segx_modes_aggr_bwd_all(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
+                            float* dZ, float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws, int Mo, int64_t R, int F,
+                            float p, uint64_t seed, uint64_t offset, void* stream);
 /* backward of the GELU(+dropout) epilogue of segx_gemm_f32 (MMSharedMid :244-245): dT = dH * keep * gelu'(T) */
 int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 

@@ -604,16 +604,21 @@ __global__ __launch_bounds__(256) void modes_aggr_fwd_kernel(const float* __rest
 // waited for every float4 separately -- 56 dependent round trips per token, 724 us for the 24576 x 4 x 1792 launch = what two waves per SIMD of
 // that chain take.  The LayerNorm / aggregation vectors (shared by the four rows of a workgroup) are staged in LDS once; the dropout keep mask
 // is applied to z in place and kept as one bit per element for the final multiply.
-template <int NV4, int MO>
+// r06 (PG = true): the PARAMETER gradients of the tail are formed here too.  They are column sums over all (mode, token) rows of quantities this kernel already holds
+// in registers -- dlnw = sum dzn * zhat, dlnb = sum dzn, dwa = sum ds * zn with dzn = pr dY + ds wa -- and used to be a pass of their own
+// (modes_aggr_pgrad_stage1_v4) that read Z and dY AGAIN and regenerated the dropout mask: 0.79 ms of the cfg2 step for 0.9 GB it had just seen.  Now a wave walks
+// `tpw` tokens (the four waves of a workgroup on four consecutive rows at a time, as before), adds each token's three column terms -- summed over the modes in
+// registers, one float4 column group at a time -- into its own [3][F] LDS vectors (a lane only ever touches its own slots: no atomics, a fixed order), and at the
+// end the workgroup adds its four waves' vectors in wave order and writes ONE chunk of the column-reduction workspace; colreduce_stage2 finishes as before.
+template <int NV4, int MO, bool PG>
 __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ lnw,
                                                              const float* __restrict__ lnb, const float* __restrict__ wa, const float* __restrict__ stats,
                                                              float* __restrict__ dZ, float* __restrict__ dscore, int64_t R, int F,
-                                                             float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+                                                             float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase,
+                                                             float* __restrict__ pws, int tpw) {
     __shared__ float4 sw[NV4 * 64], sb[NV4 * 64], sa[NV4 * 64];
+    __shared__ float4 pacc[PG ? 4 * 3 * NV4 * 64 : 1];
     off += rbase ? *rbase : 0;              // device-side step base of the Philox stream (segx_set_rng_base): replayed graphs draw fresh masks
-    const int64_t row_id = SEGX_ROW_ID();
-    const bool live = row_id < R;                                    // wave-uniform; a dead wave of the last workgroup works on row R - 1 and stores nothing
-    const int64_t row = live ? row_id : R - 1;
     const int lane = threadIdx.x & 63, F4 = F >> 2;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     for (int idx = threadIdx.x; idx < NV4 * 64; idx += 256) {
@@ -622,6 +627,16 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
         sb[idx] = lnw ? reinterpret_cast<const float4*>(lnb)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
         sa[idx] = reinterpret_cast<const float4*>(wa)[c4];
     }
+    float4* const myacc = pacc + (PG ? (threadIdx.x >> 6) * 3 * NV4 * 64 : 0);
+    if (PG) {
+#pragma unroll
+        for (int i = 0; i < 3 * NV4; ++i) myacc[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+  for (int it = 0; it < tpw; ++it) {
+    const int64_t row_id = ((int64_t)blockIdx.x * tpw + it) * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    const bool live = row_id < R;                                    // wave-uniform; a dead wave of the last workgroup works on row R - 1 and stores nothing
+    const int64_t row = live ? row_id : R - 1;
     Row<NV4> g, z[MO];
     float mean[MO], rstd[MO], pr[MO], dp[MO];
 #pragma unroll
@@ -633,7 +648,6 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < NV4; ++i) { const int c4 = lane + 64 * i; z[m].v[i] = reinterpret_cast<const float4*>(Z + mr * F)[c4 < F4 ? c4 : F4 - 1]; }
     }
-    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     unsigned kbits[MO];
     // pass 1: z -> zhat = (z * keep - mean) * rstd in place (0 outside the row);  dp_m = dY . (zhat * w + b)
@@ -667,6 +681,29 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
     float dot = 0.f;
 #pragma unroll
     for (int m = 0; m < MO; ++m) dot += pr[m] * dp[m];
+    if (PG && live) {
+        // this token's terms of the three parameter gradients (z holds zhat, 0 outside the row; columns beyond F collect garbage that is never written out)
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) {
+            const int c4 = lane + 64 * i;
+            const float4 ww = sw[c4], bb = sb[c4], aa = sa[c4];
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0;
+#pragma unroll
+            for (int m = 0; m < MO; ++m) {
+                const float dsm = pr[m] * (dp[m] - dot);
+                const float4 zh = z[m].v[i];
+#define SEGX_PGT(E) { const float dzn = pr[m] * g.v[i].E + dsm * aa.E; t0.E += dzn * zh.E; t1.E += dzn; t2.E += dsm * (zh.E * ww.E + bb.E); }
+                SEGX_PGT(x) SEGX_PGT(y) SEGX_PGT(z) SEGX_PGT(w)
+#undef SEGX_PGT
+            }
+            float4 a0 = myacc[c4], a1 = myacc[NV4 * 64 + c4], a2 = myacc[2 * NV4 * 64 + c4];
+            SEGX_F4_OP(a0, a0.x + t0.x, a0.y + t0.y, a0.z + t0.z, a0.w + t0.w);
+            SEGX_F4_OP(a1, a1.x + t1.x, a1.y + t1.y, a1.z + t1.z, a1.w + t1.w);
+            SEGX_F4_OP(a2, a2.x + t2.x, a2.y + t2.y, a2.z + t2.z, a2.w + t2.w);
+            myacc[c4] = a0; myacc[NV4 * 64 + c4] = a1; myacc[2 * NV4 * 64 + c4] = a2;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // pass 2: per mode, dzn = pr*dY + ds*wa -> LN backward -> dropout backward
 #pragma unroll
     for (int m = 0; m < MO; ++m) {
@@ -696,6 +733,21 @@ __global__ __launch_bounds__(256) void modes_aggr_bwd_kernel(const float* __rest
         }
         if (live) row_store(d, dZ + mr * F, F);
         __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+    if (PG) {
+        __syncthreads();
+        const int64_t nchunks = gridDim.x;
+        for (int idx = threadIdx.x; idx < F4; idx += 256) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 v0 = pacc[(0 * 3 + k) * NV4 * 64 + idx], v1 = pacc[(1 * 3 + k) * NV4 * 64 + idx], v2 = pacc[(2 * 3 + k) * NV4 * 64 + idx],
+                             v3 = pacc[(3 * 3 + k) * NV4 * 64 + idx];
+                float4 o;
+                SEGX_F4_OP(o, ((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y, ((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w);
+                reinterpret_cast<float4*>(pws + ((int64_t)k * nchunks + blockIdx.x) * F)[idx] = o;
+            }
+        }
     }
 }
 
@@ -903,9 +955,34 @@ extern "C" int segx_modes_aggr_bwd(const float* dY, const float* Z, const float*
     SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dZ && dscore && R > 0, "segx_modes_aggr_bwd: bad args"); SEGX_ROWCHK(F);
     SEGX_REQUIRE(F <= 2048 || Mo == 1, "segx_modes_aggr_bwd: F=%d too wide for the register-resident 4-mode kernel", F);
     SEGX_DISPATCH_NV4(F, SEGX_DISPATCH_MO(Mo,
-        hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base()),
-        hipLaunchKernelGGL((modes_aggr_bwd_kernel<NV4, 1>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base())));
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4, false>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base(), (float*)nullptr, 1),
+        hipLaunchKernelGGL((modes_aggr_bwd_kernel<NV4, 1, false>), row_grid(R), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F, p, seed, offset, rng_base(), (float*)nullptr, 1)));
     return check_launch("segx_modes_aggr_bwd");
+}
+// tokens a wave walks in the fused form: four where that still leaves two rounds of workgroups on the chip, fewer for short token lists
+static inline int modes_aggr_tpw(int64_t R) { return R >= 4096 * 4 ? 4 : R >= 2048 * 2 ? 2 : 1; }
+static inline bool modes_aggr_fused_ok(int Mo, int F) { return Mo == 4 && F % 4 == 0 && F <= 2048; }
+extern "C" int64_t segx_modes_aggr_bwd_all_ws_floats(int Mo, int64_t R, int F) {
+    if (!modes_aggr_fused_ok(Mo, F)) return segx_colreduce_ws_floats(R, F, 3);
+    const int tpw = modes_aggr_tpw(R);
+    return 3 * ((R + 4 * tpw - 1) / (4 * tpw)) * (int64_t)F;
+}
+extern "C" int segx_modes_aggr_bwd_all(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
+                                       float* dZ, float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws, int Mo, int64_t R, int F,
+                                       float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && Z && (!lnw == !lnb) && wa && stats && dZ && dscore && dlnw && dlnb && dwa && ws && R > 0, "segx_modes_aggr_bwd_all: bad args"); SEGX_ROWCHK(F);
+    if (!modes_aggr_fused_ok(Mo, F)) {                      // one mode / wide rows: the two passes of before
+        int rc = segx_modes_aggr_bwd(dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, F, p, seed, offset, stream_);
+        if (rc) return rc;
+        return segx_modes_aggr_param_grad(dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa, ws, Mo, R, F, p, seed, offset, stream_);
+    }
+    const int tpw = modes_aggr_tpw(R);
+    const int64_t nch = (R + 4 * tpw - 1) / (4 * tpw);
+    SEGX_REQUIRE(nch < 2147483647LL, "segx_modes_aggr_bwd_all: too many rows");
+    SEGX_DISPATCH_NV4(F, hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4, true>), dim3((unsigned)nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F,
+                                            p, seed, offset, rng_base(), ws, tpw));
+    hipLaunchKernelGGL(colreduce_stage2, dim3((F + 63) / 64), dim3(256), 0, stream, (const float*)ws, dlnw, dlnb, dwa, (int64_t)F, (int)nch, 3);
+    return check_launch("segx_modes_aggr_bwd_all");
 }
 extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
                                           const float* dscore, float* dlnw, float* dlnb, float* dwa, float* ws, int Mo, int64_t R, int F,

@@ -436,6 +436,7 @@ def pos_embed(posn, Wp, bp):
 
 class _ModesAggr(torch.autograd.Function):
     """Z [Mo, R, F] -> LN(dropout(Z)) -> learned soft aggregation over modes -> [R, F]."""
+    one_pass = True           # backward: segx_modes_aggr_bwd_all (False: the two passes of rounds 1-5; tools/ab_switch.py compares them on one box)
 
     @staticmethod
     def forward(ctx, Z, lnw, lnb, wa, ba, drop_p):
@@ -460,10 +461,13 @@ class _ModesAggr(torch.autograd.Function):
         dY = _c(dY)
         dZ = torch.empty_like(Z)
         dscore = _empty(Z, Mo * R)
-        L.modes_aggr_bwd(dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
         dlnw, dlnb, dwa = _empty(Z, Fd), _empty(Z, Fd), _empty(Z, Fd)             # lnw None (no LayerNorm): dlnw / dlnb are scratch
-        L.modes_aggr_param_grad(dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa,
-                                _empty(Z, L.colreduce_ws(R, Fd, 3)), Mo, R, Fd, p, seed, off)
+        if _ModesAggr.one_pass:
+            # one pass over Z and dY for dZ, dscore and the three parameter gradients (r06; the separate parameter-gradient pass re-read both and regenerated the mask)
+            L.modes_aggr_bwd_all(dY, Z, lnw, lnb, wa, stats, dZ, dscore, dlnw, dlnb, dwa, _empty(Z, L.modes_aggr_bwd_all_ws(Mo, R, Fd)), Mo, R, Fd, p, seed, off)
+        else:
+            L.modes_aggr_bwd(dY, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
+            L.modes_aggr_param_grad(dY, Z, lnw, lnb, wa, stats, dscore, dlnw, dlnb, dwa, _empty(Z, L.colreduce_ws(R, Fd, 3)), Mo, R, Fd, p, seed, off)
         dba = _empty(Z, 1)
         L.sum(dscore, Mo * R, dba, _empty(Z, 1024))
         if lnw is None:

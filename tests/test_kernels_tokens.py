@@ -227,6 +227,39 @@ def test_modes_aggr_fwd_bwd_param_grads(backend, Mo, R, Fd, p):
         close(dwa, war.grad, 1e-4)
     else:
         assert dwa.abs().max() < 1e-6 and dscore.abs().max() < 1e-6      # single mode: softmax == 1, zero grads
+    # the one-pass form (segx_modes_aggr_bwd_all: parameter-gradient terms collected inside the dZ kernel; one mode runs the two passes above)
+    dZ2 = torch.full_like(Z, float('nan')); ds2 = torch.full((Mo * R,), float('nan'))
+    g3 = [torch.full((Fd,), float('nan')) for _ in range(3)]
+    ws2 = torch.full((Lb.modes_aggr_bwd_all_ws(Mo, R, Fd),), float('nan'))
+    Lb.modes_aggr_bwd_all(G, Z, lnw, lnb, wa, stats, dZ2, ds2, g3[0], g3[1], g3[2], ws2, Mo, R, Fd, p, seed, off)
+    assert torch.equal(dZ2, dZ) and torch.equal(ds2, dscore)
+    close(g3[0], lnwr.grad, 1e-4); close(g3[1], lnbr.grad, 1e-4); close(g3[2], dwa, 1e-4 if Mo > 1 else 1.0)
+
+
+@pytest.mark.parametrize('R,Fd,lnorm', [(4096 + 6, 64, True), (16384 + 3, 32, True), (4099, 1792, False)])
+def test_modes_aggr_one_pass_backward_walks_several_tokens_per_wave(backend, R, Fd, lnorm):
+    """segx_modes_aggr_bwd_all with 2 / 4 tokens per wave (R >= 4096 / 16384), a ragged last workgroup, with and without the LayerNorm (lnw = NULL: the no-FFN
+    branch aggregates the raw mode features) -- against the two-pass form it replaces (same dZ bit for bit, the same column sums in another order)."""
+    Lb = backend.L
+    if backend.name == 'emu' and R * Fd > 300000:
+        pytest.skip('emulator: the long rows are covered by the short token list above')
+    Mo, p, seed, off = 4, 0.2, 5, 1024
+    Z = rnd(Mo, R, Fd, seed=41) * 1.5 + 0.2
+    lnw = (1 + 0.1 * rnd(Fd, seed=42)) if lnorm else None; lnb = 0.1 * rnd(Fd, seed=43) if lnorm else None
+    wa = 0.2 * rnd(Fd, seed=44); ba = torch.tensor([0.3])
+    Y = torch.empty(R, Fd); stats = torch.empty(3 * Mo * R)
+    Lb.modes_aggr_fwd(Z, lnw, lnb, wa, ba, Y, stats, Mo, R, Fd, EPS, p, seed, off)
+    G = rnd(R, Fd, seed=45)
+    dZ = torch.empty_like(Z); dscore = torch.empty(Mo * R)
+    Lb.modes_aggr_bwd(G, Z, lnw, lnb, wa, stats, dZ, dscore, Mo, R, Fd, p, seed, off)
+    ref = [torch.empty(Fd) for _ in range(3)]
+    Lb.modes_aggr_param_grad(G, Z, lnw, lnb, wa, stats, dscore, ref[0], ref[1], ref[2], torch.empty(Lb.colreduce_ws(R, Fd, 3)), Mo, R, Fd, p, seed, off)
+    dZ2 = torch.full_like(Z, float('nan')); ds2 = torch.full((Mo * R,), float('nan'))
+    got = [torch.full((Fd,), float('nan')) for _ in range(3)]
+    Lb.modes_aggr_bwd_all(G, Z, lnw, lnb, wa, stats, dZ2, ds2, got[0], got[1], got[2], torch.full((Lb.modes_aggr_bwd_all_ws(Mo, R, Fd),), float('nan')), Mo, R, Fd, p, seed, off)
+    assert torch.equal(dZ2, dZ) and torch.equal(ds2, dscore)
+    for a, b in zip(got, ref):
+        close(a, b, 2e-4)
 
 
 def test_gelu_bwd(backend):
