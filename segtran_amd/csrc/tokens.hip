@@ -832,6 +832,32 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     }
 }
 
+// The same with the COLUMN SUMS of dT collected on the way (r06): dT [rows, N] is the output gradient of the nn.Linear in front of the GELU (MMSharedMid :244), its
+// column sums are that layer's bias gradient -- which used to be a pass of its own over the 0.7 GB this kernel has just written (colreduce_stage1_v4, 0.41 ms of the
+// cfg2 step).  thread = four adjacent columns, block.y = a chunk of rows (the layout of colreduce_stage1_v4: same chunk partials, same second stage).
+__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const float* __restrict__ dH, const float* __restrict__ T, float* __restrict__ dT, float* __restrict__ ws,
+                                                              int64_t rows, int N, int nchunks, float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    off += rbase ? *rbase : 0;
+    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
+    const int chunk = blockIdx.y;
+    const int64_t per = (rows + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(rows, r0 + per);
+    if (c >= N) return;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int64_t r = r0; r < r1; ++r) {
+        const int64_t e = r * N + c;
+        const float4 g = *reinterpret_cast<const float4*>(dH + e), t = *reinterpret_cast<const float4*>(T + e);
+        float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (p > 0.f) k = f4_keep(seed, off, (uint64_t)e, p, ik);
+        float4 o;
+        SEGX_F4_OP(o, g.x * k.x * gelu_erf_grad(t.x), g.y * k.y * gelu_erf_grad(t.y), g.z * k.z * gelu_erf_grad(t.z), g.w * k.w * gelu_erf_grad(t.w));
+        *reinterpret_cast<float4*>(dT + e) = o;
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    *reinterpret_cast<float4*>(ws + (int64_t)chunk * N + c) = s;
+}
+
 }  // namespace segx
 
 using namespace segx;
@@ -1001,6 +1027,16 @@ extern "C" int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t
     const int nb = (int)i64min(4096, (n / 4 + 255) / 256);
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset, rng_base());
     return check_launch("segx_gelu_bwd");
+}
+extern "C" int segx_gelu_bwd_colsum(const float* dH, const float* T, float* dT, float* colsum, float* ws, int64_t rows, int N, float p, uint64_t seed, uint64_t offset,
+                                    void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dH && T && dT && colsum && ws && rows > 0 && N > 0 && N % 4 == 0 && offset % 4 == 0, "segx_gelu_bwd_colsum: rows=%lld N=%d offset=%llu (N, offset: multiples of 4)",
+                              (long long)rows, N, (unsigned long long)offset);
+    SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(dH) | reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(dT) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0, "segx_gelu_bwd_colsum: 16-byte alignment");
+    const int nch = chunks_for(rows);
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)((N / 4 + 255) / 256), nch), dim3(256), 0, stream, dH, T, dT, ws, rows, N, nch, p, seed, offset, rng_base());
+    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, (const float*)ws, colsum, (float*)nullptr, (float*)nullptr, (int64_t)N, nch, 1);
+    return check_launch("segx_gelu_bwd_colsum");
 }
 /* geom = {D, H, W, R, nd}: token grid (D = 1 in 2-D), radius, position dims */
 extern "C" int segx_posbias_fwd(const float* S, float* out, const float* table, int64_t nmat, int N, const int* geom, float weight, float clip,

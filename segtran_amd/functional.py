@@ -173,15 +173,22 @@ class _BGemm(torch.autograd.Function):
         if dC is None:                                       # only the alias was used
             return None, dB_alias, None, None, None, None, None, None
         dC = _c(dC)
+        dbias = None
         if ctx.gelu:
             p, seed, off = ctx.drop
             dT = torch.empty_like(dC)
-            L.gelu_bwd(dC, T, dT, dC.numel(), p, seed, off)
+            if (ctx.has_bias and ctx.needs_input_grad[2] and s.bias_mode == BIAS_N and s.bias_b0 == 0 and (s.nb[1] == 1 or s.bias_b1 == 0) and s.c[2] == s.N
+                    and s.N % 4 == 0 and off % 4 == 0 and dC.data_ptr() % 16 == 0 and T.data_ptr() % 16 == 0):
+                # the bias gradient (column sums of dT over every row of every batch member) from the pass that writes dT (r06: it was a pass of its own over dT)
+                rows = dC.numel() // s.N
+                dbias = _empty(dC, s.N)
+                L.gelu_bwd_colsum(dC, T, dT, dbias, _empty(dC, L.colreduce_ws(rows, s.N, 1)), rows, s.N, p, seed, off)
+            else:
+                L.gelu_bwd(dC, T, dT, dC.numel(), p, seed, off)
             dC = dT
         dA = _grad_operand(L, dC, B, s, 'a', A) if ctx.needs_input_grad[0] else None
         dB = _grad_operand(L, dC, A, s, 'b', B, resid=_c(dB_alias) if dB_alias is not None else None) if ctx.needs_input_grad[1] else None
-        dbias = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if dbias is None and ctx.has_bias and ctx.needs_input_grad[2]:
             dbias = _bias_grad(L, dC, s)
         return dA, dB, dbias, None, None, None, None, None
 

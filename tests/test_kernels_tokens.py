@@ -273,6 +273,19 @@ def test_gelu_bwd(backend):
     close(dT, Tr.grad, 1e-5)
 
 
+@pytest.mark.parametrize('rows,N,p', [(50, 36, 0.0), (2051, 64, 0.3), (300, 1792, 0.2)])
+def test_gelu_bwd_with_the_bias_gradient_from_the_same_pass(backend, rows, N, p):
+    """segx_gelu_bwd_colsum: dT bit-identical to segx_gelu_bwd (same mask stream), its column sums = the bias gradient of the linear layer in front of the GELU."""
+    Lb = backend.L
+    T = rnd(rows, N, seed=34) * 2; G = rnd(rows, N, seed=35)
+    ref = torch.empty_like(T)
+    Lb.gelu_bwd(G, T, ref, T.numel(), p, 7, 64)
+    dT = torch.full_like(T, float('nan')); cs = torch.full((N,), float('nan'))
+    Lb.gelu_bwd_colsum(G, T, dT, cs, torch.full((Lb.colreduce_ws(rows, N, 1),), float('nan')), rows, N, p, 7, 64)
+    assert torch.equal(dT, ref)
+    close(cs, ref.double().sum(0).float(), 2e-5)
+
+
 @pytest.mark.parametrize('engine', ['f32', 'x6'])
 @pytest.mark.parametrize('Fd,offset', [(36, 8), (36, 12), (35, 8), (64, 4096)])
 def test_gemm_gelu_dropout_mask_equals_gelu_bwd_mask(backend, engine, Fd, offset):
