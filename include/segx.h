@@ -501,6 +501,13 @@ int segx_stem_compose_bwd(const float* dWc, const float* Ws, const float* Wb, co
                           int O, int C3, int Cb, int Cc, int T, void* stream);
 /* x [B][Cb][H][W][D] -> y [B][Cc][D][H][W]: depth moved in front (segtran3d.py:422), channel Cb = 1, channels above it = 0 */
 int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc, int H, int W, int D, void* stream);
+/* The dense 3 x 3 stem of EfficientNet (efficientnet/model.py:128, 163: Conv2dStaticSamePadding(3, c0, 3, stride) on the up-sized image) as a direct convolution:
+ * X [B, 3, H, W], W [Cout, 3, 3, 3], Y [B, Cout, OH, OW], zero padding pt rows on top / pl columns on the left (the rest of the window falls off the far edges).
+ * _im2col: Xcol [B, rows, OH * OW] (rows >= 27; rows beyond 27 are zero) -- the window matrix the weight gradient contracts with dY as a batch-reduced skinny GEMM
+ * (segx_gemm_f32 with batch_reduce; SEGX_TILE_SKINNY_NT).  Cin = 3, K = 3, stride 1 or 2 only. */
+int segx_conv2d_stem_fwd(const float* X, const float* W, float* Y, int B, int Cin, int Cout, int H, int Wd, int OH, int OW, int K, int stride, int pt, int pl,
+                         void* stream);
+int segx_conv2d_stem_im2col(const float* X, float* Xcol, int B, int Cin, int H, int Wd, int OH, int OW, int K, int stride, int pt, int pl, int rows, void* stream);
 /* foreground-token mask (get_mask, segtran2d.py:229-233 / segtran3d.py:266-270): out[b][cell] = (sum_c avgpool_{kd,kh,kw}(|x|) > 0) as 0/1 floats */
 /* r05: get_mask(in_bridge_to3(batch)) of segtran3d.py:420-425 without materialising the bridged image: X = the raw batch [B][Cb][H][W][D], Wb [C3][Cb] / bb [C3]
  * (NULL: no bias) = the 1x1x1 bridge convolution; out [B][D/kd][H/kh][W/kw] (the permuted (D, H, W) order the network works in) */

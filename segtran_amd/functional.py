@@ -1821,10 +1821,48 @@ def maxpool3d_same(x, kernel, stride, pass_input=False):
     return (y, x) if pass_input else y
 
 
+class _ConvStem2d(torch.autograd.Function):
+    """The 3 -> c0 channel 3 x 3 stem on an input that needs no gradient (stem2d.hip): direct forward; dW = sum_b dY_b Xcol_b^T with the window matrix Xcol written
+    once in backward (28 rows: 27 taps + a zero row) and contracted by the streaming skinny weight-gradient kernel."""
+    ROWS = 28
+    enabled = True            # False: the implicit-GEMM path of rounds 1-5 (tools/ab_switch.py compares them on one box)
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        L = segx.lib()
+        x, w = _c(x), _c(w)
+        B, Cin, H, W = x.shape
+        Cout, _, K, _ = w.shape
+        pl, pr, pt, pb = pad
+        OH, OW = (H + pt + pb - K) // stride + 1, (W + pl + pr - K) // stride + 1
+        y = _empty(x, B, Cout, OH, OW)
+        L.conv2d_stem_fwd(x, w, y, B, Cin, Cout, H, W, OH, OW, K, stride, pt, pl)
+        ctx.cfg = (B, Cin, Cout, H, W, OH, OW, K, stride, pt, pl)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = segx.lib()
+        (x,) = ctx.saved_tensors
+        B, Cin, Cout, H, W, OH, OW, K, stride, pt, pl = ctx.cfg
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        dy = _c(dy)
+        P, R = OH * OW, _ConvStem2d.ROWS
+        xcol = _empty(x, B, R, P)
+        L.conv2d_stem_im2col(x, xcol, B, Cin, H, W, OH, OW, K, stride, pt, pl, R)
+        dwr = _empty(x, Cout, R)
+        _run_gemm(L, dy, xcol, dwr, Cout, R, P, (Cout * P, 0, P, 1), (R * P, 0, P, 1), (0, 0, R), (B, 1), 1.0, batch_reduce=True)
+        return None, dwr[:, :Cin * K * K].reshape(Cout, Cin, K, K), None, None
+
+
 def conv2d_dense(x, w, stride, pad):
-    """Dense k x k 2-D convolution (only the EfficientNet stem) on the implicit-GEMM engine: a 3-D convolution with depth 1.
-    pad = (left, right, top, bottom) zero padding."""
+    """Dense k x k 2-D convolution (only the EfficientNet stem).  pad = (left, right, top, bottom) zero padding.  The stem proper -- 3 input channels, 3 x 3, an input
+    without gradient -- runs as a direct convolution (_ConvStem2d); anything else on the implicit-GEMM engine as a 3-D convolution with depth 1."""
     s = int(stride)
+    if _ConvStem2d.enabled and x.dim() == 4 and x.shape[1] == 3 and tuple(w.shape[1:]) == (3, 3, 3) and s in (1, 2) and not x.requires_grad and x.shape[0] <= 65535:
+        return _ConvStem2d.apply(x, w, s, tuple(int(v) for v in pad))
     return _Conv3d.apply(x.unsqueeze(2), w.unsqueeze(2), (1, s, s), ((0, 0), (int(pad[2]), int(pad[3])), (int(pad[0]), int(pad[1])))).squeeze(2)
 
 

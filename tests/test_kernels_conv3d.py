@@ -189,17 +189,25 @@ def test_conv3d_forward_split_k(backend, Cout, k):
     assert L.conv3d_splitk(B, Cout, geom, False) >= 1 and L.conv3d_splitk(4, 192, (832, 3, 14, 14, 3, 14, 14, 3, 3, 3, 1, 1, 1, 1, 1, 1), False) > 1
 
 
-def test_stem_conv2d_on_implicit_gemm(backend):
-    """EfficientNet stem: dense 3x3, 3 -> 48 channels, stride 1, static pad (1,1,1,1); input needs no gradient."""
-    x = rnd(2, 3, 20, 24, seed=6)
-    w = (rnd(48, 3, 3, 3, seed=7) * 0.3).requires_grad_(True)
-    y = SF.conv2d_dense(x, w, 1, (1, 1, 1, 1))
+@pytest.mark.parametrize('B,H,W,stride,pad,Cout,xgrad', [(2, 20, 24, 1, (1, 1, 1, 1), 48, False), (2, 32, 32, 2, (0, 1, 0, 1), 48, False), (3, 17, 19, 2, (1, 1, 1, 1), 24, False),
+                                                         (1, 64, 128, 2, (0, 1, 0, 1), 48, False), (2, 20, 24, 1, (1, 1, 1, 1), 48, True)])
+def test_stem_conv2d_direct_and_on_implicit_gemm(backend, B, H, W, stride, pad, Cout, xgrad):
+    """EfficientNet stem (efficientnet/model.py:128, 163): dense 3 x 3, 3 -> c0 channels, stride 1 / 2, static TF-'same' pads.  An input without gradient takes the direct
+    kernels of stem2d.hip (forward; dW through the im2col matrix and the batch-reduced skinny GEMM), one with gradient the implicit-GEMM path (xgrad)."""
+    x = rnd(B, 3, H, W, seed=6).requires_grad_(xgrad)
+    w = (rnd(Cout, 3, 3, 3, seed=7) * 0.3).requires_grad_(True)
+    y = SF.conv2d_dense(x, w, stride, pad)
+    assert (type(y.grad_fn).__name__ == '_ConvStem2dBackward') == (not xgrad)
     wr = w.detach().clone().requires_grad_(True)
-    yr = F.conv2d(F.pad(x, (1, 1, 1, 1)), wr)
+    xr = x.detach().clone().requires_grad_(xgrad)
+    yr = F.conv2d(F.pad(xr, pad), wr, stride=stride)
+    assert y.shape == yr.shape
     close(y, yr.detach())
     G = rnd(*y.shape, seed=8)
     y.backward(G); yr.backward(G)
     close(w.grad, wr.grad, 1e-4)
+    if xgrad:
+        close(x.grad, xr.grad, 1e-4)
 
 
 @pytest.mark.parametrize('size,k,stride,cin', [((8, 10, 12), (7, 7, 7), (2, 2, 2), 3), ((7, 9, 11), (3, 3, 3), (2, 2, 2), 2),

@@ -137,6 +137,8 @@ def test_gemm_skinny_weight_gradient_streams(backend, nb, M, N, K):
     fp64, and against the tile kernels' split-K slabs (knob 18 = 0) which it replaces.  A persistent grid of 8 (knob 9) keeps the emulator run short and makes every
     workgroup cross a batch-member boundary or end inside one."""
     L = backend.L
+    if backend.name == 'emu' and (M, N) in ((32, 192), (24, 24), (56, 32), (100, 7)):
+        pytest.skip('emulator: one shape per block arrangement is enough (6 x 1, 5 x 1, 1 x 2, 1 x 5, 4 x 1); the device runs all nine')
     g = torch.Generator(device='cpu').manual_seed(11 + M + N)
     A = torch.randn(nb[0], nb[1], M, K, generator=g, device='cpu').to(backend.dev)
     B = torch.randn(nb[0], nb[1], N, K, generator=g, device='cpu').to(backend.dev)
