@@ -69,6 +69,15 @@ def _grad_operand(L, dC, other, s, which, like, resid=None):
     bcast = [(st[i] == 0 and nb[i] > 1) for i in (0, 1)]
     assert resid is None or (not any(bcast) and like.is_contiguous() and resid.is_contiguous() and resid.shape == like.shape)
     partial = any(bcast) and not all(bcast[i] or nb[i] == 1 for i in (0, 1))
+    if (partial and which == 'a' and bcast == [False, True] and st[3] == 1 and like.is_contiguous() and resid is None
+            and s.c[1] == s.N and s.c[2] >= nb[1] * s.N and ost[1] == s.N * ost[2] and (ost[2] == 1 or ost[3] == 1)):
+        # A is shared by the INNER batch dim (the modes) and both dC and B interleave that dim with the contraction index n -- dC rows are [nb1 * N] long, B's
+        # (z1, n) walk is one stride -- so the sum over the modes is part of ONE contraction of depth nb1 * N per outer member:
+        #   dA[z0](m, k) = alpha sum_{(z1, n)} dC[z0](m, (z1, n)) B[z0]((z1, n), k)
+        # instead of nb1 short-K products written as slabs and summed by a further pass (r06: squeeze-out scores GEMM, 4 x K = 256 -> K = 1024; 0.7 GB of slabs gone)
+        out = torch.empty_like(like)
+        _run_gemm(L, dC, other, out, rows, cols, nb[1] * s.N, (s.c[0], 0, s.c[2], 1), (ost[0], 0, ost[3], ost[2]), (st[0], 0, st[2]), (nb[0], 1), s.alpha)
+        return out
     if partial:
         # shared across ONE batch dim while the other one walks it (attractors shared by the batch, split into modes: Polyformer's
         # in-squeeze): one slab in the operand's own layout per broadcast index, then a deterministic sum over the slabs
@@ -214,7 +223,7 @@ def _take_plane_sums(dC, nbt, M, N):
 def _bias_grad(L, dC, s):
     """Only the layouts the model uses: C contiguous [nb0, nb1, M, N] (or [M, N])."""
     nb0, nb1 = s.nb
-    assert s.c[2] == s.N, 'bias grad needs contiguous C rows'
+    assert s.c[2] == s.N or (s.bias_mode == BIAS_N and s.bias_b0 != 0), 'bias grad needs contiguous C rows'
     if s.bias_mode == BIAS_N and s.bias_b0 != 0:
         # one bias vector per (z0, z1), stored [nb0, nb1, N]: column sums of every C slab as ONE GEMM with a row of ones
         assert s.bias_b0 == nb1 * s.N and s.bias_b1 == s.N

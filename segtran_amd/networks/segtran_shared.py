@@ -218,8 +218,8 @@ class ExpandedFeatTrans(nn.Module):
             parts.append(SF.interp_tokens(fused, shapes[s_], out_shape=geoshape).view(B, U, M, fs))            # :439
         return torch.cat(parts, dim=-1).permute(2, 0, 1, 3).contiguous()                                       # :443
 
-    def forward(self, input_feat, attention_probs, in_geoshape=None, value_last=False):
-        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] (mince: a list, one per scale) -> [B, U1, F].
+    def forward(self, input_feat, attention_probs, in_geoshape=None, value_last=False, modes_interleaved=False):
+        """input_feat [B, U2, IF]; attention_probs MODE-MAJOR [M, B, U1, U2] (mince: a list, one per scale; modes_interleaved: [B, U1, M, U2]) -> [B, U1, F].
         value_last (one mode, bias-free value projection): fuse first, project after -- (P X) Wv^T instead of P (X Wv^T); the
         projection then runs over the U1 fused rows instead of the U2 input tokens (see CrossAttFeatTrans.forward)."""
         B, U2, IF = input_feat.shape
@@ -240,8 +240,9 @@ class ExpandedFeatTrans(nn.Module):
             U1 = U2
             fused = self._fuse_mince(v, attention_probs, tuple(int(g) for g in in_geoshape))
         else:
-            U1 = attention_probs.shape[2]
-            fuse_spec = GemmSpec(U1, Fd, U2, (U1 * U2, B * U1 * U2, U2, 1), (U2 * M * Fd, Fd, 1, M * Fd),
+            U1 = attention_probs.shape[1] if modes_interleaved else attention_probs.shape[2]
+            p_strides = (U1 * M * U2, U2, M * U2, 1) if modes_interleaved else (U1 * U2, B * U1 * U2, U2, 1)
+            fuse_spec = GemmSpec(U1, Fd, U2, p_strides, (U2 * M * Fd, Fd, 1, M * Fd),
                                  (U1 * Fd, B * U1 * Fd, Fd), (M, B, U1, Fd), nb=(B, M))
             if self.has_FFN and U2 < U1 and CrossAttFeatTrans.reassociate_projections and B * U1 >= CrossAttFeatTrans.reassociate_min_rows:
                 # Squeeze-out layer: U1 tokens gather from U2 << U1 attractors, then MMSharedMid (:232-251) applies one [F, F]
@@ -288,6 +289,7 @@ class ExpandedFeatTrans(nn.Module):
 class CrossAttFeatTrans(nn.Module):
     """Multi-mode cross attention (reference :478-610)."""
     reassociate_projections = True        # False: the reference's op order everywhere (key/value projections over all tokens)
+    interleave_modes = True               # squeeze-out (re-associated): scores / probs as [B, U1, M, U2] (False: mode-major [M, B, U1, U2], rounds 1-5; tools/ab_switch.py)
     reassociate_min_rows = 4096           # below this many token rows (batch x tokens) the step is launch-bound: keep the op order
 
     def __init__(self, config, name):
@@ -369,12 +371,26 @@ class CrossAttFeatTrans(nn.Module):
             # cost 2 C^2 U2 + 2 U1 U2 C M instead of 2 U1 C^2 + 2 U1 U2 C per sample (the test above; cfg2: 100 vs 180 GFLOP).
             alpha = 1.0 / math.sqrt(d)
             wq, bq = self.query.weight, self.query.bias
-            G = SF.bgemm(wq, k, GemmSpec(C, U2, d, (0, d * C, 1, C), (U2 * M * d, d, M * d, 1), (M * C * U2, C * U2, U2),
-                                         (B, M, C, U2), nb=(B, M), alpha=alpha))
             beta = None
             if bq is not None:
                 beta = SF.bgemm(bq, k, GemmSpec(1, U2, d, (0, d, d, 1), (U2 * M * d, d, M * d, 1), (M * U2, U2, U2),
                                                 (B, M, U2), nb=(B, M), alpha=alpha))
+            if self.interleave_modes and U2 % 4 == 0:
+                # r06: G [B, C, M, U2] and scores / probs [B, U1, M, U2] -- the modes interleaved with the attractor index, so that a token's M score rows are ONE
+                # row of M U2 entries.  Forward is the same M products per sample (other strides, same operands); in backward the token gradient
+                # dX = sum_m dS_m G_m^T becomes ONE contraction of depth M U2 (= 1024) per sample instead of M short ones (K = 256: epilogue-bound, §5i)
+                # written as 0.7 GB of slabs and summed by a further pass (SF._grad_operand).  ExpandedFeatTrans reads the interleaved probabilities in place.
+                G = SF.bgemm(wq, k, GemmSpec(C, U2, d, (0, d * C, 1, C), (U2 * M * d, d, M * d, 1), (C * M * U2, U2, M * U2),
+                                             (B, C, M, U2), nb=(B, M), alpha=alpha))
+                scores = SF.bgemm(in_query, G, GemmSpec(U1, U2, C, (U1 * C, 0, C, 1), (C * M * U2, U2, 1, M * U2),
+                                                        (U1 * M * U2, U2, M * U2), (B, U1, M, U2), nb=(B, M),
+                                                        bias_mode=SF.BIAS_N, bias_b0=M * U2, bias_b1=U2), bias=beta, gmax=gmax)
+                self.attn_max_dev = gmax
+                probs = SF.softmax(scores, self.attn_clip, gmax, drop)
+                self.attention_scores = scores.permute(2, 0, 1, 3) if self.keep_attn_scores else None
+                return self.out_trans(in_key, probs, modes_interleaved=True)
+            G = SF.bgemm(wq, k, GemmSpec(C, U2, d, (0, d * C, 1, C), (U2 * M * d, d, M * d, 1), (M * C * U2, C * U2, U2),
+                                         (B, M, C, U2), nb=(B, M), alpha=alpha))
             scores = SF.bgemm(in_query, G, GemmSpec(U1, U2, C, (U1 * C, 0, C, 1), (M * C * U2, C * U2, 1, U2),
                                                     (U1 * U2, B * U1 * U2, U2), (M, B, U1, U2), nb=(B, M),
                                                     bias_mode=SF.BIAS_N, bias_b0=M * U2, bias_b1=U2), bias=beta, gmax=gmax)
