@@ -169,7 +169,8 @@ int segx_modes_aggr_bwd_all(const float* dY, const float* Z, const float* lnw, c
 /* backward of the GELU(+dropout) epilogue of segx_gemm_f32 (MMSharedMid :244-245): dT = dH * keep * gelu'(T) */
 int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t n, float p, uint64_t seed, uint64_t offset, void* stream);
 /* the same for dH, T, dT [rows, N] with colsum[n] = sum_r dT[r][n] from the same pass -- the bias gradient of the nn.Linear in front of the GELU (MMSharedMid :244), which
- * autograd would take from a second pass over dT.  N % 4 == 0, offset % 4 == 0, 16-byte aligned; ws: segx_colreduce_ws_floats(rows, N, 1) floats. */
+ * autograd would take from a second pass over dT.  N % 4 == 0, N <= 2048, offset % 4 == 0, 16-byte aligned; ws: segx_gelu_bwd_colsum_ws_floats(rows, N) floats. */
+int64_t segx_gelu_bwd_colsum_ws_floats(int64_t rows, int N);
 int segx_gelu_bwd_colsum(const float* dH, const float* T, float* dT, float* colsum, float* ws, int64_t rows, int N, float p, uint64_t seed, uint64_t offset,
                          void* stream);
 

@@ -835,11 +835,14 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
 // The same with the COLUMN SUMS of dT collected on the way (r06): dT [rows, N] is the output gradient of the nn.Linear in front of the GELU (MMSharedMid :244), its
 // column sums are that layer's bias gradient -- which used to be a pass of its own over the 0.7 GB this kernel has just written (colreduce_stage1_v4, 0.41 ms of the
 // cfg2 step).  thread = four adjacent columns, block.y = a chunk of rows (the layout of colreduce_stage1_v4: same chunk partials, same second stage).
-__global__ __launch_bounds__(256) void gelu_bwd_colsum_kernel(const float* __restrict__ dH, const float* __restrict__ T, float* __restrict__ dT, float* __restrict__ ws,
+__global__ __launch_bounds__(512) void gelu_bwd_colsum_kernel(const float* __restrict__ dH, const float* __restrict__ T, float* __restrict__ dT, float* __restrict__ ws,
                                                               int64_t rows, int N, int nchunks, float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    // a workgroup covers WHOLE rows (N / 4 <= 512 threads, one float4 column group each) of a contiguous chunk of rows: it streams one contiguous piece of
+    // dH / T / dT like the flat kernel does (the first form -- 256 threads x 4 columns, rows 7 KB apart -- moved the same bytes at 4.7 TB/s against the flat
+    // kernel's 7.9: r06_v)
     off += rbase ? *rbase : 0;
-    const int c = 4 * (blockIdx.x * 256 + threadIdx.x);
-    const int chunk = blockIdx.y;
+    const int c = 4 * threadIdx.x;
+    const int chunk = blockIdx.x;
     const int64_t per = (rows + nchunks - 1) / nchunks, r0 = chunk * per, r1 = i64min(rows, r0 + per);
     if (c >= N) return;
     const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
@@ -1028,13 +1031,16 @@ extern "C" int segx_gelu_bwd(const float* dH, const float* T, float* dT, int64_t
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(nb), dim3(256), 0, stream, dH, T, dT, n / 4, p, seed, offset, rng_base());
     return check_launch("segx_gelu_bwd");
 }
+static inline int gelu_colsum_chunks(int64_t rows) { return (int)i64max(1, i64min(2048, rows / 16)); }
+extern "C" int64_t segx_gelu_bwd_colsum_ws_floats(int64_t rows, int N) { return (int64_t)gelu_colsum_chunks(rows) * N; }
 extern "C" int segx_gelu_bwd_colsum(const float* dH, const float* T, float* dT, float* colsum, float* ws, int64_t rows, int N, float p, uint64_t seed, uint64_t offset,
                                     void* stream_) {
-    SEGX_STREAM; SEGX_REQUIRE(dH && T && dT && colsum && ws && rows > 0 && N > 0 && N % 4 == 0 && offset % 4 == 0, "segx_gelu_bwd_colsum: rows=%lld N=%d offset=%llu (N, offset: multiples of 4)",
-                              (long long)rows, N, (unsigned long long)offset);
+    SEGX_STREAM; SEGX_REQUIRE(dH && T && dT && colsum && ws && rows > 0 && N > 0 && N % 4 == 0 && N <= 2048 && offset % 4 == 0,
+                              "segx_gelu_bwd_colsum: rows=%lld N=%d offset=%llu (N <= 2048; N, offset: multiples of 4)", (long long)rows, N, (unsigned long long)offset);
     SEGX_REQUIRE(((reinterpret_cast<uintptr_t>(dH) | reinterpret_cast<uintptr_t>(T) | reinterpret_cast<uintptr_t>(dT) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0, "segx_gelu_bwd_colsum: 16-byte alignment");
-    const int nch = chunks_for(rows);
-    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)((N / 4 + 255) / 256), nch), dim3(256), 0, stream, dH, T, dT, ws, rows, N, nch, p, seed, offset, rng_base());
+    const int nch = gelu_colsum_chunks(rows);
+    const int threads = ((N / 4 + 63) / 64) * 64;
+    hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)nch), dim3(threads), 0, stream, dH, T, dT, ws, rows, N, nch, p, seed, offset, rng_base());
     hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, (const float*)ws, colsum, (float*)nullptr, (float*)nullptr, (int64_t)N, nch, 1);
     return check_launch("segx_gelu_bwd_colsum");
 }

@@ -149,6 +149,7 @@ class _BGemm(torch.autograd.Function):
     """pass_b: also return the B operand as a second output (an alias).  A caller that needs B twice -- the input of an MBConv block feeds the
     expansion convolution AND the skip connection -- uses the alias for the second consumer: autograd then hands BOTH gradients to this node,
     and the second one is added inside the dB GEMM (segx_gemm_desc.resid) instead of by a separate accumulation kernel."""
+    gelu_bias_fused = True    # GELU epilogue: the bias gradient from the pass that writes dT (segx_gelu_bwd_colsum); False: gelu_bwd + a column-sum pass (tools/ab_switch.py)
 
     @staticmethod
     def forward(ctx, A, B, bias, spec, gmax, gelu, drop_p, pass_b=False):
@@ -187,11 +188,11 @@ class _BGemm(torch.autograd.Function):
             p, seed, off = ctx.drop
             dT = torch.empty_like(dC)
             if (ctx.has_bias and ctx.needs_input_grad[2] and s.bias_mode == BIAS_N and s.bias_b0 == 0 and (s.nb[1] == 1 or s.bias_b1 == 0) and s.c[2] == s.N
-                    and s.N % 4 == 0 and off % 4 == 0 and dC.data_ptr() % 16 == 0 and T.data_ptr() % 16 == 0):
+                    and s.N % 4 == 0 and s.N <= 2048 and _BGemm.gelu_bias_fused and off % 4 == 0 and dC.data_ptr() % 16 == 0 and T.data_ptr() % 16 == 0):
                 # the bias gradient (column sums of dT over every row of every batch member) from the pass that writes dT (r06: it was a pass of its own over dT)
                 rows = dC.numel() // s.N
                 dbias = _empty(dC, s.N)
-                L.gelu_bwd_colsum(dC, T, dT, dbias, _empty(dC, L.colreduce_ws(rows, s.N, 1)), rows, s.N, p, seed, off)
+                L.gelu_bwd_colsum(dC, T, dT, dbias, _empty(dC, L.gelu_bwd_colsum_ws(rows, s.N)), rows, s.N, p, seed, off)
             else:
                 L.gelu_bwd(dC, T, dT, dC.numel(), p, seed, off)
             dC = dT

@@ -273,6 +273,9 @@ class SegxLib:
     def modes_aggr_bwd_all(self, dY, Z, lnw, lnb, wa, stats, dZ, dscore, dlnw, dlnb, dwa, ws, Mo, R, F, p, seed, offset):
         self._call('segx_modes_aggr_bwd_all', Z, dY, Z, lnw, lnb, wa, stats, dZ, dscore, dlnw, dlnb, dwa, ws, Mo, R, F, p, seed, offset)
 
+    def gelu_bwd_colsum_ws(self, rows, N):
+        return int(self.c.segx_gelu_bwd_colsum_ws_floats(rows, N))
+
     def gelu_bwd_colsum(self, dH, T, dT, colsum, ws, rows, N, p, seed, offset):
         self._call('segx_gelu_bwd_colsum', dH, dH, T, dT, colsum, ws, rows, N, p, seed, offset)
 
@@ -624,7 +627,7 @@ _SIGS = {
     'segx_posembed_fwd': 'pppppliifp', 'segx_posembed_bwd': 'ppppppliip',
     'segx_modes_aggr_fwd': 'pppppppiliffuup', 'segx_modes_aggr_bwd': 'ppppppppilifuup',
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',
-    'segx_gelu_bwd_colsum': 'ppppplifuup', 'segx_modes_aggr_bwd_all_ws_floats': 'ili', 'segx_modes_aggr_bwd_all': 'ppppppppppppilifuup',
+    'segx_gelu_bwd_colsum': 'ppppplifuup', 'segx_gelu_bwd_colsum_ws_floats': 'li', 'segx_modes_aggr_bwd_all_ws_floats': 'ili', 'segx_modes_aggr_bwd_all': 'ppppppppppppilifuup',
     'segx_loss_ws_floats': 'ii', 'segx_seg_loss_fwd': 'ppppppiilfp', 'segx_seg_loss_bwd': 'pppppppiilfp',
     'segx_mt_bertadam_step': 'pppppppppppiiiffffffpp', 'segx_mt_gather': 'pppppiiip',
     'segx_gn_ws_floats': 'iii', 'segx_groupnorm_fwd': 'pppppppiiilfp', 'segx_groupnorm_bwd': 'pppppppppiiilpp',

@@ -281,7 +281,7 @@ def test_gelu_bwd_with_the_bias_gradient_from_the_same_pass(backend, rows, N, p)
     ref = torch.empty_like(T)
     Lb.gelu_bwd(G, T, ref, T.numel(), p, 7, 64)
     dT = torch.full_like(T, float('nan')); cs = torch.full((N,), float('nan'))
-    Lb.gelu_bwd_colsum(G, T, dT, cs, torch.full((Lb.colreduce_ws(rows, N, 1),), float('nan')), rows, N, p, 7, 64)
+    Lb.gelu_bwd_colsum(G, T, dT, cs, torch.full((Lb.gelu_bwd_colsum_ws(rows, N),), float('nan')), rows, N, p, 7, 64)
     assert torch.equal(dT, ref)
     close(cs, ref.double().sum(0).float(), 2e-5)
 
