@@ -292,6 +292,12 @@ int segx_dwconv2d_bwd_data(const float* dY, const float* W, float* dX, int B, in
 /* partial weight gradients part[B * rows][C][k*k], rows = segx_dwconv2d_wgrad_rows(OH, OW) row strips per sample;
  * dW = segx_colsum over the B*rows rows (deterministic two-stage sum, no atomics) */
 int64_t segx_dwconv2d_wgrad_rows(int OH, int OW);
+/* Stride-1 'same' depthwise convolution (k = 3 / 5, pads (k - 1) / 2, rows of float4 multiples): the data gradient AND the weight-gradient partials from ONE pass over dY
+ * (efficientnet/model.py:100-104 in backward; segx_dwconv2d_bwd_data + segx_dwconv2d_bwd_weight read dY twice).  part: [B * rows][C][k * k] with rows = segx_dwconv2d_bwd_fused_rows(...)
+ * (0: shape not served -- use segx_dwconv2d_bwd_data + segx_dwconv2d_bwd_weight[_direct]); dW = segx_colsum(part) over its B * rows rows. */
+int64_t segx_dwconv2d_bwd_fused_rows(int H, int Wd, int OH, int OW, int k, int stride, int pad_t, int pad_l);
+int segx_dwconv2d_bwd_fused(const float* dY, const float* X, const float* W, float* dX, float* part, int B, int C, int H, int Wd, int OH, int OW,
+                            int k, int stride, int pad_t, int pad_l, void* stream);
 /* r04: the weight gradient dW [C][k*k] in ONE launch where a channel's B planes are one workgroup's work (B <= 8, <= 8192 outputs per plane, the float4
  * layout): returns 1 when done, 0 when the shape needs the two-stage form above (nothing launched), < 0 on error */
 int segx_dwconv2d_bwd_weight_direct(const float* dY, const float* X, float* dW, int B, int C, int H, int Wd, int OH, int OW, int k,

@@ -1012,6 +1012,92 @@ __global__ __launch_bounds__(512) void dwconv_wgrad4c_kernel(const float* __rest
     }
 }
 
+// ---- r06: stride-1 'same' depthwise backward, DATA AND WEIGHT gradient from one pass over dy ------------------------------------------------------
+//   dx[iy][ix]  = sum_{ky,kx} w[ky][kx]        dy[iy - ky + p][ix - kx + p]
+//   dw[ky][kx]  = sum_{iy,ix} x[iy][ix]        dy[iy - ky + p][ix - kx + p]          (p = (K - 1) / 2: both walk the SAME dy window of an input position)
+// The data-gradient kernel above (dwconv_rows4_kernel<K, 1, P, true>) already holds, per thread, the K + 7 dy rows x 12 columns under its 8 x 4 dx positions; the weight
+// gradient was a kernel of its own that read dy AGAIN (plus x) -- one full pass over the expanded tensor per MBConv block more than needed, and the one-wave-per-strip
+// walk of dwconv_wgrad4_kernel ran at 3.4 TB/s.  Here the thread also loads x at its 8 x 4 positions (a ring of K rows) and adds x * dy into K * K sums next to the
+// w * dy of the data gradient; a wave reduces its sums once (every lane of a wave lies in ONE plane: the launcher checks it) and lane 0 writes them as one row of the
+// partial tensor [B * strips][C][K * K] that segx_colsum adds in a fixed order, as for the separate kernel.  No early exits: lanes beyond the plane keep all-zero windows.
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_bwd_s1_fused_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ Wt,
+                                                                  float* __restrict__ dX, float* __restrict__ part, int C, int H, int W, int tiles_x, int tiles_y,
+                                                                  int tpr_log2, int64_t ngroups, int strips) {
+    constexpr int P = (K - 1) / 2, NV = 3, NR = DW4_TY - 1 + K;
+    static_assert(P <= 4 && 4 + 3 + K - 1 - P < 4 * NV, "window does not fit the loaded float4s");
+    const int64_t gid0 = ((int64_t)xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) >> tpr_log2;
+    const bool glive = gid0 < ngroups;
+    const int64_t gid = glive ? gid0 : ngroups - 1;
+    const int gpp = tiles_x * tiles_y;
+    const int64_t plane = gid / gpp;
+    const int rem = (int)(gid - plane * gpp), tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int ox0 = ((txi << tpr_log2) + (threadIdx.x & ((1 << tpr_log2) - 1))) * 4, oy0 = tyi * DW4_TY;
+    const bool live = glive && ox0 < W;
+    const int ox = live ? ox0 : 0;
+    const int c = (int)(plane % C);
+    const float* g = dY + plane * H * W;
+    const float* x = X + plane * H * W;
+    float w[K * K], gw[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) { w[i] = Wt[(int64_t)c * K * K + (K * K - 1 - i)]; gw[i] = 0.f; }
+    float acc[DW4_TY][4];
+#pragma unroll
+    for (int i = 0; i < DW4_TY; ++i) { acc[i][0] = 0.f; acc[i][1] = 0.f; acc[i][2] = 0.f; acc[i][3] = 0.f; }
+    int xo[NV]; bool okv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int col = ox - 4 + 4 * i; okv[i] = live && col >= 0 && col < W; xo[i] = min(max(col, 0), W - 4); }
+    const int iy0 = oy0 - (K - 1 - P);                       // first dy row under dx row oy0 (the rotated filter's top pad)
+    float e[DW4_AHEAD + 1][4 * NV];
+    float xr[K][4];                                          // x rows oy0 + i, ring over i % K (row i is used while r = i .. i + K - 1)
+#pragma unroll
+    for (int r = 0; r < DW4_AHEAD && r < NR; ++r)
+        dw4_load_row<NV>(e[r], g + (int64_t)min(max(iy0 + r, 0), H - 1) * W, xo, okv, iy0 + r >= 0 && iy0 + r < H);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        if (r + DW4_AHEAD < NR) {
+            const int iy = iy0 + r + DW4_AHEAD;
+            dw4_load_row<NV>(e[(r + DW4_AHEAD) % (DW4_AHEAD + 1)], g + (int64_t)min(max(iy, 0), H - 1) * W, xo, okv, iy >= 0 && iy < H);
+        }
+        if (r < DW4_TY) {                                    // x row of dx row r (first needed now, with ky = 0)
+            const float4 q = *reinterpret_cast<const float4*>(x + (int64_t)min(oy0 + r, H - 1) * W + ox);
+            const bool ok = live && oy0 + r < H;
+            xr[r % K][0] = ok ? q.x : 0.f; xr[r % K][1] = ok ? q.y : 0.f; xr[r % K][2] = ok ? q.z : 0.f; xr[r % K][3] = ok ? q.w : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            if ((r - ky) < 0 || (r - ky) >= DW4_TY) continue;     // compile-time
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+                    const float dv = e[r % (DW4_AHEAD + 1)][4 + j + kx - (K - 1 - P)];
+                    acc[r - ky][j] += w[ky * K + kx] * dv;
+                    gw[ky * K + kx] += xr[(r - ky) % K][j] * dv;
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) SEGX_PIN(acc[r - ky][j]);
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) SEGX_PIN(gw[ky * K + kx]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float* d = dX + plane * H * W + ox;
+#pragma unroll
+    for (int i = 0; i < DW4_TY; ++i)
+        if (live && oy0 + i < H) *reinterpret_cast<float4*>(d + (int64_t)(oy0 + i) * W) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    // gw[t] holds the sum for the ROTATED tap t (w was read rotated): dw index K K - 1 - t.  One row of `part` per wave.
+    const int lane = threadIdx.x & 63, gpw = 64 >> tpr_log2;
+    const int strip = rem / gpw, b = (int)(plane / C);
+    float* o = part + (((int64_t)b * strips + strip) * C + c) * (K * K);
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        const float sw = wave_sum(gw[t]);
+        if (lane == 0 && glive) o[K * K - 1 - t] = sw;
+    }
+}
+
 // Stride-2 data gradient, float4 variant (W % 8 == 0, OW % 4 == 0, pads known at compile time):
 //   dx[iy,ix] = sum over (ky,kx) with iy+PT-ky and ix+PL-kx even of  w[ky,kx] * dy[(iy+PT-ky)/2, (ix+PL-kx)/2]
 // A thread owns 8 adjacent dx columns x 4 dx rows (tile origin multiple of (4, 8), so every parity test is a compile-time
@@ -1714,6 +1800,31 @@ extern "C" int segx_dwconv2d_bwd_weight_direct(const float* dY, const float* X, 
     SEGX_DW4C(3, 1, 1) SEGX_DW4C(5, 1, 2) SEGX_DW4C(3, 2, 0) SEGX_DW4C(3, 2, 1) SEGX_DW4C(5, 2, 1) SEGX_DW4C(5, 2, 2)
 #undef SEGX_DW4C
     return 0;
+}
+/* r06: data AND weight gradient of a stride-1 'same' depthwise convolution in one pass over dY (dwconv_bwd_s1_fused_kernel).  _rows: rows of `part` per sample
+ * (one per wave of a plane), 0 where the shape is not served (stride 2, rows that are not float4 multiples, planes smaller than a wave's share, k other than 3 / 5) */
+static int dw_fused_strips(int H, int Wd, int OH, int OW, int k, int stride, int pad_t, int pad_l) {
+    if (stride != 1 || (k != 3 && k != 5) || pad_t != (k - 1) / 2 || pad_l != (k - 1) / 2 || OH != H || OW != Wd || Wd % 4 != 0 || Wd < 4) return 0;
+    const Dw4Grid g = dw4_grid(Wd);
+    const int tiles_y = (H + segx::DW4_TY - 1) / segx::DW4_TY, gpp = g.tiles_x * tiles_y, gpw = 64 >> g.tpr_log2;
+    return gpp % gpw == 0 ? gpp / gpw : 0;
+}
+extern "C" int64_t segx_dwconv2d_bwd_fused_rows(int H, int Wd, int OH, int OW, int k, int stride, int pad_t, int pad_l) {
+    return dw_fused_strips(H, Wd, OH, OW, k, stride, pad_t, pad_l);
+}
+extern "C" int segx_dwconv2d_bwd_fused(const float* dY, const float* X, const float* W, float* dX, float* part /* [B * rows][C][k * k] */, int B, int C, int H, int Wd,
+                                       int OH, int OW, int k, int stride, int pad_t, int pad_l, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && W && dX && part && B > 0 && C > 0 && (int64_t)B * C <= 65535, "segx_dwconv2d_bwd_fused: bad args");
+    const int strips = dw_fused_strips(H, Wd, OH, OW, k, stride, pad_t, pad_l);
+    SEGX_REQUIRE(strips > 0 && ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0,
+                 "segx_dwconv2d_bwd_fused: shape not served (segx_dwconv2d_bwd_fused_rows == 0) or unaligned tensors");
+    const Dw4Grid g = dw4_grid(Wd);
+    const int tiles_y = (H + segx::DW4_TY - 1) / segx::DW4_TY;
+    const int64_t ngroups = (int64_t)B * C * g.tiles_x * tiles_y, nblocks = ((ngroups << g.tpr_log2) + 255) / 256;
+    SEGX_REQUIRE(nblocks <= 2147483647LL, "segx_dwconv2d_bwd_fused: too many workgroups");
+    if (k == 3) hipLaunchKernelGGL((segx::dwconv_bwd_s1_fused_kernel<3>), dim3((unsigned)nblocks), dim3(256), 0, stream, dY, X, W, dX, part, C, H, Wd, g.tiles_x, tiles_y, g.tpr_log2, ngroups, strips);
+    else hipLaunchKernelGGL((segx::dwconv_bwd_s1_fused_kernel<5>), dim3((unsigned)nblocks), dim3(256), 0, stream, dY, X, W, dX, part, C, H, Wd, g.tiles_x, tiles_y, g.tpr_log2, ngroups, strips);
+    return check_launch("segx_dwconv2d_bwd_fused");
 }
 /* rows of `part` per sample (see segx_dwconv2d_bwd_weight) */
 extern "C" int64_t segx_dwconv2d_wgrad_rows(int OH, int OW) { return OH > 0 && OW > 0 ? dw_wgrad_strips(OH, OW) : 0; }

@@ -910,6 +910,8 @@ def bn_act_multi(x, bns, act=ACT_NONE):
 
 
 class _DWConv(torch.autograd.Function):
+    fused_backward = True     # stride-1 'same' layers: segx_dwconv2d_bwd_fused (False: data and weight gradient as two kernels, rounds 1-5; tools/ab_switch.py)
+
     @staticmethod
     def forward(ctx, x, w, stride, pad):
         L = segx.lib()
@@ -931,6 +933,17 @@ class _DWConv(torch.autograd.Function):
         B, C, H, W, OH, OW, k, stride, pt, pl = ctx.cfg
         dy = _c(dy)
         dx = dw = None
+        fr = 0
+        if _DWConv.fused_backward and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0:
+            fr = L.dwconv2d_bwd_fused_rows(H, W, OH, OW, k, stride, pt, pl)
+        if fr:
+            # r06: stride-1 'same' layers -- dx and the weight-gradient partials from ONE pass over dy (the separate kernels read it twice)
+            dx = torch.empty_like(x)
+            part = _empty(x, B * fr, C * k * k)
+            L.dwconv2d_bwd_fused(dy, x, w, dx, part, B, C, H, W, OH, OW, k, stride, pt, pl)
+            dw = _empty(x, C * k * k)
+            L.colsum(part, dw, _empty(x, L.colreduce_ws(B * fr, C * k * k, 1)), B * fr, C * k * k)
+            return dx, dw.view_as(w), None, None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.dwconv2d_bwd_data(dy, w, dx, B, C, H, W, OH, OW, k, stride, pt, pl)

@@ -351,6 +351,12 @@ class SegxLib:
             self.check(rc, 'segx_dwconv2d_bwd_weight_direct')
         return rc == 1
 
+    def dwconv2d_bwd_fused_rows(self, H, W, OH, OW, k, stride, pad_t, pad_l):
+        return int(self.c.segx_dwconv2d_bwd_fused_rows(H, W, OH, OW, k, stride, pad_t, pad_l))
+
+    def dwconv2d_bwd_fused(self, dY, X, W, dX, part, B, C, H, Wd, OH, OW, k, stride, pad_t, pad_l):
+        self._call('segx_dwconv2d_bwd_fused', dY, dY, X, W, dX, part, B, C, H, Wd, OH, OW, k, stride, pad_t, pad_l)
+
     def dwconv2d_wgrad_rows(self, OH, OW):
         return int(self.c.segx_dwconv2d_wgrad_rows(OH, OW))
 
@@ -644,7 +650,7 @@ _SIGS = {
     'segx_maxpool3d_fwd': 'ppplpp', 'segx_maxpool3d_bwd': 'ppplppp',
     'segx_bn_ws_floats': 'iil', 
     'segx_dwconv2d_fwd': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_data': 'pppiiiiiiiiiip',
-    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
+    'segx_dwconv2d_bwd_weight': 'pppiiiiiiiiiip', 'segx_dwconv2d_bwd_weight_direct': 'pppiiiiiiiiiip', 'segx_dwconv2d_wgrad_rows': 'ii', 'segx_dwconv2d_bwd_fused_rows': 'iiiiiiii', 'segx_dwconv2d_bwd_fused': 'pppppiiiiiiiiiip', 'segx_plane_scale': 'pppllp', 'segx_plane_dot': 'pppllp',
      'segx_plane_bias_add': 'ppplilp', 
     'segx_plane_chunks': 'l', 'segx_bn_pool_chunks': 'ili', 'segx_bn_parts_floats': 'iil', 'segx_bn_stats_local': 'pppiilp',
     'segx_bn_act_fwd2': 'ppippppfpppppfuuiilfillp', 'segx_bn_act_bwd2': 'ppppppppppiilfiippffuullp',

@@ -58,9 +58,13 @@ def test_bn_act(backend, shape, act, training):
                                               (3, 2, (1, 1, 1, 1), 16, 24),           # float4 path, left pad 1 at stride 2
                                               (3, 1, (1, 1, 1, 1), 100, 128),         # float4 path, two wgrad strips
                                               (5, 2, (2, 2, 2, 2), 96, 256),
-                                              (5, 2, (1, 2, 1, 2), 22, 40), (3, 2, (0, 1, 0, 1), 18, 600)])   # ragged rows / 2 column tiles
+                                              (5, 2, (1, 2, 1, 2), 22, 40), (3, 2, (0, 1, 0, 1), 18, 600),    # ragged rows / 2 column tiles
+                                              # r06, stride-1 'same': dx and dw from one pass (segx_dwconv2d_bwd_fused) -- 4 / 2 / 1 row groups per wave, ragged last rows
+                                              (5, 1, (2, 2, 2, 2), 64, 64), (3, 1, (1, 1, 1, 1), 32, 128), (5, 1, (2, 2, 2, 2), 24, 256), (3, 1, (1, 1, 1, 1), 20, 256)])
 def test_dwconv2d(backend, k, stride, pad, H, W):
     B, C = (2, 5) if H * W < 4000 else (2, 2)
+    if (k, stride, H, W) in ((5, 1, 64, 64), (3, 1, 32, 128), (5, 1, 24, 256), (3, 1, 20, 256), (3, 1, 37, 300)):
+        assert backend.L.dwconv2d_bwd_fused_rows(H, W, H, W, k, stride, pad[2], pad[0]) > 0
     x = rnd(B, C, H, W, seed=7).requires_grad_(True)
     w = rnd(C, 1, k, k, seed=8).requires_grad_(True)
     y = SF.dwconv2d(x, w, stride, pad)
