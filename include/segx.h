@@ -140,6 +140,13 @@ int segx_prenorm_fwd(const float* X, const float* w1, const float* b1, const flo
 int segx_prenorm_bwd(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld,
                      float pos_weight, const float* mask, const float* stats, float* dX, float* dU, int64_t B, int N, int C,
                      float p, uint64_t seed, uint64_t offset, void* stream);
+/* The same backward with everything the host formed FROM dU computed in the kernel, so that dU is never written (round 6): dw / db = the LayerNorm-1 parameter
+ * gradients (sum dU * xhat1, sum dU over all B N rows; autograd over :916-946), dsum [N, C] = sum_b dU[b] (the positional code's gradient before the pos_weight scale;
+ * NULL allowed when pos == NULL).  A wave owns a token and walks the batch; ws: segx_prenorm_bwd_all_ws_floats(N, C) floats; C <= 2048. */
+int64_t segx_prenorm_bwd_all_ws_floats(int N, int C);
+int segx_prenorm_bwd_all(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
+                         const float* mask, const float* stats, float* dX, float* dsum, float* dw, float* db, float* ws, int B, int N, int C,
+                         float p, uint64_t seed, uint64_t offset, void* stream);
 /* LearnedSinuPosEmbedder.forward (:989-998) for the batch-invariant [N, pd] normalised coordinates:
  *   out = LN_noaffine(interleave(sin(z_even), cos(z_odd))), z = posn Wp^T + bp.  stats = 2*N floats.
  * Backward gives dZ [N,C]; dWp = dZ^T posn (segx_gemm_f32), dbp = segx_colsum(dZ). */

@@ -456,6 +456,80 @@ __global__ __launch_bounds__(256) void prenorm_bwd_kernel(const float* __restric
     row_store(g, dX + row * C, C);
 }
 
+// r06: the same backward with everything that was computed FROM dU formed in the kernel, so that dU is never written: the LayerNorm-1 parameter gradients
+// (dw1 = sum dU * xhat1, db1 = sum dU over all rows) and the positional code's gradient (dsum[n] = sum_b dU[b][n], the caller scales it by pos_weight).  A wave owns
+// TOKEN n and walks the B samples (row b N + n): dsum[n] is a register row summed in sample order, dw1 / db1 are added into LDS vectors of the wave's own (as in
+// modes_aggr_bwd_kernel<.., true>), one chunk of the column-reduction workspace per workgroup.  Before: dU written (0.18 GB), read twice by segx_ln_param_grad (with X)
+// and once more by the batch sum -- 0.7 GB per call for two vectors and one [N, C] matrix.
+template <int NV4>
+__global__ __launch_bounds__(256) void prenorm_bwd_all_kernel(const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w1,
+                                                              const float* __restrict__ b1, const float* __restrict__ pos, int64_t pos_ld, float pos_w,
+                                                              const float* __restrict__ mask, const float* __restrict__ stats,
+                                                              float* __restrict__ dX, float* __restrict__ dsum, float* __restrict__ pws, int B, int N, int C,
+                                                              float p, uint64_t seed, uint64_t off, const uint64_t* __restrict__ rbase) {
+    __shared__ float4 pacc[4 * 2 * NV4 * 64];
+    off += rbase ? *rbase : 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, C4 = C >> 2;
+    const int n0 = blockIdx.x * ROWS_PER_BLOCK + wv;
+    const bool live = n0 < N;
+    const int n = live ? n0 : N - 1;
+    const int64_t rows = (int64_t)B * N;
+    const float ik = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    float4* const myacc = pacc + wv * 2 * NV4 * 64;
+#pragma unroll
+    for (int i = 0; i < 2 * NV4; ++i) myacc[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    Row<NV4> su;
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) su.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < B; ++b) {
+        const int64_t row = (int64_t)b * N + n;
+        const float m1 = stats[row], r1 = stats[rows + row], m2 = stats[2 * rows + row], r2 = stats[3 * rows + row];
+        const float mk = mask[row];
+        Row<NV4> xh, u, g; row_load(xh, X + row * C, C); row_load(g, dY + row * C, C);
+        SEGX_FOR_ROW(i, c4, C) {
+            const float4 ww = reinterpret_cast<const float4*>(w1)[c4], bb = reinterpret_cast<const float4*>(b1)[c4];
+            const float4 pp = pos ? reinterpret_cast<const float4*>(pos + (int64_t)n * pos_ld)[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            SEGX_F4_OP(xh.v[i], (xh.v[i].x - m1) * r1, (xh.v[i].y - m1) * r1, (xh.v[i].z - m1) * r1, (xh.v[i].w - m1) * r1);
+            SEGX_F4_OP(u.v[i], ((xh.v[i].x * ww.x + bb.x + pos_w * pp.x) - m2) * r2, ((xh.v[i].y * ww.y + bb.y + pos_w * pp.y) - m2) * r2,
+                       ((xh.v[i].z * ww.z + bb.z + pos_w * pp.z) - m2) * r2, ((xh.v[i].w * ww.w + bb.w + pos_w * pp.w) - m2) * r2);
+            float4 k = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p > 0.f) k = f4_keep(seed, off, (uint64_t)row * C + c4 * 4, p, ik);
+            SEGX_F4_OP(g.v[i], g.v[i].x * k.x * mk, g.v[i].y * k.y * mk, g.v[i].z * k.z * mk, g.v[i].w * k.w * mk);
+        }
+#pragma unroll
+        for (int i = 0; i < NV4; ++i) if (!((lane + 64 * i) * 4 < C)) { u.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); xh.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); g.v[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (pos) ln_bwd_row(g, u, C, r2);             // g := dU
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < NV4; ++i) {
+                const int c4 = lane + 64 * i;
+                float4 a0 = myacc[c4], a1 = myacc[NV4 * 64 + c4];
+                SEGX_F4_OP(a0, a0.x + g.v[i].x * xh.v[i].x, a0.y + g.v[i].y * xh.v[i].y, a0.z + g.v[i].z * xh.v[i].z, a0.w + g.v[i].w * xh.v[i].w);
+                SEGX_F4_OP(a1, a1.x + g.v[i].x, a1.y + g.v[i].y, a1.z + g.v[i].z, a1.w + g.v[i].w);
+                myacc[c4] = a0; myacc[NV4 * 64 + c4] = a1;
+                SEGX_F4_OP(su.v[i], su.v[i].x + g.v[i].x, su.v[i].y + g.v[i].y, su.v[i].z + g.v[i].z, su.v[i].w + g.v[i].w);
+            }
+        }
+        SEGX_FOR_ROW(i, c4, C) { const float4 ww = reinterpret_cast<const float4*>(w1)[c4];
+                                 SEGX_F4_OP(g.v[i], g.v[i].x * ww.x, g.v[i].y * ww.y, g.v[i].z * ww.z, g.v[i].w * ww.w); }
+        ln_bwd_row(g, xh, C, r1);
+        if (live) row_store(g, dX + row * C, C);
+    }
+    if (dsum && live) row_store(su, dsum + (int64_t)n * C, C);
+    __syncthreads();
+    const int64_t nchunks = gridDim.x;
+    for (int idx = threadIdx.x; idx < C4; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float4 v0 = pacc[(0 * 2 + k) * NV4 * 64 + idx], v1 = pacc[(1 * 2 + k) * NV4 * 64 + idx], v2 = pacc[(2 * 2 + k) * NV4 * 64 + idx],
+                         v3 = pacc[(3 * 2 + k) * NV4 * 64 + idx];
+            float4 o;
+            SEGX_F4_OP(o, ((v0.x + v1.x) + v2.x) + v3.x, ((v0.y + v1.y) + v2.y) + v3.y, ((v0.z + v1.z) + v2.z) + v3.z, ((v0.w + v1.w) + v2.w) + v3.w);
+            reinterpret_cast<float4*>(pws + ((int64_t)k * nchunks + blockIdx.x) * C)[idx] = o;
+        }
+    }
+}
+
 // =================================================================================================
 // Learned sinusoidal positional code (LearnedSinuPosEmbedder.forward :989-998, K13), batch-invariant:
 //   z = posn @ Wp^T + bp ; mix[c] = c even ? sin z : cos z ; out = LN_noaffine(mix)
@@ -955,6 +1029,18 @@ extern "C" int segx_prenorm_bwd(const float* dY, const float* X, const float* w1
     const int64_t rows = B * N;
     SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_kernel<NV4>), row_grid(rows), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dU, rows, N, C, p, seed, offset, rng_base()));
     return check_launch("segx_prenorm_bwd");
+}
+extern "C" int64_t segx_prenorm_bwd_all_ws_floats(int N, int C) { return 2 * (int64_t)((N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK) * C; }
+extern "C" int segx_prenorm_bwd_all(const float* dY, const float* X, const float* w1, const float* b1, const float* pos, int64_t pos_ld, float pos_weight,
+                                    const float* mask, const float* stats, float* dX, float* dsum, float* dw, float* db, float* ws, int B, int N, int C,
+                                    float p, uint64_t seed, uint64_t offset, void* stream_) {
+    SEGX_STREAM; SEGX_REQUIRE(dY && X && w1 && b1 && mask && stats && dX && dw && db && ws && B > 0 && N > 0 && (!pos || dsum), "segx_prenorm_bwd_all: bad args"); SEGX_ROWCHK(C);
+    SEGX_REQUIRE(C <= 2048 && (!pos || (pos_ld >= C && pos_ld % 4 == 0)), "segx_prenorm_bwd_all: C=%d (<= 2048) pos_ld=%lld", C, (long long)pos_ld);
+    const int nch = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_all_kernel<(NV4 > 8 ? 8 : NV4)>), dim3((unsigned)nch), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX,
+                                            pos ? dsum : (float*)nullptr, ws, B, N, C, p, seed, offset, rng_base()));
+    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, (const float*)ws, dw, db, (float*)nullptr, (int64_t)C, nch, 2);
+    return check_launch("segx_prenorm_bwd_all");
 }
 extern "C" int segx_posembed_fwd(const float* posn, const float* Wp, const float* bp, float* out, float* stats, int64_t N, int C, int pd,
                                  float eps, void* stream_) {

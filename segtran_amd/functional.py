@@ -377,6 +377,7 @@ def layer_norm(X, w=None, b=None, eps=LN_EPS):
 
 class _PreNorm(torch.autograd.Function):
     """mask * dropout(LN_noaffine(LN_affine(x) + pos_weight * pos[:, :C]))  (segtran_shared.py:916-946)."""
+    one_pass = True           # backward: segx_prenorm_bwd_all (False: prenorm_bwd + ln_param_grad + colsum over dU, rounds 1-5; tools/ab_switch.py)
 
     @staticmethod
     def forward(ctx, X, w1, b1, pos, mask, pos_weight, drop_p):
@@ -398,6 +399,18 @@ class _PreNorm(torch.autograd.Function):
         X, w1, b1, pos, mask, stats = ctx.saved_tensors
         pw, p, seed, off = ctx.cfg
         B, N, C = X.shape
+        if _PreNorm.one_pass and C <= 2048:
+            # r06: dX, the LayerNorm-1 parameter gradients and the positional code's batch sum from ONE kernel; dU is never written (it was written once and read three times)
+            dX = torch.empty_like(X)
+            dw, db = _empty(X, C), _empty(X, C)
+            want_pos = pos is not None
+            dsum = _empty(X, N, C) if want_pos else None
+            L.prenorm_bwd_all(_c(dY), X, w1, b1, pos, pos.shape[1] if want_pos else 0, pw, mask, stats, dX, dsum, dw, db, _empty(X, L.prenorm_bwd_all_ws(N, C)), B, N, C, p, seed, off)
+            dpos = None
+            if want_pos and ctx.needs_input_grad[3]:
+                dpos = torch.zeros_like(pos)
+                dpos[:, :C] = dsum * pw
+            return dX, dw, db, dpos, None, None, None
         dX, dU = torch.empty_like(X), torch.empty_like(X)
         L.prenorm_bwd(_c(dY), X, w1, b1, pos, pos.shape[1] if pos is not None else 0, pw, mask, stats, dX, dU, B, N, C, p, seed, off)
         rows = B * N

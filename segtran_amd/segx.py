@@ -251,6 +251,12 @@ class SegxLib:
     def prenorm_bwd(self, dY, X, w1, b1, pos, pos_ld, pw, mask, stats, dX, dU, B, N, C, p, seed, offset):
         self._call('segx_prenorm_bwd', X, dY, X, w1, b1, pos, pos_ld, pw, mask, stats, dX, dU, B, N, C, p, seed, offset)
 
+    def prenorm_bwd_all_ws(self, N, C):
+        return int(self.c.segx_prenorm_bwd_all_ws_floats(N, C))
+
+    def prenorm_bwd_all(self, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dsum, dw, db, ws, B, N, C, p, seed, offset):
+        self._call('segx_prenorm_bwd_all', X, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX, dsum, dw, db, ws, B, N, C, p, seed, offset)
+
     def posembed_fwd(self, posn, Wp, bp, out, stats, N, C, pd, eps):
         self._call('segx_posembed_fwd', out, posn, Wp, bp, out, stats, N, C, pd, eps)
 
@@ -630,6 +636,7 @@ _SIGS = {
     'segx_sum': 'plppfp', 'segx_rowsum': 'ppllp',
     'segx_prenorm_fwd': 'pppplfppplliiffuup'.replace('lliif', 'liif'),
     'segx_prenorm_bwd': 'ppppplfpppplii' + 'fuup',
+    'segx_prenorm_bwd_all_ws_floats': 'ii', 'segx_prenorm_bwd_all': 'ppppplfpppppppiiifuup',
     'segx_posembed_fwd': 'pppppliifp', 'segx_posembed_bwd': 'ppppppliip',
     'segx_modes_aggr_fwd': 'pppppppiliffuup', 'segx_modes_aggr_bwd': 'ppppppppilifuup',
     'segx_modes_aggr_param_grad': 'pppppppppppilifuup', 'segx_gelu_bwd': 'ppplfuup',

@@ -147,6 +147,11 @@ def test_prenorm_fwd_bwd(backend, B, N, C, Cpos):
     dpos = torch.empty(N * C); ws = torch.empty(Lb.colreduce_ws(B, N * C, 1))
     Lb.colsum(dU, dpos, ws, B, N * C)
     close(pw * dpos.view(N, C), posr.grad[:, :C], 5e-5)
+    # the one-pass form (segx_prenorm_bwd_all): dX bit for bit, the sums that were taken from dU formed inside the kernel
+    dX2 = torch.full_like(X, float('nan')); ds2 = torch.full((N, C), float('nan')); dw2 = torch.full((C,), float('nan')); db2 = torch.full((C,), float('nan'))
+    Lb.prenorm_bwd_all(G, X, w1, b1, pos, Cpos, pw, mask, stats, dX2, ds2, dw2, db2, torch.full((Lb.prenorm_bwd_all_ws(N, C),), float('nan')), B, N, C, 0.0, 0, 0)
+    assert torch.equal(dX2, dX)
+    close(dw2, w1r.grad, 5e-5); close(db2, b1r.grad, 5e-5); close(pw * ds2, posr.grad[:, :C], 5e-5)
 
 
 def test_prenorm_dropout_mask_matches_between_fwd_and_bwd(backend):
@@ -165,6 +170,10 @@ def test_prenorm_dropout_mask_matches_between_fwd_and_bwd(backend):
     dX = torch.empty_like(X); dU = torch.empty_like(X)
     Lb.prenorm_bwd(G, X, w1, b1, pos, C, 1.0, mask, stats, dX, dU, B, N, C, p, 5, 64)
     close(dX, Xr.grad, 5e-5)
+    dX2 = torch.full_like(X, float('nan')); ds2 = torch.empty(N, C); dw2 = torch.empty(C); db2 = torch.empty(C)
+    Lb.prenorm_bwd_all(G, X, w1, b1, pos, C, 1.0, mask, stats, dX2, ds2, dw2, db2, torch.empty(Lb.prenorm_bwd_all_ws(N, C)), B, N, C, p, 5, 64)
+    assert torch.equal(dX2, dX)
+    close(ds2, dU.sum(0), 5e-5)
 
 
 @pytest.mark.parametrize('N,C,pd', [(20, 64, 2), (7, 1792, 2), (11, 1024, 3)])
