@@ -352,6 +352,35 @@ __global__ __launch_bounds__(256) void colreduce_stage2(const float* __restrict_
     if (p == 0 && c < C)
         for (int o = 0; o < nout; ++o) (o == 0 ? out0 : o == 1 ? out1 : out2)[c] = ((part[o][0][col] + part[o][1][col]) + part[o][2][col]) + part[o][3][col];
 }
+// r06: the one-pass backward kernels (modes_aggr_bwd_all, prenorm_bwd_all, gelu_bwd_colsum) leave 1 000 - 2 000 chunks; with four parts per column a thread walked 250 - 500 dependent
+// loads on 28 workgroups (25 - 80 us per call, r06_z).  16 columns x 16 parts per workgroup: four times the workgroups, chains a quarter as long; part p adds chunks p, p + 16, ... in that
+// order and the sixteen partial sums are added in part order through LDS -- a fixed tree.
+__global__ __launch_bounds__(256) void colreduce_stage2_p16(const float* __restrict__ ws, float* __restrict__ out0, float* __restrict__ out1,
+                                                            float* __restrict__ out2, int64_t C, int nchunks, int nout) {
+    __shared__ float part[3][16][16];
+    const int col = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + col;
+    for (int o = 0; o < nout; ++o) {
+        float s = 0.f;
+        if (c < C) {
+#pragma unroll 8
+            for (int k = p; k < nchunks; k += 16) s += ws[((int64_t)o * nchunks + k) * C + c];
+        }
+        part[o][p][col] = s;
+    }
+    __syncthreads();
+    if (p == 0 && c < C)
+        for (int o = 0; o < nout; ++o) {
+            float t = part[o][0][col];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) t += part[o][q][col];
+            (o == 0 ? out0 : o == 1 ? out1 : out2)[c] = t;
+        }
+}
+static inline void launch_colreduce2(hipStream_t stream, const float* ws, float* o0, float* o1, float* o2, int64_t C, int nch, int nout) {
+    if (nch >= 256) hipLaunchKernelGGL(colreduce_stage2_p16, dim3((unsigned)((C + 15) / 16)), dim3(256), 0, stream, ws, o0, o1, o2, C, nch, nout);
+    else hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, ws, o0, o1, o2, C, nch, nout);
+}
 static inline int chunks_for(int64_t rows) { return (int)i64max(1, i64min(RED_CHUNKS, rows / 8)); }
 
 // row sums of X [R, S] (conv-style bias gradients: one value per (sample, channel)): one workgroup per row
@@ -1039,7 +1068,7 @@ extern "C" int segx_prenorm_bwd_all(const float* dY, const float* X, const float
     const int nch = (N + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     SEGX_DISPATCH_NV4(C, hipLaunchKernelGGL((prenorm_bwd_all_kernel<(NV4 > 8 ? 8 : NV4)>), dim3((unsigned)nch), dim3(256), 0, stream, dY, X, w1, b1, pos, pos_ld, pos_weight, mask, stats, dX,
                                             pos ? dsum : (float*)nullptr, ws, B, N, C, p, seed, offset, rng_base()));
-    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, stream, (const float*)ws, dw, db, (float*)nullptr, (int64_t)C, nch, 2);
+    launch_colreduce2(stream, ws, dw, db, nullptr, (int64_t)C, nch, 2);
     return check_launch("segx_prenorm_bwd_all");
 }
 extern "C" int segx_posembed_fwd(const float* posn, const float* Wp, const float* bp, float* out, float* stats, int64_t N, int C, int pd,
@@ -1096,7 +1125,7 @@ extern "C" int segx_modes_aggr_bwd_all(const float* dY, const float* Z, const fl
     SEGX_REQUIRE(nch < 2147483647LL, "segx_modes_aggr_bwd_all: too many rows");
     SEGX_DISPATCH_NV4(F, hipLaunchKernelGGL((modes_aggr_bwd_kernel<(NV4 > 8 ? 8 : NV4), 4, true>), dim3((unsigned)nch), dim3(256), 0, stream, dY, Z, lnw, lnb, wa, stats, dZ, dscore, R, F,
                                             p, seed, offset, rng_base(), ws, tpw));
-    hipLaunchKernelGGL(colreduce_stage2, dim3((F + 63) / 64), dim3(256), 0, stream, (const float*)ws, dlnw, dlnb, dwa, (int64_t)F, (int)nch, 3);
+    launch_colreduce2(stream, ws, dlnw, dlnb, dwa, (int64_t)F, (int)nch, 3);
     return check_launch("segx_modes_aggr_bwd_all");
 }
 extern "C" int segx_modes_aggr_param_grad(const float* dY, const float* Z, const float* lnw, const float* lnb, const float* wa, const float* stats,
@@ -1127,7 +1156,7 @@ extern "C" int segx_gelu_bwd_colsum(const float* dH, const float* T, float* dT, 
     const int nch = gelu_colsum_chunks(rows);
     const int threads = ((N / 4 + 63) / 64) * 64;
     hipLaunchKernelGGL(gelu_bwd_colsum_kernel, dim3((unsigned)nch), dim3(threads), 0, stream, dH, T, dT, ws, rows, N, nch, p, seed, offset, rng_base());
-    hipLaunchKernelGGL(colreduce_stage2, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, (const float*)ws, colsum, (float*)nullptr, (float*)nullptr, (int64_t)N, nch, 1);
+    launch_colreduce2(stream, ws, colsum, nullptr, nullptr, (int64_t)N, nch, 1);
     return check_launch("segx_gelu_bwd_colsum");
 }
 /* geom = {D, H, W, R, nd}: token grid (D = 1 in 2-D), radius, position dims */
