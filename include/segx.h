@@ -515,6 +515,9 @@ int segx_stem_compose_bwd(const float* dWc, const float* Ws, const float* Wb, co
                           int O, int C3, int Cb, int Cc, int T, void* stream);
 /* x [B][Cb][H][W][D] -> y [B][Cc][D][H][W]: depth moved in front (segtran3d.py:422), channel Cb = 1, channels above it = 0 */
 int segx_bridge_input(const float* X, float* Y, int B, int Cb, int Cc, int H, int W, int D, void* stream);
+/* X [B, Cb, H, W, D] -> Y [B, 2 Cb, D, H, U]: depth in front and space-to-depth along W, Y[b][2 c + j][d][h][u] = X[b][c][h][2 u + j - 2][d] (0 outside [0, W)) --
+ * the input of the stride-(2, 2, 1) form of the I3D stem (segtran3d.py:420-423 + aj_i3d.py:75-97; U = W / 2 + 3) in one pass */
+int segx_stem_s2d_input(const float* X, float* Y, int B, int Cb, int H, int W, int D, int U, void* stream);
 /* The dense 3 x 3 stem of EfficientNet (efficientnet/model.py:128, 163: Conv2dStaticSamePadding(3, c0, 3, stride) on the up-sized image) as a direct convolution:
  * X [B, 3, H, W], W [Cout, 3, 3, 3], Y [B, Cout, OH, OW], zero padding pt rows on top / pl columns on the left (the rest of the window falls off the far edges).
  * _im2col: Xcol [B, rows, OH * OW] (rows >= 27; rows beyond 27 are zero) -- the window matrix the weight gradient contracts with dY as a batch-reduced skinny GEMM

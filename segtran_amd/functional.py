@@ -1781,8 +1781,8 @@ def stem_bridge_conv_s2d(batch, stem_weight, bridge_weight, bridge_bias, stride=
     w2 = F.pad(wc, (0, 1)).view(O, Cb, KD, KH, 4, 2).permute(0, 1, 5, 2, 3, 4).reshape(O, 2 * Cb, KD, KH, 4).contiguous()
     # conv axes (D, H, W) = (batch's last axis, H, W): [B, Cb, D, H, W] padded along W by 2 in front (the 'same' front pad) and 4 behind (window end), then W -> (U, 2)
     U = W // 2 + 3
-    x = F.pad(batch.detach().permute(0, 1, 4, 2, 3), (2, 4))
-    x2 = x.reshape(B, Cb, D, H, U, 2).permute(0, 1, 5, 2, 3, 4).reshape(B, 2 * Cb, D, H, U).contiguous()
+    x2 = _empty(batch, B, 2 * Cb, D, H, U)
+    segx.lib().stem_s2d_input(_c(batch.detach()), x2, B, Cb, H, W, D, U)      # one pass (pad + permute + reshape: three ATen copies of the batch)
     y = _Conv3d.apply(x2, w2, (2, 2, 1), ((2, 3), (2, 3), (0, 0)))
     v = linear(taps, bridge_bias.view(1, C3)).view(O, KD, KH, KW)                           # the bias seen through each tap
     md, mh, mw = (_stem_axis_mask(n, 7, 2, 2, batch.device) for n in (D, H, W))

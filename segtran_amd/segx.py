@@ -563,6 +563,9 @@ class SegxLib:
     def conv2d_stem_im2col(self, X, Xcol, B, Cin, H, Wd, OH, OW, K, stride, pt, pl, rows):
         self._call('segx_conv2d_stem_im2col', X, X, Xcol, B, Cin, H, Wd, OH, OW, K, stride, pt, pl, rows)
 
+    def stem_s2d_input(self, X, Y, B, Cb, H, W, D, U):
+        self._call('segx_stem_s2d_input', X, X, Y, B, Cb, H, W, D, U)
+
     def bridge_input(self, X, Y, B, Cb, Cc, H, W, D):
         self._call('segx_bridge_input', X, X, Y, B, Cb, Cc, H, W, D)
 
@@ -650,7 +653,7 @@ _SIGS = {
     'segx_axis_gather': 'pplpp', 'segx_pixel_shuffle2': 'ppliiip', 'segx_add_noise': 'ppplffiuup', 'segx_resize2d': 'ppliiiiiip', 'segx_color_blend': 'ppilippip',
     'segx_gray_mean_ws_floats': 'il', 'segx_gray_mean': 'pppilip', 'segx_normalize': 'ppiilfppp',
     'segx_x6_presplit_elems': 'iiii', 'segx_x6_presplit': 'piilliillpp',
-    'segx_tune': 'ii', 'segx_tune_get': 'i', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_conv2d_stem_fwd': 'pppiiiiiiiiiiip', 'segx_conv2d_stem_im2col': 'ppiiiiiiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
+    'segx_tune': 'ii', 'segx_tune_get': 'i', 'segx_set_rng_base': 'p', 'segx_rng_advance': 'pup', 'segx_resized_crop3d': 'pplpp', 'segx_stem_compose_fwd': 'ppppiiiiip', 'segx_stem_compose_bwd': 'pppppppiiiiip', 'segx_bridge_input': 'ppiiiiiip', 'segx_stem_s2d_input': 'ppiiiiiip', 'segx_conv2d_stem_fwd': 'pppiiiiiiiiiiip', 'segx_conv2d_stem_im2col': 'ppiiiiiiiiiiip', 'segx_dropout': 'pplfuup', 'segx_avgpool2_fwd': 'ppliip', 'segx_avgpool2_bwd': 'ppliip', 'segx_transpose': 'ppliip', 'segx_interp_linear_fwd_axis': 'pppliilfp', 'segx_window_accum': 'pppiipp', 'segx_harden_segmap': 'ppppiilifp', 'segx_dice_ws_floats': 'll', 'segx_dice_sums': 'pppllp',
     'segx_conv3d_fwd': 'pppiipipp', 'segx_conv3d_fwd_packed': 'pppiipipp', 'segx_conv3d_fwd_packed_bs': 'pppiipipllp', 'segx_conv3d_bwd_weight_packed_bs': 'pppiipipllp', 'segx_conv3d_pack_weights': 'ppiiiip', 'segx_conv3d_splitk': 'iipi', 'segx_conv3d_flip_weights': 'ppiiip', 'segx_conv3d_bwd_weight': 'pppiipipp', 'segx_conv3d_bwd_weight_packed': 'pppiipipp', 'segx_conv3d_unpack_wgrad': 'ppiiip',
     'segx_conv3d_halo_ok': 'iip', 'segx_conv3d_halo_wq_floats': 'ii', 'segx_conv3d_halo_pack': 'ppiiip', 'segx_conv3d_halo_fwd': 'pppiipllip', 'segx_conv3d_halo_wgrad_ok': 'iip', 'segx_conv3d_halo_wgrad_ws_floats': 'iip', 'segx_conv3d_halo_wgrad': 'ppppiipllp',
     'segx_conv3d_bwd_data_direct': 'ppppiipp', 'segx_nonzero_mask': 'ppiiiiiiiip', 'segx_label_nhot': 'ppiilip',
