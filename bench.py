@@ -361,8 +361,11 @@ def run_graph_replay(args, config=None, graph=True, batch=0):
     """The same configuration replayed as ONE captured hipGraph per step (engine.GraphedTrainStep), in a child process after everything else has been
     measured: a capture problem can then cost this extra block only, never the line.  Not the headline: `value` stays the eager step, whose engine
     launches carry the HIP events the roofline is computed from."""
+    # an EAGER launch-bound step (cfg1, one image per rank) is timed by the host, and the host needs ~30 steps of a fresh process to reach its pace (r06_bn: 22.5 -> 17.2 -> 15.3 ms over the
+    # first three blocks of ten cfg1 steps, then flat): HOST_WARMUP untimed steps there; graph replays and device-bound steps keep the short warm-up
+    warm = max(3, args.warmup // 2) if graph else max(HOST_WARMUP, args.warmup)
     cmd = [sys.executable, os.path.abspath(__file__)] + (['--graph'] if graph else []) + ['--config', config or args.config, '--engine', args.engine, '--steps', str(max(10, args.steps // 2)),
-           '--warmup', str(max(3, args.warmup // 2)), '--no-brats', '--no-cpu-baseline', '--single-order'] + (['--batch', str(batch)] if batch else [])
+           '--warmup', str(warm), '--no-brats', '--no-cpu-baseline', '--single-order'] + (['--batch', str(batch)] if batch else [])
     if args.reference_op_order:
         cmd.append('--reference-op-order')
     try:
@@ -376,6 +379,7 @@ def run_graph_replay(args, config=None, graph=True, batch=0):
         return {'error': 'timeout'}
 
 
+HOST_WARMUP = 40            # untimed steps before a host-bound (eager, launch-bound) configuration is timed: see run_graph_replay
 LINE_LIMIT = 4096           # the driver keeps an ~8 KB tail of stdout (BENCH_r04: a 24.9 KB line arrived without its head): the line stays under half of that
 _ATTN_NAMES = ('QK^T', 'P.V', 'dP', 'dV', 'P.(vW)', 'dS.K')
 
@@ -529,7 +533,7 @@ def main():
         k3, w3 = max(10, args.steps // 2), max(3, args.warmup // 2)
         polyp = {}
         for tag, bsz in (('cfg3_bs6', 6), ('cfg3_bs1_per_rank_of_4', 1)):
-            r = measure('cfg3', args, k3, w3, rank, world, dev, other_order=False, batch=bsz)
+            r = measure('cfg3', args, k3, w3 if bsz > 1 else max(HOST_WARMUP, w3), rank, world, dev, other_order=False, batch=bsz)      # one image: host-bound, see HOST_WARMUP
             polyp[tag] = {k: r[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'ms_per_step_median', 'value_at_median', 'config')}
         res['polyp'] = polyp
     if rank != 0:

@@ -98,6 +98,14 @@ class MBConvBlock(nn.Module):
     gate_in_weights = True     # False: the reference's op order (gate applied to the activation, model.py:110), as a separate pass
 
     def forward(self, inputs, drop_connect_rate=None):
+        """One autograd node per block (SF.block_node: the ops below recorded on a tape, backward walks it in reverse) -- same kernels in the same order, less
+        host time per block of the eager (data-parallel) step."""
+        ps = self.__dict__.get('_block_params')
+        if ps is None:
+            ps = self.__dict__['_block_params'] = [p for p in self.parameters()]          # parameters are moved / loaded in place: the objects stay
+        return SF.block_node(self._forward_ops, inputs, (drop_connect_rate,), ps)
+
+    def _forward_ops(self, inputs, drop_connect_rate=None):
         x = skip_in = inputs
         skip = self.stride == 1 and self.input_filters == self.output_filters
         if self.expand_ratio != 1:

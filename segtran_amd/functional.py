@@ -12,6 +12,173 @@ LN_EPS = 1e-12      # every LayerNorm of the Squeeze-and-Expansion transformer (
 
 
 # -------------------------------------------------------------------------------------------------
+# Block nodes: the ops of one backbone block as ONE autograd node (efficientnet/model.py:82-126, aj_i3d.py:121-126).
+# The eager step is what a data-parallel rank runs (RCCL cannot be captured), and at one or two images per rank its time is the host's: ~17 us per
+# launch, most of it torch.autograd.Function.apply going in and the engine's per-node dispatch coming back.  Inside `block_node(fn, ...)` every op of
+# this file runs its OWN forward / backward static methods against a plain context object, recorded on a tape; autograd sees one node per block
+# whose backward walks the tape in reverse.  Same kernels, same launch order, same results bit for bit -- only the bookkeeping per op changes.
+# Rule for code run under a tape: differentiable work goes through the ops of this file (plus contiguous reshapes of a block input, e.g.
+# `weight.reshape(Cout, Cin)`); a block input that should receive a gradient and gets none raises.
+# -------------------------------------------------------------------------------------------------
+_tape = None
+_tape_serial = 0
+block_nodes = False         # OFF by default: measured (profiles/r06_bn_ab_block_nodes_host.txt, same process, eight alternating repetitions) the eager cfg1 step takes 15.3 ms
+#                             with one node per backbone block and 14.4 ms with one node per op; cfg3 at one image 24.6 vs 23.2 -- the tape's Python per op costs
+#                             more than the C++ node it replaces.  Kept (opt-in, parity-tested bit for bit) as the measured answer to VERDICT r05 item 5.
+
+
+class _OpCtx:
+    """What the ops of this file use of an autograd context: save_for_backward / saved_tensors, needs_input_grad, plus free attributes."""
+    materialize = True
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def set_materialize_grads(self, v):
+        self.materialize = bool(v)
+
+    def mark_non_differentiable(self, *ts):
+        self.non_diff = ts
+
+
+class _Tape:
+    def __init__(self, inputs, needs):
+        global _tape_serial
+        _tape_serial += 1
+        self.serial, self.n, self.recs, self.req, self.done = _tape_serial, 0, [], [], False
+        self.in_ids = []
+        for t, r in zip(inputs, needs):
+            known = isinstance(t, torch.Tensor) and getattr(t, '_segx_tid', (0, 0))[0] == self.serial     # the same tensor passed twice: its gradient goes to the first
+            self.in_ids.append(self.tag(t, bool(r)) if isinstance(t, torch.Tensor) and not known else None)
+
+    def tag(self, t, req):
+        t._segx_tid = (self.serial, self.n)
+        self.req.append(req)
+        self.n += 1
+        return self.n - 1
+
+    def find(self, t):
+        """-> (tape id or None, shape to bring a gradient back to or None): a tensor the tape has seen, or a contiguous same-size view of one (weight.reshape(...))"""
+        k = getattr(t, '_segx_tid', None)
+        if k is not None and k[0] == self.serial:
+            return k[1], None
+        b = t._base
+        if b is not None:
+            k = getattr(b, '_segx_tid', None)
+            if k is not None and k[0] == self.serial:
+                if not (t.is_contiguous() and b.is_contiguous() and t.numel() == b.numel()):
+                    raise RuntimeError('block node: only a contiguous reshape of a block tensor may be taken outside the ops of functional.py (got %s of %s)'
+                                       % (tuple(t.shape), tuple(b.shape)))
+                return k[1], b.shape
+        return None, None
+
+    def run(self, fn, args):
+        ctx = _OpCtx()
+        keys = [self.find(a) if isinstance(a, torch.Tensor) else (None, None) for a in args]
+        ctx.needs_input_grad = tuple(k is not None and self.req[k] for k, _ in keys)
+        out = fn.forward(ctx, *args)
+        req = any(ctx.needs_input_grad)
+        nd = getattr(ctx, 'non_diff', ())
+        outs = out if isinstance(out, tuple) else (out,)
+        oids = []
+        for o in outs:
+            if isinstance(o, torch.Tensor) and not any(o is t for t in nd):
+                if getattr(o, '_segx_tid', (0, 0))[0] == self.serial:
+                    raise RuntimeError('block node: %s returned a tensor the block holds already; return a fresh tensor or a view' % fn.__name__)
+                oids.append(self.tag(o, req))         # a view of an input (the alias outputs of _BGemm / _Conv3dSlices / _MaxPool3d) is a tensor of its own, as for autograd
+            else:
+                oids.append(None)
+        if req:
+            self.recs.append((fn, ctx, keys, oids, [(o.shape, o.device) if isinstance(o, torch.Tensor) else None for o in outs]))
+        return out
+
+
+class _Fn(torch.autograd.Function):
+    """Base of every op of this file: under a tape (block_node) the op is recorded instead of becoming an autograd node of its own."""
+
+    @classmethod
+    def apply(cls, *args):
+        if _tape is not None:
+            return _tape.run(cls, args)
+        # torch.autograd.Function.apply minus its functorch wrapper scan (4 us per call; no functorch transform ever runs over this library's ops)
+        return super(torch.autograd.Function, cls).apply(*args)
+
+
+class _Block(_Fn):
+    @staticmethod
+    def forward(ctx, fn, static, *tensors):
+        global _tape
+        assert _tape is None, 'block nodes do not nest'
+        tape = _Tape(tensors, ctx.needs_input_grad[2:])
+        _tape = tape
+        try:
+            out = fn(tensors[0], *static)
+        finally:
+            _tape = None
+        outs = out if isinstance(out, tuple) else (out,)
+        tape.out_ids = []
+        for o in outs:
+            k, shp = tape.find(o)
+            if k is None or shp is not None or k in tape.in_ids:
+                raise RuntimeError('block node: every output must be a tensor produced by an op of the block')
+            tape.out_ids.append(k)
+        ctx.tape = tape
+        return out
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        tape = ctx.tape
+        if tape.done:
+            raise RuntimeError('block node: backward ran already (retain_graph is not supported by block nodes)')
+        tape.done = True
+        grads = {}
+
+        def acc(k, g):
+            grads[k] = g if k not in grads else grads[k] + g          # what autograd's accumulation does for a tensor with two consumers
+
+        for k, g in zip(tape.out_ids, gouts):
+            if g is not None:
+                acc(k, g)
+        recs, tape.recs = tape.recs, None
+        while recs:
+            fn, octx, keys, oids, meta = recs.pop()
+            gs = [grads.pop(k, None) if k is not None else None for k in oids]
+            if all(g is None for g in gs):
+                continue
+            if octx.materialize:
+                gs = [g if (g is not None or m is None) else torch.zeros(m[0], dtype=torch.float32, device=m[1]) for g, m in zip(gs, meta)]
+            res = fn.backward(octx, *gs)
+            if not isinstance(res, tuple):
+                res = (res,)
+            for (k, shp), g in zip(keys, res):
+                if k is not None and g is not None and tape.req[k]:
+                    acc(k, g if shp is None else g.reshape(shp))
+        out = []
+        for i, k in enumerate(tape.in_ids):
+            g = grads.get(k) if k is not None else None
+            if g is None and k is not None and tape.req[k] and i > 0:
+                raise RuntimeError('block node: tensor input #%d requires a gradient and received none -- was it used outside the ops of functional.py?' % i)
+            out.append(g)
+        return (None, None) + tuple(out)
+
+
+def _live(t):
+    """does a gradient flow back through t?  (under a tape the tensors carry no requires_grad flag of their own: the tape knows)"""
+    if _tape is not None:
+        k = _tape.find(t)[0]
+        return k is not None and _tape.req[k]
+    return t.requires_grad and torch.is_grad_enabled()
+
+
+def block_node(fn, x, static, params):
+    """fn(x, *static) -- a block's forward written with the ops of this file -- as ONE autograd node.  params: every tensor the block reads that may
+    require a gradient (its module parameters).  Falls back to plain per-op nodes when gradients are off, a tape is active already, or block_nodes is False."""
+    if not block_nodes or _tape is not None or not torch.is_grad_enabled():
+        return fn(x, *static)
+    return _Block.apply(fn, static, x, *params)
+
+
+# -------------------------------------------------------------------------------------------------
 # Dropout RNG: one Philox stream per process; ops reserve disjoint counter ranges (multiples of 4).
 # -------------------------------------------------------------------------------------------------
 class _Rng:
@@ -145,7 +312,7 @@ def _grad_operand(L, dC, other, s, which, like, resid=None):
     return tgt
 
 
-class _BGemm(torch.autograd.Function):
+class _BGemm(_Fn):
     """pass_b: also return the B operand as a second output (an alias).  A caller that needs B twice -- the input of an MBConv block feeds the
     expansion convolution AND the skip connection -- uses the alias for the second consumer: autograd then hands BOTH gradients to this node,
     and the second one is added inside the dB GEMM (segx_gemm_desc.resid) instead of by a separate accumulation kernel."""
@@ -276,7 +443,7 @@ def linear(x, W, b=None, gelu=False, drop_p=0.0):
 # -------------------------------------------------------------------------------------------------
 # Row kernels
 # -------------------------------------------------------------------------------------------------
-class _Softmax(torch.autograd.Function):
+class _Softmax(_Fn):
     """softmax over the last axis, conditional clip (N5) and attention dropout."""
 
     @staticmethod
@@ -307,7 +474,7 @@ def softmax(S, clip=500.0, gmax=None, drop_p=0.0):
     return _Softmax.apply(S, float(clip), gmax, float(drop_p))
 
 
-class _PosBias(torch.autograd.Function):
+class _PosBias(_Fn):
     """scores [.., N, N] -> clamp_if(global max > clip)(scores) + weight * sliding positional bias (never materialised)."""
 
     @staticmethod
@@ -342,7 +509,7 @@ def pos_bias_add(S, table, grid_shape, weight=1.0, clip=500.0, gmax=None):
     return _PosBias.apply(S, table, tuple(grid_shape), float(weight), float(clip), gmax)
 
 
-class _LayerNorm(torch.autograd.Function):
+class _LayerNorm(_Fn):
     @staticmethod
     def forward(ctx, X, w, b, eps):
         L = segx.lib()
@@ -375,7 +542,7 @@ def layer_norm(X, w=None, b=None, eps=LN_EPS):
     return _LayerNorm.apply(X, w, b, eps)
 
 
-class _PreNorm(torch.autograd.Function):
+class _PreNorm(_Fn):
     """mask * dropout(LN_noaffine(LN_affine(x) + pos_weight * pos[:, :C]))  (segtran_shared.py:916-946)."""
     one_pass = True           # backward: segx_prenorm_bwd_all (False: prenorm_bwd + ln_param_grad + colsum over dU, rounds 1-5; tools/ab_switch.py)
 
@@ -429,7 +596,7 @@ def prenorm(X, w1, b1, pos, mask, pos_weight=1.0, drop_p=0.0):
     return _PreNorm.apply(X, w1, b1, pos, mask, float(pos_weight), float(drop_p))
 
 
-class _PosEmbed(torch.autograd.Function):
+class _PosEmbed(_Fn):
     """LearnedSinuPosEmbedder on batch-invariant normalised coordinates [N, pd] -> [N, C]."""
 
     @staticmethod
@@ -464,7 +631,7 @@ def pos_embed(posn, Wp, bp):
     return _PosEmbed.apply(posn, Wp, bp)
 
 
-class _ModesAggr(torch.autograd.Function):
+class _ModesAggr(_Fn):
     """Z [Mo, R, F] -> LN(dropout(Z)) -> learned soft aggregation over modes -> [R, F]."""
     one_pass = True           # backward: segx_modes_aggr_bwd_all (False: the two passes of rounds 1-5; tools/ab_switch.py compares them on one box)
 
@@ -510,7 +677,7 @@ def modes_aggr(Z, lnw, lnb, wa, ba, drop_p=0.0):
     return _ModesAggr.apply(Z, lnw, lnb, wa, ba, float(drop_p))
 
 
-class _Dropout(torch.autograd.Function):
+class _Dropout(_Fn):
     @staticmethod
     def forward(ctx, x, p):
         L = segx.lib()
@@ -538,7 +705,7 @@ def dropout(x, p, training=True):
     return _Dropout.apply(x, float(p))
 
 
-class _AvgPool2(torch.autograd.Function):
+class _AvgPool2(_Fn):
     @staticmethod
     def forward(ctx, x):
         L = segx.lib()
@@ -563,7 +730,7 @@ def avg_pool2(x):
     return _AvgPool2.apply(x)
 
 
-class _Transpose(torch.autograd.Function):
+class _Transpose(_Fn):
     @staticmethod
     def forward(ctx, x):
         L = segx.lib()
@@ -600,7 +767,7 @@ def conv1x1(x, weight, bias=None, pass_input=False):
     Cout = weight.shape[0]
     spec = GemmSpec(Cout, S, Cin, (0, 0, Cin, 1), (Cin * S, 0, 1, S), (Cout * S, 0, S),
                     (B, Cout) + tuple(x.shape[2:]), nb=(B, 1), bias_mode=BIAS_M)
-    if pass_input and x.is_contiguous() and x.requires_grad and torch.is_grad_enabled():
+    if pass_input and x.is_contiguous() and _live(x):
         return _BGemm.apply(weight.reshape(Cout, Cin), x, bias, spec, None, False, 0.0, True)
     y = bgemm(weight.reshape(Cout, Cin), x, spec, bias=bias)
     return (y, x) if pass_input else y
@@ -631,7 +798,7 @@ def compose_conv1x1(w_out, b_out, w_in, b_in):
 # -------------------------------------------------------------------------------------------------
 # Segmentation loss (train2d.py:1233-1242,1314-1318 / train3d.py:738-756), fused fwd + bwd
 # -------------------------------------------------------------------------------------------------
-class _SegLoss(torch.autograd.Function):
+class _SegLoss(_Fn):
     @staticmethod
     def forward(ctx, logits, mask, pos_weight, class_w, dice_w):
         L = segx.lib()
@@ -731,7 +898,7 @@ def _bn_act_backward(L, dy, x, mean, var, w, b, cfg, gate=None, dpool=None, inv_
     return dx, dw, db
 
 
-class _BNAct(torch.autograd.Function):
+class _BNAct(_Fn):
     """y = act(batch_norm(x)) [* drop_connect scale of the sample + resid]: the BatchNorm of every backbone layer; with `resid` also the tail of an
     MBConv block (efficientnet/model.py:116-122) -- the per-sample scale is drawn inside the kernels from the Philox stream, nothing is stored."""
 
@@ -763,7 +930,7 @@ def _slice_writable(view, S):
             and view.data_ptr() % 16 == 0)
 
 
-class _BNActCat(torch.autograd.Function):
+class _BNActCat(_Fn):
     """torch.cat([head, act(bn_1(x_1)), ..., act(bn_n(x_n))], dim=1) -- the tail of an Inception module (aj_i3d.py:101-118) -- with every BatchNorm writing its
     channels where they belong in the concatenation (segx_bn_act_fwd2 y_bs) instead of into a tensor of its own that a copy kernel then moves: one pass over each
     branch less, forward.  Backward is what autograd did with the separate nodes: each BatchNorm reads its channel slice of the concatenation's gradient in place
@@ -900,13 +1067,14 @@ def bn_act(x, bn, act=ACT_NONE, resid=None, drop_connect=0.0):
                         float(drop_connect or 0.0))
 
 
-def bn_act_multi(x, bns, act=ACT_NONE):
+def bn_act_multi(x, bns, act=ACT_NONE, wb=None):
     """BatchNorm (+ activation) of SEVERAL BatchNorm modules in one pass: x's channels are the concatenation of the modules' channels (the outputs
     of convolutions that were run as one convolution with concatenated filters).  BatchNorm is per channel, so this is exactly the separate
     layers -- with one statistics pass, one apply pass and, when synchronised, ONE exchange for all of them.  Same momentum / eps required."""
     mom, eps, training = float(bns[0].momentum), float(bns[0].eps), bns[0].training
     assert all(float(b.momentum) == mom and float(b.eps) == eps and b.training == training for b in bns)
-    w, b = torch.cat([m.weight for m in bns]), torch.cat([m.bias for m in bns])
+    # wb: (weights, biases) concatenated by the caller -- a block node (block_node) does its differentiable ATen work outside the tape
+    w, b = wb if wb is not None else (torch.cat([m.weight for m in bns]), torch.cat([m.bias for m in bns]))
     rm, rv = torch.cat([m.running_mean for m in bns]), torch.cat([m.running_var for m in bns])
     y = _BNAct.apply(x, w, b, rm, rv, training, mom, eps, act, None, 0.0)
     if training:
@@ -922,7 +1090,7 @@ def bn_act_multi(x, bns, act=ACT_NONE):
     return y
 
 
-class _DWConv(torch.autograd.Function):
+class _DWConv(_Fn):
     fused_backward = True     # stride-1 'same' layers: segx_dwconv2d_bwd_fused (False: data and weight gradient as two kernels, rounds 1-5; tools/ab_switch.py)
 
     @staticmethod
@@ -1000,7 +1168,7 @@ def _se_excite_backward(L, x, dWb, Wproj, dgate, gate, hpre, p, W1, W2, S):
     return dpool, dW1, db1, dW2, db2, dWproj
 
 
-class _BNActSE(torch.autograd.Function):
+class _BNActSE(_Fn):
     """squeeze_excite(bn_act(x)) as ONE op (MBConvBlock.forward, efficientnet/model.py:101-110): the squeeze-excite pooling comes out of the
     BatchNorm + swish pass (no separate plane-sum pass over y), and in backward the gate's product rule -- dy = dz * gate + dpool / S -- is
     applied on the fly by the BatchNorm backward kernels instead of being written out by a pass of its own."""
@@ -1034,7 +1202,7 @@ class _BNActSE(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None, None, dW1.view(w1s), db1, dW2.view(w2s), db2
 
 
-class _BNActGateW(torch.autograd.Function):
+class _BNActGateW(_Fn):
     """The middle of an MBConv block (efficientnet/model.py:100-113) up to the operands of its projection GEMM: BatchNorm + swish of the depthwise
     output, the squeeze-excite gate from the same pass, and the gate folded straight into per-sample projection weights
     Wb[b] = W_project * gate[b] (exact re-association).  Returns (y, Wb): project_conv(y * gate) == conv1x1_per_sample(y, Wb).
@@ -1095,7 +1263,7 @@ def bn_act_se(x, bn, act, w1, b1, w2, b2):
 # -------------------------------------------------------------------------------------------------
 # Feature-pyramid ops (fpn.hip): GroupNorm, linear resampling (+ fused lateral add)
 # -------------------------------------------------------------------------------------------------
-class _GroupNorm(torch.autograd.Function):
+class _GroupNorm(_Fn):
     @staticmethod
     def forward(ctx, x, w, b, G, eps):
         L = segx.lib()
@@ -1135,7 +1303,7 @@ def _corner_scale(n_in, n_out):
     return -((n_in - 1) / (n_out - 1)) if n_out > 1 and n_in > 1 else -1e-6
 
 
-class _InterpAdd(torch.autograd.Function):
+class _InterpAdd(_Fn):
     @staticmethod
     def forward(ctx, x, base, size, align_corners=False):
         L = segx.lib()
@@ -1207,7 +1375,7 @@ class _InterpAdd(torch.autograd.Function):
         return dx, (dy if ctx.needs_input_grad[1] else None), None, None
 
 
-class _UpGN(torch.autograd.Function):
+class _UpGN(_Fn):
     """group_norm(interp_linear(x, size, base)) of a pyramid level (segtran3d.py:336-360: `out_gnNb(out_fpnMN_conv3d(cur) + up(feat))`) as ONE node:
     the y/z resampling pass that writes the level also leaves GroupNorm partials of it (segx_interp_linear_fwd_axis2_gn), so the statistics pass
     over the 2 - 3.5 GB tensor is gone; the backward's plane sums give the per-plane sums of the gradient it returns for `base` in closed form
@@ -1272,7 +1440,7 @@ def _gn_fold_stat_grads(dsc, dsh, w, mean, rstd, B, C, G, S):
     return dw, db, A, Bc
 
 
-class _UpGNFold(torch.autograd.Function):
+class _UpGNFold(_Fn):
     """The pyramid level `up(x) + base` with its GroupNorm statistics, for a GroupNorm that is FOLDED into its pointwise-convolution consumer (fpn.hip: r05
     "GroupNorm folded into its consumer"): returns (pre, sc, sh) with gn(pre) == pre * sc[b, c] + sh[b, c]; the normalised tensor is never written.  Backward
     takes the consumer's data gradient (which already carries sc) plus the gradients of sc and sh -- they come out of the consumer's per-sample weight / bias
@@ -1320,7 +1488,7 @@ class _UpGNFold(torch.autograd.Function):
         return dx, dbase, dw, db, None, None, None, None
 
 
-class _UpGNFoldProj(torch.autograd.Function):
+class _UpGNFoldProj(_Fn):
     """_UpGNFold + its consumer in ONE node, for a consumer that projects onto NC <= 8 channels (the class projection): out = (W * sc_b) pre + (W sh_b + bias).
     Backward never writes the consumer's full-size data gradient: segx_gn_fold_bwd_proj forms sum_o Wb[b, o, c] dOut[b, o, s] while it makes its one pass
     over the level (at cfg5 a 3.5-GB tensor the K = 4 GEMM took 0.86 ms to write and the pass 0.6 ms to read back)."""
@@ -1447,7 +1615,7 @@ def interp_linear(x, size, base=None, align_corners=False):
     return _InterpAdd.apply(x, base, tuple(int(s) for s in size), align_corners)
 
 
-class _InterpTokens(torch.autograd.Function):
+class _InterpTokens(_Fn):
     """Linear resampling of a token grid kept channels-last, [B, prod(in_shape), C] -> [B, prod(out_shape), C]: one streaming pass
     per resized axis (innermost first = ATen's blend order), the channels riding along as the contiguous inner extent."""
 
@@ -1512,7 +1680,7 @@ def _same_pads(size, k, s):
     return out
 
 
-class _Conv3d(torch.autograd.Function):
+class _Conv3d(_Fn):
     @staticmethod
     def forward(ctx, x, w, stride, pads):
         L = segx.lib()
@@ -1615,7 +1783,7 @@ class _Conv3d(torch.autograd.Function):
         return dx, dw, None, None
 
 
-class _Conv3dSlices(torch.autograd.Function):
+class _Conv3dSlices(_Fn):
     """Stride-1 'same' convolutions over DISJOINT channel slices of one NCDHW tensor t (slice i = the next w_i.shape[1] channels), without copying
     the slices out: the implicit-GEMM kernels take the slice pointer and t's sample stride (segx_conv3d_*_bs), and in backward each transposed
     convolution writes its slice of ONE gradient tensor (every element written exactly once: no zero fill, no gradient adds).  Used by the
@@ -1716,7 +1884,7 @@ def conv3d_same(x, w, stride=(1, 1, 1)):
     return _Conv3d.apply(x, w, stride, _same_pads(x.shape[2:], w.shape[2:], stride))
 
 
-class _StemCompose(torch.autograd.Function):
+class _StemCompose(_Fn):
     """Wc [O, Cc, *k] = stem filters [O, C3, *k] composed with the input bridge (weight [C3, Cb, 1, 1, 1], bias [C3]); see segx_stem_compose_fwd."""
 
     @staticmethod
@@ -1804,7 +1972,7 @@ def bridge_input(x, Cc=8):
     return y
 
 
-class _MaxPool3d(torch.autograd.Function):
+class _MaxPool3d(_Fn):
     """pass_input: also return the input as a second output (an alias).  Where the pooled tensor has other consumers -- the I3D endpoints feats[1..3] feed the next
     backbone stage through a strided pool AND the feature pyramid (segtran3d.py:436-441) -- they read the alias: autograd then hands their summed gradient to THIS
     node, and the pool's backward kernel adds it while it writes dX (segx_maxpool3d_bwd addend) instead of autograd running an accumulation kernel over two
@@ -1851,13 +2019,13 @@ class _MaxPool3d(torch.autograd.Function):
 def maxpool3d_same(x, kernel, stride, pass_input=False):
     """MaxPool3dSamePadding (aj_i3d.py:6-30).  pass_input: -> (y, x_alias), see _MaxPool3d."""
     kernel, stride = tuple(int(k) for k in kernel), tuple(int(s) for s in stride)
-    if pass_input and x.requires_grad and torch.is_grad_enabled():
+    if pass_input and _live(x):
         return _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride), True)
     y = _MaxPool3d.apply(x, kernel, stride, _same_pads(x.shape[2:], kernel, stride))
     return (y, x) if pass_input else y
 
 
-class _ConvStem2d(torch.autograd.Function):
+class _ConvStem2d(_Fn):
     """The 3 -> c0 channel 3 x 3 stem on an input that needs no gradient (stem2d.hip): direct forward; dW = sum_b dY_b Xcol_b^T with the window matrix Xcol written
     once in backward (28 rows: 27 taps + a zero row) and contracted by the streaming skinny weight-gradient kernel."""
     ROWS = 28
@@ -1902,7 +2070,7 @@ def conv2d_dense(x, w, stride, pad):
     return _Conv3d.apply(x.unsqueeze(2), w.unsqueeze(2), (1, s, s), ((0, 0), (int(pad[2]), int(pad[3])), (int(pad[0]), int(pad[1])))).squeeze(2)
 
 
-class _PlaneBias(torch.autograd.Function):
+class _PlaneBias(_Fn):
     """y[b, c] = x[b, c] + bias[c] on NC* maps (the bias of a dense convolution that ran on the implicit-GEMM engine)."""
 
     @staticmethod
@@ -1936,7 +2104,7 @@ def conv2d_bias(x, w, bias, pad=1, stride=1):
     return y if bias is None else _PlaneBias.apply(y, bias)
 
 
-class _PixelShuffle2(torch.autograd.Function):
+class _PixelShuffle2(_Fn):
     """[B, 4 C, h, w] -> [B, C, 2h, 2w] (F.pixel_shuffle, r = 2); backward = the inverse re-arrangement"""
     @staticmethod
     def forward(ctx, x):

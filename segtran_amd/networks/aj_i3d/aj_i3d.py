@@ -80,6 +80,14 @@ class InceptionModule(nn.Module):
             # conv3d_slices (its gradient is written into t's gradient there); (c) the concatenation's gradient is read IN PLACE by the BatchNorm
             # backward kernels of the four branches (channel slices with a batch stride: no contiguous copies).
             w120 = torch.cat([self.b1a.conv3d.weight, self.b2a.conv3d.weight, self.b0.conv3d.weight], dim=0)
+            if InceptionModule.cat_in_place and self.b3b.conv3d.bias is None:
+                # r06: the module as ONE autograd node (SF.block_node: the ops recorded on a tape, backward walks it in reverse; same kernels, same order).  The
+                # concatenations of the fused layers' parameters are ATen work and stay outside the node.
+                bns = (self.b1a.bn, self.b2a.bn, self.b0.bn)
+                bw, bb = torch.cat([m.weight for m in bns]), torch.cat([m.bias for m in bns])
+                ps = [w120, bw, bb, self.b1b.conv3d.weight, self.b2b.conv3d.weight, self.b3b.conv3d.weight, self.b1b.bn.weight, self.b1b.bn.bias,
+                      self.b2b.bn.weight, self.b2b.bn.bias, self.b3b.bn.weight, self.b3b.bn.bias]
+                return SF.block_node(self._fused_ops, x, (w120, bw, bb), ps)
             t, x2 = SF.conv1x1(x, w120, pass_input=True)
             t = SF.bn_act_multi(t, [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU)
             y1, y2, y0 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight, with_tail=True)
@@ -90,6 +98,15 @@ class InceptionModule(nn.Module):
                 return SF.bn_act_cat(y0, [(y1, self.b1b.bn), (y2, self.b2b.bn), (y3, self.b3b.bn)], SF.ACT_RELU)
             return torch.cat([y0, SF.bn_act(y1, self.b1b.bn, SF.ACT_RELU), SF.bn_act(y2, self.b2b.bn, SF.ACT_RELU), self.b3b(self.b3a(x2))], dim=1)
         return torch.cat([self.b0(x), self.b1b(self.b1a(x)), self.b2b(self.b2a(x)), self.b3b(self.b3a(x))], dim=1)
+
+
+    def _fused_ops(self, x, w120, bw, bb):
+        """the fused form of forward() with the parameter concatenations handed in (see there for what each step replaces)"""
+        t, x2 = SF.conv1x1(x, w120, pass_input=True)
+        t = SF.bn_act_multi(t, [self.b1a.bn, self.b2a.bn, self.b0.bn], SF.ACT_RELU, wb=(bw, bb))
+        y1, y2, y0 = SF.conv3d_slices(t, self.b1b.conv3d.weight, self.b2b.conv3d.weight, with_tail=True)
+        y3 = SF.conv1x1(self.b3a(x2), self.b3b.conv3d.weight, None)
+        return SF.bn_act_cat(y0, [(y1, self.b1b.bn), (y2, self.b2b.bn), (y3, self.b3b.bn)], SF.ACT_RELU)
 
 
 class InceptionI3d(nn.Module):

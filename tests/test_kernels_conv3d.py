@@ -522,3 +522,35 @@ def test_inception_module_fused_reductions_equal_the_four_branches(backend, trai
             close(u, v, 1e-5)
         else:
             assert int(u) == int(v), k
+
+
+def test_inception_module_block_node_equals_per_op_nodes(backend, monkeypatch):
+    """SF.block_node over a whole Inception module (aj_i3d.py:121-126 -- the alias outputs of the fused reduction GEMM and of conv3d_slices included) against the per-op
+    autograd nodes: output, input gradient, parameter gradients and buffers bit for bit."""
+    from segtran_amd.networks.aj_i3d.aj_i3d import InceptionModule
+    from segtran_amd import functional as SF
+    import copy
+    a = InceptionModule(24, [16, 16, 24, 8, 16, 8], 'm')
+    with torch.no_grad():
+        for p in a.parameters():
+            p.copy_(rnd(*p.shape, seed=int(p.numel()) % 97) * (0.2 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 else 0.0))
+    b = copy.deepcopy(a)
+    dev = torch.get_default_device()
+    a.to(dev).train(); b.to(dev).train()
+    x = rnd(2, 24, 3, 5, 8, seed=83).requires_grad_(True); xr = x.detach().clone().requires_grad_(True)
+    monkeypatch.setattr(InceptionModule, 'fuse_reductions', True)
+    monkeypatch.setattr(InceptionModule, 'cat_in_place', True)
+    monkeypatch.setattr(SF, 'block_nodes', True)
+    y = a(x * 1.0)
+    assert type(y.grad_fn).__name__ == '_BlockBackward'
+    monkeypatch.setattr(SF, 'block_nodes', False)
+    yr = b(xr * 1.0)
+    assert type(yr.grad_fn).__name__ != '_BlockBackward'
+    assert torch.equal(y, yr)
+    G = rnd(*y.shape, seed=84)
+    y.backward(G); yr.backward(G)
+    assert torch.equal(x.grad, xr.grad)
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    for (k, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(u, v), k

@@ -3,7 +3,7 @@ kernels, checked against the golden fixtures generated from the real reference."
 import pytest
 import torch
 
-from segtran_amd import segx
+from segtran_amd import segx, functional as SF
 from segtran_amd.networks import segtran_shared as ss
 from segtran_amd.synth import synth_state_dict
 from util import golden, assert_close
@@ -358,3 +358,48 @@ def test_avgpool2_and_transpose(backend):
     assert torch.equal(tt.cpu(), t.detach().cpu().transpose(1, 2))
     tt.backward(tt.detach())
     assert torch.equal(t.grad.cpu(), t.detach().cpu())
+
+
+@pytest.mark.parametrize('k,s,e,cin,cout', [(3, 1, 6, 8, 8), (5, 2, 6, 8, 12), (3, 1, 1, 8, 8)])
+def test_mbconv_block_node_equals_per_op_nodes(backend, monkeypatch, k, s, e, cin, cout):
+    """SF.block_node (one autograd node per MBConv block, its ops recorded on a tape: efficientnet/model.py:82-126) runs the same kernels in the same order as the
+    per-op autograd nodes of rounds 1-5: output, input gradient and every parameter gradient bit for bit, drop_connect and the skip connection included."""
+    from segtran_amd.efficientnet.model import MBConvBlock
+    blk = MBConvBlock(k, s, e, cin, cout, 0.25, 16)
+    prefix = 'backbone._blocks.3.'
+    sd = synth_state_dict({prefix + n: tuple(v.shape) for n, v in blk.state_dict().items()})
+    blk.load_state_dict({n[len(prefix):]: v for n, v in sd.items()})
+    blk.to(backend.dev).train()
+    g = torch.Generator(device='cpu').manual_seed(5)
+    x = torch.randn(3, cin, 12, 10, generator=g, device='cpu').to(backend.dev)
+    G = torch.randn(3, cout, 12 // s, 10 // s, generator=g, device='cpu').to(backend.dev)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(SF, 'block_nodes', on)
+        blk.load_state_dict({n[len(prefix):]: v for n, v in sd.items()})              # running statistics back to the start
+        blk.zero_grad(set_to_none=True)
+        SF.manual_seed(21)
+        xp = x.clone().requires_grad_(True)
+        xin = xp * 1.0                                                                  # a non-leaf input, as inside the backbone
+        y = blk(xin, drop_connect_rate=0.3)
+        assert (type(y.grad_fn).__name__ == '_BlockBackward') == on
+        y.backward(G)
+        res.append([y.detach().clone(), xp.grad.clone()] + [p.grad.clone() for p in blk.parameters()] + [b.clone() for b in blk.buffers()])
+    assert len(res[0]) == len(res[1])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def test_block_node_fails_loudly_on_untracked_use(backend):
+    """A block input that requires a gradient and is used OUTSIDE the ops of functional.py inside a block node gets no gradient: that must raise, not train on zeros."""
+    w = torch.randn(4, 4, device=backend.dev, requires_grad=True)
+    x = torch.randn(2, 4, device=backend.dev, requires_grad=True)
+
+    def fn(x_):
+        return SF.linear(x_ + w.sum(), torch.eye(4, device=backend.dev))              # `+` is not a libsegx op: neither x_ nor w is seen by the tape
+
+    y = SF.block_node(fn, x, (), [w])
+    with pytest.raises(RuntimeError, match='received none'):
+        y.sum().backward()
+    with torch.no_grad():
+        assert SF.block_node(fn, x, (), [w]).grad_fn is None                            # gradients off: plain ops, no node
