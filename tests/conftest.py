@@ -8,11 +8,41 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def pytest_configure(config):
+def _register_markers(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
     config.addinivalue_line('markers', 'slow: full-size CPU checks')
     config.addinivalue_line('markers', 'experimental: kernels / code paths that are NOT on the product path (bench-only builds, opt-in schemes); never part '
                                        'of a plain `-m gpu` / `-m "not gpu"` run -- select them with SEGX_EXPERIMENTAL=1 (they then run LAST)')
+
+
+def _cpu_workers(config):
+    """The CPU suite (`-m "not gpu"`: ~770 tests, most of them whole kernels on the fiber emulator) takes ~50 min in one process and ~15 min in four.  A plain
+    `pytest tests -m "not gpu"` on a box WITHOUT a GPU therefore distributes itself over worker processes (pytest-xdist, when installed) -- the same tests, the same
+    assertions.  Never on a GPU box (one device: the -m gpu tests run in one process), never when -n / --dist was given, SEGX_TEST_WORKERS=0 switches it off."""
+    try:
+        if hasattr(config, 'workerinput') or not config.pluginmanager.hasplugin('xdist'):
+            return 0
+        opt = config.option
+        if getattr(opt, 'numprocesses', None) or getattr(opt, 'dist', 'no') != 'no' or getattr(opt, 'tx', None) or getattr(opt, 'collectonly', False) or getattr(opt, 'usepdb', False):
+            return 0
+        if 'not gpu' not in (getattr(opt, 'markexpr', '') or ''):
+            return 0
+        n = int(os.environ.get('SEGX_TEST_WORKERS', min(4, max(1, (os.cpu_count() or 2) // 2))))
+        if n < 2:
+            return 0
+        import torch
+        if torch.cuda.is_available():
+            return 0
+        return n
+    except Exception:
+        return 0
+
+
+def pytest_configure(config):
+    n = _cpu_workers(config)
+    if n:                          # what `-n <n>` sets (xdist's own pytest_configure runs last and starts the distributed session from these options)
+        config.option.numprocesses, config.option.dist, config.option.tx = n, 'load', ['popen'] * n
+    _register_markers(config)
 
 
 def pytest_sessionstart(session):
