@@ -32,7 +32,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROF_EVERY = 5                      # engine launches carry HIP events on every 5th timed step (measure())
+PROF_EVERY = 10                     # engine launches carry HIP events on every 10th timed step (measure()): two event records per launch cost ~1.7 ms of host time on such a step
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_TBS = 8.0                  # same guide: HBM3E ~8 TB/s (TFLOP/s per FLOP/byte)
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # same table: bf16 MFMA dense (32x32x16); the bf16x6 engine issues 6 of them per fp32-equivalent block product
@@ -253,7 +253,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
     torch.cuda.synchronize()
     # HIP events bracket every engine launch of EVERY prof_every-th timed step (two event records per launch cost host time and a queue marker each:
     # r04_w measured the same step at 67.2 ms without them -- H2D copies included -- and 68.9 ms with them on every step); the roofline is computed
-    # over those launches (10 of 50 steps by default; every step when fewer than 10 steps are timed: profiler runs)
+    # over those launches (5 of 50 steps by default; every step when fewer than 10 steps are timed: profiler runs)
     prof_every = 1 if (steps < 10 or graphed) else PROF_EVERY
     prof_list = None if graphed else []
     prof_steps = 0
