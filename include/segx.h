@@ -386,9 +386,12 @@ int segx_rng_advance(uint64_t* base, uint64_t span, void* stream);
  * path: the last `value` workgroups of every team launch are not launched, so their team mates time out (0 = off, the default);
  * knob 14 = slab-in-LDS form of the stride-1 3 x 3 x 3 'same' max-pools: 0 (default) where the four-cells-per-thread form does not apply (row length not a
  * multiple of 4), 1 wherever a slab fits the LDS, 2 never; knob 15 = the same pools with rows of a multiple of 4 floats: 1 (default) a thread keeps its four
- * cells for up to eight slices and slides along the depth (a third of the row loads), 0 = one slice per thread.  Identical results for every setting. */
+ * cells for up to eight slices and slides along the depth (a third of the row loads), 0 = one slice per thread;
+ * knob 19 = order in which the tiles of a GEMM are walked inside an XCD's run: 1 (default) M fastest where the A operand of a member fits the XCD's L2 (<= 2 MiB) and B is
+ * the big operand -- pointwise convolutions over 10^5 positions: B crosses the fabric once instead of once per row of tiles --, 0 = N fastest always (rounds 1-5).
+ * Identical results for every setting. */
 int segx_tune(int knob, int value);
-/* r06: the value a knob holds now (knobs 1-4, 6-9, 12-15; -1 for an unknown knob and for the counter knob 5): a caller that changes a process-wide default for its own
+/* r06: the value a knob holds now (knobs 1-4, 6-9, 12-19; -1 for an unknown knob and for the counter knob 5): a caller that changes a process-wide default for its own
  * lifetime (dist.GradReducer: knob 3) reads it first and puts it back instead of assuming the default */
 int segx_tune_get(int knob);
 /* r04: TWO adjacent outer axes of a linear resampling in one streaming pass over [outer, n1, n2, inner] (inner % 4 == 0: the contiguous extent, read

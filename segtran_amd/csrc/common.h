@@ -289,6 +289,7 @@ struct Knobs {
     std::atomic<int> conv_halo{1};                  // knob 16: 3 x 3 x 3 stride-1 'same' convolutions on the LDS-resident-halo kernels (conv3d_halo.hip) where they apply; 0 = im2col kernels only
     std::atomic<int> conv_halo_min_tiles{256};      // knob 17: fewest 128-output spatial tiles (x batch) for which the halo kernels are used (below: split-K im2col)
     std::atomic<int> skinny_nt{1};                  // knob 18: batch-reduced skinny weight gradients on the streaming kernel (gemm_skinny.hip); 0 = the tile kernels' split-K slabs
+    std::atomic<int> tile_walk{1};                  // knob 19: 1 = the GEMM kernels walk M fastest where the A operand fits an XCD's L2 and B is the big one (gemm_core.h tile_walk), 0 = N fastest always (rounds 1-5)
     std::atomic<int> team_drop{0};                  // knob 13: FAULT INJECTION (tests): the last n workgroups of a team launch are not launched -> their mates time out
 };
 inline Knobs& knobs() { static Knobs k; return k; }

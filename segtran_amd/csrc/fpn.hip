@@ -865,6 +865,7 @@ extern "C" int segx_tune(int knob, int value) {
     if (knob == 16) { if (value != 0 && value != 1) return -1; k.conv_halo = value; return 0; }
     if (knob == 17) { if (value < 1 || value > (1 << 24)) return -1; k.conv_halo_min_tiles = value; return 0; }
     if (knob == 18) { if (value != 0 && value != 1) return -1; k.skinny_nt = value; return 0; }
+    if (knob == 19) { if (value != 0 && value != 1) return -1; k.tile_walk = value; return 0; }
     if (knob == 12) { if (value < 32 || value > (1 << 24)) return -1; k.team_spin = value; return 0; }     // poll bound of a team exchange
     if (knob == 13) { if (value < 0 || value > 4096) return -1; k.team_drop = value; return 0; }          // fault injection (tests): unlaunched tail of a team grid
     return -1;
@@ -887,6 +888,7 @@ extern "C" int segx_tune_get(int knob) {
         case 16: return segx::kget(k.conv_halo);
         case 17: return segx::kget(k.conv_halo_min_tiles);
         case 18: return segx::kget(k.skinny_nt);
+        case 19: return segx::kget(k.tile_walk);
         default: return -1;
     }
 }

@@ -334,7 +334,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
 #endif
 #define SEGX_LAUNCH6(CFG, AK, BK, E, W)                                                                    \
     do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN); g.mfast = kget(knobs().tile_walk) ? tile_walk(d->M, d->N, d->K, g.tiles_m) : 0;                          \
         if (SEGX_LEAN4 && lean_ok) hipLaunchKernelGGL((gemm_x6_lean_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
         else hipLaunchKernelGGL((gemm_x6_kernel<CFG, AK, BK, E, W>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
@@ -364,7 +364,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
 #endif
 #define SEGX_LAUNCHWS(CFG, AK, BK, E)                                                                      \
     do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN); g.mfast = kget(knobs().tile_walk) ? tile_walk(d->M, d->N, d->K, g.tiles_m) : 0;                          \
         const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
         SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
         const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);                                              \
@@ -380,7 +380,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     } while (0)
 #define SEGX_LAUNCH6V(V, W)                                                                                \
     do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN);                    \
+        g.tiles_m = ceil_div(d->M, Cfg128::BM); g.tiles_n = ceil_div(d->N, Cfg128::BN); g.mfast = kget(knobs().tile_walk) ? tile_walk(d->M, d->N, d->K, g.tiles_m) : 0;                    \
         hipLaunchKernelGGL((gemm_x6_kernel<Cfg128, true, true, SEGX_EPI_NONE, W, V>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
         using Cfg128x256 = TileCfg<2, 2, 2, 4>; using Cfg64x256 = TileCfg<2, 2, 1, 4>; using Cfg96x256 = TileCfg<1, 4, 3, 2>; using Cfg256x96 = TileCfg<4, 1, 2, 3>;      // few output channels x many positions (backbone pointwise convolutions)
@@ -390,7 +390,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
             g.Bp = static_cast<const unsigned short*>(d->b_planes); g.bp_plane = (int64_t)d->N * d->K; g.bp_b0 = d->bp_b0; g.bp_b1 = d->bp_b1;
 #define SEGX_LAUNCHWS_PRE(CFG)                                                                             \
     do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN); g.mfast = kget(knobs().tile_walk) ? tile_walk(d->M, d->N, d->K, g.tiles_m) : 0;                          \
         const int64_t items = (int64_t)g.tiles_m * g.tiles_n * nbatch * splitk;                            \
         SEGX_REQUIRE(items < 2147483647LL - 512, "segx_gemm_f32: too many tiles");                         \
         const int G = (int)i64min(kget(knobs().ws_grid), (items + 7) / 8 * 8);                             \
@@ -426,7 +426,7 @@ extern "C" int segx_gemm_f32(const float* A, const float* B, float* C, const seg
     } else
 #define SEGX_LAUNCH(CFG, AK, BK, V, E)                                                                     \
     do {                                                                                                   \
-        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN);                          \
+        g.tiles_m = ceil_div(d->M, CFG::BM); g.tiles_n = ceil_div(d->N, CFG::BN); g.mfast = kget(knobs().tile_walk) ? tile_walk(d->M, d->N, d->K, g.tiles_m) : 0;                          \
         hipLaunchKernelGGL((gemm_f32_kernel<CFG, AK, BK, V, E>), dim3(g.tiles_m * g.tiles_n, nbatch, splitk), block, 0, stream, g); \
     } while (0)
 #define SEGX_LAUNCH_LAYOUT(CFG, V, E)                                   \

@@ -43,7 +43,19 @@ struct GemmArgs {
     const unsigned short* Bp; int64_t bp_plane, bp_b0, bp_b1;   // B operand pre-split into three bf16 planes (segx_x6_presplit), element strides; NULL = none
     int slab;                       // 1: write raw slabs to the workspace even when splitk == 1 (batch_reduce: the batch members are slabs too)
     const float* resid;             // C = alpha * A B^T (+ bias) + resid, resid laid out like C (plain epilogue; split-K adds it in the slab reduction)
+    int mfast = 0;                  // tile walk inside an XCD's run: 0 = N fastest (neighbours share their A row-panel), 1 = M fastest (they share their B column-panel): tile_walk()
 };
+
+// Which way the tiles of one batch member are walked (a speed choice only: every tile is computed the same way whatever its place in the order).
+// N fastest keeps ONE A row-panel in the XCD's L2 and streams the B panels past it -- every B panel is then fetched once per ROW of tiles (tiles_m times over
+// the launch, from the fabric: the other fetches happen on other XCDs or rounds later).  That is right while B is the small operand.  When A is small enough to live
+// in L2 whole (<= 2 MiB of the 4-MiB L2 an XCD owns) and B is the big one -- the pointwise convolutions over 150 528 voxels / 65 536 .. 262 144 pixels, whose
+// 'A' is a few hundred filters -- M fastest lets the tiles_m tiles that need a B panel run next to each other on one XCD: B crosses the fabric once
+// (r06: 832 x 150 528 x 480 fetched 3.5x its operands with N fastest).
+inline int tile_walk(int64_t M, int64_t N, int64_t K, int tiles_m) {
+    const int64_t a_bytes = M * K * 4, b_bytes = N * K * 4;
+    return (tiles_m > 1 && a_bytes <= (2 << 20) && b_bytes > 2 * a_bytes) ? 1 : 0;
+}
 
 // Load this thread's ROWS*BKT/1024 float4 pieces of a ROWS x BKT operand tile into registers.
 //  KC = true : operand is k-contiguous;  piece f -> row f / KCH, k-chunk f % KCH
@@ -156,7 +168,9 @@ template <class Cfg = Cfg128>
 __device__ __forceinline__ TileCoord tile_coord(const GemmArgs& g) {
     TileCoord t;
     const int tile = xcd_tile(blockIdx.x, g.tiles_m * g.tiles_n);
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    int tm, tn;
+    if (g.mfast) { tn = tile / g.tiles_m; tm = tile - tn * g.tiles_m; }
+    else { tm = tile / g.tiles_n; tn = tile - tm * g.tiles_n; }
     t.zb = blockIdx.y; t.zk = blockIdx.z;
     t.z0 = t.zb / g.nb1; t.z1 = t.zb - t.z0 * g.nb1;
     t.m0 = tm * Cfg::BM; t.n0 = tn * Cfg::BN;

@@ -34,7 +34,9 @@ __device__ __forceinline__ TileCoord ws_item_coord(const GemmArgs& g, int item) 
     TileCoord t;
     const int ntile = g.tiles_m * g.tiles_n;
     const int tile = item % ntile, rest = item / ntile;
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int inner = g.mfast ? g.tiles_m : g.tiles_n;                          // tile_walk(): M fastest puts the tiles sharing a B column-panel next to each other
+    const int q = tile / inner, r = tile - q * inner;
+    const int tm = g.mfast ? r : q, tn = g.mfast ? q : r;
     t.zb = rest % g.nbatch; t.zk = rest / g.nbatch;
     t.z0 = t.zb / g.nb1; t.z1 = t.zb - t.z0 * g.nb1;
     t.m0 = tm * Cfg::BM; t.n0 = tn * Cfg::BN;

@@ -390,8 +390,9 @@ def test_mbconv_block_node_equals_per_op_nodes(backend, monkeypatch, k, s, e, ci
         assert torch.equal(a, b)
 
 
-def test_block_node_fails_loudly_on_untracked_use(backend):
+def test_block_node_fails_loudly_on_untracked_use(backend, monkeypatch):
     """A block input that requires a gradient and is used OUTSIDE the ops of functional.py inside a block node gets no gradient: that must raise, not train on zeros."""
+    monkeypatch.setattr(SF, 'block_nodes', True)                                        # opt-in (off by default: measured slower on the host)
     w = torch.randn(4, 4, device=backend.dev, requires_grad=True)
     x = torch.randn(2, 4, device=backend.dev, requires_grad=True)
 
@@ -403,3 +404,8 @@ def test_block_node_fails_loudly_on_untracked_use(backend):
         y.sum().backward()
     with torch.no_grad():
         assert SF.block_node(fn, x, (), [w]).grad_fn is None                            # gradients off: plain ops, no node
+    monkeypatch.setattr(SF, 'block_nodes', False)
+    y = SF.block_node(fn, x, (), [w])                                                   # switched off: per-op autograd nodes, ATen work is differentiated as usual
+    assert type(y.grad_fn).__name__ != '_BlockBackward'
+    y.sum().backward()
+    assert w.grad is not None and x.grad is not None
