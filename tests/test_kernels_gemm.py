@@ -343,6 +343,31 @@ def test_x6_split_early_schedule_gives_the_same_result(backend):
         L.set_engine(prev)
 
 
+@pytest.mark.parametrize('engine,tile', [('x6', segx.TILE_128x128), ('x6', segx.TILE_64x64), ('x6', segx.TILE_256x128), ('x6', segx.TILE_WS128x256), ('f32', segx.TILE_128x128)])
+def test_tile_walk_order_gives_the_same_result(backend, engine, tile):
+    """segx_tune knob 19 (gemm_core.h tile_walk): a small A operand with several row-tiles against a B operand more than twice its size is walked M fastest inside
+    an XCD's run (the tiles sharing a B column-panel next to each other) instead of N fastest -- a different ORDER of the same tiles: bit-identical results, on the
+    4-wave kernels (tile_coord) and on the persistent wave-specialised ones (ws_item_coord), with ragged edges, a batch and split-K slabs."""
+    L = backend.L
+    prev = L.set_engine(engine)
+    try:
+        assert L.c.segx_tune_get(19) == 1                                   # the default
+        if tile in (segx.TILE_256x128, segx.TILE_WS128x256):
+            assert L.c.segx_tune(9, 8) == 0                                 # 8 persistent workgroups: several rounds of items
+        out = []
+        for v in (1, 0):
+            assert L.c.segx_tune(19, v) == 0
+            A, B, C = _x6_case(L, backend.dev, 300, 1100, 64, True, False, nb=2, sk=2, tile=tile, seed=19)
+            out.append(C.clone())
+        assert L.c.segx_tune(19, 2) == -1                                   # an unknown setting is an error
+    finally:
+        L.c.segx_tune(19, 1); L.c.segx_tune(9, 256)
+        L.set_engine(prev)
+    assert torch.equal(out[0], out[1])
+    ref = _ref(A, B)
+    assert (out[0].double() - ref).abs().max().item() < 3e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize('tile', [segx.TILE_256x128, segx.TILE_WS128x128, segx.TILE_WS128x256, segx.TILE_WS64x256, segx.TILE_WS96x256, segx.TILE_WS256x96])
 @pytest.mark.parametrize('M,N,K,akc,bkc,sk,nb', [(520, 264, 96, True, True, 1, 3), (300, 392, 128, True, False, 2, 2), (260, 136, 192, False, False, 3, 2),
                                                  (264, 260, 96, False, True, 1, 2), (264, 136, 104, True, True, 1, 2)])
