@@ -349,7 +349,7 @@ def measure(cfg_name, args, steps, warmup, rank, world, dev, other_order=True, b
                       ('reassociated_op_order' if args.reference_op_order else 'reference_op_order'):
                           None if other is None else {'value': round(B / other, 3), 'ms_per_step': round(other * 1e3, 2)},
                       'with_h2d_copy': with_h2d, 'overlap': overlap,
-                      'ranks': world, 'collective_backend': (torch.distributed.get_backend() + ' (RCCL)' if world > 1 else None)},
+                      'ranks': world, 'collective_backend': ((torch.distributed.get_backend() + (' (RCCL)' if torch.distributed.get_backend() == 'nccl' else '')) if world > 1 else None)},
            'roofline': roof}
     if rank == 0:
         print('[bench] %s: %.1f ms/step (median %.1f), %.2f %s, engine %.1f TFLOP/s' % (cfg_name, res['ms_per_step'], med, res['value'], unit, achieved),
